@@ -1,0 +1,158 @@
+"""Seeded synthetic inputs for the tracking / local-BA hot path.
+
+No dataset is available (EuRoC / KITTI are not in the container and there is no
+network), so every test and the benchmark run on procedural scenes rendered to
+the rectified stereo rig of the config being measured.
+"""
+import numpy as np
+
+# rigs from the reference configs (config/config_MH_01.yaml:33-36,95-98,
+# config/config_kitti_00.yaml:20-23,42-45); C5 from SURVEY.md §8d
+RIGS = {
+    "euroc": dict(w=752, h=480, fx=435.2046959714599, fy=435.2046959714599, cx=367.4517211914062,
+                  cy=252.2008514404297, bl=0.110074137800478, fps=20.0),
+    "kitti": dict(w=1241, h=376, fx=718.856, fy=718.856, cx=607.1928, cy=185.2157, bl=0.53716, fps=10.0),
+    "synthetic": dict(w=1920, h=1200, fx=1100.0, fy=1100.0, cx=960.0, cy=600.0, bl=0.12, fps=20.0),
+}
+
+
+def make_texture(seed=0xC0FFEE, size=2048, nrect=4000):
+    """Multi-octave value noise plus random high-contrast rectangles, u8 [size,size]."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    tex = np.zeros((size, size), np.float32)
+    amp, tot = 1.0, 0.0
+    for octave in range(3, 10):
+        n = 2 ** octave
+        g = rng.random((n + 1, n + 1), dtype=np.float32)
+        # bilinear upsample of the coarse grid
+        xs = np.linspace(0, n, size, endpoint=False, dtype=np.float32)
+        i0 = np.floor(xs).astype(np.int32)
+        f = xs - i0
+        rows = g[i0, :] * (1 - f)[:, None] + g[i0 + 1, :] * f[:, None]
+        up = rows[:, i0] * (1 - f)[None, :] + rows[:, i0 + 1] * f[None, :]
+        tex += amp * up
+        tot += amp
+        amp *= 0.6
+    tex = tex / tot
+    tex = (tex - tex.min()) / (tex.max() - tex.min())
+    img = (40 + 140 * tex).astype(np.float32)
+    for _ in range(nrect):
+        w, h = rng.integers(6, 60, 2)
+        x, y = rng.integers(0, size - 60, 2)
+        v = float(rng.integers(0, 256))
+        img[y:y + h, x:x + w] = 0.35 * img[y:y + h, x:x + w] + 0.65 * v
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+_TEX_CACHE = {}
+
+
+def texture(seed=0xC0FFEE, size=2048):
+    key = (seed, size)
+    if key not in _TEX_CACHE:
+        _TEX_CACHE[key] = make_texture(seed, size)
+    return _TEX_CACHE[key]
+
+
+def make_scene(seed=7, nboxes=14):
+    """Planes: list of (origin[3], ex[3], ey[3], half_w, half_h, tex_off[2], tex_scale px/m)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    planes = []
+    # back wall, floor-ish and two side walls so every ray hits something
+    planes.append((np.array([0, 0, 9.0]), np.array([1.0, 0, 0]), np.array([0, 1.0, 0]), 30, 30, (100, 100), 120.0))
+    planes.append((np.array([0, 1.6, 5.0]), np.array([1.0, 0, 0]), np.array([0, 0.0, 1.0]), 30, 30, (900, 300), 150.0))
+    planes.append((np.array([-6.0, 0, 5.0]), np.array([0, 0, 1.0]), np.array([0, 1.0, 0]), 30, 30, (300, 1200), 140.0))
+    planes.append((np.array([6.0, 0, 5.0]), np.array([0, 0, 1.0]), np.array([0, 1.0, 0]), 30, 30, (1300, 800), 140.0))
+    for _ in range(nboxes):
+        z = rng.uniform(1.8, 7.0)
+        c = np.array([rng.uniform(-0.7, 0.7) * z, rng.uniform(-0.45, 0.35) * z, z])
+        yaw = rng.uniform(-0.5, 0.5)
+        ex = np.array([np.cos(yaw), 0, np.sin(yaw)])
+        ey = np.array([0, 1.0, 0])
+        planes.append((c, ex, ey, rng.uniform(0.25, 0.8), rng.uniform(0.25, 0.8),
+                       (int(rng.integers(0, 1500)), int(rng.integers(0, 1500))), rng.uniform(250, 450)))
+    return planes
+
+
+def render(planes, tex, rig, T_wc, noise_seed=None, noise_sigma=2.0):
+    """Render one u8 view.  T_wc: 4x4 world<-camera.  Returns (image, depth)."""
+    w, h = rig["w"], rig["h"]
+    fx, fy, cx, cy = rig["fx"], rig["fy"], rig["cx"], rig["cy"]
+    u, v = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    d_c = np.stack([(u - cx) / fx, (v - cy) / fy, np.ones_like(u)], -1)  # camera rays, z=1
+    R, t = T_wc[:3, :3], T_wc[:3, 3]
+    d_w = d_c @ R.T
+    best = np.full((h, w), np.inf)
+    out = np.zeros((h, w), np.float32)
+    ts = tex.shape[0]
+    for (o, ex, ey, hw, hh, toff, tsc) in planes:
+        n = np.cross(ex, ey)
+        denom = d_w @ n
+        with np.errstate(divide="ignore", invalid="ignore"):
+            lam = ((o - t) @ n) / denom  # depth along camera z (since ray has z_c = 1)
+        p = t[None, None, :] + lam[..., None] * d_w
+        a = (p - o) @ ex
+        b = (p - o) @ ey
+        hit = (lam > 0.05) & (np.abs(a) <= hw) & (np.abs(b) <= hh) & (lam < best) & np.isfinite(lam)
+        if not hit.any():
+            continue
+        tu = (toff[0] + (a[hit] + hw) * tsc) % (ts - 1)
+        tv = (toff[1] + (b[hit] + hh) * tsc) % (ts - 1)
+        x0 = np.floor(tu).astype(np.int64)
+        y0 = np.floor(tv).astype(np.int64)
+        fxr, fyr = (tu - x0).astype(np.float32), (tv - y0).astype(np.float32)
+        x1, y1 = np.minimum(x0 + 1, ts - 1), np.minimum(y0 + 1, ts - 1)
+        val = (tex[y0, x0] * (1 - fxr) * (1 - fyr) + tex[y0, x1] * fxr * (1 - fyr)
+               + tex[y1, x0] * (1 - fxr) * fyr + tex[y1, x1] * fxr * fyr)
+        out[hit] = val
+        best[hit] = lam[hit]
+    if noise_seed is not None and noise_sigma > 0:
+        rng = np.random.Generator(np.random.PCG64(noise_seed))
+        out = out + rng.normal(0, noise_sigma, out.shape).astype(np.float32)
+    return np.clip(np.rint(out), 0, 255).astype(np.uint8), best
+
+
+def pose_at(i, fps=20.0):
+    """Smooth 6-DoF trajectory sample (world<-left camera), ~0.5 m/s, small rotations."""
+    s = i / fps
+    yaw = 0.08 * np.sin(0.7 * s)
+    pitch = 0.04 * np.sin(0.45 * s + 0.3)
+    roll = 0.03 * np.sin(0.6 * s + 1.0)
+    cy_, sy_ = np.cos(yaw), np.sin(yaw)
+    cp, sp = np.cos(pitch), np.sin(pitch)
+    cr, sr = np.cos(roll), np.sin(roll)
+    Ry = np.array([[cy_, 0, sy_], [0, 1, 0], [-sy_, 0, cy_]])
+    Rx = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
+    Rz = np.array([[cr, -sr, 0], [sr, cr, 0], [0, 0, 1]])
+    T = np.eye(4)
+    T[:3, :3] = Ry @ Rx @ Rz
+    T[:3, 3] = [0.35 * np.sin(0.5 * s), 0.05 * np.sin(0.9 * s), 0.25 * s * 0.5 + 0.15 * np.sin(0.4 * s)]
+    return T
+
+
+def stereo_frame(i, rig_name="euroc", scene_seed=7, tex_seed=0xC0FFEE, noise=True):
+    """Left/right u8 images of frame i plus the ground-truth pose."""
+    rig = RIGS[rig_name]
+    planes = make_scene(scene_seed)
+    tex = texture(tex_seed)
+    T = pose_at(i, rig["fps"])
+    ext = np.eye(4)
+    ext[0, 3] = rig["bl"]  # right camera = pose * extrinsics (reference src/Camera.cpp:57)
+    left, _ = render(planes, tex, rig, T, noise_seed=(1000 + 2 * i) if noise else None)
+    right, _ = render(planes, tex, rig, T @ ext, noise_seed=(1001 + 2 * i) if noise else None)
+    return left, right, T
+
+
+def random_image(w, h, seed):
+    """Cheap textured test image (crop of the noise texture + gaussian noise)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    tex = texture()
+    x, y = int(rng.integers(0, tex.shape[1] - w)) if w < tex.shape[1] else 0, \
+        int(rng.integers(0, tex.shape[0] - h)) if h < tex.shape[0] else 0
+    if w <= tex.shape[1] and h <= tex.shape[0]:
+        img = tex[y:y + h, x:x + w].astype(np.float32)
+    else:
+        reps = (h // tex.shape[0] + 1, w // tex.shape[1] + 1)
+        img = np.tile(tex, reps)[:h, :w].astype(np.float32)
+    img = img + rng.normal(0, 2.0, img.shape).astype(np.float32)
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)

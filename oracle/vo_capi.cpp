@@ -1,0 +1,108 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see vo_common.hpp).  PARITY UNPINNED.
+// Flat C entry points so tests/ and bench.py's cpu_baseline leg can drive the
+// CPU restatement through ctypes.
+#include "vo_extract.hpp"
+
+using namespace vo;
+
+extern "C" {
+
+void* vo_extractor_create(int nfeatures, int nlevels, float scale, int edge, int patch, int maxFast,
+                          int minFast) {
+    return new Extractor(nfeatures, nlevels, scale, edge, patch, maxFast, minFast);
+}
+void vo_extractor_destroy(void* h) { delete (Extractor*)h; }
+
+// tables: out arrays must hold nLevels entries (umax: 16)
+void vo_extractor_tables(void* h, float* scalePyr, float* scaleInv, float* sigma, float* invSigma,
+                         int* scaledPatch, int* featPerLevel, int* umax) {
+    Extractor* e = (Extractor*)h;
+    for (int i = 0; i < e->nLevels; i++) {
+        scalePyr[i] = e->scalePyramid[i];
+        scaleInv[i] = e->scaleInvPyramid[i];
+        sigma[i] = e->sigmaFactor[i];
+        invSigma[i] = e->InvSigmaFactor[i];
+        scaledPatch[i] = e->scaledPatchSize[i];
+        featPerLevel[i] = e->featurePerLevel[i];
+    }
+    for (int i = 0; i < 16; i++) umax[i] = e->umax[i];
+}
+
+// returns number of keypoints (or -1 if cap is too small); kps: cap x 28 B, desc: cap x 32 B
+int vo_extract(void* h, const uint8_t* gray, int w, int hgt, int stride, KeyPoint* kps,
+               uint8_t* desc, int cap) {
+    Extractor* e = (Extractor*)h;
+    Image im(w, hgt);
+    for (int y = 0; y < hgt; y++) memcpy(&im.d[(size_t)y * w], gray + (size_t)y * stride, w);
+    std::vector<KeyPoint> k;
+    std::vector<uint8_t> d;
+    e->extractKeysNew(im, k, d);
+    if ((int)k.size() > cap) return -1;
+    if (!k.empty()) {
+        memcpy(kps, k.data(), k.size() * sizeof(KeyPoint));
+        memcpy(desc, d.data(), d.size());
+    }
+    return (int)k.size();
+}
+
+void vo_level_size(void* h, int level, int* w, int* hgt) {
+    Extractor* e = (Extractor*)h;
+    *w = e->imagePyramid[level].w;
+    *hgt = e->imagePyramid[level].h;
+}
+void vo_level_copy(void* h, int level, int blurred, uint8_t* out) {
+    Extractor* e = (Extractor*)h;
+    const Image& im = blurred ? e->blurPyramid[level] : e->imagePyramid[level];
+    if (!im.d.empty()) memcpy(out, im.d.data(), im.d.size());
+}
+int vo_fast_candidates(void* h, int level, KeyPoint* out, int cap) {
+    Extractor* e = (Extractor*)h;
+    const auto& v = e->fastCandidates[level];
+    if ((int)v.size() > cap) return -(int)v.size();
+    if (!v.empty()) memcpy(out, v.data(), v.size() * sizeof(KeyPoint));
+    return (int)v.size();
+}
+
+// stand-alone pieces for known-answer tests
+void vo_resize(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh) {
+    Image s(sw, sh), d(dw, dh);
+    memcpy(s.d.data(), src, (size_t)sw * sh);
+    resizeLinear8u(s, d);
+    memcpy(dst, d.d.data(), (size_t)dw * dh);
+}
+int vo_fast(const uint8_t* img, int stride, int cols, int rows, int threshold, KeyPoint* out, int cap) {
+    std::vector<KeyPoint> v;
+    fast9_16(img, stride, cols, rows, threshold, v);
+    if ((int)v.size() > cap) return -(int)v.size();
+    if (!v.empty()) memcpy(out, v.data(), v.size() * sizeof(KeyPoint));
+    return (int)v.size();
+}
+void vo_blur(const uint8_t* src, int w, int h, uint8_t* dst) {
+    Image s(w, h), d;
+    memcpy(s.d.data(), src, (size_t)w * h);
+    gaussianBlur7(s, d);
+    memcpy(dst, d.d.data(), (size_t)w * h);
+}
+void vo_gauss_kernel(int* k7) { gaussianKernel7Sigma2(k7); }
+float vo_fast_atan2(float y, float x) { return fastAtan2(y, x); }
+float vo_orientation(void* h, const uint8_t* img, int w, int hgt, float px, float py) {
+    Extractor* e = (Extractor*)h;
+    Image s(w, hgt);
+    memcpy(s.d.data(), img, (size_t)w * hgt);
+    return e->computeOrientation(s, px, py);
+}
+void vo_orb_descriptor(const KeyPoint* kp, const uint8_t* img, int w, int hgt, uint8_t* desc32) {
+    Image s(w, hgt);
+    memcpy(s.d.data(), img, (size_t)w * hgt);
+    orbDescriptor(*kp, s, desc32);
+}
+int vo_ssc(void* h, const KeyPoint* in, int n, int numRet, float tol, int cols, int rows,
+           KeyPoint* out) {
+    Extractor* e = (Extractor*)h;
+    std::vector<KeyPoint> v(in, in + n);
+    std::vector<KeyPoint> r = e->ssc(v, numRet, tol, cols, rows);
+    if (!r.empty()) memcpy(out, r.data(), r.size() * sizeof(KeyPoint));
+    return (int)r.size();
+}
+
+}  // extern "C"
