@@ -1,0 +1,461 @@
+// HIP kernels of the ORB-style extractor for gfx950 (wave64).
+//   K1 k_resize       cv::resize INTER_LINEAR fixed point, level l from level l-1
+//   K2 k_fast         one workgroup per 35-px FAST cell: FAST-9/16 score, 3x3 NMS,
+//                     per-cell threshold fallback, order-preserving compaction (wave ballot)
+//   K2b k_gather      cell lists -> level-major candidate list (prefix over cells)
+//   K5 k_blur         7x7 sigma-2 fixed-point Gaussian, REFLECT_101, LDS-tiled
+//   K4+K6 k_orient_desc  intensity-centroid angle + 256-bit rotated BRIEF, one wave per keypoint
+// Reference behaviour restated from src/FeatureExtractor.cpp (lines cited per kernel).
+// Compiled with -ffp-contract=off: float expressions round exactly as written.
+#include "extract_kernels.hpp"
+#include "../../include/vslam_orb_pattern.h"
+#include <cfloat>
+
+namespace vslam {
+
+__constant__ signed char c_pattern[1024];
+
+void upload_pattern() {
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), VSLAM_ORB_PATTERN, 1024);
+}
+
+// ---------------------------------------------------------------------------
+// K1: resize (reference computePyramid, src/FeatureExtractor.cpp:342-366;
+// cv::resize 8UC1 INTER_LINEAR fixed-point semantics).
+// xtab[dx] = { sx | sx1<<16, a0 | a1<<16 }, ytab[dy] = { sy, b0 | b1<<16 }.
+// Each thread produces 4 horizontally adjacent pixels and stores one uchar4.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, PyrDesc P, int level,
+                                                const int2* __restrict__ xtab,
+                                                const int2* __restrict__ ytab) {
+    const int img = blockIdx.z;
+    const uint8_t* __restrict__ S = pyr + (size_t)img * P.imgStride + P.off[level - 1];
+    uint8_t* __restrict__ D = pyr + (size_t)img * P.imgStride + P.off[level];
+    const int sp = P.pitch[level - 1], dp = P.pitch[level];
+    const int dw = P.w[level], dh = P.h[level], sh = P.h[level - 1];
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (y >= dh || x0 >= dw) return;
+    const int2 yt = ytab[y];
+    int sy0 = yt.x, sy1 = yt.x + 1;
+    sy0 = sy0 < 0 ? 0 : (sy0 < sh ? sy0 : sh - 1);
+    sy1 = sy1 < 0 ? 0 : (sy1 < sh ? sy1 : sh - 1);
+    const int b0 = (short)(yt.y & 0xffff), b1 = (short)(yt.y >> 16);
+    const uint8_t* r0 = S + (size_t)sy0 * sp;
+    const uint8_t* r1 = S + (size_t)sy1 * sp;
+    uchar4 o = make_uchar4(0, 0, 0, 0);
+    uint8_t* op = (uint8_t*)&o;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int dx = x0 + i;
+        if (dx < dw) {
+            const int2 xt = xtab[dx];
+            const int sx = xt.x & 0xffff, sx1 = xt.x >> 16;
+            const int a0 = (short)(xt.y & 0xffff), a1 = (short)(xt.y >> 16);
+            const int h0 = r0[sx] * a0 + r0[sx1] * a1;
+            const int h1 = r1[sx] * a0 + r1[sx1] * a1;
+            op[i] = (uint8_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+        }
+    }
+    *(uchar4*)(D + (size_t)y * dp + x0) = o;
+}
+
+void launch_resize(hipStream_t s, uint8_t* pyr, const PyrDesc& P, int level, const int2* xtab,
+                   const int2* ytab, int nimg) {
+    dim3 block(64, 4);
+    dim3 grid((P.w[level] + 255) / 256, (P.h[level] + 3) / 4, nimg);
+    hipLaunchKernelGGL(k_resize, grid, block, 0, s, pyr, P, level, xtab, ytab);
+}
+
+// ---------------------------------------------------------------------------
+// K2: FAST.  Reference computeKeypointsORBNew src/FeatureExtractor.cpp:535-604 with
+// cv::FAST(cell, thr 20, NMS) then, only if that cell is empty, cv::FAST(cell, thr 7, NMS).
+// cv::FAST semantics: a pixel is a corner at threshold t iff some
+// 9 contiguous ring pixels are all > v+t or all < v-t; with d_k = v - ring_k,
+//   M = max( max_arcs min d_k , max_arcs min -d_k ),  corner <=> M > t,  score = M - 1;
+// 3x3 NMS keeps strict maxima, pixels that are not corners at t count as score 0, as do
+// pixels outside the cell's detection area (3-px sub-image border);  keypoints are emitted
+// row by row, x ascending.  One workgroup = one cell; M is computed once and reused by
+// both thresholds.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool has9(unsigned m) {
+    m |= m << 16;
+    unsigned t = m & (m >> 1);
+    t &= t >> 2;
+    t &= t >> 4;
+    t &= m >> 8;
+    return (t & 0xffffu) != 0;
+}
+
+__global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, PyrDesc P,
+                                              FastDesc F, uint32_t* __restrict__ cellSlots,
+                                              int* __restrict__ cellCount, int maxThr, int minThr) {
+    __shared__ uint8_t tile[FAST_TILE_MAX * FAST_TILE_PITCH];
+    __shared__ uint8_t sc[(FAST_TILE_MAX - 4) * FAST_TILE_PITCH];
+    __shared__ int wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cell = blockIdx.x, img = blockIdx.y;
+    const int nCellsTotal = F.cellBase[P.nLevels];
+    int level = 0;
+    while (level + 1 < P.nLevels && cell >= F.cellBase[level + 1]) level++;
+    const int local = cell - F.cellBase[level];
+    const int nC = F.nCols[level];
+    const int iR = local / nC, iC = local - iR * nC;
+    const int w = P.w[level], h = P.h[level], pitch = P.pitch[level];
+    const int maxX = w - F.edge3, maxY = h - F.edge3;
+    const int rStart = F.minXY + iR * F.gridH[level];
+    const int cStart = F.minXY + iC * F.gridW[level];
+    int* outCount = cellCount + (size_t)img * nCellsTotal + cell;
+    if (rStart >= maxY - 6 || cStart >= maxX - 6) {
+        if (tid == 0) *outCount = 0;
+        return;
+    }
+    int rEnd = rStart + F.gridH[level] + 6;
+    if (rEnd > maxY) rEnd = maxY;
+    int cEnd = cStart + F.gridW[level] + 6;
+    if (cEnd > maxX) cEnd = maxX;
+    const int subW = cEnd - cStart, subH = rEnd - rStart;
+    const int detW = subW - 6, detH = subH - 6;
+    if (detW <= 0 || detH <= 0) {
+        if (tid == 0) *outCount = 0;
+        return;
+    }
+    const uint8_t* __restrict__ src =
+        pyr + (size_t)img * P.imgStride + P.off[level] + (size_t)rStart * pitch + cStart;
+    for (int i = tid; i < subW * subH; i += 256) {
+        const int r = i / subW, c = i - r * subW;
+        tile[r * FAST_TILE_PITCH + c] = src[(size_t)r * pitch + c];
+    }
+    for (int i = tid; i < (detH + 2) * FAST_TILE_PITCH; i += 256) sc[i] = 0;
+    __syncthreads();
+
+    const int tq = minThr < maxThr ? minThr : maxThr;  // quick-reject threshold
+    constexpr int TP = FAST_TILE_PITCH;
+    constexpr int ro[16] = {3 * TP,      3 * TP + 1,  2 * TP + 2,  TP + 3,  3,       -TP + 3,
+                            -2 * TP + 2, -3 * TP + 1, -3 * TP,     -3 * TP - 1, -2 * TP - 2, -TP - 3,
+                            -3,          TP - 3,      2 * TP - 2,  3 * TP - 1};
+    const int npix = detW * detH;
+    for (int idx = tid; idx < npix; idx += 256) {
+        const int r = idx / detW, c = idx - r * detW;
+        const uint8_t* p = &tile[(r + 3) * TP + (c + 3)];
+        const int v = p[0];
+        int q[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) q[k] = p[ro[k]];
+        unsigned dm = 0, bm = 0;
+        const int lo = v - tq, hi = v + tq;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            dm |= (unsigned)(q[k] < lo) << k;
+            bm |= (unsigned)(q[k] > hi) << k;
+        }
+        int M = 0;
+        if (has9(dm) || has9(bm)) {
+            int d[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) d[k] = v - q[k];
+            int mn[16], mx[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {  // width-2 windows
+                mn[k] = min(d[k], d[(k + 1) & 15]);
+                mx[k] = max(d[k], d[(k + 1) & 15]);
+            }
+            int mn4[16], mx4[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                mn4[k] = min(mn[k], mn[(k + 2) & 15]);
+                mx4[k] = max(mx[k], mx[(k + 2) & 15]);
+            }
+            int A = -512, B = 512;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int m9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
+                const int x9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
+                A = max(A, m9);
+                B = min(B, x9);
+            }
+            M = max(A, -B);
+            M = M < 0 ? 0 : M;
+        }
+        sc[(r + 1) * TP + (c + 1)] = (uint8_t)M;
+    }
+    __syncthreads();
+
+    uint32_t* slots = cellSlots + ((size_t)img * nCellsTotal + cell) * F.cellCap;
+    int total = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        const int t = pass == 0 ? maxThr : minThr;
+        total = 0;
+        for (int base = 0; base < npix; base += 256) {
+            const int idx = base + tid;
+            bool flag = false;
+            int r = 0, c = 0, s = 0;
+            if (idx < npix) {
+                r = idx / detW;
+                c = idx - r * detW;
+                const uint8_t* z = &sc[(r + 1) * TP + (c + 1)];
+                s = z[0];
+                if (s > t) {
+                    flag = true;
+#pragma unroll
+                    for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+                        for (int dx = -1; dx <= 1; dx++) {
+                            if (dy == 0 && dx == 0) continue;
+                            int nv = z[dy * TP + dx];
+                            nv = nv > t ? nv : 0;
+                            flag = flag && (s > nv);
+                        }
+                }
+            }
+            const unsigned long long bal = __ballot(flag);
+            const int lanePrefix = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) wsum[wave] = __popcll(bal);
+            __syncthreads();
+            int woff = 0, chunk = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int v2 = wsum[k];
+                if (k < wave) woff += v2;
+                chunk += v2;
+            }
+            if (flag) {
+                const int pos = total + woff + lanePrefix;
+                if (pos < F.cellCap) slots[pos] = pack_cand(cStart + 3 + c, rStart + 3 + r, s - 1);
+            }
+            total += chunk;
+            __syncthreads();
+        }
+        if (total > 0) break;
+    }
+    if (tid == 0) *outCount = total;
+}
+
+void launch_fast(hipStream_t s, const uint8_t* pyr, const PyrDesc& P, const FastDesc& F,
+                 uint32_t* cellSlots, int* cellCount, int maxThr, int minThr, int nimg) {
+    dim3 grid(F.cellBase[P.nLevels], nimg);
+    hipLaunchKernelGGL(k_fast, grid, dim3(256), 0, s, pyr, P, F, cellSlots, cellCount, maxThr, minThr);
+}
+
+// ---------------------------------------------------------------------------
+// K2b: gather cell lists into one level-major, cell-row-major candidate list per image
+// (the order in which the reference appends: src/FeatureExtractor.cpp:568-602).
+// One workgroup (1024 threads) per image: block-wide exclusive scan of the cell
+// counts, then one wave per cell copies its slots.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_gather(const uint32_t* __restrict__ cellSlots,
+                                                 const int* __restrict__ cellCount, FastDesc F,
+                                                 int nLevels, int* __restrict__ cellOff,
+                                                 uint32_t* __restrict__ cand, int candCap,
+                                                 int* __restrict__ levelCount) {
+    __shared__ int wtot[16];
+    __shared__ int s_run;
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nCells = F.cellBase[nLevels];
+    const int* cnt = cellCount + (size_t)img * nCells;
+    int* off = cellOff + (size_t)img * (nCells + 1);
+    if (tid == 0) s_run = 0;
+    __syncthreads();
+    for (int base = 0; base < nCells; base += 1024) {
+        const int i = base + tid;
+        const int v = i < nCells ? cnt[i] : 0;
+        int incl = v;  // inclusive wave scan
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int n = __shfl_up(incl, d);
+            if (lane >= d) incl += n;
+        }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < wave; k++) woff += wtot[k];
+        const int run = s_run;
+        if (i < nCells) off[i] = run + woff + incl - v;
+        __syncthreads();
+        if (tid == 1023) s_run = run + woff + incl;
+        __syncthreads();
+    }
+    if (tid == 0) off[nCells] = s_run;
+    __syncthreads();
+    if (tid < nLevels) {
+        const int a = off[F.cellBase[tid]], b = off[F.cellBase[tid + 1]];
+        levelCount[img * (MAX_LEVELS + 1) + tid] = b - a;
+    }
+    if (tid == 0) levelCount[img * (MAX_LEVELS + 1) + MAX_LEVELS] = s_run;
+    uint32_t* out = cand + (size_t)img * candCap;
+    for (int cell = wave; cell < nCells; cell += 16) {
+        const int n = cnt[cell], o = off[cell];
+        const uint32_t* sl = cellSlots + ((size_t)img * nCells + cell) * F.cellCap;
+        for (int e = lane; e < n; e += 64)
+            if (o + e < candCap) out[o + e] = sl[e];
+    }
+}
+
+void launch_gather(hipStream_t s, const uint32_t* cellSlots, const int* cellCount, const FastDesc& F,
+                   int nLevels, int* cellOff, uint32_t* cand, int candCap, int* levelCount, int nimg) {
+    hipLaunchKernelGGL(k_gather, dim3(nimg), dim3(1024), 0, s, cellSlots, cellCount, F, nLevels,
+                       cellOff, cand, candCap, levelCount);
+}
+
+// ---------------------------------------------------------------------------
+// K5: cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) on every pyramid level
+// (reference src/FeatureExtractor.cpp:512-515).  Fixed-point 8.8 taps; the horizontal
+// pass is exact in 16 bits, the vertical pass rounds once: (acc + 32768) >> 16.
+// 64x16 output tile per workgroup staged through LDS with its 3-px halo.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
+    return p;
+}
+
+__global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr,
+                                              uint8_t* __restrict__ blur, PyrDesc P, BlurDesc B) {
+    constexpr int IW = BLUR_TW + 6, IH = BLUR_TH + 6, IP = 72;
+    __shared__ uint8_t in[IH * IP];
+    __shared__ uint16_t hb[IH * BLUR_TW];
+    const int tid = threadIdx.x, img = blockIdx.y;
+    int level = 0;
+    const int t = blockIdx.x;
+    while (level + 1 < P.nLevels && t >= B.tileBase[level + 1]) level++;
+    const int lt = t - B.tileBase[level];
+    const int ty = lt / B.tilesX[level], tx = lt - ty * B.tilesX[level];
+    const int w = P.w[level], h = P.h[level], pitch = P.pitch[level];
+    const uint8_t* __restrict__ S = pyr + (size_t)img * P.imgStride + P.off[level];
+    uint8_t* __restrict__ D = blur + (size_t)img * P.imgStride + P.off[level];
+    const int x0 = tx * BLUR_TW, y0 = ty * BLUR_TH;
+    for (int i = tid; i < IH * IW; i += 256) {
+        const int r = i / IW, c = i - r * IW;
+        const int sx = reflect101(x0 + c - 3, w), sy = reflect101(y0 + r - 3, h);
+        in[r * IP + c] = S[(size_t)sy * pitch + sx];
+    }
+    __syncthreads();
+    for (int i = tid; i < IH * BLUR_TW; i += 256) {
+        const int r = i / BLUR_TW, c = i - r * BLUR_TW;
+        const uint8_t* p = &in[r * IP + c];
+        unsigned acc = 0;
+#pragma unroll
+        for (int j = 0; j < 7; j++) acc += (unsigned)B.taps[j] * p[j];
+        hb[i] = (uint16_t)acc;
+    }
+    __syncthreads();
+    for (int i = tid; i < BLUR_TH * BLUR_TW; i += 256) {
+        const int r = i / BLUR_TW, c = i - r * BLUR_TW;
+        unsigned acc = 0;
+#pragma unroll
+        for (int j = 0; j < 7; j++) acc += (unsigned)B.taps[j] * hb[(r + j) * BLUR_TW + c];
+        if (x0 + c < w && y0 + r < h) D[(size_t)(y0 + r) * pitch + x0 + c] = (uint8_t)((acc + 32768u) >> 16);
+    }
+}
+
+void launch_blur(hipStream_t s, const uint8_t* pyr, uint8_t* blur, const PyrDesc& P,
+                 const BlurDesc& B, int nimg) {
+    hipLaunchKernelGGL(k_blur, dim3(B.tileBase[P.nLevels], nimg), dim3(256), 0, s, pyr, blur, P, B);
+}
+
+// ---------------------------------------------------------------------------
+// K4 + K6: orientation (reference computeOrientation src/FeatureExtractor.cpp:315-340,
+// cv::fastAtan2 polynomial) and rotated BRIEF (computeOrbDescriptor :267-305) for
+// every kept keypoint, one 64-lane wave per keypoint.  The disc moments are integer
+// sums (order-free); each lane evaluates 4 of the 256 point pairs and lane pairs
+// merge their nibbles into descriptor bytes.  Keypoints are written in the reference
+// output order (level-major, SSC order) with pt scaled AFTER the descriptor (:523-524).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+    const float scale = (float)(180 / 3.1415926535897932384626433832795);
+    const float p1 = 0.9997878412794807f * scale;
+    const float p3 = -0.3258083974640975f * scale;
+    const float p5 = 0.1555786518463281f * scale;
+    const float p7 = -0.04432655554792128f * scale;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+__global__ __launch_bounds__(256) void k_orient_desc(
+    const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur, PyrDesc P, LevelTables T,
+    const uint32_t* __restrict__ kept, const int* __restrict__ keptOff, int keptCap,
+    const int8_t* __restrict__ disc, int ndisc, vslam_keypoint* __restrict__ kps,
+    uint8_t* __restrict__ desc, int outCap) {
+    const int img = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = blockIdx.x * 4 + wave;
+    const int* koff = keptOff + img * (MAX_LEVELS + 1);
+    const int total = koff[P.nLevels];
+    if (g >= total || g >= outCap) return;
+    int level = 0;
+    while (level + 1 < P.nLevels && g >= koff[level + 1]) level++;
+    const uint32_t pk = kept[(size_t)img * keptCap + g];
+    const int x = cand_x(pk), y = cand_y(pk), score = cand_s(pk);
+    const int pitch = P.pitch[level];
+    const size_t lvlOff = (size_t)img * P.imgStride + P.off[level];
+    const uint8_t* __restrict__ c0 = pyr + lvlOff + (size_t)y * pitch + x;
+    int m10 = 0, m01 = 0;
+    for (int i = lane; i < ndisc; i += 64) {
+        const int du = disc[2 * i], dv = disc[2 * i + 1];
+        const int I = c0[dv * pitch + du];
+        m10 += du * I;
+        m01 += dv * I;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        m10 += __shfl_xor(m10, d);
+        m01 += __shfl_xor(m01, d);
+    }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    const float ang = angle * factorPI;
+    // correctly-rounded float cos/sin via the double routines (matches libm's cosf/sinf
+    // on every input the parity tests cover; see DESIGN.md "float trig")
+    const float a = (float)cos((double)ang), b = (float)sin((double)ang);
+    const uint8_t* __restrict__ bc = blur + lvlOff + (size_t)y * pitch + x;
+    int nib = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int pair = lane * 4 + j;
+        const float x0 = (float)c_pattern[4 * pair], y0 = (float)c_pattern[4 * pair + 1];
+        const float x1 = (float)c_pattern[4 * pair + 2], y1 = (float)c_pattern[4 * pair + 3];
+        const int ry0 = __float2int_rn(x0 * b + y0 * a), rx0 = __float2int_rn(x0 * a - y0 * b);
+        const int ry1 = __float2int_rn(x1 * b + y1 * a), rx1 = __float2int_rn(x1 * a - y1 * b);
+        const int t0 = bc[ry0 * pitch + rx0], t1 = bc[ry1 * pitch + rx1];
+        nib |= (t0 < t1) << j;
+    }
+    const int other = __shfl_xor(nib, 1);
+    const size_t o = (size_t)img * outCap + g;
+    if ((lane & 1) == 0) desc[o * 32 + (lane >> 1)] = (uint8_t)(nib | (other << 4));
+    if (lane == 0) {
+        vslam_keypoint k;
+        const float sc = T.scalePyr[level];
+        k.x = (float)x;
+        k.y = (float)y;
+        if (level != 0) { k.x *= sc; k.y *= sc; }
+        k.size = (float)T.scaledPatch[level];
+        k.angle = angle;
+        k.response = (float)score;
+        k.octave = level;
+        k.class_id = -1;
+        kps[o] = k;
+    }
+}
+
+void launch_orient_desc(hipStream_t s, const uint8_t* pyr, const uint8_t* blur, const PyrDesc& P,
+                        const LevelTables& T, const uint32_t* kept, const int* keptOff, int keptCap,
+                        const int8_t* disc, int ndisc, vslam_keypoint* kps, uint8_t* desc, int outCap,
+                        int maxKept, int nimg) {
+    if (maxKept <= 0) return;
+    hipLaunchKernelGGL(k_orient_desc, dim3((maxKept + 3) / 4, nimg), dim3(256), 0, s, pyr, blur, P, T,
+                       kept, keptOff, keptCap, disc, ndisc, kps, desc, outCap);
+}
+
+}  // namespace vslam

@@ -1,0 +1,65 @@
+// Device-side descriptors shared by the extraction kernels and their host launcher.
+#pragma once
+#include "common.hpp"
+
+namespace vslam {
+
+// Pyramid storage: one allocation per extractor; image i starts at i*imgStride,
+// level l at off[l]; rows are pitch[l] bytes (multiple of 64) so that 16-byte
+// vector stores and row starts stay aligned.  No border is materialised: the
+// reference's 19-px REFLECT_101 frame is never read on this path.
+struct PyrDesc {
+    int nLevels;
+    int w[MAX_LEVELS], h[MAX_LEVELS], pitch[MAX_LEVELS];
+    uint32_t off[MAX_LEVELS];
+    uint32_t imgStride;
+};
+
+// FAST cell grid (reference src/FeatureExtractor.cpp:535-575): per level nCols x nRows
+// cells of gridW x gridH (+6 px overlap); cells numbered level-major, row-major.
+struct FastDesc {
+    int minXY;                       // edgeThreshold - 3
+    int edge3;                       // edgeThreshold - 3 (maxX = w - edge3)
+    int nCols[MAX_LEVELS], nRows[MAX_LEVELS], gridW[MAX_LEVELS], gridH[MAX_LEVELS];
+    int cellBase[MAX_LEVELS + 1];    // prefix of cell counts
+    int cellCap;                     // slots per cell
+};
+
+struct BlurDesc {
+    int tilesX[MAX_LEVELS];
+    int tileBase[MAX_LEVELS + 1];
+    int taps[7];
+};
+
+struct LevelTables {
+    float scalePyr[MAX_LEVELS];
+    int scaledPatch[MAX_LEVELS];
+};
+
+// packed FAST candidate: y[31:20] x[19:8] score[7:0]
+__host__ __device__ static inline uint32_t pack_cand(int x, int y, int s) {
+    return ((uint32_t)y << 20) | ((uint32_t)x << 8) | (uint32_t)s;
+}
+__host__ __device__ static inline int cand_x(uint32_t p) { return (p >> 8) & 0xfff; }
+__host__ __device__ static inline int cand_y(uint32_t p) { return p >> 20; }
+__host__ __device__ static inline int cand_s(uint32_t p) { return p & 0xff; }
+
+constexpr int FAST_TILE_PITCH = 80;   // >= max sub-image width (gridW + 6)
+constexpr int FAST_TILE_MAX = 76;     // max sub-image side supported
+constexpr int BLUR_TW = 64, BLUR_TH = 16;
+
+void launch_resize(hipStream_t s, uint8_t* pyr, const PyrDesc& P, int level, const int2* xtab,
+                   const int2* ytab, int nimg);
+void launch_fast(hipStream_t s, const uint8_t* pyr, const PyrDesc& P, const FastDesc& F,
+                 uint32_t* cellSlots, int* cellCount, int maxThr, int minThr, int nimg);
+void launch_gather(hipStream_t s, const uint32_t* cellSlots, const int* cellCount, const FastDesc& F,
+                   int nLevels, int* cellOff, uint32_t* cand, int candCap, int* levelCount, int nimg);
+void launch_blur(hipStream_t s, const uint8_t* pyr, uint8_t* blur, const PyrDesc& P,
+                 const BlurDesc& B, int nimg);
+void launch_orient_desc(hipStream_t s, const uint8_t* pyr, const uint8_t* blur, const PyrDesc& P,
+                        const LevelTables& T, const uint32_t* kept, const int* keptOff, int keptCap,
+                        const int8_t* disc, int ndisc, vslam_keypoint* kps, uint8_t* desc, int outCap,
+                        int maxKept, int nimg);
+void upload_pattern();
+
+}  // namespace vslam

@@ -1,0 +1,506 @@
+// vslam_extractor: host side of the HIP feature extractor (tables, buffers, launch order)
+// and the extraction part of the C ABI (include/vslam_hip.h).
+#include "extractor.hpp"
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+#include <mutex>
+
+namespace vslam {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+}  // namespace vslam
+
+using namespace vslam;
+
+// --- tables of the reference constructor (src/FeatureExtractor.cpp:620-682) -------
+static void build_fe_tables(vslam_extractor& e) {
+    const int nL = e.nLevels;
+    const vslam_fe_params& p = e.prm;
+    e.scalePyramid.assign(nL, 1.f);
+    e.scaleInvPyramid.assign(nL, 1.f);
+    e.sigmaFactor.assign(nL, 1.f);
+    e.InvSigmaFactor.assign(nL, 1.f);
+    e.scaledPatchSize.assign(nL, p.patch_size);
+    for (int i = 1; i < nL; i++) {
+        e.scalePyramid[i] = e.scalePyramid[i - 1] * p.scale;
+        e.scaledPatchSize[i] = (int)((float)p.patch_size * e.scalePyramid[i]);
+        e.sigmaFactor[i] = e.scalePyramid[i] * e.scalePyramid[i];
+    }
+    for (int i = 0; i < nL; i++) {
+        e.scaleInvPyramid[i] = 1.0f / e.scalePyramid[i];
+        e.InvSigmaFactor[i] = 1.0f / e.sigmaFactor[i];
+    }
+    e.featurePerLevel.assign(nL, 0);
+    const float factor = 1.0f / p.scale;
+    float want = (float)p.n_features * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nL));
+    int sum = 0;
+    for (int l = 0; l < nL - 1; l++) {
+        e.featurePerLevel[l] = cv_round_f(want);
+        sum += e.featurePerLevel[l];
+        want *= factor;
+    }
+    e.featurePerLevel[nL - 1] = std::max(p.n_features - sum, 0);
+    const int hp = 15;
+    e.umax.assign(hp + 1, 0);
+    const int vmax = cv_floor_f((float)hp * std::sqrt(2.f) / 2 + 1);
+    const int vmin = cv_ceil_f((float)hp * std::sqrt(2.f) / 2);
+    for (int v = 0; v <= vmax; ++v) e.umax[v] = cv_round_d(std::sqrt((double)hp * hp - v * v));
+    for (int v = hp, v0 = 0; v >= vmin; --v) {
+        while (e.umax[v0] == e.umax[v0 + 1]) ++v0;
+        e.umax[v] = v0;
+        ++v0;
+    }
+}
+
+// cv::resize INTER_LINEAR coefficient tables for one level
+static void build_resize_tables(int sw, int sh, int dw, int dh, std::vector<int2>& xt,
+                                std::vector<int2>& yt) {
+    const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+    auto sat16 = [](int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); };
+    xt.resize(dw);
+    yt.resize(dh);
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = cv_floor_f(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx + 1 >= sw && sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        const int sx1 = std::min(sx + 1, sw - 1);
+        const int a0 = sat16(cv_round_f((1.f - fx) * 2048)), a1 = sat16(cv_round_f(fx * 2048));
+        xt[dx].x = sx | (sx1 << 16);
+        xt[dx].y = (a0 & 0xffff) | (a1 << 16);
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = cv_floor_f(fy);
+        fy -= sy;
+        const int b0 = sat16(cv_round_f((1.f - fy) * 2048)), b1 = sat16(cv_round_f(fy * 2048));
+        yt[dy].x = sy;
+        yt[dy].y = (b0 & 0xffff) | (b1 << 16);
+    }
+}
+
+// 8.8 fixed-point Gaussian taps (ksize 7, sigma 2) with error diffusion so that they
+// sum to 256 — the choice recorded in DESIGN.md / SURVEY App. D.1.
+static void build_gauss_taps(int taps[7]) {
+    double g[7], sum = 0;
+    for (int i = 0; i < 7; i++) {
+        const double x = i - 3.0;
+        g[i] = std::exp(-0.5 * x * x / 4.0);
+        sum += g[i];
+    }
+    double err = 0;
+    long long s = 0;
+    for (int i = 0; i < 3; i++) {
+        const double adj = g[i] / sum * 256.0 + err;
+        const long long v0 = std::llrint(adj);
+        err = adj - (double)v0;
+        taps[i] = taps[6 - i] = (int)v0;
+        s += v0;
+    }
+    taps[3] = (int)(256 - 2 * s);
+}
+
+vslam_status vslam_extractor::init(const vslam_fe_params* p, int w, int h, int batch, int dev) {
+    if (!p || w < 64 || h < 64 || batch < 1 || p->n_levels < 1 || p->n_levels > MAX_LEVELS ||
+        p->n_features < 1 || !(p->scale > 1.0f) || p->edge_threshold < 19 || w > 4095 || h > 4095) {
+        set_error("vslam_extractor_create: invalid parameters");
+        return VSLAM_ERR_INVALID;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no HIP device available (libvslam_hip has no CPU fallback)");
+        return VSLAM_ERR_NO_DEVICE;
+    }
+    if (dev < 0 || dev >= ndev) { set_error("device %d out of range", dev); return VSLAM_ERR_INVALID; }
+    VS_HIP(hipSetDevice(dev));
+    prm = *p; width = w; height = h; nimg = batch; device = dev; nLevels = p->n_levels;
+    build_fe_tables(*this);
+    upload_pattern();
+
+    // pyramid geometry (reference computePyramid, src/FeatureExtractor.cpp:346-347)
+    P.nLevels = nLevels;
+    size_t off = 0;
+    for (int l = 0; l < nLevels; l++) {
+        const float sc = scaleInvPyramid[l];
+        P.w[l] = cv_round_f((float)w * sc);
+        P.h[l] = cv_round_f((float)h * sc);
+        P.pitch[l] = align_up(P.w[l], 64);
+        P.off[l] = (uint32_t)off;
+        off += align_up_sz((size_t)P.pitch[l] * P.h[l], 256);
+        T.scalePyr[l] = scalePyramid[l];
+        T.scaledPatch[l] = scaledPatchSize[l];
+    }
+    P.imgStride = (uint32_t)off;
+
+    // FAST cell grid (src/FeatureExtractor.cpp:540-560)
+    F.minXY = p->edge_threshold - 3;
+    F.edge3 = p->edge_threshold - 3;
+    int cells = 0, cap = 1;
+    for (int l = 0; l < nLevels; l++) {
+        const int maxX = P.w[l] - F.edge3, maxY = P.h[l] - F.edge3;
+        const int wid = maxX - F.minXY, hig = maxY - F.minXY;
+        const int nC = (int)((float)wid / 35.f), nR = (int)((float)hig / 35.f);
+        if (nC < 1 || nR < 1) { set_error("pyramid level %d too small for the FAST grid", l); return VSLAM_ERR_INVALID; }
+        F.nCols[l] = nC; F.nRows[l] = nR;
+        F.gridW[l] = cv_ceil_f((float)wid / nC);
+        F.gridH[l] = cv_ceil_f((float)hig / nR);
+        if (F.gridW[l] + 6 > FAST_TILE_MAX || F.gridH[l] + 6 > FAST_TILE_MAX) {
+            set_error("FAST cell larger than the LDS tile"); return VSLAM_ERR_INVALID;
+        }
+        F.cellBase[l] = cells;
+        cells += nC * nR;
+        cap = std::max(cap, ((F.gridW[l] + 1) / 2) * ((F.gridH[l] + 1) / 2));
+    }
+    F.cellBase[nLevels] = cells;
+    for (int l = nLevels + 1; l <= MAX_LEVELS; l++) F.cellBase[l] = cells;
+    F.cellCap = cap;   // strict 3x3 maxima: at most one per 2x2 block
+    nCells = cells;
+
+    // blur tiles
+    int tiles = 0;
+    for (int l = 0; l < nLevels; l++) {
+        B.tilesX[l] = (P.w[l] + BLUR_TW - 1) / BLUR_TW;
+        B.tileBase[l] = tiles;
+        tiles += B.tilesX[l] * ((P.h[l] + BLUR_TH - 1) / BLUR_TH);
+    }
+    B.tileBase[nLevels] = tiles;
+    build_gauss_taps(B.taps);
+
+    VS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    timer.stream = stream;
+    VS_HIP(hipMalloc(&d_pyr, (size_t)nimg * P.imgStride));
+    VS_HIP(hipMalloc(&d_blur, (size_t)nimg * P.imgStride));
+    VS_HIP(hipMemset(d_pyr, 0, (size_t)nimg * P.imgStride));
+    VS_HIP(hipMemset(d_blur, 0, (size_t)nimg * P.imgStride));
+
+    // resize tables
+    std::vector<int2> allx, ally;
+    xtabOff.assign(nLevels, 0);
+    ytabOff.assign(nLevels, 0);
+    for (int l = 1; l < nLevels; l++) {
+        std::vector<int2> xt, yt;
+        build_resize_tables(P.w[l - 1], P.h[l - 1], P.w[l], P.h[l], xt, yt);
+        xtabOff[l] = (int)allx.size();
+        ytabOff[l] = (int)ally.size();
+        allx.insert(allx.end(), xt.begin(), xt.end());
+        ally.insert(ally.end(), yt.begin(), yt.end());
+    }
+    if (allx.empty()) { allx.push_back(make_int2(0, 0)); ally.push_back(make_int2(0, 0)); }
+    VS_HIP(hipMalloc(&d_xtab, allx.size() * sizeof(int2)));
+    VS_HIP(hipMalloc(&d_ytab, ally.size() * sizeof(int2)));
+    VS_HIP(hipMemcpy(d_xtab, allx.data(), allx.size() * sizeof(int2), hipMemcpyHostToDevice));
+    VS_HIP(hipMemcpy(d_ytab, ally.data(), ally.size() * sizeof(int2), hipMemcpyHostToDevice));
+
+    VS_HIP(hipMalloc(&d_cellSlots, (size_t)nimg * nCells * F.cellCap * sizeof(uint32_t)));
+    VS_HIP(hipMalloc(&d_cellCount, (size_t)nimg * nCells * sizeof(int)));
+    VS_HIP(hipMalloc(&d_cellOff, (size_t)nimg * (nCells + 1) * sizeof(int)));
+    candCap = nCells * F.cellCap;
+    VS_HIP(hipHostMalloc(&h_cand, (size_t)nimg * candCap * sizeof(uint32_t), hipHostMallocMapped));
+    VS_HIP(hipHostGetDevicePointer((void**)&d_cand, h_cand, 0));
+    VS_HIP(hipHostMalloc(&h_levelCount, (size_t)nimg * (MAX_LEVELS + 1) * sizeof(int), hipHostMallocMapped));
+    VS_HIP(hipHostGetDevicePointer((void**)&d_levelCount, h_levelCount, 0));
+
+    // a level keeps at most max(featurePerLevel * 1.1 rounded, featurePerLevel) points
+    keptCap = 0;
+    for (int l = 0; l < nLevels; l++) keptCap += (int)std::ceil(featurePerLevel[l] * 1.1f) + 2;
+    keptCap = align_up(keptCap, 64);
+    VS_HIP(hipHostMalloc(&h_kept, (size_t)nimg * keptCap * sizeof(uint32_t), hipHostMallocDefault));
+    VS_HIP(hipMalloc(&d_kept, (size_t)nimg * keptCap * sizeof(uint32_t)));
+    VS_HIP(hipHostMalloc(&h_keptOff, (size_t)nimg * (MAX_LEVELS + 1) * sizeof(int), hipHostMallocDefault));
+    VS_HIP(hipMalloc(&d_keptOff, (size_t)nimg * (MAX_LEVELS + 1) * sizeof(int)));
+    VS_HIP(hipMalloc(&d_kps, (size_t)nimg * keptCap * sizeof(vslam_keypoint)));
+    VS_HIP(hipMalloc(&d_desc, (size_t)nimg * keptCap * 32));
+
+    // radius-15 disc of the intensity centroid (src/FeatureExtractor.cpp:321-336)
+    std::vector<int8_t> disc;
+    for (int u = -15; u <= 15; u++) { disc.push_back((int8_t)u); disc.push_back(0); }
+    for (int v = 1; v <= 15; v++)
+        for (int u = -umax[v]; u <= umax[v]; u++) {
+            disc.push_back((int8_t)u); disc.push_back((int8_t)v);
+            disc.push_back((int8_t)u); disc.push_back((int8_t)-v);
+        }
+    ndisc = (int)disc.size() / 2;
+    VS_HIP(hipMalloc(&d_disc, disc.size()));
+    VS_HIP(hipMemcpy(d_disc, disc.data(), disc.size(), hipMemcpyHostToDevice));
+    nKept.assign(nimg, 0);
+    return VSLAM_OK;
+}
+
+void vslam_extractor::release() {
+    if (stream) hipStreamSynchronize(stream);
+    timer.destroy();
+    hipFree(d_pyr); hipFree(d_blur); hipFree(d_xtab); hipFree(d_ytab);
+    hipFree(d_cellSlots); hipFree(d_cellCount); hipFree(d_cellOff);
+    if (h_cand) hipHostFree(h_cand);
+    if (h_levelCount) hipHostFree(h_levelCount);
+    if (h_kept) hipHostFree(h_kept);
+    if (h_keptOff) hipHostFree(h_keptOff);
+    hipFree(d_kept); hipFree(d_keptOff); hipFree(d_kps); hipFree(d_desc); hipFree(d_disc);
+    if (stream) hipStreamDestroy(stream);
+    stream = nullptr;
+}
+
+vslam_status vslam_extractor::set_image(int idx, const void* src, int stride, bool srcOnDevice) {
+    if (idx < 0 || idx >= nimg || !src || stride < width) { set_error("set_image: bad argument"); return VSLAM_ERR_INVALID; }
+    VS_HIP(hipSetDevice(device));
+    VS_HIP(hipMemcpy2DAsync(d_pyr + (size_t)idx * P.imgStride + P.off[0], P.pitch[0], src, stride, width,
+                            height, srcOnDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
+    if (!srcOnDevice) VS_HIP(hipStreamSynchronize(stream));  // caller may reuse its buffer
+    return VSLAM_OK;
+}
+
+// Square-covering suppression on the host: the greedy cover scan and the
+// std::sort tie order it depends on are sequential by construction
+// (reference src/FeatureExtractor.cpp:368-468; cv::sortIdx = std::sort on indices
+// + reversal).  Works on packed candidates, emits packed keeps.
+void vslam_extractor::ssc_level(const uint32_t* cand, int n, int numRet, int cols, int rows,
+                                std::vector<uint32_t>& out) const {
+    std::vector<int> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(),
+              [cand](int a, int b) { return (cand[a] & 0xffu) < (cand[b] & 0xffu); });
+    std::reverse(order.begin(), order.end());
+    const int e1 = rows + cols + 2 * numRet;
+    const long long e2 = 4LL * cols + 4LL * numRet + 4LL * rows * numRet + (long long)rows * rows +
+                         (long long)cols * cols - 2LL * rows * cols + 4LL * rows * cols * numRet;
+    const double e3 = std::sqrt((double)e2), e4 = numRet - 1;
+    const double s1 = -std::round((e1 + e3) / e4), s2 = -std::round((e1 - e3) / e4);
+    int high = (int)(s1 > s2 ? s1 : s2);
+    int low = std::max(1, (int)std::floor(std::sqrt((double)n / numRet)));
+    const unsigned K = (unsigned)numRet;
+    const unsigned Kmin = (unsigned)std::round((float)K - ((float)K * 0.1f));
+    const unsigned Kmax = (unsigned)std::round((float)K + ((float)K * 0.1f));
+    std::vector<int> picked, lastPicked;
+    std::vector<uint8_t> cover;
+    int prevWidth = -1;
+    for (;;) {
+        const int width = low + (high - low) / 2;
+        if (width == prevWidth || low > high) { lastPicked = picked; break; }
+        picked.clear();
+        const double c = (double)width / 2.0;
+        const int gc = (int)std::floor(cols / c), gr = (int)std::floor(rows / c);
+        const int span = (int)std::floor(width / c);
+        cover.assign((size_t)(gr + 1) * (gc + 1), 0);
+        for (int i = 0; i < n; i++) {
+            const uint32_t pk = cand[order[i]];
+            const int row = (int)std::floor((float)cand_y(pk) / c);
+            const int col = (int)std::floor((float)cand_x(pk) / c);
+            if (cover[(size_t)row * (gc + 1) + col]) continue;
+            picked.push_back(i);
+            const int r0 = std::max(row - span, 0), r1 = std::min(row + span, gr);
+            const int c0 = std::max(col - span, 0), c1 = std::min(col + span, gc);
+            for (int rr = r0; rr <= r1; rr++)
+                memset(&cover[(size_t)rr * (gc + 1) + c0], 1, (size_t)(c1 - c0 + 1));
+        }
+        if (picked.size() >= Kmin && picked.size() <= Kmax) { lastPicked = picked; break; }
+        if (picked.size() < Kmin) high = width - 1; else low = width + 1;
+        prevWidth = width;
+    }
+    out.clear();
+    out.reserve(lastPicked.size());
+    for (int i : lastPicked) out.push_back(cand[order[i]]);
+}
+
+vslam_status vslam_extractor::run() {
+    VS_HIP(hipSetDevice(device));
+    int t;
+    t = timer.begin("pyramid");
+    for (int l = 1; l < nLevels; l++)
+        launch_resize(stream, d_pyr, P, l, d_xtab + xtabOff[l], d_ytab + ytabOff[l], nimg);
+    timer.end(t);
+    t = timer.begin("fast");
+    launch_fast(stream, d_pyr, P, F, d_cellSlots, d_cellCount, prm.max_fast_threshold,
+                prm.min_fast_threshold, nimg);
+    timer.end(t);
+    t = timer.begin("gather");
+    launch_gather(stream, d_cellSlots, d_cellCount, F, nLevels, d_cellOff, d_cand, candCap,
+                  d_levelCount, nimg);
+    timer.end(t);
+    t = timer.begin("blur");
+    launch_blur(stream, d_pyr, d_blur, P, B, nimg);
+    timer.end(t);
+    VS_HIP(hipGetLastError());
+    VS_HIP(hipStreamSynchronize(stream));
+
+    // host: SSC per (image, level); keeps are staged level-major
+    int maxKept = 0;
+    std::vector<uint32_t> keep;
+    for (int i = 0; i < nimg; i++) {
+        const int* lc = h_levelCount + (size_t)i * (MAX_LEVELS + 1);
+        const uint32_t* cand = h_cand + (size_t)i * candCap;
+        uint32_t* kout = h_kept + (size_t)i * keptCap;
+        int* koff = h_keptOff + (size_t)i * (MAX_LEVELS + 1);
+        if (lc[MAX_LEVELS] > candCap) { set_error("FAST candidate overflow"); return VSLAM_ERR_CAPACITY; }
+        int coff = 0, k = 0;
+        for (int l = 0; l < nLevels; l++) {
+            const int n = lc[l];
+            koff[l] = k;
+            if (n > featurePerLevel[l]) {
+                ssc_level(cand + coff, n, featurePerLevel[l], P.w[l], P.h[l], keep);
+                if (k + (int)keep.size() > keptCap) { set_error("kept-keypoint overflow"); return VSLAM_ERR_CAPACITY; }
+                memcpy(kout + k, keep.data(), keep.size() * sizeof(uint32_t));
+                k += (int)keep.size();
+            } else {
+                if (k + n > keptCap) { set_error("kept-keypoint overflow"); return VSLAM_ERR_CAPACITY; }
+                memcpy(kout + k, cand + coff, (size_t)n * sizeof(uint32_t));
+                k += n;
+            }
+            coff += n;
+        }
+        for (int l = nLevels; l <= MAX_LEVELS; l++) koff[l] = k;
+        nKept[i] = k;
+        maxKept = std::max(maxKept, k);
+    }
+    VS_HIP(hipMemcpyAsync(d_kept, h_kept, (size_t)nimg * keptCap * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    VS_HIP(hipMemcpyAsync(d_keptOff, h_keptOff, (size_t)nimg * (MAX_LEVELS + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
+    t = timer.begin("orient_desc");
+    launch_orient_desc(stream, d_pyr, d_blur, P, T, d_kept, d_keptOff, keptCap, d_disc, ndisc, d_kps,
+                       d_desc, keptCap, maxKept, nimg);
+    timer.end(t);
+    VS_HIP(hipGetLastError());
+    VS_HIP(hipStreamSynchronize(stream));
+    ran = true;
+    return VSLAM_OK;
+}
+
+// --------------------------------------------------------------------------- C ABI
+extern "C" {
+
+const char* vslam_last_error(void) { return vslam::g_err; }
+
+int vslam_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+vslam_status vslam_extractor_create(const vslam_fe_params* params, int32_t width, int32_t height,
+                                    int32_t batch, int32_t device, vslam_extractor** out) {
+    if (!out) return VSLAM_ERR_INVALID;
+    *out = nullptr;
+    vslam_extractor* e = new (std::nothrow) vslam_extractor();
+    if (!e) return VSLAM_ERR_INVALID;
+    vslam_status s = e->init(params, width, height, batch, device);
+    if (s != VSLAM_OK) { e->release(); delete e; return s; }
+    *out = e;
+    return VSLAM_OK;
+}
+
+void vslam_extractor_destroy(vslam_extractor* ex) {
+    if (!ex) return;
+    ex->release();
+    delete ex;
+}
+
+vslam_status vslam_extractor_tables(const vslam_extractor* ex, float* sp, float* si, float* sg,
+                                    float* isg, int32_t* ps, int32_t* fpl) {
+    if (!ex) return VSLAM_ERR_INVALID;
+    for (int i = 0; i < ex->nLevels; i++) {
+        if (sp) sp[i] = ex->scalePyramid[i];
+        if (si) si[i] = ex->scaleInvPyramid[i];
+        if (sg) sg[i] = ex->sigmaFactor[i];
+        if (isg) isg[i] = ex->InvSigmaFactor[i];
+        if (ps) ps[i] = ex->scaledPatchSize[i];
+        if (fpl) fpl[i] = ex->featurePerLevel[i];
+    }
+    return VSLAM_OK;
+}
+
+vslam_status vslam_extractor_set_image_device(vslam_extractor* ex, int32_t i, const void* d, int32_t stride) {
+    if (!ex) return VSLAM_ERR_INVALID;
+    return ex->set_image(i, d, stride, true);
+}
+vslam_status vslam_extractor_set_image_host(vslam_extractor* ex, int32_t i, const uint8_t* g, int32_t stride) {
+    if (!ex) return VSLAM_ERR_INVALID;
+    return ex->set_image(i, g, stride, false);
+}
+vslam_status vslam_extractor_run(vslam_extractor* ex) {
+    if (!ex) return VSLAM_ERR_INVALID;
+    return ex->run();
+}
+vslam_status vslam_extractor_count(const vslam_extractor* ex, int32_t i, int32_t* n) {
+    if (!ex || !n || i < 0 || i >= ex->nimg || !ex->ran) return VSLAM_ERR_INVALID;
+    *n = ex->nKept[i];
+    return VSLAM_OK;
+}
+vslam_status vslam_extractor_fetch(vslam_extractor* ex, int32_t i, vslam_keypoint* kps, uint8_t* desc,
+                                   int32_t cap, int32_t* n_out) {
+    if (!ex || i < 0 || i >= ex->nimg || !ex->ran || !n_out) return VSLAM_ERR_INVALID;
+    const int n = ex->nKept[i];
+    *n_out = n;
+    if (n > cap) { set_error("fetch: cap %d < %d keypoints", cap, n); return VSLAM_ERR_CAPACITY; }
+    if (n == 0) return VSLAM_OK;   // outputs untouched, like extractKeysNew :498-499
+    VS_HIP(hipSetDevice(ex->device));
+    if (kps) VS_HIP(hipMemcpyAsync(kps, ex->d_kps + (size_t)i * ex->keptCap, (size_t)n * sizeof(vslam_keypoint), hipMemcpyDeviceToHost, ex->stream));
+    if (desc) VS_HIP(hipMemcpyAsync(desc, ex->d_desc + (size_t)i * ex->keptCap * 32, (size_t)n * 32, hipMemcpyDeviceToHost, ex->stream));
+    VS_HIP(hipStreamSynchronize(ex->stream));
+    return VSLAM_OK;
+}
+
+vslam_status vslam_extract(vslam_extractor* ex, const uint8_t* const* gray, int32_t stride,
+                           vslam_keypoint* kps, uint8_t* desc, int32_t cap, int32_t* n_out) {
+    if (!ex || !gray || !n_out) return VSLAM_ERR_INVALID;
+    for (int i = 0; i < ex->nimg; i++) VS_CHECK(ex->set_image(i, gray[i], stride, false));
+    VS_CHECK(ex->run());
+    for (int i = 0; i < ex->nimg; i++)
+        VS_CHECK(vslam_extractor_fetch(ex, i, kps ? kps + (size_t)i * cap : nullptr,
+                                       desc ? desc + (size_t)i * cap * 32 : nullptr, cap, &n_out[i]));
+    return VSLAM_OK;
+}
+
+vslam_status vslam_extractor_level_size(const vslam_extractor* ex, int32_t level, int32_t* w, int32_t* h) {
+    if (!ex || level < 0 || level >= ex->nLevels) return VSLAM_ERR_INVALID;
+    if (w) *w = ex->P.w[level];
+    if (h) *h = ex->P.h[level];
+    return VSLAM_OK;
+}
+vslam_status vslam_extractor_level_copy(vslam_extractor* ex, int32_t i, int32_t level, int32_t blurred, uint8_t* out) {
+    if (!ex || !out || i < 0 || i >= ex->nimg || level < 0 || level >= ex->nLevels) return VSLAM_ERR_INVALID;
+    VS_HIP(hipSetDevice(ex->device));
+    const uint8_t* base = (blurred ? ex->d_blur : ex->d_pyr) + (size_t)i * ex->P.imgStride + ex->P.off[level];
+    VS_HIP(hipMemcpy2DAsync(out, ex->P.w[level], base, ex->P.pitch[level], ex->P.w[level], ex->P.h[level], hipMemcpyDeviceToHost, ex->stream));
+    VS_HIP(hipStreamSynchronize(ex->stream));
+    return VSLAM_OK;
+}
+vslam_status vslam_extractor_candidates(vslam_extractor* ex, int32_t i, int32_t level, vslam_keypoint* out, int32_t cap, int32_t* n_out) {
+    if (!ex || !n_out || i < 0 || i >= ex->nimg || level < 0 || level >= ex->nLevels || !ex->ran) return VSLAM_ERR_INVALID;
+    const int* lc = ex->h_levelCount + (size_t)i * (MAX_LEVELS + 1);
+    int off = 0;
+    for (int l = 0; l < level; l++) off += lc[l];
+    const int n = lc[level];
+    *n_out = n;
+    if (n > cap) return VSLAM_ERR_CAPACITY;
+    const uint32_t* c = ex->h_cand + (size_t)i * ex->candCap + off;
+    for (int k = 0; k < n; k++) {
+        out[k].x = (float)cand_x(c[k]); out[k].y = (float)cand_y(c[k]);
+        out[k].size = (float)ex->scaledPatchSize[level]; out[k].angle = -1.f;
+        out[k].response = (float)cand_s(c[k]); out[k].octave = level; out[k].class_id = -1;
+    }
+    return VSLAM_OK;
+}
+
+vslam_status vslam_extractor_timings(const vslam_extractor* ex, const char** names, float* ms, int32_t cap, int32_t* n_out) {
+    if (!ex || !n_out) return VSLAM_ERR_INVALID;
+    int n = 0;
+    for (const auto& it : ex->timer.items) {
+        if (n >= cap) break;
+        float v = 0;
+        if (hipEventElapsedTime(&v, it.a, it.b) != hipSuccess) v = -1.f;
+        if (names) names[n] = it.name;
+        if (ms) ms[n] = v;
+        n++;
+    }
+    *n_out = n;
+    return VSLAM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,55 @@
+// Host object behind vslam_extractor: owns the device pyramid, FAST / blur /
+// descriptor buffers and the stream of one FeatureExtractor-equivalent (batch of
+// `nimg` same-sized images per run).
+#pragma once
+#include "extract_kernels.hpp"
+
+struct vslam_extractor {
+    vslam_fe_params prm{};
+    int width = 0, height = 0, nimg = 0, device = 0;
+    int nLevels = 0;
+    // reference tables (include/FeatureExtractor.h:71-77)
+    std::vector<float> scalePyramid, scaleInvPyramid, sigmaFactor, InvSigmaFactor;
+    std::vector<int> scaledPatchSize, featurePerLevel, umax;
+
+    vslam::PyrDesc P{};
+    vslam::FastDesc F{};
+    vslam::BlurDesc B{};
+    vslam::LevelTables T{};
+    hipStream_t stream = nullptr;
+    vslam::StageTimer timer;
+
+    uint8_t* d_pyr = nullptr;    // nimg * imgStride
+    uint8_t* d_blur = nullptr;   // same layout
+    int2* d_xtab = nullptr;      // resize tables, all levels
+    int2* d_ytab = nullptr;
+    std::vector<int> xtabOff, ytabOff;
+    uint32_t* d_cellSlots = nullptr;
+    int* d_cellCount = nullptr;
+    int* d_cellOff = nullptr;
+    int nCells = 0;
+    int candCap = 0;             // per image
+    uint32_t* h_cand = nullptr;  // pinned, device-visible: nimg * candCap
+    uint32_t* d_cand = nullptr;  // device alias of h_cand
+    int* h_levelCount = nullptr; // pinned: nimg * (MAX_LEVELS+1)
+    int* d_levelCount = nullptr;
+    int keptCap = 0;             // per image
+    uint32_t* h_kept = nullptr;  // pinned staging
+    uint32_t* d_kept = nullptr;
+    int* h_keptOff = nullptr;    // pinned: nimg * (MAX_LEVELS+1)
+    int* d_keptOff = nullptr;
+    int8_t* d_disc = nullptr;
+    int ndisc = 0;
+    vslam_keypoint* d_kps = nullptr;  // nimg * keptCap
+    uint8_t* d_desc = nullptr;        // nimg * keptCap * 32
+    std::vector<int> nKept;           // per image, after the last run
+    bool ran = false;
+
+    vslam_status init(const vslam_fe_params* p, int w, int h, int batch, int dev);
+    void release();
+    vslam_status set_image(int idx, const void* src, int stride, bool srcOnDevice);
+    vslam_status run();
+    // host SSC of one level (reference FeatureExtractor::ssc, src/FeatureExtractor.cpp:368-468)
+    void ssc_level(const uint32_t* cand, int n, int numRet, int cols, int rows,
+                   std::vector<uint32_t>& out) const;
+};

@@ -1,0 +1,138 @@
+"""ctypes binding of libvslam_hip.so (the C ABI declared in include/vslam_hip.h).
+
+This is plumbing for tests/ and bench.py only: every call goes straight to the
+HIP library.  There is no Python or CPU fallback; if the library or a GPU is
+missing the calls raise.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvslam_hip.so")
+_LIB = None
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_COMM = range(6)
+
+
+class FeParams(C.Structure):
+    _fields_ = [("n_features", C.c_int32), ("n_levels", C.c_int32), ("scale", C.c_float),
+                ("edge_threshold", C.c_int32), ("patch_size", C.c_int32),
+                ("max_fast_threshold", C.c_int32), ("min_fast_threshold", C.c_int32)]
+
+
+class VslamError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("vslam status %d: %s" % (status, msg))
+        self.status = status
+
+
+def build():
+    """Compile libvslam_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-s", "-j4", "-C", os.path.join(_HERE, "csrc")])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libvslam_hip.so is not built (run __graft_entry__.build()); "
+                               "there is no CPU fallback")
+        _LIB = C.CDLL(LIB_PATH)
+        _LIB.vslam_last_error.restype = C.c_char_p
+    return _LIB
+
+
+def _chk(status):
+    if status != OK:
+        raise VslamError(status, lib().vslam_last_error().decode())
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def device_count():
+    return int(lib().vslam_device_count())
+
+
+class Extractor:
+    """FeatureExtractor (reference include/FeatureExtractor.h:53-98) on the GPU."""
+
+    def __init__(self, width, height, nfeatures=2000, nlevels=8, scale=1.2, edge=19, patch=31,
+                 max_fast=20, min_fast=7, batch=1, device=0):
+        self.L = lib()
+        self.width, self.height, self.batch, self.nlevels = width, height, batch, nlevels
+        prm = FeParams(nfeatures, nlevels, scale, edge, patch, max_fast, min_fast)
+        self.h = C.c_void_p()
+        _chk(self.L.vslam_extractor_create(C.byref(prm), width, height, batch, device, C.byref(self.h)))
+        f = lambda: np.zeros(nlevels, np.float32)
+        i = lambda: np.zeros(nlevels, np.int32)
+        self.scalePyramid, self.scaleInvPyramid, self.sigmaFactor, self.InvSigmaFactor = f(), f(), f(), f()
+        self.scaledPatchSize, self.featurePerLevel = i(), i()
+        _chk(self.L.vslam_extractor_tables(self.h, _p(self.scalePyramid), _p(self.scaleInvPyramid),
+                                           _p(self.sigmaFactor), _p(self.InvSigmaFactor),
+                                           _p(self.scaledPatchSize), _p(self.featurePerLevel)))
+
+    def close(self):
+        if self.h:
+            self.L.vslam_extractor_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_image(self, idx, gray):
+        gray = np.ascontiguousarray(gray, np.uint8)
+        assert gray.shape == (self.height, self.width)
+        _chk(self.L.vslam_extractor_set_image_host(self.h, idx, _p(gray), gray.shape[1]))
+
+    def set_image_device(self, idx, dptr, stride):
+        _chk(self.L.vslam_extractor_set_image_device(self.h, idx, C.c_void_p(dptr), stride))
+
+    def run(self):
+        _chk(self.L.vslam_extractor_run(self.h))
+
+    def fetch(self, idx, cap=None):
+        n = C.c_int32()
+        _chk(self.L.vslam_extractor_count(self.h, idx, C.byref(n)))
+        cap = max(n.value, 1) if cap is None else cap
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        _chk(self.L.vslam_extractor_fetch(self.h, idx, _p(kps), _p(desc), cap, C.byref(n)))
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def extract(self, images):
+        """images: list of `batch` u8 arrays -> list of (keypoints, descriptors)."""
+        assert len(images) == self.batch
+        for i, im in enumerate(images):
+            self.set_image(i, im)
+        self.run()
+        return [self.fetch(i) for i in range(self.batch)]
+
+    def level(self, idx, level, blurred=False):
+        w, h = C.c_int32(), C.c_int32()
+        _chk(self.L.vslam_extractor_level_size(self.h, level, C.byref(w), C.byref(h)))
+        out = np.zeros((h.value, w.value), np.uint8)
+        _chk(self.L.vslam_extractor_level_copy(self.h, idx, level, int(blurred), _p(out)))
+        return out
+
+    def candidates(self, idx, level, cap=400000):
+        out = np.zeros(cap, KP_DTYPE)
+        n = C.c_int32()
+        _chk(self.L.vslam_extractor_candidates(self.h, idx, level, _p(out), cap, C.byref(n)))
+        return out[:n.value].copy()
+
+    def timings(self):
+        names = (C.c_char_p * 32)()
+        ms = (C.c_float * 32)()
+        n = C.c_int32()
+        _chk(self.L.vslam_extractor_timings(self.h, names, ms, 32, C.byref(n)))
+        return {names[i].decode(): float(ms[i]) for i in range(n.value)}

@@ -1,0 +1,115 @@
+/*
+ * vslam_hip.h — C ABI of the MI355X (gfx950) implementation of gtsam-vSLAM's
+ * per-frame tracking + local bundle-adjustment hot path.
+ *
+ * The reference has no FFI: its boundary is the set of C++ member functions
+ * System.cpp and the two pipelines call.  Every entry point
+ * below names the reference interface it replaces (file:line under the
+ * reference root).  Plain pointers and sizes only; the caller owns every
+ * buffer; every function returns a vslam_status and never throws.
+ *
+ * All compute runs in hand-written HIP kernels; there is no CPU fallback — if
+ * no gfx950 device is usable the create functions return VSLAM_ERR_NO_DEVICE.
+ */
+#ifndef VSLAM_HIP_H
+#define VSLAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum vslam_status {
+    VSLAM_OK = 0,
+    VSLAM_ERR_INVALID = 1,    /* bad argument / shape mismatch */
+    VSLAM_ERR_NO_DEVICE = 2,  /* no usable HIP device (product path never falls back to CPU) */
+    VSLAM_ERR_HIP = 3,        /* a HIP runtime call failed; see vslam_last_error() */
+    VSLAM_ERR_CAPACITY = 4,   /* caller buffer / internal capacity too small */
+    VSLAM_ERR_COMM = 5        /* RCCL failure */
+} vslam_status;
+
+const char* vslam_last_error(void);
+/* number of visible HIP devices (0 if none); never initialises a context */
+int vslam_device_count(void);
+
+/* cv::KeyPoint, field for field (28 bytes) — reference include/FeatureExtractor.h:20 */
+typedef struct vslam_keypoint {
+    float x, y;
+    float size;
+    float angle;
+    float response;
+    int32_t octave;
+    int32_t class_id;
+} vslam_keypoint;
+
+/* FeatureExtractor constructor arguments — reference include/FeatureExtractor.h:80,
+ * src/FeatureExtractor.cpp:620 */
+typedef struct vslam_fe_params {
+    int32_t n_features;
+    int32_t n_levels;
+    float scale;
+    int32_t edge_threshold;
+    int32_t patch_size;
+    int32_t max_fast_threshold;
+    int32_t min_fast_threshold;
+} vslam_fe_params;
+
+/* ---------------------------------------------------------------------------
+ * FeatureExtractor — replaces FeatureExtractor::FeatureExtractor and
+ * FeatureExtractor::extractKeysNew (include/FeatureExtractor.h:80,87;
+ * src/FeatureExtractor.cpp:481-533).  One object extracts `batch` same-sized
+ * images per call (batch = 2 runs the left and the right image of a stereo
+ * frame in the same launches, as the reference's two threads do,
+ * src/FeatureTracker.cpp:58-61).  Not re-entrant, like the reference object.
+ * ------------------------------------------------------------------------- */
+typedef struct vslam_extractor vslam_extractor;
+
+vslam_status vslam_extractor_create(const vslam_fe_params* params, int32_t width, int32_t height,
+                                    int32_t batch, int32_t device, vslam_extractor** out);
+void vslam_extractor_destroy(vslam_extractor* ex);
+
+/* public tables of the reference object (scalePyramid, scaleInvPyramid, sigmaFactor,
+ * InvSigmaFactor, scaledPatchSize, featurePerLevel — include/FeatureExtractor.h:71-77);
+ * each out array holds n_levels entries, NULL pointers are skipped */
+vslam_status vslam_extractor_tables(const vslam_extractor* ex, float* scale_pyramid,
+                                    float* scale_inv_pyramid, float* sigma_factor,
+                                    float* inv_sigma_factor, int32_t* scaled_patch_size,
+                                    int32_t* feature_per_level);
+
+/* extractKeysNew on host images: gray[i] is image i (u8, `stride` bytes per row).
+ * kps: batch x cap keypoints, desc: batch x cap x 32 bytes, n_out: batch counts. */
+vslam_status vslam_extract(vslam_extractor* ex, const uint8_t* const* gray, int32_t stride,
+                           vslam_keypoint* kps, uint8_t* desc, int32_t cap, int32_t* n_out);
+
+/* Split form used when inputs are already device-resident (bench, pipelines):
+ *   set_image_device: copy a device image (u8, stride bytes per row) into pyramid level 0
+ *   run:              enqueue + complete extraction, results stay in HBM
+ *   fetch:            copy keypoints / descriptors of image i to host buffers */
+vslam_status vslam_extractor_set_image_device(vslam_extractor* ex, int32_t image_index,
+                                              const void* d_gray, int32_t stride);
+vslam_status vslam_extractor_set_image_host(vslam_extractor* ex, int32_t image_index,
+                                            const uint8_t* gray, int32_t stride);
+vslam_status vslam_extractor_run(vslam_extractor* ex);
+vslam_status vslam_extractor_count(const vslam_extractor* ex, int32_t image_index, int32_t* n_out);
+vslam_status vslam_extractor_fetch(vslam_extractor* ex, int32_t image_index, vslam_keypoint* kps,
+                                   uint8_t* desc, int32_t cap, int32_t* n_out);
+
+/* test / debug taps: pyramid level (blurred = 0|1) copied to a w*h host buffer,
+ * and the pre-SSC FAST candidates of one level */
+vslam_status vslam_extractor_level_size(const vslam_extractor* ex, int32_t level, int32_t* w, int32_t* h);
+vslam_status vslam_extractor_level_copy(vslam_extractor* ex, int32_t image_index, int32_t level,
+                                        int32_t blurred, uint8_t* out);
+vslam_status vslam_extractor_candidates(vslam_extractor* ex, int32_t image_index, int32_t level,
+                                        vslam_keypoint* out, int32_t cap, int32_t* n_out);
+
+/* per-kernel device time of the last run, in milliseconds (HIP events on the
+ * extractor's stream).  names/ms hold up to cap entries; n_out = entries written. */
+vslam_status vslam_extractor_timings(const vslam_extractor* ex, const char** names, float* ms,
+                                     int32_t cap, int32_t* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSLAM_HIP_H */
