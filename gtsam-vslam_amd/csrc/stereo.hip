@@ -1,0 +1,435 @@
+// Stereo left<->right matching on gfx950 (K7): reference FeatureMatcher::findStereoMatchesORB2R
+// (src/FeatureMatcher.cpp:528-708) + destributeRightKeys (:728-752) + DescriptorDistance (:710-726).
+//
+//   k_stereo_match     one 64-lane wave per left keypoint.  The right keypoints' row band
+//                      [mn,mx], octave and y are staged once per workgroup in LDS (this replaces
+//                      the reference's per-row bucket lists: a right keypoint is in bucket
+//                      `yKey` iff mn <= yKey <= mx, and buckets list indices in ascending
+//                      order, so "first minimum wins" == smallest index among minima).
+//                      Hamming = XOR + popcount over 8 x u32; 11x11 SAD over 11 shifts on the
+//                      unblurred pyramids via an LDS window; float parabola exactly as written.
+//   k_stereo_finalize  one workgroup: the nearest-1 % depth cut and the 2.1 x median-SAD cut
+//                      (:674-705) by rank counting, leftIdxs by atomicMax + kill pass.
+#include "matcher.hpp"
+#include <climits>
+
+namespace vslam {
+
+__device__ __forceinline__ int d_cvFloor(float v) { int i = (int)v; return i - (i > v); }
+__device__ __forceinline__ int d_cvCeil(float v) { int i = (int)v; return i + (i < v); }
+
+__global__ __launch_bounds__(256) void k_stereo_match(StereoArgs A, int* __restrict__ mBest,
+                                                      float* __restrict__ mDepth,
+                                                      int* __restrict__ mSad,
+                                                      unsigned long long* __restrict__ stats) {
+    extern __shared__ unsigned char smem[];
+    const int nR = A.nR, nRp = (nR + 3) & ~3;
+    float* yR = (float*)smem;
+    int* mm = (int*)(yR + nRp);
+    uint8_t* oc = (uint8_t*)(mm + nRp);
+    __shared__ uint8_t winL[4][11 * 12];
+    __shared__ uint8_t winR[4][11 * 24];
+    __shared__ int sadp[4][5 * 11];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    for (int i = tid; i < nR; i += 256) {
+        const float y = A.kpsR[i].y;
+        const int oct = A.kpsR[i].octave;
+        const int yKey = __float2int_rn(y);
+        const float r = 2.0f * A.scalePyrR[oct];
+        const int mn = d_cvFloor((float)yKey - r), mx = d_cvCeil((float)yKey + r);
+        yR[i] = y;
+        mm[i] = (mn & 0xffff) | (mx << 16);
+        oc[i] = (uint8_t)oct;
+    }
+    __syncthreads();
+
+    const int left = blockIdx.x * 4 + wave;
+    const bool have = left < A.nL;
+    float lx = 0, ly = 0;
+    int octL = 0;
+    if (have) { lx = A.kpsL[left].x; ly = A.kpsL[left].y; octL = A.kpsL[left].octave; }
+    const int yKey = __float2int_rn(ly);
+    const float uL = ly;                       // quirk: disparity window tested on y (:557)
+    const float minU = uL - A.maxD, maxU = uL;
+    bool active = have && !(maxU < 0) && yKey >= 0 && yKey < A.imageHeight;
+
+    unsigned best = (256u << 16) | 0xffffu;
+    int cnt = 0;
+    if (active) {
+        uint32_t dl[8];
+        const uint32_t* pl = (const uint32_t*)(A.descL + (size_t)left * 32);
+#pragma unroll
+        for (int k = 0; k < 8; k++) dl[k] = pl[k];
+        for (int idx = lane; idx < nR; idx += 64) {
+            const int m = mm[idx];
+            const int mn = (short)(m & 0xffff), mx = m >> 16;
+            if (yKey < mn || yKey > mx) continue;
+            const int octR = oc[idx];
+            if (octR < octL - 1 || octR > octL + 1) continue;
+            const float uR = yR[idx];
+            if (!(uR >= minU && uR <= maxU)) continue;
+            const uint4* pr = (const uint4*)(A.descR + (size_t)idx * 32);
+            const uint4 r0 = pr[0], r1 = pr[1];
+            const int dist = __popc(dl[0] ^ r0.x) + __popc(dl[1] ^ r0.y) + __popc(dl[2] ^ r0.z) +
+                             __popc(dl[3] ^ r0.w) + __popc(dl[4] ^ r1.x) + __popc(dl[5] ^ r1.y) +
+                             __popc(dl[6] ^ r1.z) + __popc(dl[7] ^ r1.w);
+            cnt++;
+            const unsigned key = ((unsigned)dist << 16) | (unsigned)idx;
+            best = key < best ? key : best;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned o = __shfl_xor(best, d);
+        best = o < best ? o : best;
+        cnt += __shfl_xor(cnt, d);
+    }
+    const int bestDist = (int)(best >> 16);
+    const int bestIdx = (int)(best & 0xffffu);
+    const bool refine = active && bestDist <= 75;       // thDist, include/FeatureMatcher.h:25
+
+    // --- SAD refinement on the unblurred pyramids at level octL (:598-632) ---------------
+    float scuR = 0;
+    int cols = 1;
+    if (refine) {
+        const float kRx = A.kpsR[bestIdx].x;
+        const float scale = A.scaleInv[octL];
+        const float scuL = roundf(lx * scale);
+        const float scvL = roundf(ly * scale);
+        scuR = roundf(kRx * scale);
+        const int pitchL = A.PL.pitch[octL], pitchR = A.PR.pitch[octL];
+        const int hL = A.PL.h[octL], wL = A.PL.w[octL], hR = A.PR.h[octL];
+        cols = A.PR.w[octL];
+        const uint8_t* imL = A.pyrL + A.PL.off[octL];
+        const uint8_t* imR = A.pyrR + A.PR.off[octL];
+        const int ly0 = (int)(scvL - 5), lx0 = (int)(scuL - 5), rx0 = (int)scuR - 10;
+        for (int i = lane; i < 121; i += 64) {
+            const int r = i / 11, c = i - r * 11;
+            int yy = ly0 + r, xx = lx0 + c;
+            yy = yy < 0 ? 0 : (yy >= hL ? hL - 1 : yy);
+            xx = xx < 0 ? 0 : (xx >= wL ? wL - 1 : xx);
+            winL[wave][r * 12 + c] = imL[(size_t)yy * pitchL + xx];
+        }
+        for (int i = lane; i < 231; i += 64) {
+            const int r = i / 21, c = i - r * 21;
+            int yy = ly0 + r;
+            const int xx = rx0 + c;
+            yy = yy < 0 ? 0 : (yy >= hR ? hR - 1 : yy);
+            winR[wave][r * 24 + c] = (xx >= 0 && xx < cols) ? imR[(size_t)yy * pitchR + xx] : 0;
+        }
+    }
+    __syncthreads();
+    if (refine && lane < 55) {
+        const int s = lane % 11, g = lane / 11;
+        int acc = 0;
+        for (int r = g; r < 11; r += 5) {
+            const uint8_t* a = &winL[wave][r * 12];
+            const uint8_t* b = &winR[wave][r * 24 + s];
+#pragma unroll
+            for (int c = 0; c < 11; c++) acc += abs((int)a[c] - (int)b[c]);
+        }
+        sadp[wave][g * 11 + s] = acc;
+    }
+    __syncthreads();
+    if (refine && lane == 0) {
+        float allDists[11];
+        int bestDistW = INT_MAX, bestX = 0;
+#pragma unroll
+        for (int s = 0; s < 11; s++) {
+            const int xMov = s - 5;
+            const float startW = scuR + xMov - 5;
+            const float endW = scuR + xMov + 5 + 1;
+            allDists[s] = 0.f;
+            if (startW < 0 || endW >= cols) continue;
+            const int tot = sadp[wave][s] + sadp[wave][11 + s] + sadp[wave][22 + s] +
+                            sadp[wave][33 + s] + sadp[wave][44 + s];
+            const float dist = (float)tot;
+            if ((float)bestDistW > dist) { bestX = xMov; bestDistW = (int)dist; }
+            allDists[s] = dist;
+        }
+        int outBest = -1;
+        float outDepth = -1.f;
+        unsigned long long accepted = 0;
+        if (!(bestX == -5 || bestX == 5)) {
+            const float dist1 = allDists[5 + bestX - 1];
+            const float dist2 = allDists[5 + bestX];
+            const float dist3 = allDists[5 + bestX + 1];
+            const float delta = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+            if (!(delta > 1 || delta < -1)) {
+                accepted = 1;
+                const float newuR = A.scalePyr[octL] * ((float)scuR + (float)bestX + delta);
+                const float disparity = lx - newuR;
+                if (disparity > 0.0f && (double)disparity < A.fx) {
+                    outDepth = (A.fxf * A.baseline) / disparity;
+                    outBest = bestIdx;
+                }
+            }
+        }
+        mBest[left] = outBest;
+        mDepth[left] = outDepth;
+        mSad[left] = bestDistW;
+        atomicAdd(&stats[1], 1ull);
+        if (accepted) atomicAdd(&stats[2], 1ull);
+    } else if (have && lane == 0 && !refine) {
+        mBest[left] = -1;
+        mDepth[left] = -1.f;
+        mSad[left] = 0;
+    }
+    if (have && lane == 0 && cnt) atomicAdd(&stats[0], (unsigned long long)cnt);
+}
+
+void launch_stereo_match(hipStream_t s, const StereoArgs& A, int* mBest, float* mDepth, int* mSad,
+                         unsigned long long* stats) {
+    if (A.nL <= 0) return;
+    const int nRp = (A.nR + 3) & ~3;
+    const size_t sh = (size_t)nRp * 9 + 16;
+    hipLaunchKernelGGL(k_stereo_match, dim3((A.nL + 3) / 4), dim3(256), sh, s, A, mBest, mDepth, mSad, stats);
+}
+
+// One workgroup; n = accepted pairs.  Dropped set = first floor(0.01 n) by (depth, index)
+// plus every pair whose SAD is not below 2.1 x the median SAD (src/FeatureMatcher.cpp:674-705).
+__global__ __launch_bounds__(1024) void k_stereo_finalize(int nL, int nR, const int* __restrict__ mBest,
+                                                          const float* __restrict__ mDepth,
+                                                          const int* __restrict__ mSad, float closeDepth,
+                                                          int* __restrict__ rightIdxs,
+                                                          int* __restrict__ leftIdxs,
+                                                          float* __restrict__ depth,
+                                                          uint8_t* __restrict__ closef) {
+    extern __shared__ unsigned char smem[];
+    int* vIdx = (int*)smem;
+    float* vDepth = (float*)(vIdx + nL);
+    int* vSad = (int*)(vDepth + nL);
+    int* rankD = vSad + nL;
+    __shared__ int s_n, s_median;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_n = 0; s_median = 0; }
+    for (int i = tid; i < nL; i += 1024) { rightIdxs[i] = -1; depth[i] = -1.f; closef[i] = 0; }
+    for (int j = tid; j < nR; j += 1024) leftIdxs[j] = -1;
+    __syncthreads();
+    for (int i = tid; i < nL; i += 1024) {
+        if (mBest[i] >= 0) {
+            const int p = atomicAdd(&s_n, 1);
+            vIdx[p] = i; vDepth[p] = mDepth[i]; vSad[p] = mSad[i];
+        }
+    }
+    __syncthreads();
+    const int n = s_n;
+    if (n == 0) return;
+    const int endDe = (int)floor((double)n * 0.01);
+    for (int e = tid; e < n; e += 1024) {
+        const float d = vDepth[e];
+        const int id = vIdx[e], sd = vSad[e];
+        int rd = 0, rs = 0;
+        for (int k = 0; k < n; k++) {
+            const float d2 = vDepth[k];
+            const int i2 = vIdx[k], s2 = vSad[k];
+            rd += (d2 < d) || (d2 == d && i2 < id);
+            rs += (s2 < sd) || (s2 == sd && i2 < id);
+        }
+        rankD[e] = rd;
+        if (rs == n / 2) s_median = sd;
+    }
+    __syncthreads();
+    const float medDistD = (float)s_median * (1.5f * 1.4f);
+    for (int e = tid; e < n; e += 1024) {
+        const int i = vIdx[e], r = mBest[i];
+        const bool dropped = rankD[e] < endDe || !((float)vSad[e] < medDistD);
+        if (!dropped) {
+            rightIdxs[i] = r;
+            depth[i] = vDepth[e];
+            closef[i] = vDepth[e] < closeDepth ? 1 : 0;
+        }
+        atomicMax(&leftIdxs[r], i);
+    }
+    __syncthreads();
+    for (int e = tid; e < n; e += 1024) {
+        const bool dropped = rankD[e] < endDe || !((float)vSad[e] < medDistD);
+        if (dropped) leftIdxs[mBest[vIdx[e]]] = -1;
+    }
+}
+
+void launch_stereo_finalize(hipStream_t s, int nL, int nR, const int* mBest, const float* mDepth,
+                            const int* mSad, float closeDepth, int* rightIdxs, int* leftIdxs,
+                            float* depth, uint8_t* closef) {
+    if (nL <= 0 && nR <= 0) return;
+    const size_t sh = (size_t)(nL > 0 ? nL : 1) * 16;
+    hipLaunchKernelGGL(k_stereo_finalize, dim3(1), dim3(1024), sh, s, nL, nR, mBest, mDepth, mSad,
+                       closeDepth, rightIdxs, leftIdxs, depth, closef);
+}
+
+}  // namespace vslam
+
+using namespace vslam;
+
+vslam_status vslam_matcher::init(const vslam_rig* r, vslam_extractor* l, int il, vslam_extractor* rr, int ir) {
+    if (!r || !l || !rr || il < 0 || il >= l->nimg || ir < 0 || ir >= rr->nimg || l->device != rr->device ||
+        l->nLevels != rr->nLevels || l->width != rr->width || l->height != rr->height ||
+        r->width != l->width || r->height != l->height) {
+        set_error("vslam_matcher_create: invalid arguments");
+        return VSLAM_ERR_INVALID;
+    }
+    rig = *r; feL = l; feR = rr; imgL = il; imgR = ir; device = l->device;
+    VS_HIP(hipSetDevice(device));
+    VS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    timer.stream = stream;
+    VS_HIP(hipMalloc(&d_stats, 4 * sizeof(unsigned long long)));
+    VS_CHECK(ensure_cap(std::max(l->keptCap, rr->keptCap)));
+    return VSLAM_OK;
+}
+
+vslam_status vslam_matcher::ensure_cap(int n) {
+    if (n <= cap) return VSLAM_OK;
+    if (n > 65535) { set_error("more than 65535 keypoints per image is not supported"); return VSLAM_ERR_CAPACITY; }
+    hipFree(d_mBest); hipFree(d_mDepth); hipFree(d_mSad); hipFree(d_rightIdxs); hipFree(d_leftIdxs);
+    hipFree(d_depth); hipFree(d_close);
+    cap = vslam::align_up(n, 256);
+    VS_HIP(hipMalloc(&d_mBest, cap * sizeof(int)));
+    VS_HIP(hipMalloc(&d_mDepth, cap * sizeof(float)));
+    VS_HIP(hipMalloc(&d_mSad, cap * sizeof(int)));
+    VS_HIP(hipMalloc(&d_rightIdxs, cap * sizeof(int)));
+    VS_HIP(hipMalloc(&d_leftIdxs, cap * sizeof(int)));
+    VS_HIP(hipMalloc(&d_depth, cap * sizeof(float)));
+    VS_HIP(hipMalloc(&d_close, cap));
+    return VSLAM_OK;
+}
+
+void vslam_matcher::release() {
+    if (stream) hipStreamSynchronize(stream);
+    timer.destroy();
+    hipFree(d_mBest); hipFree(d_mDepth); hipFree(d_mSad); hipFree(d_rightIdxs); hipFree(d_leftIdxs);
+    hipFree(d_depth); hipFree(d_close); hipFree(d_stats);
+    for (int s = 0; s < 2; s++) { hipFree(d_okps[s]); hipFree(d_odesc[s]); }
+    if (stream) hipStreamDestroy(stream);
+    stream = nullptr;
+}
+
+vslam_status vslam_matcher::refresh_keys() {
+    vslam_extractor* fe[2] = {feL, feR};
+    const int img[2] = {imgL, imgR};
+    for (int s = 0; s < 2; s++) {
+        if (overridden[s]) continue;
+        if (!fe[s]->ran) { set_error("matcher: extractor has not run"); return VSLAM_ERR_INVALID; }
+        d_kps[s] = fe[s]->d_kps + (size_t)img[s] * fe[s]->keptCap;
+        d_desc[s] = fe[s]->d_desc + (size_t)img[s] * fe[s]->keptCap * 32;
+        nKeys[s] = fe[s]->nKept[img[s]];
+    }
+    return ensure_cap(std::max(nKeys[0], nKeys[1]));
+}
+
+vslam_status vslam_matcher::stereo_match() {
+    VS_HIP(hipSetDevice(device));
+    VS_CHECK(refresh_keys());
+    StereoArgs A{};
+    A.kpsL = d_kps[0]; A.descL = d_desc[0]; A.nL = nKeys[0];
+    A.kpsR = d_kps[1]; A.descR = d_desc[1]; A.nR = nKeys[1];
+    A.pyrL = feL->d_pyr + (size_t)imgL * feL->P.imgStride;
+    A.pyrR = feR->d_pyr + (size_t)imgR * feR->P.imgStride;
+    A.PL = feL->P; A.PR = feR->P;
+    for (int l = 0; l < feL->nLevels; l++) {
+        A.scalePyr[l] = feL->scalePyramid[l];
+        A.scaleInv[l] = feL->scaleInvPyramid[l];
+        A.scalePyrR[l] = feR->scalePyramid[l];
+    }
+    A.maxD = (float)rig.fx; A.fx = rig.fx; A.fxf = (float)rig.fx; A.baseline = rig.baseline;
+    A.imageHeight = rig.height;
+    VS_HIP(hipMemsetAsync(d_stats, 0, 4 * sizeof(unsigned long long), stream));
+    int t = timer.begin("stereo_match");
+    launch_stereo_match(stream, A, d_mBest, d_mDepth, d_mSad, d_stats);
+    timer.end(t);
+    t = timer.begin("stereo_finalize");
+    const float closeDepth = rig.baseline * 40;   // closeNumber, include/FeatureMatcher.h:36
+    launch_stereo_finalize(stream, A.nL, A.nR, d_mBest, d_mDepth, d_mSad, closeDepth, d_rightIdxs,
+                           d_leftIdxs, d_depth, d_close);
+    timer.end(t);
+    VS_HIP(hipGetLastError());
+    VS_HIP(hipStreamSynchronize(stream));
+    stereoDone = true;
+    return VSLAM_OK;
+}
+
+extern "C" {
+
+vslam_status vslam_matcher_create(const vslam_rig* rig, vslam_extractor* fe_left, int32_t left_image,
+                                  vslam_extractor* fe_right, int32_t right_image, vslam_matcher** out) {
+    if (!out) return VSLAM_ERR_INVALID;
+    *out = nullptr;
+    vslam_matcher* m = new (std::nothrow) vslam_matcher();
+    if (!m) return VSLAM_ERR_INVALID;
+    vslam_status s = m->init(rig, fe_left, left_image, fe_right, right_image);
+    if (s != VSLAM_OK) { m->release(); delete m; return s; }
+    *out = m;
+    return VSLAM_OK;
+}
+
+void vslam_matcher_destroy(vslam_matcher* m) {
+    if (!m) return;
+    m->release();
+    delete m;
+}
+
+vslam_status vslam_matcher_set_keys(vslam_matcher* m, int32_t right, const vslam_keypoint* kps,
+                                    const uint8_t* desc, int32_t n) {
+    if (!m || right < 0 || right > 1 || n < 0 || (n > 0 && (!kps || !desc))) return VSLAM_ERR_INVALID;
+    VS_HIP(hipSetDevice(m->device));
+    if (n > m->ocap[right]) {
+        hipFree(m->d_okps[right]); hipFree(m->d_odesc[right]);
+        m->ocap[right] = vslam::align_up(n, 256);
+        VS_HIP(hipMalloc(&m->d_okps[right], (size_t)m->ocap[right] * sizeof(vslam_keypoint)));
+        VS_HIP(hipMalloc(&m->d_odesc[right], (size_t)m->ocap[right] * 32));
+    }
+    if (n > 0) {
+        VS_HIP(hipMemcpy(m->d_okps[right], kps, (size_t)n * sizeof(vslam_keypoint), hipMemcpyHostToDevice));
+        VS_HIP(hipMemcpy(m->d_odesc[right], desc, (size_t)n * 32, hipMemcpyHostToDevice));
+    }
+    m->overridden[right] = true;
+    m->d_kps[right] = m->d_okps[right];
+    m->d_desc[right] = m->d_odesc[right];
+    m->nKeys[right] = n;
+    return m->ensure_cap(n);
+}
+
+vslam_status vslam_matcher_use_extractor_keys(vslam_matcher* m) {
+    if (!m) return VSLAM_ERR_INVALID;
+    m->overridden[0] = m->overridden[1] = false;
+    return VSLAM_OK;
+}
+
+vslam_status vslam_stereo_match(vslam_matcher* m) {
+    if (!m) return VSLAM_ERR_INVALID;
+    return m->stereo_match();
+}
+
+vslam_status vslam_stereo_fetch(vslam_matcher* m, int32_t* right_idxs, int32_t* left_idxs, float* depth,
+                                uint8_t* close_flags, int32_t cap_left, int32_t cap_right, int64_t* stats3) {
+    if (!m || !m->stereoDone) return VSLAM_ERR_INVALID;
+    const int nL = m->nKeys[0], nR = m->nKeys[1];
+    if (cap_left < nL || cap_right < nR) { set_error("stereo_fetch: capacity"); return VSLAM_ERR_CAPACITY; }
+    VS_HIP(hipSetDevice(m->device));
+    if (right_idxs && nL) VS_HIP(hipMemcpyAsync(right_idxs, m->d_rightIdxs, (size_t)nL * 4, hipMemcpyDeviceToHost, m->stream));
+    if (depth && nL) VS_HIP(hipMemcpyAsync(depth, m->d_depth, (size_t)nL * 4, hipMemcpyDeviceToHost, m->stream));
+    if (close_flags && nL) VS_HIP(hipMemcpyAsync(close_flags, m->d_close, (size_t)nL, hipMemcpyDeviceToHost, m->stream));
+    if (left_idxs && nR) VS_HIP(hipMemcpyAsync(left_idxs, m->d_leftIdxs, (size_t)nR * 4, hipMemcpyDeviceToHost, m->stream));
+    unsigned long long st[4] = {0, 0, 0, 0};
+    VS_HIP(hipMemcpyAsync(st, m->d_stats, sizeof(st), hipMemcpyDeviceToHost, m->stream));
+    VS_HIP(hipStreamSynchronize(m->stream));
+    if (stats3) { stats3[0] = (int64_t)st[0]; stats3[1] = (int64_t)st[1]; stats3[2] = (int64_t)st[2]; }
+    return VSLAM_OK;
+}
+
+vslam_status vslam_matcher_timings(const vslam_matcher* m, const char** names, float* ms, int32_t cap, int32_t* n_out) {
+    if (!m || !n_out) return VSLAM_ERR_INVALID;
+    int n = 0;
+    for (const auto& it : m->timer.items) {
+        if (n >= cap) break;
+        float v = 0;
+        if (hipEventElapsedTime(&v, it.a, it.b) != hipSuccess) v = -1.f;
+        if (names) names[n] = it.name;
+        if (ms) ms[n] = v;
+        n++;
+    }
+    *n_out = n;
+    return VSLAM_OK;
+}
+
+}  // extern "C"

@@ -136,3 +136,62 @@ class Extractor:
         n = C.c_int32()
         _chk(self.L.vslam_extractor_timings(self.h, names, ms, 32, C.byref(n)))
         return {names[i].decode(): float(ms[i]) for i in range(n.value)}
+
+
+class Rig(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("baseline", C.c_float), ("width", C.c_int32), ("height", C.c_int32)]
+
+
+def make_rig(r):
+    return Rig(r["fx"], r["fy"], r["cx"], r["cy"], r["bl"], r["w"], r["h"])
+
+
+class Matcher:
+    """FeatureMatcher (reference include/FeatureMatcher.h:22-63) on the GPU."""
+
+    def __init__(self, rig, fe_left, left_image, fe_right, right_image):
+        self.L = lib()
+        self.fe = (fe_left, fe_right)   # keep the extractors alive
+        self.rig = make_rig(rig)
+        self.h = C.c_void_p()
+        _chk(self.L.vslam_matcher_create(C.byref(self.rig), fe_left.h, left_image, fe_right.h, right_image,
+                                         C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.L.vslam_matcher_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_keys(self, right, kps, desc):
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        assert desc.shape == (len(kps), 32)
+        _chk(self.L.vslam_matcher_set_keys(self.h, int(right), _p(kps), _p(desc), len(kps)))
+
+    def use_extractor_keys(self):
+        _chk(self.L.vslam_matcher_use_extractor_keys(self.h))
+
+    def stereo_match(self):
+        _chk(self.L.vslam_stereo_match(self.h))
+
+    def stereo_fetch(self, nL, nR):
+        ri = np.full(max(nL, 1), -1, np.int32); li = np.full(max(nR, 1), -1, np.int32)
+        dp = np.full(max(nL, 1), -1, np.float32); cl = np.zeros(max(nL, 1), np.uint8)
+        st = np.zeros(3, np.int64)
+        _chk(self.L.vslam_stereo_fetch(self.h, _p(ri), _p(li), _p(dp), _p(cl), max(nL, 1), max(nR, 1), _p(st)))
+        return dict(rightIdxs=ri[:nL], leftIdxs=li[:nR], depth=dp[:nL], close=cl[:nL],
+                    candidates=int(st[0]), sad=int(st[1]), matches=int(st[2]))
+
+    def timings(self):
+        names = (C.c_char_p * 32)()
+        ms = (C.c_float * 32)()
+        n = C.c_int32()
+        _chk(self.L.vslam_matcher_timings(self.h, names, ms, 32, C.byref(n)))
+        return {names[i].decode(): float(ms[i]) for i in range(n.value)}

@@ -109,6 +109,46 @@ vslam_status vslam_extractor_candidates(vslam_extractor* ex, int32_t image_index
 vslam_status vslam_extractor_timings(const vslam_extractor* ex, const char** names, float* ms,
                                      int32_t cap, int32_t* n_out);
 
+
+/* ---------------------------------------------------------------------------
+ * FeatureMatcher — replaces FeatureMatcher::FeatureMatcher and its matching
+ * members (include/FeatureMatcher.h:40-63).  Like the reference object it holds
+ * the two extractors (feLeft / feRight) and reads their pyramids in place
+ * (src/FeatureMatcher.cpp:606,623) — here device-resident, no copies.
+ * ------------------------------------------------------------------------- */
+/* the scalars of Camera / StereoCamera that enter the path (include/Camera.h:71,83-84) */
+typedef struct vslam_rig {
+    double fx, fy, cx, cy;
+    float baseline;
+    int32_t width, height;
+} vslam_rig;
+
+typedef struct vslam_matcher vslam_matcher;
+
+/* left_image / right_image: index of the left / right image inside the extractors'
+ * batches (one batch-2 extractor may serve as both feLeft and feRight). */
+vslam_status vslam_matcher_create(const vslam_rig* rig, vslam_extractor* fe_left, int32_t left_image,
+                                  vslam_extractor* fe_right, int32_t right_image, vslam_matcher** out);
+void vslam_matcher_destroy(vslam_matcher* m);
+
+/* By default the matcher uses the keypoints / descriptors of the extractors' last run where
+ * they lie in HBM.  set_keys overrides one side (right = 0|1) with host arrays (tests, replays);
+ * use_extractor_keys switches back. */
+vslam_status vslam_matcher_set_keys(vslam_matcher* m, int32_t right, const vslam_keypoint* kps,
+                                    const uint8_t* desc, int32_t n);
+vslam_status vslam_matcher_use_extractor_keys(vslam_matcher* m);
+
+/* findStereoMatchesORB2R (include/FeatureMatcher.h:54, src/FeatureMatcher.cpp:528-708):
+ * fills TrackedKeys::rightIdxs[nL], leftIdxs[nR], estimatedDepth[nL], close[nL] (device-resident;
+ * fetch copies them out).  stats = {Hamming tests, SAD refinements, accepted before the
+ * depth / SAD outlier cut} — the exact figures DESIGN.md's algorithmic-byte formula uses. */
+vslam_status vslam_stereo_match(vslam_matcher* m);
+vslam_status vslam_stereo_fetch(vslam_matcher* m, int32_t* right_idxs, int32_t* left_idxs,
+                                float* estimated_depth, uint8_t* close_flags, int32_t cap_left,
+                                int32_t cap_right, int64_t* stats3);
+vslam_status vslam_matcher_timings(const vslam_matcher* m, const char** names, float* ms,
+                                   int32_t cap, int32_t* n_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -130,3 +130,47 @@ def orb_descriptor(kp, img):
     d = np.zeros(32, np.uint8)
     lib().vo_orb_descriptor(_p(kp), _p(img), img.shape[1], img.shape[0], _p(d))
     return d
+
+
+# ---- matcher -------------------------------------------------------------------
+MPV_DTYPE = np.dtype([("desc", "u1", 32), ("predLx", "<f4"), ("predLy", "<f4"), ("predRx", "<f4"),
+                      ("predRy", "<f4"), ("scaleLevelL", "<i4"), ("scaleLevelR", "<i4"),
+                      ("inFrame", "u1"), ("inFrameR", "u1"), ("_pad", "u1", 2)])
+assert MPV_DTYPE.itemsize == 60
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return int(lib().vo_descriptor_distance(_p(a), _p(b)))
+
+
+def stereo_match(exL, exR, rig, kpsL, descL, kpsR, descR):
+    """findStereoMatchesORB2R on the pyramids exL/exR hold from their last extract()."""
+    kpsL = np.ascontiguousarray(kpsL, KP_DTYPE); kpsR = np.ascontiguousarray(kpsR, KP_DTYPE)
+    descL = np.ascontiguousarray(descL, np.uint8); descR = np.ascontiguousarray(descR, np.uint8)
+    nL, nR = len(kpsL), len(kpsR)
+    rightIdxs = np.full(max(nL, 1), -1, np.int32); leftIdxs = np.full(max(nR, 1), -1, np.int32)
+    depth = np.full(max(nL, 1), -1, np.float32); close = np.zeros(max(nL, 1), np.uint8)
+    stats = np.zeros(3, np.int64)
+    lib().vo_stereo_match(exL.h, exR.h, C.c_double(rig["fx"]), C.c_double(rig["fy"]), C.c_double(rig["cx"]),
+                          C.c_double(rig["cy"]), C.c_float(rig["bl"]), rig["w"], rig["h"], _p(kpsL), _p(descL), nL,
+                          _p(kpsR), _p(descR), nR, _p(rightIdxs), _p(leftIdxs), _p(depth), _p(close), _p(stats))
+    return dict(rightIdxs=rightIdxs[:nL], leftIdxs=leftIdxs[:nR], depth=depth[:nL], close=close[:nL],
+                candidates=int(stats[0]), sad=int(stats[1]), matches=int(stats[2]))
+
+
+def match_projection(exL, rig, mps, kpsL, descL, kpsR, descR, rightIdxs, leftIdxs, matchedL, matchedR, matches, rad):
+    """matchByProjectionRPred; matchedL/matchedR/matches are updated copies."""
+    mps = np.ascontiguousarray(mps, MPV_DTYPE)
+    kpsL = np.ascontiguousarray(kpsL, KP_DTYPE); kpsR = np.ascontiguousarray(kpsR, KP_DTYPE)
+    descL = np.ascontiguousarray(descL, np.uint8); descR = np.ascontiguousarray(descR, np.uint8)
+    rightIdxs = np.ascontiguousarray(rightIdxs, np.int32); leftIdxs = np.ascontiguousarray(leftIdxs, np.int32)
+    mL = np.array(matchedL, np.int32, copy=True); mR = np.array(matchedR, np.int32, copy=True)
+    mt = np.array(matches, np.int32, copy=True).reshape(-1, 2)
+    nc = C.c_longlong()
+    lib().vo_match_projection.restype = C.c_int
+    n = lib().vo_match_projection(exL.h, rig["w"], rig["h"], _p(mps), len(mps), _p(kpsL), _p(descL), len(kpsL),
+                                  _p(kpsR), _p(descR), len(kpsR), _p(rightIdxs), _p(leftIdxs), _p(mL), _p(mR),
+                                  _p(mt), C.c_float(rad), C.byref(nc))
+    return n, mL, mR, mt, nc.value

@@ -106,3 +106,60 @@ int vo_ssc(void* h, const KeyPoint* in, int n, int numRet, float tol, int cols, 
 }
 
 }  // extern "C"
+
+// ---- matcher ------------------------------------------------------------------
+#include "vo_match.hpp"
+extern "C" {
+
+int vo_descriptor_distance(const uint8_t* a, const uint8_t* b) { return descriptorDistance(a, b); }
+
+// findStereoMatchesORB2R on the pyramids the two extractors hold from their last extract().
+// stats[3] = {hamming candidates, SAD refinements, pre-filter matches}
+void vo_stereo_match(void* hL, void* hR, double fx, double fy, double cx, double cy, float baseline,
+                     int width, int height, const KeyPoint* kpsL, const uint8_t* descL, int nL,
+                     const KeyPoint* kpsR, const uint8_t* descR, int nR, int* rightIdxs, int* leftIdxs,
+                     float* depth, uint8_t* close, long long* stats) {
+    Extractor* eL = (Extractor*)hL;
+    Extractor* eR = (Extractor*)hR;
+    Rig rig{fx, fy, cx, cy, baseline, width, height};
+    TrackedKeys k;
+    k.keyPoints.assign(kpsL, kpsL + nL);
+    k.rightKeyPoints.assign(kpsR, kpsR + nR);
+    k.Desc.assign(descL, descL + (size_t)nL * 32);
+    k.rightDesc.assign(descR, descR + (size_t)nR * 32);
+    StereoStats st;
+    findStereoMatchesORB2R(*eL, *eR, rig, k, &st);
+    for (int i = 0; i < nL; i++) { rightIdxs[i] = k.rightIdxs[i]; depth[i] = k.estimatedDepth[i]; close[i] = k.close[i]; }
+    for (int i = 0; i < nR; i++) leftIdxs[i] = k.leftIdxs[i];
+    if (stats) { stats[0] = st.candidates; stats[1] = st.sadRefinements; stats[2] = st.matches; }
+}
+
+// matchByProjectionRPred.  mps: M MapPointView records; matchedIdxsL/R and matches (M x 2) are in/out.
+int vo_match_projection(void* hL, int width, int height, const MapPointView* mps, int M,
+                        const KeyPoint* kpsL, const uint8_t* descL, int nL, const KeyPoint* kpsR,
+                        const uint8_t* descR, int nR, const int* rightIdxs, const int* leftIdxs,
+                        int* matchedIdxsL, int* matchedIdxsR, int* matches, float rad, long long* nCand) {
+    Extractor* eL = (Extractor*)hL;
+    TrackedKeys k;
+    k.keyPoints.assign(kpsL, kpsL + nL);
+    k.rightKeyPoints.assign(kpsR, kpsR + nR);
+    k.Desc.assign(descL, descL + (size_t)nL * 32);
+    k.rightDesc.assign(descR, descR + (size_t)nR * 32);
+    k.rightIdxs.assign(rightIdxs, rightIdxs + nL);
+    k.leftIdxs.assign(leftIdxs, leftIdxs + nR);
+    assignKeysToGrids(k, k.keyPoints, k.lkeyGrid, width, height);
+    assignKeysToGrids(k, k.rightKeyPoints, k.rkeyGrid, width, height);
+    std::vector<MapPointView> v(mps, mps + M);
+    std::vector<int> mL(matchedIdxsL, matchedIdxsL + nL), mR(matchedIdxsR, matchedIdxsR + nR);
+    std::vector<std::pair<int, int>> mi(M);
+    for (int i = 0; i < M; i++) mi[i] = {matches[2 * i], matches[2 * i + 1]};
+    long long nc = 0;
+    int n = matchByProjectionRPred(*eL, v, k, mL, mR, mi, rad, &nc);
+    for (int i = 0; i < nL; i++) matchedIdxsL[i] = mL[i];
+    for (int i = 0; i < nR; i++) matchedIdxsR[i] = mR[i];
+    for (int i = 0; i < M; i++) { matches[2 * i] = mi[i].first; matches[2 * i + 1] = mi[i].second; }
+    if (nCand) *nCand = nc;
+    return n;
+}
+
+}  // extern "C"
