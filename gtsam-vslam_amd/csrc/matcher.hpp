@@ -34,6 +34,18 @@ struct vslam_matcher {
     unsigned long long* d_stats = nullptr;   // 4 counters
     bool stereoDone = false;
 
+    // matchByProjectionRPred buffers
+    int projCap = 0;             // map-point capacity
+    vslam_mappoint_view* d_mpv = nullptr;
+    unsigned long long* d_topk = nullptr;   // [M][2][PROJ_K] sorted candidate keys
+    int* d_matches = nullptr;    // [M][2]
+    int* d_matchedL = nullptr;   // [cap]
+    int* d_matchedR = nullptr;
+    int* d_projOut = nullptr;    // {nMatches}
+    vslam_status ensure_proj_cap(int M);
+    vslam_status match_projection(const vslam_mappoint_view* mps, int M, float rad, int* mL, int* mR,
+                                  int* matches, int* nMatches, long long* nCand);
+
     vslam_status init(const vslam_rig* r, vslam_extractor* l, int il, vslam_extractor* rr, int ir);
     void release();
     vslam_status ensure_cap(int n);
@@ -59,4 +71,16 @@ void launch_stereo_match(hipStream_t s, const StereoArgs& A, int* mBest, float* 
 void launch_stereo_finalize(hipStream_t s, int nL, int nR, const int* mBest, const float* mDepth,
                             const int* mSad, float closeDepth, int* rightIdxs, int* leftIdxs,
                             float* depth, uint8_t* close);
+constexpr int PROJ_K = 8;
+struct ProjArgs {
+    const vslam_keypoint* kps[2]; const uint8_t* desc[2]; int n[2];
+    const vslam_mappoint_view* mpv; int M;
+    float rad; float scalePyr[MAX_LEVELS];
+    float xMult, yMult; int xGrids, yGrids;
+    const int* rightIdxs; const int* leftIdxs;
+};
+void launch_proj_candidates(hipStream_t s, const ProjArgs& A, const int* matches,
+                            unsigned long long* topk, unsigned long long* stats);
+void launch_proj_resolve(hipStream_t s, const ProjArgs& A, const unsigned long long* topk,
+                         int* matchedL, int* matchedR, int* matches, int* out);
 }  // namespace vslam

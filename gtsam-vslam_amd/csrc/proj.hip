@@ -1,0 +1,321 @@
+// Map-point -> frame matching by projection (K8): reference FeatureMatcher::matchByProjectionRPred
+// (src/FeatureMatcher.cpp:254-389) with getMatchIdxs (:13-64) and the tracker's
+// assignKeysToGrids (src/FeatureTracker.cpp:28-54).
+//
+// The reference walks the map points in order; each one scans the grid cells around its predicted
+// position (cells row-major, keypoints inside a cell in index order), keeps the best / second-best
+// Hamming distance among keypoints NOT yet claimed, and on success claims the keypoint and its
+// stereo partner.  best / second = the two lexicographically smallest (distance, visit position)
+// among unclaimed candidates, so the work splits into
+//   k_proj_candidates  (parallel, one wave per map point and side): the PROJ_K smallest
+//                      (distance, cell, index) keys over ALL candidates, claims ignored;
+//   k_proj_resolve     (one wave, map points in order): first two unclaimed entries of each list,
+//                      the accept rules, and the claims — claim tables live in LDS.  If a full list
+//                      holds fewer than two unclaimed entries the wave rescans that side with the
+//                      claims applied, so the result is exact for any input.
+// No grid lists are built: a keypoint's cell follows from its coordinates, and visit order inside
+// the window is (cell row, cell col, index).
+#include "matcher.hpp"
+
+namespace vslam {
+
+__device__ __forceinline__ int p_cvFloor(float v) { int i = (int)v; return i - (i > v); }
+__device__ __forceinline__ int p_cvCeil(float v) { int i = (int)v; return i + (i < v); }
+
+constexpr unsigned long long KEY_NONE = ~0ull;
+// key = dist << 36 | cell << 24 | idx << 8 | octave   (idx unique => octave never decides order)
+__device__ __forceinline__ unsigned long long make_key(int dist, int cell, int idx, int oct) {
+    return ((unsigned long long)dist << 36) | ((unsigned long long)cell << 24) |
+           ((unsigned long long)idx << 8) | (unsigned long long)(oct & 0xff);
+}
+__device__ __forceinline__ int key_dist(unsigned long long k) { return (int)(k >> 36); }
+__device__ __forceinline__ int key_idx(unsigned long long k) { return (int)((k >> 8) & 0xffff); }
+__device__ __forceinline__ int key_oct(unsigned long long k) { return (int)(k & 0xff); }
+
+template <int K>
+__device__ __forceinline__ void insert_sorted(unsigned long long (&a)[K], unsigned long long key) {
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        if (key < a[j]) { const unsigned long long t = a[j]; a[j] = key; key = t; }
+    }
+}
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = __shfl_xor(v, d);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// Scan one side for one map point; returns the K smallest keys (wave-uniform) in out[].
+// `claimed` (may be null) = claim table to respect.  Returns the number of Hamming tests.
+template <int K>
+__device__ int scan_side(const ProjArgs& A, int side, const uint32_t (&md)[8], float px, float py,
+                         int predScale, const int* claimed, unsigned long long (&out)[K]) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long top[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) top[j] = KEY_NONE;
+    int tests = 0;
+    const float radius = A.scalePyr[predScale] * A.rad;
+    const int minX = max(0, p_cvFloor((px - radius) * A.xMult));
+    const int maxX = min(A.xGrids - 1, p_cvCeil((px + radius) * A.xMult));
+    const int minY = max(0, p_cvFloor((py - radius) * A.yMult));
+    const int maxY = min(A.yGrids - 1, p_cvCeil((py + radius) * A.yMult));
+    const bool any = !(minX >= A.xGrids || minY >= A.yGrids || maxX < 0 || maxY < 0);
+    if (any) {
+        const vslam_keypoint* kps = A.kps[side];
+        const uint8_t* desc = A.desc[side];
+        const int n = A.n[side];
+        for (int idx = lane; idx < n; idx += 64) {
+            const float kx = kps[idx].x, ky = kps[idx].y;
+            int cx = __float2int_rn(kx * A.xMult), cy = __float2int_rn(ky * A.yMult);
+            cx = cx < 0 ? 0 : (cx >= A.xGrids ? A.xGrids - 1 : cx);
+            cy = cy < 0 ? 0 : (cy >= A.yGrids ? A.yGrids - 1 : cy);
+            if (cx < minX || cx > maxX || cy < minY || cy > maxY) continue;
+            const int oct = kps[idx].octave;
+            if (oct > predScale + 1 || oct < predScale - 1) continue;
+            if (!(fabsf(kx - px) < radius && fabsf(ky - py) < radius)) continue;
+            if (claimed && claimed[idx] >= 0) continue;
+            const uint4* pr = (const uint4*)(desc + (size_t)idx * 32);
+            const uint4 r0 = pr[0], r1 = pr[1];
+            const int dist = __popc(md[0] ^ r0.x) + __popc(md[1] ^ r0.y) + __popc(md[2] ^ r0.z) +
+                             __popc(md[3] ^ r0.w) + __popc(md[4] ^ r1.x) + __popc(md[5] ^ r1.y) +
+                             __popc(md[6] ^ r1.z) + __popc(md[7] ^ r1.w);
+            tests++;
+            insert_sorted<K>(top, make_key(dist, cy * A.xGrids + cx, idx, oct));
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < K; r++) {
+        const unsigned long long head = top[0];
+        const unsigned long long m = wave_min_u64(head);
+        out[r] = m;
+        if (head == m && m != KEY_NONE) {
+#pragma unroll
+            for (int j = 0; j + 1 < K; j++) top[j] = top[j + 1];
+            top[K - 1] = KEY_NONE;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) tests += __shfl_xor(tests, d);
+    return tests;
+}
+
+__device__ __forceinline__ void load_mp_desc(const vslam_mappoint_view* mp, uint32_t (&md)[8]) {
+    const uint32_t* p = (const uint32_t*)mp->desc;   // view is 4-byte aligned (60-byte records)
+#pragma unroll
+    for (int k = 0; k < 8; k++) md[k] = p[k];
+}
+
+__global__ __launch_bounds__(256) void k_proj_candidates(ProjArgs A, const int* __restrict__ matches,
+                                                         unsigned long long* __restrict__ topk,
+                                                         unsigned long long* __restrict__ stats) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int job = blockIdx.x * 4 + wave;      // job = mp * 2 + side
+    if (job >= 2 * A.M) return;
+    const int i = job >> 1, side = job & 1;
+    unsigned long long out[PROJ_K];
+#pragma unroll
+    for (int j = 0; j < PROJ_K; j++) out[j] = KEY_NONE;
+    const vslam_mappoint_view* mp = A.mpv + i;
+    const bool skip = matches[2 * i] >= 0 || matches[2 * i + 1] >= 0;
+    const bool inF = side ? mp->in_frame_r : mp->in_frame;
+    int tests = 0;
+    if (!skip && inF) {
+        uint32_t md[8];
+        load_mp_desc(mp, md);
+        const float px = side ? mp->pred_rx : mp->pred_lx, py = side ? mp->pred_ry : mp->pred_ly;
+        const int ps = side ? mp->scale_level_r : mp->scale_level_l;
+        tests = scan_side<PROJ_K>(A, side, md, px, py, ps, nullptr, out);
+    }
+    if (lane < PROJ_K) {
+        unsigned long long v = out[0];
+#pragma unroll
+        for (int j = 1; j < PROJ_K; j++) v = lane == j ? out[j] : v;
+        topk[(size_t)job * PROJ_K + lane] = v;
+    }
+    if (lane == 0 && tests) atomicAdd(&stats[3], (unsigned long long)tests);
+}
+
+void launch_proj_candidates(hipStream_t s, const ProjArgs& A, const int* matches,
+                            unsigned long long* topk, unsigned long long* stats) {
+    if (A.M <= 0) return;
+    hipLaunchKernelGGL(k_proj_candidates, dim3((2 * A.M + 3) / 4), dim3(256), 0, s, A, matches, topk, stats);
+}
+
+// One wave walks the map points in order (the greedy claims are sequential by definition).
+__global__ __launch_bounds__(64) void k_proj_resolve(ProjArgs A, const unsigned long long* __restrict__ topk,
+                                                     int* __restrict__ matchedL, int* __restrict__ matchedR,
+                                                     int* __restrict__ matches, int* __restrict__ outp) {
+    extern __shared__ int claims[];
+    int* cl = claims;
+    int* cr = claims + A.n[0];
+    const int lane = threadIdx.x;
+    for (int k = lane; k < A.n[0]; k += 64) cl[k] = matchedL[k];
+    for (int k = lane; k < A.n[1]; k += 64) cr[k] = matchedR[k];
+    __syncthreads();
+    int nMatches = 0;
+    const int matchDistProj = 100;      // include/FeatureMatcher.h:27
+    const float ratioProj = 0.8f;       // include/FeatureMatcher.h:28
+    for (int i = 0; i < A.M; i++) {
+        if (matches[2 * i] >= 0 || matches[2 * i + 1] >= 0) continue;
+        const int side = lane >= PROJ_K ? 1 : 0;
+        unsigned long long key = KEY_NONE;
+        if (lane < 2 * PROJ_K) key = topk[((size_t)i * 2 + side) * PROJ_K + (lane - side * PROJ_K)];
+        const bool valid = key != KEY_NONE;
+        bool fre = false;
+        if (valid) fre = (side ? cr[key_idx(key)] : cl[key_idx(key)]) < 0;
+        const unsigned long long vmask = __ballot(valid), fmask = __ballot(fre);
+        unsigned long long b1k[2], b2k[2];
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const unsigned vm = (unsigned)((vmask >> (s * PROJ_K)) & ((1u << PROJ_K) - 1));
+            unsigned fm = (unsigned)((fmask >> (s * PROJ_K)) & ((1u << PROJ_K) - 1));
+            const bool full = vm == ((1u << PROJ_K) - 1);
+            if (full && __popc(fm) < 2) {
+                // rare: rescan this side with the claims applied
+                const vslam_mappoint_view* mp = A.mpv + i;
+                uint32_t md[8];
+                load_mp_desc(mp, md);
+                unsigned long long o2[2] = {KEY_NONE, KEY_NONE};
+                const float px = s ? mp->pred_rx : mp->pred_lx, py = s ? mp->pred_ry : mp->pred_ly;
+                const int ps = s ? mp->scale_level_r : mp->scale_level_l;
+                scan_side<2>(A, s, md, px, py, ps, s ? cr : cl, o2);
+                b1k[s] = o2[0];
+                b2k[s] = o2[1];
+            } else {
+                int l1 = -1, l2 = -1;
+                if (fm) { l1 = __ffs(fm) - 1; fm &= fm - 1; }
+                if (fm) { l2 = __ffs(fm) - 1; }
+                const unsigned long long k1 = __shfl(key, (l1 < 0 ? 0 : l1) + s * PROJ_K);
+                const unsigned long long k2 = __shfl(key, (l2 < 0 ? 0 : l2) + s * PROJ_K);
+                b1k[s] = l1 < 0 ? KEY_NONE : k1;
+                b2k[s] = l2 < 0 ? KEY_NONE : k2;
+            }
+        }
+        int bestDist = 256, bestIdx = -1, bestLev = -1, bestLev2 = -1, secDist = 256;
+        if (b1k[0] != KEY_NONE) { bestDist = key_dist(b1k[0]); bestIdx = key_idx(b1k[0]); bestLev = key_oct(b1k[0]); }
+        if (b2k[0] != KEY_NONE) { secDist = key_dist(b2k[0]); bestLev2 = key_oct(b2k[0]); }
+        int bestDistR = 256, bestIdxR = -1, bestLevR = -1, bestLevR2 = -1, secDistR = 256;
+        if (b1k[1] != KEY_NONE) { bestDistR = key_dist(b1k[1]); bestIdxR = key_idx(b1k[1]); bestLevR = key_oct(b1k[1]); }
+        if (b2k[1] != KEY_NONE) { secDistR = key_dist(b2k[1]); bestLevR2 = key_oct(b2k[1]); }
+        // a distance of 256 never replaces the initial 256 in the reference's strict "<" scan,
+        // and with no second candidate the reference leaves secDist = 256, bestLev2 = -1
+        if (bestDist >= 256) { bestDist = 256; bestIdx = -1; bestLev = -1; }
+        if (secDist >= 256) { secDist = 256; bestLev2 = -1; }
+        if (bestDistR >= 256) { bestDistR = 256; bestIdxR = -1; bestLevR = -1; }
+        if (secDistR >= 256) { secDistR = 256; bestLevR2 = -1; }
+        bool right = false;
+        if (bestDist > bestDistR) {
+            bestDist = bestDistR; secDist = secDistR; bestLev = bestLevR; bestLev2 = bestLevR2;
+            right = true;
+        }
+        if (bestDist > matchDistProj) continue;
+        if (bestLev == bestLev2 && (float)bestDist >= ratioProj * (float)secDist) continue;
+        nMatches++;
+        if (lane == 0) {
+            if (right) {
+                cr[bestIdxR] = i;
+                matches[2 * i + 1] = bestIdxR;
+                const int l = A.leftIdxs[bestIdxR];
+                if (l >= 0) { matches[2 * i] = l; cl[l] = i; }
+            } else {
+                cl[bestIdx] = i;
+                matches[2 * i] = bestIdx;
+                const int r = A.rightIdxs[bestIdx];
+                if (r >= 0) { matches[2 * i + 1] = r; cr[r] = i; }
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int k = lane; k < A.n[0]; k += 64) matchedL[k] = cl[k];
+    for (int k = lane; k < A.n[1]; k += 64) matchedR[k] = cr[k];
+    if (lane == 0) outp[0] = nMatches;
+}
+
+void launch_proj_resolve(hipStream_t s, const ProjArgs& A, const unsigned long long* topk,
+                         int* matchedL, int* matchedR, int* matches, int* out) {
+    const size_t sh = (size_t)(A.n[0] + A.n[1] + 1) * sizeof(int);
+    hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(64), sh, s, A, topk, matchedL, matchedR, matches, out);
+}
+
+}  // namespace vslam
+
+using namespace vslam;
+
+vslam_status vslam_matcher::ensure_proj_cap(int M) {
+    if (M <= projCap && d_matchedL) return VSLAM_OK;
+    if (M > projCap) {
+        hipFree(d_mpv); hipFree(d_topk); hipFree(d_matches);
+        projCap = vslam::align_up(std::max(M, 1), 1024);
+        VS_HIP(hipMalloc(&d_mpv, (size_t)projCap * sizeof(vslam_mappoint_view)));
+        VS_HIP(hipMalloc(&d_topk, (size_t)projCap * 2 * PROJ_K * sizeof(unsigned long long)));
+        VS_HIP(hipMalloc(&d_matches, (size_t)projCap * 2 * sizeof(int)));
+    }
+    if (!d_projOut) VS_HIP(hipMalloc(&d_projOut, 4 * sizeof(int)));
+    return VSLAM_OK;
+}
+
+vslam_status vslam_matcher::match_projection(const vslam_mappoint_view* mps, int M, float rad, int* mL,
+                                             int* mR, int* matches, int* nMatches, long long* nCand) {
+    if (M < 0 || (M > 0 && (!mps || !matches)) || !mL || !mR) { set_error("match_projection: bad argument"); return VSLAM_ERR_INVALID; }
+    if (!stereoDone) { set_error("match_projection needs a completed stereo match"); return VSLAM_ERR_INVALID; }
+    VS_HIP(hipSetDevice(device));
+    VS_CHECK(refresh_keys());
+    VS_CHECK(ensure_proj_cap(M));
+    const int nL = nKeys[0], nR = nKeys[1];
+    if (!d_matchedL) {
+        VS_HIP(hipMalloc(&d_matchedL, (size_t)65536 * sizeof(int)));
+        VS_HIP(hipMalloc(&d_matchedR, (size_t)65536 * sizeof(int)));
+    }
+    if (M) {
+        VS_HIP(hipMemcpyAsync(d_mpv, mps, (size_t)M * sizeof(vslam_mappoint_view), hipMemcpyHostToDevice, stream));
+        VS_HIP(hipMemcpyAsync(d_matches, matches, (size_t)M * 2 * sizeof(int), hipMemcpyHostToDevice, stream));
+    }
+    if (nL) VS_HIP(hipMemcpyAsync(d_matchedL, mL, (size_t)nL * sizeof(int), hipMemcpyHostToDevice, stream));
+    if (nR) VS_HIP(hipMemcpyAsync(d_matchedR, mR, (size_t)nR * sizeof(int), hipMemcpyHostToDevice, stream));
+    ProjArgs A{};
+    for (int s = 0; s < 2; s++) { A.kps[s] = d_kps[s]; A.desc[s] = d_desc[s]; A.n[s] = nKeys[s]; }
+    A.mpv = d_mpv; A.M = M; A.rad = rad;
+    for (int l = 0; l < feL->nLevels; l++) A.scalePyr[l] = feL->scalePyramid[l];
+    // assignKeysToGrids geometry (src/FeatureTracker.cpp:30-35)
+    const float imageRatio = (float)rig.width / (float)rig.height;
+    A.xGrids = 64;
+    A.yGrids = cv_ceil_f((float)A.xGrids / imageRatio);
+    A.xMult = (float)A.xGrids / (float)rig.width;
+    A.yMult = (float)A.yGrids / (float)rig.height;
+    A.rightIdxs = d_rightIdxs; A.leftIdxs = d_leftIdxs;
+    VS_HIP(hipMemsetAsync(d_stats + 3, 0, sizeof(unsigned long long), stream));
+    int t = timer.begin("proj_candidates");
+    launch_proj_candidates(stream, A, d_matches, d_topk, d_stats);
+    timer.end(t);
+    t = timer.begin("proj_resolve");
+    launch_proj_resolve(stream, A, d_topk, d_matchedL, d_matchedR, d_matches, d_projOut);
+    timer.end(t);
+    VS_HIP(hipGetLastError());
+    int out = 0;
+    unsigned long long nc = 0;
+    if (M) VS_HIP(hipMemcpyAsync(matches, d_matches, (size_t)M * 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
+    if (nL) VS_HIP(hipMemcpyAsync(mL, d_matchedL, (size_t)nL * sizeof(int), hipMemcpyDeviceToHost, stream));
+    if (nR) VS_HIP(hipMemcpyAsync(mR, d_matchedR, (size_t)nR * sizeof(int), hipMemcpyDeviceToHost, stream));
+    VS_HIP(hipMemcpyAsync(&out, d_projOut, sizeof(int), hipMemcpyDeviceToHost, stream));
+    VS_HIP(hipMemcpyAsync(&nc, d_stats + 3, sizeof(nc), hipMemcpyDeviceToHost, stream));
+    VS_HIP(hipStreamSynchronize(stream));
+    if (nMatches) *nMatches = out;
+    if (nCand) *nCand = (long long)nc;
+    return VSLAM_OK;
+}
+
+extern "C" vslam_status vslam_match_projection(vslam_matcher* m, const vslam_mappoint_view* mps, int32_t n_mps,
+                                               float rad, int32_t* matched_idxs_l, int32_t* matched_idxs_r,
+                                               int32_t* matches, int32_t* n_matches, int64_t* n_candidates) {
+    if (!m) return VSLAM_ERR_INVALID;
+    long long nc = 0;
+    vslam_status s = m->match_projection(mps, n_mps, rad, matched_idxs_l, matched_idxs_r, matches, n_matches, &nc);
+    if (n_candidates) *n_candidates = nc;
+    return s;
+}

@@ -195,3 +195,26 @@ class Matcher:
         n = C.c_int32()
         _chk(self.L.vslam_matcher_timings(self.h, names, ms, 32, C.byref(n)))
         return {names[i].decode(): float(ms[i]) for i in range(n.value)}
+
+
+MPV_DTYPE = np.dtype([("desc", "u1", 32), ("predLx", "<f4"), ("predLy", "<f4"), ("predRx", "<f4"),
+                      ("predRy", "<f4"), ("scaleLevelL", "<i4"), ("scaleLevelR", "<i4"),
+                      ("inFrame", "u1"), ("inFrameR", "u1"), ("_pad", "u1", 2)])
+assert MPV_DTYPE.itemsize == 60
+
+
+def match_projection(matcher, mps, rad, matchedL, matchedR, matches):
+    """matchByProjectionRPred through the C ABI; returns (n, matchedL, matchedR, matches, ncand)."""
+    mps = np.ascontiguousarray(mps, MPV_DTYPE)
+    mL = np.array(matchedL, np.int32, copy=True)
+    mR = np.array(matchedR, np.int32, copy=True)
+    mt = np.array(matches, np.int32, copy=True).reshape(-1, 2)
+    if len(mL) == 0:
+        mL = np.full(1, -1, np.int32)
+    if len(mR) == 0:
+        mR = np.full(1, -1, np.int32)
+    n = C.c_int32()
+    nc = C.c_int64()
+    _chk(matcher.L.vslam_match_projection(matcher.h, _p(mps), len(mps), C.c_float(rad), _p(mL), _p(mR), _p(mt),
+                                          C.byref(n), C.byref(nc)))
+    return n.value, mL[:len(matchedL)], mR[:len(matchedR)], mt, nc.value

@@ -146,6 +146,26 @@ vslam_status vslam_stereo_match(vslam_matcher* m);
 vslam_status vslam_stereo_fetch(vslam_matcher* m, int32_t* right_idxs, int32_t* left_idxs,
                                 float* estimated_depth, uint8_t* close_flags, int32_t cap_left,
                                 int32_t cap_right, int64_t* stats3);
+
+/* matchByProjectionRPred (include/FeatureMatcher.h:57, src/FeatureMatcher.cpp:254-389).
+ * vslam_mappoint_view flattens the MapPoint fields that function reads (desc, predL/predR,
+ * scaleLevelL/R, inFrame/inFrameR — include/Map.h).  Map points are processed in array order
+ * and claim keypoints greedily exactly like the reference loop.
+ *   matched_idxs_l[nL], matched_idxs_r[nR]  in/out  claim tables (-1 = free)
+ *   matches[M][2]                           in/out  (left idx, right idx) per map point
+ * The call needs a completed vslam_stereo_match (it reads rightIdxs / leftIdxs). */
+typedef struct vslam_mappoint_view {
+    uint8_t desc[32];
+    float pred_lx, pred_ly, pred_rx, pred_ry;
+    int32_t scale_level_l, scale_level_r;
+    uint8_t in_frame, in_frame_r;
+    uint8_t pad_[2];
+} vslam_mappoint_view;
+
+vslam_status vslam_match_projection(vslam_matcher* m, const vslam_mappoint_view* mps, int32_t n_mps,
+                                    float rad, int32_t* matched_idxs_l, int32_t* matched_idxs_r,
+                                    int32_t* matches, int32_t* n_matches, int64_t* n_candidates);
+
 vslam_status vslam_matcher_timings(const vslam_matcher* m, const char** names, float* ms,
                                    int32_t cap, int32_t* n_out);
 
