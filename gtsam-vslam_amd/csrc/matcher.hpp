@@ -46,6 +46,17 @@ struct vslam_matcher {
     vslam_status match_projection(const vslam_mappoint_view* mps, int M, float rad, int* mL, int* mR,
                                   int* matches, int* nMatches, long long* nCand);
 
+    // pose-only LM buffers
+    int poseCap = 0;
+    double* d_points = nullptr;      // [M][3]
+    uint8_t* d_flags = nullptr;      // [4][M]: inFrame, inFrameR, mpIsOutlier, MPsOutliers
+    double* d_factors = nullptr;     // [M][8]: type, p[3], z[3], invSigma
+    int* d_firstFail = nullptr;      // [cap]
+    double* d_poseIO = nullptr;      // 16 T_cw + report(8)
+    int* d_poseOut = nullptr;        // nIn, nStereo, iterations, inner
+    vslam_status ensure_pose_cap(int M);
+    vslam_status estimate_pose(vslam_pose_problem* prob, int* nIn, int* nStereo, vslam_lm_report* rep);
+
     vslam_status init(const vslam_rig* r, vslam_extractor* l, int il, vslam_extractor* rr, int ir);
     void release();
     vslam_status ensure_cap(int n);

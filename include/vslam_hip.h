@@ -166,6 +166,43 @@ vslam_status vslam_match_projection(vslam_matcher* m, const vslam_mappoint_view*
                                     float rad, int32_t* matched_idxs_l, int32_t* matched_idxs_r,
                                     int32_t* matches, int32_t* n_matches, int64_t* n_candidates);
 
+/* ---------------------------------------------------------------------------
+ * Tracker steps — replace FeatureTracker::estimatePoseGTSAM (stereo-only branch) with
+ * findOutliersR / check2dError (include/FeatureTracker.h, src/FeatureTracker.cpp:147-411,
+ * 582-649) and worldToFrame + MapPoint::predictScale (src/FeatureTracker.cpp:685-741,
+ * src/Map.cpp:13-23).  They act on the frame the matcher currently holds (keypoints, close,
+ * rightIdxs/leftIdxs/estimatedDepth in HBM) and mutate it exactly like the reference.
+ * ------------------------------------------------------------------------- */
+typedef struct vslam_lm_report {
+    int32_t iterations;        /* accepted outer iterations */
+    int32_t inner_iterations;  /* lambda trials */
+    double initial_error, final_error, lambda;
+} vslam_lm_report;
+
+typedef struct vslam_pose_problem {
+    int32_t n_mps;                 /* active map points */
+    const double* points_xyz;      /* n x 3 world positions (MapPoint::getWordPose3d) */
+    const uint8_t* in_frame;       /* MapPoint::inFrame / inFrameR / GetIsOutlier */
+    const uint8_t* in_frame_r;
+    const uint8_t* mp_is_outlier;
+    int32_t* matches;              /* n x 2 matchesIdxs, in/out */
+    uint8_t* mps_outliers;         /* n MPsOutliers, in/out */
+    double T_cw[16];               /* estimPose (camera <- world), row-major, in/out */
+} vslam_pose_problem;
+
+/* Motion-only LM (GTSAM 4.2 LevenbergMarquardt policy, 100 iterations max) in one kernel launch,
+ * then the chi2 (7.815) inlier pass.  n_inliers / n_stereo = the pair estimatePoseGTSAM returns. */
+vslam_status vslam_estimate_pose(vslam_matcher* m, vslam_pose_problem* prob, int32_t* n_inliers,
+                                 int32_t* n_stereo, vslam_lm_report* report);
+
+/* worldToFrame for n points and both cameras with pose T_cw: fills pred_l/pred_r (n x 2 floats),
+ * scale_level_l/r, in_frame/in_frame_r.  log_scale = KeyFrame::logScale (float log(imScale)). */
+vslam_status vslam_world_to_frame(vslam_matcher* m, const double* T_cw, int32_t n,
+                                  const double* points_xyz, const float* max_scale_dist,
+                                  float log_scale, float* pred_l, float* pred_r,
+                                  int32_t* scale_level_l, int32_t* scale_level_r,
+                                  uint8_t* in_frame, uint8_t* in_frame_r);
+
 vslam_status vslam_matcher_timings(const vslam_matcher* m, const char** names, float* ms,
                                    int32_t cap, int32_t* n_out);
 

@@ -174,3 +174,51 @@ def match_projection(exL, rig, mps, kpsL, descL, kpsR, descR, rightIdxs, leftIdx
                                   _p(kpsR), _p(descR), len(kpsR), _p(rightIdxs), _p(leftIdxs), _p(mL), _p(mR),
                                   _p(mt), C.c_float(rad), C.byref(nc))
     return n, mL, mR, mt, nc.value
+
+
+# ---- pose-only optimisation ------------------------------------------------------------
+def estimate_pose(rig, inv_sigma, points, in_frame, in_frame_r, mp_is_outlier, matches, mps_outliers,
+                  kpsL, kpsR, rightIdxs, leftIdxs, depth, close, T_cw):
+    """estimatePoseGTSAM (stereo-only) + findOutliersR.  Returns dict of the mutated state."""
+    M = len(points)
+    points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    inF = np.ascontiguousarray(in_frame, np.uint8); inFR = np.ascontiguousarray(in_frame_r, np.uint8)
+    mpo = np.ascontiguousarray(mp_is_outlier, np.uint8)
+    mt = np.array(matches, np.int32, copy=True).reshape(-1, 2)
+    out = np.array(mps_outliers, np.uint8, copy=True)
+    kpsL = np.ascontiguousarray(kpsL, KP_DTYPE); kpsR = np.ascontiguousarray(kpsR, KP_DTYPE)
+    ri = np.array(rightIdxs, np.int32, copy=True); li = np.array(leftIdxs, np.int32, copy=True)
+    dp = np.array(depth, np.float32, copy=True); cl = np.array(close, np.uint8, copy=True)
+    T = np.array(T_cw, np.float64, copy=True).reshape(4, 4)
+    inv_sigma = np.ascontiguousarray(inv_sigma, np.float32)
+    nIn, nSt = C.c_int(), C.c_int()
+    rep = np.zeros(5, np.float64)
+    lib().vo_estimate_pose(C.c_double(rig["fx"]), C.c_double(rig["fy"]), C.c_double(rig["cx"]), C.c_double(rig["cy"]),
+                           C.c_float(rig["bl"]), rig["w"], rig["h"], _p(inv_sigma), M, _p(points), _p(inF), _p(inFR),
+                           _p(mpo), _p(mt), _p(out), _p(kpsL), len(kpsL), _p(kpsR), len(kpsR), _p(ri), _p(li), _p(dp),
+                           _p(cl), _p(T), C.byref(nIn), C.byref(nSt), _p(rep))
+    return dict(T_cw=T, nIn=nIn.value, nStereo=nSt.value, matches=mt, outliers=out, rightIdxs=ri, leftIdxs=li,
+                depth=dp, close=cl, iterations=int(rep[0]), inner=int(rep[1]), initialError=rep[2],
+                finalError=rep[3], lam=rep[4])
+
+
+def world_to_frame(rig, T_cw, right, points, max_scale_dist, log_scale, n_levels=8):
+    points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    M = len(points)
+    msd = np.ascontiguousarray(max_scale_dist, np.float32)
+    T = np.ascontiguousarray(T_cw, np.float64)
+    u = np.zeros(M, np.float32); v = np.zeros(M, np.float32); lvl = np.zeros(M, np.int32); vis = np.zeros(M, np.uint8)
+    lib().vo_world_to_frame(C.c_double(rig["fx"]), C.c_double(rig["fy"]), C.c_double(rig["cx"]), C.c_double(rig["cy"]),
+                            C.c_float(rig["bl"]), rig["w"], rig["h"], _p(T), int(right), M, _p(points), _p(msd),
+                            C.c_float(log_scale), n_levels, _p(u), _p(v), _p(lvl), _p(vis))
+    return u, v, lvl, vis
+
+
+def pose_lm_raw(rig, ftype, p, z, sigma, T_wc):
+    ftype = np.ascontiguousarray(ftype, np.int32); p = np.ascontiguousarray(p, np.float64)
+    z = np.ascontiguousarray(z, np.float64); sigma = np.ascontiguousarray(sigma, np.float64)
+    T = np.array(T_wc, np.float64, copy=True).reshape(4, 4)
+    rep = np.zeros(5, np.float64)
+    lib().vo_pose_lm_raw(C.c_double(rig["fx"]), C.c_double(rig["fy"]), C.c_double(rig["cx"]), C.c_double(rig["cy"]),
+                         C.c_float(rig["bl"]), len(ftype), _p(ftype), _p(p), _p(z), _p(sigma), _p(T), _p(rep))
+    return T, dict(iterations=int(rep[0]), inner=int(rep[1]), initialError=rep[2], finalError=rep[3], lam=rep[4])

@@ -163,3 +163,80 @@ int vo_match_projection(void* hL, int width, int height, const MapPointView* mps
 }
 
 }  // extern "C"
+
+// ---- pose-only optimisation --------------------------------------------------------------
+#include "vo_pose.hpp"
+extern "C" {
+
+// estimatePoseGTSAM (stereo-only mode) + findOutliersR.  T_cw: row-major 4x4 in/out.
+// report[5] = {iterations, innerIterations, initialError, finalError, lambda}
+void vo_estimate_pose(double fx, double fy, double cx, double cy, float baseline, int width, int height,
+                      const float* invSigma, int M, const double* points, const uint8_t* inFrame,
+                      const uint8_t* inFrameR, const uint8_t* mpIsOutlier, int* matches,
+                      uint8_t* MPsOutliers, const KeyPoint* kpsL, int nL, const KeyPoint* kpsR, int nR,
+                      int* rightIdxs, int* leftIdxs, float* depth, uint8_t* close, double* T_cw,
+                      int* nIn, int* nStereo, double* report) {
+    Rig rig{fx, fy, cx, cy, baseline, width, height};
+    TrackFrame tf;
+    tf.points.resize(M); tf.inFrame.assign(inFrame, inFrame + M); tf.inFrameR.assign(inFrameR, inFrameR + M);
+    tf.mpIsOutlier.assign(mpIsOutlier, mpIsOutlier + M); tf.MPsOutliers.assign(MPsOutliers, MPsOutliers + M);
+    tf.matches.resize(M);
+    for (int i = 0; i < M; i++) {
+        for (int k = 0; k < 3; k++) tf.points[i].v[k] = points[3 * i + k];
+        tf.matches[i] = {matches[2 * i], matches[2 * i + 1]};
+    }
+    TrackedKeys k;
+    k.keyPoints.assign(kpsL, kpsL + nL);
+    k.rightKeyPoints.assign(kpsR, kpsR + nR);
+    k.rightIdxs.assign(rightIdxs, rightIdxs + nL);
+    k.leftIdxs.assign(leftIdxs, leftIdxs + nR);
+    k.estimatedDepth.assign(depth, depth + nL);
+    k.close.assign(close, close + nL);
+    Pose T = pose_from_rowmajor16(T_cw);
+    LMReport rep;
+    std::pair<int, int> r = estimatePoseStereo(tf, k, rig, invSigma, T, rep);
+    pose_to_rowmajor16(T, T_cw);
+    *nIn = r.first; *nStereo = r.second;
+    for (int i = 0; i < M; i++) {
+        matches[2 * i] = tf.matches[i].first; matches[2 * i + 1] = tf.matches[i].second;
+        MPsOutliers[i] = tf.MPsOutliers[i];
+    }
+    for (int i = 0; i < nL; i++) { rightIdxs[i] = k.rightIdxs[i]; depth[i] = k.estimatedDepth[i]; close[i] = k.close[i]; }
+    for (int i = 0; i < nR; i++) leftIdxs[i] = k.leftIdxs[i];
+    if (report) { report[0] = rep.iterations; report[1] = rep.innerIterations; report[2] = rep.initialError; report[3] = rep.finalError; report[4] = rep.lambda; }
+}
+
+// worldToFrame for M points and one camera (right = 1 applies the stereo extrinsics);
+// out: u,v (float), scale level, visible flag
+void vo_world_to_frame(double fx, double fy, double cx, double cy, float baseline, int width, int height,
+                       const double* T_cw, int right, int M, const double* points, const float* maxScaleDist,
+                       float logScale, int nScaleLev, float* u, float* v, int* lvl, uint8_t* vis) {
+    Rig rig{fx, fy, cx, cy, baseline, width, height};
+    Pose T = pose_from_rowmajor16(T_cw);
+    if (right) T.t.v[0] -= (double)baseline;   // (T_wc * ext)^-1 = ext^-1 * T_cw
+    for (int i = 0; i < M; i++) {
+        Vec3 p{{points[3 * i], points[3 * i + 1], points[3 * i + 2]}};
+        float uu = 0, vv = 0; int l = 0;
+        vis[i] = worldToFrame(p, T, rig, maxScaleDist[i], (double)logScale, nScaleLev, uu, vv, l);
+        u[i] = uu; v[i] = vv; lvl[i] = l;
+    }
+}
+
+// numeric check helper: whitened residual vector of the pose factors at T_wc (for Jacobian tests)
+int vo_pose_lm_raw(double fx, double fy, double cx, double cy, float baseline, int nf, const int* type,
+                   const double* p, const double* z, const double* sigma, double* T_wc, double* report) {
+    Rig rig{fx, fy, cx, cy, baseline, 0, 0};
+    std::vector<PoseFactor> f(nf);
+    for (int i = 0; i < nf; i++) {
+        f[i].type = type[i]; f[i].sigma = sigma[i];
+        for (int k = 0; k < 3; k++) { f[i].p[k] = p[3 * i + k]; f[i].z[k] = z[3 * i + k]; }
+    }
+    Pose T = pose_from_rowmajor16(T_wc);
+    LMReport rep;
+    poseOnlyLM(f, rig, T, rep);
+    pose_to_rowmajor16(T, T_wc);
+    if (report) { report[0] = rep.iterations; report[1] = rep.innerIterations; report[2] = rep.initialError; report[3] = rep.finalError; report[4] = rep.lambda; }
+    return rep.iterations;
+}
+
+}  // extern "C"
