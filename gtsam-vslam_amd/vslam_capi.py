@@ -218,3 +218,50 @@ def match_projection(matcher, mps, rad, matchedL, matchedR, matches):
     _chk(matcher.L.vslam_match_projection(matcher.h, _p(mps), len(mps), C.c_float(rad), _p(mL), _p(mR), _p(mt),
                                           C.byref(n), C.byref(nc)))
     return n.value, mL[:len(matchedL)], mR[:len(matchedR)], mt, nc.value
+
+
+class LmReport(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("inner_iterations", C.c_int32), ("initial_error", C.c_double),
+                ("final_error", C.c_double), ("lam", C.c_double)]
+
+
+class PoseProblem(C.Structure):
+    _fields_ = [("n_mps", C.c_int32), ("points_xyz", C.c_void_p), ("in_frame", C.c_void_p),
+                ("in_frame_r", C.c_void_p), ("mp_is_outlier", C.c_void_p), ("matches", C.c_void_p),
+                ("mps_outliers", C.c_void_p), ("T_cw", C.c_double * 16)]
+
+
+def estimate_pose(matcher, points, in_frame, in_frame_r, mp_is_outlier, matches, mps_outliers, T_cw):
+    """estimatePoseGTSAM (stereo-only) + findOutliersR on the matcher's current frame."""
+    points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    M = len(points)
+    inF = np.ascontiguousarray(in_frame, np.uint8); inFR = np.ascontiguousarray(in_frame_r, np.uint8)
+    mpo = np.ascontiguousarray(mp_is_outlier, np.uint8)
+    mt = np.array(matches, np.int32, copy=True).reshape(-1, 2)
+    out = np.array(mps_outliers, np.uint8, copy=True)
+    prob = PoseProblem()
+    prob.n_mps = M
+    prob.points_xyz, prob.in_frame, prob.in_frame_r = _p(points), _p(inF), _p(inFR)
+    prob.mp_is_outlier, prob.matches, prob.mps_outliers = _p(mpo), _p(mt), _p(out)
+    T = np.ascontiguousarray(T_cw, np.float64).reshape(16)
+    for i in range(16):
+        prob.T_cw[i] = T[i]
+    nIn, nSt = C.c_int32(), C.c_int32()
+    rep = LmReport()
+    _chk(matcher.L.vslam_estimate_pose(matcher.h, C.byref(prob), C.byref(nIn), C.byref(nSt), C.byref(rep)))
+    Tout = np.array([prob.T_cw[i] for i in range(16)], np.float64).reshape(4, 4)
+    return dict(T_cw=Tout, nIn=nIn.value, nStereo=nSt.value, matches=mt, outliers=out, iterations=rep.iterations,
+                inner=rep.inner_iterations, initialError=rep.initial_error, finalError=rep.final_error, lam=rep.lam)
+
+
+def world_to_frame(matcher, T_cw, points, max_scale_dist, log_scale):
+    points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    n = len(points)
+    msd = np.ascontiguousarray(max_scale_dist, np.float32)
+    T = np.ascontiguousarray(T_cw, np.float64)
+    pl = np.zeros((n, 2), np.float32); pr = np.zeros((n, 2), np.float32)
+    ll = np.zeros(n, np.int32); lr = np.zeros(n, np.int32)
+    vf = np.zeros(n, np.uint8); vr = np.zeros(n, np.uint8)
+    _chk(matcher.L.vslam_world_to_frame(matcher.h, _p(T), n, _p(points), _p(msd), C.c_float(log_scale), _p(pl), _p(pr),
+                                        _p(ll), _p(lr), _p(vf), _p(vr)))
+    return pl, pr, ll, lr, vf, vr
