@@ -65,8 +65,16 @@ def test_pose_lm_parity(oracle, capi, seed, shared):
     assert np.array_equal(st2["rightIdxs"], ref["rightIdxs"]) and np.array_equal(st2["leftIdxs"], ref["leftIdxs"])
     assert np.array_equal(st2["close"], ref["close"])
     assert np.array_equal(st2["depth"].view(np.uint32), ref["depth"].view(np.uint32))
-    # the optimum is the true pose (the inliers are noise-free up to the sub-pixel stereo depth)
-    assert np.abs(np.linalg.inv(ref["T_cw"]) - T_wc).max() < 5e-2
+    # second pass with the flagged outliers excluded (what TrackImage's refine pass does): both
+    # implementations agree again and land on the true pose (no robust kernel in the reference,
+    # so the first pass is biased by the gross outliers on purpose)
+    ref2 = oracle.estimate_pose(rig, oL.InvSigmaFactor, pts, inF, inFR, mpo, ref["matches"], ref["outliers"], kL, kR,
+                                ref["rightIdxs"], ref["leftIdxs"], ref["depth"], ref["close"], ref["T_cw"])
+    got2 = capi.estimate_pose(m, pts, inF, inFR, mpo, got["matches"], got["outliers"], got["T_cw"])
+    assert np.abs(got2["T_cw"] - ref2["T_cw"]).max() < 1e-9
+    assert (got2["nIn"], got2["nStereo"]) == (ref2["nIn"], ref2["nStereo"])
+    assert np.array_equal(got2["outliers"], ref2["outliers"])
+    assert np.abs(np.linalg.inv(ref2["T_cw"]) - T_wc).max() < 2e-2
 
 
 def test_pose_lm_degenerate_inputs(oracle, capi):
