@@ -1,0 +1,856 @@
+// Local bundle adjustment on gfx950 (K11/K12): numerical core of LocalMapper::localBA
+// (reference src/OptimizationBA.cpp:543-873, setOrdering :942-953, checkOutlier(R) :393-424).
+//
+// Per LM linearisation / lambda trial:
+//   k_ba_linearize   obs-parallel: whitened residual, 2x6 pose and 2x3 landmark Jacobian blocks of
+//                    every GenericProjectionFactor (left, or right with the stereo extrinsics), stored
+//                    as 20 doubles per observation; cost by fixed-tree block reduction.
+//   k_ba_edges       BetweenFactor<Pose3> chain (Logmap residual, LogmapDerivative / Adjoint Jacobians).
+//   k_ba_schur       landmark-parallel, one 64-lane wave per landmark: Hll (+lambda I) inverse by
+//                    cofactors, W = Hpl blocks staged in LDS, S -= W Hll^-1 W^T and rhs -= W Hll^-1 bl
+//                    accumulated in a workgroup-private copy of the reduced camera system in LDS
+//                    (6F x 6F doubles, F = free keyframes) and flushed once per workgroup; when that
+//                    copy exceeds LDS (F > 20) the same updates go to HBM with fp64 atomics.
+//   k_ba_solve       one workgroup: sums the partial systems (this is where the RCCL all-reduce of the
+//                    landmark-sharded multi-GPU path plugs in), adds the BetweenFactor blocks and the
+//                    damping, dense Cholesky + substitutions, retracts the trial poses.
+//   k_ba_back        landmark-parallel back-substitution, trial landmark positions.
+//   k_ba_eval        obs-parallel: linearised cost at delta (GTSAM's linear.error(delta)) and the
+//                    nonlinear cost at the trial values.
+// The LM policy (GTSAM 4.2) runs on the host between launches; both passes
+// (5 then 10 iterations) start from the caller's values, separated by the chi2 re-check kernel.
+#include "common.hpp"
+#include "dmath.hpp"
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+#include <vector>
+
+namespace vslam {
+
+struct BaEdge {
+    int a, b, fa, fb;
+    DPose measured;
+    double r[6], Ja[36], Jb[36];
+};
+
+struct BaDev {
+    int NF, Lp, F, K, NE, n;
+    const int* facKf; const int* facFi; const int* facLp; const int* facLm;
+    const double* facZ; const double* facIs; const uint8_t* facRight;
+    double* facJ;
+    const int* lpStart; const int* lpSlotStart; const int* slotStart; const int* slotFi; const int* lpOrig;
+    DPose* poseCur; DPose* poseTrial; const int* fidx;
+    double* lmCur; double* lmTrial;
+    BaEdge* edges;
+    double* S; double* rhs; double* Spart; double* dP; double* dL;
+    double* sums; double* partial;
+    int* flags;
+    double fx, fy, cx, cy, b;
+};
+
+constexpr int BA_SCHUR_WAVES = 4;
+constexpr int BA_LDS_MAX_F = 20;          // (6F)^2 doubles must fit next to the W staging in 160 KB
+
+// whitened residual / Jacobians of one projection factor (cheirality: constant 2*fx residual)
+__device__ __forceinline__ void ba_eval_fac(const BaDev& D, const DPose& T, const double* p, bool right,
+                                            const double* z, double is, double* r, double* Jp, double* Jl) {
+    const double d[3] = {p[0] - T.t[0], p[1] - T.t[1], p[2] - T.t[2]};
+    double q[3];
+    mat3T_vec(T.R, d, q);
+    if (Jp) { for (int c = 0; c < 12; c++) Jp[c] = 0; for (int c = 0; c < 6; c++) Jl[c] = 0; }
+    if (q[2] <= 0) { r[0] = r[1] = 2.0 * D.fx * is; return; }
+    const double x = q[0], y = q[1], zz = q[2], iz = 1.0 / zz;
+    const double xx = right ? x - D.b : x;
+    r[0] = (D.fx * xx * iz + D.cx - z[0]) * is;
+    r[1] = (D.fy * y * iz + D.cy - z[1]) * is;
+    if (!Jp) return;
+    const double al[2][3] = {{D.fx * iz, 0, -D.fx * xx * iz * iz}, {0, D.fy * iz, -D.fy * y * iz * iz}};
+    const double Sk[3][3] = {{0, -zz, y}, {zz, 0, -x}, {-y, x, 0}};
+    for (int a = 0; a < 2; a++)
+        for (int c = 0; c < 3; c++) {
+            Jp[a * 6 + c] = (al[a][0] * Sk[0][c] + al[a][1] * Sk[1][c] + al[a][2] * Sk[2][c]) * is;
+            Jp[a * 6 + 3 + c] = -al[a][c] * is;
+            Jl[a * 3 + c] = (al[a][0] * T.R[3 * c] + al[a][1] * T.R[3 * c + 1] + al[a][2] * T.R[3 * c + 2]) * is;
+        }
+}
+
+__device__ __forceinline__ void ba_eval_edge(const BaEdge& e, const DPose& Ta, const DPose& Tb, double* r,
+                                             double* Ja, double* Jb) {
+    const double w = 1.0 / 0.01;
+    DPose Tai, h, Mi, d;
+    pose_inverse(Ta, Tai);
+    pose_compose(Tai, Tb, h);
+    pose_inverse(e.measured, Mi);
+    pose_compose(Mi, h, d);
+    pose3_logmap(d, r);
+    for (int i = 0; i < 6; i++) r[i] *= w;
+    if (!Ja) return;
+    double Hl[36], Ad[36];
+    DPose hi;
+    pose3_logmap_derivative(d, Hl);
+    pose_inverse(h, hi);
+    pose3_adjoint(hi, Ad);
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) {
+            double s = 0;
+            for (int k = 0; k < 6; k++) s += Hl[i * 6 + k] * Ad[k * 6 + j];
+            Ja[i * 6 + j] = -s * w;
+            Jb[i * 6 + j] = Hl[i * 6 + j] * w;
+        }
+}
+
+// block-wide sum of NV doubles (fixed tree), result valid in out[] for every thread after return
+template <int NV, int NW>
+__device__ __forceinline__ void ba_block_sum(double (&v)[NV], double* red, double* out) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v[k] += __shfl_xor(v[k], d);
+    }
+    if (lane == 0)
+        for (int k = 0; k < NV; k++) red[wave * NV + k] = v[k];
+    __syncthreads();
+    if (tid < NV) {
+        double s = 0;
+        for (int w = 0; w < NW; w++) s += red[w * NV + tid];
+        out[tid] = s;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_ba_linearize(BaDev D) {
+    __shared__ double red[4], out[1];
+    double e[1] = {0};
+    for (int f = blockIdx.x * 256 + threadIdx.x; f < D.NF; f += gridDim.x * 256) {
+        double r[2], Jp[12], Jl[6];
+        ba_eval_fac(D, D.poseCur[D.facKf[f]], D.lmCur + 3 * (size_t)D.facLm[f], D.facRight[f], D.facZ + 2 * (size_t)f,
+                    D.facIs[f], r, Jp, Jl);
+        double* o = D.facJ + (size_t)f * 20;
+        o[0] = r[0]; o[1] = r[1];
+        for (int c = 0; c < 12; c++) o[2 + c] = Jp[c];
+        for (int c = 0; c < 6; c++) o[14 + c] = Jl[c];
+        e[0] += r[0] * r[0] + r[1] * r[1];
+    }
+    ba_block_sum<1, 4>(e, red, out);
+    if (threadIdx.x == 0) D.partial[blockIdx.x] = out[0];
+}
+
+// mode 0: linearise edges at poseCur, sums[0] = 0.5*(sum partial + edges)   (lin0 / current error)
+// mode 1: evaluate edges at poseTrial: sums[1] = linearised cost at delta, sums[2] = trial cost
+__global__ __launch_bounds__(256) void k_ba_edges(BaDev D, int mode, int nPartial) {
+    __shared__ double red[12], out[2];
+    const int tid = threadIdx.x;
+    double v[2] = {0, 0};
+    for (int e = tid; e < D.NE; e += 256) {
+        BaEdge& E = D.edges[e];
+        if (mode == 0) {
+            ba_eval_edge(E, D.poseCur[E.a], D.poseCur[E.b], E.r, E.Ja, E.Jb);
+            for (int i = 0; i < 6; i++) v[0] += E.r[i] * E.r[i];
+        } else {
+            double r[6];
+            ba_eval_edge(E, D.poseTrial[E.a], D.poseTrial[E.b], r, nullptr, nullptr);
+            for (int i = 0; i < 6; i++) v[1] += r[i] * r[i];
+            for (int k = 0; k < 6; k++) {
+                double l = E.r[k];
+                for (int i = 0; i < 6; i++) {
+                    if (E.fa >= 0) l += E.Ja[k * 6 + i] * D.dP[6 * E.fa + i];
+                    if (E.fb >= 0) l += E.Jb[k * 6 + i] * D.dP[6 * E.fb + i];
+                }
+                v[0] += l * l;
+            }
+        }
+    }
+    // partial sums of the obs kernels: mode 0 -> 1 value per block, mode 1 -> 2 values per block
+    for (int i = tid; i < nPartial; i += 256) {
+        if (mode == 0) v[0] += D.partial[i];
+        else { v[0] += D.partial[2 * i]; v[1] += D.partial[2 * i + 1]; }
+    }
+    ba_block_sum<2, 4>(v, red, out);
+    if (tid == 0) {
+        if (mode == 0) D.sums[0] = 0.5 * out[0];
+        else { D.sums[1] = 0.5 * out[0]; D.sums[2] = 0.5 * out[1]; }
+    }
+}
+
+// ---- landmark blocks shared by the Schur and back-substitution kernels ---------------------------
+// After the call (and a __syncthreads by the caller) W[s*18 + i*3 + j] holds Hpl of slot s; Hi / bl are
+// returned in registers (identical in every lane of the wave).
+__device__ __forceinline__ void ba_lm_blocks(const BaDev& D, int lp, double lambda, double* W, int* sfi,
+                                             double* Hi, double* bl, int& ns) {
+    const int lane = threadIdx.x & 63;
+    const int f0 = D.lpStart[lp], f1 = D.lpStart[lp + 1];
+    double h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // 6 unique Hll entries + 3 of bl
+    for (int f = f0 + lane; f < f1; f += 64) {
+        const double* o = D.facJ + (size_t)f * 20;
+        const double r0 = o[0], r1 = o[1];
+        const double* Jl = o + 14;
+        h[0] += Jl[0] * Jl[0] + Jl[3] * Jl[3];
+        h[1] += Jl[0] * Jl[1] + Jl[3] * Jl[4];
+        h[2] += Jl[0] * Jl[2] + Jl[3] * Jl[5];
+        h[3] += Jl[1] * Jl[1] + Jl[4] * Jl[4];
+        h[4] += Jl[1] * Jl[2] + Jl[4] * Jl[5];
+        h[5] += Jl[2] * Jl[2] + Jl[5] * Jl[5];
+        h[6] -= Jl[0] * r0 + Jl[3] * r1;
+        h[7] -= Jl[1] * r0 + Jl[4] * r1;
+        h[8] -= Jl[2] * r0 + Jl[5] * r1;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) h[k] += __shfl_xor(h[k], d);
+    }
+    const double Hll[9] = {h[0] + lambda, h[1], h[2], h[1], h[3] + lambda, h[4], h[2], h[4], h[5] + lambda};
+    inv3sym(Hll, Hi);
+    bl[0] = h[6]; bl[1] = h[7]; bl[2] = h[8];
+    const int s0 = D.lpSlotStart[lp];
+    ns = D.lpSlotStart[lp + 1] - s0 - 1;   // one end sentinel per landmark
+    for (int e = lane; e < ns * 18; e += 64) {
+        const int s = e / 18, ij = e - s * 18, i = ij / 3, j = ij - i * 3;
+        double acc = 0;
+        for (int f = D.slotStart[s0 + s]; f < D.slotStart[s0 + s + 1]; f++) {
+            const double* o = D.facJ + (size_t)f * 20;
+            acc += o[2 + i] * o[14 + j] + o[2 + 6 + i] * o[14 + 3 + j];
+        }
+        W[e] = acc;
+    }
+    for (int s = lane; s < ns; s += 64) sfi[s] = D.slotFi[s0 + s];
+}
+
+template <bool LDS_S>
+__global__ __launch_bounds__(256) void k_ba_schur(BaDev D, double lambda, int maxSlots) {
+    extern __shared__ double sm[];
+    const int n = D.n;
+    double* Sloc = sm;                                        // LDS_S: n*n + n
+    double* wbase = sm + (LDS_S ? (size_t)n * n + n : 0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* W = wbase + (size_t)wave * (2 * maxSlots * 18);
+    double* WH = W + maxSlots * 18;
+    int* sfi = (int*)(wbase + (size_t)BA_SCHUR_WAVES * (2 * maxSlots * 18)) + wave * maxSlots;
+    double* Sacc = LDS_S ? Sloc : D.S;
+    double* racc = LDS_S ? Sloc + (size_t)n * n : D.rhs;
+    if (LDS_S) {
+        for (int i = threadIdx.x; i < n * n + n; i += 256) Sloc[i] = 0;
+    }
+    __syncthreads();
+    const int rounds = (D.Lp + gridDim.x * BA_SCHUR_WAVES - 1) / (gridDim.x * BA_SCHUR_WAVES);
+    for (int rd = 0; rd < rounds; rd++) {
+        const int lp = (rd * gridDim.x + blockIdx.x) * BA_SCHUR_WAVES + wave;
+        const bool act = lp < D.Lp;
+        double Hi[9], bl[3];
+        int ns = 0;
+        if (act) ba_lm_blocks(D, lp, lambda, W, sfi, Hi, bl, ns);
+        __syncthreads();
+        if (act) {
+            for (int e = lane; e < ns * 18; e += 64) {
+                const int s = e / 18, ij = e - s * 18, i = ij / 3, j = ij - i * 3;
+                const double* w = W + s * 18 + i * 3;
+                WH[e] = w[0] * Hi[j] + w[1] * Hi[3 + j] + w[2] * Hi[6 + j];
+            }
+        }
+        __syncthreads();
+        if (act) {
+            // S -= W_s1 Hll^-1 W_s2^T for s1 <= s2 (upper block triangle), rhs -= W_s1 Hll^-1 bl
+            for (int s1 = 0; s1 < ns; s1++) {
+                const int k1 = sfi[s1];
+                const int cnt = (ns - s1) * 36;
+                for (int e = lane; e < cnt; e += 64) {
+                    const int s2 = s1 + e / 36, ij = e % 36, i = ij / 6, j = ij - i * 6;
+                    const double* a = WH + s1 * 18 + i * 3;
+                    const double* bb = W + s2 * 18 + j * 3;
+                    const double val = a[0] * bb[0] + a[1] * bb[1] + a[2] * bb[2];
+                    atomicAdd(&Sacc[(size_t)(6 * k1 + i) * n + 6 * sfi[s2] + j], -val);
+                }
+                if (lane < 6) {
+                    const double* a = WH + s1 * 18 + lane * 3;
+                    atomicAdd(&racc[6 * k1 + lane], -(a[0] * bl[0] + a[1] * bl[1] + a[2] * bl[2]));
+                }
+            }
+            // Hpp and bp from this landmark's observations of free keyframes
+            const int f0 = D.lpStart[lp], f1 = D.lpStart[lp + 1];
+            for (int e = lane; e < (f1 - f0) * 27; e += 64) {
+                const int f = f0 + e / 27, q = e % 27;
+                const int fi = D.facFi[f];
+                if (fi < 0) continue;
+                const double* o = D.facJ + (size_t)f * 20;
+                if (q < 21) {
+                    int i = 0, rem = q;
+                    while (rem >= 6 - i) { rem -= 6 - i; i++; }
+                    const int j = i + rem;
+                    atomicAdd(&Sacc[(size_t)(6 * fi + i) * n + 6 * fi + j], o[2 + i] * o[2 + j] + o[8 + i] * o[8 + j]);
+                } else {
+                    const int i = q - 21;
+                    atomicAdd(&racc[6 * fi + i], -(o[2 + i] * o[0] + o[8 + i] * o[1]));
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (LDS_S) {
+        double* dst = D.Spart + (size_t)blockIdx.x * ((size_t)n * n + n);
+        for (int i = threadIdx.x; i < n * n + n; i += 256) dst[i] = Sloc[i];
+    }
+}
+
+// One workgroup: assemble the reduced camera system, factorise, solve, retract the poses.
+// Spart layout: nPart x (n*n + n).  A (n x n) lives in LDS when it fits, else in D.S.
+__global__ __launch_bounds__(1024) void k_ba_solve(BaDev D, double lambda, int nPart, int useLds) {
+    extern __shared__ double sm[];
+    const int n = D.n, tid = threadIdx.x;
+    double* A = useLds ? sm : D.S;
+    double* b = useLds ? sm + (size_t)n * n : D.rhs;
+    __shared__ int sFail;
+    __shared__ double sPiv;
+    if (tid == 0) sFail = 0;
+    const size_t stride = (size_t)n * n + n;
+    if (nPart > 0) {
+        for (int i = tid; i < n * n + n; i += 1024) {
+            double s = 0;
+            for (int p = 0; p < nPart; p++) s += D.Spart[(size_t)p * stride + i];
+            if (i < n * n) A[i] = s; else b[i - n * n] = s;
+        }
+    } else if (useLds) {
+        for (int i = tid; i < n * n; i += 1024) A[i] = D.S[i];
+        for (int i = tid; i < n; i += 1024) b[i] = D.rhs[i];
+    }
+    __syncthreads();
+    // BetweenFactor blocks (upper triangle only)
+    for (int e = 0; e < D.NE; e++) {
+        const BaEdge& E = D.edges[e];
+        if (tid < 108) {
+            const int blk = tid / 36, ij = tid % 36, i = ij / 6, j = ij % 6;
+            double s = 0;
+            if (blk == 0 && E.fa >= 0) {
+                for (int k = 0; k < 6; k++) s += E.Ja[k * 6 + i] * E.Ja[k * 6 + j];
+                if (i <= j) A[(size_t)(6 * E.fa + i) * n + 6 * E.fa + j] += s;
+            } else if (blk == 1 && E.fb >= 0) {
+                for (int k = 0; k < 6; k++) s += E.Jb[k * 6 + i] * E.Jb[k * 6 + j];
+                if (i <= j) A[(size_t)(6 * E.fb + i) * n + 6 * E.fb + j] += s;
+            } else if (blk == 2 && E.fa >= 0 && E.fb >= 0) {
+                for (int k = 0; k < 6; k++) s += E.Ja[k * 6 + i] * E.Jb[k * 6 + j];
+                if (E.fa < E.fb) A[(size_t)(6 * E.fa + i) * n + 6 * E.fb + j] += s;
+                else A[(size_t)(6 * E.fb + j) * n + 6 * E.fa + i] += s;
+            }
+        } else if (tid < 120) {
+            const int q = tid - 108, side = q / 6, i = q % 6;
+            const int fi = side ? E.fb : E.fa;
+            if (fi >= 0) {
+                const double* J = side ? E.Jb : E.Ja;
+                double s = 0;
+                for (int k = 0; k < 6; k++) s += J[k * 6 + i] * E.r[k];
+                b[6 * fi + i] -= s;
+            }
+        }
+        __syncthreads();
+    }
+    // mirror upper -> lower, damping
+    for (int i = tid; i < n * n; i += 1024) {
+        const int r = i / n, c = i - r * n;
+        if (r > c) A[i] = A[(size_t)c * n + r];
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) A[(size_t)i * n + i] += lambda;
+    __syncthreads();
+    // right-looking Cholesky (lower)
+    for (int j = 0; j < n; j++) {
+        if (tid == 0) {
+            const double d = A[(size_t)j * n + j];
+            if (!(d > 0)) { sFail = 1; sPiv = 1.0; }
+            else { sPiv = sqrt(d); A[(size_t)j * n + j] = sPiv; }
+        }
+        __syncthreads();
+        if (sFail) break;
+        const double piv = sPiv;
+        for (int i = j + 1 + tid; i < n; i += 1024) A[(size_t)i * n + j] /= piv;
+        __syncthreads();
+        const int m = n - j - 1;
+        for (int e = tid; e < m * m; e += 1024) {
+            const int r = j + 1 + e / m, c = j + 1 + e % m;
+            if (c <= r) A[(size_t)r * n + c] -= A[(size_t)r * n + j] * A[(size_t)c * n + j];
+        }
+        __syncthreads();
+    }
+    if (!sFail) {
+        for (int j = 0; j < n; j++) {           // L y = b
+            if (tid == 0) b[j] /= A[(size_t)j * n + j];
+            __syncthreads();
+            const double yj = b[j];
+            for (int i = j + 1 + tid; i < n; i += 1024) b[i] -= A[(size_t)i * n + j] * yj;
+            __syncthreads();
+        }
+        for (int j = n - 1; j >= 0; j--) {      // L^T x = y
+            if (tid == 0) b[j] /= A[(size_t)j * n + j];
+            __syncthreads();
+            const double xj = b[j];
+            for (int i = tid; i < j; i += 1024) b[i] -= A[(size_t)j * n + i] * xj;
+            __syncthreads();
+        }
+        for (int i = tid; i < n; i += 1024) D.dP[i] = b[i];
+        __syncthreads();
+        for (int k = tid; k < D.K; k += 1024) {
+            const int fi = D.fidx[k];
+            if (fi >= 0) { DPose T; pose_retract(D.poseCur[k], D.dP + 6 * fi, T); D.poseTrial[k] = T; }
+            else D.poseTrial[k] = D.poseCur[k];
+        }
+    }
+    if (tid == 0) D.flags[0] = sFail;
+}
+
+// back-substitution: dl = Hll^-1 (bl - sum_k W_k^T dp_k); trial landmark = cur + dl
+__global__ __launch_bounds__(256) void k_ba_back(BaDev D, double lambda, int maxSlots) {
+    extern __shared__ double sm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* W = sm + (size_t)wave * (maxSlots * 18);
+    int* sfi = (int*)(sm + (size_t)BA_SCHUR_WAVES * (maxSlots * 18)) + wave * maxSlots;
+    const int rounds = (D.Lp + gridDim.x * BA_SCHUR_WAVES - 1) / (gridDim.x * BA_SCHUR_WAVES);
+    for (int rd = 0; rd < rounds; rd++) {
+        const int lp = (rd * gridDim.x + blockIdx.x) * BA_SCHUR_WAVES + wave;
+        const bool act = lp < D.Lp;
+        double Hi[9], bl[3];
+        int ns = 0;
+        if (act) ba_lm_blocks(D, lp, lambda, W, sfi, Hi, bl, ns);
+        __syncthreads();
+        if (act) {
+            double t[3] = {0, 0, 0};
+            for (int e = lane; e < ns * 6; e += 64) {
+                const int s = e / 6, i = e - s * 6;
+                const double dp = D.dP[6 * sfi[s] + i];
+                const double* w = W + s * 18 + i * 3;
+                t[0] += w[0] * dp; t[1] += w[1] * dp; t[2] += w[2] * dp;
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) t[k] += __shfl_xor(t[k], d);
+            }
+            if (lane < 3) {
+                const double u[3] = {bl[0] - t[0], bl[1] - t[1], bl[2] - t[2]};
+                const double dl = Hi[3 * lane] * u[0] + Hi[3 * lane + 1] * u[1] + Hi[3 * lane + 2] * u[2];
+                D.dL[3 * (size_t)lp + lane] = dl;
+                const int l = D.lpOrig[lp];
+                D.lmTrial[3 * (size_t)l + lane] = D.lmCur[3 * (size_t)l + lane] + dl;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ba_eval(BaDev D) {
+    __shared__ double red[8], out[2];
+    double v[2] = {0, 0};
+    for (int f = blockIdx.x * 256 + threadIdx.x; f < D.NF; f += gridDim.x * 256) {
+        const double* o = D.facJ + (size_t)f * 20;
+        const int fi = D.facFi[f], lp = D.facLp[f];
+        double l0 = o[0], l1 = o[1];
+        if (fi >= 0) {
+            const double* dp = D.dP + 6 * fi;
+            for (int i = 0; i < 6; i++) { l0 += o[2 + i] * dp[i]; l1 += o[8 + i] * dp[i]; }
+        }
+        const double* dl = D.dL + 3 * (size_t)lp;
+        for (int i = 0; i < 3; i++) { l0 += o[14 + i] * dl[i]; l1 += o[17 + i] * dl[i]; }
+        v[0] += l0 * l0 + l1 * l1;
+        double r[2];
+        ba_eval_fac(D, D.poseTrial[D.facKf[f]], D.lmTrial + 3 * (size_t)D.facLm[f], D.facRight[f], D.facZ + 2 * (size_t)f,
+                    D.facIs[f], r, nullptr, nullptr);
+        v[1] += r[0] * r[0] + r[1] * r[1];
+    }
+    ba_block_sum<2, 4>(v, red, out);
+    if (threadIdx.x == 0) { D.partial[2 * blockIdx.x] = out[0]; D.partial[2 * blockIdx.x + 1] = out[1]; }
+}
+
+// chi2 re-check (src/OptimizationBA.cpp:787-871): pair-parallel
+struct BaChi {
+    int NP; const int* pairKf; const int* pairLm; const uint8_t* pairFlags; const float* pairUv; const int* pairOct;
+    const uint8_t* kfLocal; const uint8_t* kfPresent; const uint8_t* lmPresent; const DPose* pose; const double* lm;
+    float thr[MAX_LEVELS]; double fx, fy, cx, cy, b; uint8_t* wrong;
+};
+__device__ __forceinline__ bool ba_outlier(const BaChi& C, const double* pc, float ou, float ov, int oct, bool right) {
+    const double x = right ? pc[0] - C.b : pc[0], y = pc[1], z = pc[2];
+    if (z <= 0) return true;
+    const double px = C.fx * x + C.cx * z, py = C.fy * y + C.cy * z;
+    const double eu = (double)ou - px / z, ev = (double)ov - py / z;
+    return (eu * eu + ev * ev) > (double)C.thr[oct];
+}
+__global__ __launch_bounds__(256) void k_ba_chi2(BaChi C) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= C.NP) return;
+    uint8_t w = 0;
+    const int kf = C.pairKf[p], lm = C.pairLm[p], fl = C.pairFlags[p];
+    if (C.kfLocal[kf] && C.kfPresent[kf] && C.lmPresent[lm] && (fl & 3)) {
+        DPose Tcw;
+        pose_inverse(C.pose[kf], Tcw);
+        double pc[3];
+        mat3_vec(Tcw.R, C.lm + 3 * (size_t)lm, pc);
+        for (int i = 0; i < 3; i++) pc[i] += Tcw.t[i];
+        const float* uv = C.pairUv + 4 * (size_t)p;
+        if (fl & 1) {
+            if (ba_outlier(C, pc, uv[0], uv[1], C.pairOct[2 * p], false)) w = 1;
+            else if ((fl & 2) && ba_outlier(C, pc, uv[2], uv[3], C.pairOct[2 * p + 1], true)) w = 1;
+        } else if (ba_outlier(C, pc, uv[2], uv[3], C.pairOct[2 * p + 1], true)) w = 1;
+    }
+    C.wrong[p] = w;
+}
+
+}  // namespace vslam
+
+using namespace vslam;
+
+namespace {
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count) {
+        if (count <= n && p) return hipSuccess;
+        if (p) hipFree(p);
+        n = std::max<size_t>(count, 1);
+        return hipMalloc(&p, n * sizeof(T));
+    }
+    ~DevBuf() { if (p) hipFree(p); }
+};
+
+thread_local StageTimer g_baTimer;
+
+struct HostFac { int pair, kf, lm, fi, lp; bool right; double z[2], is; };
+
+}  // namespace
+
+#define BA_UP(dst, vec) VS_HIP(hipMemcpyAsync((dst).p, (vec).data(), (vec).size() * sizeof((vec)[0]), hipMemcpyHostToDevice, stream))
+
+static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int device, const vslam_comm* comm) {
+    if (!P || !R || P->n_kf < 1 || P->n_lm < 0 || P->n_pairs < 0 || P->n_levels < 1 || P->n_levels > MAX_LEVELS ||
+        !P->kf_pose_wc || !P->kf_id || !P->kf_fixed || !P->kf_local || !P->sigma_factor || !P->inv_sigma_factor ||
+        !R->kf_pose_wc || !R->lm_xyz || !R->pair_wrong ||
+        (P->n_lm > 0 && !P->lm_xyz) ||
+        (P->n_pairs > 0 && (!P->pair_kf || !P->pair_lm || !P->pair_flags || !P->pair_uv || !P->pair_octave))) {
+        set_error("vslam_local_ba: invalid problem");
+        return VSLAM_ERR_INVALID;
+    }
+    if (comm) { set_error("vslam_local_ba: multi-GPU communicator not available in this build"); return VSLAM_ERR_COMM; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available (no CPU fallback)"); return VSLAM_ERR_NO_DEVICE; }
+    if (device < 0 || device >= ndev) return VSLAM_ERR_INVALID;
+    VS_HIP(hipSetDevice(device));
+    const int K = P->n_kf, L = P->n_lm, NP = P->n_pairs;
+    for (int p = 0; p < NP; p++)
+        if (P->pair_kf[p] < 0 || P->pair_kf[p] >= K || P->pair_lm[p] < 0 || P->pair_lm[p] >= L ||
+            P->pair_octave[2 * p] < 0 || P->pair_octave[2 * p] >= P->n_levels || P->pair_octave[2 * p + 1] < 0 ||
+            P->pair_octave[2 * p + 1] >= P->n_levels) { set_error("vslam_local_ba: pair index out of range"); return VSLAM_ERR_INVALID; }
+
+    hipStream_t stream;
+    VS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    g_baTimer.destroy();
+    g_baTimer.stream = stream;
+    g_baTimer.multi = true;
+
+    // static device data
+    DevBuf<DPose> d_pose0, d_poseA, d_poseB;
+    DevBuf<double> d_lm0, d_lmA, d_lmB, d_facZ, d_facIs, d_facJ, d_S, d_rhs, d_Spart, d_dP, d_dL, d_sums, d_partial;
+    DevBuf<int> d_facKf, d_facFi, d_facLp, d_facLm, d_lpStart, d_lpSlotStart, d_slotStart, d_slotFi, d_lpOrig, d_fidx, d_flags;
+    DevBuf<int> d_pairKf, d_pairLm, d_pairOct;
+    DevBuf<uint8_t> d_facRight, d_pairFlags, d_kfLocal, d_kfPresent, d_lmPresent, d_wrong;
+    DevBuf<float> d_pairUv;
+    DevBuf<BaEdge> d_edges;
+
+    std::vector<DPose> pose0(K);
+    for (int k = 0; k < K; k++) pose_from_rm16(P->kf_pose_wc + 16 * (size_t)k, pose0[k]);
+    VS_HIP(d_pose0.alloc(K)); VS_HIP(d_poseA.alloc(K)); VS_HIP(d_poseB.alloc(K));
+    VS_HIP(d_lm0.alloc((size_t)3 * L)); VS_HIP(d_lmA.alloc((size_t)3 * L)); VS_HIP(d_lmB.alloc((size_t)3 * L));
+    VS_HIP(hipMemcpyAsync(d_pose0.p, pose0.data(), K * sizeof(DPose), hipMemcpyHostToDevice, stream));
+    if (L) VS_HIP(hipMemcpyAsync(d_lm0.p, P->lm_xyz, (size_t)3 * L * sizeof(double), hipMemcpyHostToDevice, stream));
+    VS_HIP(d_pairKf.alloc(NP)); VS_HIP(d_pairLm.alloc(NP)); VS_HIP(d_pairOct.alloc((size_t)2 * NP));
+    VS_HIP(d_pairFlags.alloc(NP)); VS_HIP(d_pairUv.alloc((size_t)4 * NP)); VS_HIP(d_wrong.alloc(NP));
+    VS_HIP(d_kfLocal.alloc(K)); VS_HIP(d_kfPresent.alloc(K)); VS_HIP(d_lmPresent.alloc(L));
+    if (NP) {
+        VS_HIP(hipMemcpyAsync(d_pairKf.p, P->pair_kf, NP * sizeof(int), hipMemcpyHostToDevice, stream));
+        VS_HIP(hipMemcpyAsync(d_pairLm.p, P->pair_lm, NP * sizeof(int), hipMemcpyHostToDevice, stream));
+        VS_HIP(hipMemcpyAsync(d_pairOct.p, P->pair_octave, (size_t)2 * NP * sizeof(int), hipMemcpyHostToDevice, stream));
+        VS_HIP(hipMemcpyAsync(d_pairFlags.p, P->pair_flags, NP, hipMemcpyHostToDevice, stream));
+        VS_HIP(hipMemcpyAsync(d_pairUv.p, P->pair_uv, (size_t)4 * NP * sizeof(float), hipMemcpyHostToDevice, stream));
+    }
+    VS_HIP(hipMemcpyAsync(d_kfLocal.p, P->kf_local, K, hipMemcpyHostToDevice, stream));
+    VS_HIP(d_sums.alloc(8)); VS_HIP(d_flags.alloc(4));
+
+    std::vector<uint8_t> wrong(NP, 0), kfPresent(K), lmPresent(L);
+    DPose* poseFinal = d_pose0.p;
+    double* lmFinal = d_lm0.p;
+    const int nCU = 256;
+
+    for (int pass = 0; pass < 2; pass++) {
+        // ---- host: factor list of this pass, sorted by (landmark, free index, side) ----------------
+        std::fill(kfPresent.begin(), kfPresent.end(), 0);
+        std::fill(lmPresent.begin(), lmPresent.end(), 0);
+        std::vector<HostFac> facs;
+        facs.reserve((size_t)2 * NP);
+        for (int p = 0; p < NP; p++) {
+            if (wrong[p]) continue;
+            for (int side = 0; side < 2; side++) {
+                if (!((P->pair_flags[p] >> side) & 1)) continue;
+                HostFac f{};
+                f.pair = p; f.kf = P->pair_kf[p]; f.lm = P->pair_lm[p]; f.right = side == 1;
+                f.z[0] = P->pair_uv[4 * (size_t)p + 2 * side]; f.z[1] = P->pair_uv[4 * (size_t)p + 2 * side + 1];
+                f.is = 1.0 / (1.0 / (double)P->inv_sigma_factor[P->pair_octave[2 * p + side]]);
+                facs.push_back(f);
+                kfPresent[f.kf] = 1; lmPresent[f.lm] = 1;
+            }
+        }
+        std::vector<int> fidx(K, -1);
+        int F = 0;
+        for (int k = 0; k < K; k++) if (kfPresent[k] && !P->kf_fixed[k]) fidx[k] = F++;
+        const int n = 6 * F;
+        std::vector<int> lpOf(L, -1), lpOrig;
+        for (int l = 0; l < L; l++) if (lmPresent[l]) { lpOf[l] = (int)lpOrig.size(); lpOrig.push_back(l); }
+        const int Lp = (int)lpOrig.size();
+        for (HostFac& f : facs) { f.fi = fidx[f.kf]; f.lp = lpOf[f.lm]; }
+        std::stable_sort(facs.begin(), facs.end(), [](const HostFac& a, const HostFac& b) {
+            if (a.lp != b.lp) return a.lp < b.lp;
+            return a.fi < b.fi;
+        });
+        const int NF = (int)facs.size();
+        // Slot table: inside a landmark the factors of fixed keyframes (fi = -1) come first, then one
+        // "slot" per free keyframe (its left and/or right factor).  Padded layout: per landmark the slot
+        // starts followed by an end sentinel, so slot s spans [slotStart[s0+s], slotStart[s0+s+1]).
+        std::vector<int> facKf(NF), facFi(NF), facLp(NF), facLm(NF), lpStart(Lp + 1, 0), lpSlotStart(Lp + 1, 0), slotStart, slotFi;
+        std::vector<double> facZ((size_t)2 * NF), facIs(NF);
+        std::vector<uint8_t> facRight(NF);
+        int maxSlots = 1;
+        long long sumK2 = 0;
+        {
+            int f = 0;
+            for (int lp = 0; lp < Lp; lp++) {
+                lpStart[lp] = f;
+                lpSlotStart[lp] = (int)slotStart.size();
+                int lastFi = -2, ns = 0;
+                while (f < NF && facs[f].lp == lp) {
+                    if (facs[f].fi >= 0 && facs[f].fi != lastFi) { slotStart.push_back(f); slotFi.push_back(facs[f].fi); lastFi = facs[f].fi; ns++; }
+                    f++;
+                }
+                slotStart.push_back(f);      // end sentinel
+                slotFi.push_back(-1);
+                maxSlots = std::max(maxSlots, ns);
+                sumK2 += (long long)ns * ns;
+            }
+            lpStart[Lp] = f;
+            lpSlotStart[Lp] = (int)slotStart.size();
+        }
+        for (int i = 0; i < NF; i++) {
+            facKf[i] = facs[i].kf; facFi[i] = facs[i].fi; facLp[i] = facs[i].lp; facLm[i] = facs[i].lm;
+            facZ[2 * (size_t)i] = facs[i].z[0]; facZ[2 * (size_t)i + 1] = facs[i].z[1];
+            facIs[i] = facs[i].is; facRight[i] = facs[i].right;
+        }
+        // edges: id-consecutive keyframes of this pass's graph (src/OptimizationBA.cpp:750-768)
+        std::vector<int> order;
+        for (int k = 0; k < K; k++) if (kfPresent[k]) order.push_back(k);
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return P->kf_id[a] < P->kf_id[b]; });
+        std::vector<BaEdge> edges;
+        for (size_t i = 0; i + 1 < order.size(); i++) {
+            BaEdge e{};
+            e.a = order[i]; e.b = order[i + 1]; e.fa = fidx[e.a]; e.fb = fidx[e.b];
+            DPose ai;
+            pose_inverse(pose0[e.a], ai);
+            pose_compose(ai, pose0[e.b], e.measured);
+            edges.push_back(e);
+        }
+        const int NE = (int)edges.size();
+
+        // ---- upload ------------------------------------------------------------------------------
+        VS_HIP(d_facKf.alloc(NF)); VS_HIP(d_facFi.alloc(NF)); VS_HIP(d_facLp.alloc(NF)); VS_HIP(d_facLm.alloc(NF));
+        VS_HIP(d_facZ.alloc((size_t)2 * NF)); VS_HIP(d_facIs.alloc(NF)); VS_HIP(d_facRight.alloc(NF));
+        VS_HIP(d_facJ.alloc((size_t)20 * NF));
+        VS_HIP(d_lpStart.alloc(Lp + 1)); VS_HIP(d_lpSlotStart.alloc(Lp + 1)); VS_HIP(d_lpOrig.alloc(Lp)); VS_HIP(d_fidx.alloc(K)); VS_HIP(d_edges.alloc(NE));
+        VS_HIP(d_dP.alloc(n)); VS_HIP(d_dL.alloc((size_t)3 * Lp)); VS_HIP(d_S.alloc((size_t)n * n)); VS_HIP(d_rhs.alloc(n));
+        VS_HIP(d_slotStart.alloc(slotStart.size() + 1)); VS_HIP(d_slotFi.alloc(slotFi.size() + 1));
+        if (NF) {
+            BA_UP(d_facKf, facKf); BA_UP(d_facFi, facFi); BA_UP(d_facLp, facLp); BA_UP(d_facLm, facLm);
+            BA_UP(d_facZ, facZ); BA_UP(d_facIs, facIs); BA_UP(d_facRight, facRight);
+        }
+        BA_UP(d_lpStart, lpStart); BA_UP(d_lpSlotStart, lpSlotStart);
+        if (!slotStart.empty()) { BA_UP(d_slotStart, slotStart); BA_UP(d_slotFi, slotFi); }
+        if (Lp) BA_UP(d_lpOrig, lpOrig);
+        BA_UP(d_fidx, fidx);
+        if (NE) BA_UP(d_edges, edges);
+        VS_HIP(hipMemcpyAsync(d_poseA.p, d_pose0.p, K * sizeof(DPose), hipMemcpyDeviceToDevice, stream));
+        VS_HIP(hipMemcpyAsync(d_poseB.p, d_pose0.p, K * sizeof(DPose), hipMemcpyDeviceToDevice, stream));
+        if (L) {
+            VS_HIP(hipMemcpyAsync(d_lmA.p, d_lm0.p, (size_t)3 * L * sizeof(double), hipMemcpyDeviceToDevice, stream));
+            VS_HIP(hipMemcpyAsync(d_lmB.p, d_lm0.p, (size_t)3 * L * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        }
+
+        BaDev D{};
+        D.NF = NF; D.Lp = Lp; D.F = F; D.K = K; D.NE = NE; D.n = n;
+        D.facKf = d_facKf.p; D.facFi = d_facFi.p; D.facLp = d_facLp.p; D.facLm = d_facLm.p;
+        D.facZ = d_facZ.p; D.facIs = d_facIs.p; D.facRight = d_facRight.p; D.facJ = d_facJ.p;
+        D.lpStart = d_lpStart.p; D.lpSlotStart = d_lpSlotStart.p; D.slotStart = d_slotStart.p; D.slotFi = d_slotFi.p;
+        D.lpOrig = d_lpOrig.p; D.poseCur = d_poseA.p; D.poseTrial = d_poseB.p; D.fidx = d_fidx.p;
+        D.lmCur = d_lmA.p; D.lmTrial = d_lmB.p; D.edges = d_edges.p;
+        D.S = d_S.p; D.rhs = d_rhs.p; D.dP = d_dP.p; D.dL = d_dL.p; D.sums = d_sums.p; D.flags = d_flags.p;
+        D.fx = P->rig.fx; D.fy = P->rig.fy; D.cx = P->rig.cx; D.cy = P->rig.cy; D.b = (double)P->rig.baseline;
+
+        const int obsBlocks = std::max(1, std::min((NF + 255) / 256, 4 * nCU));
+        const int lmBlocks = std::max(1, std::min((Lp + BA_SCHUR_WAVES - 1) / BA_SCHUR_WAVES, nCU));
+        VS_HIP(d_partial.alloc((size_t)2 * obsBlocks));
+        D.partial = d_partial.p;
+        const bool ldsS = F <= BA_LDS_MAX_F;
+        const size_t sysDoubles = (size_t)n * n + n;
+        if (ldsS) VS_HIP(d_Spart.alloc(sysDoubles * lmBlocks));
+        D.Spart = d_Spart.p;
+        const size_t wStage = (size_t)BA_SCHUR_WAVES * 2 * maxSlots * 18 * sizeof(double) + (size_t)BA_SCHUR_WAVES * maxSlots * sizeof(int) + 16;
+        const size_t schurLds = (ldsS ? sysDoubles * sizeof(double) : 0) + wStage;
+        const size_t backLds = (size_t)BA_SCHUR_WAVES * maxSlots * 18 * sizeof(double) + (size_t)BA_SCHUR_WAVES * maxSlots * sizeof(int) + 16;
+        const bool solveLds = sysDoubles * sizeof(double) <= 150 * 1024;
+        if (schurLds > 160 * 1024) { set_error("local BA: landmark with too many views for the LDS staging"); return VSLAM_ERR_CAPACITY; }
+        if (ldsS) VS_HIP(hipFuncSetAttribute((const void*)k_ba_schur<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurLds));
+        else VS_HIP(hipFuncSetAttribute((const void*)k_ba_schur<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurLds));
+        if (solveLds) VS_HIP(hipFuncSetAttribute((const void*)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sysDoubles * sizeof(double) + 64)));
+
+        // ---- LM (GTSAM 4.2 policy) -----------------------------------------------------------------
+        const int maxIterations = pass == 0 ? 5 : 10;
+        const double relTol = 1e-5, absTol = 1e-5;
+        double lambda = 1e-5;
+        int iterations = 0, inner = 0;
+        auto linearize = [&]() -> vslam_status {
+            int t = g_baTimer.begin("ba_linearize");
+            if (NF) hipLaunchKernelGGL(k_ba_linearize, dim3(obsBlocks), dim3(256), 0, stream, D);
+            hipLaunchKernelGGL(k_ba_edges, dim3(1), dim3(256), 0, stream, D, 0, NF ? obsBlocks : 0);
+            g_baTimer.end(t);
+            return VSLAM_OK;
+        };
+        VS_CHECK(linearize());
+        double sums[3];
+        VS_HIP(hipMemcpyAsync(sums, d_sums.p, sizeof(double), hipMemcpyDeviceToHost, stream));
+        VS_HIP(hipStreamSynchronize(stream));
+        double error = sums[0];
+        const double initialError = error;
+        bool linearized = true;
+        if (!(error <= 0.0) && iterations < maxIterations) {
+            double newError = error, currentError;
+            do {
+                currentError = newError;
+                if (!linearized) VS_CHECK(linearize());
+                linearized = false;
+                for (;;) {   // tryLambda
+                    int t = g_baTimer.begin("ba_schur");
+                    if (n > 0) {
+                        if (ldsS) hipLaunchKernelGGL(k_ba_schur<true>, dim3(lmBlocks), dim3(256), schurLds, stream, D, lambda, maxSlots);
+                        else {
+                            VS_HIP(hipMemsetAsync(d_S.p, 0, (size_t)n * n * sizeof(double), stream));
+                            VS_HIP(hipMemsetAsync(d_rhs.p, 0, (size_t)n * sizeof(double), stream));
+                            hipLaunchKernelGGL(k_ba_schur<false>, dim3(lmBlocks), dim3(256), schurLds, stream, D, lambda, maxSlots);
+                        }
+                    }
+                    g_baTimer.end(t);
+                    t = g_baTimer.begin("ba_solve");
+                    hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(1024), solveLds ? sysDoubles * sizeof(double) + 64 : 64, stream, D,
+                                       lambda, (n > 0 && ldsS) ? lmBlocks : 0, solveLds ? 1 : 0);
+                    g_baTimer.end(t);
+                    t = g_baTimer.begin("ba_back");
+                    if (Lp) hipLaunchKernelGGL(k_ba_back, dim3(lmBlocks), dim3(256), backLds, stream, D, lambda, maxSlots);
+                    g_baTimer.end(t);
+                    t = g_baTimer.begin("ba_eval");
+                    if (NF) hipLaunchKernelGGL(k_ba_eval, dim3(obsBlocks), dim3(256), 0, stream, D);
+                    hipLaunchKernelGGL(k_ba_edges, dim3(1), dim3(256), 0, stream, D, 1, NF ? obsBlocks : 0);
+                    g_baTimer.end(t);
+                    VS_HIP(hipGetLastError());
+                    int fail = 0;
+                    VS_HIP(hipMemcpyAsync(sums, d_sums.p, 3 * sizeof(double), hipMemcpyDeviceToHost, stream));
+                    VS_HIP(hipMemcpyAsync(&fail, d_flags.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+                    VS_HIP(hipStreamSynchronize(stream));
+                    bool stepOk = false, stop = false;
+                    double newErr = INFINITY;
+                    const double linChange = error - sums[1];
+                    if (!fail && linChange >= 0) {
+                        newErr = sums[2];
+                        const double costChange = error - newErr;
+                        if (linChange > DBL_EPSILON * error) stepOk = (costChange / linChange) > 1e-3;
+                        if (std::fabs(costChange) < relTol * error) stop = true;
+                    }
+                    if (stepOk) {
+                        std::swap(D.poseCur, D.poseTrial);
+                        std::swap(D.lmCur, D.lmTrial);   // every present landmark / every pose is rewritten per trial
+                        error = newErr;
+                        lambda = std::max(0.0, lambda / 10.0);
+                        iterations++; inner++;
+                        break;
+                    } else if (!stop) {
+                        lambda *= 10.0;
+                        inner++;
+                        if (lambda >= 1e5) break;
+                    } else break;
+                }
+                newError = error;
+                bool converged;
+                if (newError <= 0.0) converged = true;
+                else {
+                    const double absDec = currentError - newError, relDec = absDec / currentError;
+                    converged = (relDec <= relTol) || (absDec <= absTol);
+                }
+                if (!(iterations < maxIterations && !converged && std::isfinite(currentError))) break;
+            } while (true);
+        }
+        R->report[pass].iterations = iterations;
+        R->report[pass].inner_iterations = inner;
+        R->report[pass].initial_error = initialError;
+        R->report[pass].final_error = error;
+        R->report[pass].lambda = lambda;
+        R->n_residuals = NF; R->n_landmarks = Lp; R->n_free_kf = F; R->sum_k2 = sumK2;
+
+        // ---- chi2 re-check with the optimised values ---------------------------------------------
+        VS_HIP(hipMemcpyAsync(d_kfPresent.p, kfPresent.data(), K, hipMemcpyHostToDevice, stream));
+        if (L) VS_HIP(hipMemcpyAsync(d_lmPresent.p, lmPresent.data(), L, hipMemcpyHostToDevice, stream));
+        BaChi C{};
+        C.NP = NP; C.pairKf = d_pairKf.p; C.pairLm = d_pairLm.p; C.pairFlags = d_pairFlags.p; C.pairUv = d_pairUv.p;
+        C.pairOct = d_pairOct.p; C.kfLocal = d_kfLocal.p; C.kfPresent = d_kfPresent.p; C.lmPresent = d_lmPresent.p;
+        C.pose = D.poseCur; C.lm = D.lmCur; C.wrong = d_wrong.p;
+        for (int l = 0; l < P->n_levels; l++) C.thr[l] = (float)((double)7.815f * (double)P->sigma_factor[l]);
+        C.fx = D.fx; C.fy = D.fy; C.cx = D.cx; C.cy = D.cy; C.b = D.b;
+        int t = g_baTimer.begin("ba_chi2");
+        if (NP) hipLaunchKernelGGL(k_ba_chi2, dim3((NP + 255) / 256), dim3(256), 0, stream, C);
+        g_baTimer.end(t);
+        VS_HIP(hipGetLastError());
+        if (NP) VS_HIP(hipMemcpyAsync(wrong.data(), d_wrong.p, NP, hipMemcpyDeviceToHost, stream));
+        VS_HIP(hipStreamSynchronize(stream));
+        if (pass == 0 && R->pair_wrong_pass1 && NP) memcpy(R->pair_wrong_pass1, wrong.data(), NP);
+        poseFinal = D.poseCur;
+        lmFinal = D.lmCur;
+    }
+    std::vector<DPose> poseOut(K);
+    VS_HIP(hipMemcpyAsync(poseOut.data(), poseFinal, K * sizeof(DPose), hipMemcpyDeviceToHost, stream));
+    if (L) VS_HIP(hipMemcpyAsync(R->lm_xyz, lmFinal, (size_t)3 * L * sizeof(double), hipMemcpyDeviceToHost, stream));
+    VS_HIP(hipStreamSynchronize(stream));
+    for (int k = 0; k < K; k++) pose_to_rm16(poseOut[k], R->kf_pose_wc + 16 * (size_t)k);
+    if (NP) memcpy(R->pair_wrong, wrong.data(), NP);
+    hipStreamDestroy(stream);
+    g_baTimer.stream = nullptr;
+    return VSLAM_OK;
+}
+
+extern "C" {
+
+vslam_status vslam_local_ba(const vslam_ba_problem* problem, vslam_ba_result* result, int32_t device,
+                            const vslam_comm* comm) {
+    return ba_run(problem, result, device, comm);
+}
+
+vslam_status vslam_local_ba_timings(const char** names, float* ms, int32_t cap, int32_t* n_out) {
+    if (!n_out) return VSLAM_ERR_INVALID;
+    int n = 0;
+    for (const auto& it : g_baTimer.items) {
+        float v = 0;
+        if (hipEventElapsedTime(&v, it.a, it.b) != hipSuccess) v = 0.f;
+        int j = 0;
+        for (; j < n; j++) if (names && !strcmp(names[j], it.name)) break;
+        if (j == n) {
+            if (n >= cap) continue;
+            if (names) names[n] = it.name;
+            if (ms) ms[n] = 0.f;
+            n++;
+        }
+        if (ms) ms[j] += v;
+    }
+    *n_out = n;
+    return VSLAM_OK;
+}
+
+}  // extern "C"

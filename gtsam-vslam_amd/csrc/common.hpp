@@ -47,8 +47,9 @@ struct StageTimer {
     struct Item { const char* name; hipEvent_t a, b; };
     std::vector<Item> items;
     hipStream_t stream = nullptr;
+    bool multi = false;   // true: one event pair per invocation (summed by name on read-out)
     int begin(const char* name) {
-        for (size_t i = 0; i < items.size(); i++)
+        for (size_t i = 0; !multi && i < items.size(); i++)
             if (!strcmp(items[i].name, name)) { hipEventRecord(items[i].a, stream); return (int)i; }
         Item it; it.name = name;
         hipEventCreate(&it.a); hipEventCreate(&it.b);

@@ -103,6 +103,109 @@ VS_HD void pose_to_rm16(const DPose& T, double* M) {
     M[12] = M[13] = M[14] = 0; M[15] = 1;
 }
 
+
+// ---- Pose3 pieces of BetweenFactor<Pose3> (GTSAM 4.2 Pose3.cpp / SO3.cpp) -------------------
+VS_HD void skew3(const double* v, double* S) {
+    S[0] = 0; S[1] = -v[2]; S[2] = v[1]; S[3] = v[2]; S[4] = 0; S[5] = -v[0]; S[6] = -v[1]; S[7] = v[0]; S[8] = 0;
+}
+VS_HD void m3_axpy(double* y, const double* x, double a) { for (int i = 0; i < 9; i++) y[i] += a * x[i]; }
+
+// Pose3::Logmap
+VS_HD void pose3_logmap(const DPose& T, double* xi) {
+    double w[3];
+    so3_logmap(T.R, w);
+    const double t = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    xi[0] = w[0]; xi[1] = w[1]; xi[2] = w[2];
+    if (t < 1e-10) { xi[3] = T.t[0]; xi[4] = T.t[1]; xi[5] = T.t[2]; return; }
+    const double wn[3] = {w[0] / t, w[1] / t, w[2] / t};
+    double W[9], WT[3], WWT[3];
+    skew3(wn, W);
+    mat3_vec(W, T.t, WT);
+    mat3_vec(W, WT, WWT);
+    const double Tan = tan(0.5 * t);
+    for (int i = 0; i < 3; i++) xi[3 + i] = T.t[i] - (0.5 * t) * WT[i] + (1 - t / (2. * Tan)) * WWT[i];
+}
+
+// SO3::LogmapDerivative
+VS_HD void so3_logmap_derivative(const double* w, double* J) {
+    for (int i = 0; i < 9; i++) J[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    const double theta2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    if (theta2 <= DBL_EPSILON) return;
+    const double theta = sqrt(theta2);
+    double W[9], WW[9];
+    skew3(w, W);
+    mat3_mul(W, W, WW);
+    m3_axpy(J, W, 0.5);
+    m3_axpy(J, WW, 1 / (theta * theta) - (1 + cos(theta)) / (2 * theta * sin(theta)));
+}
+
+// Pose3::LogmapDerivative = [Jw 0; -Jw Q Jw, Jw] with Q = computeQforExpmapDerivative(xi)
+VS_HD void pose3_logmap_derivative(const DPose& T, double* J) {
+    double xi[6];
+    pose3_logmap(T, xi);
+    double Jw[9], V[9], W[9];
+    so3_logmap_derivative(xi, Jw);
+    skew3(xi + 3, V);
+    skew3(xi, W);
+    double WV[9], VW[9], WVW[9], WW[9], WWV[9], VWW[9], WVWW[9], tmp[9], WWVW[9];
+    mat3_mul(W, V, WV); mat3_mul(V, W, VW); mat3_mul(WV, W, WVW); mat3_mul(W, W, WW);
+    mat3_mul(WW, V, WWV); mat3_mul(VW, W, VWW); mat3_mul(WVW, W, WVWW);
+    mat3_mul(V, W, tmp); mat3_mul(WW, tmp, WWVW);
+    double t1[9], t2[9], t3[9], Q[9];
+    for (int i = 0; i < 9; i++) {
+        t1[i] = WV[i] + VW[i] - WVW[i];
+        t2[i] = WWV[i] + VWW[i] - 3.0 * WVW[i];
+        t3[i] = WVWW[i] + WWVW[i];
+        Q[i] = -0.5 * V[i];
+    }
+    const double phi = sqrt(xi[0] * xi[0] + xi[1] * xi[1] + xi[2] * xi[2]);
+    if (phi > 1e-5) {
+        const double s = sin(phi), c = cos(phi);
+        const double phi2 = phi * phi, phi3 = phi2 * phi, phi4 = phi3 * phi, phi5 = phi4 * phi;
+        m3_axpy(Q, t1, (phi - s) / phi3);
+        m3_axpy(Q, t2, (1 - phi2 / 2 - c) / phi4);
+        m3_axpy(Q, t3, -0.5 * ((1 - phi2 / 2 - c) / phi4 - 3 * (phi - s - phi3 / 6.) / phi5));
+    } else {
+        m3_axpy(Q, t1, 1. / 6.);
+        m3_axpy(Q, t2, -1. / 24.);
+        m3_axpy(Q, t3, 1. / 120.);
+    }
+    double JQ[9], Q2[9];
+    mat3_mul(Jw, Q, JQ);
+    mat3_mul(JQ, Jw, Q2);
+    for (int i = 0; i < 36; i++) J[i] = 0;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            J[i * 6 + j] = Jw[3 * i + j];
+            J[(3 + i) * 6 + j] = -Q2[3 * i + j];
+            J[(3 + i) * 6 + 3 + j] = Jw[3 * i + j];
+        }
+}
+
+// Pose3::AdjointMap = [R 0; [t]x R, R]
+VS_HD void pose3_adjoint(const DPose& T, double* A) {
+    double S[9], tR[9];
+    skew3(T.t, S);
+    mat3_mul(S, T.R, tR);
+    for (int i = 0; i < 36; i++) A[i] = 0;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            A[i * 6 + j] = T.R[3 * i + j];
+            A[(3 + i) * 6 + j] = tR[3 * i + j];
+            A[(3 + i) * 6 + 3 + j] = T.R[3 * i + j];
+        }
+}
+
+// inverse of a symmetric 3x3 by cofactors
+VS_HD void inv3sym(const double* H, double* Hi) {
+    const double a = H[0], b = H[1], c = H[2], d = H[4], e = H[5], f = H[8];
+    const double A = d * f - e * e, B = c * e - b * f, C = b * e - c * d;
+    const double id = 1.0 / (a * A + b * B + c * C);
+    Hi[0] = A * id; Hi[1] = B * id; Hi[2] = C * id;
+    Hi[3] = B * id; Hi[4] = (a * f - c * c) * id; Hi[5] = (b * c - a * e) * id;
+    Hi[6] = C * id; Hi[7] = (b * c - a * e) * id; Hi[8] = (a * d - b * b) * id;
+}
+
 // in-place Cholesky solve of an N x N SPD system (row-major), single thread
 template <int N>
 VS_HD bool chol_solve_n(double* A, double* b) {

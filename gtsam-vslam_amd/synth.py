@@ -156,3 +156,85 @@ def random_image(w, h, seed):
         img = np.tile(tex, reps)[:h, :w].astype(np.float32)
     img = img + rng.normal(0, 2.0, img.shape).astype(np.float32)
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def _small_pose(rng, rot_sigma, trans_sigma):
+    """Random small rigid perturbation exp([w, v])."""
+    w = rng.normal(0, rot_sigma, 3)
+    th = np.linalg.norm(w)
+    W = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    R = np.eye(3) + W if th < 1e-12 else np.eye(3) + np.sin(th) / th * W + (1 - np.cos(th)) / th ** 2 * W @ W
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = rng.normal(0, trans_sigma, 3)
+    return T
+
+
+def make_ba_problem(rig_name="euroc", n_local=10, n_fixed=4, n_lm=3000, seed=0xBA5E, max_views=12,
+                    pix_noise=0.5, pose_noise=(0.009, 0.02), point_noise=0.03, outlier_frac=0.02, circle=False):
+    """Flattened local-BA problem: keyframes on a trajectory (or on a circle looking
+    inward for the 64-KF global case), landmarks seen by every keyframe whose frustum holds them
+    (cap max_views), left + `close` right observations, pixel noise scaled by the octave."""
+    rig = RIGS[rig_name]
+    rng = np.random.Generator(np.random.PCG64(seed))
+    K = n_local + n_fixed
+    poses = []
+    for k in range(K):
+        if circle:
+            a = 2 * np.pi * k / K
+            c = np.array([5 * np.sin(a), 0.0, -5 * np.cos(a)])
+            z = -c / np.linalg.norm(c)
+            x = np.cross([0, 1.0, 0], z); x /= np.linalg.norm(x)
+            y = np.cross(z, x)
+            T = np.eye(4); T[:3, 0], T[:3, 1], T[:3, 2], T[:3, 3] = x, y, z, c
+        else:
+            T = pose_at(4 * k, rig["fps"])
+        poses.append(T)
+    poses = np.array(poses)
+    if circle:
+        lm = rng.uniform(-2, 2, (n_lm, 3))
+    else:
+        lm = np.stack([rng.uniform(-4, 4, n_lm), rng.uniform(-2.5, 2, n_lm), rng.uniform(2.0, 12, n_lm)], 1)
+    scale = 1.2 ** np.arange(8)
+    pk, pl, pf, puv, poct = [], [], [], [], []
+    for l in range(n_lm):
+        views = 0
+        order = rng.permutation(K)
+        for k in order:
+            Tcw = np.linalg.inv(poses[k])
+            q = Tcw[:3, :3] @ lm[l] + Tcw[:3, 3]
+            if q[2] <= 0.3:
+                continue
+            u = rig["fx"] * q[0] / q[2] + rig["cx"]; v = rig["fy"] * q[1] / q[2] + rig["cy"]
+            uR = rig["fx"] * (q[0] - rig["bl"]) / q[2] + rig["cx"]
+            if not (20 <= u < rig["w"] - 20 and 20 <= v < rig["h"] - 20 and 20 <= uR):
+                continue
+            oct_ = int(np.clip(np.round(np.log(max(q[2], 1e-3) / 2.0) / np.log(1.2)), 0, 7))
+            s = pix_noise * scale[oct_]
+            close = q[2] < 40 * rig["bl"]
+            kind = rng.random()
+            if kind < 0.07:         # right-only observation
+                flags = 2
+            elif close:
+                flags = 3
+            else:
+                flags = 1
+            nz = rng.normal(0, s, 4)
+            if rng.random() < outlier_frac:
+                nz += rng.normal(0, 25, 4)
+            pk.append(k); pl.append(l); pf.append(flags)
+            puv.append([u + nz[0], v + nz[1], uR + nz[2], v + nz[3]]); poct.append([oct_, oct_])
+            views += 1
+            if views >= max_views:
+                break
+    kf_fixed = np.zeros(K, np.uint8); kf_fixed[n_local:] = 1
+    kf_local = np.ones(K, np.uint8); kf_local[n_local:] = 0
+    init_poses = poses.copy()
+    for k in range(n_local):
+        init_poses[k] = poses[k] @ _small_pose(rng, pose_noise[0], pose_noise[1])
+    init_lm = lm + rng.normal(0, point_noise, lm.shape)
+    # keyframe ids: local ones are the newest
+    kf_id = np.concatenate([np.arange(n_fixed, K), np.arange(0, n_fixed)]).astype(np.int64)
+    return dict(rig=rig, kf_pose=init_poses, kf_pose_true=poses, kf_id=kf_id, kf_fixed=kf_fixed, kf_local=kf_local,
+                lm=init_lm, lm_true=lm, pair_kf=np.array(pk, np.int32), pair_lm=np.array(pl, np.int32),
+                pair_flags=np.array(pf, np.uint8), pair_uv=np.array(puv, np.float32), pair_oct=np.array(poct, np.int32))

@@ -265,3 +265,58 @@ def world_to_frame(matcher, T_cw, points, max_scale_dist, log_scale):
     _chk(matcher.L.vslam_world_to_frame(matcher.h, _p(T), n, _p(points), _p(msd), C.c_float(log_scale), _p(pl), _p(pr),
                                         _p(ll), _p(lr), _p(vf), _p(vr)))
     return pl, pr, ll, lr, vf, vr
+
+
+class BaProblem(C.Structure):
+    _fields_ = [("rig", Rig), ("n_levels", C.c_int32), ("sigma_factor", C.c_void_p), ("inv_sigma_factor", C.c_void_p),
+                ("n_kf", C.c_int32), ("kf_pose_wc", C.c_void_p), ("kf_id", C.c_void_p), ("kf_fixed", C.c_void_p),
+                ("kf_local", C.c_void_p), ("n_lm", C.c_int32), ("lm_xyz", C.c_void_p), ("n_pairs", C.c_int32),
+                ("pair_kf", C.c_void_p), ("pair_lm", C.c_void_p), ("pair_flags", C.c_void_p), ("pair_uv", C.c_void_p),
+                ("pair_octave", C.c_void_p)]
+
+
+class BaResult(C.Structure):
+    _fields_ = [("kf_pose_wc", C.c_void_p), ("lm_xyz", C.c_void_p), ("pair_wrong", C.c_void_p),
+                ("pair_wrong_pass1", C.c_void_p), ("report", LmReport * 2), ("n_residuals", C.c_int64),
+                ("n_landmarks", C.c_int64), ("n_free_kf", C.c_int64), ("sum_k2", C.c_int64)]
+
+
+def local_ba(rig, sigma_factor, inv_sigma_factor, prob, device=0):
+    """LocalMapper::localBA numerical core through the C ABI."""
+    L = lib()
+    kfPose = np.ascontiguousarray(prob["kf_pose"], np.float64).reshape(-1, 16)
+    kfId = np.ascontiguousarray(prob["kf_id"], np.int64)
+    kfFixed = np.ascontiguousarray(prob["kf_fixed"], np.uint8); kfLocal = np.ascontiguousarray(prob["kf_local"], np.uint8)
+    lm = np.ascontiguousarray(prob["lm"], np.float64).reshape(-1, 3)
+    pk = np.ascontiguousarray(prob["pair_kf"], np.int32); pl = np.ascontiguousarray(prob["pair_lm"], np.int32)
+    pf = np.ascontiguousarray(prob["pair_flags"], np.uint8)
+    puv = np.ascontiguousarray(prob["pair_uv"], np.float32).reshape(-1, 4)
+    poct = np.ascontiguousarray(prob["pair_oct"], np.int32).reshape(-1, 2)
+    sf = np.ascontiguousarray(sigma_factor, np.float32); isf = np.ascontiguousarray(inv_sigma_factor, np.float32)
+    P = BaProblem()
+    P.rig = make_rig(rig)
+    P.n_levels = len(sf); P.sigma_factor = _p(sf); P.inv_sigma_factor = _p(isf)
+    P.n_kf = len(kfPose); P.kf_pose_wc = _p(kfPose); P.kf_id = _p(kfId); P.kf_fixed = _p(kfFixed); P.kf_local = _p(kfLocal)
+    P.n_lm = len(lm); P.lm_xyz = _p(lm) if len(lm) else None
+    P.n_pairs = len(pk)
+    if len(pk):
+        P.pair_kf, P.pair_lm, P.pair_flags, P.pair_uv, P.pair_octave = _p(pk), _p(pl), _p(pf), _p(puv), _p(poct)
+    kfOut = np.zeros_like(kfPose); lmOut = np.zeros((max(len(lm), 1), 3))
+    wrong = np.zeros(max(len(pk), 1), np.uint8); wrong1 = np.zeros(max(len(pk), 1), np.uint8)
+    R = BaResult()
+    R.kf_pose_wc, R.lm_xyz, R.pair_wrong, R.pair_wrong_pass1 = _p(kfOut), _p(lmOut), _p(wrong), _p(wrong1)
+    _chk(L.vslam_local_ba(C.byref(P), C.byref(R), device, None))
+    reps = [dict(iterations=R.report[s].iterations, inner=R.report[s].inner_iterations,
+                 initialError=R.report[s].initial_error, finalError=R.report[s].final_error, lam=R.report[s].lam)
+            for s in range(2)]
+    return dict(kf_pose=kfOut.reshape(-1, 4, 4), lm=lmOut[:len(lm)], pair_wrong=wrong[:len(pk)],
+                pair_wrong1=wrong1[:len(pk)], reports=reps, residuals=R.n_residuals, landmarks=R.n_landmarks,
+                free_kf=R.n_free_kf, sum_k2=R.sum_k2)
+
+
+def local_ba_timings():
+    names = (C.c_char_p * 32)()
+    ms = (C.c_float * 32)()
+    n = C.c_int32()
+    _chk(lib().vslam_local_ba_timings(names, ms, 32, C.byref(n)))
+    return {names[i].decode(): float(ms[i]) for i in range(n.value)}

@@ -203,6 +203,54 @@ vslam_status vslam_world_to_frame(vslam_matcher* m, const double* T_cw, int32_t 
                                   int32_t* scale_level_l, int32_t* scale_level_r,
                                   uint8_t* in_frame, uint8_t* in_frame_r);
 
+/* ---------------------------------------------------------------------------
+ * Local bundle adjustment — replaces the numerical core of LocalMapper::localBA
+ * (include/OptimizationBA.h:75, src/OptimizationBA.cpp:543-873): GenericProjectionFactor
+ * (left, and right with the stereo extrinsics) per observation, BetweenFactor<Pose3>
+ * (sigma 0.01) between id-consecutive keyframes, NonlinearEquality on fixed keyframes,
+ * landmarks-first elimination (:942-953) = Schur complement onto the free keyframes, dense
+ * Cholesky of the reduced camera system, two LM passes (5 then 10 iterations, tol 1e-5)
+ * separated by the chi2 (7.815 * sigmaFactor) re-check (:787-871).  The walk over the
+ * KeyFrame / MapPoint pointer graph that selects the window (:438-516) stays on the caller's
+ * side; the problem arrives flattened, with dense keyframe / landmark indices.
+ * ------------------------------------------------------------------------- */
+typedef struct vslam_ba_problem {
+    vslam_rig rig;
+    int32_t n_levels;
+    const float* sigma_factor;      /* KeyFrame::sigmaFactor[n_levels]    (chi2 threshold multiplier) */
+    const float* inv_sigma_factor;  /* KeyFrame::InvSigmaFactor[n_levels] (noise sigma = 1/this)      */
+    int32_t n_kf;
+    const double* kf_pose_wc;       /* n_kf x 16 row-major, world <- camera (KeyFrame pose)           */
+    const int64_t* kf_id;           /* KeyFrame::numb (orders the BetweenFactor chain)                 */
+    const uint8_t* kf_fixed;        /* 1: pinned by NonlinearEquality (kf->fixed or a fixedKFs member) */
+    const uint8_t* kf_local;        /* 1: member of localKFs (its observations are chi2-checked)       */
+    int32_t n_lm;
+    const double* lm_xyz;           /* n_lm x 3 */
+    int32_t n_pairs;                /* (keyframe, landmark) entries of MapPoint::kFMatches             */
+    const int32_t* pair_kf;
+    const int32_t* pair_lm;
+    const uint8_t* pair_flags;      /* bit0: left factor, bit1: right factor (right-only or `close`)   */
+    const float* pair_uv;           /* n_pairs x 4: uL, vL, uR, vR (cv::KeyPoint::pt)                  */
+    const int32_t* pair_octave;     /* n_pairs x 2: octave of the left / right keypoint                */
+} vslam_ba_problem;
+
+typedef struct vslam_ba_result {
+    double* kf_pose_wc;             /* n_kf x 16 optimised poses (fixed ones unchanged)                */
+    double* lm_xyz;                 /* n_lm x 3 */
+    uint8_t* pair_wrong;            /* n_pairs: wrongMatches after the second pass                     */
+    uint8_t* pair_wrong_pass1;      /* optional (may be NULL): wrongMatches after the first pass       */
+    vslam_lm_report report[2];
+    int64_t n_residuals, n_landmarks, n_free_kf, sum_k2;   /* work figures of the last pass           */
+} vslam_ba_result;
+
+/* Opaque communicator for landmark-sharded BA over RCCL (NULL = single GPU). */
+typedef struct vslam_comm vslam_comm;
+
+vslam_status vslam_local_ba(const vslam_ba_problem* problem, vslam_ba_result* result, int32_t device,
+                            const vslam_comm* comm);
+/* device time per kernel group of the last vslam_local_ba call on this thread */
+vslam_status vslam_local_ba_timings(const char** names, float* ms, int32_t cap, int32_t* n_out);
+
 vslam_status vslam_matcher_timings(const vslam_matcher* m, const char** names, float* ms,
                                    int32_t cap, int32_t* n_out);
 

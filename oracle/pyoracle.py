@@ -222,3 +222,51 @@ def pose_lm_raw(rig, ftype, p, z, sigma, T_wc):
     lib().vo_pose_lm_raw(C.c_double(rig["fx"]), C.c_double(rig["fy"]), C.c_double(rig["cx"]), C.c_double(rig["cy"]),
                          C.c_float(rig["bl"]), len(ftype), _p(ftype), _p(p), _p(z), _p(sigma), _p(T), _p(rep))
     return T, dict(iterations=int(rep[0]), inner=int(rep[1]), initialError=rep[2], finalError=rep[3], lam=rep[4])
+
+
+# ---- local bundle adjustment -----------------------------------------------------------
+def local_ba(rig, sigma_factor, inv_sigma_factor, prob):
+    """prob: dict with kf_pose (K,4,4), kf_id, kf_fixed, kf_local, lm (L,3), pair_kf, pair_lm,
+    pair_flags, pair_uv (P,4), pair_oct (P,2)."""
+    kfPose = np.ascontiguousarray(prob["kf_pose"], np.float64).reshape(-1, 16)
+    K = len(kfPose)
+    kfId = np.ascontiguousarray(prob["kf_id"], np.int64)
+    kfFixed = np.ascontiguousarray(prob["kf_fixed"], np.uint8); kfLocal = np.ascontiguousarray(prob["kf_local"], np.uint8)
+    lm = np.ascontiguousarray(prob["lm"], np.float64).reshape(-1, 3)
+    pk = np.ascontiguousarray(prob["pair_kf"], np.int32); pl = np.ascontiguousarray(prob["pair_lm"], np.int32)
+    pf = np.ascontiguousarray(prob["pair_flags"], np.uint8)
+    puv = np.ascontiguousarray(prob["pair_uv"], np.float32).reshape(-1, 4)
+    poct = np.ascontiguousarray(prob["pair_oct"], np.int32).reshape(-1, 2)
+    sf = np.ascontiguousarray(sigma_factor, np.float32); isf = np.ascontiguousarray(inv_sigma_factor, np.float32)
+    P = len(pk)
+    kfOut = np.zeros_like(kfPose); lmOut = np.zeros_like(lm)
+    wrong = np.zeros(P, np.uint8); wrong1 = np.zeros(P, np.uint8)
+    rep = np.zeros(10, np.float64); stats = np.zeros(4, np.int64)
+    lib().vo_local_ba(C.c_double(rig["fx"]), C.c_double(rig["fy"]), C.c_double(rig["cx"]), C.c_double(rig["cy"]),
+                      C.c_float(rig["bl"]), _p(sf), _p(isf), len(sf), K, _p(kfPose), _p(kfId), _p(kfFixed), _p(kfLocal),
+                      len(lm), _p(lm), P, _p(pk), _p(pl), _p(pf), _p(puv), _p(poct), _p(kfOut), _p(lmOut), _p(wrong),
+                      _p(wrong1), _p(rep), _p(stats))
+    reps = [dict(iterations=int(rep[5 * s]), inner=int(rep[5 * s + 1]), initialError=rep[5 * s + 2],
+                 finalError=rep[5 * s + 3], lam=rep[5 * s + 4]) for s in range(2)]
+    return dict(kf_pose=kfOut.reshape(-1, 4, 4), lm=lmOut, pair_wrong=wrong, pair_wrong1=wrong1, reports=reps,
+                residuals=int(stats[0]), landmarks=int(stats[1]), free_kf=int(stats[2]), sum_k2=int(stats[3]))
+
+
+def pose3_logmap(T):
+    T = np.ascontiguousarray(T, np.float64); xi = np.zeros(6)
+    lib().vo_pose3_logmap(_p(T), _p(xi)); return xi
+
+
+def pose3_expmap(xi):
+    xi = np.ascontiguousarray(xi, np.float64); T = np.zeros((4, 4))
+    lib().vo_pose3_expmap(_p(xi), _p(T)); return T
+
+
+def pose3_logmap_derivative(T):
+    T = np.ascontiguousarray(T, np.float64); J = np.zeros((6, 6))
+    lib().vo_pose3_logmap_derivative(_p(T), _p(J)); return J
+
+
+def pose3_adjoint(T):
+    T = np.ascontiguousarray(T, np.float64); A = np.zeros((6, 6))
+    lib().vo_pose3_adjoint(_p(T), _p(A)); return A

@@ -240,3 +240,54 @@ int vo_pose_lm_raw(double fx, double fy, double cx, double cy, float baseline, i
 }
 
 }  // extern "C"
+
+// ---- local bundle adjustment --------------------------------------------------------------------
+#include "vo_ba.hpp"
+extern "C" {
+
+// Flattened problem (see include/vslam_hip.h vslam_ba_problem for the field meaning).
+// pair_flags bit0 = left factor, bit1 = right factor; pair_uv = [uL,vL,uR,vR]; pair_oct = [octL,octR].
+// Outputs: kf_pose_out (K x 16), lm_out (L x 3), pair_wrong (P), pair_wrong1 (P, after pass 1),
+// report (2 x 5), stats (4): residuals, landmarks, free KFs, sum k^2 of the last pass.
+void vo_local_ba(double fx, double fy, double cx, double cy, float baseline, const float* sigmaFactor,
+                 const float* invSigmaFactor, int nLevels, int K, const double* kfPose, const long long* kfId,
+                 const uint8_t* kfFixed, const uint8_t* kfLocal, int L, const double* lm, int NP,
+                 const int* pairKf, const int* pairLm, const uint8_t* pairFlags, const float* pairUv,
+                 const int* pairOct, double* kfPoseOut, double* lmOut, uint8_t* pairWrong,
+                 uint8_t* pairWrong1, double* report, long long* stats) {
+    BAProblem P;
+    P.rig = Rig{fx, fy, cx, cy, baseline, 0, 0};
+    P.sigmaFactor.assign(sigmaFactor, sigmaFactor + nLevels);
+    P.InvSigmaFactor.assign(invSigmaFactor, invSigmaFactor + nLevels);
+    P.kfPose.resize(K); P.kfId.resize(K); P.kfFixed.assign(kfFixed, kfFixed + K); P.kfLocal.assign(kfLocal, kfLocal + K);
+    for (int k = 0; k < K; k++) { P.kfPose[k] = pose_from_rowmajor16(kfPose + 16 * k); P.kfId[k] = (long)kfId[k]; }
+    P.lm.resize(L);
+    for (int l = 0; l < L; l++) for (int i = 0; i < 3; i++) P.lm[l].v[i] = lm[3 * l + i];
+    P.pairs.resize(NP);
+    for (int p = 0; p < NP; p++) {
+        BAPair& b = P.pairs[p];
+        b.kf = pairKf[p]; b.lm = pairLm[p];
+        b.hasLeft = pairFlags[p] & 1; b.hasRight = (pairFlags[p] >> 1) & 1;
+        b.uL = pairUv[4 * p]; b.vL = pairUv[4 * p + 1]; b.uR = pairUv[4 * p + 2]; b.vR = pairUv[4 * p + 3];
+        b.octL = pairOct[2 * p]; b.octR = pairOct[2 * p + 1];
+    }
+    BAResult R;
+    localBA(P, R);
+    for (int k = 0; k < K; k++) pose_to_rowmajor16(R.kfPose[k], kfPoseOut + 16 * k);
+    for (int l = 0; l < L; l++) for (int i = 0; i < 3; i++) lmOut[3 * l + i] = R.lm[l].v[i];
+    for (int p = 0; p < NP; p++) { pairWrong[p] = R.pairWrong[p]; if (pairWrong1) pairWrong1[p] = R.pairWrongPass1[p]; }
+    if (report)
+        for (int s = 0; s < 2; s++) {
+            report[5 * s] = R.rep[s].iterations; report[5 * s + 1] = R.rep[s].innerIterations;
+            report[5 * s + 2] = R.rep[s].initialError; report[5 * s + 3] = R.rep[s].finalError; report[5 * s + 4] = R.rep[s].lambda;
+        }
+    if (stats) { stats[0] = R.nResiduals; stats[1] = R.nLandmarks; stats[2] = R.nFreeKF; stats[3] = R.sumK2; }
+}
+
+// BetweenFactor<Pose3> pieces for the finite-difference tests
+void vo_pose3_logmap(const double* T16, double* xi6) { pose3_logmap(pose_from_rowmajor16(T16), xi6); }
+void vo_pose3_expmap(const double* xi6, double* T16) { pose_to_rowmajor16(se3_expmap(xi6), T16); }
+void vo_pose3_logmap_derivative(const double* T16, double* J36) { pose3_logmap_derivative(pose_from_rowmajor16(T16), J36); }
+void vo_pose3_adjoint(const double* T16, double* A36) { pose3_adjoint(pose_from_rowmajor16(T16), A36); }
+
+}  // extern "C"

@@ -21,47 +21,32 @@ static bool checkConvergence(const LMParams& p, double currentError, double newE
            (absoluteDecrease <= p.absoluteErrorTol);
 }
 
-void levenbergMarquardt(LMProblem& P, const LMParams& prm, LMReport& rep) {
-    const int n = P.dim;
+void levenbergMarquardtX(LMProblemX& P, const LMParams& prm, LMReport& rep) {
     double lambda = prm.lambdaInitial;
     int iterations = 0, inner = 0;
-    double error = P.errorAt(nullptr);
+    double error = P.error(false);
     rep.initialError = error;
-    std::vector<double> H, g, Hd, delta(n);
     if (!(error <= prm.errorTol) && iterations < prm.maxIterations) {
         double newError = error, currentError;
         do {
             currentError = newError;
-            P.linearize(H, g);
+            P.linearize();
             for (;;) {   // tryLambda
-                Hd = H;
-                for (int i = 0; i < n; i++) Hd[i * n + i] += lambda;
-                delta = g;
-                const bool solved = chol_solve(Hd, delta, n);
+                double linChange = 0;
+                const bool solved = P.solve(lambda, linChange);
                 bool stepOk = false, stop = false;
                 double newErr = std::numeric_limits<double>::infinity();
-                if (solved) {
-                    double dg = 0, dHd = 0;
-                    for (int i = 0; i < n; i++) {
-                        dg += delta[i] * g[i];
-                        double s = 0;
-                        for (int j = 0; j < n; j++) s += H[i * n + j] * delta[j];
-                        dHd += delta[i] * s;
+                if (solved && linChange >= 0) {
+                    newErr = P.error(true);
+                    const double costChange = error - newErr;
+                    if (linChange > std::numeric_limits<double>::epsilon() * error) {
+                        const double modelFidelity = costChange / linChange;
+                        stepOk = modelFidelity > prm.minModelFidelity;
                     }
-                    const double oldLin = error;
-                    const double linChange = dg - 0.5 * dHd;   // linear.error(0) - linear.error(delta)
-                    if (linChange >= 0) {
-                        newErr = P.errorAt(delta.data());
-                        const double costChange = error - newErr;
-                        if (linChange > std::numeric_limits<double>::epsilon() * oldLin) {
-                            const double modelFidelity = costChange / linChange;
-                            stepOk = modelFidelity > prm.minModelFidelity;
-                        }
-                        if (std::fabs(costChange) < prm.relativeErrorTol * error) stop = true;
-                    }
+                    if (std::fabs(costChange) < prm.relativeErrorTol * error) stop = true;
                 }
                 if (stepOk) {
-                    P.commit(delta.data());
+                    P.commit();
                     error = newErr;
                     lambda = std::max(prm.lambdaLowerBound, lambda / prm.lambdaFactor);
                     iterations++;
@@ -83,6 +68,32 @@ void levenbergMarquardt(LMProblem& P, const LMParams& prm, LMReport& rep) {
     rep.innerIterations = inner;
     rep.finalError = error;
     rep.lambda = lambda;
+}
+
+// dense normal-equation front end: H delta = g with H = A^T A + lambda I
+void levenbergMarquardt(LMProblem& P, const LMParams& prm, LMReport& rep) {
+    const int n = P.dim;
+    std::vector<double> H, g, Hd, delta(n);
+    LMProblemX X;
+    X.linearize = [&]() { P.linearize(H, g); };
+    X.solve = [&](double lambda, double& linChange) {
+        Hd = H;
+        for (int i = 0; i < n; i++) Hd[i * n + i] += lambda;
+        delta = g;
+        if (!chol_solve(Hd, delta, n)) return false;
+        double dg = 0, dHd = 0;
+        for (int i = 0; i < n; i++) {
+            dg += delta[i] * g[i];
+            double s = 0;
+            for (int j = 0; j < n; j++) s += H[i * n + j] * delta[j];
+            dHd += delta[i] * s;
+        }
+        linChange = dg - 0.5 * dHd;   // linear.error(0) - linear.error(delta)
+        return true;
+    };
+    X.error = [&](bool atDelta) { return P.errorAt(atDelta ? delta.data() : nullptr); };
+    X.commit = [&]() { P.commit(delta.data()); };
+    levenbergMarquardtX(X, prm, rep);
 }
 
 // ------------------------------------------------------------------------------------------------

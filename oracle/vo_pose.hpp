@@ -32,6 +32,16 @@ struct LMProblem {
 };
 void levenbergMarquardt(LMProblem& P, const LMParams& prm, LMReport& rep);
 
+// The same policy with the linear algebra left to the problem (used by local BA's Schur solve).
+struct LMProblemX {
+    std::function<void()> linearize;
+    // solve the system damped with lambda*I; on success set linChange = linear.error(0) - linear.error(delta)
+    std::function<bool(double lambda, double& linChange)> solve;
+    std::function<double(bool atDelta)> error;   // nonlinear error at the current values (or retracted by delta)
+    std::function<void()> commit;                // current <- retract(current, delta)
+};
+void levenbergMarquardtX(LMProblemX& P, const LMParams& prm, LMReport& rep);
+
 // --- pose-only problem ---------------------------------------------------------------------------
 struct PoseFactor {
     int type;          // 0 stereo (uL,uR,v), 1 mono left (u,v), 2 right-only (u,v) with extrinsics
