@@ -835,20 +835,10 @@ vslam_status vslam_local_ba(const vslam_ba_problem* problem, vslam_ba_result* re
 
 vslam_status vslam_local_ba_timings(const char** names, float* ms, int32_t cap, int32_t* n_out) {
     if (!n_out) return VSLAM_ERR_INVALID;
-    int n = 0;
-    for (const auto& it : g_baTimer.items) {
-        float v = 0;
-        if (hipEventElapsedTime(&v, it.a, it.b) != hipSuccess) v = 0.f;
-        int j = 0;
-        for (; j < n; j++) if (names && !strcmp(names[j], it.name)) break;
-        if (j == n) {
-            if (n >= cap) continue;
-            if (names) names[n] = it.name;
-            if (ms) ms[n] = 0.f;
-            n++;
-        }
-        if (ms) ms[j] += v;
-    }
+    const char* nm[64];
+    float tv[64];
+    int n = g_baTimer.read(nm, tv, cap < 64 ? cap : 64);
+    for (int i = 0; i < n; i++) { if (names) names[i] = nm[i]; if (ms) ms[i] = tv[i]; }
     *n_out = n;
     return VSLAM_OK;
 }

@@ -42,23 +42,49 @@ static inline int cv_ceil_d(double v) { int i = (int)v; return i + (i < v); }
 
 constexpr int MAX_LEVELS = 12;
 
-// Named per-stage device timers (HIP events on the object's stream).
+// Named per-stage device timers (HIP events on the object's stream).  In `multi` mode every
+// invocation gets its own event pair (pairs are pooled and reused after reset()); read-out sums by name.
 struct StageTimer {
     struct Item { const char* name; hipEvent_t a, b; };
     std::vector<Item> items;
+    size_t used = 0;
     hipStream_t stream = nullptr;
-    bool multi = false;   // true: one event pair per invocation (summed by name on read-out)
+    bool multi = false;
     int begin(const char* name) {
-        for (size_t i = 0; !multi && i < items.size(); i++)
-            if (!strcmp(items[i].name, name)) { hipEventRecord(items[i].a, stream); return (int)i; }
-        Item it; it.name = name;
-        hipEventCreate(&it.a); hipEventCreate(&it.b);
-        items.push_back(it);
-        hipEventRecord(items.back().a, stream);
-        return (int)items.size() - 1;
+        if (!multi) {
+            for (size_t i = 0; i < used; i++)
+                if (!strcmp(items[i].name, name)) { hipEventRecord(items[i].a, stream); return (int)i; }
+        }
+        if (used == items.size()) {
+            Item it; it.name = name;
+            hipEventCreate(&it.a); hipEventCreate(&it.b);
+            items.push_back(it);
+        }
+        items[used].name = name;
+        hipEventRecord(items[used].a, stream);
+        return (int)used++;
     }
     void end(int i) { hipEventRecord(items[i].b, stream); }
-    void destroy() { for (auto& it : items) { hipEventDestroy(it.a); hipEventDestroy(it.b); } items.clear(); }
+    void reset() { used = 0; }
+    void destroy() { for (auto& it : items) { hipEventDestroy(it.a); hipEventDestroy(it.b); } items.clear(); used = 0; }
+    // sums by name; returns number of distinct names written
+    int read(const char** names, float* ms, int cap) const {
+        int n = 0;
+        for (size_t k = 0; k < used; k++) {
+            float v = 0;
+            if (hipEventElapsedTime(&v, items[k].a, items[k].b) != hipSuccess) v = 0.f;
+            int j = 0;
+            for (; j < n; j++) if (!strcmp(names[j], items[k].name)) break;
+            if (j == n) {
+                if (n >= cap) continue;
+                names[n] = items[k].name;
+                ms[n] = 0.f;
+                n++;
+            }
+            ms[j] += v;
+        }
+        return n;
+    }
 };
 
 }  // namespace vslam

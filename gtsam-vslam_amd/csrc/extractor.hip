@@ -490,15 +490,10 @@ vslam_status vslam_extractor_candidates(vslam_extractor* ex, int32_t i, int32_t 
 
 vslam_status vslam_extractor_timings(const vslam_extractor* ex, const char** names, float* ms, int32_t cap, int32_t* n_out) {
     if (!ex || !n_out) return VSLAM_ERR_INVALID;
-    int n = 0;
-    for (const auto& it : ex->timer.items) {
-        if (n >= cap) break;
-        float v = 0;
-        if (hipEventElapsedTime(&v, it.a, it.b) != hipSuccess) v = -1.f;
-        if (names) names[n] = it.name;
-        if (ms) ms[n] = v;
-        n++;
-    }
+    const char* nm[64];
+    float tv[64];
+    int n = ex->timer.read(nm, tv, cap < 64 ? cap : 64);
+    for (int i = 0; i < n; i++) { if (names) names[i] = nm[i]; if (ms) ms[i] = tv[i]; }
     *n_out = n;
     return VSLAM_OK;
 }

@@ -43,6 +43,7 @@ struct vslam_matcher {
     int* d_matchedR = nullptr;
     int* d_projOut = nullptr;    // {nMatches}
     vslam_status ensure_proj_cap(int M);
+    vslam_status proj_enqueue(int M, float rad);
     vslam_status match_projection(const vslam_mappoint_view* mps, int M, float rad, int* mL, int* mR,
                                   int* matches, int* nMatches, long long* nCand);
 
@@ -55,7 +56,21 @@ struct vslam_matcher {
     double* d_poseIO = nullptr;      // 16 T_cw + report(8)
     int* d_poseOut = nullptr;        // nIn, nStereo, iterations, inner
     vslam_status ensure_pose_cap(int M);
+    vslam_status pose_enqueue(int M);
     vslam_status estimate_pose(vslam_pose_problem* prob, int* nIn, int* nStereo, vslam_lm_report* rep);
+
+    // tracker state (FeatureTracker's activeMapPoints, flattened and device-resident)
+    int trCap = 0, trN = 0;
+    double* d_trXyz = nullptr;       // [N][3]
+    uint8_t* d_trDesc = nullptr;     // [N][32]
+    float* d_trMsd = nullptr;        // [N] MapPoint::maxScaleDist
+    uint8_t* d_trOutlier = nullptr;  // [N] MapPoint::GetIsOutlier
+    int* d_trAct = nullptr;          // [N] source index of each active map point of the current frame
+    int* d_trCount = nullptr;        // {trN, actN}
+    int actN = 0;
+    vslam_status ensure_track_cap(int n);
+    vslam_status track_init_map(const double* T_wc);
+    vslam_status track_frame(const double* T_wc_pred, int frameNumber, double* T_cw_out, vslam_track_report* rep);
 
     vslam_status init(const vslam_rig* r, vslam_extractor* l, int il, vslam_extractor* rr, int ir);
     void release();

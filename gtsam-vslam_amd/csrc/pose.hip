@@ -416,6 +416,26 @@ vslam_status vslam_matcher::ensure_pose_cap(int M) {
     return VSLAM_OK;
 }
 
+// device-resident form: d_points / d_flags / d_matches / d_poseIO already hold the inputs
+vslam_status vslam_matcher::pose_enqueue(int M) {
+    uint8_t* fl = d_flags;
+    const size_t pc = (size_t)poseCap;
+    PoseArgs A{};
+    A.M = M; A.points = d_points; A.inFrame = fl; A.inFrameR = fl + pc; A.mpOut = fl + 2 * pc; A.mpsOut = fl + 3 * pc;
+    A.matches = d_matches; A.kpsL = d_kps[0]; A.kpsR = d_kps[1];
+    A.closef = d_close; A.depth = d_depth; A.rightIdxs = d_rightIdxs; A.leftIdxs = d_leftIdxs;
+    A.fx = rig.fx; A.fy = rig.fy; A.cx = rig.cx; A.cy = rig.cy; A.b = (double)rig.baseline;
+    for (int l = 0; l < feL->nLevels; l++) A.invSigma[l] = feL->InvSigmaFactor[l];
+    A.closeTh = rig.baseline * 40;
+    A.factors = d_factors; A.firstFail = d_firstFail; A.code = (int*)(fl + 4 * pc); A.poseIO = d_poseIO; A.out = d_poseOut;
+    A.maxIterations = 100; A.relTol = 1e-5; A.absTol = 1e-5; A.thres = 7.815;
+    int t = timer.begin("pose_lm");
+    hipLaunchKernelGGL(k_pose_lm, dim3(1), dim3(1024), 0, stream, A);
+    timer.end(t);
+    VS_HIP(hipGetLastError());
+    return VSLAM_OK;
+}
+
 vslam_status vslam_matcher::estimate_pose(vslam_pose_problem* prob, int* nIn, int* nStereo, vslam_lm_report* rep) {
     if (!prob || prob->n_mps < 0) return VSLAM_ERR_INVALID;
     const int M = prob->n_mps;
@@ -437,19 +457,7 @@ vslam_status vslam_matcher::estimate_pose(vslam_pose_problem* prob, int* nIn, in
         VS_HIP(hipMemcpyAsync(d_matches, prob->matches, (size_t)M * 8, hipMemcpyHostToDevice, stream));
     }
     VS_HIP(hipMemcpyAsync(d_poseIO, prob->T_cw, 16 * sizeof(double), hipMemcpyHostToDevice, stream));
-    PoseArgs A{};
-    A.M = M; A.points = d_points; A.inFrame = fl; A.inFrameR = fl + pc; A.mpOut = fl + 2 * pc; A.mpsOut = fl + 3 * pc;
-    A.matches = d_matches; A.kpsL = d_kps[0]; A.kpsR = d_kps[1];
-    A.closef = d_close; A.depth = d_depth; A.rightIdxs = d_rightIdxs; A.leftIdxs = d_leftIdxs;
-    A.fx = rig.fx; A.fy = rig.fy; A.cx = rig.cx; A.cy = rig.cy; A.b = (double)rig.baseline;
-    for (int l = 0; l < feL->nLevels; l++) A.invSigma[l] = feL->InvSigmaFactor[l];
-    A.closeTh = rig.baseline * 40;
-    A.factors = d_factors; A.firstFail = d_firstFail; A.code = (int*)(fl + 4 * pc); A.poseIO = d_poseIO; A.out = d_poseOut;
-    A.maxIterations = 100; A.relTol = 1e-5; A.absTol = 1e-5; A.thres = 7.815;
-    int t = timer.begin("pose_lm");
-    hipLaunchKernelGGL(k_pose_lm, dim3(1), dim3(1024), 0, stream, A);
-    timer.end(t);
-    VS_HIP(hipGetLastError());
+    VS_CHECK(pose_enqueue(M));
     double io[19];
     int out[4];
     VS_HIP(hipMemcpyAsync(io, d_poseIO, sizeof(io), hipMemcpyDeviceToHost, stream));

@@ -248,7 +248,7 @@ void launch_proj_resolve(hipStream_t s, const ProjArgs& A, const unsigned long l
 using namespace vslam;
 
 vslam_status vslam_matcher::ensure_proj_cap(int M) {
-    if (M <= projCap && d_matchedL) return VSLAM_OK;
+    if (M <= projCap && d_matchedL && d_projOut) return VSLAM_OK;
     if (M > projCap) {
         hipFree(d_mpv); hipFree(d_topk); hipFree(d_matches);
         projCap = vslam::align_up(std::max(M, 1), 1024);
@@ -257,27 +257,15 @@ vslam_status vslam_matcher::ensure_proj_cap(int M) {
         VS_HIP(hipMalloc(&d_matches, (size_t)projCap * 2 * sizeof(int)));
     }
     if (!d_projOut) VS_HIP(hipMalloc(&d_projOut, 4 * sizeof(int)));
-    return VSLAM_OK;
-}
-
-vslam_status vslam_matcher::match_projection(const vslam_mappoint_view* mps, int M, float rad, int* mL,
-                                             int* mR, int* matches, int* nMatches, long long* nCand) {
-    if (M < 0 || (M > 0 && (!mps || !matches)) || !mL || !mR) { set_error("match_projection: bad argument"); return VSLAM_ERR_INVALID; }
-    if (!stereoDone) { set_error("match_projection needs a completed stereo match"); return VSLAM_ERR_INVALID; }
-    VS_HIP(hipSetDevice(device));
-    VS_CHECK(refresh_keys());
-    VS_CHECK(ensure_proj_cap(M));
-    const int nL = nKeys[0], nR = nKeys[1];
     if (!d_matchedL) {
         VS_HIP(hipMalloc(&d_matchedL, (size_t)65536 * sizeof(int)));
         VS_HIP(hipMalloc(&d_matchedR, (size_t)65536 * sizeof(int)));
     }
-    if (M) {
-        VS_HIP(hipMemcpyAsync(d_mpv, mps, (size_t)M * sizeof(vslam_mappoint_view), hipMemcpyHostToDevice, stream));
-        VS_HIP(hipMemcpyAsync(d_matches, matches, (size_t)M * 2 * sizeof(int), hipMemcpyHostToDevice, stream));
-    }
-    if (nL) VS_HIP(hipMemcpyAsync(d_matchedL, mL, (size_t)nL * sizeof(int), hipMemcpyHostToDevice, stream));
-    if (nR) VS_HIP(hipMemcpyAsync(d_matchedR, mR, (size_t)nR * sizeof(int), hipMemcpyHostToDevice, stream));
+    return VSLAM_OK;
+}
+
+// device-resident form: d_mpv / d_matches / d_matchedL / d_matchedR already hold the inputs
+vslam_status vslam_matcher::proj_enqueue(int M, float rad) {
     ProjArgs A{};
     for (int s = 0; s < 2; s++) { A.kps[s] = d_kps[s]; A.desc[s] = d_desc[s]; A.n[s] = nKeys[s]; }
     A.mpv = d_mpv; A.M = M; A.rad = rad;
@@ -289,7 +277,6 @@ vslam_status vslam_matcher::match_projection(const vslam_mappoint_view* mps, int
     A.xMult = (float)A.xGrids / (float)rig.width;
     A.yMult = (float)A.yGrids / (float)rig.height;
     A.rightIdxs = d_rightIdxs; A.leftIdxs = d_leftIdxs;
-    VS_HIP(hipMemsetAsync(d_stats + 3, 0, sizeof(unsigned long long), stream));
     int t = timer.begin("proj_candidates");
     launch_proj_candidates(stream, A, d_matches, d_topk, d_stats);
     timer.end(t);
@@ -297,6 +284,25 @@ vslam_status vslam_matcher::match_projection(const vslam_mappoint_view* mps, int
     launch_proj_resolve(stream, A, d_topk, d_matchedL, d_matchedR, d_matches, d_projOut);
     timer.end(t);
     VS_HIP(hipGetLastError());
+    return VSLAM_OK;
+}
+
+vslam_status vslam_matcher::match_projection(const vslam_mappoint_view* mps, int M, float rad, int* mL,
+                                             int* mR, int* matches, int* nMatches, long long* nCand) {
+    if (M < 0 || (M > 0 && (!mps || !matches)) || !mL || !mR) { set_error("match_projection: bad argument"); return VSLAM_ERR_INVALID; }
+    if (!stereoDone) { set_error("match_projection needs a completed stereo match"); return VSLAM_ERR_INVALID; }
+    VS_HIP(hipSetDevice(device));
+    VS_CHECK(refresh_keys());
+    VS_CHECK(ensure_proj_cap(M));
+    const int nL = nKeys[0], nR = nKeys[1];
+    if (M) {
+        VS_HIP(hipMemcpyAsync(d_mpv, mps, (size_t)M * sizeof(vslam_mappoint_view), hipMemcpyHostToDevice, stream));
+        VS_HIP(hipMemcpyAsync(d_matches, matches, (size_t)M * 2 * sizeof(int), hipMemcpyHostToDevice, stream));
+    }
+    if (nL) VS_HIP(hipMemcpyAsync(d_matchedL, mL, (size_t)nL * sizeof(int), hipMemcpyHostToDevice, stream));
+    if (nR) VS_HIP(hipMemcpyAsync(d_matchedR, mR, (size_t)nR * sizeof(int), hipMemcpyHostToDevice, stream));
+    VS_HIP(hipMemsetAsync(d_stats + 3, 0, sizeof(unsigned long long), stream));
+    VS_CHECK(proj_enqueue(M, rad));
     int out = 0;
     unsigned long long nc = 0;
     if (M) VS_HIP(hipMemcpyAsync(matches, d_matches, (size_t)M * 2 * sizeof(int), hipMemcpyDeviceToHost, stream));

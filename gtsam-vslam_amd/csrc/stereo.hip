@@ -300,6 +300,7 @@ void vslam_matcher::release() {
     hipFree(d_mBest); hipFree(d_mDepth); hipFree(d_mSad); hipFree(d_rightIdxs); hipFree(d_leftIdxs);
     hipFree(d_depth); hipFree(d_close); hipFree(d_stats);
     for (int s = 0; s < 2; s++) { hipFree(d_okps[s]); hipFree(d_odesc[s]); }
+    hipFree(d_trXyz); hipFree(d_trDesc); hipFree(d_trMsd); hipFree(d_trOutlier); hipFree(d_trAct); hipFree(d_trCount);
     hipFree(d_points); hipFree(d_flags); hipFree(d_factors); hipFree(d_firstFail); hipFree(d_poseIO); hipFree(d_poseOut);
     hipFree(d_mpv); hipFree(d_topk); hipFree(d_matches); hipFree(d_matchedL); hipFree(d_matchedR); hipFree(d_projOut);
     if (stream) hipStreamDestroy(stream);
@@ -421,15 +422,10 @@ vslam_status vslam_stereo_fetch(vslam_matcher* m, int32_t* right_idxs, int32_t* 
 
 vslam_status vslam_matcher_timings(const vslam_matcher* m, const char** names, float* ms, int32_t cap, int32_t* n_out) {
     if (!m || !n_out) return VSLAM_ERR_INVALID;
-    int n = 0;
-    for (const auto& it : m->timer.items) {
-        if (n >= cap) break;
-        float v = 0;
-        if (hipEventElapsedTime(&v, it.a, it.b) != hipSuccess) v = -1.f;
-        if (names) names[n] = it.name;
-        if (ms) ms[n] = v;
-        n++;
-    }
+    const char* nm[64];
+    float tv[64];
+    int n = m->timer.read(nm, tv, cap < 64 ? cap : 64);
+    for (int i = 0; i < n; i++) { if (names) names[i] = nm[i]; if (ms) ms[i] = tv[i]; }
     *n_out = n;
     return VSLAM_OK;
 }

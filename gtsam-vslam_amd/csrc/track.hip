@@ -1,0 +1,332 @@
+// Per-frame tracking loop on device-resident state: the stereo path of FeatureTracker::TrackImage
+// (reference src/FeatureTracker.cpp:1108-1278) with initializeMap (:72-123), removeOutOfFrameMPs
+// (:910-939), PredictMPsPosition (:969-1014), worldToFrame (:685-741), MapPoint::update /
+// predictScale (src/Map.cpp:13-23,58-100).  The map points live in HBM as SoA (position, 32-byte
+// descriptor, maxScaleDist); each stage writes straight into the buffers the projection-matching
+// and pose-LM kernels read, so a frame needs no host<->device traffic except the few scalars the
+// reference's own retry rule inspects (inlier count per round).
+#include "matcher.hpp"
+#include "dmath.hpp"
+
+namespace vslam {
+
+// order-preserving compaction helper: exclusive scan of a 0/1 flag over one 1024-thread workgroup
+__device__ __forceinline__ int block_excl_scan_1024(int flag, int* wsum, int& total) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long bal = __ballot(flag);
+    const int lanePrefix = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int off = 0, tot = 0;
+    for (int k = 0; k < 16; k++) { const int v = wsum[k]; if (k < wave) off += v; tot += v; }
+    __syncthreads();
+    total = tot;
+    return off + lanePrefix;
+}
+
+// initializeMap: one map point per left keypoint with estimatedDepth > 0, in keypoint order
+__global__ __launch_bounds__(1024) void k_init_map(int nL, const vslam_keypoint* __restrict__ kps,
+                                                   const uint8_t* __restrict__ desc,
+                                                   const float* __restrict__ depth, DPose Twc, double fx,
+                                                   double fy, double cx, double cy, LevelTables T,
+                                                   double* __restrict__ xyz, uint8_t* __restrict__ odesc,
+                                                   float* __restrict__ msd, uint8_t* __restrict__ outl,
+                                                   int cap, int* __restrict__ count) {
+    __shared__ int wsum[16];
+    int run = 0;
+    for (int base = 0; base < nL; base += 1024) {
+        const int i = base + threadIdx.x;
+        const bool keep = i < nL && depth[i] > 0;
+        int tot;
+        const int pos = run + block_excl_scan_1024(keep, wsum, tot);
+        if (keep && pos < cap) {
+            const vslam_keypoint k = kps[i];
+            const double zp = (double)depth[i];
+            const double xp = ((double)k.x - cx) * zp / fx;
+            const double yp = ((double)k.y - cy) * zp / fy;
+            const double pc[3] = {xp, yp, zp};
+            double pw[3];
+            mat3_vec(Twc.R, pc, pw);
+            for (int c = 0; c < 3; c++) pw[c] += Twc.t[c];
+            xyz[3 * (size_t)pos] = pw[0]; xyz[3 * (size_t)pos + 1] = pw[1]; xyz[3 * (size_t)pos + 2] = pw[2];
+            const uint4* s = (const uint4*)(desc + (size_t)i * 32);
+            uint4* d = (uint4*)(odesc + (size_t)pos * 32);
+            d[0] = s[0]; d[1] = s[1];
+            // MapPoint::update: maxScaleDist = float(|p - camera|) * scaleFactor[octave]
+            const double dx = pw[0] - Twc.t[0], dy = pw[1] - Twc.t[1], dz = pw[2] - Twc.t[2];
+            const float dist = (float)sqrt(dx * dx + dy * dy + dz * dz);
+            msd[pos] = dist * T.scalePyr[k.octave];
+            outl[pos] = 0;
+        }
+        run += tot;
+    }
+    if (threadIdx.x == 0) count[0] = run < cap ? run : cap;
+}
+
+struct W2F { bool vis; float u, v; int lvl; };
+__device__ __forceinline__ W2F world_to_frame(const double* pc, bool right, double fx, double fy, double cx,
+                                              double cy, double b, int w, int h, float maxScaleDist,
+                                              double logScale, int nLev) {
+    W2F r{false, 0.f, 0.f, 0};
+    const double x = right ? pc[0] - b : pc[0], y = pc[1], z = pc[2];
+    if (z <= 0.0) return r;
+    const double invZ = 1.0 / z;
+    const double u = fx * x * invZ + cx, v = fy * y * invZ + cy;
+    if (u < 0 || v < 0 || u >= w || v >= h) return r;
+    const float dist = (float)sqrt(x * x + y * y + z * z);
+    const float dif = maxScaleDist / dist;
+    const double s = log((double)dif) / logScale;
+    int sc = (int)s;
+    sc += (sc < s);
+    if (sc < 0) sc = 0; else if (sc >= nLev) sc = nLev - 1;
+    r.vis = true; r.u = (float)u; r.v = (float)v; r.lvl = sc;
+    return r;
+}
+
+struct TrackGeom { double fx, fy, cx, cy, b; int w, h; double logScale; int nLev; };
+
+// removeOutOfFrameMPs: keep the map points visible in BOTH cameras under the predicted pose,
+// order preserved; fills every per-frame buffer of the matching / pose kernels.
+__global__ __launch_bounds__(1024) void k_track_predict(int N, const double* __restrict__ xyz,
+                                                        const uint8_t* __restrict__ desc,
+                                                        const float* __restrict__ msd,
+                                                        const uint8_t* __restrict__ outl, DPose Tcw,
+                                                        TrackGeom G, vslam_mappoint_view* __restrict__ mpv,
+                                                        double* __restrict__ points, uint8_t* __restrict__ flags,
+                                                        size_t flagStride, int* __restrict__ matches,
+                                                        int* __restrict__ act, int* __restrict__ count) {
+    __shared__ int wsum[16];
+    int run = 0;
+    for (int base = 0; base < N; base += 1024) {
+        const int i = base + threadIdx.x;
+        bool keep = false;
+        W2F l{}, r{};
+        if (i < N && !outl[i]) {
+            const double p[3] = {xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]};
+            double pc[3];
+            mat3_vec(Tcw.R, p, pc);
+            for (int c = 0; c < 3; c++) pc[c] += Tcw.t[c];
+            l = world_to_frame(pc, false, G.fx, G.fy, G.cx, G.cy, G.b, G.w, G.h, msd[i], G.logScale, G.nLev);
+            r = world_to_frame(pc, true, G.fx, G.fy, G.cx, G.cy, G.b, G.w, G.h, msd[i], G.logScale, G.nLev);
+            keep = l.vis && r.vis;
+        }
+        int tot;
+        const int pos = run + block_excl_scan_1024(keep, wsum, tot);
+        if (keep) {
+            vslam_mappoint_view v;
+            const uint4* s = (const uint4*)(desc + (size_t)i * 32);
+            uint4* d = (uint4*)v.desc;
+            d[0] = s[0]; d[1] = s[1];
+            v.pred_lx = l.u; v.pred_ly = l.v; v.pred_rx = r.u; v.pred_ry = r.v;
+            v.scale_level_l = l.lvl; v.scale_level_r = r.lvl;
+            v.in_frame = 1; v.in_frame_r = 1; v.pad_[0] = v.pad_[1] = 0;
+            mpv[pos] = v;
+            points[3 * (size_t)pos] = xyz[3 * (size_t)i];
+            points[3 * (size_t)pos + 1] = xyz[3 * (size_t)i + 1];
+            points[3 * (size_t)pos + 2] = xyz[3 * (size_t)i + 2];
+            flags[pos] = 1; flags[flagStride + pos] = 1; flags[2 * flagStride + pos] = 0; flags[3 * flagStride + pos] = 0;
+            matches[2 * pos] = -1; matches[2 * pos + 1] = -1;
+            act[pos] = i;
+        }
+        run += tot;
+    }
+    if (threadIdx.x == 0) count[1] = run;
+}
+
+__global__ __launch_bounds__(256) void k_fill_int(int* p, int n, int v) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// reset of a failed round (src/FeatureTracker.cpp:1211-1216)
+__global__ __launch_bounds__(256) void k_track_reset(int M, int* matches, uint8_t* mpsOut) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < M) { matches[2 * i] = -1; matches[2 * i + 1] = -1; mpsOut[i] = 0; }
+}
+
+// PredictMPsPosition with the estimated pose (src/FeatureTracker.cpp:969-1014)
+__global__ __launch_bounds__(256) void k_track_repredict(int M, const double* __restrict__ points,
+                                                         const float* __restrict__ msd,
+                                                         const int* __restrict__ act, const double* __restrict__ poseIO,
+                                                         TrackGeom G, vslam_mappoint_view* __restrict__ mpv,
+                                                         uint8_t* __restrict__ flags, size_t flagStride,
+                                                         int* __restrict__ matches, int* __restrict__ matchedL,
+                                                         int* __restrict__ matchedR) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    DPose Tcw;
+    pose_from_rm16(poseIO, Tcw);
+    const double p[3] = {points[3 * (size_t)i], points[3 * (size_t)i + 1], points[3 * (size_t)i + 2]};
+    double pc[3];
+    mat3_vec(Tcw.R, p, pc);
+    for (int c = 0; c < 3; c++) pc[c] += Tcw.t[c];
+    const float m = msd[act[i]];
+    const W2F l = world_to_frame(pc, false, G.fx, G.fy, G.cx, G.cy, G.b, G.w, G.h, m, G.logScale, G.nLev);
+    const W2F r = world_to_frame(pc, true, G.fx, G.fy, G.cx, G.cy, G.b, G.w, G.h, m, G.logScale, G.nLev);
+    vslam_mappoint_view* v = mpv + i;
+    int first = matches[2 * i], second = matches[2 * i + 1];
+    v->in_frame = l.vis; flags[i] = l.vis;
+    if (l.vis) { v->pred_lx = l.u; v->pred_ly = l.v; v->scale_level_l = l.lvl; }
+    else if (first >= 0) { matchedL[first] = -1; first = -1; }
+    v->in_frame_r = r.vis; flags[flagStride + i] = r.vis;
+    if (r.vis) { v->pred_rx = r.u; v->pred_ry = r.v; v->scale_level_r = r.lvl; }
+    else if (second >= 0) { matchedR[second] = -1; second = -1; }
+    if (flags[3 * flagStride + i]) {
+        flags[3 * flagStride + i] = 0;
+        if (first >= 0) { matchedL[first] = -1; first = -1; }
+        if (second >= 0) { matchedR[second] = -1; second = -1; }
+    }
+    matches[2 * i] = first; matches[2 * i + 1] = second;
+}
+
+}  // namespace vslam
+
+using namespace vslam;
+
+vslam_status vslam_matcher::ensure_track_cap(int n) {
+    if (n <= trCap && d_trCount) return VSLAM_OK;
+    if (n > trCap) {
+        double* nx = nullptr; uint8_t* nd = nullptr; float* nm = nullptr; uint8_t* no = nullptr; int* na = nullptr;
+        const int cap = vslam::align_up(std::max(n, 1), 1024);
+        VS_HIP(hipMalloc(&nx, (size_t)cap * 24));
+        VS_HIP(hipMalloc(&nd, (size_t)cap * 32));
+        VS_HIP(hipMalloc(&nm, (size_t)cap * 4));
+        VS_HIP(hipMalloc(&no, (size_t)cap));
+        VS_HIP(hipMalloc(&na, (size_t)cap * 4));
+        hipFree(d_trXyz); hipFree(d_trDesc); hipFree(d_trMsd); hipFree(d_trOutlier); hipFree(d_trAct);
+        d_trXyz = nx; d_trDesc = nd; d_trMsd = nm; d_trOutlier = no; d_trAct = na;
+        trCap = cap;
+    }
+    if (!d_trCount) { VS_HIP(hipMalloc(&d_trCount, 4 * sizeof(int))); VS_HIP(hipMemset(d_trCount, 0, 4 * sizeof(int))); }
+    return VSLAM_OK;
+}
+
+vslam_status vslam_matcher::track_init_map(const double* T_wc) {
+    if (!T_wc) return VSLAM_ERR_INVALID;
+    if (!stereoDone) { set_error("tracker_init_map needs a completed stereo match"); return VSLAM_ERR_INVALID; }
+    VS_HIP(hipSetDevice(device));
+    VS_CHECK(refresh_keys());
+    const int nL = nKeys[0];
+    VS_CHECK(ensure_track_cap(nL));
+    DPose T;
+    pose_from_rm16(T_wc, T);
+    int t = timer.begin("track_init_map");
+    hipLaunchKernelGGL(k_init_map, dim3(1), dim3(1024), 0, stream, nL, d_kps[0], d_desc[0], d_depth, T, rig.fx, rig.fy,
+                       rig.cx, rig.cy, feL->T, d_trXyz, d_trDesc, d_trMsd, d_trOutlier, trCap, d_trCount);
+    timer.end(t);
+    VS_HIP(hipGetLastError());
+    VS_HIP(hipMemcpyAsync(&trN, d_trCount, sizeof(int), hipMemcpyDeviceToHost, stream));
+    VS_HIP(hipStreamSynchronize(stream));
+    return VSLAM_OK;
+}
+
+vslam_status vslam_matcher::track_frame(const double* T_wc_pred, int frameNumber, double* T_cw_out,
+                                        vslam_track_report* rep) {
+    if (!T_wc_pred || !T_cw_out) return VSLAM_ERR_INVALID;
+    if (!stereoDone) { set_error("tracker_track needs a completed stereo match of the new frame"); return VSLAM_ERR_INVALID; }
+    VS_HIP(hipSetDevice(device));
+    VS_CHECK(refresh_keys());
+    VS_CHECK(ensure_track_cap(std::max(trN, 1)));
+    VS_CHECK(ensure_pose_cap(std::max(trN, 1)));
+    VS_CHECK(ensure_proj_cap(std::max(trN, 1)));
+    const int nL = nKeys[0], nR = nKeys[1];
+    DPose Twc, Tcw;
+    pose_from_rm16(T_wc_pred, Twc);
+    pose_inverse(Twc, Tcw);
+    double predInv[16];
+    pose_to_rm16(Tcw, predInv);                       // predNPoseInv: initial estimPose
+    TrackGeom G{rig.fx, rig.fy, rig.cx, rig.cy, (double)rig.baseline, rig.width, rig.height,
+                (double)(float)std::log((double)feL->prm.scale), feL->nLevels};   // KeyFrame::logScale is a float
+    uint8_t* fl = d_flags;
+    const size_t pc = (size_t)poseCap;
+
+    int t = timer.begin("track_predict");
+    hipLaunchKernelGGL(k_track_predict, dim3(1), dim3(1024), 0, stream, trN, d_trXyz, d_trDesc, d_trMsd, d_trOutlier, Tcw, G,
+                       d_mpv, d_points, fl, pc, d_matches, d_trAct, d_trCount);
+    if (nL) hipLaunchKernelGGL(k_fill_int, dim3((nL + 255) / 256), dim3(256), 0, stream, d_matchedL, nL, -1);
+    if (nR) hipLaunchKernelGGL(k_fill_int, dim3((nR + 255) / 256), dim3(256), 0, stream, d_matchedR, nR, -1);
+    timer.end(t);
+    VS_HIP(hipGetLastError());
+    int cnt[2] = {0, 0};
+    VS_HIP(hipMemcpyAsync(cnt, d_trCount, sizeof(cnt), hipMemcpyDeviceToHost, stream));
+    VS_HIP(hipMemcpyAsync(d_poseIO, predInv, sizeof(predInv), hipMemcpyHostToDevice, stream));
+    VS_HIP(hipStreamSynchronize(stream));
+    const int M = cnt[1];
+    actN = M;
+
+    // retry loop (src/FeatureTracker.cpp:1184-1233)
+    const int minInliers = 50;
+    float rad = frameNumber == 1 ? 120.f : 10.f;
+    int nIn = -1, nSt = -1, prevIn = -1, rounds = 0, lmIters = 0;
+    float prevrad = rad;
+    bool toBreak = false;
+    int out[4] = {0, 0, 0, 0};
+    while (nIn < minInliers) {
+        rounds++;
+        VS_CHECK(proj_enqueue(M, rad));
+        VS_CHECK(pose_enqueue(M));
+        VS_HIP(hipMemcpyAsync(out, d_poseOut, sizeof(out), hipMemcpyDeviceToHost, stream));
+        VS_HIP(hipStreamSynchronize(stream));
+        nIn = out[0]; nSt = out[1]; lmIters += out[2];
+        if (nIn < minInliers && !toBreak) {
+            VS_HIP(hipMemcpyAsync(d_poseIO, predInv, sizeof(predInv), hipMemcpyHostToDevice, stream));
+            if (nL) hipLaunchKernelGGL(k_fill_int, dim3((nL + 255) / 256), dim3(256), 0, stream, d_matchedL, nL, -1);
+            if (nR) hipLaunchKernelGGL(k_fill_int, dim3((nR + 255) / 256), dim3(256), 0, stream, d_matchedR, nR, -1);
+            if (M) hipLaunchKernelGGL(k_track_reset, dim3((M + 255) / 256), dim3(256), 0, stream, M, d_matches, fl + 3 * pc);
+            if (nIn < prevIn) { rad = prevrad; toBreak = true; }
+            else { prevrad = rad; prevIn = nIn; rad += 30.0f; }
+        } else {
+            break;
+        }
+        if (rounds > 3 && !toBreak) toBreak = true;
+    }
+    // refine with the estimated pose (:1236-1241)
+    t = timer.begin("track_repredict");
+    if (M) hipLaunchKernelGGL(k_track_repredict, dim3((M + 255) / 256), dim3(256), 0, stream, M, d_points, d_trMsd, d_trAct,
+                              d_poseIO, G, d_mpv, fl, pc, d_matches, d_matchedL, d_matchedR);
+    timer.end(t);
+    const float lastRad = rad;
+    VS_CHECK(proj_enqueue(M, 4.f));
+    VS_CHECK(pose_enqueue(M));
+    double io[16];
+    VS_HIP(hipMemcpyAsync(out, d_poseOut, sizeof(out), hipMemcpyDeviceToHost, stream));
+    VS_HIP(hipMemcpyAsync(io, d_poseIO, sizeof(io), hipMemcpyDeviceToHost, stream));
+    VS_HIP(hipStreamSynchronize(stream));
+    memcpy(T_cw_out, io, sizeof(io));
+    if (rep) {
+        rep->n_map_points = trN; rep->n_active = M; rep->rounds = rounds; rep->n_inliers = out[0]; rep->n_stereo = out[1];
+        rep->lm_iterations = lmIters + out[2]; rep->last_radius = lastRad;
+    }
+    return VSLAM_OK;
+}
+
+extern "C" {
+
+vslam_status vslam_tracker_init_map(vslam_matcher* m, const double* T_wc) {
+    if (!m) return VSLAM_ERR_INVALID;
+    return m->track_init_map(T_wc);
+}
+
+vslam_status vslam_tracker_track(vslam_matcher* m, const double* T_wc_pred, int32_t frame_number, double* T_cw_out,
+                                 vslam_track_report* report) {
+    if (!m) return VSLAM_ERR_INVALID;
+    m->timer.multi = true;
+    return m->track_frame(T_wc_pred, frame_number, T_cw_out, report);
+}
+
+vslam_status vslam_tracker_fetch(vslam_matcher* m, int32_t* matches, uint8_t* mps_outliers, int32_t* active_index,
+                                 int32_t cap, int32_t* n_active) {
+    if (!m || !n_active) return VSLAM_ERR_INVALID;
+    *n_active = m->actN;
+    if (m->actN > cap) return VSLAM_ERR_CAPACITY;
+    if (m->actN == 0) return VSLAM_OK;
+    VS_HIP(hipSetDevice(m->device));
+    const size_t pc = (size_t)m->poseCap;
+    if (matches) VS_HIP(hipMemcpyAsync(matches, m->d_matches, (size_t)m->actN * 8, hipMemcpyDeviceToHost, m->stream));
+    if (mps_outliers) VS_HIP(hipMemcpyAsync(mps_outliers, m->d_flags + 3 * pc, m->actN, hipMemcpyDeviceToHost, m->stream));
+    if (active_index) VS_HIP(hipMemcpyAsync(active_index, m->d_trAct, (size_t)m->actN * 4, hipMemcpyDeviceToHost, m->stream));
+    VS_HIP(hipStreamSynchronize(m->stream));
+    return VSLAM_OK;
+}
+
+}  // extern "C"

@@ -320,3 +320,29 @@ def local_ba_timings():
     n = C.c_int32()
     _chk(lib().vslam_local_ba_timings(names, ms, 32, C.byref(n)))
     return {names[i].decode(): float(ms[i]) for i in range(n.value)}
+
+
+class TrackReport(C.Structure):
+    _fields_ = [("n_map_points", C.c_int32), ("n_active", C.c_int32), ("rounds", C.c_int32),
+                ("n_inliers", C.c_int32), ("n_stereo", C.c_int32), ("lm_iterations", C.c_int32),
+                ("last_radius", C.c_float)]
+
+
+def tracker_init_map(matcher, T_wc):
+    T = np.ascontiguousarray(T_wc, np.float64)
+    _chk(matcher.L.vslam_tracker_init_map(matcher.h, _p(T)))
+
+
+def tracker_track(matcher, T_wc_pred, frame_number):
+    T = np.ascontiguousarray(T_wc_pred, np.float64)
+    out = np.zeros((4, 4), np.float64)
+    rep = TrackReport()
+    _chk(matcher.L.vslam_tracker_track(matcher.h, _p(T), int(frame_number), _p(out), C.byref(rep)))
+    return out, {f[0]: getattr(rep, f[0]) for f in TrackReport._fields_}
+
+
+def tracker_fetch(matcher, cap=65536):
+    mt = np.zeros((cap, 2), np.int32); out = np.zeros(cap, np.uint8); act = np.zeros(cap, np.int32)
+    n = C.c_int32()
+    _chk(matcher.L.vslam_tracker_fetch(matcher.h, _p(mt), _p(out), _p(act), cap, C.byref(n)))
+    return mt[:n.value].copy(), out[:n.value].copy(), act[:n.value].copy()

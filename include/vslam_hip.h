@@ -251,6 +251,37 @@ vslam_status vslam_local_ba(const vslam_ba_problem* problem, vslam_ba_result* re
 /* device time per kernel group of the last vslam_local_ba call on this thread */
 vslam_status vslam_local_ba_timings(const char** names, float* ms, int32_t cap, int32_t* n_out);
 
+/* ---------------------------------------------------------------------------
+ * Per-frame tracking loop on device-resident state — the stereo path of
+ * FeatureTracker::TrackImage (src/FeatureTracker.cpp:1108-1278):
+ *   init_map : initializeMap (:72-123) — every stereo keypoint of the matcher's current frame
+ *              (estimatedDepth > 0) becomes an active map point (position, descriptor,
+ *              MapPoint::maxScaleDist), replacing the tracker's map-point set;
+ *   track    : removeOutOfFrameMPs (:910-939) with the predicted pose, then the retry loop
+ *              { matchByProjectionRPred(rad 10|120, +30) ; estimatePoseGTSAM } while inliers < 50
+ *              (:1184-1233), PredictMPsPosition (:969-1014), the rad-4 refine match and the final
+ *              pose solve (:1236-1241).  Needs a completed extraction + stereo match of the NEW
+ *              frame; the map points come from earlier init_map / track calls.
+ * Keyframe insertion, map growth and culling stay on the caller's side.
+ * ------------------------------------------------------------------------- */
+typedef struct vslam_track_report {
+    int32_t n_map_points;     /* map points held by the tracker */
+    int32_t n_active;         /* visible in both cameras under the predicted pose */
+    int32_t rounds;           /* match+solve rounds before the refine pass */
+    int32_t n_inliers;        /* pair returned by the last estimatePoseGTSAM */
+    int32_t n_stereo;
+    int32_t lm_iterations;    /* summed over all solves of this frame */
+    float last_radius;
+} vslam_track_report;
+
+vslam_status vslam_tracker_init_map(vslam_matcher* m, const double* T_wc);
+vslam_status vslam_tracker_track(vslam_matcher* m, const double* T_wc_pred, int32_t frame_number,
+                                 double* T_cw_out, vslam_track_report* report);
+/* copies of the per-frame tracking state for tests: matches (n_active x 2), MPsOutliers (n_active),
+ * source map-point index of every active point */
+vslam_status vslam_tracker_fetch(vslam_matcher* m, int32_t* matches, uint8_t* mps_outliers,
+                                 int32_t* active_index, int32_t cap, int32_t* n_active);
+
 vslam_status vslam_matcher_timings(const vslam_matcher* m, const char** names, float* ms,
                                    int32_t cap, int32_t* n_out);
 

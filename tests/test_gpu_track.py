@@ -1,0 +1,136 @@
+"""GPU parity of the device-resident per-frame tracking loop (initializeMap -> removeOutOfFrameMPs ->
+{match, pose LM} retry loop -> PredictMPsPosition -> refine) against the same sequence composed from
+the CPU oracle's stage functions."""
+import numpy as np
+import pytest
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def rigid_inv(T):
+    Ti = np.eye(4)
+    Rt = T[:3, :3].T.copy()
+    Ti[:3, :3] = Rt
+    for i in range(3):
+        Ti[i, 3] = -(Rt[i, 0] * T[0, 3] + Rt[i, 1] * T[1, 3] + Rt[i, 2] * T[2, 3])
+    return Ti
+
+
+def oracle_init_map(rig, ex, kL, dL, st, T_wc):
+    idx = np.nonzero(st["depth"] > 0)[0]
+    xyz = np.zeros((len(idx), 3)); msd = np.zeros(len(idx), np.float32)
+    R, t = T_wc[:3, :3], T_wc[:3, 3]
+    for j, i in enumerate(idx):
+        zp = float(st["depth"][i]); xp = (float(kL["x"][i]) - rig["cx"]) * zp / rig["fx"]; yp = (float(kL["y"][i]) - rig["cy"]) * zp / rig["fy"]
+        pw = [(R[c, 0] * xp + R[c, 1] * yp + R[c, 2] * zp) + t[c] for c in range(3)]
+        xyz[j] = pw
+        d = [pw[c] - t[c] for c in range(3)]
+        dist = np.float32(np.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]))
+        msd[j] = np.float32(dist * ex.scalePyramid[kL["octave"][i]])
+    return xyz, dL[idx].copy(), msd
+
+
+def oracle_track(oracle, rig, ex, keys, st, mp, T_wc_pred, frame_number):
+    kL, dL, kR, dR = keys
+    xyz, desc, msd = mp
+    log_scale = np.float32(np.log(np.float64(np.float32(1.2))))
+    T_cw = rigid_inv(T_wc_pred)
+    uL, vL, lL, visL = oracle.world_to_frame(rig, T_cw, False, xyz, msd, log_scale)
+    uR, vR, lR, visR = oracle.world_to_frame(rig, T_cw, True, xyz, msd, log_scale)
+    act = np.nonzero(visL & visR)[0]
+    M = len(act)
+    mps = np.zeros(M, oracle.MPV_DTYPE)
+    mps["desc"] = desc[act]
+    mps["predLx"], mps["predLy"], mps["predRx"], mps["predRy"] = uL[act], vL[act], uR[act], vR[act]
+    mps["scaleLevelL"], mps["scaleLevelR"] = lL[act], lR[act]
+    mps["inFrame"] = 1; mps["inFrameR"] = 1
+    pts = xyz[act]
+    mL = np.full(len(kL), -1, np.int32); mR = np.full(len(kR), -1, np.int32)
+    mt = np.full((M, 2), -1, np.int32); outl = np.zeros(M, np.uint8)
+    mpo = np.zeros(M, np.uint8)
+    state = dict(st)
+    est = T_cw.copy()
+    rad = 120.0 if frame_number == 1 else 10.0
+    nIn, prevIn, prevrad, toBreak, rounds, iters = -1, -1, rad, False, 0, 0
+
+    def solve(est, mt, outl, state):
+        r = oracle.estimate_pose(rig, ex.InvSigmaFactor, pts, mps["inFrame"], mps["inFrameR"], mpo, mt, outl, kL, kR,
+                                 state["rightIdxs"], state["leftIdxs"], state["depth"], state["close"], est)
+        for k in ("rightIdxs", "leftIdxs", "depth", "close"):
+            state[k] = r[k]
+        return r
+
+    while nIn < 50:
+        rounds += 1
+        _, mL, mR, mt, _ = oracle.match_projection(ex, rig, mps, kL, dL, kR, dR, state["rightIdxs"], state["leftIdxs"], mL, mR, mt, rad)
+        r = solve(est, mt, outl, state)
+        est, mt, outl, nIn = r["T_cw"], r["matches"], r["outliers"], r["nIn"]
+        iters += r["iterations"]
+        if nIn < 50 and not toBreak:
+            est = T_cw.copy(); mL[:] = -1; mR[:] = -1; mt[:] = -1; outl[:] = 0
+            if nIn < prevIn:
+                rad = prevrad; toBreak = True
+            else:
+                prevrad = rad; prevIn = nIn; rad += 30.0
+        else:
+            break
+        if rounds > 3 and not toBreak:
+            toBreak = True
+    # PredictMPsPosition
+    uL, vL, lL, visL = oracle.world_to_frame(rig, est, False, pts, msd[act], log_scale)
+    uR, vR, lR, visR = oracle.world_to_frame(rig, est, True, pts, msd[act], log_scale)
+    for i in range(M):
+        mps["inFrame"][i] = visL[i]; mps["inFrameR"][i] = visR[i]
+        if visL[i]:
+            mps["predLx"][i], mps["predLy"][i], mps["scaleLevelL"][i] = uL[i], vL[i], lL[i]
+        elif mt[i, 0] >= 0:
+            mL[mt[i, 0]] = -1; mt[i, 0] = -1
+        if visR[i]:
+            mps["predRx"][i], mps["predRy"][i], mps["scaleLevelR"][i] = uR[i], vR[i], lR[i]
+        elif mt[i, 1] >= 0:
+            mR[mt[i, 1]] = -1; mt[i, 1] = -1
+        if outl[i]:
+            outl[i] = 0
+            if mt[i, 0] >= 0:
+                mL[mt[i, 0]] = -1; mt[i, 0] = -1
+            if mt[i, 1] >= 0:
+                mR[mt[i, 1]] = -1; mt[i, 1] = -1
+    _, mL, mR, mt, _ = oracle.match_projection(ex, rig, mps, kL, dL, kR, dR, state["rightIdxs"], state["leftIdxs"], mL, mR, mt, 4.0)
+    r = solve(est, mt, outl, state)
+    return dict(T_cw=r["T_cw"], nIn=r["nIn"], nStereo=r["nStereo"], matches=r["matches"], outliers=r["outliers"],
+                act=act, rounds=rounds, iters=iters + r["iterations"], state=state)
+
+
+@pytest.mark.parametrize("f0,f1,frame_number", [(4, 5, 7), (8, 10, 1), (2, 3, 3)])
+def test_track_frame_parity(oracle, capi, f0, f1, frame_number):
+    rig = synth.RIGS["euroc"]
+    La, Ra, Ta = synth.stereo_frame(f0)
+    Lb, Rb, Tb = synth.stereo_frame(f1)
+    oL, oR = oracle.Extractor(1500), oracle.Extractor(1500)
+    ge = capi.Extractor(rig["w"], rig["h"], 1500, batch=2)
+    m = capi.Matcher(rig, ge, 0, ge, 1)
+    # frame a: map initialisation
+    kL, dL = oL.extract(La); kR, dR = oR.extract(Ra)
+    st = oracle.stereo_match(oL, oR, rig, kL, dL, kR, dR)
+    mp = oracle_init_map(rig, oL, kL, dL, st, Ta)
+    ge.extract([La, Ra]); m.stereo_match(); capi.tracker_init_map(m, Ta)
+    # frame b: track with a constant-velocity style prediction (ground truth of an intermediate time)
+    pred = synth.pose_at(f1 - 0.3)
+    kL, dL = oL.extract(Lb); kR, dR = oR.extract(Rb)
+    st = oracle.stereo_match(oL, oR, rig, kL, dL, kR, dR)
+    ref = oracle_track(oracle, rig, oL, (kL, dL, kR, dR), st, mp, pred, frame_number)
+    ge.extract([Lb, Rb]); m.stereo_match()
+    T_cw, rep = capi.tracker_track(m, pred, frame_number)
+    mt, outl, act = capi.tracker_fetch(m)
+    assert rep["n_map_points"] == len(mp[0]) and rep["n_active"] == len(ref["act"]) and rep["n_active"] > 150
+    assert np.array_equal(act, ref["act"])
+    assert rep["rounds"] == ref["rounds"] and rep["lm_iterations"] == ref["iters"]
+    assert (rep["n_inliers"], rep["n_stereo"]) == (ref["nIn"], ref["nStereo"])
+    assert np.abs(T_cw - ref["T_cw"]).max() < 1e-9
+    assert np.array_equal(mt, ref["matches"]) and np.array_equal(outl, ref["outliers"])
+    st2 = m.stereo_fetch(len(kL), len(kR))
+    assert np.array_equal(st2["rightIdxs"], ref["state"]["rightIdxs"]) and np.array_equal(st2["close"], ref["state"]["close"])
+    # tracking recovers the true pose of frame b
+    assert np.abs(rigid_inv(T_cw) - Tb).max() < 0.05
+    assert rep["n_inliers"] >= 50
