@@ -5,9 +5,15 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it
 through torch.distributed.run, one rank per GPU.  W untimed warm-up steps, then exactly K timed
 steps bracketed by barrier + device synchronize; MAX over ranks; rank 0 prints ONE JSON line.
 
-A "step" is one stereo frame through the hot path (stages listed in `config.stages`), inputs
-already resident in HBM.  PyTorch is used for device buffers and torch.distributed only; all
-compute goes through the C ABI of gtsam-vslam_amd/libvslam_hip.so.
+A "step" is one stereo frame through the hot path, inputs (the rendered stereo images) already
+resident in HBM:
+    extract L+R (pyramid, FAST, SSC, orientation, blur, BRIEF)  ->  stereo match  ->
+    tracking loop against the map points of the previous frame
+        (removeOutOfFrameMPs, {projection match, pose-only LM} rounds, PredictMPsPosition, refine)  ->
+    initializeMap-style map refresh  ->  every KF_PERIOD-th frame one local BA (amortised).
+PyTorch is used for device buffers and torch.distributed only; all compute goes through the C ABI
+of gtsam-vslam_amd/libvslam_hip.so.  Multi-GPU: replicas (each rank tracks its own sequence and
+runs its own local BAs; the path has no cross-frame exchange — DESIGN.md "multi-GPU").
 """
 import argparse
 import json
@@ -21,37 +27,45 @@ sys.path.insert(0, os.path.join(ROOT, "gtsam-vslam_amd"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+KF_PERIOD = 5           # keyFrameCountEnd (include/FeatureTracker.h): a keyframe, hence a local BA, every 5 frames
 
 
 def level_pixels(w, h, nlevels=8, scale=1.2):
-    """Σ level pixels, from the reference constructor formulas (float arithmetic)."""
+    """level pixel counts from the reference constructor formulas (float arithmetic)."""
     px, s = [], np.float32(1.0)
-    for l in range(nlevels):
+    for _ in range(nlevels):
         inv = np.float32(1.0) / s
-        lw = int(np.rint(np.float32(w) * inv))
-        lh = int(np.rint(np.float32(h) * inv))
-        px.append(lw * lh)
+        px.append(int(np.rint(np.float32(w) * inv)) * int(np.rint(np.float32(h) * inv)))
         s = np.float32(s * np.float32(scale))
     return px
 
 
-def cpu_baseline(frames, rig, nfeat, budget_s=12.0):
-    """Oracle (CPU restatement, single thread) on a bounded sample of the same workload."""
+def cpu_baseline(frames, poses, rig, nfeat, ba_prob, budget_s=15.0):
+    """Oracle (CPU restatement, single thread) on a bounded sample of the same per-frame workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import pyoracle as po
+    from test_gpu_track import oracle_init_map, oracle_track
     eL, eR = po.Extractor(nfeat), po.Extractor(nfeat)
-    n, t0 = 0, time.perf_counter()
+    n, t0, mp = 0, time.perf_counter(), None
     while True:
-        L, R = frames[n % len(frames)]
+        i = n % len(frames)
+        L, R = frames[i]
         kL, dL = eL.extract(L)
         kR, dR = eR.extract(R)
-        po.stereo_match(eL, eR, rig, kL, dL, kR, dR)
+        st = po.stereo_match(eL, eR, rig, kL, dL, kR, dR)
+        if mp is not None and i > 0:
+            oracle_track(po, rig, eL, (kL, dL, kR, dR), st, mp, poses[i][1], 5)
+        mp = oracle_init_map(rig, eL, kL, dL, st, poses[i][0])
+        if n % KF_PERIOD == KF_PERIOD - 1:
+            po.local_ba(rig, eL.sigmaFactor, eL.InvSigmaFactor, ba_prob)
         n += 1
         el = time.perf_counter() - t0
         if el > budget_s or n >= 200:
             break
     return {"value": n / el, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d stereo frames (extract L+R + stereo match), single thread, oracle/ -O2" % n}
+            "sample": "%d stereo frames of the same workload (extract L+R, stereo, tracking loop, local BA every %d "
+                      "frames), single thread, oracle/ built -O2" % (n, KF_PERIOD)}
 
 
 def main():
@@ -59,7 +73,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--frames", type=int, default=6, help="distinct synthetic stereo frames kept in HBM")
+    ap.add_argument("--frames", type=int, default=8, help="distinct synthetic stereo frames kept in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -81,36 +95,60 @@ def main():
     rig_name, nfeat = "euroc", 1500
     rig = synth.RIGS[rig_name]
     w, h = rig["w"], rig["h"]
-    frames = []
+    # a short rendered sequence (consecutive frames, so that tracking has real inter-frame motion);
+    # it is replayed cyclically, frame 0 of each cycle re-initialises the map
+    frames, poses = [], []
     for i in range(args.frames):
-        L, R, _ = synth.stereo_frame(3 * i + 7 * rank, rig_name)
+        f = i + 11 * rank
+        L, R, T = synth.stereo_frame(f, rig_name)
         frames.append((L, R))
+        poses.append((T, synth.pose_at(f - 0.3, rig["fps"])))   # (ground truth, constant-velocity style prediction)
     d_frames = [(torch.from_numpy(L).to(dev), torch.from_numpy(R).to(dev)) for (L, R) in frames]
+    ba_prob = synth.make_ba_problem(rig_name, n_local=10, n_fixed=4, n_lm=3000, seed=0xBA5E + rank)
 
     fe = vc.Extractor(w, h, nfeat, batch=2, device=local)
     fm = vc.Matcher(rig, fe, 0, fe, 1)
+    sigmaF, invSigmaF = fe.sigmaFactor, fe.InvSigmaFactor
 
-    stage_ms = {}
+    stage_ms, counters = {}, {"track_inliers": 0, "track_frames": 0, "ba_calls": 0, "kps": 0, "stereo_cand": 0,
+                              "stereo_sad": 0, "ba_residuals": 0, "ba_landmarks": 0, "ba_sum_k2": 0, "ba_trials": 0}
 
-    def step(i, record):
-        dL, dR = d_frames[i % len(d_frames)]
+    def add(d):
+        for k, v in d.items():
+            stage_ms[k] = stage_ms.get(k, 0.0) + v
+
+    def step(n, record):
+        i = n % len(d_frames)
+        dL, dR = d_frames[i]
         fe.set_image_device(0, dL.data_ptr(), w)
         fe.set_image_device(1, dR.data_ptr(), w)
         fe.run()
         fm.stereo_match()
         if record:
-            for k, v in list(fe.timings().items()) + list(fm.timings().items()):
-                stage_ms[k] = stage_ms.get(k, 0.0) + v
+            add(fe.timings()); add(fm.timings())
+        if i > 0:
+            T_cw, rep = vc.tracker_track(fm, poses[i][1], 5)
+            if record:
+                add(fm.timings())
+                counters["track_inliers"] += rep["n_inliers"]; counters["track_frames"] += 1
+        vc.tracker_init_map(fm, poses[i][0])
+        if n % KF_PERIOD == KF_PERIOD - 1:
+            r = vc.local_ba(rig, sigmaF, invSigmaF, ba_prob, device=local)
+            if record:
+                add(vc.local_ba_timings())
+                counters["ba_calls"] += 1
+                counters["ba_residuals"], counters["ba_landmarks"], counters["ba_sum_k2"] = r["residuals"], r["landmarks"], r["sum_k2"]
+                counters["ba_trials"] += r["reports"][0]["inner"] + r["reports"][1]["inner"]
 
-    for i in range(args.warmup):
-        step(i, False)
+    for n in range(args.warmup):
+        step(n, False)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, True)
+    for n in range(args.steps):
+        step(n, True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -122,23 +160,36 @@ def main():
         el = float(t.item())
 
     if rank == 0:
-        # dominant kernel + its algorithmic bytes per launch (DESIGN.md "algorithmic bytes")
+        # dominant kernel group + its algorithmic bytes per launch (DESIGN.md "algorithmic bytes")
         px = level_pixels(w, h)
-        sumP = sum(px)
-        nimg = 2
+        sumP, nimg = sum(px), 2
         nk = sum(len(fe.fetch(i)[0]) for i in range(2)) / 2.0
-        alg = {
-            "pyramid": nimg * (sum(px[:-1]) + sum(px[1:])),          # read level l-1, write level l
-            "fast": nimg * (sumP + 4 * 3.3 * nfeat),                 # read every level once + packed candidates
-            "blur": nimg * (2 * sumP),                               # read + write every level
-            "orient_desc": nimg * nk * (28 + 32 + 709 + 512),        # keypoint + descriptor + disc + BRIEF taps
+        st = fm.stereo_fetch(int(nk * 2), int(nk * 2)) if False else None
+        R_, L_, k2 = counters["ba_residuals"], counters["ba_landmarks"], counters["ba_sum_k2"]
+        alg = {   # bytes per launch of each kernel group
+            "pyramid": nimg * (sum(px[:-1]) + sum(px[1:])),            # 7 launches: read level l-1, write level l
+            "fast": nimg * (sumP + 4 * 3.3 * nfeat),                   # every level read once + packed candidates
             "gather": nimg * (8 * 3.3 * nfeat),
+            "blur": nimg * (2 * sumP),                                 # read + write every level
+            "orient_desc": nimg * nk * (28 + 32 + 709 + 512),          # keypoint + descriptor + disc + BRIEF taps
+            "ba_linearize": R_ * (8 + 16 + 8 + 96 + 24 + 160),         # idx, uv, sigma, pose, point, stored J
+            "ba_schur": R_ * 160 + L_ * 24,                            # stored J read once + (S stays in LDS)
+            "ba_back": R_ * 160 + L_ * 48,
+            "ba_eval": R_ * (160 + 16 + 8 + 96 + 24),
         }
+        launches = {"pyramid": 7}
         dom = max(stage_ms, key=lambda k: stage_ms[k])
-        dom_ms = stage_ms[dom] / args.steps
+        # per-launch duration of the dominant group: total device time / number of launches
+        n_launch = {"ba_schur": max(counters["ba_trials"], 1), "ba_solve": max(counters["ba_trials"], 1),
+                    "ba_back": max(counters["ba_trials"], 1), "ba_eval": max(counters["ba_trials"], 1)}.get(
+                        dom, args.steps * launches.get(dom, 1))
+        dom_ms = stage_ms[dom] / n_launch
         alg_bytes = alg.get(dom)
-        roof = {"bound": "hbm", "kernel": dom, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": None, "traffic": None, "launch_ms": dom_ms, "algorithmic_bytes": alg_bytes}
+        if alg_bytes is not None and dom in launches:
+            alg_bytes = alg_bytes / launches[dom]
+        roof = {"bound": "hbm", "kernel": dom, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                "traffic": None, "launch_ms": dom_ms, "algorithmic_bytes": alg_bytes,
+                "note": "see DESIGN.md for per-kernel algorithmic bytes; latency-bound kernels have no byte figure"}
         if alg_bytes:
             roof["achieved"] = alg_bytes / (dom_ms * 1e-3) / 1e9
             roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
@@ -146,18 +197,21 @@ def main():
             "metric": "frames/sec (extract+match+localBA), 1500 feat stereo 752x480",
             "value": world * args.steps / el, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32 (extract, match), f32 scalars",
-            "data": "synthetic",
-            "config": {"workload": "EuRoC-like stereo 752x480, 1500 features/image, %d rendered frames resident in HBM"
-                                   % args.frames,
-                       "stages": ["extract L+R (pyramid, FAST, SSC, orientation, blur, BRIEF)", "stereo match"],
-                       "not_yet_in_step": ["projection match", "pose-only LM", "local BA"],
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/i32 (extract, match) + f64 (pose LM, local BA)", "data": "synthetic",
+            "config": {"workload": "C1-class: EuRoC-like stereo 752x480, 1500 features/image, %d rendered consecutive "
+                                   "frames resident in HBM replayed cyclically, 10-KF local BA (3000 landmarks, ~%d "
+                                   "residuals) every %d frames; IMU factors (C2) not yet in the path"
+                                   % (args.frames, counters["ba_residuals"], KF_PERIOD),
+                       "stages": ["extract L+R", "stereo match", "tracking loop (projection match + pose-only LM)",
+                                  "map refresh", "local BA (amortised)"],
                        "parallelism": "replicas x%d" % world},
             "stage_ms_per_step": {k: v / args.steps for k, v in sorted(stage_ms.items())},
+            "mean_track_inliers": counters["track_inliers"] / max(counters["track_frames"], 1),
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(frames, rig, nfeat)
+            out["cpu_baseline"] = cpu_baseline(frames, poses, rig, nfeat, ba_prob)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

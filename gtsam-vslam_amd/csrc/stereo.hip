@@ -273,6 +273,7 @@ vslam_status vslam_matcher::init(const vslam_rig* r, vslam_extractor* l, int il,
     VS_HIP(hipSetDevice(device));
     VS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     timer.stream = stream;
+    timer.multi = true;
     VS_HIP(hipMalloc(&d_stats, 4 * sizeof(unsigned long long)));
     VS_CHECK(ensure_cap(std::max(l->keptCap, rr->keptCap)));
     return VSLAM_OK;
@@ -425,6 +426,7 @@ vslam_status vslam_matcher_timings(const vslam_matcher* m, const char** names, f
     const char* nm[64];
     float tv[64];
     int n = m->timer.read(nm, tv, cap < 64 ? cap : 64);
+    const_cast<vslam_matcher*>(m)->timer.reset();   // read-and-reset: the next read reports only newer launches
     for (int i = 0; i < n; i++) { if (names) names[i] = nm[i]; if (ms) ms[i] = tv[i]; }
     *n_out = n;
     return VSLAM_OK;

@@ -282,6 +282,7 @@ vslam_status vslam_tracker_track(vslam_matcher* m, const double* T_wc_pred, int3
 vslam_status vslam_tracker_fetch(vslam_matcher* m, int32_t* matches, uint8_t* mps_outliers,
                                  int32_t* active_index, int32_t cap, int32_t* n_active);
 
+/* device time per kernel group since the previous call (summed over launches; read-and-reset) */
 vslam_status vslam_matcher_timings(const vslam_matcher* m, const char** names, float* ms,
                                    int32_t cap, int32_t* n_out);
 
