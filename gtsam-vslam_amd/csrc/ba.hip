@@ -32,6 +32,7 @@ struct BaEdge {
     int a, b, fa, fb;
     DPose measured;
     double r[6], Ja[36], Jb[36];
+    double Haa[36], Hab[36], Hbb[36], ga[6], gb[6];   // Ja^T Ja, Ja^T Jb, Jb^T Jb, Ja^T r, Jb^T r (filled at linearisation)
 };
 
 struct BaDev {
@@ -43,7 +44,7 @@ struct BaDev {
     DPose* poseCur; DPose* poseTrial; const int* fidx;
     double* lmCur; double* lmTrial;
     BaEdge* edges;
-    double* S; double* rhs; double* Spart; double* dP; double* dL;
+    double* S; double* rhs; double* Spart; double* Sedge; double* dP; double* dL;
     double* sums; double* partial;
     int* flags;
     double fx, fy, cx, cy, b;
@@ -148,6 +149,29 @@ __global__ __launch_bounds__(256) void k_ba_edges(BaDev D, int mode, int nPartia
         if (mode == 0) {
             ba_eval_edge(E, D.poseCur[E.a], D.poseCur[E.b], E.r, E.Ja, E.Jb);
             for (int i = 0; i < 6; i++) v[0] += E.r[i] * E.r[i];
+            for (int i = 0; i < 6; i++) {
+                double ga = 0, gb = 0;
+                for (int k = 0; k < 6; k++) { ga += E.Ja[k * 6 + i] * E.r[k]; gb += E.Jb[k * 6 + i] * E.r[k]; }
+                E.ga[i] = ga; E.gb[i] = gb;
+                for (int j = 0; j < 6; j++) {
+                    double aa = 0, ab = 0, bb = 0;
+                    for (int k = 0; k < 6; k++) {
+                        aa += E.Ja[k * 6 + i] * E.Ja[k * 6 + j];
+                        ab += E.Ja[k * 6 + i] * E.Jb[k * 6 + j];
+                        bb += E.Jb[k * 6 + i] * E.Jb[k * 6 + j];
+                    }
+                    E.Haa[i * 6 + j] = aa; E.Hab[i * 6 + j] = ab; E.Hbb[i * 6 + j] = bb;
+                    const int n = D.n;
+                    if (E.fa >= 0) atomicAdd(&D.Sedge[(size_t)(6 * E.fa + i) * n + 6 * E.fa + j], aa);
+                    if (E.fb >= 0) atomicAdd(&D.Sedge[(size_t)(6 * E.fb + i) * n + 6 * E.fb + j], bb);
+                    if (E.fa >= 0 && E.fb >= 0) {     // upper triangle only (the solve mirrors it)
+                        if (E.fa < E.fb) atomicAdd(&D.Sedge[(size_t)(6 * E.fa + i) * n + 6 * E.fb + j], ab);
+                        else atomicAdd(&D.Sedge[(size_t)(6 * E.fb + j) * n + 6 * E.fa + i], ab);
+                    }
+                }
+                if (E.fa >= 0) atomicAdd(&D.Sedge[(size_t)D.n * D.n + 6 * E.fa + i], -ga);
+                if (E.fb >= 0) atomicAdd(&D.Sedge[(size_t)D.n * D.n + 6 * E.fb + i], -gb);
+            }
         } else {
             double r[6];
             ba_eval_edge(E, D.poseTrial[E.a], D.poseTrial[E.b], r, nullptr, nullptr);
@@ -293,107 +317,201 @@ __global__ __launch_bounds__(256) void k_ba_schur(BaDev D, double lambda, int ma
     }
 }
 
-// One workgroup: assemble the reduced camera system, factorise, solve, retract the poses.
-// Spart layout: nPart x (n*n + n).  A (n x n) lives in LDS when it fits, else in D.S.
-__global__ __launch_bounds__(1024) void k_ba_solve(BaDev D, double lambda, int nPart, int useLds) {
+// Sum of the per-workgroup partial systems (grid-parallel, coalesced over entries).  This is the
+// buffer the landmark-sharded multi-GPU path all-reduces (RCCL) before k_ba_solve.
+__global__ __launch_bounds__(256) void k_ba_reduce(BaDev D, int nPart) {
+    const int total = D.n * D.n + D.n;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const size_t stride = (size_t)total;
+    // blockIdx.y = slice of the partial systems; 4 independent accumulators keep the strided loads in flight
+    const int per = (nPart + gridDim.y - 1) / gridDim.y;
+    const int p0 = blockIdx.y * per, p1 = min(nPart, p0 + per);
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int p = p0;
+    for (; p + 3 < p1; p += 4) {
+        s0 += D.Spart[(size_t)p * stride + i];
+        s1 += D.Spart[(size_t)(p + 1) * stride + i];
+        s2 += D.Spart[(size_t)(p + 2) * stride + i];
+        s3 += D.Spart[(size_t)(p + 3) * stride + i];
+    }
+    for (; p < p1; p++) s0 += D.Spart[(size_t)p * stride + i];
+    double s = (s0 + s1) + (s2 + s3);
+    if (blockIdx.y == 0) s += D.Sedge[i];      // BetweenFactor blocks of this linearisation
+    if (i < D.n * D.n) atomicAdd(&D.S[i], s); else atomicAdd(&D.rhs[i - D.n * D.n], s);
+}
+
+// One workgroup of n threads (rounded up to whole waves): thread i owns row i.  Assembles the
+// reduced camera system from D.S / D.rhs (upper triangle valid) + BetweenFactor blocks + lambda I,
+// left-looking Cholesky (2 barriers per column), the two substitutions (1 barrier per column), then
+// retracts the trial poses.  A (n x n) lives in LDS when it fits, else in D.S (L2-resident).
+__global__ __launch_bounds__(1024) void k_ba_solve(BaDev D, double lambda, int useLds, int ld) {
     extern __shared__ double sm[];
-    const int n = D.n, tid = threadIdx.x;
-    double* A = useLds ? sm : D.S;
-    double* b = useLds ? sm + (size_t)n * n : D.rhs;
+    const int n = D.n, tid = threadIdx.x, nt = blockDim.x;
+    double* A = useLds ? sm : D.S;                              // leading dimension ld (LDS: odd multiple, conflict-free rows)
+    double* col = useLds ? sm + (size_t)n * ld : D.rhs + n;     // n scratch doubles (D.rhs holds 2n)
     __shared__ int sFail;
-    __shared__ double sPiv;
+    __shared__ double rhsl[1024], idiag[1024];
+#ifdef VSLAM_BA_STAMPS
+#define BA_STAMP(i) if (tid == 0) D.sums[8 + (i)] = (double)__builtin_readcyclecounter();
+#else
+#define BA_STAMP(i)
+#endif
+    BA_STAMP(0)
     if (tid == 0) sFail = 0;
-    const size_t stride = (size_t)n * n + n;
-    if (nPart > 0) {
-        for (int i = tid; i < n * n + n; i += 1024) {
-            double s = 0;
-            for (int p = 0; p < nPart; p++) s += D.Spart[(size_t)p * stride + i];
-            if (i < n * n) A[i] = s; else b[i - n * n] = s;
+    if (useLds) {
+        // column c = lane, rows unrolled: independent coalesced loads (the upper triangle of D.S is valid)
+        for (int c = tid; c < n; c += nt) {
+#pragma unroll 6
+            for (int r = 0; r < n; r++) A[(size_t)r * ld + c] = D.S[r <= c ? (size_t)r * n + c : (size_t)c * n + r];
         }
-    } else if (useLds) {
-        for (int i = tid; i < n * n; i += 1024) A[i] = D.S[i];
-        for (int i = tid; i < n; i += 1024) b[i] = D.rhs[i];
+    } else {
+        __syncthreads();
+        for (int e = tid; e < n * n; e += nt) {
+            const int r = e / n, c = e - r * n;
+            if (r > c) A[e] = A[(size_t)c * n + r];
+        }
     }
+    if (tid < n) rhsl[tid] = D.rhs[tid];
     __syncthreads();
-    // BetweenFactor blocks (upper triangle only)
-    for (int e = 0; e < D.NE; e++) {
-        const BaEdge& E = D.edges[e];
-        if (tid < 108) {
-            const int blk = tid / 36, ij = tid % 36, i = ij / 6, j = ij % 6;
-            double s = 0;
-            if (blk == 0 && E.fa >= 0) {
-                for (int k = 0; k < 6; k++) s += E.Ja[k * 6 + i] * E.Ja[k * 6 + j];
-                if (i <= j) A[(size_t)(6 * E.fa + i) * n + 6 * E.fa + j] += s;
-            } else if (blk == 1 && E.fb >= 0) {
-                for (int k = 0; k < 6; k++) s += E.Jb[k * 6 + i] * E.Jb[k * 6 + j];
-                if (i <= j) A[(size_t)(6 * E.fb + i) * n + 6 * E.fb + j] += s;
-            } else if (blk == 2 && E.fa >= 0 && E.fb >= 0) {
-                for (int k = 0; k < 6; k++) s += E.Ja[k * 6 + i] * E.Jb[k * 6 + j];
-                if (E.fa < E.fb) A[(size_t)(6 * E.fa + i) * n + 6 * E.fb + j] += s;
-                else A[(size_t)(6 * E.fb + j) * n + 6 * E.fa + i] += s;
+    BA_STAMP(1)
+    BA_STAMP(2)
+    if (tid < n) A[(size_t)tid * ld + tid] += lambda;
+    __syncthreads();
+    // Blocked left-looking Cholesky, 6-column panels (n is a multiple of 6): thread i owns row i.
+    // Per panel: (1) row update against the finished columns, (2) every thread factors the 6x6
+    // diagonal block redundantly in registers and solves its own row against it, (3) write-back.
+    for (int J = 0; J < n; J += 6) {
+        if (tid >= J && tid < n) {
+            double u[6];
+            double* ri = A + (size_t)tid * ld;
+#pragma unroll
+            for (int c = 0; c < 6; c++) u[c] = ri[J + c];
+            // J is a multiple of 6: issue the 7 x 6 LDS reads of six columns together, then the FMAs
+            for (int k = 0; k < J; k += 6) {
+                double a[6], l[6][6];
+#pragma unroll
+                for (int q = 0; q < 6; q++) a[q] = ri[k + q];
+#pragma unroll
+                for (int c = 0; c < 6; c++)
+#pragma unroll
+                    for (int q = 0; q < 6; q++) l[c][q] = A[(size_t)(J + c) * ld + k + q];
+#pragma unroll
+                for (int q = 0; q < 6; q++)
+#pragma unroll
+                    for (int c = 0; c < 6; c++) u[c] -= a[q] * l[c][q];
             }
-        } else if (tid < 120) {
-            const int q = tid - 108, side = q / 6, i = q % 6;
-            const int fi = side ? E.fb : E.fa;
-            if (fi >= 0) {
-                const double* J = side ? E.Jb : E.Ja;
-                double s = 0;
-                for (int k = 0; k < 6; k++) s += J[k * 6 + i] * E.r[k];
-                b[6 * fi + i] -= s;
+#pragma unroll
+            for (int c = 0; c < 6; c++) ri[J + c] = u[c];
+        }
+        __syncthreads();
+        double Ld[6][6], inv[6];
+        bool bad = false;
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int c = 0; c <= r; c++) Ld[r][c] = A[(size_t)(J + r) * ld + J + c];
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            double d = Ld[c][c];
+#pragma unroll
+            for (int m = 0; m < c; m++) d -= Ld[c][m] * Ld[c][m];
+            if (!(d > 0)) { bad = true; d = 1.0; }
+            const double id = rsqrt(d);          // one reciprocal square root per pivot; the rest are multiplies
+            Ld[c][c] = d * id;
+            inv[c] = id;
+#pragma unroll
+            for (int r = c + 1; r < 6; r++) {
+                double v = Ld[r][c];
+#pragma unroll
+                for (int m = 0; m < c; m++) v -= Ld[r][m] * Ld[c][m];
+                Ld[r][c] = v * id;
+            }
+        }
+        double x[6];
+        if (tid > J + 5 && tid < n) {
+            const double* ri = A + (size_t)tid * ld;
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                double v = ri[J + c];
+#pragma unroll
+                for (int m = 0; m < c; m++) v -= x[m] * Ld[c][m];
+                x[c] = v * inv[c];
             }
         }
         __syncthreads();
-    }
-    // mirror upper -> lower, damping
-    for (int i = tid; i < n * n; i += 1024) {
-        const int r = i / n, c = i - r * n;
-        if (r > c) A[i] = A[(size_t)c * n + r];
-    }
-    __syncthreads();
-    for (int i = tid; i < n; i += 1024) A[(size_t)i * n + i] += lambda;
-    __syncthreads();
-    // right-looking Cholesky (lower)
-    for (int j = 0; j < n; j++) {
-        if (tid == 0) {
-            const double d = A[(size_t)j * n + j];
-            if (!(d > 0)) { sFail = 1; sPiv = 1.0; }
-            else { sPiv = sqrt(d); A[(size_t)j * n + j] = sPiv; }
-        }
-        __syncthreads();
-        if (sFail) break;
-        const double piv = sPiv;
-        for (int i = j + 1 + tid; i < n; i += 1024) A[(size_t)i * n + j] /= piv;
-        __syncthreads();
-        const int m = n - j - 1;
-        for (int e = tid; e < m * m; e += 1024) {
-            const int r = j + 1 + e / m, c = j + 1 + e % m;
-            if (c <= r) A[(size_t)r * n + c] -= A[(size_t)r * n + j] * A[(size_t)c * n + j];
+        if (bad) { if (tid == 0) sFail = 1; break; }
+        if (tid > J + 5 && tid < n) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) A[(size_t)tid * ld + J + c] = x[c];
+        } else if (tid >= J && tid < J + 6) {
+            const int r = tid - J;
+#pragma unroll
+            for (int c = 0; c < 6; c++) if (c <= r) A[(size_t)tid * ld + J + c] = Ld[r][c];
+            idiag[tid] = inv[r];
         }
         __syncthreads();
     }
+    __syncthreads();
+    BA_STAMP(3)
     if (!sFail) {
-        for (int j = 0; j < n; j++) {           // L y = b
-            if (tid == 0) b[j] /= A[(size_t)j * n + j];
-            __syncthreads();
-            const double yj = b[j];
-            for (int i = j + 1 + tid; i < n; i += 1024) b[i] -= A[(size_t)i * n + j] * yj;
+        // L y = b, panel by panel: the 6 unknowns of a panel are solved redundantly by every thread
+        double* bv = rhsl;
+        for (int J = 0; J < n; J += 6) {
+            double y[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                double v = bv[J + c];
+#pragma unroll
+                for (int m = 0; m < c; m++) v -= A[(size_t)(J + c) * ld + J + m] * y[m];
+                y[c] = v * idiag[J + c];
+            }
+            if (tid > J + 5 && tid < n) {
+                const double* ri = A + (size_t)tid * ld + J;
+                double v = bv[tid];
+#pragma unroll
+                for (int c = 0; c < 6; c++) v -= ri[c] * y[c];
+                bv[tid] = v;
+            }
+            if (tid == J) {
+#pragma unroll
+                for (int c = 0; c < 6; c++) col[J + c] = y[c];
+            }
             __syncthreads();
         }
-        for (int j = n - 1; j >= 0; j--) {      // L^T x = y
-            if (tid == 0) b[j] /= A[(size_t)j * n + j];
+        BA_STAMP(4)
+        // L^T x = y, panels in reverse
+        for (int J = n - 6; J >= 0; J -= 6) {
+            double x[6];
+#pragma unroll
+            for (int c = 5; c >= 0; c--) {
+                double v = col[J + c];
+#pragma unroll
+                for (int m = 5; m > c; m--) v -= A[(size_t)(J + m) * ld + J + c] * x[m];
+                x[c] = v * idiag[J + c];
+            }
             __syncthreads();
-            const double xj = b[j];
-            for (int i = tid; i < j; i += 1024) b[i] -= A[(size_t)j * n + i] * xj;
+            if (tid < J) {
+                double v = col[tid];
+#pragma unroll
+                for (int c = 0; c < 6; c++) v -= A[(size_t)(J + c) * ld + tid] * x[c];
+                col[tid] = v;
+            }
+            if (tid == J) {
+#pragma unroll
+                for (int c = 0; c < 6; c++) D.dP[J + c] = x[c];
+            }
             __syncthreads();
         }
-        for (int i = tid; i < n; i += 1024) D.dP[i] = b[i];
-        __syncthreads();
-        for (int k = tid; k < D.K; k += 1024) {
+        BA_STAMP(5)
+        for (int k = tid; k < D.K; k += nt) {
             const int fi = D.fidx[k];
             if (fi >= 0) { DPose T; pose_retract(D.poseCur[k], D.dP + 6 * fi, T); D.poseTrial[k] = T; }
             else D.poseTrial[k] = D.poseCur[k];
         }
     }
+    __syncthreads();
+    BA_STAMP(6)
     if (tid == 0) D.flags[0] = sFail;
 }
 
@@ -508,7 +626,6 @@ struct DevBuf {
         n = std::max<size_t>(count, 1);
         return hipMalloc(&p, n * sizeof(T));
     }
-    ~DevBuf() { if (p) hipFree(p); }
 };
 
 thread_local StageTimer g_baTimer;
@@ -539,20 +656,35 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
             P->pair_octave[2 * p] < 0 || P->pair_octave[2 * p] >= P->n_levels || P->pair_octave[2 * p + 1] < 0 ||
             P->pair_octave[2 * p + 1] >= P->n_levels) { set_error("vslam_local_ba: pair index out of range"); return VSLAM_ERR_INVALID; }
 
-    hipStream_t stream;
-    VS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    g_baTimer.destroy();
+    // grow-only device workspace + stream, kept per host thread across calls (one local BA per keyframe:
+    // re-allocating ~40 buffers every call cost more than the solve itself)
+    struct Workspace {
+        hipStream_t stream = nullptr;
+        int device = -1;
+        DevBuf<DPose> d_pose0, d_poseA, d_poseB;
+        DevBuf<double> d_lm0, d_lmA, d_lmB, d_facZ, d_facIs, d_facJ, d_S, d_rhs, d_Spart, d_Sedge, d_dP, d_dL, d_sums, d_partial;
+        DevBuf<int> d_facKf, d_facFi, d_facLp, d_facLm, d_lpStart, d_lpSlotStart, d_slotStart, d_slotFi, d_lpOrig, d_fidx, d_flags;
+        DevBuf<int> d_pairKf, d_pairLm, d_pairOct;
+        DevBuf<uint8_t> d_facRight, d_pairFlags, d_kfLocal, d_kfPresent, d_lmPresent, d_wrong;
+        DevBuf<float> d_pairUv;
+        DevBuf<BaEdge> d_edges;
+    };
+    static thread_local Workspace* ws = nullptr;
+    if (!ws || ws->device != device) { ws = new Workspace(); ws->device = device; VS_HIP(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking)); }
+    hipStream_t stream = ws->stream;
+    g_baTimer.reset();
     g_baTimer.stream = stream;
     g_baTimer.multi = true;
-
-    // static device data
-    DevBuf<DPose> d_pose0, d_poseA, d_poseB;
-    DevBuf<double> d_lm0, d_lmA, d_lmB, d_facZ, d_facIs, d_facJ, d_S, d_rhs, d_Spart, d_dP, d_dL, d_sums, d_partial;
-    DevBuf<int> d_facKf, d_facFi, d_facLp, d_facLm, d_lpStart, d_lpSlotStart, d_slotStart, d_slotFi, d_lpOrig, d_fidx, d_flags;
-    DevBuf<int> d_pairKf, d_pairLm, d_pairOct;
-    DevBuf<uint8_t> d_facRight, d_pairFlags, d_kfLocal, d_kfPresent, d_lmPresent, d_wrong;
-    DevBuf<float> d_pairUv;
-    DevBuf<BaEdge> d_edges;
+    auto &d_pose0 = ws->d_pose0, &d_poseA = ws->d_poseA, &d_poseB = ws->d_poseB;
+    auto &d_lm0 = ws->d_lm0, &d_lmA = ws->d_lmA, &d_lmB = ws->d_lmB, &d_facZ = ws->d_facZ, &d_facIs = ws->d_facIs, &d_facJ = ws->d_facJ,
+         &d_S = ws->d_S, &d_rhs = ws->d_rhs, &d_Spart = ws->d_Spart, &d_Sedge = ws->d_Sedge, &d_dP = ws->d_dP, &d_dL = ws->d_dL, &d_sums = ws->d_sums, &d_partial = ws->d_partial;
+    auto &d_facKf = ws->d_facKf, &d_facFi = ws->d_facFi, &d_facLp = ws->d_facLp, &d_facLm = ws->d_facLm, &d_lpStart = ws->d_lpStart,
+         &d_lpSlotStart = ws->d_lpSlotStart, &d_slotStart = ws->d_slotStart, &d_slotFi = ws->d_slotFi, &d_lpOrig = ws->d_lpOrig,
+         &d_fidx = ws->d_fidx, &d_flags = ws->d_flags, &d_pairKf = ws->d_pairKf, &d_pairLm = ws->d_pairLm, &d_pairOct = ws->d_pairOct;
+    auto &d_facRight = ws->d_facRight, &d_pairFlags = ws->d_pairFlags, &d_kfLocal = ws->d_kfLocal, &d_kfPresent = ws->d_kfPresent,
+         &d_lmPresent = ws->d_lmPresent, &d_wrong = ws->d_wrong;
+    auto &d_pairUv = ws->d_pairUv;
+    auto &d_edges = ws->d_edges;
 
     std::vector<DPose> pose0(K);
     for (int k = 0; k < K; k++) pose_from_rm16(P->kf_pose_wc + 16 * (size_t)k, pose0[k]);
@@ -571,7 +703,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         VS_HIP(hipMemcpyAsync(d_pairUv.p, P->pair_uv, (size_t)4 * NP * sizeof(float), hipMemcpyHostToDevice, stream));
     }
     VS_HIP(hipMemcpyAsync(d_kfLocal.p, P->kf_local, K, hipMemcpyHostToDevice, stream));
-    VS_HIP(d_sums.alloc(8)); VS_HIP(d_flags.alloc(4));
+    VS_HIP(d_sums.alloc(32)); VS_HIP(d_flags.alloc(4));
 
     std::vector<uint8_t> wrong(NP, 0), kfPresent(K), lmPresent(L);
     DPose* poseFinal = d_pose0.p;
@@ -604,10 +736,18 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         for (int l = 0; l < L; l++) if (lmPresent[l]) { lpOf[l] = (int)lpOrig.size(); lpOrig.push_back(l); }
         const int Lp = (int)lpOrig.size();
         for (HostFac& f : facs) { f.fi = fidx[f.kf]; f.lp = lpOf[f.lm]; }
-        std::stable_sort(facs.begin(), facs.end(), [](const HostFac& a, const HostFac& b) {
-            if (a.lp != b.lp) return a.lp < b.lp;
-            return a.fi < b.fi;
-        });
+        {   // bucket by landmark (counting sort, stable), then order each short bucket by free index
+            std::vector<int> start(Lp + 1, 0);
+            for (const HostFac& f : facs) start[f.lp + 1]++;
+            for (int l = 0; l < Lp; l++) start[l + 1] += start[l];
+            std::vector<HostFac> sorted(facs.size());
+            std::vector<int> fill(start.begin(), start.end() - 1);
+            for (const HostFac& f : facs) sorted[fill[f.lp]++] = f;
+            for (int l = 0; l < Lp; l++)
+                std::stable_sort(sorted.begin() + start[l], sorted.begin() + start[l + 1],
+                                 [](const HostFac& a, const HostFac& b) { return a.fi < b.fi; });
+            facs.swap(sorted);
+        }
         const int NF = (int)facs.size();
         // Slot table: inside a landmark the factors of fixed keyframes (fi = -1) come first, then one
         // "slot" per free keyframe (its left and/or right factor).  Padded layout: per landmark the slot
@@ -660,7 +800,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         VS_HIP(d_facZ.alloc((size_t)2 * NF)); VS_HIP(d_facIs.alloc(NF)); VS_HIP(d_facRight.alloc(NF));
         VS_HIP(d_facJ.alloc((size_t)20 * NF));
         VS_HIP(d_lpStart.alloc(Lp + 1)); VS_HIP(d_lpSlotStart.alloc(Lp + 1)); VS_HIP(d_lpOrig.alloc(Lp)); VS_HIP(d_fidx.alloc(K)); VS_HIP(d_edges.alloc(NE));
-        VS_HIP(d_dP.alloc(n)); VS_HIP(d_dL.alloc((size_t)3 * Lp)); VS_HIP(d_S.alloc((size_t)n * n)); VS_HIP(d_rhs.alloc(n));
+        VS_HIP(d_dP.alloc(n)); VS_HIP(d_dL.alloc((size_t)3 * Lp)); VS_HIP(d_S.alloc((size_t)n * n)); VS_HIP(d_rhs.alloc((size_t)2 * n + 2)); VS_HIP(d_Sedge.alloc((size_t)n * n + n));
         VS_HIP(d_slotStart.alloc(slotStart.size() + 1)); VS_HIP(d_slotFi.alloc(slotFi.size() + 1));
         if (NF) {
             BA_UP(d_facKf, facKf); BA_UP(d_facFi, facFi); BA_UP(d_facLp, facLp); BA_UP(d_facLm, facLm);
@@ -685,7 +825,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         D.lpStart = d_lpStart.p; D.lpSlotStart = d_lpSlotStart.p; D.slotStart = d_slotStart.p; D.slotFi = d_slotFi.p;
         D.lpOrig = d_lpOrig.p; D.poseCur = d_poseA.p; D.poseTrial = d_poseB.p; D.fidx = d_fidx.p;
         D.lmCur = d_lmA.p; D.lmTrial = d_lmB.p; D.edges = d_edges.p;
-        D.S = d_S.p; D.rhs = d_rhs.p; D.dP = d_dP.p; D.dL = d_dL.p; D.sums = d_sums.p; D.flags = d_flags.p;
+        D.S = d_S.p; D.rhs = d_rhs.p; D.Sedge = d_Sedge.p; D.dP = d_dP.p; D.dL = d_dL.p; D.sums = d_sums.p; D.flags = d_flags.p;
         D.fx = P->rig.fx; D.fy = P->rig.fy; D.cx = P->rig.cx; D.cy = P->rig.cy; D.b = (double)P->rig.baseline;
 
         const int obsBlocks = std::max(1, std::min((NF + 255) / 256, 4 * nCU));
@@ -699,11 +839,14 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         const size_t wStage = (size_t)BA_SCHUR_WAVES * 2 * maxSlots * 18 * sizeof(double) + (size_t)BA_SCHUR_WAVES * maxSlots * sizeof(int) + 16;
         const size_t schurLds = (ldsS ? sysDoubles * sizeof(double) : 0) + wStage;
         const size_t backLds = (size_t)BA_SCHUR_WAVES * maxSlots * 18 * sizeof(double) + (size_t)BA_SCHUR_WAVES * maxSlots * sizeof(int) + 16;
-        const bool solveLds = sysDoubles * sizeof(double) <= 150 * 1024;
+        const int ldA = ((n + 31) / 32) * 32 + 1;     // row stride = 1 (mod 32) doubles: conflict-free row-per-lane access
+        const size_t solveLdsBytes = ((size_t)n * ldA + n + 8) * sizeof(double);
+        const bool solveLds = solveLdsBytes <= 150 * 1024;
+        if (n > 1024) { set_error("local BA: more than 170 free keyframes is not supported"); return VSLAM_ERR_CAPACITY; }
         if (schurLds > 160 * 1024) { set_error("local BA: landmark with too many views for the LDS staging"); return VSLAM_ERR_CAPACITY; }
         if (ldsS) VS_HIP(hipFuncSetAttribute((const void*)k_ba_schur<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurLds));
         else VS_HIP(hipFuncSetAttribute((const void*)k_ba_schur<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurLds));
-        if (solveLds) VS_HIP(hipFuncSetAttribute((const void*)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sysDoubles * sizeof(double) + 64)));
+        if (solveLds) VS_HIP(hipFuncSetAttribute((const void*)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solveLdsBytes));
 
         // ---- LM (GTSAM 4.2 policy) -----------------------------------------------------------------
         const int maxIterations = pass == 0 ? 5 : 10;
@@ -713,6 +856,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         auto linearize = [&]() -> vslam_status {
             int t = g_baTimer.begin("ba_linearize");
             if (NF) hipLaunchKernelGGL(k_ba_linearize, dim3(obsBlocks), dim3(256), 0, stream, D);
+            VS_HIP(hipMemsetAsync(d_Sedge.p, 0, ((size_t)n * n + n) * sizeof(double), stream));
             hipLaunchKernelGGL(k_ba_edges, dim3(1), dim3(256), 0, stream, D, 0, NF ? obsBlocks : 0);
             g_baTimer.end(t);
             return VSLAM_OK;
@@ -742,8 +886,15 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
                     }
                     g_baTimer.end(t);
                     t = g_baTimer.begin("ba_solve");
-                    hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(1024), solveLds ? sysDoubles * sizeof(double) + 64 : 64, stream, D,
-                                       lambda, (n > 0 && ldsS) ? lmBlocks : 0, solveLds ? 1 : 0);
+                    if (n > 0 && ldsS) {
+                        VS_HIP(hipMemsetAsync(d_S.p, 0, (size_t)n * n * sizeof(double), stream));
+                        VS_HIP(hipMemsetAsync(d_rhs.p, 0, (size_t)n * sizeof(double), stream));
+                        hipLaunchKernelGGL(k_ba_reduce, dim3(((int)sysDoubles + 255) / 256, 8), dim3(256), 0, stream, D, lmBlocks);
+                    } else if (n > 0) {
+                        hipLaunchKernelGGL(k_ba_reduce, dim3(((int)sysDoubles + 255) / 256, 1), dim3(256), 0, stream, D, 0);   // + BetweenFactor blocks
+                    }
+                    hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(std::max(64, vslam::align_up(n, 64))),
+                                       solveLds ? solveLdsBytes : 64, stream, D, lambda, solveLds ? 1 : 0, solveLds ? ldA : n);
                     g_baTimer.end(t);
                     t = g_baTimer.begin("ba_back");
                     if (Lp) hipLaunchKernelGGL(k_ba_back, dim3(lmBlocks), dim3(256), backLds, stream, D, lambda, maxSlots);
@@ -754,6 +905,9 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
                     g_baTimer.end(t);
                     VS_HIP(hipGetLastError());
                     int fail = 0;
+#ifdef VSLAM_BA_STAMPS
+                    { double st[16]; hipMemcpy(st, d_sums.p + 8, 7 * sizeof(double), hipMemcpyDeviceToHost); fprintf(stderr, "solve stamps (cycles): load %.0f edges %.0f chol %.0f fwd %.0f bwd %.0f retract %.0f\n", st[1]-st[0], st[2]-st[1], st[3]-st[2], st[4]-st[3], st[5]-st[4], st[6]-st[5]); }
+#endif
                     VS_HIP(hipMemcpyAsync(sums, d_sums.p, 3 * sizeof(double), hipMemcpyDeviceToHost, stream));
                     VS_HIP(hipMemcpyAsync(&fail, d_flags.p, sizeof(int), hipMemcpyDeviceToHost, stream));
                     VS_HIP(hipStreamSynchronize(stream));
@@ -821,8 +975,6 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
     VS_HIP(hipStreamSynchronize(stream));
     for (int k = 0; k < K; k++) pose_to_rm16(poseOut[k], R->kf_pose_wc + 16 * (size_t)k);
     if (NP) memcpy(R->pair_wrong, wrong.data(), NP);
-    hipStreamDestroy(stream);
-    g_baTimer.stream = nullptr;
     return VSLAM_OK;
 }
 
