@@ -146,90 +146,147 @@ void launch_proj_candidates(hipStream_t s, const ProjArgs& A, const int* matches
     hipLaunchKernelGGL(k_proj_candidates, dim3((2 * A.M + 3) / 4), dim3(256), 0, s, A, matches, topk, stats);
 }
 
+// The accept rule of the reference scan given the first / second unclaimed key of each side
+// (src/FeatureMatcher.cpp:341-383).  Returns -1 (no match) or (right << 16) | keypoint index.
+__device__ __forceinline__ int proj_decide(unsigned long long l1, unsigned long long l2, unsigned long long r1,
+                                           unsigned long long r2) {
+    const int matchDistProj = 100;      // include/FeatureMatcher.h:27
+    const float ratioProj = 0.8f;       // include/FeatureMatcher.h:28
+    int bestDist = 256, bestIdx = -1, bestLev = -1, bestLev2 = -1, secDist = 256;
+    if (l1 != KEY_NONE) { bestDist = key_dist(l1); bestIdx = key_idx(l1); bestLev = key_oct(l1); }
+    if (l2 != KEY_NONE) { secDist = key_dist(l2); bestLev2 = key_oct(l2); }
+    int bestDistR = 256, bestIdxR = -1, bestLevR = -1, bestLevR2 = -1, secDistR = 256;
+    if (r1 != KEY_NONE) { bestDistR = key_dist(r1); bestIdxR = key_idx(r1); bestLevR = key_oct(r1); }
+    if (r2 != KEY_NONE) { secDistR = key_dist(r2); bestLevR2 = key_oct(r2); }
+    // a distance of 256 never replaces the initial 256 in the reference's strict "<" scan,
+    // and with no second candidate the reference leaves secDist = 256, bestLev2 = -1
+    if (bestDist >= 256) { bestDist = 256; bestIdx = -1; bestLev = -1; }
+    if (secDist >= 256) { secDist = 256; bestLev2 = -1; }
+    if (bestDistR >= 256) { bestDistR = 256; bestIdxR = -1; bestLevR = -1; }
+    if (secDistR >= 256) { secDistR = 256; bestLevR2 = -1; }
+    bool right = false;
+    if (bestDist > bestDistR) {
+        bestDist = bestDistR; secDist = secDistR; bestLev = bestLevR; bestLev2 = bestLevR2; bestIdx = bestIdxR;
+        right = true;
+    }
+    if (bestDist > matchDistProj) return -1;
+    if (bestLev == bestLev2 && (float)bestDist >= ratioProj * (float)secDist) return -1;
+    return (right ? 1 << 16 : 0) | bestIdx;
+}
+
+// Parallel: the decision each map point takes IF the two best keys of both its lists are still unclaimed
+// when its turn comes (the common case).  need[i] = those four keypoint indices (0xffff = none),
+// tent[i] = proj_decide of them.
+__global__ __launch_bounds__(256) void k_proj_tentative(int M, const unsigned long long* __restrict__ topk,
+                                                        const int* __restrict__ matches, int* __restrict__ tent,
+                                                        unsigned long long* __restrict__ need) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const unsigned long long* k = topk + (size_t)i * 16;
+    const unsigned long long l1 = k[0], l2 = k[1], r1 = k[8], r2 = k[9];
+    const bool skip = matches[2 * i] >= 0 || matches[2 * i + 1] >= 0;
+    tent[i] = skip ? -2 : proj_decide(l1, l2, r1, r2);
+    auto ix = [](unsigned long long key) -> unsigned long long { return key == KEY_NONE ? 0xffffull : (unsigned long long)key_idx(key); };
+    need[i] = ix(l1) | (ix(l2) << 16) | (ix(r1) << 32) | (ix(r2) << 48);
+}
+
 // One wave walks the map points in order (the greedy claims are sequential by definition).
+// Sixteen map points per step (lane = 4*q + e): each lane prefetches one of the four keypoint indices
+// whose claim state decides whether the precomputed decision stands; if any of them has been claimed
+// meanwhile, the general path re-derives the first two unclaimed keys of both lists (and, if a full list
+// is exhausted, rescans that side with the claims applied), so the result is exact for any input.
 __global__ __launch_bounds__(64) void k_proj_resolve(ProjArgs A, const unsigned long long* __restrict__ topk,
+                                                     const int* __restrict__ tent,
+                                                     const unsigned long long* __restrict__ need,
                                                      int* __restrict__ matchedL, int* __restrict__ matchedR,
                                                      int* __restrict__ matches, int* __restrict__ outp) {
     extern __shared__ int claims[];
     int* cl = claims;
     int* cr = claims + A.n[0];
+    int* ri = cr + A.n[1];      // TrackedKeys::rightIdxs / leftIdxs staged next to the claim tables:
+    int* li = ri + A.n[0];      // the stereo-partner lookup is on the serial path
     const int lane = threadIdx.x;
-    for (int k = lane; k < A.n[0]; k += 64) cl[k] = matchedL[k];
-    for (int k = lane; k < A.n[1]; k += 64) cr[k] = matchedR[k];
+    for (int k = lane; k < A.n[0]; k += 64) { cl[k] = matchedL[k]; ri[k] = A.rightIdxs[k]; }
+    for (int k = lane; k < A.n[1]; k += 64) { cr[k] = matchedR[k]; li[k] = A.leftIdxs[k]; }
     __syncthreads();
     int nMatches = 0;
-    const int matchDistProj = 100;      // include/FeatureMatcher.h:27
-    const float ratioProj = 0.8f;       // include/FeatureMatcher.h:28
-    for (int i = 0; i < A.M; i++) {
-        if (matches[2 * i] >= 0 || matches[2 * i + 1] >= 0) continue;
-        const int side = lane >= PROJ_K ? 1 : 0;
-        unsigned long long key = KEY_NONE;
-        if (lane < 2 * PROJ_K) key = topk[((size_t)i * 2 + side) * PROJ_K + (lane - side * PROJ_K)];
-        const bool valid = key != KEY_NONE;
-        bool fre = false;
-        if (valid) fre = (side ? cr[key_idx(key)] : cl[key_idx(key)]) < 0;
-        const unsigned long long vmask = __ballot(valid), fmask = __ballot(fre);
-        unsigned long long b1k[2], b2k[2];
+    const int q = lane >> 2, e = lane & 3;
+    auto load_need = [&](int base) -> int {
+        const int i = base + q;
+        return i < A.M ? (int)((need[i] >> (16 * e)) & 0xffffull) : 0xffff;
+    };
+    auto load_tent = [&](int base) -> int {
+        const int i = base + q;
+        return i < A.M ? tent[i] : -2;
+    };
+    int nextNeed = load_need(0), nextTent = load_tent(0);
+    for (int base = 0; base < A.M; base += 16) {
+        const int myNeed = nextNeed, myTent = nextTent;
+        nextNeed = load_need(base + 16);
+        nextTent = load_tent(base + 16);
+        for (int qq = 0; qq < 16; qq++) {
+            const int i = base + qq;
+            if (i >= A.M) break;
+            const int t = __shfl(myTent, qq * 4);
+            if (t == -2) continue;                               // already matched before this call
+            bool claimed = false;
+            if (q == qq && myNeed != 0xffff) claimed = (e >= 2 ? cr[myNeed] : cl[myNeed]) >= 0;
+            int dec = t;
+            if (__ballot(claimed)) {
+                // general path: first two unclaimed keys of each list
+                const int side = lane >= PROJ_K ? 1 : 0;
+                unsigned long long key = KEY_NONE;
+                if (lane < 16) key = topk[(size_t)i * 16 + lane];
+                const bool valid = key != KEY_NONE;
+                bool fre = false;
+                if (valid) fre = (side ? cr[key_idx(key)] : cl[key_idx(key)]) < 0;
+                const unsigned long long vmask = __ballot(valid), fmask = __ballot(fre);
+                unsigned long long b1k[2], b2k[2];
 #pragma unroll
-        for (int s = 0; s < 2; s++) {
-            const unsigned vm = (unsigned)((vmask >> (s * PROJ_K)) & ((1u << PROJ_K) - 1));
-            unsigned fm = (unsigned)((fmask >> (s * PROJ_K)) & ((1u << PROJ_K) - 1));
-            const bool full = vm == ((1u << PROJ_K) - 1);
-            if (full && __popc(fm) < 2) {
-                // rare: rescan this side with the claims applied
-                const vslam_mappoint_view* mp = A.mpv + i;
-                uint32_t md[8];
-                load_mp_desc(mp, md);
-                unsigned long long o2[2] = {KEY_NONE, KEY_NONE};
-                const float px = s ? mp->pred_rx : mp->pred_lx, py = s ? mp->pred_ry : mp->pred_ly;
-                const int ps = s ? mp->scale_level_r : mp->scale_level_l;
-                scan_side<2>(A, s, md, px, py, ps, s ? cr : cl, o2);
-                b1k[s] = o2[0];
-                b2k[s] = o2[1];
-            } else {
-                int l1 = -1, l2 = -1;
-                if (fm) { l1 = __ffs(fm) - 1; fm &= fm - 1; }
-                if (fm) { l2 = __ffs(fm) - 1; }
-                const unsigned long long k1 = __shfl(key, (l1 < 0 ? 0 : l1) + s * PROJ_K);
-                const unsigned long long k2 = __shfl(key, (l2 < 0 ? 0 : l2) + s * PROJ_K);
-                b1k[s] = l1 < 0 ? KEY_NONE : k1;
-                b2k[s] = l2 < 0 ? KEY_NONE : k2;
+                for (int s = 0; s < 2; s++) {
+                    const int sh = s * PROJ_K;
+                    const unsigned vm = (unsigned)((vmask >> sh) & 0xffu);
+                    unsigned fm = (unsigned)((fmask >> sh) & 0xffu);
+                    if (vm == 0xffu && __popc(fm) < 2) {
+                        const vslam_mappoint_view* mp = A.mpv + i;
+                        uint32_t md[8];
+                        load_mp_desc(mp, md);
+                        unsigned long long o2[2] = {KEY_NONE, KEY_NONE};
+                        const float px = s ? mp->pred_rx : mp->pred_lx, py = s ? mp->pred_ry : mp->pred_ly;
+                        const int ps = s ? mp->scale_level_r : mp->scale_level_l;
+                        scan_side<2>(A, s, md, px, py, ps, s ? cr : cl, o2);
+                        b1k[s] = o2[0];
+                        b2k[s] = o2[1];
+                    } else {
+                        int l1 = -1, l2 = -1;
+                        if (fm) { l1 = __ffs(fm) - 1; fm &= fm - 1; }
+                        if (fm) { l2 = __ffs(fm) - 1; }
+                        const unsigned long long k1 = __shfl(key, (l1 < 0 ? 0 : l1) + sh);
+                        const unsigned long long k2 = __shfl(key, (l2 < 0 ? 0 : l2) + sh);
+                        b1k[s] = l1 < 0 ? KEY_NONE : k1;
+                        b2k[s] = l2 < 0 ? KEY_NONE : k2;
+                    }
+                }
+                dec = proj_decide(b1k[0], b2k[0], b1k[1], b2k[1]);
             }
-        }
-        int bestDist = 256, bestIdx = -1, bestLev = -1, bestLev2 = -1, secDist = 256;
-        if (b1k[0] != KEY_NONE) { bestDist = key_dist(b1k[0]); bestIdx = key_idx(b1k[0]); bestLev = key_oct(b1k[0]); }
-        if (b2k[0] != KEY_NONE) { secDist = key_dist(b2k[0]); bestLev2 = key_oct(b2k[0]); }
-        int bestDistR = 256, bestIdxR = -1, bestLevR = -1, bestLevR2 = -1, secDistR = 256;
-        if (b1k[1] != KEY_NONE) { bestDistR = key_dist(b1k[1]); bestIdxR = key_idx(b1k[1]); bestLevR = key_oct(b1k[1]); }
-        if (b2k[1] != KEY_NONE) { secDistR = key_dist(b2k[1]); bestLevR2 = key_oct(b2k[1]); }
-        // a distance of 256 never replaces the initial 256 in the reference's strict "<" scan,
-        // and with no second candidate the reference leaves secDist = 256, bestLev2 = -1
-        if (bestDist >= 256) { bestDist = 256; bestIdx = -1; bestLev = -1; }
-        if (secDist >= 256) { secDist = 256; bestLev2 = -1; }
-        if (bestDistR >= 256) { bestDistR = 256; bestIdxR = -1; bestLevR = -1; }
-        if (secDistR >= 256) { secDistR = 256; bestLevR2 = -1; }
-        bool right = false;
-        if (bestDist > bestDistR) {
-            bestDist = bestDistR; secDist = secDistR; bestLev = bestLevR; bestLev2 = bestLevR2;
-            right = true;
-        }
-        if (bestDist > matchDistProj) continue;
-        if (bestLev == bestLev2 && (float)bestDist >= ratioProj * (float)secDist) continue;
-        nMatches++;
-        if (lane == 0) {
-            if (right) {
-                cr[bestIdxR] = i;
-                matches[2 * i + 1] = bestIdxR;
-                const int l = A.leftIdxs[bestIdxR];
-                if (l >= 0) { matches[2 * i] = l; cl[l] = i; }
-            } else {
-                cl[bestIdx] = i;
-                matches[2 * i] = bestIdx;
-                const int r = A.rightIdxs[bestIdx];
-                if (r >= 0) { matches[2 * i + 1] = r; cr[r] = i; }
+            if (dec < 0) continue;
+            nMatches++;
+            if (lane == 0) {
+                const int idx = dec & 0xffff;
+                if (dec >> 16) {
+                    cr[idx] = i;
+                    matches[2 * i + 1] = idx;
+                    const int l = li[idx];
+                    if (l >= 0) { matches[2 * i] = l; cl[l] = i; }
+                } else {
+                    cl[idx] = i;
+                    matches[2 * i] = idx;
+                    const int r = ri[idx];
+                    if (r >= 0) { matches[2 * i + 1] = r; cr[r] = i; }
+                }
             }
+            __syncthreads();   // single wave: orders the LDS claim writes before the next map point's reads
         }
-        __syncthreads();
     }
     __syncthreads();
     for (int k = lane; k < A.n[0]; k += 64) matchedL[k] = cl[k];
@@ -237,10 +294,11 @@ __global__ __launch_bounds__(64) void k_proj_resolve(ProjArgs A, const unsigned 
     if (lane == 0) outp[0] = nMatches;
 }
 
-void launch_proj_resolve(hipStream_t s, const ProjArgs& A, const unsigned long long* topk,
-                         int* matchedL, int* matchedR, int* matches, int* out) {
-    const size_t sh = (size_t)(A.n[0] + A.n[1] + 1) * sizeof(int);
-    hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(64), sh, s, A, topk, matchedL, matchedR, matches, out);
+void launch_proj_resolve(hipStream_t s, const ProjArgs& A, const unsigned long long* topk, int* tent,
+                         unsigned long long* need, int* matchedL, int* matchedR, int* matches, int* out) {
+    if (A.M > 0) hipLaunchKernelGGL(k_proj_tentative, dim3((A.M + 255) / 256), dim3(256), 0, s, A.M, topk, matches, tent, need);
+    const size_t sh = (size_t)(2 * (A.n[0] + A.n[1]) + 1) * sizeof(int);
+    hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(64), sh, s, A, topk, tent, need, matchedL, matchedR, matches, out);
 }
 
 }  // namespace vslam
@@ -250,11 +308,13 @@ using namespace vslam;
 vslam_status vslam_matcher::ensure_proj_cap(int M) {
     if (M <= projCap && d_matchedL && d_projOut) return VSLAM_OK;
     if (M > projCap) {
-        hipFree(d_mpv); hipFree(d_topk); hipFree(d_matches);
+        hipFree(d_mpv); hipFree(d_topk); hipFree(d_matches); hipFree(d_tent); hipFree(d_need);
         projCap = vslam::align_up(std::max(M, 1), 1024);
         VS_HIP(hipMalloc(&d_mpv, (size_t)projCap * sizeof(vslam_mappoint_view)));
         VS_HIP(hipMalloc(&d_topk, (size_t)projCap * 2 * PROJ_K * sizeof(unsigned long long)));
         VS_HIP(hipMalloc(&d_matches, (size_t)projCap * 2 * sizeof(int)));
+        VS_HIP(hipMalloc(&d_tent, (size_t)projCap * sizeof(int)));
+        VS_HIP(hipMalloc(&d_need, (size_t)projCap * sizeof(unsigned long long)));
     }
     if (!d_projOut) VS_HIP(hipMalloc(&d_projOut, 4 * sizeof(int)));
     if (!d_matchedL) {
@@ -281,7 +341,7 @@ vslam_status vslam_matcher::proj_enqueue(int M, float rad) {
     launch_proj_candidates(stream, A, d_matches, d_topk, d_stats);
     timer.end(t);
     t = timer.begin("proj_resolve");
-    launch_proj_resolve(stream, A, d_topk, d_matchedL, d_matchedR, d_matches, d_projOut);
+    launch_proj_resolve(stream, A, d_topk, d_tent, d_need, d_matchedL, d_matchedR, d_matches, d_projOut);
     timer.end(t);
     VS_HIP(hipGetLastError());
     return VSLAM_OK;
