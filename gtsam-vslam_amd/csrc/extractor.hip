@@ -232,10 +232,17 @@ vslam_status vslam_extractor::init(const vslam_fe_params* p, int w, int h, int b
     VS_HIP(hipMalloc(&d_disc, disc.size()));
     VS_HIP(hipMemcpy(d_disc, disc.data(), disc.size(), hipMemcpyHostToDevice));
     nKept.assign(nimg, 0);
+    sscOut.assign((size_t)nimg * nLevels, {});
+    {
+        int nt = 3;   // + the calling thread; VSLAM_HOST_THREADS overrides (0 = no extra threads)
+        if (const char* e = getenv("VSLAM_HOST_THREADS")) nt = std::max(0, std::min(15, atoi(e)));
+        pool_start(nt);
+    }
     return VSLAM_OK;
 }
 
 void vslam_extractor::release() {
+    pool_stop();
     if (stream) hipStreamSynchronize(stream);
     timer.destroy();
     hipFree(d_pyr); hipFree(d_blur); hipFree(d_xtab); hipFree(d_ytab);
@@ -310,6 +317,66 @@ void vslam_extractor::ssc_level(const uint32_t* cand, int n, int numRet, int col
     for (int i : lastPicked) out.push_back(cand[order[i]]);
 }
 
+void vslam_extractor::ssc_task(int task) {
+    // tasks are ordered level-major so the big level-0 jobs start first
+    const int l = task / nimg, i = task % nimg;
+    const int* lc = h_levelCount + (size_t)i * (MAX_LEVELS + 1);
+    int coff = 0;
+    for (int q = 0; q < l; q++) coff += lc[q];
+    const int n = lc[l];
+    std::vector<uint32_t>& out = sscOut[(size_t)i * nLevels + l];
+    const uint32_t* cand = h_cand + (size_t)i * candCap + coff;
+    if (n > featurePerLevel[l]) ssc_level(cand, n, featurePerLevel[l], P.w[l], P.h[l], out);
+    else out.assign(cand, cand + n);
+}
+
+void vslam_extractor::pool_start(int nThreads) {
+    for (int t = 0; t < nThreads; t++)
+        pool.workers.emplace_back([this]() {
+            int seen = 0;
+            for (;;) {
+                {
+                    std::unique_lock<std::mutex> lk(pool.mu);
+                    pool.cvStart.wait(lk, [&] { return pool.stop || pool.generation != seen; });
+                    if (pool.stop) return;
+                    seen = pool.generation;
+                }
+                for (;;) {
+                    const int task = pool.next.fetch_add(1);
+                    if (task >= pool.nTasks) break;
+                    ssc_task(task);
+                    std::lock_guard<std::mutex> lk(pool.mu);
+                    if (++pool.finished == pool.nTasks) pool.cvDone.notify_all();
+                }
+            }
+        });
+}
+
+void vslam_extractor::pool_stop() {
+    { std::lock_guard<std::mutex> lk(pool.mu); pool.stop = true; }
+    pool.cvStart.notify_all();
+    for (auto& w : pool.workers) w.join();
+    pool.workers.clear();
+}
+
+void vslam_extractor::pool_run(int nTasks) {
+    {
+        std::lock_guard<std::mutex> lk(pool.mu);
+        pool.nTasks = nTasks; pool.finished = 0; pool.next = 0; pool.generation++;
+    }
+    pool.cvStart.notify_all();
+    // the calling thread works too
+    for (;;) {
+        const int task = pool.next.fetch_add(1);
+        if (task >= nTasks) break;
+        ssc_task(task);
+        std::lock_guard<std::mutex> lk(pool.mu);
+        if (++pool.finished == nTasks) pool.cvDone.notify_all();
+    }
+    std::unique_lock<std::mutex> lk(pool.mu);
+    pool.cvDone.wait(lk, [&] { return pool.finished == pool.nTasks; });
+}
+
 vslam_status vslam_extractor::run() {
     VS_HIP(hipSetDevice(device));
     int t;
@@ -331,30 +398,21 @@ vslam_status vslam_extractor::run() {
     VS_HIP(hipGetLastError());
     VS_HIP(hipStreamSynchronize(stream));
 
-    // host: SSC per (image, level); keeps are staged level-major
+    // host: SSC per (image, level) on the worker pool; keeps are staged level-major
+    for (int i = 0; i < nimg; i++)
+        if (h_levelCount[(size_t)i * (MAX_LEVELS + 1) + MAX_LEVELS] > candCap) { set_error("FAST candidate overflow"); return VSLAM_ERR_CAPACITY; }
+    pool_run(nimg * nLevels);
     int maxKept = 0;
-    std::vector<uint32_t> keep;
     for (int i = 0; i < nimg; i++) {
-        const int* lc = h_levelCount + (size_t)i * (MAX_LEVELS + 1);
-        const uint32_t* cand = h_cand + (size_t)i * candCap;
         uint32_t* kout = h_kept + (size_t)i * keptCap;
         int* koff = h_keptOff + (size_t)i * (MAX_LEVELS + 1);
-        if (lc[MAX_LEVELS] > candCap) { set_error("FAST candidate overflow"); return VSLAM_ERR_CAPACITY; }
-        int coff = 0, k = 0;
+        int k = 0;
         for (int l = 0; l < nLevels; l++) {
-            const int n = lc[l];
+            const std::vector<uint32_t>& keep = sscOut[(size_t)i * nLevels + l];
             koff[l] = k;
-            if (n > featurePerLevel[l]) {
-                ssc_level(cand + coff, n, featurePerLevel[l], P.w[l], P.h[l], keep);
-                if (k + (int)keep.size() > keptCap) { set_error("kept-keypoint overflow"); return VSLAM_ERR_CAPACITY; }
-                memcpy(kout + k, keep.data(), keep.size() * sizeof(uint32_t));
-                k += (int)keep.size();
-            } else {
-                if (k + n > keptCap) { set_error("kept-keypoint overflow"); return VSLAM_ERR_CAPACITY; }
-                memcpy(kout + k, cand + coff, (size_t)n * sizeof(uint32_t));
-                k += n;
-            }
-            coff += n;
+            if (k + (int)keep.size() > keptCap) { set_error("kept-keypoint overflow"); return VSLAM_ERR_CAPACITY; }
+            if (!keep.empty()) memcpy(kout + k, keep.data(), keep.size() * sizeof(uint32_t));
+            k += (int)keep.size();
         }
         for (int l = nLevels; l <= MAX_LEVELS; l++) koff[l] = k;
         nKept[i] = k;

@@ -3,6 +3,10 @@
 // `nimg` same-sized images per run).
 #pragma once
 #include "extract_kernels.hpp"
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 
 struct vslam_extractor {
     vslam_fe_params prm{};
@@ -44,6 +48,21 @@ struct vslam_extractor {
     uint8_t* d_desc = nullptr;        // nimg * keptCap * 32
     std::vector<int> nKept;           // per image, after the last run
     bool ran = false;
+
+    // host worker pool for the sequential SSC stage: one task per (image, level)
+    struct SscPool {
+        std::vector<std::thread> workers;
+        std::mutex mu;
+        std::condition_variable cvStart, cvDone;
+        std::atomic<int> next{0};
+        int nTasks = 0, generation = 0, finished = 0;
+        bool stop = false;
+    } pool;
+    std::vector<std::vector<uint32_t>> sscOut;     // [nimg * nLevels]
+    void pool_start(int nThreads);
+    void pool_stop();
+    void pool_run(int nTasks);
+    void ssc_task(int task);
 
     vslam_status init(const vslam_fe_params* p, int w, int h, int batch, int dev);
     void release();
