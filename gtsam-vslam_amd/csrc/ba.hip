@@ -20,6 +20,7 @@
 // The LM policy (GTSAM 4.2) runs on the host between launches; both passes
 // (5 then 10 iterations) start from the caller's values, separated by the chi2 re-check kernel.
 #include "common.hpp"
+#include "comm.hpp"
 #include "dmath.hpp"
 #include <algorithm>
 #include <cmath>
@@ -610,6 +611,20 @@ __global__ __launch_bounds__(256) void k_ba_chi2(BaChi C) {
     C.wrong[p] = w;
 }
 
+// landmark exchange of the sharded path: diff = cur - init (zero for landmarks this rank does not own),
+// all-reduce, cur = init + diff
+__global__ __launch_bounds__(256) void k_ba_lm_diff(int n, const double* __restrict__ cur, const double* __restrict__ init,
+                                                    double* __restrict__ diff, int mode) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (mode == 0) diff[i] = cur[i] - init[i];
+}
+__global__ __launch_bounds__(256) void k_ba_lm_apply(int n, double* __restrict__ cur, const double* __restrict__ init,
+                                                     const double* __restrict__ diff) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) cur[i] = init[i] + diff[i];
+}
+
 }  // namespace vslam
 
 using namespace vslam;
@@ -645,7 +660,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         set_error("vslam_local_ba: invalid problem");
         return VSLAM_ERR_INVALID;
     }
-    if (comm) { set_error("vslam_local_ba: multi-GPU communicator not available in this build"); return VSLAM_ERR_COMM; }
+    const int rank = comm ? comm->rank : 0, world = comm ? comm->world : 1;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available (no CPU fallback)"); return VSLAM_ERR_NO_DEVICE; }
     if (device < 0 || device >= ndev) return VSLAM_ERR_INVALID;
@@ -662,7 +677,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         hipStream_t stream = nullptr;
         int device = -1;
         DevBuf<DPose> d_pose0, d_poseA, d_poseB;
-        DevBuf<double> d_lm0, d_lmA, d_lmB, d_facZ, d_facIs, d_facJ, d_S, d_rhs, d_Spart, d_Sedge, d_dP, d_dL, d_sums, d_partial;
+        DevBuf<double> d_lm0, d_lmA, d_lmB, d_facZ, d_facIs, d_facJ, d_S, d_rhs, d_Spart, d_Sedge, d_dP, d_dL, d_lmDiff, d_sums, d_partial;
         DevBuf<int> d_facKf, d_facFi, d_facLp, d_facLm, d_lpStart, d_lpSlotStart, d_slotStart, d_slotFi, d_lpOrig, d_fidx, d_flags;
         DevBuf<int> d_pairKf, d_pairLm, d_pairOct;
         DevBuf<uint8_t> d_facRight, d_pairFlags, d_kfLocal, d_kfPresent, d_lmPresent, d_wrong;
@@ -677,7 +692,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
     g_baTimer.multi = true;
     auto &d_pose0 = ws->d_pose0, &d_poseA = ws->d_poseA, &d_poseB = ws->d_poseB;
     auto &d_lm0 = ws->d_lm0, &d_lmA = ws->d_lmA, &d_lmB = ws->d_lmB, &d_facZ = ws->d_facZ, &d_facIs = ws->d_facIs, &d_facJ = ws->d_facJ,
-         &d_S = ws->d_S, &d_rhs = ws->d_rhs, &d_Spart = ws->d_Spart, &d_Sedge = ws->d_Sedge, &d_dP = ws->d_dP, &d_dL = ws->d_dL, &d_sums = ws->d_sums, &d_partial = ws->d_partial;
+         &d_S = ws->d_S, &d_rhs = ws->d_rhs, &d_Spart = ws->d_Spart, &d_Sedge = ws->d_Sedge, &d_dP = ws->d_dP, &d_dL = ws->d_dL, &d_lmDiff = ws->d_lmDiff, &d_sums = ws->d_sums, &d_partial = ws->d_partial;
     auto &d_facKf = ws->d_facKf, &d_facFi = ws->d_facFi, &d_facLp = ws->d_facLp, &d_facLm = ws->d_facLm, &d_lpStart = ws->d_lpStart,
          &d_lpSlotStart = ws->d_lpSlotStart, &d_slotStart = ws->d_slotStart, &d_slotFi = ws->d_slotFi, &d_lpOrig = ws->d_lpOrig,
          &d_fidx = ws->d_fidx, &d_flags = ws->d_flags, &d_pairKf = ws->d_pairKf, &d_pairLm = ws->d_pairLm, &d_pairOct = ws->d_pairOct;
@@ -718,6 +733,8 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         facs.reserve((size_t)2 * NP);
         for (int p = 0; p < NP; p++) {
             if (wrong[p]) continue;
+            if (P->pair_flags[p] & 3) { kfPresent[P->pair_kf[p]] = 1; lmPresent[P->pair_lm[p]] = 1; }   // graph membership is global
+            if (P->pair_lm[p] % world != rank) continue;      // landmark shard of this rank
             for (int side = 0; side < 2; side++) {
                 if (!((P->pair_flags[p] >> side) & 1)) continue;
                 HostFac f{};
@@ -733,7 +750,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         for (int k = 0; k < K; k++) if (kfPresent[k] && !P->kf_fixed[k]) fidx[k] = F++;
         const int n = 6 * F;
         std::vector<int> lpOf(L, -1), lpOrig;
-        for (int l = 0; l < L; l++) if (lmPresent[l]) { lpOf[l] = (int)lpOrig.size(); lpOrig.push_back(l); }
+        for (int l = 0; l < L; l++) if (lmPresent[l] && l % world == rank) { lpOf[l] = (int)lpOrig.size(); lpOrig.push_back(l); }
         const int Lp = (int)lpOrig.size();
         for (HostFac& f : facs) { f.fi = fidx[f.kf]; f.lp = lpOf[f.lm]; }
         {   // bucket by landmark (counting sort, stable), then order each short bucket by free index
@@ -793,6 +810,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
             pose_compose(ai, pose0[e.b], e.measured);
             edges.push_back(e);
         }
+        if (rank != 0) edges.clear();      // the BetweenFactor chain is counted once (rank 0); S is summed over ranks
         const int NE = (int)edges.size();
 
         // ---- upload ------------------------------------------------------------------------------
@@ -800,7 +818,8 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         VS_HIP(d_facZ.alloc((size_t)2 * NF)); VS_HIP(d_facIs.alloc(NF)); VS_HIP(d_facRight.alloc(NF));
         VS_HIP(d_facJ.alloc((size_t)20 * NF));
         VS_HIP(d_lpStart.alloc(Lp + 1)); VS_HIP(d_lpSlotStart.alloc(Lp + 1)); VS_HIP(d_lpOrig.alloc(Lp)); VS_HIP(d_fidx.alloc(K)); VS_HIP(d_edges.alloc(NE));
-        VS_HIP(d_dP.alloc(n)); VS_HIP(d_dL.alloc((size_t)3 * Lp)); VS_HIP(d_S.alloc((size_t)n * n)); VS_HIP(d_rhs.alloc((size_t)2 * n + 2)); VS_HIP(d_Sedge.alloc((size_t)n * n + n));
+        VS_HIP(d_dP.alloc(n)); VS_HIP(d_dL.alloc((size_t)3 * Lp)); VS_HIP(d_S.alloc((size_t)n * n + 2 * n + 8));
+        VS_HIP(d_Sedge.alloc((size_t)n * n + n));   // (S | rhs | scratch are contiguous: one all-reduce buffer)
         VS_HIP(d_slotStart.alloc(slotStart.size() + 1)); VS_HIP(d_slotFi.alloc(slotFi.size() + 1));
         if (NF) {
             BA_UP(d_facKf, facKf); BA_UP(d_facFi, facFi); BA_UP(d_facLp, facLp); BA_UP(d_facLm, facLm);
@@ -825,7 +844,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         D.lpStart = d_lpStart.p; D.lpSlotStart = d_lpSlotStart.p; D.slotStart = d_slotStart.p; D.slotFi = d_slotFi.p;
         D.lpOrig = d_lpOrig.p; D.poseCur = d_poseA.p; D.poseTrial = d_poseB.p; D.fidx = d_fidx.p;
         D.lmCur = d_lmA.p; D.lmTrial = d_lmB.p; D.edges = d_edges.p;
-        D.S = d_S.p; D.rhs = d_rhs.p; D.Sedge = d_Sedge.p; D.dP = d_dP.p; D.dL = d_dL.p; D.sums = d_sums.p; D.flags = d_flags.p;
+        D.S = d_S.p; D.rhs = d_S.p + (size_t)n * n; D.Sedge = d_Sedge.p; D.dP = d_dP.p; D.dL = d_dL.p; D.sums = d_sums.p; D.flags = d_flags.p;
         D.fx = P->rig.fx; D.fy = P->rig.fy; D.cx = P->rig.cx; D.cy = P->rig.cy; D.b = (double)P->rig.baseline;
 
         const int obsBlocks = std::max(1, std::min((NF + 255) / 256, 4 * nCU));
@@ -859,6 +878,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
             VS_HIP(hipMemsetAsync(d_Sedge.p, 0, ((size_t)n * n + n) * sizeof(double), stream));
             hipLaunchKernelGGL(k_ba_edges, dim3(1), dim3(256), 0, stream, D, 0, NF ? obsBlocks : 0);
             g_baTimer.end(t);
+            if (comm) { const int tc = g_baTimer.begin("ba_allreduce"); VS_CHECK(comm_allreduce(comm, d_sums.p, 1, stream)); g_baTimer.end(tc); }
             return VSLAM_OK;
         };
         VS_CHECK(linearize());
@@ -879,20 +899,19 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
                     if (n > 0) {
                         if (ldsS) hipLaunchKernelGGL(k_ba_schur<true>, dim3(lmBlocks), dim3(256), schurLds, stream, D, lambda, maxSlots);
                         else {
-                            VS_HIP(hipMemsetAsync(d_S.p, 0, (size_t)n * n * sizeof(double), stream));
-                            VS_HIP(hipMemsetAsync(d_rhs.p, 0, (size_t)n * sizeof(double), stream));
+                            VS_HIP(hipMemsetAsync(d_S.p, 0, ((size_t)n * n + n) * sizeof(double), stream));
                             hipLaunchKernelGGL(k_ba_schur<false>, dim3(lmBlocks), dim3(256), schurLds, stream, D, lambda, maxSlots);
                         }
                     }
                     g_baTimer.end(t);
                     t = g_baTimer.begin("ba_solve");
                     if (n > 0 && ldsS) {
-                        VS_HIP(hipMemsetAsync(d_S.p, 0, (size_t)n * n * sizeof(double), stream));
-                        VS_HIP(hipMemsetAsync(d_rhs.p, 0, (size_t)n * sizeof(double), stream));
+                        VS_HIP(hipMemsetAsync(d_S.p, 0, ((size_t)n * n + n) * sizeof(double), stream));
                         hipLaunchKernelGGL(k_ba_reduce, dim3(((int)sysDoubles + 255) / 256, 8), dim3(256), 0, stream, D, lmBlocks);
                     } else if (n > 0) {
                         hipLaunchKernelGGL(k_ba_reduce, dim3(((int)sysDoubles + 255) / 256, 1), dim3(256), 0, stream, D, 0);   // + BetweenFactor blocks
                     }
+                    if (comm && n > 0) { const int tc = g_baTimer.begin("ba_allreduce"); VS_CHECK(comm_allreduce(comm, d_S.p, (size_t)n * n + n, stream)); g_baTimer.end(tc); }
                     hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(std::max(64, vslam::align_up(n, 64))),
                                        solveLds ? solveLdsBytes : 64, stream, D, lambda, solveLds ? 1 : 0, solveLds ? ldA : n);
                     g_baTimer.end(t);
@@ -903,6 +922,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
                     if (NF) hipLaunchKernelGGL(k_ba_eval, dim3(obsBlocks), dim3(256), 0, stream, D);
                     hipLaunchKernelGGL(k_ba_edges, dim3(1), dim3(256), 0, stream, D, 1, NF ? obsBlocks : 0);
                     g_baTimer.end(t);
+                    if (comm) { const int tc = g_baTimer.begin("ba_allreduce"); VS_CHECK(comm_allreduce(comm, d_sums.p + 1, 2, stream)); g_baTimer.end(tc); }
                     VS_HIP(hipGetLastError());
                     int fail = 0;
 #ifdef VSLAM_BA_STAMPS
@@ -950,6 +970,23 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         R->report[pass].lambda = lambda;
         R->n_residuals = NF; R->n_landmarks = Lp; R->n_free_kf = F; R->sum_k2 = sumK2;
 
+        if (comm) {
+            // every rank needs all landmarks for the chi2 pass and the result: exchange the shard updates
+            const int tc = g_baTimer.begin("ba_allreduce");
+            if (L) {
+                VS_HIP(d_lmDiff.alloc((size_t)3 * L));
+                hipLaunchKernelGGL(k_ba_lm_diff, dim3((3 * L + 255) / 256), dim3(256), 0, stream, 3 * L, D.lmCur, d_lm0.p, d_lmDiff.p, 0);
+                VS_CHECK(comm_allreduce(comm, d_lmDiff.p, (size_t)3 * L, stream));
+                hipLaunchKernelGGL(k_ba_lm_apply, dim3((3 * L + 255) / 256), dim3(256), 0, stream, 3 * L, D.lmCur, d_lm0.p, d_lmDiff.p);
+            }
+            double st[4] = {(double)NF, (double)Lp, (double)sumK2, 0.0};
+            VS_HIP(hipMemcpyAsync(d_sums.p + 4, st, sizeof(st), hipMemcpyHostToDevice, stream));
+            VS_CHECK(comm_allreduce(comm, d_sums.p + 4, 3, stream));
+            VS_HIP(hipMemcpyAsync(st, d_sums.p + 4, sizeof(st), hipMemcpyDeviceToHost, stream));
+            VS_HIP(hipStreamSynchronize(stream));
+            R->n_residuals = (int64_t)llround(st[0]); R->n_landmarks = (int64_t)llround(st[1]); R->sum_k2 = (int64_t)llround(st[2]);
+            g_baTimer.end(tc);
+        }
         // ---- chi2 re-check with the optimised values ---------------------------------------------
         VS_HIP(hipMemcpyAsync(d_kfPresent.p, kfPresent.data(), K, hipMemcpyHostToDevice, stream));
         if (L) VS_HIP(hipMemcpyAsync(d_lmPresent.p, lmPresent.data(), L, hipMemcpyHostToDevice, stream));

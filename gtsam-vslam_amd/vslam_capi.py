@@ -281,7 +281,7 @@ class BaResult(C.Structure):
                 ("n_landmarks", C.c_int64), ("n_free_kf", C.c_int64), ("sum_k2", C.c_int64)]
 
 
-def local_ba(rig, sigma_factor, inv_sigma_factor, prob, device=0):
+def local_ba(rig, sigma_factor, inv_sigma_factor, prob, device=0, comm=None):
     """LocalMapper::localBA numerical core through the C ABI."""
     L = lib()
     kfPose = np.ascontiguousarray(prob["kf_pose"], np.float64).reshape(-1, 16)
@@ -305,7 +305,7 @@ def local_ba(rig, sigma_factor, inv_sigma_factor, prob, device=0):
     wrong = np.zeros(max(len(pk), 1), np.uint8); wrong1 = np.zeros(max(len(pk), 1), np.uint8)
     R = BaResult()
     R.kf_pose_wc, R.lm_xyz, R.pair_wrong, R.pair_wrong_pass1 = _p(kfOut), _p(lmOut), _p(wrong), _p(wrong1)
-    _chk(L.vslam_local_ba(C.byref(P), C.byref(R), device, None))
+    _chk(L.vslam_local_ba(C.byref(P), C.byref(R), device, comm.h if comm is not None else None))
     reps = [dict(iterations=R.report[s].iterations, inner=R.report[s].inner_iterations,
                  initialError=R.report[s].initial_error, finalError=R.report[s].final_error, lam=R.report[s].lam)
             for s in range(2)]
@@ -346,3 +346,40 @@ def tracker_fetch(matcher, cap=65536):
     n = C.c_int32()
     _chk(matcher.L.vslam_tracker_fetch(matcher.h, _p(mt), _p(out), _p(act), cap, C.byref(n)))
     return mt[:n.value].copy(), out[:n.value].copy(), act[:n.value].copy()
+
+
+# ---- communicators for the landmark-sharded BA ----------------------------------------------
+class Comm:
+    def __init__(self, handle):
+        self.h = handle
+
+    def close(self):
+        if self.h:
+            lib().vslam_comm_destroy(self.h)
+            self.h = None
+
+
+def comm_create_local(world):
+    """`world` in-process ranks (host threads sharing one GPU)."""
+    arr = (C.c_void_p * world)()
+    _chk(lib().vslam_comm_create_local(world, arr))
+    return [Comm(C.c_void_p(arr[r])) for r in range(world)]
+
+
+def comm_create_rccl(rank, world, device, broadcast_bytes):
+    """RCCL communicator.  broadcast_bytes(buf: bytes|None) -> bytes must return rank 0's 128-byte id on
+    every rank (e.g. via torch.distributed.broadcast_object_list)."""
+    idbuf = (C.c_uint8 * 128)()
+    if rank == 0:
+        _chk(lib().vslam_comm_unique_id(idbuf))
+    uid = broadcast_bytes(bytes(idbuf) if rank == 0 else None)
+    assert len(uid) == 128
+    idbuf = (C.c_uint8 * 128).from_buffer_copy(uid)
+    h = C.c_void_p()
+    _chk(lib().vslam_comm_create_rccl(idbuf, rank, world, device, C.byref(h)))
+    return Comm(h)
+
+
+def landmark_owner(landmark_index, world):
+    """Shard rule of the multi-GPU BA: landmark l belongs to rank l % world."""
+    return landmark_index % world

@@ -243,8 +243,21 @@ typedef struct vslam_ba_result {
     int64_t n_residuals, n_landmarks, n_free_kf, sum_k2;   /* work figures of the last pass           */
 } vslam_ba_result;
 
-/* Opaque communicator for landmark-sharded BA over RCCL (NULL = single GPU). */
+/* Communicator for landmark-sharded BA (NULL = single GPU).  Every rank passes the SAME flattened problem;
+ * rank r owns the landmarks with index % world == r, forms its partial reduced camera system, and one
+ * all-reduce(sum, fp64) of [(6F)^2 + 6F] doubles per lambda trial (plus a 3-double cost reduction) makes the
+ * system identical everywhere; every rank then solves it redundantly and back-substitutes its own landmarks.
+ * Two transports:
+ *   rccl  : one process per GPU, RCCL over xGMI.  Rank 0 calls vslam_comm_unique_id, the host program
+ *           broadcasts the 128 bytes (e.g. torch.distributed), every rank calls vslam_comm_create_rccl.
+ *   local : `world` host threads of ONE process sharing one GPU, exchanging through host memory in a
+ *           fixed rank order (deterministic) — the single-box stand-in used by the tests. */
 typedef struct vslam_comm vslam_comm;
+vslam_status vslam_comm_unique_id(uint8_t id_out[128]);
+vslam_status vslam_comm_create_rccl(const uint8_t id[128], int32_t rank, int32_t world, int32_t device,
+                                    vslam_comm** out);
+vslam_status vslam_comm_create_local(int32_t world, vslam_comm** out_array /* world handles */);
+void vslam_comm_destroy(vslam_comm* comm);
 
 vslam_status vslam_local_ba(const vslam_ba_problem* problem, vslam_ba_result* result, int32_t device,
                             const vslam_comm* comm);

@@ -270,3 +270,25 @@ def pose3_logmap_derivative(T):
 def pose3_adjoint(T):
     T = np.ascontiguousarray(T, np.float64); A = np.zeros((6, 6))
     lib().vo_pose3_adjoint(_p(T), _p(A)); return A
+
+
+def ba_reduced_system_shard(rig, sigma_factor, inv_sigma_factor, prob, rank, world, lam=1e-5):
+    """Test-only: [S | rhs | cost] that landmark shard `rank` of `world` contributes (multi-GPU decomposition)."""
+    kfPose = np.ascontiguousarray(prob["kf_pose"], np.float64).reshape(-1, 16)
+    K = len(kfPose)
+    kfId = np.ascontiguousarray(prob["kf_id"], np.int64)
+    kfFixed = np.ascontiguousarray(prob["kf_fixed"], np.uint8); kfLocal = np.ascontiguousarray(prob["kf_local"], np.uint8)
+    lm = np.ascontiguousarray(prob["lm"], np.float64).reshape(-1, 3)
+    pk = np.ascontiguousarray(prob["pair_kf"], np.int32); pl = np.ascontiguousarray(prob["pair_lm"], np.int32)
+    pf = np.ascontiguousarray(prob["pair_flags"], np.uint8)
+    puv = np.ascontiguousarray(prob["pair_uv"], np.float32).reshape(-1, 4)
+    poct = np.ascontiguousarray(prob["pair_oct"], np.int32).reshape(-1, 2)
+    sf = np.ascontiguousarray(sigma_factor, np.float32); isf = np.ascontiguousarray(inv_sigma_factor, np.float32)
+    out = np.zeros((6 * K) ** 2 + 6 * K + 1, np.float64)
+    lib().vo_ba_reduced_system_shard.restype = C.c_int
+    F = lib().vo_ba_reduced_system_shard(C.c_double(rig["fx"]), C.c_double(rig["fy"]), C.c_double(rig["cx"]),
+                                         C.c_double(rig["cy"]), C.c_float(rig["bl"]), _p(sf), _p(isf), len(sf), K,
+                                         _p(kfPose), _p(kfId), _p(kfFixed), _p(kfLocal), len(lm), _p(lm), len(pk), _p(pk),
+                                         _p(pl), _p(pf), _p(puv), _p(poct), int(rank), int(world), C.c_double(lam), _p(out))
+    n = 6 * F
+    return out[:n * n + n + 1].copy(), F

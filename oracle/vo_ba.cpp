@@ -162,9 +162,32 @@ void inv3sym(const double* H, double* Hi) {     // inverse of a symmetric 3x3 by
 
 }  // namespace
 
+struct ShardSpec { int rank = 0, world = 1; double lambda = 0; std::vector<double>* S = nullptr; std::vector<double>* rhs = nullptr; double* cost = nullptr; int* nFree = nullptr; };
+
+static void localBAPassImpl(const BAProblem& P, const std::vector<uint8_t>& active, int maxIterations,
+                            std::vector<Pose>& kfPose, std::vector<Vec3>& lm, std::vector<uint8_t>& kfPresent,
+                            std::vector<uint8_t>& lmPresent, LMReport& rep, BAResult* stats, const ShardSpec* shard);
+
 void localBAPass(const BAProblem& P, const std::vector<uint8_t>& active, int maxIterations,
                  std::vector<Pose>& kfPose, std::vector<Vec3>& lm, std::vector<uint8_t>& kfPresent,
                  std::vector<uint8_t>& lmPresent, LMReport& rep, BAResult* stats) {
+    localBAPassImpl(P, active, maxIterations, kfPose, lm, kfPresent, lmPresent, rep, stats, nullptr);
+}
+
+void reducedSystemShard(const BAProblem& P, int rank, int world, double lambda, std::vector<double>& S,
+                        std::vector<double>& rhs, double& cost, int& nFree) {
+    std::vector<uint8_t> active(P.pairs.size(), 1), kp, lp;
+    std::vector<Pose> poses = P.kfPose;
+    std::vector<Vec3> lm = P.lm;
+    LMReport rep;
+    ShardSpec sp;
+    sp.rank = rank; sp.world = world; sp.lambda = lambda; sp.S = &S; sp.rhs = &rhs; sp.cost = &cost; sp.nFree = &nFree;
+    localBAPassImpl(P, active, 0, poses, lm, kp, lp, rep, nullptr, &sp);
+}
+
+static void localBAPassImpl(const BAProblem& P, const std::vector<uint8_t>& active, int maxIterations,
+                            std::vector<Pose>& kfPose, std::vector<Vec3>& lm, std::vector<uint8_t>& kfPresent,
+                            std::vector<uint8_t>& lmPresent, LMReport& rep, BAResult* stats, const ShardSpec* shard) {
     const int K = (int)P.kfPose.size(), L = (int)P.lm.size();
     kfPresent.assign(K, 0);
     lmPresent.assign(L, 0);
@@ -172,6 +195,8 @@ void localBAPass(const BAProblem& P, const std::vector<uint8_t>& active, int max
     for (size_t p = 0; p < P.pairs.size(); p++) {
         if (!active[p]) continue;
         const BAPair& bp = P.pairs[p];
+        if (bp.hasLeft || bp.hasRight) { kfPresent[bp.kf] = 1; lmPresent[bp.lm] = 1; }
+        if (shard && bp.lm % shard->world != shard->rank) continue;
         for (int side = 0; side < 2; side++) {
             if (side == 0 ? !bp.hasLeft : !bp.hasRight) continue;
             Fac f{};
@@ -193,7 +218,7 @@ void localBAPass(const BAProblem& P, const std::vector<uint8_t>& active, int max
     for (int k = 0; k < K; k++) if (kfPresent[k]) order.push_back(k);
     std::sort(order.begin(), order.end(), [&](int a, int b) { return P.kfId[a] < P.kfId[b]; });
     std::vector<Edge> edges;
-    for (size_t i = 0; i + 1 < order.size(); i++) {
+    for (size_t i = 0; i + 1 < order.size() && (!shard || shard->rank == 0); i++) {
         Edge e{};
         e.a = order[i]; e.b = order[i + 1]; e.fa = fidx[e.a]; e.fb = fidx[e.b];
         e.measured = pose_compose(pose_inverse(kfPose[e.a]), kfPose[e.b]);
@@ -285,12 +310,12 @@ void localBAPass(const BAProblem& P, const std::vector<uint8_t>& active, int max
                 if (fb >= 0) rhs[6 * fb + i] -= gb;
             }
         }
-        for (int i = 0; i < n; i++) S[(size_t)i * n + i] += lambda;
+        if (!shard || shard->rank == 0) for (int i = 0; i < n; i++) S[(size_t)i * n + i] += lambda;
         // landmark elimination (Schur complement)
         struct LmBlk { double Hi[9], bl[3]; std::vector<int> ks; std::vector<double> W; };
         std::vector<LmBlk> blk(L);
         for (int l = 0; l < L; l++) {
-            if (!lmPresent[l]) continue;
+            if (!lmPresent[l] || (shard && l % shard->world != shard->rank)) continue;
             LmBlk& B = blk[l];
             double Hll[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
             B.bl[0] = B.bl[1] = B.bl[2] = 0;
@@ -339,6 +364,7 @@ void localBAPass(const BAProblem& P, const std::vector<uint8_t>& active, int max
                 }
             }
         }
+        if (shard) { *shard->S = S; *shard->rhs = rhs; return false; }
         std::vector<double> sol = rhs;
         if (n > 0 && !chol_solve(S, sol, n)) return false;
         for (int i = 0; i < n; i++) dP[i] = sol[i];
@@ -381,6 +407,14 @@ void localBAPass(const BAProblem& P, const std::vector<uint8_t>& active, int max
     };
     X.error = [&](bool atDelta) { return atDelta ? totalError(trialPose, trialLm) : totalError(kfPose, lm); };
     X.commit = [&]() { kfPose = trialPose; lm = trialLm; };
+    if (shard) {
+        X.linearize();
+        double dummy = 0;
+        X.solve(shard->lambda, dummy);
+        *shard->cost = linErr0;
+        *shard->nFree = F;
+        return;
+    }
     LMParams prm;
     prm.maxIterations = maxIterations;     // 5 on the first pass, 10 on the second (:772-777)
     prm.relativeErrorTol = 1e-5;

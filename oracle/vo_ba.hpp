@@ -42,6 +42,11 @@ struct BAResult {
 void localBAPass(const BAProblem& P, const std::vector<uint8_t>& active, int maxIterations,
                  std::vector<Pose>& kfPose, std::vector<Vec3>& lm, std::vector<uint8_t>& kfPresent,
                  std::vector<uint8_t>& lmPresent, LMReport& rep, BAResult* stats = nullptr);
+// Multi-GPU decomposition check (test-only): the damped reduced camera system [S | rhs] and the cost that
+// landmark shard `rank` of `world` contributes at the initial linearisation (BetweenFactors and the pose
+// damping counted on rank 0 only).  Summed over ranks it must equal the world = 1 system.
+void reducedSystemShard(const BAProblem& P, int rank, int world, double lambda, std::vector<double>& S,
+                        std::vector<double>& rhs, double& cost, int& nFree);
 void chi2Check(const BAProblem& P, const std::vector<Pose>& kfPose, const std::vector<Vec3>& lm,
                const std::vector<uint8_t>& kfPresent, const std::vector<uint8_t>& lmPresent,
                std::vector<uint8_t>& pairWrong);

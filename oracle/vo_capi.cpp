@@ -291,3 +291,39 @@ void vo_pose3_logmap_derivative(const double* T16, double* J36) { pose3_logmap_d
 void vo_pose3_adjoint(const double* T16, double* A36) { pose3_adjoint(pose_from_rowmajor16(T16), A36); }
 
 }  // extern "C"
+
+extern "C" {
+// test-only: [S | rhs | cost] contribution of one landmark shard (see vo_ba.hpp reducedSystemShard).
+// out must hold (6K)^2 + 6K + 1 doubles; returns the number of free keyframes F (system size 6F).
+int vo_ba_reduced_system_shard(double fx, double fy, double cx, double cy, float baseline, const float* sigmaFactor,
+                               const float* invSigmaFactor, int nLevels, int K, const double* kfPose, const long long* kfId,
+                               const uint8_t* kfFixed, const uint8_t* kfLocal, int L, const double* lm, int NP,
+                               const int* pairKf, const int* pairLm, const uint8_t* pairFlags, const float* pairUv,
+                               const int* pairOct, int rank, int world, double lambda, double* out) {
+    BAProblem P;
+    P.rig = Rig{fx, fy, cx, cy, baseline, 0, 0};
+    P.sigmaFactor.assign(sigmaFactor, sigmaFactor + nLevels);
+    P.InvSigmaFactor.assign(invSigmaFactor, invSigmaFactor + nLevels);
+    P.kfPose.resize(K); P.kfId.resize(K); P.kfFixed.assign(kfFixed, kfFixed + K); P.kfLocal.assign(kfLocal, kfLocal + K);
+    for (int k = 0; k < K; k++) { P.kfPose[k] = pose_from_rowmajor16(kfPose + 16 * k); P.kfId[k] = (long)kfId[k]; }
+    P.lm.resize(L);
+    for (int l = 0; l < L; l++) for (int i = 0; i < 3; i++) P.lm[l].v[i] = lm[3 * l + i];
+    P.pairs.resize(NP);
+    for (int p = 0; p < NP; p++) {
+        BAPair& b = P.pairs[p];
+        b.kf = pairKf[p]; b.lm = pairLm[p];
+        b.hasLeft = pairFlags[p] & 1; b.hasRight = (pairFlags[p] >> 1) & 1;
+        b.uL = pairUv[4 * p]; b.vL = pairUv[4 * p + 1]; b.uR = pairUv[4 * p + 2]; b.vR = pairUv[4 * p + 3];
+        b.octL = pairOct[2 * p]; b.octR = pairOct[2 * p + 1];
+    }
+    std::vector<double> S, rhs;
+    double cost = 0;
+    int F = 0;
+    reducedSystemShard(P, rank, world, lambda, S, rhs, cost, F);
+    const int n = 6 * F;
+    for (int i = 0; i < n * n; i++) out[i] = S[i];
+    for (int i = 0; i < n; i++) out[n * n + i] = rhs[i];
+    out[n * n + n] = cost;
+    return F;
+}
+}  // extern "C"
