@@ -238,3 +238,43 @@ def make_ba_problem(rig_name="euroc", n_local=10, n_fixed=4, n_lm=3000, seed=0xB
     return dict(rig=rig, kf_pose=init_poses, kf_pose_true=poses, kf_id=kf_id, kf_fixed=kf_fixed, kf_local=kf_local,
                 lm=init_lm, lm_true=lm, pair_kf=np.array(pk, np.int32), pair_lm=np.array(pl, np.int32),
                 pair_flags=np.array(pf, np.uint8), pair_uv=np.array(puv, np.float32), pair_oct=np.array(poct, np.int32))
+
+
+# T_bc1 of the EuRoC configs (config/config_MH_01.yaml T_bc1.data): body_P_sensor of the IMU factor
+T_BC1 = np.array([[0.0148655429818, -0.999880929698, 0.00414029679422, -0.0216401454975],
+                  [0.999557249008, 0.0149672133247, 0.025715529948, -0.064676986768],
+                  [-0.0257744366974, 0.00375618835797, 0.999660727178, 0.00981073058949],
+                  [0.0, 0.0, 0.0, 1.0]])
+IMU_NOISE = dict(gyro_density=1.6968e-04, gyro_walk=1.9393e-05, acc_density=2.0e-3, acc_walk=3.0e-3, hz=200)
+
+
+def imu_samples(t0, t1, fps=20.0, hz=200, T_bs=T_BC1, gravity=(0.0, 9.81, 0.0), noise_seed=None, bias=None):
+    """IMU samples (acc, gyro in the SENSOR frame) strictly between frame times t0 < t1 (in frame units), generated
+    from the pose_at() spline by central differences; returns (samples [n,6], dts [n]) with the reference's dt rule
+    (dt_i = t_{i+1} - t_i, the last sample reuses the previous dt; src/FeatureTracker.cpp:338-353)."""
+    g = np.asarray(gravity, float)
+    ts = np.arange(np.ceil(t0 * hz / fps + 1e-9), np.floor(t1 * hz / fps - 1e-9) + 1) / hz     # seconds
+    h = 1e-4
+    out = []
+    Rbs, tbs = T_bs[:3, :3], T_bs[:3, 3]
+    for s in ts:
+        f = s * fps
+        Tm, T0, Tp = pose_at(f - h * fps, fps), pose_at(f, fps), pose_at(f + h * fps, fps)
+        R = T0[:3, :3]
+        Rdot = (Tp[:3, :3] - Tm[:3, :3]) / (2 * h)
+        Wm = R.T @ Rdot
+        w_b = np.array([Wm[2, 1] - Wm[1, 2], Wm[0, 2] - Wm[2, 0], Wm[1, 0] - Wm[0, 1]]) * 0.5
+        acc_n = (Tp[:3, 3] - 2 * T0[:3, 3] + Tm[:3, 3]) / (h * h)
+        # sensor position = p_b + R t_bs : add the centripetal term the factor models (angular acceleration ignored)
+        a_b = R.T @ (acc_n - g) + np.cross(w_b, np.cross(w_b, tbs))
+        out.append(np.concatenate([Rbs.T @ a_b, Rbs.T @ w_b]))
+    samples = np.array(out).reshape(-1, 6)
+    if bias is not None:
+        samples = samples + np.asarray(bias)[None, :]
+    if noise_seed is not None:
+        rng = np.random.Generator(np.random.PCG64(noise_seed))
+        samples[:, :3] += rng.normal(0, IMU_NOISE["acc_density"] * np.sqrt(hz), samples[:, :3].shape)
+        samples[:, 3:] += rng.normal(0, IMU_NOISE["gyro_density"] * np.sqrt(hz), samples[:, 3:].shape)
+    n = len(ts)
+    dts = np.full(n, 1.0 / hz)
+    return samples, dts, g

@@ -292,3 +292,54 @@ def ba_reduced_system_shard(rig, sigma_factor, inv_sigma_factor, prob, rank, wor
                                          _p(pl), _p(pf), _p(puv), _p(poct), int(rank), int(world), C.c_double(lam), _p(out))
     n = 6 * F
     return out[:n * n + n + 1].copy(), F
+
+
+# ---- IMU -----------------------------------------------------------------------------------
+def imu_params(gravity, gyro_density, acc_density, gyro_walk, acc_walk, T_body_sensor, integration_cov=1e-5):
+    """PreintegrationCombinedParams as the reference sets them (src/FeatureTracker.cpp:312-334)."""
+    T = np.asarray(T_body_sensor, np.float64)
+    return np.concatenate([np.asarray(gravity, np.float64), [gyro_density ** 2, acc_density ** 2, gyro_walk ** 2,
+                           acc_walk ** 2, integration_cov], np.eye(6).ravel(), T[:3, :3].ravel(), T[:3, 3]]).astype(np.float64)
+
+
+def imu_preintegrate(prm, bias_hat, samples, dts):
+    samples = np.ascontiguousarray(samples, np.float64).reshape(-1, 6); dts = np.ascontiguousarray(dts, np.float64)
+    bias_hat = np.ascontiguousarray(bias_hat, np.float64); prm = np.ascontiguousarray(prm, np.float64)
+    pim = np.zeros(295, np.float64)
+    lib().vo_imu_preintegrate(_p(prm), _p(bias_hat), _p(samples), _p(dts), len(dts), _p(pim))
+    return pim
+
+
+def pim_fields(pim):
+    return dict(deltaTij=pim[0], preint=pim[1:10], H_biasAcc=pim[10:37].reshape(9, 3), H_biasOmega=pim[37:64].reshape(9, 3),
+                cov=pim[64:289].reshape(15, 15), biasHat=pim[289:295])
+
+
+def nav_state(R, t, v):
+    return np.concatenate([np.asarray(R, np.float64).ravel(), np.asarray(t, np.float64), np.asarray(v, np.float64)])
+
+
+def imu_predict(prm, pim, si):
+    sj = np.zeros(15, np.float64)
+    lib().vo_imu_predict(_p(np.ascontiguousarray(prm)), _p(np.ascontiguousarray(pim)), _p(np.ascontiguousarray(si)), _p(sj))
+    return sj
+
+
+def imu_factor(prm, pim, si, sj, bias_j):
+    r = np.zeros(15); Hp = np.zeros((15, 6)); Hv = np.zeros((15, 3)); Hb = np.zeros((15, 6))
+    lib().vo_imu_factor(_p(np.ascontiguousarray(prm)), _p(np.ascontiguousarray(pim)), _p(np.ascontiguousarray(si)),
+                        _p(np.ascontiguousarray(sj)), _p(np.ascontiguousarray(bias_j, np.float64)), _p(r), _p(Hp), _p(Hv), _p(Hb))
+    return r, Hp, Hv, Hb
+
+
+def pose_imu_lm(rig, ftype, p, z, sigma, prm, T_wc_prev, vel_prev, bias_prev, samples, dts):
+    ftype = np.ascontiguousarray(ftype, np.int32); p = np.ascontiguousarray(p, np.float64)
+    z = np.ascontiguousarray(z, np.float64); sigma = np.ascontiguousarray(sigma, np.float64)
+    samples = np.ascontiguousarray(samples, np.float64).reshape(-1, 6); dts = np.ascontiguousarray(dts, np.float64)
+    out = np.zeros(30, np.float64)
+    lib().vo_pose_imu_lm(C.c_double(rig["fx"]), C.c_double(rig["fy"]), C.c_double(rig["cx"]), C.c_double(rig["cy"]),
+                         C.c_float(rig["bl"]), len(ftype), _p(ftype), _p(p), _p(z), _p(sigma), _p(np.ascontiguousarray(prm)),
+                         _p(np.ascontiguousarray(T_wc_prev, np.float64)), _p(np.ascontiguousarray(vel_prev, np.float64)),
+                         _p(np.ascontiguousarray(bias_prev, np.float64)), _p(samples), _p(dts), len(dts), _p(out))
+    return dict(T_wc=out[:16].reshape(4, 4).copy(), vel=out[16:19].copy(), bias=out[19:25].copy(), iterations=int(out[25]),
+                inner=int(out[26]), initialError=out[27], finalError=out[28], lam=out[29])

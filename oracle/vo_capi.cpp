@@ -327,3 +327,53 @@ int vo_ba_reduced_system_shard(double fx, double fy, double cx, double cy, float
     return F;
 }
 }  // extern "C"
+
+// ---- IMU pre-integration / 15-dof solve -----------------------------------------------------------
+#include "vo_imu.hpp"
+extern "C" {
+// ImuParams and Pim are plain arrays of doubles: prm[56] = gravity(3) gyroCov accCov biasOmegaCov biasAccCov
+// integrationCov biasAccOmegaInt(36) body_P_sensor R(9) t(3);  pim[295] = deltaTij preint(9) H_biasAcc(27)
+// H_biasOmega(27) cov(225) biasHat(6).
+static_assert(sizeof(ImuParams) == 56 * sizeof(double), "ImuParams layout");
+static_assert(sizeof(Pim) == 295 * sizeof(double), "Pim layout");
+
+void vo_imu_preintegrate(const double* prm, const double* biasHat, const double* samples, const double* dts, int n, double* pimOut) {
+    ImuParams P; memcpy(&P, prm, sizeof(P));
+    Pim pim; pimReset(pim, biasHat);
+    for (int i = 0; i < n; i++) pimIntegrate(pim, P, samples + 6 * i, samples + 6 * i + 3, dts[i]);
+    memcpy(pimOut, &pim, sizeof(pim));
+}
+// state = R(9) t(3) v(3)
+void vo_imu_predict(const double* prm, const double* pimIn, const double* si, double* sj) {
+    ImuParams P; memcpy(&P, prm, sizeof(P));
+    Pim pim; memcpy(&pim, pimIn, sizeof(pim));
+    NavState a; memcpy(&a, si, sizeof(a));
+    NavState b = pimPredict(pim, P, a);
+    memcpy(sj, &b, sizeof(b));
+}
+void vo_imu_factor(const double* prm, const double* pimIn, const double* si, const double* sj, const double* bias_j,
+                   double* r15, double* Hp, double* Hv, double* Hb) {
+    ImuParams P; memcpy(&P, prm, sizeof(P));
+    Pim pim; memcpy(&pim, pimIn, sizeof(pim));
+    NavState a, b; memcpy(&a, si, sizeof(a)); memcpy(&b, sj, sizeof(b));
+    imuFactorError(pim, P, a, b, bias_j, r15, Hp, Hv, Hb);
+}
+// vision factors as in vo_pose_lm_raw; out = T_wc(16) vel(3) bias(6) report(5)
+void vo_pose_imu_lm(double fx, double fy, double cx, double cy, float baseline, int nf, const int* type, const double* p,
+                    const double* z, const double* sigma, const double* prm, const double* T_wc_prev, const double* vel_prev,
+                    const double* bias_prev, const double* samples, const double* dts, int n, double* out) {
+    Rig rig{fx, fy, cx, cy, baseline, 0, 0};
+    std::vector<PoseFactor> f(nf);
+    for (int i = 0; i < nf; i++) {
+        f[i].type = type[i]; f[i].sigma = sigma[i];
+        for (int k = 0; k < 3; k++) { f[i].p[k] = p[3 * i + k]; f[i].z[k] = z[3 * i + k]; }
+    }
+    ImuParams P; memcpy(&P, prm, sizeof(P));
+    ImuSolveResult R;
+    poseImuLM(f, rig, P, pose_from_rowmajor16(T_wc_prev), vel_prev, bias_prev, samples, dts, n, R);
+    pose_to_rowmajor16(R.T_wc, out);
+    for (int i = 0; i < 3; i++) out[16 + i] = R.vel[i];
+    for (int i = 0; i < 6; i++) out[19 + i] = R.bias[i];
+    out[25] = R.rep.iterations; out[26] = R.rep.innerIterations; out[27] = R.rep.initialError; out[28] = R.rep.finalError; out[29] = R.rep.lambda;
+}
+}  // extern "C"

@@ -137,7 +137,7 @@ void buildPoseFactors(const TrackFrame& tf, const TrackedKeys& keys, const float
 // GenericStereoFactor / GenericProjectionFactor with Pose3 local coordinates [omega, v],
 // d(transformTo)/d(xi) = [ skew(q), -I ]; behind-camera points give the constant residual
 // 2*fx with zero Jacobian (throwCheirality = false).
-static int factorResidual(const PoseFactor& f, const Pose& T, const Rig& rig, double r[3], double J[3][6]) {
+int poseFactorResidual(const PoseFactor& f, const Pose& T, const Rig& rig, double r[3], double J[3][6]) {
     const Vec3 d{{f.p[0] - T.t.v[0], f.p[1] - T.t.v[1], f.p[2] - T.t.v[2]}};
     Vec3 q = mat3T_vec(T.R, d);
     const int rows = f.type == 0 ? 3 : 2;
@@ -185,7 +185,7 @@ void poseOnlyLM(const std::vector<PoseFactor>& factors, const Rig& rig, Pose& T_
         g.assign(6, 0.0);
         for (const PoseFactor& f : factors) {
             double r[3], J[3][6];
-            const int rows = factorResidual(f, cur, rig, r, J);
+            const int rows = poseFactorResidual(f, cur, rig, r, J);
             for (int a = 0; a < rows; a++)
                 for (int i = 0; i < 6; i++) {
                     g[i] -= J[a][i] * r[a];
@@ -198,7 +198,7 @@ void poseOnlyLM(const std::vector<PoseFactor>& factors, const Rig& rig, Pose& T_
         double e = 0;
         for (const PoseFactor& f : factors) {
             double r[3];
-            const int rows = factorResidual(f, T, rig, r, nullptr);
+            const int rows = poseFactorResidual(f, T, rig, r, nullptr);
             for (int a = 0; a < rows; a++) e += r[a] * r[a];
         }
         return 0.5 * e;

@@ -57,6 +57,8 @@ struct TrackFrame {           // the slice of tracker state estimatePoseGTSAM / 
     std::vector<uint8_t> MPsOutliers;
 };
 
+// whitened residual (rows returned) and optional 6-column Jacobian of one vision factor at T_wc
+int poseFactorResidual(const PoseFactor& f, const Pose& T, const Rig& rig, double r[3], double J[3][6]);
 void buildPoseFactors(const TrackFrame& tf, const TrackedKeys& keys, const float* InvSigmaFactor,
                       std::vector<PoseFactor>& out);
 // optimise T_wc from an initial guess; returns the LM report
