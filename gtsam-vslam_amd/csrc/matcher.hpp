@@ -59,6 +59,10 @@ struct vslam_matcher {
     int* d_poseOut = nullptr;        // nIn, nStereo, iterations, inner
     vslam_status ensure_pose_cap(int M);
     vslam_status pose_enqueue(int M);
+    double* d_imuBuf = nullptr;      // IMU scratch: samples, dts, DPim, information, state io
+    int imuCap = 0;
+    vslam_status estimate_pose_imu(vslam_pose_problem* prob, const vslam_imu_input* imu, vslam_imu_output* out,
+                                   int* nIn, int* nStereo, vslam_lm_report* rep);
     vslam_status estimate_pose(vslam_pose_problem* prob, int* nIn, int* nStereo, vslam_lm_report* rep);
 
     // tracker state (FeatureTracker's activeMapPoints, flattened and device-resident)

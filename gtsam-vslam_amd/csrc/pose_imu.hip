@@ -1,0 +1,416 @@
+// Pose / velocity / bias solve of the stereo + IMU mode (C2): the IMU branch of
+// FeatureTracker::estimatePoseGTSAM (reference src/FeatureTracker.cpp:301-406) on gfx950.
+//   k_imu_preintegrate  one workgroup: PreintegratedCombinedMeasurements over the frame's IMU bucket
+//                       (3x3-level algebra by one thread, the 15x15 covariance products F P F^T by 225
+//                       threads), then the factor's information matrix (inverse of the 15x15 covariance).
+//   k_pose_imu_lm       the 15-dof Levenberg-Marquardt solve in ONE launch, same structure as k_pose_lm:
+//                       vision factors reduced block-wide (they only touch the 6 pose columns), the
+//                       CombinedImuFactor / bias BetweenFactor / unit priors added as dense 15x15 terms
+//                       (J^T Lambda J by 225 threads), GTSAM LM policy on thread 0, then the chi2 inlier pass.
+#include "pose_dev.hpp"
+#include "imu_dev.hpp"
+
+namespace vslam {
+
+__global__ __launch_bounds__(256) void k_imu_preintegrate(DImuParams P, const double* __restrict__ samples,
+                                                          const double* __restrict__ dts, int n,
+                                                          const double* __restrict__ biasHat, DPim* __restrict__ pimOut,
+                                                          double* __restrict__ Lam) {
+    __shared__ DPim pim;
+    __shared__ double A[81], B[27], C[27], F[225], G[225], FP[225], plus[9], t1[27], t2[27];
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        pim.deltaTij = 0;
+        for (int i = 0; i < 9; i++) pim.preint[i] = 0;
+        for (int i = 0; i < 27; i++) { pim.Hba[i] = 0; pim.Hbg[i] = 0; }
+        for (int i = 0; i < 6; i++) pim.biasHat[i] = biasHat[i];
+    }
+    if (tid < 225) pim.cov[tid] = 0;
+    __syncthreads();
+    for (int s = 0; s < n; s++) {
+        if (tid == 0) pim_step_small(pim, P, samples + 6 * s, samples + 6 * s + 3, dts[s], plus, A, B, C, F, G);
+        __syncthreads();
+        if (tid < 225) {
+            const int i = tid / 15, j = tid % 15;
+            double v = 0;
+            for (int k = 0; k < 15; k++) v += F[i * 15 + k] * pim.cov[k * 15 + j];
+            FP[tid] = v;
+        }
+        if (tid < 27) {
+            const int i = tid / 3, j = tid % 3;
+            double a = 0, b = 0;
+            for (int k = 0; k < 9; k++) { a += A[i * 9 + k] * pim.Hba[k * 3 + j]; b += A[i * 9 + k] * pim.Hbg[k * 3 + j]; }
+            t1[tid] = a - B[tid];
+            t2[tid] = b - C[tid];
+        }
+        __syncthreads();
+        if (tid < 225) {
+            const int i = tid / 15, j = tid % 15;
+            double v = 0;
+            for (int k = 0; k < 15; k++) v += FP[i * 15 + k] * F[j * 15 + k];
+            pim.cov[tid] = v + G[tid];
+        }
+        if (tid < 27) { pim.Hba[tid] = t1[tid]; pim.Hbg[tid] = t2[tid]; }
+        if (tid == 0) { pim.deltaTij += dts[s]; for (int i = 0; i < 9; i++) pim.preint[i] = plus[i]; }
+        __syncthreads();
+    }
+    // information matrix Lambda = cov^-1 (Cholesky + 15 column solves), one thread
+    if (tid == 0) {
+        double L[225];
+        for (int i = 0; i < 225; i++) L[i] = pim.cov[i];
+        bool ok = true;
+        for (int j = 0; j < 15 && ok; j++) {
+            double d = L[j * 15 + j];
+            for (int k = 0; k < j; k++) d -= L[j * 15 + k] * L[j * 15 + k];
+            if (!(d > 0)) { ok = false; break; }
+            d = sqrt(d);
+            L[j * 15 + j] = d;
+            for (int i = j + 1; i < 15; i++) {
+                double v = L[i * 15 + j];
+                for (int k = 0; k < j; k++) v -= L[i * 15 + k] * L[j * 15 + k];
+                L[i * 15 + j] = v / d;
+            }
+        }
+        for (int c = 0; c < 15; c++) {
+            double e[15];
+            for (int i = 0; i < 15; i++) e[i] = (i == c) ? 1.0 : 0.0;
+            if (ok) {
+                for (int i = 0; i < 15; i++) { double v = e[i]; for (int k = 0; k < i; k++) v -= L[i * 15 + k] * e[k]; e[i] = v / L[i * 15 + i]; }
+                for (int i = 14; i >= 0; i--) { double v = e[i]; for (int k = i + 1; k < 15; k++) v -= L[k * 15 + i] * e[k]; e[i] = v / L[i * 15 + i]; }
+            }
+            for (int i = 0; i < 15; i++) Lam[i * 15 + c] = ok ? e[i] : 0.0;
+        }
+    }
+    for (int i = tid; i < (int)(sizeof(DPim) / sizeof(double)); i += 256) ((double*)pimOut)[i] = ((double*)&pim)[i];
+}
+
+struct ImuLmArgs {
+    const DPim* pim; const double* Lam; DImuParams P;
+    DNav si;                 // x0, v0
+    double biasPrev[6];      // b0
+    double* io;              // out: vel(3), bias(6)
+};
+
+__global__ __launch_bounds__(1024) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I) {
+    __shared__ double red[16 * 28];
+    __shared__ double acc[28];
+    __shared__ DPose sT, sT2, sPT, sTcw;
+    __shared__ double sV[3], sB[6], sV2[3], sB2[6], sPV[3];
+    __shared__ DNav sPred;
+    __shared__ double sJ[225], sLJ[225], sH[225], sLam[225], sR15[15], sLr[15], sG[15], sDelta[15], sRp[6], sJp[36];
+    __shared__ double sError, sLambda, sNewErr, sCurErr, sLin, sNV;
+    __shared__ int sPhase, sEval, sIter, sInner, sCnt[2];
+    const int tid = threadIdx.x, M = A.M;
+
+    pose_build_factors(A);
+    if (tid < 225) sLam[tid] = I.Lam[tid];
+    if (tid == 0) {
+        pim_predict(*I.pim, I.P, I.si, sPred);                   // prop_state: initial values, priors, factor prediction
+        for (int i = 0; i < 9; i++) { sT.R[i] = sPred.R[i]; sPT.R[i] = sPred.R[i]; }
+        for (int i = 0; i < 3; i++) { sT.t[i] = sPred.t[i]; sPT.t[i] = sPred.t[i]; sV[i] = sPred.v[i]; sPV[i] = sPred.v[i]; }
+        for (int i = 0; i < 6; i++) sB[i] = I.biasPrev[i];
+        sLambda = 1e-5; sIter = 0; sInner = 0; sCnt[0] = sCnt[1] = 0;
+    }
+    __syncthreads();
+
+    auto vision_error = [&](const DPose& T) {
+        double e = 0;
+        for (int i = tid; i < M; i += 1024) {
+            const double* f = A.factors + (size_t)i * 8;
+            if (f[0] < 0) continue;
+            double r[3];
+            pose_factor_eval(f, T, A, r, nullptr);
+            e += r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+        }
+        return e;
+    };
+    // sum of squares of the non-vision factors at (T, v, b); thread 0 only
+    auto nonvision_error = [&](const DPose& T, const double* v, const double* b) {
+        double r[15];
+        imu_factor_eval(sPred, I.pim->biasHat, T.R, T.t, v, b, r, nullptr);
+        double e = 0;
+        for (int i = 0; i < 15; i++) { double s = 0; for (int j = 0; j < 15; j++) s += sLam[i * 15 + j] * r[j]; e += r[i] * s; }
+        for (int i = 0; i < 6; i++) { const double rb = (b[i] - I.biasPrev[i]) * 1e3; e += rb * rb; }
+        DPose pi, d;
+        pose_inverse(sPT, pi);
+        pose_compose(pi, T, d);
+        double rp[6];
+        pose3_logmap(d, rp);
+        for (int i = 0; i < 6; i++) e += rp[i] * rp[i];
+        for (int i = 0; i < 3; i++) { const double rv = v[i] - sPV[i]; e += rv * rv; }
+        return e;
+    };
+
+    {
+        double v1[1] = {vision_error(sT)};
+        block_reduce<1>(v1, red, acc);
+        if (tid == 0) {
+            sError = 0.5 * (acc[0] + nonvision_error(sT, sV, sB));
+            A.poseIO[16] = sError;
+            sCurErr = sError;
+            sPhase = (!(sError <= 0.0) && sIter < A.maxIterations) ? 0 : 2;
+        }
+        __syncthreads();
+    }
+
+    for (;;) {
+        const int phase = sPhase;
+        if (phase == 2) break;
+        if (phase == 0) {
+            double v[28];
+#pragma unroll
+            for (int k = 0; k < 28; k++) v[k] = 0;
+            const DPose T = sT;
+            for (int i = tid; i < M; i += 1024) {
+                const double* f = A.factors + (size_t)i * 8;
+                if (f[0] < 0) continue;
+                double r[3], J[3][6];
+                const int rows = pose_factor_eval(f, T, A, r, J);
+                for (int a = 0; a < rows; a++) {
+                    int k = 0;
+#pragma unroll
+                    for (int p = 0; p < 6; p++) {
+#pragma unroll
+                        for (int q2 = p; q2 < 6; q2++) v[k++] += J[a][p] * J[a][q2];
+                    }
+#pragma unroll
+                    for (int p = 0; p < 6; p++) v[21 + p] -= J[a][p] * r[a];
+                }
+            }
+            block_reduce<28>(v, red, acc);
+            if (tid == 0) {
+                imu_factor_eval(sPred, I.pim->biasHat, sT.R, sT.t, sV, sB, sR15, sJ);
+                DPose pi, d;
+                pose_inverse(sPT, pi);
+                pose_compose(pi, sT, d);
+                pose3_logmap(d, sRp);
+                pose3_logmap_derivative(d, sJp);
+            }
+            __syncthreads();
+            if (tid < 225) {
+                const int i = tid / 15, c = tid % 15;
+                double s = 0;
+                for (int k = 0; k < 15; k++) s += sLam[i * 15 + k] * sJ[k * 15 + c];
+                sLJ[tid] = s;
+            } else if (tid < 240) {
+                const int i = tid - 225;
+                double s = 0;
+                for (int k = 0; k < 15; k++) s += sLam[i * 15 + k] * sR15[k];
+                sLr[i] = s;
+            }
+            __syncthreads();
+            if (tid < 225) {
+                const int a = tid / 15, c = tid % 15;
+                double s = 0;
+                for (int i = 0; i < 15; i++) s += sJ[i * 15 + a] * sLJ[i * 15 + c];
+                if (a < 6 && c < 6) {
+                    const int p = a < c ? a : c, q2 = a < c ? c : a;
+                    s += acc[p * 6 - p * (p - 1) / 2 + (q2 - p)];           // packed upper triangle of the vision block
+                    for (int i = 0; i < 6; i++) s += sJp[i * 6 + a] * sJp[i * 6 + c];
+                }
+                if (a == c && a >= 9) s += 1e6;
+                if (a == c && a >= 6 && a < 9) s += 1.0;
+                sH[tid] = s;
+            } else if (tid < 240) {
+                const int a = tid - 225;
+                double s = 0;
+                for (int i = 0; i < 15; i++) s -= sJ[i * 15 + a] * sLr[i];
+                if (a < 6) { s += acc[21 + a]; for (int i = 0; i < 6; i++) s -= sJp[i * 6 + a] * sRp[i]; }
+                else if (a < 9) s -= sV[a - 6] - sPV[a - 6];
+                else s -= 1e6 * (sB[a - 9] - I.biasPrev[a - 9]);
+                sG[a] = s;
+            }
+            __syncthreads();
+            if (tid == 0) { sCurErr = sError; sPhase = 1; }
+            __syncthreads();
+            continue;
+        }
+        if (tid == 0) {
+            double Hd[225], dl[15];
+            for (int k = 0; k < 225; k++) Hd[k] = sH[k];
+            for (int p = 0; p < 15; p++) { Hd[p * 15 + p] += sLambda; dl[p] = sG[p]; }
+            const bool solved = chol_solve_n<15>(Hd, dl);
+            sEval = 0;
+            if (solved) {
+                double dg = 0, dHd = 0;
+                for (int p = 0; p < 15; p++) {
+                    dg += dl[p] * sG[p];
+                    double s = 0;
+                    for (int q2 = 0; q2 < 15; q2++) s += sH[p * 15 + q2] * dl[q2];
+                    dHd += dl[p] * s;
+                }
+                sLin = dg - 0.5 * dHd;
+                if (sLin >= 0) {
+                    for (int p = 0; p < 15; p++) sDelta[p] = dl[p];
+                    pose_retract(sT, dl, sT2);
+                    for (int i = 0; i < 3; i++) sV2[i] = sV[i] + dl[6 + i];
+                    for (int i = 0; i < 6; i++) sB2[i] = sB[i] + dl[9 + i];
+                    sNV = nonvision_error(sT2, sV2, sB2);
+                    sEval = 1;
+                }
+            }
+        }
+        __syncthreads();
+        if (sEval) {
+            double v1[1] = {vision_error(sT2)};
+            block_reduce<1>(v1, red, acc);
+            if (tid == 0) sNewErr = 0.5 * (acc[0] + sNV);
+        }
+        if (tid == 0) {
+            bool stepOk = false, stop = false;
+            if (sEval) {
+                const double costChange = sError - sNewErr;
+                if (sLin > DBL_EPSILON * sError) stepOk = (costChange / sLin) > 1e-3;
+                if (fabs(costChange) < A.relTol * sError) stop = true;
+            }
+            bool endInner = false;
+            if (stepOk) {
+                sT = sT2;
+                for (int i = 0; i < 3; i++) sV[i] = sV2[i];
+                for (int i = 0; i < 6; i++) sB[i] = sB2[i];
+                sError = sNewErr;
+                const double nl = sLambda / 10.0;
+                sLambda = nl > 0.0 ? nl : 0.0;
+                sIter++; sInner++;
+                endInner = true;
+            } else if (!stop) {
+                sLambda *= 10.0;
+                sInner++;
+                if (sLambda >= 1e5) endInner = true;
+            } else {
+                endInner = true;
+            }
+            if (endInner) {
+                const double currentError = sCurErr, newError = sError;
+                bool converged;
+                if (newError <= 0.0) converged = true;
+                else {
+                    const double absDec = currentError - newError, relDec = absDec / currentError;
+                    converged = (A.relTol != 0.0 && relDec <= A.relTol) || (absDec <= A.absTol);
+                }
+                const bool cont = sIter < A.maxIterations && !converged && isfinite(currentError);
+                sPhase = cont ? 0 : 2;
+            }
+        }
+        __syncthreads();
+    }
+
+    if (tid == 0) {
+        pose_inverse(sT, sTcw);
+        pose_to_rm16(sTcw, A.poseIO);
+        A.poseIO[17] = sError;
+        A.poseIO[18] = sLambda;
+        A.out[2] = sIter;
+        A.out[3] = sInner;
+        for (int i = 0; i < 3; i++) I.io[i] = sV[i];
+        for (int i = 0; i < 6; i++) I.io[3 + i] = sB[i];
+    }
+    __syncthreads();
+    pose_find_outliers(A, sTcw, sCnt);
+    if (tid == 0) { A.out[0] = sCnt[0]; A.out[1] = sCnt[1]; }
+}
+
+}  // namespace vslam
+
+using namespace vslam;
+
+vslam_status vslam_matcher::estimate_pose_imu(vslam_pose_problem* prob, const vslam_imu_input* imu, vslam_imu_output* outp,
+                                              int* nIn, int* nStereo, vslam_lm_report* rep) {
+    if (!prob || !imu || prob->n_mps < 0 || imu->n_samples < 0) return VSLAM_ERR_INVALID;
+    const int M = prob->n_mps, n = imu->n_samples;
+    if (M > 0 && (!prob->points_xyz || !prob->in_frame || !prob->in_frame_r || !prob->mp_is_outlier || !prob->matches ||
+                  !prob->mps_outliers)) { set_error("estimate_pose_imu: null array"); return VSLAM_ERR_INVALID; }
+    if (n > 0 && (!imu->acceleration || !imu->angular_velocity || !imu->timestamps_ns)) { set_error("estimate_pose_imu: null IMU array"); return VSLAM_ERR_INVALID; }
+    if (n == 0 || imu->hz <= 0) { set_error("estimate_pose_imu: empty IMU bucket"); return VSLAM_ERR_INVALID; }
+    if (!stereoDone) { set_error("estimate_pose_imu needs a completed stereo match"); return VSLAM_ERR_INVALID; }
+    VS_HIP(hipSetDevice(device));
+    VS_CHECK(refresh_keys());
+    VS_CHECK(ensure_pose_cap(M));
+    VS_CHECK(ensure_proj_cap(M));
+    // scratch layout: samples (6n) | dts (n) | biasHat (6) | DPim | Lambda (225) | io (16)
+    const size_t pimD = sizeof(DPim) / sizeof(double);
+    const size_t need = (size_t)7 * n + 6 + pimD + 225 + 16;
+    if ((int)need > imuCap) {
+        hipFree(d_imuBuf);
+        imuCap = (int)need + 1024;
+        VS_HIP(hipMalloc(&d_imuBuf, (size_t)imuCap * sizeof(double)));
+    }
+    std::vector<double> h((size_t)7 * n + 6);
+    double dt = 1.0 / imu->hz;                                  // src/FeatureTracker.cpp:337
+    for (int i = 0; i < n; i++) {
+        for (int k = 0; k < 3; k++) { h[6 * (size_t)i + k] = imu->acceleration[3 * i + k]; h[6 * (size_t)i + 3 + k] = imu->angular_velocity[3 * i + k]; }
+        if (i + 1 < n) dt = (imu->timestamps_ns[i + 1] - imu->timestamps_ns[i]) / 1e9;     // :345-350
+        h[(size_t)6 * n + i] = dt;
+    }
+    for (int k = 0; k < 6; k++) h[(size_t)7 * n + k] = imu->bias_prev[k];
+    double* d_samples = d_imuBuf;
+    double* d_dts = d_samples + (size_t)6 * n;
+    double* d_bias = d_dts + n;
+    DPim* d_pim = (DPim*)(d_bias + 6);
+    double* d_lam = (double*)d_pim + pimD;
+    double* d_io = d_lam + 225;
+    VS_HIP(hipMemcpyAsync(d_samples, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+    DImuParams P{};
+    for (int k = 0; k < 3; k++) P.gravity[k] = imu->gravity[k];
+    P.gyroCov = imu->gyro_noise_density * imu->gyro_noise_density;        // pow(density, 2) (:318-321)
+    P.accCov = imu->accel_noise_density * imu->accel_noise_density;
+    P.biasOmegaCov = imu->gyro_random_walk * imu->gyro_random_walk;
+    P.biasAccCov = imu->accel_random_walk * imu->accel_random_walk;
+    P.integrationCov = 1e-5;
+    for (int k = 0; k < 36; k++) P.biasInt[k] = (k % 7 == 0) ? 1.0 : 0.0;
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) P.bRs[3 * r + c] = imu->T_body_sensor[4 * r + c]; P.arm[r] = imu->T_body_sensor[4 * r + 3]; }
+    int t = timer.begin("imu_preintegrate");
+    hipLaunchKernelGGL(k_imu_preintegrate, dim3(1), dim3(256), 0, stream, P, d_samples, d_dts, n, d_bias, d_pim, d_lam);
+    timer.end(t);
+
+    uint8_t* fl = d_flags;
+    const size_t pc = (size_t)poseCap;
+    if (M) {
+        VS_HIP(hipMemcpyAsync(d_points, prob->points_xyz, (size_t)M * 24, hipMemcpyHostToDevice, stream));
+        VS_HIP(hipMemcpyAsync(fl, prob->in_frame, M, hipMemcpyHostToDevice, stream));
+        VS_HIP(hipMemcpyAsync(fl + pc, prob->in_frame_r, M, hipMemcpyHostToDevice, stream));
+        VS_HIP(hipMemcpyAsync(fl + 2 * pc, prob->mp_is_outlier, M, hipMemcpyHostToDevice, stream));
+        VS_HIP(hipMemcpyAsync(fl + 3 * pc, prob->mps_outliers, M, hipMemcpyHostToDevice, stream));
+        VS_HIP(hipMemcpyAsync(d_matches, prob->matches, (size_t)M * 8, hipMemcpyHostToDevice, stream));
+    }
+    PoseArgs A{};
+    A.M = M; A.points = d_points; A.inFrame = fl; A.inFrameR = fl + pc; A.mpOut = fl + 2 * pc; A.mpsOut = fl + 3 * pc;
+    A.matches = d_matches; A.kpsL = d_kps[0]; A.kpsR = d_kps[1];
+    A.closef = d_close; A.depth = d_depth; A.rightIdxs = d_rightIdxs; A.leftIdxs = d_leftIdxs;
+    A.fx = rig.fx; A.fy = rig.fy; A.cx = rig.cx; A.cy = rig.cy; A.b = (double)rig.baseline;
+    for (int l = 0; l < feL->nLevels; l++) A.invSigma[l] = feL->InvSigmaFactor[l];
+    A.closeTh = rig.baseline * 40;
+    A.factors = d_factors; A.firstFail = d_firstFail; A.code = (int*)(fl + 4 * pc); A.poseIO = d_poseIO; A.out = d_poseOut;
+    A.maxIterations = 100; A.relTol = 1e-5; A.absTol = 1e-5; A.thres = 7.815;
+    ImuLmArgs I{};
+    I.pim = d_pim; I.Lam = d_lam; I.P = P; I.io = d_io;
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) I.si.R[3 * r + c] = imu->T_wc_prev[4 * r + c]; I.si.t[r] = imu->T_wc_prev[4 * r + 3]; I.si.v[r] = imu->velocity_prev[r]; }
+    for (int k = 0; k < 6; k++) I.biasPrev[k] = imu->bias_prev[k];
+    t = timer.begin("pose_imu_lm");
+    hipLaunchKernelGGL(k_pose_imu_lm, dim3(1), dim3(1024), 0, stream, A, I);
+    timer.end(t);
+    VS_HIP(hipGetLastError());
+    double io[19], vb[9];
+    int out[4];
+    VS_HIP(hipMemcpyAsync(io, d_poseIO, sizeof(io), hipMemcpyDeviceToHost, stream));
+    VS_HIP(hipMemcpyAsync(vb, d_io, sizeof(vb), hipMemcpyDeviceToHost, stream));
+    VS_HIP(hipMemcpyAsync(out, d_poseOut, sizeof(out), hipMemcpyDeviceToHost, stream));
+    if (M) {
+        VS_HIP(hipMemcpyAsync(prob->matches, d_matches, (size_t)M * 8, hipMemcpyDeviceToHost, stream));
+        VS_HIP(hipMemcpyAsync(prob->mps_outliers, fl + 3 * pc, M, hipMemcpyDeviceToHost, stream));
+    }
+    VS_HIP(hipStreamSynchronize(stream));
+    memcpy(prob->T_cw, io, 16 * sizeof(double));
+    if (outp) { for (int k = 0; k < 3; k++) outp->velocity[k] = vb[k]; for (int k = 0; k < 6; k++) outp->bias[k] = vb[3 + k]; }
+    if (nIn) *nIn = out[0];
+    if (nStereo) *nStereo = out[1];
+    if (rep) { rep->iterations = out[2]; rep->inner_iterations = out[3]; rep->initial_error = io[16]; rep->final_error = io[17]; rep->lambda = io[18]; }
+    return VSLAM_OK;
+}
+
+extern "C" vslam_status vslam_estimate_pose_imu(vslam_matcher* m, vslam_pose_problem* prob, const vslam_imu_input* imu,
+                                                vslam_imu_output* out, int32_t* n_inliers, int32_t* n_stereo,
+                                                vslam_lm_report* report) {
+    if (!m) return VSLAM_ERR_INVALID;
+    return m->estimate_pose_imu(prob, imu, out, n_inliers, n_stereo, report);
+}

@@ -302,6 +302,7 @@ void vslam_matcher::release() {
     hipFree(d_depth); hipFree(d_close); hipFree(d_stats);
     for (int s = 0; s < 2; s++) { hipFree(d_okps[s]); hipFree(d_odesc[s]); }
     hipFree(d_trXyz); hipFree(d_trDesc); hipFree(d_trMsd); hipFree(d_trOutlier); hipFree(d_trAct); hipFree(d_trCount);
+    hipFree(d_imuBuf);
     hipFree(d_points); hipFree(d_flags); hipFree(d_factors); hipFree(d_firstFail); hipFree(d_poseIO); hipFree(d_poseOut);
     hipFree(d_mpv); hipFree(d_topk); hipFree(d_matches); hipFree(d_tent); hipFree(d_need); hipFree(d_matchedL); hipFree(d_matchedR); hipFree(d_projOut);
     if (stream) hipStreamDestroy(stream);

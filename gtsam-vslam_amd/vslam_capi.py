@@ -383,3 +383,51 @@ def comm_create_rccl(rank, world, device, broadcast_bytes):
 def landmark_owner(landmark_index, world):
     """Shard rule of the multi-GPU BA: landmark l belongs to rank l % world."""
     return landmark_index % world
+
+
+class ImuInput(C.Structure):
+    _fields_ = [("gravity", C.c_double * 3), ("gyro_noise_density", C.c_double), ("gyro_random_walk", C.c_double),
+                ("accel_noise_density", C.c_double), ("accel_random_walk", C.c_double), ("T_body_sensor", C.c_double * 16),
+                ("T_wc_prev", C.c_double * 16), ("velocity_prev", C.c_double * 3), ("bias_prev", C.c_double * 6),
+                ("n_samples", C.c_int32), ("hz", C.c_int32), ("acceleration", C.c_void_p), ("angular_velocity", C.c_void_p),
+                ("timestamps_ns", C.c_void_p)]
+
+
+class ImuOutput(C.Structure):
+    _fields_ = [("velocity", C.c_double * 3), ("bias", C.c_double * 6)]
+
+
+def estimate_pose_imu(matcher, points, in_frame, in_frame_r, mp_is_outlier, matches, mps_outliers, gravity, noise,
+                      T_body_sensor, T_wc_prev, vel_prev, bias_prev, acc, gyro, timestamps_ns, hz):
+    """estimatePoseGTSAM IMU branch + findOutliersR on the matcher's current frame.
+    noise = (gyro_density, gyro_walk, acc_density, acc_walk)."""
+    points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    M = len(points)
+    inF = np.ascontiguousarray(in_frame, np.uint8); inFR = np.ascontiguousarray(in_frame_r, np.uint8)
+    mpo = np.ascontiguousarray(mp_is_outlier, np.uint8)
+    mt = np.array(matches, np.int32, copy=True).reshape(-1, 2); out = np.array(mps_outliers, np.uint8, copy=True)
+    prob = PoseProblem()
+    prob.n_mps = M
+    prob.points_xyz, prob.in_frame, prob.in_frame_r = _p(points), _p(inF), _p(inFR)
+    prob.mp_is_outlier, prob.matches, prob.mps_outliers = _p(mpo), _p(mt), _p(out)
+    acc = np.ascontiguousarray(acc, np.float64).reshape(-1, 3); gyro = np.ascontiguousarray(gyro, np.float64).reshape(-1, 3)
+    ts = np.ascontiguousarray(timestamps_ns, np.float64)
+    imu = ImuInput()
+    for i in range(3):
+        imu.gravity[i] = gravity[i]; imu.velocity_prev[i] = vel_prev[i]
+    imu.gyro_noise_density, imu.gyro_random_walk, imu.accel_noise_density, imu.accel_random_walk = noise
+    Tb = np.asarray(T_body_sensor, np.float64).reshape(16); Tp = np.asarray(T_wc_prev, np.float64).reshape(16)
+    for i in range(16):
+        imu.T_body_sensor[i] = Tb[i]; imu.T_wc_prev[i] = Tp[i]
+    for i in range(6):
+        imu.bias_prev[i] = bias_prev[i]
+    imu.n_samples, imu.hz = len(ts), int(hz)
+    imu.acceleration, imu.angular_velocity, imu.timestamps_ns = _p(acc), _p(gyro), _p(ts)
+    o = ImuOutput()
+    nIn, nSt = C.c_int32(), C.c_int32()
+    rep = LmReport()
+    _chk(matcher.L.vslam_estimate_pose_imu(matcher.h, C.byref(prob), C.byref(imu), C.byref(o), C.byref(nIn), C.byref(nSt), C.byref(rep)))
+    Tout = np.array([prob.T_cw[i] for i in range(16)], np.float64).reshape(4, 4)
+    return dict(T_cw=Tout, vel=np.array(list(o.velocity)), bias=np.array(list(o.bias)), nIn=nIn.value, nStereo=nSt.value,
+                matches=mt, outliers=out, iterations=rep.iterations, inner=rep.inner_iterations,
+                initialError=rep.initial_error, finalError=rep.final_error, lam=rep.lam)

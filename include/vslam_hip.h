@@ -195,6 +195,34 @@ typedef struct vslam_pose_problem {
 vslam_status vslam_estimate_pose(vslam_matcher* m, vslam_pose_problem* prob, int32_t* n_inliers,
                                  int32_t* n_stereo, vslam_lm_report* report);
 
+/* estimatePoseGTSAM, IMU branch (slamMode 0; src/FeatureTracker.cpp:301-406): the same vision factors plus a
+ * CombinedImuFactor(x0,v0,x1,v1,b0,b1) built from the frame's IMU bucket (PreintegratedCombinedMeasurements,
+ * tangent pre-integration, body_P_sensor = T_bc1), BetweenFactor<ConstantBias>(sigma 1e-3) and the two
+ * unit-covariance priors on x1 / v1; x0, v0, b0 are pinned, x1 / v1 / b1 start at the IMU prediction.
+ * prob->T_cw is OUTPUT only here (the optimised camera<-world pose). */
+typedef struct vslam_imu_input {
+    double gravity[3];                 /* Camera::mIMUGravity (src/VIOSlam.cpp:274) */
+    double gyro_noise_density, gyro_random_walk, accel_noise_density, accel_random_walk;   /* IMUData */
+    double T_body_sensor[16];          /* Camera::TBodyToCam (T_bc1), row-major */
+    double T_wc_prev[16];              /* zedPtr->mCameraPose pose (x0) */
+    double velocity_prev[3];           /* Camera::mVelocity (v0) */
+    double bias_prev[6];               /* initialBias [accelerometer, gyroscope] (b0) */
+    int32_t n_samples;
+    int32_t hz;                        /* IMUData::mHz: dt of a single-sample bucket */
+    const double* acceleration;        /* n x 3 */
+    const double* angular_velocity;    /* n x 3 */
+    const double* timestamps_ns;       /* n; dt_i = (t[i+1]-t[i])/1e9, the last sample reuses the previous dt (:338-353) */
+} vslam_imu_input;
+
+typedef struct vslam_imu_output {
+    double velocity[3];                /* -> Camera::mNewVelocity */
+    double bias[6];                    /* -> initialBias */
+} vslam_imu_output;
+
+vslam_status vslam_estimate_pose_imu(vslam_matcher* m, vslam_pose_problem* prob, const vslam_imu_input* imu,
+                                     vslam_imu_output* out, int32_t* n_inliers, int32_t* n_stereo,
+                                     vslam_lm_report* report);
+
 /* worldToFrame for n points and both cameras with pose T_cw: fills pred_l/pred_r (n x 2 floats),
  * scale_level_l/r, in_frame/in_frame_r.  log_scale = KeyFrame::logScale (float log(imScale)). */
 vslam_status vslam_world_to_frame(vslam_matcher* m, const double* T_cw, int32_t n,

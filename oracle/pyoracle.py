@@ -343,3 +343,29 @@ def pose_imu_lm(rig, ftype, p, z, sigma, prm, T_wc_prev, vel_prev, bias_prev, sa
                          _p(np.ascontiguousarray(bias_prev, np.float64)), _p(samples), _p(dts), len(dts), _p(out))
     return dict(T_wc=out[:16].reshape(4, 4).copy(), vel=out[16:19].copy(), bias=out[19:25].copy(), iterations=int(out[25]),
                 inner=int(out[26]), initialError=out[27], finalError=out[28], lam=out[29])
+
+
+def estimate_pose_imu(rig, inv_sigma, points, in_frame, in_frame_r, mp_is_outlier, matches, mps_outliers, kpsL, kpsR,
+                      rightIdxs, leftIdxs, depth, close, prm, T_wc_prev, vel_prev, bias_prev, samples, dts):
+    """estimatePoseGTSAM IMU branch + findOutliersR."""
+    M = len(points)
+    points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    inF = np.ascontiguousarray(in_frame, np.uint8); inFR = np.ascontiguousarray(in_frame_r, np.uint8)
+    mpo = np.ascontiguousarray(mp_is_outlier, np.uint8)
+    mt = np.array(matches, np.int32, copy=True).reshape(-1, 2); out = np.array(mps_outliers, np.uint8, copy=True)
+    kpsL = np.ascontiguousarray(kpsL, KP_DTYPE); kpsR = np.ascontiguousarray(kpsR, KP_DTYPE)
+    ri = np.array(rightIdxs, np.int32, copy=True); li = np.array(leftIdxs, np.int32, copy=True)
+    dp = np.array(depth, np.float32, copy=True); cl = np.array(close, np.uint8, copy=True)
+    samples = np.ascontiguousarray(samples, np.float64).reshape(-1, 6); dts = np.ascontiguousarray(dts, np.float64)
+    inv_sigma = np.ascontiguousarray(inv_sigma, np.float32)
+    T = np.zeros((4, 4)); imu = np.zeros(9); rep = np.zeros(5)
+    nIn, nSt = C.c_int(), C.c_int()
+    lib().vo_estimate_pose_imu(C.c_double(rig["fx"]), C.c_double(rig["fy"]), C.c_double(rig["cx"]), C.c_double(rig["cy"]),
+                               C.c_float(rig["bl"]), rig["w"], rig["h"], _p(inv_sigma), M, _p(points), _p(inF), _p(inFR), _p(mpo),
+                               _p(mt), _p(out), _p(kpsL), len(kpsL), _p(kpsR), len(kpsR), _p(ri), _p(li), _p(dp), _p(cl),
+                               _p(np.ascontiguousarray(prm)), _p(np.ascontiguousarray(T_wc_prev, np.float64)),
+                               _p(np.ascontiguousarray(vel_prev, np.float64)), _p(np.ascontiguousarray(bias_prev, np.float64)),
+                               _p(samples), _p(dts), len(dts), _p(T), _p(imu), C.byref(nIn), C.byref(nSt), _p(rep))
+    return dict(T_cw=T, vel=imu[:3].copy(), bias=imu[3:].copy(), nIn=nIn.value, nStereo=nSt.value, matches=mt, outliers=out,
+                rightIdxs=ri, leftIdxs=li, depth=dp, close=cl, iterations=int(rep[0]), inner=int(rep[1]), initialError=rep[2],
+                finalError=rep[3], lam=rep[4])

@@ -377,3 +377,48 @@ void vo_pose_imu_lm(double fx, double fy, double cx, double cy, float baseline, 
     out[25] = R.rep.iterations; out[26] = R.rep.innerIterations; out[27] = R.rep.initialError; out[28] = R.rep.finalError; out[29] = R.rep.lambda;
 }
 }  // extern "C"
+
+extern "C" {
+// estimatePoseGTSAM, IMU branch + findOutliersR (same argument meaning as vo_estimate_pose; T_cw is output only).
+// imuOut = vel(3) bias(6)
+void vo_estimate_pose_imu(double fx, double fy, double cx, double cy, float baseline, int width, int height,
+                          const float* invSigma, int M, const double* points, const uint8_t* inFrame,
+                          const uint8_t* inFrameR, const uint8_t* mpIsOutlier, int* matches, uint8_t* MPsOutliers,
+                          const KeyPoint* kpsL, int nL, const KeyPoint* kpsR, int nR, int* rightIdxs, int* leftIdxs,
+                          float* depth, uint8_t* close, const double* prm, const double* T_wc_prev, const double* vel_prev,
+                          const double* bias_prev, const double* samples, const double* dts, int n, double* T_cw,
+                          double* imuOut, int* nIn, int* nStereo, double* report) {
+    Rig rig{fx, fy, cx, cy, baseline, width, height};
+    TrackFrame tf;
+    tf.points.resize(M); tf.inFrame.assign(inFrame, inFrame + M); tf.inFrameR.assign(inFrameR, inFrameR + M);
+    tf.mpIsOutlier.assign(mpIsOutlier, mpIsOutlier + M); tf.MPsOutliers.assign(MPsOutliers, MPsOutliers + M);
+    tf.matches.resize(M);
+    for (int i = 0; i < M; i++) {
+        for (int k = 0; k < 3; k++) tf.points[i].v[k] = points[3 * i + k];
+        tf.matches[i] = {matches[2 * i], matches[2 * i + 1]};
+    }
+    TrackedKeys k;
+    k.keyPoints.assign(kpsL, kpsL + nL);
+    k.rightKeyPoints.assign(kpsR, kpsR + nR);
+    k.rightIdxs.assign(rightIdxs, rightIdxs + nL);
+    k.leftIdxs.assign(leftIdxs, leftIdxs + nR);
+    k.estimatedDepth.assign(depth, depth + nL);
+    k.close.assign(close, close + nL);
+    std::vector<PoseFactor> factors;
+    buildPoseFactors(tf, k, invSigma, factors);
+    ImuParams P; memcpy(&P, prm, sizeof(P));
+    ImuSolveResult R;
+    poseImuLM(factors, rig, P, pose_from_rowmajor16(T_wc_prev), vel_prev, bias_prev, samples, dts, n, R);
+    Pose Tcw = pose_inverse(R.T_wc);
+    pose_to_rowmajor16(Tcw, T_cw);
+    int in = 0;
+    const int st = findOutliersR(Tcw, tf, k, rig, invSigma, 7.815, in);
+    *nIn = in; *nStereo = st;
+    for (int i = 0; i < 3; i++) imuOut[i] = R.vel[i];
+    for (int i = 0; i < 6; i++) imuOut[3 + i] = R.bias[i];
+    for (int i = 0; i < M; i++) { matches[2 * i] = tf.matches[i].first; matches[2 * i + 1] = tf.matches[i].second; MPsOutliers[i] = tf.MPsOutliers[i]; }
+    for (int i = 0; i < nL; i++) { rightIdxs[i] = k.rightIdxs[i]; depth[i] = k.estimatedDepth[i]; close[i] = k.close[i]; }
+    for (int i = 0; i < nR; i++) leftIdxs[i] = k.leftIdxs[i];
+    if (report) { report[0] = R.rep.iterations; report[1] = R.rep.innerIterations; report[2] = R.rep.initialError; report[3] = R.rep.finalError; report[4] = R.rep.lambda; }
+}
+}  // extern "C"
