@@ -27,6 +27,8 @@ sys.path.insert(0, os.path.join(ROOT, "gtsam-vslam_amd"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+GRAVITY = (0.0, 9.81, 0.0)
+IMU_NOISE = (1.6968e-04, 1.9393e-05, 2.0e-3, 3.0e-3)   # gyro density / walk, accel density / walk (config_V1_02.yaml)
 KF_PERIOD = 5           # keyFrameCountEnd (include/FeatureTracker.h): a keyframe, hence a local BA, every 5 frames
 
 
@@ -40,13 +42,15 @@ def level_pixels(w, h, nlevels=8, scale=1.2):
     return px
 
 
-def cpu_baseline(frames, poses, rig, nfeat, ba_prob, budget_s=15.0):
+def cpu_baseline(frames, poses, imus, rig, nfeat, ba_prob, budget_s=15.0):
     """Oracle (CPU restatement, single thread) on a bounded sample of the same per-frame workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import pyoracle as po
     from test_gpu_track import oracle_init_map, oracle_track
+    import synth
     eL, eR = po.Extractor(nfeat), po.Extractor(nfeat)
+    prm = po.imu_params(GRAVITY, IMU_NOISE[0], IMU_NOISE[2], IMU_NOISE[1], IMU_NOISE[3], synth.T_BC1)
     n, t0, mp = 0, time.perf_counter(), None
     while True:
         i = n % len(frames)
@@ -55,7 +59,8 @@ def cpu_baseline(frames, poses, rig, nfeat, ba_prob, budget_s=15.0):
         kR, dR = eR.extract(R)
         st = po.stereo_match(eL, eR, rig, kL, dL, kR, dR)
         if mp is not None and i > 0:
-            oracle_track(po, rig, eL, (kL, dL, kR, dR), st, mp, poses[i][1], 5)
+            oracle_track(po, rig, eL, (kL, dL, kR, dR), st, mp, poses[i][1], 5,
+                         imu=(prm, poses[i - 1][0], imus[i][3], np.zeros(6), imus[i][0], imus[i][1]))
         mp = oracle_init_map(rig, eL, kL, dL, st, poses[i][0])
         if n % KF_PERIOD == KF_PERIOD - 1:
             po.local_ba(rig, eL.sigmaFactor, eL.InvSigmaFactor, ba_prob)
@@ -97,12 +102,17 @@ def main():
     w, h = rig["w"], rig["h"]
     # a short rendered sequence (consecutive frames, so that tracking has real inter-frame motion);
     # it is replayed cyclically, frame 0 of each cycle re-initialises the map
-    frames, poses = [], []
+    frames, poses, imus = [], [], []
     for i in range(args.frames):
         f = i + 11 * rank
         L, R, T = synth.stereo_frame(f, rig_name)
         frames.append((L, R))
         poses.append((T, synth.pose_at(f - 0.3, rig["fps"])))   # (ground truth, constant-velocity style prediction)
+        # IMU bucket between frame f-1 and f (200 Hz, reference noise densities) + velocity at frame f-1
+        S, dts, _ = synth.imu_samples(f - 1, f, rig["fps"], noise_seed=0x1A00 + f)
+        hh = 1e-4
+        v_prev = (synth.pose_at(f - 1 + hh * rig["fps"], rig["fps"])[:3, 3] - synth.pose_at(f - 1 - hh * rig["fps"], rig["fps"])[:3, 3]) / (2 * hh)
+        imus.append((S, dts, np.arange(len(dts)) * 5e6, v_prev))
     d_frames = [(torch.from_numpy(L).to(dev), torch.from_numpy(R).to(dev)) for (L, R) in frames]
     ba_prob = synth.make_ba_problem(rig_name, n_local=10, n_fixed=4, n_lm=3000, seed=0xBA5E + rank)
 
@@ -152,7 +162,9 @@ def main():
         if record:
             add(fe.timings()); add(fm.timings())
         if i > 0:
-            T_cw, rep = vc.tracker_track(fm, poses[i][1], 5)
+            S, dts, ts, v_prev = imus[i]
+            T_cw, rep, vel, bias = vc.tracker_track_imu(fm, poses[i][1], 5, GRAVITY, IMU_NOISE, synth.T_BC1, poses[i - 1][0],
+                                                        v_prev, np.zeros(6), S[:, :3], S[:, 3:], ts, 200)
             if record:
                 add(fm.timings())
                 counters["track_inliers"] += rep["n_inliers"]; counters["track_frames"] += 1
@@ -222,11 +234,11 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/i32 (extract, match) + f64 (pose LM, local BA)", "data": "synthetic",
-            "config": {"workload": "C1-class: EuRoC-like stereo 752x480, 1500 features/image, %d rendered consecutive "
-                                   "frames resident in HBM replayed cyclically, 10-KF local BA (3000 landmarks, ~%d "
-                                   "residuals) every %d frames; IMU factors (C2) not yet in the path"
+            "config": {"workload": "C2-class: EuRoC-like stereo+IMU (slamMode 0) 752x480, 1500 features/image, 200 Hz IMU "
+                                   "pre-integration factor in every pose solve, %d rendered consecutive frames resident in "
+                                   "HBM replayed cyclically, 10-KF local BA (3000 landmarks, ~%d residuals) every %d frames"
                                    % (args.frames, counters["ba_residuals"], KF_PERIOD),
-                       "stages": ["extract L+R", "stereo match", "tracking loop (projection match + pose-only LM)",
+                       "stages": ["extract L+R", "stereo match", "tracking loop (projection match + IMU pre-integration + 15-dof pose/velocity/bias LM)",
                                   "map refresh", "local BA (amortised)"],
                        "threads": "tracking on the main thread, local BA on a second host thread / HIP stream (as the reference's optimizer thread)",
                        "parallelism": "replicas x%d" % world},
@@ -235,7 +247,7 @@ def main():
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(frames, poses, rig, nfeat, ba_prob)
+            out["cpu_baseline"] = cpu_baseline(frames, poses, imus, rig, nfeat, ba_prob)
         print(json.dumps(out))
     ba_q.put(None)
     if world > 1:

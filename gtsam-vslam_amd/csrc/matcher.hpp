@@ -61,6 +61,11 @@ struct vslam_matcher {
     vslam_status pose_enqueue(int M);
     double* d_imuBuf = nullptr;      // IMU scratch: samples, dts, DPim, information, state io
     int imuCap = 0;
+    void* imuPim = nullptr; double* imuLam = nullptr; double* imuIo = nullptr;   // views into d_imuBuf
+    double imuParams[64] = {0};      // DImuParams of the current frame
+    double imuSi[15] = {0}, imuBiasPrev[6] = {0};
+    vslam_status imu_setup(const vslam_imu_input* imu);
+    vslam_status pose_imu_enqueue(int M);
     vslam_status estimate_pose_imu(vslam_pose_problem* prob, const vslam_imu_input* imu, vslam_imu_output* out,
                                    int* nIn, int* nStereo, vslam_lm_report* rep);
     vslam_status estimate_pose(vslam_pose_problem* prob, int* nIn, int* nStereo, vslam_lm_report* rep);
@@ -76,7 +81,8 @@ struct vslam_matcher {
     int actN = 0;
     vslam_status ensure_track_cap(int n);
     vslam_status track_init_map(const double* T_wc);
-    vslam_status track_frame(const double* T_wc_pred, int frameNumber, double* T_cw_out, vslam_track_report* rep);
+    vslam_status track_frame(const double* T_wc_pred, int frameNumber, double* T_cw_out, vslam_track_report* rep,
+                             const vslam_imu_input* imu = nullptr, vslam_imu_output* imuOut = nullptr);
 
     vslam_status init(const vslam_rig* r, vslam_extractor* l, int il, vslam_extractor* rr, int ir);
     void release();

@@ -314,19 +314,12 @@ __global__ __launch_bounds__(1024) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I) {
 
 using namespace vslam;
 
-vslam_status vslam_matcher::estimate_pose_imu(vslam_pose_problem* prob, const vslam_imu_input* imu, vslam_imu_output* outp,
-                                              int* nIn, int* nStereo, vslam_lm_report* rep) {
-    if (!prob || !imu || prob->n_mps < 0 || imu->n_samples < 0) return VSLAM_ERR_INVALID;
-    const int M = prob->n_mps, n = imu->n_samples;
-    if (M > 0 && (!prob->points_xyz || !prob->in_frame || !prob->in_frame_r || !prob->mp_is_outlier || !prob->matches ||
-                  !prob->mps_outliers)) { set_error("estimate_pose_imu: null array"); return VSLAM_ERR_INVALID; }
-    if (n > 0 && (!imu->acceleration || !imu->angular_velocity || !imu->timestamps_ns)) { set_error("estimate_pose_imu: null IMU array"); return VSLAM_ERR_INVALID; }
-    if (n == 0 || imu->hz <= 0) { set_error("estimate_pose_imu: empty IMU bucket"); return VSLAM_ERR_INVALID; }
-    if (!stereoDone) { set_error("estimate_pose_imu needs a completed stereo match"); return VSLAM_ERR_INVALID; }
-    VS_HIP(hipSetDevice(device));
-    VS_CHECK(refresh_keys());
-    VS_CHECK(ensure_pose_cap(M));
-    VS_CHECK(ensure_proj_cap(M));
+// upload the frame's IMU bucket, pre-integrate it once (the reference re-integrates the same samples on every
+// estimatePoseGTSAM call of a frame; the result is identical), remember x0 / v0 / b0
+vslam_status vslam_matcher::imu_setup(const vslam_imu_input* imu) {
+    const int n = imu->n_samples;
+    if (n > 0 && (!imu->acceleration || !imu->angular_velocity || !imu->timestamps_ns)) { set_error("IMU input: null array"); return VSLAM_ERR_INVALID; }
+    if (n <= 0 || imu->hz <= 0) { set_error("IMU input: empty bucket"); return VSLAM_ERR_INVALID; }
     // scratch layout: samples (6n) | dts (n) | biasHat (6) | DPim | Lambda (225) | io (16)
     const size_t pimD = sizeof(DPim) / sizeof(double);
     const size_t need = (size_t)7 * n + 6 + pimD + 225 + 16;
@@ -346,10 +339,11 @@ vslam_status vslam_matcher::estimate_pose_imu(vslam_pose_problem* prob, const vs
     double* d_samples = d_imuBuf;
     double* d_dts = d_samples + (size_t)6 * n;
     double* d_bias = d_dts + n;
-    DPim* d_pim = (DPim*)(d_bias + 6);
-    double* d_lam = (double*)d_pim + pimD;
-    double* d_io = d_lam + 225;
+    imuPim = (void*)(d_bias + 6);
+    imuLam = (double*)imuPim + pimD;
+    imuIo = imuLam + 225;
     VS_HIP(hipMemcpyAsync(d_samples, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+    VS_HIP(hipStreamSynchronize(stream));      // h is a stack-lifetime staging buffer
     DImuParams P{};
     for (int k = 0; k < 3; k++) P.gravity[k] = imu->gravity[k];
     P.gyroCov = imu->gyro_noise_density * imu->gyro_noise_density;        // pow(density, 2) (:318-321)
@@ -359,20 +353,21 @@ vslam_status vslam_matcher::estimate_pose_imu(vslam_pose_problem* prob, const vs
     P.integrationCov = 1e-5;
     for (int k = 0; k < 36; k++) P.biasInt[k] = (k % 7 == 0) ? 1.0 : 0.0;
     for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) P.bRs[3 * r + c] = imu->T_body_sensor[4 * r + c]; P.arm[r] = imu->T_body_sensor[4 * r + 3]; }
+    static_assert(sizeof(DImuParams) <= sizeof(imuParams), "imuParams storage too small");
+    memcpy(imuParams, &P, sizeof(P));
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) imuSi[3 * r + c] = imu->T_wc_prev[4 * r + c]; imuSi[9 + r] = imu->T_wc_prev[4 * r + 3]; imuSi[12 + r] = imu->velocity_prev[r]; }
+    for (int k = 0; k < 6; k++) imuBiasPrev[k] = imu->bias_prev[k];
     int t = timer.begin("imu_preintegrate");
-    hipLaunchKernelGGL(k_imu_preintegrate, dim3(1), dim3(256), 0, stream, P, d_samples, d_dts, n, d_bias, d_pim, d_lam);
+    hipLaunchKernelGGL(k_imu_preintegrate, dim3(1), dim3(256), 0, stream, P, d_samples, d_dts, n, d_bias, (DPim*)imuPim, imuLam);
     timer.end(t);
+    VS_HIP(hipGetLastError());
+    return VSLAM_OK;
+}
 
+// device-resident form of the IMU solve (inputs as for pose_enqueue, plus a completed imu_setup)
+vslam_status vslam_matcher::pose_imu_enqueue(int M) {
     uint8_t* fl = d_flags;
     const size_t pc = (size_t)poseCap;
-    if (M) {
-        VS_HIP(hipMemcpyAsync(d_points, prob->points_xyz, (size_t)M * 24, hipMemcpyHostToDevice, stream));
-        VS_HIP(hipMemcpyAsync(fl, prob->in_frame, M, hipMemcpyHostToDevice, stream));
-        VS_HIP(hipMemcpyAsync(fl + pc, prob->in_frame_r, M, hipMemcpyHostToDevice, stream));
-        VS_HIP(hipMemcpyAsync(fl + 2 * pc, prob->mp_is_outlier, M, hipMemcpyHostToDevice, stream));
-        VS_HIP(hipMemcpyAsync(fl + 3 * pc, prob->mps_outliers, M, hipMemcpyHostToDevice, stream));
-        VS_HIP(hipMemcpyAsync(d_matches, prob->matches, (size_t)M * 8, hipMemcpyHostToDevice, stream));
-    }
     PoseArgs A{};
     A.M = M; A.points = d_points; A.inFrame = fl; A.inFrameR = fl + pc; A.mpOut = fl + 2 * pc; A.mpsOut = fl + 3 * pc;
     A.matches = d_matches; A.kpsL = d_kps[0]; A.kpsR = d_kps[1];
@@ -383,17 +378,45 @@ vslam_status vslam_matcher::estimate_pose_imu(vslam_pose_problem* prob, const vs
     A.factors = d_factors; A.firstFail = d_firstFail; A.code = (int*)(fl + 4 * pc); A.poseIO = d_poseIO; A.out = d_poseOut;
     A.maxIterations = 100; A.relTol = 1e-5; A.absTol = 1e-5; A.thres = 7.815;
     ImuLmArgs I{};
-    I.pim = d_pim; I.Lam = d_lam; I.P = P; I.io = d_io;
-    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) I.si.R[3 * r + c] = imu->T_wc_prev[4 * r + c]; I.si.t[r] = imu->T_wc_prev[4 * r + 3]; I.si.v[r] = imu->velocity_prev[r]; }
-    for (int k = 0; k < 6; k++) I.biasPrev[k] = imu->bias_prev[k];
-    t = timer.begin("pose_imu_lm");
+    I.pim = (const DPim*)imuPim; I.Lam = imuLam; I.io = imuIo;
+    memcpy(&I.P, imuParams, sizeof(DImuParams));
+    for (int k = 0; k < 9; k++) I.si.R[k] = imuSi[k];
+    for (int k = 0; k < 3; k++) { I.si.t[k] = imuSi[9 + k]; I.si.v[k] = imuSi[12 + k]; }
+    for (int k = 0; k < 6; k++) I.biasPrev[k] = imuBiasPrev[k];
+    int t = timer.begin("pose_imu_lm");
     hipLaunchKernelGGL(k_pose_imu_lm, dim3(1), dim3(1024), 0, stream, A, I);
     timer.end(t);
     VS_HIP(hipGetLastError());
+    return VSLAM_OK;
+}
+
+vslam_status vslam_matcher::estimate_pose_imu(vslam_pose_problem* prob, const vslam_imu_input* imu, vslam_imu_output* outp,
+                                              int* nIn, int* nStereo, vslam_lm_report* rep) {
+    if (!prob || !imu || prob->n_mps < 0 || imu->n_samples < 0) return VSLAM_ERR_INVALID;
+    const int M = prob->n_mps;
+    if (M > 0 && (!prob->points_xyz || !prob->in_frame || !prob->in_frame_r || !prob->mp_is_outlier || !prob->matches ||
+                  !prob->mps_outliers)) { set_error("estimate_pose_imu: null array"); return VSLAM_ERR_INVALID; }
+    if (!stereoDone) { set_error("estimate_pose_imu needs a completed stereo match"); return VSLAM_ERR_INVALID; }
+    VS_HIP(hipSetDevice(device));
+    VS_CHECK(refresh_keys());
+    VS_CHECK(ensure_pose_cap(M));
+    VS_CHECK(ensure_proj_cap(M));
+    VS_CHECK(imu_setup(imu));
+    uint8_t* fl = d_flags;
+    const size_t pc = (size_t)poseCap;
+    if (M) {
+        VS_HIP(hipMemcpyAsync(d_points, prob->points_xyz, (size_t)M * 24, hipMemcpyHostToDevice, stream));
+        VS_HIP(hipMemcpyAsync(fl, prob->in_frame, M, hipMemcpyHostToDevice, stream));
+        VS_HIP(hipMemcpyAsync(fl + pc, prob->in_frame_r, M, hipMemcpyHostToDevice, stream));
+        VS_HIP(hipMemcpyAsync(fl + 2 * pc, prob->mp_is_outlier, M, hipMemcpyHostToDevice, stream));
+        VS_HIP(hipMemcpyAsync(fl + 3 * pc, prob->mps_outliers, M, hipMemcpyHostToDevice, stream));
+        VS_HIP(hipMemcpyAsync(d_matches, prob->matches, (size_t)M * 8, hipMemcpyHostToDevice, stream));
+    }
+    VS_CHECK(pose_imu_enqueue(M));
     double io[19], vb[9];
     int out[4];
     VS_HIP(hipMemcpyAsync(io, d_poseIO, sizeof(io), hipMemcpyDeviceToHost, stream));
-    VS_HIP(hipMemcpyAsync(vb, d_io, sizeof(vb), hipMemcpyDeviceToHost, stream));
+    VS_HIP(hipMemcpyAsync(vb, imuIo, sizeof(vb), hipMemcpyDeviceToHost, stream));
     VS_HIP(hipMemcpyAsync(out, d_poseOut, sizeof(out), hipMemcpyDeviceToHost, stream));
     if (M) {
         VS_HIP(hipMemcpyAsync(prob->matches, d_matches, (size_t)M * 8, hipMemcpyDeviceToHost, stream));

@@ -221,7 +221,7 @@ vslam_status vslam_matcher::track_init_map(const double* T_wc) {
 }
 
 vslam_status vslam_matcher::track_frame(const double* T_wc_pred, int frameNumber, double* T_cw_out,
-                                        vslam_track_report* rep) {
+                                        vslam_track_report* rep, const vslam_imu_input* imu, vslam_imu_output* imuOut) {
     if (!T_wc_pred || !T_cw_out) return VSLAM_ERR_INVALID;
     if (!stereoDone) { set_error("tracker_track needs a completed stereo match of the new frame"); return VSLAM_ERR_INVALID; }
     VS_HIP(hipSetDevice(device));
@@ -229,6 +229,7 @@ vslam_status vslam_matcher::track_frame(const double* T_wc_pred, int frameNumber
     VS_CHECK(ensure_track_cap(std::max(trN, 1)));
     VS_CHECK(ensure_pose_cap(std::max(trN, 1)));
     VS_CHECK(ensure_proj_cap(std::max(trN, 1)));
+    if (imu) VS_CHECK(imu_setup(imu));      // currentIMUData: every pose solve of this frame uses the IMU branch
     const int nL = nKeys[0], nR = nKeys[1];
     DPose Twc, Tcw;
     pose_from_rm16(T_wc_pred, Twc);
@@ -264,7 +265,7 @@ vslam_status vslam_matcher::track_frame(const double* T_wc_pred, int frameNumber
     while (nIn < minInliers) {
         rounds++;
         VS_CHECK(proj_enqueue(M, rad));
-        VS_CHECK(pose_enqueue(M));
+        VS_CHECK(imu ? pose_imu_enqueue(M) : pose_enqueue(M));
         VS_HIP(hipMemcpyAsync(out, d_poseOut, sizeof(out), hipMemcpyDeviceToHost, stream));
         VS_HIP(hipStreamSynchronize(stream));
         nIn = out[0]; nSt = out[1]; lmIters += out[2];
@@ -287,12 +288,14 @@ vslam_status vslam_matcher::track_frame(const double* T_wc_pred, int frameNumber
     timer.end(t);
     const float lastRad = rad;
     VS_CHECK(proj_enqueue(M, 4.f));
-    VS_CHECK(pose_enqueue(M));
-    double io[16];
+    VS_CHECK(imu ? pose_imu_enqueue(M) : pose_enqueue(M));
+    double io[16], vb[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (imu) VS_HIP(hipMemcpyAsync(vb, imuIo, sizeof(vb), hipMemcpyDeviceToHost, stream));
     VS_HIP(hipMemcpyAsync(out, d_poseOut, sizeof(out), hipMemcpyDeviceToHost, stream));
     VS_HIP(hipMemcpyAsync(io, d_poseIO, sizeof(io), hipMemcpyDeviceToHost, stream));
     VS_HIP(hipStreamSynchronize(stream));
     memcpy(T_cw_out, io, sizeof(io));
+    if (imu && imuOut) { for (int k = 0; k < 3; k++) imuOut->velocity[k] = vb[k]; for (int k = 0; k < 6; k++) imuOut->bias[k] = vb[3 + k]; }
     if (rep) {
         rep->n_map_points = trN; rep->n_active = M; rep->rounds = rounds; rep->n_inliers = out[0]; rep->n_stereo = out[1];
         rep->lm_iterations = lmIters + out[2]; rep->last_radius = lastRad;
@@ -312,6 +315,14 @@ vslam_status vslam_tracker_track(vslam_matcher* m, const double* T_wc_pred, int3
     if (!m) return VSLAM_ERR_INVALID;
     m->timer.multi = true;
     return m->track_frame(T_wc_pred, frame_number, T_cw_out, report);
+}
+
+vslam_status vslam_tracker_track_imu(vslam_matcher* m, const double* T_wc_pred, int32_t frame_number,
+                                     const vslam_imu_input* imu, double* T_cw_out, vslam_imu_output* imu_out,
+                                     vslam_track_report* report) {
+    if (!m || !imu) return VSLAM_ERR_INVALID;
+    m->timer.multi = true;
+    return m->track_frame(T_wc_pred, frame_number, T_cw_out, report, imu, imu_out);
 }
 
 vslam_status vslam_tracker_fetch(vslam_matcher* m, int32_t* matches, uint8_t* mps_outliers, int32_t* active_index,

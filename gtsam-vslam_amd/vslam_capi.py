@@ -431,3 +431,32 @@ def estimate_pose_imu(matcher, points, in_frame, in_frame_r, mp_is_outlier, matc
     return dict(T_cw=Tout, vel=np.array(list(o.velocity)), bias=np.array(list(o.bias)), nIn=nIn.value, nStereo=nSt.value,
                 matches=mt, outliers=out, iterations=rep.iterations, inner=rep.inner_iterations,
                 initialError=rep.initial_error, finalError=rep.final_error, lam=rep.lam)
+
+
+def _imu_input(gravity, noise, T_body_sensor, T_wc_prev, vel_prev, bias_prev, acc, gyro, timestamps_ns, hz):
+    acc = np.ascontiguousarray(acc, np.float64).reshape(-1, 3); gyro = np.ascontiguousarray(gyro, np.float64).reshape(-1, 3)
+    ts = np.ascontiguousarray(timestamps_ns, np.float64)
+    imu = ImuInput()
+    for i in range(3):
+        imu.gravity[i] = gravity[i]; imu.velocity_prev[i] = vel_prev[i]
+    imu.gyro_noise_density, imu.gyro_random_walk, imu.accel_noise_density, imu.accel_random_walk = noise
+    Tb = np.asarray(T_body_sensor, np.float64).reshape(16); Tp = np.asarray(T_wc_prev, np.float64).reshape(16)
+    for i in range(16):
+        imu.T_body_sensor[i] = Tb[i]; imu.T_wc_prev[i] = Tp[i]
+    for i in range(6):
+        imu.bias_prev[i] = bias_prev[i]
+    imu.n_samples, imu.hz = len(ts), int(hz)
+    imu.acceleration, imu.angular_velocity, imu.timestamps_ns = _p(acc), _p(gyro), _p(ts)
+    imu._keep = (acc, gyro, ts)      # keep the arrays alive while the struct is in use
+    return imu
+
+
+def tracker_track_imu(matcher, T_wc_pred, frame_number, gravity, noise, T_body_sensor, T_wc_prev, vel_prev, bias_prev,
+                      acc, gyro, timestamps_ns, hz):
+    T = np.ascontiguousarray(T_wc_pred, np.float64)
+    imu = _imu_input(gravity, noise, T_body_sensor, T_wc_prev, vel_prev, bias_prev, acc, gyro, timestamps_ns, hz)
+    out = np.zeros((4, 4), np.float64)
+    o = ImuOutput()
+    rep = TrackReport()
+    _chk(matcher.L.vslam_tracker_track_imu(matcher.h, _p(T), int(frame_number), C.byref(imu), _p(out), C.byref(o), C.byref(rep)))
+    return out, {f[0]: getattr(rep, f[0]) for f in TrackReport._fields_}, np.array(list(o.velocity)), np.array(list(o.bias))

@@ -318,6 +318,10 @@ typedef struct vslam_track_report {
 vslam_status vslam_tracker_init_map(vslam_matcher* m, const double* T_wc);
 vslam_status vslam_tracker_track(vslam_matcher* m, const double* T_wc_pred, int32_t frame_number,
                                  double* T_cw_out, vslam_track_report* report);
+/* the same loop in stereo + IMU mode (slamMode 0): every pose solve of the frame is the IMU branch */
+vslam_status vslam_tracker_track_imu(vslam_matcher* m, const double* T_wc_pred, int32_t frame_number,
+                                     const vslam_imu_input* imu, double* T_cw_out, vslam_imu_output* imu_out,
+                                     vslam_track_report* report);
 /* copies of the per-frame tracking state for tests: matches (n_active x 2), MPsOutliers (n_active),
  * source map-point index of every active point */
 vslam_status vslam_tracker_fetch(vslam_matcher* m, int32_t* matches, uint8_t* mps_outliers,

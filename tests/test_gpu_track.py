@@ -31,7 +31,7 @@ def oracle_init_map(rig, ex, kL, dL, st, T_wc):
     return xyz, dL[idx].copy(), msd
 
 
-def oracle_track(oracle, rig, ex, keys, st, mp, T_wc_pred, frame_number):
+def oracle_track(oracle, rig, ex, keys, st, mp, T_wc_pred, frame_number, imu=None):
     kL, dL, kR, dR = keys
     xyz, desc, msd = mp
     log_scale = np.float32(np.log(np.float64(np.float32(1.2))))
@@ -55,8 +55,12 @@ def oracle_track(oracle, rig, ex, keys, st, mp, T_wc_pred, frame_number):
     nIn, prevIn, prevrad, toBreak, rounds, iters = -1, -1, rad, False, 0, 0
 
     def solve(est, mt, outl, state):
-        r = oracle.estimate_pose(rig, ex.InvSigmaFactor, pts, mps["inFrame"], mps["inFrameR"], mpo, mt, outl, kL, kR,
-                                 state["rightIdxs"], state["leftIdxs"], state["depth"], state["close"], est)
+        if imu is not None:     # IMU branch: the initial pose comes from the IMU prediction, `est` is ignored
+            r = oracle.estimate_pose_imu(rig, ex.InvSigmaFactor, pts, mps["inFrame"], mps["inFrameR"], mpo, mt, outl, kL, kR,
+                                         state["rightIdxs"], state["leftIdxs"], state["depth"], state["close"], *imu)
+        else:
+            r = oracle.estimate_pose(rig, ex.InvSigmaFactor, pts, mps["inFrame"], mps["inFrameR"], mpo, mt, outl, kL, kR,
+                                     state["rightIdxs"], state["leftIdxs"], state["depth"], state["close"], est)
         for k in ("rightIdxs", "leftIdxs", "depth", "close"):
             state[k] = r[k]
         return r
@@ -99,7 +103,7 @@ def oracle_track(oracle, rig, ex, keys, st, mp, T_wc_pred, frame_number):
     _, mL, mR, mt, _ = oracle.match_projection(ex, rig, mps, kL, dL, kR, dR, state["rightIdxs"], state["leftIdxs"], mL, mR, mt, 4.0)
     r = solve(est, mt, outl, state)
     return dict(T_cw=r["T_cw"], nIn=r["nIn"], nStereo=r["nStereo"], matches=r["matches"], outliers=r["outliers"],
-                act=act, rounds=rounds, iters=iters + r["iterations"], state=state)
+                act=act, rounds=rounds, iters=iters + r["iterations"], state=state, vel=r.get("vel"), bias=r.get("bias"))
 
 
 @pytest.mark.parametrize("f0,f1,frame_number", [(4, 5, 7), (8, 10, 1), (2, 3, 3)])
@@ -134,3 +138,37 @@ def test_track_frame_parity(oracle, capi, f0, f1, frame_number):
     # tracking recovers the true pose of frame b
     assert np.abs(rigid_inv(T_cw) - Tb).max() < 0.05
     assert rep["n_inliers"] >= 50
+
+
+def test_track_frame_imu_parity(oracle, capi):
+    """Stereo + IMU mode (C2): the same loop with the IMU branch of the pose solve."""
+    rig = synth.RIGS["euroc"]
+    f0, f1 = 9, 10
+    La, Ra, Ta = synth.stereo_frame(f0)
+    Lb, Rb, Tb = synth.stereo_frame(f1)
+    oL, oR = oracle.Extractor(1500), oracle.Extractor(1500)
+    ge = capi.Extractor(rig["w"], rig["h"], 1500, batch=2)
+    m = capi.Matcher(rig, ge, 0, ge, 1)
+    kL, dL = oL.extract(La); kR, dR = oR.extract(Ra)
+    st = oracle.stereo_match(oL, oR, rig, kL, dL, kR, dR)
+    mp = oracle_init_map(rig, oL, kL, dL, st, Ta)
+    ge.extract([La, Ra]); m.stereo_match(); capi.tracker_init_map(m, Ta)
+    G = (0.0, 9.81, 0.0); NOISE = (1.6968e-4, 1.9393e-5, 2.0e-3, 3.0e-3)
+    h = 1e-4
+    v_prev = (synth.pose_at(f0 + h * 20)[:3, 3] - synth.pose_at(f0 - h * 20)[:3, 3]) / (2 * h)
+    S, dts, _ = synth.imu_samples(f0, f1, noise_seed=5)
+    ts = np.arange(len(dts)) * 5e6
+    prm = oracle.imu_params(G, NOISE[0], NOISE[2], NOISE[1], NOISE[3], synth.T_BC1)
+    pred = synth.pose_at(f1 - 0.3)
+    kL, dL = oL.extract(Lb); kR, dR = oR.extract(Rb)
+    st = oracle.stereo_match(oL, oR, rig, kL, dL, kR, dR)
+    ref = oracle_track(oracle, rig, oL, (kL, dL, kR, dR), st, mp, pred, 5, imu=(prm, Ta, v_prev, np.zeros(6), S, dts))
+    ge.extract([Lb, Rb]); m.stereo_match()
+    T_cw, rep, vel, bias = capi.tracker_track_imu(m, pred, 5, G, NOISE, synth.T_BC1, Ta, v_prev, np.zeros(6), S[:, :3], S[:, 3:], ts, 200)
+    mt, outl, act = capi.tracker_fetch(m)
+    assert rep["rounds"] == ref["rounds"] and rep["lm_iterations"] == ref["iters"]
+    assert (rep["n_inliers"], rep["n_stereo"]) == (ref["nIn"], ref["nStereo"]) and rep["n_inliers"] >= 50
+    assert np.abs(T_cw - ref["T_cw"]).max() < 1e-8
+    assert np.abs(vel - ref["vel"]).max() < 1e-8 and np.abs(bias - ref["bias"]).max() < 1e-9
+    assert np.array_equal(mt, ref["matches"]) and np.array_equal(outl, ref["outliers"])
+    assert np.abs(rigid_inv(T_cw) - Tb).max() < 0.05
