@@ -16,8 +16,8 @@
 
 namespace vslam {
 
-__global__ __launch_bounds__(1024) void k_pose_lm(PoseArgs A) {
-    __shared__ double red[16 * 28];
+__global__ __launch_bounds__(POSE_NT) void k_pose_lm(PoseArgs A) {
+    __shared__ double red[(POSE_NT / 64) * 28];
     __shared__ double acc[28];
     __shared__ DPose sCur, sTrial;
     __shared__ double sH[36], sG[6];
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(1024) void k_pose_lm(PoseArgs A) {
 
     auto local_error = [&](const DPose& T) {
         double e = 0;
-        for (int i = tid; i < M; i += 1024) {
+        for (int i = tid; i < M; i += POSE_NT) {
             const double* f = A.factors + (size_t)i * 8;
             if (f[0] < 0) continue;
             double r[3];
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(1024) void k_pose_lm(PoseArgs A) {
 #pragma unroll
             for (int k = 0; k < 28; k++) v[k] = 0;
             const DPose T = sCur;
-            for (int i = tid; i < M; i += 1024) {
+            for (int i = tid; i < M; i += POSE_NT) {
                 const double* f = A.factors + (size_t)i * 8;
                 if (f[0] < 0) continue;
                 double r[3], J[3][6];
@@ -249,7 +249,7 @@ vslam_status vslam_matcher::pose_enqueue(int M) {
     A.factors = d_factors; A.firstFail = d_firstFail; A.code = (int*)(fl + 4 * pc); A.poseIO = d_poseIO; A.out = d_poseOut;
     A.maxIterations = 100; A.relTol = 1e-5; A.absTol = 1e-5; A.thres = 7.815;
     int t = timer.begin("pose_lm");
-    hipLaunchKernelGGL(k_pose_lm, dim3(1), dim3(1024), 0, stream, A);
+    hipLaunchKernelGGL(k_pose_lm, dim3(1), dim3(POSE_NT), 0, stream, A);
     timer.end(t);
     VS_HIP(hipGetLastError());
     return VSLAM_OK;

@@ -6,6 +6,8 @@
 
 namespace vslam {
 
+constexpr int POSE_NT = 256;      // threads of the single-workgroup pose kernels (4 waves: cheap barriers, ~3 factors / thread)
+
 struct PoseArgs {
     int M;
     const double* points;
@@ -85,7 +87,7 @@ __device__ __forceinline__ void block_reduce(double (&v)[NV], double* red, doubl
     __syncthreads();
     if (tid < NV) {
         double s = 0;
-        for (int w = 0; w < 16; w++) s += red[w * NV + tid];
+        for (int w = 0; w < POSE_NT / 64; w++) s += red[w * NV + tid];
         out[tid] = s;
     }
     __syncthreads();
@@ -104,7 +106,7 @@ __device__ __forceinline__ bool check2d(const double* pc, float ox, float oy, co
 // factor list of estimatePoseGTSAM (src/FeatureTracker.cpp:219-299); every thread of the workgroup calls it
 __device__ __forceinline__ void pose_build_factors(const PoseArgs& A) {
     const int tid = threadIdx.x, M = A.M;
-    for (int i = tid; i < M; i += 1024) {
+    for (int i = tid; i < M; i += POSE_NT) {
         double* f = A.factors + (size_t)i * 8;
         int type = -1;
         const int first = A.matches[2 * i], second = A.matches[2 * i + 1];
@@ -139,13 +141,13 @@ __device__ __forceinline__ void pose_build_factors(const PoseArgs& A) {
 // every thread of the workgroup calls it
 __device__ __forceinline__ void pose_find_outliers(const PoseArgs& A, const DPose& Tcw, int* sCnt) {
     const int tid = threadIdx.x, M = A.M;
-    for (int i = tid; i < M; i += 1024) {           // pass A0: reset firstFail for touched keypoints
+    for (int i = tid; i < M; i += POSE_NT) {           // pass A0: reset firstFail for touched keypoints
         const int first = A.matches[2 * i];
         if (first >= 0) A.firstFail[first] = INT_MAX;
     }
     __syncthreads();
     int nIn = 0;
-    for (int i = tid; i < M; i += 1024) {           // pass A: classify
+    for (int i = tid; i < M; i += POSE_NT) {           // pass A: classify
         const int first = A.matches[2 * i], second = A.matches[2 * i + 1];
         int code = 0;
         const double p[3] = {A.points[3 * i], A.points[3 * i + 1], A.points[3 * i + 2]};
@@ -176,7 +178,7 @@ __device__ __forceinline__ void pose_find_outliers(const PoseArgs& A, const DPos
     }
     __syncthreads();
     int nSt = 0;
-    for (int i = tid; i < M; i += 1024) {           // pass B: apply in reference order
+    for (int i = tid; i < M; i += POSE_NT) {           // pass B: apply in reference order
         const int code = A.code[i];
         if (!code) continue;
         const int nIdx = A.matches[2 * i];

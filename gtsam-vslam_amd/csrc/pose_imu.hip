@@ -91,8 +91,8 @@ struct ImuLmArgs {
     double* io;              // out: vel(3), bias(6)
 };
 
-__global__ __launch_bounds__(1024) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I) {
-    __shared__ double red[16 * 28];
+__global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I) {
+    __shared__ double red[(POSE_NT / 64) * 28];
     __shared__ double acc[28];
     __shared__ DPose sT, sT2, sPT, sTcw;
     __shared__ double sV[3], sB[6], sV2[3], sB2[6], sPV[3];
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(1024) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I) {
 
     auto vision_error = [&](const DPose& T) {
         double e = 0;
-        for (int i = tid; i < M; i += 1024) {
+        for (int i = tid; i < M; i += POSE_NT) {
             const double* f = A.factors + (size_t)i * 8;
             if (f[0] < 0) continue;
             double r[3];
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(1024) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I) {
 #pragma unroll
             for (int k = 0; k < 28; k++) v[k] = 0;
             const DPose T = sT;
-            for (int i = tid; i < M; i += 1024) {
+            for (int i = tid; i < M; i += POSE_NT) {
                 const double* f = A.factors + (size_t)i * 8;
                 if (f[0] < 0) continue;
                 double r[3], J[3][6];
@@ -384,7 +384,7 @@ vslam_status vslam_matcher::pose_imu_enqueue(int M) {
     for (int k = 0; k < 3; k++) { I.si.t[k] = imuSi[9 + k]; I.si.v[k] = imuSi[12 + k]; }
     for (int k = 0; k < 6; k++) I.biasPrev[k] = imuBiasPrev[k];
     int t = timer.begin("pose_imu_lm");
-    hipLaunchKernelGGL(k_pose_imu_lm, dim3(1), dim3(1024), 0, stream, A, I);
+    hipLaunchKernelGGL(k_pose_imu_lm, dim3(1), dim3(POSE_NT), 0, stream, A, I);
     timer.end(t);
     VS_HIP(hipGetLastError());
     return VSLAM_OK;
