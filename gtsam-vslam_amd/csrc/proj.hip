@@ -174,30 +174,19 @@ __device__ __forceinline__ int proj_decide(unsigned long long l1, unsigned long 
     return (right ? 1 << 16 : 0) | bestIdx;
 }
 
-// Parallel: the decision each map point takes IF the two best keys of both its lists are still unclaimed
-// when its turn comes (the common case).  need[i] = those four keypoint indices (0xffff = none),
-// tent[i] = proj_decide of them.
-__global__ __launch_bounds__(256) void k_proj_tentative(int M, const unsigned long long* __restrict__ topk,
-                                                        const int* __restrict__ matches, int* __restrict__ tent,
-                                                        unsigned long long* __restrict__ need) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= M) return;
-    const unsigned long long* k = topk + (size_t)i * 16;
-    const unsigned long long l1 = k[0], l2 = k[1], r1 = k[8], r2 = k[9];
-    const bool skip = matches[2 * i] >= 0 || matches[2 * i + 1] >= 0;
-    tent[i] = skip ? -2 : proj_decide(l1, l2, r1, r2);
-    auto ix = [](unsigned long long key) -> unsigned long long { return key == KEY_NONE ? 0xffffull : (unsigned long long)key_idx(key); };
-    need[i] = ix(l1) | (ix(l2) << 16) | (ix(r1) << 32) | (ix(r2) << 48);
-}
+// One wave walks the map points in order (the greedy claims are sequential by definition), sixteen per
+// step (lane = 4*q + e; lanes e = 0,1 hold the left key list of point q, e = 2,3 the right one, four keys
+// each, prefetched one step ahead).  Per step every point derives, in parallel, the first two unclaimed
+// keys of both lists from the claim tables in LDS and the reference's accept rule; the sixteen decisions
+// are applied at once unless a point's lists contain a keypoint claimed by an earlier point of the same
+// step, two points of the step claim the same keypoint, or a full list is (almost) exhausted — then the
+// step is replayed point by point (with the exact rescan when a list is exhausted), so the result is the
+// reference's for any input.
+constexpr int PROJ_SUPER = 512;      // map points staged in LDS per super-step (64 KB of keys)
 
-// One wave walks the map points in order (the greedy claims are sequential by definition).
-// Sixteen map points per step (lane = 4*q + e): each lane prefetches one of the four keypoint indices
-// whose claim state decides whether the precomputed decision stands; if any of them has been claimed
-// meanwhile, the general path re-derives the first two unclaimed keys of both lists (and, if a full list
-// is exhausted, rescans that side with the claims applied), so the result is exact for any input.
-__global__ __launch_bounds__(64) void k_proj_resolve(ProjArgs A, const unsigned long long* __restrict__ topk,
-                                                     const int* __restrict__ tent,
-                                                     const unsigned long long* __restrict__ need,
+__device__ __forceinline__ void lds_order() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+__global__ __launch_bounds__(256) void k_proj_resolve(ProjArgs A, const unsigned long long* __restrict__ topk,
                                                      int* __restrict__ matchedL, int* __restrict__ matchedR,
                                                      int* __restrict__ matches, int* __restrict__ outp) {
     extern __shared__ int claims[];
@@ -205,100 +194,165 @@ __global__ __launch_bounds__(64) void k_proj_resolve(ProjArgs A, const unsigned 
     int* cr = claims + A.n[0];
     int* ri = cr + A.n[1];      // TrackedKeys::rightIdxs / leftIdxs staged next to the claim tables:
     int* li = ri + A.n[0];      // the stereo-partner lookup is on the serial path
-    const int lane = threadIdx.x;
-    for (int k = lane; k < A.n[0]; k += 64) { cl[k] = matchedL[k]; ri[k] = A.rightIdxs[k]; }
-    for (int k = lane; k < A.n[1]; k += 64) { cr[k] = matchedR[k]; li[k] = A.leftIdxs[k]; }
-    __syncthreads();
+    int* spair = li + A.n[1];                                                      // [PROJ_SUPER][2]
+    unsigned long long* skeys = (unsigned long long*)(((uintptr_t)(spair + 2 * PROJ_SUPER) + 15) & ~(uintptr_t)15);   // [PROJ_SUPER][16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int k = tid; k < A.n[0]; k += 256) { cl[k] = matchedL[k]; ri[k] = A.rightIdxs[k]; }
+    for (int k = tid; k < A.n[1]; k += 256) { cr[k] = matchedR[k]; li[k] = A.leftIdxs[k]; }
     int nMatches = 0;
-    const int q = lane >> 2, e = lane & 3;
-    auto load_need = [&](int base) -> int {
-        const int i = base + q;
-        return i < A.M ? (int)((need[i] >> (16 * e)) & 0xffffull) : 0xffff;
-    };
-    auto load_tent = [&](int base) -> int {
-        const int i = base + q;
-        return i < A.M ? tent[i] : -2;
-    };
-    int nextNeed = load_need(0), nextTent = load_tent(0);
-    for (int base = 0; base < A.M; base += 16) {
-        const int myNeed = nextNeed, myTent = nextTent;
-        nextNeed = load_need(base + 16);
-        nextTent = load_tent(base + 16);
-        for (int qq = 0; qq < 16; qq++) {
-            const int i = base + qq;
-            if (i >= A.M) break;
-            const int t = __shfl(myTent, qq * 4);
-            if (t == -2) continue;                               // already matched before this call
-            bool claimed = false;
-            if (q == qq && myNeed != 0xffff) claimed = (e >= 2 ? cr[myNeed] : cl[myNeed]) >= 0;
-            int dec = t;
-            if (__ballot(claimed)) {
-                // general path: first two unclaimed keys of each list
-                const int side = lane >= PROJ_K ? 1 : 0;
+    static_assert(PROJ_K == 8, "lane layout assumes 8 keys per side");
+    const int q = lane >> 2, e = lane & 3, side = e >> 1, half = e & 1;
+    for (int sc = 0; sc < A.M; sc += PROJ_SUPER) {
+        const int n = min(PROJ_SUPER, A.M - sc);
+        __syncthreads();
+        // all four waves stage this super-step's key lists and current pairs in LDS (deep, coalesced loads):
+        // the serial walk below then never waits on HBM / L2
+        {
+            const ulonglong2* src = (const ulonglong2*)(topk + (size_t)sc * 16);
+            ulonglong2* dst = (ulonglong2*)skeys;
+            for (int k = tid; k < n * 8; k += 256) dst[k] = src[k];
+            for (int k = tid; k < n * 2; k += 256) spair[k] = matches[2 * (size_t)sc + k];
+        }
+        __syncthreads();
+        if (wave != 0) continue;
+        for (int base = 0; base < n; base += 16) {
+            const int pl = base + q;                          // point index inside the super-step
+            const bool have = pl < n;
+            unsigned long long k4[4] = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE};
+            int pairv = 0;                                    // >= 0 -> treated as already matched -> skipped
+            if (have) {
+                const ulonglong2* p = (const ulonglong2*)(skeys + (size_t)pl * 16 + e * 4);
+                const ulonglong2 a = p[0], b2v = p[1];
+                k4[0] = a.x; k4[1] = a.y; k4[2] = b2v.x; k4[3] = b2v.y;
+                pairv = spair[2 * pl + (e & 1)];
+            }
+            const int* tab = side ? cr : cl;
+            const bool skip = (pairv >= 0) || (__shfl_xor(pairv, 1) >= 0);
+            unsigned fb = 0, vb = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bool valid = k4[j] != KEY_NONE;
+                vb |= (unsigned)valid << j;
+                if (valid && tab[key_idx(k4[j])] < 0) fb |= 1u << j;
+            }
+            const unsigned ofb = __shfl_xor(fb, 1), ovb = __shfl_xor(vb, 1);
+            const unsigned fm = half ? (ofb | (fb << 4)) : (fb | (ofb << 4));
+            const unsigned vm = half ? (ovb | (vb << 4)) : (vb | (ovb << 4));
+            bool bad = !skip && vm == 0xffu && __popc(fm) < 2;          // exhausted list: needs the exact rescan
+            int p1 = -1, p2 = -1;
+            { unsigned m = fm; if (m) { p1 = __ffs(m) - 1; m &= m - 1; } if (m) p2 = __ffs(m) - 1; }
+            auto sel = [&](int pos) -> unsigned long long {
+                const int sl = pos & 3;
+                return sl == 0 ? k4[0] : (sl == 1 ? k4[1] : (sl == 2 ? k4[2] : k4[3]));
+            };
+            const int pairBase = lane & ~1;
+            unsigned long long b1 = __shfl(sel(p1 < 0 ? 0 : p1), pairBase | ((p1 < 0 ? 0 : p1) >> 2));
+            unsigned long long b2 = __shfl(sel(p2 < 0 ? 0 : p2), pairBase | ((p2 < 0 ? 0 : p2) >> 2));
+            if (p1 < 0) b1 = KEY_NONE;
+            if (p2 < 0) b2 = KEY_NONE;
+            const unsigned long long o1 = __shfl_xor(b1, 2), o2 = __shfl_xor(b2, 2);
+            const int dec = skip ? -1 : (side ? proj_decide(o1, o2, b1, b2) : proj_decide(b1, b2, o1, o2));
+            int cLq = -1, cRq = -1;
+            if (dec >= 0) {
+                const int idx = dec & 0xffff;
+                if (dec >> 16) { cRq = idx; cLq = li[idx]; } else { cLq = idx; cRq = ri[idx]; }
+            }
+#pragma unroll
+            for (int q2 = 0; q2 < 15; q2++) {
+                const int ocl = __shfl(cLq, q2 * 4), ocr = __shfl(cRq, q2 * 4);
+                if (q2 < q && !skip) {
+                    const int oc = side ? ocr : ocl;
+                    if (oc >= 0) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if (k4[j] != KEY_NONE && key_idx(k4[j]) == oc) bad = true;
+                    }
+                    if ((cLq >= 0 && cLq == ocl) || (cRq >= 0 && cRq == ocr)) bad = true;
+                }
+            }
+            if (__ballot(bad) == 0ull) {
+                if (e == 0 && dec >= 0) {
+                    const int i = sc + pl;
+                    if (cLq >= 0) { cl[cLq] = i; matches[2 * (size_t)i] = cLq; }
+                    if (cRq >= 0) { cr[cRq] = i; matches[2 * (size_t)i + 1] = cRq; }
+                }
+                nMatches += __popcll(__ballot(e == 0 && dec >= 0));
+                lds_order();
+                continue;
+            }
+            // ---- replay this step point by point ----------------------------------------------------------
+            for (int qq = 0; qq < 16; qq++) {
+                const int pli = base + qq;
+                if (pli >= n) break;
+                const int i = sc + pli;
+                if (__shfl((int)skip, qq * 4)) continue;
+                const int sd = lane >= PROJ_K ? 1 : 0;
                 unsigned long long key = KEY_NONE;
-                if (lane < 16) key = topk[(size_t)i * 16 + lane];
+                if (lane < 16) key = skeys[(size_t)pli * 16 + lane];
                 const bool valid = key != KEY_NONE;
                 bool fre = false;
-                if (valid) fre = (side ? cr[key_idx(key)] : cl[key_idx(key)]) < 0;
+                if (valid) fre = (sd ? cr[key_idx(key)] : cl[key_idx(key)]) < 0;
                 const unsigned long long vmask = __ballot(valid), fmask = __ballot(fre);
                 unsigned long long b1k[2], b2k[2];
 #pragma unroll
                 for (int s = 0; s < 2; s++) {
                     const int sh = s * PROJ_K;
-                    const unsigned vm = (unsigned)((vmask >> sh) & 0xffu);
-                    unsigned fm = (unsigned)((fmask >> sh) & 0xffu);
-                    if (vm == 0xffu && __popc(fm) < 2) {
+                    const unsigned vmm = (unsigned)((vmask >> sh) & 0xffu);
+                    unsigned fmm = (unsigned)((fmask >> sh) & 0xffu);
+                    if (vmm == 0xffu && __popc(fmm) < 2) {
                         const vslam_mappoint_view* mp = A.mpv + i;
                         uint32_t md[8];
                         load_mp_desc(mp, md);
-                        unsigned long long o2[2] = {KEY_NONE, KEY_NONE};
+                        unsigned long long o2k[2] = {KEY_NONE, KEY_NONE};
                         const float px = s ? mp->pred_rx : mp->pred_lx, py = s ? mp->pred_ry : mp->pred_ly;
                         const int ps = s ? mp->scale_level_r : mp->scale_level_l;
-                        scan_side<2>(A, s, md, px, py, ps, s ? cr : cl, o2);
-                        b1k[s] = o2[0];
-                        b2k[s] = o2[1];
+                        scan_side<2>(A, s, md, px, py, ps, s ? cr : cl, o2k);
+                        b1k[s] = o2k[0];
+                        b2k[s] = o2k[1];
                     } else {
                         int l1 = -1, l2 = -1;
-                        if (fm) { l1 = __ffs(fm) - 1; fm &= fm - 1; }
-                        if (fm) { l2 = __ffs(fm) - 1; }
+                        if (fmm) { l1 = __ffs(fmm) - 1; fmm &= fmm - 1; }
+                        if (fmm) { l2 = __ffs(fmm) - 1; }
                         const unsigned long long k1 = __shfl(key, (l1 < 0 ? 0 : l1) + sh);
                         const unsigned long long k2 = __shfl(key, (l2 < 0 ? 0 : l2) + sh);
                         b1k[s] = l1 < 0 ? KEY_NONE : k1;
                         b2k[s] = l2 < 0 ? KEY_NONE : k2;
                     }
                 }
-                dec = proj_decide(b1k[0], b2k[0], b1k[1], b2k[1]);
-            }
-            if (dec < 0) continue;
-            nMatches++;
-            if (lane == 0) {
-                const int idx = dec & 0xffff;
-                if (dec >> 16) {
-                    cr[idx] = i;
-                    matches[2 * i + 1] = idx;
-                    const int l = li[idx];
-                    if (l >= 0) { matches[2 * i] = l; cl[l] = i; }
-                } else {
-                    cl[idx] = i;
-                    matches[2 * i] = idx;
-                    const int r = ri[idx];
-                    if (r >= 0) { matches[2 * i + 1] = r; cr[r] = i; }
+                const int d2 = proj_decide(b1k[0], b2k[0], b1k[1], b2k[1]);
+                if (d2 < 0) continue;
+                nMatches++;
+                if (lane == 0) {
+                    const int idx = d2 & 0xffff;
+                    if (d2 >> 16) {
+                        cr[idx] = i;
+                        matches[2 * (size_t)i + 1] = idx;
+                        const int l = li[idx];
+                        if (l >= 0) { matches[2 * (size_t)i] = l; cl[l] = i; }
+                    } else {
+                        cl[idx] = i;
+                        matches[2 * (size_t)i] = idx;
+                        const int r = ri[idx];
+                        if (r >= 0) { matches[2 * (size_t)i + 1] = r; cr[r] = i; }
+                    }
                 }
+                lds_order();      // single wave: the LDS claim writes are ordered before the next point's reads
             }
-            __syncthreads();   // single wave: orders the LDS claim writes before the next map point's reads
         }
     }
     __syncthreads();
-    for (int k = lane; k < A.n[0]; k += 64) matchedL[k] = cl[k];
-    for (int k = lane; k < A.n[1]; k += 64) matchedR[k] = cr[k];
-    if (lane == 0) outp[0] = nMatches;
+    for (int k = tid; k < A.n[0]; k += 256) matchedL[k] = cl[k];
+    for (int k = tid; k < A.n[1]; k += 256) matchedR[k] = cr[k];
+    if (tid == 0) outp[0] = nMatches;
 }
 
 void launch_proj_resolve(hipStream_t s, const ProjArgs& A, const unsigned long long* topk, int* tent,
                          unsigned long long* need, int* matchedL, int* matchedR, int* matches, int* out) {
-    if (A.M > 0) hipLaunchKernelGGL(k_proj_tentative, dim3((A.M + 255) / 256), dim3(256), 0, s, A.M, topk, matches, tent, need);
-    const size_t sh = (size_t)(2 * (A.n[0] + A.n[1]) + 1) * sizeof(int);
-    hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(64), sh, s, A, topk, tent, need, matchedL, matchedR, matches, out);
+    (void)tent; (void)need;
+    const size_t sh = (size_t)(2 * (A.n[0] + A.n[1]) + 2 * PROJ_SUPER) * sizeof(int) + 32 + (size_t)PROJ_SUPER * 16 * sizeof(unsigned long long);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_proj_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(256), sh, s, A, topk, matchedL, matchedR, matches, out);
 }
 
 }  // namespace vslam
@@ -343,6 +397,9 @@ vslam_status vslam_matcher::proj_enqueue(int M, float rad) {
     t = timer.begin("proj_resolve");
     launch_proj_resolve(stream, A, d_topk, d_tent, d_need, d_matchedL, d_matchedR, d_matches, d_projOut);
     timer.end(t);
+#ifdef VSLAM_PROJ_STAMPS
+    { int o[4]; hipStreamSynchronize(stream); hipMemcpy(o, d_projOut, sizeof(o), hipMemcpyDeviceToHost); fprintf(stderr, "proj_resolve M=%d rad=%.0f: loop cycles %d  batch chunks %d  serial chunks %d\n", M, rad, o[1], o[2], o[3]); }
+#endif
     VS_HIP(hipGetLastError());
     return VSLAM_OK;
 }
