@@ -234,4 +234,67 @@ VS_HD bool chol_solve_n(double* A, double* b) {
     return true;
 }
 
+
+#ifdef __HIPCC__
+// readlane of a double from a compile-time-uniform lane (2 x v_readlane_b32, result in SGPRs)
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// Wave-cooperative form of chol_solve_n for the damped LM step (H + lambda I) delta = g, N <= 64: lane i keeps
+// row i of the matrix in registers, pivots and multipliers travel by readlane.  Every entry sees exactly the
+// operations of the single-thread routine in the same order (right-looking updates subtract k = 0..j-1 in
+// order; the back-substitution chain runs in ascending k), so the result is bit-identical to it.
+// Must be called by all 64 lanes of one wave.  H, g: N x N row-major / N (LDS).  Returns false when a pivot
+// is not positive; otherwise delta[0..N) is written by lanes < N and dg = delta.g, dHd = delta^T H delta.
+template <int N>
+__device__ __forceinline__ bool wave_chol_solve(const double* H, double lambda, const double* g, double* delta,
+                                                double& dg, double& dHd) {
+    const int lane = threadIdx.x & 63;
+    const int r = lane < N ? lane : N - 1;          // spare lanes shadow the last row
+    double a[N], h[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) { h[j] = H[r * N + j]; a[j] = (j == r) ? h[j] + lambda : h[j]; }
+    const double gi = g[r];
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        double d = readlane_d(a[k], k);
+        if (!(d > 0)) { ok = false; break; }
+        d = sqrt(d);
+        const double lk = (r == k) ? d : a[k] / d;
+        a[k] = lk;
+#pragma unroll
+        for (int j = k + 1; j < N; j++) a[j] -= lk * readlane_d(lk, j);
+    }
+    if (!ok) return false;
+    double b = gi;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const double yk = readlane_d(b, k) / readlane_d(a[k], k);
+        if (r == k) b = yk; else if (r > k) b -= a[k] * yk;
+    }
+#pragma unroll
+    for (int i = N - 1; i >= 0; i--) {
+        const double pr = a[i] * b;                 // lane k > i: L[k][i] * x[k]
+        double s = readlane_d(b, i);
+#pragma unroll
+        for (int k = i + 1; k < N; k++) s -= readlane_d(pr, k);
+        const double xi = s / readlane_d(a[i], i);
+        if (r == i) b = xi;
+    }
+    double hs = 0;
+#pragma unroll
+    for (int q = 0; q < N; q++) hs += h[q] * readlane_d(b, q);
+    const double pg = b * gi, ph = b * hs;
+    dg = 0; dHd = 0;
+#pragma unroll
+    for (int p = 0; p < N; p++) { dg += readlane_d(pg, p); dHd += readlane_d(ph, p); }
+    if (lane < N) delta[lane] = b;
+    return true;
+}
+#endif
+
 }  // namespace vslam

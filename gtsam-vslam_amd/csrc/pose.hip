@@ -98,25 +98,17 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_lm(PoseArgs A) {
         }
         // phase 1: tryLambda
         __shared__ double sDelta[6], sLin;
-        if (tid == 0) {
-            double Hd[36], dl[6];
-            for (int k = 0; k < 36; k++) Hd[k] = sH[k];
-            for (int p = 0; p < 6; p++) { Hd[p * 6 + p] += sLambda; dl[p] = sG[p]; }
-            const bool solved = chol_solve_n<6>(Hd, dl);
-            sEval = 0;
-            if (solved) {
-                double dg = 0, dHd = 0;
-                for (int p = 0; p < 6; p++) {
-                    dg += dl[p] * sG[p];
-                    double s = 0;
-                    for (int q2 = 0; q2 < 6; q2++) s += sH[p * 6 + q2] * dl[q2];
-                    dHd += dl[p] * s;
-                }
-                sLin = dg - 0.5 * dHd;
-                if (sLin >= 0) {
-                    for (int p = 0; p < 6; p++) sDelta[p] = dl[p];
-                    pose_retract(sCur, dl, sTrial);
-                    sEval = 1;
+        if (tid < 64) {
+            double dg, dHd;
+            const bool solved = wave_chol_solve<6>(sH, sLambda, sG, sDelta, dg, dHd);
+            if (tid == 0) {
+                sEval = 0;
+                if (solved) {
+                    sLin = dg - 0.5 * dHd;
+                    if (sLin >= 0) {
+                        pose_retract(sCur, sDelta, sTrial);
+                        sEval = 1;
+                    }
                 }
             }
         }

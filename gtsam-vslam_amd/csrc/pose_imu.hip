@@ -84,6 +84,15 @@ __global__ __launch_bounds__(256) void k_imu_preintegrate(DImuParams P, const do
     for (int i = tid; i < (int)(sizeof(DPim) / sizeof(double)); i += 256) ((double*)pimOut)[i] = ((double*)&pim)[i];
 }
 
+#ifdef VSLAM_POSE_STAMPS
+__device__ long long g_ps[16];
+#define PS_ACC(k) do { if (threadIdx.x == 0) { const long long n_ = clock64(); g_ps[k] += n_ - ps_t; ps_t = n_; } } while (0)
+#define PS_CNT(k) do { if (threadIdx.x == 0) g_ps[k] += 1; } while (0)
+#else
+#define PS_ACC(k) do {} while (0)
+#define PS_CNT(k) do {} while (0)
+#endif
+
 struct ImuLmArgs {
     const DPim* pim; const double* Lam; DImuParams P;
     DNav si;                 // x0, v0
@@ -101,8 +110,12 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I
     __shared__ double sError, sLambda, sNewErr, sCurErr, sLin, sNV;
     __shared__ int sPhase, sEval, sIter, sInner, sCnt[2];
     const int tid = threadIdx.x, M = A.M;
+#ifdef VSLAM_POSE_STAMPS
+    long long ps_t = clock64();
+#endif
 
     pose_build_factors(A);
+    PS_ACC(0);
     if (tid < 225) sLam[tid] = I.Lam[tid];
     if (tid == 0) {
         pim_predict(*I.pim, I.P, I.si, sPred);                   // prop_state: initial values, priors, factor prediction
@@ -152,6 +165,7 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I
         }
         __syncthreads();
     }
+    PS_ACC(1);
 
     for (;;) {
         const int phase = sPhase;
@@ -178,6 +192,7 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I
                 }
             }
             block_reduce<28>(v, red, acc);
+            PS_ACC(2);
             if (tid == 0) {
                 imu_factor_eval(sPred, I.pim->biasHat, sT.R, sT.t, sV, sB, sR15, sJ);
                 DPose pi, d;
@@ -186,6 +201,7 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I
                 pose3_logmap(d, sRp);
                 pose3_logmap_derivative(d, sJp);
             }
+            PS_ACC(3);
             __syncthreads();
             if (tid < 225) {
                 const int i = tid / 15, c = tid % 15;
@@ -223,39 +239,35 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I
             __syncthreads();
             if (tid == 0) { sCurErr = sError; sPhase = 1; }
             __syncthreads();
+            PS_ACC(4); PS_CNT(10);
             continue;
         }
-        if (tid == 0) {
-            double Hd[225], dl[15];
-            for (int k = 0; k < 225; k++) Hd[k] = sH[k];
-            for (int p = 0; p < 15; p++) { Hd[p * 15 + p] += sLambda; dl[p] = sG[p]; }
-            const bool solved = chol_solve_n<15>(Hd, dl);
-            sEval = 0;
-            if (solved) {
-                double dg = 0, dHd = 0;
-                for (int p = 0; p < 15; p++) {
-                    dg += dl[p] * sG[p];
-                    double s = 0;
-                    for (int q2 = 0; q2 < 15; q2++) s += sH[p * 15 + q2] * dl[q2];
-                    dHd += dl[p] * s;
-                }
-                sLin = dg - 0.5 * dHd;
-                if (sLin >= 0) {
-                    for (int p = 0; p < 15; p++) sDelta[p] = dl[p];
-                    pose_retract(sT, dl, sT2);
-                    for (int i = 0; i < 3; i++) sV2[i] = sV[i] + dl[6 + i];
-                    for (int i = 0; i < 6; i++) sB2[i] = sB[i] + dl[9 + i];
-                    sNV = nonvision_error(sT2, sV2, sB2);
-                    sEval = 1;
+        if (tid < 64) {
+            double dg, dHd;
+            const bool solved = wave_chol_solve<15>(sH, sLambda, sG, sDelta, dg, dHd);
+            PS_ACC(5);
+            if (tid == 0) {
+                sEval = 0;
+                if (solved) {
+                    sLin = dg - 0.5 * dHd;
+                    if (sLin >= 0) {
+                        pose_retract(sT, sDelta, sT2);
+                        for (int i = 0; i < 3; i++) sV2[i] = sV[i] + sDelta[6 + i];
+                        for (int i = 0; i < 6; i++) sB2[i] = sB[i] + sDelta[9 + i];
+                        sNV = nonvision_error(sT2, sV2, sB2);
+                        sEval = 1;
+                    }
                 }
             }
         }
+        PS_ACC(6);
         __syncthreads();
         if (sEval) {
             double v1[1] = {vision_error(sT2)};
             block_reduce<1>(v1, red, acc);
             if (tid == 0) sNewErr = 0.5 * (acc[0] + sNV);
         }
+        PS_ACC(7); PS_CNT(11);
         if (tid == 0) {
             bool stepOk = false, stop = false;
             if (sEval) {
@@ -293,6 +305,7 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I
             }
         }
         __syncthreads();
+        PS_ACC(8);
     }
 
     if (tid == 0) {
@@ -308,6 +321,7 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I
     __syncthreads();
     pose_find_outliers(A, sTcw, sCnt);
     if (tid == 0) { A.out[0] = sCnt[0]; A.out[1] = sCnt[1]; }
+    PS_ACC(9);
 }
 
 }  // namespace vslam
@@ -384,8 +398,20 @@ vslam_status vslam_matcher::pose_imu_enqueue(int M) {
     for (int k = 0; k < 3; k++) { I.si.t[k] = imuSi[9 + k]; I.si.v[k] = imuSi[12 + k]; }
     for (int k = 0; k < 6; k++) I.biasPrev[k] = imuBiasPrev[k];
     int t = timer.begin("pose_imu_lm");
+#ifdef VSLAM_POSE_STAMPS
+    { long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ps), z, sizeof(z)); }
+#endif
     hipLaunchKernelGGL(k_pose_imu_lm, dim3(1), dim3(POSE_NT), 0, stream, A, I);
     timer.end(t);
+#ifdef VSLAM_POSE_STAMPS
+    {
+        long long z[16];
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_ps), sizeof(z));
+        fprintf(stderr, "pose_imu_lm M=%d: build %lld init %lld | lin: vis %lld imuJ %lld prod %lld (x%lld) | trial: solve %lld nv %lld+%lld vis %lld ctl %lld (x%lld) | outl %lld\n",
+                M, z[0], z[1], z[2], z[3], z[4], z[10], z[5], z[6], 0LL, z[7], z[8], z[11], z[9]);
+    }
+#endif
     VS_HIP(hipGetLastError());
     return VSLAM_OK;
 }
