@@ -516,6 +516,71 @@ __global__ __launch_bounds__(1024) void k_ba_solve(BaDev D, double lambda, int u
     if (tid == 0) D.flags[0] = sFail;
 }
 
+// Reduced camera systems of up to BA_WAVE_N unknowns (10 free keyframes - the reference's local window) are
+// solved by ONE wave with the matrix in registers: lane i owns row i, pivots and multipliers travel by
+// v_readlane, no LDS round trip or barrier per column.  Right-looking Cholesky (rsqrt pivots as in k_ba_solve),
+// forward substitution, transpose of L through LDS, column-oriented back substitution, pose retraction.
+constexpr int BA_WAVE_N = 60;
+__global__ __launch_bounds__(64) void k_ba_solve_wave(BaDev D, double lambda) {
+    constexpr int N = BA_WAVE_N;
+    __shared__ double Lt[N * (N + 1)];
+    const int n = D.n, lane = threadIdx.x;
+    const int r = lane < N ? lane : N - 1;
+    double a[N];
+    // rows >= n are identity padding; the upper triangle of D.S is the valid one
+#pragma unroll
+    for (int c = 0; c < N; c++) {
+        double v = (c == r) ? 1.0 : 0.0;
+        if (r < n && c < n) v = D.S[r <= c ? (size_t)r * n + c : (size_t)c * n + r] + ((c == r) ? lambda : 0.0);
+        a[c] = v;
+    }
+    double b = r < n ? D.rhs[r] : 0.0;
+    bool bad = false;
+    double idg = 1.0;                 // 1 / L[r][r] once the pivot of this lane's row is known
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        double d = readlane_d(a[k], k);
+        if (!(d > 0)) { bad = true; d = 1.0; }
+        const double id = rsqrt(d);
+        const double lk = (r == k) ? d * id : a[k] * id;
+        if (r == k) idg = id;
+        a[k] = lk;
+#pragma unroll
+        for (int j = k + 1; j < N; j++) a[j] -= lk * readlane_d(lk, j);
+    }
+    if (!bad) {
+        // L y = b
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const double yk = readlane_d(b, k) * readlane_d(idg, k);
+            if (r == k) b = yk; else if (r > k) b -= a[k] * yk;
+        }
+        // column form of L: lane i gets L[k][i], k >= i
+        if (lane < N) {
+#pragma unroll
+            for (int j = 0; j < N; j++) Lt[lane * (N + 1) + j] = a[j];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < N; k++) a[k] = Lt[k * (N + 1) + r];
+        // L^T x = y
+#pragma unroll
+        for (int k = N - 1; k >= 0; k--) {
+            const double xk = readlane_d(b, k) * readlane_d(idg, k);
+            if (r == k) b = xk; else if (r < k) b -= a[k] * xk;
+        }
+        if (lane < n) D.dP[lane] = b;
+        Lt[lane] = b;                 // (the column reads above have completed: their values are in registers)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int k = lane; k < D.K; k += 64) {
+            const int fi = D.fidx[k];
+            if (fi >= 0) { DPose T; pose_retract(D.poseCur[k], Lt + 6 * fi, T); D.poseTrial[k] = T; }
+            else D.poseTrial[k] = D.poseCur[k];
+        }
+    }
+    if (lane == 0) D.flags[0] = bad ? 1 : 0;
+}
+
 // back-substitution: dl = Hll^-1 (bl - sum_k W_k^T dp_k); trial landmark = cur + dl
 __global__ __launch_bounds__(256) void k_ba_back(BaDev D, double lambda, int maxSlots) {
     extern __shared__ double sm[];
@@ -912,8 +977,9 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
                         hipLaunchKernelGGL(k_ba_reduce, dim3(((int)sysDoubles + 255) / 256, 1), dim3(256), 0, stream, D, 0);   // + BetweenFactor blocks
                     }
                     if (comm && n > 0) { const int tc = g_baTimer.begin("ba_allreduce"); VS_CHECK(comm_allreduce(comm, d_S.p, (size_t)n * n + n, stream)); g_baTimer.end(tc); }
-                    hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(std::max(64, vslam::align_up(n, 64))),
-                                       solveLds ? solveLdsBytes : 64, stream, D, lambda, solveLds ? 1 : 0, solveLds ? ldA : n);
+                    if (n <= BA_WAVE_N) hipLaunchKernelGGL(k_ba_solve_wave, dim3(1), dim3(64), 0, stream, D, lambda);
+                    else hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(std::max(64, vslam::align_up(n, 64))),
+                                            solveLds ? solveLdsBytes : 64, stream, D, lambda, solveLds ? 1 : 0, solveLds ? ldA : n);
                     g_baTimer.end(t);
                     t = g_baTimer.begin("ba_back");
                     if (Lp) hipLaunchKernelGGL(k_ba_back, dim3(lmBlocks), dim3(256), backLds, stream, D, lambda, maxSlots);
@@ -1029,6 +1095,11 @@ vslam_status vslam_local_ba_timings(const char** names, float* ms, int32_t cap, 
     int n = g_baTimer.read(nm, tv, cap < 64 ? cap : 64);
     for (int i = 0; i < n; i++) { if (names) names[i] = nm[i]; if (ms) ms[i] = tv[i]; }
     *n_out = n;
+    return VSLAM_OK;
+}
+
+vslam_status vslam_local_ba_set_timing(int32_t on) {
+    g_baTimer.enabled = on != 0;
     return VSLAM_OK;
 }
 

@@ -50,7 +50,9 @@ struct StageTimer {
     size_t used = 0;
     hipStream_t stream = nullptr;
     bool multi = false;
+    bool enabled = true;     // off: begin/end record nothing (two hipEventRecord per launch are not free on a launch-bound path)
     int begin(const char* name) {
+        if (!enabled) return -1;
         if (!multi) {
             for (size_t i = 0; i < used; i++)
                 if (!strcmp(items[i].name, name)) { hipEventRecord(items[i].a, stream); return (int)i; }
@@ -64,7 +66,7 @@ struct StageTimer {
         hipEventRecord(items[used].a, stream);
         return (int)used++;
     }
-    void end(int i) { hipEventRecord(items[i].b, stream); }
+    void end(int i) { if (i >= 0) hipEventRecord(items[i].b, stream); }
     void reset() { used = 0; }
     void destroy() { for (auto& it : items) { hipEventDestroy(it.a); hipEventDestroy(it.b); } items.clear(); used = 0; }
     // sums by name; returns number of distinct names written

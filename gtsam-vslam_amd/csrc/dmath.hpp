@@ -295,6 +295,61 @@ __device__ __forceinline__ bool wave_chol_solve(const double* H, double lambda, 
     if (lane < N) delta[lane] = b;
     return true;
 }
+
+// Wave-cooperative inverse of an N x N SPD matrix (N <= 64) through its Cholesky factor: the factorisation as in
+// wave_chol_solve (lane i = row i), then lane c solves for column c of the inverse with L broadcast from LDS.
+// Same operation order per entry as the single-thread "factor, then N column solves" routine.  Ls: N*N doubles
+// of LDS scratch; out: N x N row-major (any address space).  All 64 lanes of one wave must call it.
+template <int N>
+__device__ __forceinline__ bool wave_spd_inverse(const double* Ain, double* Ls, double* out) {
+    const int lane = threadIdx.x & 63;
+    const int r = lane < N ? lane : N - 1;
+    double a[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) a[j] = Ain[r * N + j];
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        double d = readlane_d(a[k], k);
+        if (!(d > 0)) { ok = false; break; }
+        d = sqrt(d);
+        const double lk = (r == k) ? d : a[k] / d;
+        a[k] = lk;
+#pragma unroll
+        for (int j = k + 1; j < N; j++) a[j] -= lk * readlane_d(lk, j);
+    }
+    if (!ok) {
+        if (lane < N) for (int i = 0; i < N; i++) out[i * N + lane] = 0.0;
+        return false;
+    }
+    if (lane < N) {
+#pragma unroll
+        for (int j = 0; j < N; j++) Ls[lane * N + j] = a[j];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    double e[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) e[i] = (i == r) ? 1.0 : 0.0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        double v = e[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) v -= Ls[i * N + k] * e[k];
+        e[i] = v / Ls[i * N + i];
+    }
+#pragma unroll
+    for (int i = N - 1; i >= 0; i--) {
+        double v = e[i];
+#pragma unroll
+        for (int k = i + 1; k < N; k++) v -= Ls[k * N + i] * e[k];
+        e[i] = v / Ls[i * N + i];
+    }
+    if (lane < N) {
+#pragma unroll
+        for (int i = 0; i < N; i++) out[i * N + lane] = e[i];
+    }
+    return true;
+}
 #endif
 
 }  // namespace vslam

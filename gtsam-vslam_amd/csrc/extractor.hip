@@ -176,6 +176,8 @@ vslam_status vslam_extractor::init(const vslam_fe_params* p, int w, int h, int b
     build_gauss_taps(B.taps);
 
     VS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    VS_HIP(hipEventCreateWithFlags(&evGather, hipEventDisableTiming));
+    VS_HIP(hipEventCreateWithFlags(&evDone, hipEventDisableTiming));
     timer.stream = stream;
     VS_HIP(hipMalloc(&d_pyr, (size_t)nimg * P.imgStride));
     VS_HIP(hipMalloc(&d_blur, (size_t)nimg * P.imgStride));
@@ -234,7 +236,7 @@ vslam_status vslam_extractor::init(const vslam_fe_params* p, int w, int h, int b
     nKept.assign(nimg, 0);
     sscOut.assign((size_t)nimg * nLevels, {});
     {
-        int nt = 3;   // + the calling thread; VSLAM_HOST_THREADS overrides (0 = no extra threads)
+        int nt = 5;   // + the calling thread; VSLAM_HOST_THREADS overrides (0 = no extra threads)
         if (const char* e = getenv("VSLAM_HOST_THREADS")) nt = std::max(0, std::min(15, atoi(e)));
         pool_start(nt);
     }
@@ -252,13 +254,31 @@ void vslam_extractor::release() {
     if (h_kept) hipHostFree(h_kept);
     if (h_keptOff) hipHostFree(h_keptOff);
     hipFree(d_kept); hipFree(d_keptOff); hipFree(d_kps); hipFree(d_desc); hipFree(d_disc);
+    if (evGather) hipEventDestroy(evGather);
+    if (evDone) hipEventDestroy(evDone);
+    evGather = evDone = nullptr;
     if (stream) hipStreamDestroy(stream);
     stream = nullptr;
+}
+
+void vslam_extractor::add_consumer(hipEvent_t e) {
+    std::lock_guard<std::mutex> lk(consumersMu);
+    for (hipEvent_t c : consumers) if (c == e) return;
+    consumers.push_back(e);
+}
+void vslam_extractor::remove_consumer(hipEvent_t e) {
+    std::lock_guard<std::mutex> lk(consumersMu);
+    consumers.erase(std::remove(consumers.begin(), consumers.end(), e), consumers.end());
+}
+void vslam_extractor::wait_consumers() {
+    std::lock_guard<std::mutex> lk(consumersMu);
+    for (hipEvent_t c : consumers) hipStreamWaitEvent(stream, c, 0);
 }
 
 vslam_status vslam_extractor::set_image(int idx, const void* src, int stride, bool srcOnDevice) {
     if (idx < 0 || idx >= nimg || !src || stride < width) { set_error("set_image: bad argument"); return VSLAM_ERR_INVALID; }
     VS_HIP(hipSetDevice(device));
+    wait_consumers();
     VS_HIP(hipMemcpy2DAsync(d_pyr + (size_t)idx * P.imgStride + P.off[0], P.pitch[0], src, stride, width,
                             height, srcOnDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
     if (!srcOnDevice) VS_HIP(hipStreamSynchronize(stream));  // caller may reuse its buffer
@@ -377,9 +397,22 @@ void vslam_extractor::pool_run(int nTasks) {
     pool.cvDone.wait(lk, [&] { return pool.finished == pool.nTasks; });
 }
 
+#ifdef VSLAM_HOST_STAMPS
+#include <chrono>
+static double hs_now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define HS(k) hs[k] = hs_now()
+#else
+#define HS(k) do {} while (0)
+#endif
+
 vslam_status vslam_extractor::run() {
     VS_HIP(hipSetDevice(device));
     int t;
+#ifdef VSLAM_HOST_STAMPS
+    double hs[8];
+#endif
+    HS(0);
+    wait_consumers();
     t = timer.begin("pyramid");
     for (int l = 1; l < nLevels; l++)
         launch_resize(stream, d_pyr, P, l, d_xtab + xtabOff[l], d_ytab + ytabOff[l], nimg);
@@ -392,16 +425,20 @@ vslam_status vslam_extractor::run() {
     launch_gather(stream, d_cellSlots, d_cellCount, F, nLevels, d_cellOff, d_cand, candCap,
                   d_levelCount, nimg);
     timer.end(t);
-    t = timer.begin("blur");
+    VS_HIP(hipEventRecord(evGather, stream));
+    t = timer.begin("blur");       // runs under the host SSC below
     launch_blur(stream, d_pyr, d_blur, P, B, nimg);
     timer.end(t);
     VS_HIP(hipGetLastError());
-    VS_HIP(hipStreamSynchronize(stream));
+    HS(1);
+    VS_HIP(hipEventSynchronize(evGather));
+    HS(2);
 
     // host: SSC per (image, level) on the worker pool; keeps are staged level-major
     for (int i = 0; i < nimg; i++)
         if (h_levelCount[(size_t)i * (MAX_LEVELS + 1) + MAX_LEVELS] > candCap) { set_error("FAST candidate overflow"); return VSLAM_ERR_CAPACITY; }
     pool_run(nimg * nLevels);
+    HS(3);
     int maxKept = 0;
     for (int i = 0; i < nimg; i++) {
         uint32_t* kout = h_kept + (size_t)i * keptCap;
@@ -425,7 +462,12 @@ vslam_status vslam_extractor::run() {
                        d_desc, keptCap, maxKept, nimg);
     timer.end(t);
     VS_HIP(hipGetLastError());
-    VS_HIP(hipStreamSynchronize(stream));
+    HS(4);
+    VS_HIP(hipEventRecord(evDone, stream));      // consumers order themselves after this; no host sync here
+    HS(5);
+#ifdef VSLAM_HOST_STAMPS
+    fprintf(stderr, "extract host us: launch %.1f sync %.1f ssc %.1f stage+launch %.1f sync %.1f\n", hs[1] - hs[0], hs[2] - hs[1], hs[3] - hs[2], hs[4] - hs[3], hs[5] - hs[4]);
+#endif
     ran = true;
     return VSLAM_OK;
 }
@@ -550,9 +592,16 @@ vslam_status vslam_extractor_timings(const vslam_extractor* ex, const char** nam
     if (!ex || !n_out) return VSLAM_ERR_INVALID;
     const char* nm[64];
     float tv[64];
+    hipStreamSynchronize(ex->stream);
     int n = ex->timer.read(nm, tv, cap < 64 ? cap : 64);
     for (int i = 0; i < n; i++) { if (names) names[i] = nm[i]; if (ms) ms[i] = tv[i]; }
     *n_out = n;
+    return VSLAM_OK;
+}
+
+vslam_status vslam_extractor_set_timing(vslam_extractor* ex, int32_t on) {
+    if (!ex) return VSLAM_ERR_INVALID;
+    ex->timer.enabled = on != 0;
     return VSLAM_OK;
 }
 

@@ -22,6 +22,16 @@ struct vslam_extractor {
     vslam::LevelTables T{};
     hipStream_t stream = nullptr;
     vslam::StageTimer timer;
+    // cross-stream ordering without host syncs: evGather = FAST candidates are in host-visible memory,
+    // evDone = keys / descriptors / pyramids of the last run are complete (matchers wait on it);
+    // consumers = "last read of this extractor's buffers" events of the bound matchers, waited on before
+    // the next frame overwrites the buffers
+    hipEvent_t evGather = nullptr, evDone = nullptr;
+    std::vector<hipEvent_t> consumers;
+    std::mutex consumersMu;
+    void add_consumer(hipEvent_t e);
+    void remove_consumer(hipEvent_t e);
+    void wait_consumers();
 
     uint8_t* d_pyr = nullptr;    // nimg * imgStride
     uint8_t* d_blur = nullptr;   // same layout

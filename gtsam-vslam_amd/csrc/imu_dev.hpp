@@ -85,17 +85,15 @@ VS_HD void dexp_apply_inv(const double* th, const double* v, double* R, double* 
     for (int i = 0; i < 9; i++) H1[i] = -ID[i];
 }
 
-// The 3x3-level part of one integrateMeasurement step, by ONE thread: new preintegrated vector,
-// A (9x9), B, C (9x3, sensor-pose corrected), F (15x15) and G = G Q G^T (15x15).
-VS_HD void pim_step_small(const DPim& pim, const DImuParams& P, const double* accM, const double* omegaM, double dt,
-                          double* plus, double* A, double* B, double* C, double* F, double* G) {
+// correctMeasurementsBySensorPose: bias-corrected measurements in the body frame (+ D_correctedAcc_unbiasedOmega)
+VS_HD bool pim_correct(const DPim& pim, const DImuParams& P, const double* accM, const double* omegaM, double* acc, double* om,
+                       double* D_acc_omega) {
     double accS[3] = {accM[0] - pim.biasHat[0], accM[1] - pim.biasHat[1], accM[2] - pim.biasHat[2]};
     double omS[3] = {omegaM[0] - pim.biasHat[3], omegaM[1] - pim.biasHat[4], omegaM[2] - pim.biasHat[5]};
-    double acc[3], om[3];
     mat3_vec(P.bRs, omS, om);
     mat3_vec(P.bRs, accS, acc);
     const bool hasArm = !(P.arm[0] == 0 && P.arm[1] == 0 && P.arm[2] == 0);
-    double D_acc_omega[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 9; i++) D_acc_omega[i] = 0;
     if (hasArm) {
         double Om[9], vb[3], cen[3];
         skew3(om, Om);
@@ -110,16 +108,36 @@ VS_HD void pim_step_small(const DPim& pim, const DImuParams& P, const double* ac
         m3_outer(P.arm, omS, o2);
         for (int i = 0; i < 9; i++) D_acc_omega[i] = -tb[i] + 2.0 * o2[i];
     }
+    return hasArm;
+}
+
+// The state recursion of one integrateMeasurement step (TangentPreintegration::UpdatePreintegrated value):
+// preint -> plus.  This is the only part that is serial over the samples of a bucket.
+VS_HD void pim_step_state(const DPim& pim, const double* preint, const DImuParams& P, const double* accM, const double* omegaM,
+                          double dt, double* plus) {
+    double acc[3], om[3], D_acc_omega[9];
+    pim_correct(pim, P, accM, omegaM, acc, om, D_acc_omega);
     double R[9], dexp[9], wt[3], wtH[9], invH[9];
-    dexp_apply_inv(pim.preint, om, R, dexp, wt, wtH, invH);
+    dexp_apply_inv(preint, om, R, dexp, wt, wtH, invH);
     double a_nav[3];
     mat3_vec(R, acc, a_nav);
     const double dt22 = 0.5 * dt * dt;
     for (int i = 0; i < 3; i++) {
-        plus[i] = pim.preint[i] + wt[i] * dt;
-        plus[3 + i] = pim.preint[3 + i] + pim.preint[6 + i] * dt + a_nav[i] * dt22;
-        plus[6 + i] = pim.preint[6 + i] + a_nav[i] * dt;
+        plus[i] = preint[i] + wt[i] * dt;
+        plus[3 + i] = preint[3 + i] + preint[6 + i] * dt + a_nav[i] * dt22;
+        plus[6 + i] = preint[6 + i] + a_nav[i] * dt;
     }
+}
+
+// The matrices of one integrateMeasurement step at the pre-integrated state `preint` (the state BEFORE the
+// sample): A (9x9), B, C (9x3, sensor-pose corrected), F (15x15) and G Q G^T (15x15).  Independent per sample.
+VS_HD void pim_step_mats(const DPim& pim, const double* preint, const DImuParams& P, const double* accM, const double* omegaM,
+                         double dt, double* A, double* B, double* C, double* F, double* G) {
+    double acc[3], om[3], D_acc_omega[9];
+    const bool hasArm = pim_correct(pim, P, accM, omegaM, acc, om, D_acc_omega);
+    double R[9], dexp[9], wt[3], wtH[9], invH[9];
+    dexp_apply_inv(preint, om, R, dexp, wt, wtH, invH);
+    const double dt22 = 0.5 * dt * dt;
     double na[3] = {-acc[0], -acc[1], -acc[2]}, Sa[9], RS[9], aH[9];
     skew3(na, Sa);
     mat3_mul(R, Sa, RS);

@@ -11,6 +11,12 @@ struct vslam_matcher {
     int device = 0;
     hipStream_t stream = nullptr;
     vslam::StageTimer timer;
+    hipEvent_t evUse = nullptr;      // recorded after every operation that reads the extractors' buffers
+    struct UseMark {                 // scope guard: records evUse on every exit path
+        vslam_matcher* m;
+        ~UseMark() { if (m->evUse) hipEventRecord(m->evUse, m->stream); }
+    };
+    vslam_status bind(vslam_extractor* l, int il, vslam_extractor* rr, int ir);
 
     // key views (either the extractors' buffers or the override uploads)
     const vslam_keypoint* d_kps[2] = {nullptr, nullptr};
@@ -45,7 +51,7 @@ struct vslam_matcher {
     int* d_matchedR = nullptr;
     int* d_projOut = nullptr;    // {nMatches}
     vslam_status ensure_proj_cap(int M);
-    vslam_status proj_enqueue(int M, float rad);
+    vslam_status proj_enqueue(int M, float rad, const int* Mdev = nullptr, const int* gate = nullptr, int gateMin = 0);
     vslam_status match_projection(const vslam_mappoint_view* mps, int M, float rad, int* mL, int* mR,
                                   int* matches, int* nMatches, long long* nCand);
 
@@ -58,14 +64,19 @@ struct vslam_matcher {
     double* d_poseIO = nullptr;      // 16 T_cw + report(8)
     int* d_poseOut = nullptr;        // nIn, nStereo, iterations, inner
     vslam_status ensure_pose_cap(int M);
-    vslam_status pose_enqueue(int M);
+    vslam_status pose_enqueue(int M, const int* Mdev = nullptr, const int* gate = nullptr, int gateMin = 0, int outSlot = 0);
+    // small device results in ONE block (one D2H copy per frame): poseIO [0,32) | imu io [32,48) | poseOut 2x4 ints
+    // at [48,52) | trCount 2 ints at [52,53); h_res is its pinned host mirror
+    double* d_res = nullptr; double* h_res = nullptr;
+    vslam_status ensure_res();
     double* d_imuBuf = nullptr;      // IMU scratch: samples, dts, DPim, information, state io
     int imuCap = 0;
     void* imuPim = nullptr; double* imuLam = nullptr; double* imuIo = nullptr;   // views into d_imuBuf
     double imuParams[64] = {0};      // DImuParams of the current frame
     double imuSi[15] = {0}, imuBiasPrev[6] = {0};
     vslam_status imu_setup(const vslam_imu_input* imu);
-    vslam_status pose_imu_enqueue(int M);
+    vslam_status pose_imu_enqueue(int M, const int* Mdev = nullptr, const int* gate = nullptr, int gateMin = 0, int outSlot = 0);
+    double* h_imuStage = nullptr; int imuStageCap = 0;     // pinned upload staging
     vslam_status estimate_pose_imu(vslam_pose_problem* prob, const vslam_imu_input* imu, vslam_imu_output* out,
                                    int* nIn, int* nStereo, vslam_lm_report* rep);
     vslam_status estimate_pose(vslam_pose_problem* prob, int* nIn, int* nStereo, vslam_lm_report* rep);
@@ -79,6 +90,7 @@ struct vslam_matcher {
     int* d_trAct = nullptr;          // [N] source index of each active map point of the current frame
     int* d_trCount = nullptr;        // {trN, actN}
     int actN = 0;
+    int trNub = 0;                   // host-side upper bound of trN (the real count stays on the device)
     vslam_status ensure_track_cap(int n);
     vslam_status track_init_map(const double* T_wc);
     vslam_status track_frame(const double* T_wc_pred, int frameNumber, double* T_cw_out, vslam_track_report* rep,
@@ -116,6 +128,9 @@ struct ProjArgs {
     float rad; float scalePyr[MAX_LEVELS];
     float xMult, yMult; int xGrids, yGrids;
     const int* rightIdxs; const int* leftIdxs;
+    // device-side control (tracking loop without host round trips): M is an upper bound (grid size) when
+    // Mdev is set, the kernel reads the real count; with a gate the kernel is a no-op unless *gate >= gateMin
+    const int* Mdev; const int* gate; int gateMin;
 };
 void launch_proj_candidates(hipStream_t s, const ProjArgs& A, const int* matches,
                             unsigned long long* topk, unsigned long long* stats);

@@ -24,6 +24,8 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_lm(PoseArgs A) {
     __shared__ double sError, sLambda, sNewErr, sCurErr;
     __shared__ int sPhase, sEval, sIter, sInner, sCnt[2];
     const int tid = threadIdx.x;
+    if (A.gate && *A.gate < A.gateMin) return;
+    if (A.Mdev) A.M = min(A.M, *A.Mdev);
     const int M = A.M;
 
     pose_build_factors(A);
@@ -222,23 +224,35 @@ vslam_status vslam_matcher::ensure_pose_cap(int M) {
     VS_HIP(hipMalloc(&d_flags, (size_t)poseCap * 8));
     VS_HIP(hipMalloc(&d_factors, (size_t)poseCap * 8 * sizeof(double)));
     if (!d_firstFail) VS_HIP(hipMalloc(&d_firstFail, (size_t)65536 * sizeof(int)));
-    if (!d_poseIO) VS_HIP(hipMalloc(&d_poseIO, 32 * sizeof(double)));
-    if (!d_poseOut) VS_HIP(hipMalloc(&d_poseOut, 8 * sizeof(int)));
+    VS_CHECK(ensure_res());
+    return VSLAM_OK;
+}
+
+vslam_status vslam_matcher::ensure_res() {
+    if (d_res) return VSLAM_OK;
+    VS_HIP(hipMalloc(&d_res, 64 * sizeof(double)));
+    VS_HIP(hipMemset(d_res, 0, 64 * sizeof(double)));
+    VS_HIP(hipHostMalloc(&h_res, 64 * sizeof(double), hipHostMallocDefault));
+    d_poseIO = d_res;
+    imuIo = d_res + 32;
+    d_poseOut = (int*)(d_res + 48);
+    d_trCount = (int*)(d_res + 52);
     return VSLAM_OK;
 }
 
 // device-resident form: d_points / d_flags / d_matches / d_poseIO already hold the inputs
-vslam_status vslam_matcher::pose_enqueue(int M) {
+vslam_status vslam_matcher::pose_enqueue(int M, const int* Mdev, const int* gate, int gateMin, int outSlot) {
     uint8_t* fl = d_flags;
     const size_t pc = (size_t)poseCap;
     PoseArgs A{};
+    A.Mdev = Mdev; A.gate = gate; A.gateMin = gateMin;
     A.M = M; A.points = d_points; A.inFrame = fl; A.inFrameR = fl + pc; A.mpOut = fl + 2 * pc; A.mpsOut = fl + 3 * pc;
     A.matches = d_matches; A.kpsL = d_kps[0]; A.kpsR = d_kps[1];
     A.closef = d_close; A.depth = d_depth; A.rightIdxs = d_rightIdxs; A.leftIdxs = d_leftIdxs;
     A.fx = rig.fx; A.fy = rig.fy; A.cx = rig.cx; A.cy = rig.cy; A.b = (double)rig.baseline;
     for (int l = 0; l < feL->nLevels; l++) A.invSigma[l] = feL->InvSigmaFactor[l];
     A.closeTh = rig.baseline * 40;
-    A.factors = d_factors; A.firstFail = d_firstFail; A.code = (int*)(fl + 4 * pc); A.poseIO = d_poseIO; A.out = d_poseOut;
+    A.factors = d_factors; A.firstFail = d_firstFail; A.code = (int*)(fl + 4 * pc); A.poseIO = d_poseIO; A.out = d_poseOut + 4 * outSlot;
     A.maxIterations = 100; A.relTol = 1e-5; A.absTol = 1e-5; A.thres = 7.815;
     int t = timer.begin("pose_lm");
     hipLaunchKernelGGL(k_pose_lm, dim3(1), dim3(POSE_NT), 0, stream, A);
@@ -254,6 +268,7 @@ vslam_status vslam_matcher::estimate_pose(vslam_pose_problem* prob, int* nIn, in
                   !prob->matches || !prob->mps_outliers)) { set_error("estimate_pose: null array"); return VSLAM_ERR_INVALID; }
     if (!stereoDone) { set_error("estimate_pose needs a completed stereo match"); return VSLAM_ERR_INVALID; }
     VS_HIP(hipSetDevice(device));
+    UseMark mark{this};
     VS_CHECK(refresh_keys());
     VS_CHECK(ensure_pose_cap(M));
     VS_CHECK(ensure_proj_cap(M));

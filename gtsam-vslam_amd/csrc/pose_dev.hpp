@@ -26,6 +26,7 @@ struct PoseArgs {
     int* out;             // nIn, nStereo, iterations, inner
     int maxIterations;
     double relTol, absTol, thres;
+    const int* Mdev; const int* gate; int gateMin;     // device-side control, as in ProjArgs
 };
 
 // whitened residual (and Jacobian rows wrt [omega, v]) of one factor at T (world <- camera)

@@ -12,12 +12,16 @@
 
 namespace vslam {
 
+constexpr int PIM_CHUNK = 12;        // samples whose step matrices are held in LDS at once (55 KB)
+
 __global__ __launch_bounds__(256) void k_imu_preintegrate(DImuParams P, const double* __restrict__ samples,
                                                           const double* __restrict__ dts, int n,
                                                           const double* __restrict__ biasHat, DPim* __restrict__ pimOut,
                                                           double* __restrict__ Lam) {
     __shared__ DPim pim;
-    __shared__ double A[81], B[27], C[27], F[225], G[225], FP[225], plus[9], t1[27], t2[27];
+    __shared__ double sA[PIM_CHUNK][81], sB[PIM_CHUNK][27], sC[PIM_CHUNK][27], sF[PIM_CHUNK][225], sG[PIM_CHUNK][225];
+    __shared__ double sState[PIM_CHUNK + 1][9];
+    __shared__ double FP[225], t1[27], t2[27];
     const int tid = threadIdx.x;
     if (tid == 0) {
         pim.deltaTij = 0;
@@ -27,60 +31,57 @@ __global__ __launch_bounds__(256) void k_imu_preintegrate(DImuParams P, const do
     }
     if (tid < 225) pim.cov[tid] = 0;
     __syncthreads();
-    for (int s = 0; s < n; s++) {
-        if (tid == 0) pim_step_small(pim, P, samples + 6 * s, samples + 6 * s + 3, dts[s], plus, A, B, C, F, G);
-        __syncthreads();
-        if (tid < 225) {
-            const int i = tid / 15, j = tid % 15;
-            double v = 0;
-            for (int k = 0; k < 15; k++) v += F[i * 15 + k] * pim.cov[k * 15 + j];
-            FP[tid] = v;
-        }
-        if (tid < 27) {
-            const int i = tid / 3, j = tid % 3;
-            double a = 0, b = 0;
-            for (int k = 0; k < 9; k++) { a += A[i * 9 + k] * pim.Hba[k * 3 + j]; b += A[i * 9 + k] * pim.Hbg[k * 3 + j]; }
-            t1[tid] = a - B[tid];
-            t2[tid] = b - C[tid];
-        }
-        __syncthreads();
-        if (tid < 225) {
-            const int i = tid / 15, j = tid % 15;
-            double v = 0;
-            for (int k = 0; k < 15; k++) v += FP[i * 15 + k] * F[j * 15 + k];
-            pim.cov[tid] = v + G[tid];
-        }
-        if (tid < 27) { pim.Hba[tid] = t1[tid]; pim.Hbg[tid] = t2[tid]; }
-        if (tid == 0) { pim.deltaTij += dts[s]; for (int i = 0; i < 9; i++) pim.preint[i] = plus[i]; }
-        __syncthreads();
-    }
-    // information matrix Lambda = cov^-1 (Cholesky + 15 column solves), one thread
-    if (tid == 0) {
-        double L[225];
-        for (int i = 0; i < 225; i++) L[i] = pim.cov[i];
-        bool ok = true;
-        for (int j = 0; j < 15 && ok; j++) {
-            double d = L[j * 15 + j];
-            for (int k = 0; k < j; k++) d -= L[j * 15 + k] * L[j * 15 + k];
-            if (!(d > 0)) { ok = false; break; }
-            d = sqrt(d);
-            L[j * 15 + j] = d;
-            for (int i = j + 1; i < 15; i++) {
-                double v = L[i * 15 + j];
-                for (int k = 0; k < j; k++) v -= L[i * 15 + k] * L[j * 15 + k];
-                L[i * 15 + j] = v / d;
+    for (int s0 = 0; s0 < n; s0 += PIM_CHUNK) {
+        const int nc = min(PIM_CHUNK, n - s0);
+        // (1) the state recursion theta/pos/vel: serial over samples, one thread
+        if (tid == 0) {
+            for (int i = 0; i < 9; i++) sState[0][i] = pim.preint[i];
+            for (int c = 0; c < nc; c++) {
+                const int s = s0 + c;
+                pim_step_state(pim, sState[c], P, samples + 6 * s, samples + 6 * s + 3, dts[s], sState[c + 1]);
             }
         }
-        for (int c = 0; c < 15; c++) {
-            double e[15];
-            for (int i = 0; i < 15; i++) e[i] = (i == c) ? 1.0 : 0.0;
-            if (ok) {
-                for (int i = 0; i < 15; i++) { double v = e[i]; for (int k = 0; k < i; k++) v -= L[i * 15 + k] * e[k]; e[i] = v / L[i * 15 + i]; }
-                for (int i = 14; i >= 0; i--) { double v = e[i]; for (int k = i + 1; k < 15; k++) v -= L[k * 15 + i] * e[k]; e[i] = v / L[i * 15 + i]; }
-            }
-            for (int i = 0; i < 15; i++) Lam[i * 15 + c] = ok ? e[i] : 0.0;
+        __syncthreads();
+        // (2) step matrices: one lane per sample
+        if (tid < nc) {
+            const int s = s0 + tid;
+            pim_step_mats(pim, sState[tid], P, samples + 6 * s, samples + 6 * s + 3, dts[s], sA[tid], sB[tid], sC[tid], sF[tid], sG[tid]);
         }
+        __syncthreads();
+        // (3) covariance / bias-Jacobian recursion: serial over samples, each step 225 + 27 threads
+        for (int c = 0; c < nc; c++) {
+            const double* F = sF[c];
+            const double* A = sA[c];
+            if (tid < 225) {
+                const int i = tid / 15, j = tid % 15;
+                double v = 0;
+                for (int k = 0; k < 15; k++) v += F[i * 15 + k] * pim.cov[k * 15 + j];
+                FP[tid] = v;
+            } else if (tid < 252) {
+                const int t = tid - 225, i = t / 3, j = t % 3;
+                double a = 0, b = 0;
+                for (int k = 0; k < 9; k++) { a += A[i * 9 + k] * pim.Hba[k * 3 + j]; b += A[i * 9 + k] * pim.Hbg[k * 3 + j]; }
+                t1[t] = a - sB[c][t];
+                t2[t] = b - sC[c][t];
+            }
+            __syncthreads();
+            if (tid < 225) {
+                const int i = tid / 15, j = tid % 15;
+                double v = 0;
+                for (int k = 0; k < 15; k++) v += FP[i * 15 + k] * F[j * 15 + k];
+                pim.cov[tid] = v + sG[c][tid];
+            } else if (tid < 252) {
+                const int t = tid - 225;
+                pim.Hba[t] = t1[t]; pim.Hbg[t] = t2[t];
+            }
+            if (tid == 255) pim.deltaTij += dts[s0 + c];
+            __syncthreads();
+        }
+        if (tid < 9) pim.preint[tid] = sState[nc][tid];
+        __syncthreads();
     }
+    // information matrix Lambda = cov^-1 (Cholesky + 15 column solves), one wave
+    if (tid < 64) wave_spd_inverse<15>(pim.cov, FP, Lam);
     for (int i = tid; i < (int)(sizeof(DPim) / sizeof(double)); i += 256) ((double*)pimOut)[i] = ((double*)&pim)[i];
 }
 
@@ -109,7 +110,10 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I
     __shared__ double sJ[225], sLJ[225], sH[225], sLam[225], sR15[15], sLr[15], sG[15], sDelta[15], sRp[6], sJp[36];
     __shared__ double sError, sLambda, sNewErr, sCurErr, sLin, sNV;
     __shared__ int sPhase, sEval, sIter, sInner, sCnt[2];
-    const int tid = threadIdx.x, M = A.M;
+    const int tid = threadIdx.x;
+    if (A.gate && *A.gate < A.gateMin) return;
+    if (A.Mdev) A.M = min(A.M, *A.Mdev);
+    const int M = A.M;
 #ifdef VSLAM_POSE_STAMPS
     long long ps_t = clock64();
 #endif
@@ -334,15 +338,25 @@ vslam_status vslam_matcher::imu_setup(const vslam_imu_input* imu) {
     const int n = imu->n_samples;
     if (n > 0 && (!imu->acceleration || !imu->angular_velocity || !imu->timestamps_ns)) { set_error("IMU input: null array"); return VSLAM_ERR_INVALID; }
     if (n <= 0 || imu->hz <= 0) { set_error("IMU input: empty bucket"); return VSLAM_ERR_INVALID; }
-    // scratch layout: samples (6n) | dts (n) | biasHat (6) | DPim | Lambda (225) | io (16)
+    // scratch layout: samples (6n) | dts (n) | biasHat (6) | DPim | Lambda (225); the io block lives in d_res
     const size_t pimD = sizeof(DPim) / sizeof(double);
-    const size_t need = (size_t)7 * n + 6 + pimD + 225 + 16;
+    const size_t need = (size_t)7 * n + 6 + pimD + 225;
+    VS_CHECK(ensure_res());
     if ((int)need > imuCap) {
+        VS_HIP(hipStreamSynchronize(stream));
         hipFree(d_imuBuf);
         imuCap = (int)need + 1024;
         VS_HIP(hipMalloc(&d_imuBuf, (size_t)imuCap * sizeof(double)));
     }
-    std::vector<double> h((size_t)7 * n + 6);
+    const int hn = 7 * n + 6;
+    if (hn > imuStageCap) {
+        VS_HIP(hipStreamSynchronize(stream));
+        if (h_imuStage) hipHostFree(h_imuStage);
+        imuStageCap = hn + 256;
+        VS_HIP(hipHostMalloc(&h_imuStage, (size_t)imuStageCap * sizeof(double), hipHostMallocDefault));
+    }
+    // the previous frame's upload has been consumed: every tracking call ends with a stream synchronisation
+    double* h = h_imuStage;
     double dt = 1.0 / imu->hz;                                  // src/FeatureTracker.cpp:337
     for (int i = 0; i < n; i++) {
         for (int k = 0; k < 3; k++) { h[6 * (size_t)i + k] = imu->acceleration[3 * i + k]; h[6 * (size_t)i + 3 + k] = imu->angular_velocity[3 * i + k]; }
@@ -355,9 +369,7 @@ vslam_status vslam_matcher::imu_setup(const vslam_imu_input* imu) {
     double* d_bias = d_dts + n;
     imuPim = (void*)(d_bias + 6);
     imuLam = (double*)imuPim + pimD;
-    imuIo = imuLam + 225;
-    VS_HIP(hipMemcpyAsync(d_samples, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, stream));
-    VS_HIP(hipStreamSynchronize(stream));      // h is a stack-lifetime staging buffer
+    VS_HIP(hipMemcpyAsync(d_samples, h, (size_t)hn * sizeof(double), hipMemcpyHostToDevice, stream));
     DImuParams P{};
     for (int k = 0; k < 3; k++) P.gravity[k] = imu->gravity[k];
     P.gyroCov = imu->gyro_noise_density * imu->gyro_noise_density;        // pow(density, 2) (:318-321)
@@ -379,17 +391,18 @@ vslam_status vslam_matcher::imu_setup(const vslam_imu_input* imu) {
 }
 
 // device-resident form of the IMU solve (inputs as for pose_enqueue, plus a completed imu_setup)
-vslam_status vslam_matcher::pose_imu_enqueue(int M) {
+vslam_status vslam_matcher::pose_imu_enqueue(int M, const int* Mdev, const int* gate, int gateMin, int outSlot) {
     uint8_t* fl = d_flags;
     const size_t pc = (size_t)poseCap;
     PoseArgs A{};
+    A.Mdev = Mdev; A.gate = gate; A.gateMin = gateMin;
     A.M = M; A.points = d_points; A.inFrame = fl; A.inFrameR = fl + pc; A.mpOut = fl + 2 * pc; A.mpsOut = fl + 3 * pc;
     A.matches = d_matches; A.kpsL = d_kps[0]; A.kpsR = d_kps[1];
     A.closef = d_close; A.depth = d_depth; A.rightIdxs = d_rightIdxs; A.leftIdxs = d_leftIdxs;
     A.fx = rig.fx; A.fy = rig.fy; A.cx = rig.cx; A.cy = rig.cy; A.b = (double)rig.baseline;
     for (int l = 0; l < feL->nLevels; l++) A.invSigma[l] = feL->InvSigmaFactor[l];
     A.closeTh = rig.baseline * 40;
-    A.factors = d_factors; A.firstFail = d_firstFail; A.code = (int*)(fl + 4 * pc); A.poseIO = d_poseIO; A.out = d_poseOut;
+    A.factors = d_factors; A.firstFail = d_firstFail; A.code = (int*)(fl + 4 * pc); A.poseIO = d_poseIO; A.out = d_poseOut + 4 * outSlot;
     A.maxIterations = 100; A.relTol = 1e-5; A.absTol = 1e-5; A.thres = 7.815;
     ImuLmArgs I{};
     I.pim = (const DPim*)imuPim; I.Lam = imuLam; I.io = imuIo;
@@ -424,6 +437,7 @@ vslam_status vslam_matcher::estimate_pose_imu(vslam_pose_problem* prob, const vs
                   !prob->mps_outliers)) { set_error("estimate_pose_imu: null array"); return VSLAM_ERR_INVALID; }
     if (!stereoDone) { set_error("estimate_pose_imu needs a completed stereo match"); return VSLAM_ERR_INVALID; }
     VS_HIP(hipSetDevice(device));
+    UseMark mark{this};
     VS_CHECK(refresh_keys());
     VS_CHECK(ensure_pose_cap(M));
     VS_CHECK(ensure_proj_cap(M));

@@ -115,6 +115,8 @@ __global__ __launch_bounds__(256) void k_proj_candidates(ProjArgs A, const int* 
                                                          unsigned long long* __restrict__ stats) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int job = blockIdx.x * 4 + wave;      // job = mp * 2 + side
+    if (A.gate && *A.gate < A.gateMin) return;
+    if (A.Mdev) A.M = min(A.M, *A.Mdev);
     if (job >= 2 * A.M) return;
     const int i = job >> 1, side = job & 1;
     unsigned long long out[PROJ_K];
@@ -197,6 +199,8 @@ __global__ __launch_bounds__(256) void k_proj_resolve(ProjArgs A, const unsigned
     int* spair = li + A.n[1];                                                      // [PROJ_SUPER][2]
     unsigned long long* skeys = (unsigned long long*)(((uintptr_t)(spair + 2 * PROJ_SUPER) + 15) & ~(uintptr_t)15);   // [PROJ_SUPER][16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (A.gate && *A.gate < A.gateMin) return;
+    if (A.Mdev) A.M = min(A.M, *A.Mdev);
     for (int k = tid; k < A.n[0]; k += 256) { cl[k] = matchedL[k]; ri[k] = A.rightIdxs[k]; }
     for (int k = tid; k < A.n[1]; k += 256) { cr[k] = matchedR[k]; li[k] = A.leftIdxs[k]; }
     int nMatches = 0;
@@ -379,8 +383,9 @@ vslam_status vslam_matcher::ensure_proj_cap(int M) {
 }
 
 // device-resident form: d_mpv / d_matches / d_matchedL / d_matchedR already hold the inputs
-vslam_status vslam_matcher::proj_enqueue(int M, float rad) {
+vslam_status vslam_matcher::proj_enqueue(int M, float rad, const int* Mdev, const int* gate, int gateMin) {
     ProjArgs A{};
+    A.Mdev = Mdev; A.gate = gate; A.gateMin = gateMin;
     for (int s = 0; s < 2; s++) { A.kps[s] = d_kps[s]; A.desc[s] = d_desc[s]; A.n[s] = nKeys[s]; }
     A.mpv = d_mpv; A.M = M; A.rad = rad;
     for (int l = 0; l < feL->nLevels; l++) A.scalePyr[l] = feL->scalePyramid[l];
@@ -409,6 +414,7 @@ vslam_status vslam_matcher::match_projection(const vslam_mappoint_view* mps, int
     if (M < 0 || (M > 0 && (!mps || !matches)) || !mL || !mR) { set_error("match_projection: bad argument"); return VSLAM_ERR_INVALID; }
     if (!stereoDone) { set_error("match_projection needs a completed stereo match"); return VSLAM_ERR_INVALID; }
     VS_HIP(hipSetDevice(device));
+    UseMark mark{this};
     VS_CHECK(refresh_keys());
     VS_CHECK(ensure_proj_cap(M));
     const int nL = nKeys[0], nR = nKeys[1];

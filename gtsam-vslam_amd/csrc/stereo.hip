@@ -262,16 +262,30 @@ void launch_stereo_finalize(hipStream_t s, int nL, int nR, const int* mBest, con
 
 using namespace vslam;
 
-vslam_status vslam_matcher::init(const vslam_rig* r, vslam_extractor* l, int il, vslam_extractor* rr, int ir) {
-    if (!r || !l || !rr || il < 0 || il >= l->nimg || ir < 0 || ir >= rr->nimg || l->device != rr->device ||
+// (re)bind the matcher to a pair of extractors: the views follow the new pair from the next call on
+vslam_status vslam_matcher::bind(vslam_extractor* l, int il, vslam_extractor* rr, int ir) {
+    if (!l || !rr || il < 0 || il >= l->nimg || ir < 0 || ir >= rr->nimg || l->device != rr->device ||
         l->nLevels != rr->nLevels || l->width != rr->width || l->height != rr->height ||
-        r->width != l->width || r->height != l->height) {
-        set_error("vslam_matcher_create: invalid arguments");
+        rig.width != l->width || rig.height != l->height || (stream && l->device != device) ||
+        (feL && (l->nLevels != feL->nLevels || l->prm.scale != feL->prm.scale))) {
+        set_error("matcher: extractor pair does not fit the rig / the previous pair");
         return VSLAM_ERR_INVALID;
     }
-    rig = *r; feL = l; feR = rr; imgL = il; imgR = ir; device = l->device;
+    feL = l; feR = rr; imgL = il; imgR = ir;
+    if (evUse) { feL->add_consumer(evUse); feR->add_consumer(evUse); }
+    stereoDone = false;
+    return VSLAM_OK;
+}
+
+vslam_status vslam_matcher::init(const vslam_rig* r, vslam_extractor* l, int il, vslam_extractor* rr, int ir) {
+    if (!r) { set_error("vslam_matcher_create: invalid arguments"); return VSLAM_ERR_INVALID; }
+    rig = *r;
+    VS_CHECK(bind(l, il, rr, ir));
+    device = l->device;
     VS_HIP(hipSetDevice(device));
     VS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    VS_HIP(hipEventCreateWithFlags(&evUse, hipEventDisableTiming));
+    feL->add_consumer(evUse); feR->add_consumer(evUse);
     timer.stream = stream;
     timer.multi = true;
     VS_HIP(hipMalloc(&d_stats, 4 * sizeof(unsigned long long)));
@@ -297,13 +311,17 @@ vslam_status vslam_matcher::ensure_cap(int n) {
 
 void vslam_matcher::release() {
     if (stream) hipStreamSynchronize(stream);
+    // NOTE: extractors this matcher was ever bound to must still be alive here (destroy matchers first)
+    if (evUse) { if (feL) feL->remove_consumer(evUse); if (feR) feR->remove_consumer(evUse); hipEventDestroy(evUse); evUse = nullptr; }
     timer.destroy();
     hipFree(d_mBest); hipFree(d_mDepth); hipFree(d_mSad); hipFree(d_rightIdxs); hipFree(d_leftIdxs);
     hipFree(d_depth); hipFree(d_close); hipFree(d_stats);
     for (int s = 0; s < 2; s++) { hipFree(d_okps[s]); hipFree(d_odesc[s]); }
-    hipFree(d_trXyz); hipFree(d_trDesc); hipFree(d_trMsd); hipFree(d_trOutlier); hipFree(d_trAct); hipFree(d_trCount);
+    hipFree(d_trXyz); hipFree(d_trDesc); hipFree(d_trMsd); hipFree(d_trOutlier); hipFree(d_trAct);
     hipFree(d_imuBuf);
-    hipFree(d_points); hipFree(d_flags); hipFree(d_factors); hipFree(d_firstFail); hipFree(d_poseIO); hipFree(d_poseOut);
+    hipFree(d_points); hipFree(d_flags); hipFree(d_factors); hipFree(d_firstFail); hipFree(d_res);
+    if (h_res) hipHostFree(h_res);
+    if (h_imuStage) hipHostFree(h_imuStage);
     hipFree(d_mpv); hipFree(d_topk); hipFree(d_matches); hipFree(d_tent); hipFree(d_need); hipFree(d_matchedL); hipFree(d_matchedR); hipFree(d_projOut);
     if (stream) hipStreamDestroy(stream);
     stream = nullptr;
@@ -312,6 +330,9 @@ void vslam_matcher::release() {
 vslam_status vslam_matcher::refresh_keys() {
     vslam_extractor* fe[2] = {feL, feR};
     const int img[2] = {imgL, imgR};
+    // order this stream after the extractors' last run (keys, descriptors and pyramids complete)
+    if (feL->evDone) hipStreamWaitEvent(stream, feL->evDone, 0);
+    if (feR != feL && feR->evDone) hipStreamWaitEvent(stream, feR->evDone, 0);
     for (int s = 0; s < 2; s++) {
         if (overridden[s]) continue;
         if (!fe[s]->ran) { set_error("matcher: extractor has not run"); return VSLAM_ERR_INVALID; }
@@ -324,6 +345,7 @@ vslam_status vslam_matcher::refresh_keys() {
 
 vslam_status vslam_matcher::stereo_match() {
     VS_HIP(hipSetDevice(device));
+    UseMark mark{this};
     VS_CHECK(refresh_keys());
     StereoArgs A{};
     A.kpsL = d_kps[0]; A.descL = d_desc[0]; A.nL = nKeys[0];
@@ -348,8 +370,7 @@ vslam_status vslam_matcher::stereo_match() {
                            d_leftIdxs, d_depth, d_close);
     timer.end(t);
     VS_HIP(hipGetLastError());
-    VS_HIP(hipStreamSynchronize(stream));
-    stereoDone = true;
+    stereoDone = true;           // enqueued: every consumer runs on this stream (vslam_stereo_fetch synchronises)
     return VSLAM_OK;
 }
 
@@ -394,6 +415,12 @@ vslam_status vslam_matcher_set_keys(vslam_matcher* m, int32_t right, const vslam
     return m->ensure_cap(n);
 }
 
+vslam_status vslam_matcher_bind_extractors(vslam_matcher* m, vslam_extractor* fe_left, int32_t left_image,
+                                           vslam_extractor* fe_right, int32_t right_image) {
+    if (!m) return VSLAM_ERR_INVALID;
+    return m->bind(fe_left, left_image, fe_right, right_image);
+}
+
 vslam_status vslam_matcher_use_extractor_keys(vslam_matcher* m) {
     if (!m) return VSLAM_ERR_INVALID;
     m->overridden[0] = m->overridden[1] = false;
@@ -426,10 +453,17 @@ vslam_status vslam_matcher_timings(const vslam_matcher* m, const char** names, f
     if (!m || !n_out) return VSLAM_ERR_INVALID;
     const char* nm[64];
     float tv[64];
+    hipStreamSynchronize(m->stream);
     int n = m->timer.read(nm, tv, cap < 64 ? cap : 64);
     const_cast<vslam_matcher*>(m)->timer.reset();   // read-and-reset: the next read reports only newer launches
     for (int i = 0; i < n; i++) { if (names) names[i] = nm[i]; if (ms) ms[i] = tv[i]; }
     *n_out = n;
+    return VSLAM_OK;
+}
+
+vslam_status vslam_matcher_set_timing(vslam_matcher* m, int32_t on) {
+    if (!m) return VSLAM_ERR_INVALID;
+    m->timer.enabled = on != 0;
     return VSLAM_OK;
 }
 

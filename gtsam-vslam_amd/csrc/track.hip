@@ -94,9 +94,16 @@ __global__ __launch_bounds__(1024) void k_track_predict(int N, const double* __r
                                                         TrackGeom G, vslam_mappoint_view* __restrict__ mpv,
                                                         double* __restrict__ points, uint8_t* __restrict__ flags,
                                                         size_t flagStride, int* __restrict__ matches,
-                                                        int* __restrict__ act, int* __restrict__ count) {
+                                                        int* __restrict__ act, int* __restrict__ count,
+                                                        int* __restrict__ matchedL, int nL,
+                                                        int* __restrict__ matchedR, int nR,
+                                                        double* __restrict__ poseIO) {
     __shared__ int wsum[16];
     int run = 0;
+    N = min(N, count[0]);          // N is the host's upper bound; the map size stays on the device
+    for (int k = threadIdx.x; k < nL; k += 1024) matchedL[k] = -1;
+    for (int k = threadIdx.x; k < nR; k += 1024) matchedR[k] = -1;
+    if (threadIdx.x == 0) pose_to_rm16(Tcw, poseIO);      // predNPoseInv: initial estimPose
     for (int base = 0; base < N; base += 1024) {
         const int i = base + threadIdx.x;
         bool keep = false;
@@ -145,7 +152,8 @@ __global__ __launch_bounds__(256) void k_track_reset(int M, int* matches, uint8_
 }
 
 // PredictMPsPosition with the estimated pose (src/FeatureTracker.cpp:969-1014)
-__global__ __launch_bounds__(256) void k_track_repredict(int M, const double* __restrict__ points,
+__global__ __launch_bounds__(256) void k_track_repredict(int M, const int* __restrict__ Mdev, const int* __restrict__ gate,
+                                                         int gateMin, const double* __restrict__ points,
                                                          const float* __restrict__ msd,
                                                          const int* __restrict__ act, const double* __restrict__ poseIO,
                                                          TrackGeom G, vslam_mappoint_view* __restrict__ mpv,
@@ -153,6 +161,8 @@ __global__ __launch_bounds__(256) void k_track_repredict(int M, const double* __
                                                          int* __restrict__ matches, int* __restrict__ matchedL,
                                                          int* __restrict__ matchedR) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (gate && *gate < gateMin) return;
+    if (Mdev) M = min(M, *Mdev);
     if (i >= M) return;
     DPose Tcw;
     pose_from_rm16(poseIO, Tcw);
@@ -197,7 +207,7 @@ vslam_status vslam_matcher::ensure_track_cap(int n) {
         d_trXyz = nx; d_trDesc = nd; d_trMsd = nm; d_trOutlier = no; d_trAct = na;
         trCap = cap;
     }
-    if (!d_trCount) { VS_HIP(hipMalloc(&d_trCount, 4 * sizeof(int))); VS_HIP(hipMemset(d_trCount, 0, 4 * sizeof(int))); }
+    VS_CHECK(ensure_res());
     return VSLAM_OK;
 }
 
@@ -205,6 +215,7 @@ vslam_status vslam_matcher::track_init_map(const double* T_wc) {
     if (!T_wc) return VSLAM_ERR_INVALID;
     if (!stereoDone) { set_error("tracker_init_map needs a completed stereo match"); return VSLAM_ERR_INVALID; }
     VS_HIP(hipSetDevice(device));
+    UseMark mark{this};
     VS_CHECK(refresh_keys());
     const int nL = nKeys[0];
     VS_CHECK(ensure_track_cap(nL));
@@ -215,8 +226,8 @@ vslam_status vslam_matcher::track_init_map(const double* T_wc) {
                        rig.cx, rig.cy, feL->T, d_trXyz, d_trDesc, d_trMsd, d_trOutlier, trCap, d_trCount);
     timer.end(t);
     VS_HIP(hipGetLastError());
-    VS_HIP(hipMemcpyAsync(&trN, d_trCount, sizeof(int), hipMemcpyDeviceToHost, stream));
-    VS_HIP(hipStreamSynchronize(stream));
+    trNub = std::min(nL, trCap);        // the exact count stays in d_trCount[0]; no host round trip
+    trN = -1;
     return VSLAM_OK;
 }
 
@@ -225,10 +236,12 @@ vslam_status vslam_matcher::track_frame(const double* T_wc_pred, int frameNumber
     if (!T_wc_pred || !T_cw_out) return VSLAM_ERR_INVALID;
     if (!stereoDone) { set_error("tracker_track needs a completed stereo match of the new frame"); return VSLAM_ERR_INVALID; }
     VS_HIP(hipSetDevice(device));
+    UseMark mark{this};
     VS_CHECK(refresh_keys());
-    VS_CHECK(ensure_track_cap(std::max(trN, 1)));
-    VS_CHECK(ensure_pose_cap(std::max(trN, 1)));
-    VS_CHECK(ensure_proj_cap(std::max(trN, 1)));
+    const int Nub = std::max(trNub, 1);
+    VS_CHECK(ensure_track_cap(Nub));
+    VS_CHECK(ensure_pose_cap(Nub));
+    VS_CHECK(ensure_proj_cap(Nub));
     if (imu) VS_CHECK(imu_setup(imu));      // currentIMUData: every pose solve of this frame uses the IMU branch
     const int nL = nKeys[0], nR = nKeys[1];
     DPose Twc, Tcw;
@@ -240,65 +253,79 @@ vslam_status vslam_matcher::track_frame(const double* T_wc_pred, int frameNumber
                 (double)(float)std::log((double)feL->prm.scale), feL->nLevels};   // KeyFrame::logScale is a float
     uint8_t* fl = d_flags;
     const size_t pc = (size_t)poseCap;
+    const int minInliers = 50;
+    const int* Mdev = d_trCount + 1;
+    const int* gate = d_poseOut;        // inlier count of the first round
+    int* h_out = (int*)(h_res + 48);    // host mirror: poseOut slots 0 / 1
+    int* h_cnt = (int*)(h_res + 52);
 
+    // The whole frame is enqueued in one go: predict, first matching round + pose solve, and - gated on the
+    // device by the first round's inlier count - the refinement pass.  The host looks at the result once; only
+    // when the first round fails (fewer than minInliers) does it step through the reference's retry rule.
     int t = timer.begin("track_predict");
-    hipLaunchKernelGGL(k_track_predict, dim3(1), dim3(1024), 0, stream, trN, d_trXyz, d_trDesc, d_trMsd, d_trOutlier, Tcw, G,
-                       d_mpv, d_points, fl, pc, d_matches, d_trAct, d_trCount);
-    if (nL) hipLaunchKernelGGL(k_fill_int, dim3((nL + 255) / 256), dim3(256), 0, stream, d_matchedL, nL, -1);
-    if (nR) hipLaunchKernelGGL(k_fill_int, dim3((nR + 255) / 256), dim3(256), 0, stream, d_matchedR, nR, -1);
+    hipLaunchKernelGGL(k_track_predict, dim3(1), dim3(1024), 0, stream, trNub, d_trXyz, d_trDesc, d_trMsd, d_trOutlier, Tcw, G,
+                       d_mpv, d_points, fl, pc, d_matches, d_trAct, d_trCount, d_matchedL, nL, d_matchedR, nR, d_poseIO);
     timer.end(t);
     VS_HIP(hipGetLastError());
-    int cnt[2] = {0, 0};
-    VS_HIP(hipMemcpyAsync(cnt, d_trCount, sizeof(cnt), hipMemcpyDeviceToHost, stream));
-    VS_HIP(hipMemcpyAsync(d_poseIO, predInv, sizeof(predInv), hipMemcpyHostToDevice, stream));
-    VS_HIP(hipStreamSynchronize(stream));
-    const int M = cnt[1];
-    actN = M;
 
-    // retry loop (src/FeatureTracker.cpp:1184-1233)
-    const int minInliers = 50;
     float rad = frameNumber == 1 ? 120.f : 10.f;
-    int nIn = -1, nSt = -1, prevIn = -1, rounds = 0, lmIters = 0;
-    float prevrad = rad;
-    bool toBreak = false;
-    int out[4] = {0, 0, 0, 0};
-    while (nIn < minInliers) {
-        rounds++;
-        VS_CHECK(proj_enqueue(M, rad));
-        VS_CHECK(imu ? pose_imu_enqueue(M) : pose_enqueue(M));
-        VS_HIP(hipMemcpyAsync(out, d_poseOut, sizeof(out), hipMemcpyDeviceToHost, stream));
+    auto solve = [&](const int* g, int slot) { return imu ? pose_imu_enqueue(Nub, Mdev, g, minInliers, slot) : pose_enqueue(Nub, Mdev, g, minInliers, slot); };
+    auto refine = [&](const int* g) -> vslam_status {
+        // refine with the estimated pose (:1236-1241)
+        int tt = timer.begin("track_repredict");
+        hipLaunchKernelGGL(k_track_repredict, dim3((Nub + 255) / 256), dim3(256), 0, stream, Nub, Mdev, g, minInliers, d_points,
+                           d_trMsd, d_trAct, d_poseIO, G, d_mpv, fl, pc, d_matches, d_matchedL, d_matchedR);
+        timer.end(tt);
+        VS_CHECK(proj_enqueue(Nub, 4.f, Mdev, g, minInliers));
+        VS_CHECK(solve(g, 1));
+        return VSLAM_OK;
+    };
+    auto fetch = [&]() -> vslam_status {
+        VS_HIP(hipMemcpyAsync(h_res, d_res, 64 * sizeof(double), hipMemcpyDeviceToHost, stream));
         VS_HIP(hipStreamSynchronize(stream));
-        nIn = out[0]; nSt = out[1]; lmIters += out[2];
-        if (nIn < minInliers && !toBreak) {
+        return VSLAM_OK;
+    };
+    VS_CHECK(proj_enqueue(Nub, rad, Mdev));
+    VS_CHECK(solve(nullptr, 0));
+    VS_CHECK(refine(gate));
+    VS_CHECK(fetch());
+    const int M = h_cnt[1];
+    trN = h_cnt[0];
+    actN = M;
+    int rounds = 1, nIn = h_out[0], lmIters = h_out[2];
+
+    if (nIn < minInliers) {
+        // retry loop (src/FeatureTracker.cpp:1184-1233); the gated refinement above did nothing
+        int prevIn = -1;
+        float prevrad = rad;
+        bool toBreak = false;
+        for (;;) {
+            // tail of the failed round: reset, widen or fall back
+            if (toBreak) break;
             VS_HIP(hipMemcpyAsync(d_poseIO, predInv, sizeof(predInv), hipMemcpyHostToDevice, stream));
             if (nL) hipLaunchKernelGGL(k_fill_int, dim3((nL + 255) / 256), dim3(256), 0, stream, d_matchedL, nL, -1);
             if (nR) hipLaunchKernelGGL(k_fill_int, dim3((nR + 255) / 256), dim3(256), 0, stream, d_matchedR, nR, -1);
             if (M) hipLaunchKernelGGL(k_track_reset, dim3((M + 255) / 256), dim3(256), 0, stream, M, d_matches, fl + 3 * pc);
             if (nIn < prevIn) { rad = prevrad; toBreak = true; }
             else { prevrad = rad; prevIn = nIn; rad += 30.0f; }
-        } else {
-            break;
+            if (rounds > 3 && !toBreak) toBreak = true;
+            // next round
+            rounds++;
+            VS_CHECK(proj_enqueue(Nub, rad, Mdev));
+            VS_CHECK(solve(nullptr, 0));
+            VS_CHECK(fetch());
+            nIn = h_out[0]; lmIters += h_out[2];
+            if (nIn >= minInliers) break;
         }
-        if (rounds > 3 && !toBreak) toBreak = true;
+        VS_CHECK(refine(nullptr));
+        VS_CHECK(fetch());
     }
-    // refine with the estimated pose (:1236-1241)
-    t = timer.begin("track_repredict");
-    if (M) hipLaunchKernelGGL(k_track_repredict, dim3((M + 255) / 256), dim3(256), 0, stream, M, d_points, d_trMsd, d_trAct,
-                              d_poseIO, G, d_mpv, fl, pc, d_matches, d_matchedL, d_matchedR);
-    timer.end(t);
     const float lastRad = rad;
-    VS_CHECK(proj_enqueue(M, 4.f));
-    VS_CHECK(imu ? pose_imu_enqueue(M) : pose_enqueue(M));
-    double io[16], vb[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (imu) VS_HIP(hipMemcpyAsync(vb, imuIo, sizeof(vb), hipMemcpyDeviceToHost, stream));
-    VS_HIP(hipMemcpyAsync(out, d_poseOut, sizeof(out), hipMemcpyDeviceToHost, stream));
-    VS_HIP(hipMemcpyAsync(io, d_poseIO, sizeof(io), hipMemcpyDeviceToHost, stream));
-    VS_HIP(hipStreamSynchronize(stream));
-    memcpy(T_cw_out, io, sizeof(io));
-    if (imu && imuOut) { for (int k = 0; k < 3; k++) imuOut->velocity[k] = vb[k]; for (int k = 0; k < 6; k++) imuOut->bias[k] = vb[3 + k]; }
+    memcpy(T_cw_out, h_res, 16 * sizeof(double));
+    if (imu && imuOut) { for (int k = 0; k < 3; k++) imuOut->velocity[k] = h_res[32 + k]; for (int k = 0; k < 6; k++) imuOut->bias[k] = h_res[35 + k]; }
     if (rep) {
-        rep->n_map_points = trN; rep->n_active = M; rep->rounds = rounds; rep->n_inliers = out[0]; rep->n_stereo = out[1];
-        rep->lm_iterations = lmIters + out[2]; rep->last_radius = lastRad;
+        rep->n_map_points = trN; rep->n_active = M; rep->rounds = rounds; rep->n_inliers = h_out[4]; rep->n_stereo = h_out[5];
+        rep->lm_iterations = lmIters + h_out[6]; rep->last_radius = lastRad;
     }
     return VSLAM_OK;
 }

@@ -137,6 +137,9 @@ class Extractor:
         _chk(self.L.vslam_extractor_timings(self.h, names, ms, 32, C.byref(n)))
         return {names[i].decode(): float(ms[i]) for i in range(n.value)}
 
+    def set_timing(self, on):
+        _chk(self.L.vslam_extractor_set_timing(self.h, int(bool(on))))
+
 
 class Rig(C.Structure):
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
@@ -195,6 +198,13 @@ class Matcher:
         n = C.c_int32()
         _chk(self.L.vslam_matcher_timings(self.h, names, ms, 32, C.byref(n)))
         return {names[i].decode(): float(ms[i]) for i in range(n.value)}
+
+    def set_timing(self, on):
+        _chk(self.L.vslam_matcher_set_timing(self.h, int(bool(on))))
+
+    def bind_extractors(self, feL, iL, feR, iR):
+        _chk(self.L.vslam_matcher_bind_extractors(self.h, feL.h, iL, feR.h, iR))
+        self.fe = (feL, feR)      # keep them alive
 
 
 MPV_DTYPE = np.dtype([("desc", "u1", 32), ("predLx", "<f4"), ("predLy", "<f4"), ("predRx", "<f4"),
@@ -320,6 +330,10 @@ def local_ba_timings():
     n = C.c_int32()
     _chk(lib().vslam_local_ba_timings(names, ms, 32, C.byref(n)))
     return {names[i].decode(): float(ms[i]) for i in range(n.value)}
+
+
+def local_ba_set_timing(on):
+    _chk(lib().vslam_local_ba_set_timing(int(bool(on))))
 
 
 class TrackReport(C.Structure):

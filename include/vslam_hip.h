@@ -108,6 +108,9 @@ vslam_status vslam_extractor_candidates(vslam_extractor* ex, int32_t image_index
  * extractor's stream).  names/ms hold up to cap entries; n_out = entries written. */
 vslam_status vslam_extractor_timings(const vslam_extractor* ex, const char** names, float* ms,
                                      int32_t cap, int32_t* n_out);
+/* per-kernel HIP-event timing on (default) / off for this extractor's following runs; off removes the
+ * two event records per launch from the launch-bound path */
+vslam_status vslam_extractor_set_timing(vslam_extractor* ex, int32_t on);
 
 
 /* ---------------------------------------------------------------------------
@@ -137,6 +140,12 @@ void vslam_matcher_destroy(vslam_matcher* m);
 vslam_status vslam_matcher_set_keys(vslam_matcher* m, int32_t right, const vslam_keypoint* kps,
                                     const uint8_t* desc, int32_t n);
 vslam_status vslam_matcher_use_extractor_keys(vslam_matcher* m);
+/* Re-bind the matcher to another extractor pair of the same geometry (frame-level pipelining: extractor
+ * pair B works on frame n+1 on its own stream while the matcher / tracker consumes pair A's frame n).
+ * The matcher's map state is kept.  Ordering between the extractors' streams and the matcher's stream is
+ * by HIP events, in both directions; matchers must be destroyed before the extractors they were bound to. */
+vslam_status vslam_matcher_bind_extractors(vslam_matcher* m, vslam_extractor* fe_left, int32_t left_image,
+                                           vslam_extractor* fe_right, int32_t right_image);
 
 /* findStereoMatchesORB2R (include/FeatureMatcher.h:54, src/FeatureMatcher.cpp:528-708):
  * fills TrackedKeys::rightIdxs[nL], leftIdxs[nR], estimatedDepth[nL], close[nL] (device-resident;
@@ -291,6 +300,8 @@ vslam_status vslam_local_ba(const vslam_ba_problem* problem, vslam_ba_result* re
                             const vslam_comm* comm);
 /* device time per kernel group of the last vslam_local_ba call on this thread */
 vslam_status vslam_local_ba_timings(const char** names, float* ms, int32_t cap, int32_t* n_out);
+/* event timing on (default) / off for the following vslam_local_ba calls of the calling thread */
+vslam_status vslam_local_ba_set_timing(int32_t on);
 
 /* ---------------------------------------------------------------------------
  * Per-frame tracking loop on device-resident state — the stereo path of
@@ -330,6 +341,7 @@ vslam_status vslam_tracker_fetch(vslam_matcher* m, int32_t* matches, uint8_t* mp
 /* device time per kernel group since the previous call (summed over launches; read-and-reset) */
 vslam_status vslam_matcher_timings(const vslam_matcher* m, const char** names, float* ms,
                                    int32_t cap, int32_t* n_out);
+vslam_status vslam_matcher_set_timing(vslam_matcher* m, int32_t on);
 
 #ifdef __cplusplus
 }
