@@ -51,7 +51,8 @@ struct BaDev {
     double fx, fy, cx, cy, b;
 };
 
-constexpr int BA_SCHUR_WAVES = 4;
+constexpr int BA_SCHUR_WAVES = 16;         // max landmarks in flight per workgroup (one per wave): the LDS copy of S is
+                                           // zeroed / written out once per group; the host picks 16, 8 or 4 to fit the LDS
 constexpr int BA_LDS_MAX_F = 20;          // (6F)^2 doubles must fit next to the W staging in 160 KB
 
 // whitened residual / Jacobians of one projection factor (cheirality: constant 2*fx residual)
@@ -141,61 +142,115 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BaDev D) {
 
 // mode 0: linearise edges at poseCur, sums[0] = 0.5*(sum partial + edges)   (lin0 / current error)
 // mode 1: evaluate edges at poseTrial: sums[1] = linearised cost at delta, sums[2] = trial cost
-__global__ __launch_bounds__(256) void k_ba_edges(BaDev D, int mode, int nPartial) {
-    __shared__ double red[12], out[2];
-    const int tid = threadIdx.x;
+// BetweenFactor<Pose3> edges + the final reduction of the observation kernels' partial sums.  One single-wave
+// workgroup per edge (the Lie-group algebra of the linearisation wants the full register file): lane 0 does
+// logmap / its derivative / the adjoint, the 6x6 products and the scatter into the reduced system are spread
+// over 36 lanes.  The last workgroup to finish sums the partials in array order (deterministic).
+__global__ __launch_bounds__(64) void k_ba_edges(BaDev D, int mode, int nPartial) {
+    __shared__ double sW[160];       // Hl 36 | Ad 36 | Ja 36 | Jb 36 | r 6
+    __shared__ int sLast;
+    const int lane = threadIdx.x, e = blockIdx.x;
+    double* Hl = sW; double* Ad = Hl + 36; double* Ja = Ad + 36; double* Jb = Ja + 36; double* rr = Jb + 36;
+    const double w = 1.0 / 0.01;
     double v[2] = {0, 0};
-    for (int e = tid; e < D.NE; e += 256) {
+    if (e < D.NE) {
         BaEdge& E = D.edges[e];
+        const int fa = E.fa, fb = E.fb, n = D.n;
         if (mode == 0) {
-            ba_eval_edge(E, D.poseCur[E.a], D.poseCur[E.b], E.r, E.Ja, E.Jb);
-            for (int i = 0; i < 6; i++) v[0] += E.r[i] * E.r[i];
-            for (int i = 0; i < 6; i++) {
-                double ga = 0, gb = 0;
-                for (int k = 0; k < 6; k++) { ga += E.Ja[k * 6 + i] * E.r[k]; gb += E.Jb[k * 6 + i] * E.r[k]; }
-                E.ga[i] = ga; E.gb[i] = gb;
-                for (int j = 0; j < 6; j++) {
-                    double aa = 0, ab = 0, bb = 0;
-                    for (int k = 0; k < 6; k++) {
-                        aa += E.Ja[k * 6 + i] * E.Ja[k * 6 + j];
-                        ab += E.Ja[k * 6 + i] * E.Jb[k * 6 + j];
-                        bb += E.Jb[k * 6 + i] * E.Jb[k * 6 + j];
-                    }
-                    E.Haa[i * 6 + j] = aa; E.Hab[i * 6 + j] = ab; E.Hbb[i * 6 + j] = bb;
-                    const int n = D.n;
-                    if (E.fa >= 0) atomicAdd(&D.Sedge[(size_t)(6 * E.fa + i) * n + 6 * E.fa + j], aa);
-                    if (E.fb >= 0) atomicAdd(&D.Sedge[(size_t)(6 * E.fb + i) * n + 6 * E.fb + j], bb);
-                    if (E.fa >= 0 && E.fb >= 0) {     // upper triangle only (the solve mirrors it)
-                        if (E.fa < E.fb) atomicAdd(&D.Sedge[(size_t)(6 * E.fa + i) * n + 6 * E.fb + j], ab);
-                        else atomicAdd(&D.Sedge[(size_t)(6 * E.fb + j) * n + 6 * E.fa + i], ab);
-                    }
+            if (lane == 0) {
+                DPose Tai, h, Mi, d, hi;
+                pose_inverse(D.poseCur[E.a], Tai);
+                pose_compose(Tai, D.poseCur[E.b], h);
+                pose_inverse(E.measured, Mi);
+                pose_compose(Mi, h, d);
+                double r[6];
+                pose3_logmap(d, r);
+                for (int i = 0; i < 6; i++) { r[i] *= w; rr[i] = r[i]; E.r[i] = r[i]; v[0] += r[i] * r[i]; }
+                pose3_logmap_derivative(d, Hl);
+                pose_inverse(h, hi);
+                pose3_adjoint(hi, Ad);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int i = lane / 6, j = lane % 6;
+            if (lane < 36) {
+                double s = 0;
+                for (int k = 0; k < 6; k++) s += Hl[i * 6 + k] * Ad[k * 6 + j];
+                const double ja = -s * w, jb = Hl[i * 6 + j] * w;
+                Ja[lane] = ja; Jb[lane] = jb;
+                E.Ja[lane] = ja; E.Jb[lane] = jb;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane < 36) {
+                double aa = 0, ab = 0, bb = 0;
+                for (int k = 0; k < 6; k++) {
+                    aa += Ja[k * 6 + i] * Ja[k * 6 + j];
+                    ab += Ja[k * 6 + i] * Jb[k * 6 + j];
+                    bb += Jb[k * 6 + i] * Jb[k * 6 + j];
                 }
-                if (E.fa >= 0) atomicAdd(&D.Sedge[(size_t)D.n * D.n + 6 * E.fa + i], -ga);
-                if (E.fb >= 0) atomicAdd(&D.Sedge[(size_t)D.n * D.n + 6 * E.fb + i], -gb);
+                E.Haa[lane] = aa; E.Hab[lane] = ab; E.Hbb[lane] = bb;
+                if (fa >= 0) atomicAdd(&D.Sedge[(size_t)(6 * fa + i) * n + 6 * fa + j], aa);
+                if (fb >= 0) atomicAdd(&D.Sedge[(size_t)(6 * fb + i) * n + 6 * fb + j], bb);
+                if (fa >= 0 && fb >= 0) {     // upper triangle only (the solve mirrors it)
+                    if (fa < fb) atomicAdd(&D.Sedge[(size_t)(6 * fa + i) * n + 6 * fb + j], ab);
+                    else atomicAdd(&D.Sedge[(size_t)(6 * fb + j) * n + 6 * fa + i], ab);
+                }
+            } else if (lane < 42) {
+                const int q = lane - 36;
+                double ga = 0, gb = 0;
+                for (int k = 0; k < 6; k++) { ga += Ja[k * 6 + q] * rr[k]; gb += Jb[k * 6 + q] * rr[k]; }
+                E.ga[q] = ga; E.gb[q] = gb;
+                if (fa >= 0) atomicAdd(&D.Sedge[(size_t)n * n + 6 * fa + q], -ga);
+                if (fb >= 0) atomicAdd(&D.Sedge[(size_t)n * n + 6 * fb + q], -gb);
             }
         } else {
-            double r[6];
-            ba_eval_edge(E, D.poseTrial[E.a], D.poseTrial[E.b], r, nullptr, nullptr);
-            for (int i = 0; i < 6; i++) v[1] += r[i] * r[i];
-            for (int k = 0; k < 6; k++) {
+            if (lane == 0) {
+                DPose Tai, h, Mi, d;
+                pose_inverse(D.poseTrial[E.a], Tai);
+                pose_compose(Tai, D.poseTrial[E.b], h);
+                pose_inverse(E.measured, Mi);
+                pose_compose(Mi, h, d);
+                double r[6];
+                pose3_logmap(d, r);
+                for (int i = 0; i < 6; i++) { r[i] *= w; v[1] += r[i] * r[i]; }
+            } else if (lane >= 8 && lane < 14) {
+                const int k = lane - 8;
                 double l = E.r[k];
                 for (int i = 0; i < 6; i++) {
-                    if (E.fa >= 0) l += E.Ja[k * 6 + i] * D.dP[6 * E.fa + i];
-                    if (E.fb >= 0) l += E.Jb[k * 6 + i] * D.dP[6 * E.fb + i];
+                    if (fa >= 0) l += E.Ja[k * 6 + i] * D.dP[6 * fa + i];
+                    if (fb >= 0) l += E.Jb[k * 6 + i] * D.dP[6 * fb + i];
                 }
                 v[0] += l * l;
             }
         }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v[k] += __shfl_xor(v[k], d);
+        }
+        if (lane == 0) { D.partial[2 * nPartial + 2 * e] = v[0]; D.partial[2 * nPartial + 2 * e + 1] = v[1]; }
     }
-    // partial sums of the obs kernels: mode 0 -> 1 value per block, mode 1 -> 2 values per block
-    for (int i = tid; i < nPartial; i += 256) {
-        if (mode == 0) v[0] += D.partial[i];
-        else { v[0] += D.partial[2 * i]; v[1] += D.partial[2 * i + 1]; }
+    // the last workgroup to arrive sums every partial in array order
+    __threadfence();
+    if (lane == 0) sLast = (atomicAdd(&D.flags[1], 1) == (int)gridDim.x - 1);
+    __syncthreads();
+    if (!sLast) return;
+    __threadfence();
+    double t[2] = {0, 0};
+    // obs kernels: mode 0 -> 1 value per block, mode 1 -> 2 values per block; edges: 2 values per edge
+    for (int i = lane; i < nPartial; i += 64) {
+        if (mode == 0) t[0] += D.partial[i];
+        else { t[0] += D.partial[2 * i]; t[1] += D.partial[2 * i + 1]; }
     }
-    ba_block_sum<2, 4>(v, red, out);
-    if (tid == 0) {
-        if (mode == 0) D.sums[0] = 0.5 * out[0];
-        else { D.sums[1] = 0.5 * out[0]; D.sums[2] = 0.5 * out[1]; }
+    for (int i = lane; i < D.NE; i += 64) { t[0] += D.partial[2 * nPartial + 2 * i]; t[1] += D.partial[2 * nPartial + 2 * i + 1]; }
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) t[k] += __shfl_xor(t[k], d);
+    }
+    if (lane == 0) {
+        if (mode == 0) D.sums[0] = 0.5 * t[0];
+        else { D.sums[1] = 0.5 * t[0]; D.sums[2] = 0.5 * t[1]; }
+        D.flags[1] = 0;
     }
 }
 
@@ -244,7 +299,7 @@ __device__ __forceinline__ void ba_lm_blocks(const BaDev& D, int lp, double lamb
 }
 
 template <bool LDS_S>
-__global__ __launch_bounds__(256) void k_ba_schur(BaDev D, double lambda, int maxSlots) {
+__global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_schur(BaDev D, double lambda, int maxSlots) {
     extern __shared__ double sm[];
     const int n = D.n;
     double* Sloc = sm;                                        // LDS_S: n*n + n
@@ -252,16 +307,17 @@ __global__ __launch_bounds__(256) void k_ba_schur(BaDev D, double lambda, int ma
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double* W = wbase + (size_t)wave * (2 * maxSlots * 18);
     double* WH = W + maxSlots * 18;
-    int* sfi = (int*)(wbase + (size_t)BA_SCHUR_WAVES * (2 * maxSlots * 18)) + wave * maxSlots;
+    const int nw = blockDim.x >> 6, nt = blockDim.x;
+    int* sfi = (int*)(wbase + (size_t)nw * (2 * maxSlots * 18)) + wave * maxSlots;
     double* Sacc = LDS_S ? Sloc : D.S;
     double* racc = LDS_S ? Sloc + (size_t)n * n : D.rhs;
     if (LDS_S) {
-        for (int i = threadIdx.x; i < n * n + n; i += 256) Sloc[i] = 0;
+        for (int i = threadIdx.x; i < n * n + n; i += nt) Sloc[i] = 0;
     }
     __syncthreads();
-    const int rounds = (D.Lp + gridDim.x * BA_SCHUR_WAVES - 1) / (gridDim.x * BA_SCHUR_WAVES);
+    const int rounds = (D.Lp + gridDim.x * nw - 1) / (gridDim.x * nw);
     for (int rd = 0; rd < rounds; rd++) {
-        const int lp = (rd * gridDim.x + blockIdx.x) * BA_SCHUR_WAVES + wave;
+        const int lp = (rd * gridDim.x + blockIdx.x) * nw + wave;
         const bool act = lp < D.Lp;
         double Hi[9], bl[3];
         int ns = 0;
@@ -314,7 +370,7 @@ __global__ __launch_bounds__(256) void k_ba_schur(BaDev D, double lambda, int ma
     }
     if (LDS_S) {
         double* dst = D.Spart + (size_t)blockIdx.x * ((size_t)n * n + n);
-        for (int i = threadIdx.x; i < n * n + n; i += 256) dst[i] = Sloc[i];
+        for (int i = threadIdx.x; i < n * n + n; i += nt) dst[i] = Sloc[i];
     }
 }
 
@@ -527,15 +583,28 @@ __global__ __launch_bounds__(64) void k_ba_solve_wave(BaDev D, double lambda) {
     const int n = D.n, lane = threadIdx.x;
     const int r = lane < N ? lane : N - 1;
     double a[N];
-    // rows >= n are identity padding; the upper triangle of D.S is the valid one
+#ifdef VSLAM_BA_STAMPS
+#define BAW_STAMP(i) if (lane == 0) D.sums[8 + (i)] = (double)__builtin_readcyclecounter();
+#else
+#define BAW_STAMP(i)
+#endif
+    BAW_STAMP(0)
+    // stage D.S through LDS with coalesced row reads (lane = column), then every lane picks up its own row;
+    // the upper triangle of D.S is the valid one, rows >= n are identity padding
+    for (int row = 0; row < n; row++)
+        if (lane < n) Lt[row * (N + 1) + lane] = D.S[(size_t)row * n + lane];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int c = 0; c < N; c++) {
         double v = (c == r) ? 1.0 : 0.0;
-        if (r < n && c < n) v = D.S[r <= c ? (size_t)r * n + c : (size_t)c * n + r] + ((c == r) ? lambda : 0.0);
+        if (r < n && c < n) v = Lt[r <= c ? r * (N + 1) + c : c * (N + 1) + r] + ((c == r) ? lambda : 0.0);
         a[c] = v;
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     double b = r < n ? D.rhs[r] : 0.0;
     bool bad = false;
+    BAW_STAMP(1)
+    BAW_STAMP(2)
     double idg = 1.0;                 // 1 / L[r][r] once the pivot of this lane's row is known
 #pragma unroll
     for (int k = 0; k < N; k++) {
@@ -546,8 +615,9 @@ __global__ __launch_bounds__(64) void k_ba_solve_wave(BaDev D, double lambda) {
         if (r == k) idg = id;
         a[k] = lk;
 #pragma unroll
-        for (int j = k + 1; j < N; j++) a[j] -= lk * readlane_d(lk, j);
+        for (int j = k + 1; j < N; j++) a[j] = __builtin_fma(-lk, readlane_d(lk, j), a[j]);     // (this solve is not on the bit-exact path)
     }
+    BAW_STAMP(3)
     if (!bad) {
         // L y = b
 #pragma unroll
@@ -555,6 +625,7 @@ __global__ __launch_bounds__(64) void k_ba_solve_wave(BaDev D, double lambda) {
             const double yk = readlane_d(b, k) * readlane_d(idg, k);
             if (r == k) b = yk; else if (r > k) b -= a[k] * yk;
         }
+        BAW_STAMP(4)
         // column form of L: lane i gets L[k][i], k >= i
         if (lane < N) {
 #pragma unroll
@@ -569,6 +640,7 @@ __global__ __launch_bounds__(64) void k_ba_solve_wave(BaDev D, double lambda) {
             const double xk = readlane_d(b, k) * readlane_d(idg, k);
             if (r == k) b = xk; else if (r < k) b -= a[k] * xk;
         }
+        BAW_STAMP(5)
         if (lane < n) D.dP[lane] = b;
         Lt[lane] = b;                 // (the column reads above have completed: their values are in registers)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -578,18 +650,20 @@ __global__ __launch_bounds__(64) void k_ba_solve_wave(BaDev D, double lambda) {
             else D.poseTrial[k] = D.poseCur[k];
         }
     }
+    BAW_STAMP(6)
     if (lane == 0) D.flags[0] = bad ? 1 : 0;
 }
 
 // back-substitution: dl = Hll^-1 (bl - sum_k W_k^T dp_k); trial landmark = cur + dl
-__global__ __launch_bounds__(256) void k_ba_back(BaDev D, double lambda, int maxSlots) {
+__global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_back(BaDev D, double lambda, int maxSlots) {
     extern __shared__ double sm[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double* W = sm + (size_t)wave * (maxSlots * 18);
-    int* sfi = (int*)(sm + (size_t)BA_SCHUR_WAVES * (maxSlots * 18)) + wave * maxSlots;
-    const int rounds = (D.Lp + gridDim.x * BA_SCHUR_WAVES - 1) / (gridDim.x * BA_SCHUR_WAVES);
+    const int nw = blockDim.x >> 6;
+    int* sfi = (int*)(sm + (size_t)nw * (maxSlots * 18)) + wave * maxSlots;
+    const int rounds = (D.Lp + gridDim.x * nw - 1) / (gridDim.x * nw);
     for (int rd = 0; rd < rounds; rd++) {
-        const int lp = (rd * gridDim.x + blockIdx.x) * BA_SCHUR_WAVES + wave;
+        const int lp = (rd * gridDim.x + blockIdx.x) * nw + wave;
         const bool act = lp < D.Lp;
         double Hi[9], bl[3];
         int ns = 0;
@@ -716,6 +790,14 @@ struct HostFac { int pair, kf, lm, fi, lp; bool right; double z[2], is; };
 
 #define BA_UP(dst, vec) VS_HIP(hipMemcpyAsync((dst).p, (vec).data(), (vec).size() * sizeof((vec)[0]), hipMemcpyHostToDevice, stream))
 
+#ifdef VSLAM_HOST_STAMPS
+#include <chrono>
+static double bhs_now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define BHS(name) do { hipStreamSynchronize(stream); const double t_ = bhs_now(); fprintf(stderr, "  ba host: %-12s %8.1f us\n", name, t_ - bhs_t); bhs_t = t_; } while (0)
+#else
+#define BHS(name) do {} while (0)
+#endif
+
 static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int device, const vslam_comm* comm) {
     if (!P || !R || P->n_kf < 1 || P->n_lm < 0 || P->n_pairs < 0 || P->n_levels < 1 || P->n_levels > MAX_LEVELS ||
         !P->kf_pose_wc || !P->kf_id || !P->kf_fixed || !P->kf_local || !P->sigma_factor || !P->inv_sigma_factor ||
@@ -783,13 +865,18 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         VS_HIP(hipMemcpyAsync(d_pairUv.p, P->pair_uv, (size_t)4 * NP * sizeof(float), hipMemcpyHostToDevice, stream));
     }
     VS_HIP(hipMemcpyAsync(d_kfLocal.p, P->kf_local, K, hipMemcpyHostToDevice, stream));
-    VS_HIP(d_sums.alloc(32)); VS_HIP(d_flags.alloc(4));
+    VS_HIP(d_sums.alloc(32));
+    if (!d_flags.p) { VS_HIP(d_flags.alloc(4)); VS_HIP(hipMemsetAsync(d_flags.p, 0, 4 * sizeof(int), stream)); }
 
     std::vector<uint8_t> wrong(NP, 0), kfPresent(K), lmPresent(L);
     DPose* poseFinal = d_pose0.p;
     double* lmFinal = d_lm0.p;
     const int nCU = 256;
 
+#ifdef VSLAM_HOST_STAMPS
+    double bhs_t = bhs_now();
+#endif
+    BHS("setup");
     for (int pass = 0; pass < 2; pass++) {
         // ---- host: factor list of this pass, sorted by (landmark, free index, side) ----------------
         std::fill(kfPresent.begin(), kfPresent.end(), 0);
@@ -878,6 +965,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         if (rank != 0) edges.clear();      // the BetweenFactor chain is counted once (rank 0); S is summed over ranks
         const int NE = (int)edges.size();
 
+        BHS("prep");
         // ---- upload ------------------------------------------------------------------------------
         VS_HIP(d_facKf.alloc(NF)); VS_HIP(d_facFi.alloc(NF)); VS_HIP(d_facLp.alloc(NF)); VS_HIP(d_facLm.alloc(NF));
         VS_HIP(d_facZ.alloc((size_t)2 * NF)); VS_HIP(d_facIs.alloc(NF)); VS_HIP(d_facRight.alloc(NF));
@@ -913,16 +1001,18 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         D.fx = P->rig.fx; D.fy = P->rig.fy; D.cx = P->rig.cx; D.cy = P->rig.cy; D.b = (double)P->rig.baseline;
 
         const int obsBlocks = std::max(1, std::min((NF + 255) / 256, 4 * nCU));
-        const int lmBlocks = std::max(1, std::min((Lp + BA_SCHUR_WAVES - 1) / BA_SCHUR_WAVES, nCU));
-        VS_HIP(d_partial.alloc((size_t)2 * obsBlocks));
-        D.partial = d_partial.p;
         const bool ldsS = F <= BA_LDS_MAX_F;
         const size_t sysDoubles = (size_t)n * n + n;
+        int schurWaves = BA_SCHUR_WAVES;
+        auto schur_lds = [&](int nw) { return (ldsS ? sysDoubles * sizeof(double) : 0) + (size_t)nw * 2 * maxSlots * 18 * sizeof(double) + (size_t)nw * maxSlots * sizeof(int) + 16; };
+        while (schurWaves > 4 && schur_lds(schurWaves) > 150 * 1024) schurWaves /= 2;
+        const int lmBlocks = std::max(1, std::min((Lp + schurWaves - 1) / schurWaves, nCU));
+        VS_HIP(d_partial.alloc((size_t)2 * obsBlocks + 2 * (size_t)std::max(NE, 1)));
+        D.partial = d_partial.p;
         if (ldsS) VS_HIP(d_Spart.alloc(sysDoubles * lmBlocks));
         D.Spart = d_Spart.p;
-        const size_t wStage = (size_t)BA_SCHUR_WAVES * 2 * maxSlots * 18 * sizeof(double) + (size_t)BA_SCHUR_WAVES * maxSlots * sizeof(int) + 16;
-        const size_t schurLds = (ldsS ? sysDoubles * sizeof(double) : 0) + wStage;
-        const size_t backLds = (size_t)BA_SCHUR_WAVES * maxSlots * 18 * sizeof(double) + (size_t)BA_SCHUR_WAVES * maxSlots * sizeof(int) + 16;
+        const size_t schurLds = schur_lds(schurWaves);
+        const size_t backLds = (size_t)schurWaves * maxSlots * 18 * sizeof(double) + (size_t)schurWaves * maxSlots * sizeof(int) + 16;
         const int ldA = ((n + 31) / 32) * 32 + 1;     // row stride = 1 (mod 32) doubles: conflict-free row-per-lane access
         const size_t solveLdsBytes = ((size_t)n * ldA + n + 8) * sizeof(double);
         const bool solveLds = solveLdsBytes <= 150 * 1024;
@@ -931,7 +1021,9 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         if (ldsS) VS_HIP(hipFuncSetAttribute((const void*)k_ba_schur<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurLds));
         else VS_HIP(hipFuncSetAttribute((const void*)k_ba_schur<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurLds));
         if (solveLds) VS_HIP(hipFuncSetAttribute((const void*)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solveLdsBytes));
+        if (backLds > 48 * 1024) VS_HIP(hipFuncSetAttribute((const void*)k_ba_back, hipFuncAttributeMaxDynamicSharedMemorySize, (int)backLds));
 
+        BHS("upload");
         // ---- LM (GTSAM 4.2 policy) -----------------------------------------------------------------
         const int maxIterations = pass == 0 ? 5 : 10;
         const double relTol = 1e-5, absTol = 1e-5;
@@ -941,7 +1033,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
             int t = g_baTimer.begin("ba_linearize");
             if (NF) hipLaunchKernelGGL(k_ba_linearize, dim3(obsBlocks), dim3(256), 0, stream, D);
             VS_HIP(hipMemsetAsync(d_Sedge.p, 0, ((size_t)n * n + n) * sizeof(double), stream));
-            hipLaunchKernelGGL(k_ba_edges, dim3(1), dim3(256), 0, stream, D, 0, NF ? obsBlocks : 0);
+            hipLaunchKernelGGL(k_ba_edges, dim3(std::max(NE, 1)), dim3(64), 0, stream, D, 0, NF ? obsBlocks : 0);
             g_baTimer.end(t);
             if (comm) { const int tc = g_baTimer.begin("ba_allreduce"); VS_CHECK(comm_allreduce(comm, d_sums.p, 1, stream)); g_baTimer.end(tc); }
             return VSLAM_OK;
@@ -962,10 +1054,10 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
                 for (;;) {   // tryLambda
                     int t = g_baTimer.begin("ba_schur");
                     if (n > 0) {
-                        if (ldsS) hipLaunchKernelGGL(k_ba_schur<true>, dim3(lmBlocks), dim3(256), schurLds, stream, D, lambda, maxSlots);
+                        if (ldsS) hipLaunchKernelGGL(k_ba_schur<true>, dim3(lmBlocks), dim3(64 * schurWaves), schurLds, stream, D, lambda, maxSlots);
                         else {
                             VS_HIP(hipMemsetAsync(d_S.p, 0, ((size_t)n * n + n) * sizeof(double), stream));
-                            hipLaunchKernelGGL(k_ba_schur<false>, dim3(lmBlocks), dim3(256), schurLds, stream, D, lambda, maxSlots);
+                            hipLaunchKernelGGL(k_ba_schur<false>, dim3(lmBlocks), dim3(64 * schurWaves), schurLds, stream, D, lambda, maxSlots);
                         }
                     }
                     g_baTimer.end(t);
@@ -982,11 +1074,11 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
                                             solveLds ? solveLdsBytes : 64, stream, D, lambda, solveLds ? 1 : 0, solveLds ? ldA : n);
                     g_baTimer.end(t);
                     t = g_baTimer.begin("ba_back");
-                    if (Lp) hipLaunchKernelGGL(k_ba_back, dim3(lmBlocks), dim3(256), backLds, stream, D, lambda, maxSlots);
+                    if (Lp) hipLaunchKernelGGL(k_ba_back, dim3(lmBlocks), dim3(64 * schurWaves), backLds, stream, D, lambda, maxSlots);
                     g_baTimer.end(t);
                     t = g_baTimer.begin("ba_eval");
                     if (NF) hipLaunchKernelGGL(k_ba_eval, dim3(obsBlocks), dim3(256), 0, stream, D);
-                    hipLaunchKernelGGL(k_ba_edges, dim3(1), dim3(256), 0, stream, D, 1, NF ? obsBlocks : 0);
+                    hipLaunchKernelGGL(k_ba_edges, dim3(std::max(NE, 1)), dim3(64), 0, stream, D, 1, NF ? obsBlocks : 0);
                     g_baTimer.end(t);
                     if (comm) { const int tc = g_baTimer.begin("ba_allreduce"); VS_CHECK(comm_allreduce(comm, d_sums.p + 1, 2, stream)); g_baTimer.end(tc); }
                     VS_HIP(hipGetLastError());
@@ -1053,6 +1145,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
             R->n_residuals = (int64_t)llround(st[0]); R->n_landmarks = (int64_t)llround(st[1]); R->sum_k2 = (int64_t)llround(st[2]);
             g_baTimer.end(tc);
         }
+        BHS("lm");
         // ---- chi2 re-check with the optimised values ---------------------------------------------
         VS_HIP(hipMemcpyAsync(d_kfPresent.p, kfPresent.data(), K, hipMemcpyHostToDevice, stream));
         if (L) VS_HIP(hipMemcpyAsync(d_lmPresent.p, lmPresent.data(), L, hipMemcpyHostToDevice, stream));
@@ -1072,6 +1165,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         poseFinal = D.poseCur;
         lmFinal = D.lmCur;
     }
+    BHS("chi2");
     std::vector<DPose> poseOut(K);
     VS_HIP(hipMemcpyAsync(poseOut.data(), poseFinal, K * sizeof(DPose), hipMemcpyDeviceToHost, stream));
     if (L) VS_HIP(hipMemcpyAsync(R->lm_xyz, lmFinal, (size_t)3 * L * sizeof(double), hipMemcpyDeviceToHost, stream));

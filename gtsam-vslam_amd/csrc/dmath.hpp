@@ -13,17 +13,22 @@ namespace vslam {
 struct DPose { double R[9]; double t[3]; };   // world <- camera unless stated otherwise
 
 VS_HD void mat3_mul(const double* a, const double* b, double* r) {
+    #pragma unroll
     for (int i = 0; i < 3; i++)
+        #pragma unroll
         for (int j = 0; j < 3; j++) {
             double s = 0;
+            #pragma unroll
             for (int k = 0; k < 3; k++) s += a[3 * i + k] * b[3 * k + j];
             r[3 * i + j] = s;
         }
 }
 VS_HD void mat3_vec(const double* a, const double* x, double* r) {
+    #pragma unroll
     for (int i = 0; i < 3; i++) r[i] = a[3 * i] * x[0] + a[3 * i + 1] * x[1] + a[3 * i + 2] * x[2];
 }
 VS_HD void mat3T_vec(const double* a, const double* x, double* r) {
+    #pragma unroll
     for (int i = 0; i < 3; i++) r[i] = a[i] * x[0] + a[3 + i] * x[1] + a[6 + i] * x[2];
 }
 
@@ -31,16 +36,20 @@ VS_HD void mat3T_vec(const double* a, const double* x, double* r) {
 VS_HD void so3_expmap(const double* w, double* R) {
     const double theta2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
     const double W[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+    #pragma unroll
     for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
     if (theta2 <= DBL_EPSILON) {
+        #pragma unroll
         for (int i = 0; i < 9; i++) R[i] += W[i];
         return;
     }
     const double theta = sqrt(theta2);
     const double s = sin(theta), s2 = sin(theta / 2.0), omc = 2.0 * s2 * s2;
     double K[9], KK[9];
+    #pragma unroll
     for (int i = 0; i < 9; i++) K[i] = W[i] / theta;
     mat3_mul(K, K, KK);
+    #pragma unroll
     for (int i = 0; i < 9; i++) R[i] += s * K[i] + omc * KK[i];
 }
 
@@ -73,8 +82,10 @@ VS_HD void se3_expmap(const double* xi, DPose& T) {
         const double wxv[3] = {w[1] * v[2] - w[2] * v[1], w[2] * v[0] - w[0] * v[2], w[0] * v[1] - w[1] * v[0]};
         double Rwxv[3];
         mat3_vec(T.R, wxv, Rwxv);
+        #pragma unroll
         for (int i = 0; i < 3; i++) T.t[i] = (wxv[i] - Rwxv[i] + w[i] * wv) / theta2;
     } else {
+        #pragma unroll
         for (int i = 0; i < 3; i++) T.t[i] = v[i];
     }
 }
@@ -82,12 +93,15 @@ VS_HD void pose_compose(const DPose& a, const DPose& b, DPose& r) {
     mat3_mul(a.R, b.R, r.R);
     double rt[3];
     mat3_vec(a.R, b.t, rt);
+    #pragma unroll
     for (int i = 0; i < 3; i++) r.t[i] = a.t[i] + rt[i];
 }
 VS_HD void pose_inverse(const DPose& a, DPose& r) {
+    #pragma unroll
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.R[3 * i + j] = a.R[3 * j + i];
     double rt[3];
     mat3_vec(r.R, a.t, rt);
+    #pragma unroll
     for (int i = 0; i < 3; i++) r.t[i] = -rt[i];
 }
 VS_HD void pose_retract(const DPose& T, const double* xi, DPose& r) {
@@ -96,9 +110,11 @@ VS_HD void pose_retract(const DPose& T, const double* xi, DPose& r) {
     pose_compose(T, e, r);
 }
 VS_HD void pose_from_rm16(const double* M, DPose& T) {
+    #pragma unroll
     for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) T.R[3 * i + j] = M[4 * i + j]; T.t[i] = M[4 * i + 3]; }
 }
 VS_HD void pose_to_rm16(const DPose& T, double* M) {
+    #pragma unroll
     for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) M[4 * i + j] = T.R[3 * i + j]; M[4 * i + 3] = T.t[i]; }
     M[12] = M[13] = M[14] = 0; M[15] = 1;
 }
@@ -123,11 +139,13 @@ VS_HD void pose3_logmap(const DPose& T, double* xi) {
     mat3_vec(W, T.t, WT);
     mat3_vec(W, WT, WWT);
     const double Tan = tan(0.5 * t);
+    #pragma unroll
     for (int i = 0; i < 3; i++) xi[3 + i] = T.t[i] - (0.5 * t) * WT[i] + (1 - t / (2. * Tan)) * WWT[i];
 }
 
 // SO3::LogmapDerivative
 VS_HD void so3_logmap_derivative(const double* w, double* J) {
+    #pragma unroll
     for (int i = 0; i < 9; i++) J[i] = (i % 4 == 0) ? 1.0 : 0.0;
     const double theta2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
     if (theta2 <= DBL_EPSILON) return;
@@ -152,6 +170,7 @@ VS_HD void pose3_logmap_derivative(const DPose& T, double* J) {
     mat3_mul(WW, V, WWV); mat3_mul(VW, W, VWW); mat3_mul(WVW, W, WVWW);
     mat3_mul(V, W, tmp); mat3_mul(WW, tmp, WWVW);
     double t1[9], t2[9], t3[9], Q[9];
+    #pragma unroll
     for (int i = 0; i < 9; i++) {
         t1[i] = WV[i] + VW[i] - WVW[i];
         t2[i] = WWV[i] + VWW[i] - 3.0 * WVW[i];
@@ -173,8 +192,11 @@ VS_HD void pose3_logmap_derivative(const DPose& T, double* J) {
     double JQ[9], Q2[9];
     mat3_mul(Jw, Q, JQ);
     mat3_mul(JQ, Jw, Q2);
+    #pragma unroll
     for (int i = 0; i < 36; i++) J[i] = 0;
+    #pragma unroll
     for (int i = 0; i < 3; i++)
+        #pragma unroll
         for (int j = 0; j < 3; j++) {
             J[i * 6 + j] = Jw[3 * i + j];
             J[(3 + i) * 6 + j] = -Q2[3 * i + j];
@@ -187,8 +209,11 @@ VS_HD void pose3_adjoint(const DPose& T, double* A) {
     double S[9], tR[9];
     skew3(T.t, S);
     mat3_mul(S, T.R, tR);
+    #pragma unroll
     for (int i = 0; i < 36; i++) A[i] = 0;
+    #pragma unroll
     for (int i = 0; i < 3; i++)
+        #pragma unroll
         for (int j = 0; j < 3; j++) {
             A[i * 6 + j] = T.R[3 * i + j];
             A[(3 + i) * 6 + j] = tR[3 * i + j];

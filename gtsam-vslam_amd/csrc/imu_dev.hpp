@@ -52,6 +52,7 @@ VS_HD void dexp_apply_inv(const double* th, const double* v, double* R, double* 
         sin_theta = sin(theta);
         const double s2 = sin(theta / 2.0);
         omc = 2.0 * s2 * s2;
+        #pragma unroll
         for (int i = 0; i < 9; i++) K[i] = W[i] / theta;
         mat3_mul(K, K, KK);
         a = omc / theta;
@@ -69,19 +70,23 @@ VS_HD void dexp_apply_inv(const double* th, const double* v, double* R, double* 
         mat3_vec(K, c, Kv);
         const double Da = (sin_theta - 2.0 * a) / theta2, Db = (omc - 3.0 * b) / theta2;
         double M1[9], u[3], t1[9], t2[9], M3[9], sv[9], t3[9];
+        #pragma unroll
         for (int i = 0; i < 9; i++) M1[i] = Db * K[i] - ((i % 4 == 0) ? Da : 0.0);
         mat3_vec(M1, Kv, u);
         m3_outer(u, th, t1);
         const double kb[3] = {Kv[0] * b / theta, Kv[1] * b / theta, Kv[2] * b / theta};
         skew3(kb, t2);
+        #pragma unroll
         for (int i = 0; i < 9; i++) M3[i] = ((i % 4 == 0) ? a : 0.0) - b * K[i];
         const double vt[3] = {c[0] / theta, c[1] / theta, c[2] / theta};
         skew3(vt, sv);
         mat3_mul(M3, sv, t3);
+        #pragma unroll
         for (int i = 0; i < 9; i++) D[i] = t1[i] - t2[i] + t3[i];
     }
     double ID[9];
     mat3_mul(H2, D, ID);
+    #pragma unroll
     for (int i = 0; i < 9; i++) H1[i] = -ID[i];
 }
 
@@ -93,12 +98,14 @@ VS_HD bool pim_correct(const DPim& pim, const DImuParams& P, const double* accM,
     mat3_vec(P.bRs, omS, om);
     mat3_vec(P.bRs, accS, acc);
     const bool hasArm = !(P.arm[0] == 0 && P.arm[1] == 0 && P.arm[2] == 0);
+    #pragma unroll
     for (int i = 0; i < 9; i++) D_acc_omega[i] = 0;
     if (hasArm) {
         double Om[9], vb[3], cen[3];
         skew3(om, Om);
         mat3_vec(Om, P.arm, vb);
         mat3_vec(Om, vb, cen);
+        #pragma unroll
         for (int i = 0; i < 3; i++) acc[i] -= cen[i];
         const double wdp = om[0] * P.arm[0] + om[1] * P.arm[1] + om[2] * P.arm[2];
         double t[9], tb[9], o2[9];
@@ -106,6 +113,7 @@ VS_HD bool pim_correct(const DPim& pim, const DImuParams& P, const double* accM,
         t[0] += wdp; t[4] += wdp; t[8] += wdp;
         mat3_mul(t, P.bRs, tb);
         m3_outer(P.arm, omS, o2);
+        #pragma unroll
         for (int i = 0; i < 9; i++) D_acc_omega[i] = -tb[i] + 2.0 * o2[i];
     }
     return hasArm;
@@ -122,6 +130,7 @@ VS_HD void pim_step_state(const DPim& pim, const double* preint, const DImuParam
     double a_nav[3];
     mat3_vec(R, acc, a_nav);
     const double dt22 = 0.5 * dt * dt;
+    #pragma unroll
     for (int i = 0; i < 3; i++) {
         plus[i] = preint[i] + wt[i] * dt;
         plus[3 + i] = preint[3 + i] + preint[6 + i] * dt + a_nav[i] * dt22;
@@ -142,12 +151,18 @@ VS_HD void pim_step_mats(const DPim& pim, const double* preint, const DImuParams
     skew3(na, Sa);
     mat3_mul(R, Sa, RS);
     mat3_mul(RS, dexp, aH);
+    #pragma unroll
     for (int i = 0; i < 81; i++) A[i] = 0;
+    #pragma unroll
     for (int i = 0; i < 27; i++) { B[i] = 0; C[i] = 0; }
+    #pragma unroll
     for (int i = 0; i < 9; i++) A[i * 9 + i] = 1.0;
     double B0[27], C0[27];
+    #pragma unroll
     for (int i = 0; i < 27; i++) { B0[i] = 0; C0[i] = 0; }
+    #pragma unroll
     for (int i = 0; i < 3; i++)
+        #pragma unroll
         for (int j = 0; j < 3; j++) {
             A[i * 9 + j] += wtH[3 * i + j] * dt;
             A[(3 + i) * 9 + j] = aH[3 * i + j] * dt22;
@@ -156,26 +171,39 @@ VS_HD void pim_step_mats(const DPim& pim, const double* preint, const DImuParams
             B0[(6 + i) * 3 + j] = R[3 * i + j] * dt;
             C0[i * 3 + j] = invH[3 * i + j] * dt;
         }
+    #pragma unroll
     for (int i = 0; i < 3; i++) A[(3 + i) * 9 + 6 + i] = dt;
     // C = C0 * bRs (+ B0 * D_acc_omega), B = B0 * bRs
+    #pragma unroll
     for (int i = 0; i < 9; i++)
+        #pragma unroll
         for (int j = 0; j < 3; j++) {
             double sc = 0, sb = 0, sd = 0;
+            #pragma unroll
             for (int k = 0; k < 3; k++) { sc += C0[i * 3 + k] * P.bRs[3 * k + j]; sb += B0[i * 3 + k] * P.bRs[3 * k + j]; sd += B0[i * 3 + k] * D_acc_omega[3 * k + j]; }
             C[i * 3 + j] = sc + (hasArm ? sd : 0.0);
             B[i * 3 + j] = sb;
         }
     // F and G
     double thH[9], posH[9], velH[9];
+    #pragma unroll
     for (int i = 0; i < 3; i++)
+        #pragma unroll
         for (int j = 0; j < 3; j++) { thH[3 * i + j] = -C[i * 3 + j]; posH[3 * i + j] = -B[(3 + i) * 3 + j]; velH[3 * i + j] = -B[(6 + i) * 3 + j]; }
+    #pragma unroll
     for (int i = 0; i < 225; i++) { F[i] = 0; G[i] = 0; }
+    #pragma unroll
     for (int i = 0; i < 9; i++) for (int j = 0; j < 9; j++) F[i * 15 + j] = A[i * 9 + j];
+    #pragma unroll
     for (int i = 0; i < 3; i++)
+        #pragma unroll
         for (int j = 0; j < 3; j++) { F[i * 15 + 12 + j] = thH[3 * i + j]; F[(3 + i) * 15 + 9 + j] = posH[3 * i + j]; F[(6 + i) * 15 + 9 + j] = velH[3 * i + j]; }
+    #pragma unroll
     for (int i = 9; i < 15; i++) F[i * 15 + i] = 1.0;
     double b11[9], b12[9], b21[9], b22[9];
+    #pragma unroll
     for (int i = 0; i < 3; i++)
+        #pragma unroll
         for (int j = 0; j < 3; j++) {
             b11[3 * i + j] = P.biasInt[i * 6 + j] / dt; b12[3 * i + j] = P.biasInt[i * 6 + 3 + j] / dt;
             b21[3 * i + j] = P.biasInt[(3 + i) * 6 + j] / dt; b22[3 * i + j] = P.biasInt[(3 + i) * 6 + 3 + j] / dt;
@@ -184,11 +212,14 @@ VS_HD void pim_step_mats(const DPim& pim, const double* preint, const DImuParams
     auto put = [&](int r, int c, const double* X, const double* M, double diagM, const double* Y, double addDiag, bool accumulate) {
         // G[r..,c..] (+)= X * (M + diagM*I) * Y^T (+ addDiag * I)
         double Mx[9], XM[9], Yt[9], res[9];
+        #pragma unroll
         for (int i = 0; i < 9; i++) Mx[i] = (M ? M[i] : 0.0) + ((i % 4 == 0) ? diagM : 0.0);
         mat3_mul(X, Mx, XM);
         m3_T(Y, Yt);
         mat3_mul(XM, Yt, res);
+        #pragma unroll
         for (int i = 0; i < 3; i++)
+            #pragma unroll
             for (int j = 0; j < 3; j++) {
                 const double v = res[3 * i + j] + ((i == j) ? addDiag : 0.0);
                 if (accumulate) G[(r + i) * 15 + c + j] += v; else G[(r + i) * 15 + c + j] = v;
@@ -198,6 +229,7 @@ VS_HD void pim_step_mats(const DPim& pim, const double* preint, const DImuParams
     put(0, 0, thH, nullptr, wC, thH, 0.0, false);   put(0, 0, thH, b22, 0.0, thH, 0.0, true);
     put(3, 3, posH, nullptr, aC, posH, 0.0, false); put(3, 3, posH, b11, 0.0, posH, dt * P.integrationCov, true);
     put(6, 6, velH, nullptr, aC, velH, 0.0, false); put(6, 6, velH, b11, 0.0, velH, 0.0, true);
+    #pragma unroll
     for (int i = 0; i < 3; i++) { G[(9 + i) * 15 + 9 + i] = dt * P.biasAccCov; G[(12 + i) * 15 + 12 + i] = dt * P.biasOmegaCov; }
     put(0, 3, thH, b21, 0.0, posH, 0.0, false);
     put(0, 6, thH, b21, 0.0, velH, 0.0, false);
@@ -213,11 +245,13 @@ VS_HD void pim_predict(const DPim& pim, const DImuParams& P, const DNav& si, DNa
     double Rtv[3], Rtg[3], dP[3], dV[3], E[9], RdP[3], RdV[3];
     mat3T_vec(si.R, si.v, Rtv);
     mat3T_vec(si.R, P.gravity, Rtg);
+    #pragma unroll
     for (int i = 0; i < 3; i++) { dP[i] = pim.preint[3 + i] + dt * Rtv[i] + dt22 * Rtg[i]; dV[i] = pim.preint[6 + i] + dt * Rtg[i]; }
     so3_expmap(pim.preint, E);
     mat3_mul(si.R, E, sj.R);
     mat3_vec(si.R, dP, RdP);
     mat3_vec(si.R, dV, RdV);
+    #pragma unroll
     for (int i = 0; i < 3; i++) { sj.t[i] = si.t[i] + RdP[i]; sj.v[i] = si.v[i] + RdV[i]; }
 }
 
@@ -228,12 +262,16 @@ VS_HD void imu_factor_eval(const DNav& pred, const double* biasHat, const double
     m3_T(Rj, RjT);
     mat3_mul(RjT, pred.R, dR);
     so3_logmap(dR, xi);
+    #pragma unroll
     for (int i = 0; i < 3; i++) { dt_[i] = pred.t[i] - tj[i]; dv_[i] = pred.v[i] - vj[i]; }
     mat3_vec(RjT, dt_, dP);
     mat3_vec(RjT, dv_, dV);
+    #pragma unroll
     for (int i = 0; i < 3; i++) { r[i] = xi[i]; r[3 + i] = dP[i]; r[6 + i] = dV[i]; }
+    #pragma unroll
     for (int i = 0; i < 6; i++) r[9 + i] = biasHat[i] - bj[i];
     if (!J) return;
+    #pragma unroll
     for (int i = 0; i < 225; i++) J[i] = 0;
     double Dx[9], dRT[9], M[9], S1[9], S2[9];
     so3_logmap_derivative(xi, Dx);
@@ -241,14 +279,18 @@ VS_HD void imu_factor_eval(const DNav& pred, const double* biasHat, const double
     mat3_mul(Dx, dRT, M);
     skew3(dP, S1);
     skew3(dV, S2);
+    #pragma unroll
     for (int i = 0; i < 3; i++)
+        #pragma unroll
         for (int j = 0; j < 3; j++) {
             J[i * 15 + j] = -M[3 * i + j];
             J[(3 + i) * 15 + j] = S1[3 * i + j];
             J[(6 + i) * 15 + j] = S2[3 * i + j];
             J[(6 + i) * 15 + 6 + j] = -RjT[3 * i + j];
         }
+    #pragma unroll
     for (int i = 0; i < 3; i++) J[(3 + i) * 15 + 3 + i] = -1.0;
+    #pragma unroll
     for (int i = 0; i < 6; i++) J[(9 + i) * 15 + 9 + i] = -1.0;
 }
 
