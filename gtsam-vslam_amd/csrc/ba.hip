@@ -49,7 +49,25 @@ struct BaDev {
     double* sums; double* partial;
     int* flags;
     double fx, fy, cx, cy, b;
+    double* ctl;      // device-side LM state (below)
 };
+
+// The LM policy (GTSAM 4.2) runs on the DEVICE: a 1-thread control kernel after each linearisation / trial
+// updates this block, every other kernel starts by checking that it is its turn (state) and picks the
+// current / trial buffers by `sel`.  The host enqueues a few speculative steps at a time and only reads the
+// block back to learn whether the pass has finished - no host round trip per lambda trial.
+enum { CTL_LAMBDA = 0, CTL_ERROR = 1, CTL_CUR = 2, CTL_INIT_ERR = 3, CTL_INTS = 8, CTL_DOUBLES = 16 };
+enum { CI_STATE = 0, CI_SEL = 1, CI_ITER = 2, CI_INNER = 3, CI_MAXIT = 4, CI_FIRST = 5 };
+enum { BA_LINEARIZE = 0, BA_TRY = 1, BA_DONE = 2 };
+__device__ __forceinline__ bool ba_enter(BaDev& D, int state) {
+    const int* ci = (const int*)(D.ctl + CTL_INTS);
+    if (ci[CI_STATE] != state) return false;
+    if (ci[CI_SEL]) {
+        DPose* tp = D.poseCur; D.poseCur = D.poseTrial; D.poseTrial = tp;
+        double* tl = D.lmCur; D.lmCur = D.lmTrial; D.lmTrial = tl;
+    }
+    return true;
+}
 
 constexpr int BA_SCHUR_WAVES = 16;         // max landmarks in flight per workgroup (one per wave): the LDS copy of S is
                                            // zeroed / written out once per group; the host picks 16, 8 or 4 to fit the LDS
@@ -125,6 +143,8 @@ __device__ __forceinline__ void ba_block_sum(double (&v)[NV], double* red, doubl
 
 __global__ __launch_bounds__(256) void k_ba_linearize(BaDev D) {
     __shared__ double red[4], out[1];
+    if (!ba_enter(D, BA_LINEARIZE)) return;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < D.n * D.n + D.n; i += gridDim.x * 256) D.Sedge[i] = 0;   // the edge kernel accumulates into it
     double e[1] = {0};
     for (int f = blockIdx.x * 256 + threadIdx.x; f < D.NF; f += gridDim.x * 256) {
         double r[2], Jp[12], Jl[6];
@@ -150,6 +170,7 @@ __global__ __launch_bounds__(64) void k_ba_edges(BaDev D, int mode, int nPartial
     __shared__ double sW[160];       // Hl 36 | Ad 36 | Ja 36 | Jb 36 | r 6
     __shared__ int sLast;
     const int lane = threadIdx.x, e = blockIdx.x;
+    if (!ba_enter(D, mode == 0 ? BA_LINEARIZE : BA_TRY)) return;
     double* Hl = sW; double* Ad = Hl + 36; double* Ja = Ad + 36; double* Jb = Ja + 36; double* rr = Jb + 36;
     const double w = 1.0 / 0.01;
     double v[2] = {0, 0};
@@ -299,9 +320,14 @@ __device__ __forceinline__ void ba_lm_blocks(const BaDev& D, int lp, double lamb
 }
 
 template <bool LDS_S>
-__global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_schur(BaDev D, double lambda, int maxSlots) {
+__global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_schur(BaDev D, int maxSlots) {
     extern __shared__ double sm[];
+    if (!ba_enter(D, BA_TRY)) return;
+    const double lambda = D.ctl[CTL_LAMBDA];
     const int n = D.n;
+    if (LDS_S) {   // D.S | D.rhs receive the sum of the per-workgroup partial systems (k_ba_reduce): zero them here
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n * n + n; i += gridDim.x * blockDim.x) D.S[i] = 0;
+    }
     double* Sloc = sm;                                        // LDS_S: n*n + n
     double* wbase = sm + (LDS_S ? (size_t)n * n + n : 0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -377,6 +403,7 @@ __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_schur(BaDev D, doubl
 // Sum of the per-workgroup partial systems (grid-parallel, coalesced over entries).  This is the
 // buffer the landmark-sharded multi-GPU path all-reduces (RCCL) before k_ba_solve.
 __global__ __launch_bounds__(256) void k_ba_reduce(BaDev D, int nPart) {
+    if (!ba_enter(D, BA_TRY)) return;
     const int total = D.n * D.n + D.n;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
@@ -402,8 +429,10 @@ __global__ __launch_bounds__(256) void k_ba_reduce(BaDev D, int nPart) {
 // reduced camera system from D.S / D.rhs (upper triangle valid) + BetweenFactor blocks + lambda I,
 // left-looking Cholesky (2 barriers per column), the two substitutions (1 barrier per column), then
 // retracts the trial poses.  A (n x n) lives in LDS when it fits, else in D.S (L2-resident).
-__global__ __launch_bounds__(1024) void k_ba_solve(BaDev D, double lambda, int useLds, int ld) {
+__global__ __launch_bounds__(1024) void k_ba_solve(BaDev D, int useLds, int ld) {
     extern __shared__ double sm[];
+    if (!ba_enter(D, BA_TRY)) return;
+    const double lambda = D.ctl[CTL_LAMBDA];
     const int n = D.n, tid = threadIdx.x, nt = blockDim.x;
     double* A = useLds ? sm : D.S;                              // leading dimension ld (LDS: odd multiple, conflict-free rows)
     double* col = useLds ? sm + (size_t)n * ld : D.rhs + n;     // n scratch doubles (D.rhs holds 2n)
@@ -577,9 +606,11 @@ __global__ __launch_bounds__(1024) void k_ba_solve(BaDev D, double lambda, int u
 // v_readlane, no LDS round trip or barrier per column.  Right-looking Cholesky (rsqrt pivots as in k_ba_solve),
 // forward substitution, transpose of L through LDS, column-oriented back substitution, pose retraction.
 constexpr int BA_WAVE_N = 60;
-__global__ __launch_bounds__(64) void k_ba_solve_wave(BaDev D, double lambda) {
+__global__ __launch_bounds__(64) void k_ba_solve_wave(BaDev D) {
     constexpr int N = BA_WAVE_N;
     __shared__ double Lt[N * (N + 1)];
+    if (!ba_enter(D, BA_TRY)) return;
+    const double lambda = D.ctl[CTL_LAMBDA];
     const int n = D.n, lane = threadIdx.x;
     const int r = lane < N ? lane : N - 1;
     double a[N];
@@ -655,8 +686,10 @@ __global__ __launch_bounds__(64) void k_ba_solve_wave(BaDev D, double lambda) {
 }
 
 // back-substitution: dl = Hll^-1 (bl - sum_k W_k^T dp_k); trial landmark = cur + dl
-__global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_back(BaDev D, double lambda, int maxSlots) {
+__global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_back(BaDev D, int maxSlots) {
     extern __shared__ double sm[];
+    if (!ba_enter(D, BA_TRY)) return;
+    const double lambda = D.ctl[CTL_LAMBDA];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double* W = sm + (size_t)wave * (maxSlots * 18);
     const int nw = blockDim.x >> 6;
@@ -696,6 +729,7 @@ __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_back(BaDev D, double
 
 __global__ __launch_bounds__(256) void k_ba_eval(BaDev D) {
     __shared__ double red[8], out[2];
+    if (!ba_enter(D, BA_TRY)) return;
     double v[2] = {0, 0};
     for (int f = blockIdx.x * 256 + threadIdx.x; f < D.NF; f += gridDim.x * 256) {
         const double* o = D.facJ + (size_t)f * 20;
@@ -730,6 +764,60 @@ __device__ __forceinline__ bool ba_outlier(const BaChi& C, const double* pc, flo
     const double eu = (double)ou - px / z, ev = (double)ov - py / z;
     return (eu * eu + ev * ev) > (double)C.thr[oct];
 }
+// LevenbergMarquardtOptimizer::iterate / tryLambda bookkeeping (GTSAM 4.2), one thread.
+// mode 0: after a linearisation (sums[0] = current error);  mode 1: after a trial (sums[1] = linearised
+// cost at delta, sums[2] = cost at the trial values, flags[0] = Cholesky failure).
+__global__ void k_ba_ctl(BaDev D, int mode, double relTol, double absTol) {
+    double* c = D.ctl;
+    int* ci = (int*)(D.ctl + CTL_INTS);
+    if (mode == 0) {
+        if (ci[CI_STATE] != BA_LINEARIZE) return;
+        if (ci[CI_FIRST]) {
+            ci[CI_FIRST] = 0;
+            c[CTL_ERROR] = D.sums[0];
+            c[CTL_INIT_ERR] = D.sums[0];
+            ci[CI_STATE] = (!(c[CTL_ERROR] <= 0.0) && ci[CI_ITER] < ci[CI_MAXIT]) ? BA_TRY : BA_DONE;
+        } else ci[CI_STATE] = BA_TRY;
+        c[CTL_CUR] = c[CTL_ERROR];          // currentError = newError at the top of the do-body
+        return;
+    }
+    if (ci[CI_STATE] != BA_TRY) return;
+    const double error = c[CTL_ERROR];
+    double lambda = c[CTL_LAMBDA];
+    bool stepOk = false, stop = false;
+    double newErr = INFINITY;
+    const double linChange = error - D.sums[1];
+    if (!D.flags[0] && linChange >= 0) {
+        newErr = D.sums[2];
+        const double costChange = error - newErr;
+        if (linChange > DBL_EPSILON * error) stepOk = (costChange / linChange) > 1e-3;
+        if (fabs(costChange) < relTol * error) stop = true;
+    }
+    bool endInner = false;
+    if (stepOk) {
+        ci[CI_SEL] ^= 1;                    // every present landmark / every pose is rewritten per trial
+        c[CTL_ERROR] = newErr;
+        lambda = lambda / 10.0;
+        c[CTL_LAMBDA] = lambda > 0.0 ? lambda : 0.0;
+        ci[CI_ITER]++; ci[CI_INNER]++;
+        endInner = true;
+    } else if (!stop) {
+        lambda *= 10.0;
+        c[CTL_LAMBDA] = lambda;
+        ci[CI_INNER]++;
+        if (lambda >= 1e5) endInner = true;
+    } else endInner = true;
+    if (!endInner) return;                   // same linearisation, larger lambda
+    const double currentError = c[CTL_CUR], newError = c[CTL_ERROR];
+    bool converged;
+    if (newError <= 0.0) converged = true;
+    else {
+        const double absDec = currentError - newError, relDec = absDec / currentError;
+        converged = (relDec <= relTol) || (absDec <= absTol);
+    }
+    ci[CI_STATE] = (ci[CI_ITER] < ci[CI_MAXIT] && !converged && isfinite(currentError)) ? BA_LINEARIZE : BA_DONE;
+}
+
 __global__ __launch_bounds__(256) void k_ba_chi2(BaChi C) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= C.NP) return;
@@ -784,6 +872,38 @@ struct DevBuf {
 
 thread_local StageTimer g_baTimer;
 
+// Pinned host arena with a device mirror: the per-pass index / measurement arrays are written straight into
+// pinned memory and travel in ONE copy.
+struct PinnedArena {
+    uint8_t* h = nullptr; uint8_t* d = nullptr;
+    size_t cap = 0, used = 0;
+    hipError_t ensure(size_t bytes, hipStream_t s) {
+        if (bytes <= cap) return hipSuccess;
+        hipError_t e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return e;
+        if (h) hipHostFree(h);
+        if (d) hipFree(d);
+        h = nullptr; d = nullptr;
+        cap = bytes + bytes / 4 + 4096;
+        e = hipHostMalloc((void**)&h, cap, hipHostMallocDefault);
+        if (e != hipSuccess) return e;
+        return hipMalloc((void**)&d, cap);
+    }
+    void reset() { used = 0; }
+    template <class T> T* take(size_t count) {
+        used = (used + 255) & ~(size_t)255;
+        T* p = (T*)(h + used);
+        used += std::max<size_t>(count, 1) * sizeof(T);
+        return used <= cap ? p : nullptr;
+    }
+    template <class T> T* dev(T* hostPtr) const { return (T*)(d + ((uint8_t*)hostPtr - h)); }
+    hipError_t upload(hipStream_t s) const { return hipMemcpyAsync(d, h, used, hipMemcpyHostToDevice, s); }
+};
+struct BaHostTmp {
+    std::vector<uint8_t> kfPresent, lmPresent;
+    std::vector<int> cnt, fidx, lpOf, order, fill, key, src;
+};
+
 struct HostFac { int pair, kf, lm, fi, lp; bool right; double z[2], is; };
 
 }  // namespace
@@ -824,29 +944,36 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         hipStream_t stream = nullptr;
         int device = -1;
         DevBuf<DPose> d_pose0, d_poseA, d_poseB;
-        DevBuf<double> d_lm0, d_lmA, d_lmB, d_facZ, d_facIs, d_facJ, d_S, d_rhs, d_Spart, d_Sedge, d_dP, d_dL, d_lmDiff, d_sums, d_partial;
-        DevBuf<int> d_facKf, d_facFi, d_facLp, d_facLm, d_lpStart, d_lpSlotStart, d_slotStart, d_slotFi, d_lpOrig, d_fidx, d_flags;
-        DevBuf<int> d_pairKf, d_pairLm, d_pairOct;
-        DevBuf<uint8_t> d_facRight, d_pairFlags, d_kfLocal, d_kfPresent, d_lmPresent, d_wrong;
+        DevBuf<double> d_lm0, d_lmA, d_lmB, d_facJ, d_S, d_Spart, d_Sedge, d_dP, d_dL, d_lmDiff, d_sums, d_partial;
+        DevBuf<int> d_flags, d_pairKf, d_pairLm, d_pairOct;
+        DevBuf<uint8_t> d_pairFlags, d_kfLocal, d_wrong;
         DevBuf<float> d_pairUv;
-        DevBuf<BaEdge> d_edges;
+        PinnedArena arena;
+        BaHostTmp tmp;
+        double* h_ctlOut = nullptr;
+        uint8_t* h_wrong = nullptr; size_t wrongCap = 0;
     };
     static thread_local Workspace* ws = nullptr;
-    if (!ws || ws->device != device) { ws = new Workspace(); ws->device = device; VS_HIP(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking)); }
+    if (!ws || ws->device != device) {
+        ws = new Workspace(); ws->device = device;
+        VS_HIP(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));
+        VS_HIP(hipHostMalloc((void**)&ws->h_ctlOut, CTL_DOUBLES * sizeof(double), hipHostMallocDefault));
+    }
+    if ((size_t)P->n_pairs > ws->wrongCap) {
+        if (ws->h_wrong) hipHostFree(ws->h_wrong);
+        ws->wrongCap = (size_t)P->n_pairs + 4096;
+        VS_HIP(hipHostMalloc((void**)&ws->h_wrong, ws->wrongCap, hipHostMallocDefault));
+    }
     hipStream_t stream = ws->stream;
     g_baTimer.reset();
     g_baTimer.stream = stream;
     g_baTimer.multi = true;
     auto &d_pose0 = ws->d_pose0, &d_poseA = ws->d_poseA, &d_poseB = ws->d_poseB;
-    auto &d_lm0 = ws->d_lm0, &d_lmA = ws->d_lmA, &d_lmB = ws->d_lmB, &d_facZ = ws->d_facZ, &d_facIs = ws->d_facIs, &d_facJ = ws->d_facJ,
-         &d_S = ws->d_S, &d_rhs = ws->d_rhs, &d_Spart = ws->d_Spart, &d_Sedge = ws->d_Sedge, &d_dP = ws->d_dP, &d_dL = ws->d_dL, &d_lmDiff = ws->d_lmDiff, &d_sums = ws->d_sums, &d_partial = ws->d_partial;
-    auto &d_facKf = ws->d_facKf, &d_facFi = ws->d_facFi, &d_facLp = ws->d_facLp, &d_facLm = ws->d_facLm, &d_lpStart = ws->d_lpStart,
-         &d_lpSlotStart = ws->d_lpSlotStart, &d_slotStart = ws->d_slotStart, &d_slotFi = ws->d_slotFi, &d_lpOrig = ws->d_lpOrig,
-         &d_fidx = ws->d_fidx, &d_flags = ws->d_flags, &d_pairKf = ws->d_pairKf, &d_pairLm = ws->d_pairLm, &d_pairOct = ws->d_pairOct;
-    auto &d_facRight = ws->d_facRight, &d_pairFlags = ws->d_pairFlags, &d_kfLocal = ws->d_kfLocal, &d_kfPresent = ws->d_kfPresent,
-         &d_lmPresent = ws->d_lmPresent, &d_wrong = ws->d_wrong;
+    auto &d_lm0 = ws->d_lm0, &d_lmA = ws->d_lmA, &d_lmB = ws->d_lmB, &d_facJ = ws->d_facJ, &d_S = ws->d_S, &d_Spart = ws->d_Spart,
+         &d_Sedge = ws->d_Sedge, &d_dP = ws->d_dP, &d_dL = ws->d_dL, &d_lmDiff = ws->d_lmDiff, &d_sums = ws->d_sums, &d_partial = ws->d_partial;
+    auto &d_flags = ws->d_flags, &d_pairKf = ws->d_pairKf, &d_pairLm = ws->d_pairLm, &d_pairOct = ws->d_pairOct;
+    auto &d_pairFlags = ws->d_pairFlags, &d_kfLocal = ws->d_kfLocal, &d_wrong = ws->d_wrong;
     auto &d_pairUv = ws->d_pairUv;
-    auto &d_edges = ws->d_edges;
 
     std::vector<DPose> pose0(K);
     for (int k = 0; k < K; k++) pose_from_rm16(P->kf_pose_wc + 16 * (size_t)k, pose0[k]);
@@ -856,7 +983,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
     if (L) VS_HIP(hipMemcpyAsync(d_lm0.p, P->lm_xyz, (size_t)3 * L * sizeof(double), hipMemcpyHostToDevice, stream));
     VS_HIP(d_pairKf.alloc(NP)); VS_HIP(d_pairLm.alloc(NP)); VS_HIP(d_pairOct.alloc((size_t)2 * NP));
     VS_HIP(d_pairFlags.alloc(NP)); VS_HIP(d_pairUv.alloc((size_t)4 * NP)); VS_HIP(d_wrong.alloc(NP));
-    VS_HIP(d_kfLocal.alloc(K)); VS_HIP(d_kfPresent.alloc(K)); VS_HIP(d_lmPresent.alloc(L));
+    VS_HIP(d_kfLocal.alloc(K));
     if (NP) {
         VS_HIP(hipMemcpyAsync(d_pairKf.p, P->pair_kf, NP * sizeof(int), hipMemcpyHostToDevice, stream));
         VS_HIP(hipMemcpyAsync(d_pairLm.p, P->pair_lm, NP * sizeof(int), hipMemcpyHostToDevice, stream));
@@ -868,121 +995,135 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
     VS_HIP(d_sums.alloc(32));
     if (!d_flags.p) { VS_HIP(d_flags.alloc(4)); VS_HIP(hipMemsetAsync(d_flags.p, 0, 4 * sizeof(int), stream)); }
 
-    std::vector<uint8_t> wrong(NP, 0), kfPresent(K), lmPresent(L);
+    std::vector<uint8_t> wrong(NP, 0);
     DPose* poseFinal = d_pose0.p;
     double* lmFinal = d_lm0.p;
     const int nCU = 256;
+    auto& A = ws->arena;
+    auto& T = ws->tmp;
 
 #ifdef VSLAM_HOST_STAMPS
     double bhs_t = bhs_now();
 #endif
     BHS("setup");
     for (int pass = 0; pass < 2; pass++) {
-        // ---- host: factor list of this pass, sorted by (landmark, free index, side) ----------------
-        std::fill(kfPresent.begin(), kfPresent.end(), 0);
-        std::fill(lmPresent.begin(), lmPresent.end(), 0);
-        std::vector<HostFac> facs;
-        facs.reserve((size_t)2 * NP);
+        // ---- host: factor list of this pass, ordered by (landmark, free index, pair, side) -----------
+        // Everything the kernels read is written straight into ONE pinned arena and uploaded with one copy.
+        T.kfPresent.assign(K, 0); T.lmPresent.assign(L, 0); T.cnt.assign((size_t)L + 1, 0);
+        int NF = 0;
         for (int p = 0; p < NP; p++) {
             if (wrong[p]) continue;
-            if (P->pair_flags[p] & 3) { kfPresent[P->pair_kf[p]] = 1; lmPresent[P->pair_lm[p]] = 1; }   // graph membership is global
-            if (P->pair_lm[p] % world != rank) continue;      // landmark shard of this rank
+            const int fl = P->pair_flags[p] & 3;
+            if (!fl) continue;
+            const int l = P->pair_lm[p];
+            T.kfPresent[P->pair_kf[p]] = 1; T.lmPresent[l] = 1;       // graph membership is global
+            if (l % world != rank) continue;                           // landmark shard of this rank
+            const int c = (fl & 1) + (fl >> 1);
+            T.cnt[l] += c; NF += c;
+        }
+        T.fidx.assign(K, -1);
+        int F = 0;
+        for (int k = 0; k < K; k++) if (T.kfPresent[k] && !P->kf_fixed[k]) T.fidx[k] = F++;
+        const int n = 6 * F;
+        T.lpOf.assign(L, -1);
+        int Lp = 0;
+        for (int l = 0; l < L; l++) if (T.lmPresent[l] && l % world == rank) T.lpOf[l] = Lp++;
+        // edges: id-consecutive keyframes of this pass's graph (src/OptimizationBA.cpp:750-768)
+        T.order.clear();
+        for (int k = 0; k < K; k++) if (T.kfPresent[k]) T.order.push_back(k);
+        std::sort(T.order.begin(), T.order.end(), [&](int a, int b) { return P->kf_id[a] < P->kf_id[b]; });
+        // the BetweenFactor chain is counted once (rank 0); S is summed over ranks
+        const int NE = rank == 0 ? std::max((int)T.order.size() - 1, 0) : 0;
+
+        VS_HIP(A.ensure(8192 + (size_t)NF * 48 + ((size_t)NF + Lp + 2) * 8 + ((size_t)Lp + 2) * 12 + (size_t)K * 8 + L +
+                        (size_t)NE * sizeof(BaEdge) + 20 * 256, stream));
+        A.reset();
+        double* h_ctl = A.take<double>(CTL_DOUBLES);
+        int* h_facKf = A.take<int>(NF); int* h_facFi = A.take<int>(NF); int* h_facLp = A.take<int>(NF); int* h_facLm = A.take<int>(NF);
+        double* h_facZ = A.take<double>((size_t)2 * NF); double* h_facIs = A.take<double>(NF);
+        uint8_t* h_facRight = A.take<uint8_t>(NF);
+        int* h_lpStart = A.take<int>(Lp + 1); int* h_lpSlotStart = A.take<int>(Lp + 1); int* h_lpOrig = A.take<int>(Lp);
+        int* h_slotStart = A.take<int>((size_t)NF + Lp + 1); int* h_slotFi = A.take<int>((size_t)NF + Lp + 1);
+        int* h_fidx = A.take<int>(K);
+        BaEdge* h_edges = A.take<BaEdge>(NE);
+        uint8_t* h_kfPresent = A.take<uint8_t>(K); uint8_t* h_lmPresent = A.take<uint8_t>(L);
+        if (!h_lmPresent) { set_error("local BA: upload arena too small"); return VSLAM_ERR_CAPACITY; }
+
+        // bucket by landmark (counting sort, pair order preserved), then order each short bucket by free index
+        for (int l = 0; l < L; l++) if (T.lpOf[l] >= 0) { h_lpOrig[T.lpOf[l]] = l; }
+        {
+            int run = 0;
+            for (int lp = 0; lp < Lp; lp++) { h_lpStart[lp] = run; run += T.cnt[h_lpOrig[lp]]; }
+            h_lpStart[Lp] = run;
+        }
+        T.fill.assign(h_lpStart, h_lpStart + Lp);
+        T.key.resize(NF); T.src.resize(NF);
+        for (int p = 0; p < NP; p++) {
+            if (wrong[p]) continue;
+            const int l = P->pair_lm[p];
+            if (l % world != rank) continue;
+            const int lp = T.lpOf[l];
+            const int fi = T.fidx[P->pair_kf[p]];
             for (int side = 0; side < 2; side++) {
                 if (!((P->pair_flags[p] >> side) & 1)) continue;
-                HostFac f{};
-                f.pair = p; f.kf = P->pair_kf[p]; f.lm = P->pair_lm[p]; f.right = side == 1;
-                f.z[0] = P->pair_uv[4 * (size_t)p + 2 * side]; f.z[1] = P->pair_uv[4 * (size_t)p + 2 * side + 1];
-                f.is = 1.0 / (1.0 / (double)P->inv_sigma_factor[P->pair_octave[2 * p + side]]);
-                facs.push_back(f);
-                kfPresent[f.kf] = 1; lmPresent[f.lm] = 1;
+                const int pos = T.fill[lp]++;
+                T.key[pos] = fi; T.src[pos] = 2 * p + side;
             }
         }
-        std::vector<int> fidx(K, -1);
-        int F = 0;
-        for (int k = 0; k < K; k++) if (kfPresent[k] && !P->kf_fixed[k]) fidx[k] = F++;
-        const int n = 6 * F;
-        std::vector<int> lpOf(L, -1), lpOrig;
-        for (int l = 0; l < L; l++) if (lmPresent[l] && l % world == rank) { lpOf[l] = (int)lpOrig.size(); lpOrig.push_back(l); }
-        const int Lp = (int)lpOrig.size();
-        for (HostFac& f : facs) { f.fi = fidx[f.kf]; f.lp = lpOf[f.lm]; }
-        {   // bucket by landmark (counting sort, stable), then order each short bucket by free index
-            std::vector<int> start(Lp + 1, 0);
-            for (const HostFac& f : facs) start[f.lp + 1]++;
-            for (int l = 0; l < Lp; l++) start[l + 1] += start[l];
-            std::vector<HostFac> sorted(facs.size());
-            std::vector<int> fill(start.begin(), start.end() - 1);
-            for (const HostFac& f : facs) sorted[fill[f.lp]++] = f;
-            for (int l = 0; l < Lp; l++)
-                std::stable_sort(sorted.begin() + start[l], sorted.begin() + start[l + 1],
-                                 [](const HostFac& a, const HostFac& b) { return a.fi < b.fi; });
-            facs.swap(sorted);
-        }
-        const int NF = (int)facs.size();
-        // Slot table: inside a landmark the factors of fixed keyframes (fi = -1) come first, then one
-        // "slot" per free keyframe (its left and/or right factor).  Padded layout: per landmark the slot
-        // starts followed by an end sentinel, so slot s spans [slotStart[s0+s], slotStart[s0+s+1]).
-        std::vector<int> facKf(NF), facFi(NF), facLp(NF), facLm(NF), lpStart(Lp + 1, 0), lpSlotStart(Lp + 1, 0), slotStart, slotFi;
-        std::vector<double> facZ((size_t)2 * NF), facIs(NF);
-        std::vector<uint8_t> facRight(NF);
-        int maxSlots = 1;
+        int maxSlots = 1, nSlotEntries = 0;
         long long sumK2 = 0;
-        {
-            int f = 0;
-            for (int lp = 0; lp < Lp; lp++) {
-                lpStart[lp] = f;
-                lpSlotStart[lp] = (int)slotStart.size();
-                int lastFi = -2, ns = 0;
-                while (f < NF && facs[f].lp == lp) {
-                    if (facs[f].fi >= 0 && facs[f].fi != lastFi) { slotStart.push_back(f); slotFi.push_back(facs[f].fi); lastFi = facs[f].fi; ns++; }
-                    f++;
-                }
-                slotStart.push_back(f);      // end sentinel
-                slotFi.push_back(-1);
-                maxSlots = std::max(maxSlots, ns);
-                sumK2 += (long long)ns * ns;
+        for (int lp = 0; lp < Lp; lp++) {
+            const int f0 = h_lpStart[lp], f1 = h_lpStart[lp + 1];
+            for (int i = f0 + 1; i < f1; i++) {          // stable insertion sort by free index (buckets are ~10 long)
+                const int k = T.key[i], v = T.src[i];
+                int j = i - 1;
+                while (j >= f0 && T.key[j] > k) { T.key[j + 1] = T.key[j]; T.src[j + 1] = T.src[j]; j--; }
+                T.key[j + 1] = k; T.src[j + 1] = v;
             }
-            lpStart[Lp] = f;
-            lpSlotStart[Lp] = (int)slotStart.size();
+            // Slot table: inside a landmark the factors of fixed keyframes (fi = -1) come first, then one
+            // "slot" per free keyframe (its left and/or right factor).  Padded layout: per landmark the slot
+            // starts followed by an end sentinel, so slot s spans [slotStart[s0+s], slotStart[s0+s+1]).
+            h_lpSlotStart[lp] = nSlotEntries;
+            int lastFi = -2, ns = 0;
+            for (int f = f0; f < f1; f++) {
+                const int fi = T.key[f], p = T.src[f] >> 1, side = T.src[f] & 1;
+                if (fi >= 0 && fi != lastFi) { h_slotStart[nSlotEntries] = f; h_slotFi[nSlotEntries] = fi; nSlotEntries++; lastFi = fi; ns++; }
+                h_facKf[f] = P->pair_kf[p]; h_facFi[f] = fi; h_facLp[f] = lp; h_facLm[f] = P->pair_lm[p];
+                h_facZ[2 * (size_t)f] = P->pair_uv[4 * (size_t)p + 2 * side]; h_facZ[2 * (size_t)f + 1] = P->pair_uv[4 * (size_t)p + 2 * side + 1];
+                h_facIs[f] = 1.0 / (1.0 / (double)P->inv_sigma_factor[P->pair_octave[2 * p + side]]);
+                h_facRight[f] = (uint8_t)side;
+            }
+            h_slotStart[nSlotEntries] = f1; h_slotFi[nSlotEntries] = -1; nSlotEntries++;     // end sentinel
+            maxSlots = std::max(maxSlots, ns);
+            sumK2 += (long long)ns * ns;
         }
-        for (int i = 0; i < NF; i++) {
-            facKf[i] = facs[i].kf; facFi[i] = facs[i].fi; facLp[i] = facs[i].lp; facLm[i] = facs[i].lm;
-            facZ[2 * (size_t)i] = facs[i].z[0]; facZ[2 * (size_t)i + 1] = facs[i].z[1];
-            facIs[i] = facs[i].is; facRight[i] = facs[i].right;
-        }
-        // edges: id-consecutive keyframes of this pass's graph (src/OptimizationBA.cpp:750-768)
-        std::vector<int> order;
-        for (int k = 0; k < K; k++) if (kfPresent[k]) order.push_back(k);
-        std::sort(order.begin(), order.end(), [&](int a, int b) { return P->kf_id[a] < P->kf_id[b]; });
-        std::vector<BaEdge> edges;
-        for (size_t i = 0; i + 1 < order.size(); i++) {
+        h_lpSlotStart[Lp] = nSlotEntries;
+        for (int k = 0; k < K; k++) { h_fidx[k] = T.fidx[k]; h_kfPresent[k] = T.kfPresent[k]; }
+        for (int l = 0; l < L; l++) h_lmPresent[l] = T.lmPresent[l];
+        for (int i = 0; i < NE; i++) {
             BaEdge e{};
-            e.a = order[i]; e.b = order[i + 1]; e.fa = fidx[e.a]; e.fb = fidx[e.b];
+            e.a = T.order[i]; e.b = T.order[i + 1]; e.fa = T.fidx[e.a]; e.fb = T.fidx[e.b];
             DPose ai;
             pose_inverse(pose0[e.a], ai);
             pose_compose(ai, pose0[e.b], e.measured);
-            edges.push_back(e);
+            h_edges[i] = e;
         }
-        if (rank != 0) edges.clear();      // the BetweenFactor chain is counted once (rank 0); S is summed over ranks
-        const int NE = (int)edges.size();
-
+        // ---- LM control block (GTSAM 4.2 policy; k_ba_ctl) ---------------------------------------------
+        const int maxIterations = pass == 0 ? 5 : 10;
+        const double relTol = 1e-5, absTol = 1e-5;
+        for (int i = 0; i < CTL_DOUBLES; i++) h_ctl[i] = 0;
+        h_ctl[CTL_LAMBDA] = 1e-5;
+        {
+            int* ci = (int*)(h_ctl + CTL_INTS);
+            ci[CI_STATE] = BA_LINEARIZE; ci[CI_SEL] = 0; ci[CI_ITER] = 0; ci[CI_INNER] = 0; ci[CI_MAXIT] = maxIterations; ci[CI_FIRST] = 1;
+        }
         BHS("prep");
+
         // ---- upload ------------------------------------------------------------------------------
-        VS_HIP(d_facKf.alloc(NF)); VS_HIP(d_facFi.alloc(NF)); VS_HIP(d_facLp.alloc(NF)); VS_HIP(d_facLm.alloc(NF));
-        VS_HIP(d_facZ.alloc((size_t)2 * NF)); VS_HIP(d_facIs.alloc(NF)); VS_HIP(d_facRight.alloc(NF));
+        VS_HIP(A.upload(stream));
         VS_HIP(d_facJ.alloc((size_t)20 * NF));
-        VS_HIP(d_lpStart.alloc(Lp + 1)); VS_HIP(d_lpSlotStart.alloc(Lp + 1)); VS_HIP(d_lpOrig.alloc(Lp)); VS_HIP(d_fidx.alloc(K)); VS_HIP(d_edges.alloc(NE));
         VS_HIP(d_dP.alloc(n)); VS_HIP(d_dL.alloc((size_t)3 * Lp)); VS_HIP(d_S.alloc((size_t)n * n + 2 * n + 8));
         VS_HIP(d_Sedge.alloc((size_t)n * n + n));   // (S | rhs | scratch are contiguous: one all-reduce buffer)
-        VS_HIP(d_slotStart.alloc(slotStart.size() + 1)); VS_HIP(d_slotFi.alloc(slotFi.size() + 1));
-        if (NF) {
-            BA_UP(d_facKf, facKf); BA_UP(d_facFi, facFi); BA_UP(d_facLp, facLp); BA_UP(d_facLm, facLm);
-            BA_UP(d_facZ, facZ); BA_UP(d_facIs, facIs); BA_UP(d_facRight, facRight);
-        }
-        BA_UP(d_lpStart, lpStart); BA_UP(d_lpSlotStart, lpSlotStart);
-        if (!slotStart.empty()) { BA_UP(d_slotStart, slotStart); BA_UP(d_slotFi, slotFi); }
-        if (Lp) BA_UP(d_lpOrig, lpOrig);
-        BA_UP(d_fidx, fidx);
-        if (NE) BA_UP(d_edges, edges);
         VS_HIP(hipMemcpyAsync(d_poseA.p, d_pose0.p, K * sizeof(DPose), hipMemcpyDeviceToDevice, stream));
         VS_HIP(hipMemcpyAsync(d_poseB.p, d_pose0.p, K * sizeof(DPose), hipMemcpyDeviceToDevice, stream));
         if (L) {
@@ -992,13 +1133,14 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
 
         BaDev D{};
         D.NF = NF; D.Lp = Lp; D.F = F; D.K = K; D.NE = NE; D.n = n;
-        D.facKf = d_facKf.p; D.facFi = d_facFi.p; D.facLp = d_facLp.p; D.facLm = d_facLm.p;
-        D.facZ = d_facZ.p; D.facIs = d_facIs.p; D.facRight = d_facRight.p; D.facJ = d_facJ.p;
-        D.lpStart = d_lpStart.p; D.lpSlotStart = d_lpSlotStart.p; D.slotStart = d_slotStart.p; D.slotFi = d_slotFi.p;
-        D.lpOrig = d_lpOrig.p; D.poseCur = d_poseA.p; D.poseTrial = d_poseB.p; D.fidx = d_fidx.p;
-        D.lmCur = d_lmA.p; D.lmTrial = d_lmB.p; D.edges = d_edges.p;
+        D.facKf = A.dev(h_facKf); D.facFi = A.dev(h_facFi); D.facLp = A.dev(h_facLp); D.facLm = A.dev(h_facLm);
+        D.facZ = A.dev(h_facZ); D.facIs = A.dev(h_facIs); D.facRight = A.dev(h_facRight); D.facJ = d_facJ.p;
+        D.lpStart = A.dev(h_lpStart); D.lpSlotStart = A.dev(h_lpSlotStart); D.slotStart = A.dev(h_slotStart); D.slotFi = A.dev(h_slotFi);
+        D.lpOrig = A.dev(h_lpOrig); D.poseCur = d_poseA.p; D.poseTrial = d_poseB.p; D.fidx = A.dev(h_fidx);
+        D.lmCur = d_lmA.p; D.lmTrial = d_lmB.p; D.edges = A.dev(h_edges);
         D.S = d_S.p; D.rhs = d_S.p + (size_t)n * n; D.Sedge = d_Sedge.p; D.dP = d_dP.p; D.dL = d_dL.p; D.sums = d_sums.p; D.flags = d_flags.p;
         D.fx = P->rig.fx; D.fy = P->rig.fy; D.cx = P->rig.cx; D.cy = P->rig.cy; D.b = (double)P->rig.baseline;
+        D.ctl = A.dev(h_ctl);
 
         const int obsBlocks = std::max(1, std::min((NF + 255) / 256, 4 * nCU));
         const bool ldsS = F <= BA_LDS_MAX_F;
@@ -1022,110 +1164,63 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         else VS_HIP(hipFuncSetAttribute((const void*)k_ba_schur<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurLds));
         if (solveLds) VS_HIP(hipFuncSetAttribute((const void*)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solveLdsBytes));
         if (backLds > 48 * 1024) VS_HIP(hipFuncSetAttribute((const void*)k_ba_back, hipFuncAttributeMaxDynamicSharedMemorySize, (int)backLds));
-
         BHS("upload");
-        // ---- LM (GTSAM 4.2 policy) -----------------------------------------------------------------
-        const int maxIterations = pass == 0 ? 5 : 10;
-        const double relTol = 1e-5, absTol = 1e-5;
-        double lambda = 1e-5;
-        int iterations = 0, inner = 0;
-        auto linearize = [&]() -> vslam_status {
+
+        // ---- LM: speculative steps, the device decides (k_ba_ctl) -----------------------------------
+        // One step = [linearise if the state asks for it] + one lambda trial.  Kernels that are not due
+        // return at once, so the host may enqueue a few steps ahead and only then look at the state.
+        auto step = [&]() -> vslam_status {
             int t = g_baTimer.begin("ba_linearize");
             if (NF) hipLaunchKernelGGL(k_ba_linearize, dim3(obsBlocks), dim3(256), 0, stream, D);
-            VS_HIP(hipMemsetAsync(d_Sedge.p, 0, ((size_t)n * n + n) * sizeof(double), stream));
             hipLaunchKernelGGL(k_ba_edges, dim3(std::max(NE, 1)), dim3(64), 0, stream, D, 0, NF ? obsBlocks : 0);
             g_baTimer.end(t);
             if (comm) { const int tc = g_baTimer.begin("ba_allreduce"); VS_CHECK(comm_allreduce(comm, d_sums.p, 1, stream)); g_baTimer.end(tc); }
+            hipLaunchKernelGGL(k_ba_ctl, dim3(1), dim3(1), 0, stream, D, 0, relTol, absTol);
+            t = g_baTimer.begin("ba_schur");
+            if (n > 0) {
+                if (ldsS) hipLaunchKernelGGL(k_ba_schur<true>, dim3(lmBlocks), dim3(64 * schurWaves), schurLds, stream, D, maxSlots);
+                else {
+                    VS_HIP(hipMemsetAsync(d_S.p, 0, ((size_t)n * n + n) * sizeof(double), stream));
+                    hipLaunchKernelGGL(k_ba_schur<false>, dim3(lmBlocks), dim3(64 * schurWaves), schurLds, stream, D, maxSlots);
+                }
+            }
+            g_baTimer.end(t);
+            t = g_baTimer.begin("ba_solve");
+            if (n > 0) hipLaunchKernelGGL(k_ba_reduce, dim3(((int)sysDoubles + 255) / 256, ldsS ? 8 : 1), dim3(256), 0, stream, D, ldsS ? lmBlocks : 0);   // + BetweenFactor blocks
+            if (comm && n > 0) { const int tc = g_baTimer.begin("ba_allreduce"); VS_CHECK(comm_allreduce(comm, d_S.p, (size_t)n * n + n, stream)); g_baTimer.end(tc); }
+            if (n <= BA_WAVE_N) hipLaunchKernelGGL(k_ba_solve_wave, dim3(1), dim3(64), 0, stream, D);
+            else hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(std::max(64, vslam::align_up(n, 64))),
+                                    solveLds ? solveLdsBytes : 64, stream, D, solveLds ? 1 : 0, solveLds ? ldA : n);
+            g_baTimer.end(t);
+            t = g_baTimer.begin("ba_back");
+            if (Lp) hipLaunchKernelGGL(k_ba_back, dim3(lmBlocks), dim3(64 * schurWaves), backLds, stream, D, maxSlots);
+            g_baTimer.end(t);
+            t = g_baTimer.begin("ba_eval");
+            if (NF) hipLaunchKernelGGL(k_ba_eval, dim3(obsBlocks), dim3(256), 0, stream, D);
+            hipLaunchKernelGGL(k_ba_edges, dim3(std::max(NE, 1)), dim3(64), 0, stream, D, 1, NF ? obsBlocks : 0);
+            g_baTimer.end(t);
+            if (comm) { const int tc = g_baTimer.begin("ba_allreduce"); VS_CHECK(comm_allreduce(comm, d_sums.p + 1, 2, stream)); g_baTimer.end(tc); }
+            hipLaunchKernelGGL(k_ba_ctl, dim3(1), dim3(1), 0, stream, D, 1, relTol, absTol);
+            VS_HIP(hipGetLastError());
             return VSLAM_OK;
         };
-        VS_CHECK(linearize());
-        double sums[3];
-        VS_HIP(hipMemcpyAsync(sums, d_sums.p, sizeof(double), hipMemcpyDeviceToHost, stream));
-        VS_HIP(hipStreamSynchronize(stream));
-        double error = sums[0];
-        const double initialError = error;
-        bool linearized = true;
-        if (!(error <= 0.0) && iterations < maxIterations) {
-            double newError = error, currentError;
-            do {
-                currentError = newError;
-                if (!linearized) VS_CHECK(linearize());
-                linearized = false;
-                for (;;) {   // tryLambda
-                    int t = g_baTimer.begin("ba_schur");
-                    if (n > 0) {
-                        if (ldsS) hipLaunchKernelGGL(k_ba_schur<true>, dim3(lmBlocks), dim3(64 * schurWaves), schurLds, stream, D, lambda, maxSlots);
-                        else {
-                            VS_HIP(hipMemsetAsync(d_S.p, 0, ((size_t)n * n + n) * sizeof(double), stream));
-                            hipLaunchKernelGGL(k_ba_schur<false>, dim3(lmBlocks), dim3(64 * schurWaves), schurLds, stream, D, lambda, maxSlots);
-                        }
-                    }
-                    g_baTimer.end(t);
-                    t = g_baTimer.begin("ba_solve");
-                    if (n > 0 && ldsS) {
-                        VS_HIP(hipMemsetAsync(d_S.p, 0, ((size_t)n * n + n) * sizeof(double), stream));
-                        hipLaunchKernelGGL(k_ba_reduce, dim3(((int)sysDoubles + 255) / 256, 8), dim3(256), 0, stream, D, lmBlocks);
-                    } else if (n > 0) {
-                        hipLaunchKernelGGL(k_ba_reduce, dim3(((int)sysDoubles + 255) / 256, 1), dim3(256), 0, stream, D, 0);   // + BetweenFactor blocks
-                    }
-                    if (comm && n > 0) { const int tc = g_baTimer.begin("ba_allreduce"); VS_CHECK(comm_allreduce(comm, d_S.p, (size_t)n * n + n, stream)); g_baTimer.end(tc); }
-                    if (n <= BA_WAVE_N) hipLaunchKernelGGL(k_ba_solve_wave, dim3(1), dim3(64), 0, stream, D, lambda);
-                    else hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(std::max(64, vslam::align_up(n, 64))),
-                                            solveLds ? solveLdsBytes : 64, stream, D, lambda, solveLds ? 1 : 0, solveLds ? ldA : n);
-                    g_baTimer.end(t);
-                    t = g_baTimer.begin("ba_back");
-                    if (Lp) hipLaunchKernelGGL(k_ba_back, dim3(lmBlocks), dim3(64 * schurWaves), backLds, stream, D, lambda, maxSlots);
-                    g_baTimer.end(t);
-                    t = g_baTimer.begin("ba_eval");
-                    if (NF) hipLaunchKernelGGL(k_ba_eval, dim3(obsBlocks), dim3(256), 0, stream, D);
-                    hipLaunchKernelGGL(k_ba_edges, dim3(std::max(NE, 1)), dim3(64), 0, stream, D, 1, NF ? obsBlocks : 0);
-                    g_baTimer.end(t);
-                    if (comm) { const int tc = g_baTimer.begin("ba_allreduce"); VS_CHECK(comm_allreduce(comm, d_sums.p + 1, 2, stream)); g_baTimer.end(tc); }
-                    VS_HIP(hipGetLastError());
-                    int fail = 0;
-#ifdef VSLAM_BA_STAMPS
-                    { double st[16]; hipMemcpy(st, d_sums.p + 8, 7 * sizeof(double), hipMemcpyDeviceToHost); fprintf(stderr, "solve stamps (cycles): load %.0f edges %.0f chol %.0f fwd %.0f bwd %.0f retract %.0f\n", st[1]-st[0], st[2]-st[1], st[3]-st[2], st[4]-st[3], st[5]-st[4], st[6]-st[5]); }
-#endif
-                    VS_HIP(hipMemcpyAsync(sums, d_sums.p, 3 * sizeof(double), hipMemcpyDeviceToHost, stream));
-                    VS_HIP(hipMemcpyAsync(&fail, d_flags.p, sizeof(int), hipMemcpyDeviceToHost, stream));
-                    VS_HIP(hipStreamSynchronize(stream));
-                    bool stepOk = false, stop = false;
-                    double newErr = INFINITY;
-                    const double linChange = error - sums[1];
-                    if (!fail && linChange >= 0) {
-                        newErr = sums[2];
-                        const double costChange = error - newErr;
-                        if (linChange > DBL_EPSILON * error) stepOk = (costChange / linChange) > 1e-3;
-                        if (std::fabs(costChange) < relTol * error) stop = true;
-                    }
-                    if (stepOk) {
-                        std::swap(D.poseCur, D.poseTrial);
-                        std::swap(D.lmCur, D.lmTrial);   // every present landmark / every pose is rewritten per trial
-                        error = newErr;
-                        lambda = std::max(0.0, lambda / 10.0);
-                        iterations++; inner++;
-                        break;
-                    } else if (!stop) {
-                        lambda *= 10.0;
-                        inner++;
-                        if (lambda >= 1e5) break;
-                    } else break;
-                }
-                newError = error;
-                bool converged;
-                if (newError <= 0.0) converged = true;
-                else {
-                    const double absDec = currentError - newError, relDec = absDec / currentError;
-                    converged = (relDec <= relTol) || (absDec <= absTol);
-                }
-                if (!(iterations < maxIterations && !converged && std::isfinite(currentError))) break;
-            } while (true);
+        double* h_ctlOut = ws->h_ctlOut;
+        const int* co = (const int*)(h_ctlOut + CTL_INTS);
+        int enq = 0;
+        for (;;) {
+            for (int b = 0; b < 4; b++) VS_CHECK(step());
+            enq += 4;
+            VS_HIP(hipMemcpyAsync(h_ctlOut, D.ctl, CTL_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, stream));
+            VS_HIP(hipStreamSynchronize(stream));
+            if (co[CI_STATE] == BA_DONE) break;
+            if (enq > 400) { set_error("local BA: LM did not terminate"); return VSLAM_ERR_INVALID; }
         }
-        R->report[pass].iterations = iterations;
-        R->report[pass].inner_iterations = inner;
-        R->report[pass].initial_error = initialError;
-        R->report[pass].final_error = error;
-        R->report[pass].lambda = lambda;
+        if (co[CI_SEL]) { std::swap(D.poseCur, D.poseTrial); std::swap(D.lmCur, D.lmTrial); }
+        R->report[pass].iterations = co[CI_ITER];
+        R->report[pass].inner_iterations = co[CI_INNER];
+        R->report[pass].initial_error = h_ctlOut[CTL_INIT_ERR];
+        R->report[pass].final_error = h_ctlOut[CTL_ERROR];
+        R->report[pass].lambda = h_ctlOut[CTL_LAMBDA];
         R->n_residuals = NF; R->n_landmarks = Lp; R->n_free_kf = F; R->sum_k2 = sumK2;
 
         if (comm) {
@@ -1147,11 +1242,9 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         }
         BHS("lm");
         // ---- chi2 re-check with the optimised values ---------------------------------------------
-        VS_HIP(hipMemcpyAsync(d_kfPresent.p, kfPresent.data(), K, hipMemcpyHostToDevice, stream));
-        if (L) VS_HIP(hipMemcpyAsync(d_lmPresent.p, lmPresent.data(), L, hipMemcpyHostToDevice, stream));
         BaChi C{};
         C.NP = NP; C.pairKf = d_pairKf.p; C.pairLm = d_pairLm.p; C.pairFlags = d_pairFlags.p; C.pairUv = d_pairUv.p;
-        C.pairOct = d_pairOct.p; C.kfLocal = d_kfLocal.p; C.kfPresent = d_kfPresent.p; C.lmPresent = d_lmPresent.p;
+        C.pairOct = d_pairOct.p; C.kfLocal = d_kfLocal.p; C.kfPresent = A.dev(h_kfPresent); C.lmPresent = A.dev(h_lmPresent);
         C.pose = D.poseCur; C.lm = D.lmCur; C.wrong = d_wrong.p;
         for (int l = 0; l < P->n_levels; l++) C.thr[l] = (float)((double)7.815f * (double)P->sigma_factor[l]);
         C.fx = D.fx; C.fy = D.fy; C.cx = D.cx; C.cy = D.cy; C.b = D.b;
@@ -1159,8 +1252,9 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         if (NP) hipLaunchKernelGGL(k_ba_chi2, dim3((NP + 255) / 256), dim3(256), 0, stream, C);
         g_baTimer.end(t);
         VS_HIP(hipGetLastError());
-        if (NP) VS_HIP(hipMemcpyAsync(wrong.data(), d_wrong.p, NP, hipMemcpyDeviceToHost, stream));
+        if (NP) VS_HIP(hipMemcpyAsync(ws->h_wrong, d_wrong.p, NP, hipMemcpyDeviceToHost, stream));
         VS_HIP(hipStreamSynchronize(stream));
+        if (NP) memcpy(wrong.data(), ws->h_wrong, NP);
         if (pass == 0 && R->pair_wrong_pass1 && NP) memcpy(R->pair_wrong_pass1, wrong.data(), NP);
         poseFinal = D.poseCur;
         lmFinal = D.lmCur;
