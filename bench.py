@@ -206,7 +206,7 @@ def main():
         if rec:
             counters["sampled_frames"] += 1
             add(fm.timings())
-        if n % KF_PERIOD == KF_PERIOD - 1:
+        if n % KF_PERIOD == KF_PERIOD - 1 and not os.environ.get("VSLAM_BENCH_SKIP_BA"):     # (diagnostic switch only)
             ba_state["record"] = record
             ba_q.put(1)          # blocks while the previous local BA is still running
 

@@ -141,138 +141,223 @@ __device__ __forceinline__ void ba_block_sum(double (&v)[NV], double* red, doubl
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_ba_linearize(BaDev D) {
-    __shared__ double red[4], out[1];
-    if (!ba_enter(D, BA_LINEARIZE)) return;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < D.n * D.n + D.n; i += gridDim.x * 256) D.Sedge[i] = 0;   // the edge kernel accumulates into it
-    double e[1] = {0};
-    for (int f = blockIdx.x * 256 + threadIdx.x; f < D.NF; f += gridDim.x * 256) {
-        double r[2], Jp[12], Jl[6];
-        ba_eval_fac(D, D.poseCur[D.facKf[f]], D.lmCur + 3 * (size_t)D.facLm[f], D.facRight[f], D.facZ + 2 * (size_t)f,
-                    D.facIs[f], r, Jp, Jl);
-        double* o = D.facJ + (size_t)f * 20;
-        o[0] = r[0]; o[1] = r[1];
-        for (int c = 0; c < 12; c++) o[2 + c] = Jp[c];
-        for (int c = 0; c < 6; c++) o[14 + c] = Jl[c];
-        e[0] += r[0] * r[0] + r[1] * r[1];
+// LevenbergMarquardtOptimizer::iterate / tryLambda bookkeeping (GTSAM 4.2, SURVEY App. B.2), one thread.
+// mode 0: after a linearisation (sums[0] = current error);  mode 1: after a trial (sums[1] = linearised
+// cost at delta, sums[2] = cost at the trial values, flags[0] = Cholesky failure).
+__device__ __forceinline__ void ba_ctl(const BaDev& D, int mode, double relTol, double absTol) {
+    double* c = D.ctl;
+    int* ci = (int*)(D.ctl + CTL_INTS);
+    if (mode == 0) {
+        if (ci[CI_STATE] != BA_LINEARIZE) return;
+        if (ci[CI_FIRST]) {
+            ci[CI_FIRST] = 0;
+            c[CTL_ERROR] = D.sums[0];
+            c[CTL_INIT_ERR] = D.sums[0];
+            ci[CI_STATE] = (!(c[CTL_ERROR] <= 0.0) && ci[CI_ITER] < ci[CI_MAXIT]) ? BA_TRY : BA_DONE;
+        } else ci[CI_STATE] = BA_TRY;
+        c[CTL_CUR] = c[CTL_ERROR];          // currentError = newError at the top of the do-body
+        return;
     }
-    ba_block_sum<1, 4>(e, red, out);
-    if (threadIdx.x == 0) D.partial[blockIdx.x] = out[0];
+    if (ci[CI_STATE] != BA_TRY) return;
+    const double error = c[CTL_ERROR];
+    double lambda = c[CTL_LAMBDA];
+    bool stepOk = false, stop = false;
+    double newErr = INFINITY;
+    const double linChange = error - D.sums[1];
+    if (!D.flags[0] && linChange >= 0) {
+        newErr = D.sums[2];
+        const double costChange = error - newErr;
+        if (linChange > DBL_EPSILON * error) stepOk = (costChange / linChange) > 1e-3;
+        if (fabs(costChange) < relTol * error) stop = true;
+    }
+    bool endInner = false;
+    if (stepOk) {
+        ci[CI_SEL] ^= 1;                    // every present landmark / every pose is rewritten per trial
+        c[CTL_ERROR] = newErr;
+        lambda = lambda / 10.0;
+        c[CTL_LAMBDA] = lambda > 0.0 ? lambda : 0.0;
+        ci[CI_ITER]++; ci[CI_INNER]++;
+        endInner = true;
+    } else if (!stop) {
+        lambda *= 10.0;
+        c[CTL_LAMBDA] = lambda;
+        ci[CI_INNER]++;
+        if (lambda >= 1e5) endInner = true;
+    } else endInner = true;
+    if (!endInner) return;                   // same linearisation, larger lambda
+    const double currentError = c[CTL_CUR], newError = c[CTL_ERROR];
+    bool converged;
+    if (newError <= 0.0) converged = true;
+    else {
+        const double absDec = currentError - newError, relDec = absDec / currentError;
+        converged = (relDec <= relTol) || (absDec <= absTol);
+    }
+    ci[CI_STATE] = (ci[CI_ITER] < ci[CI_MAXIT] && !converged && isfinite(currentError)) ? BA_LINEARIZE : BA_DONE;
 }
 
-// mode 0: linearise edges at poseCur, sums[0] = 0.5*(sum partial + edges)   (lin0 / current error)
-// mode 1: evaluate edges at poseTrial: sums[1] = linearised cost at delta, sums[2] = trial cost
-// BetweenFactor<Pose3> edges + the final reduction of the observation kernels' partial sums.  One single-wave
-// workgroup per edge (the Lie-group algebra of the linearisation wants the full register file): lane 0 does
-// logmap / its derivative / the adjoint, the 6x6 products and the scatter into the reduced system are spread
-// over 36 lanes.  The last workgroup to finish sums the partials in array order (deterministic).
-__global__ __launch_bounds__(64) void k_ba_edges(BaDev D, int mode, int nPartial) {
-    __shared__ double sW[160];       // Hl 36 | Ad 36 | Ja 36 | Jb 36 | r 6
+// The control step as its own launch: the multi-GPU path, where the cost sums are all-reduced between the
+// evaluation and the decision.  After a trial that ends the inner loop the edge accumulator is cleared for the
+// next linearisation (the fused kernel below does the same in its last workgroup).
+__global__ __launch_bounds__(256) void k_ba_ctl(BaDev D, int mode, double relTol, double absTol) {
+    __shared__ int sZero;
+    if (threadIdx.x == 0) {
+        ba_ctl(D, mode, relTol, absTol);
+        sZero = mode == 1 && ((const int*)(D.ctl + CTL_INTS))[CI_STATE] == BA_LINEARIZE;
+    }
+    __syncthreads();
+    if (sZero) for (int i = threadIdx.x; i < D.n * D.n + D.n; i += 256) D.Sedge[i] = 0;
+}
+
+// One launch per half-step: observation factors (one workgroup per 256-factor slice), BetweenFactor<Pose3>
+// edges (one workgroup each, wave 0: the Lie-group algebra of the linearisation wants a large register
+// budget; lane 0 does logmap / its derivative / the adjoint, the 6x6 products and the scatter into the reduced
+// system are spread over 36 lanes), then the LAST workgroup to finish sums every partial in array order
+// (deterministic) and - single GPU - takes the LM decision.
+//   MODE 0: linearise at the current values: facJ, edge blocks into Sedge, sums[0] = current error
+//   MODE 1: evaluate a trial: sums[1] = linearised cost at delta, sums[2] = cost at the trial values
+template <int MODE>
+__global__ __launch_bounds__(256) void k_ba_factors(BaDev D, int obsBlocks, int fuseCtl, double relTol, double absTol) {
+    __shared__ double red[8], out[2];
+    __shared__ double sW[160];       // edge scratch: Hl 36 | Ad 36 | Ja 36 | Jb 36 | r 6
     __shared__ int sLast;
-    const int lane = threadIdx.x, e = blockIdx.x;
-    if (!ba_enter(D, mode == 0 ? BA_LINEARIZE : BA_TRY)) return;
-    double* Hl = sW; double* Ad = Hl + 36; double* Ja = Ad + 36; double* Jb = Ja + 36; double* rr = Jb + 36;
-    const double w = 1.0 / 0.01;
-    double v[2] = {0, 0};
-    if (e < D.NE) {
-        BaEdge& E = D.edges[e];
-        const int fa = E.fa, fb = E.fb, n = D.n;
-        if (mode == 0) {
-            if (lane == 0) {
-                DPose Tai, h, Mi, d, hi;
-                pose_inverse(D.poseCur[E.a], Tai);
-                pose_compose(Tai, D.poseCur[E.b], h);
-                pose_inverse(E.measured, Mi);
-                pose_compose(Mi, h, d);
-                double r[6];
-                pose3_logmap(d, r);
-                for (int i = 0; i < 6; i++) { r[i] *= w; rr[i] = r[i]; E.r[i] = r[i]; v[0] += r[i] * r[i]; }
-                pose3_logmap_derivative(d, Hl);
-                pose_inverse(h, hi);
-                pose3_adjoint(hi, Ad);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const int i = lane / 6, j = lane % 6;
-            if (lane < 36) {
-                double s = 0;
-                for (int k = 0; k < 6; k++) s += Hl[i * 6 + k] * Ad[k * 6 + j];
-                const double ja = -s * w, jb = Hl[i * 6 + j] * w;
-                Ja[lane] = ja; Jb[lane] = jb;
-                E.Ja[lane] = ja; E.Jb[lane] = jb;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane < 36) {
-                double aa = 0, ab = 0, bb = 0;
-                for (int k = 0; k < 6; k++) {
-                    aa += Ja[k * 6 + i] * Ja[k * 6 + j];
-                    ab += Ja[k * 6 + i] * Jb[k * 6 + j];
-                    bb += Jb[k * 6 + i] * Jb[k * 6 + j];
+    if (!ba_enter(D, MODE == 0 ? BA_LINEARIZE : BA_TRY)) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if ((int)blockIdx.x < obsBlocks) {
+        double v[2] = {0, 0};
+        for (int f = blockIdx.x * 256 + tid; f < D.NF; f += obsBlocks * 256) {
+            if (MODE == 0) {
+                double r[2], Jp[12], Jl[6];
+                ba_eval_fac(D, D.poseCur[D.facKf[f]], D.lmCur + 3 * (size_t)D.facLm[f], D.facRight[f], D.facZ + 2 * (size_t)f,
+                            D.facIs[f], r, Jp, Jl);
+                double* o = D.facJ + (size_t)f * 20;
+                o[0] = r[0]; o[1] = r[1];
+                for (int c = 0; c < 12; c++) o[2 + c] = Jp[c];
+                for (int c = 0; c < 6; c++) o[14 + c] = Jl[c];
+                v[0] += r[0] * r[0] + r[1] * r[1];
+            } else {
+                const double* o = D.facJ + (size_t)f * 20;
+                const int fi = D.facFi[f], lp = D.facLp[f];
+                double l0 = o[0], l1 = o[1];
+                if (fi >= 0) {
+                    const double* dp = D.dP + 6 * fi;
+                    for (int i = 0; i < 6; i++) { l0 += o[2 + i] * dp[i]; l1 += o[8 + i] * dp[i]; }
                 }
-                E.Haa[lane] = aa; E.Hab[lane] = ab; E.Hbb[lane] = bb;
-                if (fa >= 0) atomicAdd(&D.Sedge[(size_t)(6 * fa + i) * n + 6 * fa + j], aa);
-                if (fb >= 0) atomicAdd(&D.Sedge[(size_t)(6 * fb + i) * n + 6 * fb + j], bb);
-                if (fa >= 0 && fb >= 0) {     // upper triangle only (the solve mirrors it)
-                    if (fa < fb) atomicAdd(&D.Sedge[(size_t)(6 * fa + i) * n + 6 * fb + j], ab);
-                    else atomicAdd(&D.Sedge[(size_t)(6 * fb + j) * n + 6 * fa + i], ab);
-                }
-            } else if (lane < 42) {
-                const int q = lane - 36;
-                double ga = 0, gb = 0;
-                for (int k = 0; k < 6; k++) { ga += Ja[k * 6 + q] * rr[k]; gb += Jb[k * 6 + q] * rr[k]; }
-                E.ga[q] = ga; E.gb[q] = gb;
-                if (fa >= 0) atomicAdd(&D.Sedge[(size_t)n * n + 6 * fa + q], -ga);
-                if (fb >= 0) atomicAdd(&D.Sedge[(size_t)n * n + 6 * fb + q], -gb);
-            }
-        } else {
-            if (lane == 0) {
-                DPose Tai, h, Mi, d;
-                pose_inverse(D.poseTrial[E.a], Tai);
-                pose_compose(Tai, D.poseTrial[E.b], h);
-                pose_inverse(E.measured, Mi);
-                pose_compose(Mi, h, d);
-                double r[6];
-                pose3_logmap(d, r);
-                for (int i = 0; i < 6; i++) { r[i] *= w; v[1] += r[i] * r[i]; }
-            } else if (lane >= 8 && lane < 14) {
-                const int k = lane - 8;
-                double l = E.r[k];
-                for (int i = 0; i < 6; i++) {
-                    if (fa >= 0) l += E.Ja[k * 6 + i] * D.dP[6 * fa + i];
-                    if (fb >= 0) l += E.Jb[k * 6 + i] * D.dP[6 * fb + i];
-                }
-                v[0] += l * l;
+                const double* dl = D.dL + 3 * (size_t)lp;
+                for (int i = 0; i < 3; i++) { l0 += o[14 + i] * dl[i]; l1 += o[17 + i] * dl[i]; }
+                v[0] += l0 * l0 + l1 * l1;
+                double r[2];
+                ba_eval_fac(D, D.poseTrial[D.facKf[f]], D.lmTrial + 3 * (size_t)D.facLm[f], D.facRight[f], D.facZ + 2 * (size_t)f,
+                            D.facIs[f], r, nullptr, nullptr);
+                v[1] += r[0] * r[0] + r[1] * r[1];
             }
         }
+        ba_block_sum<2, 4>(v, red, out);
+        if (tid == 0) { D.partial[2 * blockIdx.x] = out[0]; D.partial[2 * blockIdx.x + 1] = out[1]; }
+    } else if (tid < 64) {
+        const int e = blockIdx.x - obsBlocks;
+        double* Hl = sW; double* Ad = Hl + 36; double* Ja = Ad + 36; double* Jb = Ja + 36; double* rr = Jb + 36;
+        const double w = 1.0 / 0.01;
+        double v[2] = {0, 0};
+        if (e < D.NE) {
+            BaEdge& E = D.edges[e];
+            const int fa = E.fa, fb = E.fb, n = D.n;
+            if (MODE == 0) {
+                if (lane == 0) {
+                    DPose Tai, h, Mi, d, hi;
+                    pose_inverse(D.poseCur[E.a], Tai);
+                    pose_compose(Tai, D.poseCur[E.b], h);
+                    pose_inverse(E.measured, Mi);
+                    pose_compose(Mi, h, d);
+                    double r[6];
+                    pose3_logmap(d, r);
+                    for (int i = 0; i < 6; i++) { r[i] *= w; rr[i] = r[i]; E.r[i] = r[i]; v[0] += r[i] * r[i]; }
+                    pose3_logmap_derivative(d, Hl);
+                    pose_inverse(h, hi);
+                    pose3_adjoint(hi, Ad);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const int i = lane / 6, j = lane % 6;
+                if (lane < 36) {
+                    double s = 0;
+                    for (int k = 0; k < 6; k++) s += Hl[i * 6 + k] * Ad[k * 6 + j];
+                    const double ja = -s * w, jb = Hl[i * 6 + j] * w;
+                    Ja[lane] = ja; Jb[lane] = jb;
+                    E.Ja[lane] = ja; E.Jb[lane] = jb;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane < 36) {
+                    double aa = 0, ab = 0, bb = 0;
+                    for (int k = 0; k < 6; k++) {
+                        aa += Ja[k * 6 + i] * Ja[k * 6 + j];
+                        ab += Ja[k * 6 + i] * Jb[k * 6 + j];
+                        bb += Jb[k * 6 + i] * Jb[k * 6 + j];
+                    }
+                    E.Haa[lane] = aa; E.Hab[lane] = ab; E.Hbb[lane] = bb;
+                    if (fa >= 0) atomicAdd(&D.Sedge[(size_t)(6 * fa + i) * n + 6 * fa + j], aa);
+                    if (fb >= 0) atomicAdd(&D.Sedge[(size_t)(6 * fb + i) * n + 6 * fb + j], bb);
+                    if (fa >= 0 && fb >= 0) {     // upper triangle only (the solve mirrors it)
+                        if (fa < fb) atomicAdd(&D.Sedge[(size_t)(6 * fa + i) * n + 6 * fb + j], ab);
+                        else atomicAdd(&D.Sedge[(size_t)(6 * fb + j) * n + 6 * fa + i], ab);
+                    }
+                } else if (lane < 42) {
+                    const int q = lane - 36;
+                    double ga = 0, gb = 0;
+                    for (int k = 0; k < 6; k++) { ga += Ja[k * 6 + q] * rr[k]; gb += Jb[k * 6 + q] * rr[k]; }
+                    E.ga[q] = ga; E.gb[q] = gb;
+                    if (fa >= 0) atomicAdd(&D.Sedge[(size_t)n * n + 6 * fa + q], -ga);
+                    if (fb >= 0) atomicAdd(&D.Sedge[(size_t)n * n + 6 * fb + q], -gb);
+                }
+            } else {
+                if (lane == 0) {
+                    DPose Tai, h, Mi, d;
+                    pose_inverse(D.poseTrial[E.a], Tai);
+                    pose_compose(Tai, D.poseTrial[E.b], h);
+                    pose_inverse(E.measured, Mi);
+                    pose_compose(Mi, h, d);
+                    double r[6];
+                    pose3_logmap(d, r);
+                    for (int i = 0; i < 6; i++) { r[i] *= w; v[1] += r[i] * r[i]; }
+                } else if (lane >= 8 && lane < 14) {
+                    const int k = lane - 8;
+                    double l = E.r[k];
+                    for (int i = 0; i < 6; i++) {
+                        if (fa >= 0) l += E.Ja[k * 6 + i] * D.dP[6 * fa + i];
+                        if (fb >= 0) l += E.Jb[k * 6 + i] * D.dP[6 * fb + i];
+                    }
+                    v[0] += l * l;
+                }
+            }
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
+            for (int k = 0; k < 2; k++) {
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) v[k] += __shfl_xor(v[k], d);
+                for (int d = 32; d >= 1; d >>= 1) v[k] += __shfl_xor(v[k], d);
+            }
+            if (lane == 0) { D.partial[2 * obsBlocks + 2 * e] = v[0]; D.partial[2 * obsBlocks + 2 * e + 1] = v[1]; }
         }
-        if (lane == 0) { D.partial[2 * nPartial + 2 * e] = v[0]; D.partial[2 * nPartial + 2 * e + 1] = v[1]; }
     }
     // the last workgroup to arrive sums every partial in array order
     __threadfence();
-    if (lane == 0) sLast = (atomicAdd(&D.flags[1], 1) == (int)gridDim.x - 1);
+    __syncthreads();
+    if (tid == 0) sLast = (atomicAdd(&D.flags[1], 1) == (int)gridDim.x - 1);
     __syncthreads();
     if (!sLast) return;
     __threadfence();
     double t[2] = {0, 0};
-    // obs kernels: mode 0 -> 1 value per block, mode 1 -> 2 values per block; edges: 2 values per edge
-    for (int i = lane; i < nPartial; i += 64) {
-        if (mode == 0) t[0] += D.partial[i];
-        else { t[0] += D.partial[2 * i]; t[1] += D.partial[2 * i + 1]; }
-    }
-    for (int i = lane; i < D.NE; i += 64) { t[0] += D.partial[2 * nPartial + 2 * i]; t[1] += D.partial[2 * nPartial + 2 * i + 1]; }
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) t[k] += __shfl_xor(t[k], d);
-    }
-    if (lane == 0) {
-        if (mode == 0) D.sums[0] = 0.5 * t[0];
-        else { D.sums[1] = 0.5 * t[0]; D.sums[2] = 0.5 * t[1]; }
+    const int nPart = obsBlocks + D.NE;         // (edge partials follow the observation partials)
+    for (int i = tid; i < nPart; i += 256) { t[0] += D.partial[2 * i]; t[1] += D.partial[2 * i + 1]; }
+    ba_block_sum<2, 4>(t, red, out);
+    if (tid == 0) {
+        if (MODE == 0) D.sums[0] = 0.5 * out[0];
+        else { D.sums[1] = 0.5 * out[0]; D.sums[2] = 0.5 * out[1]; }
         D.flags[1] = 0;
+        sLast = 0;
+        if (fuseCtl) {
+            ba_ctl(D, MODE, relTol, absTol);
+            sLast = MODE == 1 && ((const int*)(D.ctl + CTL_INTS))[CI_STATE] == BA_LINEARIZE;
+        }
     }
+    __syncthreads();
+    if (sLast) for (int i = tid; i < D.n * D.n + D.n; i += 256) D.Sedge[i] = 0;     // cleared for the next linearisation
 }
 
 // ---- landmark blocks shared by the Schur and back-substitution kernels ---------------------------
@@ -727,30 +812,6 @@ __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_back(BaDev D, int ma
     }
 }
 
-__global__ __launch_bounds__(256) void k_ba_eval(BaDev D) {
-    __shared__ double red[8], out[2];
-    if (!ba_enter(D, BA_TRY)) return;
-    double v[2] = {0, 0};
-    for (int f = blockIdx.x * 256 + threadIdx.x; f < D.NF; f += gridDim.x * 256) {
-        const double* o = D.facJ + (size_t)f * 20;
-        const int fi = D.facFi[f], lp = D.facLp[f];
-        double l0 = o[0], l1 = o[1];
-        if (fi >= 0) {
-            const double* dp = D.dP + 6 * fi;
-            for (int i = 0; i < 6; i++) { l0 += o[2 + i] * dp[i]; l1 += o[8 + i] * dp[i]; }
-        }
-        const double* dl = D.dL + 3 * (size_t)lp;
-        for (int i = 0; i < 3; i++) { l0 += o[14 + i] * dl[i]; l1 += o[17 + i] * dl[i]; }
-        v[0] += l0 * l0 + l1 * l1;
-        double r[2];
-        ba_eval_fac(D, D.poseTrial[D.facKf[f]], D.lmTrial + 3 * (size_t)D.facLm[f], D.facRight[f], D.facZ + 2 * (size_t)f,
-                    D.facIs[f], r, nullptr, nullptr);
-        v[1] += r[0] * r[0] + r[1] * r[1];
-    }
-    ba_block_sum<2, 4>(v, red, out);
-    if (threadIdx.x == 0) { D.partial[2 * blockIdx.x] = out[0]; D.partial[2 * blockIdx.x + 1] = out[1]; }
-}
-
 // chi2 re-check (src/OptimizationBA.cpp:787-871): pair-parallel
 struct BaChi {
     int NP; const int* pairKf; const int* pairLm; const uint8_t* pairFlags; const float* pairUv; const int* pairOct;
@@ -764,60 +825,6 @@ __device__ __forceinline__ bool ba_outlier(const BaChi& C, const double* pc, flo
     const double eu = (double)ou - px / z, ev = (double)ov - py / z;
     return (eu * eu + ev * ev) > (double)C.thr[oct];
 }
-// LevenbergMarquardtOptimizer::iterate / tryLambda bookkeeping (GTSAM 4.2, SURVEY App. B.2), one thread.
-// mode 0: after a linearisation (sums[0] = current error);  mode 1: after a trial (sums[1] = linearised
-// cost at delta, sums[2] = cost at the trial values, flags[0] = Cholesky failure).
-__global__ void k_ba_ctl(BaDev D, int mode, double relTol, double absTol) {
-    double* c = D.ctl;
-    int* ci = (int*)(D.ctl + CTL_INTS);
-    if (mode == 0) {
-        if (ci[CI_STATE] != BA_LINEARIZE) return;
-        if (ci[CI_FIRST]) {
-            ci[CI_FIRST] = 0;
-            c[CTL_ERROR] = D.sums[0];
-            c[CTL_INIT_ERR] = D.sums[0];
-            ci[CI_STATE] = (!(c[CTL_ERROR] <= 0.0) && ci[CI_ITER] < ci[CI_MAXIT]) ? BA_TRY : BA_DONE;
-        } else ci[CI_STATE] = BA_TRY;
-        c[CTL_CUR] = c[CTL_ERROR];          // currentError = newError at the top of the do-body
-        return;
-    }
-    if (ci[CI_STATE] != BA_TRY) return;
-    const double error = c[CTL_ERROR];
-    double lambda = c[CTL_LAMBDA];
-    bool stepOk = false, stop = false;
-    double newErr = INFINITY;
-    const double linChange = error - D.sums[1];
-    if (!D.flags[0] && linChange >= 0) {
-        newErr = D.sums[2];
-        const double costChange = error - newErr;
-        if (linChange > DBL_EPSILON * error) stepOk = (costChange / linChange) > 1e-3;
-        if (fabs(costChange) < relTol * error) stop = true;
-    }
-    bool endInner = false;
-    if (stepOk) {
-        ci[CI_SEL] ^= 1;                    // every present landmark / every pose is rewritten per trial
-        c[CTL_ERROR] = newErr;
-        lambda = lambda / 10.0;
-        c[CTL_LAMBDA] = lambda > 0.0 ? lambda : 0.0;
-        ci[CI_ITER]++; ci[CI_INNER]++;
-        endInner = true;
-    } else if (!stop) {
-        lambda *= 10.0;
-        c[CTL_LAMBDA] = lambda;
-        ci[CI_INNER]++;
-        if (lambda >= 1e5) endInner = true;
-    } else endInner = true;
-    if (!endInner) return;                   // same linearisation, larger lambda
-    const double currentError = c[CTL_CUR], newError = c[CTL_ERROR];
-    bool converged;
-    if (newError <= 0.0) converged = true;
-    else {
-        const double absDec = currentError - newError, relDec = absDec / currentError;
-        converged = (relDec <= relTol) || (absDec <= absTol);
-    }
-    ci[CI_STATE] = (ci[CI_ITER] < ci[CI_MAXIT] && !converged && isfinite(currentError)) ? BA_LINEARIZE : BA_DONE;
-}
-
 __global__ __launch_bounds__(256) void k_ba_chi2(BaChi C) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= C.NP) return;
@@ -1169,13 +1176,18 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         // ---- LM: speculative steps, the device decides (k_ba_ctl) -----------------------------------
         // One step = [linearise if the state asks for it] + one lambda trial.  Kernels that are not due
         // return at once, so the host may enqueue a few steps ahead and only then look at the state.
+        const int fuseCtl = comm ? 0 : 1;
+        const int facBlocks = (NF ? obsBlocks : 0) + std::max(NE, 1);
+        const int nObs = NF ? obsBlocks : 0;
+        VS_HIP(hipMemsetAsync(d_Sedge.p, 0, ((size_t)n * n + n) * sizeof(double), stream));     // first linearisation; later ones: see k_ba_factors
         auto step = [&]() -> vslam_status {
             int t = g_baTimer.begin("ba_linearize");
-            if (NF) hipLaunchKernelGGL(k_ba_linearize, dim3(obsBlocks), dim3(256), 0, stream, D);
-            hipLaunchKernelGGL(k_ba_edges, dim3(std::max(NE, 1)), dim3(64), 0, stream, D, 0, NF ? obsBlocks : 0);
+            hipLaunchKernelGGL(k_ba_factors<0>, dim3(facBlocks), dim3(256), 0, stream, D, nObs, fuseCtl, relTol, absTol);
             g_baTimer.end(t);
-            if (comm) { const int tc = g_baTimer.begin("ba_allreduce"); VS_CHECK(comm_allreduce(comm, d_sums.p, 1, stream)); g_baTimer.end(tc); }
-            hipLaunchKernelGGL(k_ba_ctl, dim3(1), dim3(1), 0, stream, D, 0, relTol, absTol);
+            if (comm) {
+                const int tc = g_baTimer.begin("ba_allreduce"); VS_CHECK(comm_allreduce(comm, d_sums.p, 1, stream)); g_baTimer.end(tc);
+                hipLaunchKernelGGL(k_ba_ctl, dim3(1), dim3(256), 0, stream, D, 0, relTol, absTol);
+            }
             t = g_baTimer.begin("ba_schur");
             if (n > 0) {
                 if (ldsS) hipLaunchKernelGGL(k_ba_schur<true>, dim3(lmBlocks), dim3(64 * schurWaves), schurLds, stream, D, maxSlots);
@@ -1196,11 +1208,12 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
             if (Lp) hipLaunchKernelGGL(k_ba_back, dim3(lmBlocks), dim3(64 * schurWaves), backLds, stream, D, maxSlots);
             g_baTimer.end(t);
             t = g_baTimer.begin("ba_eval");
-            if (NF) hipLaunchKernelGGL(k_ba_eval, dim3(obsBlocks), dim3(256), 0, stream, D);
-            hipLaunchKernelGGL(k_ba_edges, dim3(std::max(NE, 1)), dim3(64), 0, stream, D, 1, NF ? obsBlocks : 0);
+            hipLaunchKernelGGL(k_ba_factors<1>, dim3(facBlocks), dim3(256), 0, stream, D, nObs, fuseCtl, relTol, absTol);
             g_baTimer.end(t);
-            if (comm) { const int tc = g_baTimer.begin("ba_allreduce"); VS_CHECK(comm_allreduce(comm, d_sums.p + 1, 2, stream)); g_baTimer.end(tc); }
-            hipLaunchKernelGGL(k_ba_ctl, dim3(1), dim3(1), 0, stream, D, 1, relTol, absTol);
+            if (comm) {
+                const int tc = g_baTimer.begin("ba_allreduce"); VS_CHECK(comm_allreduce(comm, d_sums.p + 1, 2, stream)); g_baTimer.end(tc);
+                hipLaunchKernelGGL(k_ba_ctl, dim3(1), dim3(256), 0, stream, D, 1, relTol, absTol);
+            }
             VS_HIP(hipGetLastError());
             return VSLAM_OK;
         };

@@ -11,10 +11,17 @@ struct vslam_matcher {
     int device = 0;
     hipStream_t stream = nullptr;
     vslam::StageTimer timer;
-    hipEvent_t evUse = nullptr;      // recorded after every operation that reads the extractors' buffers
-    struct UseMark {                 // scope guard: records evUse on every exit path
+    // "last read of extractor X's buffers" events, one per extractor this matcher has been bound to: recorded after
+    // every operation on the currently bound pair, so that only THAT pair's next frame waits for it
+    struct UseEvent { vslam_extractor* fe; hipEvent_t ev; };
+    std::vector<UseEvent> useEvents;
+    hipEvent_t use_event(vslam_extractor* fe, bool create);
+    struct UseMark {                 // scope guard: records on every exit path
         vslam_matcher* m;
-        ~UseMark() { if (m->evUse) hipEventRecord(m->evUse, m->stream); }
+        ~UseMark() {
+            if (hipEvent_t e = m->use_event(m->feL, false)) hipEventRecord(e, m->stream);
+            if (m->feR != m->feL) if (hipEvent_t e = m->use_event(m->feR, false)) hipEventRecord(e, m->stream);
+        }
     };
     vslam_status bind(vslam_extractor* l, int il, vslam_extractor* rr, int ir);
 

@@ -272,9 +272,19 @@ vslam_status vslam_matcher::bind(vslam_extractor* l, int il, vslam_extractor* rr
         return VSLAM_ERR_INVALID;
     }
     feL = l; feR = rr; imgL = il; imgR = ir;
-    if (evUse) { feL->add_consumer(evUse); feR->add_consumer(evUse); }
+    if (stream) { use_event(feL, true); use_event(feR, true); }
     stereoDone = false;
     return VSLAM_OK;
+}
+
+hipEvent_t vslam_matcher::use_event(vslam_extractor* fe, bool create) {
+    for (const UseEvent& u : useEvents) if (u.fe == fe) return u.ev;
+    if (!create) return nullptr;
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    useEvents.push_back({fe, e});
+    fe->add_consumer(e);
+    return e;
 }
 
 vslam_status vslam_matcher::init(const vslam_rig* r, vslam_extractor* l, int il, vslam_extractor* rr, int ir) {
@@ -284,8 +294,7 @@ vslam_status vslam_matcher::init(const vslam_rig* r, vslam_extractor* l, int il,
     device = l->device;
     VS_HIP(hipSetDevice(device));
     VS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    VS_HIP(hipEventCreateWithFlags(&evUse, hipEventDisableTiming));
-    feL->add_consumer(evUse); feR->add_consumer(evUse);
+    use_event(feL, true); use_event(feR, true);
     timer.stream = stream;
     timer.multi = true;
     VS_HIP(hipMalloc(&d_stats, 4 * sizeof(unsigned long long)));
@@ -312,7 +321,8 @@ vslam_status vslam_matcher::ensure_cap(int n) {
 void vslam_matcher::release() {
     if (stream) hipStreamSynchronize(stream);
     // NOTE: extractors this matcher was ever bound to must still be alive here (destroy matchers first)
-    if (evUse) { if (feL) feL->remove_consumer(evUse); if (feR) feR->remove_consumer(evUse); hipEventDestroy(evUse); evUse = nullptr; }
+    for (const UseEvent& u : useEvents) { u.fe->remove_consumer(u.ev); hipEventDestroy(u.ev); }
+    useEvents.clear();
     timer.destroy();
     hipFree(d_mBest); hipFree(d_mDepth); hipFree(d_mSad); hipFree(d_rightIdxs); hipFree(d_leftIdxs);
     hipFree(d_depth); hipFree(d_close); hipFree(d_stats);
