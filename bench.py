@@ -21,6 +21,11 @@ import os
 import sys
 import time
 
+# The path uses 5 HIP streams (2 extractor pairs, matcher/tracker, local BA, torch); the HIP runtime multiplexes
+# streams onto 4 hardware queues by default, which serialises independent streams behind each other's long
+# single-workgroup kernels.  Must be set before the runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "gtsam-vslam_amd"))
 
