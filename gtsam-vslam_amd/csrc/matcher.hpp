@@ -58,9 +58,10 @@ struct vslam_matcher {
     int* d_matchedR = nullptr;
     int* d_projOut = nullptr;    // {nMatches}
     vslam_status ensure_proj_cap(int M);
-    vslam_status proj_enqueue(int M, float rad, const int* Mdev = nullptr, const int* gate = nullptr, int gateMin = 0);
+    vslam_status proj_enqueue(int M, float rad, const int* Mdev = nullptr, const int* gate = nullptr, int gateMin = 0, int mode = 0);
+    bool mono = false;               // created without a right extractor: left-only operations
     vslam_status match_projection(const vslam_mappoint_view* mps, int M, float rad, int* mL, int* mR,
-                                  int* matches, int* nMatches, long long* nCand);
+                                  int* matches, int* nMatches, long long* nCand, int mode = 0);
 
     // pose-only LM buffers
     int poseCap = 0;
@@ -81,11 +82,12 @@ struct vslam_matcher {
     void* imuPim = nullptr; double* imuLam = nullptr; double* imuIo = nullptr;   // views into d_imuBuf
     double imuParams[64] = {0};      // DImuParams of the current frame
     double imuSi[15] = {0}, imuBiasPrev[6] = {0};
-    vslam_status imu_setup(const vslam_imu_input* imu);
-    vslam_status pose_imu_enqueue(int M, const int* Mdev = nullptr, const int* gate = nullptr, int gateMin = 0, int outSlot = 0);
+    vslam_status imu_setup(const vslam_imu_input* imu, double lastDt = 0.0);
+    vslam_status pose_imu_enqueue(int M, const int* Mdev = nullptr, const int* gate = nullptr, int gateMin = 0, int outSlot = 0, int monoOnly = 0);
     double* h_imuStage = nullptr; int imuStageCap = 0;     // pinned upload staging
     vslam_status estimate_pose_imu(vslam_pose_problem* prob, const vslam_imu_input* imu, vslam_imu_output* out,
-                                   int* nIn, int* nStereo, vslam_lm_report* rep);
+                                   int* nIn, int* nStereo, vslam_lm_report* rep, int monoOnly = 0);
+    vslam_status imu_predict(const vslam_imu_input* imu, const double* predVelocity, double lastDt, double* T_wc_out, double* vel_out);
     vslam_status estimate_pose(vslam_pose_problem* prob, int* nIn, int* nStereo, vslam_lm_report* rep);
 
     // tracker state (FeatureTracker's activeMapPoints, flattened and device-resident)
@@ -102,6 +104,10 @@ struct vslam_matcher {
     vslam_status track_init_map(const double* T_wc);
     vslam_status track_frame(const double* T_wc_pred, int frameNumber, double* T_cw_out, vslam_track_report* rep,
                              const vslam_imu_input* imu = nullptr, vslam_imu_output* imuOut = nullptr);
+
+    vslam_status track_frame_mono(const vslam_imu_input* imu, const double* predVelocity, double fps, double* T_cw_out,
+                                  vslam_track_report* rep, vslam_imu_output* imuOut, double* T_wc_pred_out, double* predVelOut);
+    vslam_status track_set_map(const double* xyz, const uint8_t* desc, const float* msd, const uint8_t* outlier, int n);
 
     vslam_status init(const vslam_rig* r, vslam_extractor* l, int il, vslam_extractor* rr, int ir);
     void release();
@@ -138,7 +144,9 @@ struct ProjArgs {
     // device-side control (tracking loop without host round trips): M is an upper bound (grid size) when
     // Mdev is set, the kernel reads the real count; with a gate the kernel is a no-op unless *gate >= gateMin
     const int* Mdev; const int* gate; int gateMin;
+    int mode;            // 0 matchByProjectionRPred, 1 matchByProjectionMono, 2 matchByRadius (left side only in 1 / 2)
 };
+enum { PROJ_STEREO = 0, PROJ_MONO = 1, PROJ_RADIUS = 2 };
 void launch_proj_candidates(hipStream_t s, const ProjArgs& A, const int* matches,
                             unsigned long long* topk, unsigned long long* stats);
 void launch_proj_resolve(hipStream_t s, const ProjArgs& A, const unsigned long long* topk, int* tent,

@@ -27,6 +27,7 @@ struct PoseArgs {
     int maxIterations;
     double relTol, absTol, thres;
     const int* Mdev; const int* gate; int gateMin;     // device-side control, as in ProjArgs
+    int monoOnly;         // estimatePoseGTSAMMono / findOutliersMono: left GenericProjectionFactors only
 };
 
 // whitened residual (and Jacobian rows wrt [omega, v]) of one factor at T (world <- camera)
@@ -116,7 +117,7 @@ __device__ __forceinline__ void pose_build_factors(const PoseArgs& A) {
                 if (A.inFrame[i]) {
                     const vslam_keypoint kl = A.kpsL[first];
                     f[7] = 1.0 / (1.0 / (double)A.invSigma[kl.octave]);
-                    if (A.closef[first] && second >= 0) {
+                    if (!A.monoOnly && A.closef[first] && second >= 0) {
                         type = 0;
                         f[4] = kl.x; f[5] = A.kpsR[second].x; f[6] = kl.y;
                     } else {
@@ -124,7 +125,7 @@ __device__ __forceinline__ void pose_build_factors(const PoseArgs& A) {
                         f[4] = kl.x; f[5] = kl.y; f[6] = 0;
                     }
                 }
-            } else if (second >= 0) {
+            } else if (second >= 0 && !A.monoOnly) {
                 if (A.inFrameR[i]) {
                     const vslam_keypoint kr = A.kpsR[second];
                     f[7] = 1.0 / (1.0 / (double)A.invSigma[kr.octave]);
@@ -159,7 +160,7 @@ __device__ __forceinline__ void pose_find_outliers(const PoseArgs& A, const DPos
         bool handled = false, right = false;
         int nIdx = -1;
         if (first >= 0) { if (A.inFrame[i]) { handled = true; nIdx = first; } }
-        else if (second >= 0) { if (A.inFrameR[i]) { handled = true; right = true; nIdx = second; } }
+        else if (second >= 0 && !A.monoOnly) { if (A.inFrameR[i]) { handled = true; right = true; nIdx = second; } }
         if (handled) {
             const vslam_keypoint k = right ? A.kpsR[nIdx] : A.kpsL[nIdx];
             const bool outlier = check2d(right ? pr : pc, k.x, k.y, A, (double)A.invSigma[k.octave]);
@@ -167,7 +168,7 @@ __device__ __forceinline__ void pose_find_outliers(const PoseArgs& A, const DPos
             if (!outlier) {
                 nIn++;
                 const double z = right ? pr[2] : pc[2];
-                if (z < (double)A.closeTh && !right && A.closef[nIdx] && second >= 0) {
+                if (!A.monoOnly && z < (double)A.closeTh && !right && A.closef[nIdx] && second >= 0) {
                     const vslam_keypoint kr = A.kpsR[second];
                     const bool fail = check2d(pr, kr.x, kr.y, A, (double)A.invSigma[kr.octave]);
                     code = fail ? 3 : 1;
@@ -195,6 +196,7 @@ __device__ __forceinline__ void pose_find_outliers(const PoseArgs& A, const DPos
         }
     }
     if (nIn) atomicAdd(&sCnt[0], nIn);
+    if (A.monoOnly) nSt = nIn;           // findOutliersMono returns the inlier count in both slots (:651-683)
     if (nSt) atomicAdd(&sCnt[1], nSt);
     __syncthreads();
 }

@@ -85,6 +85,13 @@ __global__ __launch_bounds__(256) void k_imu_preintegrate(DImuParams P, const do
     for (int i = tid; i < (int)(sizeof(DPim) / sizeof(double)); i += 256) ((double*)pimOut)[i] = ((double*)&pim)[i];
 }
 
+struct ImuLmArgs {
+    const DPim* pim; const double* Lam; DImuParams P;
+    DNav si;                 // x0, v0
+    double biasPrev[6];      // b0
+    double* io;              // out: vel(3), bias(6)
+};
+
 #ifdef VSLAM_POSE_STAMPS
 __device__ long long g_ps[16];
 #define PS_ACC(k) do { if (threadIdx.x == 0) { const long long n_ = clock64(); g_ps[k] += n_ - ps_t; ps_t = n_; } } while (0)
@@ -94,12 +101,44 @@ __device__ long long g_ps[16];
 #define PS_CNT(k) do {} while (0)
 #endif
 
-struct ImuLmArgs {
-    const DPim* pim; const double* Lam; DImuParams P;
-    DNav si;                 // x0, v0
-    double biasPrev[6];      // b0
-    double* io;              // out: vel(3), bias(6)
-};
+// The single-thread sections of the solve are kept out of line: inlined into the kernel their temporaries
+// (dozens of 3x3 / 6x6 blocks) drive the register allocation of the factor-parallel loops into spilling.
+__device__ __noinline__ void imu_lin_serial(const DNav* pred, const double* biasHat, const DPose* T, const double* v, const double* b,
+                                            const DPose* priorT, double* r15, double* J, double* rp, double* Jp) {
+    imu_factor_eval(*pred, biasHat, T->R, T->t, v, b, r15, J);
+    DPose pi, d;
+    pose_inverse(*priorT, pi);
+    pose_compose(pi, *T, d);
+    pose3_logmap(d, rp);
+    pose3_logmap_derivative(d, Jp);
+}
+// sum of squares of the non-vision factors at (T, v, b): CombinedImuFactor (information Lam), bias BetweenFactor,
+// the two unit-covariance priors
+__device__ __noinline__ double imu_nonvision_error(const DNav* pred, const double* biasHat, const double* Lam, const double* biasPrev,
+                                                   const DPose* priorT, const double* priorV, const DPose* T, const double* v,
+                                                   const double* b) {
+    double r[15];
+#ifdef VSLAM_POSE_STAMPS
+    long long ps_t = clock64();
+#endif
+    imu_factor_eval(*pred, biasHat, T->R, T->t, v, b, r, nullptr);
+    PS_ACC(12);
+    double e = 0;
+    for (int i = 0; i < 15; i++) { double s = 0; for (int j = 0; j < 15; j++) s += Lam[i * 15 + j] * r[j]; e += r[i] * s; }
+    PS_ACC(13);
+    for (int i = 0; i < 6; i++) { const double rb = (b[i] - biasPrev[i]) * 1e3; e += rb * rb; }
+    DPose pi, d;
+    pose_inverse(*priorT, pi);
+    pose_compose(pi, *T, d);
+    double rp[6];
+    pose3_logmap(d, rp);
+    for (int i = 0; i < 6; i++) e += rp[i] * rp[i];
+    for (int i = 0; i < 3; i++) { const double rv = v[i] - priorV[i]; e += rv * rv; }
+    PS_ACC(14);
+    return e;
+}
+__device__ __noinline__ void imu_predict_serial(const DPim* pim, const DImuParams* P, const DNav* si, DNav* out) { pim_predict(*pim, *P, *si, *out); }
+__device__ __noinline__ void pose_retract_serial(const DPose* T, const double* xi, DPose* r) { pose_retract(*T, xi, *r); }
 
 __global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I) {
     __shared__ double red[(POSE_NT / 64) * 28];
@@ -122,7 +161,7 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I
     PS_ACC(0);
     if (tid < 225) sLam[tid] = I.Lam[tid];
     if (tid == 0) {
-        pim_predict(*I.pim, I.P, I.si, sPred);                   // prop_state: initial values, priors, factor prediction
+        imu_predict_serial(I.pim, &I.P, &I.si, &sPred);          // prop_state: initial values, priors, factor prediction
         for (int i = 0; i < 9; i++) { sT.R[i] = sPred.R[i]; sPT.R[i] = sPred.R[i]; }
         for (int i = 0; i < 3; i++) { sT.t[i] = sPred.t[i]; sPT.t[i] = sPred.t[i]; sV[i] = sPred.v[i]; sPV[i] = sPred.v[i]; }
         for (int i = 0; i < 6; i++) sB[i] = I.biasPrev[i];
@@ -141,21 +180,8 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I
         }
         return e;
     };
-    // sum of squares of the non-vision factors at (T, v, b); thread 0 only
-    auto nonvision_error = [&](const DPose& T, const double* v, const double* b) {
-        double r[15];
-        imu_factor_eval(sPred, I.pim->biasHat, T.R, T.t, v, b, r, nullptr);
-        double e = 0;
-        for (int i = 0; i < 15; i++) { double s = 0; for (int j = 0; j < 15; j++) s += sLam[i * 15 + j] * r[j]; e += r[i] * s; }
-        for (int i = 0; i < 6; i++) { const double rb = (b[i] - I.biasPrev[i]) * 1e3; e += rb * rb; }
-        DPose pi, d;
-        pose_inverse(sPT, pi);
-        pose_compose(pi, T, d);
-        double rp[6];
-        pose3_logmap(d, rp);
-        for (int i = 0; i < 6; i++) e += rp[i] * rp[i];
-        for (int i = 0; i < 3; i++) { const double rv = v[i] - sPV[i]; e += rv * rv; }
-        return e;
+    auto nonvision_error = [&](const DPose& T, const double* v, const double* b) {      // thread 0 only
+        return imu_nonvision_error(&sPred, I.pim->biasHat, sLam, I.biasPrev, &sPT, sPV, &T, v, b);
     };
 
     {
@@ -198,12 +224,7 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I
             block_reduce<28>(v, red, acc);
             PS_ACC(2);
             if (tid == 0) {
-                imu_factor_eval(sPred, I.pim->biasHat, sT.R, sT.t, sV, sB, sR15, sJ);
-                DPose pi, d;
-                pose_inverse(sPT, pi);
-                pose_compose(pi, sT, d);
-                pose3_logmap(d, sRp);
-                pose3_logmap_derivative(d, sJp);
+                imu_lin_serial(&sPred, I.pim->biasHat, &sT, sV, sB, &sPT, sR15, sJ, sRp, sJp);
             }
             PS_ACC(3);
             __syncthreads();
@@ -255,7 +276,7 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I
                 if (solved) {
                     sLin = dg - 0.5 * dHd;
                     if (sLin >= 0) {
-                        pose_retract(sT, sDelta, sT2);
+                        pose_retract_serial(&sT, sDelta, &sT2);
                         for (int i = 0; i < 3; i++) sV2[i] = sV[i] + sDelta[6 + i];
                         for (int i = 0; i < 6; i++) sB2[i] = sB[i] + sDelta[9 + i];
                         sNV = nonvision_error(sT2, sV2, sB2);
@@ -334,7 +355,7 @@ using namespace vslam;
 
 // upload the frame's IMU bucket, pre-integrate it once (the reference re-integrates the same samples on every
 // estimatePoseGTSAM call of a frame; the result is identical), remember x0 / v0 / b0
-vslam_status vslam_matcher::imu_setup(const vslam_imu_input* imu) {
+vslam_status vslam_matcher::imu_setup(const vslam_imu_input* imu, double lastDt) {
     const int n = imu->n_samples;
     if (n > 0 && (!imu->acceleration || !imu->angular_velocity || !imu->timestamps_ns)) { set_error("IMU input: null array"); return VSLAM_ERR_INVALID; }
     if (n <= 0 || imu->hz <= 0) { set_error("IMU input: empty bucket"); return VSLAM_ERR_INVALID; }
@@ -357,7 +378,7 @@ vslam_status vslam_matcher::imu_setup(const vslam_imu_input* imu) {
     }
     // the previous frame's upload has been consumed: every tracking call ends with a stream synchronisation
     double* h = h_imuStage;
-    double dt = 1.0 / imu->hz;                                  // src/FeatureTracker.cpp:337
+    double dt = lastDt > 0.0 ? lastDt : 1.0 / imu->hz;          // src/FeatureTracker.cpp:337 (PredictNextPoseIMU :1067 starts from hz / fps)
     for (int i = 0; i < n; i++) {
         for (int k = 0; k < 3; k++) { h[6 * (size_t)i + k] = imu->acceleration[3 * i + k]; h[6 * (size_t)i + 3 + k] = imu->angular_velocity[3 * i + k]; }
         if (i + 1 < n) dt = (imu->timestamps_ns[i + 1] - imu->timestamps_ns[i]) / 1e9;     // :345-350
@@ -391,11 +412,11 @@ vslam_status vslam_matcher::imu_setup(const vslam_imu_input* imu) {
 }
 
 // device-resident form of the IMU solve (inputs as for pose_enqueue, plus a completed imu_setup)
-vslam_status vslam_matcher::pose_imu_enqueue(int M, const int* Mdev, const int* gate, int gateMin, int outSlot) {
+vslam_status vslam_matcher::pose_imu_enqueue(int M, const int* Mdev, const int* gate, int gateMin, int outSlot, int monoOnly) {
     uint8_t* fl = d_flags;
     const size_t pc = (size_t)poseCap;
     PoseArgs A{};
-    A.Mdev = Mdev; A.gate = gate; A.gateMin = gateMin;
+    A.Mdev = Mdev; A.gate = gate; A.gateMin = gateMin; A.monoOnly = monoOnly;
     A.M = M; A.points = d_points; A.inFrame = fl; A.inFrameR = fl + pc; A.mpOut = fl + 2 * pc; A.mpsOut = fl + 3 * pc;
     A.matches = d_matches; A.kpsL = d_kps[0]; A.kpsR = d_kps[1];
     A.closef = d_close; A.depth = d_depth; A.rightIdxs = d_rightIdxs; A.leftIdxs = d_leftIdxs;
@@ -423,6 +444,7 @@ vslam_status vslam_matcher::pose_imu_enqueue(int M, const int* Mdev, const int* 
         (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_ps), sizeof(z));
         fprintf(stderr, "pose_imu_lm M=%d: build %lld init %lld | lin: vis %lld imuJ %lld prod %lld (x%lld) | trial: solve %lld nv %lld+%lld vis %lld ctl %lld (x%lld) | outl %lld\n",
                 M, z[0], z[1], z[2], z[3], z[4], z[10], z[5], z[6], 0LL, z[7], z[8], z[11], z[9]);
+        fprintf(stderr, "    nonvision: imu eval %lld  Lam quad %lld  prior %lld\n", z[12], z[13], z[14]);
     }
 #endif
     VS_HIP(hipGetLastError());
@@ -430,12 +452,12 @@ vslam_status vslam_matcher::pose_imu_enqueue(int M, const int* Mdev, const int* 
 }
 
 vslam_status vslam_matcher::estimate_pose_imu(vslam_pose_problem* prob, const vslam_imu_input* imu, vslam_imu_output* outp,
-                                              int* nIn, int* nStereo, vslam_lm_report* rep) {
+                                              int* nIn, int* nStereo, vslam_lm_report* rep, int monoOnly) {
     if (!prob || !imu || prob->n_mps < 0 || imu->n_samples < 0) return VSLAM_ERR_INVALID;
     const int M = prob->n_mps;
-    if (M > 0 && (!prob->points_xyz || !prob->in_frame || !prob->in_frame_r || !prob->mp_is_outlier || !prob->matches ||
+    if (M > 0 && (!prob->points_xyz || !prob->in_frame || (!monoOnly && !prob->in_frame_r) || !prob->mp_is_outlier || !prob->matches ||
                   !prob->mps_outliers)) { set_error("estimate_pose_imu: null array"); return VSLAM_ERR_INVALID; }
-    if (!stereoDone) { set_error("estimate_pose_imu needs a completed stereo match"); return VSLAM_ERR_INVALID; }
+    if (!monoOnly && (mono || !stereoDone)) { set_error("estimate_pose_imu needs a completed stereo match"); return VSLAM_ERR_INVALID; }
     VS_HIP(hipSetDevice(device));
     UseMark mark{this};
     VS_CHECK(refresh_keys());
@@ -447,12 +469,12 @@ vslam_status vslam_matcher::estimate_pose_imu(vslam_pose_problem* prob, const vs
     if (M) {
         VS_HIP(hipMemcpyAsync(d_points, prob->points_xyz, (size_t)M * 24, hipMemcpyHostToDevice, stream));
         VS_HIP(hipMemcpyAsync(fl, prob->in_frame, M, hipMemcpyHostToDevice, stream));
-        VS_HIP(hipMemcpyAsync(fl + pc, prob->in_frame_r, M, hipMemcpyHostToDevice, stream));
+        if (!monoOnly) VS_HIP(hipMemcpyAsync(fl + pc, prob->in_frame_r, M, hipMemcpyHostToDevice, stream));
         VS_HIP(hipMemcpyAsync(fl + 2 * pc, prob->mp_is_outlier, M, hipMemcpyHostToDevice, stream));
         VS_HIP(hipMemcpyAsync(fl + 3 * pc, prob->mps_outliers, M, hipMemcpyHostToDevice, stream));
         VS_HIP(hipMemcpyAsync(d_matches, prob->matches, (size_t)M * 8, hipMemcpyHostToDevice, stream));
     }
-    VS_CHECK(pose_imu_enqueue(M));
+    VS_CHECK(pose_imu_enqueue(M, nullptr, nullptr, 0, 0, monoOnly));
     double io[19], vb[9];
     int out[4];
     VS_HIP(hipMemcpyAsync(io, d_poseIO, sizeof(io), hipMemcpyDeviceToHost, stream));
@@ -476,4 +498,50 @@ extern "C" vslam_status vslam_estimate_pose_imu(vslam_matcher* m, vslam_pose_pro
                                                 vslam_lm_report* report) {
     if (!m) return VSLAM_ERR_INVALID;
     return m->estimate_pose_imu(prob, imu, out, n_inliers, n_stereo, report);
+}
+
+// estimatePoseGTSAMMono + findOutliersMono (src/FeatureTracker.cpp:413-580,651-683): the IMU solve over left
+// GenericProjectionFactors only; in_frame_r / the right halves of `matches` are ignored
+extern "C" vslam_status vslam_estimate_pose_mono(vslam_matcher* m, vslam_pose_problem* prob, const vslam_imu_input* imu,
+                                                 vslam_imu_output* out, int32_t* n_inliers, vslam_lm_report* report) {
+    if (!m) return VSLAM_ERR_INVALID;
+    int nSt = 0;
+    return m->estimate_pose_imu(prob, imu, out, n_inliers, &nSt, report, 1);
+}
+
+// PredictNextPoseIMU (src/FeatureTracker.cpp:1036-1106): pre-integrate the bucket (the last sample with
+// last_dt; the reference starts its dt at mHz / mFps) and predict from (T_wc_prev, pred_velocity, bias_prev)
+__global__ void k_imu_predict_out(const DPim* pim, DImuParams P, DNav si, double* out) {
+    if (threadIdx.x) return;
+    DNav sj;
+    pim_predict(*pim, P, si, sj);
+    for (int i = 0; i < 9; i++) out[i] = sj.R[i];
+    for (int i = 0; i < 3; i++) { out[9 + i] = sj.t[i]; out[12 + i] = sj.v[i]; }
+}
+
+vslam_status vslam_matcher::imu_predict(const vslam_imu_input* imu, const double* predVelocity, double lastDt, double* T_wc_out,
+                                        double* vel_out) {
+    if (!imu || !predVelocity || !T_wc_out) return VSLAM_ERR_INVALID;
+    VS_HIP(hipSetDevice(device));
+    VS_CHECK(imu_setup(imu, lastDt));
+    DImuParams P;
+    memcpy(&P, imuParams, sizeof(P));
+    DNav si;
+    for (int k = 0; k < 9; k++) si.R[k] = imuSi[k];
+    for (int k = 0; k < 3; k++) { si.t[k] = imuSi[9 + k]; si.v[k] = predVelocity[k]; }
+    hipLaunchKernelGGL(k_imu_predict_out, dim3(1), dim3(64), 0, stream, (const DPim*)imuPim, P, si, imuIo);
+    VS_HIP(hipGetLastError());
+    VS_HIP(hipMemcpyAsync(h_res + 32, imuIo, 15 * sizeof(double), hipMemcpyDeviceToHost, stream));
+    VS_HIP(hipStreamSynchronize(stream));
+    const double* o = h_res + 32;
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) T_wc_out[4 * r + c] = o[3 * r + c]; T_wc_out[4 * r + 3] = o[9 + r]; }
+    T_wc_out[12] = T_wc_out[13] = T_wc_out[14] = 0; T_wc_out[15] = 1;
+    if (vel_out) for (int k = 0; k < 3; k++) vel_out[k] = o[12 + k];
+    return VSLAM_OK;
+}
+
+extern "C" vslam_status vslam_imu_predict(vslam_matcher* m, const vslam_imu_input* imu, const double* pred_velocity, double last_dt,
+                                          double* T_wc_out, double* velocity_out) {
+    if (!m) return VSLAM_ERR_INVALID;
+    return m->imu_predict(imu, pred_velocity, last_dt, T_wc_out, velocity_out);
 }

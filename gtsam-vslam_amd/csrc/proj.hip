@@ -79,6 +79,10 @@ __device__ int scan_side(const ProjArgs& A, int side, const uint32_t (&md)[8], f
             if (oct > predScale + 1 || oct < predScale - 1) continue;
             if (!(fabsf(kx - px) < radius && fabsf(ky - py) < radius)) continue;
             if (claimed && claimed[idx] >= 0) continue;
+            if (A.mode == PROJ_RADIUS) {      // Converter::checkPixelParallax (include/Conversions.h:25,140-144)
+                const double dx = (double)kx - (double)px, dy = (double)ky - (double)py;
+                if (!(sqrt(dx * dx + dy * dy) > 10.0)) continue;
+            }
             const uint4* pr = (const uint4*)(desc + (size_t)idx * 32);
             const uint4 r0 = pr[0], r1 = pr[1];
             const int dist = __popc(md[0] ^ r0.x) + __popc(md[1] ^ r0.y) + __popc(md[2] ^ r0.z) +
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(256) void k_proj_candidates(ProjArgs A, const int* 
     for (int j = 0; j < PROJ_K; j++) out[j] = KEY_NONE;
     const vslam_mappoint_view* mp = A.mpv + i;
     const bool skip = matches[2 * i] >= 0 || matches[2 * i + 1] >= 0;
-    const bool inF = side ? mp->in_frame_r : mp->in_frame;
+    const bool inF = side ? (A.mode == PROJ_STEREO && mp->in_frame_r) : mp->in_frame;
     int tests = 0;
     if (!skip && inF) {
         uint32_t md[8];
@@ -150,8 +154,10 @@ void launch_proj_candidates(hipStream_t s, const ProjArgs& A, const int* matches
 
 // The accept rule of the reference scan given the first / second unclaimed key of each side
 // (src/FeatureMatcher.cpp:341-383).  Returns -1 (no match) or (right << 16) | keypoint index.
+// mode 1 (matchByProjectionMono :441-454): threshold matchDistProj + 50, ratio (ratioProj + 0.1) in double;
+// mode 2 (matchByRadius :511-524): the stereo constants.  The right lists are empty in both.
 __device__ __forceinline__ int proj_decide(unsigned long long l1, unsigned long long l2, unsigned long long r1,
-                                           unsigned long long r2) {
+                                           unsigned long long r2, int mode) {
     const int matchDistProj = 100;      // include/FeatureMatcher.h:27
     const float ratioProj = 0.8f;       // include/FeatureMatcher.h:28
     int bestDist = 256, bestIdx = -1, bestLev = -1, bestLev2 = -1, secDist = 256;
@@ -170,6 +176,11 @@ __device__ __forceinline__ int proj_decide(unsigned long long l1, unsigned long 
     if (bestDist > bestDistR) {
         bestDist = bestDistR; secDist = secDistR; bestLev = bestLevR; bestLev2 = bestLevR2; bestIdx = bestIdxR;
         right = true;
+    }
+    if (mode == PROJ_MONO) {
+        if (bestDist > matchDistProj + 50) return -1;
+        if (bestLev == bestLev2 && (double)bestDist >= ((double)ratioProj + 0.1) * (double)secDist) return -1;
+        return bestIdx;
     }
     if (bestDist > matchDistProj) return -1;
     if (bestLev == bestLev2 && (float)bestDist >= ratioProj * (float)secDist) return -1;
@@ -201,7 +212,7 @@ __global__ __launch_bounds__(256) void k_proj_resolve(ProjArgs A, const unsigned
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (A.gate && *A.gate < A.gateMin) return;
     if (A.Mdev) A.M = min(A.M, *A.Mdev);
-    for (int k = tid; k < A.n[0]; k += 256) { cl[k] = matchedL[k]; ri[k] = A.rightIdxs[k]; }
+    for (int k = tid; k < A.n[0]; k += 256) { cl[k] = matchedL[k]; ri[k] = A.mode == PROJ_STEREO ? A.rightIdxs[k] : -1; }
     for (int k = tid; k < A.n[1]; k += 256) { cr[k] = matchedR[k]; li[k] = A.leftIdxs[k]; }
     int nMatches = 0;
     static_assert(PROJ_K == 8, "lane layout assumes 8 keys per side");
@@ -255,7 +266,7 @@ __global__ __launch_bounds__(256) void k_proj_resolve(ProjArgs A, const unsigned
             if (p1 < 0) b1 = KEY_NONE;
             if (p2 < 0) b2 = KEY_NONE;
             const unsigned long long o1 = __shfl_xor(b1, 2), o2 = __shfl_xor(b2, 2);
-            const int dec = skip ? -1 : (side ? proj_decide(o1, o2, b1, b2) : proj_decide(b1, b2, o1, o2));
+            const int dec = skip ? -1 : (side ? proj_decide(o1, o2, b1, b2, A.mode) : proj_decide(b1, b2, o1, o2, A.mode));
             int cLq = -1, cRq = -1;
             if (dec >= 0) {
                 const int idx = dec & 0xffff;
@@ -323,7 +334,7 @@ __global__ __launch_bounds__(256) void k_proj_resolve(ProjArgs A, const unsigned
                         b2k[s] = l2 < 0 ? KEY_NONE : k2;
                     }
                 }
-                const int d2 = proj_decide(b1k[0], b2k[0], b1k[1], b2k[1]);
+                const int d2 = proj_decide(b1k[0], b2k[0], b1k[1], b2k[1], A.mode);
                 if (d2 < 0) continue;
                 nMatches++;
                 if (lane == 0) {
@@ -383,9 +394,9 @@ vslam_status vslam_matcher::ensure_proj_cap(int M) {
 }
 
 // device-resident form: d_mpv / d_matches / d_matchedL / d_matchedR already hold the inputs
-vslam_status vslam_matcher::proj_enqueue(int M, float rad, const int* Mdev, const int* gate, int gateMin) {
+vslam_status vslam_matcher::proj_enqueue(int M, float rad, const int* Mdev, const int* gate, int gateMin, int mode) {
     ProjArgs A{};
-    A.Mdev = Mdev; A.gate = gate; A.gateMin = gateMin;
+    A.Mdev = Mdev; A.gate = gate; A.gateMin = gateMin; A.mode = mode;
     for (int s = 0; s < 2; s++) { A.kps[s] = d_kps[s]; A.desc[s] = d_desc[s]; A.n[s] = nKeys[s]; }
     A.mpv = d_mpv; A.M = M; A.rad = rad;
     for (int l = 0; l < feL->nLevels; l++) A.scalePyr[l] = feL->scalePyramid[l];
@@ -410,14 +421,14 @@ vslam_status vslam_matcher::proj_enqueue(int M, float rad, const int* Mdev, cons
 }
 
 vslam_status vslam_matcher::match_projection(const vslam_mappoint_view* mps, int M, float rad, int* mL,
-                                             int* mR, int* matches, int* nMatches, long long* nCand) {
-    if (M < 0 || (M > 0 && (!mps || !matches)) || !mL || !mR) { set_error("match_projection: bad argument"); return VSLAM_ERR_INVALID; }
-    if (!stereoDone) { set_error("match_projection needs a completed stereo match"); return VSLAM_ERR_INVALID; }
+                                             int* mR, int* matches, int* nMatches, long long* nCand, int mode) {
+    if (M < 0 || (M > 0 && (!mps || !matches)) || !mL || (mode == PROJ_STEREO && !mR)) { set_error("match_projection: bad argument"); return VSLAM_ERR_INVALID; }
+    if (mode == PROJ_STEREO && (mono || !stereoDone)) { set_error("match_projection needs a completed stereo match"); return VSLAM_ERR_INVALID; }
     VS_HIP(hipSetDevice(device));
     UseMark mark{this};
     VS_CHECK(refresh_keys());
     VS_CHECK(ensure_proj_cap(M));
-    const int nL = nKeys[0], nR = nKeys[1];
+    const int nL = nKeys[0], nR = mode == PROJ_STEREO ? nKeys[1] : 0;
     if (M) {
         VS_HIP(hipMemcpyAsync(d_mpv, mps, (size_t)M * sizeof(vslam_mappoint_view), hipMemcpyHostToDevice, stream));
         VS_HIP(hipMemcpyAsync(d_matches, matches, (size_t)M * 2 * sizeof(int), hipMemcpyHostToDevice, stream));
@@ -425,7 +436,7 @@ vslam_status vslam_matcher::match_projection(const vslam_mappoint_view* mps, int
     if (nL) VS_HIP(hipMemcpyAsync(d_matchedL, mL, (size_t)nL * sizeof(int), hipMemcpyHostToDevice, stream));
     if (nR) VS_HIP(hipMemcpyAsync(d_matchedR, mR, (size_t)nR * sizeof(int), hipMemcpyHostToDevice, stream));
     VS_HIP(hipMemsetAsync(d_stats + 3, 0, sizeof(unsigned long long), stream));
-    VS_CHECK(proj_enqueue(M, rad));
+    VS_CHECK(proj_enqueue(M, rad, nullptr, nullptr, 0, mode));
     int out = 0;
     unsigned long long nc = 0;
     if (M) VS_HIP(hipMemcpyAsync(matches, d_matches, (size_t)M * 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -447,4 +458,36 @@ extern "C" vslam_status vslam_match_projection(vslam_matcher* m, const vslam_map
     vslam_status s = m->match_projection(mps, n_mps, rad, matched_idxs_l, matched_idxs_r, matches, n_matches, &nc);
     if (n_candidates) *n_candidates = nc;
     return s;
+}
+
+// matchByProjectionMono (src/FeatureMatcher.cpp:391-456): left image only
+extern "C" vslam_status vslam_match_projection_mono(vslam_matcher* m, const vslam_mappoint_view* mps, int32_t n_mps, float rad,
+                                                    int32_t* matched_idxs_l, int32_t* matches, int32_t* n_matches,
+                                                    int64_t* n_candidates) {
+    if (!m) return VSLAM_ERR_INVALID;
+    long long nc = 0;
+    vslam_status s = m->match_projection(mps, n_mps, rad, matched_idxs_l, nullptr, matches, n_matches, &nc, PROJ_MONO);
+    if (n_candidates) *n_candidates = nc;
+    return s;
+}
+
+// matchByRadius (src/FeatureMatcher.cpp:458-526): the "map points" are the last keyframe's keypoints
+// (pred_l = keypoint position, scale_level_l = octave, desc = its descriptor); match_out[i] = matched keypoint or -1
+extern "C" vslam_status vslam_match_by_radius(vslam_matcher* m, const vslam_keypoint* last_kps, const uint8_t* last_desc,
+                                              int32_t n_last, float rad, int32_t* matched_idxs_l, int32_t* match_out,
+                                              int32_t* n_matches) {
+    if (!m || n_last < 0 || (n_last > 0 && (!last_kps || !last_desc || !match_out))) return VSLAM_ERR_INVALID;
+    std::vector<vslam_mappoint_view> v((size_t)n_last);
+    std::vector<int> mt((size_t)2 * n_last, -1);
+    for (int i = 0; i < n_last; i++) {
+        vslam_mappoint_view& q = v[i];
+        memcpy(q.desc, last_desc + (size_t)i * 32, 32);
+        q.pred_lx = last_kps[i].x; q.pred_ly = last_kps[i].y; q.pred_rx = q.pred_ry = 0.f;
+        q.scale_level_l = last_kps[i].octave; q.scale_level_r = 0;
+        q.in_frame = 1; q.in_frame_r = 0; q.pad_[0] = q.pad_[1] = 0;
+    }
+    vslam_status s = m->match_projection(v.data(), n_last, rad, matched_idxs_l, nullptr, mt.data(), n_matches, nullptr, PROJ_RADIUS);
+    if (s != VSLAM_OK) return s;
+    for (int i = 0; i < n_last; i++) match_out[i] = mt[2 * (size_t)i];
+    return VSLAM_OK;
 }

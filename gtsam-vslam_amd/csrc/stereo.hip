@@ -264,6 +264,8 @@ using namespace vslam;
 
 // (re)bind the matcher to a pair of extractors: the views follow the new pair from the next call on
 vslam_status vslam_matcher::bind(vslam_extractor* l, int il, vslam_extractor* rr, int ir) {
+    if (l && !rr) { rr = l; ir = il; mono = true; }      // mono matcher: every right-side view aliases the left one, with 0 keys
+    else mono = false;
     if (!l || !rr || il < 0 || il >= l->nimg || ir < 0 || ir >= rr->nimg || l->device != rr->device ||
         l->nLevels != rr->nLevels || l->width != rr->width || l->height != rr->height ||
         rig.width != l->width || rig.height != l->height || (stream && l->device != device) ||
@@ -298,7 +300,7 @@ vslam_status vslam_matcher::init(const vslam_rig* r, vslam_extractor* l, int il,
     timer.stream = stream;
     timer.multi = true;
     VS_HIP(hipMalloc(&d_stats, 4 * sizeof(unsigned long long)));
-    VS_CHECK(ensure_cap(std::max(l->keptCap, rr->keptCap)));
+    VS_CHECK(ensure_cap(std::max(feL->keptCap, feR->keptCap)));
     return VSLAM_OK;
 }
 
@@ -348,12 +350,13 @@ vslam_status vslam_matcher::refresh_keys() {
         if (!fe[s]->ran) { set_error("matcher: extractor has not run"); return VSLAM_ERR_INVALID; }
         d_kps[s] = fe[s]->d_kps + (size_t)img[s] * fe[s]->keptCap;
         d_desc[s] = fe[s]->d_desc + (size_t)img[s] * fe[s]->keptCap * 32;
-        nKeys[s] = fe[s]->nKept[img[s]];
+        nKeys[s] = (s == 1 && mono) ? 0 : fe[s]->nKept[img[s]];
     }
     return ensure_cap(std::max(nKeys[0], nKeys[1]));
 }
 
 vslam_status vslam_matcher::stereo_match() {
+    if (mono) { set_error("stereo_match on a mono matcher"); return VSLAM_ERR_INVALID; }
     VS_HIP(hipSetDevice(device));
     UseMark mark{this};
     VS_CHECK(refresh_keys());

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(1024) void k_track_predict(int N, const double* __r
                                                         int* __restrict__ act, int* __restrict__ count,
                                                         int* __restrict__ matchedL, int nL,
                                                         int* __restrict__ matchedR, int nR,
-                                                        double* __restrict__ poseIO) {
+                                                        double* __restrict__ poseIO, int leftOnly) {
     __shared__ int wsum[16];
     int run = 0;
     N = min(N, count[0]);          // N is the host's upper bound; the map size stays on the device
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(1024) void k_track_predict(int N, const double* __r
             for (int c = 0; c < 3; c++) pc[c] += Tcw.t[c];
             l = world_to_frame(pc, false, G.fx, G.fy, G.cx, G.cy, G.b, G.w, G.h, msd[i], G.logScale, G.nLev);
             r = world_to_frame(pc, true, G.fx, G.fy, G.cx, G.cy, G.b, G.w, G.h, msd[i], G.logScale, G.nLev);
-            keep = l.vis && r.vis;
+            keep = l.vis && (leftOnly || r.vis);     // removeOutOfFrameMPs / removeOutOfFrameMPsMono (:910-968)
         }
         int tot;
         const int pos = run + block_excl_scan_1024(keep, wsum, tot);
@@ -126,12 +126,12 @@ __global__ __launch_bounds__(1024) void k_track_predict(int N, const double* __r
             d[0] = s[0]; d[1] = s[1];
             v.pred_lx = l.u; v.pred_ly = l.v; v.pred_rx = r.u; v.pred_ry = r.v;
             v.scale_level_l = l.lvl; v.scale_level_r = r.lvl;
-            v.in_frame = 1; v.in_frame_r = 1; v.pad_[0] = v.pad_[1] = 0;
+            v.in_frame = 1; v.in_frame_r = r.vis ? 1 : 0; v.pad_[0] = v.pad_[1] = 0;
             mpv[pos] = v;
             points[3 * (size_t)pos] = xyz[3 * (size_t)i];
             points[3 * (size_t)pos + 1] = xyz[3 * (size_t)i + 1];
             points[3 * (size_t)pos + 2] = xyz[3 * (size_t)i + 2];
-            flags[pos] = 1; flags[flagStride + pos] = 1; flags[2 * flagStride + pos] = 0; flags[3 * flagStride + pos] = 0;
+            flags[pos] = 1; flags[flagStride + pos] = r.vis ? 1 : 0; flags[2 * flagStride + pos] = 0; flags[3 * flagStride + pos] = 0;
             matches[2 * pos] = -1; matches[2 * pos + 1] = -1;
             act[pos] = i;
         }
@@ -264,7 +264,7 @@ vslam_status vslam_matcher::track_frame(const double* T_wc_pred, int frameNumber
     // when the first round fails (fewer than minInliers) does it step through the reference's retry rule.
     int t = timer.begin("track_predict");
     hipLaunchKernelGGL(k_track_predict, dim3(1), dim3(1024), 0, stream, trNub, d_trXyz, d_trDesc, d_trMsd, d_trOutlier, Tcw, G,
-                       d_mpv, d_points, fl, pc, d_matches, d_trAct, d_trCount, d_matchedL, nL, d_matchedR, nR, d_poseIO);
+                       d_mpv, d_points, fl, pc, d_matches, d_trAct, d_trCount, d_matchedL, nL, d_matchedR, nR, d_poseIO, 0);
     timer.end(t);
     VS_HIP(hipGetLastError());
 
@@ -330,6 +330,93 @@ vslam_status vslam_matcher::track_frame(const double* T_wc_pred, int frameNumber
     return VSLAM_OK;
 }
 
+
+// Mono + IMU frame (C4): the tracking block of FeatureTracker::TrackImageMonoIMU (src/FeatureTracker.cpp:1379-1450)
+// with PredictNextPoseIMU (:1036-1106), removeOutOfFrameMPsMono (:941-967), matchByProjectionMono and
+// estimatePoseGTSAMMono.  Host-driven rounds (one synchronisation per round): this path is not the benchmarked one.
+vslam_status vslam_matcher::track_frame_mono(const vslam_imu_input* imu, const double* predVelocity, double fps, double* T_cw_out,
+                                             vslam_track_report* rep, vslam_imu_output* imuOut, double* T_wc_pred_out,
+                                             double* predVelOut) {
+    if (!imu || !predVelocity || !T_cw_out || !(fps > 0)) return VSLAM_ERR_INVALID;
+    VS_HIP(hipSetDevice(device));
+    UseMark mark{this};
+    VS_CHECK(refresh_keys());
+    const int Nub = std::max(trNub, 1);
+    VS_CHECK(ensure_track_cap(Nub));
+    VS_CHECK(ensure_pose_cap(Nub));
+    VS_CHECK(ensure_proj_cap(Nub));
+    double Twc16[16], pv[3];
+    VS_CHECK(imu_predict(imu, predVelocity, (double)imu->hz / fps, Twc16, pv));     // predNPose, predVelocity
+    if (T_wc_pred_out) memcpy(T_wc_pred_out, Twc16, sizeof(Twc16));
+    if (predVelOut) memcpy(predVelOut, pv, sizeof(pv));
+    VS_CHECK(imu_setup(imu));          // estimatePoseGTSAMMono integrates the bucket again, dt starting at 1 / hz (:510)
+    const int nL = nKeys[0];
+    DPose Twc, Tcw;
+    pose_from_rm16(Twc16, Twc);
+    pose_inverse(Twc, Tcw);
+    double predInv[16];
+    pose_to_rm16(Tcw, predInv);
+    TrackGeom G{rig.fx, rig.fy, rig.cx, rig.cy, (double)rig.baseline, rig.width, rig.height,
+                (double)(float)std::log((double)feL->prm.scale), feL->nLevels};
+    uint8_t* fl = d_flags;
+    const size_t pc = (size_t)poseCap;
+    const int minInliers = 50;
+    const int* Mdev = d_trCount + 1;
+    int* h_out = (int*)(h_res + 48);
+    int* h_cnt = (int*)(h_res + 52);
+    hipLaunchKernelGGL(k_track_predict, dim3(1), dim3(1024), 0, stream, trNub, d_trXyz, d_trDesc, d_trMsd, d_trOutlier, Tcw, G,
+                       d_mpv, d_points, fl, pc, d_matches, d_trAct, d_trCount, d_matchedL, nL, d_matchedR, 0, d_poseIO, 1);
+    VS_HIP(hipGetLastError());
+    float rad = 1200.f;                // :1398 overrides the 10 / 120 choice
+    int nIn = -1, prevIn = -1, rounds = 0, lmIters = 0, M = 0;
+    float prevrad = rad;
+    bool toBreak = false;
+    while (nIn < minInliers) {
+        rounds++;
+        VS_CHECK(proj_enqueue(Nub, rad, Mdev, nullptr, 0, PROJ_MONO));
+        VS_CHECK(pose_imu_enqueue(Nub, Mdev, nullptr, 0, 0, 1));
+        VS_HIP(hipMemcpyAsync(h_res, d_res, 64 * sizeof(double), hipMemcpyDeviceToHost, stream));
+        VS_HIP(hipStreamSynchronize(stream));
+        M = h_cnt[1];
+        nIn = h_out[0]; lmIters += h_out[2];
+        if (nIn < minInliers && !toBreak) {
+            VS_HIP(hipMemcpyAsync(d_poseIO, predInv, sizeof(predInv), hipMemcpyHostToDevice, stream));
+            if (nL) hipLaunchKernelGGL(k_fill_int, dim3((nL + 255) / 256), dim3(256), 0, stream, d_matchedL, nL, -1);
+            if (M) hipLaunchKernelGGL(k_track_reset, dim3((M + 255) / 256), dim3(256), 0, stream, M, d_matches, fl + 3 * pc);
+            if (nIn < prevIn) { rad = prevrad; toBreak = true; }
+            else { prevrad = rad; prevIn = nIn; rad += 30.0f; }
+        } else break;
+        if (rounds > 3 && !toBreak) toBreak = true;
+    }
+    trN = h_cnt[0];
+    actN = M;
+    memcpy(T_cw_out, h_res, 16 * sizeof(double));
+    if (imuOut) { for (int k = 0; k < 3; k++) imuOut->velocity[k] = h_res[32 + k]; for (int k = 0; k < 6; k++) imuOut->bias[k] = h_res[35 + k]; }
+    if (rep) {
+        rep->n_map_points = trN; rep->n_active = M; rep->rounds = rounds; rep->n_inliers = h_out[0]; rep->n_stereo = h_out[1];
+        rep->lm_iterations = lmIters; rep->last_radius = rad;
+    }
+    return VSLAM_OK;
+}
+
+// flattened activeMapPoints from the caller (mono initialisation / new-point pipeline / tests)
+vslam_status vslam_matcher::track_set_map(const double* xyz, const uint8_t* desc, const float* msd, const uint8_t* outlier, int n) {
+    if (n < 0 || (n > 0 && (!xyz || !desc || !msd))) return VSLAM_ERR_INVALID;
+    VS_HIP(hipSetDevice(device));
+    VS_CHECK(ensure_track_cap(std::max(n, 1)));
+    VS_HIP(hipStreamSynchronize(stream));
+    if (n) {
+        VS_HIP(hipMemcpy(d_trXyz, xyz, (size_t)n * 24, hipMemcpyHostToDevice));
+        VS_HIP(hipMemcpy(d_trDesc, desc, (size_t)n * 32, hipMemcpyHostToDevice));
+        VS_HIP(hipMemcpy(d_trMsd, msd, (size_t)n * 4, hipMemcpyHostToDevice));
+        if (outlier) VS_HIP(hipMemcpy(d_trOutlier, outlier, (size_t)n, hipMemcpyHostToDevice));
+        else VS_HIP(hipMemset(d_trOutlier, 0, (size_t)n));
+    }
+    VS_HIP(hipMemcpy(d_trCount, &n, sizeof(int), hipMemcpyHostToDevice));
+    trNub = n; trN = n;
+    return VSLAM_OK;
+}
+
 extern "C" {
 
 vslam_status vslam_tracker_init_map(vslam_matcher* m, const double* T_wc) {
@@ -350,6 +437,20 @@ vslam_status vslam_tracker_track_imu(vslam_matcher* m, const double* T_wc_pred, 
     if (!m || !imu) return VSLAM_ERR_INVALID;
     m->timer.multi = true;
     return m->track_frame(T_wc_pred, frame_number, T_cw_out, report, imu, imu_out);
+}
+
+vslam_status vslam_tracker_track_mono_imu(vslam_matcher* m, const vslam_imu_input* imu, const double* pred_velocity, double fps,
+                                          double* T_cw_out, vslam_imu_output* imu_out, double* T_wc_pred_out,
+                                          double* pred_velocity_out, vslam_track_report* report) {
+    if (!m) return VSLAM_ERR_INVALID;
+    m->timer.multi = true;
+    return m->track_frame_mono(imu, pred_velocity, fps, T_cw_out, report, imu_out, T_wc_pred_out, pred_velocity_out);
+}
+
+vslam_status vslam_tracker_set_map(vslam_matcher* m, const double* xyz, const uint8_t* desc, const float* max_scale_dist,
+                                   const uint8_t* is_outlier, int32_t n) {
+    if (!m) return VSLAM_ERR_INVALID;
+    return m->track_set_map(xyz, desc, max_scale_dist, is_outlier, n);
 }
 
 vslam_status vslam_tracker_fetch(vslam_matcher* m, int32_t* matches, uint8_t* mps_outliers, int32_t* active_index,

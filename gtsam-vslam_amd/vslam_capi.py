@@ -158,8 +158,9 @@ class Matcher:
         self.fe = (fe_left, fe_right)   # keep the extractors alive
         self.rig = make_rig(rig)
         self.h = C.c_void_p()
-        _chk(self.L.vslam_matcher_create(C.byref(self.rig), fe_left.h, left_image, fe_right.h, right_image,
-                                         C.byref(self.h)))
+        # fe_right = None -> mono matcher (left-only operations of the mono + IMU mode)
+        _chk(self.L.vslam_matcher_create(C.byref(self.rig), fe_left.h, left_image,
+                                         fe_right.h if fe_right is not None else None, right_image, C.byref(self.h)))
 
     def close(self):
         if self.h:
@@ -474,3 +475,78 @@ def tracker_track_imu(matcher, T_wc_pred, frame_number, gravity, noise, T_body_s
     rep = TrackReport()
     _chk(matcher.L.vslam_tracker_track_imu(matcher.h, _p(T), int(frame_number), C.byref(imu), _p(out), C.byref(o), C.byref(rep)))
     return out, {f[0]: getattr(rep, f[0]) for f in TrackReport._fields_}, np.array(list(o.velocity)), np.array(list(o.bias))
+
+
+# ---- mono + IMU mode (C4) -------------------------------------------------------------------------
+def match_projection_mono(matcher, mps, rad, matchedL, matches):
+    """matchByProjectionMono; returns (n, matchedL, matches, ncand)."""
+    mps = np.ascontiguousarray(mps, MPV_DTYPE)
+    mL = np.array(matchedL, np.int32, copy=True)
+    if len(mL) == 0:
+        mL = np.full(1, -1, np.int32)
+    mt = np.array(matches, np.int32, copy=True).reshape(-1, 2)
+    n, nc = C.c_int32(), C.c_int64()
+    _chk(matcher.L.vslam_match_projection_mono(matcher.h, _p(mps), len(mps), C.c_float(rad), _p(mL), _p(mt), C.byref(n), C.byref(nc)))
+    return n.value, mL[:len(matchedL)], mt, nc.value
+
+
+def match_by_radius(matcher, last_kps, last_desc, rad, matchedL):
+    """matchByRadius; returns (n, matchedL, match_out)."""
+    lk = np.ascontiguousarray(last_kps, KP_DTYPE); ld = np.ascontiguousarray(last_desc, np.uint8).reshape(-1, 32)
+    mL = np.array(matchedL, np.int32, copy=True)
+    out = np.full(max(len(lk), 1), -1, np.int32)
+    n = C.c_int32()
+    _chk(matcher.L.vslam_match_by_radius(matcher.h, _p(lk), _p(ld), len(lk), C.c_float(rad), _p(mL), _p(out), C.byref(n)))
+    return n.value, mL, out[:len(lk)]
+
+
+def estimate_pose_mono(matcher, points, in_frame, mp_is_outlier, matches, mps_outliers, gravity, noise, T_body_sensor,
+                       T_wc_prev, vel_prev, bias_prev, acc, gyro, timestamps_ns, hz):
+    """estimatePoseGTSAMMono + findOutliersMono on the matcher's current (left) keypoints."""
+    points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    M = len(points)
+    inF = np.ascontiguousarray(in_frame, np.uint8); mpo = np.ascontiguousarray(mp_is_outlier, np.uint8)
+    mt = np.array(matches, np.int32, copy=True).reshape(-1, 2); out = np.array(mps_outliers, np.uint8, copy=True)
+    prob = PoseProblem()
+    prob.n_mps = M
+    prob.points_xyz, prob.in_frame, prob.in_frame_r = _p(points), _p(inF), None
+    prob.mp_is_outlier, prob.matches, prob.mps_outliers = _p(mpo), _p(mt), _p(out)
+    imu = _imu_input(gravity, noise, T_body_sensor, T_wc_prev, vel_prev, bias_prev, acc, gyro, timestamps_ns, hz)
+    o = ImuOutput()
+    nIn = C.c_int32()
+    rep = LmReport()
+    _chk(matcher.L.vslam_estimate_pose_mono(matcher.h, C.byref(prob), C.byref(imu), C.byref(o), C.byref(nIn), C.byref(rep)))
+    Tout = np.array([prob.T_cw[i] for i in range(16)], np.float64).reshape(4, 4)
+    return dict(T_cw=Tout, vel=np.array(list(o.velocity)), bias=np.array(list(o.bias)), nIn=nIn.value, outliers=out,
+                iterations=rep.iterations, inner=rep.inner_iterations, initialError=rep.initial_error,
+                finalError=rep.final_error, lam=rep.lam)
+
+
+def imu_predict(matcher, gravity, noise, T_body_sensor, T_wc_prev, pred_velocity, bias_prev, acc, gyro, timestamps_ns, hz, last_dt):
+    """PredictNextPoseIMU; returns (T_wc_pred, velocity_pred)."""
+    imu = _imu_input(gravity, noise, T_body_sensor, T_wc_prev, pred_velocity, bias_prev, acc, gyro, timestamps_ns, hz)
+    pv = np.ascontiguousarray(pred_velocity, np.float64)
+    T = np.zeros((4, 4)); v = np.zeros(3)
+    _chk(matcher.L.vslam_imu_predict(matcher.h, C.byref(imu), _p(pv), C.c_double(last_dt), _p(T), _p(v)))
+    return T, v
+
+
+def tracker_set_map(matcher, xyz, desc, max_scale_dist, is_outlier=None):
+    xyz = np.ascontiguousarray(xyz, np.float64).reshape(-1, 3)
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    msd = np.ascontiguousarray(max_scale_dist, np.float32)
+    ol = None if is_outlier is None else np.ascontiguousarray(is_outlier, np.uint8)
+    _chk(matcher.L.vslam_tracker_set_map(matcher.h, _p(xyz), _p(desc), _p(msd), _p(ol) if ol is not None else None, len(xyz)))
+
+
+def tracker_track_mono_imu(matcher, gravity, noise, T_body_sensor, T_wc_prev, vel_prev, bias_prev, pred_velocity, fps,
+                           acc, gyro, timestamps_ns, hz):
+    """Tracking block of TrackImageMonoIMU; returns (T_cw, report, velocity, bias, T_wc_pred, pred_velocity)."""
+    imu = _imu_input(gravity, noise, T_body_sensor, T_wc_prev, vel_prev, bias_prev, acc, gyro, timestamps_ns, hz)
+    pv = np.ascontiguousarray(pred_velocity, np.float64)
+    out = np.zeros((4, 4)); Tp = np.zeros((4, 4)); pvo = np.zeros(3)
+    o = ImuOutput()
+    rep = TrackReport()
+    _chk(matcher.L.vslam_tracker_track_mono_imu(matcher.h, C.byref(imu), _p(pv), C.c_double(fps), _p(out), C.byref(o), _p(Tp), _p(pvo),
+                                                C.byref(rep)))
+    return out, {f[0]: getattr(rep, f[0]) for f in TrackReport._fields_}, np.array(list(o.velocity)), np.array(list(o.bias)), Tp, pvo

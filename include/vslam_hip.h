@@ -175,6 +175,20 @@ vslam_status vslam_match_projection(vslam_matcher* m, const vslam_mappoint_view*
                                     float rad, int32_t* matched_idxs_l, int32_t* matched_idxs_r,
                                     int32_t* matches, int32_t* n_matches, int64_t* n_candidates);
 
+/* FeatureMatcher::matchByProjectionMono (include/FeatureMatcher.h:57, src/FeatureMatcher.cpp:391-456): the left-only
+ * variant of the mono + IMU mode (thresholds matchDistProj + 50 and ratioProj + 0.1); only matches[2i] is written.
+ * Works on a stereo matcher and on a mono matcher (vslam_matcher_create with fe_right = NULL). */
+vslam_status vslam_match_projection_mono(vslam_matcher* m, const vslam_mappoint_view* mps, int32_t n_mps, float rad,
+                                         int32_t* matched_idxs_l, int32_t* matches, int32_t* n_matches,
+                                         int64_t* n_candidates);
+/* FeatureMatcher::matchByRadius (include/FeatureMatcher.h:60, src/FeatureMatcher.cpp:458-526): keypoints of the
+ * last keyframe against the current frame's left keypoints inside rad * scalePyramid[octave], with the
+ * Converter::checkPixelParallax gate (include/Conversions.h:25,140-144).  match_out[i] = index the reference
+ * appends to keyframeIdxMatchs[i], or -1; matched_idxs_l (current keypoints) is in/out. */
+vslam_status vslam_match_by_radius(vslam_matcher* m, const vslam_keypoint* last_kps, const uint8_t* last_desc,
+                                   int32_t n_last, float rad, int32_t* matched_idxs_l, int32_t* match_out,
+                                   int32_t* n_matches);
+
 /* ---------------------------------------------------------------------------
  * Tracker steps — replace FeatureTracker::estimatePoseGTSAM (stereo-only branch) with
  * findOutliersR / check2dError (include/FeatureTracker.h, src/FeatureTracker.cpp:147-411,
@@ -231,6 +245,17 @@ typedef struct vslam_imu_output {
 vslam_status vslam_estimate_pose_imu(vslam_matcher* m, vslam_pose_problem* prob, const vslam_imu_input* imu,
                                      vslam_imu_output* out, int32_t* n_inliers, int32_t* n_stereo,
                                      vslam_lm_report* report);
+/* FeatureTracker::estimatePoseGTSAMMono + findOutliersMono (src/FeatureTracker.cpp:413-580,651-683): the same IMU
+ * solve over left GenericProjectionFactors only (in_frame_r and matches[2i+1] are ignored, may be NULL / -1). */
+vslam_status vslam_estimate_pose_mono(vslam_matcher* m, vslam_pose_problem* prob, const vslam_imu_input* imu,
+                                      vslam_imu_output* out, int32_t* n_inliers, vslam_lm_report* report);
+/* FeatureTracker::PredictNextPoseIMU (src/FeatureTracker.cpp:1036-1106): pre-integrate the bucket and predict
+ * from (imu->T_wc_prev, pred_velocity, imu->bias_prev).  dt0 = start value of the sample period: the reference
+ * initialises it to mHz / mFps here (:1067) and to 1 / mHz in the pose solves (:337,510); a sample takes the
+ * difference to the next timestamp, the last sample reuses the previous value, so dt0 only survives for a
+ * single-sample bucket.  dt0 <= 0 selects 1 / hz. */
+vslam_status vslam_imu_predict(vslam_matcher* m, const vslam_imu_input* imu, const double* pred_velocity, double dt0,
+                               double* T_wc_out, double* velocity_out);
 
 /* worldToFrame for n points and both cameras with pose T_cw: fills pred_l/pred_r (n x 2 floats),
  * scale_level_l/r, in_frame/in_frame_r.  log_scale = KeyFrame::logScale (float log(imScale)). */
@@ -333,6 +358,16 @@ vslam_status vslam_tracker_track(vslam_matcher* m, const double* T_wc_pred, int3
 vslam_status vslam_tracker_track_imu(vslam_matcher* m, const double* T_wc_pred, int32_t frame_number,
                                      const vslam_imu_input* imu, double* T_cw_out, vslam_imu_output* imu_out,
                                      vslam_track_report* report);
+/* Mono + IMU frame (slamMode 2): the tracking block of FeatureTracker::TrackImageMonoIMU (src/FeatureTracker.cpp:
+ * 1379-1450): PredictNextPoseIMU, removeOutOfFrameMPsMono, {matchByProjectionMono (rad 1200, +30 per retry),
+ * estimatePoseGTSAMMono} rounds while inliers < 50.  T_wc_pred_out / pred_velocity_out = predNPose / predVelocity. */
+vslam_status vslam_tracker_track_mono_imu(vslam_matcher* m, const vslam_imu_input* imu, const double* pred_velocity, double fps,
+                                          double* T_cw_out, vslam_imu_output* imu_out, double* T_wc_pred_out,
+                                          double* pred_velocity_out, vslam_track_report* report);
+/* Replace the tracker's map with a flattened activeMapPoints list (position, descriptor, maxScaleDist, outlier
+ * flag): mono initialisation, the new-point pipeline and replays feed the device-resident tracker through it. */
+vslam_status vslam_tracker_set_map(vslam_matcher* m, const double* xyz, const uint8_t* desc, const float* max_scale_dist,
+                                   const uint8_t* is_outlier, int32_t n);
 /* copies of the per-frame tracking state for tests: matches (n_active x 2), MPsOutliers (n_active),
  * source map-point index of every active point */
 vslam_status vslam_tracker_fetch(vslam_matcher* m, int32_t* matches, uint8_t* mps_outliers,

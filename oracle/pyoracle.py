@@ -369,3 +369,51 @@ def estimate_pose_imu(rig, inv_sigma, points, in_frame, in_frame_r, mp_is_outlie
     return dict(T_cw=T, vel=imu[:3].copy(), bias=imu[3:].copy(), nIn=nIn.value, nStereo=nSt.value, matches=mt, outliers=out,
                 rightIdxs=ri, leftIdxs=li, depth=dp, close=cl, iterations=int(rep[0]), inner=int(rep[1]), initialError=rep[2],
                 finalError=rep[3], lam=rep[4])
+
+
+# ---- mono path (C4) ------------------------------------------------------------------------
+def match_projection_mono(exL, rig, mps, kpsL, descL, matchedL, matches, rad):
+    """matchByProjectionMono; matchedL / matches are updated copies."""
+    mps = np.ascontiguousarray(mps, MPV_DTYPE)
+    kpsL = np.ascontiguousarray(kpsL, KP_DTYPE); descL = np.ascontiguousarray(descL, np.uint8)
+    mL = np.array(matchedL, np.int32, copy=True)
+    mt = np.array(matches, np.int32, copy=True).reshape(-1, 2)
+    nc = C.c_longlong()
+    lib().vo_match_projection_mono.restype = C.c_int
+    n = lib().vo_match_projection_mono(exL.h, rig["w"], rig["h"], _p(mps), len(mps), _p(kpsL), _p(descL), len(kpsL),
+                                       _p(mL), _p(mt), C.c_float(rad), C.byref(nc))
+    return n, mL, mt, nc.value
+
+
+def match_by_radius(exL, rig, last_kps, last_desc, act_kps, act_desc, matchedL, rad):
+    """matchByRadius; returns (nMatches, matchedL, matchOut[nLast])."""
+    lk = np.ascontiguousarray(last_kps, KP_DTYPE); ld = np.ascontiguousarray(last_desc, np.uint8)
+    ak = np.ascontiguousarray(act_kps, KP_DTYPE); ad = np.ascontiguousarray(act_desc, np.uint8)
+    mL = np.array(matchedL, np.int32, copy=True)
+    out = np.full(len(lk), -1, np.int32)
+    lib().vo_match_by_radius.restype = C.c_int
+    n = lib().vo_match_by_radius(exL.h, rig["w"], rig["h"], _p(lk), _p(ld), len(lk), _p(ak), _p(ad), len(ak), _p(mL),
+                                 C.c_float(rad), _p(out))
+    return n, mL, out
+
+
+def estimate_pose_mono(rig, inv_sigma, points, in_frame, mp_is_outlier, matches, mps_outliers, kpsL, prm, T_wc_prev,
+                       vel_prev, bias_prev, samples, dts):
+    """estimatePoseGTSAMMono + findOutliersMono."""
+    M = len(points)
+    points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    inF = np.ascontiguousarray(in_frame, np.uint8); mpo = np.ascontiguousarray(mp_is_outlier, np.uint8)
+    mt = np.ascontiguousarray(matches, np.int32).reshape(-1, 2); out = np.array(mps_outliers, np.uint8, copy=True)
+    kpsL = np.ascontiguousarray(kpsL, KP_DTYPE)
+    samples = np.ascontiguousarray(samples, np.float64).reshape(-1, 6); dts = np.ascontiguousarray(dts, np.float64)
+    inv_sigma = np.ascontiguousarray(inv_sigma, np.float32)
+    T = np.zeros((4, 4)); imu = np.zeros(9); rep = np.zeros(5)
+    nIn = C.c_int()
+    lib().vo_estimate_pose_mono(C.c_double(rig["fx"]), C.c_double(rig["fy"]), C.c_double(rig["cx"]), C.c_double(rig["cy"]),
+                                C.c_float(rig["bl"]), rig["w"], rig["h"], _p(inv_sigma), M, _p(points), _p(inF), _p(mpo), _p(mt),
+                                _p(out), _p(kpsL), len(kpsL), _p(np.ascontiguousarray(prm)),
+                                _p(np.ascontiguousarray(T_wc_prev, np.float64)), _p(np.ascontiguousarray(vel_prev, np.float64)),
+                                _p(np.ascontiguousarray(bias_prev, np.float64)), _p(samples), _p(dts), len(dts), _p(T), _p(imu),
+                                C.byref(nIn), _p(rep))
+    return dict(T_cw=T, vel=imu[:3].copy(), bias=imu[3:].copy(), nIn=nIn.value, outliers=out, iterations=int(rep[0]),
+                inner=int(rep[1]), initialError=rep[2], finalError=rep[3], lam=rep[4])

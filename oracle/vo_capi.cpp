@@ -422,3 +422,74 @@ void vo_estimate_pose_imu(double fx, double fy, double cx, double cy, float base
     if (report) { report[0] = R.rep.iterations; report[1] = R.rep.innerIterations; report[2] = R.rep.initialError; report[3] = R.rep.finalError; report[4] = R.rep.lambda; }
 }
 }  // extern "C"
+
+extern "C" {
+// matchByProjectionMono: matchedIdxsL and matches (M x 2) are in/out
+int vo_match_projection_mono(void* hL, int width, int height, const MapPointView* mps, int M, const KeyPoint* kpsL,
+                             const uint8_t* descL, int nL, int* matchedIdxsL, int* matches, float rad, long long* nCand) {
+    Extractor* eL = (Extractor*)hL;
+    TrackedKeys k;
+    k.keyPoints.assign(kpsL, kpsL + nL);
+    k.Desc.assign(descL, descL + (size_t)nL * 32);
+    assignKeysToGrids(k, k.keyPoints, k.lkeyGrid, width, height);
+    std::vector<MapPointView> v(mps, mps + M);
+    std::vector<int> mL(matchedIdxsL, matchedIdxsL + nL);
+    std::vector<std::pair<int, int>> mi(M);
+    for (int i = 0; i < M; i++) mi[i] = {matches[2 * i], matches[2 * i + 1]};
+    long long nc = 0;
+    const int n = matchByProjectionMono(*eL, v, k, mL, mi, rad, &nc);
+    for (int i = 0; i < nL; i++) matchedIdxsL[i] = mL[i];
+    for (int i = 0; i < M; i++) { matches[2 * i] = mi[i].first; matches[2 * i + 1] = mi[i].second; }
+    if (nCand) *nCand = nc;
+    return n;
+}
+
+// matchByRadius: matchedIdxsL in/out, matchOut[nLast] out
+int vo_match_by_radius(void* hL, int width, int height, const KeyPoint* lastKps, const uint8_t* lastDesc, int nLast,
+                       const KeyPoint* actKps, const uint8_t* actDesc, int nAct, int* matchedIdxsL, float rad, int* matchOut) {
+    Extractor* eL = (Extractor*)hL;
+    TrackedKeys k;
+    k.keyPoints.assign(actKps, actKps + nAct);
+    k.Desc.assign(actDesc, actDesc + (size_t)nAct * 32);
+    assignKeysToGrids(k, k.keyPoints, k.lkeyGrid, width, height);
+    std::vector<KeyPoint> lk(lastKps, lastKps + nLast);
+    std::vector<uint8_t> ld(lastDesc, lastDesc + (size_t)nLast * 32);
+    std::vector<int> mL(matchedIdxsL, matchedIdxsL + nAct), out;
+    const int n = matchByRadius(*eL, lk, ld, k, mL, rad, out);
+    for (int i = 0; i < nAct; i++) matchedIdxsL[i] = mL[i];
+    for (int i = 0; i < nLast; i++) matchOut[i] = out[i];
+    return n;
+}
+
+// estimatePoseGTSAMMono + findOutliersMono.  T_cw is output only; imuOut = vel(3) bias(6)
+void vo_estimate_pose_mono(double fx, double fy, double cx, double cy, float baseline, int width, int height,
+                           const float* invSigma, int M, const double* points, const uint8_t* inFrame,
+                           const uint8_t* mpIsOutlier, const int* matches, uint8_t* MPsOutliers, const KeyPoint* kpsL, int nL,
+                           const double* prm, const double* T_wc_prev, const double* vel_prev, const double* bias_prev,
+                           const double* samples, const double* dts, int n, double* T_cw, double* imuOut, int* nIn,
+                           double* report) {
+    Rig rig{fx, fy, cx, cy, baseline, width, height};
+    TrackFrame tf;
+    tf.points.resize(M); tf.inFrame.assign(inFrame, inFrame + M); tf.inFrameR.assign(M, 0);
+    tf.mpIsOutlier.assign(mpIsOutlier, mpIsOutlier + M); tf.MPsOutliers.assign(MPsOutliers, MPsOutliers + M);
+    tf.matches.resize(M);
+    for (int i = 0; i < M; i++) {
+        for (int k = 0; k < 3; k++) tf.points[i].v[k] = points[3 * i + k];
+        tf.matches[i] = {matches[2 * i], matches[2 * i + 1]};
+    }
+    TrackedKeys k;
+    k.keyPoints.assign(kpsL, kpsL + nL);
+    std::vector<PoseFactor> factors;
+    buildPoseFactorsMono(tf, k, invSigma, factors);
+    ImuParams P; memcpy(&P, prm, sizeof(P));
+    ImuSolveResult R;
+    poseImuLM(factors, rig, P, pose_from_rowmajor16(T_wc_prev), vel_prev, bias_prev, samples, dts, n, R);
+    Pose Tcw = pose_inverse(R.T_wc);
+    pose_to_rowmajor16(Tcw, T_cw);
+    *nIn = findOutliersMono(Tcw, tf, k, rig, invSigma, 7.815);
+    for (int i = 0; i < 3; i++) imuOut[i] = R.vel[i];
+    for (int i = 0; i < 6; i++) imuOut[3 + i] = R.bias[i];
+    for (int i = 0; i < M; i++) MPsOutliers[i] = tf.MPsOutliers[i];
+    if (report) { report[0] = R.rep.iterations; report[1] = R.rep.innerIterations; report[2] = R.rep.initialError; report[3] = R.rep.finalError; report[4] = R.rep.lambda; }
+}
+}  // extern "C"

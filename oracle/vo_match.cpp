@@ -265,4 +265,78 @@ int matchByProjectionRPred(const Extractor& feLeft, const std::vector<MapPointVi
     return nMatches;
 }
 
+// matchByProjectionMono: src/FeatureMatcher.cpp:391-456
+int matchByProjectionMono(const Extractor& feLeft, const std::vector<MapPointView>& mps, const TrackedKeys& keys,
+                          std::vector<int>& matchedIdxsL, std::vector<std::pair<int, int>>& matchesIdxs, float rad,
+                          long long* nCandidates) {
+    const int matchDistProj = 100;     // include/FeatureMatcher.h:27
+    const float ratioProj = 0.8f;      // :28
+    int nMatches = 0;
+    for (size_t i = 0; i < mps.size(); i++) {
+        std::pair<int, int>& keyPair = matchesIdxs[i];
+        const MapPointView& mp = mps[i];
+        if (keyPair.first >= 0 || keyPair.second >= 0) continue;
+        const int predScaleLevel = mp.scaleLevelL;
+        const float radius = feLeft.scalePyramid[predScaleLevel] * rad;
+        std::vector<int> idxs;
+        getMatchIdxs(mp.predLx, mp.predLy, idxs, keys, predScaleLevel, radius, false);
+        int bestDist = 256, bestIdx = -1, bestLev = -1, bestLev2 = -1, secDist = 256;
+        if (!idxs.empty() && mp.inFrame) {
+            for (int idx : idxs) {
+                if (matchedIdxsL[idx] >= 0) continue;
+                const int lev = keys.keyPoints[idx].octave;
+                const int dist = descriptorDistance(mp.desc, &keys.Desc[(size_t)idx * 32]);
+                if (nCandidates) (*nCandidates)++;
+                if (dist < bestDist) { secDist = bestDist; bestLev2 = bestLev; bestDist = dist; bestLev = lev; bestIdx = idx; continue; }
+                if (dist < secDist) { secDist = dist; bestLev2 = lev; }
+            }
+        }
+        if (bestDist > (matchDistProj + 50)) continue;
+        if (bestLev == bestLev2 && bestDist >= (ratioProj + 0.1) * secDist) continue;
+        if (bestLev != bestLev2 || bestDist < (ratioProj + 0.1) * secDist) {
+            nMatches++;
+            matchedIdxsL[bestIdx] = (int)i;
+            keyPair.first = bestIdx;
+        }
+    }
+    return nMatches;
+}
+
+// matchByRadius: src/FeatureMatcher.cpp:458-526
+int matchByRadius(const Extractor& feLeft, const std::vector<KeyPoint>& lastKps, const std::vector<uint8_t>& lastDesc,
+                  const TrackedKeys& actKeys, std::vector<int>& matchedIdxsL, float rad, std::vector<int>& matchOut) {
+    const int matchDistProj = 100;
+    const float ratioProj = 0.8f;
+    const double pixelParallaxThresh = 10.0;
+    int nMatches = 0;
+    matchOut.assign(lastKps.size(), -1);
+    for (size_t i = 0; i < lastKps.size(); i++) {
+        const KeyPoint key = lastKps[i];
+        const uint8_t* mpDesc = &lastDesc[i * 32];
+        const int predScaleLevel = key.octave;
+        const float radius = feLeft.scalePyramid[predScaleLevel] * rad;
+        std::vector<int> idxs;
+        getMatchIdxs(key.x, key.y, idxs, actKeys, predScaleLevel, radius, false);
+        int bestDist = 256, bestIdx = -1, bestLev = -1, bestLev2 = -1, secDist = 256;
+        for (int idx : idxs) {
+            if (matchedIdxsL[idx] >= 0) continue;
+            const KeyPoint& kPL = actKeys.keyPoints[idx];
+            const double dx = (double)kPL.x - (double)key.x, dy = (double)kPL.y - (double)key.y;
+            if (!(std::sqrt(dx * dx + dy * dy) > pixelParallaxThresh)) continue;      // (p2 - p1).norm() > thresh
+            const int lev = kPL.octave;
+            const int dist = descriptorDistance(mpDesc, &actKeys.Desc[(size_t)idx * 32]);
+            if (dist < bestDist) { secDist = bestDist; bestLev2 = bestLev; bestDist = dist; bestLev = lev; bestIdx = idx; continue; }
+            if (dist < secDist) { secDist = dist; bestLev2 = lev; }
+        }
+        if (bestDist > matchDistProj) continue;
+        if (bestLev == bestLev2 && (float)bestDist >= ratioProj * (float)secDist) continue;
+        if (bestLev != bestLev2 || (float)bestDist < ratioProj * (float)secDist) {
+            nMatches++;
+            matchedIdxsL[bestIdx] = (int)i;
+            matchOut[i] = bestIdx;
+        }
+    }
+    return nMatches;
+}
+
 }  // namespace vo

@@ -47,4 +47,15 @@ int matchByProjectionRPred(const Extractor& feLeft, const std::vector<MapPointVi
                            std::vector<int>& matchedIdxsR, std::vector<std::pair<int, int>>& matchesIdxs,
                            float rad, long long* nCandidates = nullptr);
 
+// matchByProjectionMono (src/FeatureMatcher.cpp:391-456): left-only variant, thresholds matchDistProj + 50 and
+// (ratioProj + 0.1) (evaluated in double, as the C++ expression promotes)
+int matchByProjectionMono(const Extractor& feLeft, const std::vector<MapPointView>& mps, const TrackedKeys& keys,
+                          std::vector<int>& matchedIdxsL, std::vector<std::pair<int, int>>& matchesIdxs, float rad,
+                          long long* nCandidates = nullptr);
+// matchByRadius (src/FeatureMatcher.cpp:458-526): last-keyframe keypoints against the current frame's, with the
+// pixel-parallax gate of Converter::checkPixelParallax (include/Conversions.h:25,140-144).  matchOut[i] = index of
+// the matched current keypoint (what the reference appends to keyframeIdxMatchs[i]) or -1.
+int matchByRadius(const Extractor& feLeft, const std::vector<KeyPoint>& lastKps, const std::vector<uint8_t>& lastDesc,
+                  const TrackedKeys& actKeys, std::vector<int>& matchedIdxsL, float rad, std::vector<int>& matchOut);
+
 }  // namespace vo

@@ -133,6 +133,25 @@ void buildPoseFactors(const TrackFrame& tf, const TrackedKeys& keys, const float
     }
 }
 
+void buildPoseFactorsMono(const TrackFrame& tf, const TrackedKeys& keys, const float* InvSigmaFactor,
+                          std::vector<PoseFactor>& out) {
+    out.clear();
+    for (size_t i = 0; i < tf.matches.size(); i++) {
+        if (tf.MPsOutliers[i]) continue;
+        if (tf.mpIsOutlier[i]) continue;
+        const std::pair<int, int>& kp = tf.matches[i];
+        if (kp.first < 0) continue;
+        if (!tf.inFrame[i]) continue;
+        PoseFactor f{};
+        for (int k = 0; k < 3; k++) f.p[k] = tf.points[i].v[k];
+        const KeyPoint& kl = keys.keyPoints[kp.first];
+        f.sigma = 1.0 / InvSigmaFactor[kl.octave];
+        f.type = 1;
+        f.z[0] = kl.x; f.z[1] = kl.y;
+        out.push_back(f);
+    }
+}
+
 // residual (whitened) and, optionally, the 6-column Jacobian rows (whitened) of one factor.
 // GenericStereoFactor / GenericProjectionFactor with Pose3 local coordinates [omega, v],
 // d(transformTo)/d(xi) = [ skew(q), -I ]; behind-camera points give the constant residual
@@ -307,6 +326,25 @@ bool worldToFrame(const Vec3& wp, const Pose& T_cw, const Rig& rig, float maxSca
     uo = (float)u;
     vo = (float)v;
     return true;
+}
+
+// findOutliersMono: src/FeatureTracker.cpp:651-683
+int findOutliersMono(const Pose& T_cw, TrackFrame& tf, const TrackedKeys& keys, const Rig& rig,
+                     const float* InvSigmaFactor, double thres) {
+    int nInliers = 0;
+    for (size_t i = 0; i < tf.matches.size(); i++) {
+        const std::pair<int, int>& kp = tf.matches[i];
+        if (kp.first < 0) continue;
+        if (!tf.inFrame[i]) continue;
+        Vec3 pc = mat3_vec(T_cw.R, tf.points[i]);
+        for (int k = 0; k < 3; k++) pc.v[k] += T_cw.t.v[k];
+        const KeyPoint& kl = keys.keyPoints[kp.first];
+        const double weight = (double)InvSigmaFactor[kl.octave];
+        const bool outlier = check2dError(pc, kl.x, kl.y, rig, thres, weight);
+        tf.MPsOutliers[i] = outlier;
+        if (!outlier) nInliers++;
+    }
+    return nInliers;
 }
 
 }  // namespace vo

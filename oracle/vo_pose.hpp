@@ -61,6 +61,12 @@ struct TrackFrame {           // the slice of tracker state estimatePoseGTSAM / 
 int poseFactorResidual(const PoseFactor& f, const Pose& T, const Rig& rig, double r[3], double J[3][6]);
 void buildPoseFactors(const TrackFrame& tf, const TrackedKeys& keys, const float* InvSigmaFactor,
                       std::vector<PoseFactor>& out);
+// factor list of estimatePoseGTSAMMono (src/FeatureTracker.cpp:440-476): left GenericProjectionFactors only
+void buildPoseFactorsMono(const TrackFrame& tf, const TrackedKeys& keys, const float* InvSigmaFactor,
+                          std::vector<PoseFactor>& out);
+// findOutliersMono (:651-683): returns nInliers (the reference returns it in both slots of its pair)
+int findOutliersMono(const Pose& T_cw, TrackFrame& tf, const TrackedKeys& keys, const Rig& rig,
+                     const float* InvSigmaFactor, double thres);
 // optimise T_wc from an initial guess; returns the LM report
 void poseOnlyLM(const std::vector<PoseFactor>& factors, const Rig& rig, Pose& T_wc, LMReport& rep,
                 const LMParams& prm = LMParams());
