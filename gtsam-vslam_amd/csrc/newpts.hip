@@ -1,0 +1,483 @@
+// New-point pipeline of the optimizer thread on gfx950 — LocalMapper::findNewPoints without the map insertion
+// (reference src/OptimizationBA.cpp:14-391): calcAllMpsOfKFROnlyEst, predictKeysPosR,
+// FeatureMatcher::matchByProjectionRPredLBA (src/FeatureMatcher.cpp:66-252), triangulateNewPoints
+// (gtsam::triangulatePoint3<Cal3_S2>: DLT + cheirality, GTSAM 4.2) and checkReprojError; plus
+// MapPoint::calcDescriptor (src/Map.cpp:145-210).
+//   k_np_candidates   one workgroup: order-preserving compaction of the last keyframe's left keypoints into the
+//                     candidate list (back-projected stereo keypoints / unassociated map points)
+//   k_np_match        wave = (candidate, keyframe): predicted L/R positions, window scan with popcount Hamming
+//                     (scan_side of the projection matcher; no claims here, so all pairs run in parallel),
+//                     the accept rules incl. the parallax gate
+//   k_np_triangulate  thread = candidate, 64 per workgroup, the 2m x 4 DLT system in LDS: one-sided Jacobi SVD,
+//                     rank / cheirality tests, the reprojection filter (sequential by definition, a few entries)
+//   k_calc_descriptor wave = map point: N x N Hamming distances, rank-selected median, first minimum
+#include "proj_dev.hpp"
+#include "dmath.hpp"
+#include <vector>
+
+namespace vslam {
+
+constexpr int NP_MAX_KF = 16;          // keyframes per call (the reference window is 10)
+constexpr int NP_MAX_ROWS = 4 * NP_MAX_KF;
+
+struct NpKf {                           // device view of one keyframe
+    DPose Twc, Tcw;
+    const vslam_keypoint* kpsL; const vslam_keypoint* kpsR;
+    const uint8_t* descL; const uint8_t* descR;
+    const int* rightIdxs; const int* leftIdxs; const int* unF; const int* unFR;
+    int nL, nR;
+    int skip;                           // same keyframe as lastKF (src/OptimizationBA.cpp:358-359)
+};
+struct NpArgs {
+    NpKf kf[NP_MAX_KF];
+    int nKf;
+    const float* depth; const uint8_t* hasMp; const double* mpXyz; const uint8_t* mpDesc;   // last keyframe extras
+    double fx, fy, cx, cy, b; int w, h;
+    float scalePyr[MAX_LEVELS], sigma[MAX_LEVELS];
+    float logScale; int nLev;
+    float xMult, yMult; int xGrids, yGrids;
+    // candidates
+    double* wPos; int* key; float* mds; uint8_t* cdesc; int* count; int cap;
+    int* match;            // [cap][NP_MAX_KF][2]  (-2 = keyframe not matched)
+    // results
+    uint8_t* accepted; double* xyz; int* nObs; int* obs;     // obs: [cap][NP_MAX_KF][3] = (kf, l, r)
+};
+
+__device__ __forceinline__ int np_block_scan_1024(int flag, int* wsum, int& total) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long bal = __ballot(flag);
+    const int lanePrefix = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int off = 0, tot = 0;
+    for (int k = 0; k < 16; k++) { const int v = wsum[k]; if (k < wave) off += v; tot += v; }
+    __syncthreads();
+    total = tot;
+    return off + lanePrefix;
+}
+
+__global__ __launch_bounds__(1024) void k_np_candidates(NpArgs A) {
+    __shared__ int wsum[16];
+    const NpKf& K0 = A.kf[0];
+    int run = 0;
+    for (int base = 0; base < K0.nL; base += 1024) {
+        const int i = base + threadIdx.x;
+        bool keep = false;
+        double wp[3] = {0, 0, 0};
+        if (i < K0.nL) {
+            if (!A.hasMp[i]) {
+                if (A.depth[i] > 0) {
+                    keep = true;
+                    const double zp = (double)A.depth[i];
+                    const double xp = ((double)K0.kpsL[i].x - A.cx) * zp / A.fx;
+                    const double yp = ((double)K0.kpsL[i].y - A.cy) * zp / A.fy;
+                    const double pc[3] = {xp, yp, zp};
+                    mat3_vec(K0.Twc.R, pc, wp);
+                    for (int k = 0; k < 3; k++) wp[k] += K0.Twc.t[k];
+                }
+            } else if (K0.unF[i] < 0) {
+                keep = true;
+                for (int k = 0; k < 3; k++) wp[k] = A.mpXyz[3 * (size_t)i + k];
+            }
+        }
+        int tot;
+        const int pos = run + np_block_scan_1024(keep, wsum, tot);
+        if (keep && pos < A.cap) {
+            for (int k = 0; k < 3; k++) A.wPos[3 * (size_t)pos + k] = wp[k];
+            A.key[2 * pos] = i; A.key[2 * pos + 1] = K0.rightIdxs[i];
+            const double d[3] = {wp[0] - K0.Twc.t[0], wp[1] - K0.Twc.t[1], wp[2] - K0.Twc.t[2]};
+            float dist = (float)sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+            dist *= A.scalePyr[K0.kpsL[i].octave];
+            A.mds[pos] = dist;
+            // the descriptor matched against: the map point's if the keypoint has one, else the keypoint's (:76-86)
+            const uint4* s = (const uint4*)((A.hasMp[i] ? A.mpDesc : K0.descL) + (size_t)i * 32);
+            uint4* dd = (uint4*)(A.cdesc + (size_t)pos * 32);
+            dd[0] = s[0]; dd[1] = s[1];
+        }
+        run += tot;
+    }
+    if (threadIdx.x == 0) A.count[0] = run < A.cap ? run : A.cap;
+}
+
+// predictKeysPosR + matchByProjectionRPredLBA for (candidate = blockIdx.x * 4 + wave, keyframe = blockIdx.y + 1)
+__global__ __launch_bounds__(256) void k_np_match(NpArgs A) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 4 + wave, k = blockIdx.y + 1;
+    if (c >= A.count[0]) return;
+    const NpKf& K = A.kf[k];
+    int outL = -2, outR = -2;
+    if (K.skip) { if (lane == 0) { A.match[((size_t)c * NP_MAX_KF + k) * 2] = -2; A.match[((size_t)c * NP_MAX_KF + k) * 2 + 1] = -2; } return; }
+    const double wp[3] = {A.wPos[3 * (size_t)c], A.wPos[3 * (size_t)c + 1], A.wPos[3 * (size_t)c + 2]};
+    double p[3];
+    mat3_vec(K.Tcw.R, wp, p);
+    for (int q = 0; q < 3; q++) p[q] += K.Tcw.t[q];
+    const double pRx3 = p[0] - A.b;
+    bool hasL = false, hasR = false;
+    float pLx = 0, pLy = 0, pRx = 0, pRy = 0;
+    if (!(p[2] <= 0.0)) {
+        const double invZ = 1.0f / p[2];
+        const double u = A.fx * p[0] * invZ + A.cx, v = A.fy * p[1] * invZ + A.cy;
+        const double uR = A.fx * pRx3 * invZ + A.cx, vR = A.fy * p[1] * invZ + A.cy;
+        if (!(u < 15 || v < 15 || u >= A.w - 15 || v >= A.h - 15)) { hasL = true; pLx = (float)u; pLy = (float)v; }
+        if (!(uR < 15 || vR < 15 || uR >= A.w - 15 || vR >= A.h - 15)) { hasR = true; pRx = (float)uR; pRy = (float)vR; }
+    }
+    const double d[3] = {wp[0] - K.Twc.t[0], wp[1] - K.Twc.t[1], wp[2] - K.Twc.t[2]};
+    const float dist = (float)sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    const float dif = A.mds[c] / dist;
+    const double qs = log((double)dif) / (double)A.logScale;
+    int predScale = (int)qs;
+    predScale += (predScale < qs);
+    if (predScale < 0) predScale = 0; else if (predScale >= A.nLev) predScale = A.nLev - 1;
+    uint32_t md[8];
+    {
+        const uint32_t* pd = (const uint32_t*)(A.cdesc + (size_t)c * 32);
+#pragma unroll
+        for (int q = 0; q < 8; q++) md[q] = pd[q];
+    }
+    ProjArgs S{};
+    S.kps[0] = K.kpsL; S.kps[1] = K.kpsR; S.desc[0] = K.descL; S.desc[1] = K.descR; S.n[0] = K.nL; S.n[1] = K.nR;
+    S.rad = 4.f;
+#pragma unroll
+    for (int l = 0; l < MAX_LEVELS; l++) S.scalePyr[l] = A.scalePyr[l];
+    S.xMult = A.xMult; S.yMult = A.yMult; S.xGrids = A.xGrids; S.yGrids = A.yGrids; S.mode = PROJ_STEREO;
+    unsigned long long l2[2] = {KEY_NONE, KEY_NONE}, r2[2] = {KEY_NONE, KEY_NONE};
+    if (hasL && pLx > 0 && pLy > 0) scan_side<2>(S, 0, md, pLx, pLy, predScale, K.unF, l2);
+    if (hasR && pRx > 0 && pRy > 0) scan_side<2>(S, 1, md, pRx, pRy, predScale, K.unFR, r2);
+    if (lane == 0) {
+        const int matchDistLBA = 50;         // include/FeatureMatcher.h:29
+        const float ratioLBA = 0.6f;         // :30
+        const unsigned long long POS = ((1ull << 36) - 1ull) & ~0xffull;      // (cell, idx) = visit position
+        int bestDist = 256, bestIdx = -1, bestLev = -1, bestLev2 = -1, secDist = 256;
+        if (l2[0] != KEY_NONE && key_dist(l2[0]) < 256) { bestDist = key_dist(l2[0]); bestIdx = key_idx(l2[0]); bestLev = key_oct(l2[0]); }
+        if (l2[1] != KEY_NONE && key_dist(l2[1]) < 256 && bestIdx >= 0) {
+            secDist = key_dist(l2[1]);
+            // (sic) the reference's left scan stores the BEST level when a later candidate becomes second (:131)
+            bestLev2 = ((l2[1] & POS) > (l2[0] & POS)) ? bestLev : key_oct(l2[1]);
+        }
+        int bestDistR = 256, bestIdxR = -1, bestLevR = -1, bestLevR2 = -1, secDistR = 256;
+        if (r2[0] != KEY_NONE && key_dist(r2[0]) < 256) { bestDistR = key_dist(r2[0]); bestIdxR = key_idx(r2[0]); bestLevR = key_oct(r2[0]); }
+        if (r2[1] != KEY_NONE && key_dist(r2[1]) < 256 && bestIdxR >= 0) { secDistR = key_dist(r2[1]); bestLevR2 = key_oct(r2[1]); }
+        bool right = false;
+        if (bestDist > bestDistR) { bestDist = bestDistR; secDist = secDistR; bestLev = bestLevR; bestLev2 = bestLevR2; right = true; }
+        bool ok = !(bestDist > matchDistLBA);
+        if (ok && bestLev == bestLev2 && (float)bestDist >= ratioLBA * (float)secDist) ok = false;
+        if (ok) {
+            const int keyL = A.key[2 * c], keyR = A.key[2 * c + 1];
+            const NpKf& K0 = A.kf[0];
+            const vslam_keypoint kk = right ? (keyR >= 0 ? K0.kpsR[keyR] : K0.kpsL[keyL]) : (keyL >= 0 ? K0.kpsL[keyL] : K0.kpsR[keyR]);
+            const double dx = (double)(right ? pRx : pLx) - (double)kk.x, dy = (double)(right ? pRy : pLy) - (double)kk.y;
+            if (!(sqrt(dx * dx + dy * dy) > 10.0)) ok = false;         // Converter::checkPixelParallax
+        }
+        if (ok) {
+            if (right) { outR = bestIdxR; const int l = K.leftIdxs[bestIdxR]; outL = l >= 0 ? l : -1; }
+            else { outL = bestIdx; const int r = K.rightIdxs[bestIdx]; outR = r >= 0 ? r : -1; }
+        }
+        A.match[((size_t)c * NP_MAX_KF + k) * 2] = outL;
+        A.match[((size_t)c * NP_MAX_KF + k) * 2 + 1] = outR;
+    }
+}
+
+// triangulateNewPoints + checkReprojError: thread = candidate; the DLT rows of 64 candidates live in LDS,
+// element (row, col) of thread t at ((row * 4 + col) * 64 + t) - conflict-free
+__global__ __launch_bounds__(64) void k_np_triangulate(NpArgs A) {
+    extern __shared__ double sA[];
+    const int t = threadIdx.x, c = blockIdx.x * 64 + t;
+    if (c >= A.count[0]) return;
+    auto a = [&](int r, int q) -> double& { return sA[((size_t)(r * 4 + q)) * 64 + t]; };
+    int* obs = A.obs + (size_t)c * NP_MAX_KF * 3;
+    // matchesOfPoint: (lastKF, keyPos) then the matched keyframes in window order
+    int n = 0;
+    obs[0] = 0; obs[1] = A.key[2 * c]; obs[2] = A.key[2 * c + 1]; n = 1;
+    for (int k = 1; k < A.nKf; k++) {
+        const int l = A.match[((size_t)c * NP_MAX_KF + k) * 2], r = A.match[((size_t)c * NP_MAX_KF + k) * 2 + 1];
+        if (l == -2 && r == -2) continue;
+        obs[3 * n] = k; obs[3 * n + 1] = l; obs[3 * n + 2] = r; n++;
+    }
+    A.accepted[c] = 0;
+    A.nObs[c] = n;
+    if (n < 3) return;                                   // minCount (include/OptimizationBA.h:47)
+    // DLT rows
+    int rows = 0;
+    for (int e = 0; e < n; e++) {
+        const NpKf& K = A.kf[obs[3 * e]];
+        for (int side = 0; side < 2; side++) {
+            const int idx = obs[3 * e + 1 + side];
+            if (idx < 0) continue;
+            const vslam_keypoint kp = side ? K.kpsR[idx] : K.kpsL[idx];
+            const double u = (double)kp.x, v = (double)kp.y;
+            double M[12];
+            for (int r = 0; r < 3; r++) { for (int q = 0; q < 3; q++) M[4 * r + q] = K.Tcw.R[3 * r + q]; M[4 * r + 3] = K.Tcw.t[r]; }
+            if (side) M[3] -= A.b;
+            for (int q = 0; q < 4; q++) {
+                const double P0 = A.fx * M[q] + 0.0 * M[4 + q] + A.cx * M[8 + q];
+                const double P1 = 0.0 * M[q] + A.fy * M[4 + q] + A.cy * M[8 + q];
+                const double P2 = 0.0 * M[q] + 0.0 * M[4 + q] + 1.0 * M[8 + q];
+                a(rows, q) = u * P2 - P0;
+                a(rows + 1, q) = v * P2 - P1;
+            }
+            rows += 2;
+        }
+    }
+    if (rows < 4) return;                                // fewer than two observations
+    // one-sided Jacobi SVD, fixed pair order
+    double V[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) V[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; sweep++) {
+        bool rotated = false;
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int q = p + 1; q < 4; q++) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int r = 0; r < rows; r++) {
+                    const double ap = a(r, p), aq = a(r, q);
+                    alpha += ap * ap; beta += aq * aq; gamma += ap * aq;
+                }
+                if (gamma == 0.0 || fabs(gamma) <= 1e-15 * sqrt(alpha * beta)) continue;
+                rotated = true;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+                for (int r = 0; r < rows; r++) {
+                    const double ap = a(r, p), aq = a(r, q);
+                    a(r, p) = cs * ap - sn * aq;
+                    a(r, q) = sn * ap + cs * aq;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const double vp = V[4 * r + p], vq = V[4 * r + q];
+                    V[4 * r + p] = cs * vp - sn * vq;
+                    V[4 * r + q] = sn * vp + cs * vq;
+                }
+            }
+        if (!rotated) break;
+    }
+    double s[4];
+    int rank = 0, minc = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        double n2 = 0;
+        for (int r = 0; r < rows; r++) n2 += a(r, q) * a(r, q);
+        s[q] = sqrt(n2);
+        if (s[q] > 1e-9) rank++;
+    }
+#pragma unroll
+    for (int q = 1; q < 4; q++) if (s[q] < s[minc]) minc = q;
+    if (rank < 3) return;                                // TriangulationUnderconstrainedException
+    double vm[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        double v = V[4 * r];
+#pragma unroll
+        for (int q = 1; q < 4; q++) v = (q == minc) ? V[4 * r + q] : v;
+        vm[r] = v;
+    }
+    const double pt[3] = {vm[0] / vm[3], vm[1] / vm[3], vm[2] / vm[3]};
+    for (int k = 0; k < 3; k++) A.xyz[3 * (size_t)c + k] = pt[k];
+    // cheirality (GTSAM_THROW_CHEIRALITY_EXCEPTION): behind any camera -> rejected
+    for (int e = 0; e < n; e++) {
+        const NpKf& K = A.kf[obs[3 * e]];
+        const double z = K.Tcw.R[6] * pt[0] + K.Tcw.R[7] * pt[1] + K.Tcw.R[8] * pt[2];
+        for (int side = 0; side < 2; side++)
+            if (obs[3 * e + 1 + side] >= 0 && z + K.Tcw.t[2] <= 0) return;
+    }
+    // checkReprojError (:14-88), literally: entries are compacted in place, `match` aliases entry i
+    const float reprjThreshold = 7.815f;
+    int count = 0;
+    bool correctKF = false;
+    for (int i = 0; i < n; i++) {
+        const int kfi = obs[3 * i];
+        const NpKf& K = A.kf[kfi];
+        bool cor = false;
+        for (int side = 0; side < 2; side++) {
+            const int idx = obs[3 * i + 1 + side];
+            if (idx < 0) continue;
+            const vslam_keypoint kp = side ? K.kpsR[idx] : K.kpsL[idx];
+            double pc[3];
+            mat3_vec(K.Tcw.R, pt, pc);
+            for (int q = 0; q < 3; q++) pc[q] += K.Tcw.t[q];
+            if (side) pc[0] -= A.b;
+            const double px = A.fx * pc[0] + A.cx * pc[2], py = A.fy * pc[1] + A.cy * pc[2], pz = pc[2];
+            const double e1 = (double)kp.x - px / pz, e2 = (double)kp.y - py / pz;
+            const float err = (float)(e1 * e1 + e2 * e2);
+            const double weight = (double)A.sigma[kp.octave];
+            if ((double)err > (double)reprjThreshold * weight) obs[3 * i + 1 + side] = -1;
+            else {
+                obs[3 * count] = obs[3 * i]; obs[3 * count + 1] = obs[3 * i + 1]; obs[3 * count + 2] = obs[3 * i + 2];
+                cor = true;
+                if (kfi == 0) correctKF = true;
+            }
+        }
+        if (cor) count++;
+    }
+    A.nObs[c] = count;
+    A.accepted[c] = (count >= 3 && correctKF) ? 1 : 0;
+}
+
+// MapPoint::calcDescriptor: wave = one map point with n <= 64 observation descriptors (lane = descriptor)
+__global__ __launch_bounds__(256) void k_calc_descriptor(int nMp, const uint8_t* __restrict__ descs, const int* __restrict__ start,
+                                                         int* __restrict__ best) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = blockIdx.x * 4 + wave;
+    if (m >= nMp) return;
+    const int s0 = start[m], n = start[m + 1] - s0;
+    if (n <= 0) { if (lane == 0) best[m] = -1; return; }
+    uint32_t mine[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (lane < n) {
+        const uint32_t* p = (const uint32_t*)(descs + (size_t)(s0 + lane) * 32);
+#pragma unroll
+        for (int q = 0; q < 8; q++) mine[q] = p[q];
+    }
+    // dist[j] for j < n in registers is too much for n = 64; the median only needs a rank selection:
+    // k-th smallest of {d(lane, j)} = smallest v with #{d <= v} > k, found by counting over the 257 values
+    int d[64];
+#pragma unroll
+    for (int j = 0; j < 64; j++) {
+        int dd = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) dd += __popc(mine[q] ^ (uint32_t)__shfl((int)mine[q], j));
+        d[j] = (j < n && j != lane) ? dd : (j == lane ? 0 : 1 << 20);
+    }
+    const int kth = (int)(0.5 * (n - 1));
+    int median = 1 << 20;
+    if (lane < n) {
+        // selection by counting: the kth order statistic is the value v = d[j] with #{d < v} <= kth < #{d <= v}
+#pragma unroll
+        for (int j = 0; j < 64; j++) {
+            const int v = d[j];
+            int lt = 0, le = 0;
+#pragma unroll
+            for (int i = 0; i < 64; i++) { lt += d[i] < v; le += d[i] <= v; }
+            if (lt <= kth && kth < le) median = v;
+        }
+    }
+    // first lane with the least median
+    int bm = median;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) bm = min(bm, __shfl_xor(bm, o));
+    const unsigned long long bal = __ballot(median == bm);
+    if (lane == 0) best[m] = __ffsll((long long)bal) - 1;
+}
+
+}  // namespace vslam
+
+using namespace vslam;
+
+namespace {
+template <class T>
+struct Dev {
+    T* p = nullptr;
+    ~Dev() { if (p) hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T)); }
+    hipError_t up(const T* h, size_t n, hipStream_t s) { hipError_t e = alloc(n); if (e != hipSuccess || !n) return e; return hipMemcpyAsync(p, h, n * sizeof(T), hipMemcpyHostToDevice, s); }
+};
+}  // namespace
+
+extern "C" vslam_status vslam_find_new_points(const vslam_new_points_problem* P, vslam_new_points_result* R, int32_t device) {
+    if (!P || !R || P->n_kf < 1 || P->n_kf > NP_MAX_KF || !P->kfs || P->n_levels < 1 || P->n_levels > MAX_LEVELS ||
+        !P->scale_pyramid || !P->sigma_factor || !R->cand_left || !R->cand_right || !R->accepted || !R->xyz || !R->n_obs || !R->obs) {
+        set_error("vslam_find_new_points: invalid problem");
+        return VSLAM_ERR_INVALID;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available (no CPU fallback)"); return VSLAM_ERR_NO_DEVICE; }
+    if (device < 0 || device >= ndev) return VSLAM_ERR_INVALID;
+    VS_HIP(hipSetDevice(device));
+    const vslam_kf_view& K0 = P->kfs[0];
+    if (K0.n_left > 0 && (!P->estimated_depth || !P->has_mp || !K0.right_idxs || !K0.unmatched_f)) { set_error("vslam_find_new_points: last keyframe arrays missing"); return VSLAM_ERR_INVALID; }
+    hipStream_t stream;
+    VS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { hipStreamSynchronize(s); hipStreamDestroy(s); } } guard{stream};
+    const int cap = std::max(K0.n_left, 1);
+    NpArgs A{};
+    A.nKf = P->n_kf;
+    std::vector<Dev<vslam_keypoint>> dKL(P->n_kf), dKR(P->n_kf);
+    std::vector<Dev<uint8_t>> dDL(P->n_kf), dDR(P->n_kf);
+    std::vector<Dev<int>> dRi(P->n_kf), dLi(P->n_kf), dUf(P->n_kf), dUfr(P->n_kf);
+    for (int k = 0; k < P->n_kf; k++) {
+        const vslam_kf_view& V = P->kfs[k];
+        if (V.n_left < 0 || V.n_right < 0 || !V.T_wc || (V.n_left > 0 && (!V.kps_l || !V.desc_l || !V.right_idxs || !V.unmatched_f)) ||
+            (V.n_right > 0 && (!V.kps_r || !V.desc_r || !V.left_idxs || !V.unmatched_fr)) || V.n_left > 65535 || V.n_right > 65535) {
+            set_error("vslam_find_new_points: keyframe %d arrays missing", k);
+            return VSLAM_ERR_INVALID;
+        }
+        NpKf& D = A.kf[k];
+        pose_from_rm16(V.T_wc, D.Twc);
+        pose_inverse(D.Twc, D.Tcw);
+        VS_HIP(dKL[k].up(V.kps_l, V.n_left, stream)); VS_HIP(dKR[k].up(V.kps_r, V.n_right, stream));
+        VS_HIP(dDL[k].up(V.desc_l, (size_t)V.n_left * 32, stream)); VS_HIP(dDR[k].up(V.desc_r, (size_t)V.n_right * 32, stream));
+        VS_HIP(dRi[k].up(V.right_idxs, V.n_left, stream)); VS_HIP(dLi[k].up(V.left_idxs, V.n_right, stream));
+        VS_HIP(dUf[k].up(V.unmatched_f, V.n_left, stream)); VS_HIP(dUfr[k].up(V.unmatched_fr, V.n_right, stream));
+        D.kpsL = dKL[k].p; D.kpsR = dKR[k].p; D.descL = dDL[k].p; D.descR = dDR[k].p;
+        D.rightIdxs = dRi[k].p; D.leftIdxs = dLi[k].p; D.unF = dUf[k].p; D.unFR = dUfr[k].p;
+        D.nL = V.n_left; D.nR = V.n_right;
+        D.skip = (k > 0 && V.id == P->kfs[0].id) ? 1 : 0;
+    }
+    Dev<float> dDepth; Dev<uint8_t> dHas, dMpDesc, dCdesc, dAcc; Dev<double> dMpXyz, dWpos, dXyz; Dev<int> dKey, dCount, dMatch, dNobs, dObs; Dev<float> dMds;
+    std::vector<uint8_t> zeroDesc;
+    VS_HIP(dDepth.up(P->estimated_depth, K0.n_left, stream)); VS_HIP(dHas.up(P->has_mp, K0.n_left, stream));
+    if (P->mp_xyz) VS_HIP(dMpXyz.up(P->mp_xyz, (size_t)3 * K0.n_left, stream)); else VS_HIP(dMpXyz.alloc((size_t)3 * cap));
+    if (P->mp_desc) VS_HIP(dMpDesc.up(P->mp_desc, (size_t)32 * K0.n_left, stream)); else VS_HIP(dMpDesc.alloc((size_t)32 * cap));
+    VS_HIP(dWpos.alloc((size_t)3 * cap)); VS_HIP(dKey.alloc((size_t)2 * cap)); VS_HIP(dMds.alloc(cap)); VS_HIP(dCdesc.alloc((size_t)32 * cap));
+    VS_HIP(dCount.alloc(4)); VS_HIP(dMatch.alloc((size_t)cap * NP_MAX_KF * 2)); VS_HIP(dAcc.alloc(cap)); VS_HIP(dXyz.alloc((size_t)3 * cap));
+    VS_HIP(dNobs.alloc(cap)); VS_HIP(dObs.alloc((size_t)cap * NP_MAX_KF * 3));
+    VS_HIP(hipMemsetAsync(dAcc.p, 0, cap, stream)); VS_HIP(hipMemsetAsync(dXyz.p, 0, (size_t)3 * cap * sizeof(double), stream));
+    VS_HIP(hipMemsetAsync(dNobs.p, 0, (size_t)cap * sizeof(int), stream));
+    VS_HIP(hipMemsetAsync(dObs.p, 0xff, (size_t)cap * NP_MAX_KF * 3 * sizeof(int), stream));
+    A.depth = dDepth.p; A.hasMp = dHas.p; A.mpXyz = dMpXyz.p; A.mpDesc = dMpDesc.p;
+    A.fx = P->rig.fx; A.fy = P->rig.fy; A.cx = P->rig.cx; A.cy = P->rig.cy; A.b = (double)P->rig.baseline; A.w = P->rig.width; A.h = P->rig.height;
+    for (int l = 0; l < P->n_levels; l++) { A.scalePyr[l] = P->scale_pyramid[l]; A.sigma[l] = P->sigma_factor[l]; }
+    A.logScale = P->log_scale; A.nLev = P->n_levels;
+    const float imageRatio = (float)P->rig.width / (float)P->rig.height;      // assignKeysToGrids (src/FeatureTracker.cpp:30-35)
+    A.xGrids = 64; A.yGrids = cv_ceil_f((float)A.xGrids / imageRatio);
+    A.xMult = (float)A.xGrids / (float)P->rig.width; A.yMult = (float)A.yGrids / (float)P->rig.height;
+    A.wPos = dWpos.p; A.key = dKey.p; A.mds = dMds.p; A.cdesc = dCdesc.p; A.count = dCount.p; A.cap = cap; A.match = dMatch.p;
+    A.accepted = dAcc.p; A.xyz = dXyz.p; A.nObs = dNobs.p; A.obs = dObs.p;
+
+    hipLaunchKernelGGL(k_np_candidates, dim3(1), dim3(1024), 0, stream, A);
+    if (P->n_kf > 1) hipLaunchKernelGGL(k_np_match, dim3((cap + 3) / 4, P->n_kf - 1), dim3(256), 0, stream, A);
+    else VS_HIP(hipMemsetAsync(dMatch.p, 0xfe, (size_t)cap * NP_MAX_KF * 2 * sizeof(int), stream));
+    const size_t lds = (size_t)NP_MAX_ROWS * 4 * 64 * sizeof(double);
+    VS_HIP(hipFuncSetAttribute((const void*)k_np_triangulate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_np_triangulate, dim3((cap + 63) / 64), dim3(64), lds, stream, A);
+    VS_HIP(hipGetLastError());
+    int n = 0;
+    VS_HIP(hipMemcpyAsync(&n, dCount.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+    VS_HIP(hipStreamSynchronize(stream));
+    R->n_candidates = n;
+    if (n > R->capacity) { set_error("vslam_find_new_points: result capacity %d < %d candidates", R->capacity, n); return VSLAM_ERR_CAPACITY; }
+    if (n) {
+        std::vector<int> key((size_t)2 * n);
+        VS_HIP(hipMemcpy(key.data(), dKey.p, key.size() * sizeof(int), hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; i++) { R->cand_left[i] = key[2 * i]; R->cand_right[i] = key[2 * i + 1]; }
+        VS_HIP(hipMemcpy(R->accepted, dAcc.p, n, hipMemcpyDeviceToHost));
+        VS_HIP(hipMemcpy(R->xyz, dXyz.p, (size_t)3 * n * sizeof(double), hipMemcpyDeviceToHost));
+        VS_HIP(hipMemcpy(R->n_obs, dNobs.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+        std::vector<int> obs((size_t)n * NP_MAX_KF * 3);
+        VS_HIP(hipMemcpy(obs.data(), dObs.p, obs.size() * sizeof(int), hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; i++)
+            for (int e = 0; e < P->n_kf; e++)
+                for (int q = 0; q < 3; q++) R->obs[((size_t)i * P->n_kf + e) * 3 + q] = e < R->n_obs[i] ? obs[((size_t)i * NP_MAX_KF + e) * 3 + q] : -1;
+    }
+    return VSLAM_OK;
+}
+
+// MapPoint::calcDescriptor for a batch of map points: descs = concatenated observation descriptors, start[n_mp + 1]
+extern "C" vslam_status vslam_calc_descriptors(const uint8_t* descs, const int32_t* start, int32_t n_mp, int32_t device, int32_t* best_out) {
+    if (n_mp < 0 || (n_mp > 0 && (!descs || !start || !best_out))) return VSLAM_ERR_INVALID;
+    if (n_mp == 0) return VSLAM_OK;
+    for (int m = 0; m < n_mp; m++)
+        if (start[m + 1] < start[m] || start[m + 1] - start[m] > 64) { set_error("vslam_calc_descriptors: a map point has more than 64 observations"); return VSLAM_ERR_CAPACITY; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available (no CPU fallback)"); return VSLAM_ERR_NO_DEVICE; }
+    if (device < 0 || device >= ndev) return VSLAM_ERR_INVALID;
+    VS_HIP(hipSetDevice(device));
+    Dev<uint8_t> dD; Dev<int> dS, dB;
+    const size_t total = (size_t)start[n_mp];
+    VS_HIP(dD.up(descs, total * 32, nullptr)); VS_HIP(dS.up(start, (size_t)n_mp + 1, nullptr)); VS_HIP(dB.alloc(n_mp));
+    hipLaunchKernelGGL(k_calc_descriptor, dim3((n_mp + 3) / 4), dim3(256), 0, nullptr, n_mp, dD.p, dS.p, dB.p);
+    VS_HIP(hipGetLastError());
+    VS_HIP(hipMemcpy(best_out, dB.p, (size_t)n_mp * sizeof(int), hipMemcpyDeviceToHost));
+    return VSLAM_OK;
+}

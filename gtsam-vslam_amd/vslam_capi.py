@@ -550,3 +550,69 @@ def tracker_track_mono_imu(matcher, gravity, noise, T_body_sensor, T_wc_prev, ve
     _chk(matcher.L.vslam_tracker_track_mono_imu(matcher.h, C.byref(imu), _p(pv), C.c_double(fps), _p(out), C.byref(o), _p(Tp), _p(pvo),
                                                 C.byref(rep)))
     return out, {f[0]: getattr(rep, f[0]) for f in TrackReport._fields_}, np.array(list(o.velocity)), np.array(list(o.bias)), Tp, pvo
+
+
+# ---- new-point pipeline (LocalMapper::findNewPoints) / MapPoint::calcDescriptor ------------------------
+class KfView(C.Structure):
+    _fields_ = [("T_wc", C.c_void_p), ("id", C.c_int64), ("n_left", C.c_int32), ("n_right", C.c_int32),
+                ("kps_l", C.c_void_p), ("desc_l", C.c_void_p), ("kps_r", C.c_void_p), ("desc_r", C.c_void_p),
+                ("right_idxs", C.c_void_p), ("left_idxs", C.c_void_p), ("unmatched_f", C.c_void_p), ("unmatched_fr", C.c_void_p)]
+
+
+class NewPointsProblem(C.Structure):
+    _fields_ = [("rig", Rig), ("n_levels", C.c_int32), ("scale_pyramid", C.c_void_p), ("sigma_factor", C.c_void_p),
+                ("log_scale", C.c_float), ("n_kf", C.c_int32), ("kfs", C.c_void_p), ("estimated_depth", C.c_void_p),
+                ("has_mp", C.c_void_p), ("mp_xyz", C.c_void_p), ("mp_desc", C.c_void_p)]
+
+
+class NewPointsResult(C.Structure):
+    _fields_ = [("capacity", C.c_int32), ("n_candidates", C.c_int32), ("cand_left", C.c_void_p), ("cand_right", C.c_void_p),
+                ("accepted", C.c_void_p), ("xyz", C.c_void_p), ("n_obs", C.c_void_p), ("obs", C.c_void_p)]
+
+
+def find_new_points(rig, scale_pyramid, sigma_factor, kfs, last, device=0):
+    """kfs: list of dicts (T_wc, id, kpsL, descL, kpsR, descR, rightIdxs, leftIdxs, unF, unFR), kfs[0] = lastKF;
+    last: dict(depth, hasMp, mpXyz, mpDesc)."""
+    n = len(kfs)
+    keep = []
+
+    def ptr(a, dt):
+        a = np.ascontiguousarray(a, dt)
+        keep.append(a)
+        return a.ctypes.data if a.size else None
+
+    views = (KfView * n)()
+    for k, kf in enumerate(kfs):
+        v = views[k]
+        v.T_wc = ptr(kf["T_wc"], np.float64); v.id = int(kf["id"]); v.n_left = len(kf["kpsL"]); v.n_right = len(kf["kpsR"])
+        v.kps_l, v.desc_l = ptr(kf["kpsL"], KP_DTYPE), ptr(kf["descL"], np.uint8)
+        v.kps_r, v.desc_r = ptr(kf["kpsR"], KP_DTYPE), ptr(kf["descR"], np.uint8)
+        v.right_idxs, v.left_idxs = ptr(kf["rightIdxs"], np.int32), ptr(kf["leftIdxs"], np.int32)
+        v.unmatched_f, v.unmatched_fr = ptr(kf["unF"], np.int32), ptr(kf["unFR"], np.int32)
+    sp = np.ascontiguousarray(scale_pyramid, np.float32); sg = np.ascontiguousarray(sigma_factor, np.float32)
+    P = NewPointsProblem()
+    P.rig = make_rig(rig); P.n_levels = len(sp); P.scale_pyramid, P.sigma_factor = _p(sp), _p(sg)
+    P.log_scale = float(np.float32(np.log(np.float64(sp[1])))); P.n_kf = n; P.kfs = C.cast(views, C.c_void_p)
+    P.estimated_depth, P.has_mp = ptr(last["depth"], np.float32), ptr(last["hasMp"], np.uint8)
+    P.mp_xyz, P.mp_desc = ptr(last["mpXyz"], np.float64), ptr(last["mpDesc"], np.uint8)
+    n0 = max(len(kfs[0]["kpsL"]), 1)
+    cL = np.zeros(n0, np.int32); cR = np.zeros(n0, np.int32); acc = np.zeros(n0, np.uint8); xyz = np.zeros((n0, 3))
+    nObs = np.zeros(n0, np.int32); obs = np.full((n0, n, 3), -1, np.int32)
+    R = NewPointsResult()
+    R.capacity = n0
+    R.cand_left, R.cand_right, R.accepted, R.xyz, R.n_obs, R.obs = _p(cL), _p(cR), _p(acc), _p(xyz), _p(nObs), _p(obs)
+    _chk(lib().vslam_find_new_points(C.byref(P), C.byref(R), int(device)))
+    nc = R.n_candidates
+    return dict(n=nc, candL=cL[:nc], candR=cR[:nc], accepted=acc[:nc], xyz=xyz[:nc], nObs=nObs[:nc], obs=obs[:nc])
+
+
+def calc_descriptors(desc_lists, device=0):
+    """desc_lists: list of (n_i, 32) uint8 arrays; returns the chosen index per map point."""
+    start = np.zeros(len(desc_lists) + 1, np.int32)
+    for i, d in enumerate(desc_lists):
+        start[i + 1] = start[i] + len(d)
+    allv = [np.ascontiguousarray(d, np.uint8).reshape(-1, 32) for d in desc_lists if len(d)]
+    descs = np.concatenate(allv) if allv else np.zeros((1, 32), np.uint8)
+    best = np.full(max(len(desc_lists), 1), -1, np.int32)
+    _chk(lib().vslam_calc_descriptors(_p(descs), _p(start), len(desc_lists), int(device), _p(best)))
+    return best[:len(desc_lists)]

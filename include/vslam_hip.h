@@ -329,6 +329,62 @@ vslam_status vslam_local_ba_timings(const char** names, float* ms, int32_t cap, 
 vslam_status vslam_local_ba_set_timing(int32_t on);
 
 /* ---------------------------------------------------------------------------
+ * New-point pipeline of the optimizer thread — replaces the numerical part of LocalMapper::findNewPoints
+ * (include/OptimizationBA.h:54-100, src/OptimizationBA.cpp:340-391): calcAllMpsOfKFROnlyEst (:234-287),
+ * predictKeysPosR (:289-338), FeatureMatcher::matchByProjectionRPredLBA (src/FeatureMatcher.cpp:66-252),
+ * triangulateNewPoints (:127-209, gtsam::triangulatePoint3<Cal3_S2>: DLT, rank_tol 1e-9, cheirality) and
+ * checkReprojError (:14-88).  The KeyFrame / MapPoint pointer graph arrives flattened; creating the MapPoint
+ * objects from the result (addMultiViewMapPointsR / addNewMapPoints) stays with the caller.
+ * kfs[0] is lastKF (= actKeyF.front()), the others follow in the window's order.
+ * ------------------------------------------------------------------------- */
+typedef struct {
+    const double* T_wc;                /* KeyFrame::pose.pose, row-major 4x4 */
+    int64_t id;                        /* KeyFrame::numb */
+    int32_t n_left, n_right;
+    const vslam_keypoint* kps_l; const uint8_t* desc_l;      /* keys.keyPoints / Desc */
+    const vslam_keypoint* kps_r; const uint8_t* desc_r;      /* keys.rightKeyPoints / rightDesc */
+    const int32_t* right_idxs; const int32_t* left_idxs;     /* keys.rightIdxs / leftIdxs */
+    const int32_t* unmatched_f; const int32_t* unmatched_fr; /* KeyFrame::unMatchedF / unMatchedFR (>= 0: has a map point) */
+} vslam_kf_view;
+
+typedef struct {
+    vslam_rig rig;
+    int32_t n_levels;
+    const float* scale_pyramid;        /* KeyFrame::scaleFactor */
+    const float* sigma_factor;         /* KeyFrame::sigmaFactor */
+    float log_scale;                   /* KeyFrame::logScale */
+    int32_t n_kf;                      /* <= 16 */
+    const vslam_kf_view* kfs;
+    /* last keyframe only, one entry per left keypoint */
+    const float* estimated_depth;      /* keys.estimatedDepth */
+    const uint8_t* has_mp;             /* localMapPoints[i] != nullptr */
+    const double* mp_xyz;              /* its world position (read where has_mp) */
+    const uint8_t* mp_desc;            /* its descriptor, 32 B (read where has_mp) */
+} vslam_new_points_problem;
+
+typedef struct {
+    int32_t capacity;                  /* entries the arrays below can hold (kfs[0].n_left is always enough) */
+    int32_t n_candidates;              /* out: p4d.size() */
+    int32_t* cand_left; int32_t* cand_right;   /* out: the candidate's (left, right) keypoint in lastKF */
+    uint8_t* accepted;                 /* out: triangulated, in front of every camera, >= 3 keyframes left after the
+                                          reprojection filter, lastKF among them */
+    double* xyz;                       /* out [n][3]: triangulated position (valid where accepted) */
+    int32_t* n_obs;                    /* out: matchesOfPoint.size() on exit */
+    int32_t* obs;                      /* out [n][n_kf][3]: (keyframe index, left idx, right idx), -1 padded */
+} vslam_new_points_result;
+
+vslam_status vslam_find_new_points(const vslam_new_points_problem* problem, vslam_new_points_result* result,
+                                   int32_t device);
+
+/* MapPoint::calcDescriptor (src/Map.cpp:145-210) for a batch of map points: descs = the observation
+ * descriptors of all points concatenated (32 B each, in the order the caller iterates kFMatches),
+ * start[n_mp + 1] = first descriptor of each point; best_out[m] = index (within the point) of the descriptor
+ * with the least median Hamming distance to the others (first minimum), -1 for a point without observations.
+ * At most 64 observations per point. */
+vslam_status vslam_calc_descriptors(const uint8_t* descs, const int32_t* start, int32_t n_mp, int32_t device,
+                                    int32_t* best_out);
+
+/* ---------------------------------------------------------------------------
  * Per-frame tracking loop on device-resident state — the stereo path of
  * FeatureTracker::TrackImage (src/FeatureTracker.cpp:1108-1278):
  *   init_map : initializeMap (:72-123) — every stereo keypoint of the matcher's current frame

@@ -417,3 +417,55 @@ def estimate_pose_mono(rig, inv_sigma, points, in_frame, mp_is_outlier, matches,
                                 C.byref(nIn), _p(rep))
     return dict(T_cw=T, vel=imu[:3].copy(), bias=imu[3:].copy(), nIn=nIn.value, outliers=out, iterations=int(rep[0]),
                 inner=int(rep[1]), initialError=rep[2], finalError=rep[3], lam=rep[4])
+
+
+# ---- new-point pipeline (findNewPoints) and MapPoint::calcDescriptor -------------------------------
+def find_new_points(exL, rig, kfs, last):
+    """kfs: list of dicts (T_wc, id, kpsL, descL, kpsR, descR, rightIdxs, leftIdxs, unF, unFR), kfs[0] = lastKF;
+    last: dict(depth, hasMp, mpXyz, mpDesc).  Returns dict of the candidate arrays."""
+    n = len(kfs)
+    keep = []
+
+    def arr(tp, vals):
+        a = (tp * n)(*vals)
+        return a
+
+    def ptrs(key, dt):
+        out = []
+        for k in kfs:
+            a = np.ascontiguousarray(k[key], dt)
+            if a.size == 0:
+                a = np.zeros(32, dt) if dt != KP_DTYPE else np.zeros(1, KP_DTYPE)
+            keep.append(a)
+            out.append(a.ctypes.data)
+        return (C.c_void_p * n)(*out)
+
+    Tp = ptrs("T_wc", np.float64)
+    ids = (C.c_longlong * n)(*[int(k["id"]) for k in kfs])
+    nL = (C.c_int * n)(*[len(k["kpsL"]) for k in kfs]); nR = (C.c_int * n)(*[len(k["kpsR"]) for k in kfs])
+    kL, dL, kR, dR = ptrs("kpsL", KP_DTYPE), ptrs("descL", np.uint8), ptrs("kpsR", KP_DTYPE), ptrs("descR", np.uint8)
+    ri, li, uf, ufr = ptrs("rightIdxs", np.int32), ptrs("leftIdxs", np.int32), ptrs("unF", np.int32), ptrs("unFR", np.int32)
+    n0 = len(kfs[0]["kpsL"])
+    depth = np.ascontiguousarray(last["depth"], np.float32); has = np.ascontiguousarray(last["hasMp"], np.uint8)
+    mpx = np.ascontiguousarray(last["mpXyz"], np.float64).reshape(-1, 3); mpd = np.ascontiguousarray(last["mpDesc"], np.uint8).reshape(-1, 32)
+    cL = np.zeros(n0, np.int32); cR = np.zeros(n0, np.int32); acc = np.zeros(n0, np.uint8); xyz = np.zeros((n0, 3))
+    nObs = np.zeros(n0, np.int32); obs = np.full((n0, n, 3), -1, np.int32)
+    lib().vo_find_new_points.restype = C.c_int
+    nc = lib().vo_find_new_points(exL.h, C.c_double(rig["fx"]), C.c_double(rig["fy"]), C.c_double(rig["cx"]), C.c_double(rig["cy"]),
+                                  C.c_float(rig["bl"]), rig["w"], rig["h"], n, Tp, ids, nL, nR, kL, dL, kR, dR, ri, li, uf, ufr,
+                                  _p(depth), _p(has), _p(mpx), _p(mpd), _p(cL), _p(cR), _p(acc), _p(xyz), _p(nObs), _p(obs))
+    return dict(n=nc, candL=cL[:nc], candR=cR[:nc], accepted=acc[:nc], xyz=xyz[:nc], nObs=nObs[:nc], obs=obs[:nc])
+
+
+def calc_descriptor(descs):
+    d = np.ascontiguousarray(descs, np.uint8).reshape(-1, 32)
+    lib().vo_calc_descriptor.restype = C.c_int
+    return lib().vo_calc_descriptor(_p(d), len(d))
+
+
+def triangulate_dlt(P34, uv):
+    P = np.ascontiguousarray(P34, np.float64).reshape(-1, 12); z = np.ascontiguousarray(uv, np.float64).reshape(-1, 2)
+    out = np.zeros(3)
+    lib().vo_triangulate_dlt.restype = C.c_int
+    ok = lib().vo_triangulate_dlt(_p(P), _p(z), len(P), _p(out))
+    return bool(ok), out

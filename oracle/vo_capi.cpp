@@ -493,3 +493,52 @@ void vo_estimate_pose_mono(double fx, double fy, double cx, double cy, float bas
     if (report) { report[0] = R.rep.iterations; report[1] = R.rep.innerIterations; report[2] = R.rep.initialError; report[3] = R.rep.finalError; report[4] = R.rep.lambda; }
 }
 }  // extern "C"
+
+#include "vo_newpts.hpp"
+extern "C" {
+// findNewPoints without the map insertion.  Per keyframe k: T_wc (16), id, nL, nR, kpsL, descL, kpsR, descR, rightIdxs,
+// leftIdxs, unMatchedF, unMatchedFR passed as arrays of pointers.  Outputs as in vslam_new_points_result.
+int vo_find_new_points(void* hL, double fx, double fy, double cx, double cy, float baseline, int width, int height, int nKf,
+                       const double* const* T_wc, const long long* ids, const int* nL, const int* nR,
+                       const KeyPoint* const* kpsL, const uint8_t* const* descL, const KeyPoint* const* kpsR,
+                       const uint8_t* const* descR, const int* const* rightIdxs, const int* const* leftIdxs,
+                       const int* const* unF, const int* const* unFR, const float* depth, const uint8_t* hasMp,
+                       const double* mpXyz, const uint8_t* mpDesc, int* candL, int* candR, uint8_t* accepted, double* xyz,
+                       int* nObs, int* obs) {
+    Extractor* fe = (Extractor*)hL;
+    Rig rig{fx, fy, cx, cy, baseline, width, height};
+    std::vector<KFView> kfs(nKf);
+    for (int k = 0; k < nKf; k++) {
+        KFView& V = kfs[k];
+        V.T_wc = pose_from_rowmajor16(T_wc[k]); V.id = (long)ids[k];
+        V.kpsL.assign(kpsL[k], kpsL[k] + nL[k]); V.kpsR.assign(kpsR[k], kpsR[k] + nR[k]);
+        V.descL.assign(descL[k], descL[k] + (size_t)nL[k] * 32); V.descR.assign(descR[k], descR[k] + (size_t)nR[k] * 32);
+        V.rightIdxs.assign(rightIdxs[k], rightIdxs[k] + nL[k]); V.leftIdxs.assign(leftIdxs[k], leftIdxs[k] + nR[k]);
+        V.unMatchedF.assign(unF[k], unF[k] + nL[k]); V.unMatchedFR.assign(unFR[k], unFR[k] + nR[k]);
+    }
+    LastKFExtra ex;
+    const int n0 = nL[0];
+    ex.estimatedDepth.assign(depth, depth + n0); ex.hasMp.assign(hasMp, hasMp + n0);
+    ex.mpPos.resize(n0); ex.mpDesc.assign(mpDesc, mpDesc + (size_t)n0 * 32);
+    for (int i = 0; i < n0; i++) for (int q = 0; q < 3; q++) ex.mpPos[i].v[q] = mpXyz[3 * i + q];
+    std::vector<NewPointCand> cands;
+    findNewPoints(*fe, kfs, ex, rig, cands);
+    for (size_t i = 0; i < cands.size(); i++) {
+        const NewPointCand& c = cands[i];
+        candL[i] = c.keyL; candR[i] = c.keyR; accepted[i] = c.accepted;
+        for (int q = 0; q < 3; q++) xyz[3 * i + q] = c.xyz.v[q];
+        nObs[i] = (int)c.kf.size();
+        for (int e = 0; e < nKf; e++)
+            for (int q = 0; q < 3; q++) obs[(i * nKf + e) * 3 + q] = e < (int)c.kf.size() ? (q == 0 ? c.kf[e] : (q == 1 ? c.l[e] : c.r[e])) : -1;
+    }
+    return (int)cands.size();
+}
+int vo_calc_descriptor(const uint8_t* descs, int n) { return calcDescriptorIndex(descs, n); }
+int vo_triangulate_dlt(const double* P34, const double* uv, int m, double* out) {
+    std::vector<double> P(P34, P34 + 12 * (size_t)m), z(uv, uv + 2 * (size_t)m);
+    Vec3 r{};
+    const bool ok = triangulateDLT(P, z, 1e-9, r);
+    for (int q = 0; q < 3; q++) out[q] = r.v[q];
+    return ok ? 1 : 0;
+}
+}  // extern "C"

@@ -1,0 +1,39 @@
+"""CPU checks of the oracle's new-point restatement (no GPU): DLT triangulation against ground truth and the
+rank / degenerate cases of gtsam::triangulatePoint3 (GTSAM 4.2 triangulation.cpp), calcDescriptor's median rule."""
+import numpy as np
+import synth
+
+
+def _P(K, T_wc):
+    Tcw = np.linalg.inv(T_wc)
+    return K @ Tcw[:3, :]
+
+
+def test_dlt_recovers_point_and_detects_degeneracy(oracle):
+    rig = synth.RIGS["euroc"]
+    K = np.array([[rig["fx"], 0, rig["cx"]], [0, rig["fy"], rig["cy"]], [0, 0, 1.0]])
+    rng = np.random.default_rng(0)
+    X = np.array([0.4, -0.2, 5.0])
+    Ps, uv = [], []
+    for i in range(5):
+        T = np.eye(4); T[:3, 3] = [0.3 * i, 0.05 * i, 0.0]
+        P = _P(K, T); x = P @ np.append(X, 1.0)
+        Ps.append(P.ravel()); uv.append(x[:2] / x[2])
+    ok, p = oracle.triangulate_dlt(Ps, uv)
+    assert ok and np.abs(p - X).max() < 1e-9
+    # noisy observations: the algebraic solution stays close
+    uvn = [u + rng.normal(0, 0.3, 2) for u in uv]
+    ok, p = oracle.triangulate_dlt(Ps, uvn)
+    assert ok and np.abs(p - X).max() < 0.2
+    # the same camera twice: rank 2 -> underconstrained
+    ok, _ = oracle.triangulate_dlt([Ps[0], Ps[0]], [uv[0], uv[0]])
+    assert not ok
+
+
+def test_calc_descriptor_median_rule(oracle):
+    rng = np.random.default_rng(1)
+    d = rng.integers(0, 256, (7, 32), dtype=np.uint8)
+    dist = np.array([[int(np.unpackbits(a ^ b).sum()) for b in d] for a in d])
+    med = [sorted(row)[int(0.5 * (len(d) - 1))] for row in dist]
+    assert oracle.calc_descriptor(d) == int(np.argmin(med))
+    assert oracle.calc_descriptor(d[:1]) == 0
