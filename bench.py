@@ -24,7 +24,7 @@ import time
 # The path uses 5 HIP streams (2 extractor pairs, matcher/tracker, local BA, torch); the HIP runtime multiplexes
 # streams onto 4 hardware queues by default, which serialises independent streams behind each other's long
 # single-workgroup kernels.  Must be set before the runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8" if "--sessions" not in sys.argv else "24")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "gtsam-vslam_amd"))
@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic stereo frames kept in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sessions", type=int, default=1,
+                    help="independent SLAM sessions (sequences) sharing each GPU; the headline number uses 1")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="extract and track on one host thread (frame n+1 is not extracted while frame n is tracked)")
     args = ap.parse_args()
@@ -133,10 +135,6 @@ def main():
     ba_prob = synth.make_ba_problem(rig_name, n_local=10, n_fixed=4, n_lm=3000, seed=0xBA5E + rank)
 
     pipelined = not args.no_pipeline
-    fes = [vc.Extractor(w, h, nfeat, batch=2, device=local) for _ in range(2 if pipelined else 1)]
-    fm = vc.Matcher(rig, fes[0], 0, fes[0], 1)
-    sigmaF, invSigmaF = fes[0].sigmaFactor, fes[0].InvSigmaFactor
-
     stage_ms = {}
     counters = {"track_inliers": 0, "track_frames": 0, "ba_calls": 0, "ba_residuals": 0, "ba_landmarks": 0, "ba_sum_k2": 0,
                 "ba_trials": 0, "ba_iters": 0, "ba_free_kf": 0, "sampled_frames": 0, "sampled_solves": 0, "sampled_tracked": 0}
@@ -147,108 +145,142 @@ def main():
             for k, v in d.items():
                 stage_ms[k] = stage_ms.get(k, 0.0) + v
 
-    # Local BA runs on its own host thread / HIP stream, concurrently with tracking — the reference's optimizer
-    # thread (src/System.cpp:19, LocalMapper::beginLocalMapping).  At most one BA is in flight (the reference's
-    # keyFrameAdded / LBADone handshake: the tracker blocks on the hand-over while the previous one still runs);
-    # all of them finish inside the timed region.
-    ba_q = queue.Queue(maxsize=1)
-    ba_state = {"record": False, "n": 0}
+    class Session:
+        """One SLAM session (one camera rig / sequence): its extractor pair(s), matcher + tracker state, local-BA thread.
+        Session 0 carries the stage timers and counters; further sessions (--sessions) are independent replicas that share
+        the GPU (every kernel of this path occupies a few CUs at most, so sequences are the unit that fills the chip)."""
 
-    def ba_worker():
-        torch.cuda.set_device(local)
-        while True:
-            job = ba_q.get()
-            if job is None:
-                ba_q.task_done()
-                return
-            sample = ba_state["record"] and (ba_state["n"] % BA_SAMPLE == 0)
-            ba_state["n"] += 1
-            vc.local_ba_set_timing(sample)
-            r = vc.local_ba(rig, sigmaF, invSigmaF, ba_prob, device=local)
-            if sample:
-                add(vc.local_ba_timings())
-                counters["ba_calls"] += 1
-                counters["ba_residuals"], counters["ba_landmarks"], counters["ba_sum_k2"] = r["residuals"], r["landmarks"], r["sum_k2"]
-                counters["ba_free_kf"] = r["free_kf"]
-                counters["ba_trials"] += r["reports"][0]["inner"] + r["reports"][1]["inner"]
-                counters["ba_iters"] += r["reports"][0]["iterations"] + r["reports"][1]["iterations"]
-            ba_q.task_done()
+        def __init__(self, sid):
+            self.sid = sid
+            self.timed = sid == 0
+            self.fes = [vc.Extractor(w, h, nfeat, batch=2, device=local) for _ in range(2 if pipelined else 1)]
+            self.fm = vc.Matcher(rig, self.fes[0], 0, self.fes[0], 1)
+            self.sigmaF, self.invSigmaF = self.fes[0].sigmaFactor, self.fes[0].InvSigmaFactor
+            # Local BA runs on its own host thread / HIP stream, concurrently with tracking - the reference's optimizer
+            # thread (src/System.cpp:19, LocalMapper::beginLocalMapping).  At most one BA is in flight (the reference's
+            # keyFrameAdded / LBADone handshake: the tracker blocks on the hand-over while the previous one still runs);
+            # all of them finish inside the timed region.
+            self.ba_q = queue.Queue(maxsize=1)
+            self.ba_state = {"record": False, "n": 0}
+            self.ba_thread = threading.Thread(target=self.ba_worker, daemon=True)
+            self.ba_thread.start()
 
-    ba_thread = threading.Thread(target=ba_worker, daemon=True)
-    ba_thread.start()
+        def ba_worker(self):
+            torch.cuda.set_device(local)
+            while True:
+                job = self.ba_q.get()
+                if job is None:
+                    self.ba_q.task_done()
+                    return
+                sample = self.timed and self.ba_state["record"] and (self.ba_state["n"] % BA_SAMPLE == 0)
+                self.ba_state["n"] += 1
+                vc.local_ba_set_timing(sample)
+                r = vc.local_ba(rig, self.sigmaF, self.invSigmaF, ba_prob, device=local)
+                if sample:
+                    add(vc.local_ba_timings())
+                    counters["ba_calls"] += 1
+                    counters["ba_residuals"], counters["ba_landmarks"], counters["ba_sum_k2"] = r["residuals"], r["landmarks"], r["sum_k2"]
+                    counters["ba_free_kf"] = r["free_kf"]
+                    counters["ba_trials"] += r["reports"][0]["inner"] + r["reports"][1]["inner"]
+                    counters["ba_iters"] += r["reports"][0]["iterations"] + r["reports"][1]["iterations"]
+                self.ba_q.task_done()
 
-    def sampled(n, record):
-        return record and (n % STAGE_SAMPLE == 0)
+        def sampled(self, n, record):
+            return self.timed and record and (n % STAGE_SAMPLE == 0)
 
-    def extract(n, record):
-        fe = fes[n % len(fes)]
-        dL, dR = d_frames[n % len(d_frames)]
-        rec = sampled(n, record)
-        fe.set_timing(rec)
-        fe.set_image_device(0, dL.data_ptr(), w)
-        fe.set_image_device(1, dR.data_ptr(), w)
-        fe.run()
-        if rec:
-            add(fe.timings())
-
-    def track(n, record):
-        i = n % len(d_frames)
-        fe = fes[n % len(fes)]
-        rec = sampled(n, record)
-        fm.set_timing(rec)
-        if len(fes) > 1:
-            fm.bind_extractors(fe, 0, fe, 1)
-        fm.stereo_match()
-        if i > 0:
-            S, dts, ts, v_prev = imus[i]
-            T_cw, rep, vel, bias = vc.tracker_track_imu(fm, poses[i][1], 5, GRAVITY, IMU_NOISE, synth.T_BC1, poses[i - 1][0],
-                                                        v_prev, np.zeros(6), S[:, :3], S[:, 3:], ts, 200)
-            if record:
-                counters["track_inliers"] += rep["n_inliers"]; counters["track_frames"] += 1
+        def extract(self, n, record):
+            fe = self.fes[n % len(self.fes)]
+            dL, dR = d_frames[n % len(d_frames)]
+            rec = self.sampled(n, record)
+            fe.set_timing(rec)
+            fe.set_image_device(0, dL.data_ptr(), w)
+            fe.set_image_device(1, dR.data_ptr(), w)
+            fe.run()
             if rec:
-                counters["sampled_solves"] += rep["rounds"] + 1; counters["sampled_tracked"] += 1
-        vc.tracker_init_map(fm, poses[i][0])
-        if rec:
-            counters["sampled_frames"] += 1
-            add(fm.timings())
-        if n % KF_PERIOD == KF_PERIOD - 1 and not os.environ.get("VSLAM_BENCH_SKIP_BA"):     # (diagnostic switch only)
-            ba_state["record"] = record
-            ba_q.put(1)          # blocks while the previous local BA is still running
+                add(fe.timings())
+
+        def track(self, n, record):
+            i = n % len(d_frames)
+            fe, fm = self.fes[n % len(self.fes)], self.fm
+            rec = self.sampled(n, record)
+            fm.set_timing(rec)
+            if len(self.fes) > 1:
+                fm.bind_extractors(fe, 0, fe, 1)
+            fm.stereo_match()
+            if i > 0:
+                S, dts, ts, v_prev = imus[i]
+                T_cw, rep, vel, bias = vc.tracker_track_imu(fm, poses[i][1], 5, GRAVITY, IMU_NOISE, synth.T_BC1, poses[i - 1][0],
+                                                            v_prev, np.zeros(6), S[:, :3], S[:, 3:], ts, 200)
+                if record and self.timed:
+                    counters["track_inliers"] += rep["n_inliers"]; counters["track_frames"] += 1
+                if rec:
+                    counters["sampled_solves"] += rep["rounds"] + 1; counters["sampled_tracked"] += 1
+            vc.tracker_init_map(fm, poses[i][0])
+            if rec:
+                counters["sampled_frames"] += 1
+                add(fm.timings())
+            if n % KF_PERIOD == KF_PERIOD - 1 and not os.environ.get("VSLAM_BENCH_SKIP_BA"):     # (diagnostic switch only)
+                self.ba_state["record"] = record
+                self.ba_q.put(1)          # blocks while the previous local BA is still running
+
+        def run_frames(self, first, count, record):
+            """`count` frames through the path; returns when every one of them (and every local BA) has completed."""
+            torch.cuda.set_device(local)
+            if not pipelined:
+                for n in range(first, first + count):
+                    self.extract(n, record)
+                    self.track(n, record)
+            else:
+                # frame-level pipeline: the extraction thread works on frame n+1 (own extractor pair, own stream)
+                # while this thread matches / tracks frame n; two extractor buffers, so it is at most one frame ahead
+                free = threading.Semaphore(len(self.fes))
+                ready = queue.Queue()
+                err = []
+
+                def extract_worker():
+                    try:
+                        torch.cuda.set_device(local)
+                        for n in range(first, first + count):
+                            free.acquire()
+                            self.extract(n, record)
+                            ready.put(n)
+                    except Exception as e:      # noqa: BLE001
+                        err.append(e)
+                        ready.put(-1)
+
+                th = threading.Thread(target=extract_worker, daemon=True)
+                th.start()
+                for _ in range(count):
+                    n = ready.get()
+                    if n < 0:
+                        raise err[0]
+                    self.track(n, record)
+                    free.release()
+                th.join()
+            self.ba_q.join()
+
+    sessions = [Session(i) for i in range(args.sessions)]
+    fes = sessions[0].fes
 
     def run_frames(first, count, record):
-        """`count` frames through the path; returns when every one of them (and every local BA) has completed."""
-        if not pipelined:
-            for n in range(first, first + count):
-                extract(n, record)
-                track(n, record)
-        else:
-            # frame-level pipeline: the extraction thread works on frame n+1 (own extractor pair, own stream)
-            # while this thread matches / tracks frame n; two extractor buffers, so it is at most one frame ahead
-            free = threading.Semaphore(len(fes))
-            ready = queue.Queue()
-            err = []
+        if len(sessions) == 1:
+            sessions[0].run_frames(first, count, record)
+            return
+        errs = []
 
-            def extract_worker():
-                try:
-                    torch.cuda.set_device(local)
-                    for n in range(first, first + count):
-                        free.acquire()
-                        extract(n, record)
-                        ready.put(n)
-                except Exception as e:      # noqa: BLE001
-                    err.append(e)
-                    ready.put(-1)
+        def go(s):
+            try:
+                s.run_frames(first, count, record)
+            except Exception as e:      # noqa: BLE001
+                errs.append(e)
 
-            th = threading.Thread(target=extract_worker, daemon=True)
-            th.start()
-            for _ in range(count):
-                n = ready.get()
-                if n < 0:
-                    raise err[0]
-                track(n, record)
-                free.release()
-            th.join()
-        ba_q.join()
+        ths = [threading.Thread(target=go, args=(s,), daemon=True) for s in sessions]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        if errs:
+            raise errs[0]
 
     run_frames(0, args.warmup, False)
     torch.cuda.synchronize()
@@ -334,7 +366,7 @@ def main():
             roof["fp64_frac"] = roof["achieved_gflops"] / (FP64_PEAK_TFLOPS * 1e3)
         out = {
             "metric": "frames/sec (extract+match+localBA), 1500 feat stereo 752x480",
-            "value": world * args.steps / el, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "value": world * args.sessions * args.steps / el, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/i32 (extract, match) + f64 (pose LM, local BA)", "data": "synthetic",
@@ -347,7 +379,7 @@ def main():
                        "threads": ("frame-level pipeline: extraction of frame n+1 on one host thread / HIP stream while frame n is "
                                    "matched and tracked on another; " if pipelined else "extraction and tracking on one host thread; ") +
                                   "local BA on its own host thread / HIP stream (the reference's optimizer thread)",
-                       "parallelism": "replicas x%d" % world},
+                       "parallelism": "replicas x%d" % world + (", %d sessions per GPU" % args.sessions if args.sessions > 1 else "")},
             "stage_ms_per_step": {k: v for k, v in sorted(per_frame.items())},
             "stage_sampling": "HIP events on every %d-th frame / %d-th local BA; BA stages amortised over %d frames" % (STAGE_SAMPLE, BA_SAMPLE, KF_PERIOD),
             "mean_track_inliers": counters["track_inliers"] / max(counters["track_frames"], 1),
@@ -356,7 +388,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames, poses, imus, rig, nfeat, ba_prob)
         print(json.dumps(out))
-    ba_q.put(None)
+    for sess in sessions:
+        sess.ba_q.put(None)
     if world > 1:
         dist.destroy_process_group()
 
