@@ -62,4 +62,19 @@ void launch_orient_desc(hipStream_t s, const uint8_t* pyr, const uint8_t* blur, 
                         int maxKept, int nimg);
 void upload_pattern();
 
+// device-side SSC (ssc.hip)
+struct SscArgs {
+    const uint32_t* cand; int candCap; const int* levelCount;      // gather output (device-visible pinned memory)
+    int nLevels, nimg;
+    int numRet[MAX_LEVELS], cols[MAX_LEVELS], rows[MAX_LEVELS], high[MAX_LEVELS], kmin[MAX_LEVELS], kmax[MAX_LEVELS];
+    uint32_t* tmp;          // [nimg][candCap]: picks of level l at the level's candidate offset
+    uint32_t* scratch;      // [nimg][candCap]: HBM copy of the candidates
+    uint32_t* gridG;        // HBM bit grids for probes too fine for the LDS arena (width 1: (2 rows + 1) x (2 cols + 1) cells)
+    size_t gridOff[2 * MAX_LEVELS];      // word offset of task (img * nLevels + level); nimg <= 2
+    int* taskCount;         // [nimg * nLevels]
+    int* flags;             // per image: [2 img] fallback needed, [2 img + 1] capacity overflow
+};
+
+void launch_ssc(hipStream_t s, const SscArgs& A, uint32_t* kept, int keptCap, int* keptOff, int* hostCounts);
+
 }  // namespace vslam

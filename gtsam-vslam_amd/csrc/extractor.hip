@@ -235,6 +235,38 @@ vslam_status vslam_extractor::init(const vslam_fe_params* p, int w, int h, int b
     VS_HIP(hipMemcpy(d_disc, disc.data(), disc.size(), hipMemcpyHostToDevice));
     nKept.assign(nimg, 0);
     sscOut.assign((size_t)nimg * nLevels, {});
+    // device SSC: per-level constants of the binary search (same expressions as ssc_level below)
+    for (int l = 0; l < nLevels; l++) {
+        const int numRet = featurePerLevel[l], cols = P.w[l], rows = P.h[l];
+        const int e1 = rows + cols + 2 * numRet;
+        const long long e2 = 4LL * cols + 4LL * numRet + 4LL * rows * numRet + (long long)rows * rows +
+                             (long long)cols * cols - 2LL * rows * cols + 4LL * rows * cols * numRet;
+        const double e3 = std::sqrt((double)e2), e4 = numRet - 1;
+        const double s1 = -std::round((e1 + e3) / e4), s2 = -std::round((e1 - e3) / e4);
+        sscHigh[l] = (int)(s1 > s2 ? s1 : s2);
+        const unsigned K = (unsigned)numRet;
+        sscKmin[l] = (int)(unsigned)std::round((float)K - ((float)K * 0.1f));
+        sscKmax[l] = (int)(unsigned)std::round((float)K + ((float)K * 0.1f));
+    }
+    VS_HIP(hipMalloc(&d_sscTmp, (size_t)2 * nimg * candCap * sizeof(uint32_t)));      // picks | HBM copy of the candidates
+    {
+        size_t words = 0;
+        sscGridOff.assign((size_t)nimg * nLevels, 0);
+        for (int i = 0; i < nimg; i++)
+            for (int l = 0; l < nLevels; l++) {
+                sscGridOff[(size_t)i * nLevels + l] = words;
+                words += (size_t)(2 * P.h[l] + 2) * (size_t)((2 * P.w[l] + 2 + 31) / 32);
+            }
+        VS_HIP(hipMalloc(&d_sscGrid, words * sizeof(uint32_t)));
+    }
+    VS_HIP(hipMalloc(&d_taskCount, (size_t)nimg * MAX_LEVELS * sizeof(int) + (size_t)nimg * MAX_LEVELS * 8 * sizeof(long long)));
+    VS_HIP(hipMalloc(&d_sscFlags, (size_t)nimg * 2 * sizeof(int)));
+    VS_HIP(hipMemset(d_sscFlags, 0, (size_t)nimg * 2 * sizeof(int)));
+    VS_HIP(hipHostMalloc(&h_counts, (size_t)nimg * 3 * sizeof(int), hipHostMallocMapped));
+    VS_HIP(hipHostGetDevicePointer((void**)&d_counts, h_counts, 0));
+    memset(h_counts, 0, (size_t)nimg * 3 * sizeof(int));
+    if (const char* e = getenv("VSLAM_HOST_SSC")) deviceSsc = atoi(e) == 0;
+    if (nimg > 2) deviceSsc = false;      // SscArgs carries the HBM-grid offsets of two images
     {
         int nt = 5;   // + the calling thread; VSLAM_HOST_THREADS overrides (0 = no extra threads)
         if (const char* e = getenv("VSLAM_HOST_THREADS")) nt = std::max(0, std::min(15, atoi(e)));
@@ -254,6 +286,9 @@ void vslam_extractor::release() {
     if (h_kept) hipHostFree(h_kept);
     if (h_keptOff) hipHostFree(h_keptOff);
     hipFree(d_kept); hipFree(d_keptOff); hipFree(d_kps); hipFree(d_desc); hipFree(d_disc);
+    hipFree(d_sscTmp); hipFree(d_taskCount); hipFree(d_sscFlags); hipFree(d_sscGrid); d_sscGrid = nullptr;
+    if (h_counts) hipHostFree(h_counts);
+    d_sscTmp = nullptr; d_taskCount = nullptr; d_sscFlags = nullptr; h_counts = nullptr;
     if (evGather) hipEventDestroy(evGather);
     if (evDone) hipEventDestroy(evDone);
     evGather = evDone = nullptr;
@@ -397,6 +432,69 @@ void vslam_extractor::pool_run(int nTasks) {
     pool.cvDone.wait(lk, [&] { return pool.finished == pool.nTasks; });
 }
 
+// host SSC per (image, level) on the worker pool + upload of the kept lists + the descriptor kernel
+// (the VSLAM_HOST_SSC=1 path and the fallback of the device SSC); the FAST candidates must be complete (evGather)
+vslam_status vslam_extractor::host_ssc_and_describe() {
+    for (int i = 0; i < nimg; i++)
+        if (h_levelCount[(size_t)i * (MAX_LEVELS + 1) + MAX_LEVELS] > candCap) { set_error("FAST candidate overflow"); return VSLAM_ERR_CAPACITY; }
+    pool_run(nimg * nLevels);
+    int maxKept = 0;
+    for (int i = 0; i < nimg; i++) {
+        uint32_t* kout = h_kept + (size_t)i * keptCap;
+        int* koff = h_keptOff + (size_t)i * (MAX_LEVELS + 1);
+        int k = 0;
+        for (int l = 0; l < nLevels; l++) {
+            const std::vector<uint32_t>& keep = sscOut[(size_t)i * nLevels + l];
+            koff[l] = k;
+            if (k + (int)keep.size() > keptCap) { set_error("kept-keypoint overflow"); return VSLAM_ERR_CAPACITY; }
+            if (!keep.empty()) memcpy(kout + k, keep.data(), keep.size() * sizeof(uint32_t));
+            k += (int)keep.size();
+        }
+        for (int l = nLevels; l <= MAX_LEVELS; l++) koff[l] = k;
+        nKept[i] = k;
+        maxKept = std::max(maxKept, k);
+    }
+    VS_HIP(hipMemcpyAsync(d_kept, h_kept, (size_t)nimg * keptCap * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    VS_HIP(hipMemcpyAsync(d_keptOff, h_keptOff, (size_t)nimg * (MAX_LEVELS + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
+    int t = timer.begin("orient_desc");
+    launch_orient_desc(stream, d_pyr, d_blur, P, T, d_kept, d_keptOff, keptCap, d_disc, ndisc, d_kps,
+                       d_desc, keptCap, maxKept, nimg);
+    timer.end(t);
+    VS_HIP(hipGetLastError());
+    return VSLAM_OK;
+}
+
+// After a device-SSC run: wait for the frame, read the per-image totals; if a level raised the fallback flag
+// (more candidates than the LDS holds, introsort depth limit, probe grid larger than the arena) the frame's SSC is
+// redone by the host path.
+vslam_status vslam_extractor::wait_counts() {
+    if (!countsPending) return VSLAM_OK;
+    VS_HIP(hipSetDevice(device));
+    VS_HIP(hipEventSynchronize(evDone));
+    countsPending = false;
+#ifdef VSLAM_SSC_STAMPS
+    {
+        std::vector<long long> st((size_t)nimg * nLevels * 8);
+        hipMemcpy(st.data(), d_taskCount + nimg * MAX_LEVELS, st.size() * sizeof(long long), hipMemcpyDeviceToHost);
+        for (int i = 0; i < nimg; i++) for (int l = 0; l < nLevels; l++) { const long long* q = &st[(size_t)(i * nLevels + l) * 8]; fprintf(stderr, "ssc img %d lvl %d: n %lld partitions %lld countsort %lld search %lld (probes %lld final w %lld) emit %lld\n", i, l, q[4], q[0], q[1], q[2], q[5], q[6], q[3]); }
+    }
+#endif
+    bool fallback = false;
+    for (int i = 0; i < nimg; i++) {
+        if (h_counts[nimg + 2 * i + 1]) { set_error("FAST candidate / kept-keypoint overflow"); return VSLAM_ERR_CAPACITY; }
+        fallback |= h_counts[nimg + 2 * i] != 0;
+        nKept[i] = h_counts[i];
+    }
+    if (fallback) {
+        sscFallbacks++;
+        if (getenv("VSLAM_SSC_DEBUG")) for (int i = 0; i < nimg; i++) fprintf(stderr, "device SSC fallback: image %d reason mask %d\n", i, h_counts[nimg + 2 * i]);
+        VS_CHECK(host_ssc_and_describe());
+        VS_HIP(hipEventRecord(evDone, stream));
+        VS_HIP(hipStreamSynchronize(stream));
+    }
+    return VSLAM_OK;
+}
+
 #ifdef VSLAM_HOST_STAMPS
 #include <chrono>
 static double hs_now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -426,6 +524,33 @@ vslam_status vslam_extractor::run() {
                   d_levelCount, nimg);
     timer.end(t);
     VS_HIP(hipEventRecord(evGather, stream));
+    if (deviceSsc) {
+        // K3 on the device (ssc.hip): no host hop between FAST and the descriptors
+        SscArgs S{};
+        S.cand = d_cand; S.candCap = candCap; S.levelCount = d_levelCount; S.nLevels = nLevels; S.nimg = nimg;
+        for (int l = 0; l < nLevels; l++) {
+            S.numRet[l] = featurePerLevel[l]; S.cols[l] = P.w[l]; S.rows[l] = P.h[l];
+            S.high[l] = sscHigh[l]; S.kmin[l] = sscKmin[l]; S.kmax[l] = sscKmax[l];
+        }
+        S.gridG = d_sscGrid;
+        for (size_t q = 0; q < sscGridOff.size() && q < 2 * (size_t)MAX_LEVELS; q++) S.gridOff[q] = sscGridOff[q];
+        S.tmp = d_sscTmp; S.scratch = d_sscTmp + (size_t)nimg * candCap; S.taskCount = d_taskCount; S.flags = d_sscFlags;
+        t = timer.begin("ssc");
+        launch_ssc(stream, S, d_kept, keptCap, d_keptOff, d_counts);
+        timer.end(t);
+        t = timer.begin("blur");
+        launch_blur(stream, d_pyr, d_blur, P, B, nimg);
+        timer.end(t);
+        t = timer.begin("orient_desc");
+        launch_orient_desc(stream, d_pyr, d_blur, P, T, d_kept, d_keptOff, keptCap, d_disc, ndisc, d_kps,
+                           d_desc, keptCap, keptCap, nimg);
+        timer.end(t);
+        VS_HIP(hipGetLastError());
+        VS_HIP(hipEventRecord(evDone, stream));
+        countsPending = true;          // totals / flags are read (after evDone) by wait_counts()
+        ran = true;
+        return VSLAM_OK;
+    }
     t = timer.begin("blur");       // runs under the host SSC below
     launch_blur(stream, d_pyr, d_blur, P, B, nimg);
     timer.end(t);
@@ -433,40 +558,12 @@ vslam_status vslam_extractor::run() {
     HS(1);
     VS_HIP(hipEventSynchronize(evGather));
     HS(2);
-
-    // host: SSC per (image, level) on the worker pool; keeps are staged level-major
-    for (int i = 0; i < nimg; i++)
-        if (h_levelCount[(size_t)i * (MAX_LEVELS + 1) + MAX_LEVELS] > candCap) { set_error("FAST candidate overflow"); return VSLAM_ERR_CAPACITY; }
-    pool_run(nimg * nLevels);
-    HS(3);
-    int maxKept = 0;
-    for (int i = 0; i < nimg; i++) {
-        uint32_t* kout = h_kept + (size_t)i * keptCap;
-        int* koff = h_keptOff + (size_t)i * (MAX_LEVELS + 1);
-        int k = 0;
-        for (int l = 0; l < nLevels; l++) {
-            const std::vector<uint32_t>& keep = sscOut[(size_t)i * nLevels + l];
-            koff[l] = k;
-            if (k + (int)keep.size() > keptCap) { set_error("kept-keypoint overflow"); return VSLAM_ERR_CAPACITY; }
-            if (!keep.empty()) memcpy(kout + k, keep.data(), keep.size() * sizeof(uint32_t));
-            k += (int)keep.size();
-        }
-        for (int l = nLevels; l <= MAX_LEVELS; l++) koff[l] = k;
-        nKept[i] = k;
-        maxKept = std::max(maxKept, k);
-    }
-    VS_HIP(hipMemcpyAsync(d_kept, h_kept, (size_t)nimg * keptCap * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-    VS_HIP(hipMemcpyAsync(d_keptOff, h_keptOff, (size_t)nimg * (MAX_LEVELS + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
-    t = timer.begin("orient_desc");
-    launch_orient_desc(stream, d_pyr, d_blur, P, T, d_kept, d_keptOff, keptCap, d_disc, ndisc, d_kps,
-                       d_desc, keptCap, maxKept, nimg);
-    timer.end(t);
-    VS_HIP(hipGetLastError());
+    VS_CHECK(host_ssc_and_describe());
     HS(4);
     VS_HIP(hipEventRecord(evDone, stream));      // consumers order themselves after this; no host sync here
     HS(5);
 #ifdef VSLAM_HOST_STAMPS
-    fprintf(stderr, "extract host us: launch %.1f sync %.1f ssc %.1f stage+launch %.1f sync %.1f\n", hs[1] - hs[0], hs[2] - hs[1], hs[3] - hs[2], hs[4] - hs[3], hs[5] - hs[4]);
+    fprintf(stderr, "extract host us: launch %.1f sync %.1f ssc+launch %.1f\n", hs[1] - hs[0], hs[2] - hs[1], hs[4] - hs[2]);
 #endif
     ran = true;
     return VSLAM_OK;
@@ -529,12 +626,14 @@ vslam_status vslam_extractor_run(vslam_extractor* ex) {
 }
 vslam_status vslam_extractor_count(const vslam_extractor* ex, int32_t i, int32_t* n) {
     if (!ex || !n || i < 0 || i >= ex->nimg || !ex->ran) return VSLAM_ERR_INVALID;
+    VS_CHECK(const_cast<vslam_extractor*>(ex)->wait_counts());
     *n = ex->nKept[i];
     return VSLAM_OK;
 }
 vslam_status vslam_extractor_fetch(vslam_extractor* ex, int32_t i, vslam_keypoint* kps, uint8_t* desc,
                                    int32_t cap, int32_t* n_out) {
     if (!ex || i < 0 || i >= ex->nimg || !ex->ran || !n_out) return VSLAM_ERR_INVALID;
+    VS_CHECK(ex->wait_counts());
     const int n = ex->nKept[i];
     *n_out = n;
     if (n > cap) { set_error("fetch: cap %d < %d keypoints", cap, n); return VSLAM_ERR_CAPACITY; }
@@ -573,6 +672,7 @@ vslam_status vslam_extractor_level_copy(vslam_extractor* ex, int32_t i, int32_t 
 }
 vslam_status vslam_extractor_candidates(vslam_extractor* ex, int32_t i, int32_t level, vslam_keypoint* out, int32_t cap, int32_t* n_out) {
     if (!ex || !n_out || i < 0 || i >= ex->nimg || level < 0 || level >= ex->nLevels || !ex->ran) return VSLAM_ERR_INVALID;
+    VS_HIP(hipEventSynchronize(ex->evGather));       // the candidate list lives in mapped host memory
     const int* lc = ex->h_levelCount + (size_t)i * (MAX_LEVELS + 1);
     int off = 0;
     for (int l = 0; l < level; l++) off += lc[l];
@@ -596,6 +696,14 @@ vslam_status vslam_extractor_timings(const vslam_extractor* ex, const char** nam
     int n = ex->timer.read(nm, tv, cap < 64 ? cap : 64);
     for (int i = 0; i < n; i++) { if (names) names[i] = nm[i]; if (ms) ms[i] = tv[i]; }
     *n_out = n;
+    return VSLAM_OK;
+}
+
+vslam_status vslam_extractor_ssc_stats(vslam_extractor* ex, int32_t* on_device, int32_t* host_fallbacks) {
+    if (!ex) return VSLAM_ERR_INVALID;
+    VS_CHECK(ex->wait_counts());
+    if (on_device) *on_device = ex->deviceSsc ? 1 : 0;
+    if (host_fallbacks) *host_fallbacks = ex->sscFallbacks;
     return VSLAM_OK;
 }
 

@@ -56,8 +56,23 @@ struct vslam_extractor {
     int ndisc = 0;
     vslam_keypoint* d_kps = nullptr;  // nimg * keptCap
     uint8_t* d_desc = nullptr;        // nimg * keptCap * 32
-    std::vector<int> nKept;           // per image, after the last run
+    std::vector<int> nKept;           // per image, after the last run (valid after wait_counts())
     bool ran = false;
+    // device-side SSC (default; VSLAM_HOST_SSC=1 selects the host worker pool): picks, per-task counts, flags,
+    // and the per-image totals / flags mirrored into mapped host memory
+    bool deviceSsc = true;
+    uint32_t* d_sscTmp = nullptr;
+    uint32_t* d_sscGrid = nullptr;
+    std::vector<size_t> sscGridOff;
+    int* d_taskCount = nullptr;
+    int* d_sscFlags = nullptr;
+    int* h_counts = nullptr;          // pinned mapped: [nimg] totals, then 2 flags per image
+    int* d_counts = nullptr;
+    int sscHigh[vslam::MAX_LEVELS] = {0}, sscKmin[vslam::MAX_LEVELS] = {0}, sscKmax[vslam::MAX_LEVELS] = {0};
+    bool countsPending = false;
+    int sscFallbacks = 0;             // frames whose SSC was redone by the host path
+    vslam_status wait_counts();       // completes a device-SSC run on the host side (counts; rare host fallback)
+    vslam_status host_ssc_and_describe();
 
     // host worker pool for the sequential SSC stage: one task per (image, level)
     struct SscPool {

@@ -1,0 +1,499 @@
+// K3 on the device: FeatureExtractor::ssc (reference src/FeatureExtractor.cpp:368-468, ANMS "SSC") for every
+// (image, level) of a frame, bit-exact with the host restatement in extractor.hip.
+//
+// The two sequential pieces of the reference are reproduced exactly, in parallel:
+//  (1) cv::sortIdx = libstdc++ std::sort on indices (+ reversal): the TIE ORDER of introsort decides which of
+//      several equal-response corners survives.  Introsort = a tree of median-of-3 Hoare partitions down to
+//      16-element blocks + one insertion sort.  A Hoare partition is a deterministic permutation: the k-th
+//      element >= pivot from the left is exchanged with the k-th element <= pivot from the right while they have
+//      not crossed, so one wave computes it with ballots / prefix counts; sibling segments are independent, so the
+//      tree is walked level by level with one wave per segment.  The closing insertion sort never moves an element
+//      past an equal one and the blocks are already ordered among themselves, hence it equals ONE stable counting
+//      sort by the 8-bit response of the partitioned array.  (Depth-limit exhaustion -> heapsort in libstdc++; never
+//      seen with 8-bit keys, it raises the fallback flag and the host redoes the frame.)
+//  (2) the binary search over the suppression width, each probe a greedy cover scan in response order: a wave
+//      takes 64 candidates per step, tests the LDS bit grid, resolves the picks inside the step in order (a pick
+//      covers the 5x5 cells around it), marks them.  The search is speculated three probes deep (7 waves evaluate
+//      both outcomes of the next probes), the decision logic replays the reference loop on the cached counts.
+#include "extract_kernels.hpp"
+
+namespace vslam {
+
+constexpr int SSC_NT = 1024, SSC_NW = SSC_NT / 64;      // 16 waves: the short-segment sorts and the slices of the counting sort
+constexpr int SSC_NPROBE = 8;                           // speculative probes per round (waves 0..6 are used: a depth-3 tree)
+constexpr int SSC_PICKW = 256;                          // words of a probe's pick bitmask (SSC_NMAX / 32)
+constexpr int SSC_NMAX = 8192;           // candidates of one level the LDS arrays hold (more -> fallback flag)
+constexpr int SSC_SEGMAX = 512;
+constexpr int SSC_ARENA_WORDS = 18 * 1024;     // 72 KB of cover-grid bits (9 KB per speculating wave)
+
+__device__ __forceinline__ void ssc_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// floor(v / (width / 2.0)) for integer v >= 0: 2v / width exactly (the double quotient of the reference is either an exact
+// integer or at least 1 / width away from one, far above its rounding error), via a float estimate and one fix-up step
+__device__ __forceinline__ int ssc_cell(int v, int width, float rcpw) {
+    const int t = 2 * v;
+    int q = (int)((float)t * rcpw);
+    q -= (q * width > t);
+    q += ((q + 1) * width <= t);
+    return q;
+}
+
+// greedy cover scan at `width` over sc[0..n) (response order); returns the number of picks.  picks (may be null):
+// one bit per candidate, set for the picked ones (wave-private words: word = index >> 5)
+// abortAbove >= 0: stop as soon as the count exceeds it (the search only needs "too many"); the return value is then > abortAbove
+__device__ int ssc_eval(const uint32_t* sc, int n, int width, int cols, int rows, uint32_t* grid, int gridWords,
+                        uint32_t* picks, bool& fits, int abortAbove) {
+    const int lane = threadIdx.x & 63;
+    const float rcpw = 1.0f / (float)width;
+    const int gc = ssc_cell(cols, width, rcpw), gr = ssc_cell(rows, width, rcpw);
+    const int span = 2;                                  // floor(width / (width / 2.0))
+    const int rowWords = (gc + 1 + 31) >> 5;
+    const int words = (gr + 1) * rowWords;
+    fits = words <= gridWords;
+    if (!fits) return -1;
+    for (int i = lane; i < words; i += 64) grid[i] = 0;
+    ssc_lds_fence();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the HBM grid of the very fine probes)
+    int count = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const bool valid = i < n;
+        const uint32_t pk = valid ? sc[i] : 0u;
+        const int row = ssc_cell(cand_y(pk), width, rcpw);
+        const int col = ssc_cell(cand_x(pk), width, rcpw);
+        bool covered = true;
+        if (valid) covered = (grid[row * rowWords + (col >> 5)] >> (col & 31)) & 1u;
+        unsigned long long pend = __ballot(!covered), picked = 0ull;
+        while (pend) {
+            const int l = __ffsll((long long)pend) - 1;
+            picked |= 1ull << l;
+            const int rl = __builtin_amdgcn_readlane(row, l), cl = __builtin_amdgcn_readlane(col, l);     // l is wave-uniform
+            const bool conflict = abs(row - rl) <= span && abs(col - cl) <= span;
+            pend &= ~__ballot(conflict);
+        }
+        if ((picked >> lane) & 1ull) {
+            const int r0 = max(row - span, 0), r1 = min(row + span, gr);
+            const int c0 = max(col - span, 0), c1 = min(col + span, gc);
+            const int w0 = c0 >> 5, w1 = c1 >> 5;
+            for (int rr = r0; rr <= r1; rr++) {
+                if (w0 == w1) {
+                    const uint32_t m = ((1u << (c1 - c0 + 1)) - 1u) << (c0 & 31);
+                    atomicOr(&grid[rr * rowWords + w0], m);
+                } else {
+                    atomicOr(&grid[rr * rowWords + w0], 0xffffffffu << (c0 & 31));
+                    atomicOr(&grid[rr * rowWords + w1], 0xffffffffu >> (31 - (c1 & 31)));
+                }
+            }
+        }
+        if (picks && lane < 2) picks[(base >> 5) + lane] = (uint32_t)(picked >> (32 * lane));
+        count += __popcll(picked);
+        ssc_lds_fence();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (abortAbove >= 0 && count > abortAbove) break;
+    }
+    return count;
+}
+
+// position of the k-th (0-based) set bit of m counted from the LSB / from the MSB; k < popcount(m)
+__device__ __forceinline__ int ssc_sel_lo(unsigned long long m, int k) {
+    unsigned w = (unsigned)m;
+    int pos = 0;
+    const int cl = __popc(w);
+    if (k >= cl) { k -= cl; w = (unsigned)(m >> 32); pos = 32; }
+#pragma unroll
+    for (int s = 16; s >= 1; s >>= 1) {
+        const unsigned lowmask = (1u << s) - 1u;
+        const int c = __popc(w & lowmask);
+        if (k >= c) { k -= c; w >>= s; pos += s; } else w &= lowmask;
+    }
+    return pos;
+}
+__device__ __forceinline__ int ssc_sel_hi(unsigned long long m, int k) { return 63 - ssc_sel_lo(__brevll(m), k); }
+
+// Introsort's partition tree of a segment of at most 64 elements, entirely in registers (lane = element), one tree
+// LEVEL per iteration: every lane carries the bounds [lo, hi) of the sub-segment it currently belongs to, all
+// sub-segments of a level run their median-of-3 / Hoare partition at once (ballots masked to the lane's segment, the
+// partner of an exchange found by bit selection, one bpermute).  Same permutation as the LDS path below.
+// Returns false if the depth limit is exhausted.
+__device__ bool ssc_small_segment(uint32_t* a, int f, int e, int depth, uint16_t* Lp, uint16_t* Rp) {
+    const int lane = threadIdx.x & 63, m = e - f;
+    uint32_t v = lane < m ? a[f + lane] : 0u;
+    int lo = lane < m ? 0 : 64, hi = lane < m ? m : 64, d = depth;
+    bool ok = true;
+    for (;;) {
+        const bool act = (hi - lo) > 16;
+        if (__ballot(act) == 0ull) break;
+        if (__ballot(act && d == 0) != 0ull) { ok = false; break; }
+        const int ia = act ? lo + 1 : lane, ib = act ? lo + (hi - lo) / 2 : lane, ic = act ? hi - 1 : lane;
+        const uint32_t va = __shfl(v, ia), vb = __shfl(v, ib), vc = __shfl(v, ic), vlo = __shfl(v, act ? lo : lane);
+        const uint32_t ka = va >> 16, kb = vb >> 16, kc = vc >> 16;
+        int mi;
+        if (ka < kb) { if (kb < kc) mi = ib; else if (ka < kc) mi = ic; else mi = ia; }
+        else if (ka < kc) mi = ia; else if (kb < kc) mi = ic; else mi = ib;
+        const uint32_t vm = mi == ia ? va : (mi == ib ? vb : vc);
+        if (act) { if (lane == lo) v = vm; else if (lane == mi) v = vlo; }
+        const uint32_t pk = vm >> 16;
+        const bool inR = act && lane > lo && lane < hi;
+        const uint32_t kx = v >> 16;
+        const bool isL = inR && kx >= pk, isR = inR && kx <= pk;
+        const unsigned long long below = hi >= 64 ? ~0ull : ((1ull << hi) - 1ull);
+        const unsigned long long segmask = act ? (below & ~((1ull << lo) - 1ull)) : 0ull;
+        const unsigned long long mL = __ballot(isL) & segmask, mR = __ballot(isR) & segmask;
+        const int nL = __popcll(mL), nR = __popcll(mR);
+        const int kL = __popcll(mL & ((1ull << lane) - 1ull));
+        const int kR = lane == 63 ? 0 : __popcll(mR >> (lane + 1));
+        // stopper positions by rank, in the segment's own slice of the LDS lists (left stoppers ascending, right
+        // stoppers from the top): the partner of the k-th left stopper is the k-th right stopper from the top
+        if (isL) Lp[f + lo + kL] = (uint16_t)lane;
+        if (isR) Rp[f + lo + kR] = (uint16_t)lane;
+        ssc_lds_fence();
+        int src = lane;
+        bool asL = false;
+        if (isL && kL < nR) { const int p = Rp[f + lo + kL]; if (lane < p) { src = p; asL = true; } }
+        if (!asL && isR && kR < nL) { const int p = Lp[f + lo + kR]; if (p < lane) src = p; }
+        const int K = __popcll(__ballot(asL) & segmask);
+        v = __shfl(v, src);
+        if (act) {
+            int cut = K >= 1 ? (int)Rp[f + lo + K - 1] : hi;
+            if (K < nL) cut = min(cut, (int)Lp[f + lo + K]);
+            d--;
+            if (lane < cut) hi = cut; else lo = cut;
+        }
+        ssc_lds_fence();
+    }
+    if (lane < m) a[f + lane] = v;
+    ssc_lds_fence();
+    return ok;
+}
+
+__global__ __launch_bounds__(SSC_NT) void k_ssc(SscArgs A) {
+    extern __shared__ uint32_t lds[];
+    uint32_t* a = lds;                                    // [SSC_NMAX] (key << 16 | index)
+    uint16_t* Lp = (uint16_t*)(a + SSC_NMAX);             // [SSC_NMAX]
+    uint16_t* Rp = Lp + SSC_NMAX;                         // [SSC_NMAX]
+    int* seg = (int*)(Rp + SSC_NMAX);                     // 2 x [SSC_SEGMAX][3]
+    uint32_t* arena = (uint32_t*)(seg + 2 * SSC_SEGMAX * 3);     // [SSC_ARENA_WORDS]
+    __shared__ int hist[256], sCnt[2], sFail;
+    __shared__ int cacheW[64], cacheC[64], cacheSlot[64], nCache, sched[8], nSched, sFinal, sDone, sSolo;
+    __shared__ int sLow, sHigh, sPrev, sLast;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int img = blockIdx.x % A.nimg, l = blockIdx.x / A.nimg;
+#ifdef VSLAM_SSC_STAMPS
+    long long st_t = clock64();
+    long long* st = (long long*)(A.taskCount + A.nimg * MAX_LEVELS) + (size_t)(img * A.nLevels + l) * 8;
+#define SSC_STAMP(k) do { if (tid == 0) { const long long n_ = clock64(); st[k] = n_ - st_t; st_t = n_; } } while (0)
+#else
+#define SSC_STAMP(k) do {} while (0)
+#endif
+    const int* lc = A.levelCount + (size_t)img * (MAX_LEVELS + 1);
+    int coff = 0;
+    for (int q = 0; q < l; q++) coff += lc[q];
+    const int n = lc[l];
+    const uint32_t* cand = A.cand + (size_t)img * A.candCap + coff;
+    uint32_t* out = A.tmp + (size_t)img * A.candCap + coff;
+    int* taskCount = A.taskCount + img * A.nLevels + l;
+    if (lc[MAX_LEVELS] > A.candCap) { if (tid == 0) { A.flags[2 * img + 1] = 1; *taskCount = 0; } return; }
+    const int numRet = A.numRet[l];
+    if (n <= numRet) {                                   // (:371-374 of the restatement) everything is kept, original order
+        for (int i = tid; i < n; i += SSC_NT) out[i] = cand[i];
+        if (tid == 0) *taskCount = n;
+        return;
+    }
+    if (n > SSC_NMAX) { if (tid == 0) { atomicOr(&A.flags[2 * img], 1); *taskCount = 0; } return; }
+
+    // ---- (1) std::sort on indices by response, exact tie order ----------------------------------------
+    // the level's candidates move from mapped host memory into HBM (`out`, overwritten by the picks at the very end)
+    uint32_t* b = A.scratch + (size_t)img * A.candCap + coff;
+    for (int i = tid; i < n; i += SSC_NT) { const uint32_t pk = cand[i]; b[i] = pk; a[i] = ((uint32_t)cand_s(pk) << 16) | (uint32_t)i; }
+    if (tid < 256) hist[tid] = 0;
+    if (tid == 0) {
+        sFail = 0;
+        int lg = 0;
+        while ((1 << (lg + 1)) <= n) lg++;
+        sCnt[0] = 0; sCnt[1] = 0;
+        if (n > 16) { seg[0] = 0; seg[1] = n; seg[2] = 2 * lg; sCnt[0] = 1; }
+    }
+    __syncthreads();
+    int cur = 0;
+    for (;;) {
+        const int nseg = sCnt[cur];
+        if (nseg == 0) break;
+        int* segC = seg + cur * SSC_SEGMAX * 3;
+        int* segN = seg + (cur ^ 1) * SSC_SEGMAX * 3;
+        for (int s = wave; s < nseg; s += SSC_NW) {
+            const int f = segC[3 * s], e = segC[3 * s + 1], depth = segC[3 * s + 2];
+            if (e - f <= 64) {                            // the whole subtree of a short segment, in registers
+                if (!ssc_small_segment(a, f, e, depth, Lp, Rp) && lane == 0) sFail = 2;
+                continue;
+            }
+            if (depth == 0) { if (lane == 0) sFail = 2; continue; }       // libstdc++ would switch to heapsort here
+            // __move_median_to_first(f, f+1, mid, e-1)
+            if (lane == 0) {
+                const int ia = f + 1, ib = f + (e - f) / 2, ic = e - 1;
+                const uint32_t ka = a[ia] >> 16, kb = a[ib] >> 16, kc = a[ic] >> 16;
+                int m;
+                if (ka < kb) { if (kb < kc) m = ib; else if (ka < kc) m = ic; else m = ia; }
+                else if (ka < kc) m = ia; else if (kb < kc) m = ic; else m = ib;
+                const uint32_t t = a[f]; a[f] = a[m]; a[m] = t;
+            }
+            ssc_lds_fence();
+            const uint32_t pk = a[f] >> 16;
+            // __unguarded_partition(f+1, e, pivot): stoppers from the left (>= pivot) / from the right (<= pivot)
+            int nL = 0, nR = 0;
+            for (int base = f + 1; base < e; base += 64) {
+                const int x = base + lane;
+                const bool v = x < e;
+                const uint32_t kx = v ? (a[x] >> 16) : 0u;
+                const bool isL = v && kx >= pk, isR = v && kx <= pk;
+                const unsigned long long bl = __ballot(isL), br = __ballot(isR);
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                if (isL) Lp[f + 1 + nL + __popcll(bl & lt)] = (uint16_t)x;
+                if (isR) Rp[f + 1 + nR + __popcll(br & lt)] = (uint16_t)x;
+                nL += __popcll(bl); nR += __popcll(br);
+            }
+            ssc_lds_fence();
+            const int nPair = min(nL, nR);
+            int K = 0;
+            for (int base = 0; base < nPair; base += 64) {
+                const int k = base + lane;           // 0-based pair index
+                const bool ok = k < nPair && Lp[f + 1 + k] < Rp[f + 1 + nR - 1 - k];
+                const unsigned long long bo = __ballot(ok);
+                K += __popcll(bo);
+                if (bo != ~0ull) break;              // monotone: the first failure ends the run
+            }
+            for (int k = lane; k < K; k += 64) {
+                const int xl = Lp[f + 1 + k], xr = Rp[f + 1 + nR - 1 - k];
+                const uint32_t t = a[xl]; a[xl] = a[xr]; a[xr] = t;
+            }
+            ssc_lds_fence();
+            int cut = K >= 1 ? (int)Rp[f + 1 + nR - K] : e;
+            if (K < nL) cut = min(cut, (int)Lp[f + 1 + K]);
+            if (lane == 0) {
+                // __introsort_loop(cut, last, depth - 1); last = cut
+                if (e - cut > 16) { const int q = atomicAdd(&sCnt[cur ^ 1], 1); if (q < SSC_SEGMAX) { segN[3 * q] = cut; segN[3 * q + 1] = e; segN[3 * q + 2] = depth - 1; } else sFail = 4; }
+                if (cut - f > 16) { const int q = atomicAdd(&sCnt[cur ^ 1], 1); if (q < SSC_SEGMAX) { segN[3 * q] = f; segN[3 * q + 1] = cut; segN[3 * q + 2] = depth - 1; } else sFail = 4; }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) sCnt[cur] = 0;
+        cur ^= 1;
+        __syncthreads();
+    }
+    SSC_STAMP(0);
+    if (sFail) { if (tid == 0) { atomicOr(&A.flags[2 * img], sFail); *taskCount = 0; } return; }
+    // __final_insertion_sort == stable counting sort by the 8-bit key of the partitioned array.  Eight slices in
+    // array order, one per wave: per-(slice, key) counts, offsets ordered by (key, slice), stable scatter per slice.
+    int* h2 = (int*)arena;                               // [SSC_NW][256]
+    for (int i = tid; i < SSC_NW * 256; i += SSC_NT) h2[i] = 0;
+    __syncthreads();
+    const int per = ((n + SSC_NW - 1) / SSC_NW + 63) & ~63;
+    const int s0 = min(n, wave * per), s1 = min(n, s0 + per);
+    for (int i = s0 + lane; i < s1; i += 64) atomicAdd(&h2[wave * 256 + (int)(a[i] >> 16)], 1);
+    __syncthreads();
+    if (tid < 256) { int t = 0; for (int w = 0; w < SSC_NW; w++) t += h2[w * 256 + tid]; hist[tid] = t; }
+    __syncthreads();
+    if (wave == 0) {                                     // exclusive prefix over 256 bins
+        int run = 0;
+        for (int base = 0; base < 256; base += 64) {
+            const int v = hist[base + lane];
+            int incl = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+            hist[base + lane] = run + incl - v;
+            run += __shfl(incl, 63);
+        }
+    }
+    __syncthreads();
+    if (tid < 256) { int run = hist[tid]; for (int w = 0; w < SSC_NW; w++) { const int t = h2[w * 256 + tid]; h2[w * 256 + tid] = run; run += t; } }
+    __syncthreads();
+    {
+        // sorted ascending -> written reversed (cv::sortIdx DESCENDING reverses the index array), as packed candidates
+        uint32_t* sorted = (uint32_t*)Lp;                // Lp | Rp together hold SSC_NMAX u32
+        int* off = h2 + wave * 256;
+        for (int base = s0; base < s1; base += 64) {
+            const int i = base + lane;
+            const bool v = i < s1;
+            const uint32_t e = v ? a[i] : 0u;
+            const int key = (int)(e >> 16);
+            unsigned long long same = v ? ~0ull : 0ull;
+#pragma unroll
+            for (int bit = 0; bit < 8; bit++) {
+                const unsigned long long bb = __ballot(v && ((key >> bit) & 1));
+                same &= ((key >> bit) & 1) ? bb : ~bb;
+            }
+            same &= __ballot(v);
+            if (v) {
+                const int rank = __popcll(same & ((1ull << lane) - 1ull));
+                sorted[n - 1 - (off[key] + rank)] = b[e & 0xffffu];
+            }
+            ssc_lds_fence();
+            if (v && (same >> lane) == 1ull) off[key] += __popcll(same);      // the highest lane of each key group
+            ssc_lds_fence();
+        }
+    }
+    __syncthreads();
+    SSC_STAMP(1);
+    const uint32_t* sc = (const uint32_t*)Lp;            // candidates in response order (descending, reference tie order)
+
+    // ---- (2) binary search over the suppression width ---------------------------------------------------
+    if (tid == 0) {
+        sLow = max(1, (int)floor(sqrt((double)n / numRet)));
+        sHigh = A.high[l]; sPrev = -1; sLast = -1; nCache = 0; sDone = 0; sFinal = -1; sSolo = 0;
+    }
+    __syncthreads();
+    const int kmin = A.kmin[l], kmax = A.kmax[l];
+    const int cols = A.cols[l], rows = A.rows[l];
+    uint32_t* gridG = A.gridG + A.gridOff[img * A.nLevels + l];
+    for (int round = 0; round < 64; round++) {
+        if (tid == 0) {
+            // replay the reference loop on the cached counts
+            nSched = 0;
+            for (;;) {
+                const int width = sLow + (sHigh - sLow) / 2;
+                if (width == sPrev || sLow > sHigh) { sFinal = sLast; sDone = 1; break; }
+                int cnt = -1;
+                for (int q = 0; q < nCache; q++) if (cacheW[q] == width) cnt = cacheC[q];
+                if (cnt < 0) break;
+                sLast = width;
+                if (cnt >= kmin && cnt <= kmax) { sFinal = width; sDone = 1; break; }
+                if (cnt < kmin) sHigh = width - 1; else sLow = width + 1;
+                sPrev = width;
+            }
+            if (!sDone) {
+                // speculate: the next probe and both outcomes, three levels deep (breadth first)
+                int qlow[8], qhigh[8], qprev[8];
+                qlow[1] = sLow; qhigh[1] = sHigh; qprev[1] = sPrev;
+                for (int node = 1; node < 8; node++) {
+                    const int lo = qlow[node], hi = qhigh[node], pv = qprev[node];
+                    const int width = lo + (hi - lo) / 2;
+                    const bool term = lo > hi || width == pv;
+                    if (!term) {
+                        bool dup = false;
+                        for (int q = 0; q < nSched; q++) dup |= sched[q] == width;
+                        for (int q = 0; q < nCache; q++) dup |= cacheW[q] == width;
+                        if (!dup && nSched < SSC_NPROBE - 1) sched[nSched++] = width;
+                    }
+                    if (2 * node + 1 < 8) {
+                        qlow[2 * node] = term ? 1 : lo; qhigh[2 * node] = term ? 0 : width - 1; qprev[2 * node] = width;         // too few
+                        qlow[2 * node + 1] = term ? 1 : width + 1; qhigh[2 * node + 1] = term ? 0 : hi; qprev[2 * node + 1] = width;   // too many
+                    }
+                }
+                if (sSolo) nSched = 1;
+            }
+        }
+        __syncthreads();
+        if (sDone) break;
+        const int ns = nSched;
+        const bool solo = sSolo != 0;
+        int cnt = -2;
+        bool fits = true;
+        constexpr int SLICE = SSC_ARENA_WORDS / SSC_NPROBE;
+        uint32_t* picks = solo ? arena + SSC_ARENA_WORDS - SSC_PICKW : arena + wave * SLICE + SLICE - SSC_PICKW;
+        if (wave < ns) {
+            uint32_t* grid = solo ? arena : arena + wave * SLICE;
+            cnt = ssc_eval(sc, n, sched[wave], cols, rows, grid, (solo ? SSC_ARENA_WORDS : SLICE) - SSC_PICKW, picks, fits, kmax);
+            // a probe whose bit grid exceeds even the whole LDS arena (width 1-2 on a large level) uses the task's HBM grid
+            if (solo && !fits) cnt = ssc_eval(sc, n, sched[wave], cols, rows, gridG, 1 << 30, picks, fits, kmax);
+        }
+        __syncthreads();
+        if (wave < ns && lane == 0) {
+            if (fits) { const int q = atomicAdd(&nCache, 1); if (q < 64) { cacheW[q] = sched[wave]; cacheC[q] = cnt; cacheSlot[q] = solo ? -1 : wave; } else sFail = 8; }
+            else if (wave == 0) { if (solo) sFail = 16; else sSolo = 1; }       // the needed probe needs the whole arena
+        }
+        __syncthreads();
+        if (sFail) { if (tid == 0) { atomicOr(&A.flags[2 * img], sFail); *taskCount = 0; } return; }
+        if (tid == 0 && sSolo && ns > 0) {
+            // leave solo mode once the probe that required it has been served
+            bool served = false;
+            for (int q = 0; q < nCache; q++) served |= cacheW[q] == sched[0];
+            if (served && solo) sSolo = 0;
+        }
+        __syncthreads();
+    }
+    SSC_STAMP(2);
+#ifdef VSLAM_SSC_STAMPS
+    if (tid == 0) { st[4] = n; st[5] = nCache; st[6] = sFinal; }
+#endif
+    if (!sDone) { if (tid == 0) { atomicOr(&A.flags[2 * img], 32); *taskCount = 0; } return; }
+    // emit the picks of the last evaluated width (lastPicked of the reference loop).  That probe always belongs to
+    // the latest round, so its pick bitmask is still in its wave's slice: prefix over the words, one thread per word.
+    int total = 0;
+    if (sFinal >= 0) {
+        int slot = -1;
+        for (int q = 0; q < nCache; q++) if (cacheW[q] == sFinal) { slot = cacheSlot[q]; total = cacheC[q]; }
+        constexpr int SLICE = SSC_ARENA_WORDS / SSC_NPROBE;
+        const uint32_t* picks = slot < 0 ? arena + SSC_ARENA_WORDS - SSC_PICKW : arena + slot * SLICE + SLICE - SSC_PICKW;
+        if (total > kmax) {
+            // the search ended on a "too many" probe (width == prevWidth / low > high): its scan was cut short, redo it in full
+            __syncthreads();
+            if (wave == 0) {
+                uint32_t* pk = arena + SSC_ARENA_WORDS - SSC_PICKW;
+                bool fits;
+                int cnt = ssc_eval(sc, n, sFinal, cols, rows, arena, SSC_ARENA_WORDS - SSC_PICKW, pk, fits, -1);
+                if (!fits) cnt = ssc_eval(sc, n, sFinal, cols, rows, gridG, 1 << 30, pk, fits, -1);
+                if (lane == 0) sCnt[0] = cnt;
+            }
+            __syncthreads();
+            total = sCnt[0];
+            picks = arena + SSC_ARENA_WORDS - SSC_PICKW;
+        }
+        const int nWords = (n + 31) >> 5;
+        int* pre = hist;                                 // 256 ints: exclusive prefix of the per-word pick counts
+        if (tid < 256) pre[tid] = tid < nWords ? __popc(picks[tid]) : 0;
+        __syncthreads();
+        if (wave == 0) {
+            int run = 0;
+            for (int base = 0; base < 256; base += 64) {
+                const int v = pre[base + lane];
+                int incl = v;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+                pre[base + lane] = run + incl - v;
+                run += __shfl(incl, 63);
+            }
+        }
+        __syncthreads();
+        if (tid < nWords) {
+            uint32_t w = picks[tid];
+            int o = pre[tid];
+            while (w) { const int bit = __ffs((int)w) - 1; w &= w - 1; out[o++] = sc[32 * tid + bit]; }
+        }
+    }
+    if (tid == 0) *taskCount = total;
+    SSC_STAMP(3);
+}
+
+// level-major concatenation of the per-level picks: kept[img][...], keptOff[img][0..MAX_LEVELS]
+__global__ __launch_bounds__(256) void k_ssc_pack(SscArgs A, uint32_t* __restrict__ kept, int keptCap, int* __restrict__ keptOff,
+                                                  int* __restrict__ hostCounts) {
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const int* lc = A.levelCount + (size_t)img * (MAX_LEVELS + 1);
+    int* koff = keptOff + (size_t)img * (MAX_LEVELS + 1);
+    int k = 0, coff = 0;
+    for (int l = 0; l < A.nLevels; l++) {
+        const int cnt = A.taskCount[img * A.nLevels + l];
+        const int room = max(0, min(cnt, keptCap - k));
+        const uint32_t* src = A.tmp + (size_t)img * A.candCap + coff;
+        for (int i = tid; i < room; i += 256) kept[(size_t)img * keptCap + k + i] = src[i];
+        if (tid == 0) { koff[l] = k; if (cnt > room) A.flags[2 * img + 1] = 1; }
+        k += room;
+        coff += lc[l];
+    }
+    if (tid == 0) {
+        for (int l = A.nLevels; l <= MAX_LEVELS; l++) koff[l] = k;
+        hostCounts[img] = k;
+        hostCounts[A.nimg + 2 * img] = A.flags[2 * img];
+        hostCounts[A.nimg + 2 * img + 1] = A.flags[2 * img + 1];
+        A.flags[2 * img] = 0; A.flags[2 * img + 1] = 0;
+    }
+}
+
+void launch_ssc(hipStream_t s, const SscArgs& A, uint32_t* kept, int keptCap, int* keptOff, int* hostCounts) {
+    const size_t lds = (size_t)SSC_NMAX * 4 + (size_t)2 * SSC_NMAX * 2 + (size_t)2 * SSC_SEGMAX * 3 * 4 + (size_t)SSC_ARENA_WORDS * 4;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_ssc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    hipLaunchKernelGGL(k_ssc, dim3(A.nimg * A.nLevels), dim3(SSC_NT), lds, s, A);
+    hipLaunchKernelGGL(k_ssc_pack, dim3(A.nimg), dim3(256), 0, s, A, kept, keptCap, keptOff, hostCounts);
+}
+
+}  // namespace vslam

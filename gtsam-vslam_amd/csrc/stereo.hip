@@ -348,6 +348,7 @@ vslam_status vslam_matcher::refresh_keys() {
     for (int s = 0; s < 2; s++) {
         if (overridden[s]) continue;
         if (!fe[s]->ran) { set_error("matcher: extractor has not run"); return VSLAM_ERR_INVALID; }
+        VS_CHECK(fe[s]->wait_counts());        // keypoint totals of a device-SSC run (the frame itself is ordered by evDone)
         d_kps[s] = fe[s]->d_kps + (size_t)img[s] * fe[s]->keptCap;
         d_desc[s] = fe[s]->d_desc + (size_t)img[s] * fe[s]->keptCap * 32;
         nKeys[s] = (s == 1 && mono) ? 0 : fe[s]->nKept[img[s]];

@@ -140,6 +140,11 @@ class Extractor:
     def set_timing(self, on):
         _chk(self.L.vslam_extractor_set_timing(self.h, int(bool(on))))
 
+    def ssc_stats(self):
+        on, fb = C.c_int32(), C.c_int32()
+        _chk(self.L.vslam_extractor_ssc_stats(self.h, C.byref(on), C.byref(fb)))
+        return on.value, fb.value
+
 
 class Rig(C.Structure):
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),

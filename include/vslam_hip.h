@@ -111,6 +111,11 @@ vslam_status vslam_extractor_timings(const vslam_extractor* ex, const char** nam
 /* per-kernel HIP-event timing on (default) / off for this extractor's following runs; off removes the
  * two event records per launch from the launch-bound path */
 vslam_status vslam_extractor_set_timing(vslam_extractor* ex, int32_t on);
+/* SSC placement: on_device = 1 when the suppression (FeatureExtractor::ssc, src/FeatureExtractor.cpp:368-468) runs in
+ * the k_ssc kernel (default; the environment variable VSLAM_HOST_SSC=1 selects the host worker pool);
+ * host_fallbacks = frames whose SSC was redone on the host because a level exceeded a device limit (more than 4096
+ * candidates in one level, introsort depth limit reached, probe grid larger than the LDS arena). */
+vslam_status vslam_extractor_ssc_stats(vslam_extractor* ex, int32_t* on_device, int32_t* host_fallbacks);
 
 
 /* ---------------------------------------------------------------------------
