@@ -770,6 +770,179 @@ __global__ __launch_bounds__(64) void k_ba_solve_wave(BaDev D) {
     if (lane == 0) D.flags[0] = bad ? 1 : 0;
 }
 
+// Reduced camera systems of 61..256 unknowns (11..42 free keyframes, e.g. the 20-KF KITTI window): blocked
+// right-looking Cholesky with the WHOLE lower triangle resident in MFMA accumulators - 136 tiles of 16x16 doubles
+// over 8 waves (17 tiles = 136 VGPRs per wave, two waves per SIMD), so the factorisation never touches HBM.  (A
+// 384-unknown system is 614 KB of tiles, more than one CU's 512 KB register file: it needs the two-workgroup form.)  Per block
+// column: the owners drop the panel tiles into LDS, wave 0 factors the 16x16 diagonal block in registers, every
+// thread solves one panel row against it, then every wave updates its tiles with v_mfma_f64_16x16x4 (A and B
+// operands straight from the LDS panel).  L is streamed to global memory column block by column block for the
+// blocked forward / backward substitutions that follow.  Padding rows are identity.
+constexpr int BA_MFMA_N = 256, BA_MFMA_NB = BA_MFMA_N / 16, BA_MFMA_NW = 8, BA_MFMA_SLOTS = 17, BA_MFMA_LD = 17;
+typedef double ba_d4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(64 * BA_MFMA_NW) void k_ba_solve_mfma(BaDev D, double* __restrict__ Lg) {
+    extern __shared__ double sm[];
+    double* P = sm;                                   // [BA_MFMA_N][BA_MFMA_LD] current panel
+    double* sInv = P + BA_MFMA_N * BA_MFMA_LD;        // [16]
+    double* sB = sInv + 16;                           // [BA_MFMA_N] right-hand side / solution
+    __shared__ int sBad;
+    if (!ba_enter(D, BA_TRY)) return;
+    const double lambda = D.ctl[CTL_LAMBDA];
+    constexpr int N = BA_MFMA_N, NB = BA_MFMA_NB, LD = BA_MFMA_LD;
+    const int n = D.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) sBad = 0;
+    // tile t = ib (ib + 1) / 2 + jb (jb <= ib) lives in slot t / 8 of wave t % 8; accumulator layout of
+    // v_mfma_f64_16x16x4: register r of lane l = element (row (l >> 4) + 4 r, column l & 15)
+    ba_d4 acc[BA_MFMA_SLOTS];
+    int tib[BA_MFMA_SLOTS], tjb[BA_MFMA_SLOTS];
+#pragma unroll
+    for (int s = 0; s < BA_MFMA_SLOTS; s++) {
+        const int t = s * BA_MFMA_NW + wave;
+        int ib = 0;
+        while ((ib + 1) * (ib + 2) / 2 <= t) ib++;
+        const int jb = t - ib * (ib + 1) / 2;
+        const bool valid = ib < NB;
+        tib[s] = valid ? ib : -1; tjb[s] = jb;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = ib * 16 + (lane >> 4) + 4 * r, col = jb * 16 + (lane & 15);
+            double v = (row == col) ? 1.0 : 0.0;              // identity padding
+            if (valid && row < n && col < n) v = D.S[(size_t)col * n + row] + ((row == col) ? lambda : 0.0);   // upper triangle of D.S is the valid one
+            acc[s][r] = v;
+        }
+    }
+    for (int i = tid; i < N; i += 64 * BA_MFMA_NW) sB[i] = i < n ? D.rhs[i] : 0.0;
+    __syncthreads();
+    for (int kb = 0; kb < NB; kb++) {
+        // (a) panel tiles (ib, kb), ib >= kb -> LDS
+#pragma unroll
+        for (int s = 0; s < BA_MFMA_SLOTS; s++) {
+            if (tib[s] >= kb && tjb[s] == kb) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) P[(tib[s] * 16 + (lane >> 4) + 4 * r) * LD + (lane & 15)] = acc[s][r];
+            }
+        }
+        __syncthreads();
+        // (b) 16x16 diagonal block: lane i = row i, pivots by readlane (as k_ba_solve_wave)
+        if (wave == 0) {
+            const int r = lane & 15;
+            double a[16];
+#pragma unroll
+            for (int c = 0; c < 16; c++) a[c] = P[(kb * 16 + r) * LD + c];
+            bool bad = false;
+            double idg = 1.0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                double d = readlane_d(a[k], k);
+                if (!(d > 0)) { bad = true; d = 1.0; }
+                const double id = rsqrt(d);
+                const double lk = (r == k) ? d * id : a[k] * id;
+                if (r == k) idg = id;
+                a[k] = lk;
+#pragma unroll
+                for (int j = k + 1; j < 16; j++) a[j] = __builtin_fma(-lk, readlane_d(lk, j), a[j]);
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int c = 0; c < 16; c++) P[(kb * 16 + r) * LD + c] = a[c];
+                sInv[r] = idg;
+            }
+            if (bad && lane == 0) sBad = 1;
+        }
+        __syncthreads();
+        // (c) panel rows below the diagonal block: row <- row L11^-T; the finished column block goes to global L
+        for (int row = (kb + 1) * 16 + tid; row < N; row += 64 * BA_MFMA_NW) {
+            double x[16];
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                double v = P[row * LD + c];
+#pragma unroll
+                for (int m = 0; m < c; m++) v = __builtin_fma(-x[m], P[(kb * 16 + c) * LD + m], v);
+                x[c] = v * sInv[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 16; c++) { P[row * LD + c] = x[c]; Lg[(size_t)row * N + kb * 16 + c] = x[c]; }
+        }
+        if (tid < 16) {
+#pragma unroll
+            for (int c = 0; c < 16; c++) Lg[(size_t)(kb * 16 + tid) * N + kb * 16 + c] = c <= tid ? P[(kb * 16 + tid) * LD + c] : 0.0;
+        }
+        __syncthreads();
+        // (d) trailing update: tile (ib, jb) -= L21[ib] L21[jb]^T, 4 k-steps of v_mfma_f64_16x16x4
+#pragma unroll
+        for (int s = 0; s < BA_MFMA_SLOTS; s++) {
+            if (tib[s] > kb && tjb[s] > kb) {
+                const double* pa = P + (tib[s] * 16 + (lane & 15)) * LD + (lane >> 4);
+                const double* pb = P + (tjb[s] * 16 + (lane & 15)) * LD + (lane >> 4);
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * ks], pb[4 * ks], acc[s], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    const bool fail = sBad != 0;
+    if (!fail) {
+        __threadfence_block();
+        // L y = b, block by block: wave 0 solves the 16 unknowns of the block, every later row takes its 16 products
+        for (int kb = 0; kb < NB; kb++) {
+            if (wave == 0) {
+                const int r = lane & 15;
+                double b = sB[kb * 16 + r];
+                double lrow[16];
+#pragma unroll
+                for (int c = 0; c < 16; c++) lrow[c] = Lg[(size_t)(kb * 16 + r) * N + kb * 16 + c];
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const double yk = readlane_d(b, k) / readlane_d(lrow[k], k);
+                    if (r == k) b = yk; else if (r > k) b = __builtin_fma(-lrow[k], yk, b);
+                }
+                if (lane < 16) sB[kb * 16 + r] = b;
+            }
+            __syncthreads();
+            for (int row = (kb + 1) * 16 + tid; row < N; row += 64 * BA_MFMA_NW) {
+                double v = sB[row];
+                const double* lr = Lg + (size_t)row * N + kb * 16;
+#pragma unroll
+                for (int c = 0; c < 16; c++) v = __builtin_fma(-lr[c], sB[kb * 16 + c], v);
+                sB[row] = v;
+            }
+            __syncthreads();
+        }
+        // L^T x = y, blocks in reverse
+        for (int kb = NB - 1; kb >= 0; kb--) {
+            if (wave == 0) {
+                const int r = lane & 15;
+                double b = sB[kb * 16 + r];
+                double lcol[16];                         // column r of the diagonal block = row r of its transpose
+#pragma unroll
+                for (int c = 0; c < 16; c++) lcol[c] = Lg[(size_t)(kb * 16 + c) * N + kb * 16 + r];
+#pragma unroll
+                for (int k = 15; k >= 0; k--) {
+                    const double xk = readlane_d(b, k) / readlane_d(lcol[k], k);
+                    if (r == k) b = xk; else if (r < k) b = __builtin_fma(-lcol[k], xk, b);
+                }
+                if (lane < 16) sB[kb * 16 + r] = b;
+            }
+            __syncthreads();
+            for (int row = tid; row < kb * 16; row += 64 * BA_MFMA_NW) {
+                double v = sB[row];
+#pragma unroll
+                for (int c = 0; c < 16; c++) v = __builtin_fma(-Lg[(size_t)(kb * 16 + c) * N + row], sB[kb * 16 + c], v);
+                sB[row] = v;
+            }
+            __syncthreads();
+        }
+        for (int i = tid; i < n; i += 64 * BA_MFMA_NW) D.dP[i] = sB[i];
+        for (int k = tid; k < D.K; k += 64 * BA_MFMA_NW) {
+            const int fi = D.fidx[k];
+            if (fi >= 0) { DPose T; pose_retract(D.poseCur[k], sB + 6 * fi, T); D.poseTrial[k] = T; }
+            else D.poseTrial[k] = D.poseCur[k];
+        }
+    }
+    if (tid == 0) D.flags[0] = fail ? 1 : 0;
+}
+
 // back-substitution: dl = Hll^-1 (bl - sum_k W_k^T dp_k); trial landmark = cur + dl
 __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_back(BaDev D, int maxSlots) {
     extern __shared__ double sm[];
@@ -951,7 +1124,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         hipStream_t stream = nullptr;
         int device = -1;
         DevBuf<DPose> d_pose0, d_poseA, d_poseB;
-        DevBuf<double> d_lm0, d_lmA, d_lmB, d_facJ, d_S, d_Spart, d_Sedge, d_dP, d_dL, d_lmDiff, d_sums, d_partial;
+        DevBuf<double> d_lm0, d_lmA, d_lmB, d_facJ, d_S, d_Spart, d_Sedge, d_dP, d_dL, d_lmDiff, d_sums, d_partial, d_Lg;
         DevBuf<int> d_flags, d_pairKf, d_pairLm, d_pairOct;
         DevBuf<uint8_t> d_pairFlags, d_kfLocal, d_wrong;
         DevBuf<float> d_pairUv;
@@ -977,7 +1150,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
     g_baTimer.multi = true;
     auto &d_pose0 = ws->d_pose0, &d_poseA = ws->d_poseA, &d_poseB = ws->d_poseB;
     auto &d_lm0 = ws->d_lm0, &d_lmA = ws->d_lmA, &d_lmB = ws->d_lmB, &d_facJ = ws->d_facJ, &d_S = ws->d_S, &d_Spart = ws->d_Spart,
-         &d_Sedge = ws->d_Sedge, &d_dP = ws->d_dP, &d_dL = ws->d_dL, &d_lmDiff = ws->d_lmDiff, &d_sums = ws->d_sums, &d_partial = ws->d_partial;
+         &d_Sedge = ws->d_Sedge, &d_dP = ws->d_dP, &d_dL = ws->d_dL, &d_lmDiff = ws->d_lmDiff, &d_sums = ws->d_sums, &d_partial = ws->d_partial, &d_Lg = ws->d_Lg;
     auto &d_flags = ws->d_flags, &d_pairKf = ws->d_pairKf, &d_pairLm = ws->d_pairLm, &d_pairOct = ws->d_pairOct;
     auto &d_pairFlags = ws->d_pairFlags, &d_kfLocal = ws->d_kfLocal, &d_wrong = ws->d_wrong;
     auto &d_pairUv = ws->d_pairUv;
@@ -1171,6 +1344,12 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         else VS_HIP(hipFuncSetAttribute((const void*)k_ba_schur<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurLds));
         if (solveLds) VS_HIP(hipFuncSetAttribute((const void*)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solveLdsBytes));
         if (backLds > 48 * 1024) VS_HIP(hipFuncSetAttribute((const void*)k_ba_back, hipFuncAttributeMaxDynamicSharedMemorySize, (int)backLds));
+        const size_t mfmaLds = ((size_t)BA_MFMA_N * BA_MFMA_LD + 16 + BA_MFMA_N) * sizeof(double);
+        static const bool useMfma = !getenv("VSLAM_BA_NO_MFMA");
+        if (n > BA_WAVE_N && n <= BA_MFMA_N && useMfma) {
+            VS_HIP(d_Lg.alloc((size_t)BA_MFMA_N * BA_MFMA_N));
+            VS_HIP(hipFuncSetAttribute((const void*)k_ba_solve_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfmaLds));
+        }
         BHS("upload");
 
         // ---- LM: speculative steps, the device decides (k_ba_ctl) -----------------------------------
@@ -1201,6 +1380,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
             if (n > 0) hipLaunchKernelGGL(k_ba_reduce, dim3(((int)sysDoubles + 255) / 256, ldsS ? 8 : 1), dim3(256), 0, stream, D, ldsS ? lmBlocks : 0);   // + BetweenFactor blocks
             if (comm && n > 0) { const int tc = g_baTimer.begin("ba_allreduce"); VS_CHECK(comm_allreduce(comm, d_S.p, (size_t)n * n + n, stream)); g_baTimer.end(tc); }
             if (n <= BA_WAVE_N) hipLaunchKernelGGL(k_ba_solve_wave, dim3(1), dim3(64), 0, stream, D);
+            else if (n <= BA_MFMA_N && useMfma) hipLaunchKernelGGL(k_ba_solve_mfma, dim3(1), dim3(64 * BA_MFMA_NW), mfmaLds, stream, D, d_Lg.p);
             else hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(std::max(64, vslam::align_up(n, 64))),
                                     solveLds ? solveLdsBytes : 64, stream, D, solveLds ? 1 : 0, solveLds ? ldA : n);
             g_baTimer.end(t);
