@@ -119,13 +119,15 @@ __global__ __launch_bounds__(256) void k_proj_resolve(ProjArgs A, const unsigned
     int* cr = claims + A.n[0];
     int* ri = cr + A.n[1];      // TrackedKeys::rightIdxs / leftIdxs staged next to the claim tables:
     int* li = ri + A.n[0];      // the stereo-partner lookup is on the serial path
-    int* spair = li + A.n[1];                                                      // [PROJ_SUPER][2]
+    int* tl = li + A.n[1];      // tentative claims of the current 16-point step (lowest point index wins), INT_MAX = none
+    int* tr = tl + A.n[0];
+    int* spair = tr + A.n[1];                                                      // [PROJ_SUPER][2]
     unsigned long long* skeys = (unsigned long long*)(((uintptr_t)(spair + 2 * PROJ_SUPER) + 15) & ~(uintptr_t)15);   // [PROJ_SUPER][16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (A.gate && *A.gate < A.gateMin) return;
     if (A.Mdev) A.M = min(A.M, *A.Mdev);
-    for (int k = tid; k < A.n[0]; k += 256) { cl[k] = matchedL[k]; ri[k] = A.mode == PROJ_STEREO ? A.rightIdxs[k] : -1; }
-    for (int k = tid; k < A.n[1]; k += 256) { cr[k] = matchedR[k]; li[k] = A.leftIdxs[k]; }
+    for (int k = tid; k < A.n[0]; k += 256) { cl[k] = matchedL[k]; ri[k] = A.mode == PROJ_STEREO ? A.rightIdxs[k] : -1; tl[k] = INT_MAX; }
+    for (int k = tid; k < A.n[1]; k += 256) { cr[k] = matchedR[k]; li[k] = A.leftIdxs[k]; tr[k] = INT_MAX; }
     int nMatches = 0;
     static_assert(PROJ_K == 8, "lane layout assumes 8 keys per side");
     const int q = lane >> 2, e = lane & 3, side = e >> 1, half = e & 1;
@@ -184,18 +186,24 @@ __global__ __launch_bounds__(256) void k_proj_resolve(ProjArgs A, const unsigned
                 const int idx = dec & 0xffff;
                 if (dec >> 16) { cRq = idx; cLq = li[idx]; } else { cLq = idx; cRq = ri[idx]; }
             }
+            // in-step conflicts through the tentative-claim tables: an earlier point of this step claiming a keypoint of
+            // my lists (my first / second unclaimed key could change) or the keypoint I claim -> replay the step in order
+            if (e == 0 && dec >= 0) {
+                if (cLq >= 0) atomicMin(&tl[cLq], q);
+                if (cRq >= 0) atomicMin(&tr[cRq], q);
+            }
+            lds_order();
+            if (!skip) {
+                const int* tt = side ? tr : tl;
 #pragma unroll
-            for (int q2 = 0; q2 < 15; q2++) {
-                const int ocl = __shfl(cLq, q2 * 4), ocr = __shfl(cRq, q2 * 4);
-                if (q2 < q && !skip) {
-                    const int oc = side ? ocr : ocl;
-                    if (oc >= 0) {
-#pragma unroll
-                        for (int j = 0; j < 4; j++)
-                            if (k4[j] != KEY_NONE && key_idx(k4[j]) == oc) bad = true;
-                    }
-                    if ((cLq >= 0 && cLq == ocl) || (cRq >= 0 && cRq == ocr)) bad = true;
-                }
+                for (int j = 0; j < 4; j++)
+                    if (k4[j] != KEY_NONE && tt[key_idx(k4[j])] < q) bad = true;
+                if ((cLq >= 0 && tl[cLq] < q) || (cRq >= 0 && tr[cRq] < q)) bad = true;
+            }
+            lds_order();
+            if (e == 0 && dec >= 0) {                       // the tables are empty again before the next step
+                if (cLq >= 0) tl[cLq] = INT_MAX;
+                if (cRq >= 0) tr[cRq] = INT_MAX;
             }
             if (__ballot(bad) == 0ull) {
                 if (e == 0 && dec >= 0) {
@@ -276,7 +284,7 @@ __global__ __launch_bounds__(256) void k_proj_resolve(ProjArgs A, const unsigned
 void launch_proj_resolve(hipStream_t s, const ProjArgs& A, const unsigned long long* topk, int* tent,
                          unsigned long long* need, int* matchedL, int* matchedR, int* matches, int* out) {
     (void)tent; (void)need;
-    const size_t sh = (size_t)(2 * (A.n[0] + A.n[1]) + 2 * PROJ_SUPER) * sizeof(int) + 32 + (size_t)PROJ_SUPER * 16 * sizeof(unsigned long long);
+    const size_t sh = (size_t)(3 * (A.n[0] + A.n[1]) + 2 * PROJ_SUPER) * sizeof(int) + 32 + (size_t)PROJ_SUPER * 16 * sizeof(unsigned long long);
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)k_proj_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(256), sh, s, A, topk, matchedL, matchedR, matches, out);
