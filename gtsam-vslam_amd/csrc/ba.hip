@@ -943,6 +943,127 @@ __global__ __launch_bounds__(64 * BA_MFMA_NW) void k_ba_solve_mfma(BaDev D, doub
     if (tid == 0) D.flags[0] = fail ? 1 : 0;
 }
 
+// The 10-keyframe window (6F <= 64) on ONE wave with the same MFMA scheme: the 10 lower tiles of the 64 x 64 system
+// stay in accumulators, the panel / L live in LDS, no workgroup barrier anywhere (wave-ordered LDS traffic only).
+__global__ __launch_bounds__(64) void k_ba_solve_mfma64(BaDev D) {
+    constexpr int N = 64, LDF = 65, LD = 17;
+    __shared__ double Lf[N * LDF];                    // staged system (upper triangle valid), then L (lower)
+    __shared__ double P[N * LD];                      // current panel
+    __shared__ double sInv[16], sB[N];
+    if (!ba_enter(D, BA_TRY)) return;
+    const double lambda = D.ctl[CTL_LAMBDA];
+    const int n = D.n, lane = threadIdx.x;
+    auto fence = []() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+    for (int row = 0; row < n; row++)
+        if (lane < n) Lf[row * LDF + lane] = D.S[(size_t)row * n + lane];
+    sB[lane] = lane < n ? D.rhs[lane] : 0.0;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    ba_d4 acc[10];
+#pragma unroll
+    for (int ib = 0; ib < 4; ib++)
+#pragma unroll
+        for (int jb = 0; jb <= ib; jb++) {
+            const int s = ib * (ib + 1) / 2 + jb;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = ib * 16 + (lane >> 4) + 4 * r, col = jb * 16 + (lane & 15);
+                double v = (row == col) ? 1.0 : 0.0;
+                if (row < n && col < n) v = (row >= col ? Lf[col * LDF + row] : Lf[row * LDF + col]) + ((row == col) ? lambda : 0.0);
+                acc[s][r] = v;
+            }
+        }
+    fence();
+    bool bad = false;
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++) {
+#pragma unroll
+        for (int ib = kb; ib < 4; ib++) {
+            const int s = ib * (ib + 1) / 2 + kb;
+#pragma unroll
+            for (int r = 0; r < 4; r++) P[(ib * 16 + (lane >> 4) + 4 * r) * LD + (lane & 15)] = acc[s][r];
+        }
+        fence();
+        {
+            const int r = lane & 15;
+            double a[16];
+#pragma unroll
+            for (int c = 0; c < 16; c++) a[c] = P[(kb * 16 + r) * LD + c];
+            double idg = 1.0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                double d = readlane_d(a[k], k);
+                if (!(d > 0)) { bad = true; d = 1.0; }
+                const double id = rsqrt(d);
+                const double lk = (r == k) ? d * id : a[k] * id;
+                if (r == k) idg = id;
+                a[k] = lk;
+#pragma unroll
+                for (int j = k + 1; j < 16; j++) a[j] = __builtin_fma(-lk, readlane_d(lk, j), a[j]);
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int c = 0; c < 16; c++) { P[(kb * 16 + r) * LD + c] = a[c]; Lf[(kb * 16 + r) * LDF + kb * 16 + c] = c <= r ? a[c] : 0.0; }
+                sInv[r] = idg;
+            }
+        }
+        fence();
+        {
+            const int row = (kb + 1) * 16 + lane;
+            if (row < N) {
+                double x[16];
+#pragma unroll
+                for (int c = 0; c < 16; c++) {
+                    double v = P[row * LD + c];
+#pragma unroll
+                    for (int m = 0; m < c; m++) v = __builtin_fma(-x[m], P[(kb * 16 + c) * LD + m], v);
+                    x[c] = v * sInv[c];
+                }
+#pragma unroll
+                for (int c = 0; c < 16; c++) { P[row * LD + c] = x[c]; Lf[row * LDF + kb * 16 + c] = x[c]; }
+            }
+        }
+        fence();
+#pragma unroll
+        for (int ib = kb + 1; ib < 4; ib++)
+#pragma unroll
+            for (int jb = kb + 1; jb <= ib; jb++) {
+                const int s = ib * (ib + 1) / 2 + jb;
+                const double* pa = P + (ib * 16 + (lane & 15)) * LD + (lane >> 4);
+                const double* pb = P + (jb * 16 + (lane & 15)) * LD + (lane >> 4);
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * ks], pb[4 * ks], acc[s], 0, 0, 0);
+            }
+        fence();
+    }
+    if (!bad) {
+        // L y = b, L^T x = y: lane = row, columns in order; 1 / L[k][k] sits in lane k's register (readlane), the
+        // multipliers of a column are one LDS read per lane, prefetched a few columns ahead by the unrolling
+        const double inv = 1.0 / Lf[lane * LDF + lane];
+        double b = sB[lane];
+#pragma unroll 8
+        for (int k = 0; k < N; k++) {
+            const double lik = Lf[lane * LDF + k];
+            const double yk = readlane_d(b, k) * readlane_d(inv, k);
+            if (lane == k) b = yk; else if (lane > k) b = __builtin_fma(-lik, yk, b);
+        }
+#pragma unroll 8
+        for (int k = N - 1; k >= 0; k--) {
+            const double lki = Lf[k * LDF + lane];
+            const double xk = readlane_d(b, k) * readlane_d(inv, k);
+            if (lane == k) b = xk; else if (lane < k) b = __builtin_fma(-lki, xk, b);
+        }
+        if (lane < n) D.dP[lane] = b;
+        sB[lane] = b;
+        fence();
+        for (int k = lane; k < D.K; k += 64) {
+            const int fi = D.fidx[k];
+            if (fi >= 0) { DPose T; pose_retract(D.poseCur[k], sB + 6 * fi, T); D.poseTrial[k] = T; }
+            else D.poseTrial[k] = D.poseCur[k];
+        }
+    }
+    if (lane == 0) D.flags[0] = bad ? 1 : 0;
+}
+
 // back-substitution: dl = Hll^-1 (bl - sum_k W_k^T dp_k); trial landmark = cur + dl
 __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_back(BaDev D, int maxSlots) {
     extern __shared__ double sm[];
@@ -1379,7 +1500,8 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
             t = g_baTimer.begin("ba_solve");
             if (n > 0) hipLaunchKernelGGL(k_ba_reduce, dim3(((int)sysDoubles + 255) / 256, ldsS ? 8 : 1), dim3(256), 0, stream, D, ldsS ? lmBlocks : 0);   // + BetweenFactor blocks
             if (comm && n > 0) { const int tc = g_baTimer.begin("ba_allreduce"); VS_CHECK(comm_allreduce(comm, d_S.p, (size_t)n * n + n, stream)); g_baTimer.end(tc); }
-            if (n <= BA_WAVE_N) hipLaunchKernelGGL(k_ba_solve_wave, dim3(1), dim3(64), 0, stream, D);
+            if (n <= 64 && useMfma) hipLaunchKernelGGL(k_ba_solve_mfma64, dim3(1), dim3(64), 0, stream, D);
+            else if (n <= BA_WAVE_N) hipLaunchKernelGGL(k_ba_solve_wave, dim3(1), dim3(64), 0, stream, D);
             else if (n <= BA_MFMA_N && useMfma) hipLaunchKernelGGL(k_ba_solve_mfma, dim3(1), dim3(64 * BA_MFMA_NW), mfmaLds, stream, D, d_Lg.p);
             else hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(std::max(64, vslam::align_up(n, 64))),
                                     solveLds ? solveLdsBytes : 64, stream, D, solveLds ? 1 : 0, solveLds ? ldA : n);
