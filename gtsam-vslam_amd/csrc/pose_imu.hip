@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256) void k_imu_preintegrate(DImuParams P, const do
 }
 
 struct ImuLmArgs {
+    int ldsFactors;          // capacity (factors) of the dynamic LDS buffer
     const DPim* pim; const double* Lam; DImuParams P;
     DNav si;                 // x0, v0
     double biasPrev[6];      // b0
@@ -149,10 +150,13 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I
     __shared__ double sJ[225], sLJ[225], sH[225], sLam[225], sR15[15], sLr[15], sG[15], sDelta[15], sRp[6], sJp[36];
     __shared__ double sError, sLambda, sNewErr, sCurErr, sLin, sNV;
     __shared__ int sPhase, sEval, sIter, sInner, sCnt[2];
+    extern __shared__ double sFacLds[];
     const int tid = threadIdx.x;
     if (A.gate && *A.gate < A.gateMin) return;
     if (A.Mdev) A.M = min(A.M, *A.Mdev);
     const int M = A.M;
+    if (I.ldsFactors >= M) A.factors = sFacLds;      // the factor list is read 6+ times: keep it in LDS when it fits
+    constexpr int VNT = POSE_NT - 64;                // waves 0..2 evaluate vision factors, wave 3 the IMU / prior algebra
 #ifdef VSLAM_POSE_STAMPS
     long long ps_t = clock64();
 #endif
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I
 
     auto vision_error = [&](const DPose& T) {
         double e = 0;
-        for (int i = tid; i < M; i += POSE_NT) {
+        for (int i = tid; i < M && tid < VNT; i += VNT) {
             const double* f = A.factors + (size_t)i * 8;
             if (f[0] < 0) continue;
             double r[3];
@@ -185,10 +189,11 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I
     };
 
     {
+        if (tid == VNT) sNV = nonvision_error(sT, sV, sB);        // wave 3, under the vision pass of waves 0..2
         double v1[1] = {vision_error(sT)};
         block_reduce<1>(v1, red, acc);
         if (tid == 0) {
-            sError = 0.5 * (acc[0] + nonvision_error(sT, sV, sB));
+            sError = 0.5 * (acc[0] + sNV);
             A.poseIO[16] = sError;
             sCurErr = sError;
             sPhase = (!(sError <= 0.0) && sIter < A.maxIterations) ? 0 : 2;
@@ -205,7 +210,8 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I
 #pragma unroll
             for (int k = 0; k < 28; k++) v[k] = 0;
             const DPose T = sT;
-            for (int i = tid; i < M; i += POSE_NT) {
+            if (tid == VNT) imu_lin_serial(&sPred, I.pim->biasHat, &sT, sV, sB, &sPT, sR15, sJ, sRp, sJp);   // wave 3, concurrently
+            for (int i = tid; i < M && tid < VNT; i += VNT) {
                 const double* f = A.factors + (size_t)i * 8;
                 if (f[0] < 0) continue;
                 double r[3], J[3][6];
@@ -223,11 +229,7 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I
             }
             block_reduce<28>(v, red, acc);
             PS_ACC(2);
-            if (tid == 0) {
-                imu_lin_serial(&sPred, I.pim->biasHat, &sT, sV, sB, &sPT, sR15, sJ, sRp, sJp);
-            }
             PS_ACC(3);
-            __syncthreads();
             if (tid < 225) {
                 const int i = tid / 15, c = tid % 15;
                 double s = 0;
@@ -279,7 +281,6 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I
                         pose_retract_serial(&sT, sDelta, &sT2);
                         for (int i = 0; i < 3; i++) sV2[i] = sV[i] + sDelta[6 + i];
                         for (int i = 0; i < 6; i++) sB2[i] = sB[i] + sDelta[9 + i];
-                        sNV = nonvision_error(sT2, sV2, sB2);
                         sEval = 1;
                     }
                 }
@@ -288,6 +289,7 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I
         PS_ACC(6);
         __syncthreads();
         if (sEval) {
+            if (tid == VNT) sNV = nonvision_error(sT2, sV2, sB2);       // wave 3, under the vision pass
             double v1[1] = {vision_error(sT2)};
             block_reduce<1>(v1, red, acc);
             if (tid == 0) sNewErr = 0.5 * (acc[0] + sNV);
@@ -435,7 +437,13 @@ vslam_status vslam_matcher::pose_imu_enqueue(int M, const int* Mdev, const int* 
 #ifdef VSLAM_POSE_STAMPS
     { long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ps), z, sizeof(z)); }
 #endif
-    hipLaunchKernelGGL(k_pose_imu_lm, dim3(1), dim3(POSE_NT), 0, stream, A, I);
+    // dynamic LDS: the factor list (8 doubles per map point) when it fits next to the kernel's static 10 KB
+    const int ldsCap = 17000;                       // factors: 136 KB
+    I.ldsFactors = M <= ldsCap ? M : 0;
+    const size_t lds = (size_t)I.ldsFactors * 8 * sizeof(double);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_pose_imu_lm, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); attr = true; }
+    hipLaunchKernelGGL(k_pose_imu_lm, dim3(1), dim3(POSE_NT), lds, stream, A, I);
     timer.end(t);
 #ifdef VSLAM_POSE_STAMPS
     {
