@@ -172,3 +172,68 @@ def test_track_frame_imu_parity(oracle, capi):
     assert np.abs(vel - ref["vel"]).max() < 1e-8 and np.abs(bias - ref["bias"]).max() < 1e-9
     assert np.array_equal(mt, ref["matches"]) and np.array_equal(outl, ref["outliers"])
     assert np.abs(rigid_inv(T_cw) - Tb).max() < 0.05
+
+
+def test_pipelined_two_extractor_pairs_match_serial(capi):
+    """Frame-level pipelining: extraction of frame n+1 on its own thread / extractor pair while
+    frame n is matched and tracked, ordered only by HIP events (no host sync in run / stereo_match / init_map).
+    Every per-frame result must be bit-identical to the serial single-extractor run."""
+    import threading, queue
+    rig = synth.RIGS["euroc"]
+    w, h = rig["w"], rig["h"]
+    frames = [synth.stereo_frame(f) for f in range(3, 9)]
+    preds = [synth.pose_at(f - 0.3) for f in range(3, 9)]
+    NREP = 3                                           # replay the sequence a few times to give races a chance
+
+    def track(m, fe, i):
+        m.stereo_match()
+        out = None
+        if i > 0:
+            T, rep = capi.tracker_track(m, preds[i], 5)
+            mt, outl, act = capi.tracker_fetch(m)
+            out = (T.copy(), rep["n_inliers"], rep["n_stereo"], rep["lm_iterations"], mt.copy(), outl.copy())
+        capi.tracker_init_map(m, frames[i][2])
+        return out
+
+    # serial reference
+    fe = capi.Extractor(w, h, 1500, batch=2)
+    m = capi.Matcher(rig, fe, 0, fe, 1)
+    ref = []
+    for n in range(NREP * len(frames)):
+        i = n % len(frames)
+        fe.set_image(0, frames[i][0]); fe.set_image(1, frames[i][1])
+        fe.run()
+        ref.append(track(m, fe, i))
+    # pipelined
+    fes = [capi.Extractor(w, h, 1500, batch=2) for _ in range(2)]
+    mp = capi.Matcher(rig, fes[0], 0, fes[0], 1)
+    free = threading.Semaphore(2)
+    ready = queue.Queue()
+    total = NREP * len(frames)
+
+    def extract_worker():
+        for n in range(total):
+            free.acquire()
+            i = n % len(frames)
+            f = fes[n % 2]
+            f.set_image(0, frames[i][0]); f.set_image(1, frames[i][1])
+            f.run()
+            ready.put(n)
+
+    th = threading.Thread(target=extract_worker, daemon=True)
+    th.start()
+    got = []
+    for _ in range(total):
+        n = ready.get(timeout=60)
+        f = fes[n % 2]
+        mp.bind_extractors(f, 0, f, 1)
+        got.append(track(mp, f, n % len(frames)))
+        free.release()
+    th.join(timeout=60)
+    assert all(f.ssc_stats() == (1, 0) for f in fes)
+    for a, b in zip(ref, got):
+        assert (a is None) == (b is None)
+        if a is None:
+            continue
+        assert np.array_equal(a[0], b[0]) and a[1:4] == b[1:4]
+        assert np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
