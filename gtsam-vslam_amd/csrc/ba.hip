@@ -1,24 +1,27 @@
 // Local bundle adjustment on gfx950 (K11/K12): numerical core of LocalMapper::localBA
 // (reference src/OptimizationBA.cpp:543-873, setOrdering :942-953, checkOutlier(R) :393-424).
 //
-// Per LM linearisation / lambda trial:
-//   k_ba_linearize   obs-parallel: whitened residual, 2x6 pose and 2x3 landmark Jacobian blocks of
-//                    every GenericProjectionFactor (left, or right with the stereo extrinsics), stored
-//                    as 20 doubles per observation; cost by fixed-tree block reduction.
-//   k_ba_edges       BetweenFactor<Pose3> chain (Logmap residual, LogmapDerivative / Adjoint Jacobians).
-//   k_ba_schur       landmark-parallel, one 64-lane wave per landmark: Hll (+lambda I) inverse by
+// Per LM step (one linearisation if due + one lambda trial); every kernel first checks the device-side LM state:
+//   k_ba_factors<0>  ONE launch: obs-parallel whitened residual, 2x6 pose and 2x3 landmark Jacobian blocks of every
+//                    GenericProjectionFactor (left, or right with the stereo extrinsics), stored as 20 doubles per
+//                    observation; one workgroup per BetweenFactor<Pose3> edge (Logmap residual, LogmapDerivative /
+//                    Adjoint Jacobians, 6x6 products); last-workgroup deterministic cost reduction; LM control.
+//   k_ba_schur       landmark-parallel, one 64-lane wave per landmark, 16 per workgroup: Hll (+lambda I) inverse by
 //                    cofactors, W = Hpl blocks staged in LDS, S -= W Hll^-1 W^T and rhs -= W Hll^-1 bl
 //                    accumulated in a workgroup-private copy of the reduced camera system in LDS
 //                    (6F x 6F doubles, F = free keyframes) and flushed once per workgroup; when that
 //                    copy exceeds LDS (F > 20) the same updates go to HBM with fp64 atomics.
-//   k_ba_solve       one workgroup: sums the partial systems (this is where the RCCL all-reduce of the
-//                    landmark-sharded multi-GPU path plugs in), adds the BetweenFactor blocks and the
-//                    damping, dense Cholesky + substitutions, retracts the trial poses.
+//   k_ba_reduce      sums the partial systems (the buffer the landmark-sharded multi-GPU path all-reduces over RCCL).
+//   k_ba_solve_*     reduced camera system + damping, Cholesky + substitutions, trial poses: one wave with the 10
+//                    16x16 tiles in MFMA accumulators (6F <= 64), eight waves with 136 tiles (6F <= 256), LDS / L2
+//                    row-per-thread beyond.
 //   k_ba_back        landmark-parallel back-substitution, trial landmark positions.
-//   k_ba_eval        obs-parallel: linearised cost at delta (GTSAM's linear.error(delta)) and the
-//                    nonlinear cost at the trial values.
-// The LM policy (GTSAM 4.2) runs on the host between launches; both passes
-// (5 then 10 iterations) start from the caller's values, separated by the chi2 re-check kernel.
+//   k_ba_factors<1>  linearised cost at delta (GTSAM's linear.error(delta)), nonlinear cost at the trial values,
+//                    reduction, and the LM decision (accept / reject, lambda, convergence) - k_ba_ctl when the sums
+//                    are all-reduced first.
+// The LM policy (GTSAM 4.2) runs on the DEVICE (control block `ctl`); the host enqueues speculative
+// steps and reads the block back to learn that a pass is done.  Both passes (5 then 10 iterations) start from the
+// caller's values, separated by the chi2 re-check kernel.
 #include "common.hpp"
 #include "comm.hpp"
 #include "dmath.hpp"

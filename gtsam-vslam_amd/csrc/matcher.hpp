@@ -52,8 +52,6 @@ struct vslam_matcher {
     vslam_mappoint_view* d_mpv = nullptr;
     unsigned long long* d_topk = nullptr;   // [M][2][PROJ_K] sorted candidate keys
     int* d_matches = nullptr;    // [M][2]
-    int* d_tent = nullptr;       // [M] precomputed decision
-    unsigned long long* d_need = nullptr;   // [M] the four keypoints that decision depends on
     int* d_matchedL = nullptr;   // [cap]
     int* d_matchedR = nullptr;
     int* d_projOut = nullptr;    // {nMatches}
@@ -149,6 +147,6 @@ struct ProjArgs {
 enum { PROJ_STEREO = 0, PROJ_MONO = 1, PROJ_RADIUS = 2 };
 void launch_proj_candidates(hipStream_t s, const ProjArgs& A, const int* matches,
                             unsigned long long* topk, unsigned long long* stats);
-void launch_proj_resolve(hipStream_t s, const ProjArgs& A, const unsigned long long* topk, int* tent,
-                         unsigned long long* need, int* matchedL, int* matchedR, int* matches, int* out);
+void launch_proj_resolve(hipStream_t s, const ProjArgs& A, const unsigned long long* topk, int* matchedL, int* matchedR,
+                         int* matches, int* out);
 }  // namespace vslam

@@ -281,9 +281,8 @@ __global__ __launch_bounds__(256) void k_proj_resolve(ProjArgs A, const unsigned
     if (tid == 0) outp[0] = nMatches;
 }
 
-void launch_proj_resolve(hipStream_t s, const ProjArgs& A, const unsigned long long* topk, int* tent,
-                         unsigned long long* need, int* matchedL, int* matchedR, int* matches, int* out) {
-    (void)tent; (void)need;
+void launch_proj_resolve(hipStream_t s, const ProjArgs& A, const unsigned long long* topk, int* matchedL, int* matchedR,
+                         int* matches, int* out) {
     const size_t sh = (size_t)(3 * (A.n[0] + A.n[1]) + 2 * PROJ_SUPER) * sizeof(int) + 32 + (size_t)PROJ_SUPER * 16 * sizeof(unsigned long long);
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)k_proj_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
@@ -297,13 +296,11 @@ using namespace vslam;
 vslam_status vslam_matcher::ensure_proj_cap(int M) {
     if (M <= projCap && d_matchedL && d_projOut) return VSLAM_OK;
     if (M > projCap) {
-        hipFree(d_mpv); hipFree(d_topk); hipFree(d_matches); hipFree(d_tent); hipFree(d_need);
+        hipFree(d_mpv); hipFree(d_topk); hipFree(d_matches);
         projCap = vslam::align_up(std::max(M, 1), 1024);
         VS_HIP(hipMalloc(&d_mpv, (size_t)projCap * sizeof(vslam_mappoint_view)));
         VS_HIP(hipMalloc(&d_topk, (size_t)projCap * 2 * PROJ_K * sizeof(unsigned long long)));
         VS_HIP(hipMalloc(&d_matches, (size_t)projCap * 2 * sizeof(int)));
-        VS_HIP(hipMalloc(&d_tent, (size_t)projCap * sizeof(int)));
-        VS_HIP(hipMalloc(&d_need, (size_t)projCap * sizeof(unsigned long long)));
     }
     if (!d_projOut) VS_HIP(hipMalloc(&d_projOut, 4 * sizeof(int)));
     if (!d_matchedL) {
@@ -331,11 +328,8 @@ vslam_status vslam_matcher::proj_enqueue(int M, float rad, const int* Mdev, cons
     launch_proj_candidates(stream, A, d_matches, d_topk, d_stats);
     timer.end(t);
     t = timer.begin("proj_resolve");
-    launch_proj_resolve(stream, A, d_topk, d_tent, d_need, d_matchedL, d_matchedR, d_matches, d_projOut);
+    launch_proj_resolve(stream, A, d_topk, d_matchedL, d_matchedR, d_matches, d_projOut);
     timer.end(t);
-#ifdef VSLAM_PROJ_STAMPS
-    { int o[4]; hipStreamSynchronize(stream); hipMemcpy(o, d_projOut, sizeof(o), hipMemcpyDeviceToHost); fprintf(stderr, "proj_resolve M=%d rad=%.0f: loop cycles %d  batch chunks %d  serial chunks %d\n", M, rad, o[1], o[2], o[3]); }
-#endif
     VS_HIP(hipGetLastError());
     return VSLAM_OK;
 }
