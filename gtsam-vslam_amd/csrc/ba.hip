@@ -29,6 +29,11 @@
 #include <cmath>
 #include <numeric>
 #include <vector>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 
 namespace vslam {
 
@@ -1203,9 +1208,61 @@ struct PinnedArena {
     template <class T> T* dev(T* hostPtr) const { return (T*)(d + ((uint8_t*)hostPtr - h)); }
     hipError_t upload(hipStream_t s) const { return hipMemcpyAsync(d, h, used, hipMemcpyHostToDevice, s); }
 };
+// Small persistent worker pool of the optimizer thread's host-side preparation (ordering ~34 k factors by landmark /
+// keyframe and writing the upload arena is 0.35 ms on one core; the landmark ranges are independent).
+struct BaPool {
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cvStart, cvDone;
+    std::function<void(int)> job;
+    std::atomic<int> next{0};
+    int nTasks = 0, finished = 0;
+    std::atomic<int> generation{0};
+    bool stop = false;
+    void start(int n) {
+        for (int t = 0; t < n; t++)
+            workers.emplace_back([this]() {
+                int seen = 0;
+                for (;;) {
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cvStart.wait(lk, [&] { return stop || generation.load() != seen; });
+                        if (stop) return;
+                        seen = generation.load();
+                    }
+                    work();
+                }
+            });
+    }
+    void work() {
+        for (;;) {
+            const int t = next.fetch_add(1);
+            if (t >= nTasks) break;
+            job(t);
+            std::lock_guard<std::mutex> lk(mu);
+            if (++finished == nTasks) cvDone.notify_all();
+        }
+    }
+    void run(int n, std::function<void(int)> f) {
+        if (workers.empty() || n <= 1) { for (int t = 0; t < n; t++) f(t); return; }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            job = std::move(f); nTasks = n; finished = 0; next = 0; generation++;
+        }
+        cvStart.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(mu);
+        cvDone.wait(lk, [&] { return finished == nTasks; });
+    }
+    ~BaPool() {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cvStart.notify_all();
+        for (auto& w : workers) w.join();
+    }
+};
 struct BaHostTmp {
     std::vector<uint8_t> kfPresent, lmPresent;
-    std::vector<int> cnt, fidx, lpOf, order, fill, key, src;
+    std::vector<int> cnt, fidx, lpOf, order, fill, key, src, ns;
 };
 
 struct HostFac { int pair, kf, lm, fi, lp; bool right; double z[2], is; };
@@ -1218,8 +1275,10 @@ struct HostFac { int pair, kf, lm, fi, lp; bool right; double z[2], is; };
 #include <chrono>
 static double bhs_now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 #define BHS(name) do { hipStreamSynchronize(stream); const double t_ = bhs_now(); fprintf(stderr, "  ba host: %-12s %8.1f us\n", name, t_ - bhs_t); bhs_t = t_; } while (0)
+#define BHS2(name) do { const double t_ = bhs_now(); fprintf(stderr, "     prep: %-12s %8.1f us\n", name, t_ - bhs_t2); bhs_t2 = t_; } while (0)
 #else
 #define BHS(name) do {} while (0)
+#define BHS2(name) do {} while (0)
 #endif
 
 static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int device, const vslam_comm* comm) {
@@ -1254,6 +1313,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         DevBuf<float> d_pairUv;
         PinnedArena arena;
         BaHostTmp tmp;
+        BaPool pool;
         double* h_ctlOut = nullptr;
         uint8_t* h_wrong = nullptr; size_t wrongCap = 0;
     };
@@ -1262,6 +1322,11 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         ws = new Workspace(); ws->device = device;
         VS_HIP(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));
         VS_HIP(hipHostMalloc((void**)&ws->h_ctlOut, CTL_DOUBLES * sizeof(double), hipHostMallocDefault));
+        {
+            int nt = 3;      // + the calling thread; VSLAM_BA_HOST_THREADS overrides (0 = none)
+            if (const char* e = getenv("VSLAM_BA_HOST_THREADS")) nt = std::max(0, std::min(15, atoi(e)));
+            ws->pool.start(nt);
+        }
     }
     if ((size_t)P->n_pairs > ws->wrongCap) {
         if (ws->h_wrong) hipHostFree(ws->h_wrong);
@@ -1313,6 +1378,9 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
     for (int pass = 0; pass < 2; pass++) {
         // ---- host: factor list of this pass, ordered by (landmark, free index, pair, side) -----------
         // Everything the kernels read is written straight into ONE pinned arena and uploaded with one copy.
+#ifdef VSLAM_HOST_STAMPS
+        double bhs_t2 = bhs_now();
+#endif
         T.kfPresent.assign(K, 0); T.lmPresent.assign(L, 0); T.cnt.assign((size_t)L + 1, 0);
         int NF = 0;
         for (int p = 0; p < NP; p++) {
@@ -1325,6 +1393,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
             const int c = (fl & 1) + (fl >> 1);
             T.cnt[l] += c; NF += c;
         }
+        BHS2("count");
         T.fidx.assign(K, -1);
         int F = 0;
         for (int k = 0; k < K; k++) if (T.kfPresent[k] && !P->kf_fixed[k]) T.fidx[k] = F++;
@@ -1360,6 +1429,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
             for (int lp = 0; lp < Lp; lp++) { h_lpStart[lp] = run; run += T.cnt[h_lpOrig[lp]]; }
             h_lpStart[Lp] = run;
         }
+        BHS2("arena");
         T.fill.assign(h_lpStart, h_lpStart + Lp);
         T.key.resize(NF); T.src.resize(NF);
         for (int p = 0; p < NP; p++) {
@@ -1374,34 +1444,58 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
                 T.key[pos] = fi; T.src[pos] = 2 * p + side;
             }
         }
+        BHS2("scatter");
+        // landmark ranges in parallel: (1) order each bucket by free index and count its slots, (2) after the slot prefix,
+        // write the factor arrays and the slot table.
+        // Slot table: inside a landmark the factors of fixed keyframes (fi = -1) come first, then one
+        // "slot" per free keyframe (its left and/or right factor).  Padded layout: per landmark the slot
+        // starts followed by an end sentinel, so slot s spans [slotStart[s0+s], slotStart[s0+s+1]).
+        T.ns.resize(Lp);
+        const int nChunk = std::max(1, std::min(32, Lp / 64));
+        auto chunk = [&](int c, int& a0, int& a1) { a0 = (int)((long long)Lp * c / nChunk); a1 = (int)((long long)Lp * (c + 1) / nChunk); };
+        ws->pool.run(nChunk, [&](int c) {
+            int a0, a1;
+            chunk(c, a0, a1);
+            for (int lp = a0; lp < a1; lp++) {
+                const int f0 = h_lpStart[lp], f1 = h_lpStart[lp + 1];
+                for (int i = f0 + 1; i < f1; i++) {          // stable insertion sort by free index (buckets are ~10 long)
+                    const int k = T.key[i], v = T.src[i];
+                    int j = i - 1;
+                    while (j >= f0 && T.key[j] > k) { T.key[j + 1] = T.key[j]; T.src[j + 1] = T.src[j]; j--; }
+                    T.key[j + 1] = k; T.src[j + 1] = v;
+                }
+                int lastFi = -2, ns = 0;
+                for (int f = f0; f < f1; f++) { const int fi = T.key[f]; if (fi >= 0 && fi != lastFi) { lastFi = fi; ns++; } }
+                T.ns[lp] = ns;
+            }
+        });
         int maxSlots = 1, nSlotEntries = 0;
         long long sumK2 = 0;
         for (int lp = 0; lp < Lp; lp++) {
-            const int f0 = h_lpStart[lp], f1 = h_lpStart[lp + 1];
-            for (int i = f0 + 1; i < f1; i++) {          // stable insertion sort by free index (buckets are ~10 long)
-                const int k = T.key[i], v = T.src[i];
-                int j = i - 1;
-                while (j >= f0 && T.key[j] > k) { T.key[j + 1] = T.key[j]; T.src[j + 1] = T.src[j]; j--; }
-                T.key[j + 1] = k; T.src[j + 1] = v;
-            }
-            // Slot table: inside a landmark the factors of fixed keyframes (fi = -1) come first, then one
-            // "slot" per free keyframe (its left and/or right factor).  Padded layout: per landmark the slot
-            // starts followed by an end sentinel, so slot s spans [slotStart[s0+s], slotStart[s0+s+1]).
             h_lpSlotStart[lp] = nSlotEntries;
-            int lastFi = -2, ns = 0;
-            for (int f = f0; f < f1; f++) {
-                const int fi = T.key[f], p = T.src[f] >> 1, side = T.src[f] & 1;
-                if (fi >= 0 && fi != lastFi) { h_slotStart[nSlotEntries] = f; h_slotFi[nSlotEntries] = fi; nSlotEntries++; lastFi = fi; ns++; }
-                h_facKf[f] = P->pair_kf[p]; h_facFi[f] = fi; h_facLp[f] = lp; h_facLm[f] = P->pair_lm[p];
-                h_facZ[2 * (size_t)f] = P->pair_uv[4 * (size_t)p + 2 * side]; h_facZ[2 * (size_t)f + 1] = P->pair_uv[4 * (size_t)p + 2 * side + 1];
-                h_facIs[f] = 1.0 / (1.0 / (double)P->inv_sigma_factor[P->pair_octave[2 * p + side]]);
-                h_facRight[f] = (uint8_t)side;
-            }
-            h_slotStart[nSlotEntries] = f1; h_slotFi[nSlotEntries] = -1; nSlotEntries++;     // end sentinel
-            maxSlots = std::max(maxSlots, ns);
-            sumK2 += (long long)ns * ns;
+            nSlotEntries += T.ns[lp] + 1;
+            maxSlots = std::max(maxSlots, T.ns[lp]);
+            sumK2 += (long long)T.ns[lp] * T.ns[lp];
         }
+        ws->pool.run(nChunk, [&](int c) {
+            int a0, a1;
+            chunk(c, a0, a1);
+            for (int lp = a0; lp < a1; lp++) {
+                const int f0 = h_lpStart[lp], f1 = h_lpStart[lp + 1];
+                int se = h_lpSlotStart[lp], lastFi = -2;
+                for (int f = f0; f < f1; f++) {
+                    const int fi = T.key[f], p = T.src[f] >> 1, side = T.src[f] & 1;
+                    if (fi >= 0 && fi != lastFi) { h_slotStart[se] = f; h_slotFi[se] = fi; se++; lastFi = fi; }
+                    h_facKf[f] = P->pair_kf[p]; h_facFi[f] = fi; h_facLp[f] = lp; h_facLm[f] = P->pair_lm[p];
+                    h_facZ[2 * (size_t)f] = P->pair_uv[4 * (size_t)p + 2 * side]; h_facZ[2 * (size_t)f + 1] = P->pair_uv[4 * (size_t)p + 2 * side + 1];
+                    h_facIs[f] = 1.0 / (1.0 / (double)P->inv_sigma_factor[P->pair_octave[2 * p + side]]);
+                    h_facRight[f] = (uint8_t)side;
+                }
+                h_slotStart[se] = f1; h_slotFi[se] = -1;     // end sentinel
+            }
+        });
         h_lpSlotStart[Lp] = nSlotEntries;
+        BHS2("sort+emit");
         for (int k = 0; k < K; k++) { h_fidx[k] = T.fidx[k]; h_kfPresent[k] = T.kfPresent[k]; }
         for (int l = 0; l < L; l++) h_lmPresent[l] = T.lmPresent[l];
         for (int i = 0; i < NE; i++) {
