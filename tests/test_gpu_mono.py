@@ -205,3 +205,27 @@ def test_track_mono_imu_parity(oracle, capi):
     assert np.array_equal(mt, ref["matches"]) and np.array_equal(outl, ref["outliers"])
     assert np.abs(T_cw - ref["T_cw"]).max() < 1e-8
     assert np.abs(vel - ref["vel"]).max() < 1e-8 and np.abs(bias - ref["bias"]).max() < 1e-9
+
+
+def test_mono_and_new_point_entry_points_with_empty_inputs(oracle, capi):
+    """Edge cases: no map points, no last-keyframe keypoints, a window of one keyframe without keypoints."""
+    rig, oL, kL, dL, ge, m, _ = _mono_frontend(oracle, capi)
+    mL0 = np.full(len(kL), -1, np.int32)
+    n, mL, mt, nc = capi.match_projection_mono(m, np.zeros(0, oracle.MPV_DTYPE), 10.0, mL0, np.zeros((0, 2), np.int32))
+    assert n == 0 and np.array_equal(mL, mL0) and nc == 0
+    n, mL, out = capi.match_by_radius(m, np.zeros(0, kL.dtype), np.zeros((0, 32), np.uint8), 120.0, mL0)
+    assert n == 0 and len(out) == 0 and np.array_equal(mL, mL0)
+    kf = dict(T_wc=np.eye(4), id=0, kpsL=np.zeros(0, kL.dtype), descL=np.zeros((0, 32), np.uint8), kpsR=np.zeros(0, kL.dtype),
+              descR=np.zeros((0, 32), np.uint8), rightIdxs=np.zeros(0, np.int32), leftIdxs=np.zeros(0, np.int32),
+              unF=np.zeros(0, np.int32), unFR=np.zeros(0, np.int32))
+    last = dict(depth=np.zeros(0, np.float32), hasMp=np.zeros(0, np.uint8), mpXyz=np.zeros((0, 3)), mpDesc=np.zeros((0, 32), np.uint8))
+    r = capi.find_new_points(rig, oL.scalePyramid, oL.sigmaFactor, [kf], last)
+    assert r["n"] == 0
+    # a tracker with an empty map: no active points, the solve returns the IMU prediction, zero inliers
+    capi.tracker_set_map(m, np.zeros((0, 3)), np.zeros((0, 32), np.uint8), np.zeros(0, np.float32))
+    S, dts, _ = synth.imu_samples(3, 4, noise_seed=1)
+    T_prev = synth.pose_at(3)
+    T_cw, rep, vel, bias, T_pred, pv = capi.tracker_track_mono_imu(m, G, NOISE, synth.T_BC1, T_prev, [0.1, 0, 0], np.zeros(6), [0.1, 0, 0], 20.0,
+                                                                   S[:, :3], S[:, 3:], np.arange(len(dts)) * 5e6, 200)
+    assert rep["n_active"] == 0 and rep["n_inliers"] == 0 and np.isfinite(T_cw).all()
+    assert np.abs(np.linalg.inv(T_cw) - T_pred).max() < 1e-9
