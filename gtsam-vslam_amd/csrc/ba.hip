@@ -58,22 +58,52 @@ struct BaDev {
     int* flags;
     double fx, fy, cx, cy, b;
     double* ctl;      // device-side LM state (below)
+    // ---- lambda look-ahead + speculative linearisation (single GPU) --------------------------------------
+    // One "trial" launch evaluates NB candidates lambda, 10 lambda, 100 lambda ... at once (grid dimension y / z /
+    // x of the per-trial kernels); the control step then walks them in order exactly as the sequential policy
+    // would (the outcome of a rejected trial only changes lambda), so the result is bit-identical to NB = 1
+    // while a chain of rejections costs one round instead of NB.
+    // Values live in NB + 1 slots; slot `sel` is current, candidate c writes slot (sel + 1 + c) mod (NB + 1).
+    // With specLin every candidate also linearises at its trial values into its slot's facJ / edge buffers, so
+    // an accepted step needs no linearisation launch of its own.
+    int NB, specLin, cand;
+    double lambda;                       // set by ba_enter: damping of this workgroup's candidate
+    DPose* poseBase; double* lmBase; size_t lmStride;
+    double* facJBase; size_t facJStride; double* SedgeBase; BaEdge* edgesBase;
+    double* facJ2; double* Sedge2; BaEdge* edges2;            // set by ba_enter (slot of the candidate)
+    size_t sysStride, spartStride, partialStride, dLStride;
 };
 
-// The LM policy (GTSAM 4.2) runs on the DEVICE: a 1-thread control kernel after each linearisation / trial
-// updates this block, every other kernel starts by checking that it is its turn (state) and picks the
-// current / trial buffers by `sel`.  The host enqueues a few speculative steps at a time and only reads the
+// The LM policy (GTSAM 4.2) runs on the DEVICE: the control step after each linearisation / trial updates this
+// block, every other kernel starts by checking that it is its turn (state) and picks the current / trial
+// buffers by `sel`.  The host enqueues a few speculative steps at a time and only reads the
 // block back to learn whether the pass has finished - no host round trip per lambda trial.
 enum { CTL_LAMBDA = 0, CTL_ERROR = 1, CTL_CUR = 2, CTL_INIT_ERR = 3, CTL_INTS = 8, CTL_DOUBLES = 16 };
 enum { CI_STATE = 0, CI_SEL = 1, CI_ITER = 2, CI_INNER = 3, CI_MAXIT = 4, CI_FIRST = 5 };
 enum { BA_LINEARIZE = 0, BA_TRY = 1, BA_DONE = 2 };
-__device__ __forceinline__ bool ba_enter(BaDev& D, int state) {
+enum { BA_MAX_NB = 4, SUMS_CAND = 16, FLAG_COUNT = 1, FLAG_FAIL = 4 };   // sums[16 + 2c | 17 + 2c], flags[4 + c] per candidate
+__device__ __forceinline__ int ba_slot(int sel, int c, int NB) {
+    const int s = sel + 1 + c;
+    return s > NB ? s - (NB + 1) : s;
+}
+__device__ __forceinline__ bool ba_enter(BaDev& D, int state, int c = 0) {
     const int* ci = (const int*)(D.ctl + CTL_INTS);
     if (ci[CI_STATE] != state) return false;
-    if (ci[CI_SEL]) {
-        DPose* tp = D.poseCur; D.poseCur = D.poseTrial; D.poseTrial = tp;
-        double* tl = D.lmCur; D.lmCur = D.lmTrial; D.lmTrial = tl;
+    const int sel = ci[CI_SEL], ts = ba_slot(sel, c, D.NB);
+    D.cand = c;
+    D.poseCur = D.poseBase + (size_t)sel * D.K; D.poseTrial = D.poseBase + (size_t)ts * D.K;
+    D.lmCur = D.lmBase + (size_t)sel * D.lmStride; D.lmTrial = D.lmBase + (size_t)ts * D.lmStride;
+    if (D.specLin) {
+        const size_t se = (size_t)D.n * D.n + D.n;
+        D.facJ = D.facJBase + (size_t)sel * D.facJStride; D.facJ2 = D.facJBase + (size_t)ts * D.facJStride;
+        D.Sedge = D.SedgeBase + (size_t)sel * se; D.Sedge2 = D.SedgeBase + (size_t)ts * se;
+        D.edges = D.edgesBase + (size_t)sel * D.NE; D.edges2 = D.edgesBase + (size_t)ts * D.NE;
     }
+    D.S += (size_t)c * D.sysStride; D.rhs += (size_t)c * D.sysStride; D.Spart += (size_t)c * D.spartStride;
+    D.dP += (size_t)c * D.n; D.dL += (size_t)c * D.dLStride; D.partial += (size_t)c * D.partialStride;
+    double lam = D.ctl[CTL_LAMBDA];
+    for (int i = 0; i < c; i++) lam *= 10.0;       // the sequence the sequential policy would walk
+    D.lambda = lam;
     return true;
 }
 
@@ -129,6 +159,68 @@ __device__ __forceinline__ void ba_eval_edge(const BaEdge& e, const DPose& Ta, c
         }
 }
 
+// Linearisation of one BetweenFactor<Pose3> edge by one wave: lane 0 does the Lie-group algebra, 36 lanes the 6x6
+// products and the scatter into the edge accumulator Sacc (n x n | n, upper block triangle).  Static fields come
+// from E, the linearisation is stored in `out` (the same element, or its twin of the speculative buffers).
+// Returns sum r^2 on lane 0 (0 elsewhere).
+__device__ __forceinline__ double ba_edge_linearize(BaEdge& out, const BaEdge& E, const DPose& Ta, const DPose& Tb,
+                                                    double* sW, double* Sacc, int n, int lane) {
+    double* Hl = sW; double* Ad = Hl + 36; double* Ja = Ad + 36; double* Jb = Ja + 36; double* rr = Jb + 36;
+    const double w = 1.0 / 0.01;
+    const int fa = E.fa, fb = E.fb;
+    double v = 0;
+    if (lane == 0) {
+        DPose Tai, h, Mi, d, hi;
+        pose_inverse(Ta, Tai);
+        pose_compose(Tai, Tb, h);
+        pose_inverse(E.measured, Mi);
+        pose_compose(Mi, h, d);
+        double r[6];
+        pose3_logmap(d, r);
+        for (int i = 0; i < 6; i++) { r[i] *= w; rr[i] = r[i]; out.r[i] = r[i]; v += r[i] * r[i]; }
+        pose3_logmap_derivative(d, Hl);
+        pose_inverse(h, hi);
+        pose3_adjoint(hi, Ad);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int i = lane / 6, j = lane % 6;
+    if (lane < 36) {
+        double s = 0;
+        for (int k = 0; k < 6; k++) s += Hl[i * 6 + k] * Ad[k * 6 + j];
+        const double ja = -s * w, jb = Hl[i * 6 + j] * w;
+        Ja[lane] = ja; Jb[lane] = jb;
+        out.Ja[lane] = ja; out.Jb[lane] = jb;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane < 36) {
+        double aa = 0, ab = 0, bb = 0;
+        for (int k = 0; k < 6; k++) {
+            aa += Ja[k * 6 + i] * Ja[k * 6 + j];
+            ab += Ja[k * 6 + i] * Jb[k * 6 + j];
+            bb += Jb[k * 6 + i] * Jb[k * 6 + j];
+        }
+        out.Haa[lane] = aa; out.Hab[lane] = ab; out.Hbb[lane] = bb;
+        if (fa >= 0) atomicAdd(&Sacc[(size_t)(6 * fa + i) * n + 6 * fa + j], aa);
+        if (fb >= 0) atomicAdd(&Sacc[(size_t)(6 * fb + i) * n + 6 * fb + j], bb);
+        if (fa >= 0 && fb >= 0) {     // upper triangle only (the solve mirrors it)
+            if (fa < fb) atomicAdd(&Sacc[(size_t)(6 * fa + i) * n + 6 * fb + j], ab);
+            else atomicAdd(&Sacc[(size_t)(6 * fb + j) * n + 6 * fa + i], ab);
+        }
+    } else if (lane < 42) {
+        const int q = lane - 36;
+        double ga = 0, gb = 0;
+        for (int k = 0; k < 6; k++) { ga += Ja[k * 6 + q] * rr[k]; gb += Jb[k * 6 + q] * rr[k]; }
+        out.ga[q] = ga; out.gb[q] = gb;
+        if (fa >= 0) atomicAdd(&Sacc[(size_t)n * n + 6 * fa + q], -ga);
+        if (fb >= 0) atomicAdd(&Sacc[(size_t)n * n + 6 * fb + q], -gb);
+    }
+    return v;
+}
+
+// cross-workgroup hand-off of the cost partials without a fence (see k_ba_factors)
+__device__ __forceinline__ void ba_publish(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ba_collect(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // block-wide sum of NV doubles (fixed tree), result valid in out[] for every thread after return
 template <int NV, int NW>
 __device__ __forceinline__ void ba_block_sum(double (&v)[NV], double* red, double* out) {
@@ -167,40 +259,48 @@ __device__ __forceinline__ void ba_ctl(const BaDev& D, int mode, double relTol, 
         return;
     }
     if (ci[CI_STATE] != BA_TRY) return;
-    const double error = c[CTL_ERROR];
-    double lambda = c[CTL_LAMBDA];
-    bool stepOk = false, stop = false;
-    double newErr = INFINITY;
-    const double linChange = error - D.sums[1];
-    if (!D.flags[0] && linChange >= 0) {
-        newErr = D.sums[2];
-        const double costChange = error - newErr;
-        if (linChange > DBL_EPSILON * error) stepOk = (costChange / linChange) > 1e-3;
-        if (fabs(costChange) < relTol * error) stop = true;
+    // walk the candidates in the order the sequential policy would have tried them
+    for (int cand = 0; cand < D.NB; cand++) {
+        const double error = c[CTL_ERROR];
+        double lambda = c[CTL_LAMBDA];
+        bool stepOk = false, stop = false;
+        double newErr = INFINITY;
+        const double linChange = error - D.sums[SUMS_CAND + 2 * cand];
+        if (!D.flags[FLAG_FAIL + cand] && linChange >= 0) {
+            newErr = D.sums[SUMS_CAND + 2 * cand + 1];
+            const double costChange = error - newErr;
+            if (linChange > DBL_EPSILON * error) stepOk = (costChange / linChange) > 1e-3;
+            if (fabs(costChange) < relTol * error) stop = true;
+        }
+        bool endInner = false;
+        if (stepOk) {
+            ci[CI_SEL] = ba_slot(ci[CI_SEL], cand, D.NB);   // every present landmark / every pose is rewritten per trial
+            c[CTL_ERROR] = newErr;
+            lambda = lambda / 10.0;
+            c[CTL_LAMBDA] = lambda > 0.0 ? lambda : 0.0;
+            ci[CI_ITER]++; ci[CI_INNER]++;
+            endInner = true;
+        } else if (!stop) {
+            lambda *= 10.0;
+            c[CTL_LAMBDA] = lambda;
+            ci[CI_INNER]++;
+            if (lambda >= 1e5) endInner = true;
+        } else endInner = true;
+        if (!endInner) continue;                 // same linearisation, larger lambda: the next candidate
+        const double currentError = c[CTL_CUR], newError = c[CTL_ERROR];
+        bool converged;
+        if (newError <= 0.0) converged = true;
+        else {
+            const double absDec = currentError - newError, relDec = absDec / currentError;
+            converged = (relDec <= relTol) || (absDec <= absTol);
+        }
+        ci[CI_STATE] = (ci[CI_ITER] < ci[CI_MAXIT] && !converged && isfinite(currentError)) ? BA_LINEARIZE : BA_DONE;
+        if (D.specLin && ci[CI_STATE] == BA_LINEARIZE) {   // the trial just accepted was linearised speculatively
+            c[CTL_CUR] = c[CTL_ERROR];
+            ci[CI_STATE] = BA_TRY;
+        }
+        return;
     }
-    bool endInner = false;
-    if (stepOk) {
-        ci[CI_SEL] ^= 1;                    // every present landmark / every pose is rewritten per trial
-        c[CTL_ERROR] = newErr;
-        lambda = lambda / 10.0;
-        c[CTL_LAMBDA] = lambda > 0.0 ? lambda : 0.0;
-        ci[CI_ITER]++; ci[CI_INNER]++;
-        endInner = true;
-    } else if (!stop) {
-        lambda *= 10.0;
-        c[CTL_LAMBDA] = lambda;
-        ci[CI_INNER]++;
-        if (lambda >= 1e5) endInner = true;
-    } else endInner = true;
-    if (!endInner) return;                   // same linearisation, larger lambda
-    const double currentError = c[CTL_CUR], newError = c[CTL_ERROR];
-    bool converged;
-    if (newError <= 0.0) converged = true;
-    else {
-        const double absDec = currentError - newError, relDec = absDec / currentError;
-        converged = (relDec <= relTol) || (absDec <= absTol);
-    }
-    ci[CI_STATE] = (ci[CI_ITER] < ci[CI_MAXIT] && !converged && isfinite(currentError)) ? BA_LINEARIZE : BA_DONE;
 }
 
 // The control step as its own launch: the multi-GPU path, where the cost sums are all-reduced between the
@@ -228,7 +328,9 @@ __global__ __launch_bounds__(256) void k_ba_factors(BaDev D, int obsBlocks, int 
     __shared__ double red[8], out[2];
     __shared__ double sW[160];       // edge scratch: Hl 36 | Ad 36 | Ja 36 | Jb 36 | r 6
     __shared__ int sLast;
-    if (!ba_enter(D, MODE == 0 ? BA_LINEARIZE : BA_TRY)) return;
+    double* const partialBase = D.partial;
+    const int cand = MODE == 0 ? 0 : (int)blockIdx.y;      // trial launches: grid y = lambda candidate
+    if (!ba_enter(D, MODE == 0 ? BA_LINEARIZE : BA_TRY, cand)) return;
     const int tid = threadIdx.x, lane = tid & 63;
     if ((int)blockIdx.x < obsBlocks) {
         double v[2] = {0, 0};
@@ -254,78 +356,32 @@ __global__ __launch_bounds__(256) void k_ba_factors(BaDev D, int obsBlocks, int 
                 for (int i = 0; i < 3; i++) { l0 += o[14 + i] * dl[i]; l1 += o[17 + i] * dl[i]; }
                 v[0] += l0 * l0 + l1 * l1;
                 double r[2];
-                ba_eval_fac(D, D.poseTrial[D.facKf[f]], D.lmTrial + 3 * (size_t)D.facLm[f], D.facRight[f], D.facZ + 2 * (size_t)f,
-                            D.facIs[f], r, nullptr, nullptr);
+                if (D.specLin) {
+                    double Jp[12], Jl[6];
+                    ba_eval_fac(D, D.poseTrial[D.facKf[f]], D.lmTrial + 3 * (size_t)D.facLm[f], D.facRight[f], D.facZ + 2 * (size_t)f,
+                                D.facIs[f], r, Jp, Jl);
+                    double* o2 = D.facJ2 + (size_t)f * 20;
+                    o2[0] = r[0]; o2[1] = r[1];
+                    for (int c = 0; c < 12; c++) o2[2 + c] = Jp[c];
+                    for (int c = 0; c < 6; c++) o2[14 + c] = Jl[c];
+                } else
+                    ba_eval_fac(D, D.poseTrial[D.facKf[f]], D.lmTrial + 3 * (size_t)D.facLm[f], D.facRight[f], D.facZ + 2 * (size_t)f,
+                                D.facIs[f], r, nullptr, nullptr);
                 v[1] += r[0] * r[0] + r[1] * r[1];
             }
         }
         ba_block_sum<2, 4>(v, red, out);
-        if (tid == 0) { D.partial[2 * blockIdx.x] = out[0]; D.partial[2 * blockIdx.x + 1] = out[1]; }
+        if (tid == 0) { ba_publish(&D.partial[2 * blockIdx.x], out[0]); ba_publish(&D.partial[2 * blockIdx.x + 1], out[1]); }
     } else if (tid < 64) {
         const int e = blockIdx.x - obsBlocks;
-        double* Hl = sW; double* Ad = Hl + 36; double* Ja = Ad + 36; double* Jb = Ja + 36; double* rr = Jb + 36;
-        const double w = 1.0 / 0.01;
         double v[2] = {0, 0};
         if (e < D.NE) {
-            BaEdge& E = D.edges[e];
-            const int fa = E.fa, fb = E.fb, n = D.n;
+            const BaEdge& E = D.edges[e];
+            const int fa = E.fa, fb = E.fb;
             if (MODE == 0) {
-                if (lane == 0) {
-                    DPose Tai, h, Mi, d, hi;
-                    pose_inverse(D.poseCur[E.a], Tai);
-                    pose_compose(Tai, D.poseCur[E.b], h);
-                    pose_inverse(E.measured, Mi);
-                    pose_compose(Mi, h, d);
-                    double r[6];
-                    pose3_logmap(d, r);
-                    for (int i = 0; i < 6; i++) { r[i] *= w; rr[i] = r[i]; E.r[i] = r[i]; v[0] += r[i] * r[i]; }
-                    pose3_logmap_derivative(d, Hl);
-                    pose_inverse(h, hi);
-                    pose3_adjoint(hi, Ad);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                const int i = lane / 6, j = lane % 6;
-                if (lane < 36) {
-                    double s = 0;
-                    for (int k = 0; k < 6; k++) s += Hl[i * 6 + k] * Ad[k * 6 + j];
-                    const double ja = -s * w, jb = Hl[i * 6 + j] * w;
-                    Ja[lane] = ja; Jb[lane] = jb;
-                    E.Ja[lane] = ja; E.Jb[lane] = jb;
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (lane < 36) {
-                    double aa = 0, ab = 0, bb = 0;
-                    for (int k = 0; k < 6; k++) {
-                        aa += Ja[k * 6 + i] * Ja[k * 6 + j];
-                        ab += Ja[k * 6 + i] * Jb[k * 6 + j];
-                        bb += Jb[k * 6 + i] * Jb[k * 6 + j];
-                    }
-                    E.Haa[lane] = aa; E.Hab[lane] = ab; E.Hbb[lane] = bb;
-                    if (fa >= 0) atomicAdd(&D.Sedge[(size_t)(6 * fa + i) * n + 6 * fa + j], aa);
-                    if (fb >= 0) atomicAdd(&D.Sedge[(size_t)(6 * fb + i) * n + 6 * fb + j], bb);
-                    if (fa >= 0 && fb >= 0) {     // upper triangle only (the solve mirrors it)
-                        if (fa < fb) atomicAdd(&D.Sedge[(size_t)(6 * fa + i) * n + 6 * fb + j], ab);
-                        else atomicAdd(&D.Sedge[(size_t)(6 * fb + j) * n + 6 * fa + i], ab);
-                    }
-                } else if (lane < 42) {
-                    const int q = lane - 36;
-                    double ga = 0, gb = 0;
-                    for (int k = 0; k < 6; k++) { ga += Ja[k * 6 + q] * rr[k]; gb += Jb[k * 6 + q] * rr[k]; }
-                    E.ga[q] = ga; E.gb[q] = gb;
-                    if (fa >= 0) atomicAdd(&D.Sedge[(size_t)n * n + 6 * fa + q], -ga);
-                    if (fb >= 0) atomicAdd(&D.Sedge[(size_t)n * n + 6 * fb + q], -gb);
-                }
+                v[0] = ba_edge_linearize(D.edges[e], E, D.poseCur[E.a], D.poseCur[E.b], sW, D.Sedge, D.n, lane);
             } else {
-                if (lane == 0) {
-                    DPose Tai, h, Mi, d;
-                    pose_inverse(D.poseTrial[E.a], Tai);
-                    pose_compose(Tai, D.poseTrial[E.b], h);
-                    pose_inverse(E.measured, Mi);
-                    pose_compose(Mi, h, d);
-                    double r[6];
-                    pose3_logmap(d, r);
-                    for (int i = 0; i < 6; i++) { r[i] *= w; v[1] += r[i] * r[i]; }
-                } else if (lane >= 8 && lane < 14) {
+                if (lane >= 8 && lane < 14) {          // linearised cost at delta, from the current linearisation
                     const int k = lane - 8;
                     double l = E.r[k];
                     for (int i = 0; i < 6; i++) {
@@ -334,34 +390,53 @@ __global__ __launch_bounds__(256) void k_ba_factors(BaDev D, int obsBlocks, int 
                     }
                     v[0] += l * l;
                 }
+                if (D.specLin) v[1] = ba_edge_linearize(D.edges2[e], E, D.poseTrial[E.a], D.poseTrial[E.b], sW, D.Sedge2, D.n, lane);
+                else if (lane == 0) {
+                    DPose Tai, h, Mi, d;
+                    pose_inverse(D.poseTrial[E.a], Tai);
+                    pose_compose(Tai, D.poseTrial[E.b], h);
+                    pose_inverse(E.measured, Mi);
+                    pose_compose(Mi, h, d);
+                    double r[6];
+                    pose3_logmap(d, r);
+                    for (int i = 0; i < 6; i++) { r[i] *= 1.0 / 0.01; v[1] += r[i] * r[i]; }
+                }
             }
 #pragma unroll
             for (int k = 0; k < 2; k++) {
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1) v[k] += __shfl_xor(v[k], d);
             }
-            if (lane == 0) { D.partial[2 * obsBlocks + 2 * e] = v[0]; D.partial[2 * obsBlocks + 2 * e + 1] = v[1]; }
+            if (lane == 0) { ba_publish(&D.partial[2 * obsBlocks + 2 * e], v[0]); ba_publish(&D.partial[2 * obsBlocks + 2 * e + 1], v[1]); }
         }
     }
-    // the last workgroup to arrive sums every partial in array order
-    __threadfence();
+    // The last workgroup to arrive sums every partial in array order.  No __threadfence here: on gfx950 an
+    // agent-scope fence is an L2 write-back + invalidate (buffer_wbl2 / buffer_inv sc1) per workgroup, which
+    // dominated this kernel.  The partials travel as agent-scope relaxed atomics (sc1 stores / loads that bypass
+    // the per-XCD L2), each publisher waits for its stores to complete before it bumps the arrival counter.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) sLast = (atomicAdd(&D.flags[1], 1) == (int)gridDim.x - 1);
+    if (tid == 0) sLast = (__hip_atomic_fetch_add(&D.flags[FLAG_COUNT], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)(gridDim.x * gridDim.y) - 1);
     __syncthreads();
     if (!sLast) return;
-    __threadfence();
-    double t[2] = {0, 0};
     const int nPart = obsBlocks + D.NE;         // (edge partials follow the observation partials)
-    for (int i = tid; i < nPart; i += 256) { t[0] += D.partial[2 * i]; t[1] += D.partial[2 * i + 1]; }
-    ba_block_sum<2, 4>(t, red, out);
+    for (int c = 0; c < (int)gridDim.y; c++) {
+        const double* part = partialBase + (size_t)c * D.partialStride;
+        double t[2] = {0, 0};
+        for (int i = tid; i < nPart; i += 256) { t[0] += ba_collect(&part[2 * i]); t[1] += ba_collect(&part[2 * i + 1]); }
+        ba_block_sum<2, 4>(t, red, out);
+        if (tid == 0) {
+            if (MODE == 0) D.sums[0] = 0.5 * out[0];
+            else { D.sums[SUMS_CAND + 2 * c] = 0.5 * out[0]; D.sums[SUMS_CAND + 2 * c + 1] = 0.5 * out[1]; }
+        }
+        __syncthreads();
+    }
     if (tid == 0) {
-        if (MODE == 0) D.sums[0] = 0.5 * out[0];
-        else { D.sums[1] = 0.5 * out[0]; D.sums[2] = 0.5 * out[1]; }
-        D.flags[1] = 0;
+        D.flags[FLAG_COUNT] = 0;
         sLast = 0;
         if (fuseCtl) {
             ba_ctl(D, MODE, relTol, absTol);
-            sLast = MODE == 1 && ((const int*)(D.ctl + CTL_INTS))[CI_STATE] == BA_LINEARIZE;
+            sLast = MODE == 1 && !D.specLin && ((const int*)(D.ctl + CTL_INTS))[CI_STATE] == BA_LINEARIZE;
         }
     }
     __syncthreads();
@@ -415,8 +490,8 @@ __device__ __forceinline__ void ba_lm_blocks(const BaDev& D, int lp, double lamb
 template <bool LDS_S>
 __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_schur(BaDev D, int maxSlots) {
     extern __shared__ double sm[];
-    if (!ba_enter(D, BA_TRY)) return;
-    const double lambda = D.ctl[CTL_LAMBDA];
+    if (!ba_enter(D, BA_TRY, blockIdx.y)) return;
+    const double lambda = D.lambda;
     const int n = D.n;
     if (LDS_S) {   // D.S | D.rhs receive the sum of the per-workgroup partial systems (k_ba_reduce): zero them here
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n * n + n; i += gridDim.x * blockDim.x) D.S[i] = 0;
@@ -496,7 +571,7 @@ __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_schur(BaDev D, int m
 // Sum of the per-workgroup partial systems (grid-parallel, coalesced over entries).  This is the
 // buffer the landmark-sharded multi-GPU path all-reduces (RCCL) before k_ba_solve.
 __global__ __launch_bounds__(256) void k_ba_reduce(BaDev D, int nPart) {
-    if (!ba_enter(D, BA_TRY)) return;
+    if (!ba_enter(D, BA_TRY, blockIdx.z)) return;
     const int total = D.n * D.n + D.n;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
@@ -514,7 +589,10 @@ __global__ __launch_bounds__(256) void k_ba_reduce(BaDev D, int nPart) {
     }
     for (; p < p1; p++) s0 += D.Spart[(size_t)p * stride + i];
     double s = (s0 + s1) + (s2 + s3);
-    if (blockIdx.y == 0) s += D.Sedge[i];      // BetweenFactor blocks of this linearisation
+    if (blockIdx.y == 0) {
+        s += D.Sedge[i];      // BetweenFactor blocks of this linearisation
+        if (D.specLin) D.Sedge2[i] = 0;    // the trial's speculative linearisation accumulates here
+    }
     if (i < D.n * D.n) atomicAdd(&D.S[i], s); else atomicAdd(&D.rhs[i - D.n * D.n], s);
 }
 
@@ -524,8 +602,8 @@ __global__ __launch_bounds__(256) void k_ba_reduce(BaDev D, int nPart) {
 // retracts the trial poses.  A (n x n) lives in LDS when it fits, else in D.S (L2-resident).
 __global__ __launch_bounds__(1024) void k_ba_solve(BaDev D, int useLds, int ld) {
     extern __shared__ double sm[];
-    if (!ba_enter(D, BA_TRY)) return;
-    const double lambda = D.ctl[CTL_LAMBDA];
+    if (!ba_enter(D, BA_TRY, blockIdx.x)) return;      // one workgroup per lambda candidate
+    const double lambda = D.lambda;
     const int n = D.n, tid = threadIdx.x, nt = blockDim.x;
     double* A = useLds ? sm : D.S;                              // leading dimension ld (LDS: odd multiple, conflict-free rows)
     double* col = useLds ? sm + (size_t)n * ld : D.rhs + n;     // n scratch doubles (D.rhs holds 2n)
@@ -691,7 +769,7 @@ __global__ __launch_bounds__(1024) void k_ba_solve(BaDev D, int useLds, int ld) 
     }
     __syncthreads();
     BA_STAMP(6)
-    if (tid == 0) D.flags[0] = sFail;
+    if (tid == 0) D.flags[FLAG_FAIL + D.cand] = sFail;
 }
 
 // Reduced camera systems of up to BA_WAVE_N unknowns (10 free keyframes - the reference's local window) are
@@ -702,8 +780,8 @@ constexpr int BA_WAVE_N = 60;
 __global__ __launch_bounds__(64) void k_ba_solve_wave(BaDev D) {
     constexpr int N = BA_WAVE_N;
     __shared__ double Lt[N * (N + 1)];
-    if (!ba_enter(D, BA_TRY)) return;
-    const double lambda = D.ctl[CTL_LAMBDA];
+    if (!ba_enter(D, BA_TRY, blockIdx.x)) return;      // one workgroup per lambda candidate
+    const double lambda = D.lambda;
     const int n = D.n, lane = threadIdx.x;
     const int r = lane < N ? lane : N - 1;
     double a[N];
@@ -775,7 +853,7 @@ __global__ __launch_bounds__(64) void k_ba_solve_wave(BaDev D) {
         }
     }
     BAW_STAMP(6)
-    if (lane == 0) D.flags[0] = bad ? 1 : 0;
+    if (lane == 0) D.flags[FLAG_FAIL + D.cand] = bad ? 1 : 0;
 }
 
 // Reduced camera systems of 61..256 unknowns (11..42 free keyframes, e.g. the 20-KF KITTI window): blocked
@@ -795,9 +873,10 @@ __global__ __launch_bounds__(64 * BA_MFMA_NW) void k_ba_solve_mfma(BaDev D, doub
     double* sInv = P + BA_MFMA_N * BA_MFMA_LD;        // [16]
     double* sB = sInv + 16;                           // [BA_MFMA_N] right-hand side / solution
     __shared__ int sBad;
-    if (!ba_enter(D, BA_TRY)) return;
-    const double lambda = D.ctl[CTL_LAMBDA];
+    if (!ba_enter(D, BA_TRY, blockIdx.x)) return;      // one workgroup per lambda candidate
+    const double lambda = D.lambda;
     constexpr int N = BA_MFMA_N, NB = BA_MFMA_NB, LD = BA_MFMA_LD;
+    Lg += (size_t)D.cand * N * N;
     const int n = D.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) sBad = 0;
     // tile t = ib (ib + 1) / 2 + jb (jb <= ib) lives in slot t / 8 of wave t % 8; accumulator layout of
@@ -948,7 +1027,7 @@ __global__ __launch_bounds__(64 * BA_MFMA_NW) void k_ba_solve_mfma(BaDev D, doub
             else D.poseTrial[k] = D.poseCur[k];
         }
     }
-    if (tid == 0) D.flags[0] = fail ? 1 : 0;
+    if (tid == 0) D.flags[FLAG_FAIL + D.cand] = fail ? 1 : 0;
 }
 
 // The 10-keyframe window (6F <= 64) on ONE wave with the same MFMA scheme: the 10 lower tiles of the 64 x 64 system
@@ -958,8 +1037,8 @@ __global__ __launch_bounds__(64) void k_ba_solve_mfma64(BaDev D) {
     __shared__ double Lf[N * LDF];                    // staged system (upper triangle valid), then L (lower)
     __shared__ double P[N * LD];                      // current panel
     __shared__ double sInv[16], sB[N];
-    if (!ba_enter(D, BA_TRY)) return;
-    const double lambda = D.ctl[CTL_LAMBDA];
+    if (!ba_enter(D, BA_TRY, blockIdx.x)) return;      // one workgroup per lambda candidate
+    const double lambda = D.lambda;
     const int n = D.n, lane = threadIdx.x;
     auto fence = []() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
     for (int row = 0; row < n; row++)
@@ -1069,14 +1148,14 @@ __global__ __launch_bounds__(64) void k_ba_solve_mfma64(BaDev D) {
             else D.poseTrial[k] = D.poseCur[k];
         }
     }
-    if (lane == 0) D.flags[0] = bad ? 1 : 0;
+    if (lane == 0) D.flags[FLAG_FAIL + D.cand] = bad ? 1 : 0;
 }
 
 // back-substitution: dl = Hll^-1 (bl - sum_k W_k^T dp_k); trial landmark = cur + dl
 __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_back(BaDev D, int maxSlots) {
     extern __shared__ double sm[];
-    if (!ba_enter(D, BA_TRY)) return;
-    const double lambda = D.ctl[CTL_LAMBDA];
+    if (!ba_enter(D, BA_TRY, blockIdx.y)) return;
+    const double lambda = D.lambda;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double* W = sm + (size_t)wave * (maxSlots * 18);
     const int nw = blockDim.x >> 6;
@@ -1159,6 +1238,14 @@ __global__ __launch_bounds__(256) void k_ba_lm_apply(int n, double* __restrict__
                                                      const double* __restrict__ diff) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) cur[i] = init[i] + diff[i];
+}
+
+// every value slot starts from the caller's poses / landmarks (landmarks outside the graph are never rewritten)
+__global__ __launch_bounds__(256) void k_ba_init_slots(int nPose, const double* __restrict__ pose0, double* __restrict__ poseBase,
+                                                       int nLm, const double* __restrict__ lm0, double* __restrict__ lmBase) {
+    const int i = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
+    if (i < nPose) poseBase[(size_t)s * nPose + i] = pose0[i];
+    if (i < nLm) lmBase[(size_t)s * nLm + i] = lm0[i];
 }
 
 }  // namespace vslam
@@ -1265,6 +1352,8 @@ struct BaHostTmp {
     std::vector<int> cnt, fidx, lpOf, order, fill, key, src, ns;
 };
 
+std::atomic<int> g_baLookahead{-1}, g_baSpecLin{-1};     // vslam_local_ba_set_lookahead (-1: environment / default)
+
 struct HostFac { int pair, kf, lm, fi, lp; bool right; double z[2], is; };
 
 }  // namespace
@@ -1306,8 +1395,8 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
     struct Workspace {
         hipStream_t stream = nullptr;
         int device = -1;
-        DevBuf<DPose> d_pose0, d_poseA, d_poseB;
-        DevBuf<double> d_lm0, d_lmA, d_lmB, d_facJ, d_S, d_Spart, d_Sedge, d_dP, d_dL, d_lmDiff, d_sums, d_partial, d_Lg;
+        DevBuf<DPose> d_pose0, d_poseS;
+        DevBuf<double> d_lm0, d_lmS, d_facJ, d_S, d_Spart, d_Sedge, d_dP, d_dL, d_lmDiff, d_sums, d_partial, d_Lg;
         DevBuf<int> d_flags, d_pairKf, d_pairLm, d_pairOct;
         DevBuf<uint8_t> d_pairFlags, d_kfLocal, d_wrong;
         DevBuf<float> d_pairUv;
@@ -1337,8 +1426,8 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
     g_baTimer.reset();
     g_baTimer.stream = stream;
     g_baTimer.multi = true;
-    auto &d_pose0 = ws->d_pose0, &d_poseA = ws->d_poseA, &d_poseB = ws->d_poseB;
-    auto &d_lm0 = ws->d_lm0, &d_lmA = ws->d_lmA, &d_lmB = ws->d_lmB, &d_facJ = ws->d_facJ, &d_S = ws->d_S, &d_Spart = ws->d_Spart,
+    auto &d_pose0 = ws->d_pose0, &d_poseS = ws->d_poseS;
+    auto &d_lm0 = ws->d_lm0, &d_lmS = ws->d_lmS, &d_facJ = ws->d_facJ, &d_S = ws->d_S, &d_Spart = ws->d_Spart,
          &d_Sedge = ws->d_Sedge, &d_dP = ws->d_dP, &d_dL = ws->d_dL, &d_lmDiff = ws->d_lmDiff, &d_sums = ws->d_sums, &d_partial = ws->d_partial, &d_Lg = ws->d_Lg;
     auto &d_flags = ws->d_flags, &d_pairKf = ws->d_pairKf, &d_pairLm = ws->d_pairLm, &d_pairOct = ws->d_pairOct;
     auto &d_pairFlags = ws->d_pairFlags, &d_kfLocal = ws->d_kfLocal, &d_wrong = ws->d_wrong;
@@ -1346,8 +1435,14 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
 
     std::vector<DPose> pose0(K);
     for (int k = 0; k < K; k++) pose_from_rm16(P->kf_pose_wc + 16 * (size_t)k, pose0[k]);
-    VS_HIP(d_pose0.alloc(K)); VS_HIP(d_poseA.alloc(K)); VS_HIP(d_poseB.alloc(K));
-    VS_HIP(d_lm0.alloc((size_t)3 * L)); VS_HIP(d_lmA.alloc((size_t)3 * L)); VS_HIP(d_lmB.alloc((size_t)3 * L));
+    // lambda look-ahead (see BaDev): candidates per trial round; the sharded path keeps the plain sequential scheme
+    static const int nbEnv = [] { const char* e = getenv("VSLAM_BA_LOOKAHEAD"); return e ? std::max(1, std::min((int)BA_MAX_NB, atoi(e))) : (int)BA_MAX_NB; }();
+    static const bool specEnv = !getenv("VSLAM_BA_NO_SPECLIN");
+    const int nbSet = g_baLookahead.load(), specSet = g_baSpecLin.load();
+    const int NB = comm ? 1 : (nbSet > 0 ? std::min(nbSet, (int)BA_MAX_NB) : nbEnv), nSlots = NB + 1;
+    const bool specLin = !comm && (specSet >= 0 ? specSet != 0 : specEnv);
+    VS_HIP(d_pose0.alloc(K)); VS_HIP(d_poseS.alloc((size_t)nSlots * K));
+    VS_HIP(d_lm0.alloc((size_t)3 * L)); VS_HIP(d_lmS.alloc((size_t)nSlots * 3 * L));
     VS_HIP(hipMemcpyAsync(d_pose0.p, pose0.data(), K * sizeof(DPose), hipMemcpyHostToDevice, stream));
     if (L) VS_HIP(hipMemcpyAsync(d_lm0.p, P->lm_xyz, (size_t)3 * L * sizeof(double), hipMemcpyHostToDevice, stream));
     VS_HIP(d_pairKf.alloc(NP)); VS_HIP(d_pairLm.alloc(NP)); VS_HIP(d_pairOct.alloc((size_t)2 * NP));
@@ -1362,7 +1457,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
     }
     VS_HIP(hipMemcpyAsync(d_kfLocal.p, P->kf_local, K, hipMemcpyHostToDevice, stream));
     VS_HIP(d_sums.alloc(32));
-    if (!d_flags.p) { VS_HIP(d_flags.alloc(4)); VS_HIP(hipMemsetAsync(d_flags.p, 0, 4 * sizeof(int), stream)); }
+    if (!d_flags.p) { VS_HIP(d_flags.alloc(16)); VS_HIP(hipMemsetAsync(d_flags.p, 0, 16 * sizeof(int), stream)); }
 
     std::vector<uint8_t> wrong(NP, 0);
     DPose* poseFinal = d_pose0.p;
@@ -1409,7 +1504,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         const int NE = rank == 0 ? std::max((int)T.order.size() - 1, 0) : 0;
 
         VS_HIP(A.ensure(8192 + (size_t)NF * 48 + ((size_t)NF + Lp + 2) * 8 + ((size_t)Lp + 2) * 12 + (size_t)K * 8 + L +
-                        (size_t)NE * sizeof(BaEdge) + 20 * 256, stream));
+                        (size_t)(BA_MAX_NB + 1) * NE * sizeof(BaEdge) + 24 * 256, stream));
         A.reset();
         double* h_ctl = A.take<double>(CTL_DOUBLES);
         int* h_facKf = A.take<int>(NF); int* h_facFi = A.take<int>(NF); int* h_facLp = A.take<int>(NF); int* h_facLm = A.take<int>(NF);
@@ -1418,7 +1513,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         int* h_lpStart = A.take<int>(Lp + 1); int* h_lpSlotStart = A.take<int>(Lp + 1); int* h_lpOrig = A.take<int>(Lp);
         int* h_slotStart = A.take<int>((size_t)NF + Lp + 1); int* h_slotFi = A.take<int>((size_t)NF + Lp + 1);
         int* h_fidx = A.take<int>(K);
-        BaEdge* h_edges = A.take<BaEdge>(NE);
+        BaEdge* h_edges = A.take<BaEdge>((size_t)(specLin ? nSlots : 1) * NE);
         uint8_t* h_kfPresent = A.take<uint8_t>(K); uint8_t* h_lmPresent = A.take<uint8_t>(L);
         if (!h_lmPresent) { set_error("local BA: upload arena too small"); return VSLAM_ERR_CAPACITY; }
 
@@ -1504,7 +1599,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
             DPose ai;
             pose_inverse(pose0[e.a], ai);
             pose_compose(ai, pose0[e.b], e.measured);
-            h_edges[i] = e;
+            for (int sl = 0; sl < (specLin ? nSlots : 1); sl++) h_edges[(size_t)sl * NE + i] = e;
         }
         // ---- LM control block (GTSAM 4.2 policy; k_ba_ctl) ---------------------------------------------
         const int maxIterations = pass == 0 ? 5 : 10;
@@ -1519,14 +1614,15 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
 
         // ---- upload ------------------------------------------------------------------------------
         VS_HIP(A.upload(stream));
-        VS_HIP(d_facJ.alloc((size_t)20 * NF));
-        VS_HIP(d_dP.alloc(n)); VS_HIP(d_dL.alloc((size_t)3 * Lp)); VS_HIP(d_S.alloc((size_t)n * n + 2 * n + 8));
-        VS_HIP(d_Sedge.alloc((size_t)n * n + n));   // (S | rhs | scratch are contiguous: one all-reduce buffer)
-        VS_HIP(hipMemcpyAsync(d_poseA.p, d_pose0.p, K * sizeof(DPose), hipMemcpyDeviceToDevice, stream));
-        VS_HIP(hipMemcpyAsync(d_poseB.p, d_pose0.p, K * sizeof(DPose), hipMemcpyDeviceToDevice, stream));
-        if (L) {
-            VS_HIP(hipMemcpyAsync(d_lmA.p, d_lm0.p, (size_t)3 * L * sizeof(double), hipMemcpyDeviceToDevice, stream));
-            VS_HIP(hipMemcpyAsync(d_lmB.p, d_lm0.p, (size_t)3 * L * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        const size_t sysStride = (size_t)n * n + 2 * n + 8, seDoubles = (size_t)n * n + n;
+        VS_HIP(d_facJ.alloc((size_t)20 * NF * (specLin ? nSlots : 1)));
+        VS_HIP(d_dP.alloc((size_t)NB * n)); VS_HIP(d_dL.alloc((size_t)NB * 3 * Lp));
+        VS_HIP(d_S.alloc(sysStride * NB));         // per candidate: S | rhs | scratch contiguous (one all-reduce buffer)
+        VS_HIP(d_Sedge.alloc(seDoubles * (specLin ? nSlots : 1)));
+        {
+            const int nPose = K * (int)(sizeof(DPose) / sizeof(double)), nLm = 3 * L;
+            hipLaunchKernelGGL(k_ba_init_slots, dim3((std::max(nPose, nLm) + 255) / 256, nSlots), dim3(256), 0, stream,
+                               nPose, (const double*)d_pose0.p, (double*)d_poseS.p, nLm, d_lm0.p, d_lmS.p);
         }
 
         BaDev D{};
@@ -1534,11 +1630,15 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         D.facKf = A.dev(h_facKf); D.facFi = A.dev(h_facFi); D.facLp = A.dev(h_facLp); D.facLm = A.dev(h_facLm);
         D.facZ = A.dev(h_facZ); D.facIs = A.dev(h_facIs); D.facRight = A.dev(h_facRight); D.facJ = d_facJ.p;
         D.lpStart = A.dev(h_lpStart); D.lpSlotStart = A.dev(h_lpSlotStart); D.slotStart = A.dev(h_slotStart); D.slotFi = A.dev(h_slotFi);
-        D.lpOrig = A.dev(h_lpOrig); D.poseCur = d_poseA.p; D.poseTrial = d_poseB.p; D.fidx = A.dev(h_fidx);
-        D.lmCur = d_lmA.p; D.lmTrial = d_lmB.p; D.edges = A.dev(h_edges);
+        D.lpOrig = A.dev(h_lpOrig); D.poseCur = d_poseS.p; D.poseTrial = d_poseS.p + K; D.fidx = A.dev(h_fidx);
+        D.lmCur = d_lmS.p; D.lmTrial = d_lmS.p + (size_t)3 * L; D.edges = A.dev(h_edges);
         D.S = d_S.p; D.rhs = d_S.p + (size_t)n * n; D.Sedge = d_Sedge.p; D.dP = d_dP.p; D.dL = d_dL.p; D.sums = d_sums.p; D.flags = d_flags.p;
         D.fx = P->rig.fx; D.fy = P->rig.fy; D.cx = P->rig.cx; D.cy = P->rig.cy; D.b = (double)P->rig.baseline;
         D.ctl = A.dev(h_ctl);
+        D.NB = NB; D.specLin = specLin ? 1 : 0;
+        D.poseBase = d_poseS.p; D.lmBase = d_lmS.p; D.lmStride = (size_t)3 * L;
+        D.facJBase = d_facJ.p; D.facJStride = (size_t)20 * NF; D.SedgeBase = d_Sedge.p; D.edgesBase = A.dev(h_edges);
+        D.sysStride = sysStride; D.dLStride = (size_t)3 * Lp;
 
         const int obsBlocks = std::max(1, std::min((NF + 255) / 256, 4 * nCU));
         const bool ldsS = F <= BA_LDS_MAX_F;
@@ -1547,9 +1647,11 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         auto schur_lds = [&](int nw) { return (ldsS ? sysDoubles * sizeof(double) : 0) + (size_t)nw * 2 * maxSlots * 18 * sizeof(double) + (size_t)nw * maxSlots * sizeof(int) + 16; };
         while (schurWaves > 4 && schur_lds(schurWaves) > 150 * 1024) schurWaves /= 2;
         const int lmBlocks = std::max(1, std::min((Lp + schurWaves - 1) / schurWaves, nCU));
-        VS_HIP(d_partial.alloc((size_t)2 * obsBlocks + 2 * (size_t)std::max(NE, 1)));
+        D.partialStride = (size_t)2 * obsBlocks + 2 * (size_t)std::max(NE, 1);
+        VS_HIP(d_partial.alloc(D.partialStride * NB));
         D.partial = d_partial.p;
-        if (ldsS) VS_HIP(d_Spart.alloc(sysDoubles * lmBlocks));
+        D.spartStride = sysDoubles * lmBlocks;
+        if (ldsS) VS_HIP(d_Spart.alloc(D.spartStride * NB));
         D.Spart = d_Spart.p;
         const size_t schurLds = schur_lds(schurWaves);
         const size_t backLds = (size_t)schurWaves * maxSlots * 18 * sizeof(double) + (size_t)schurWaves * maxSlots * sizeof(int) + 16;
@@ -1565,7 +1667,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         const size_t mfmaLds = ((size_t)BA_MFMA_N * BA_MFMA_LD + 16 + BA_MFMA_N) * sizeof(double);
         static const bool useMfma = !getenv("VSLAM_BA_NO_MFMA");
         if (n > BA_WAVE_N && n <= BA_MFMA_N && useMfma) {
-            VS_HIP(d_Lg.alloc((size_t)BA_MFMA_N * BA_MFMA_N));
+            VS_HIP(d_Lg.alloc((size_t)BA_MFMA_N * BA_MFMA_N * NB));
             VS_HIP(hipFuncSetAttribute((const void*)k_ba_solve_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfmaLds));
         }
         BHS("upload");
@@ -1577,9 +1679,10 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         const int facBlocks = (NF ? obsBlocks : 0) + std::max(NE, 1);
         const int nObs = NF ? obsBlocks : 0;
         VS_HIP(hipMemsetAsync(d_Sedge.p, 0, ((size_t)n * n + n) * sizeof(double), stream));     // first linearisation; later ones: see k_ba_factors
-        auto step = [&]() -> vslam_status {
+        auto step = [&](bool first) -> vslam_status {
             int t = g_baTimer.begin("ba_linearize");
-            hipLaunchKernelGGL(k_ba_factors<0>, dim3(facBlocks), dim3(256), 0, stream, D, nObs, fuseCtl, relTol, absTol);
+            // with speculative linearisation only the first step of a pass linearises on its own
+            if (first || !specLin) hipLaunchKernelGGL(k_ba_factors<0>, dim3(facBlocks), dim3(256), 0, stream, D, nObs, fuseCtl, relTol, absTol);
             g_baTimer.end(t);
             if (comm) {
                 const int tc = g_baTimer.begin("ba_allreduce"); VS_CHECK(comm_allreduce(comm, d_sums.p, 1, stream)); g_baTimer.end(tc);
@@ -1587,30 +1690,30 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
             }
             t = g_baTimer.begin("ba_schur");
             if (n > 0) {
-                if (ldsS) hipLaunchKernelGGL(k_ba_schur<true>, dim3(lmBlocks), dim3(64 * schurWaves), schurLds, stream, D, maxSlots);
+                if (ldsS) hipLaunchKernelGGL(k_ba_schur<true>, dim3(lmBlocks, NB), dim3(64 * schurWaves), schurLds, stream, D, maxSlots);
                 else {
-                    VS_HIP(hipMemsetAsync(d_S.p, 0, ((size_t)n * n + n) * sizeof(double), stream));
-                    hipLaunchKernelGGL(k_ba_schur<false>, dim3(lmBlocks), dim3(64 * schurWaves), schurLds, stream, D, maxSlots);
+                    VS_HIP(hipMemsetAsync(d_S.p, 0, sysStride * NB * sizeof(double), stream));
+                    hipLaunchKernelGGL(k_ba_schur<false>, dim3(lmBlocks, NB), dim3(64 * schurWaves), schurLds, stream, D, maxSlots);
                 }
             }
             g_baTimer.end(t);
             t = g_baTimer.begin("ba_solve");
-            if (n > 0) hipLaunchKernelGGL(k_ba_reduce, dim3(((int)sysDoubles + 255) / 256, ldsS ? 8 : 1), dim3(256), 0, stream, D, ldsS ? lmBlocks : 0);   // + BetweenFactor blocks
+            if (n > 0) hipLaunchKernelGGL(k_ba_reduce, dim3(((int)sysDoubles + 255) / 256, ldsS ? 8 : 1, NB), dim3(256), 0, stream, D, ldsS ? lmBlocks : 0);   // + BetweenFactor blocks
             if (comm && n > 0) { const int tc = g_baTimer.begin("ba_allreduce"); VS_CHECK(comm_allreduce(comm, d_S.p, (size_t)n * n + n, stream)); g_baTimer.end(tc); }
-            if (n <= 64 && useMfma) hipLaunchKernelGGL(k_ba_solve_mfma64, dim3(1), dim3(64), 0, stream, D);
-            else if (n <= BA_WAVE_N) hipLaunchKernelGGL(k_ba_solve_wave, dim3(1), dim3(64), 0, stream, D);
-            else if (n <= BA_MFMA_N && useMfma) hipLaunchKernelGGL(k_ba_solve_mfma, dim3(1), dim3(64 * BA_MFMA_NW), mfmaLds, stream, D, d_Lg.p);
-            else hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(std::max(64, vslam::align_up(n, 64))),
+            if (n <= 64 && useMfma) hipLaunchKernelGGL(k_ba_solve_mfma64, dim3(NB), dim3(64), 0, stream, D);
+            else if (n <= BA_WAVE_N) hipLaunchKernelGGL(k_ba_solve_wave, dim3(NB), dim3(64), 0, stream, D);
+            else if (n <= BA_MFMA_N && useMfma) hipLaunchKernelGGL(k_ba_solve_mfma, dim3(NB), dim3(64 * BA_MFMA_NW), mfmaLds, stream, D, d_Lg.p);
+            else hipLaunchKernelGGL(k_ba_solve, dim3(NB), dim3(std::max(64, vslam::align_up(n, 64))),
                                     solveLds ? solveLdsBytes : 64, stream, D, solveLds ? 1 : 0, solveLds ? ldA : n);
             g_baTimer.end(t);
             t = g_baTimer.begin("ba_back");
-            if (Lp) hipLaunchKernelGGL(k_ba_back, dim3(lmBlocks), dim3(64 * schurWaves), backLds, stream, D, maxSlots);
+            if (Lp) hipLaunchKernelGGL(k_ba_back, dim3(lmBlocks, NB), dim3(64 * schurWaves), backLds, stream, D, maxSlots);
             g_baTimer.end(t);
             t = g_baTimer.begin("ba_eval");
-            hipLaunchKernelGGL(k_ba_factors<1>, dim3(facBlocks), dim3(256), 0, stream, D, nObs, fuseCtl, relTol, absTol);
+            hipLaunchKernelGGL(k_ba_factors<1>, dim3(facBlocks, NB), dim3(256), 0, stream, D, nObs, fuseCtl, relTol, absTol);
             g_baTimer.end(t);
             if (comm) {
-                const int tc = g_baTimer.begin("ba_allreduce"); VS_CHECK(comm_allreduce(comm, d_sums.p + 1, 2, stream)); g_baTimer.end(tc);
+                const int tc = g_baTimer.begin("ba_allreduce"); VS_CHECK(comm_allreduce(comm, d_sums.p + SUMS_CAND, 2, stream)); g_baTimer.end(tc);
                 hipLaunchKernelGGL(k_ba_ctl, dim3(1), dim3(256), 0, stream, D, 1, relTol, absTol);
             }
             VS_HIP(hipGetLastError());
@@ -1620,14 +1723,14 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         const int* co = (const int*)(h_ctlOut + CTL_INTS);
         int enq = 0;
         for (;;) {
-            for (int b = 0; b < 4; b++) VS_CHECK(step());
+            for (int b = 0; b < 4; b++) VS_CHECK(step(enq + b == 0));
             enq += 4;
             VS_HIP(hipMemcpyAsync(h_ctlOut, D.ctl, CTL_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, stream));
             VS_HIP(hipStreamSynchronize(stream));
             if (co[CI_STATE] == BA_DONE) break;
             if (enq > 400) { set_error("local BA: LM did not terminate"); return VSLAM_ERR_INVALID; }
         }
-        if (co[CI_SEL]) { std::swap(D.poseCur, D.poseTrial); std::swap(D.lmCur, D.lmTrial); }
+        D.poseCur = d_poseS.p + (size_t)co[CI_SEL] * K; D.lmCur = d_lmS.p + (size_t)co[CI_SEL] * 3 * L;
         R->report[pass].iterations = co[CI_ITER];
         R->report[pass].inner_iterations = co[CI_INNER];
         R->report[pass].initial_error = h_ctlOut[CTL_INIT_ERR];
@@ -1695,6 +1798,13 @@ vslam_status vslam_local_ba_timings(const char** names, float* ms, int32_t cap, 
     int n = g_baTimer.read(nm, tv, cap < 64 ? cap : 64);
     for (int i = 0; i < n; i++) { if (names) names[i] = nm[i]; if (ms) ms[i] = tv[i]; }
     *n_out = n;
+    return VSLAM_OK;
+}
+
+vslam_status vslam_local_ba_set_lookahead(int32_t candidates, int32_t speculative_linearize) {
+    if (candidates > BA_MAX_NB) return VSLAM_ERR_INVALID;
+    g_baLookahead.store(candidates > 0 ? candidates : -1);
+    g_baSpecLin.store(speculative_linearize < 0 ? -1 : (speculative_linearize ? 1 : 0));
     return VSLAM_OK;
 }
 

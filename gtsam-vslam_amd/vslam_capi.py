@@ -342,6 +342,12 @@ def local_ba_set_timing(on):
     _chk(lib().vslam_local_ba_set_timing(int(bool(on))))
 
 
+def local_ba_set_lookahead(candidates=0, speculative_linearize=-1):
+    """Tuning only (results are bit-identical): lambda candidates per trial round (1..4, 0 = default) and
+    speculative linearisation (0 / 1, -1 = default)."""
+    _chk(lib().vslam_local_ba_set_lookahead(int(candidates), int(speculative_linearize)))
+
+
 class TrackReport(C.Structure):
     _fields_ = [("n_map_points", C.c_int32), ("n_active", C.c_int32), ("rounds", C.c_int32),
                 ("n_inliers", C.c_int32), ("n_stereo", C.c_int32), ("lm_iterations", C.c_int32),

@@ -332,6 +332,11 @@ vslam_status vslam_local_ba(const vslam_ba_problem* problem, vslam_ba_result* re
 vslam_status vslam_local_ba_timings(const char** names, float* ms, int32_t cap, int32_t* n_out);
 /* event timing on (default) / off for the following vslam_local_ba calls of the calling thread */
 vslam_status vslam_local_ba_set_timing(int32_t on);
+/* Tuning knob, results are bit-identical for every setting: `candidates` (1..4, <= 0: default 4) damping values
+ * lambda, 10 lambda, ... are evaluated per trial round and then walked in GTSAM's sequential order on the device;
+ * `speculative_linearize` (0 / 1, < 0: default on) linearises at every trial point so that an accepted step needs
+ * no launch of its own.  Process-wide; the landmark-sharded path (comm != NULL) always runs 1 / off. */
+vslam_status vslam_local_ba_set_lookahead(int32_t candidates, int32_t speculative_linearize);
 
 /* ---------------------------------------------------------------------------
  * New-point pipeline of the optimizer thread — replaces the numerical part of LocalMapper::findNewPoints
