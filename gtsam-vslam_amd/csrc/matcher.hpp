@@ -83,6 +83,10 @@ struct vslam_matcher {
     vslam_status imu_setup(const vslam_imu_input* imu, double lastDt = 0.0);
     vslam_status pose_imu_enqueue(int M, const int* Mdev = nullptr, const int* gate = nullptr, int gateMin = 0, int outSlot = 0, int monoOnly = 0);
     double* h_imuStage = nullptr; int imuStageCap = 0;     // pinned upload staging
+    // the bucket upload + pre-integration depend on nothing the frame's matching produces: they run on a side stream
+    // next to stereo / projection matching, the pose solve waits for evImu (imu_join)
+    hipStream_t imuStream = nullptr; hipEvent_t evImu = nullptr; bool imuPending = false;
+    vslam_status imu_join();
     vslam_status estimate_pose_imu(vslam_pose_problem* prob, const vslam_imu_input* imu, vslam_imu_output* out,
                                    int* nIn, int* nStereo, vslam_lm_report* rep, int monoOnly = 0);
     vslam_status imu_predict(const vslam_imu_input* imu, const double* predVelocity, double lastDt, double* T_wc_out, double* vel_out);

@@ -365,8 +365,16 @@ vslam_status vslam_matcher::imu_setup(const vslam_imu_input* imu, double lastDt)
     const size_t pimD = sizeof(DPim) / sizeof(double);
     const size_t need = (size_t)7 * n + 6 + pimD + 225;
     VS_CHECK(ensure_res());
+    if (!imuStream) {
+        VS_HIP(hipStreamCreateWithFlags(&imuStream, hipStreamNonBlocking));
+        VS_HIP(hipEventCreateWithFlags(&evImu, hipEventDisableTiming));
+    }
+    // stage timing brackets kernels with events on the main stream: keep the pre-integration there when it is on
+    static const bool sideOff = getenv("VSLAM_IMU_MAIN_STREAM") != nullptr;
+    hipStream_t is = (timer.enabled || sideOff) ? stream : imuStream;
     if ((int)need > imuCap) {
         VS_HIP(hipStreamSynchronize(stream));
+        VS_HIP(hipStreamSynchronize(imuStream));
         hipFree(d_imuBuf);
         imuCap = (int)need + 1024;
         VS_HIP(hipMalloc(&d_imuBuf, (size_t)imuCap * sizeof(double)));
@@ -392,7 +400,7 @@ vslam_status vslam_matcher::imu_setup(const vslam_imu_input* imu, double lastDt)
     double* d_bias = d_dts + n;
     imuPim = (void*)(d_bias + 6);
     imuLam = (double*)imuPim + pimD;
-    VS_HIP(hipMemcpyAsync(d_samples, h, (size_t)hn * sizeof(double), hipMemcpyHostToDevice, stream));
+    VS_HIP(hipMemcpyAsync(d_samples, h, (size_t)hn * sizeof(double), hipMemcpyHostToDevice, is));
     DImuParams P{};
     for (int k = 0; k < 3; k++) P.gravity[k] = imu->gravity[k];
     P.gyroCov = imu->gyro_noise_density * imu->gyro_noise_density;        // pow(density, 2) (:318-321)
@@ -407,9 +415,17 @@ vslam_status vslam_matcher::imu_setup(const vslam_imu_input* imu, double lastDt)
     for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) imuSi[3 * r + c] = imu->T_wc_prev[4 * r + c]; imuSi[9 + r] = imu->T_wc_prev[4 * r + 3]; imuSi[12 + r] = imu->velocity_prev[r]; }
     for (int k = 0; k < 6; k++) imuBiasPrev[k] = imu->bias_prev[k];
     int t = timer.begin("imu_preintegrate");
-    hipLaunchKernelGGL(k_imu_preintegrate, dim3(1), dim3(256), 0, stream, P, d_samples, d_dts, n, d_bias, (DPim*)imuPim, imuLam);
+    hipLaunchKernelGGL(k_imu_preintegrate, dim3(1), dim3(256), 0, is, P, d_samples, d_dts, n, d_bias, (DPim*)imuPim, imuLam);
     timer.end(t);
     VS_HIP(hipGetLastError());
+    imuPending = is != stream;
+    if (imuPending) VS_HIP(hipEventRecord(evImu, imuStream));
+    return VSLAM_OK;
+}
+
+// make the main stream wait for the side-stream pre-integration (once per imu_setup)
+vslam_status vslam_matcher::imu_join() {
+    if (imuPending) { VS_HIP(hipStreamWaitEvent(stream, evImu, 0)); imuPending = false; }
     return VSLAM_OK;
 }
 
@@ -433,6 +449,7 @@ vslam_status vslam_matcher::pose_imu_enqueue(int M, const int* Mdev, const int* 
     for (int k = 0; k < 9; k++) I.si.R[k] = imuSi[k];
     for (int k = 0; k < 3; k++) { I.si.t[k] = imuSi[9 + k]; I.si.v[k] = imuSi[12 + k]; }
     for (int k = 0; k < 6; k++) I.biasPrev[k] = imuBiasPrev[k];
+    VS_CHECK(imu_join());
     int t = timer.begin("pose_imu_lm");
 #ifdef VSLAM_POSE_STAMPS
     { long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ps), z, sizeof(z)); }
@@ -537,6 +554,7 @@ vslam_status vslam_matcher::imu_predict(const vslam_imu_input* imu, const double
     DNav si;
     for (int k = 0; k < 9; k++) si.R[k] = imuSi[k];
     for (int k = 0; k < 3; k++) { si.t[k] = imuSi[9 + k]; si.v[k] = predVelocity[k]; }
+    VS_CHECK(imu_join());
     hipLaunchKernelGGL(k_imu_predict_out, dim3(1), dim3(64), 0, stream, (const DPim*)imuPim, P, si, imuIo);
     VS_HIP(hipGetLastError());
     VS_HIP(hipMemcpyAsync(h_res + 32, imuIo, 15 * sizeof(double), hipMemcpyDeviceToHost, stream));

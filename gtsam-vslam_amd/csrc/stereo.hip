@@ -334,6 +334,8 @@ void vslam_matcher::release() {
     hipFree(d_points); hipFree(d_flags); hipFree(d_factors); hipFree(d_firstFail); hipFree(d_res);
     if (h_res) hipHostFree(h_res);
     if (h_imuStage) hipHostFree(h_imuStage);
+    if (imuStream) { (void)hipStreamSynchronize(imuStream); (void)hipStreamDestroy(imuStream); }
+    if (evImu) (void)hipEventDestroy(evImu);
     hipFree(d_mpv); hipFree(d_topk); hipFree(d_matches); hipFree(d_matchedL); hipFree(d_matchedR); hipFree(d_projOut);
     if (stream) hipStreamDestroy(stream);
     stream = nullptr;
