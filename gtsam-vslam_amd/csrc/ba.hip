@@ -444,13 +444,17 @@ __global__ __launch_bounds__(256) void k_ba_factors(BaDev D, int obsBlocks, int 
 }
 
 // ---- landmark blocks shared by the Schur and back-substitution kernels ---------------------------
-// After the call (and a __syncthreads by the caller) W[s*18 + i*3 + j] holds Hpl of slot s; Hi / bl are
-// returned in registers (identical in every lane of the wave).
-__device__ __forceinline__ void ba_lm_blocks(const BaDev& D, int lp, double lambda, double* W, int* sfi,
-                                             double* Hi, double* bl, int& ns) {
+// W / sfi are private to the calling wave: LDS traffic of one wave is processed in order, so a compiler-level
+// fence (no workgroup barrier) is all that separates the writes below from the reads that follow.
+__device__ __forceinline__ void ba_wave_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// After the call (and a ba_wave_fence) W[s*18 + i*3 + j] holds Hpl of slot s; h = 6 unique entries of Hll (undamped)
+// followed by bl, identical in every lane of the wave.
+__device__ __forceinline__ void ba_lm_blocks(const BaDev& D, int lp, double* W, int* sfi, double* h, int& ns) {
     const int lane = threadIdx.x & 63;
     const int f0 = D.lpStart[lp], f1 = D.lpStart[lp + 1];
-    double h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // 6 unique Hll entries + 3 of bl
+#pragma unroll
+    for (int k = 0; k < 9; k++) h[k] = 0;
     for (int f = f0 + lane; f < f1; f += 64) {
         const double* o = D.facJ + (size_t)f * 20;
         const double r0 = o[0], r1 = o[1];
@@ -470,9 +474,6 @@ __device__ __forceinline__ void ba_lm_blocks(const BaDev& D, int lp, double lamb
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) h[k] += __shfl_xor(h[k], d);
     }
-    const double Hll[9] = {h[0] + lambda, h[1], h[2], h[1], h[3] + lambda, h[4], h[2], h[4], h[5] + lambda};
-    inv3sym(Hll, Hi);
-    bl[0] = h[6]; bl[1] = h[7]; bl[2] = h[8];
     const int s0 = D.lpSlotStart[lp];
     ns = D.lpSlotStart[lp + 1] - s0 - 1;   // one end sentinel per landmark
     for (int e = lane; e < ns * 18; e += 64) {
@@ -486,46 +487,62 @@ __device__ __forceinline__ void ba_lm_blocks(const BaDev& D, int lp, double lamb
     }
     for (int s = lane; s < ns; s += 64) sfi[s] = D.slotFi[s0 + s];
 }
+// (Hll + lambda I)^-1
+__device__ __forceinline__ void ba_hll_inverse(const double* h, double lambda, double* Hi) {
+    const double Hll[9] = {h[0] + lambda, h[1], h[2], h[1], h[3] + lambda, h[4], h[2], h[4], h[5] + lambda};
+    inv3sym(Hll, Hi);
+}
 
+// One wave per landmark.  sharedW: the workgroup serves every lambda candidate (grid y = 1): Hll, bl and the W blocks
+// do not depend on the damping and are built once, only Hll^-1 and the rank-3 updates are per candidate, each into
+// its own LDS copy of the reduced system.  Otherwise grid y = candidate.
 template <bool LDS_S>
-__global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_schur(BaDev D, int maxSlots) {
+__global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_schur(BaDev D, int maxSlots, int sharedW) {
     extern __shared__ double sm[];
-    if (!ba_enter(D, BA_TRY, blockIdx.y)) return;
-    const double lambda = D.lambda;
+    double* const SBase = D.S;
+    double* const SpartBase = D.Spart;
+    const int c0 = sharedW ? 0 : (int)blockIdx.y;
+    if (!ba_enter(D, BA_TRY, c0)) return;
+    const int nc = sharedW ? D.NB : 1;
     const int n = D.n;
+    const size_t sys = (size_t)n * n + n;
     if (LDS_S) {   // D.S | D.rhs receive the sum of the per-workgroup partial systems (k_ba_reduce): zero them here
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n * n + n; i += gridDim.x * blockDim.x) D.S[i] = 0;
+        for (int k = 0; k < nc; k++) {
+            double* Sg = SBase + (size_t)(c0 + k) * D.sysStride;
+            for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (int)sys; i += gridDim.x * blockDim.x) Sg[i] = 0;
+        }
     }
-    double* Sloc = sm;                                        // LDS_S: n*n + n
-    double* wbase = sm + (LDS_S ? (size_t)n * n + n : 0);
+    double* Sloc = sm;                                        // LDS_S: nc copies of n*n + n
+    double* wbase = sm + (LDS_S ? (size_t)nc * sys : 0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double* W = wbase + (size_t)wave * (2 * maxSlots * 18);
     double* WH = W + maxSlots * 18;
     const int nw = blockDim.x >> 6, nt = blockDim.x;
     int* sfi = (int*)(wbase + (size_t)nw * (2 * maxSlots * 18)) + wave * maxSlots;
-    double* Sacc = LDS_S ? Sloc : D.S;
-    double* racc = LDS_S ? Sloc + (size_t)n * n : D.rhs;
     if (LDS_S) {
-        for (int i = threadIdx.x; i < n * n + n; i += nt) Sloc[i] = 0;
+        for (int i = threadIdx.x; i < (int)(nc * sys); i += nt) Sloc[i] = 0;
     }
     __syncthreads();
     const int rounds = (D.Lp + gridDim.x * nw - 1) / (gridDim.x * nw);
     for (int rd = 0; rd < rounds; rd++) {
         const int lp = (rd * gridDim.x + blockIdx.x) * nw + wave;
-        const bool act = lp < D.Lp;
-        double Hi[9], bl[3];
+        if (lp >= D.Lp) break;
+        double h[9];
         int ns = 0;
-        if (act) ba_lm_blocks(D, lp, lambda, W, sfi, Hi, bl, ns);
-        __syncthreads();
-        if (act) {
+        ba_lm_blocks(D, lp, W, sfi, h, ns);
+        ba_wave_fence();
+        double lamk = D.lambda;             // candidate c0 + k: lambda * 10^k, the sequence of the sequential policy
+        for (int k = 0; k < nc; k++, lamk *= 10.0) {
+            double* Sacc = LDS_S ? Sloc + (size_t)k * sys : SBase + (size_t)(c0 + k) * D.sysStride;
+            double* racc = Sacc + (size_t)n * n;
+            double Hi[9];
+            ba_hll_inverse(h, lamk, Hi);
             for (int e = lane; e < ns * 18; e += 64) {
                 const int s = e / 18, ij = e - s * 18, i = ij / 3, j = ij - i * 3;
                 const double* w = W + s * 18 + i * 3;
                 WH[e] = w[0] * Hi[j] + w[1] * Hi[3 + j] + w[2] * Hi[6 + j];
             }
-        }
-        __syncthreads();
-        if (act) {
+            ba_wave_fence();
             // S -= W_s1 Hll^-1 W_s2^T for s1 <= s2 (upper block triangle), rhs -= W_s1 Hll^-1 bl
             for (int s1 = 0; s1 < ns; s1++) {
                 const int k1 = sfi[s1];
@@ -539,32 +556,40 @@ __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_schur(BaDev D, int m
                 }
                 if (lane < 6) {
                     const double* a = WH + s1 * 18 + lane * 3;
-                    atomicAdd(&racc[6 * k1 + lane], -(a[0] * bl[0] + a[1] * bl[1] + a[2] * bl[2]));
+                    atomicAdd(&racc[6 * k1 + lane], -(a[0] * h[6] + a[1] * h[7] + a[2] * h[8]));
                 }
             }
-            // Hpp and bp from this landmark's observations of free keyframes
-            const int f0 = D.lpStart[lp], f1 = D.lpStart[lp + 1];
-            for (int e = lane; e < (f1 - f0) * 27; e += 64) {
-                const int f = f0 + e / 27, q = e % 27;
-                const int fi = D.facFi[f];
-                if (fi < 0) continue;
-                const double* o = D.facJ + (size_t)f * 20;
-                if (q < 21) {
-                    int i = 0, rem = q;
-                    while (rem >= 6 - i) { rem -= 6 - i; i++; }
-                    const int j = i + rem;
-                    atomicAdd(&Sacc[(size_t)(6 * fi + i) * n + 6 * fi + j], o[2 + i] * o[2 + j] + o[8 + i] * o[8 + j]);
-                } else {
-                    const int i = q - 21;
-                    atomicAdd(&racc[6 * fi + i], -(o[2 + i] * o[0] + o[8 + i] * o[1]));
-                }
-            }
+            ba_wave_fence();        // WH is rewritten for the next candidate
         }
-        __syncthreads();
+        // Hpp and bp from this landmark's observations of free keyframes (the same for every candidate)
+        const int f0 = D.lpStart[lp], f1 = D.lpStart[lp + 1];
+        for (int e = lane; e < (f1 - f0) * 27; e += 64) {
+            const int f = f0 + e / 27, q = e % 27;
+            const int fi = D.facFi[f];
+            if (fi < 0) continue;
+            const double* o = D.facJ + (size_t)f * 20;
+            size_t idx;
+            double val;
+            if (q < 21) {
+                int i = 0, rem = q;
+                while (rem >= 6 - i) { rem -= 6 - i; i++; }
+                const int j = i + rem;
+                idx = (size_t)(6 * fi + i) * n + 6 * fi + j;
+                val = o[2 + i] * o[2 + j] + o[8 + i] * o[8 + j];
+            } else {
+                const int i = q - 21;
+                idx = (size_t)n * n + 6 * fi + i;
+                val = -(o[2 + i] * o[0] + o[8 + i] * o[1]);
+            }
+            for (int k = 0; k < nc; k++) atomicAdd((LDS_S ? Sloc + (size_t)k * sys : SBase + (size_t)(c0 + k) * D.sysStride) + idx, val);
+        }
     }
     if (LDS_S) {
-        double* dst = D.Spart + (size_t)blockIdx.x * ((size_t)n * n + n);
-        for (int i = threadIdx.x; i < n * n + n; i += nt) dst[i] = Sloc[i];
+        __syncthreads();
+        for (int k = 0; k < nc; k++) {
+            double* dst = SpartBase + (size_t)(c0 + k) * D.spartStride + (size_t)blockIdx.x * sys;
+            for (int i = threadIdx.x; i < (int)sys; i += nt) dst[i] = Sloc[(size_t)k * sys + i];
+        }
     }
 }
 
@@ -1151,11 +1176,14 @@ __global__ __launch_bounds__(64) void k_ba_solve_mfma64(BaDev D) {
     if (lane == 0) D.flags[FLAG_FAIL + D.cand] = bad ? 1 : 0;
 }
 
-// back-substitution: dl = Hll^-1 (bl - sum_k W_k^T dp_k); trial landmark = cur + dl
-__global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_back(BaDev D, int maxSlots) {
+// back-substitution: dl = Hll^-1 (bl - sum_k W_k^T dp_k); trial landmark = cur + dl.  One wave per landmark;
+// allCand: the wave serves every lambda candidate from one build of Hll / bl / W (grid y = 1), else grid y = candidate.
+__global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_back(BaDev D, int maxSlots, int allCand) {
     extern __shared__ double sm[];
-    if (!ba_enter(D, BA_TRY, blockIdx.y)) return;
-    const double lambda = D.lambda;
+    const int c0 = allCand ? 0 : (int)blockIdx.y;
+    if (!ba_enter(D, BA_TRY, c0)) return;
+    const int nc = allCand ? D.NB : 1;
+    const int sel = ((const int*)(D.ctl + CTL_INTS))[CI_SEL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double* W = sm + (size_t)wave * (maxSlots * 18);
     const int nw = blockDim.x >> 6;
@@ -1163,33 +1191,38 @@ __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_back(BaDev D, int ma
     const int rounds = (D.Lp + gridDim.x * nw - 1) / (gridDim.x * nw);
     for (int rd = 0; rd < rounds; rd++) {
         const int lp = (rd * gridDim.x + blockIdx.x) * nw + wave;
-        const bool act = lp < D.Lp;
-        double Hi[9], bl[3];
+        if (lp >= D.Lp) break;
+        double h[9];
         int ns = 0;
-        if (act) ba_lm_blocks(D, lp, lambda, W, sfi, Hi, bl, ns);
-        __syncthreads();
-        if (act) {
+        ba_lm_blocks(D, lp, W, sfi, h, ns);
+        ba_wave_fence();
+        const int l = D.lpOrig[lp];
+        double lamk = D.lambda;
+        for (int k = 0; k < nc; k++, lamk *= 10.0) {
+            const double* dPk = D.dP + (size_t)k * D.n;         // (ba_enter already applied candidate c0)
+            double Hi[9];
+            ba_hll_inverse(h, lamk, Hi);
             double t[3] = {0, 0, 0};
             for (int e = lane; e < ns * 6; e += 64) {
                 const int s = e / 6, i = e - s * 6;
-                const double dp = D.dP[6 * sfi[s] + i];
+                const double dp = dPk[6 * sfi[s] + i];
                 const double* w = W + s * 18 + i * 3;
                 t[0] += w[0] * dp; t[1] += w[1] * dp; t[2] += w[2] * dp;
             }
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
+            for (int q = 0; q < 3; q++) {
 #pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) t[k] += __shfl_xor(t[k], d);
+                for (int d = 32; d >= 1; d >>= 1) t[q] += __shfl_xor(t[q], d);
             }
             if (lane < 3) {
-                const double u[3] = {bl[0] - t[0], bl[1] - t[1], bl[2] - t[2]};
+                const double u[3] = {h[6] - t[0], h[7] - t[1], h[8] - t[2]};
                 const double dl = Hi[3 * lane] * u[0] + Hi[3 * lane + 1] * u[1] + Hi[3 * lane + 2] * u[2];
-                D.dL[3 * (size_t)lp + lane] = dl;
-                const int l = D.lpOrig[lp];
-                D.lmTrial[3 * (size_t)l + lane] = D.lmCur[3 * (size_t)l + lane] + dl;
+                D.dL[(size_t)k * D.dLStride + 3 * (size_t)lp + lane] = dl;
+                double* lmT = D.lmBase + (size_t)ba_slot(sel, c0 + k, D.NB) * D.lmStride;
+                lmT[3 * (size_t)l + lane] = D.lmCur[3 * (size_t)l + lane] + dl;
             }
         }
-        __syncthreads();
+        ba_wave_fence();            // W / sfi are rewritten in the next round
     }
 }
 
@@ -1644,17 +1677,29 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         const bool ldsS = F <= BA_LDS_MAX_F;
         const size_t sysDoubles = (size_t)n * n + n;
         int schurWaves = BA_SCHUR_WAVES;
-        auto schur_lds = [&](int nw) { return (ldsS ? sysDoubles * sizeof(double) : 0) + (size_t)nw * 2 * maxSlots * 18 * sizeof(double) + (size_t)nw * maxSlots * sizeof(int) + 16; };
-        while (schurWaves > 4 && schur_lds(schurWaves) > 150 * 1024) schurWaves /= 2;
+        auto schur_lds = [&](int nw, int copies) { return (ldsS ? copies * sysDoubles * sizeof(double) : 0) + (size_t)nw * 2 * maxSlots * 18 * sizeof(double) + (size_t)nw * maxSlots * sizeof(int) + 16; };
+        // one workgroup for all candidates (W blocks built once) when NB copies of the system fit LDS with >= 8 waves
+        static const bool sharedEnv = !getenv("VSLAM_BA_NO_SHARED_W");
+        int sharedW = 0;
+        if (NB > 1 && sharedEnv && true) {
+            for (int nw : {16, 12, 8})
+                if (schur_lds(nw, NB) <= 150 * 1024) { sharedW = 1; schurWaves = nw; break; }
+        }
+        if (!sharedW) while (schurWaves > 4 && schur_lds(schurWaves, 1) > 150 * 1024) schurWaves /= 2;
         const int lmBlocks = std::max(1, std::min((Lp + schurWaves - 1) / schurWaves, nCU));
+        int backWaves = BA_SCHUR_WAVES;
+        auto back_lds = [&](int nw) { return (size_t)nw * maxSlots * 18 * sizeof(double) + (size_t)nw * maxSlots * sizeof(int) + 16; };
+        while (backWaves > 1 && back_lds(backWaves) > 150 * 1024) backWaves /= 2;
+        const int backBlocks = std::max(1, std::min((Lp + backWaves - 1) / backWaves, nCU));
         D.partialStride = (size_t)2 * obsBlocks + 2 * (size_t)std::max(NE, 1);
         VS_HIP(d_partial.alloc(D.partialStride * NB));
         D.partial = d_partial.p;
         D.spartStride = sysDoubles * lmBlocks;
         if (ldsS) VS_HIP(d_Spart.alloc(D.spartStride * NB));
         D.Spart = d_Spart.p;
-        const size_t schurLds = schur_lds(schurWaves);
-        const size_t backLds = (size_t)schurWaves * maxSlots * 18 * sizeof(double) + (size_t)schurWaves * maxSlots * sizeof(int) + 16;
+        const size_t schurLds = schur_lds(schurWaves, sharedW ? NB : 1);
+        const size_t backLds = back_lds(backWaves);
+        const int sharedBack = (NB > 1 && sharedEnv) ? 1 : 0;
         const int ldA = ((n + 31) / 32) * 32 + 1;     // row stride = 1 (mod 32) doubles: conflict-free row-per-lane access
         const size_t solveLdsBytes = ((size_t)n * ldA + n + 8) * sizeof(double);
         const bool solveLds = solveLdsBytes <= 150 * 1024;
@@ -1690,10 +1735,10 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
             }
             t = g_baTimer.begin("ba_schur");
             if (n > 0) {
-                if (ldsS) hipLaunchKernelGGL(k_ba_schur<true>, dim3(lmBlocks, NB), dim3(64 * schurWaves), schurLds, stream, D, maxSlots);
+                if (ldsS) hipLaunchKernelGGL(k_ba_schur<true>, dim3(lmBlocks, sharedW ? 1 : NB), dim3(64 * schurWaves), schurLds, stream, D, maxSlots, sharedW);
                 else {
                     VS_HIP(hipMemsetAsync(d_S.p, 0, sysStride * NB * sizeof(double), stream));
-                    hipLaunchKernelGGL(k_ba_schur<false>, dim3(lmBlocks, NB), dim3(64 * schurWaves), schurLds, stream, D, maxSlots);
+                    hipLaunchKernelGGL(k_ba_schur<false>, dim3(lmBlocks, sharedW ? 1 : NB), dim3(64 * schurWaves), schurLds, stream, D, maxSlots, sharedW);
                 }
             }
             g_baTimer.end(t);
@@ -1707,7 +1752,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
                                     solveLds ? solveLdsBytes : 64, stream, D, solveLds ? 1 : 0, solveLds ? ldA : n);
             g_baTimer.end(t);
             t = g_baTimer.begin("ba_back");
-            if (Lp) hipLaunchKernelGGL(k_ba_back, dim3(lmBlocks, NB), dim3(64 * schurWaves), backLds, stream, D, maxSlots);
+            if (Lp) hipLaunchKernelGGL(k_ba_back, dim3(backBlocks, sharedBack ? 1 : NB), dim3(64 * backWaves), backLds, stream, D, maxSlots, sharedBack);
             g_baTimer.end(t);
             t = g_baTimer.begin("ba_eval");
             hipLaunchKernelGGL(k_ba_factors<1>, dim3(facBlocks, NB), dim3(256), 0, stream, D, nObs, fuseCtl, relTol, absTol);
