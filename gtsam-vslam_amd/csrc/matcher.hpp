@@ -78,6 +78,7 @@ struct vslam_matcher {
     double* d_imuBuf = nullptr;      // IMU scratch: samples, dts, DPim, information, state io
     int imuCap = 0;
     void* imuPim = nullptr; double* imuLam = nullptr; double* imuIo = nullptr;   // views into d_imuBuf
+    double* imuPred = nullptr;      // DNav predicted from (T_wc_prev, velocity_prev, bias_prev) by the pre-integration kernel
     double imuParams[64] = {0};      // DImuParams of the current frame
     double imuSi[15] = {0}, imuBiasPrev[6] = {0};
     vslam_status imu_setup(const vslam_imu_input* imu, double lastDt = 0.0);

@@ -28,7 +28,10 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_lm(PoseArgs A) {
     if (A.Mdev) A.M = min(A.M, *A.Mdev);
     const int M = A.M;
 
-    pose_build_factors(A);
+    __shared__ float sLvl[MAX_LEVELS];
+    __shared__ int sCntTab[2 * POSE_BATCH * (POSE_NT / 64)];
+    pose_stage_levels(A, sLvl);
+    const int nF = pose_build_factors(A, sLvl, sCntTab);
     if (tid == 0) {
         DPose Tcw;
         pose_from_rm16(A.poseIO, Tcw);
@@ -39,9 +42,8 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_lm(PoseArgs A) {
 
     auto local_error = [&](const DPose& T) {
         double e = 0;
-        for (int i = tid; i < M; i += POSE_NT) {
+        for (int i = tid; i < nF; i += POSE_NT) {
             const double* f = A.factors + (size_t)i * 8;
-            if (f[0] < 0) continue;
             double r[3];
             pose_factor_eval(f, T, A, r, nullptr);
             e += r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
@@ -70,21 +72,11 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_lm(PoseArgs A) {
 #pragma unroll
             for (int k = 0; k < 28; k++) v[k] = 0;
             const DPose T = sCur;
-            for (int i = tid; i < M; i += POSE_NT) {
+            for (int i = tid; i < nF; i += POSE_NT) {
                 const double* f = A.factors + (size_t)i * 8;
-                if (f[0] < 0) continue;
-                double r[3], J[3][6];
-                const int rows = pose_factor_eval(f, T, A, r, J);
-                for (int a = 0; a < rows; a++) {
-                    int k = 0;
-#pragma unroll
-                    for (int p = 0; p < 6; p++) {
-#pragma unroll
-                        for (int q2 = p; q2 < 6; q2++) v[k++] += J[a][p] * J[a][q2];
-                    }
-#pragma unroll
-                    for (int p = 0; p < 6; p++) v[21 + p] -= J[a][p] * r[a];
-                }
+                PoseLin L;
+                pose_factor_lin(f, T, A, L);
+                pose_acc_factor(L, v);
             }
             block_reduce<28>(v, red, acc);
             if (tid == 0) {
@@ -170,7 +162,7 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_lm(PoseArgs A) {
     }
     __syncthreads();
 
-    pose_find_outliers(A, sTcw, sCnt);
+    pose_find_outliers(A, sTcw, sCnt, sLvl);
     if (tid == 0) { A.out[0] = sCnt[0]; A.out[1] = sCnt[1]; }
 }
 

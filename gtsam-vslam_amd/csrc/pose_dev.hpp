@@ -74,6 +74,81 @@ __device__ __forceinline__ int pose_factor_eval(const double* f, const DPose& T,
     return rows;
 }
 
+// ---- linearisation of one factor in canonical row form --------------------------------------------------------
+// Every factor is   row A: a u-row (left u, or the only u of a mono factor)
+//                   row B: the right-u row of a stereo factor (all zero otherwise)
+//                   row C: the v-row
+// which is the reference's row order with an all-zero row inserted for mono factors (adding exact zeros changes
+// nothing).  A u-row has al = (a0, 0, a2), a v-row al = (0, a1, a2); with S = [q]x the products against the
+// structural zeros of al and S are dropped (they are exact zeros in the general formula), so are the products
+// against the structurally zero Jacobian entry (index 4 of a u-row, index 3 of a v-row) in J^T J.
+struct PoseLin { double JA[6], JB[6], JC[6], rA, rB, rC; };
+
+__device__ __forceinline__ void pose_row_u(double a0, double a2, double x, double y, double z, double is, double* J) {
+    J[0] = (a2 * -y) * is;
+    J[1] = (a0 * -z + a2 * x) * is;
+    J[2] = (a0 * y) * is;
+    J[3] = -a0 * is; J[4] = 0.0; J[5] = -a2 * is;
+}
+__device__ __forceinline__ void pose_row_v(double a1, double a2, double x, double y, double z, double is, double* J) {
+    J[0] = (a1 * z + a2 * -y) * is;
+    J[1] = (a2 * x) * is;
+    J[2] = (a1 * -x) * is;
+    J[3] = 0.0; J[4] = -a1 * is; J[5] = -a2 * is;
+}
+__device__ __forceinline__ void pose_factor_lin(const double* f, const DPose& T, const PoseArgs& A, PoseLin& L) {
+    const int type = (int)f[0];
+    const double d[3] = {f[1] - T.t[0], f[2] - T.t[1], f[3] - T.t[2]};
+    double q[3];
+    mat3T_vec(T.R, d, q);
+    const double is = f[7];
+#pragma unroll
+    for (int c = 0; c < 6; c++) { L.JA[c] = 0; L.JB[c] = 0; L.JC[c] = 0; }
+    if (q[2] <= 0) {                 // cheirality: constant residual, zero Jacobian
+        const double rr = 2.0 * A.fx * is;
+        L.rA = rr; L.rB = type == 0 ? rr : 0.0; L.rC = rr;
+        return;
+    }
+    const double x = q[0], y = q[1], z = q[2], iz = 1.0 / z;
+    const double xb = x - A.b;
+    const double xx = type == 2 ? xb : x;             // mono factor of the right camera: its own u
+    const double a0 = A.fx * iz, a1 = A.fy * iz;
+    if (type == 0) {
+        L.rA = (A.fx * x * iz + A.cx - f[4]) * is;
+        L.rB = (A.fx * xb * iz + A.cx - f[5]) * is;
+        L.rC = (A.fy * y * iz + A.cy - f[6]) * is;
+        pose_row_u(a0, -A.fx * x * iz * iz, x, y, z, is, L.JA);
+        pose_row_u(a0, -A.fx * xb * iz * iz, x, y, z, is, L.JB);
+    } else {
+        L.rA = (A.fx * xx * iz + A.cx - f[4]) * is;
+        L.rB = 0.0;
+        L.rC = (A.fy * y * iz + A.cy - f[5]) * is;
+        pose_row_u(a0, -A.fx * xx * iz * iz, x, y, z, is, L.JA);
+    }
+    pose_row_v(a1, -A.fy * y * iz * iz, x, y, z, is, L.JC);
+}
+// v[0..20] += upper triangle of J^T J, v[21..26] -= J^T r, for one row whose entry `Z` is structurally zero
+template <int Z>
+__device__ __forceinline__ void pose_acc_row(const double* J, double r, double* v) {
+    int k = 0;
+#pragma unroll
+    for (int p = 0; p < 6; p++) {
+#pragma unroll
+        for (int q2 = p; q2 < 6; q2++) {
+            if (p != Z && q2 != Z) v[k] += J[p] * J[q2];
+            k++;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 6; p++) if (p != Z) v[21 + p] -= J[p] * r;
+}
+// one factor into the 28 (+1: sum r^2) block-wide accumulators
+__device__ __forceinline__ void pose_acc_factor(const PoseLin& L, double* v) {
+    pose_acc_row<4>(L.JA, L.rA, v);
+    pose_acc_row<4>(L.JB, L.rB, v);
+    pose_acc_row<3>(L.JC, L.rC, v);
+}
+
 template <int NV>
 __device__ __forceinline__ void block_reduce(double (&v)[NV], double* red, double* out) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -105,94 +180,188 @@ __device__ __forceinline__ bool check2d(const double* pc, float ox, float oy, co
 }
 
 
-// factor list of estimatePoseGTSAM (src/FeatureTracker.cpp:219-299); every thread of the workgroup calls it
-__device__ __forceinline__ void pose_build_factors(const PoseArgs& A) {
-    const int tid = threadIdx.x, M = A.M;
-    for (int i = tid; i < M; i += POSE_NT) {
-        double* f = A.factors + (size_t)i * 8;
-        int type = -1;
-        const int first = A.matches[2 * i], second = A.matches[2 * i + 1];
-        if (!A.mpsOut[i] && !A.mpOut[i]) {
-            if (first >= 0) {
-                if (A.inFrame[i]) {
-                    const vslam_keypoint kl = A.kpsL[first];
-                    f[7] = 1.0 / (1.0 / (double)A.invSigma[kl.octave]);
-                    if (!A.monoOnly && A.closef[first] && second >= 0) {
-                        type = 0;
-                        f[4] = kl.x; f[5] = A.kpsR[second].x; f[6] = kl.y;
-                    } else {
-                        type = 1;
-                        f[4] = kl.x; f[5] = kl.y; f[6] = 0;
-                    }
-                }
-            } else if (second >= 0 && !A.monoOnly) {
-                if (A.inFrameR[i]) {
-                    const vslam_keypoint kr = A.kpsR[second];
-                    f[7] = 1.0 / (1.0 / (double)A.invSigma[kr.octave]);
-                    type = 2;
-                    f[4] = kr.x; f[5] = kr.y; f[6] = 0;
-                }
+// Both passes below are gather chains (match -> keypoint -> level table) over a few thousand points with ONE
+// workgroup: each thread handles POSE_BATCH points per trip and issues the loads of one dependency level for all of
+// them before any is consumed (the stores of a trip come last, so nothing can alias a pending load).  The level
+// table is dynamically indexed: it is staged in LDS (`lvl`, MAX_LEVELS floats, filled by pose_stage_levels).
+constexpr int POSE_BATCH = 4;
+
+__device__ __forceinline__ void pose_stage_levels(const PoseArgs& A, float* lvl) {
+    if (threadIdx.x < MAX_LEVELS) lvl[threadIdx.x] = A.invSigma[threadIdx.x];
+    __syncthreads();
+}
+
+// factor list of estimatePoseGTSAM (src/FeatureTracker.cpp:219-299); every thread of the workgroup calls it.
+// Only about a third of the active map points carry a factor: the list is COMPACTED (map-point order kept, so the
+// block-wide sums downstream stay deterministic) and the LM loops run over nF factors instead of M slots.
+// cntTab: 2 * POSE_BATCH * (POSE_NT / 64) ints of LDS.  Returns nF (the same value in every thread).
+__device__ __forceinline__ int pose_build_factors(const PoseArgs& A, const float* lvl, int* cntTab) {
+    constexpr int NW = POSE_NT / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, M = A.M;
+    int run = 0, trip = 0;
+    for (int base0 = 0; base0 < M; base0 += POSE_BATCH * POSE_NT, trip++) {
+        const int base = base0 + tid;
+        int first[POSE_BATCH], second[POSE_BATCH], use[POSE_BATCH];
+        double px[POSE_BATCH], py[POSE_BATCH], pz[POSE_BATCH];
+#pragma unroll
+        for (int u = 0; u < POSE_BATCH; u++) {
+            const int i = base + u * POSE_NT;
+            first[u] = second[u] = -1; use[u] = 0; px[u] = py[u] = pz[u] = 0;
+            if (i < M) {
+                first[u] = A.matches[2 * i]; second[u] = A.matches[2 * i + 1];
+                const bool live = !A.mpsOut[i] && !A.mpOut[i];
+                // bit 0: left factor candidate, bit 1: right-only candidate
+                use[u] = (live && A.inFrame[i] ? 1 : 0) | (live && A.inFrameR[i] ? 2 : 0);
+                px[u] = A.points[3 * i]; py[u] = A.points[3 * i + 1]; pz[u] = A.points[3 * i + 2];
             }
         }
-        f[0] = (double)type;
-        f[1] = A.points[3 * i]; f[2] = A.points[3 * i + 1]; f[3] = A.points[3 * i + 2];
+        float kx[POSE_BATCH], ky[POSE_BATCH], rx[POSE_BATCH];
+        int oct[POSE_BATCH], type[POSE_BATCH];
+#pragma unroll
+        for (int u = 0; u < POSE_BATCH; u++) {
+            type[u] = -1; kx[u] = ky[u] = rx[u] = 0; oct[u] = 0;
+            if (first[u] >= 0) {
+                if (use[u] & 1) {
+                    const vslam_keypoint kl = A.kpsL[first[u]];
+                    kx[u] = kl.x; ky[u] = kl.y; oct[u] = kl.octave;
+                    type[u] = 1;
+                    if (!A.monoOnly && second[u] >= 0 && A.closef[first[u]]) { type[u] = 0; rx[u] = A.kpsR[second[u]].x; }
+                }
+            } else if (second[u] >= 0 && !A.monoOnly && (use[u] & 2)) {
+                const vslam_keypoint kr = A.kpsR[second[u]];
+                kx[u] = kr.x; ky[u] = kr.y; oct[u] = kr.octave;
+                type[u] = 2;
+            }
+        }
+        // positions in map-point order: point index = base0 + u * POSE_NT + wave * 64 + lane
+        int* tab = cntTab + (trip & 1) * POSE_BATCH * NW;
+        int pre[POSE_BATCH];
+#pragma unroll
+        for (int u = 0; u < POSE_BATCH; u++) {
+            const unsigned long long m = __ballot(type[u] >= 0);
+            pre[u] = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) tab[u * NW + wave] = __popcll(m);
+        }
+        __syncthreads();
+        int offU[POSE_BATCH];
+#pragma unroll
+        for (int u = 0; u < POSE_BATCH; u++) {
+            offU[u] = 0;
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                if (w == wave) offU[u] = run;
+                run += tab[u * NW + w];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < POSE_BATCH; u++) {
+            if (type[u] < 0) continue;
+            double* f = A.factors + (size_t)(offU[u] + pre[u]) * 8;
+            f[7] = 1.0 / (1.0 / (double)lvl[oct[u]]);
+            if (type[u] == 0) { f[4] = kx[u]; f[5] = rx[u]; f[6] = ky[u]; }
+            else { f[4] = kx[u]; f[5] = ky[u]; f[6] = 0; }
+            f[0] = (double)type[u];
+            f[1] = px[u]; f[2] = py[u]; f[3] = pz[u];
+        }
     }
+    return run;
 }
 
 // findOutliersR (src/FeatureTracker.cpp:582-649); sCnt = {inliers, stereo} in LDS, zeroed by the caller;
 // every thread of the workgroup calls it
-__device__ __forceinline__ void pose_find_outliers(const PoseArgs& A, const DPose& Tcw, int* sCnt) {
+__device__ __forceinline__ void pose_find_outliers(const PoseArgs& A, const DPose& Tcw, int* sCnt, const float* lvl) {
     const int tid = threadIdx.x, M = A.M;
-    for (int i = tid; i < M; i += POSE_NT) {           // pass A0: reset firstFail for touched keypoints
-        const int first = A.matches[2 * i];
-        if (first >= 0) A.firstFail[first] = INT_MAX;
+    for (int base = tid; base < M; base += POSE_BATCH * POSE_NT) {     // pass A0: reset firstFail for touched keypoints
+        int first[POSE_BATCH];
+#pragma unroll
+        for (int u = 0; u < POSE_BATCH; u++) { const int i = base + u * POSE_NT; first[u] = i < M ? A.matches[2 * i] : -1; }
+#pragma unroll
+        for (int u = 0; u < POSE_BATCH; u++) if (first[u] >= 0) A.firstFail[first[u]] = INT_MAX;
     }
     __syncthreads();
     int nIn = 0;
-    for (int i = tid; i < M; i += POSE_NT) {           // pass A: classify
-        const int first = A.matches[2 * i], second = A.matches[2 * i + 1];
-        int code = 0;
-        const double p[3] = {A.points[3 * i], A.points[3 * i + 1], A.points[3 * i + 2]};
-        double pc[3], pr[3];
-        mat3_vec(Tcw.R, p, pc);
-        for (int k = 0; k < 3; k++) pc[k] += Tcw.t[k];
-        pr[0] = pc[0] - A.b; pr[1] = pc[1]; pr[2] = pc[2];
-        bool handled = false, right = false;
-        int nIdx = -1;
-        if (first >= 0) { if (A.inFrame[i]) { handled = true; nIdx = first; } }
-        else if (second >= 0 && !A.monoOnly) { if (A.inFrameR[i]) { handled = true; right = true; nIdx = second; } }
-        if (handled) {
-            const vslam_keypoint k = right ? A.kpsR[nIdx] : A.kpsL[nIdx];
-            const bool outlier = check2d(right ? pr : pc, k.x, k.y, A, (double)A.invSigma[k.octave]);
-            A.mpsOut[i] = outlier ? 1 : 0;
-            if (!outlier) {
-                nIn++;
-                const double z = right ? pr[2] : pc[2];
-                if (!A.monoOnly && z < (double)A.closeTh && !right && A.closef[nIdx] && second >= 0) {
-                    const vslam_keypoint kr = A.kpsR[second];
-                    const bool fail = check2d(pr, kr.x, kr.y, A, (double)A.invSigma[kr.octave]);
-                    code = fail ? 3 : 1;
-                    if (fail) atomicMin(&A.firstFail[nIdx], i);
+    for (int base = tid; base < M; base += POSE_BATCH * POSE_NT) {     // pass A: classify
+        int first[POSE_BATCH], second[POSE_BATCH], nIdx[POSE_BATCH];
+        bool right[POSE_BATCH];
+        double pc[POSE_BATCH][3];
+#pragma unroll
+        for (int u = 0; u < POSE_BATCH; u++) {
+            const int i = base + u * POSE_NT;
+            first[u] = second[u] = nIdx[u] = -1; right[u] = false;
+            pc[u][0] = pc[u][1] = pc[u][2] = 0;
+            if (i < M) {
+                first[u] = A.matches[2 * i]; second[u] = A.matches[2 * i + 1];
+                const double p[3] = {A.points[3 * i], A.points[3 * i + 1], A.points[3 * i + 2]};
+                mat3_vec(Tcw.R, p, pc[u]);
+                for (int k = 0; k < 3; k++) pc[u][k] += Tcw.t[k];
+                if (first[u] >= 0) { if (A.inFrame[i]) nIdx[u] = first[u]; }
+                else if (second[u] >= 0 && !A.monoOnly) { if (A.inFrameR[i]) { right[u] = true; nIdx[u] = second[u]; } }
+            }
+        }
+        float kx[POSE_BATCH], ky[POSE_BATCH], rkx[POSE_BATCH], rky[POSE_BATCH];
+        int oct[POSE_BATCH], roct[POSE_BATCH];
+        bool stereoCand[POSE_BATCH];
+#pragma unroll
+        for (int u = 0; u < POSE_BATCH; u++) {
+            kx[u] = ky[u] = rkx[u] = rky[u] = 0; oct[u] = roct[u] = 0; stereoCand[u] = false;
+            if (nIdx[u] >= 0) {
+                const vslam_keypoint k = right[u] ? A.kpsR[nIdx[u]] : A.kpsL[nIdx[u]];
+                kx[u] = k.x; ky[u] = k.y; oct[u] = k.octave;
+                // the right observation of a close stereo point is only looked at for an inlier; fetch it anyway
+                if (!A.monoOnly && !right[u] && second[u] >= 0 && A.closef[nIdx[u]]) {
+                    const vslam_keypoint kr = A.kpsR[second[u]];
+                    rkx[u] = kr.x; rky[u] = kr.y; roct[u] = kr.octave; stereoCand[u] = true;
                 }
             }
         }
-        A.code[i] = code;
+#pragma unroll
+        for (int u = 0; u < POSE_BATCH; u++) {
+            const int i = base + u * POSE_NT;
+            if (i >= M) continue;
+            int code = 0;
+            if (nIdx[u] >= 0) {
+                const double pr[3] = {pc[u][0] - A.b, pc[u][1], pc[u][2]};
+                const bool outlier = check2d(right[u] ? pr : pc[u], kx[u], ky[u], A, (double)lvl[oct[u]]);
+                A.mpsOut[i] = outlier ? 1 : 0;
+                if (!outlier) {
+                    nIn++;
+                    const double z = pc[u][2];          // (pr[2] == pc[2])
+                    if (stereoCand[u] && z < (double)A.closeTh) {
+                        const bool fail = check2d(pr, rkx[u], rky[u], A, (double)lvl[roct[u]]);
+                        code = fail ? 3 : 1;
+                        if (fail) atomicMin(&A.firstFail[nIdx[u]], i);
+                    }
+                }
+            }
+            A.code[i] = code;
+        }
     }
     __syncthreads();
     int nSt = 0;
-    for (int i = tid; i < M; i += POSE_NT) {           // pass B: apply in reference order
-        const int code = A.code[i];
-        if (!code) continue;
-        const int nIdx = A.matches[2 * i];
-        const int ff = A.firstFail[nIdx];
-        if (code == 1) { if (i < ff) nSt++; }
-        else if (i == ff) {
-            A.depth[nIdx] = -1.f;
-            A.closef[nIdx] = 0;
-            const int rIdx = A.rightIdxs[nIdx];
-            A.rightIdxs[nIdx] = -1;
-            if (rIdx >= 0) A.leftIdxs[rIdx] = -1;
-            A.matches[2 * i + 1] = -1;
+    for (int base = tid; base < M; base += POSE_BATCH * POSE_NT) {     // pass B: apply in reference order
+        int code[POSE_BATCH], nIdx[POSE_BATCH], ff[POSE_BATCH];
+#pragma unroll
+        for (int u = 0; u < POSE_BATCH; u++) {
+            const int i = base + u * POSE_NT;
+            code[u] = i < M ? A.code[i] : 0;
+            nIdx[u] = i < M ? A.matches[2 * i] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < POSE_BATCH; u++) ff[u] = code[u] ? A.firstFail[nIdx[u]] : 0;       // (code != 0 implies nIdx >= 0)
+#pragma unroll
+        for (int u = 0; u < POSE_BATCH; u++) {
+            const int i = base + u * POSE_NT;
+            if (!code[u]) continue;
+            if (code[u] == 1) { if (i < ff[u]) nSt++; }
+            else if (i == ff[u]) {
+                const int k = nIdx[u];
+                A.depth[k] = -1.f;
+                A.closef[k] = 0;
+                const int rIdx = A.rightIdxs[k];
+                A.rightIdxs[k] = -1;
+                if (rIdx >= 0) A.leftIdxs[rIdx] = -1;
+                A.matches[2 * i + 1] = -1;
+            }
         }
     }
     if (nIn) atomicAdd(&sCnt[0], nIn);

@@ -17,7 +17,7 @@ constexpr int PIM_CHUNK = 12;        // samples whose step matrices are held in 
 __global__ __launch_bounds__(256) void k_imu_preintegrate(DImuParams P, const double* __restrict__ samples,
                                                           const double* __restrict__ dts, int n,
                                                           const double* __restrict__ biasHat, DPim* __restrict__ pimOut,
-                                                          double* __restrict__ Lam) {
+                                                          double* __restrict__ Lam, DNav si, DNav* __restrict__ predOut) {
     __shared__ DPim pim;
     __shared__ double sA[PIM_CHUNK][81], sB[PIM_CHUNK][27], sC[PIM_CHUNK][27], sF[PIM_CHUNK][225], sG[PIM_CHUNK][225];
     __shared__ double sState[PIM_CHUNK + 1][9];
@@ -80,15 +80,17 @@ __global__ __launch_bounds__(256) void k_imu_preintegrate(DImuParams P, const do
         if (tid < 9) pim.preint[tid] = sState[nc][tid];
         __syncthreads();
     }
-    // information matrix Lambda = cov^-1 (Cholesky + 15 column solves), one wave
+    // information matrix Lambda = cov^-1 (Cholesky + 15 column solves), one wave; next to it a second wave predicts
+    // the state at j from (x_i, v_i, biasHat) - the initial value, prior mean and factor prediction of the pose solve
     if (tid < 64) wave_spd_inverse<15>(pim.cov, FP, Lam);
+    else if (tid == 64) { DNav pr; pim_predict(pim, P, si, pr); *predOut = pr; }
     for (int i = tid; i < (int)(sizeof(DPim) / sizeof(double)); i += 256) ((double*)pimOut)[i] = ((double*)&pim)[i];
 }
 
 struct ImuLmArgs {
     int ldsFactors;          // capacity (factors) of the dynamic LDS buffer
-    const DPim* pim; const double* Lam; DImuParams P;
-    DNav si;                 // x0, v0
+    const DPim* pim; const double* Lam;
+    const DNav* pred;        // state predicted from (x0, v0, b0) by k_imu_preintegrate
     double biasPrev[6];      // b0
     double* io;              // out: vel(3), bias(6)
 };
@@ -96,76 +98,78 @@ struct ImuLmArgs {
 #ifdef VSLAM_POSE_STAMPS
 __device__ long long g_ps[16];
 #define PS_ACC(k) do { if (threadIdx.x == 0) { const long long n_ = clock64(); g_ps[k] += n_ - ps_t; ps_t = n_; } } while (0)
+#define PS_ACCW(k) do { { const long long n_ = clock64(); g_ps[k] += n_ - ps_t; ps_t = n_; } } while (0)
 #define PS_CNT(k) do { if (threadIdx.x == 0) g_ps[k] += 1; } while (0)
 #else
 #define PS_ACC(k) do {} while (0)
+#define PS_ACCW(k) do {} while (0)
 #define PS_CNT(k) do {} while (0)
 #endif
 
 // The single-thread sections of the solve are kept out of line: inlined into the kernel their temporaries
 // (dozens of 3x3 / 6x6 blocks) drive the register allocation of the factor-parallel loops into spilling.
 __device__ __noinline__ void imu_lin_serial(const DNav* pred, const double* biasHat, const DPose* T, const double* v, const double* b,
-                                            const DPose* priorT, double* r15, double* J, double* rp, double* Jp) {
+                                            double* r15, double* J) {
     imu_factor_eval(*pred, biasHat, T->R, T->t, v, b, r15, J);
+}
+// PriorFactor<Pose3>: Logmap(prior^-1 T) and its derivative
+__device__ __noinline__ void prior_lin_serial(const DPose* T, const DPose* priorT, double* rp, double* Jp) {
     DPose pi, d;
     pose_inverse(*priorT, pi);
     pose_compose(pi, *T, d);
     pose3_logmap(d, rp);
     pose3_logmap_derivative(d, Jp);
 }
-// sum of squares of the non-vision factors at (T, v, b): CombinedImuFactor (information Lam), bias BetweenFactor,
-// the two unit-covariance priors
-__device__ __noinline__ double imu_nonvision_error(const DNav* pred, const double* biasHat, const double* Lam, const double* biasPrev,
-                                                   const DPose* priorT, const double* priorV, const DPose* T, const double* v,
-                                                   const double* b) {
+// The sum of squares of the non-vision factors at (T, v, b) - CombinedImuFactor (information Lam), bias BetweenFactor,
+// the two unit-covariance priors - is accumulated in this order: IMU quadratic form, bias terms (imu_error_head,
+// one wave), then the pose-prior residual (prior_residual_serial, another wave) and the velocity prior (summed by
+// the thread that closes the trial).
+__device__ __noinline__ double imu_error_head(const DNav* pred, const double* biasHat, const double* Lam, const double* biasPrev,
+                                              const DPose* T, const double* v, const double* b) {
     double r[15];
-#ifdef VSLAM_POSE_STAMPS
-    long long ps_t = clock64();
-#endif
     imu_factor_eval(*pred, biasHat, T->R, T->t, v, b, r, nullptr);
-    PS_ACC(12);
     double e = 0;
     for (int i = 0; i < 15; i++) { double s = 0; for (int j = 0; j < 15; j++) s += Lam[i * 15 + j] * r[j]; e += r[i] * s; }
-    PS_ACC(13);
     for (int i = 0; i < 6; i++) { const double rb = (b[i] - biasPrev[i]) * 1e3; e += rb * rb; }
+    return e;
+}
+__device__ __noinline__ void prior_residual_serial(const DPose* T, const DPose* priorT, double* rp) {
     DPose pi, d;
     pose_inverse(*priorT, pi);
     pose_compose(pi, *T, d);
-    double rp[6];
     pose3_logmap(d, rp);
-    for (int i = 0; i < 6; i++) e += rp[i] * rp[i];
-    for (int i = 0; i < 3; i++) { const double rv = v[i] - priorV[i]; e += rv * rv; }
-    PS_ACC(14);
-    return e;
 }
-__device__ __noinline__ void imu_predict_serial(const DPim* pim, const DImuParams* P, const DNav* si, DNav* out) { pim_predict(*pim, *P, *si, *out); }
 __device__ __noinline__ void pose_retract_serial(const DPose* T, const double* xi, DPose* r) { pose_retract(*T, xi, *r); }
 
 __global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I) {
-    __shared__ double red[(POSE_NT / 64) * 28];
-    __shared__ double acc[28];
+    __shared__ double red[(POSE_NT / 64) * 29];
+    __shared__ double acc[29];
     __shared__ DPose sT, sT2, sPT, sTcw;
     __shared__ double sV[3], sB[6], sV2[3], sB2[6], sPV[3];
     __shared__ DNav sPred;
     __shared__ double sJ[225], sLJ[225], sH[225], sLam[225], sR15[15], sLr[15], sG[15], sDelta[15], sRp[6], sJp[36];
     __shared__ double sError, sLambda, sNewErr, sCurErr, sLin, sNV;
-    __shared__ int sPhase, sEval, sIter, sInner, sCnt[2];
+    __shared__ int sPhase, sEval, sIter, sInner, sCnt[2], sFirst;
     extern __shared__ double sFacLds[];
     const int tid = threadIdx.x;
     if (A.gate && *A.gate < A.gateMin) return;
     if (A.Mdev) A.M = min(A.M, *A.Mdev);
     const int M = A.M;
     if (I.ldsFactors >= M) A.factors = sFacLds;      // the factor list is read 6+ times: keep it in LDS when it fits
-    constexpr int VNT = POSE_NT - 64;                // waves 0..2 evaluate vision factors, wave 3 the IMU / prior algebra
+    constexpr int VNT = POSE_NT - 128;               // waves 0..1 evaluate vision factors; lane 0 of wave 2: pose-prior algebra,
+    constexpr int TPRIOR = VNT, TIMU = VNT + 64;     // lane 0 of wave 3: CombinedImuFactor algebra (all three concurrently)
 #ifdef VSLAM_POSE_STAMPS
     long long ps_t = clock64();
 #endif
 
-    pose_build_factors(A);
+    __shared__ float sLvl[MAX_LEVELS];
+    __shared__ int sCntTab[2 * POSE_BATCH * (POSE_NT / 64)];
+    pose_stage_levels(A, sLvl);
+    const int nF = pose_build_factors(A, sLvl, sCntTab);
     PS_ACC(0);
     if (tid < 225) sLam[tid] = I.Lam[tid];
     if (tid == 0) {
-        imu_predict_serial(I.pim, &I.P, &I.si, &sPred);          // prop_state: initial values, priors, factor prediction
+        sPred = *I.pred;                                         // prop_state: initial values, priors, factor prediction
         for (int i = 0; i < 9; i++) { sT.R[i] = sPred.R[i]; sPT.R[i] = sPred.R[i]; }
         for (int i = 0; i < 3; i++) { sT.t[i] = sPred.t[i]; sPT.t[i] = sPred.t[i]; sV[i] = sPred.v[i]; sPV[i] = sPred.v[i]; }
         for (int i = 0; i < 6; i++) sB[i] = I.biasPrev[i];
@@ -175,61 +179,44 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I
 
     auto vision_error = [&](const DPose& T) {
         double e = 0;
-        for (int i = tid; i < M && tid < VNT; i += VNT) {
+        for (int i = tid; i < nF && tid < VNT; i += VNT) {
             const double* f = A.factors + (size_t)i * 8;
-            if (f[0] < 0) continue;
             double r[3];
             pose_factor_eval(f, T, A, r, nullptr);
             e += r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
         }
         return e;
     };
-    auto nonvision_error = [&](const DPose& T, const double* v, const double* b) {      // thread 0 only
-        return imu_nonvision_error(&sPred, I.pim->biasHat, sLam, I.biasPrev, &sPT, sPV, &T, v, b);
-    };
+    __shared__ double sRpT[6];          // pose-prior residual of the trial point
 
-    {
-        if (tid == VNT) sNV = nonvision_error(sT, sV, sB);        // wave 3, under the vision pass of waves 0..2
-        double v1[1] = {vision_error(sT)};
-        block_reduce<1>(v1, red, acc);
-        if (tid == 0) {
-            sError = 0.5 * (acc[0] + sNV);
-            A.poseIO[16] = sError;
-            sCurErr = sError;
-            sPhase = (!(sError <= 0.0) && sIter < A.maxIterations) ? 0 : 2;
-        }
-        __syncthreads();
-    }
+    // The initial error is not a pass of its own: the first linearisation evaluates every factor at the same
+    // point, so its residuals give error(x0) with the very same arithmetic (sFirst below).
+    if (tid == 0) { sFirst = 1; sPhase = 0; sError = 0; sCurErr = 0; }
+    __syncthreads();
     PS_ACC(1);
 
     for (;;) {
         const int phase = sPhase;
         if (phase == 2) break;
         if (phase == 0) {
-            double v[28];
+            double v[29];
 #pragma unroll
-            for (int k = 0; k < 28; k++) v[k] = 0;
+            for (int k = 0; k < 29; k++) v[k] = 0;
             const DPose T = sT;
-            if (tid == VNT) imu_lin_serial(&sPred, I.pim->biasHat, &sT, sV, sB, &sPT, sR15, sJ, sRp, sJp);   // wave 3, concurrently
-            for (int i = tid; i < M && tid < VNT; i += VNT) {
+            // linearisation: three waves share the vision factors; the IMU factor is linearised by lane 0 of wave 3, the
+            // pose prior by lane 0 of wave 2 ahead of its vision share (the trial evaluation below splits 2 + 1 + 1)
+            constexpr int VL = POSE_NT - 64;
+            if (tid == TIMU) imu_lin_serial(&sPred, I.pim->biasHat, &sT, sV, sB, sR15, sJ);
+            else if (tid == TPRIOR) prior_lin_serial(&sT, &sPT, sRp, sJp);
+            for (int i = tid; i < nF && tid < VL; i += VL) {
                 const double* f = A.factors + (size_t)i * 8;
-                if (f[0] < 0) continue;
-                double r[3], J[3][6];
-                const int rows = pose_factor_eval(f, T, A, r, J);
-                for (int a = 0; a < rows; a++) {
-                    int k = 0;
-#pragma unroll
-                    for (int p = 0; p < 6; p++) {
-#pragma unroll
-                        for (int q2 = p; q2 < 6; q2++) v[k++] += J[a][p] * J[a][q2];
-                    }
-#pragma unroll
-                    for (int p = 0; p < 6; p++) v[21 + p] -= J[a][p] * r[a];
-                }
+                PoseLin L;
+                pose_factor_lin(f, T, A, L);
+                pose_acc_factor(L, v);
+                v[28] += L.rA * L.rA + L.rB * L.rB + L.rC * L.rC;
             }
-            block_reduce<28>(v, red, acc);
+            block_reduce<29>(v, red, acc);
             PS_ACC(2);
-            PS_ACC(3);
             if (tid < 225) {
                 const int i = tid / 15, c = tid % 15;
                 double s = 0;
@@ -262,9 +249,25 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I
                 else if (a < 9) s -= sV[a - 6] - sPV[a - 6];
                 else s -= 1e6 * (sB[a - 9] - I.biasPrev[a - 9]);
                 sG[a] = s;
+            } else if (tid == 240 && sFirst) {
+                // error(x0) of the non-vision factors, term by term in the order of the trial evaluation (imu_error_head, prior, velocity)
+                double e = 0;
+                for (int i = 0; i < 15; i++) e += sR15[i] * sLr[i];
+                for (int i = 0; i < 6; i++) { const double rb = (sB[i] - I.biasPrev[i]) * 1e3; e += rb * rb; }
+                for (int i = 0; i < 6; i++) e += sRp[i] * sRp[i];
+                for (int i = 0; i < 3; i++) { const double rv = sV[i] - sPV[i]; e += rv * rv; }
+                sNV = e;
             }
             __syncthreads();
-            if (tid == 0) { sCurErr = sError; sPhase = 1; }
+            if (tid == 0) {
+                if (sFirst) {
+                    sFirst = 0;
+                    sError = 0.5 * (acc[28] + sNV);
+                    A.poseIO[16] = sError;
+                    sCurErr = sError;
+                    sPhase = (!(sError <= 0.0) && sIter < A.maxIterations) ? 1 : 2;
+                } else { sCurErr = sError; sPhase = 1; }
+            }
             __syncthreads();
             PS_ACC(4); PS_CNT(10);
             continue;
@@ -289,10 +292,16 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I
         PS_ACC(6);
         __syncthreads();
         if (sEval) {
-            if (tid == VNT) sNV = nonvision_error(sT2, sV2, sB2);       // wave 3, under the vision pass
+            if (tid == TIMU) sNV = imu_error_head(&sPred, I.pim->biasHat, sLam, I.biasPrev, &sT2, sV2, sB2);   // wave 3 and
+            else if (tid == TPRIOR) prior_residual_serial(&sT2, &sPT, sRpT);                                  // wave 2, under the vision pass
             double v1[1] = {vision_error(sT2)};
             block_reduce<1>(v1, red, acc);
-            if (tid == 0) sNewErr = 0.5 * (acc[0] + sNV);
+            if (tid == 0) {
+                double e = sNV;
+                for (int i = 0; i < 6; i++) e += sRpT[i] * sRpT[i];
+                for (int i = 0; i < 3; i++) { const double rv = sV2[i] - sPV[i]; e += rv * rv; }
+                sNewErr = 0.5 * (acc[0] + e);
+            }
         }
         PS_ACC(7); PS_CNT(11);
         if (tid == 0) {
@@ -346,7 +355,7 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I
         for (int i = 0; i < 6; i++) I.io[3 + i] = sB[i];
     }
     __syncthreads();
-    pose_find_outliers(A, sTcw, sCnt);
+    pose_find_outliers(A, sTcw, sCnt, sLvl);
     if (tid == 0) { A.out[0] = sCnt[0]; A.out[1] = sCnt[1]; }
     PS_ACC(9);
 }
@@ -361,9 +370,9 @@ vslam_status vslam_matcher::imu_setup(const vslam_imu_input* imu, double lastDt)
     const int n = imu->n_samples;
     if (n > 0 && (!imu->acceleration || !imu->angular_velocity || !imu->timestamps_ns)) { set_error("IMU input: null array"); return VSLAM_ERR_INVALID; }
     if (n <= 0 || imu->hz <= 0) { set_error("IMU input: empty bucket"); return VSLAM_ERR_INVALID; }
-    // scratch layout: samples (6n) | dts (n) | biasHat (6) | DPim | Lambda (225); the io block lives in d_res
+    // scratch layout: samples (6n) | dts (n) | biasHat (6) | DPim | Lambda (225) | DNav prediction; the io block lives in d_res
     const size_t pimD = sizeof(DPim) / sizeof(double);
-    const size_t need = (size_t)7 * n + 6 + pimD + 225;
+    const size_t need = (size_t)7 * n + 6 + pimD + 225 + sizeof(DNav) / sizeof(double);
     VS_CHECK(ensure_res());
     if (!imuStream) {
         VS_HIP(hipStreamCreateWithFlags(&imuStream, hipStreamNonBlocking));
@@ -400,6 +409,7 @@ vslam_status vslam_matcher::imu_setup(const vslam_imu_input* imu, double lastDt)
     double* d_bias = d_dts + n;
     imuPim = (void*)(d_bias + 6);
     imuLam = (double*)imuPim + pimD;
+    imuPred = imuLam + 225;
     VS_HIP(hipMemcpyAsync(d_samples, h, (size_t)hn * sizeof(double), hipMemcpyHostToDevice, is));
     DImuParams P{};
     for (int k = 0; k < 3; k++) P.gravity[k] = imu->gravity[k];
@@ -415,7 +425,10 @@ vslam_status vslam_matcher::imu_setup(const vslam_imu_input* imu, double lastDt)
     for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) imuSi[3 * r + c] = imu->T_wc_prev[4 * r + c]; imuSi[9 + r] = imu->T_wc_prev[4 * r + 3]; imuSi[12 + r] = imu->velocity_prev[r]; }
     for (int k = 0; k < 6; k++) imuBiasPrev[k] = imu->bias_prev[k];
     int t = timer.begin("imu_preintegrate");
-    hipLaunchKernelGGL(k_imu_preintegrate, dim3(1), dim3(256), 0, is, P, d_samples, d_dts, n, d_bias, (DPim*)imuPim, imuLam);
+    DNav si0;
+    for (int k = 0; k < 9; k++) si0.R[k] = imuSi[k];
+    for (int k = 0; k < 3; k++) { si0.t[k] = imuSi[9 + k]; si0.v[k] = imuSi[12 + k]; }
+    hipLaunchKernelGGL(k_imu_preintegrate, dim3(1), dim3(256), 0, is, P, d_samples, d_dts, n, d_bias, (DPim*)imuPim, imuLam, si0, (DNav*)imuPred);
     timer.end(t);
     VS_HIP(hipGetLastError());
     imuPending = is != stream;
@@ -445,9 +458,7 @@ vslam_status vslam_matcher::pose_imu_enqueue(int M, const int* Mdev, const int* 
     A.maxIterations = 100; A.relTol = 1e-5; A.absTol = 1e-5; A.thres = 7.815;
     ImuLmArgs I{};
     I.pim = (const DPim*)imuPim; I.Lam = imuLam; I.io = imuIo;
-    memcpy(&I.P, imuParams, sizeof(DImuParams));
-    for (int k = 0; k < 9; k++) I.si.R[k] = imuSi[k];
-    for (int k = 0; k < 3; k++) { I.si.t[k] = imuSi[9 + k]; I.si.v[k] = imuSi[12 + k]; }
+    I.pred = (const DNav*)imuPred;
     for (int k = 0; k < 6; k++) I.biasPrev[k] = imuBiasPrev[k];
     VS_CHECK(imu_join());
     int t = timer.begin("pose_imu_lm");
@@ -469,7 +480,7 @@ vslam_status vslam_matcher::pose_imu_enqueue(int M, const int* Mdev, const int* 
         (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_ps), sizeof(z));
         fprintf(stderr, "pose_imu_lm M=%d: build %lld init %lld | lin: vis %lld imuJ %lld prod %lld (x%lld) | trial: solve %lld nv %lld+%lld vis %lld ctl %lld (x%lld) | outl %lld\n",
                 M, z[0], z[1], z[2], z[3], z[4], z[10], z[5], z[6], 0LL, z[7], z[8], z[11], z[9]);
-        fprintf(stderr, "    nonvision: imu eval %lld  Lam quad %lld  prior %lld\n", z[12], z[13], z[14]);
+        fprintf(stderr, "    nonvision: imu eval %lld  Lam quad %lld  prior %lld | lin serial: imu %lld prior %lld\n", z[12], z[13], z[14], z[15], z[3]);
     }
 #endif
     VS_HIP(hipGetLastError());
