@@ -118,6 +118,7 @@ __device__ __forceinline__ void ba_eval_fac(const BaDev& D, const DPose& T, cons
     double q[3];
     mat3T_vec(T.R, d, q);
     if (Jp) { for (int c = 0; c < 12; c++) Jp[c] = 0; for (int c = 0; c < 6; c++) Jl[c] = 0; }
+    if (is == 0.0) { r[0] = r[1] = 0.0; return; }          // factor masked out for the second pass (k_ba_mask)
     if (q[2] <= 0) { r[0] = r[1] = 2.0 * D.fx * is; return; }
     const double x = q[0], y = q[1], zz = q[2], iz = 1.0 / zz;
     const double xx = right ? x - D.b : x;
@@ -1273,6 +1274,14 @@ __global__ __launch_bounds__(256) void k_ba_lm_apply(int n, double* __restrict__
     if (i < n) cur[i] = init[i] + diff[i];
 }
 
+// Second pass without a rebuild: the factors of the pairs the first chi2 check rejected get weight zero (exact-zero
+// residual and Jacobian rows), everything else - ordering, slots, free set - is the first pass's structure.
+__global__ __launch_bounds__(256) void k_ba_mask(int NF, const int* __restrict__ facPair, const uint8_t* __restrict__ wrong,
+                                                 double* __restrict__ facIs) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f < NF && wrong[facPair[f]]) facIs[f] = 0.0;
+}
+
 // every value slot starts from the caller's poses / landmarks (landmarks outside the graph are never rewritten)
 __global__ __launch_bounds__(256) void k_ba_init_slots(int nPose, const double* __restrict__ pose0, double* __restrict__ poseBase,
                                                        int nLm, const double* __restrict__ lm0, double* __restrict__ lmBase) {
@@ -1385,7 +1394,7 @@ struct BaHostTmp {
     std::vector<int> cnt, fidx, lpOf, order, fill, key, src, ns;
 };
 
-std::atomic<int> g_baLookahead{-1}, g_baSpecLin{-1};     // vslam_local_ba_set_lookahead (-1: environment / default)
+std::atomic<int> g_baLookahead{-1}, g_baSpecLin{-1}, g_baMask{1};     // vslam_local_ba_set_lookahead (-1: environment / default)
 
 struct HostFac { int pair, kf, lm, fi, lp; bool right; double z[2], is; };
 
@@ -1536,13 +1545,14 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         // the BetweenFactor chain is counted once (rank 0); S is summed over ranks
         const int NE = rank == 0 ? std::max((int)T.order.size() - 1, 0) : 0;
 
-        VS_HIP(A.ensure(8192 + (size_t)NF * 48 + ((size_t)NF + Lp + 2) * 8 + ((size_t)Lp + 2) * 12 + (size_t)K * 8 + L +
+        VS_HIP(A.ensure(8192 + (size_t)NF * 56 + ((size_t)NF + Lp + 2) * 8 + ((size_t)Lp + 2) * 12 + (size_t)K * 8 + L +
                         (size_t)(BA_MAX_NB + 1) * NE * sizeof(BaEdge) + 24 * 256, stream));
         A.reset();
         double* h_ctl = A.take<double>(CTL_DOUBLES);
         int* h_facKf = A.take<int>(NF); int* h_facFi = A.take<int>(NF); int* h_facLp = A.take<int>(NF); int* h_facLm = A.take<int>(NF);
         double* h_facZ = A.take<double>((size_t)2 * NF); double* h_facIs = A.take<double>(NF);
         uint8_t* h_facRight = A.take<uint8_t>(NF);
+        int* h_facPair = A.take<int>(NF);
         int* h_lpStart = A.take<int>(Lp + 1); int* h_lpSlotStart = A.take<int>(Lp + 1); int* h_lpOrig = A.take<int>(Lp);
         int* h_slotStart = A.take<int>((size_t)NF + Lp + 1); int* h_slotFi = A.take<int>((size_t)NF + Lp + 1);
         int* h_fidx = A.take<int>(K);
@@ -1618,6 +1628,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
                     h_facZ[2 * (size_t)f] = P->pair_uv[4 * (size_t)p + 2 * side]; h_facZ[2 * (size_t)f + 1] = P->pair_uv[4 * (size_t)p + 2 * side + 1];
                     h_facIs[f] = 1.0 / (1.0 / (double)P->inv_sigma_factor[P->pair_octave[2 * p + side]]);
                     h_facRight[f] = (uint8_t)side;
+                    h_facPair[f] = p;
                 }
                 h_slotStart[se] = f1; h_slotFi[se] = -1;     // end sentinel
             }
@@ -1635,14 +1646,14 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
             for (int sl = 0; sl < (specLin ? nSlots : 1); sl++) h_edges[(size_t)sl * NE + i] = e;
         }
         // ---- LM control block (GTSAM 4.2 policy; k_ba_ctl) ---------------------------------------------
-        const int maxIterations = pass == 0 ? 5 : 10;
         const double relTol = 1e-5, absTol = 1e-5;
-        for (int i = 0; i < CTL_DOUBLES; i++) h_ctl[i] = 0;
-        h_ctl[CTL_LAMBDA] = 1e-5;
-        {
+        auto init_ctl = [&](int ps) {
+            for (int i = 0; i < CTL_DOUBLES; i++) h_ctl[i] = 0;
+            h_ctl[CTL_LAMBDA] = 1e-5;
             int* ci = (int*)(h_ctl + CTL_INTS);
-            ci[CI_STATE] = BA_LINEARIZE; ci[CI_SEL] = 0; ci[CI_ITER] = 0; ci[CI_INNER] = 0; ci[CI_MAXIT] = maxIterations; ci[CI_FIRST] = 1;
-        }
+            ci[CI_STATE] = BA_LINEARIZE; ci[CI_SEL] = 0; ci[CI_ITER] = 0; ci[CI_INNER] = 0; ci[CI_MAXIT] = ps == 0 ? 5 : 10; ci[CI_FIRST] = 1;
+        };
+        init_ctl(pass);
         BHS("prep");
 
         // ---- upload ------------------------------------------------------------------------------
@@ -1718,6 +1729,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         BHS("upload");
 
         // ---- LM: speculative steps, the device decides (k_ba_ctl) -----------------------------------
+        auto run_lm = [&](int ps, long long nfStat, long long lpStat, long long k2Stat) -> vslam_status {
         // One step = [linearise if the state asks for it] + one lambda trial.  Kernels that are not due
         // return at once, so the host may enqueue a few steps ahead and only then look at the state.
         const int fuseCtl = comm ? 0 : 1;
@@ -1776,12 +1788,12 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
             if (enq > 400) { set_error("local BA: LM did not terminate"); return VSLAM_ERR_INVALID; }
         }
         D.poseCur = d_poseS.p + (size_t)co[CI_SEL] * K; D.lmCur = d_lmS.p + (size_t)co[CI_SEL] * 3 * L;
-        R->report[pass].iterations = co[CI_ITER];
-        R->report[pass].inner_iterations = co[CI_INNER];
-        R->report[pass].initial_error = h_ctlOut[CTL_INIT_ERR];
-        R->report[pass].final_error = h_ctlOut[CTL_ERROR];
-        R->report[pass].lambda = h_ctlOut[CTL_LAMBDA];
-        R->n_residuals = NF; R->n_landmarks = Lp; R->n_free_kf = F; R->sum_k2 = sumK2;
+        R->report[ps].iterations = co[CI_ITER];
+        R->report[ps].inner_iterations = co[CI_INNER];
+        R->report[ps].initial_error = h_ctlOut[CTL_INIT_ERR];
+        R->report[ps].final_error = h_ctlOut[CTL_ERROR];
+        R->report[ps].lambda = h_ctlOut[CTL_LAMBDA];
+        R->n_residuals = nfStat; R->n_landmarks = lpStat; R->n_free_kf = F; R->sum_k2 = k2Stat;
 
         if (comm) {
             // every rank needs all landmarks for the chi2 pass and the result: exchange the shard updates
@@ -1792,7 +1804,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
                 VS_CHECK(comm_allreduce(comm, d_lmDiff.p, (size_t)3 * L, stream));
                 hipLaunchKernelGGL(k_ba_lm_apply, dim3((3 * L + 255) / 256), dim3(256), 0, stream, 3 * L, D.lmCur, d_lm0.p, d_lmDiff.p);
             }
-            double st[4] = {(double)NF, (double)Lp, (double)sumK2, 0.0};
+            double st[4] = {(double)nfStat, (double)lpStat, (double)k2Stat, 0.0};
             VS_HIP(hipMemcpyAsync(d_sums.p + 4, st, sizeof(st), hipMemcpyHostToDevice, stream));
             VS_CHECK(comm_allreduce(comm, d_sums.p + 4, 3, stream));
             VS_HIP(hipMemcpyAsync(st, d_sums.p + 4, sizeof(st), hipMemcpyDeviceToHost, stream));
@@ -1815,9 +1827,56 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         if (NP) VS_HIP(hipMemcpyAsync(ws->h_wrong, d_wrong.p, NP, hipMemcpyDeviceToHost, stream));
         VS_HIP(hipStreamSynchronize(stream));
         if (NP) memcpy(wrong.data(), ws->h_wrong, NP);
-        if (pass == 0 && R->pair_wrong_pass1 && NP) memcpy(R->pair_wrong_pass1, wrong.data(), NP);
+        if (ps == 0 && R->pair_wrong_pass1 && NP) memcpy(R->pair_wrong_pass1, wrong.data(), NP);
         poseFinal = D.poseCur;
         lmFinal = D.lmCur;
+        return VSLAM_OK;
+        };
+        VS_CHECK(run_lm(pass, NF, Lp, sumK2));
+
+        // ---- second pass on the first pass's structure (single GPU): mask instead of rebuild ------------------
+        static const bool maskEnv = !getenv("VSLAM_BA_NO_MASK");
+        if (pass == 0 && !comm && maskEnv && g_baMask.load()) {
+            // membership / statistics of the second graph from the chi2 flags
+            std::vector<uint8_t> kfP2(K, 0), lmP2(L, 0);
+            long long NF2 = 0;
+            for (int p = 0; p < NP; p++) {
+                if (wrong[p]) continue;
+                const int fl = P->pair_flags[p] & 3;
+                if (!fl) continue;
+                kfP2[P->pair_kf[p]] = 1; lmP2[P->pair_lm[p]] = 1;
+                NF2 += (fl & 1) + (fl >> 1);
+            }
+            bool same = true;
+            for (int k = 0; k < K; k++) if (kfP2[k] != T.kfPresent[k]) { same = false; break; }
+            if (same) {       // same keyframes => same free set, same BetweenFactor chain; landmarks may only drop out
+                long long Lp2 = 0, k2 = 0;
+                for (int l = 0; l < L; l++) Lp2 += lmP2[l];
+                for (int lp = 0; lp < Lp; lp++) {
+                    int ns = 0, last = -2;
+                    for (int f = h_lpStart[lp]; f < h_lpStart[lp + 1]; f++) {
+                        if (wrong[h_facPair[f]]) continue;
+                        const int fi = h_facFi[f];
+                        if (fi >= 0 && fi != last) { last = fi; ns++; }
+                    }
+                    k2 += (long long)ns * ns;
+                }
+                for (int k = 0; k < K; k++) h_kfPresent[k] = kfP2[k];
+                for (int l = 0; l < L; l++) h_lmPresent[l] = lmP2[l];
+                init_ctl(1);
+                VS_HIP(hipMemcpyAsync(A.dev(h_kfPresent), h_kfPresent, K, hipMemcpyHostToDevice, stream));
+                if (L) VS_HIP(hipMemcpyAsync(A.dev(h_lmPresent), h_lmPresent, L, hipMemcpyHostToDevice, stream));
+                VS_HIP(hipMemcpyAsync(A.dev(h_ctl), h_ctl, CTL_DOUBLES * sizeof(double), hipMemcpyHostToDevice, stream));
+                if (NF) hipLaunchKernelGGL(k_ba_mask, dim3((NF + 255) / 256), dim3(256), 0, stream, NF, A.dev(h_facPair), d_wrong.p, A.dev(h_facIs));
+                {
+                    const int nPose = K * (int)(sizeof(DPose) / sizeof(double)), nLm = 3 * L;
+                    hipLaunchKernelGGL(k_ba_init_slots, dim3((std::max(nPose, nLm) + 255) / 256, nSlots), dim3(256), 0, stream,
+                                       nPose, (const double*)d_pose0.p, (double*)d_poseS.p, nLm, d_lm0.p, d_lmS.p);
+                }
+                VS_CHECK(run_lm(1, NF2, Lp2, k2));
+                break;
+            }
+        }
     }
     BHS("chi2");
     std::vector<DPose> poseOut(K);
@@ -1846,10 +1905,11 @@ vslam_status vslam_local_ba_timings(const char** names, float* ms, int32_t cap, 
     return VSLAM_OK;
 }
 
-vslam_status vslam_local_ba_set_lookahead(int32_t candidates, int32_t speculative_linearize) {
+vslam_status vslam_local_ba_set_lookahead(int32_t candidates, int32_t speculative_linearize, int32_t mask_second_pass) {
     if (candidates > BA_MAX_NB) return VSLAM_ERR_INVALID;
     g_baLookahead.store(candidates > 0 ? candidates : -1);
     g_baSpecLin.store(speculative_linearize < 0 ? -1 : (speculative_linearize ? 1 : 0));
+    g_baMask.store(mask_second_pass != 0 ? 1 : 0);
     return VSLAM_OK;
 }
 

@@ -342,10 +342,10 @@ def local_ba_set_timing(on):
     _chk(lib().vslam_local_ba_set_timing(int(bool(on))))
 
 
-def local_ba_set_lookahead(candidates=0, speculative_linearize=-1):
-    """Tuning only (results are bit-identical): lambda candidates per trial round (1..4, 0 = default) and
-    speculative linearisation (0 / 1, -1 = default)."""
-    _chk(lib().vslam_local_ba_set_lookahead(int(candidates), int(speculative_linearize)))
+def local_ba_set_lookahead(candidates=0, speculative_linearize=-1, mask_second_pass=1):
+    """Scheduling knobs only: lambda candidates per trial round (1..4, 0 = default), speculative linearisation
+    (0 / 1, -1 = default), second pass by masking instead of a host rebuild (0 / 1)."""
+    _chk(lib().vslam_local_ba_set_lookahead(int(candidates), int(speculative_linearize), int(mask_second_pass)))
 
 
 class TrackReport(C.Structure):

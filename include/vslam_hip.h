@@ -332,11 +332,17 @@ vslam_status vslam_local_ba(const vslam_ba_problem* problem, vslam_ba_result* re
 vslam_status vslam_local_ba_timings(const char** names, float* ms, int32_t cap, int32_t* n_out);
 /* event timing on (default) / off for the following vslam_local_ba calls of the calling thread */
 vslam_status vslam_local_ba_set_timing(int32_t on);
-/* Tuning knob, results are bit-identical for every setting: `candidates` (1..4, <= 0: default 4) damping values
- * lambda, 10 lambda, ... are evaluated per trial round and then walked in GTSAM's sequential order on the device;
- * `speculative_linearize` (0 / 1, < 0: default on) linearises at every trial point so that an accepted step needs
- * no launch of its own.  Process-wide; the landmark-sharded path (comm != NULL) always runs 1 / off. */
-vslam_status vslam_local_ba_set_lookahead(int32_t candidates, int32_t speculative_linearize);
+/* Scheduling knobs of the single-GPU path.  They do not change the algorithm (same LM trajectory; values equal up
+ * to the summation order of fp64 atomics, which already varies from run to run):
+ *   candidates (1..4, <= 0: default 4)  damping values lambda, 10 lambda, ... evaluated per trial round and then
+ *                                       walked in GTSAM's sequential order on the device;
+ *   speculative_linearize (0 / 1, < 0: default on)  linearise at every trial point, so an accepted step needs no
+ *                                       launch of its own;
+ *   mask_second_pass (0 / 1, default 1)  run the second optimisation on the first one's factor ordering with the
+ *                                       rejected pairs' weights set to zero instead of rebuilding it on the host
+ *                                       (falls back to the rebuild when a keyframe loses all its observations).
+ * Process-wide; the landmark-sharded path (comm != NULL) always runs 1 / off / rebuild. */
+vslam_status vslam_local_ba_set_lookahead(int32_t candidates, int32_t speculative_linearize, int32_t mask_second_pass);
 
 /* ---------------------------------------------------------------------------
  * New-point pipeline of the optimizer thread — replaces the numerical part of LocalMapper::findNewPoints

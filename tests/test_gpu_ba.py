@@ -142,7 +142,8 @@ def test_ba_c5_class_properties(capi):
 @pytest.mark.parametrize("kind", ["window10", "window20", "atomic_path"])
 def test_ba_lookahead_matches_sequential_trials(capi, oracle, kind):
     """The lambda look-ahead (4 damping candidates per trial round, walked on the device in GTSAM's sequential
-    order) and the speculative linearisation are scheduling changes only: same LM trajectory (iteration / trial
+    order), the speculative linearisation and the masked (instead of rebuilt) second pass are scheduling changes
+    only: same LM trajectory (iteration / trial
     counts, wrong-match flags) as the plain one-trial-per-round scheme, values equal up to the summation order of
     the fp64 atomics that already varies from run to run (1e-9 relative on the costs, the oracle comparison's bars on the values)."""
     if kind == "window10":
@@ -154,11 +155,11 @@ def test_ba_lookahead_matches_sequential_trials(capi, oracle, kind):
     ex = oracle.Extractor(1500)
     outs = []
     try:
-        for nb, spec in ((1, 0), (4, 1), (2, 0), (3, 1)):
-            capi.local_ba_set_lookahead(nb, spec)
+        for nb, spec, mask in ((1, 0, 0), (4, 1, 1), (2, 0, 1), (3, 1, 0)):
+            capi.local_ba_set_lookahead(nb, spec, mask)
             outs.append(capi.local_ba(prob["rig"], ex.sigmaFactor, ex.InvSigmaFactor, prob))
     finally:
-        capi.local_ba_set_lookahead(0, -1)
+        capi.local_ba_set_lookahead(0, -1, 1)
     base = outs[0]
     assert base["reports"][0]["inner"] + base["reports"][1]["inner"] > 4
     for o in outs[1:]:
