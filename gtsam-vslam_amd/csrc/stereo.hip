@@ -187,8 +187,60 @@ void launch_stereo_match(hipStream_t s, const StereoArgs& A, int* mBest, float* 
     hipLaunchKernelGGL(k_stereo_match, dim3((A.nL + 3) / 4), dim3(256), sh, s, A, mBest, mDepth, mSad, stats);
 }
 
+// Radix select over n 32-bit keys in LDS (1024 threads, 4 passes of 8 bits): returns the key of 0-based rank k and,
+// in `less` / `equal`, how many keys are strictly smaller / equal to it.  hist: 256 ints, sel: 3 ints of LDS.  k < n.
+__device__ __forceinline__ unsigned stereo_radix_select(const unsigned* keys, int n, int k, int* hist, int* sel, int& less, int& equal) {
+    const int tid = threadIdx.x;
+    unsigned prefix = 0, mask = 0;
+    int rem = k;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        for (int e = tid; e < n; e += 1024) {
+            const unsigned key = keys[e];
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+            const int tot = h0 + h1 + h2 + h3;
+            int inc = tot;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (tid >= d) inc += o; }
+            int cum = inc - tot;                       // keys in bins below 4 * tid
+            const int hh[4] = {h0, h1, h2, h3};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (rem >= cum && rem < cum + hh[j]) { sel[0] = 4 * tid + j; sel[1] = rem - cum; sel[2] = hh[j]; }
+                cum += hh[j];
+            }
+        }
+        __syncthreads();
+        prefix |= (unsigned)sel[0] << shift;
+        mask |= 255u << shift;
+        rem = sel[1];
+        equal = sel[2];            // after the last pass: keys equal to the selected one
+        __syncthreads();
+    }
+    less = k - rem;
+    return prefix;
+}
+__device__ __forceinline__ unsigned stereo_float_key(float f) {       // order-preserving map float -> unsigned
+    const unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+#ifdef VSLAM_STEREO_STAMPS
+__device__ long long g_st[8];
+#define ST_ACC(k) do { if (threadIdx.x == 0) { const long long n_ = clock64(); g_st[k] += n_ - st_t; st_t = n_; } } while (0)
+#else
+#define ST_ACC(k) do {} while (0)
+#endif
+
 // One workgroup; n = accepted pairs.  Dropped set = first floor(0.01 n) by (depth, index)
 // plus every pair whose SAD is not below 2.1 x the median SAD (src/FeatureMatcher.cpp:674-705).
+// Both order statistics come from radix selects (the cut-off depth + the index tie-break among equal depths, and the
+// value of rank n / 2 of the SADs) instead of an all-pairs rank count.
 __global__ __launch_bounds__(1024) void k_stereo_finalize(int nL, int nR, const int* __restrict__ mBest,
                                                           const float* __restrict__ mDepth,
                                                           const int* __restrict__ mSad, float closeDepth,
@@ -200,10 +252,14 @@ __global__ __launch_bounds__(1024) void k_stereo_finalize(int nL, int nR, const 
     int* vIdx = (int*)smem;
     float* vDepth = (float*)(vIdx + nL);
     int* vSad = (int*)(vDepth + nL);
-    int* rankD = vSad + nL;
-    __shared__ int s_n, s_median;
+    int* rankD = vSad + nL;                   // 1 = inside the nearest-1 % cut
+    unsigned* keys = (unsigned*)(rankD + nL);
+    __shared__ int s_n, hist[256], sel[3];
     const int tid = threadIdx.x;
-    if (tid == 0) { s_n = 0; s_median = 0; }
+#ifdef VSLAM_STEREO_STAMPS
+    long long st_t = clock64();
+#endif
+    if (tid == 0) s_n = 0;
     for (int i = tid; i < nL; i += 1024) { rightIdxs[i] = -1; depth[i] = -1.f; closef[i] = 0; }
     for (int j = tid; j < nR; j += 1024) leftIdxs[j] = -1;
     __syncthreads();
@@ -216,25 +272,40 @@ __global__ __launch_bounds__(1024) void k_stereo_finalize(int nL, int nR, const 
     __syncthreads();
     const int n = s_n;
     if (n == 0) return;
+    ST_ACC(0);
     const int endDe = (int)floor((double)n * 0.01);
-    for (int e = tid; e < n; e += 1024) {
-        const float d = vDepth[e];
-        const int id = vIdx[e], sd = vSad[e];
-        int rd = 0, rs = 0;
-        for (int k = 0; k < n; k++) {
-            const float d2 = vDepth[k];
-            const int i2 = vIdx[k], s2 = vSad[k];
-            rd += (d2 < d) || (d2 == d && i2 < id);
-            rs += (s2 < sd) || (s2 == sd && i2 < id);
+    // median SAD: value of rank n / 2 in (sad, index) order = value of rank n / 2 by sad alone
+    for (int e = tid; e < n; e += 1024) keys[e] = (unsigned)vSad[e] ^ 0x80000000u;
+    __syncthreads();
+    int lessS, eqS;
+    const int s_median = (int)(stereo_radix_select(keys, n, n / 2, hist, sel, lessS, eqS) ^ 0x80000000u);
+    ST_ACC(1);
+    // nearest-1 % cut: rank by (depth, index) below endDe
+    for (int e = tid; e < n; e += 1024) rankD[e] = 0;
+    if (endDe > 0) {
+        for (int e = tid; e < n; e += 1024) keys[e] = stereo_float_key(vDepth[e]);
+        __syncthreads();
+        int lessD, eqD;
+        const unsigned cut = stereo_radix_select(keys, n, endDe - 1, hist, sel, lessD, eqD);   // depth of the last dropped pair
+        const int quota = endDe - lessD;          // how many of the pairs AT the cut depth are dropped (lowest indices)
+        for (int e = tid; e < n; e += 1024) {
+            const unsigned key = keys[e];
+            int in = key <= cut ? 1 : 0;
+            if (key == cut && quota < eqD) {      // equal depths straddle the cut (rare): index order decides
+                const int id = vIdx[e];
+                int r = 0;
+                for (int k2 = 0; k2 < n; k2++) r += (keys[k2] == cut && vIdx[k2] < id) ? 1 : 0;
+                in = r < quota ? 1 : 0;
+            }
+            rankD[e] = in;
         }
-        rankD[e] = rd;
-        if (rs == n / 2) s_median = sd;
     }
     __syncthreads();
+    ST_ACC(2);
     const float medDistD = (float)s_median * (1.5f * 1.4f);
     for (int e = tid; e < n; e += 1024) {
         const int i = vIdx[e], r = mBest[i];
-        const bool dropped = rankD[e] < endDe || !((float)vSad[e] < medDistD);
+        const bool dropped = rankD[e] != 0 || !((float)vSad[e] < medDistD);
         if (!dropped) {
             rightIdxs[i] = r;
             depth[i] = vDepth[e];
@@ -243,19 +314,32 @@ __global__ __launch_bounds__(1024) void k_stereo_finalize(int nL, int nR, const 
         atomicMax(&leftIdxs[r], i);
     }
     __syncthreads();
+    ST_ACC(3);
     for (int e = tid; e < n; e += 1024) {
-        const bool dropped = rankD[e] < endDe || !((float)vSad[e] < medDistD);
+        const bool dropped = rankD[e] != 0 || !((float)vSad[e] < medDistD);
         if (dropped) leftIdxs[mBest[vIdx[e]]] = -1;
     }
+    ST_ACC(4);
 }
 
 void launch_stereo_finalize(hipStream_t s, int nL, int nR, const int* mBest, const float* mDepth,
                             const int* mSad, float closeDepth, int* rightIdxs, int* leftIdxs,
                             float* depth, uint8_t* closef) {
     if (nL <= 0 && nR <= 0) return;
-    const size_t sh = (size_t)(nL > 0 ? nL : 1) * 16;
+    const size_t sh = (size_t)(nL > 0 ? nL : 1) * 20;
+#ifdef VSLAM_STEREO_STAMPS
+    { long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_st), z, sizeof(z)); }
+#endif
     hipLaunchKernelGGL(k_stereo_finalize, dim3(1), dim3(1024), sh, s, nL, nR, mBest, mDepth, mSad,
                        closeDepth, rightIdxs, leftIdxs, depth, closef);
+#ifdef VSLAM_STEREO_STAMPS
+    {
+        long long z[8];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_st), sizeof(z));
+        fprintf(stderr, "stereo_finalize nL=%d: init+compact %lld  median %lld  depth cut %lld  apply %lld  kill %lld\n", nL, z[0], z[1], z[2], z[3], z[4]);
+    }
+#endif
 }
 
 }  // namespace vslam
