@@ -108,12 +108,15 @@ __device__ __forceinline__ int proj_decide(unsigned long long l1, unsigned long 
 // step is replayed point by point (with the exact rescan when a list is exhausted), so the result is the
 // reference's for any input.
 constexpr int PROJ_SUPER = 512;      // map points staged in LDS per super-step (64 KB of keys)
+constexpr int PROJ_NT = 512;         // threads of k_proj_resolve
+constexpr int PROJ_PAR_PASSES = 8;   // parallel phase: key lists of up to 8 x 128 map points live in registers
+constexpr int PROJ_PAR_ROUNDS = 16;  // fixed-point rounds before the sequential walk takes over
 
 __device__ __forceinline__ void lds_order() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-__global__ __launch_bounds__(256) void k_proj_resolve(ProjArgs A, const unsigned long long* __restrict__ topk,
+__global__ __launch_bounds__(PROJ_NT) void k_proj_resolve(ProjArgs A, const unsigned long long* __restrict__ topk,
                                                      int* __restrict__ matchedL, int* __restrict__ matchedR,
-                                                     int* __restrict__ matches, int* __restrict__ outp) {
+                                                     int* __restrict__ matches, int* __restrict__ outp, int forceSeq) {
     extern __shared__ int claims[];
     int* cl = claims;
     int* cr = claims + A.n[0];
@@ -126,12 +129,122 @@ __global__ __launch_bounds__(256) void k_proj_resolve(ProjArgs A, const unsigned
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (A.gate && *A.gate < A.gateMin) return;
     if (A.Mdev) A.M = min(A.M, *A.Mdev);
-    for (int k = tid; k < A.n[0]; k += 256) { cl[k] = matchedL[k]; ri[k] = A.mode == PROJ_STEREO ? A.rightIdxs[k] : -1; tl[k] = INT_MAX; }
-    for (int k = tid; k < A.n[1]; k += 256) { cr[k] = matchedR[k]; li[k] = A.leftIdxs[k]; tr[k] = INT_MAX; }
+    for (int k = tid; k < A.n[0]; k += PROJ_NT) { cl[k] = matchedL[k]; ri[k] = A.mode == PROJ_STEREO ? A.rightIdxs[k] : -1; tl[k] = INT_MAX; }
+    for (int k = tid; k < A.n[1]; k += PROJ_NT) { cr[k] = matchedR[k]; li[k] = A.leftIdxs[k]; tr[k] = INT_MAX; }
     int nMatches = 0;
     static_assert(PROJ_K == 8, "lane layout assumes 8 keys per side");
     const int q = lane >> 2, e = lane & 3, side = e >> 1, half = e & 1;
-    for (int sc = 0; sc < A.M; sc += PROJ_SUPER) {
+
+    // ---- parallel fixed point ----------------------------------------------------------------------------------
+    // The greedy walk is "decision_i = f(claims of the points before i)".  That system has exactly one solution (by
+    // induction over i), so ANY iteration that reaches a fixed point has found the sequential result: every point
+    // decides in parallel against the initial claim tables plus the current decisions of LOWER-indexed points
+    // (tl / tr hold the lowest point index claiming a keypoint), until a round changes nothing.  Dependency chains
+    // are short (a few rounds).  A point whose 8-key list is exhausted needs the exact rescan -> the sequential walk
+    // below redoes the whole frame (it also covers M > 1024 and non-convergence); results are identical either way.
+    __shared__ int sChanged, sFall, sCount;
+    bool solved = false;
+    const int Mtot = A.M;
+    int roundsUsed = -1;                                      // diagnostics: outp[1] (-1 = sequential walk)
+    if (!forceSeq && Mtot > 0 && Mtot <= PROJ_PAR_PASSES * (PROJ_NT / 4)) {
+        int* decT = (int*)skeys;                              // current decision per point (-1 = none)
+        unsigned long long K[PROJ_PAR_PASSES][4];
+        int PV[PROJ_PAR_PASSES];
+#pragma unroll
+        for (int p = 0; p < PROJ_PAR_PASSES; p++) {
+            const int i = p * (PROJ_NT / 4) + wave * 16 + q;
+            K[p][0] = K[p][1] = K[p][2] = K[p][3] = KEY_NONE;
+            PV[p] = 0;                                        // >= 0 -> treated as already matched -> skipped
+            if (i < Mtot) {
+                const ulonglong2* src = (const ulonglong2*)(topk + (size_t)i * 16 + e * 4);
+                const ulonglong2 a = src[0], b2v = src[1];
+                K[p][0] = a.x; K[p][1] = a.y; K[p][2] = b2v.x; K[p][3] = b2v.y;
+                PV[p] = matches[2 * (size_t)i + (e & 1)];
+            }
+        }
+        for (int i = tid; i < Mtot; i += PROJ_NT) decT[i] = -1;
+        if (tid == 0) { sFall = 0; sCount = 0; }
+        __syncthreads();
+        for (int round = 0; round < PROJ_PAR_ROUNDS; round++) {
+            if (tid == 0) sChanged = 0;
+            for (int i = tid; i < Mtot; i += PROJ_NT) {       // publish the current decisions
+                const int d = decT[i];
+                if (d < 0) continue;
+                const int idx = d & 0xffff;
+                int cL, cR;
+                if (d >> 16) { cR = idx; cL = li[idx]; } else { cL = idx; cR = ri[idx]; }
+                if (cL >= 0) atomicMin(&tl[cL], i);
+                if (cR >= 0) atomicMin(&tr[cR], i);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < PROJ_PAR_PASSES; p++) {
+                if (p * (PROJ_NT / 4) >= Mtot) break;
+                const int i = p * (PROJ_NT / 4) + wave * 16 + q;
+                const int pairv = PV[p];
+                const bool skip = (pairv >= 0) || (__shfl_xor(pairv, 1) >= 0);
+                const int* tab = side ? cr : cl;
+                const int* tt = side ? tr : tl;
+                unsigned fb = 0, vb = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const bool valid = K[p][j] != KEY_NONE;
+                    vb |= (unsigned)valid << j;
+                    if (valid) {
+                        const int kk = key_idx(K[p][j]);
+                        if (tab[kk] < 0 && tt[kk] >= i) fb |= 1u << j;     // free before point i
+                    }
+                }
+                const unsigned ofb = __shfl_xor(fb, 1), ovb = __shfl_xor(vb, 1);
+                const unsigned fm = half ? (ofb | (fb << 4)) : (fb | (ofb << 4));
+                const unsigned vm = half ? (ovb | (vb << 4)) : (vb | (ovb << 4));
+                if (!skip && vm == 0xffu && __popc(fm) < 2) sFall = 1;    // exhausted list: exact rescan needed
+                int p1 = -1, p2 = -1;
+                { unsigned m = fm; if (m) { p1 = __ffs(m) - 1; m &= m - 1; } if (m) p2 = __ffs(m) - 1; }
+                auto sel = [&](int pos) -> unsigned long long {
+                    const int sl = pos & 3;
+                    return sl == 0 ? K[p][0] : (sl == 1 ? K[p][1] : (sl == 2 ? K[p][2] : K[p][3]));
+                };
+                const int pairBase = lane & ~1;
+                unsigned long long b1 = __shfl(sel(p1 < 0 ? 0 : p1), pairBase | ((p1 < 0 ? 0 : p1) >> 2));
+                unsigned long long b2 = __shfl(sel(p2 < 0 ? 0 : p2), pairBase | ((p2 < 0 ? 0 : p2) >> 2));
+                if (p1 < 0) b1 = KEY_NONE;
+                if (p2 < 0) b2 = KEY_NONE;
+                const unsigned long long o1 = __shfl_xor(b1, 2), o2 = __shfl_xor(b2, 2);
+                const int dec = skip ? -1 : (side ? proj_decide(o1, o2, b1, b2, A.mode) : proj_decide(b1, b2, o1, o2, A.mode));
+                if (e == 0 && !skip && dec != decT[i]) { decT[i] = dec; sChanged = 1; }
+            }
+            __syncthreads();
+            const int changed = sChanged, fall = sFall;
+            for (int k = tid; k < A.n[0]; k += PROJ_NT) tl[k] = INT_MAX;
+            for (int k = tid; k < A.n[1]; k += PROJ_NT) tr[k] = INT_MAX;
+            __syncthreads();
+            if (fall) break;
+            if (!changed) { solved = true; roundsUsed = round + 1; break; }
+        }
+        if (solved) {
+            // apply: the walk overwrites a claim-table entry whenever a later point takes the keypoint as a stereo
+            // partner (rightIdxs is not injective), so the surviving value is the HIGHEST point index that wrote it
+            for (int k = tid; k < A.n[0]; k += PROJ_NT) tl[k] = -1;
+            for (int k = tid; k < A.n[1]; k += PROJ_NT) tr[k] = -1;
+            __syncthreads();
+            for (int i = tid; i < Mtot; i += PROJ_NT) {
+                const int d = decT[i];
+                if (d < 0) continue;
+                const int idx = d & 0xffff;
+                int cL, cR;
+                if (d >> 16) { cR = idx; cL = li[idx]; } else { cL = idx; cR = ri[idx]; }
+                if (cL >= 0) { atomicMax(&tl[cL], i); matches[2 * (size_t)i] = cL; }
+                if (cR >= 0) { atomicMax(&tr[cR], i); matches[2 * (size_t)i + 1] = cR; }
+                atomicAdd(&sCount, 1);
+            }
+            __syncthreads();
+            for (int k = tid; k < A.n[0]; k += PROJ_NT) if (tl[k] >= 0) cl[k] = tl[k];
+            for (int k = tid; k < A.n[1]; k += PROJ_NT) if (tr[k] >= 0) cr[k] = tr[k];
+            nMatches = sCount;
+        }
+    }
+    for (int sc = 0; sc < (solved ? 0 : A.M); sc += PROJ_SUPER) {
         const int n = min(PROJ_SUPER, A.M - sc);
         __syncthreads();
         // all four waves stage this super-step's key lists and current pairs in LDS (deep, coalesced loads):
@@ -139,8 +252,8 @@ __global__ __launch_bounds__(256) void k_proj_resolve(ProjArgs A, const unsigned
         {
             const ulonglong2* src = (const ulonglong2*)(topk + (size_t)sc * 16);
             ulonglong2* dst = (ulonglong2*)skeys;
-            for (int k = tid; k < n * 8; k += 256) dst[k] = src[k];
-            for (int k = tid; k < n * 2; k += 256) spair[k] = matches[2 * (size_t)sc + k];
+            for (int k = tid; k < n * 8; k += PROJ_NT) dst[k] = src[k];
+            for (int k = tid; k < n * 2; k += PROJ_NT) spair[k] = matches[2 * (size_t)sc + k];
         }
         __syncthreads();
         if (wave != 0) continue;
@@ -276,17 +389,18 @@ __global__ __launch_bounds__(256) void k_proj_resolve(ProjArgs A, const unsigned
         }
     }
     __syncthreads();
-    for (int k = tid; k < A.n[0]; k += 256) matchedL[k] = cl[k];
-    for (int k = tid; k < A.n[1]; k += 256) matchedR[k] = cr[k];
-    if (tid == 0) outp[0] = nMatches;
+    for (int k = tid; k < A.n[0]; k += PROJ_NT) matchedL[k] = cl[k];
+    for (int k = tid; k < A.n[1]; k += PROJ_NT) matchedR[k] = cr[k];
+    if (tid == 0) { outp[0] = nMatches; outp[1] = roundsUsed; }
 }
 
 void launch_proj_resolve(hipStream_t s, const ProjArgs& A, const unsigned long long* topk, int* matchedL, int* matchedR,
                          int* matches, int* out) {
     const size_t sh = (size_t)(3 * (A.n[0] + A.n[1]) + 2 * PROJ_SUPER) * sizeof(int) + 32 + (size_t)PROJ_SUPER * 16 * sizeof(unsigned long long);
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k_proj_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-    hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(256), sh, s, A, topk, matchedL, matchedR, matches, out);
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_proj_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); attr = true; }
+    const int forceSeq = getenv("VSLAM_PROJ_SEQUENTIAL") ? 1 : 0;     // A/B and fallback testing (read per launch)
+    hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(PROJ_NT), sh, s, A, topk, matchedL, matchedR, matches, out, forceSeq);
 }
 
 }  // namespace vslam

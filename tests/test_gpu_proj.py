@@ -109,3 +109,27 @@ def test_projection_empty_inputs(oracle, capi):
     mR0 = np.full(len(kR), -1, np.int32)
     n, mL, mR, mt, _ = capi.match_projection(m, np.zeros(0, oracle.MPV_DTYPE), 10.0, mL0, mR0, np.zeros((0, 2), np.int32))
     assert n == 0 and (mL == -1).all() and (mR == -1).all()
+
+
+def test_parallel_fixed_point_equals_sequential_walk(oracle, capi):
+    """k_proj_resolve first tries the parallel fixed-point iteration and keeps the sequential walk as fallback
+    (exhausted lists, > 1024 points, no convergence): both must give the oracle's result, here on a case with
+    duplicated map points (many claim conflicts) so that several rounds are needed."""
+    import os
+    rig, oL, (kL, dL, kR, dR), st, ge, m = _frontend(oracle, capi)
+    rng = np.random.default_rng(77)
+    mps = _make_mps(oracle, kL, dL, kR, dR, st, rng, 900, 5.0, dup=250)
+    M = len(mps)
+    mL0 = np.full(len(kL), -1, np.int32); mR0 = np.full(len(kR), -1, np.int32); mt0 = np.full((M, 2), -1, np.int32)
+    ref = oracle.match_projection(oL, rig, mps, kL, dL, kR, dR, st["rightIdxs"], st["leftIdxs"], mL0, mR0, mt0, 10.0)
+    outs = []
+    for seq in (False, True):
+        if seq:
+            os.environ["VSLAM_PROJ_SEQUENTIAL"] = "1"
+        try:
+            outs.append(capi.match_projection(m, mps, 10.0, mL0, mR0, mt0))
+        finally:
+            os.environ.pop("VSLAM_PROJ_SEQUENTIAL", None)
+    for n, mL, mR, mt, _ in outs:
+        assert n == ref[0] and n > 100
+        assert np.array_equal(mt, ref[3]) and np.array_equal(mL, ref[1]) and np.array_equal(mR, ref[2])
