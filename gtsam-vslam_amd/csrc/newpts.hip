@@ -179,46 +179,11 @@ __global__ __launch_bounds__(256) void k_np_match(NpArgs A) {
 
 // triangulateNewPoints + checkReprojError: thread = candidate; the DLT rows of 64 candidates live in LDS,
 // element (row, col) of thread t at ((row * 4 + col) * 64 + t) - conflict-free
-__global__ __launch_bounds__(64) void k_np_triangulate(NpArgs A) {
-    extern __shared__ double sA[];
-    const int t = threadIdx.x, c = blockIdx.x * 64 + t;
-    if (c >= A.count[0]) return;
+// gtsam::triangulateDLT on the rows x 4 system of thread t (column-of-threads layout in LDS, see k_np_triangulate):
+// smallest right singular vector by a one-sided Jacobi SVD with a fixed pair order, rank test 1e-9.
+__device__ __forceinline__ bool np_dlt_point(double* sA, int t, int rows, double* pt) {
     auto a = [&](int r, int q) -> double& { return sA[((size_t)(r * 4 + q)) * 64 + t]; };
-    int* obs = A.obs + (size_t)c * NP_MAX_KF * 3;
-    // matchesOfPoint: (lastKF, keyPos) then the matched keyframes in window order
-    int n = 0;
-    obs[0] = 0; obs[1] = A.key[2 * c]; obs[2] = A.key[2 * c + 1]; n = 1;
-    for (int k = 1; k < A.nKf; k++) {
-        const int l = A.match[((size_t)c * NP_MAX_KF + k) * 2], r = A.match[((size_t)c * NP_MAX_KF + k) * 2 + 1];
-        if (l == -2 && r == -2) continue;
-        obs[3 * n] = k; obs[3 * n + 1] = l; obs[3 * n + 2] = r; n++;
-    }
-    A.accepted[c] = 0;
-    A.nObs[c] = n;
-    if (n < 3) return;                                   // minCount (include/OptimizationBA.h:47)
-    // DLT rows
-    int rows = 0;
-    for (int e = 0; e < n; e++) {
-        const NpKf& K = A.kf[obs[3 * e]];
-        for (int side = 0; side < 2; side++) {
-            const int idx = obs[3 * e + 1 + side];
-            if (idx < 0) continue;
-            const vslam_keypoint kp = side ? K.kpsR[idx] : K.kpsL[idx];
-            const double u = (double)kp.x, v = (double)kp.y;
-            double M[12];
-            for (int r = 0; r < 3; r++) { for (int q = 0; q < 3; q++) M[4 * r + q] = K.Tcw.R[3 * r + q]; M[4 * r + 3] = K.Tcw.t[r]; }
-            if (side) M[3] -= A.b;
-            for (int q = 0; q < 4; q++) {
-                const double P0 = A.fx * M[q] + 0.0 * M[4 + q] + A.cx * M[8 + q];
-                const double P1 = 0.0 * M[q] + A.fy * M[4 + q] + A.cy * M[8 + q];
-                const double P2 = 0.0 * M[q] + 0.0 * M[4 + q] + 1.0 * M[8 + q];
-                a(rows, q) = u * P2 - P0;
-                a(rows + 1, q) = v * P2 - P1;
-            }
-            rows += 2;
-        }
-    }
-    if (rows < 4) return;                                // fewer than two observations
+    if (rows < 4) return false;                          // fewer than two observations
     // one-sided Jacobi SVD, fixed pair order
     double V[16];
 #pragma unroll
@@ -264,7 +229,7 @@ __global__ __launch_bounds__(64) void k_np_triangulate(NpArgs A) {
     }
 #pragma unroll
     for (int q = 1; q < 4; q++) if (s[q] < s[minc]) minc = q;
-    if (rank < 3) return;                                // TriangulationUnderconstrainedException
+    if (rank < 3) return false;                          // TriangulationUnderconstrainedException
     double vm[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -273,7 +238,51 @@ __global__ __launch_bounds__(64) void k_np_triangulate(NpArgs A) {
         for (int q = 1; q < 4; q++) v = (q == minc) ? V[4 * r + q] : v;
         vm[r] = v;
     }
-    const double pt[3] = {vm[0] / vm[3], vm[1] / vm[3], vm[2] / vm[3]};
+    pt[0] = vm[0] / vm[3]; pt[1] = vm[1] / vm[3]; pt[2] = vm[2] / vm[3];
+    return true;
+}
+
+__global__ __launch_bounds__(64) void k_np_triangulate(NpArgs A) {
+    extern __shared__ double sA[];
+    const int t = threadIdx.x, c = blockIdx.x * 64 + t;
+    if (c >= A.count[0]) return;
+    auto a = [&](int r, int q) -> double& { return sA[((size_t)(r * 4 + q)) * 64 + t]; };
+    int* obs = A.obs + (size_t)c * NP_MAX_KF * 3;
+    // matchesOfPoint: (lastKF, keyPos) then the matched keyframes in window order
+    int n = 0;
+    obs[0] = 0; obs[1] = A.key[2 * c]; obs[2] = A.key[2 * c + 1]; n = 1;
+    for (int k = 1; k < A.nKf; k++) {
+        const int l = A.match[((size_t)c * NP_MAX_KF + k) * 2], r = A.match[((size_t)c * NP_MAX_KF + k) * 2 + 1];
+        if (l == -2 && r == -2) continue;
+        obs[3 * n] = k; obs[3 * n + 1] = l; obs[3 * n + 2] = r; n++;
+    }
+    A.accepted[c] = 0;
+    A.nObs[c] = n;
+    if (n < 3) return;                                   // minCount (include/OptimizationBA.h:47)
+    // DLT rows
+    int rows = 0;
+    for (int e = 0; e < n; e++) {
+        const NpKf& K = A.kf[obs[3 * e]];
+        for (int side = 0; side < 2; side++) {
+            const int idx = obs[3 * e + 1 + side];
+            if (idx < 0) continue;
+            const vslam_keypoint kp = side ? K.kpsR[idx] : K.kpsL[idx];
+            const double u = (double)kp.x, v = (double)kp.y;
+            double M[12];
+            for (int r = 0; r < 3; r++) { for (int q = 0; q < 3; q++) M[4 * r + q] = K.Tcw.R[3 * r + q]; M[4 * r + 3] = K.Tcw.t[r]; }
+            if (side) M[3] -= A.b;
+            for (int q = 0; q < 4; q++) {
+                const double P0 = A.fx * M[q] + 0.0 * M[4 + q] + A.cx * M[8 + q];
+                const double P1 = 0.0 * M[q] + A.fy * M[4 + q] + A.cy * M[8 + q];
+                const double P2 = 0.0 * M[q] + 0.0 * M[4 + q] + 1.0 * M[8 + q];
+                a(rows, q) = u * P2 - P0;
+                a(rows + 1, q) = v * P2 - P1;
+            }
+            rows += 2;
+        }
+    }
+    double pt[3];
+    if (!np_dlt_point(sA, t, rows, pt)) return;
     for (int k = 0; k < 3; k++) A.xyz[3 * (size_t)c + k] = pt[k];
     // cheirality (GTSAM_THROW_CHEIRALITY_EXCEPTION): behind any camera -> rejected
     for (int e = 0; e < n; e++) {
@@ -313,6 +322,85 @@ __global__ __launch_bounds__(64) void k_np_triangulate(NpArgs A) {
     }
     A.nObs[c] = count;
     A.accepted[c] = (count >= 3 && correctKF) ? 1 : 0;
+}
+
+// ---- mono map-point creation: calculateMPFromMono + the mono checkReprojError (src/FeatureTracker.cpp:1580-1684) ----
+// thread = keypoint of lastKF, 64 per workgroup, same DLT layout as k_np_triangulate.  Restated literally, quirks
+// included: the accept test `p4d(2) < 0.1` looks at the WORLD z of the point, and the reprojection check multiplies
+// with K * pose.block<3,4>() of KeyFrame::pose.pose (camera-to-world) - not its inverse.
+struct NpMonoArgs {
+    int nKf, nPts;
+    DPose Twc[NP_MAX_KF], Tcw[NP_MAX_KF];
+    int kfId[NP_MAX_KF];
+    const int* nViews; const int* viewKf; const float* viewXy; const int* viewOct;      // [nPts], [nPts][nKf], ...
+    double fx, fy, cx, cy;
+    float sigma[MAX_LEVELS];
+    uint8_t* accepted; double* xyz; int* nObs; uint8_t* keep;                           // keep: [nPts][nKf]
+};
+__global__ __launch_bounds__(64) void k_np_mono_points(NpMonoArgs A) {
+    extern __shared__ double sA[];
+    const int t = threadIdx.x, c = blockIdx.x * 64 + t;
+    if (c >= A.nPts) return;
+    auto a = [&](int r, int q) -> double& { return sA[((size_t)(r * 4 + q)) * 64 + t]; };
+    const int n = A.nViews[c];
+    const int* vk = A.viewKf + (size_t)c * A.nKf;
+    const float* vxy = A.viewXy + (size_t)c * A.nKf * 2;
+    const int* vo = A.viewOct + (size_t)c * A.nKf;
+    uint8_t* keep = A.keep + (size_t)c * A.nKf;
+    A.accepted[c] = 0;
+    A.nObs[c] = n;
+    for (int e = 0; e < A.nKf; e++) keep[e] = e < n ? 1 : 0;      // untouched unless checkReprojError runs
+    if (n < 2) return;                                   // minNumberOfKFsForMp (include/FeatureTracker.h:54)
+    for (int e = 0; e < n; e++) {
+        const DPose& T = A.Tcw[vk[e]];
+        const double u = (double)vxy[2 * e], v = (double)vxy[2 * e + 1];
+        double M[12];
+        for (int r = 0; r < 3; r++) { for (int q = 0; q < 3; q++) M[4 * r + q] = T.R[3 * r + q]; M[4 * r + 3] = T.t[r]; }
+        for (int q = 0; q < 4; q++) {
+            const double P0 = A.fx * M[q] + 0.0 * M[4 + q] + A.cx * M[8 + q];
+            const double P1 = 0.0 * M[q] + A.fy * M[4 + q] + A.cy * M[8 + q];
+            const double P2 = 0.0 * M[q] + 0.0 * M[4 + q] + 1.0 * M[8 + q];
+            a(2 * e, q) = u * P2 - P0;
+            a(2 * e + 1, q) = v * P2 - P1;
+        }
+    }
+    double pt[3];
+    if (!np_dlt_point(sA, t, 2 * n, pt)) return;
+    for (int k = 0; k < 3; k++) A.xyz[3 * (size_t)c + k] = pt[k];
+    for (int e = 0; e < n; e++) {                        // TriangulationCheiralityException
+        const DPose& T = A.Tcw[vk[e]];
+        if (T.R[6] * pt[0] + T.R[7] * pt[1] + T.R[8] * pt[2] + T.t[2] <= 0) return;
+    }
+    if (pt[2] < 0.1) return;                             // :1625 (world z)
+    const float reprjThreshold = 7.815f;
+    int count = 0;
+    bool correctKF = false;
+    for (int i = 0; i < n; i++) {
+        const DPose& T = A.Twc[vk[i]];                   // observationPoses[i] = KF->pose.pose (:1606)
+        double p[3];
+        for (int r = 0; r < 3; r++) {
+            const double K0 = r == 0 ? A.fx : 0.0, K1 = r == 1 ? A.fy : 0.0, K2 = r == 0 ? A.cx : (r == 1 ? A.cy : 1.0);
+            double acc = 0;
+            for (int q = 0; q < 4; q++) {
+                const double m0 = q < 3 ? T.R[q] : T.t[0], m1 = q < 3 ? T.R[3 + q] : T.t[1], m2 = q < 3 ? T.R[6 + q] : T.t[2];
+                const double Prq = K0 * m0 + K1 * m1 + K2 * m2;              // (K * pose.block<3,4>)(r, q)
+                const double x = q < 3 ? pt[q] : 1.0;
+                acc = q == 0 ? Prq * x : acc + Prq * x;
+            }
+            p[r] = acc;
+        }
+        const double e1 = (double)vxy[2 * i] - p[0] / p[2], e2 = (double)vxy[2 * i + 1] - p[1] / p[2];
+        const float err = (float)(e1 * e1 + e2 * e2);
+        const double weight = (double)A.sigma[vo[i]];
+        keep[i] = 0;
+        if (!((double)err > (double)reprjThreshold * weight)) {
+            keep[i] = 1;
+            count++;
+            if (A.kfId[vk[i]] == A.kfId[0]) correctKF = true;
+        }
+    }
+    A.nObs[c] = count;
+    A.accepted[c] = (count >= 2 && correctKF) ? 1 : 0;
 }
 
 // MapPoint::calcDescriptor: wave = one map point with n <= 64 observation descriptors (lane = descriptor)
@@ -479,5 +567,48 @@ extern "C" vslam_status vslam_calc_descriptors(const uint8_t* descs, const int32
     hipLaunchKernelGGL(k_calc_descriptor, dim3((n_mp + 3) / 4), dim3(256), 0, nullptr, n_mp, dD.p, dS.p, dB.p);
     VS_HIP(hipGetLastError());
     VS_HIP(hipMemcpy(best_out, dB.p, (size_t)n_mp * sizeof(int), hipMemcpyDeviceToHost));
+    return VSLAM_OK;
+}
+
+// calculateMPFromMono for every keypoint of lastKF (views gathered by the caller's matchByRadius passes)
+extern "C" vslam_status vslam_mono_new_points(const vslam_mono_points_problem* P, vslam_mono_points_result* R, int32_t device) {
+    if (!P || !R || P->n_kf < 1 || P->n_kf > NP_MAX_KF || P->n_points < 0 || P->n_levels < 1 || P->n_levels > MAX_LEVELS ||
+        !P->kf_pose_wc || !P->kf_id || !P->sigma_factor ||
+        (P->n_points > 0 && (!P->n_views || !P->view_kf || !P->view_xy || !P->view_octave || !R->accepted || !R->xyz || !R->n_obs || !R->keep))) {
+        set_error("vslam_mono_new_points: invalid problem");
+        return VSLAM_ERR_INVALID;
+    }
+    const int nP = P->n_points, nK = P->n_kf;
+    for (int i = 0; i < nP; i++) {
+        if (P->n_views[i] < 0 || P->n_views[i] > nK) { set_error("vslam_mono_new_points: n_views out of range"); return VSLAM_ERR_INVALID; }
+        for (int e = 0; e < P->n_views[i]; e++)
+            if (P->view_kf[(size_t)i * nK + e] < 0 || P->view_kf[(size_t)i * nK + e] >= nK || P->view_octave[(size_t)i * nK + e] < 0 ||
+                P->view_octave[(size_t)i * nK + e] >= P->n_levels) { set_error("vslam_mono_new_points: view index out of range"); return VSLAM_ERR_INVALID; }
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available (no CPU fallback)"); return VSLAM_ERR_NO_DEVICE; }
+    if (device < 0 || device >= ndev) return VSLAM_ERR_INVALID;
+    if (nP == 0) return VSLAM_OK;
+    VS_HIP(hipSetDevice(device));
+    NpMonoArgs A{};
+    A.nKf = nK; A.nPts = nP;
+    for (int k = 0; k < nK; k++) { pose_from_rm16(P->kf_pose_wc + 16 * (size_t)k, A.Twc[k]); pose_inverse(A.Twc[k], A.Tcw[k]); A.kfId[k] = P->kf_id[k]; }
+    A.fx = P->rig.fx; A.fy = P->rig.fy; A.cx = P->rig.cx; A.cy = P->rig.cy;
+    for (int l = 0; l < P->n_levels; l++) A.sigma[l] = P->sigma_factor[l];
+    Dev<int> dNv, dVk, dVo, dNo; Dev<float> dXy; Dev<uint8_t> dAcc, dKeep; Dev<double> dXyz;
+    VS_HIP(dNv.up(P->n_views, (size_t)nP, nullptr)); VS_HIP(dVk.up(P->view_kf, (size_t)nP * nK, nullptr));
+    VS_HIP(dVo.up(P->view_octave, (size_t)nP * nK, nullptr)); VS_HIP(dXy.up(P->view_xy, (size_t)nP * nK * 2, nullptr));
+    VS_HIP(dAcc.alloc(nP)); VS_HIP(dKeep.alloc((size_t)nP * nK)); VS_HIP(dXyz.alloc((size_t)nP * 3)); VS_HIP(dNo.alloc(nP));
+    VS_HIP(hipMemset(dXyz.p, 0, (size_t)nP * 3 * sizeof(double)));
+    A.nViews = dNv.p; A.viewKf = dVk.p; A.viewXy = dXy.p; A.viewOct = dVo.p;
+    A.accepted = dAcc.p; A.xyz = dXyz.p; A.nObs = dNo.p; A.keep = dKeep.p;
+    const size_t lds = (size_t)2 * nK * 4 * 64 * sizeof(double);
+    VS_HIP(hipFuncSetAttribute((const void*)k_np_mono_points, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_np_mono_points, dim3((nP + 63) / 64), dim3(64), lds, nullptr, A);
+    VS_HIP(hipGetLastError());
+    VS_HIP(hipMemcpy(R->accepted, dAcc.p, nP, hipMemcpyDeviceToHost));
+    VS_HIP(hipMemcpy(R->keep, dKeep.p, (size_t)nP * nK, hipMemcpyDeviceToHost));
+    VS_HIP(hipMemcpy(R->xyz, dXyz.p, (size_t)nP * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    VS_HIP(hipMemcpy(R->n_obs, dNo.p, (size_t)nP * sizeof(int), hipMemcpyDeviceToHost));
     return VSLAM_OK;
 }

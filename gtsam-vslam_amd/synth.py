@@ -278,3 +278,43 @@ def imu_samples(t0, t1, fps=20.0, hz=200, T_bs=T_BC1, gravity=(0.0, 9.81, 0.0), 
     n = len(ts)
     dts = np.full(n, 1.0 / hz)
     return samples, dts, g
+
+
+def make_mono_points_problem(rig_name="euroc", n_kf=4, n_points=400, seed=0x4D4F, trans_sigma=0.01, rot_sigma=0.002,
+                             pix_noise=0.3, outlier_frac=0.1):
+    """Input of FeatureTracker::addMappointsMono after its matchByRadius passes: n_kf keyframes a few centimetres apart
+    (mono initialisation), every keypoint of keyframe 0 with 1..n_kf views.  A share of the views are outliers, a few
+    points sit behind a camera or below world z = 0.1 (the reference's accept test looks at the world z).
+    Returns dict(rig, kf_pose (n_kf,4,4) camera-to-world, kf_id, n_views, view_kf, view_xy, view_oct, truth)."""
+    rng = np.random.default_rng(seed)
+    rig = RIGS[rig_name]
+    poses = [np.eye(4)]
+    for _ in range(n_kf - 1):
+        poses.append(poses[-1] @ _small_pose(rng, rot_sigma, trans_sigma))
+    poses = np.stack(poses)
+    ids = np.arange(100, 100 + n_kf, dtype=np.int32)[::-1].copy()        # lastKF (index 0) is the newest
+    truth = np.zeros((n_points, 3))
+    n_views = np.zeros(n_points, np.int32)
+    view_kf = np.zeros((n_points, n_kf), np.int32)
+    view_xy = np.zeros((n_points, n_kf, 2), np.float32)
+    view_oct = np.zeros((n_points, n_kf), np.int32)
+    for i in range(n_points):
+        z = rng.uniform(2.0, 12.0) if rng.random() > 0.04 else rng.uniform(-1.0, 0.09)
+        u, v = rng.uniform(20, rig["w"] - 20), rng.uniform(20, rig["h"] - 20)
+        pc = np.array([(u - rig["cx"]) / rig["fx"] * z, (v - rig["cy"]) / rig["fy"] * z, z, 1.0])
+        pw = poses[0] @ pc
+        truth[i] = pw[:3]
+        nv = int(rng.integers(1, n_kf + 1))
+        others = list(rng.permutation(np.arange(1, n_kf))[:nv - 1])
+        ks = [0] + sorted(int(k) for k in others)
+        n_views[i] = len(ks)
+        for e, k in enumerate(ks):
+            q = np.linalg.inv(poses[k]) @ pw
+            zz = q[2] if abs(q[2]) > 1e-6 else 1e-6
+            x = rig["fx"] * q[0] / zz + rig["cx"] + rng.normal(0, pix_noise)
+            y = rig["fy"] * q[1] / zz + rig["cy"] + rng.normal(0, pix_noise)
+            if rng.random() < outlier_frac and e > 0:
+                x += rng.uniform(-40, 40); y += rng.uniform(-40, 40)
+            view_kf[i, e] = k; view_xy[i, e] = (x, y); view_oct[i, e] = int(rng.integers(0, 8))
+    return dict(rig=rig, kf_pose=poses, kf_id=ids, n_views=n_views, view_kf=view_kf, view_xy=view_xy, view_oct=view_oct,
+                truth=truth)

@@ -617,6 +617,38 @@ def find_new_points(rig, scale_pyramid, sigma_factor, kfs, last, device=0):
     return dict(n=nc, candL=cL[:nc], candR=cR[:nc], accepted=acc[:nc], xyz=xyz[:nc], nObs=nObs[:nc], obs=obs[:nc])
 
 
+class MonoPointsProblem(C.Structure):
+    _fields_ = [("rig", Rig), ("n_levels", C.c_int32), ("sigma_factor", C.c_void_p), ("n_kf", C.c_int32),
+                ("kf_pose_wc", C.c_void_p), ("kf_id", C.c_void_p), ("n_points", C.c_int32), ("n_views", C.c_void_p),
+                ("view_kf", C.c_void_p), ("view_xy", C.c_void_p), ("view_octave", C.c_void_p)]
+
+
+class MonoPointsResult(C.Structure):
+    _fields_ = [("accepted", C.c_void_p), ("xyz", C.c_void_p), ("n_obs", C.c_void_p), ("keep", C.c_void_p)]
+
+
+def mono_new_points(rig, sigma_factor, kf_pose_wc, kf_id, n_views, view_kf, view_xy, view_octave, device=0):
+    """calculateMPFromMono + mono checkReprojError for every keypoint of lastKF (keyframe 0).
+    view_*: (n_points, n_kf[, 2]) arrays, the first n_views[i] entries of row i are used."""
+    T = np.ascontiguousarray(kf_pose_wc, np.float64).reshape(-1, 16)
+    nK = len(T)
+    ids = np.ascontiguousarray(kf_id, np.int32)
+    sg = np.ascontiguousarray(sigma_factor, np.float32)
+    nv = np.ascontiguousarray(n_views, np.int32); nP = len(nv)
+    vk = np.ascontiguousarray(view_kf, np.int32).reshape(nP, nK)
+    vxy = np.ascontiguousarray(view_xy, np.float32).reshape(nP, nK, 2)
+    vo = np.ascontiguousarray(view_octave, np.int32).reshape(nP, nK)
+    acc = np.zeros(max(nP, 1), np.uint8); xyz = np.zeros((max(nP, 1), 3)); nobs = np.zeros(max(nP, 1), np.int32)
+    keep = np.zeros((max(nP, 1), nK), np.uint8)
+    P = MonoPointsProblem()
+    P.rig = make_rig(rig); P.n_levels = len(sg); P.sigma_factor = _p(sg); P.n_kf = nK; P.kf_pose_wc = _p(T); P.kf_id = _p(ids)
+    P.n_points = nP; P.n_views, P.view_kf, P.view_xy, P.view_octave = _p(nv), _p(vk), _p(vxy), _p(vo)
+    R = MonoPointsResult()
+    R.accepted, R.xyz, R.n_obs, R.keep = _p(acc), _p(xyz), _p(nobs), _p(keep)
+    _chk(lib().vslam_mono_new_points(C.byref(P), C.byref(R), int(device)))
+    return dict(accepted=acc[:nP], xyz=xyz[:nP], nObs=nobs[:nP], keep=keep[:nP])
+
+
 def calc_descriptors(desc_lists, device=0):
     """desc_lists: list of (n_i, 32) uint8 arrays; returns the chosen index per map point."""
     start = np.zeros(len(desc_lists) + 1, np.int32)

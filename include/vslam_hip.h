@@ -392,6 +392,37 @@ typedef struct {
 vslam_status vslam_find_new_points(const vslam_new_points_problem* problem, vslam_new_points_result* result,
                                    int32_t device);
 
+/* Mono map-point creation — replaces the numerical part of FeatureTracker::addMappointsMono
+ * (src/FeatureTracker.cpp:1497-1553) after its matchByRadius passes (vslam_match_by_radius):
+ * calculateMPFromMono (:1580-1636: gtsam::triangulatePoint3 DLT over the left observations, cheirality, the
+ * `p4d(2) < 0.1` test) and the mono checkReprojError (:1638-1684) for every keypoint of the last keyframe.
+ * Quirks kept: that test looks at the WORLD z; the reprojection check projects with K * pose.block<3,4>() of
+ * KeyFrame::pose.pose (camera-to-world), not its inverse.  KeyFrame construction (initializeMono,
+ * insertKeyFrameMono) and MapPoint insertion stay with the caller. */
+typedef struct {
+    vslam_rig rig;
+    int32_t n_levels;
+    const float* sigma_factor;         /* KeyFrame::sigmaFactor */
+    int32_t n_kf;                      /* <= 16; keyframe 0 = lastKF */
+    const double* kf_pose_wc;          /* [n_kf][16] KeyFrame::pose.pose, row-major */
+    const int32_t* kf_id;              /* KeyFrame::numb */
+    int32_t n_points;                  /* keypoints of lastKF */
+    const int32_t* n_views;            /* [n_points] keyframeIdxMatchs[i].size() (lastKF itself first) */
+    const int32_t* view_kf;            /* [n_points][n_kf] keyframe index of each view */
+    const float* view_xy;              /* [n_points][n_kf][2] keypoint position in that keyframe */
+    const int32_t* view_octave;        /* [n_points][n_kf] its octave */
+} vslam_mono_points_problem;
+
+typedef struct {
+    uint8_t* accepted;                 /* out [n_points]: calculateMPFromMono returned true */
+    double* xyz;                       /* out [n_points][3]: triangulated position (valid where accepted) */
+    int32_t* n_obs;                    /* out [n_points]: views left after checkReprojError (n_views if it was not reached) */
+    uint8_t* keep;                     /* out [n_points][n_kf]: view e survived checkReprojError */
+} vslam_mono_points_result;
+
+vslam_status vslam_mono_new_points(const vslam_mono_points_problem* problem, vslam_mono_points_result* result,
+                                   int32_t device);
+
 /* MapPoint::calcDescriptor (src/Map.cpp:145-210) for a batch of map points: descs = the observation
  * descriptors of all points concatenated (32 B each, in the order the caller iterates kFMatches),
  * start[n_mp + 1] = first descriptor of each point; best_out[m] = index (within the point) of the descriptor

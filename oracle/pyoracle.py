@@ -252,6 +252,23 @@ def local_ba(rig, sigma_factor, inv_sigma_factor, prob):
                 residuals=int(stats[0]), landmarks=int(stats[1]), free_kf=int(stats[2]), sum_k2=int(stats[3]))
 
 
+def mono_new_points(rig, sigma_factor, kf_pose_wc, kf_id, n_views, view_kf, view_xy, view_octave):
+    """FeatureTracker::calculateMPFromMono + the mono checkReprojError for every keypoint of lastKF (keyframe 0)."""
+    T = np.ascontiguousarray(kf_pose_wc, np.float64).reshape(-1, 16)
+    nK = len(T)
+    ids = np.ascontiguousarray(kf_id, np.int64)
+    sg = np.ascontiguousarray(sigma_factor, np.float32)
+    nv = np.ascontiguousarray(n_views, np.int32); nP = len(nv)
+    vk = np.ascontiguousarray(view_kf, np.int32).reshape(nP, nK)
+    vxy = np.ascontiguousarray(view_xy, np.float32).reshape(nP, nK, 2)
+    vo = np.ascontiguousarray(view_octave, np.int32).reshape(nP, nK)
+    acc = np.zeros(max(nP, 1), np.uint8); xyz = np.zeros((max(nP, 1), 3)); nobs = np.zeros(max(nP, 1), np.int32)
+    keep = np.zeros((max(nP, 1), nK), np.uint8)
+    lib().vo_mono_new_points(C.c_double(rig["fx"]), C.c_double(rig["fy"]), C.c_double(rig["cx"]), C.c_double(rig["cy"]), nK,
+                             _p(T), _p(ids), _p(sg), nP, _p(nv), _p(vk), _p(vxy), _p(vo), _p(acc), _p(xyz), _p(nobs), _p(keep))
+    return dict(accepted=acc[:nP], xyz=xyz[:nP], nObs=nobs[:nP], keep=keep[:nP])
+
+
 def pose3_logmap(T):
     T = np.ascontiguousarray(T, np.float64); xi = np.zeros(6)
     lib().vo_pose3_logmap(_p(T), _p(xi)); return xi

@@ -541,4 +541,29 @@ int vo_triangulate_dlt(const double* P34, const double* uv, int m, double* out) 
     for (int q = 0; q < 3; q++) out[q] = r.v[q];
     return ok ? 1 : 0;
 }
+// addMappointsMono's numerical part for every keypoint of lastKF (views gathered by the caller)
+void vo_mono_new_points(double fx, double fy, double cx, double cy, int nKf, const double* T_wc16, const long long* ids,
+                        const float* sigmaFactor, int nPts, const int* nViews, const int* viewKf, const float* viewXy,
+                        const int* viewOct, uint8_t* accepted, double* xyz, int* nObs, uint8_t* keepOut) {
+    Rig rig{};
+    rig.fx = fx; rig.fy = fy; rig.cx = cx; rig.cy = cy;
+    std::vector<Pose> T(nKf);
+    std::vector<long> id(nKf);
+    for (int k = 0; k < nKf; k++) {
+        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) T[k].R.m[3 * r + c] = T_wc16[16 * k + 4 * r + c]; T[k].t.v[r] = T_wc16[16 * k + 4 * r + 3]; }
+        id[k] = (long)ids[k];
+    }
+    for (int i = 0; i < nPts; i++) {
+        std::vector<MonoView> views;
+        for (int e = 0; e < nViews[i]; e++)
+            views.push_back(MonoView{viewKf[(size_t)i * nKf + e], viewXy[((size_t)i * nKf + e) * 2], viewXy[((size_t)i * nKf + e) * 2 + 1], viewOct[(size_t)i * nKf + e]});
+        Vec3 p{};
+        std::vector<uint8_t> keep;
+        int no = 0;
+        accepted[i] = calculateMPFromMono(views, T, id, rig, sigmaFactor, p, keep, no) ? 1 : 0;
+        for (int q = 0; q < 3; q++) xyz[3 * (size_t)i + q] = p.v[q];
+        nObs[i] = no;
+        for (int e = 0; e < nKf; e++) keepOut[(size_t)i * nKf + e] = e < (int)keep.size() ? keep[e] : 0;
+    }
+}
 }  // extern "C"

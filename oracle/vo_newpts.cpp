@@ -274,4 +274,63 @@ int calcDescriptorIndex(const uint8_t* descs, int n) {
     return BestIdx;
 }
 
+// calculateMPFromMono (:1580-1636) and the mono checkReprojError (:1638-1684), literally: the z test is on the world
+// coordinate (:1625), the reprojection uses K * pose.block<3,4>() of KeyFrame::pose.pose (:1606, :1655)
+bool calculateMPFromMono(const std::vector<MonoView>& views, const std::vector<Pose>& T_wc, const std::vector<long>& kfId,
+                         const Rig& rig, const float* sigmaFactor, Vec3& xyz, std::vector<uint8_t>& keep, int& nObs) {
+    const int n = (int)views.size();
+    keep.assign(n, 1);
+    nObs = n;
+    xyz = Vec3{};
+    if (n < 2) return false;                               // minNumberOfKFsForMp (:1526)
+    std::vector<double> P, uv;
+    for (const MonoView& v : views) {
+        const Pose T = pose_inverse(T_wc[v.kf]);
+        uv.push_back((double)v.x); uv.push_back((double)v.y);
+        const double K[9] = {rig.fx, 0, rig.cx, 0, rig.fy, rig.cy, 0, 0, 1};
+        double M[12];
+        for (int r = 0; r < 3; r++) { for (int q = 0; q < 3; q++) M[4 * r + q] = T.R.m[3 * r + q]; M[4 * r + 3] = T.t.v[r]; }
+        for (int r = 0; r < 3; r++)
+            for (int q = 0; q < 4; q++) P.push_back(K[3 * r] * M[q] + K[3 * r + 1] * M[4 + q] + K[3 * r + 2] * M[8 + q]);
+    }
+    Vec3 pt;
+    if (!triangulateDLT(P, uv, 1e-9, pt)) return false;    // TriangulationUnderconstrainedException
+    xyz = pt;
+    for (const MonoView& v : views) {                      // TriangulationCheiralityException
+        const Pose T = pose_inverse(T_wc[v.kf]);
+        const Vec3 pl = mat3_vec(T.R, pt);
+        if (pl.v[2] + T.t.v[2] <= 0) return false;
+    }
+    if (pt.v[2] < 0.1) return false;
+    const float reprjThreshold = 7.815f;
+    int count = 0;
+    bool correctKF = false;
+    for (int i = 0; i < n; i++) {
+        const Pose& T = T_wc[views[i].kf];
+        const double K[9] = {rig.fx, 0, rig.cx, 0, rig.fy, rig.cy, 0, 0, 1};
+        double p[3];
+        for (int r = 0; r < 3; r++) {
+            double acc = 0;
+            for (int q = 0; q < 4; q++) {
+                const double m0 = q < 3 ? T.R.m[q] : T.t.v[0], m1 = q < 3 ? T.R.m[3 + q] : T.t.v[1], m2 = q < 3 ? T.R.m[6 + q] : T.t.v[2];
+                const double Prq = K[3 * r] * m0 + K[3 * r + 1] * m1 + K[3 * r + 2] * m2;
+                const double x = q < 3 ? pt.v[q] : 1.0;
+                acc = q == 0 ? Prq * x : acc + Prq * x;
+            }
+            p[r] = acc;
+        }
+        const double err1 = (double)views[i].x - p[0] / p[2], err2 = (double)views[i].y - p[1] / p[2];
+        const float err = (float)(err1 * err1 + err2 * err2);
+        const double weight = (double)sigmaFactor[views[i].oct];
+        keep[i] = 0;
+        if (!(err > reprjThreshold * weight)) {
+            keep[i] = 1;
+            count++;
+            if (kfId[views[i].kf] == kfId[0]) correctKF = true;
+        }
+    }
+    nObs = count;
+    return count >= 2 && correctKF;
+}
+
 }  // namespace vo

@@ -45,4 +45,11 @@ void findNewPoints(const Extractor& fe, const std::vector<KFView>& kfs, const La
 // MapPoint::calcDescriptor: index of the representative descriptor among n (least median Hamming distance)
 int calcDescriptorIndex(const uint8_t* descs, int n);
 
+// FeatureTracker::calculateMPFromMono (src/FeatureTracker.cpp:1580-1636) + the mono checkReprojError (:1638-1684) for
+// one keypoint of lastKF: views = keyframeIdxMatchs[i] (keyframe index, keypoint position, octave; lastKF first).
+// keep[e] = view e is still in `keys` on return; nObs = keys.size() on return.
+struct MonoView { int kf; float x, y; int oct; };
+bool calculateMPFromMono(const std::vector<MonoView>& views, const std::vector<Pose>& T_wc, const std::vector<long>& kfId,
+                         const Rig& rig, const float* sigmaFactor, Vec3& xyz, std::vector<uint8_t>& keep, int& nObs);
+
 }  // namespace vo

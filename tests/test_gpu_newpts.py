@@ -79,3 +79,18 @@ def test_calc_descriptor_parity(oracle, capi):
     assert list(got) == ref
     with pytest.raises(capi.VslamError):
         capi.calc_descriptors([np.zeros((65, 32), np.uint8)])
+
+
+def test_mono_map_point_creation_parity(oracle, capi):
+    """vslam_mono_new_points (calculateMPFromMono + mono checkReprojError) vs the oracle: identical accept flags, view
+    filters and counts; positions to 1e-9 relative (same DLT / Jacobi-SVD operation order, no FMA contraction)."""
+    import synth
+    sf = np.array([1.2 ** (2 * i) for i in range(8)], np.float32)
+    for kw in (dict(), dict(n_kf=10, n_points=1500, seed=5, trans_sigma=0.05), dict(n_kf=2, n_points=70, seed=9, outlier_frac=0.3)):
+        pr = synth.make_mono_points_problem(**kw)
+        args = (pr["rig"], sf, pr["kf_pose"], pr["kf_id"], pr["n_views"], pr["view_kf"], pr["view_xy"], pr["view_oct"])
+        ref, got = oracle.mono_new_points(*args), capi.mono_new_points(*args)
+        assert np.array_equal(got["accepted"], ref["accepted"]) and ref["accepted"].sum() > 5
+        assert np.array_equal(got["nObs"], ref["nObs"]) and np.array_equal(got["keep"], ref["keep"])
+        m = ref["accepted"] > 0
+        assert np.abs(got["xyz"][m] - ref["xyz"][m]).max() <= 1e-9 * np.abs(ref["xyz"][m]).max()

@@ -37,3 +37,28 @@ def test_calc_descriptor_median_rule(oracle):
     med = [sorted(row)[int(0.5 * (len(d) - 1))] for row in dist]
     assert oracle.calc_descriptor(d) == int(np.argmin(med))
     assert oracle.calc_descriptor(d[:1]) == 0
+
+
+def test_mono_map_point_creation_quirks_and_sanity(oracle):
+    """calculateMPFromMono + the mono checkReprojError (src/FeatureTracker.cpp:1580-1684) as restated: needs >= 2 views,
+    rejects world z < 0.1, and its reprojection check multiplies with KeyFrame::pose.pose (camera-to-world), so with the
+    centimetre baselines of mono initialisation it acts as a loose gate; accepted points sit near the truth."""
+    import synth
+    pr = synth.make_mono_points_problem()
+    sf = np.array([1.2 ** (2 * i) for i in range(8)], np.float32)
+    r = oracle.mono_new_points(pr["rig"], sf, pr["kf_pose"], pr["kf_id"], pr["n_views"], pr["view_kf"], pr["view_xy"], pr["view_oct"])
+    acc = r["accepted"].astype(bool)
+    assert 40 < acc.sum() < len(acc)
+    assert not acc[pr["n_views"] < 2].any()                       # minNumberOfKFsForMp
+    assert not acc[r["xyz"][:, 2] < 0.1].any()                    # the world-z test
+    assert (r["nObs"][acc] >= 2).all() and (r["keep"][acc, 0] == 1).all()      # lastKF must survive the filter
+    assert (r["keep"].sum(1)[acc] == r["nObs"][acc]).all()
+    # triangulation quality of accepted points whose every view was an inlier: depth is weakly observed at these
+    # baselines, the bearing is not
+    ok = acc & (r["nObs"] == pr["n_views"])
+    b_est = r["xyz"][ok] / np.linalg.norm(r["xyz"][ok], axis=1, keepdims=True)
+    b_tru = pr["truth"][ok] / np.linalg.norm(pr["truth"][ok], axis=1, keepdims=True)
+    assert np.median(np.arccos(np.clip((b_est * b_tru).sum(1), -1, 1))) < 2e-3
+    # a single view or an empty row is never triangulated
+    r1 = oracle.mono_new_points(pr["rig"], sf, pr["kf_pose"], pr["kf_id"], np.minimum(pr["n_views"], 1), pr["view_kf"], pr["view_xy"], pr["view_oct"])
+    assert r1["accepted"].sum() == 0
