@@ -240,20 +240,21 @@ void launch_fast(hipStream_t s, const uint8_t* pyr, const PyrDesc& P, const Fast
 // ---------------------------------------------------------------------------
 // K2b: gather cell lists into one level-major, cell-row-major candidate list per image
 // (the order in which the reference appends: src/FeatureExtractor.cpp:568-602).
-// One workgroup (1024 threads) per image: block-wide exclusive scan of the cell
-// counts, then one wave per cell copies its slots.
 // ---------------------------------------------------------------------------
+// grid (image, slice): every workgroup scans the cell counts of its image into LDS (a few thousand ints), then the
+// output elements are spread over all slices: element j finds its cell by binary search in the LDS offsets - no
+// per-cell dependent-load chain (that chain made the one-workgroup-per-image form 45 us).
 __global__ __launch_bounds__(1024) void k_gather(const uint32_t* __restrict__ cellSlots,
                                                  const int* __restrict__ cellCount, FastDesc F,
                                                  int nLevels, int* __restrict__ cellOff,
                                                  uint32_t* __restrict__ cand, int candCap,
                                                  int* __restrict__ levelCount) {
+    extern __shared__ int soff[];          // [nCells + 1]
     __shared__ int wtot[16];
     __shared__ int s_run;
     const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nCells = F.cellBase[nLevels];
     const int* cnt = cellCount + (size_t)img * nCells;
-    int* off = cellOff + (size_t)img * (nCells + 1);
     if (tid == 0) s_run = 0;
     __syncthreads();
     for (int base = 0; base < nCells; base += 1024) {
@@ -270,30 +271,36 @@ __global__ __launch_bounds__(1024) void k_gather(const uint32_t* __restrict__ ce
         int woff = 0;
         for (int k = 0; k < wave; k++) woff += wtot[k];
         const int run = s_run;
-        if (i < nCells) off[i] = run + woff + incl - v;
+        if (i < nCells) soff[i] = run + woff + incl - v;
         __syncthreads();
         if (tid == 1023) s_run = run + woff + incl;
         __syncthreads();
     }
-    if (tid == 0) off[nCells] = s_run;
+    const int total = s_run;
+    if (tid == 0) soff[nCells] = total;
     __syncthreads();
-    if (tid < nLevels) {
-        const int a = off[F.cellBase[tid]], b = off[F.cellBase[tid + 1]];
-        levelCount[img * (MAX_LEVELS + 1) + tid] = b - a;
+    if (blockIdx.y == 0) {                 // one slice publishes the offsets / per-level counts
+        int* off = cellOff + (size_t)img * (nCells + 1);
+        for (int i = tid; i <= nCells; i += 1024) off[i] = soff[i];
+        if (tid < nLevels) levelCount[img * (MAX_LEVELS + 1) + tid] = soff[F.cellBase[tid + 1]] - soff[F.cellBase[tid]];
+        if (tid == 0) levelCount[img * (MAX_LEVELS + 1) + MAX_LEVELS] = total;
     }
-    if (tid == 0) levelCount[img * (MAX_LEVELS + 1) + MAX_LEVELS] = s_run;
     uint32_t* out = cand + (size_t)img * candCap;
-    for (int cell = wave; cell < nCells; cell += 16) {
-        const int n = cnt[cell], o = off[cell];
-        const uint32_t* sl = cellSlots + ((size_t)img * nCells + cell) * F.cellCap;
-        for (int e = lane; e < n; e += 64)
-            if (o + e < candCap) out[o + e] = sl[e];
+    const int lim = min(total, candCap);
+    for (int j = blockIdx.y * 1024 + tid; j < lim; j += gridDim.y * 1024) {
+        int lo = 0, hi = nCells;           // first cell with soff[cell + 1] > j
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (soff[mid + 1] > j) hi = mid; else lo = mid + 1;
+        }
+        out[j] = cellSlots[((size_t)img * nCells + lo) * F.cellCap + (j - soff[lo])];
     }
 }
 
 void launch_gather(hipStream_t s, const uint32_t* cellSlots, const int* cellCount, const FastDesc& F,
                    int nLevels, int* cellOff, uint32_t* cand, int candCap, int* levelCount, int nimg) {
-    hipLaunchKernelGGL(k_gather, dim3(nimg), dim3(1024), 0, s, cellSlots, cellCount, F, nLevels,
+    const int nCells = F.cellBase[nLevels];
+    hipLaunchKernelGGL(k_gather, dim3(nimg, 8), dim3(1024), (size_t)(nCells + 1) * sizeof(int), s, cellSlots, cellCount, F, nLevels,
                        cellOff, cand, candCap, levelCount);
 }
 
