@@ -165,24 +165,35 @@ __device__ __forceinline__ void ba_eval_edge(const BaEdge& e, const DPose& Ta, c
 // from E, the linearisation is stored in `out` (the same element, or its twin of the speculative buffers).
 // Returns sum r^2 on lane 0 (0 elsewhere).
 __device__ __forceinline__ double ba_edge_linearize(BaEdge& out, const BaEdge& E, const DPose& Ta, const DPose& Tb,
-                                                    double* sW, double* Sacc, int n, int lane) {
+                                                    double* sW, double* Sacc, int n, int tid) {
     double* Hl = sW; double* Ad = Hl + 36; double* Ja = Ad + 36; double* Jb = Ja + 36; double* rr = Jb + 36;
     const double w = 1.0 / 0.01;
     const int fa = E.fa, fb = E.fb;
+    const int lane = tid & 63, wave = tid >> 6;
     double v = 0;
-    if (lane == 0) {
-        DPose Tai, h, Mi, d, hi;
+    // the three single-lane chains run on three waves at once (every thread of the workgroup calls this function):
+    // wave 0 the residual (Logmap), wave 1 LogmapDerivative, wave 2 the adjoint; each rebuilds the cheap pose products
+    if (lane == 0 && wave < 3) {
+        DPose Tai, h;
         pose_inverse(Ta, Tai);
         pose_compose(Tai, Tb, h);
-        pose_inverse(E.measured, Mi);
-        pose_compose(Mi, h, d);
-        double r[6];
-        pose3_logmap(d, r);
-        for (int i = 0; i < 6; i++) { r[i] *= w; rr[i] = r[i]; out.r[i] = r[i]; v += r[i] * r[i]; }
-        pose3_logmap_derivative(d, Hl);
-        pose_inverse(h, hi);
-        pose3_adjoint(hi, Ad);
+        if (wave == 2) {
+            DPose hi;
+            pose_inverse(h, hi);
+            pose3_adjoint(hi, Ad);
+        } else {
+            DPose Mi, d;
+            pose_inverse(E.measured, Mi);
+            pose_compose(Mi, h, d);
+            if (wave == 0) {
+                double r[6];
+                pose3_logmap(d, r);
+                for (int i = 0; i < 6; i++) { r[i] *= w; rr[i] = r[i]; out.r[i] = r[i]; v += r[i] * r[i]; }
+            } else pose3_logmap_derivative(d, Hl);
+        }
     }
+    __syncthreads();
+    if (wave != 0) return 0.0;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const int i = lane / 6, j = lane % 6;
     if (lane < 36) {
@@ -373,17 +384,17 @@ __global__ __launch_bounds__(256) void k_ba_factors(BaDev D, int obsBlocks, int 
         }
         ba_block_sum<2, 4>(v, red, out);
         if (tid == 0) { ba_publish(&D.partial[2 * blockIdx.x], out[0]); ba_publish(&D.partial[2 * blockIdx.x + 1], out[1]); }
-    } else if (tid < 64) {
+    } else {
         const int e = blockIdx.x - obsBlocks;
         double v[2] = {0, 0};
         if (e < D.NE) {
             const BaEdge& E = D.edges[e];
             const int fa = E.fa, fb = E.fb;
             if (MODE == 0) {
-                v[0] = ba_edge_linearize(D.edges[e], E, D.poseCur[E.a], D.poseCur[E.b], sW, D.Sedge, D.n, lane);
+                v[0] = ba_edge_linearize(D.edges[e], E, D.poseCur[E.a], D.poseCur[E.b], sW, D.Sedge, D.n, tid);
             } else {
-                if (lane >= 8 && lane < 14) {          // linearised cost at delta, from the current linearisation
-                    const int k = lane - 8;
+                if (tid >= 8 && tid < 14) {            // linearised cost at delta, from the current linearisation
+                    const int k = tid - 8;
                     double l = E.r[k];
                     for (int i = 0; i < 6; i++) {
                         if (fa >= 0) l += E.Ja[k * 6 + i] * D.dP[6 * fa + i];
@@ -391,8 +402,8 @@ __global__ __launch_bounds__(256) void k_ba_factors(BaDev D, int obsBlocks, int 
                     }
                     v[0] += l * l;
                 }
-                if (D.specLin) v[1] = ba_edge_linearize(D.edges2[e], E, D.poseTrial[E.a], D.poseTrial[E.b], sW, D.Sedge2, D.n, lane);
-                else if (lane == 0) {
+                if (D.specLin) v[1] = ba_edge_linearize(D.edges2[e], E, D.poseTrial[E.a], D.poseTrial[E.b], sW, D.Sedge2, D.n, tid);
+                else if (tid == 0) {
                     DPose Tai, h, Mi, d;
                     pose_inverse(D.poseTrial[E.a], Tai);
                     pose_compose(Tai, D.poseTrial[E.b], h);
@@ -408,7 +419,7 @@ __global__ __launch_bounds__(256) void k_ba_factors(BaDev D, int obsBlocks, int 
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1) v[k] += __shfl_xor(v[k], d);
             }
-            if (lane == 0) { ba_publish(&D.partial[2 * obsBlocks + 2 * e], v[0]); ba_publish(&D.partial[2 * obsBlocks + 2 * e + 1], v[1]); }
+            if (tid == 0) { ba_publish(&D.partial[2 * obsBlocks + 2 * e], v[0]); ba_publish(&D.partial[2 * obsBlocks + 2 * e + 1], v[1]); }
         }
     }
     // The last workgroup to arrive sums every partial in array order.  No __threadfence here: on gfx950 an
