@@ -384,7 +384,7 @@ def main():
         roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launch_ms": dom_ms, "algorithmic_bytes": alg_bytes,
                 "launches_timed": n_launch,
-                "note": "single-workgroup, latency-bound kernel (serial dependency chain of the reference algorithm): "
+                "note": "latency-bound kernel, one workgroup per problem instance (serial dependency chain of the reference algorithm): "
                         "the fraction is reported against the HBM roofline as the contract asks, the kernel is bound by "
                         "instruction latency, not by bytes or flops (DESIGN.md section 4)"}
         # HBM-side traffic of the same kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE are
