@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void k_ba_factors(BaDev D, int obsBlocks, int 
     double* const partialBase = D.partial;
     const int cand = MODE == 0 ? 0 : (int)blockIdx.y;      // trial launches: grid y = lambda candidate
     if (!ba_enter(D, MODE == 0 ? BA_LINEARIZE : BA_TRY, cand)) return;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x;
     if ((int)blockIdx.x < obsBlocks) {
         double v[2] = {0, 0};
         for (int f = blockIdx.x * 256 + tid; f < D.NF; f += obsBlocks * 256) {

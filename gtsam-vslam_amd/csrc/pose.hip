@@ -26,7 +26,6 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_lm(PoseArgs A) {
     const int tid = threadIdx.x;
     if (A.gate && *A.gate < A.gateMin) return;
     if (A.Mdev) A.M = min(A.M, *A.Mdev);
-    const int M = A.M;
 
     __shared__ float sLvl[MAX_LEVELS];
     __shared__ int sCntTab[2 * POSE_BATCH * (POSE_NT / 64)];

@@ -215,10 +215,24 @@ __global__ __launch_bounds__(SSC_NT) void k_ssc(SscArgs A) {
     }
     __syncthreads();
     int cur = 0;
+#ifdef VSLAM_SSC_STAMPS
+    int it_ = 0;
+    long long it_t = clock64();
+#endif
     for (;;) {
         const int nseg = sCnt[cur];
         if (nseg == 0) break;
         int* segC = seg + cur * SSC_SEGMAX * 3;
+#ifdef VSLAM_SSC_STAMPS
+        if (tid == 0 && l == 0 && img == 0) {
+            int mx = 0, small = 0;
+            for (int s = 0; s < nseg; s++) { const int len = segC[3 * s + 1] - segC[3 * s]; mx = max(mx, len); small += len <= 64; }
+            const long long now = clock64();
+            printf("  ssc iter %d: nseg %d (<=64: %d) maxlen %d | previous iteration %lld cycles\n", it_, nseg, small, mx, now - it_t);
+            it_t = clock64();
+        }
+        it_++;
+#endif
         int* segN = seg + (cur ^ 1) * SSC_SEGMAX * 3;
         for (int s = wave; s < nseg; s += SSC_NW) {
             const int f = segC[3 * s], e = segC[3 * s + 1], depth = segC[3 * s + 2];
