@@ -1271,6 +1271,28 @@ __global__ __launch_bounds__(256) void k_ba_chi2(BaChi C) {
     C.wrong[p] = w;
 }
 
+// MapPoint::updatePos (src/Map.cpp:212-234) for every kFMatches entry: depth / close refresh from the optimised values
+__global__ __launch_bounds__(256) void k_ba_refresh_depth(int NP, const int* __restrict__ pairKf, const int* __restrict__ pairLm,
+                                                          const uint8_t* __restrict__ pairWrong, const uint8_t* __restrict__ lmOutlier,
+                                                          const float* __restrict__ curDepth, const DPose* __restrict__ Tcw,
+                                                          const double* __restrict__ lm, float closeTh, float* __restrict__ depthOut,
+                                                          uint8_t* __restrict__ closeOut, uint8_t* __restrict__ updated) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= NP) return;
+    uint8_t up = 0, cl = 0;
+    float d = 0.f;
+    const int l = pairLm[p];
+    if (!pairWrong[p] && !lmOutlier[l] && !(curDepth[p] <= 0)) {
+        const DPose& T = Tcw[pairKf[p]];
+        const double* w = lm + 3 * (size_t)l;
+        const double z = T.R[6] * w[0] + T.R[7] * w[1] + T.R[8] * w[2] + T.t[2] * 1.0;     // row 2 of getInvPose() * wp
+        d = (float)z;
+        cl = z <= (double)closeTh ? 1 : 0;
+        up = 1;
+    }
+    depthOut[p] = d; closeOut[p] = cl; updated[p] = up;
+}
+
 // landmark exchange of the sharded path: diff = cur - init (zero for landmarks this rank does not own),
 // all-reduce, cur = init + diff
 __global__ __launch_bounds__(256) void k_ba_lm_diff(int n, const double* __restrict__ cur, const double* __restrict__ init,
@@ -1926,6 +1948,53 @@ vslam_status vslam_local_ba_set_lookahead(int32_t candidates, int32_t speculativ
 
 vslam_status vslam_local_ba_set_timing(int32_t on) {
     g_baTimer.enabled = on != 0;
+    return VSLAM_OK;
+}
+
+vslam_status vslam_ba_refresh_depth(const vslam_rig* rig, int32_t n_kf, const double* kf_pose_wc, int32_t n_lm,
+                                    const double* lm_xyz, const uint8_t* lm_outlier, int32_t n_pairs,
+                                    const int32_t* pair_kf, const int32_t* pair_lm, const uint8_t* pair_wrong,
+                                    const float* cur_depth, int32_t device, float* depth_out, uint8_t* close_out,
+                                    uint8_t* updated_out) {
+    if (!rig || n_kf < 1 || n_lm < 0 || n_pairs < 0 || !kf_pose_wc || (n_lm > 0 && (!lm_xyz || !lm_outlier)) ||
+        (n_pairs > 0 && (!pair_kf || !pair_lm || !pair_wrong || !cur_depth || !depth_out || !close_out || !updated_out))) {
+        set_error("vslam_ba_refresh_depth: invalid arguments");
+        return VSLAM_ERR_INVALID;
+    }
+    for (int p = 0; p < n_pairs; p++)
+        if (pair_kf[p] < 0 || pair_kf[p] >= n_kf || pair_lm[p] < 0 || pair_lm[p] >= n_lm) { set_error("vslam_ba_refresh_depth: pair index out of range"); return VSLAM_ERR_INVALID; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available (no CPU fallback)"); return VSLAM_ERR_NO_DEVICE; }
+    if (device < 0 || device >= ndev) return VSLAM_ERR_INVALID;
+    if (n_pairs == 0) return VSLAM_OK;
+    VS_HIP(hipSetDevice(device));
+    std::vector<DPose> Tcw(n_kf);
+    for (int k = 0; k < n_kf; k++) { DPose T; pose_from_rm16(kf_pose_wc + 16 * (size_t)k, T); pose_inverse(T, Tcw[k]); }
+    // one device allocation for all operands (released on every exit path)
+    struct Scoped { uint8_t* p = nullptr; ~Scoped() { if (p) hipFree(p); } } mem;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+    const size_t oT = take(n_kf * sizeof(DPose)), oLm = take((size_t)3 * std::max(n_lm, 1) * sizeof(double)), oO = take(std::max(n_lm, 1)),
+                 oKf = take(n_pairs * sizeof(int)), oL = take(n_pairs * sizeof(int)), oW = take(n_pairs), oCur = take(n_pairs * sizeof(float)),
+                 oD = take(n_pairs * sizeof(float)), oC = take(n_pairs), oU = take(n_pairs);
+    VS_HIP(hipMalloc((void**)&mem.p, off));
+    VS_HIP(hipMemcpy(mem.p + oT, Tcw.data(), n_kf * sizeof(DPose), hipMemcpyHostToDevice));
+    if (n_lm) {
+        VS_HIP(hipMemcpy(mem.p + oLm, lm_xyz, (size_t)3 * n_lm * sizeof(double), hipMemcpyHostToDevice));
+        VS_HIP(hipMemcpy(mem.p + oO, lm_outlier, n_lm, hipMemcpyHostToDevice));
+    }
+    VS_HIP(hipMemcpy(mem.p + oKf, pair_kf, n_pairs * sizeof(int), hipMemcpyHostToDevice));
+    VS_HIP(hipMemcpy(mem.p + oL, pair_lm, n_pairs * sizeof(int), hipMemcpyHostToDevice));
+    VS_HIP(hipMemcpy(mem.p + oW, pair_wrong, n_pairs, hipMemcpyHostToDevice));
+    VS_HIP(hipMemcpy(mem.p + oCur, cur_depth, n_pairs * sizeof(float), hipMemcpyHostToDevice));
+    const float closeTh = rig->baseline * 40;
+    hipLaunchKernelGGL(k_ba_refresh_depth, dim3((n_pairs + 255) / 256), dim3(256), 0, nullptr, n_pairs, (const int*)(mem.p + oKf),
+                       (const int*)(mem.p + oL), (const uint8_t*)(mem.p + oW), (const uint8_t*)(mem.p + oO), (const float*)(mem.p + oCur),
+                       (const DPose*)(mem.p + oT), (const double*)(mem.p + oLm), closeTh, (float*)(mem.p + oD), mem.p + oC, mem.p + oU);
+    VS_HIP(hipGetLastError());
+    VS_HIP(hipMemcpy(depth_out, mem.p + oD, n_pairs * sizeof(float), hipMemcpyDeviceToHost));
+    VS_HIP(hipMemcpy(close_out, mem.p + oC, n_pairs, hipMemcpyDeviceToHost));
+    VS_HIP(hipMemcpy(updated_out, mem.p + oU, n_pairs, hipMemcpyDeviceToHost));
     return VSLAM_OK;
 }
 

@@ -338,6 +338,20 @@ def local_ba_timings():
     return {names[i].decode(): float(ms[i]) for i in range(n.value)}
 
 
+def ba_refresh_depth(rig, kf_pose_wc, lm_xyz, lm_outlier, pair_kf, pair_lm, pair_wrong, cur_depth, device=0):
+    """MapPoint::updatePos depth / close refresh after localBA (vslam_ba_refresh_depth); returns (depth, close, updated)."""
+    T = np.ascontiguousarray(kf_pose_wc, np.float64).reshape(-1, 16)
+    lm = np.ascontiguousarray(lm_xyz, np.float64).reshape(-1, 3); lo = np.ascontiguousarray(lm_outlier, np.uint8)
+    pk = np.ascontiguousarray(pair_kf, np.int32); pl = np.ascontiguousarray(pair_lm, np.int32)
+    pw = np.ascontiguousarray(pair_wrong, np.uint8); cd = np.ascontiguousarray(cur_depth, np.float32)
+    n = len(pk)
+    d = np.zeros(max(n, 1), np.float32); c = np.zeros(max(n, 1), np.uint8); u = np.zeros(max(n, 1), np.uint8)
+    r = make_rig(rig)
+    _chk(lib().vslam_ba_refresh_depth(C.byref(r), len(T), _p(T), len(lm), _p(lm), _p(lo), n, _p(pk), _p(pl), _p(pw), _p(cd), int(device),
+                                      _p(d), _p(c), _p(u)))
+    return d[:n], c[:n], u[:n]
+
+
 def local_ba_set_timing(on):
     _chk(lib().vslam_local_ba_set_timing(int(bool(on))))
 

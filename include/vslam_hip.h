@@ -310,6 +310,20 @@ typedef struct vslam_ba_result {
     int64_t n_residuals, n_landmarks, n_free_kf, sum_k2;   /* work figures of the last pass           */
 } vslam_ba_result;
 
+/* Write-back of localBA, numerical part of MapPoint::updatePos (src/Map.cpp:212-234) as called from
+ * src/OptimizationBA.cpp:913-933 after the keyframe poses were set (:891-910): for every (keyframe, landmark) entry
+ * still in kFMatches (pair_wrong == 0) of a landmark that is not flagged an outlier, whose left keypoint currently
+ * has estimatedDepth > 0:  estimatedDepth = (T_cw * wp).z  (stored as float),  close = true when that z <=
+ * 40 * baseline (never reset).  Pair-parallel; the caller scatters depth_out / close_out into
+ * TrackedKeys::estimatedDepth / close at keyPos.first where updated_out is 1.  (Entries with keyPos.first < 0
+ * index estimatedDepth[-1] in the reference: pass cur_depth <= 0 for them; they are skipped.)
+ * calcDescriptor of the same function is vslam_calc_descriptors. */
+vslam_status vslam_ba_refresh_depth(const vslam_rig* rig, int32_t n_kf, const double* kf_pose_wc, int32_t n_lm,
+                                    const double* lm_xyz, const uint8_t* lm_outlier, int32_t n_pairs,
+                                    const int32_t* pair_kf, const int32_t* pair_lm, const uint8_t* pair_wrong,
+                                    const float* cur_depth, int32_t device, float* depth_out, uint8_t* close_out,
+                                    uint8_t* updated_out);
+
 /* Communicator for landmark-sharded BA (NULL = single GPU).  Every rank passes the SAME flattened problem;
  * rank r owns the landmarks with index % world == r, forms its partial reduced camera system, and one
  * all-reduce(sum, fp64) of [(6F)^2 + 6F] doubles per lambda trial (plus a 3-double cost reduction) makes the

@@ -269,6 +269,19 @@ def mono_new_points(rig, sigma_factor, kf_pose_wc, kf_id, n_views, view_kf, view
     return dict(accepted=acc[:nP], xyz=xyz[:nP], nObs=nobs[:nP], keep=keep[:nP])
 
 
+def ba_refresh_depth(rig, kf_pose_wc, lm_xyz, lm_outlier, pair_kf, pair_lm, pair_wrong, cur_depth):
+    """MapPoint::updatePos depth / close refresh after localBA's pose write-back; returns (depth, close, updated)."""
+    T = np.ascontiguousarray(kf_pose_wc, np.float64).reshape(-1, 16)
+    lm = np.ascontiguousarray(lm_xyz, np.float64).reshape(-1, 3); lo = np.ascontiguousarray(lm_outlier, np.uint8)
+    pk = np.ascontiguousarray(pair_kf, np.int32); pl = np.ascontiguousarray(pair_lm, np.int32)
+    pw = np.ascontiguousarray(pair_wrong, np.uint8); cd = np.ascontiguousarray(cur_depth, np.float32)
+    n = len(pk)
+    d = np.zeros(max(n, 1), np.float32); c = np.zeros(max(n, 1), np.uint8); u = np.zeros(max(n, 1), np.uint8)
+    lib().vo_ba_refresh_depth(C.c_float(rig["bl"]), len(T), _p(T), len(lm), _p(lm), _p(lo), n, _p(pk), _p(pl), _p(pw), _p(cd),
+                              _p(d), _p(c), _p(u))
+    return d[:n], c[:n], u[:n]
+
+
 def pose3_logmap(T):
     T = np.ascontiguousarray(T, np.float64); xi = np.zeros(6)
     lib().vo_pose3_logmap(_p(T), _p(xi)); return xi

@@ -466,4 +466,27 @@ void localBA(const BAProblem& P, BAResult& R) {
     R.pairWrong = wrong;
 }
 
+void refreshDepth(float baseline, int nKf, const double* T_wc16, int nLm, const double* lm, const uint8_t* lmOutlier, int nPairs,
+                  const int* pairKf, const int* pairLm, const uint8_t* pairWrong, const float* curDepth, float* depthOut,
+                  uint8_t* closeOut, uint8_t* updated) {
+    (void)nLm;
+    std::vector<Pose> Tcw(nKf);
+    for (int k = 0; k < nKf; k++) {
+        Pose T;
+        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) T.R.m[3 * r + c] = T_wc16[16 * k + 4 * r + c]; T.t.v[r] = T_wc16[16 * k + 4 * r + 3]; }
+        Tcw[k] = pose_inverse(T);
+    }
+    const float closeTh = baseline * 40;
+    for (int p = 0; p < nPairs; p++) {
+        depthOut[p] = 0.f; closeOut[p] = 0; updated[p] = 0;
+        const int l = pairLm[p];
+        if (pairWrong[p] || lmOutlier[l] || curDepth[p] <= 0) continue;
+        const Pose& T = Tcw[pairKf[p]];
+        const double z = T.R.m[6] * lm[3 * l] + T.R.m[7] * lm[3 * l + 1] + T.R.m[8] * lm[3 * l + 2] + T.t.v[2] * 1.0;
+        depthOut[p] = (float)z;
+        closeOut[p] = z <= (double)closeTh ? 1 : 0;
+        updated[p] = 1;
+    }
+}
+
 }  // namespace vo

@@ -57,4 +57,10 @@ void pose3_logmap(const Pose& T, double xi[6]);
 void pose3_logmap_derivative(const Pose& T, double J[36]);
 void pose3_adjoint(const Pose& T, double A[36]);
 
+// MapPoint::updatePos (src/Map.cpp:212-234) for every kFMatches entry after localBA's write-back of the poses
+// (src/OptimizationBA.cpp:891-933): estimatedDepth = (T_cw * wp).z as float, close set when z <= 40 * baseline.
+void refreshDepth(float baseline, int nKf, const double* T_wc16, int nLm, const double* lm, const uint8_t* lmOutlier, int nPairs,
+                  const int* pairKf, const int* pairLm, const uint8_t* pairWrong, const float* curDepth, float* depthOut,
+                  uint8_t* closeOut, uint8_t* updated);
+
 }  // namespace vo

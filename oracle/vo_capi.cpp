@@ -566,4 +566,9 @@ void vo_mono_new_points(double fx, double fy, double cx, double cy, int nKf, con
         for (int e = 0; e < nKf; e++) keepOut[(size_t)i * nKf + e] = e < (int)keep.size() ? keep[e] : 0;
     }
 }
+void vo_ba_refresh_depth(float baseline, int nKf, const double* T_wc16, int nLm, const double* lm, const uint8_t* lmOutlier, int nPairs,
+                         const int* pairKf, const int* pairLm, const uint8_t* pairWrong, const float* curDepth, float* depthOut,
+                         uint8_t* closeOut, uint8_t* updated) {
+    refreshDepth(baseline, nKf, T_wc16, nLm, lm, lmOutlier, nPairs, pairKf, pairLm, pairWrong, curDepth, depthOut, closeOut, updated);
+}
 }  // extern "C"

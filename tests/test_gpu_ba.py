@@ -170,3 +170,19 @@ def test_ba_lookahead_matches_sequential_trials(capi, oracle, kind):
         assert np.abs(o["kf_pose"] - base["kf_pose"]).max() < 1e-7        # the bar of the oracle comparison above
         assert np.median(np.linalg.norm(o["lm"] - base["lm"], axis=1)) < 1e-5   # (weakly observed depth rays amplify round-off)
         assert np.array_equal(o["pair_wrong"], base["pair_wrong"]) and np.array_equal(o["pair_wrong1"], base["pair_wrong1"])
+
+
+def test_write_back_depth_refresh_parity(oracle, capi):
+    """vslam_ba_refresh_depth (MapPoint::updatePos after localBA) vs the oracle on a solved problem: bit-identical."""
+    prob = synth.make_ba_problem(n_local=10, n_fixed=4, n_lm=3000, seed=11)
+    ex = oracle.Extractor(1500)
+    res = capi.local_ba(prob["rig"], ex.sigmaFactor, ex.InvSigmaFactor, prob)
+    rng = np.random.default_rng(3)
+    P = len(prob["pair_kf"])
+    cur = np.where(rng.random(P) < 0.7, rng.uniform(0.5, 30, P), -1.0).astype(np.float32)
+    out = (rng.random(len(prob["lm"])) < 0.1).astype(np.uint8)
+    args = (prob["rig"], res["kf_pose"], res["lm"], out, prob["pair_kf"], prob["pair_lm"], res["pair_wrong"], cur)
+    d0, c0, u0 = oracle.ba_refresh_depth(*args)
+    d1, c1, u1 = capi.ba_refresh_depth(*args)
+    assert np.array_equal(u0, u1) and u0.sum() > 1000 and (u0 == 0).sum() > 1000
+    assert np.array_equal(d0, d1) and np.array_equal(c0, c1) and 0 < c0.sum() < u0.sum()

@@ -84,3 +84,22 @@ def test_local_ba_flags_gross_outliers_and_caps_iterations(oracle):
     e0 = np.abs(prob["kf_pose"][:10, :3, 3] - prob["kf_pose_true"][:10, :3, 3]).max()
     e1 = np.abs(r["kf_pose"][:10, :3, 3] - prob["kf_pose_true"][:10, :3, 3]).max()
     assert e1 < e0
+
+
+def test_write_back_depth_refresh_known_answers(oracle):
+    """MapPoint::updatePos after localBA (src/Map.cpp:212-234): depth = z in the (new) keyframe frame as float, close set
+    below 40 baselines, entries that are wrong / belong to an outlier landmark / have no stereo depth are left alone."""
+    import synth
+    rig = synth.RIGS["euroc"]
+    T = np.stack([np.eye(4), np.eye(4)])
+    T[1, :3, 3] = [0.5, 0.0, 1.0]                      # camera 1 one metre ahead
+    lm = np.array([[0.0, 0.0, 3.0], [1.0, 0.5, 10.0], [0.0, 0.0, 2.0]])
+    out = np.array([0, 0, 1], np.uint8)
+    pk = np.array([0, 1, 0, 1, 0, 1], np.int32); pl = np.array([0, 0, 1, 1, 2, 0], np.int32)
+    wrong = np.array([0, 0, 0, 1, 0, 0], np.uint8)
+    cur = np.array([3.1, 2.2, 9.0, 9.0, 2.0, -1.0], np.float32)
+    d, c, u = oracle.ba_refresh_depth(rig, T, lm, out, pk, pl, wrong, cur)
+    assert list(u) == [1, 1, 1, 0, 0, 0]               # wrong pair, outlier landmark, no stereo depth
+    assert np.allclose(d[:3], [3.0, 2.0, 10.0]) and d.dtype == np.float32
+    th = np.float32(rig["bl"]) * np.float32(40)
+    assert list(c[:3]) == [int(3.0 <= th), int(2.0 <= th), int(10.0 <= th)]
