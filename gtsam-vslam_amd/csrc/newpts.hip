@@ -403,6 +403,48 @@ __global__ __launch_bounds__(64) void k_np_mono_points(NpMonoArgs A) {
     A.accepted[c] = (count >= 2 && correctKF) ? 1 : 0;
 }
 
+// KeyFrame::updatePose (src/KeyFrame.cpp:6-76): thread = slot of localMapPoints (blockIdx.y = 0) / localMapPointsR (1)
+struct KfUpdArgs {
+    int nL, nR; long long numb;
+    DPose newPose, newPoseInv, newPoseRInv, curInv;
+    const vslam_keypoint* kpsL; const vslam_keypoint* kpsR; const int* slotL; const int* slotR;
+    double* lm; const long long* kdx; const uint8_t* outlier;
+    double fx, fy, cx, cy;
+    float invSigma[MAX_LEVELS];
+    uint8_t* dropL; uint8_t* dropR;
+};
+__global__ __launch_bounds__(256) void k_kf_update_pose(KfUpdArgs A) {
+    const int idx = blockIdx.x * 256 + threadIdx.x, right = blockIdx.y;
+    if (idx >= (right ? A.nR : A.nL)) return;
+    uint8_t drop = 0;
+    const int m = right ? A.slotR[idx] : A.slotL[idx];
+    if (m >= 0 && !A.outlier[m]) {
+        double* p = A.lm + 3 * (size_t)m;
+        const double w[3] = {p[0], p[1], p[2]};
+        if (A.kdx[m] == A.numb) {
+            if (!right) {                                  // moves with its keyframe
+                double c[3], n[3];
+                mat3_vec(A.curInv.R, w, c);
+                for (int q = 0; q < 3; q++) c[q] += A.curInv.t[q];
+                mat3_vec(A.newPose.R, c, n);
+                for (int q = 0; q < 3; q++) p[q] = n[q] + A.newPose.t[q];
+            }
+        } else if (A.kdx[m] < A.numb) {
+            const DPose& T = right ? A.newPoseRInv : A.newPoseInv;
+            const vslam_keypoint obs = right ? A.kpsR[idx] : A.kpsL[idx];
+            double c[3];
+            mat3_vec(T.R, w, c);
+            for (int q = 0; q < 3; q++) c[q] += T.t[q];
+            const double invZ = 1.0 / c[2];
+            const double u = A.fx * c[0] * invZ + A.cx, v = A.fy * c[1] * invZ + A.cy;
+            const double e1 = (double)obs.x - u, e2 = (double)obs.y - v;
+            const double err = ((e1 * e1) + (e2 * e2)) * (double)A.invSigma[obs.octave];
+            if (err > 7.815f) drop = 1;
+        }
+    }
+    (right ? A.dropR : A.dropL)[idx] = drop;
+}
+
 // MapPoint::calcDescriptor: wave = one map point with n <= 64 observation descriptors (lane = descriptor)
 __global__ __launch_bounds__(256) void k_calc_descriptor(int nMp, const uint8_t* __restrict__ descs, const int* __restrict__ start,
                                                          int* __restrict__ best) {
@@ -610,5 +652,49 @@ extern "C" vslam_status vslam_mono_new_points(const vslam_mono_points_problem* P
     VS_HIP(hipMemcpy(R->keep, dKeep.p, (size_t)nP * nK, hipMemcpyDeviceToHost));
     VS_HIP(hipMemcpy(R->xyz, dXyz.p, (size_t)nP * 3 * sizeof(double), hipMemcpyDeviceToHost));
     VS_HIP(hipMemcpy(R->n_obs, dNo.p, (size_t)nP * sizeof(int), hipMemcpyDeviceToHost));
+    return VSLAM_OK;
+}
+
+extern "C" vslam_status vslam_keyframe_update_pose(const vslam_kf_update_problem* P, int32_t device, uint8_t* drop_l, uint8_t* drop_r,
+                                                   double* pose_out) {
+    if (!P || !pose_out || !P->key_pose || !P->ref_pose || !P->cur_pose_inv || !P->inv_sigma_factor || P->n_levels < 1 ||
+        P->n_levels > MAX_LEVELS || P->n_left < 0 || P->n_right < 0 || P->n_lm < 0 ||
+        (P->n_left > 0 && (!P->kps_left || !P->slot_lm_l || !drop_l)) || (P->n_right > 0 && (!P->kps_right || !P->slot_lm_r || !drop_r)) ||
+        (P->n_lm > 0 && (!P->lm_xyz || !P->lm_kdx || !P->lm_outlier))) {
+        set_error("vslam_keyframe_update_pose: invalid problem");
+        return VSLAM_ERR_INVALID;
+    }
+    for (int i = 0; i < P->n_left; i++) if (P->slot_lm_l[i] >= P->n_lm || P->kps_left[i].octave < 0 || P->kps_left[i].octave >= P->n_levels) { set_error("vslam_keyframe_update_pose: left slot out of range"); return VSLAM_ERR_INVALID; }
+    for (int i = 0; i < P->n_right; i++) if (P->slot_lm_r[i] >= P->n_lm || P->kps_right[i].octave < 0 || P->kps_right[i].octave >= P->n_levels) { set_error("vslam_keyframe_update_pose: right slot out of range"); return VSLAM_ERR_INVALID; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available (no CPU fallback)"); return VSLAM_ERR_NO_DEVICE; }
+    if (device < 0 || device >= ndev) return VSLAM_ERR_INVALID;
+    VS_HIP(hipSetDevice(device));
+    KfUpdArgs A{};
+    DPose key, ref;
+    pose_from_rm16(P->key_pose, key); pose_from_rm16(P->ref_pose, ref); pose_from_rm16(P->cur_pose_inv, A.curInv);
+    pose_compose(key, ref, A.newPose);                           // newPose = keyPose * pose.refPose
+    pose_inverse(A.newPose, A.newPoseInv);
+    A.newPoseRInv = A.newPoseInv;
+    A.newPoseRInv.t[0] -= (double)P->rig.baseline;               // (newPose * extr)^-1 for the rectified rig
+    pose_to_rm16(A.newPose, pose_out);
+    A.nL = P->n_left; A.nR = P->n_right; A.numb = P->numb;
+    A.fx = P->rig.fx; A.fy = P->rig.fy; A.cx = P->rig.cx; A.cy = P->rig.cy;
+    for (int l = 0; l < P->n_levels; l++) A.invSigma[l] = P->inv_sigma_factor[l];
+    if (A.nL + A.nR == 0) return VSLAM_OK;
+    Dev<vslam_keypoint> dKl, dKr; Dev<int> dSl, dSr; Dev<double> dLm; Dev<long long> dKdx; Dev<uint8_t> dOut, dDl, dDr;
+    VS_HIP(dKl.up(P->kps_left, (size_t)A.nL, nullptr)); VS_HIP(dKr.up(P->kps_right, (size_t)A.nR, nullptr));
+    VS_HIP(dSl.up(P->slot_lm_l, (size_t)A.nL, nullptr)); VS_HIP(dSr.up(P->slot_lm_r, (size_t)A.nR, nullptr));
+    VS_HIP(dLm.up(P->lm_xyz, (size_t)3 * P->n_lm, nullptr));
+    std::vector<long long> kdx(P->lm_kdx, P->lm_kdx + P->n_lm);
+    VS_HIP(dKdx.up(kdx.data(), (size_t)P->n_lm, nullptr)); VS_HIP(dOut.up(P->lm_outlier, (size_t)P->n_lm, nullptr));
+    VS_HIP(dDl.alloc(std::max(A.nL, 1))); VS_HIP(dDr.alloc(std::max(A.nR, 1)));
+    A.kpsL = dKl.p; A.kpsR = dKr.p; A.slotL = dSl.p; A.slotR = dSr.p; A.lm = dLm.p; A.kdx = dKdx.p; A.outlier = dOut.p;
+    A.dropL = dDl.p; A.dropR = dDr.p;
+    hipLaunchKernelGGL(k_kf_update_pose, dim3((std::max(A.nL, A.nR) + 255) / 256, 2), dim3(256), 0, nullptr, A);
+    VS_HIP(hipGetLastError());
+    if (A.nL) VS_HIP(hipMemcpy(drop_l, dDl.p, A.nL, hipMemcpyDeviceToHost));
+    if (A.nR) VS_HIP(hipMemcpy(drop_r, dDr.p, A.nR, hipMemcpyDeviceToHost));
+    if (P->n_lm) VS_HIP(hipMemcpy(P->lm_xyz, dLm.p, (size_t)3 * P->n_lm * sizeof(double), hipMemcpyDeviceToHost));
     return VSLAM_OK;
 }

@@ -318,3 +318,40 @@ def make_mono_points_problem(rig_name="euroc", n_kf=4, n_points=400, seed=0x4D4F
             view_kf[i, e] = k; view_xy[i, e] = (x, y); view_oct[i, e] = int(rng.integers(0, 8))
     return dict(rig=rig, kf_pose=poses, kf_id=ids, n_views=n_views, view_kf=view_kf, view_xy=view_xy, view_oct=view_oct,
                 truth=truth)
+
+
+def make_kf_update_problem(rig_name="euroc", n_left=1500, n_right=1400, n_lm=2500, seed=0x4B46, shift=0.02, pix_noise=0.7):
+    """Input of KeyFrame::updatePose: a keyframe (numb 7) whose pose is re-derived from a corrected previous keyframe;
+    its slots point at landmarks created by itself (kdx == 7: they move along), by older keyframes (re-projected and
+    gated) or newer ones (untouched); some slots are empty, some landmarks outliers.  Keypoints: structured array with
+    fields x, y, octave (the caller converts to its keypoint dtype)."""
+    rng = np.random.default_rng(seed)
+    rig = RIGS[rig_name]
+    cur = _small_pose(rng, 0.2, 1.0)                                  # current pose (world <- camera)
+    ref = _small_pose(rng, 0.05, 0.3)                                 # refPose: relative to the previous keyframe
+    key_old = cur @ np.linalg.inv(ref)
+    key_new = key_old @ _small_pose(rng, 0.004, shift)                # the corrected previous keyframe
+    kdx = rng.choice([3, 5, 7, 7, 9], n_lm).astype(np.int64)
+    outlier = (rng.random(n_lm) < 0.05).astype(np.uint8)
+    z = rng.uniform(1.5, 25.0, n_lm)
+    u = rng.uniform(10, rig["w"] - 10, n_lm); v = rng.uniform(10, rig["h"] - 10, n_lm)
+    pc = np.stack([(u - rig["cx"]) / rig["fx"] * z, (v - rig["cy"]) / rig["fy"] * z, z, np.ones(n_lm)], 1)
+    lm = (cur @ pc.T).T[:, :3]
+
+    def side(n, right):
+        slot = rng.permutation(n_lm)[:n].astype(np.int32) if n <= n_lm else rng.integers(0, n_lm, n).astype(np.int32)
+        slot[rng.random(n) < 0.15] = -1                               # (a map point sits in at most one slot per side)
+        x = np.zeros(n, np.float32); y = np.zeros(n, np.float32); octv = rng.integers(0, 8, n).astype(np.int32)
+        for i in range(n):
+            m = slot[i] if slot[i] >= 0 else 0
+            q = pc[m].copy()
+            if right:
+                q[0] -= rig["bl"]
+            x[i] = rig["fx"] * q[0] / q[2] + rig["cx"] + rng.normal(0, pix_noise)
+            y[i] = rig["fy"] * q[1] / q[2] + rig["cy"] + rng.normal(0, pix_noise)
+        return slot, x, y, octv
+
+    sl, xl, yl, ol = side(n_left, False)
+    sr, xr, yr, orr = side(n_right, True)
+    return dict(rig=rig, numb=7, key_pose=key_new, ref_pose=ref, cur_pose_inv=np.linalg.inv(cur), slotL=sl, slotR=sr,
+                kL=(xl, yl, ol), kR=(xr, yr, orr), lm=lm, kdx=kdx, outlier=outlier, cur=cur)

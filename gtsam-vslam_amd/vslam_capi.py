@@ -663,6 +663,34 @@ def mono_new_points(rig, sigma_factor, kf_pose_wc, kf_id, n_views, view_kf, view
     return dict(accepted=acc[:nP], xyz=xyz[:nP], nObs=nobs[:nP], keep=keep[:nP])
 
 
+class KfUpdateProblem(C.Structure):
+    _fields_ = [("rig", Rig), ("n_levels", C.c_int32), ("inv_sigma_factor", C.c_void_p), ("numb", C.c_int64),
+                ("key_pose", C.c_void_p), ("ref_pose", C.c_void_p), ("cur_pose_inv", C.c_void_p),
+                ("n_left", C.c_int32), ("n_right", C.c_int32), ("kps_left", C.c_void_p), ("kps_right", C.c_void_p),
+                ("slot_lm_l", C.c_void_p), ("slot_lm_r", C.c_void_p), ("n_lm", C.c_int32), ("lm_xyz", C.c_void_p),
+                ("lm_kdx", C.c_void_p), ("lm_outlier", C.c_void_p)]
+
+
+def keyframe_update_pose(rig, inv_sigma_factor, numb, key_pose, ref_pose, cur_pose_inv, kpsL, kpsR, slotL, slotR,
+                         lm_xyz, lm_kdx, lm_outlier, device=0):
+    """KeyFrame::updatePose; returns dict(lm (updated copy), dropL, dropR, pose)."""
+    isf = np.ascontiguousarray(inv_sigma_factor, np.float32)
+    kp, rp, ci = (np.ascontiguousarray(a, np.float64).reshape(16) for a in (key_pose, ref_pose, cur_pose_inv))
+    kl = np.ascontiguousarray(kpsL, KP_DTYPE); kr = np.ascontiguousarray(kpsR, KP_DTYPE)
+    sl = np.ascontiguousarray(slotL, np.int32); sr = np.ascontiguousarray(slotR, np.int32)
+    lm = np.array(lm_xyz, np.float64).reshape(-1, 3).copy()
+    kd = np.ascontiguousarray(lm_kdx, np.int64); ol = np.ascontiguousarray(lm_outlier, np.uint8)
+    dl = np.zeros(max(len(kl), 1), np.uint8); dr = np.zeros(max(len(kr), 1), np.uint8); pose = np.zeros(16)
+    P = KfUpdateProblem()
+    P.rig = make_rig(rig); P.n_levels = len(isf); P.inv_sigma_factor = _p(isf); P.numb = int(numb)
+    P.key_pose, P.ref_pose, P.cur_pose_inv = _p(kp), _p(rp), _p(ci)
+    P.n_left, P.n_right = len(kl), len(kr)
+    P.kps_left, P.kps_right, P.slot_lm_l, P.slot_lm_r = _p(kl), _p(kr), _p(sl), _p(sr)
+    P.n_lm = len(lm); P.lm_xyz, P.lm_kdx, P.lm_outlier = _p(lm), _p(kd), _p(ol)
+    _chk(lib().vslam_keyframe_update_pose(C.byref(P), int(device), _p(dl), _p(dr), _p(pose)))
+    return dict(lm=lm, dropL=dl[:len(kl)], dropR=dr[:len(kr)], pose=pose.reshape(4, 4))
+
+
 def calc_descriptors(desc_lists, device=0):
     """desc_lists: list of (n_i, 32) uint8 arrays; returns the chosen index per map point."""
     start = np.zeros(len(desc_lists) + 1, np.int32)

@@ -324,6 +324,35 @@ vslam_status vslam_ba_refresh_depth(const vslam_rig* rig, int32_t n_kf, const do
                                     const float* cur_depth, int32_t device, float* depth_out, uint8_t* close_out,
                                     uint8_t* updated_out);
 
+/* KeyFrame::updatePose(keyPose) (src/KeyFrame.cpp:6-76) — the per-keyframe step of FeatureTracker::changePosesLCA
+ * (src/FeatureTracker.cpp:884-908), applied along the keyframe chain after a local BA / loop closure moved an earlier
+ * keyframe: newPose = keyPose * refPose; map points created by this keyframe (kdx == numb) move with it
+ * (newPose * (currPoseInv * p)); observations of older points (kdx < numb) are re-projected into the new left / right
+ * camera and dropped when ((du^2 + dv^2) * InvSigmaFactor[octave]) > 7.815f.  slot_lm_l / slot_lm_r give the landmark
+ * index of localMapPoints[idx] / localMapPointsR[idx] (-1 = nullptr).  Outputs: lm_xyz updated in place, drop_l /
+ * drop_r = 1 where the reference nulls the slot (caller: unMatchedF[idx] = -1, eraseKFConnection), pose_out =
+ * the keyframe's new pose (CameraPose::changePose).  A map point occupies at most one left slot (as in the reference's
+ * localMapPoints).  Call per keyframe in chain order. */
+typedef struct {
+    vslam_rig rig;
+    int32_t n_levels;
+    const float* inv_sigma_factor;
+    int64_t numb;                       /* KeyFrame::numb */
+    const double* key_pose;             /* [16] pose of the previous keyframe in the chain (kf->getPose()) */
+    const double* ref_pose;             /* [16] pose.refPose */
+    const double* cur_pose_inv;         /* [16] pose.poseInverse before the update */
+    int32_t n_left, n_right;
+    const vslam_keypoint* kps_left; const vslam_keypoint* kps_right;
+    const int32_t* slot_lm_l; const int32_t* slot_lm_r;
+    int32_t n_lm;
+    double* lm_xyz;                     /* in/out [n_lm][3] */
+    const int64_t* lm_kdx;              /* MapPoint::kdx */
+    const uint8_t* lm_outlier;          /* MapPoint::GetIsOutlier() */
+} vslam_kf_update_problem;
+
+vslam_status vslam_keyframe_update_pose(const vslam_kf_update_problem* problem, int32_t device, uint8_t* drop_l,
+                                        uint8_t* drop_r, double* pose_out);
+
 /* Communicator for landmark-sharded BA (NULL = single GPU).  Every rank passes the SAME flattened problem;
  * rank r owns the landmarks with index % world == r, forms its partial reduced camera system, and one
  * all-reduce(sum, fp64) of [(6F)^2 + 6F] doubles per lambda trial (plus a 3-double cost reduction) makes the

@@ -282,6 +282,22 @@ def ba_refresh_depth(rig, kf_pose_wc, lm_xyz, lm_outlier, pair_kf, pair_lm, pair
     return d[:n], c[:n], u[:n]
 
 
+def keyframe_update_pose(rig, inv_sigma_factor, numb, key_pose, ref_pose, cur_pose_inv, kpsL, kpsR, slotL, slotR,
+                         lm_xyz, lm_kdx, lm_outlier):
+    """KeyFrame::updatePose (src/KeyFrame.cpp:6-76); returns dict(lm (updated copy), dropL, dropR, pose)."""
+    isf = np.ascontiguousarray(inv_sigma_factor, np.float32)
+    kp, rp, ci = (np.ascontiguousarray(a, np.float64).reshape(16) for a in (key_pose, ref_pose, cur_pose_inv))
+    kl = np.ascontiguousarray(kpsL, KP_DTYPE); kr = np.ascontiguousarray(kpsR, KP_DTYPE)
+    sl = np.ascontiguousarray(slotL, np.int32); sr = np.ascontiguousarray(slotR, np.int32)
+    lm = np.array(lm_xyz, np.float64).reshape(-1, 3).copy()
+    kd = np.ascontiguousarray(lm_kdx, np.int64); ol = np.ascontiguousarray(lm_outlier, np.uint8)
+    dl = np.zeros(max(len(kl), 1), np.uint8); dr = np.zeros(max(len(kr), 1), np.uint8); pose = np.zeros(16)
+    lib().vo_keyframe_update_pose(C.c_double(rig["fx"]), C.c_double(rig["fy"]), C.c_double(rig["cx"]), C.c_double(rig["cy"]),
+                                  C.c_float(rig["bl"]), _p(isf), C.c_longlong(int(numb)), _p(kp), _p(rp), _p(ci), len(kl), _p(kl), _p(sl),
+                                  len(kr), _p(kr), _p(sr), len(lm), _p(lm), _p(kd), _p(ol), _p(dl), _p(dr), _p(pose))
+    return dict(lm=lm, dropL=dl[:len(kl)], dropR=dr[:len(kr)], pose=pose.reshape(4, 4))
+
+
 def pose3_logmap(T):
     T = np.ascontiguousarray(T, np.float64); xi = np.zeros(6)
     lib().vo_pose3_logmap(_p(T), _p(xi)); return xi

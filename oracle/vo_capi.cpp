@@ -571,4 +571,27 @@ void vo_ba_refresh_depth(float baseline, int nKf, const double* T_wc16, int nLm,
                          uint8_t* closeOut, uint8_t* updated) {
     refreshDepth(baseline, nKf, T_wc16, nLm, lm, lmOutlier, nPairs, pairKf, pairLm, pairWrong, curDepth, depthOut, closeOut, updated);
 }
+void vo_keyframe_update_pose(double fx, double fy, double cx, double cy, float baseline, const float* invSigma, long long numb,
+                             const double* keyPose16, const double* refPose16, const double* curInv16, int nL, const KeyPoint* kpsL,
+                             const int* slotL, int nR, const KeyPoint* kpsR, const int* slotR, int nLm, double* lmXyz,
+                             const long long* kdx, const uint8_t* outlier, uint8_t* dropL, uint8_t* dropR, double* poseOut16) {
+    Rig rig{};
+    rig.fx = fx; rig.fy = fy; rig.cx = cx; rig.cy = cy; rig.baseline = baseline;
+    auto rd = [](const double* m) { Pose T; for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) T.R.m[3 * r + c] = m[4 * r + c]; T.t.v[r] = m[4 * r + 3]; } return T; };
+    std::vector<KeyPoint> kl(kpsL, kpsL + nL), kr(kpsR, kpsR + nR);
+    std::vector<int> sl(slotL, slotL + nL), sr(slotR, slotR + nR);
+    std::vector<Vec3> lm(nLm);
+    for (int i = 0; i < nLm; i++) for (int q = 0; q < 3; q++) lm[i].v[q] = lmXyz[3 * i + q];
+    std::vector<long> kd(nLm);
+    for (int i = 0; i < nLm; i++) kd[i] = (long)kdx[i];
+    std::vector<uint8_t> ol(outlier, outlier + nLm), dl, dr;
+    Pose np;
+    keyframeUpdatePose(rig, invSigma, (long)numb, rd(keyPose16), rd(refPose16), rd(curInv16), kl, kr, sl, sr, lm, kd, ol, dl, dr, np);
+    for (int i = 0; i < nLm; i++) for (int q = 0; q < 3; q++) lmXyz[3 * i + q] = lm[i].v[q];
+    for (int i = 0; i < nL; i++) dropL[i] = dl[i];
+    for (int i = 0; i < nR; i++) dropR[i] = dr[i];
+    for (int k = 0; k < 16; k++) poseOut16[k] = 0;
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) poseOut16[4 * r + c] = np.R.m[3 * r + c]; poseOut16[4 * r + 3] = np.t.v[r]; }
+    poseOut16[15] = 1;
+}
 }  // extern "C"

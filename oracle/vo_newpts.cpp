@@ -333,4 +333,44 @@ bool calculateMPFromMono(const std::vector<MonoView>& views, const std::vector<P
     return count >= 2 && correctKF;
 }
 
+void keyframeUpdatePose(const Rig& rig, const float* invSigmaFactor, long numb, const Pose& keyPose, const Pose& refPose,
+                        const Pose& curPoseInv, const std::vector<KeyPoint>& kpsL, const std::vector<KeyPoint>& kpsR,
+                        const std::vector<int>& slotL, const std::vector<int>& slotR, std::vector<Vec3>& lm,
+                        const std::vector<long>& kdx, const std::vector<uint8_t>& outlier, std::vector<uint8_t>& dropL,
+                        std::vector<uint8_t>& dropR, Pose& newPoseOut) {
+    const Pose newPose = pose_compose(keyPose, refPose);
+    const Pose newPoseInv = pose_inverse(newPose);
+    Pose newPoseRInv = newPoseInv;
+    newPoseRInv.t.v[0] -= (double)rig.baseline;              // (newPose * extr)^-1, rectified rig
+    newPoseOut = newPose;
+    auto gate = [&](const Pose& T, const Vec3& w, const KeyPoint& obs) {
+        Vec3 c = mat3_vec(T.R, w);
+        for (int q = 0; q < 3; q++) c.v[q] += T.t.v[q];
+        const double invZ = 1.0 / c.v[2];
+        const double u = rig.fx * c.v[0] * invZ + rig.cx, v = rig.fy * c.v[1] * invZ + rig.cy;
+        const double e1 = (double)obs.x - u, e2 = (double)obs.y - v;
+        const double err = ((e1 * e1) + (e2 * e2)) * (double)invSigmaFactor[obs.octave];
+        return err > 7.815f;
+    };
+    dropL.assign(slotL.size(), 0); dropR.assign(slotR.size(), 0);
+    for (size_t idx = 0; idx < slotL.size(); idx++) {
+        const int m = slotL[idx];
+        if (m < 0 || outlier[m]) continue;
+        if (kdx[m] == numb) {
+            Vec3 c = mat3_vec(curPoseInv.R, lm[m]);
+            for (int q = 0; q < 3; q++) c.v[q] += curPoseInv.t.v[q];
+            Vec3 n = mat3_vec(newPose.R, c);
+            for (int q = 0; q < 3; q++) lm[m].v[q] = n.v[q] + newPose.t.v[q];
+        } else if (kdx[m] < numb) {
+            if (gate(newPoseInv, lm[m], kpsL[idx])) dropL[idx] = 1;
+        }
+    }
+    for (size_t idx = 0; idx < slotR.size(); idx++) {
+        const int m = slotR[idx];
+        if (m < 0 || outlier[m]) continue;
+        if (kdx[m] == numb) continue;
+        if (kdx[m] < numb && gate(newPoseRInv, lm[m], kpsR[idx])) dropR[idx] = 1;
+    }
+}
+
 }  // namespace vo

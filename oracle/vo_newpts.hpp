@@ -45,6 +45,14 @@ void findNewPoints(const Extractor& fe, const std::vector<KFView>& kfs, const La
 // MapPoint::calcDescriptor: index of the representative descriptor among n (least median Hamming distance)
 int calcDescriptorIndex(const uint8_t* descs, int n);
 
+// KeyFrame::updatePose (src/KeyFrame.cpp:6-76): new pose = keyPose * refPose; own points (kdx == numb) move with the
+// keyframe, observations of older points are re-projected and dropped above 7.815f.  lm is updated in place.
+void keyframeUpdatePose(const Rig& rig, const float* invSigmaFactor, long numb, const Pose& keyPose, const Pose& refPose,
+                        const Pose& curPoseInv, const std::vector<KeyPoint>& kpsL, const std::vector<KeyPoint>& kpsR,
+                        const std::vector<int>& slotL, const std::vector<int>& slotR, std::vector<Vec3>& lm,
+                        const std::vector<long>& kdx, const std::vector<uint8_t>& outlier, std::vector<uint8_t>& dropL,
+                        std::vector<uint8_t>& dropR, Pose& newPoseOut);
+
 // FeatureTracker::calculateMPFromMono (src/FeatureTracker.cpp:1580-1636) + the mono checkReprojError (:1638-1684) for
 // one keypoint of lastKF: views = keyframeIdxMatchs[i] (keyframe index, keypoint position, octave; lastKF first).
 // keep[e] = view e is still in `keys` on return; nObs = keys.size() on return.

@@ -94,3 +94,16 @@ def test_mono_map_point_creation_parity(oracle, capi):
         assert np.array_equal(got["nObs"], ref["nObs"]) and np.array_equal(got["keep"], ref["keep"])
         m = ref["accepted"] > 0
         assert np.abs(got["xyz"][m] - ref["xyz"][m]).max() <= 1e-9 * np.abs(ref["xyz"][m]).max()
+
+
+def test_keyframe_update_pose_parity(oracle, capi):
+    """vslam_keyframe_update_pose (KeyFrame::updatePose) vs the oracle: identical drop flags, bit-identical moved
+    landmarks and new pose."""
+    import synth
+    from test_oracle_newpts import _kf_update_args
+    for kw in (dict(), dict(shift=0.3, seed=5, n_left=700, n_right=0), dict(seed=9, n_left=0, n_right=300, n_lm=400)):
+        pr = synth.make_kf_update_problem(**kw)
+        ref = oracle.keyframe_update_pose(*_kf_update_args(oracle, pr))
+        got = capi.keyframe_update_pose(*_kf_update_args(capi, pr))
+        assert np.array_equal(got["dropL"], ref["dropL"]) and np.array_equal(got["dropR"], ref["dropR"])
+        assert np.array_equal(got["lm"], ref["lm"]) and np.array_equal(got["pose"], ref["pose"])

@@ -62,3 +62,38 @@ def test_mono_map_point_creation_quirks_and_sanity(oracle):
     # a single view or an empty row is never triangulated
     r1 = oracle.mono_new_points(pr["rig"], sf, pr["kf_pose"], pr["kf_id"], np.minimum(pr["n_views"], 1), pr["view_kf"], pr["view_xy"], pr["view_oct"])
     assert r1["accepted"].sum() == 0
+
+
+def _kf_update_args(mod, pr):
+    def kp(t):
+        k = np.zeros(len(t[0]), mod.KP_DTYPE)
+        k["x"], k["y"], k["octave"] = t
+        return k
+    isf = np.array([1.0 / 1.2 ** (2 * i) for i in range(8)], np.float32)
+    return (pr["rig"], isf, pr["numb"], pr["key_pose"], pr["ref_pose"], pr["cur_pose_inv"], kp(pr["kL"]), kp(pr["kR"]),
+            pr["slotL"], pr["slotR"], pr["lm"], pr["kdx"], pr["outlier"])
+
+
+def test_keyframe_update_pose_semantics(oracle):
+    """KeyFrame::updatePose (src/KeyFrame.cpp:6-76): own landmarks keep their camera-frame coordinates under the new
+    pose, older ones are only gated, newer ones / outliers / empty slots are untouched; a zero correction drops nothing
+    but noise outliers, a large one drops many."""
+    import synth
+    pr = synth.make_kf_update_problem()
+    r = oracle.keyframe_update_pose(*_kf_update_args(oracle, pr))
+    newPose = pr["key_pose"] @ pr["ref_pose"]
+    assert np.abs(r["pose"] - newPose).max() < 1e-12
+    own = np.zeros(len(pr["lm"]), bool)
+    own[pr["slotL"][pr["slotL"] >= 0]] = True
+    own &= (pr["kdx"] == pr["numb"]) & (pr["outlier"] == 0)
+    h = lambda X: np.c_[X, np.ones(len(X))]
+    before = (pr["cur_pose_inv"] @ h(pr["lm"][own]).T).T[:, :3]
+    after = (np.linalg.inv(newPose) @ h(r["lm"][own]).T).T[:, :3]
+    assert own.sum() > 100 and np.abs(before - after).max() < 1e-9
+    assert np.array_equal(r["lm"][~own], pr["lm"][~own])
+    older = lambda slot: (slot >= 0) & (pr["kdx"][np.maximum(slot, 0)] < pr["numb"]) & (pr["outlier"][np.maximum(slot, 0)] == 0)
+    assert not r["dropL"][~older(pr["slotL"])].any() and not r["dropR"][~older(pr["slotR"])].any()
+    assert 0 < r["dropL"].sum() < older(pr["slotL"]).sum() and 0 < r["dropR"].sum() < older(pr["slotR"]).sum()
+    big = synth.make_kf_update_problem(shift=0.5)
+    rb = oracle.keyframe_update_pose(*_kf_update_args(oracle, big))
+    assert rb["dropL"].sum() > 2 * r["dropL"].sum()
