@@ -691,6 +691,13 @@ def keyframe_update_pose(rig, inv_sigma_factor, numb, key_pose, ref_pose, cur_po
     return dict(lm=lm, dropL=dl[:len(kl)], dropR=dr[:len(kr)], pose=pose.reshape(4, 4))
 
 
+def save_trajectory(path, path_positions, is_keyframe, pose_or_ref):
+    """VSlamSystem::saveTrajectoryAndPosition: is_keyframe (n,), pose_or_ref (n,4,4): the pose of a keyframe, the
+    refPose (relative to the closest previous keyframe) of any other frame."""
+    kf = np.ascontiguousarray(is_keyframe, np.uint8); T = np.ascontiguousarray(pose_or_ref, np.float64).reshape(-1, 16)
+    _chk(lib().vslam_save_trajectory(path.encode(), path_positions.encode() if path_positions else None, len(kf), _p(kf), _p(T)))
+
+
 def calc_descriptors(desc_lists, device=0):
     """desc_lists: list of (n_i, 32) uint8 arrays; returns the chosen index per map point."""
     start = np.zeros(len(desc_lists) + 1, np.int32)

@@ -353,6 +353,15 @@ typedef struct {
 vslam_status vslam_keyframe_update_pose(const vslam_kf_update_problem* problem, int32_t device, uint8_t* drop_l,
                                         uint8_t* drop_r, double* pose_out);
 
+/* VSlamSystem::saveTrajectoryAndPosition (src/System.cpp:87-124), host only: one line per frame of allFramesPoses in
+ * the KITTI format (the 12 entries of the first three rows of the camera-to-world pose, row-major, separated by
+ * blanks, default ostream formatting = 6 significant digits) and, in the second file, its translation "tx ty tz ".
+ * A keyframe contributes pose_or_ref[i] as its pose; any other frame pose(closest previous keyframe) * pose_or_ref[i]
+ * (its refPose).  Before the first keyframe the closest keyframe is frame 0, as in the reference.
+ * path_positions may be NULL. */
+vslam_status vslam_save_trajectory(const char* path_trajectory, const char* path_positions, int32_t n_frames,
+                                   const uint8_t* is_keyframe, const double* pose_or_ref);
+
 /* Communicator for landmark-sharded BA (NULL = single GPU).  Every rank passes the SAME flattened problem;
  * rank r owns the landmarks with index % world == r, forms its partial reduced camera system, and one
  * all-reduce(sum, fp64) of [(6F)^2 + 6F] doubles per lambda trial (plus a 3-double cost reduction) makes the
