@@ -18,6 +18,13 @@ namespace vslam {
 __device__ __forceinline__ int d_cvFloor(float v) { int i = (int)v; return i - (i > v); }
 __device__ __forceinline__ int d_cvCeil(float v) { int i = (int)v; return i + (i < v); }
 
+#ifdef VSLAM_STEREO_STAMPS
+__device__ long long g_sm[8];
+#define SM_ACC(k) do { if (blockIdx.x == 100 && threadIdx.x == 0) { const long long n_ = clock64(); g_sm[k] = n_ - sm_t; sm_t = n_; } } while (0)
+#else
+#define SM_ACC(k) do {} while (0)
+#endif
+
 __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs A, int* __restrict__ mBest,
                                                       float* __restrict__ mDepth,
                                                       int* __restrict__ mSad,
@@ -30,7 +37,12 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs A, int* __restr
     __shared__ uint8_t winL[4][11 * 12];
     __shared__ uint8_t winR[4][11 * 24];
     __shared__ int sadp[4][5 * 11];
+    __shared__ unsigned int sStat[3];                 // tests, refined, accepted of this workgroup (one global atomic each)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef VSLAM_STEREO_STAMPS
+    long long sm_t = clock64();
+#endif
+    if (tid < 3) sStat[tid] = 0;
 
     for (int i = tid; i < nR; i += 256) {
         const float y = A.kpsR[i].y;
@@ -43,6 +55,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs A, int* __restr
         oc[i] = (uint8_t)oct;
     }
     __syncthreads();
+    SM_ACC(0);
 
     const int left = blockIdx.x * 4 + wave;
     const bool have = left < A.nL;
@@ -85,6 +98,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs A, int* __restr
         best = o < best ? o : best;
         cnt += __shfl_xor(cnt, d);
     }
+    SM_ACC(1);
     const int bestDist = (int)(best >> 16);
     const int bestIdx = (int)(best & 0xffffu);
     const bool refine = active && bestDist <= 75;       // thDist, include/FeatureMatcher.h:25
@@ -120,6 +134,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs A, int* __restr
         }
     }
     __syncthreads();
+    SM_ACC(2);
     if (refine && lane < 55) {
         const int s = lane % 11, g = lane / 11;
         int acc = 0;
@@ -132,6 +147,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs A, int* __restr
         sadp[wave][g * 11 + s] = acc;
     }
     __syncthreads();
+    SM_ACC(3);
     if (refine && lane == 0) {
         float allDists[11];
         int bestDistW = INT_MAX, bestX = 0;
@@ -169,14 +185,18 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs A, int* __restr
         mBest[left] = outBest;
         mDepth[left] = outDepth;
         mSad[left] = bestDistW;
-        atomicAdd(&stats[1], 1ull);
-        if (accepted) atomicAdd(&stats[2], 1ull);
+        atomicAdd(&sStat[1], 1u);
+        if (accepted) atomicAdd(&sStat[2], 1u);
     } else if (have && lane == 0 && !refine) {
         mBest[left] = -1;
         mDepth[left] = -1.f;
         mSad[left] = 0;
     }
-    if (have && lane == 0 && cnt) atomicAdd(&stats[0], (unsigned long long)cnt);
+    if (have && lane == 0 && cnt) atomicAdd(&sStat[0], (unsigned int)cnt);
+    SM_ACC(4);
+    __syncthreads();
+    if (tid < 3 && sStat[tid]) atomicAdd(&stats[tid], (unsigned long long)sStat[tid]);
+    SM_ACC(5);
 }
 
 void launch_stereo_match(hipStream_t s, const StereoArgs& A, int* mBest, float* mDepth, int* mSad,
@@ -184,7 +204,18 @@ void launch_stereo_match(hipStream_t s, const StereoArgs& A, int* mBest, float* 
     if (A.nL <= 0) return;
     const int nRp = (A.nR + 3) & ~3;
     const size_t sh = (size_t)nRp * 9 + 16;
+#ifdef VSLAM_STEREO_STAMPS
+    { long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sm), z, sizeof(z)); }
+#endif
     hipLaunchKernelGGL(k_stereo_match, dim3((A.nL + 3) / 4), dim3(256), sh, s, A, mBest, mDepth, mSad, stats);
+#ifdef VSLAM_STEREO_STAMPS
+    {
+        long long z[8];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_sm), sizeof(z));
+        fprintf(stderr, "stereo_match (block 100, wave 0): stage %lld  scan %lld  windows %lld  sad %lld  decide %lld  flush %lld\n", z[0], z[1], z[2], z[3], z[4], z[5]);
+    }
+#endif
 }
 
 // Radix select over n 32-bit keys in LDS (1024 threads, 4 passes of 8 bits): returns the key of 0-based rank k and,
