@@ -31,31 +31,37 @@ __global__ __launch_bounds__(256) void k_proj_candidates(ProjArgs A, const int* 
                                                          unsigned long long* __restrict__ stats) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int job = blockIdx.x * 4 + wave;      // job = mp * 2 + side
-    if (A.gate && *A.gate < A.gateMin) return;
+    __shared__ unsigned int sTests;             // descriptor tests of this workgroup (ONE global atomic: thousands of waves
+    if (A.gate && *A.gate < A.gateMin) return;  //  adding to a single address serialise in the L2 and dominated the kernel)
     if (A.Mdev) A.M = min(A.M, *A.Mdev);
-    if (job >= 2 * A.M) return;
-    const int i = job >> 1, side = job & 1;
-    unsigned long long out[PROJ_K];
-#pragma unroll
-    for (int j = 0; j < PROJ_K; j++) out[j] = KEY_NONE;
-    const vslam_mappoint_view* mp = A.mpv + i;
-    const bool skip = matches[2 * i] >= 0 || matches[2 * i + 1] >= 0;
-    const bool inF = side ? (A.mode == PROJ_STEREO && mp->in_frame_r) : mp->in_frame;
+    if (threadIdx.x == 0) sTests = 0;
+    __syncthreads();
     int tests = 0;
-    if (!skip && inF) {
-        uint32_t md[8];
-        load_mp_desc(mp, md);
-        const float px = side ? mp->pred_rx : mp->pred_lx, py = side ? mp->pred_ry : mp->pred_ly;
-        const int ps = side ? mp->scale_level_r : mp->scale_level_l;
-        tests = scan_side<PROJ_K>(A, side, md, px, py, ps, nullptr, out);
-    }
-    if (lane < PROJ_K) {
-        unsigned long long v = out[0];
+    if (job < 2 * A.M) {
+        const int i = job >> 1, side = job & 1;
+        unsigned long long out[PROJ_K];
 #pragma unroll
-        for (int j = 1; j < PROJ_K; j++) v = lane == j ? out[j] : v;
-        topk[(size_t)job * PROJ_K + lane] = v;
+        for (int j = 0; j < PROJ_K; j++) out[j] = KEY_NONE;
+        const vslam_mappoint_view* mp = A.mpv + i;
+        const bool skip = matches[2 * i] >= 0 || matches[2 * i + 1] >= 0;
+        const bool inF = side ? (A.mode == PROJ_STEREO && mp->in_frame_r) : mp->in_frame;
+        if (!skip && inF) {
+            uint32_t md[8];
+            load_mp_desc(mp, md);
+            const float px = side ? mp->pred_rx : mp->pred_lx, py = side ? mp->pred_ry : mp->pred_ly;
+            const int ps = side ? mp->scale_level_r : mp->scale_level_l;
+            tests = scan_side<PROJ_K>(A, side, md, px, py, ps, nullptr, out);
+        }
+        if (lane < PROJ_K) {
+            unsigned long long v = out[0];
+#pragma unroll
+            for (int j = 1; j < PROJ_K; j++) v = lane == j ? out[j] : v;
+            topk[(size_t)job * PROJ_K + lane] = v;
+        }
     }
-    if (lane == 0 && tests) atomicAdd(&stats[3], (unsigned long long)tests);
+    if (lane == 0 && tests) atomicAdd(&sTests, (unsigned int)tests);
+    __syncthreads();
+    if (threadIdx.x == 0 && sTests) atomicAdd(&stats[3], (unsigned long long)sTests);
 }
 
 void launch_proj_candidates(hipStream_t s, const ProjArgs& A, const int* matches,
