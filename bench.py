@@ -388,17 +388,17 @@ def main():
                         "the fraction is reported against the HBM roofline as the contract asks, the kernel is bound by "
                         "instruction latency, not by bytes or flops (DESIGN.md section 4)"}
         # HBM-side traffic of the same kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE are
-        # collected in separate runs of this bench, profiles/r01_g_pmc_summary.json; KB per launch).  Correction per
+        # collected in separate runs of this bench, profiles/r01_h_pmc_summary.json; KB per launch).  Correction per
         # MI355X_MICROARCH.md: FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced reads -> doubled.
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_g_pmc_summary.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_h_pmc_summary.json")))
             kname = {"proj_resolve": "k_proj_resolve", "pose_imu_lm": "k_pose_imu_lm", "ba_solve": "k_ba_solve_mfma64", "ssc": "k_ssc",
                      "ba_schur": "k_ba_schur<true>", "ba_back": "k_ba_back", "ba_eval": "k_ba_factors<1>",
                      "ba_linearize": "k_ba_factors<0>", "fast": "k_fast", "blur": "k_blur", "gather": "k_gather",
                      "stereo_match": "k_stereo_match", "orient_desc": "k_orient_desc"}.get(dom)
             if kname in pmc:
                 roof["traffic"] = (2.0 * pmc[kname]["FETCH_SIZE_avg"] + pmc[kname]["WRITE_SIZE_avg"]) * 1024.0
-                roof["traffic_source"] = "profiles/r01_g_pmc_summary.json (2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, per launch)"
+                roof["traffic_source"] = "profiles/r01_h_pmc_summary.json (2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, per launch)"
         except Exception:      # noqa: BLE001
             pass
         if alg_flops:
