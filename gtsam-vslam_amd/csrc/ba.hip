@@ -462,12 +462,18 @@ __device__ __forceinline__ void ba_wave_fence() { asm volatile("s_waitcnt lgkmcn
 
 // After the call (and a ba_wave_fence) W[s*18 + i*3 + j] holds Hpl of slot s; h = 6 unique entries of Hll (undamped)
 // followed by bl, identical in every lane of the wave.
-__device__ __forceinline__ void ba_lm_blocks(const BaDev& D, int lp, double* W, int* sfi, double* h, int& ns) {
-    const int lane = threadIdx.x & 63;
-    const int f0 = D.lpStart[lp], f1 = D.lpStart[lp + 1];
+// BA_LPL lanes serve one landmark (a landmark has ~13 factors and <= 10 slots, a 64-lane wave per landmark leaves
+// lanes idle; a wave can carry 64 / BA_LPL landmarks side by side; `act` = this lane group has a landmark);
+// measured: the back-substitution is faster with two landmarks per wave, the Schur accumulation (longer per-landmark
+// chains of LDS atomics) with one.
+constexpr int BA_LPL_SCHUR = 64, BA_LPL_BACK = 32;
+template <int BA_LPL>
+__device__ __forceinline__ void ba_lm_blocks(const BaDev& D, int lp, bool act, double* W, int* sfi, double* h, int& ns) {
+    const int lane = threadIdx.x & (BA_LPL - 1);
+    const int f0 = act ? D.lpStart[lp] : 0, f1 = act ? D.lpStart[lp + 1] : 0;
 #pragma unroll
     for (int k = 0; k < 9; k++) h[k] = 0;
-    for (int f = f0 + lane; f < f1; f += 64) {
+    for (int f = f0 + lane; f < f1; f += BA_LPL) {
         const double* o = D.facJ + (size_t)f * 20;
         const double r0 = o[0], r1 = o[1];
         const double* Jl = o + 14;
@@ -484,11 +490,11 @@ __device__ __forceinline__ void ba_lm_blocks(const BaDev& D, int lp, double* W, 
 #pragma unroll
     for (int k = 0; k < 9; k++) {
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) h[k] += __shfl_xor(h[k], d);
+        for (int d = BA_LPL / 2; d >= 1; d >>= 1) h[k] += __shfl_xor(h[k], d);
     }
-    const int s0 = D.lpSlotStart[lp];
-    ns = D.lpSlotStart[lp + 1] - s0 - 1;   // one end sentinel per landmark
-    for (int e = lane; e < ns * 18; e += 64) {
+    const int s0 = act ? D.lpSlotStart[lp] : 0;
+    ns = act ? D.lpSlotStart[lp + 1] - s0 - 1 : 0;   // one end sentinel per landmark
+    for (int e = lane; e < ns * 18; e += BA_LPL) {
         const int s = e / 18, ij = e - s * 18, i = ij / 3, j = ij - i * 3;
         double acc = 0;
         for (int f = D.slotStart[s0 + s]; f < D.slotStart[s0 + s + 1]; f++) {
@@ -497,7 +503,7 @@ __device__ __forceinline__ void ba_lm_blocks(const BaDev& D, int lp, double* W, 
         }
         W[e] = acc;
     }
-    for (int s = lane; s < ns; s += 64) sfi[s] = D.slotFi[s0 + s];
+    for (int s = lane; s < ns; s += BA_LPL) sfi[s] = D.slotFi[s0 + s];
 }
 // (Hll + lambda I)^-1
 __device__ __forceinline__ void ba_hll_inverse(const double* h, double lambda, double* Hi) {
@@ -524,24 +530,25 @@ __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_schur(BaDev D, int m
             for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (int)sys; i += gridDim.x * blockDim.x) Sg[i] = 0;
         }
     }
+    constexpr int BA_LPL = BA_LPL_SCHUR;
     double* Sloc = sm;                                        // LDS_S: nc copies of n*n + n
     double* wbase = sm + (LDS_S ? (size_t)nc * sys : 0);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double* W = wbase + (size_t)wave * (2 * maxSlots * 18);
+    const int lane = threadIdx.x & (BA_LPL - 1), unit = threadIdx.x / BA_LPL;    // unit = landmark lane group of the workgroup
+    double* W = wbase + (size_t)unit * (2 * maxSlots * 18);
     double* WH = W + maxSlots * 18;
-    const int nw = blockDim.x >> 6, nt = blockDim.x;
-    int* sfi = (int*)(wbase + (size_t)nw * (2 * maxSlots * 18)) + wave * maxSlots;
+    const int nu = blockDim.x / BA_LPL, nt = blockDim.x;
+    int* sfi = (int*)(wbase + (size_t)nu * (2 * maxSlots * 18)) + unit * maxSlots;
     if (LDS_S) {
         for (int i = threadIdx.x; i < (int)(nc * sys); i += nt) Sloc[i] = 0;
     }
     __syncthreads();
-    const int rounds = (D.Lp + gridDim.x * nw - 1) / (gridDim.x * nw);
+    const int rounds = (D.Lp + gridDim.x * nu - 1) / (gridDim.x * nu);
     for (int rd = 0; rd < rounds; rd++) {
-        const int lp = (rd * gridDim.x + blockIdx.x) * nw + wave;
-        if (lp >= D.Lp) break;
+        const int lp = (rd * gridDim.x + blockIdx.x) * nu + unit;
+        const bool act = lp < D.Lp;
         double h[9];
         int ns = 0;
-        ba_lm_blocks(D, lp, W, sfi, h, ns);
+        ba_lm_blocks<BA_LPL>(D, lp, act, W, sfi, h, ns);
         ba_wave_fence();
         double lamk = D.lambda;             // candidate c0 + k: lambda * 10^k, the sequence of the sequential policy
         for (int k = 0; k < nc; k++, lamk *= 10.0) {
@@ -549,7 +556,7 @@ __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_schur(BaDev D, int m
             double* racc = Sacc + (size_t)n * n;
             double Hi[9];
             ba_hll_inverse(h, lamk, Hi);
-            for (int e = lane; e < ns * 18; e += 64) {
+            for (int e = lane; e < ns * 18; e += BA_LPL) {
                 const int s = e / 18, ij = e - s * 18, i = ij / 3, j = ij - i * 3;
                 const double* w = W + s * 18 + i * 3;
                 WH[e] = w[0] * Hi[j] + w[1] * Hi[3 + j] + w[2] * Hi[6 + j];
@@ -559,7 +566,7 @@ __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_schur(BaDev D, int m
             for (int s1 = 0; s1 < ns; s1++) {
                 const int k1 = sfi[s1];
                 const int cnt = (ns - s1) * 36;
-                for (int e = lane; e < cnt; e += 64) {
+                for (int e = lane; e < cnt; e += BA_LPL) {
                     const int s2 = s1 + e / 36, ij = e % 36, i = ij / 6, j = ij - i * 6;
                     const double* a = WH + s1 * 18 + i * 3;
                     const double* bb = W + s2 * 18 + j * 3;
@@ -574,8 +581,8 @@ __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_schur(BaDev D, int m
             ba_wave_fence();        // WH is rewritten for the next candidate
         }
         // Hpp and bp from this landmark's observations of free keyframes (the same for every candidate)
-        const int f0 = D.lpStart[lp], f1 = D.lpStart[lp + 1];
-        for (int e = lane; e < (f1 - f0) * 27; e += 64) {
+        const int f0 = act ? D.lpStart[lp] : 0, f1 = act ? D.lpStart[lp + 1] : 0;
+        for (int e = lane; e < (f1 - f0) * 27; e += BA_LPL) {
             const int f = f0 + e / 27, q = e % 27;
             const int fi = D.facFi[f];
             if (fi < 0) continue;
@@ -1196,26 +1203,27 @@ __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_back(BaDev D, int ma
     if (!ba_enter(D, BA_TRY, c0)) return;
     const int nc = allCand ? D.NB : 1;
     const int sel = ((const int*)(D.ctl + CTL_INTS))[CI_SEL];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double* W = sm + (size_t)wave * (maxSlots * 18);
-    const int nw = blockDim.x >> 6;
-    int* sfi = (int*)(sm + (size_t)nw * (maxSlots * 18)) + wave * maxSlots;
-    const int rounds = (D.Lp + gridDim.x * nw - 1) / (gridDim.x * nw);
+    constexpr int BA_LPL = BA_LPL_BACK;
+    const int lane = threadIdx.x & (BA_LPL - 1), unit = threadIdx.x / BA_LPL;
+    double* W = sm + (size_t)unit * (maxSlots * 18);
+    const int nu = blockDim.x / BA_LPL;
+    int* sfi = (int*)(sm + (size_t)nu * (maxSlots * 18)) + unit * maxSlots;
+    const int rounds = (D.Lp + gridDim.x * nu - 1) / (gridDim.x * nu);
     for (int rd = 0; rd < rounds; rd++) {
-        const int lp = (rd * gridDim.x + blockIdx.x) * nw + wave;
-        if (lp >= D.Lp) break;
+        const int lp = (rd * gridDim.x + blockIdx.x) * nu + unit;
+        const bool act = lp < D.Lp;
         double h[9];
         int ns = 0;
-        ba_lm_blocks(D, lp, W, sfi, h, ns);
+        ba_lm_blocks<BA_LPL>(D, lp, act, W, sfi, h, ns);
         ba_wave_fence();
-        const int l = D.lpOrig[lp];
+        const int l = act ? D.lpOrig[lp] : 0;
         double lamk = D.lambda;
         for (int k = 0; k < nc; k++, lamk *= 10.0) {
             const double* dPk = D.dP + (size_t)k * D.n;         // (ba_enter already applied candidate c0)
             double Hi[9];
             ba_hll_inverse(h, lamk, Hi);
             double t[3] = {0, 0, 0};
-            for (int e = lane; e < ns * 6; e += 64) {
+            for (int e = lane; e < ns * 6; e += BA_LPL) {
                 const int s = e / 6, i = e - s * 6;
                 const double dp = dPk[6 * sfi[s] + i];
                 const double* w = W + s * 18 + i * 3;
@@ -1224,9 +1232,9 @@ __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_back(BaDev D, int ma
 #pragma unroll
             for (int q = 0; q < 3; q++) {
 #pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) t[q] += __shfl_xor(t[q], d);
+                for (int d = BA_LPL / 2; d >= 1; d >>= 1) t[q] += __shfl_xor(t[q], d);
             }
-            if (lane < 3) {
+            if (act && lane < 3) {
                 const double u[3] = {h[6] - t[0], h[7] - t[1], h[8] - t[2]};
                 const double dl = Hi[3 * lane] * u[0] + Hi[3 * lane + 1] * u[1] + Hi[3 * lane + 2] * u[2];
                 D.dL[(size_t)k * D.dLStride + 3 * (size_t)lp + lane] = dl;
@@ -1721,20 +1729,23 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         const bool ldsS = F <= BA_LDS_MAX_F;
         const size_t sysDoubles = (size_t)n * n + n;
         int schurWaves = BA_SCHUR_WAVES;
-        auto schur_lds = [&](int nw, int copies) { return (ldsS ? copies * sysDoubles * sizeof(double) : 0) + (size_t)nw * 2 * maxSlots * 18 * sizeof(double) + (size_t)nw * maxSlots * sizeof(int) + 16; };
+        constexpr int SCHUR_LPW = 64 / BA_LPL_SCHUR, BACK_LPW = 64 / BA_LPL_BACK;      // landmarks per wave
+        // (nw waves = nw * LPW landmark units per workgroup)
+        auto schur_lds = [&](int nw, int copies) { return (ldsS ? copies * sysDoubles * sizeof(double) : 0) + (size_t)nw * SCHUR_LPW * 2 * maxSlots * 18 * sizeof(double) + (size_t)nw * SCHUR_LPW * maxSlots * sizeof(int) + 16; };
         // one workgroup for all candidates (W blocks built once) when NB copies of the system fit LDS with >= 8 waves
         static const bool sharedEnv = !getenv("VSLAM_BA_NO_SHARED_W");
         int sharedW = 0;
         if (NB > 1 && sharedEnv && true) {
-            for (int nw : {16, 12, 8})
+            for (int nw : {16, 12, 8, 6, 4})
                 if (schur_lds(nw, NB) <= 150 * 1024) { sharedW = 1; schurWaves = nw; break; }
         }
-        if (!sharedW) while (schurWaves > 4 && schur_lds(schurWaves, 1) > 150 * 1024) schurWaves /= 2;
-        const int lmBlocks = std::max(1, std::min((Lp + schurWaves - 1) / schurWaves, nCU));
-        int backWaves = BA_SCHUR_WAVES;
-        auto back_lds = [&](int nw) { return (size_t)nw * maxSlots * 18 * sizeof(double) + (size_t)nw * maxSlots * sizeof(int) + 16; };
+        if (!sharedW) while (schurWaves > 2 && schur_lds(schurWaves, 1) > 150 * 1024) schurWaves /= 2;
+        const int schurUnits = schurWaves * SCHUR_LPW;
+        const int lmBlocks = std::max(1, std::min((Lp + schurUnits - 1) / schurUnits, nCU));
+        int backWaves = BA_SCHUR_WAVES / BACK_LPW;
+        auto back_lds = [&](int nw) { return (size_t)nw * BACK_LPW * maxSlots * 18 * sizeof(double) + (size_t)nw * BACK_LPW * maxSlots * sizeof(int) + 16; };
         while (backWaves > 1 && back_lds(backWaves) > 150 * 1024) backWaves /= 2;
-        const int backBlocks = std::max(1, std::min((Lp + backWaves - 1) / backWaves, nCU));
+        const int backBlocks = std::max(1, std::min((Lp + backWaves * BACK_LPW - 1) / (backWaves * BACK_LPW), nCU));
         D.partialStride = (size_t)2 * obsBlocks + 2 * (size_t)std::max(NE, 1);
         VS_HIP(d_partial.alloc(D.partialStride * NB));
         D.partial = d_partial.p;
