@@ -407,6 +407,9 @@ void launch_proj_resolve(hipStream_t s, const ProjArgs& A, const unsigned long l
     if (!attr) { (void)hipFuncSetAttribute((const void*)k_proj_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); attr = true; }
     const int forceSeq = getenv("VSLAM_PROJ_SEQUENTIAL") ? 1 : 0;     // A/B and fallback testing (read per launch)
     hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(PROJ_NT), sh, s, A, topk, matchedL, matchedR, matches, out, forceSeq);
+#ifdef VSLAM_PROJ_STAMPS
+    { int o[2]; (void)hipStreamSynchronize(s); (void)hipMemcpy(o, out, sizeof(o), hipMemcpyDeviceToHost); fprintf(stderr, "proj_resolve: matches %d, fixed-point rounds %d (-1 = sequential walk)\n", o[0], o[1]); }
+#endif
 }
 
 }  // namespace vslam
