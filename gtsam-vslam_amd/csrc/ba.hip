@@ -25,6 +25,7 @@
 #include "common.hpp"
 #include "comm.hpp"
 #include "dmath.hpp"
+#include "ba_pool.hpp"
 #include <algorithm>
 #include <cmath>
 #include <numeric>
@@ -32,6 +33,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -1378,64 +1380,14 @@ struct PinnedArena {
     template <class T> T* dev(T* hostPtr) const { return (T*)(d + ((uint8_t*)hostPtr - h)); }
     hipError_t upload(hipStream_t s) const { return hipMemcpyAsync(d, h, used, hipMemcpyHostToDevice, s); }
 };
-// Small persistent worker pool of the optimizer thread's host-side preparation (ordering ~34 k factors by landmark /
-// keyframe and writing the upload arena is 0.35 ms on one core; the landmark ranges are independent).
-struct BaPool {
-    std::vector<std::thread> workers;
-    std::mutex mu;
-    std::condition_variable cvStart, cvDone;
-    std::function<void(int)> job;
-    std::atomic<int> next{0};
-    int nTasks = 0, finished = 0;
-    std::atomic<int> generation{0};
-    bool stop = false;
-    void start(int n) {
-        for (int t = 0; t < n; t++)
-            workers.emplace_back([this]() {
-                int seen = 0;
-                for (;;) {
-                    {
-                        std::unique_lock<std::mutex> lk(mu);
-                        cvStart.wait(lk, [&] { return stop || generation.load() != seen; });
-                        if (stop) return;
-                        seen = generation.load();
-                    }
-                    work();
-                }
-            });
-    }
-    void work() {
-        for (;;) {
-            const int t = next.fetch_add(1);
-            if (t >= nTasks) break;
-            job(t);
-            std::lock_guard<std::mutex> lk(mu);
-            if (++finished == nTasks) cvDone.notify_all();
-        }
-    }
-    void run(int n, std::function<void(int)> f) {
-        if (workers.empty() || n <= 1) { for (int t = 0; t < n; t++) f(t); return; }
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            job = std::move(f); nTasks = n; finished = 0; next = 0; generation++;
-        }
-        cvStart.notify_all();
-        work();
-        std::unique_lock<std::mutex> lk(mu);
-        cvDone.wait(lk, [&] { return finished == nTasks; });
-    }
-    ~BaPool() {
-        { std::lock_guard<std::mutex> lk(mu); stop = true; }
-        cvStart.notify_all();
-        for (auto& w : workers) w.join();
-    }
-};
 struct BaHostTmp {
     std::vector<uint8_t> kfPresent, lmPresent;
     std::vector<int> cnt, fidx, lpOf, order, fill, key, src, ns;
 };
 
-std::atomic<int> g_baLookahead{-1}, g_baSpecLin{-1}, g_baMask{1};     // vslam_local_ba_set_lookahead (-1: environment / default)
+// vslam_local_ba_set_lookahead (-1: environment / default).  Like the timing switch and the workspace these belong to
+// the CALLING THREAD (one optimizer thread = one local-BA context): sessions with different settings do not interact.
+thread_local int g_baLookahead = -1, g_baSpecLin = -1, g_baMask = 1;
 
 struct HostFac { int pair, kf, lm, fi, lp; bool right; double z[2], is; };
 
@@ -1488,10 +1440,24 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         BaPool pool;
         double* h_ctlOut = nullptr;
         uint8_t* h_wrong = nullptr; size_t wrongCap = 0;
+        // released when the owning host thread ends (or switches device): a short-lived optimizer thread must not
+        // leak its stream, pinned buffers and pool threads
+        ~Workspace() {
+            if (device < 0 || hipSetDevice(device) != hipSuccess) return;
+            if (stream) { hipStreamSynchronize(stream); hipStreamDestroy(stream); }
+            for (void* p : {(void*)d_pose0.p, (void*)d_poseS.p, (void*)d_lm0.p, (void*)d_lmS.p, (void*)d_facJ.p, (void*)d_S.p, (void*)d_Spart.p,
+                            (void*)d_Sedge.p, (void*)d_dP.p, (void*)d_dL.p, (void*)d_lmDiff.p, (void*)d_sums.p, (void*)d_partial.p, (void*)d_Lg.p,
+                            (void*)d_flags.p, (void*)d_pairKf.p, (void*)d_pairLm.p, (void*)d_pairOct.p, (void*)d_pairFlags.p,
+                            (void*)d_kfLocal.p, (void*)d_wrong.p, (void*)d_pairUv.p, (void*)arena.d})
+                if (p) hipFree(p);
+            if (arena.h) hipHostFree(arena.h);
+            if (h_ctlOut) hipHostFree(h_ctlOut);
+            if (h_wrong) hipHostFree(h_wrong);
+        }
     };
-    static thread_local Workspace* ws = nullptr;
+    static thread_local std::unique_ptr<Workspace> ws;
     if (!ws || ws->device != device) {
-        ws = new Workspace(); ws->device = device;
+        ws.reset(new Workspace()); ws->device = device;
         VS_HIP(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));
         VS_HIP(hipHostMalloc((void**)&ws->h_ctlOut, CTL_DOUBLES * sizeof(double), hipHostMallocDefault));
         {
@@ -1521,7 +1487,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
     // lambda look-ahead (see BaDev): candidates per trial round; the sharded path keeps the plain sequential scheme
     static const int nbEnv = [] { const char* e = getenv("VSLAM_BA_LOOKAHEAD"); return e ? std::max(1, std::min((int)BA_MAX_NB, atoi(e))) : (int)BA_MAX_NB; }();
     static const bool specEnv = !getenv("VSLAM_BA_NO_SPECLIN");
-    const int nbSet = g_baLookahead.load(), specSet = g_baSpecLin.load();
+    const int nbSet = g_baLookahead, specSet = g_baSpecLin;
     const int NB = comm ? 1 : (nbSet > 0 ? std::min(nbSet, (int)BA_MAX_NB) : nbEnv), nSlots = NB + 1;
     const bool specLin = !comm && (specSet >= 0 ? specSet != 0 : specEnv);
     VS_HIP(d_pose0.alloc(K)); VS_HIP(d_poseS.alloc((size_t)nSlots * K));
@@ -1880,7 +1846,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
 
         // ---- second pass on the first pass's structure (single GPU): mask instead of rebuild ------------------
         static const bool maskEnv = !getenv("VSLAM_BA_NO_MASK");
-        if (pass == 0 && !comm && maskEnv && g_baMask.load()) {
+        if (pass == 0 && !comm && maskEnv && g_baMask) {
             // membership / statistics of the second graph from the chi2 flags
             std::vector<uint8_t> kfP2(K, 0), lmP2(L, 0);
             long long NF2 = 0;
@@ -1951,9 +1917,9 @@ vslam_status vslam_local_ba_timings(const char** names, float* ms, int32_t cap, 
 
 vslam_status vslam_local_ba_set_lookahead(int32_t candidates, int32_t speculative_linearize, int32_t mask_second_pass) {
     if (candidates > BA_MAX_NB) return VSLAM_ERR_INVALID;
-    g_baLookahead.store(candidates > 0 ? candidates : -1);
-    g_baSpecLin.store(speculative_linearize < 0 ? -1 : (speculative_linearize ? 1 : 0));
-    g_baMask.store(mask_second_pass != 0 ? 1 : 0);
+    g_baLookahead = candidates > 0 ? candidates : -1;
+    g_baSpecLin = speculative_linearize < 0 ? -1 : (speculative_linearize ? 1 : 0);
+    g_baMask = mask_second_pass != 0 ? 1 : 0;
     return VSLAM_OK;
 }
 

@@ -52,20 +52,25 @@ vslam_status comm_allreduce(const vslam_comm* c, double* dbuf, size_t n, hipStre
         if (r != 0) { set_error("ncclAllReduce failed: %s", api.GetErrorString ? api.GetErrorString(r) : "?"); return VSLAM_ERR_COMM; }
         return VSLAM_OK;
     }
-    // local transport: device -> slot, barrier, fixed-order sum, barrier, -> device
+    // local transport: device -> slot, barrier, fixed-order sum, barrier, -> device.
+    // Error handling: a rank that fails never leaves early - it raises the group's `failed` flag and still passes BOTH
+    // barriers, so its peers are not stranded; every rank then returns VSLAM_ERR_COMM.  (RCCL transport: a failure on
+    // one rank leaves the others inside ncclAllReduce; the caller has to abort the job, as with any NCCL program.)
     vslam_local_group* g = c->grp.get();
     std::vector<double>& mine = g->slots[c->rank];
     mine.resize(n);
-    VS_HIP(hipMemcpyAsync(mine.data(), dbuf, n * sizeof(double), hipMemcpyDeviceToHost, stream));
-    VS_HIP(hipStreamSynchronize(stream));
+    bool ok = hipMemcpyAsync(mine.data(), dbuf, n * sizeof(double), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+              hipStreamSynchronize(stream) == hipSuccess;
+    if (!ok) { set_error("local all-reduce: device -> host copy failed"); g->failed.store(1); }
     g->barrier();
     std::vector<double> sum(n, 0.0);
     for (int r = 0; r < c->world; r++) {
         const std::vector<double>& s = g->slots[r];
-        if (s.size() != n) { set_error("local all-reduce: size mismatch between ranks"); return VSLAM_ERR_COMM; }
+        if (s.size() != n) { set_error("local all-reduce: size mismatch between ranks"); g->failed.store(1); break; }
         for (size_t i = 0; i < n; i++) sum[i] += s[i];
     }
     g->barrier();
+    if (g->failed.load()) return VSLAM_ERR_COMM;
     VS_HIP(hipMemcpyAsync(dbuf, sum.data(), n * sizeof(double), hipMemcpyHostToDevice, stream));
     VS_HIP(hipStreamSynchronize(stream));
     return VSLAM_OK;

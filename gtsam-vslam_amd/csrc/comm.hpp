@@ -2,6 +2,7 @@
 // in-process "local" transport (host threads sharing one GPU, deterministic rank-order sums).
 #pragma once
 #include "common.hpp"
+#include <atomic>
 #include <condition_variable>
 #include <memory>
 #include <mutex>
@@ -11,6 +12,7 @@ struct vslam_local_group {
     std::mutex mu;
     std::condition_variable cv;
     int arrived = 0, generation = 0;
+    std::atomic<int> failed{0};       // sticky: a failed rank poisons the group instead of leaving its peers in the barrier
     std::vector<std::vector<double>> slots;
     void barrier() {
         std::unique_lock<std::mutex> lk(mu);

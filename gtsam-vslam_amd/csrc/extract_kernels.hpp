@@ -63,16 +63,22 @@ void launch_orient_desc(hipStream_t s, const uint8_t* pyr, const uint8_t* blur, 
 void upload_pattern();
 
 // device-side SSC (ssc.hip)
+constexpr int SSC_NMAX_LDS = 16384;      // candidates of one level whose sort arrays the LDS instantiation holds
+constexpr int SSC_NMAX = 65535;          // ... the HBM instantiation (16-bit index field of the sort key)
+constexpr int SSC_PICKW_G = 2048;        // words of a probe's pick bitmask in the HBM instantiation (SSC_NMAX / 32)
 struct SscArgs {
-    const uint32_t* cand; int candCap; const int* levelCount;      // gather output (device-visible pinned memory)
+    const uint32_t* cand; int candCap; const int* levelCount;      // gather output (HBM)
     int nLevels, nimg;
     int numRet[MAX_LEVELS], cols[MAX_LEVELS], rows[MAX_LEVELS], high[MAX_LEVELS], kmin[MAX_LEVELS], kmax[MAX_LEVELS];
     uint32_t* tmp;          // [nimg][candCap]: picks of level l at the level's candidate offset
-    uint32_t* scratch;      // [nimg][candCap]: HBM copy of the candidates
     uint32_t* gridG;        // HBM bit grids for probes too fine for the LDS arena (width 1: (2 rows + 1) x (2 cols + 1) cells)
-    size_t gridOff[2 * MAX_LEVELS];      // word offset of task (img * nLevels + level); nimg <= 2
+    const size_t* gridOff;  // [nimg * nLevels] word offset of task (img * nLevels + level) in gridG
+    // HBM instantiation (levels with more than SSC_NMAX_LDS candidates): sort keys, stopper lists / sorted candidates at
+    // the level's candidate offset, pick bitmasks per (task, probe)
+    uint32_t* aG; uint32_t* sortedG; uint32_t* picksG;
+    int forceGlobal;        // tests: every level goes through the HBM instantiation
     int* taskCount;         // [nimg * nLevels]
-    int* flags;             // per image: [2 img] fallback needed, [2 img + 1] capacity overflow
+    int* flags;             // per image: [2 img] error bits of the suppression, [2 img + 1] capacity overflow
 };
 
 void launch_ssc(hipStream_t s, const SscArgs& A, uint32_t* kept, int keptCap, int* keptOff, int* hostCounts);

@@ -3,7 +3,6 @@
 #include "extractor.hpp"
 #include <algorithm>
 #include <cmath>
-#include <numeric>
 #include <mutex>
 
 namespace vslam {
@@ -206,18 +205,14 @@ vslam_status vslam_extractor::init(const vslam_fe_params* p, int w, int h, int b
     VS_HIP(hipMalloc(&d_cellCount, (size_t)nimg * nCells * sizeof(int)));
     VS_HIP(hipMalloc(&d_cellOff, (size_t)nimg * (nCells + 1) * sizeof(int)));
     candCap = nCells * F.cellCap;
-    VS_HIP(hipHostMalloc(&h_cand, (size_t)nimg * candCap * sizeof(uint32_t), hipHostMallocMapped));
-    VS_HIP(hipHostGetDevicePointer((void**)&d_cand, h_cand, 0));
-    VS_HIP(hipHostMalloc(&h_levelCount, (size_t)nimg * (MAX_LEVELS + 1) * sizeof(int), hipHostMallocMapped));
-    VS_HIP(hipHostGetDevicePointer((void**)&d_levelCount, h_levelCount, 0));
+    VS_HIP(hipMalloc(&d_cand, (size_t)nimg * candCap * sizeof(uint32_t)));
+    VS_HIP(hipMalloc(&d_levelCount, (size_t)nimg * (MAX_LEVELS + 1) * sizeof(int)));
 
     // a level keeps at most max(featurePerLevel * 1.1 rounded, featurePerLevel) points
     keptCap = 0;
     for (int l = 0; l < nLevels; l++) keptCap += (int)std::ceil(featurePerLevel[l] * 1.1f) + 2;
     keptCap = align_up(keptCap, 64);
-    VS_HIP(hipHostMalloc(&h_kept, (size_t)nimg * keptCap * sizeof(uint32_t), hipHostMallocDefault));
     VS_HIP(hipMalloc(&d_kept, (size_t)nimg * keptCap * sizeof(uint32_t)));
-    VS_HIP(hipHostMalloc(&h_keptOff, (size_t)nimg * (MAX_LEVELS + 1) * sizeof(int), hipHostMallocDefault));
     VS_HIP(hipMalloc(&d_keptOff, (size_t)nimg * (MAX_LEVELS + 1) * sizeof(int)));
     VS_HIP(hipMalloc(&d_kps, (size_t)nimg * keptCap * sizeof(vslam_keypoint)));
     VS_HIP(hipMalloc(&d_desc, (size_t)nimg * keptCap * 32));
@@ -234,8 +229,8 @@ vslam_status vslam_extractor::init(const vslam_fe_params* p, int w, int h, int b
     VS_HIP(hipMalloc(&d_disc, disc.size()));
     VS_HIP(hipMemcpy(d_disc, disc.data(), disc.size(), hipMemcpyHostToDevice));
     nKept.assign(nimg, 0);
-    sscOut.assign((size_t)nimg * nLevels, {});
-    // device SSC: per-level constants of the binary search (same expressions as ssc_level below)
+    // SSC: per-level constants of the binary search (src/FeatureExtractor.cpp:382-406: the closed-form upper bound of the
+    // suppression width, round(K -+ K * tolerance))
     for (int l = 0; l < nLevels; l++) {
         const int numRet = featurePerLevel[l], cols = P.w[l], rows = P.h[l];
         const int e1 = rows + cols + 2 * numRet;
@@ -248,16 +243,19 @@ vslam_status vslam_extractor::init(const vslam_fe_params* p, int w, int h, int b
         sscKmin[l] = (int)(unsigned)std::round((float)K - ((float)K * 0.1f));
         sscKmax[l] = (int)(unsigned)std::round((float)K + ((float)K * 0.1f));
     }
-    VS_HIP(hipMalloc(&d_sscTmp, (size_t)2 * nimg * candCap * sizeof(uint32_t)));      // picks | HBM copy of the candidates
+    VS_HIP(hipMalloc(&d_sscTmp, (size_t)3 * nimg * candCap * sizeof(uint32_t)));      // picks | sort keys | sorted (HBM instantiation)
+    VS_HIP(hipMalloc(&d_sscPicks, (size_t)nimg * nLevels * 8 * SSC_PICKW_G * sizeof(uint32_t)));
     {
         size_t words = 0;
-        sscGridOff.assign((size_t)nimg * nLevels, 0);
+        std::vector<size_t> off((size_t)nimg * nLevels, 0);
         for (int i = 0; i < nimg; i++)
             for (int l = 0; l < nLevels; l++) {
-                sscGridOff[(size_t)i * nLevels + l] = words;
+                off[(size_t)i * nLevels + l] = words;
                 words += (size_t)(2 * P.h[l] + 2) * (size_t)((2 * P.w[l] + 2 + 31) / 32);
             }
         VS_HIP(hipMalloc(&d_sscGrid, words * sizeof(uint32_t)));
+        VS_HIP(hipMalloc(&d_sscGridOff, off.size() * sizeof(size_t)));
+        VS_HIP(hipMemcpy(d_sscGridOff, off.data(), off.size() * sizeof(size_t), hipMemcpyHostToDevice));
     }
     VS_HIP(hipMalloc(&d_taskCount, (size_t)nimg * MAX_LEVELS * sizeof(int) + (size_t)nimg * MAX_LEVELS * 8 * sizeof(long long)));
     VS_HIP(hipMalloc(&d_sscFlags, (size_t)nimg * 2 * sizeof(int)));
@@ -265,28 +263,19 @@ vslam_status vslam_extractor::init(const vslam_fe_params* p, int w, int h, int b
     VS_HIP(hipHostMalloc(&h_counts, (size_t)nimg * 3 * sizeof(int), hipHostMallocMapped));
     VS_HIP(hipHostGetDevicePointer((void**)&d_counts, h_counts, 0));
     memset(h_counts, 0, (size_t)nimg * 3 * sizeof(int));
-    if (const char* e = getenv("VSLAM_HOST_SSC")) deviceSsc = atoi(e) == 0;
-    if (nimg > 2) deviceSsc = false;      // SscArgs carries the HBM-grid offsets of two images
-    {
-        int nt = 5;   // + the calling thread; VSLAM_HOST_THREADS overrides (0 = no extra threads)
-        if (const char* e = getenv("VSLAM_HOST_THREADS")) nt = std::max(0, std::min(15, atoi(e)));
-        pool_start(nt);
-    }
+    if (const char* e = getenv("VSLAM_SSC_FORCE_GLOBAL")) sscForceGlobal = atoi(e) != 0;
     return VSLAM_OK;
 }
 
 void vslam_extractor::release() {
-    pool_stop();
     if (stream) hipStreamSynchronize(stream);
     timer.destroy();
     hipFree(d_pyr); hipFree(d_blur); hipFree(d_xtab); hipFree(d_ytab);
     hipFree(d_cellSlots); hipFree(d_cellCount); hipFree(d_cellOff);
-    if (h_cand) hipHostFree(h_cand);
-    if (h_levelCount) hipHostFree(h_levelCount);
-    if (h_kept) hipHostFree(h_kept);
-    if (h_keptOff) hipHostFree(h_keptOff);
+    hipFree(d_cand); hipFree(d_levelCount);
     hipFree(d_kept); hipFree(d_keptOff); hipFree(d_kps); hipFree(d_desc); hipFree(d_disc);
-    hipFree(d_sscTmp); hipFree(d_taskCount); hipFree(d_sscFlags); hipFree(d_sscGrid); d_sscGrid = nullptr;
+    hipFree(d_sscTmp); hipFree(d_sscPicks); hipFree(d_taskCount); hipFree(d_sscFlags); hipFree(d_sscGrid); hipFree(d_sscGridOff);
+    d_sscGrid = nullptr; d_sscGridOff = nullptr; d_sscPicks = nullptr;
     if (h_counts) hipHostFree(h_counts);
     d_sscTmp = nullptr; d_taskCount = nullptr; d_sscFlags = nullptr; h_counts = nullptr;
     if (evGather) hipEventDestroy(evGather);
@@ -320,153 +309,8 @@ vslam_status vslam_extractor::set_image(int idx, const void* src, int stride, bo
     return VSLAM_OK;
 }
 
-// Square-covering suppression on the host: the greedy cover scan and the
-// std::sort tie order it depends on are sequential by construction
-// (reference src/FeatureExtractor.cpp:368-468; cv::sortIdx = std::sort on indices
-// + reversal).  Works on packed candidates, emits packed keeps.
-void vslam_extractor::ssc_level(const uint32_t* cand, int n, int numRet, int cols, int rows,
-                                std::vector<uint32_t>& out) const {
-    std::vector<int> order(n);
-    std::iota(order.begin(), order.end(), 0);
-    std::sort(order.begin(), order.end(),
-              [cand](int a, int b) { return (cand[a] & 0xffu) < (cand[b] & 0xffu); });
-    std::reverse(order.begin(), order.end());
-    const int e1 = rows + cols + 2 * numRet;
-    const long long e2 = 4LL * cols + 4LL * numRet + 4LL * rows * numRet + (long long)rows * rows +
-                         (long long)cols * cols - 2LL * rows * cols + 4LL * rows * cols * numRet;
-    const double e3 = std::sqrt((double)e2), e4 = numRet - 1;
-    const double s1 = -std::round((e1 + e3) / e4), s2 = -std::round((e1 - e3) / e4);
-    int high = (int)(s1 > s2 ? s1 : s2);
-    int low = std::max(1, (int)std::floor(std::sqrt((double)n / numRet)));
-    const unsigned K = (unsigned)numRet;
-    const unsigned Kmin = (unsigned)std::round((float)K - ((float)K * 0.1f));
-    const unsigned Kmax = (unsigned)std::round((float)K + ((float)K * 0.1f));
-    std::vector<int> picked, lastPicked;
-    std::vector<uint8_t> cover;
-    int prevWidth = -1;
-    for (;;) {
-        const int width = low + (high - low) / 2;
-        if (width == prevWidth || low > high) { lastPicked = picked; break; }
-        picked.clear();
-        const double c = (double)width / 2.0;
-        const int gc = (int)std::floor(cols / c), gr = (int)std::floor(rows / c);
-        const int span = (int)std::floor(width / c);
-        cover.assign((size_t)(gr + 1) * (gc + 1), 0);
-        for (int i = 0; i < n; i++) {
-            const uint32_t pk = cand[order[i]];
-            const int row = (int)std::floor((float)cand_y(pk) / c);
-            const int col = (int)std::floor((float)cand_x(pk) / c);
-            if (cover[(size_t)row * (gc + 1) + col]) continue;
-            picked.push_back(i);
-            const int r0 = std::max(row - span, 0), r1 = std::min(row + span, gr);
-            const int c0 = std::max(col - span, 0), c1 = std::min(col + span, gc);
-            for (int rr = r0; rr <= r1; rr++)
-                memset(&cover[(size_t)rr * (gc + 1) + c0], 1, (size_t)(c1 - c0 + 1));
-        }
-        if (picked.size() >= Kmin && picked.size() <= Kmax) { lastPicked = picked; break; }
-        if (picked.size() < Kmin) high = width - 1; else low = width + 1;
-        prevWidth = width;
-    }
-    out.clear();
-    out.reserve(lastPicked.size());
-    for (int i : lastPicked) out.push_back(cand[order[i]]);
-}
-
-void vslam_extractor::ssc_task(int task) {
-    // tasks are ordered level-major so the big level-0 jobs start first
-    const int l = task / nimg, i = task % nimg;
-    const int* lc = h_levelCount + (size_t)i * (MAX_LEVELS + 1);
-    int coff = 0;
-    for (int q = 0; q < l; q++) coff += lc[q];
-    const int n = lc[l];
-    std::vector<uint32_t>& out = sscOut[(size_t)i * nLevels + l];
-    const uint32_t* cand = h_cand + (size_t)i * candCap + coff;
-    if (n > featurePerLevel[l]) ssc_level(cand, n, featurePerLevel[l], P.w[l], P.h[l], out);
-    else out.assign(cand, cand + n);
-}
-
-void vslam_extractor::pool_start(int nThreads) {
-    for (int t = 0; t < nThreads; t++)
-        pool.workers.emplace_back([this]() {
-            int seen = 0;
-            for (;;) {
-                {
-                    std::unique_lock<std::mutex> lk(pool.mu);
-                    pool.cvStart.wait(lk, [&] { return pool.stop || pool.generation != seen; });
-                    if (pool.stop) return;
-                    seen = pool.generation;
-                }
-                for (;;) {
-                    const int task = pool.next.fetch_add(1);
-                    if (task >= pool.nTasks) break;
-                    ssc_task(task);
-                    std::lock_guard<std::mutex> lk(pool.mu);
-                    if (++pool.finished == pool.nTasks) pool.cvDone.notify_all();
-                }
-            }
-        });
-}
-
-void vslam_extractor::pool_stop() {
-    { std::lock_guard<std::mutex> lk(pool.mu); pool.stop = true; }
-    pool.cvStart.notify_all();
-    for (auto& w : pool.workers) w.join();
-    pool.workers.clear();
-}
-
-void vslam_extractor::pool_run(int nTasks) {
-    {
-        std::lock_guard<std::mutex> lk(pool.mu);
-        pool.nTasks = nTasks; pool.finished = 0; pool.next = 0; pool.generation++;
-    }
-    pool.cvStart.notify_all();
-    // the calling thread works too
-    for (;;) {
-        const int task = pool.next.fetch_add(1);
-        if (task >= nTasks) break;
-        ssc_task(task);
-        std::lock_guard<std::mutex> lk(pool.mu);
-        if (++pool.finished == nTasks) pool.cvDone.notify_all();
-    }
-    std::unique_lock<std::mutex> lk(pool.mu);
-    pool.cvDone.wait(lk, [&] { return pool.finished == pool.nTasks; });
-}
-
-// host SSC per (image, level) on the worker pool + upload of the kept lists + the descriptor kernel
-// (the VSLAM_HOST_SSC=1 path and the fallback of the device SSC); the FAST candidates must be complete (evGather)
-vslam_status vslam_extractor::host_ssc_and_describe() {
-    for (int i = 0; i < nimg; i++)
-        if (h_levelCount[(size_t)i * (MAX_LEVELS + 1) + MAX_LEVELS] > candCap) { set_error("FAST candidate overflow"); return VSLAM_ERR_CAPACITY; }
-    pool_run(nimg * nLevels);
-    int maxKept = 0;
-    for (int i = 0; i < nimg; i++) {
-        uint32_t* kout = h_kept + (size_t)i * keptCap;
-        int* koff = h_keptOff + (size_t)i * (MAX_LEVELS + 1);
-        int k = 0;
-        for (int l = 0; l < nLevels; l++) {
-            const std::vector<uint32_t>& keep = sscOut[(size_t)i * nLevels + l];
-            koff[l] = k;
-            if (k + (int)keep.size() > keptCap) { set_error("kept-keypoint overflow"); return VSLAM_ERR_CAPACITY; }
-            if (!keep.empty()) memcpy(kout + k, keep.data(), keep.size() * sizeof(uint32_t));
-            k += (int)keep.size();
-        }
-        for (int l = nLevels; l <= MAX_LEVELS; l++) koff[l] = k;
-        nKept[i] = k;
-        maxKept = std::max(maxKept, k);
-    }
-    VS_HIP(hipMemcpyAsync(d_kept, h_kept, (size_t)nimg * keptCap * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-    VS_HIP(hipMemcpyAsync(d_keptOff, h_keptOff, (size_t)nimg * (MAX_LEVELS + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
-    int t = timer.begin("orient_desc");
-    launch_orient_desc(stream, d_pyr, d_blur, P, T, d_kept, d_keptOff, keptCap, d_disc, ndisc, d_kps,
-                       d_desc, keptCap, maxKept, nimg);
-    timer.end(t);
-    VS_HIP(hipGetLastError());
-    return VSLAM_OK;
-}
-
-// After a device-SSC run: wait for the frame, read the per-image totals; if a level raised the fallback flag
-// (more candidates than the LDS holds, introsort depth limit, probe grid larger than the arena) the frame's SSC is
-// redone by the host path.
+// After a run: wait for the frame, read the per-image keypoint totals and the error flags of the suppression.
+// There is no host path: a level beyond the kernel's limits (more than 65 535 FAST candidates in one level) is an error.
 vslam_status vslam_extractor::wait_counts() {
     if (!countsPending) return VSLAM_OK;
     VS_HIP(hipSetDevice(device));
@@ -479,19 +323,30 @@ vslam_status vslam_extractor::wait_counts() {
         for (int i = 0; i < nimg; i++) for (int l = 0; l < nLevels; l++) { const long long* q = &st[(size_t)(i * nLevels + l) * 8]; fprintf(stderr, "ssc img %d lvl %d: n %lld partitions %lld countsort %lld search %lld (probes %lld final w %lld) emit %lld\n", i, l, q[4], q[0], q[1], q[2], q[5], q[6], q[3]); }
     }
 #endif
-    bool fallback = false;
     for (int i = 0; i < nimg; i++) {
         if (h_counts[nimg + 2 * i + 1]) { set_error("FAST candidate / kept-keypoint overflow"); return VSLAM_ERR_CAPACITY; }
-        fallback |= h_counts[nimg + 2 * i] != 0;
+        if (h_counts[nimg + 2 * i]) {
+            set_error("SSC: image %d exceeds a kernel limit (mask %d: 1 = more than %d candidates in one level, 4 = segment list, "
+                      "8 / 32 = width search, 16 = probe grid)", i, h_counts[nimg + 2 * i], SSC_NMAX);
+            return VSLAM_ERR_CAPACITY;
+        }
         nKept[i] = h_counts[i];
     }
-    if (fallback) {
-        sscFallbacks++;
-        if (getenv("VSLAM_SSC_DEBUG")) for (int i = 0; i < nimg; i++) fprintf(stderr, "device SSC fallback: image %d reason mask %d\n", i, h_counts[nimg + 2 * i]);
-        VS_CHECK(host_ssc_and_describe());
-        VS_HIP(hipEventRecord(evDone, stream));
-        VS_HIP(hipStreamSynchronize(stream));
+    return VSLAM_OK;
+}
+
+vslam_status vslam_extractor::enqueue_ssc() {
+    SscArgs S{};
+    S.cand = d_cand; S.candCap = candCap; S.levelCount = d_levelCount; S.nLevels = nLevels; S.nimg = nimg;
+    for (int l = 0; l < nLevels; l++) {
+        S.numRet[l] = featurePerLevel[l]; S.cols[l] = P.w[l]; S.rows[l] = P.h[l];
+        S.high[l] = sscHigh[l]; S.kmin[l] = sscKmin[l]; S.kmax[l] = sscKmax[l];
     }
+    S.gridG = d_sscGrid; S.gridOff = d_sscGridOff;
+    S.tmp = d_sscTmp; S.aG = d_sscTmp + (size_t)nimg * candCap; S.sortedG = d_sscTmp + (size_t)2 * nimg * candCap;
+    S.picksG = d_sscPicks; S.forceGlobal = sscForceGlobal ? 1 : 0;
+    S.taskCount = d_taskCount; S.flags = d_sscFlags;
+    launch_ssc(stream, S, d_kept, keptCap, d_keptOff, d_counts);
     return VSLAM_OK;
 }
 
@@ -524,47 +379,20 @@ vslam_status vslam_extractor::run() {
                   d_levelCount, nimg);
     timer.end(t);
     VS_HIP(hipEventRecord(evGather, stream));
-    if (deviceSsc) {
-        // K3 on the device (ssc.hip): no host hop between FAST and the descriptors
-        SscArgs S{};
-        S.cand = d_cand; S.candCap = candCap; S.levelCount = d_levelCount; S.nLevels = nLevels; S.nimg = nimg;
-        for (int l = 0; l < nLevels; l++) {
-            S.numRet[l] = featurePerLevel[l]; S.cols[l] = P.w[l]; S.rows[l] = P.h[l];
-            S.high[l] = sscHigh[l]; S.kmin[l] = sscKmin[l]; S.kmax[l] = sscKmax[l];
-        }
-        S.gridG = d_sscGrid;
-        for (size_t q = 0; q < sscGridOff.size() && q < 2 * (size_t)MAX_LEVELS; q++) S.gridOff[q] = sscGridOff[q];
-        S.tmp = d_sscTmp; S.scratch = d_sscTmp + (size_t)nimg * candCap; S.taskCount = d_taskCount; S.flags = d_sscFlags;
-        t = timer.begin("ssc");
-        launch_ssc(stream, S, d_kept, keptCap, d_keptOff, d_counts);
-        timer.end(t);
-        t = timer.begin("blur");
-        launch_blur(stream, d_pyr, d_blur, P, B, nimg);
-        timer.end(t);
-        t = timer.begin("orient_desc");
-        launch_orient_desc(stream, d_pyr, d_blur, P, T, d_kept, d_keptOff, keptCap, d_disc, ndisc, d_kps,
-                           d_desc, keptCap, keptCap, nimg);
-        timer.end(t);
-        VS_HIP(hipGetLastError());
-        VS_HIP(hipEventRecord(evDone, stream));
-        countsPending = true;          // totals / flags are read (after evDone) by wait_counts()
-        ran = true;
-        return VSLAM_OK;
-    }
-    t = timer.begin("blur");       // runs under the host SSC below
+    // K3 on the device (ssc.hip): no host hop between FAST and the descriptors
+    t = timer.begin("ssc");
+    VS_CHECK(enqueue_ssc());
+    timer.end(t);
+    t = timer.begin("blur");
     launch_blur(stream, d_pyr, d_blur, P, B, nimg);
     timer.end(t);
+    t = timer.begin("orient_desc");
+    launch_orient_desc(stream, d_pyr, d_blur, P, T, d_kept, d_keptOff, keptCap, d_disc, ndisc, d_kps,
+                       d_desc, keptCap, keptCap, nimg);
+    timer.end(t);
     VS_HIP(hipGetLastError());
-    HS(1);
-    VS_HIP(hipEventSynchronize(evGather));
-    HS(2);
-    VS_CHECK(host_ssc_and_describe());
-    HS(4);
-    VS_HIP(hipEventRecord(evDone, stream));      // consumers order themselves after this; no host sync here
-    HS(5);
-#ifdef VSLAM_HOST_STAMPS
-    fprintf(stderr, "extract host us: launch %.1f sync %.1f ssc+launch %.1f\n", hs[1] - hs[0], hs[2] - hs[1], hs[4] - hs[2]);
-#endif
+    VS_HIP(hipEventRecord(evDone, stream));
+    countsPending = true;          // totals / flags are read (after evDone) by wait_counts()
     ran = true;
     return VSLAM_OK;
 }
@@ -672,18 +500,59 @@ vslam_status vslam_extractor_level_copy(vslam_extractor* ex, int32_t i, int32_t 
 }
 vslam_status vslam_extractor_candidates(vslam_extractor* ex, int32_t i, int32_t level, vslam_keypoint* out, int32_t cap, int32_t* n_out) {
     if (!ex || !n_out || i < 0 || i >= ex->nimg || level < 0 || level >= ex->nLevels || !ex->ran) return VSLAM_ERR_INVALID;
-    VS_HIP(hipEventSynchronize(ex->evGather));       // the candidate list lives in mapped host memory
-    const int* lc = ex->h_levelCount + (size_t)i * (MAX_LEVELS + 1);
+    VS_HIP(hipSetDevice(ex->device));
+    VS_HIP(hipEventSynchronize(ex->evGather));
+    int lc[MAX_LEVELS + 1];
+    VS_HIP(hipMemcpy(lc, ex->d_levelCount + (size_t)i * (MAX_LEVELS + 1), sizeof(lc), hipMemcpyDeviceToHost));
     int off = 0;
     for (int l = 0; l < level; l++) off += lc[l];
     const int n = lc[level];
     *n_out = n;
     if (n > cap) return VSLAM_ERR_CAPACITY;
-    const uint32_t* c = ex->h_cand + (size_t)i * ex->candCap + off;
+    std::vector<uint32_t> c((size_t)std::max(n, 1));
+    if (n) VS_HIP(hipMemcpy(c.data(), ex->d_cand + (size_t)i * ex->candCap + off, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (int k = 0; k < n; k++) {
         out[k].x = (float)cand_x(c[k]); out[k].y = (float)cand_y(c[k]);
         out[k].size = (float)ex->scaledPatchSize[level]; out[k].angle = -1.f;
         out[k].response = (float)cand_s(c[k]); out[k].octave = level; out[k].class_id = -1;
+    }
+    return VSLAM_OK;
+}
+
+vslam_status vslam_extractor_ssc_level(vslam_extractor* ex, int32_t level, const vslam_keypoint* cand, int32_t n,
+                                       vslam_keypoint* out, int32_t cap, int32_t* n_out) {
+    if (!ex || !n_out || level < 0 || level >= ex->nLevels || n < 0 || (n > 0 && !cand)) return VSLAM_ERR_INVALID;
+    if (n > ex->candCap) { set_error("ssc_level: %d candidates > capacity %d", n, ex->candCap); return VSLAM_ERR_CAPACITY; }
+    VS_HIP(hipSetDevice(ex->device));
+    VS_CHECK(ex->wait_counts());
+    ex->wait_consumers();
+    std::vector<uint32_t> pk((size_t)std::max(n, 1));
+    for (int k = 0; k < n; k++) {
+        const int x = (int)cand[k].x, y = (int)cand[k].y, r = (int)cand[k].response;
+        if (x < 0 || x > 4095 || y < 0 || y > 4095 || r < 0 || r > 255) { set_error("ssc_level: candidate %d out of range", k); return VSLAM_ERR_INVALID; }
+        pk[k] = pack_cand(x, y, r);
+    }
+    std::vector<int> lc((size_t)ex->nimg * (MAX_LEVELS + 1), 0);
+    lc[level] = n; lc[MAX_LEVELS] = n;
+    VS_HIP(hipMemcpyAsync(ex->d_levelCount, lc.data(), lc.size() * sizeof(int), hipMemcpyHostToDevice, ex->stream));
+    if (n) VS_HIP(hipMemcpyAsync(ex->d_cand, pk.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, ex->stream));
+    VS_CHECK(ex->enqueue_ssc());
+    VS_HIP(hipGetLastError());
+    int koff[MAX_LEVELS + 1];
+    VS_HIP(hipMemcpyAsync(koff, ex->d_keptOff, sizeof(koff), hipMemcpyDeviceToHost, ex->stream));
+    VS_HIP(hipStreamSynchronize(ex->stream));
+    ex->ran = false;                 // the extractor's frame outputs no longer describe an image
+    if (ex->h_counts[ex->nimg + 1]) { set_error("ssc_level: kept-keypoint overflow"); return VSLAM_ERR_CAPACITY; }
+    if (ex->h_counts[ex->nimg]) { set_error("ssc_level: kernel limit, mask %d", ex->h_counts[ex->nimg]); return VSLAM_ERR_CAPACITY; }
+    const int k0 = koff[level], k1 = koff[level + 1];
+    *n_out = k1 - k0;
+    if (k1 - k0 > cap) return VSLAM_ERR_CAPACITY;
+    std::vector<uint32_t> kept((size_t)std::max(k1 - k0, 1));
+    if (k1 > k0) VS_HIP(hipMemcpy(kept.data(), ex->d_kept + k0, (size_t)(k1 - k0) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (int k = 0; k < k1 - k0; k++) {
+        out[k].x = (float)cand_x(kept[k]); out[k].y = (float)cand_y(kept[k]);
+        out[k].size = (float)ex->scaledPatchSize[level]; out[k].angle = -1.f;
+        out[k].response = (float)cand_s(kept[k]); out[k].octave = level; out[k].class_id = -1;
     }
     return VSLAM_OK;
 }
@@ -702,8 +571,8 @@ vslam_status vslam_extractor_timings(const vslam_extractor* ex, const char** nam
 vslam_status vslam_extractor_ssc_stats(vslam_extractor* ex, int32_t* on_device, int32_t* host_fallbacks) {
     if (!ex) return VSLAM_ERR_INVALID;
     VS_CHECK(ex->wait_counts());
-    if (on_device) *on_device = ex->deviceSsc ? 1 : 0;
-    if (host_fallbacks) *host_fallbacks = ex->sscFallbacks;
+    if (on_device) *on_device = 1;            // the only path
+    if (host_fallbacks) *host_fallbacks = 0;
     return VSLAM_OK;
 }
 

@@ -3,10 +3,7 @@
 // `nimg` same-sized images per run).
 #pragma once
 #include "extract_kernels.hpp"
-#include <atomic>
-#include <condition_variable>
 #include <mutex>
-#include <thread>
 
 struct vslam_extractor {
     vslam_fe_params prm{};
@@ -22,7 +19,7 @@ struct vslam_extractor {
     vslam::LevelTables T{};
     hipStream_t stream = nullptr;
     vslam::StageTimer timer;
-    // cross-stream ordering without host syncs: evGather = FAST candidates are in host-visible memory,
+    // cross-stream ordering without host syncs: evGather = FAST candidates complete (debug tap),
     // evDone = keys / descriptors / pyramids of the last run are complete (matchers wait on it);
     // consumers = "last read of this extractor's buffers" events of the bound matchers, waited on before
     // the next frame overwrites the buffers
@@ -43,14 +40,10 @@ struct vslam_extractor {
     int* d_cellOff = nullptr;
     int nCells = 0;
     int candCap = 0;             // per image
-    uint32_t* h_cand = nullptr;  // pinned, device-visible: nimg * candCap
-    uint32_t* d_cand = nullptr;  // device alias of h_cand
-    int* h_levelCount = nullptr; // pinned: nimg * (MAX_LEVELS+1)
-    int* d_levelCount = nullptr;
+    uint32_t* d_cand = nullptr;  // nimg * candCap packed FAST candidates (HBM)
+    int* d_levelCount = nullptr; // nimg * (MAX_LEVELS+1)
     int keptCap = 0;             // per image
-    uint32_t* h_kept = nullptr;  // pinned staging
     uint32_t* d_kept = nullptr;
-    int* h_keptOff = nullptr;    // pinned: nimg * (MAX_LEVELS+1)
     int* d_keptOff = nullptr;
     int8_t* d_disc = nullptr;
     int ndisc = 0;
@@ -58,42 +51,24 @@ struct vslam_extractor {
     uint8_t* d_desc = nullptr;        // nimg * keptCap * 32
     std::vector<int> nKept;           // per image, after the last run (valid after wait_counts())
     bool ran = false;
-    // device-side SSC (default; VSLAM_HOST_SSC=1 selects the host worker pool): picks, per-task counts, flags,
-    // and the per-image totals / flags mirrored into mapped host memory
-    bool deviceSsc = true;
-    uint32_t* d_sscTmp = nullptr;
+    // SSC (FeatureExtractor::ssc) runs in k_ssc, on the device only: picks, per-task counts, flags, and the per-image
+    // totals / flags mirrored into mapped host memory
+    uint32_t* d_sscTmp = nullptr;     // picks | (HBM instantiation) sort keys | stopper lists / sorted candidates
+    uint32_t* d_sscPicks = nullptr;   // (HBM instantiation) pick bitmasks per (task, probe)
     uint32_t* d_sscGrid = nullptr;
-    std::vector<size_t> sscGridOff;
+    size_t* d_sscGridOff = nullptr;
     int* d_taskCount = nullptr;
     int* d_sscFlags = nullptr;
     int* h_counts = nullptr;          // pinned mapped: [nimg] totals, then 2 flags per image
     int* d_counts = nullptr;
     int sscHigh[vslam::MAX_LEVELS] = {0}, sscKmin[vslam::MAX_LEVELS] = {0}, sscKmax[vslam::MAX_LEVELS] = {0};
+    bool sscForceGlobal = false;      // VSLAM_SSC_FORCE_GLOBAL=1 (tests): every level through the HBM instantiation
     bool countsPending = false;
-    int sscFallbacks = 0;             // frames whose SSC was redone by the host path
-    vslam_status wait_counts();       // completes a device-SSC run on the host side (counts; rare host fallback)
-    vslam_status host_ssc_and_describe();
-
-    // host worker pool for the sequential SSC stage: one task per (image, level)
-    struct SscPool {
-        std::vector<std::thread> workers;
-        std::mutex mu;
-        std::condition_variable cvStart, cvDone;
-        std::atomic<int> next{0};
-        int nTasks = 0, generation = 0, finished = 0;
-        bool stop = false;
-    } pool;
-    std::vector<std::vector<uint32_t>> sscOut;     // [nimg * nLevels]
-    void pool_start(int nThreads);
-    void pool_stop();
-    void pool_run(int nTasks);
-    void ssc_task(int task);
+    vslam_status wait_counts();       // completes a run on the host side (keypoint totals, error flags)
+    vslam_status enqueue_ssc();
 
     vslam_status init(const vslam_fe_params* p, int w, int h, int batch, int dev);
     void release();
     vslam_status set_image(int idx, const void* src, int stride, bool srcOnDevice);
     vslam_status run();
-    // host SSC of one level (reference FeatureExtractor::ssc, src/FeatureExtractor.cpp:368-468)
-    void ssc_level(const uint32_t* cand, int n, int numRet, int cols, int rows,
-                   std::vector<uint32_t>& out) const;
 };

@@ -466,7 +466,7 @@ vslam_status vslam_matcher::pose_imu_enqueue(int M, const int* Mdev, const int* 
     { long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ps), z, sizeof(z)); }
 #endif
     // dynamic LDS: the factor list (8 doubles per map point) when it fits next to the kernel's static 10 KB
-    const int ldsCap = 17000;                       // factors: 136 KB
+    const int ldsCap = 2125;                        // factors of 8 doubles: 136 KB
     I.ldsFactors = M <= ldsCap ? M : 0;
     const size_t lds = (size_t)I.ldsFactors * 8 * sizeof(double);
     static bool attr = false;

@@ -1,31 +1,46 @@
 // K3 on the device: FeatureExtractor::ssc (reference src/FeatureExtractor.cpp:368-468, ANMS "SSC") for every
-// (image, level) of a frame, bit-exact with the host restatement in extractor.hip.
+// (image, level) of a frame, bit-exact with the reference loop (the CPU restatement lives with the tests).
 //
 // The two sequential pieces of the reference are reproduced exactly, in parallel:
 //  (1) cv::sortIdx = libstdc++ std::sort on indices (+ reversal): the TIE ORDER of introsort decides which of
 //      several equal-response corners survives.  Introsort = a tree of median-of-3 Hoare partitions down to
 //      16-element blocks + one insertion sort.  A Hoare partition is a deterministic permutation: the k-th
 //      element >= pivot from the left is exchanged with the k-th element <= pivot from the right while they have
-//      not crossed, so one wave computes it with ballots / prefix counts; sibling segments are independent, so the
-//      tree is walked level by level with one wave per segment.  The closing insertion sort never moves an element
+//      not crossed.  Segments longer than SSC_COOP_MIN are partitioned by the WHOLE workgroup (16 waves scan slices,
+//      stopper lists by prefix counts, the crossing point by one parallel test, the exchanges by all threads);
+//      shorter ones by one wave each, sibling segments in parallel, the tree walked level by level; segments of
+//      <= 64 elements finish their whole subtree in registers.  The closing insertion sort never moves an element
 //      past an equal one and the blocks are already ordered among themselves, hence it equals ONE stable counting
-//      sort by the 8-bit response of the partitioned array.  (Depth-limit exhaustion -> heapsort in libstdc++; never
-//      seen with 8-bit keys, it raises the fallback flag and the host redoes the frame.)
+//      sort by the 8-bit response of the partitioned array.  A segment that exhausts introsort's depth limit is
+//      heap-sorted by one lane with libstdc++'s exact __make_heap / __sort_heap sequence (never seen on images).
 //  (2) the binary search over the suppression width, each probe a greedy cover scan in response order: a wave
 //      takes 64 candidates per step, tests the LDS bit grid, resolves the picks inside the step in order (a pick
 //      covers the 5x5 cells around it), marks them.  The search is speculated three probes deep (7 waves evaluate
 //      both outcomes of the next probes), the decision logic replays the reference loop on the cached counts.
+//
+// Two instantiations of the same code: k_ssc<false> keeps the sort arrays of a level in LDS (<= 16 384 candidates:
+// every level of the 752x480 / 1241x376 rigs and of a 1920x1200 frame); k_ssc<true> keeps them in HBM scratch
+// (up to 65 535 candidates per level, the width of the index field).  Each (image, level) task is taken by exactly
+// one of them; the other returns at once.  There is no host path.
 #include "extract_kernels.hpp"
 
 namespace vslam {
 
-constexpr int SSC_NT = 1024, SSC_NW = SSC_NT / 64;      // 16 waves: the short-segment sorts and the slices of the counting sort
+constexpr int SSC_NT = 1024, SSC_NW = SSC_NT / 64;      // 16 waves
 constexpr int SSC_NPROBE = 8;                           // speculative probes per round (waves 0..6 are used: a depth-3 tree)
-constexpr int SSC_PICKW = 256;                          // words of a probe's pick bitmask (SSC_NMAX / 32)
-constexpr int SSC_NMAX = 8192;           // candidates of one level the LDS arrays hold (more -> fallback flag)
-constexpr int SSC_SEGMAX = 512;
-constexpr int SSC_ARENA_WORDS = 18 * 1024;     // 72 KB of cover-grid bits (9 KB per speculating wave)
+constexpr int SSC_COOP_MIN = 1024;                      // longer segments: block-cooperative partition
+constexpr int SSC_ARENA_WORDS = 20 * 1024;              // 80 KB of cover-grid bits (10 KB per speculating wave)
 
+template <bool G> struct SscCfg;
+template <> struct SscCfg<false> { static constexpr int NMAX = SSC_NMAX_LDS, SEGMAX = 1024, PICKW = SSC_NMAX_LDS / 32; };
+template <> struct SscCfg<true> { static constexpr int NMAX = SSC_NMAX, SEGMAX = 4096, PICKW = SSC_PICKW_G; };
+
+// ordering of a wave's own accesses to the sort arrays: LDS traffic of a wave is processed in order (lgkmcnt);
+// the HBM instantiation also waits for its vector-memory operations
+template <bool G> __device__ __forceinline__ void ssc_fence() {
+    if (G) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
 __device__ __forceinline__ void ssc_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // floor(v / (width / 2.0)) for integer v >= 0: 2v / width exactly (the double quotient of the reference is either an exact
@@ -41,8 +56,9 @@ __device__ __forceinline__ int ssc_cell(int v, int width, float rcpw) {
 // greedy cover scan at `width` over sc[0..n) (response order); returns the number of picks.  picks (may be null):
 // one bit per candidate, set for the picked ones (wave-private words: word = index >> 5)
 // abortAbove >= 0: stop as soon as the count exceeds it (the search only needs "too many"); the return value is then > abortAbove
-__device__ int ssc_eval(const uint32_t* sc, int n, int width, int cols, int rows, uint32_t* grid, int gridWords,
-                        uint32_t* picks, bool& fits, int abortAbove) {
+template <bool G>
+__device__ __forceinline__ int ssc_eval(const uint32_t* sc, int n, int width, int cols, int rows, uint32_t* grid, int gridWords,
+                                        uint32_t* picks, bool& fits, int abortAbove) {
     const int lane = threadIdx.x & 63;
     const float rcpw = 1.0f / (float)width;
     const int gc = ssc_cell(cols, width, rcpw), gr = ssc_cell(rows, width, rcpw);
@@ -55,10 +71,12 @@ __device__ int ssc_eval(const uint32_t* sc, int n, int width, int cols, int rows
     ssc_lds_fence();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the HBM grid of the very fine probes)
     int count = 0;
+    uint32_t pkNext = lane < n ? sc[lane] : 0u;
     for (int base = 0; base < n; base += 64) {
         const int i = base + lane;
         const bool valid = i < n;
-        const uint32_t pk = valid ? sc[i] : 0u;
+        const uint32_t pk = pkNext;
+        if (G) pkNext = (i + 64 < n) ? sc[i + 64] : 0u;   // HBM: the next step's candidates are in flight during the pick resolution
         const int row = ssc_cell(cand_y(pk), width, rcpw);
         const int col = ssc_cell(cand_x(pk), width, rcpw);
         bool covered = true;
@@ -87,11 +105,65 @@ __device__ int ssc_eval(const uint32_t* sc, int n, int width, int cols, int rows
         }
         if (picks && lane < 2) picks[(base >> 5) + lane] = (uint32_t)(picked >> (32 * lane));
         count += __popcll(picked);
+        if (!G) pkNext = (i + 64 < n) ? sc[i + 64] : 0u;
         ssc_lds_fence();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (abortAbove >= 0 && count > abortAbove) break;
     }
     return count;
+}
+
+// segment list entry: word 0 = first | last << 16 (last <= 65 535), word 1 = remaining introsort depth
+__device__ __forceinline__ void ssc_push(uint32_t* segN, int* cntN, int segMax, int f, int e, int depth, int* sFail) {
+    const int q = atomicAdd(cntN, 1);
+    if (q < segMax) { segN[2 * q] = (uint32_t)f | ((uint32_t)e << 16); segN[2 * q + 1] = (uint32_t)depth; }
+    else *sFail = 4;
+}
+
+// libstdc++ std::__adjust_heap + std::__push_heap (bits/stl_heap.h), comparator key(i) < key(j), one lane
+template <bool G>
+__device__ void ssc_adjust_heap(uint32_t* first, int holeIndex, int len, uint32_t value) {
+    const int topIndex = holeIndex;
+    int secondChild = holeIndex;
+    while (secondChild < (len - 1) / 2) {
+        secondChild = 2 * (secondChild + 1);
+        if ((first[secondChild] >> 16) < (first[secondChild - 1] >> 16)) secondChild--;
+        first[holeIndex] = first[secondChild];
+        ssc_fence<G>();
+        holeIndex = secondChild;
+    }
+    if ((len & 1) == 0 && secondChild == (len - 2) / 2) {
+        secondChild = 2 * (secondChild + 1);
+        first[holeIndex] = first[secondChild - 1];
+        ssc_fence<G>();
+        holeIndex = secondChild - 1;
+    }
+    int parent = (holeIndex - 1) / 2;
+    while (holeIndex > topIndex && (first[parent] >> 16) < (value >> 16)) {
+        first[holeIndex] = first[parent];
+        ssc_fence<G>();
+        holeIndex = parent;
+        parent = (holeIndex - 1) / 2;
+    }
+    first[holeIndex] = value;
+    ssc_fence<G>();
+}
+// std::__partial_sort(first, last, last) of introsort's depth-limit branch: __make_heap, then __sort_heap
+template <bool G>
+__device__ void ssc_heapsort(uint32_t* first, int len) {
+    if (len < 2) return;
+    for (int parent = (len - 2) / 2;; parent--) {
+        const uint32_t value = first[parent];
+        ssc_adjust_heap<G>(first, parent, len, value);
+        if (parent == 0) break;
+    }
+    for (int last = len; last > 1;) {
+        --last;
+        const uint32_t value = first[last];
+        first[last] = first[0];
+        ssc_fence<G>();
+        ssc_adjust_heap<G>(first, 0, last, value);
+    }
 }
 
 // position of the k-th (0-based) set bit of m counted from the LSB / from the MSB; k < popcount(m)
@@ -108,22 +180,28 @@ __device__ __forceinline__ int ssc_sel_lo(unsigned long long m, int k) {
     }
     return pos;
 }
-__device__ __forceinline__ int ssc_sel_hi(unsigned long long m, int k) { return 63 - ssc_sel_lo(__brevll(m), k); }
 
 // Introsort's partition tree of a segment of at most 64 elements, entirely in registers (lane = element), one tree
 // LEVEL per iteration: every lane carries the bounds [lo, hi) of the sub-segment it currently belongs to, all
 // sub-segments of a level run their median-of-3 / Hoare partition at once (ballots masked to the lane's segment, the
-// partner of an exchange found by bit selection, one bpermute).  Same permutation as the LDS path below.
-// Returns false if the depth limit is exhausted.
-__device__ bool ssc_small_segment(uint32_t* a, int f, int e, int depth, uint16_t* Lp, uint16_t* Rp) {
+// partner of an exchange found through the stopper lists, one bpermute).  Same permutation as the array paths below.
+// A sub-segment that reaches depth 0 while still longer than 16 ends the register walk: the values go back to the
+// array and every unfinished sub-segment is pushed to the next level's list (depth 0 -> heap sort there).
+template <bool G>
+__device__ __forceinline__ void ssc_small_segment(uint32_t* a, int f, int e, int depth, uint16_t* Lp, uint16_t* Rp,
+                                                  uint32_t* segN, int* cntN, int segMax, int* sFail) {
     const int lane = threadIdx.x & 63, m = e - f;
     uint32_t v = lane < m ? a[f + lane] : 0u;
     int lo = lane < m ? 0 : 64, hi = lane < m ? m : 64, d = depth;
-    bool ok = true;
     for (;;) {
         const bool act = (hi - lo) > 16;
         if (__ballot(act) == 0ull) break;
-        if (__ballot(act && d == 0) != 0ull) { ok = false; break; }
+        if (__ballot(act && d == 0) != 0ull) {
+            if (lane < m) a[f + lane] = v;
+            if (act && lane == lo) ssc_push(segN, cntN, segMax, f + lo, f + hi, d, sFail);
+            ssc_fence<G>();
+            return;
+        }
         const int ia = act ? lo + 1 : lane, ib = act ? lo + (hi - lo) / 2 : lane, ic = act ? hi - 1 : lane;
         const uint32_t va = __shfl(v, ia), vb = __shfl(v, ib), vc = __shfl(v, ic), vlo = __shfl(v, act ? lo : lane);
         const uint32_t ka = va >> 16, kb = vb >> 16, kc = vc >> 16;
@@ -142,11 +220,11 @@ __device__ bool ssc_small_segment(uint32_t* a, int f, int e, int depth, uint16_t
         const int nL = __popcll(mL), nR = __popcll(mR);
         const int kL = __popcll(mL & ((1ull << lane) - 1ull));
         const int kR = lane == 63 ? 0 : __popcll(mR >> (lane + 1));
-        // stopper positions by rank, in the segment's own slice of the LDS lists (left stoppers ascending, right
+        // stopper positions by rank, in the segment's own slice of the stopper lists (left stoppers ascending, right
         // stoppers from the top): the partner of the k-th left stopper is the k-th right stopper from the top
         if (isL) Lp[f + lo + kL] = (uint16_t)lane;
         if (isR) Rp[f + lo + kR] = (uint16_t)lane;
-        ssc_lds_fence();
+        ssc_fence<G>();
         int src = lane;
         bool asL = false;
         if (isL && kL < nR) { const int p = Rp[f + lo + kL]; if (lane < p) { src = p; asL = true; } }
@@ -159,98 +237,167 @@ __device__ bool ssc_small_segment(uint32_t* a, int f, int e, int depth, uint16_t
             d--;
             if (lane < cut) hi = cut; else lo = cut;
         }
-        ssc_lds_fence();
+        ssc_fence<G>();
     }
     if (lane < m) a[f + lane] = v;
-    ssc_lds_fence();
-    return ok;
+    ssc_fence<G>();
 }
 
-__global__ __launch_bounds__(SSC_NT) void k_ssc(SscArgs A) {
-    extern __shared__ uint32_t lds[];
-    uint32_t* a = lds;                                    // [SSC_NMAX] (key << 16 | index)
-    uint16_t* Lp = (uint16_t*)(a + SSC_NMAX);             // [SSC_NMAX]
-    uint16_t* Rp = Lp + SSC_NMAX;                         // [SSC_NMAX]
-    int* seg = (int*)(Rp + SSC_NMAX);                     // 2 x [SSC_SEGMAX][3]
-    uint32_t* arena = (uint32_t*)(seg + 2 * SSC_SEGMAX * 3);     // [SSC_ARENA_WORDS]
-    __shared__ int hist[256], sCnt[2], sFail;
-    __shared__ int cacheW[64], cacheC[64], cacheSlot[64], nCache, sched[8], nSched, sFinal, sDone, sSolo;
-    __shared__ int sLow, sHigh, sPrev, sLast;
+// median of (f + 1, mid, e - 1) moved to f: std::__move_median_to_first
+__device__ __forceinline__ void ssc_median_to_first(uint32_t* a, int f, int e) {
+    const int ia = f + 1, ib = f + (e - f) / 2, ic = e - 1;
+    const uint32_t ka = a[ia] >> 16, kb = a[ib] >> 16, kc = a[ic] >> 16;
+    int m;
+    if (ka < kb) { if (kb < kc) m = ib; else if (ka < kc) m = ic; else m = ia; }
+    else if (ka < kc) m = ia; else if (kb < kc) m = ic; else m = ib;
+    const uint32_t t = a[f]; a[f] = a[m]; a[m] = t;
+}
+
+// One introsort step (__unguarded_partition_pivot) of segment [f, e) by the WHOLE workgroup; every thread calls it.
+// sW: 2 * SSC_NW + 2 ints of LDS.
+template <bool G>
+__device__ __forceinline__ void ssc_partition_coop(uint32_t* a, uint16_t* Lp, uint16_t* Rp, int f, int e, int depth, int* sW,
+                                                   uint32_t* segN, int* cntN, int segMax, int* sFail) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { ssc_median_to_first(a, f, e); ssc_fence<G>(); }
+    __syncthreads();
+    const uint32_t pk = a[f] >> 16;
+    const int m = e - f - 1;
+    const int per = ((m + SSC_NW - 1) / SSC_NW + 63) & ~63;
+    const int c0 = min(e, f + 1 + wave * per), c1 = min(e, c0 + per);
+    int nl = 0, nr = 0;
+    for (int base = c0; base < c1; base += 64) {
+        const int x = base + lane;
+        const bool v = x < c1;
+        const uint32_t kx = v ? (a[x] >> 16) : 0u;
+        nl += __popcll(__ballot(v && kx >= pk)); nr += __popcll(__ballot(v && kx <= pk));
+    }
+    if (lane == 0) { sW[wave] = nl; sW[SSC_NW + wave] = nr; }
+    __syncthreads();
+    int offL = 0, offR = 0, nL = 0, nR = 0;
+#pragma unroll
+    for (int w = 0; w < SSC_NW; w++) {
+        const int l = sW[w], r = sW[SSC_NW + w];
+        if (w < wave) { offL += l; offR += r; }
+        nL += l; nR += r;
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int base = c0; base < c1; base += 64) {
+        const int x = base + lane;
+        const bool v = x < c1;
+        const uint32_t kx = v ? (a[x] >> 16) : 0u;
+        const bool isL = v && kx >= pk, isR = v && kx <= pk;
+        const unsigned long long bl = __ballot(isL), br = __ballot(isR);
+        if (isL) Lp[f + 1 + offL + __popcll(bl & lt)] = (uint16_t)x;
+        if (isR) Rp[f + 1 + offR + __popcll(br & lt)] = (uint16_t)x;
+        offL += __popcll(bl); offR += __popcll(br);
+    }
+    const int nPair = min(nL, nR);
+    if (tid == 0) sW[2 * SSC_NW] = nPair;
+    ssc_fence<G>();
+    __syncthreads();
+    // K = number of leading pairs that have not crossed (monotone: the first failure ends the run)
+    for (int k = tid; k < nPair; k += SSC_NT)
+        if (!(Lp[f + 1 + k] < Rp[f + 1 + nR - 1 - k])) { atomicMin(&sW[2 * SSC_NW], k); break; }
+    __syncthreads();
+    const int K = sW[2 * SSC_NW];
+    for (int k = tid; k < K; k += SSC_NT) {
+        const int xl = Lp[f + 1 + k], xr = Rp[f + 1 + nR - 1 - k];
+        const uint32_t t = a[xl]; a[xl] = a[xr]; a[xr] = t;
+    }
+    if (tid == 0) {
+        int cut = K >= 1 ? (int)Rp[f + 1 + nR - K] : e;
+        if (K < nL) cut = min(cut, (int)Lp[f + 1 + K]);
+        // __introsort_loop(cut, last, depth - 1); last = cut
+        if (e - cut > 16) ssc_push(segN, cntN, segMax, cut, e, depth - 1, sFail);
+        if (cut - f > 16) ssc_push(segN, cntN, segMax, f, cut, depth - 1, sFail);
+    }
+    ssc_fence<G>();
+    __syncthreads();
+}
+
+template <bool G>
+__global__ __launch_bounds__(SSC_NT) void k_ssc(SscArgs A) {
+    using C = SscCfg<G>;
+    extern __shared__ uint32_t lds[];
+    // LDS instantiation:  [sorted = Lp | Rp : NMAX u32] [a : NMAX u32] [seg : 2 x SEGMAX x 2 u32]; after the sort the
+    //                     cover-grid arena reuses a | seg (80 KB), the counting-sort histogram the seg lists (16 KB)
+    // HBM instantiation:  [seg : 2 x SEGMAX x 2 u32] [arena]; a / sorted live in the task's HBM scratch
     const int img = blockIdx.x % A.nimg, l = blockIdx.x / A.nimg;
-#ifdef VSLAM_SSC_STAMPS
-    long long st_t = clock64();
-    long long* st = (long long*)(A.taskCount + A.nimg * MAX_LEVELS) + (size_t)(img * A.nLevels + l) * 8;
-#define SSC_STAMP(k) do { if (tid == 0) { const long long n_ = clock64(); st[k] = n_ - st_t; st_t = n_; } } while (0)
-#else
-#define SSC_STAMP(k) do {} while (0)
-#endif
+    const int task = img * A.nLevels + l;
     const int* lc = A.levelCount + (size_t)img * (MAX_LEVELS + 1);
     int coff = 0;
     for (int q = 0; q < l; q++) coff += lc[q];
     const int n = lc[l];
+    const bool big = A.forceGlobal || n > SSC_NMAX_LDS;
+    if (big != G) return;                                // the other instantiation's task
+    uint32_t* sortedU = G ? A.sortedG + (size_t)img * A.candCap + coff : lds;
+    uint32_t* a = G ? A.aG + (size_t)img * A.candCap + coff : lds + C::NMAX;
+    uint16_t* Lp = (uint16_t*)sortedU;
+    uint16_t* Rp = Lp + (G ? n : C::NMAX);
+    uint32_t* seg = G ? lds : lds + 2 * C::NMAX;
+    uint32_t* arena = G ? lds + 4 * C::SEGMAX : lds + C::NMAX;
+    int* h2 = G ? (int*)arena : (int*)seg;               // [SSC_NW][256]
+    __shared__ int hist[256], sCnt[2], sFail, sW[2 * SSC_NW + 2];
+    __shared__ int cacheW[64], cacheC[64], cacheSlot[64], nCache, sched[8], nSched, sFinal, sDone, sSolo;
+    __shared__ int sLow, sHigh, sPrev, sLast;
+    __shared__ int pre[C::PICKW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef VSLAM_SSC_STAMPS
+    long long st_t = clock64();
+    long long* st = (long long*)(A.taskCount + A.nimg * MAX_LEVELS) + (size_t)task * 8;
+#define SSC_STAMP(k) do { if (tid == 0) { const long long n_ = clock64(); st[k] = n_ - st_t; st_t = n_; } } while (0)
+#else
+#define SSC_STAMP(k) do {} while (0)
+#endif
     const uint32_t* cand = A.cand + (size_t)img * A.candCap + coff;
     uint32_t* out = A.tmp + (size_t)img * A.candCap + coff;
-    int* taskCount = A.taskCount + img * A.nLevels + l;
+    int* taskCount = A.taskCount + task;
     if (lc[MAX_LEVELS] > A.candCap) { if (tid == 0) { A.flags[2 * img + 1] = 1; *taskCount = 0; } return; }
     const int numRet = A.numRet[l];
-    if (n <= numRet) {                                   // (:371-374 of the restatement) everything is kept, original order
+    if (n <= numRet) {                                   // (src/FeatureExtractor.cpp:371-374) everything is kept, original order
         for (int i = tid; i < n; i += SSC_NT) out[i] = cand[i];
         if (tid == 0) *taskCount = n;
         return;
     }
-    if (n > SSC_NMAX) { if (tid == 0) { atomicOr(&A.flags[2 * img], 1); *taskCount = 0; } return; }
+    if (n > C::NMAX) { if (tid == 0) { atomicOr(&A.flags[2 * img], 1); *taskCount = 0; } return; }
 
     // ---- (1) std::sort on indices by response, exact tie order ----------------------------------------
-    // the level's candidates move from mapped host memory into HBM (`out`, overwritten by the picks at the very end)
-    uint32_t* b = A.scratch + (size_t)img * A.candCap + coff;
-    for (int i = tid; i < n; i += SSC_NT) { const uint32_t pk = cand[i]; b[i] = pk; a[i] = ((uint32_t)cand_s(pk) << 16) | (uint32_t)i; }
+    for (int i = tid; i < n; i += SSC_NT) a[i] = ((uint32_t)cand_s(cand[i]) << 16) | (uint32_t)i;
     if (tid < 256) hist[tid] = 0;
     if (tid == 0) {
         sFail = 0;
         int lg = 0;
         while ((1 << (lg + 1)) <= n) lg++;
         sCnt[0] = 0; sCnt[1] = 0;
-        if (n > 16) { seg[0] = 0; seg[1] = n; seg[2] = 2 * lg; sCnt[0] = 1; }
+        if (n > 16) { seg[0] = 0u | ((uint32_t)n << 16); seg[1] = (uint32_t)(2 * lg); sCnt[0] = 1; }
     }
+    ssc_fence<G>();
     __syncthreads();
     int cur = 0;
-#ifdef VSLAM_SSC_STAMPS
-    int it_ = 0;
-    long long it_t = clock64();
-#endif
     for (;;) {
-        const int nseg = sCnt[cur];
+        const int nseg = min(sCnt[cur], C::SEGMAX);
         if (nseg == 0) break;
-        int* segC = seg + cur * SSC_SEGMAX * 3;
-#ifdef VSLAM_SSC_STAMPS
-        if (tid == 0 && l == 0 && img == 0) {
-            int mx = 0, small = 0;
-            for (int s = 0; s < nseg; s++) { const int len = segC[3 * s + 1] - segC[3 * s]; mx = max(mx, len); small += len <= 64; }
-            const long long now = clock64();
-            printf("  ssc iter %d: nseg %d (<=64: %d) maxlen %d | previous iteration %lld cycles\n", it_, nseg, small, mx, now - it_t);
-            it_t = clock64();
+        const uint32_t* segC = seg + cur * C::SEGMAX * 2;
+        uint32_t* segN = seg + (cur ^ 1) * C::SEGMAX * 2;
+        int* cntN = &sCnt[cur ^ 1];
+        // long segments first, one after the other, by the whole workgroup (uniform control flow: the list is shared)
+        for (int s = 0; s < nseg; s++) {
+            const int f = (int)(segC[2 * s] & 0xffffu), e = (int)(segC[2 * s] >> 16), depth = (int)segC[2 * s + 1];
+            if (e - f <= SSC_COOP_MIN) continue;
+            if (depth == 0) { if (tid == 0) ssc_heapsort<G>(a + f, e - f); continue; }
+            ssc_partition_coop<G>(a, Lp, Rp, f, e, depth, sW, segN, cntN, C::SEGMAX, &sFail);
         }
-        it_++;
-#endif
-        int* segN = seg + (cur ^ 1) * SSC_SEGMAX * 3;
         for (int s = wave; s < nseg; s += SSC_NW) {
-            const int f = segC[3 * s], e = segC[3 * s + 1], depth = segC[3 * s + 2];
+            const int f = (int)(segC[2 * s] & 0xffffu), e = (int)(segC[2 * s] >> 16), depth = (int)segC[2 * s + 1];
+            if (e - f > SSC_COOP_MIN) continue;
+            if (depth == 0) { if (lane == 0) ssc_heapsort<G>(a + f, e - f); continue; }      // libstdc++ switches to heapsort here
             if (e - f <= 64) {                            // the whole subtree of a short segment, in registers
-                if (!ssc_small_segment(a, f, e, depth, Lp, Rp) && lane == 0) sFail = 2;
+                ssc_small_segment<G>(a, f, e, depth, Lp, Rp, segN, cntN, C::SEGMAX, &sFail);
                 continue;
             }
-            if (depth == 0) { if (lane == 0) sFail = 2; continue; }       // libstdc++ would switch to heapsort here
-            // __move_median_to_first(f, f+1, mid, e-1)
-            if (lane == 0) {
-                const int ia = f + 1, ib = f + (e - f) / 2, ic = e - 1;
-                const uint32_t ka = a[ia] >> 16, kb = a[ib] >> 16, kc = a[ic] >> 16;
-                int m;
-                if (ka < kb) { if (kb < kc) m = ib; else if (ka < kc) m = ic; else m = ia; }
-                else if (ka < kc) m = ia; else if (kb < kc) m = ic; else m = ib;
-                const uint32_t t = a[f]; a[f] = a[m]; a[m] = t;
-            }
-            ssc_lds_fence();
+            if (lane == 0) ssc_median_to_first(a, f, e);
+            ssc_fence<G>();
             const uint32_t pk = a[f] >> 16;
             // __unguarded_partition(f+1, e, pivot): stoppers from the left (>= pivot) / from the right (<= pivot)
             int nL = 0, nR = 0;
@@ -265,7 +412,7 @@ __global__ __launch_bounds__(SSC_NT) void k_ssc(SscArgs A) {
                 if (isR) Rp[f + 1 + nR + __popcll(br & lt)] = (uint16_t)x;
                 nL += __popcll(bl); nR += __popcll(br);
             }
-            ssc_lds_fence();
+            ssc_fence<G>();
             const int nPair = min(nL, nR);
             int K = 0;
             for (int base = 0; base < nPair; base += 64) {
@@ -279,15 +426,16 @@ __global__ __launch_bounds__(SSC_NT) void k_ssc(SscArgs A) {
                 const int xl = Lp[f + 1 + k], xr = Rp[f + 1 + nR - 1 - k];
                 const uint32_t t = a[xl]; a[xl] = a[xr]; a[xr] = t;
             }
-            ssc_lds_fence();
+            ssc_fence<G>();
             int cut = K >= 1 ? (int)Rp[f + 1 + nR - K] : e;
             if (K < nL) cut = min(cut, (int)Lp[f + 1 + K]);
             if (lane == 0) {
                 // __introsort_loop(cut, last, depth - 1); last = cut
-                if (e - cut > 16) { const int q = atomicAdd(&sCnt[cur ^ 1], 1); if (q < SSC_SEGMAX) { segN[3 * q] = cut; segN[3 * q + 1] = e; segN[3 * q + 2] = depth - 1; } else sFail = 4; }
-                if (cut - f > 16) { const int q = atomicAdd(&sCnt[cur ^ 1], 1); if (q < SSC_SEGMAX) { segN[3 * q] = f; segN[3 * q + 1] = cut; segN[3 * q + 2] = depth - 1; } else sFail = 4; }
+                if (e - cut > 16) ssc_push(segN, cntN, C::SEGMAX, cut, e, depth - 1, &sFail);
+                if (cut - f > 16) ssc_push(segN, cntN, C::SEGMAX, f, cut, depth - 1, &sFail);
             }
         }
+        ssc_fence<G>();
         __syncthreads();
         if (tid == 0) sCnt[cur] = 0;
         cur ^= 1;
@@ -295,9 +443,8 @@ __global__ __launch_bounds__(SSC_NT) void k_ssc(SscArgs A) {
     }
     SSC_STAMP(0);
     if (sFail) { if (tid == 0) { atomicOr(&A.flags[2 * img], sFail); *taskCount = 0; } return; }
-    // __final_insertion_sort == stable counting sort by the 8-bit key of the partitioned array.  Eight slices in
+    // __final_insertion_sort == stable counting sort by the 8-bit key of the partitioned array.  Sixteen slices in
     // array order, one per wave: per-(slice, key) counts, offsets ordered by (key, slice), stable scatter per slice.
-    int* h2 = (int*)arena;                               // [SSC_NW][256]
     for (int i = tid; i < SSC_NW * 256; i += SSC_NT) h2[i] = 0;
     __syncthreads();
     const int per = ((n + SSC_NW - 1) / SSC_NW + 63) & ~63;
@@ -322,7 +469,6 @@ __global__ __launch_bounds__(SSC_NT) void k_ssc(SscArgs A) {
     __syncthreads();
     {
         // sorted ascending -> written reversed (cv::sortIdx DESCENDING reverses the index array), as packed candidates
-        uint32_t* sorted = (uint32_t*)Lp;                // Lp | Rp together hold SSC_NMAX u32
         int* off = h2 + wave * 256;
         for (int base = s0; base < s1; base += 64) {
             const int i = base + lane;
@@ -338,16 +484,17 @@ __global__ __launch_bounds__(SSC_NT) void k_ssc(SscArgs A) {
             same &= __ballot(v);
             if (v) {
                 const int rank = __popcll(same & ((1ull << lane) - 1ull));
-                sorted[n - 1 - (off[key] + rank)] = b[e & 0xffffu];
+                sortedU[n - 1 - (off[key] + rank)] = cand[e & 0xffffu];
             }
             ssc_lds_fence();
             if (v && (same >> lane) == 1ull) off[key] += __popcll(same);      // the highest lane of each key group
             ssc_lds_fence();
         }
     }
+    ssc_fence<G>();
     __syncthreads();
     SSC_STAMP(1);
-    const uint32_t* sc = (const uint32_t*)Lp;            // candidates in response order (descending, reference tie order)
+    const uint32_t* sc = sortedU;                        // candidates in response order (descending, reference tie order)
 
     // ---- (2) binary search over the suppression width ---------------------------------------------------
     if (tid == 0) {
@@ -357,7 +504,15 @@ __global__ __launch_bounds__(SSC_NT) void k_ssc(SscArgs A) {
     __syncthreads();
     const int kmin = A.kmin[l], kmax = A.kmax[l];
     const int cols = A.cols[l], rows = A.rows[l];
-    uint32_t* gridG = A.gridG + A.gridOff[img * A.nLevels + l];
+    uint32_t* gridG = A.gridG + A.gridOff[task];
+    constexpr int SLICE = SSC_ARENA_WORDS / SSC_NPROBE;
+    // pick bitmasks: LDS instantiation at the top of the probing wave's arena slice; HBM instantiation in the task's scratch
+    uint32_t* picksG = G ? A.picksG + (size_t)task * SSC_NPROBE * SSC_PICKW_G : nullptr;
+    constexpr int PICKW_L = G ? 0 : C::PICKW;
+    auto picks_of = [&](int slot) -> uint32_t* {         // slot < 0: the solo probe
+        if (G) return picksG + (size_t)(slot < 0 ? SSC_NPROBE - 1 : slot) * SSC_PICKW_G;
+        return slot < 0 ? arena + SSC_ARENA_WORDS - PICKW_L : arena + slot * SLICE + SLICE - PICKW_L;
+    };
     for (int round = 0; round < 64; round++) {
         if (tid == 0) {
             // replay the reference loop on the cached counts
@@ -401,13 +556,12 @@ __global__ __launch_bounds__(SSC_NT) void k_ssc(SscArgs A) {
         const bool solo = sSolo != 0;
         int cnt = -2;
         bool fits = true;
-        constexpr int SLICE = SSC_ARENA_WORDS / SSC_NPROBE;
-        uint32_t* picks = solo ? arena + SSC_ARENA_WORDS - SSC_PICKW : arena + wave * SLICE + SLICE - SSC_PICKW;
+        uint32_t* picks = picks_of(solo ? -1 : wave);
         if (wave < ns) {
             uint32_t* grid = solo ? arena : arena + wave * SLICE;
-            cnt = ssc_eval(sc, n, sched[wave], cols, rows, grid, (solo ? SSC_ARENA_WORDS : SLICE) - SSC_PICKW, picks, fits, kmax);
+            cnt = ssc_eval<G>(sc, n, sched[wave], cols, rows, grid, (solo ? SSC_ARENA_WORDS : SLICE) - PICKW_L, picks, fits, kmax);
             // a probe whose bit grid exceeds even the whole LDS arena (width 1-2 on a large level) uses the task's HBM grid
-            if (solo && !fits) cnt = ssc_eval(sc, n, sched[wave], cols, rows, gridG, 1 << 30, picks, fits, kmax);
+            if (solo && !fits) cnt = ssc_eval<G>(sc, n, sched[wave], cols, rows, gridG, 1 << 30, picks, fits, kmax);
         }
         __syncthreads();
         if (wave < ns && lane == 0) {
@@ -430,34 +584,32 @@ __global__ __launch_bounds__(SSC_NT) void k_ssc(SscArgs A) {
 #endif
     if (!sDone) { if (tid == 0) { atomicOr(&A.flags[2 * img], 32); *taskCount = 0; } return; }
     // emit the picks of the last evaluated width (lastPicked of the reference loop).  That probe always belongs to
-    // the latest round, so its pick bitmask is still in its wave's slice: prefix over the words, one thread per word.
+    // the latest round, so its pick bitmask is still in its wave's slot: prefix over the words, one thread per word.
     int total = 0;
     if (sFinal >= 0) {
         int slot = -1;
         for (int q = 0; q < nCache; q++) if (cacheW[q] == sFinal) { slot = cacheSlot[q]; total = cacheC[q]; }
-        constexpr int SLICE = SSC_ARENA_WORDS / SSC_NPROBE;
-        const uint32_t* picks = slot < 0 ? arena + SSC_ARENA_WORDS - SSC_PICKW : arena + slot * SLICE + SLICE - SSC_PICKW;
+        const uint32_t* picks = picks_of(slot);
         if (total > kmax) {
             // the search ended on a "too many" probe (width == prevWidth / low > high): its scan was cut short, redo it in full
             __syncthreads();
             if (wave == 0) {
-                uint32_t* pk = arena + SSC_ARENA_WORDS - SSC_PICKW;
+                uint32_t* pk = picks_of(-1);
                 bool fits;
-                int cnt = ssc_eval(sc, n, sFinal, cols, rows, arena, SSC_ARENA_WORDS - SSC_PICKW, pk, fits, -1);
-                if (!fits) cnt = ssc_eval(sc, n, sFinal, cols, rows, gridG, 1 << 30, pk, fits, -1);
+                int cnt = ssc_eval<G>(sc, n, sFinal, cols, rows, arena, SSC_ARENA_WORDS - PICKW_L, pk, fits, -1);
+                if (!fits) cnt = ssc_eval<G>(sc, n, sFinal, cols, rows, gridG, 1 << 30, pk, fits, -1);
                 if (lane == 0) sCnt[0] = cnt;
             }
             __syncthreads();
             total = sCnt[0];
-            picks = arena + SSC_ARENA_WORDS - SSC_PICKW;
+            picks = picks_of(-1);
         }
         const int nWords = (n + 31) >> 5;
-        int* pre = hist;                                 // 256 ints: exclusive prefix of the per-word pick counts
-        if (tid < 256) pre[tid] = tid < nWords ? __popc(picks[tid]) : 0;
+        for (int w = tid; w < C::PICKW; w += SSC_NT) pre[w] = w < nWords ? __popc(picks[w]) : 0;
         __syncthreads();
-        if (wave == 0) {
+        if (wave == 0) {                                 // exclusive prefix of the per-word pick counts
             int run = 0;
-            for (int base = 0; base < 256; base += 64) {
+            for (int base = 0; base < nWords; base += 64) {
                 const int v = pre[base + lane];
                 int incl = v;
 #pragma unroll
@@ -467,10 +619,10 @@ __global__ __launch_bounds__(SSC_NT) void k_ssc(SscArgs A) {
             }
         }
         __syncthreads();
-        if (tid < nWords) {
-            uint32_t w = picks[tid];
-            int o = pre[tid];
-            while (w) { const int bit = __ffs((int)w) - 1; w &= w - 1; out[o++] = sc[32 * tid + bit]; }
+        for (int wd = tid; wd < nWords; wd += SSC_NT) {
+            uint32_t w = picks[wd];
+            int o = pre[wd];
+            while (w) { const int bit = __ffs((int)w) - 1; w &= w - 1; out[o++] = sc[32 * wd + bit]; }
         }
     }
     if (tid == 0) *taskCount = total;
@@ -503,10 +655,17 @@ __global__ __launch_bounds__(256) void k_ssc_pack(SscArgs A, uint32_t* __restric
 }
 
 void launch_ssc(hipStream_t s, const SscArgs& A, uint32_t* kept, int keptCap, int* keptOff, int* hostCounts) {
-    const size_t lds = (size_t)SSC_NMAX * 4 + (size_t)2 * SSC_NMAX * 2 + (size_t)2 * SSC_SEGMAX * 3 * 4 + (size_t)SSC_ARENA_WORDS * 4;
+    const size_t ldsL = ((size_t)2 * SscCfg<false>::NMAX + (size_t)4 * SscCfg<false>::SEGMAX) * 4;
+    const size_t ldsG = ((size_t)4 * SscCfg<true>::SEGMAX + (size_t)SSC_ARENA_WORDS) * 4;
+    static_assert((size_t)SscCfg<false>::NMAX + 4 * SscCfg<false>::SEGMAX >= (size_t)SSC_ARENA_WORDS, "arena must fit a | seg");
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k_ssc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    hipLaunchKernelGGL(k_ssc, dim3(A.nimg * A.nLevels), dim3(SSC_NT), lds, s, A);
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)k_ssc<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsL);
+        (void)hipFuncSetAttribute((const void*)k_ssc<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsG);
+        attr = true;
+    }
+    hipLaunchKernelGGL(k_ssc<false>, dim3(A.nimg * A.nLevels), dim3(SSC_NT), ldsL, s, A);
+    hipLaunchKernelGGL(k_ssc<true>, dim3(A.nimg * A.nLevels), dim3(SSC_NT), ldsG, s, A);
     hipLaunchKernelGGL(k_ssc_pack, dim3(A.nimg), dim3(256), 0, s, A, kept, keptCap, keptOff, hostCounts);
 }
 

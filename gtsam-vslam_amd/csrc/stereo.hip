@@ -491,6 +491,18 @@ vslam_status vslam_matcher::stereo_match() {
     }
     A.maxD = (float)rig.fx; A.fx = rig.fx; A.fxf = (float)rig.fx; A.baseline = rig.baseline;
     A.imageHeight = rig.height;
+    // dynamic LDS of the two kernels: 9 B per right key (row band, octave, y) / 20 B per left key (accepted-pair lists)
+    constexpr int STEREO_LDS = 150 * 1024, STEREO_MAX_R = (STEREO_LDS - 16) / 9 - 4, STEREO_MAX_L = STEREO_LDS / 20;
+    if (A.nR > STEREO_MAX_R || A.nL > STEREO_MAX_L) {
+        set_error("stereo_match: %d left / %d right keypoints exceed the LDS staging (%d / %d)", A.nL, A.nR, STEREO_MAX_L, STEREO_MAX_R);
+        return VSLAM_ERR_CAPACITY;
+    }
+    static bool attr = false;
+    if (!attr) {
+        VS_HIP(hipFuncSetAttribute((const void*)k_stereo_match, hipFuncAttributeMaxDynamicSharedMemorySize, STEREO_LDS));
+        VS_HIP(hipFuncSetAttribute((const void*)k_stereo_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, STEREO_LDS));
+        attr = true;
+    }
     VS_HIP(hipMemsetAsync(d_stats, 0, 4 * sizeof(unsigned long long), stream));
     int t = timer.begin("stereo_match");
     launch_stereo_match(stream, A, d_mBest, d_mDepth, d_mSad, d_stats);

@@ -130,8 +130,22 @@ def pose_at(i, fps=20.0):
     return T
 
 
+_FRAME_CACHE = {}
+
+
 def stereo_frame(i, rig_name="euroc", scene_seed=7, tex_seed=0xC0FFEE, noise=True):
-    """Left/right u8 images of frame i plus the ground-truth pose."""
+    """Left/right u8 images of frame i plus the ground-truth pose (rendered once per process: a 1920x1200 pair takes
+    seconds on the host)."""
+    key = (i, rig_name, scene_seed, tex_seed, noise)
+    if key not in _FRAME_CACHE:
+        if len(_FRAME_CACHE) > 64:
+            _FRAME_CACHE.clear()
+        _FRAME_CACHE[key] = _render_stereo_frame(i, rig_name, scene_seed, tex_seed, noise)
+    L, R, T = _FRAME_CACHE[key]
+    return L.copy(), R.copy(), T.copy()
+
+
+def _render_stereo_frame(i, rig_name, scene_seed, tex_seed, noise):
     rig = RIGS[rig_name]
     planes = make_scene(scene_seed)
     tex = texture(tex_seed)

@@ -130,6 +130,14 @@ class Extractor:
         _chk(self.L.vslam_extractor_candidates(self.h, idx, level, _p(out), cap, C.byref(n)))
         return out[:n.value].copy()
 
+    def ssc_level(self, level, cand):
+        """FeatureExtractor::ssc of one pyramid level on caller-supplied candidates (test tap)."""
+        cand = np.ascontiguousarray(cand, KP_DTYPE)
+        out = np.zeros(max(len(cand), 1), KP_DTYPE)
+        n = C.c_int32()
+        _chk(self.L.vslam_extractor_ssc_level(self.h, level, _p(cand), len(cand), _p(out), len(out), C.byref(n)))
+        return out[:n.value].copy()
+
     def timings(self):
         names = (C.c_char_p * 32)()
         ms = (C.c_float * 32)()

@@ -104,6 +104,12 @@ vslam_status vslam_extractor_level_copy(vslam_extractor* ex, int32_t image_index
 vslam_status vslam_extractor_candidates(vslam_extractor* ex, int32_t image_index, int32_t level,
                                         vslam_keypoint* out, int32_t cap, int32_t* n_out);
 
+/* test tap: FeatureExtractor::ssc (src/FeatureExtractor.cpp:368-468) of pyramid level `level` on caller-supplied
+ * candidates (x, y integer-valued < 4096, response 0..255; tol 0.1, numRetPoints = featurePerLevel[level], the level's
+ * cols / rows) - the same kernel a frame runs, fed directly.  Invalidates the extractor's last frame. */
+vslam_status vslam_extractor_ssc_level(vslam_extractor* ex, int32_t level, const vslam_keypoint* cand, int32_t n,
+                                       vslam_keypoint* out, int32_t cap, int32_t* n_out);
+
 /* per-kernel device time of the last run, in milliseconds (HIP events on the
  * extractor's stream).  names/ms hold up to cap entries; n_out = entries written. */
 vslam_status vslam_extractor_timings(const vslam_extractor* ex, const char** names, float* ms,
@@ -111,10 +117,10 @@ vslam_status vslam_extractor_timings(const vslam_extractor* ex, const char** nam
 /* per-kernel HIP-event timing on (default) / off for this extractor's following runs; off removes the
  * two event records per launch from the launch-bound path */
 vslam_status vslam_extractor_set_timing(vslam_extractor* ex, int32_t on);
-/* SSC placement: on_device = 1 when the suppression (FeatureExtractor::ssc, src/FeatureExtractor.cpp:368-468) runs in
- * the k_ssc kernel (default; the environment variable VSLAM_HOST_SSC=1 selects the host worker pool);
- * host_fallbacks = frames whose SSC was redone on the host because a level exceeded a device limit (more than 4096
- * candidates in one level, introsort depth limit reached, probe grid larger than the LDS arena). */
+/* SSC placement: the suppression (FeatureExtractor::ssc, src/FeatureExtractor.cpp:368-468) runs in the k_ssc kernels
+ * only - on_device is always 1 and host_fallbacks always 0 (kept for callers of the earlier interface).  A level with
+ * more than 65 535 FAST candidates makes the run fail with VSLAM_ERR_CAPACITY.  VSLAM_SSC_FORCE_GLOBAL=1 (tests) sends
+ * every level through the HBM-resident instantiation that levels above 16 384 candidates use. */
 vslam_status vslam_extractor_ssc_stats(vslam_extractor* ex, int32_t* on_device, int32_t* host_fallbacks);
 
 
@@ -393,7 +399,8 @@ vslam_status vslam_local_ba_set_timing(int32_t on);
  *   mask_second_pass (0 / 1, default 1)  run the second optimisation on the first one's factor ordering with the
  *                                       rejected pairs' weights set to zero instead of rebuilding it on the host
  *                                       (falls back to the rebuild when a keyframe loses all its observations).
- * Process-wide; the landmark-sharded path (comm != NULL) always runs 1 / off / rebuild. */
+ * The settings belong to the CALLING THREAD (like the timing switch and the workspace: one optimizer thread = one
+ * local-BA context), so sessions with different settings do not interact. */
 vslam_status vslam_local_ba_set_lookahead(int32_t candidates, int32_t speculative_linearize, int32_t mask_second_pass);
 
 /* ---------------------------------------------------------------------------

@@ -8,7 +8,7 @@ import synth
 pytestmark = pytest.mark.gpu
 
 
-def _compare(oracle, capi, img, nfeat, levels_check=True, allow_host_fallback=False):
+def _compare(oracle, capi, img, nfeat, levels_check=True):
     h, w = img.shape
     oe = oracle.Extractor(nfeat)
     ok, od = oe.extract(img)
@@ -28,7 +28,7 @@ def _compare(oracle, capi, img, nfeat, levels_check=True, allow_host_fallback=Fa
         assert np.array_equal(ok[f], gk[f]), "keypoint field %s" % f
     assert np.array_equal(od, gd)
     on_device, fallbacks = ge.ssc_stats()
-    assert on_device == 1 and (fallbacks == 0 or allow_host_fallback), "SSC must have run in the k_ssc kernel (no host fallback)"
+    assert (on_device, fallbacks) == (1, 0), "SSC runs in the k_ssc kernels only (there is no host path)"
     ge.close()
     return len(ok)
 
@@ -79,9 +79,8 @@ def test_extract_min_threshold_fallback_cells(oracle, capi):
 
 def test_extract_full_size_c5(oracle, capi):
     """Largest config (1920x1200, 4000 features): full parity on the keypoints/descriptors."""
-    # level 0 of this size holds more than the 8192 candidates the kernel's LDS arrays take: the frame's SSC is redone by
-    # the host path (documented limit, DESIGN.md section 3.1) - results must still be identical
-    _compare(oracle, capi, synth.random_image(1920, 1200, 55), 4000, levels_check=False, allow_host_fallback=True)
+    # level 0 of this size holds ~10 000 FAST candidates (the LDS instantiation of k_ssc takes up to 16 384)
+    _compare(oracle, capi, synth.random_image(1920, 1200, 55), 4000, levels_check=False)
 
 
 def test_extract_capacity_and_bad_args(capi):
@@ -92,18 +91,3 @@ def test_extract_capacity_and_bad_args(capi):
     with pytest.raises(capi.VslamError) as e:
         ge.fetch(0, cap=10)
     assert e.value.status == capi.ERR_CAPACITY
-
-
-def test_host_ssc_path_matches_device_ssc(oracle, capi, monkeypatch):
-    """VSLAM_HOST_SSC=1 keeps the host worker-pool SSC (also the fallback of the device kernel): same keypoints."""
-    img = synth.random_image(752, 480, 55)
-    ge = capi.Extractor(752, 480, 1500)
-    (k1, d1), = ge.extract([img])
-    assert ge.ssc_stats() == (1, 0)
-    monkeypatch.setenv("VSLAM_HOST_SSC", "1")
-    gh = capi.Extractor(752, 480, 1500)
-    (k2, d2), = gh.extract([img])
-    assert gh.ssc_stats()[0] == 0
-    for f in k1.dtype.names:
-        assert np.array_equal(k1[f], k2[f]), f
-    assert np.array_equal(d1, d2)

@@ -8,13 +8,13 @@ import synth
 pytestmark = pytest.mark.gpu
 
 
-def _window(oracle, frames, seed=0, mp_frac=0.3):
-    rig = synth.RIGS["euroc"]
+def _window(oracle, frames, seed=0, mp_frac=0.3, rig_name="euroc", nfeat=1500):
+    rig = synth.RIGS[rig_name]
     rng = np.random.default_rng(seed)
-    oL, oR = oracle.Extractor(1500), oracle.Extractor(1500)
+    oL, oR = oracle.Extractor(nfeat), oracle.Extractor(nfeat)
     kfs = []
     for f in frames:
-        L, R, T = synth.stereo_frame(f)
+        L, R, T = synth.stereo_frame(f, rig_name)
         kL, dL = oL.extract(L); kR, dR = oR.extract(R)
         st = oracle.stereo_match(oL, oR, rig, kL, dL, kR, dR)
         unF = np.where(rng.random(len(kL)) < 0.2, rng.integers(0, 1000, len(kL)), -1).astype(np.int32)
@@ -40,7 +40,11 @@ def _window(oracle, frames, seed=0, mp_frac=0.3):
 
 @pytest.mark.parametrize("frames,seed", [((30, 24, 18, 12, 6), 0), ((20, 14, 8, 20, 2), 1), ((9,), 2)])
 def test_find_new_points_parity(oracle, capi, frames, seed):
-    rig, oL, kfs, last = _window(oracle, frames, seed)
+    _find_new_points_parity(oracle, capi, frames, seed)
+
+
+def _find_new_points_parity(oracle, capi, frames, seed, rig_name="euroc", nfeat=1500):
+    rig, oL, kfs, last = _window(oracle, frames, seed, rig_name=rig_name, nfeat=nfeat)
     ref = oracle.find_new_points(oL, rig, kfs, last)
     got = capi.find_new_points(rig, oL.scalePyramid, oL.sigmaFactor, kfs, last)
     assert got["n"] == ref["n"] and ref["n"] > 300

@@ -8,19 +8,19 @@ import synth
 pytestmark = pytest.mark.gpu
 
 
-def _scene(oracle, capi, frame=6, seed=0, outlier_frac=0.08, shared_left=0):
-    rig = synth.RIGS["euroc"]
-    L, R, _ = synth.stereo_frame(frame)
-    oL, oR = oracle.Extractor(1500), oracle.Extractor(1500)
+def _scene(oracle, capi, frame=6, seed=0, outlier_frac=0.08, shared_left=0, rig_name="euroc", nfeat=1500):
+    rig = synth.RIGS[rig_name]
+    L, R, _ = synth.stereo_frame(frame, rig_name)
+    oL, oR = oracle.Extractor(nfeat), oracle.Extractor(nfeat)
     kL, dL = oL.extract(L)
     kR, dR = oR.extract(R)
     st = oracle.stereo_match(oL, oR, rig, kL, dL, kR, dR)
-    ge = capi.Extractor(rig["w"], rig["h"], 1500, batch=2)
+    ge = capi.Extractor(rig["w"], rig["h"], nfeat, batch=2)
     ge.extract([L, R])
     m = capi.Matcher(rig, ge, 0, ge, 1)
     m.stereo_match()
     rng = np.random.default_rng(seed)
-    T_wc = synth.pose_at(frame)
+    T_wc = synth.pose_at(frame, rig["fps"])
     # map points: stereo keypoints back-projected with their depth, plus far (mono) and right-only ones
     idx = np.nonzero(st["rightIdxs"] >= 0)[0]
     pts, matches = [], []
@@ -49,8 +49,13 @@ def _scene(oracle, capi, frame=6, seed=0, outlier_frac=0.08, shared_left=0):
 
 @pytest.mark.parametrize("seed,shared", [(0, 0), (1, 40), (2, 0)])
 def test_pose_lm_parity(oracle, capi, seed, shared):
-    rig, oL, (kL, dL, kR, dR), st, m, pts, matches, inF, inFR, mpo, out0, T_wc = _scene(oracle, capi, seed=seed, shared_left=shared)
-    T0 = np.linalg.inv(synth.pose_at(6 - 1 - seed))              # previous-frame pose as the initial guess
+    _pose_lm_parity(oracle, capi, seed, shared)
+
+
+def _pose_lm_parity(oracle, capi, seed, shared, rig_name="euroc", nfeat=1500):
+    rig, oL, (kL, dL, kR, dR), st, m, pts, matches, inF, inFR, mpo, out0, T_wc = _scene(oracle, capi, seed=seed, shared_left=shared,
+                                                                                         rig_name=rig_name, nfeat=nfeat)
+    T0 = np.linalg.inv(synth.pose_at(6 - 1 - seed, rig["fps"]))   # previous-frame pose as the initial guess
     ref = oracle.estimate_pose(rig, oL.InvSigmaFactor, pts, inF, inFR, mpo, matches, out0, kL, kR,
                                st["rightIdxs"], st["leftIdxs"], st["depth"], st["close"], T0)
     got = capi.estimate_pose(m, pts, inF, inFR, mpo, matches, out0, T0)

@@ -7,9 +7,9 @@ import synth
 pytestmark = pytest.mark.gpu
 
 
-def _frontend(oracle, capi, frame=4, nfeat=1500):
-    rig = synth.RIGS["euroc"]
-    L, R, _ = synth.stereo_frame(frame)
+def _frontend(oracle, capi, frame=4, nfeat=1500, rig_name="euroc"):
+    rig = synth.RIGS[rig_name]
+    L, R, _ = synth.stereo_frame(frame, rig_name)
     oL, oR = oracle.Extractor(nfeat), oracle.Extractor(nfeat)
     kL, dL = oL.extract(L)
     kR, dR = oR.extract(R)
@@ -50,9 +50,13 @@ def _make_mps(oracle, kL, dL, kR, dR, st, rng, n, jitter, flip_bits=12, dup=0):
 
 @pytest.mark.parametrize("rad,jitter,dup", [(10.0, 6.0, 0), (4.0, 2.0, 150), (120.0, 40.0, 300)])
 def test_projection_parity(oracle, capi, rad, jitter, dup):
-    rig, oL, (kL, dL, kR, dR), st, ge, m = _frontend(oracle, capi)
+    _projection_parity(oracle, capi, rad, jitter, dup)
+
+
+def _projection_parity(oracle, capi, rad, jitter, dup, rig_name="euroc", nfeat=1500, n_mps=900):
+    rig, oL, (kL, dL, kR, dR), st, ge, m = _frontend(oracle, capi, nfeat=nfeat, rig_name=rig_name)
     rng = np.random.default_rng(int(rad) + dup)
-    mps = _make_mps(oracle, kL, dL, kR, dR, st, rng, 900, jitter, dup=dup)
+    mps = _make_mps(oracle, kL, dL, kR, dR, st, rng, n_mps, jitter, dup=dup)
     M = len(mps)
     mL0 = np.full(len(kL), -1, np.int32)
     mR0 = np.full(len(kR), -1, np.int32)

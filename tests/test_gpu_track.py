@@ -108,11 +108,15 @@ def oracle_track(oracle, rig, ex, keys, st, mp, T_wc_pred, frame_number, imu=Non
 
 @pytest.mark.parametrize("f0,f1,frame_number", [(4, 5, 7), (8, 10, 1), (2, 3, 3)])
 def test_track_frame_parity(oracle, capi, f0, f1, frame_number):
-    rig = synth.RIGS["euroc"]
-    La, Ra, Ta = synth.stereo_frame(f0)
-    Lb, Rb, Tb = synth.stereo_frame(f1)
-    oL, oR = oracle.Extractor(1500), oracle.Extractor(1500)
-    ge = capi.Extractor(rig["w"], rig["h"], 1500, batch=2)
+    _track_frame_parity(oracle, capi, f0, f1, frame_number)
+
+
+def _track_frame_parity(oracle, capi, f0, f1, frame_number, rig_name="euroc", nfeat=1500, min_active=150):
+    rig = synth.RIGS[rig_name]
+    La, Ra, Ta = synth.stereo_frame(f0, rig_name)
+    Lb, Rb, Tb = synth.stereo_frame(f1, rig_name)
+    oL, oR = oracle.Extractor(nfeat), oracle.Extractor(nfeat)
+    ge = capi.Extractor(rig["w"], rig["h"], nfeat, batch=2)
     m = capi.Matcher(rig, ge, 0, ge, 1)
     # frame a: map initialisation
     kL, dL = oL.extract(La); kR, dR = oR.extract(Ra)
@@ -120,14 +124,14 @@ def test_track_frame_parity(oracle, capi, f0, f1, frame_number):
     mp = oracle_init_map(rig, oL, kL, dL, st, Ta)
     ge.extract([La, Ra]); m.stereo_match(); capi.tracker_init_map(m, Ta)
     # frame b: track with a constant-velocity style prediction (ground truth of an intermediate time)
-    pred = synth.pose_at(f1 - 0.3)
+    pred = synth.pose_at(f1 - 0.3, rig["fps"])
     kL, dL = oL.extract(Lb); kR, dR = oR.extract(Rb)
     st = oracle.stereo_match(oL, oR, rig, kL, dL, kR, dR)
     ref = oracle_track(oracle, rig, oL, (kL, dL, kR, dR), st, mp, pred, frame_number)
     ge.extract([Lb, Rb]); m.stereo_match()
     T_cw, rep = capi.tracker_track(m, pred, frame_number)
     mt, outl, act = capi.tracker_fetch(m)
-    assert rep["n_map_points"] == len(mp[0]) and rep["n_active"] == len(ref["act"]) and rep["n_active"] > 150
+    assert rep["n_map_points"] == len(mp[0]) and rep["n_active"] == len(ref["act"]) and rep["n_active"] > min_active
     assert np.array_equal(act, ref["act"])
     assert rep["rounds"] == ref["rounds"] and rep["lm_iterations"] == ref["iters"]
     assert (rep["n_inliers"], rep["n_stereo"]) == (ref["nIn"], ref["nStereo"])
@@ -138,6 +142,7 @@ def test_track_frame_parity(oracle, capi, f0, f1, frame_number):
     # tracking recovers the true pose of frame b
     assert np.abs(rigid_inv(T_cw) - Tb).max() < 0.05
     assert rep["n_inliers"] >= 50
+    return ge, rep
 
 
 def test_track_frame_imu_parity(oracle, capi):

@@ -8,4 +8,4 @@ ge = vc.Extractor(752, 480, 1500, batch=2)
 ge.extract([L, R])
 print("----", file=sys.stderr)
 ge.extract([L, R])
-print(ge.ssc_stats(), ge.timings())
+print(ge.timings())
