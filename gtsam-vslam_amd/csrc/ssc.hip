@@ -32,7 +32,7 @@ constexpr int SSC_COOP_MIN = 1024;                      // longer segments: bloc
 constexpr int SSC_ARENA_WORDS = 20 * 1024;              // 80 KB of cover-grid bits (10 KB per speculating wave)
 
 template <bool G> struct SscCfg;
-template <> struct SscCfg<false> { static constexpr int NMAX = SSC_NMAX_LDS, SEGMAX = 1024, PICKW = SSC_NMAX_LDS / 32; };
+template <> struct SscCfg<false> { static constexpr int NMAX = SSC_NMAX_LDS, SEGMAX = 1088, PICKW = SSC_NMAX_LDS / 32; };
 template <> struct SscCfg<true> { static constexpr int NMAX = SSC_NMAX, SEGMAX = 4096, PICKW = SSC_PICKW_G; };
 
 // ordering of a wave's own accesses to the sort arrays: LDS traffic of a wave is processed in order (lgkmcnt);
@@ -113,9 +113,18 @@ __device__ __forceinline__ int ssc_eval(const uint32_t* sc, int n, int width, in
     return count;
 }
 
-// segment list entry: word 0 = first | last << 16 (last <= 65 535), word 1 = remaining introsort depth
+// segment list entry: word 0 = first | last << 16 (last <= 65 535), word 1 = remaining introsort depth.
+// A level's list has two parts: [0, SSC_LONGMAX) the segments longer than SSC_COOP_MIN (count cntN[2]; at most
+// 65 535 / 1 025 of them exist at once), [SSC_LONGMAX, ...) the others (count cntN[0]).
+constexpr int SSC_LONGMAX = 64;
 __device__ __forceinline__ void ssc_push(uint32_t* segN, int* cntN, int segMax, int f, int e, int depth, int* sFail) {
-    const int q = atomicAdd(cntN, 1);
+    if (e - f > SSC_COOP_MIN) {
+        const int q = atomicAdd(cntN + 2, 1);
+        if (q < SSC_LONGMAX) { segN[2 * q] = (uint32_t)f | ((uint32_t)e << 16); segN[2 * q + 1] = (uint32_t)depth; }
+        else *sFail = 4;
+        return;
+    }
+    const int q = atomicAdd(cntN, 1) + SSC_LONGMAX;
     if (q < segMax) { segN[2 * q] = (uint32_t)f | ((uint32_t)e << 16); segN[2 * q + 1] = (uint32_t)depth; }
     else *sFail = 4;
 }
@@ -338,7 +347,7 @@ __global__ __launch_bounds__(SSC_NT) void k_ssc(SscArgs A) {
     uint32_t* seg = G ? lds : lds + 2 * C::NMAX;
     uint32_t* arena = G ? lds + 4 * C::SEGMAX : lds + C::NMAX;
     int* h2 = G ? (int*)arena : (int*)seg;               // [SSC_NW][256]
-    __shared__ int hist[256], sCnt[2], sFail, sW[2 * SSC_NW + 2];
+    __shared__ int hist[256], sCnt[4], sFail, sW[2 * SSC_NW + 2];      // sCnt[list]: short segments, sCnt[2 + list]: long ones
     __shared__ int cacheW[64], cacheC[64], cacheSlot[64], nCache, sched[8], nSched, sFinal, sDone, sSolo;
     __shared__ int sLow, sHigh, sPrev, sLast;
     __shared__ int pre[C::PICKW];
@@ -369,28 +378,27 @@ __global__ __launch_bounds__(SSC_NT) void k_ssc(SscArgs A) {
         sFail = 0;
         int lg = 0;
         while ((1 << (lg + 1)) <= n) lg++;
-        sCnt[0] = 0; sCnt[1] = 0;
-        if (n > 16) { seg[0] = 0u | ((uint32_t)n << 16); seg[1] = (uint32_t)(2 * lg); sCnt[0] = 1; }
+        sCnt[0] = sCnt[1] = sCnt[2] = sCnt[3] = 0;
+        if (n > 16) ssc_push(seg, &sCnt[0], C::SEGMAX, 0, n, 2 * lg, &sFail);
     }
     ssc_fence<G>();
     __syncthreads();
     int cur = 0;
     for (;;) {
-        const int nseg = min(sCnt[cur], C::SEGMAX);
-        if (nseg == 0) break;
-        const uint32_t* segC = seg + cur * C::SEGMAX * 2;
+        const int nseg = min(sCnt[cur], C::SEGMAX - SSC_LONGMAX), nlong = min(sCnt[2 + cur], SSC_LONGMAX);
+        if (nseg == 0 && nlong == 0) break;
+        const uint32_t* segL = seg + cur * C::SEGMAX * 2;
+        const uint32_t* segC = segL + 2 * SSC_LONGMAX;
         uint32_t* segN = seg + (cur ^ 1) * C::SEGMAX * 2;
         int* cntN = &sCnt[cur ^ 1];
         // long segments first, one after the other, by the whole workgroup (uniform control flow: the list is shared)
-        for (int s = 0; s < nseg; s++) {
-            const int f = (int)(segC[2 * s] & 0xffffu), e = (int)(segC[2 * s] >> 16), depth = (int)segC[2 * s + 1];
-            if (e - f <= SSC_COOP_MIN) continue;
+        for (int s = 0; s < nlong; s++) {
+            const int f = (int)(segL[2 * s] & 0xffffu), e = (int)(segL[2 * s] >> 16), depth = (int)segL[2 * s + 1];
             if (depth == 0) { if (tid == 0) ssc_heapsort<G>(a + f, e - f); continue; }
             ssc_partition_coop<G>(a, Lp, Rp, f, e, depth, sW, segN, cntN, C::SEGMAX, &sFail);
         }
         for (int s = wave; s < nseg; s += SSC_NW) {
             const int f = (int)(segC[2 * s] & 0xffffu), e = (int)(segC[2 * s] >> 16), depth = (int)segC[2 * s + 1];
-            if (e - f > SSC_COOP_MIN) continue;
             if (depth == 0) { if (lane == 0) ssc_heapsort<G>(a + f, e - f); continue; }      // libstdc++ switches to heapsort here
             if (e - f <= 64) {                            // the whole subtree of a short segment, in registers
                 ssc_small_segment<G>(a, f, e, depth, Lp, Rp, segN, cntN, C::SEGMAX, &sFail);
@@ -437,7 +445,7 @@ __global__ __launch_bounds__(SSC_NT) void k_ssc(SscArgs A) {
         }
         ssc_fence<G>();
         __syncthreads();
-        if (tid == 0) sCnt[cur] = 0;
+        if (tid == 0) { sCnt[cur] = 0; sCnt[2 + cur] = 0; }
         cur ^= 1;
         __syncthreads();
     }
