@@ -516,22 +516,17 @@ __device__ __forceinline__ void ba_hll_inverse(const double* h, double lambda, d
 // One wave per landmark.  sharedW: the workgroup serves every lambda candidate (grid y = 1): Hll, bl and the W blocks
 // do not depend on the damping and are built once, only Hll^-1 and the rank-3 updates are per candidate, each into
 // its own LDS copy of the reduced system.  Otherwise grid y = candidate.
-template <bool LDS_S>
 __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_schur(BaDev D, int maxSlots, int sharedW) {
+    constexpr bool LDS_S = true;       // (windows of larger systems: k_ba_schur_win)
     extern __shared__ double sm[];
     double* const SBase = D.S;
     double* const SpartBase = D.Spart;
+    (void)SBase;
     const int c0 = sharedW ? 0 : (int)blockIdx.y;
     if (!ba_enter(D, BA_TRY, c0)) return;
     const int nc = sharedW ? D.NB : 1;
     const int n = D.n;
     const size_t sys = (size_t)n * n + n;
-    if (LDS_S) {   // D.S | D.rhs receive the sum of the per-workgroup partial systems (k_ba_reduce): zero them here
-        for (int k = 0; k < nc; k++) {
-            double* Sg = SBase + (size_t)(c0 + k) * D.sysStride;
-            for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (int)sys; i += gridDim.x * blockDim.x) Sg[i] = 0;
-        }
-    }
     constexpr int BA_LPL = BA_LPL_SCHUR;
     double* Sloc = sm;                                        // LDS_S: nc copies of n*n + n
     double* wbase = sm + (LDS_S ? (size_t)nc * sys : 0);
@@ -614,32 +609,208 @@ __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_schur(BaDev D, int m
     }
 }
 
-// Sum of the per-workgroup partial systems (grid-parallel, coalesced over entries).  This is the
-// buffer the landmark-sharded multi-GPU path all-reduces (RCCL) before k_ba_solve.
+// Sum of the per-workgroup partial systems.  This is the buffer the landmark-sharded multi-GPU path all-reduces (RCCL)
+// before the solve.  A workgroup owns 32 entries; 8 thread groups sum slices of the partials, the 8 slice sums are
+// then added in slice order through LDS - a fixed summation order, no atomics: the reduced system is bit-identical
+// from run to run.
 __global__ __launch_bounds__(256) void k_ba_reduce(BaDev D, int nPart) {
-    if (!ba_enter(D, BA_TRY, blockIdx.z)) return;
+    __shared__ double sSl[8][33];
+    if (!ba_enter(D, BA_TRY, blockIdx.y)) return;
     const int total = D.n * D.n + D.n;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
+    const int e = threadIdx.x & 31, y = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + e;
     const size_t stride = (size_t)total;
-    // blockIdx.y = slice of the partial systems; 4 independent accumulators keep the strided loads in flight
-    const int per = (nPart + gridDim.y - 1) / gridDim.y;
-    const int p0 = blockIdx.y * per, p1 = min(nPart, p0 + per);
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    int p = p0;
-    for (; p + 3 < p1; p += 4) {
-        s0 += D.Spart[(size_t)p * stride + i];
-        s1 += D.Spart[(size_t)(p + 1) * stride + i];
-        s2 += D.Spart[(size_t)(p + 2) * stride + i];
-        s3 += D.Spart[(size_t)(p + 3) * stride + i];
+    double s = 0;
+    if (i < total) {
+        const int per = (nPart + 7) / 8;
+        const int p0 = y * per, p1 = min(nPart, p0 + per);
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;      // 4 independent accumulators keep the strided loads in flight
+        int p = p0;
+        for (; p + 3 < p1; p += 4) {
+            s0 += D.Spart[(size_t)p * stride + i];
+            s1 += D.Spart[(size_t)(p + 1) * stride + i];
+            s2 += D.Spart[(size_t)(p + 2) * stride + i];
+            s3 += D.Spart[(size_t)(p + 3) * stride + i];
+        }
+        for (; p < p1; p++) s0 += D.Spart[(size_t)p * stride + i];
+        s = (s0 + s1) + (s2 + s3);
     }
-    for (; p < p1; p++) s0 += D.Spart[(size_t)p * stride + i];
-    double s = (s0 + s1) + (s2 + s3);
-    if (blockIdx.y == 0) {
-        s += D.Sedge[i];      // BetweenFactor blocks of this linearisation
-        if (D.specLin) D.Sedge2[i] = 0;    // the trial's speculative linearisation accumulates here
+    sSl[y][e] = s;
+    __syncthreads();
+    if (y == 0 && i < total) {
+        double t = D.Sedge[i];           // BetweenFactor blocks of this linearisation
+        for (int q = 0; q < 8; q++) t += sSl[q][e];
+        if (D.specLin) D.Sedge2[i] = 0;  // the trial's speculative linearisation accumulates here
+        if (i < D.n * D.n) D.S[i] = t; else D.rhs[i - D.n * D.n] = t;
     }
-    if (i < D.n * D.n) atomicAdd(&D.S[i], s); else atomicAdd(&D.rhs[i - D.n * D.n], s);
+}
+
+// ---- windowed Schur accumulation (more free keyframes than one LDS copy of the reduced system holds) ---------------
+// The reduced camera system is tiled into WINDOWS of TB x TB keyframe blocks (upper block triangle, a <= b); a
+// workgroup owns one window and a slice of the landmarks that touch it (host-built work lists: a landmark observed
+// by free keyframes of block rows {a, b, ...} is listed under every window (a, b) of that set).  The window - one copy
+// per lambda candidate - lives in LDS; a landmark adds the 6x6 blocks of its (slot, slot) pairs that fall inside
+// it.  Partial windows are written out once and summed in a fixed order by k_ba_reduce_win.  No fp64 global atomics.
+struct BaWin {
+    int TB, T, tileDoubles, nWin;          // T = 6 TB; tile = T x T (+ T right-hand-side entries on diagonal windows)
+    const int* winA; const int* winB;      // [nWin] block row / block column of a window
+    const int* winFirstWg;                 // [nWin + 1] first workgroup (= partial) of each window
+    const int* wgWin; const int* wgBegin; const int* wgEnd;   // [nWg] window and range of winLm of a workgroup
+    const int* winLm;                      // concatenated landmark lists (local landmark index lp)
+    double* part;                          // [nWg][NB][tileDoubles]
+    double* Wg; double* Hg;                // per slot entry: Hpl block (18), per landmark: Hll (6) | bl (3) - k_ba_lm_prep
+};
+
+// Landmark blocks of the current linearisation, once per trial round: a landmark that is seen from several block rows
+// sits in several windows' lists, which then only fetch the W blocks of their own rows / columns (144 B each) instead of
+// rebuilding everything from the landmark's factors.
+__global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_lm_prep(BaDev D, BaWin Wn, int maxSlots) {
+    extern __shared__ int smi[];
+    if (!ba_enter(D, BA_TRY, 0)) return;
+    constexpr int BA_LPL = 64;
+    const int lane = threadIdx.x & 63, unit = threadIdx.x >> 6, nu = blockDim.x >> 6;
+    int* sfi = smi + unit * maxSlots;
+    for (int lp = blockIdx.x * nu + unit; lp < D.Lp; lp += gridDim.x * nu) {
+        double h[9];
+        int ns = 0;
+        ba_lm_blocks<BA_LPL>(D, lp, true, Wn.Wg + (size_t)D.lpSlotStart[lp] * 18, sfi, h, ns);
+        if (lane < 9) {
+            double v = h[0];
+#pragma unroll
+            for (int k = 1; k < 9; k++) if (lane == k) v = h[k];
+            Wn.Hg[(size_t)lp * 9 + lane] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_schur_win(BaDev D, BaWin Wn, int maxSlots) {
+    extern __shared__ double sm[];
+    if (!ba_enter(D, BA_TRY, 0)) return;
+    const int nc = D.NB, T = Wn.T, tile = Wn.tileDoubles;
+    const int win = Wn.wgWin[blockIdx.x], wa = Wn.winA[win], wb = Wn.winB[win];
+    const int r0 = wa * Wn.TB, r1 = min(D.F, r0 + Wn.TB), c0 = wb * Wn.TB, c1 = min(D.F, c0 + Wn.TB);
+    const bool diag = wa == wb;
+    constexpr int BA_LPL = BA_LPL_SCHUR;
+    double* Sloc = sm;                                        // nc copies of the window
+    double* wbase = sm + (size_t)nc * tile;
+    const int lane = threadIdx.x & (BA_LPL - 1), unit = threadIdx.x / BA_LPL;
+    double* W = wbase + (size_t)unit * (2 * maxSlots * 18);
+    double* WH = W + maxSlots * 18;
+    const int nu = blockDim.x / BA_LPL, nt = blockDim.x;
+    int* sfi = (int*)(wbase + (size_t)nu * (2 * maxSlots * 18)) + unit * maxSlots;
+    for (int i = threadIdx.x; i < nc * tile; i += nt) Sloc[i] = 0;
+    __syncthreads();
+    const int i0 = Wn.wgBegin[blockIdx.x], i1 = Wn.wgEnd[blockIdx.x];
+    for (int idx = i0 + unit; idx < i1; idx += nu) {
+        const int lp = Wn.winLm[idx];
+        const int se0 = D.lpSlotStart[lp], ns = D.lpSlotStart[lp + 1] - se0 - 1;
+        for (int q = lane; q < ns; q += BA_LPL) sfi[q] = D.slotFi[se0 + q];
+        ba_wave_fence();
+        // slots (ascending free index) inside the window's row / column range
+        int sr0 = ns, sr1 = 0, sc0 = ns, sc1 = 0;
+        for (int q = 0; q < ns; q++) {
+            const int fi = sfi[q];
+            if (fi >= r0 && fi < r1) { sr0 = min(sr0, q); sr1 = q + 1; }
+            if (fi >= c0 && fi < c1) { sc0 = min(sc0, q); sc1 = q + 1; }
+        }
+        if (sr1 <= sr0 || sc1 <= sc0) continue;
+        double h[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) h[k] = Wn.Hg[(size_t)lp * 9 + k];
+        for (int e = lane; e < (sr1 - sr0) * 18; e += BA_LPL) W[sr0 * 18 + e] = Wn.Wg[(size_t)(se0 + sr0) * 18 + e];
+        if (!diag) for (int e = lane; e < (sc1 - sc0) * 18; e += BA_LPL) W[sc0 * 18 + e] = Wn.Wg[(size_t)(se0 + sc0) * 18 + e];
+        ba_wave_fence();
+        double lamk = D.lambda;
+        for (int k = 0; k < nc; k++, lamk *= 10.0) {
+            double* Sacc = Sloc + (size_t)k * tile;
+            double* racc = Sacc + (size_t)T * T;
+            double Hi[9];
+            ba_hll_inverse(h, lamk, Hi);
+            for (int e = lane; e < (sr1 - sr0) * 18; e += BA_LPL) {
+                const int q = sr0 * 18 + e, sidx = q / 18, ij = q - sidx * 18, i = ij / 3, j = ij - i * 3;
+                const double* w = W + sidx * 18 + i * 3;
+                WH[q] = w[0] * Hi[j] + w[1] * Hi[3 + j] + w[2] * Hi[6 + j];
+            }
+            ba_wave_fence();
+            for (int s1 = sr0; s1 < sr1; s1++) {
+                const int k1 = sfi[s1] - r0;
+                const int sb = max(s1, sc0);
+                const int cnt = (sc1 - sb) * 36;
+                for (int e = lane; e < cnt; e += BA_LPL) {
+                    const int s2 = sb + e / 36, ij = e % 36, i = ij / 6, j = ij - i * 6;
+                    const double* a = WH + s1 * 18 + i * 3;
+                    const double* bb = W + s2 * 18 + j * 3;
+                    const double val = a[0] * bb[0] + a[1] * bb[1] + a[2] * bb[2];
+                    atomicAdd(&Sacc[(size_t)(6 * k1 + i) * T + 6 * (sfi[s2] - c0) + j], -val);
+                }
+                if (diag && lane < 6) {
+                    const double* a = WH + s1 * 18 + lane * 3;
+                    atomicAdd(&racc[6 * k1 + lane], -(a[0] * h[6] + a[1] * h[7] + a[2] * h[8]));
+                }
+            }
+            ba_wave_fence();        // WH is rewritten for the next candidate
+        }
+        if (diag) {
+            // Hpp and bp from this landmark's observations of the window's free keyframes (the same for every candidate)
+            const int f0 = D.slotStart[D.lpSlotStart[lp] + sr0], f1 = D.slotStart[D.lpSlotStart[lp] + sr1];
+            for (int e = lane; e < (f1 - f0) * 27; e += BA_LPL) {
+                const int f = f0 + e / 27, q = e % 27;
+                const int fi = D.facFi[f] - r0;
+                const double* o = D.facJ + (size_t)f * 20;
+                size_t idx2;
+                double val;
+                if (q < 21) {
+                    int i = 0, rem = q;
+                    while (rem >= 6 - i) { rem -= 6 - i; i++; }
+                    const int j = i + rem;
+                    idx2 = (size_t)(6 * fi + i) * T + 6 * fi + j;
+                    val = o[2 + i] * o[2 + j] + o[8 + i] * o[8 + j];
+                } else {
+                    const int i = q - 21;
+                    idx2 = (size_t)T * T + 6 * fi + i;
+                    val = -(o[2 + i] * o[0] + o[8 + i] * o[1]);
+                }
+                for (int k = 0; k < nc; k++) atomicAdd(Sloc + (size_t)k * tile + idx2, val);
+            }
+        }
+        ba_wave_fence();            // W / sfi are rewritten for the next landmark
+    }
+    __syncthreads();
+    double* dst = Wn.part + (size_t)blockIdx.x * nc * tile;
+    for (int i = threadIdx.x; i < nc * tile; i += nt) dst[i] = Sloc[i];
+}
+
+// fixed-order sum of a window's partials into the reduced system (+ the BetweenFactor blocks of this linearisation);
+// grid (window, candidate).  Entries of the lower block triangle are never written nor read (the solvers mirror the upper one).
+__global__ __launch_bounds__(256) void k_ba_reduce_win(BaDev D, BaWin Wn) {
+    if (!ba_enter(D, BA_TRY, blockIdx.y)) return;
+    const int win = blockIdx.x, cand = blockIdx.y, nc = D.NB, T = Wn.T, tile = Wn.tileDoubles, n = D.n;
+    const int wa = Wn.winA[win], wb = Wn.winB[win];
+    const int g0 = Wn.winFirstWg[win], g1 = Wn.winFirstWg[win + 1];
+    const int rows = 6 * (min(D.F, (wa + 1) * Wn.TB) - wa * Wn.TB), cols = 6 * (min(D.F, (wb + 1) * Wn.TB) - wb * Wn.TB);
+    const int lim = wa == wb ? T * T + T : T * T;
+    for (int e = threadIdx.x; e < lim; e += 256) {
+        size_t dst;
+        if (e < T * T) {
+            const int r = e / T, c = e - r * T;
+            if (r >= rows || c >= cols) continue;
+            dst = (size_t)(6 * wa * Wn.TB + r) * n + 6 * wb * Wn.TB + c;
+        } else {
+            const int r = e - T * T;
+            if (r >= rows) continue;
+            dst = (size_t)n * n + 6 * wa * Wn.TB + r;
+        }
+        double s0 = 0, s1 = 0;
+        int g = g0;
+        for (; g + 1 < g1; g += 2) {
+            s0 += Wn.part[((size_t)g * nc + cand) * tile + e];
+            s1 += Wn.part[((size_t)(g + 1) * nc + cand) * tile + e];
+        }
+        if (g < g1) s0 += Wn.part[((size_t)g * nc + cand) * tile + e];
+        const double t = D.Sedge[dst] + (s0 + s1);
+        if (D.specLin) D.Sedge2[dst] = 0;
+        if (dst < (size_t)n * n) D.S[dst] = t; else D.rhs[dst - (size_t)n * n] = t;
+    }
 }
 
 // One workgroup of n threads (rounded up to whole waves): thread i owns row i.  Assembles the
@@ -1197,6 +1368,252 @@ __global__ __launch_bounds__(64) void k_ba_solve_mfma64(BaDev D) {
     if (lane == 0) D.flags[FLAG_FAIL + D.cand] = bad ? 1 : 0;
 }
 
+// ---- reduced camera systems of more than 256 unknowns (43..170 free keyframes; the 64-keyframe window = 384) ---------
+// Blocked left-looking Cholesky over 64-column blocks, ONE LAUNCH PER BLOCK COLUMN J (the dependency chain of the
+// factorisation is the launch order; inside a launch the row tiles are independent workgroups - no cross-workgroup
+// synchronisation, nothing to spin on).  Workgroup I >= J (4 waves):
+//   C  = A[I,J] - sum_{K<J} L[I,K] L[J,K]^T        64x64 tile in v_mfma_f64_16x16x4 accumulators (wave w: rows 16w..),
+//   Dg = A[J,J] - sum_{K<J} L[J,K] L[J,K]^T        the diagonal tile, recomputed by every workgroup (cheaper than a
+//                                                  second launch), factored L_JJ L_JJ^T in LDS / registers (16-column
+//                                                  panels: readlane Cholesky of the 16x16 block, row-per-thread
+//                                                  triangular solve, MFMA trailing update),
+//   L[I,J] = C L_JJ^-T                             per wave on its own 16 rows: 16-column blocks, MFMA updates in between.
+// The workgroup I == J also carries the forward substitution y_J = L_JJ^-1 (b_J - sum_K L[J,K] y_K).  L (N x N, N = n
+// rounded up to 64, identity padding) and y live in HBM / L2.  k_ba_chol_back then solves L^T x = y block by block in
+// one workgroup and retracts the trial poses.  (n = 384: 6 + 1 launches, ~0.15 ms, against 1.7 ms for the row-per-thread
+// kernel this replaces.)
+constexpr int CH_B = 64, CH_LD = 65, CH_PLD = 17;
+
+__global__ __launch_bounds__(256) void k_ba_chol_col(BaDev D, double* __restrict__ Lg, double* __restrict__ yG, int N, int J, int* __restrict__ failFlag) {
+    extern __shared__ double sm[];
+    double* sA = sm;                         // [64][65] L[I,K]; later the wave-private X rows of the triangular solve
+    double* sB = sA + CH_B * CH_LD;          // [64][65] L[J,K]; later L_JJ
+    double* sP = sB + CH_B * CH_LD;          // [64][17] current 16-column panel of the diagonal factorisation
+    double* sInv = sP + CH_B * CH_PLD;       // [64] 1 / L_JJ[k][k]
+    double* sT = sInv + CH_B;                // [64] forward-substitution right-hand side
+    double* sY = sT + CH_B;                  // [64] y_K of the current K block
+    __shared__ int sBad;
+    if (!ba_enter(D, BA_TRY, blockIdx.y)) return;
+    const double lambda = D.lambda;
+    const int n = D.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int I = J + (int)blockIdx.x;
+    const bool isDiag = blockIdx.x == 0;
+    Lg += (size_t)D.cand * N * N; yG += (size_t)D.cand * N;
+    if (tid == 0) sBad = 0;
+    // A(i, j) of the damped system (upper triangle of D.S valid), identity padding
+    auto Aij = [&](int i, int j) -> double {
+        if (i >= n || j >= n) return i == j ? 1.0 : 0.0;
+        return D.S[i <= j ? (size_t)i * n + j : (size_t)j * n + i] + (i == j ? lambda : 0.0);
+    };
+    ba_d4 accC[4], accD[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; cb++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int lr = 16 * wave + (lane >> 4) + 4 * r, lc = cb * 16 + (lane & 15);
+            accD[cb][r] = Aij(J * CH_B + lr, J * CH_B + lc);
+            accC[cb][r] = isDiag ? 0.0 : Aij(I * CH_B + lr, J * CH_B + lc);
+        }
+    double t = 0;
+    if (isDiag && tid < CH_B) t = (J * CH_B + tid) < n ? D.rhs[J * CH_B + tid] : 0.0;
+    for (int K = 0; K < J; K++) {
+        __syncthreads();
+        for (int e = tid; e < CH_B * CH_B; e += 256) {
+            const int r = e >> 6, c = e & 63;
+            sB[r * CH_LD + c] = Lg[(size_t)(J * CH_B + r) * N + K * CH_B + c];
+            if (!isDiag) sA[r * CH_LD + c] = Lg[(size_t)(I * CH_B + r) * N + K * CH_B + c];
+        }
+        if (isDiag && tid < CH_B) sY[tid] = yG[K * CH_B + tid];
+        __syncthreads();
+        const double* pd = sB + (16 * wave + (lane & 15)) * CH_LD + (lane >> 4);
+        const double* pa = sA + (16 * wave + (lane & 15)) * CH_LD + (lane >> 4);
+#pragma unroll
+        for (int cb = 0; cb < 4; cb++) {
+            const double* pb = sB + (cb * 16 + (lane & 15)) * CH_LD + (lane >> 4);
+#pragma unroll
+            for (int ks = 0; ks < 16; ks++) {
+                const double b = pb[4 * ks];
+                if (cb <= wave) accD[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pd[4 * ks], b, accD[cb], 0, 0, 0);
+                if (!isDiag) accC[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * ks], b, accC[cb], 0, 0, 0);
+            }
+        }
+        if (isDiag && tid < CH_B) {
+            const double* lr = sB + tid * CH_LD;
+            double a0 = 0, a1 = 0;
+#pragma unroll 8
+            for (int c = 0; c < CH_B; c += 2) { a0 += lr[c] * sY[c]; a1 += lr[c + 1] * sY[c + 1]; }
+            t -= a0 + a1;
+        }
+    }
+    __syncthreads();
+    // ---- factor the diagonal tile: wave ib owns tile row ib (subtiles jb <= ib); L_JJ is assembled in sB ----------
+    for (int e = tid; e < CH_B * CH_LD; e += 256) sB[e] = 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++) {
+        if (wave >= kb) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) sP[(wave * 16 + (lane >> 4) + 4 * r) * CH_PLD + (lane & 15)] = accD[kb][r];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const int r = lane & 15;
+            double a[16];
+#pragma unroll
+            for (int c = 0; c < 16; c++) a[c] = sP[(kb * 16 + r) * CH_PLD + c];
+            bool bad = false;
+            double idg = 1.0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                double d = readlane_d(a[k], k);
+                if (!(d > 0)) { bad = true; d = 1.0; }
+                const double id = rsqrt(d);
+                const double lk = (r == k) ? d * id : a[k] * id;
+                if (r == k) idg = id;
+                a[k] = lk;
+#pragma unroll
+                for (int j = k + 1; j < 16; j++) a[j] = __builtin_fma(-lk, readlane_d(lk, j), a[j]);
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int c = 0; c < 16; c++) { sP[(kb * 16 + r) * CH_PLD + c] = a[c]; sB[(kb * 16 + r) * CH_LD + kb * 16 + c] = c <= r ? a[c] : 0.0; }
+                sInv[kb * 16 + r] = idg;
+            }
+            if (bad && lane == 0) sBad = 1;
+        }
+        __syncthreads();
+        {
+            const int row = (kb + 1) * 16 + tid;
+            if (row < CH_B) {
+                double x[16];
+#pragma unroll
+                for (int c = 0; c < 16; c++) {
+                    double v = sP[row * CH_PLD + c];
+#pragma unroll
+                    for (int m = 0; m < c; m++) v = __builtin_fma(-x[m], sP[(kb * 16 + c) * CH_PLD + m], v);
+                    x[c] = v * sInv[kb * 16 + c];
+                }
+#pragma unroll
+                for (int c = 0; c < 16; c++) { sP[row * CH_PLD + c] = x[c]; sB[row * CH_LD + kb * 16 + c] = x[c]; }
+            }
+        }
+        __syncthreads();
+        if (wave > kb) {
+            const double* pa = sP + (wave * 16 + (lane & 15)) * CH_PLD + (lane >> 4);
+#pragma unroll
+            for (int jb = 1; jb < 4; jb++) {
+                if (jb > kb && jb <= wave) {
+                    const double* pb = sP + (jb * 16 + (lane & 15)) * CH_PLD + (lane >> 4);
+#pragma unroll
+                    for (int ks = 0; ks < 4; ks++) accD[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * ks], pb[4 * ks], accD[jb], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (sBad) { if (tid == 0) atomicOr(failFlag + D.cand, 1); }
+    if (isDiag) {
+        for (int e = tid; e < CH_B * CH_B; e += 256) {
+            const int r = e >> 6, c = e & 63;
+            Lg[(size_t)(J * CH_B + r) * N + J * CH_B + c] = sB[r * CH_LD + c];
+        }
+        if (tid < CH_B) sT[tid] = t;
+        __syncthreads();
+        if (wave == 0) {          // y_J = L_JJ^-1 t : lane = row, columns in order
+            double b = sT[lane];
+            const double inv = sInv[lane];
+#pragma unroll 8
+            for (int k = 0; k < CH_B; k++) {
+                const double lik = sB[lane * CH_LD + k];
+                const double yk = readlane_d(b, k) * readlane_d(inv, k);
+                if (lane == k) b = yk; else if (lane > k) b = __builtin_fma(-lik, yk, b);
+            }
+            yG[J * CH_B + lane] = b;
+        }
+        return;
+    }
+    // ---- X = C L_JJ^-T on the wave's own 16 rows: 16-column blocks; no workgroup barrier (wave-ordered LDS traffic) ----
+    double* X = sA + (size_t)(16 * wave) * CH_LD;
+#pragma unroll
+    for (int cb = 0; cb < 4; cb++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) X[((lane >> 4) + 4 * r) * CH_LD + cb * 16 + (lane & 15)] = accC[cb][r];
+        ba_wave_fence();
+        if (lane < 16) {
+            double x[16];
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                double v = X[lane * CH_LD + cb * 16 + c];
+#pragma unroll
+                for (int m = 0; m < c; m++) v = __builtin_fma(-x[m], sB[(cb * 16 + c) * CH_LD + cb * 16 + m], v);
+                x[c] = v * sInv[cb * 16 + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 16; c++) X[lane * CH_LD + cb * 16 + c] = x[c];
+        }
+        ba_wave_fence();
+        const double* pa = X + (lane & 15) * CH_LD + cb * 16 + (lane >> 4);
+#pragma unroll
+        for (int c2 = 1; c2 < 4; c2++) {
+            if (c2 > cb) {
+                const double* pb = sB + (c2 * 16 + (lane & 15)) * CH_LD + cb * 16 + (lane >> 4);
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) accC[c2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * ks], pb[4 * ks], accC[c2], 0, 0, 0);
+            }
+        }
+    }
+    ba_wave_fence();
+    for (int e = lane; e < 16 * CH_B; e += 64) {
+        const int r = e >> 6, c = e & 63;
+        Lg[(size_t)(I * CH_B + 16 * wave + r) * N + J * CH_B + c] = X[r * CH_LD + c];
+    }
+}
+
+// L^T x = y, block columns in reverse, one workgroup per candidate; then the trial poses
+__global__ __launch_bounds__(256) void k_ba_chol_back(BaDev D, const double* __restrict__ Lg, const double* __restrict__ yG, int N, int* __restrict__ failFlag) {
+    extern __shared__ double sm[];
+    double* sL = sm;                 // [64][65] L_JJ
+    double* sX = sL + CH_B * CH_LD;  // [N] solution
+    double* sR = sX + N;             // [4][64] partial sums
+    if (!ba_enter(D, BA_TRY, blockIdx.x)) return;
+    const int n = D.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    Lg += (size_t)D.cand * N * N; yG += (size_t)D.cand * N;
+    const bool fail = failFlag[D.cand] != 0;
+    __syncthreads();
+    if (tid == 0) { D.flags[FLAG_FAIL + D.cand] = fail ? 1 : 0; failFlag[D.cand] = 0; }
+    if (fail) return;
+    const int NBk = N / CH_B;
+    for (int J = NBk - 1; J >= 0; J--) {
+        // t_j = y_J[j] - sum_{i >= (J+1) 64} L[i][J 64 + j] x[i] : thread (g, j) takes the rows i = g (mod 4)
+        double acc = 0;
+        for (int i = (J + 1) * CH_B + wave; i < N; i += 4) acc += Lg[(size_t)i * N + J * CH_B + lane] * sX[i];
+        sR[wave * CH_B + lane] = acc;
+        for (int e = tid; e < CH_B * CH_B; e += 256) {
+            const int r = e >> 6, c = e & 63;
+            sL[r * CH_LD + c] = Lg[(size_t)(J * CH_B + r) * N + J * CH_B + c];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            double b = yG[J * CH_B + lane] - ((sR[lane] + sR[CH_B + lane]) + (sR[2 * CH_B + lane] + sR[3 * CH_B + lane]));
+            const double inv = 1.0 / sL[lane * CH_LD + lane];
+#pragma unroll 8
+            for (int k = CH_B - 1; k >= 0; k--) {
+                const double lki = sL[k * CH_LD + lane];
+                const double xk = readlane_d(b, k) * readlane_d(inv, k);
+                if (lane == k) b = xk; else if (lane < k) b = __builtin_fma(-lki, xk, b);
+            }
+            sX[J * CH_B + lane] = b;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += 256) D.dP[i] = sX[i];
+    for (int k = tid; k < D.K; k += 256) {
+        const int fi = D.fidx[k];
+        if (fi >= 0) { DPose T; pose_retract(D.poseCur[k], sX + 6 * fi, T); D.poseTrial[k] = T; }
+        else D.poseTrial[k] = D.poseCur[k];
+    }
+}
+
 // back-substitution: dl = Hll^-1 (bl - sum_k W_k^T dp_k); trial landmark = cur + dl.  One wave per landmark;
 // allCand: the wave serves every lambda candidate from one build of Hll / bl / W (grid y = 1), else grid y = candidate.
 __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_back(BaDev D, int maxSlots, int allCand) {
@@ -1432,7 +1849,8 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         int device = -1;
         DevBuf<DPose> d_pose0, d_poseS;
         DevBuf<double> d_lm0, d_lmS, d_facJ, d_S, d_Spart, d_Sedge, d_dP, d_dL, d_lmDiff, d_sums, d_partial, d_Lg;
-        DevBuf<int> d_flags, d_pairKf, d_pairLm, d_pairOct;
+        DevBuf<int> d_flags, d_pairKf, d_pairLm, d_pairOct, d_win, d_cholFail;
+        DevBuf<double> d_cholY, d_winW, d_winH;
         DevBuf<uint8_t> d_pairFlags, d_kfLocal, d_wrong;
         DevBuf<float> d_pairUv;
         PinnedArena arena;
@@ -1447,7 +1865,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
             if (stream) { hipStreamSynchronize(stream); hipStreamDestroy(stream); }
             for (void* p : {(void*)d_pose0.p, (void*)d_poseS.p, (void*)d_lm0.p, (void*)d_lmS.p, (void*)d_facJ.p, (void*)d_S.p, (void*)d_Spart.p,
                             (void*)d_Sedge.p, (void*)d_dP.p, (void*)d_dL.p, (void*)d_lmDiff.p, (void*)d_sums.p, (void*)d_partial.p, (void*)d_Lg.p,
-                            (void*)d_flags.p, (void*)d_pairKf.p, (void*)d_pairLm.p, (void*)d_pairOct.p, (void*)d_pairFlags.p,
+                            (void*)d_win.p, (void*)d_cholFail.p, (void*)d_cholY.p, (void*)d_winW.p, (void*)d_winH.p, (void*)d_flags.p, (void*)d_pairKf.p, (void*)d_pairLm.p, (void*)d_pairOct.p, (void*)d_pairFlags.p,
                             (void*)d_kfLocal.p, (void*)d_wrong.p, (void*)d_pairUv.p, (void*)arena.d})
                 if (p) hipFree(p);
             if (arena.h) hipHostFree(arena.h);
@@ -1477,7 +1895,9 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
     g_baTimer.multi = true;
     auto &d_pose0 = ws->d_pose0, &d_poseS = ws->d_poseS;
     auto &d_lm0 = ws->d_lm0, &d_lmS = ws->d_lmS, &d_facJ = ws->d_facJ, &d_S = ws->d_S, &d_Spart = ws->d_Spart,
-         &d_Sedge = ws->d_Sedge, &d_dP = ws->d_dP, &d_dL = ws->d_dL, &d_lmDiff = ws->d_lmDiff, &d_sums = ws->d_sums, &d_partial = ws->d_partial, &d_Lg = ws->d_Lg;
+         &d_Sedge = ws->d_Sedge, &d_dP = ws->d_dP, &d_dL = ws->d_dL, &d_lmDiff = ws->d_lmDiff, &d_sums = ws->d_sums, &d_partial = ws->d_partial, &d_Lg = ws->d_Lg,
+         &d_cholY = ws->d_cholY;
+    auto &d_win = ws->d_win, &d_cholFail = ws->d_cholFail;
     auto &d_flags = ws->d_flags, &d_pairKf = ws->d_pairKf, &d_pairLm = ws->d_pairLm, &d_pairOct = ws->d_pairOct;
     auto &d_pairFlags = ws->d_pairFlags, &d_kfLocal = ws->d_kfLocal, &d_wrong = ws->d_wrong;
     auto &d_pairUv = ws->d_pairUv;
@@ -1488,8 +1908,10 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
     static const int nbEnv = [] { const char* e = getenv("VSLAM_BA_LOOKAHEAD"); return e ? std::max(1, std::min((int)BA_MAX_NB, atoi(e))) : (int)BA_MAX_NB; }();
     static const bool specEnv = !getenv("VSLAM_BA_NO_SPECLIN");
     const int nbSet = g_baLookahead, specSet = g_baSpecLin;
-    const int NB = comm ? 1 : (nbSet > 0 ? std::min(nbSet, (int)BA_MAX_NB) : nbEnv), nSlots = NB + 1;
-    const bool specLin = !comm && (specSet >= 0 ? specSet != 0 : specEnv);
+    // (the landmark-sharded path runs the same scheme: every rank evaluates the same candidates, the NB partial systems
+    // travel in one all-reduce, the control step walks them identically on every rank)
+    const int NB = nbSet > 0 ? std::min(nbSet, (int)BA_MAX_NB) : nbEnv, nSlots = NB + 1;
+    const bool specLin = specSet >= 0 ? specSet != 0 : specEnv;
     VS_HIP(d_pose0.alloc(K)); VS_HIP(d_poseS.alloc((size_t)nSlots * K));
     VS_HIP(d_lm0.alloc((size_t)3 * L)); VS_HIP(d_lmS.alloc((size_t)nSlots * 3 * L));
     VS_HIP(hipMemcpyAsync(d_pose0.p, pose0.data(), K * sizeof(DPose), hipMemcpyHostToDevice, stream));
@@ -1697,15 +2119,95 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         int schurWaves = BA_SCHUR_WAVES;
         constexpr int SCHUR_LPW = 64 / BA_LPL_SCHUR, BACK_LPW = 64 / BA_LPL_BACK;      // landmarks per wave
         // (nw waves = nw * LPW landmark units per workgroup)
-        auto schur_lds = [&](int nw, int copies) { return (ldsS ? copies * sysDoubles * sizeof(double) : 0) + (size_t)nw * SCHUR_LPW * 2 * maxSlots * 18 * sizeof(double) + (size_t)nw * SCHUR_LPW * maxSlots * sizeof(int) + 16; };
+        auto stage_lds = [&](int nw) { return (size_t)nw * SCHUR_LPW * 2 * maxSlots * 18 * sizeof(double) + (size_t)nw * SCHUR_LPW * maxSlots * sizeof(int) + 16; };
+        auto schur_lds = [&](int nw, int copies) { return copies * sysDoubles * sizeof(double) + stage_lds(nw); };
         // one workgroup for all candidates (W blocks built once) when NB copies of the system fit LDS with >= 8 waves
         static const bool sharedEnv = !getenv("VSLAM_BA_NO_SHARED_W");
         int sharedW = 0;
-        if (NB > 1 && sharedEnv && true) {
-            for (int nw : {16, 12, 8, 6, 4})
-                if (schur_lds(nw, NB) <= 150 * 1024) { sharedW = 1; schurWaves = nw; break; }
+        BaWin Wn{};
+        int nWinWg = 0;
+        size_t schurLds = 0;
+        if (ldsS) {
+            if (NB > 1 && sharedEnv) {
+                for (int nw : {16, 12, 8, 6, 4})
+                    if (schur_lds(nw, NB) <= 150 * 1024) { sharedW = 1; schurWaves = nw; break; }
+            }
+            if (!sharedW) while (schurWaves > 2 && schur_lds(schurWaves, 1) > 150 * 1024) schurWaves /= 2;
+            schurLds = schur_lds(schurWaves, sharedW ? NB : 1);
+        } else if (n > 0) {
+            // ---- windowed accumulation: tile size, work lists -------------------------------------------------
+            // TB keyframes per block row: the largest tile whose NB copies leave room for >= 8 waves of staging
+            int TB = 4;
+            for (int tb : {32, 24, 16, 12, 8, 6, 4}) {
+                const size_t tileB = ((size_t)36 * tb * tb + 6 * tb) * sizeof(double) * NB;
+                if (tileB + stage_lds(8) <= 150 * 1024) { TB = tb; break; }
+            }
+            if (const char* e = getenv("VSLAM_BA_WINDOW_TB")) TB = std::max(1, std::min(32, atoi(e)));
+            const int nBR = (F + TB - 1) / TB, nWin = nBR * (nBR + 1) / 2;
+            Wn.TB = TB; Wn.T = 6 * TB; Wn.tileDoubles = Wn.T * Wn.T + Wn.T; Wn.nWin = nWin;
+            schurWaves = BA_SCHUR_WAVES;
+            while (schurWaves > 2 && (size_t)Wn.tileDoubles * sizeof(double) * NB + stage_lds(schurWaves) > 150 * 1024) schurWaves /= 2;
+            schurLds = (size_t)Wn.tileDoubles * sizeof(double) * NB + stage_lds(schurWaves);
+            if (schurLds > 160 * 1024) { set_error("local BA: landmark with too many views for the LDS staging"); return VSLAM_ERR_CAPACITY; }
+            auto win_of = [nBR](int a, int b2) { return a * nBR - a * (a - 1) / 2 + (b2 - a); };     // a <= b2
+            std::vector<int> winA(nWin), winB(nWin), winCnt((size_t)nWin + 1, 0);
+            for (int a2 = 0; a2 < nBR; a2++) for (int b2 = a2; b2 < nBR; b2++) { winA[win_of(a2, b2)] = a2; winB[win_of(a2, b2)] = b2; }
+            // block rows touched by every landmark (its slots are sorted by free index)
+            std::vector<int> lmRows;                 // concatenated distinct block rows per landmark
+            std::vector<int> lmRowStart((size_t)Lp + 1, 0);
+            lmRows.reserve((size_t)Lp * 3);
+            for (int lp = 0; lp < Lp; lp++) {
+                lmRowStart[lp] = (int)lmRows.size();
+                int last = -1;
+                for (int se = h_lpSlotStart[lp]; se < h_lpSlotStart[lp + 1] - 1; se++) {
+                    const int br = h_slotFi[se] / TB;
+                    if (br != last) { lmRows.push_back(br); last = br; }
+                }
+            }
+            lmRowStart[Lp] = (int)lmRows.size();
+            for (int lp = 0; lp < Lp; lp++)
+                for (int i = lmRowStart[lp]; i < lmRowStart[lp + 1]; i++)
+                    for (int j = i; j < lmRowStart[lp + 1]; j++) winCnt[win_of(lmRows[i], lmRows[j]) + 1]++;
+            for (int w = 0; w < nWin; w++) winCnt[w + 1] += winCnt[w];
+            const int total = winCnt[nWin];
+            std::vector<int> winLm((size_t)std::max(total, 1)), fill(winCnt.begin(), winCnt.end() - 1);
+            for (int lp = 0; lp < Lp; lp++)
+                for (int i = lmRowStart[lp]; i < lmRowStart[lp + 1]; i++)
+                    for (int j = i; j < lmRowStart[lp + 1]; j++) winLm[fill[win_of(lmRows[i], lmRows[j])]++] = lp;
+            // workgroups: a window's list is cut into chunks of >= 4 landmarks per wave, ~2 workgroups per CU overall
+            const int chunk = std::max(4 * schurWaves, (total + 2 * nCU - 1) / (2 * nCU));
+            std::vector<int> wgWin, wgBegin, wgEnd, winFirst((size_t)nWin + 1, 0);
+            for (int w = 0; w < nWin; w++) {
+                winFirst[w] = (int)wgWin.size();
+                for (int i0 = winCnt[w]; i0 < winCnt[w + 1]; i0 += chunk) { wgWin.push_back(w); wgBegin.push_back(i0); wgEnd.push_back(std::min(i0 + chunk, winCnt[w + 1])); }
+            }
+            winFirst[nWin] = (int)wgWin.size();
+            nWinWg = (int)wgWin.size();
+            // one device buffer: winA | winB | winFirst | wgWin | wgBegin | wgEnd | winLm
+            const size_t nInts = (size_t)2 * nWin + (nWin + 1) + (size_t)3 * std::max(nWinWg, 1) + std::max(total, 1);
+            std::vector<int> pack;
+            pack.reserve(nInts);
+            pack.insert(pack.end(), winA.begin(), winA.end()); pack.insert(pack.end(), winB.begin(), winB.end());
+            pack.insert(pack.end(), winFirst.begin(), winFirst.end());
+            const size_t oWg = pack.size();
+            pack.insert(pack.end(), wgWin.begin(), wgWin.end()); pack.resize(oWg + std::max(nWinWg, 1));
+            pack.insert(pack.end(), wgBegin.begin(), wgBegin.end()); pack.resize(oWg + 2 * (size_t)std::max(nWinWg, 1));
+            pack.insert(pack.end(), wgEnd.begin(), wgEnd.end()); pack.resize(oWg + 3 * (size_t)std::max(nWinWg, 1));
+            pack.insert(pack.end(), winLm.begin(), winLm.end());
+            VS_HIP(d_win.alloc(pack.size()));
+            VS_HIP(hipMemcpyAsync(d_win.p, pack.data(), pack.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+            VS_HIP(hipStreamSynchronize(stream));          // (pack is a local: the copy must have left it)
+            Wn.winA = d_win.p; Wn.winB = d_win.p + nWin; Wn.winFirstWg = d_win.p + 2 * nWin;
+            Wn.wgWin = d_win.p + oWg; Wn.wgBegin = Wn.wgWin + std::max(nWinWg, 1); Wn.wgEnd = Wn.wgBegin + std::max(nWinWg, 1);
+            Wn.winLm = Wn.wgEnd + std::max(nWinWg, 1);
+            VS_HIP(d_Spart.alloc((size_t)std::max(nWinWg, 1) * NB * Wn.tileDoubles));
+            Wn.part = d_Spart.p;
+            VS_HIP(ws->d_winW.alloc((size_t)std::max(nSlotEntries, 1) * 18)); VS_HIP(ws->d_winH.alloc((size_t)std::max(Lp, 1) * 9));
+            Wn.Wg = ws->d_winW.p; Wn.Hg = ws->d_winH.p;
+            VS_HIP(hipFuncSetAttribute((const void*)k_ba_schur_win, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurLds));
+            // the lower block triangle is never written (nor read by a solver): keep it at zero for the all-reduce
+            VS_HIP(hipMemsetAsync(d_S.p, 0, sysStride * NB * sizeof(double), stream));
         }
-        if (!sharedW) while (schurWaves > 2 && schur_lds(schurWaves, 1) > 150 * 1024) schurWaves /= 2;
         const int schurUnits = schurWaves * SCHUR_LPW;
         const int lmBlocks = std::max(1, std::min((Lp + schurUnits - 1) / schurUnits, nCU));
         int backWaves = BA_SCHUR_WAVES / BACK_LPW;
@@ -1716,9 +2218,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         VS_HIP(d_partial.alloc(D.partialStride * NB));
         D.partial = d_partial.p;
         D.spartStride = sysDoubles * lmBlocks;
-        if (ldsS) VS_HIP(d_Spart.alloc(D.spartStride * NB));
-        D.Spart = d_Spart.p;
-        const size_t schurLds = schur_lds(schurWaves, sharedW ? NB : 1);
+        if (ldsS) { VS_HIP(d_Spart.alloc(D.spartStride * NB)); D.Spart = d_Spart.p; }
         const size_t backLds = back_lds(backWaves);
         const int sharedBack = (NB > 1 && sharedEnv) ? 1 : 0;
         const int ldA = ((n + 31) / 32) * 32 + 1;     // row stride = 1 (mod 32) doubles: conflict-free row-per-lane access
@@ -1726,8 +2226,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         const bool solveLds = solveLdsBytes <= 150 * 1024;
         if (n > 1024) { set_error("local BA: more than 170 free keyframes is not supported"); return VSLAM_ERR_CAPACITY; }
         if (schurLds > 160 * 1024) { set_error("local BA: landmark with too many views for the LDS staging"); return VSLAM_ERR_CAPACITY; }
-        if (ldsS) VS_HIP(hipFuncSetAttribute((const void*)k_ba_schur<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurLds));
-        else VS_HIP(hipFuncSetAttribute((const void*)k_ba_schur<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurLds));
+        if (ldsS) VS_HIP(hipFuncSetAttribute((const void*)k_ba_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurLds));
         if (solveLds) VS_HIP(hipFuncSetAttribute((const void*)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solveLdsBytes));
         if (backLds > 48 * 1024) VS_HIP(hipFuncSetAttribute((const void*)k_ba_back, hipFuncAttributeMaxDynamicSharedMemorySize, (int)backLds));
         const size_t mfmaLds = ((size_t)BA_MFMA_N * BA_MFMA_LD + 16 + BA_MFMA_N) * sizeof(double);
@@ -1735,6 +2234,18 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         if (n > BA_WAVE_N && n <= BA_MFMA_N && useMfma) {
             VS_HIP(d_Lg.alloc((size_t)BA_MFMA_N * BA_MFMA_N * NB));
             VS_HIP(hipFuncSetAttribute((const void*)k_ba_solve_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfmaLds));
+        }
+        // larger systems: block-column MFMA Cholesky (k_ba_chol_col / k_ba_chol_back)
+        const bool useChol = n > BA_MFMA_N && useMfma;
+        const int cholN = vslam::align_up(std::max(n, 1), CH_B);
+        const size_t cholColLds = ((size_t)2 * CH_B * CH_LD + (size_t)CH_B * CH_PLD + 3 * CH_B) * sizeof(double);
+        const size_t cholBackLds = ((size_t)CH_B * CH_LD + cholN + 4 * CH_B) * sizeof(double);
+        if (useChol) {
+            VS_HIP(d_Lg.alloc((size_t)cholN * cholN * NB));
+            VS_HIP(d_cholY.alloc((size_t)cholN * NB));
+            if (!d_cholFail.p) { VS_HIP(d_cholFail.alloc(BA_MAX_NB)); VS_HIP(hipMemsetAsync(d_cholFail.p, 0, BA_MAX_NB * sizeof(int), stream)); }
+            VS_HIP(hipFuncSetAttribute((const void*)k_ba_chol_col, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cholColLds));
+            VS_HIP(hipFuncSetAttribute((const void*)k_ba_chol_back, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cholBackLds));
         }
         BHS("upload");
 
@@ -1757,20 +2268,29 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
             }
             t = g_baTimer.begin("ba_schur");
             if (n > 0) {
-                if (ldsS) hipLaunchKernelGGL(k_ba_schur<true>, dim3(lmBlocks, sharedW ? 1 : NB), dim3(64 * schurWaves), schurLds, stream, D, maxSlots, sharedW);
-                else {
-                    VS_HIP(hipMemsetAsync(d_S.p, 0, sysStride * NB * sizeof(double), stream));
-                    hipLaunchKernelGGL(k_ba_schur<false>, dim3(lmBlocks, sharedW ? 1 : NB), dim3(64 * schurWaves), schurLds, stream, D, maxSlots, sharedW);
+                if (ldsS) hipLaunchKernelGGL(k_ba_schur, dim3(lmBlocks, sharedW ? 1 : NB), dim3(64 * schurWaves), schurLds, stream, D, maxSlots, sharedW);
+                else if (nWinWg) {
+                    hipLaunchKernelGGL(k_ba_lm_prep, dim3(std::max(1, std::min((Lp + BA_SCHUR_WAVES - 1) / BA_SCHUR_WAVES, 4 * nCU))), dim3(64 * BA_SCHUR_WAVES),
+                                       (size_t)BA_SCHUR_WAVES * maxSlots * sizeof(int), stream, D, Wn, maxSlots);
+                    hipLaunchKernelGGL(k_ba_schur_win, dim3(nWinWg), dim3(64 * schurWaves), schurLds, stream, D, Wn, maxSlots);
                 }
             }
             g_baTimer.end(t);
             t = g_baTimer.begin("ba_solve");
-            if (n > 0) hipLaunchKernelGGL(k_ba_reduce, dim3(((int)sysDoubles + 255) / 256, ldsS ? 8 : 1, NB), dim3(256), 0, stream, D, ldsS ? lmBlocks : 0);   // + BetweenFactor blocks
-            if (comm && n > 0) { const int tc = g_baTimer.begin("ba_allreduce"); VS_CHECK(comm_allreduce(comm, d_S.p, (size_t)n * n + n, stream)); g_baTimer.end(tc); }
+            if (n > 0) {     // sum of the partial systems + BetweenFactor blocks
+                if (ldsS) hipLaunchKernelGGL(k_ba_reduce, dim3(((int)sysDoubles + 31) / 32, NB), dim3(256), 0, stream, D, lmBlocks);
+                else hipLaunchKernelGGL(k_ba_reduce_win, dim3(Wn.nWin, NB), dim3(256), 0, stream, D, Wn);
+            }
+            // the NB candidates' systems are contiguous (sysStride apart): one all-reduce for all of them
+            if (comm && n > 0) { const int tc = g_baTimer.begin("ba_allreduce"); VS_CHECK(comm_allreduce(comm, d_S.p, sysStride * (NB - 1) + (size_t)n * n + n, stream)); g_baTimer.end(tc); }
             if (n <= 64 && useMfma) hipLaunchKernelGGL(k_ba_solve_mfma64, dim3(NB), dim3(64), 0, stream, D);
             else if (n <= BA_WAVE_N) hipLaunchKernelGGL(k_ba_solve_wave, dim3(NB), dim3(64), 0, stream, D);
             else if (n <= BA_MFMA_N && useMfma) hipLaunchKernelGGL(k_ba_solve_mfma, dim3(NB), dim3(64 * BA_MFMA_NW), mfmaLds, stream, D, d_Lg.p);
-            else hipLaunchKernelGGL(k_ba_solve, dim3(NB), dim3(std::max(64, vslam::align_up(n, 64))),
+            else if (useChol) {
+                for (int J = 0; J < cholN / CH_B; J++)
+                    hipLaunchKernelGGL(k_ba_chol_col, dim3(cholN / CH_B - J, NB), dim3(256), cholColLds, stream, D, d_Lg.p, d_cholY.p, cholN, J, d_cholFail.p);
+                hipLaunchKernelGGL(k_ba_chol_back, dim3(NB), dim3(256), cholBackLds, stream, D, (const double*)d_Lg.p, (const double*)d_cholY.p, cholN, d_cholFail.p);
+            } else hipLaunchKernelGGL(k_ba_solve, dim3(NB), dim3(std::max(64, vslam::align_up(n, 64))),
                                     solveLds ? solveLdsBytes : 64, stream, D, solveLds ? 1 : 0, solveLds ? ldA : n);
             g_baTimer.end(t);
             t = g_baTimer.begin("ba_back");
@@ -1780,7 +2300,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
             hipLaunchKernelGGL(k_ba_factors<1>, dim3(facBlocks, NB), dim3(256), 0, stream, D, nObs, fuseCtl, relTol, absTol);
             g_baTimer.end(t);
             if (comm) {
-                const int tc = g_baTimer.begin("ba_allreduce"); VS_CHECK(comm_allreduce(comm, d_sums.p + SUMS_CAND, 2, stream)); g_baTimer.end(tc);
+                const int tc = g_baTimer.begin("ba_allreduce"); VS_CHECK(comm_allreduce(comm, d_sums.p + SUMS_CAND, (size_t)2 * NB, stream)); g_baTimer.end(tc);
                 hipLaunchKernelGGL(k_ba_ctl, dim3(1), dim3(256), 0, stream, D, 1, relTol, absTol);
             }
             VS_HIP(hipGetLastError());
@@ -1846,7 +2366,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
 
         // ---- second pass on the first pass's structure (single GPU): mask instead of rebuild ------------------
         static const bool maskEnv = !getenv("VSLAM_BA_NO_MASK");
-        if (pass == 0 && !comm && maskEnv && g_baMask) {
+        if (pass == 0 && maskEnv && g_baMask) {
             // membership / statistics of the second graph from the chi2 flags
             std::vector<uint8_t> kfP2(K, 0), lmP2(L, 0);
             long long NF2 = 0;
@@ -1855,13 +2375,13 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
                 const int fl = P->pair_flags[p] & 3;
                 if (!fl) continue;
                 kfP2[P->pair_kf[p]] = 1; lmP2[P->pair_lm[p]] = 1;
-                NF2 += (fl & 1) + (fl >> 1);
+                if (P->pair_lm[p] % world == rank) NF2 += (fl & 1) + (fl >> 1);      // (statistics are per shard, summed in run_lm)
             }
             bool same = true;
             for (int k = 0; k < K; k++) if (kfP2[k] != T.kfPresent[k]) { same = false; break; }
             if (same) {       // same keyframes => same free set, same BetweenFactor chain; landmarks may only drop out
                 long long Lp2 = 0, k2 = 0;
-                for (int l = 0; l < L; l++) Lp2 += lmP2[l];
+                for (int l = 0; l < L; l++) if (l % world == rank) Lp2 += lmP2[l];
                 for (int lp = 0; lp < Lp; lp++) {
                     int ns = 0, last = -2;
                     for (int f = h_lpStart[lp]; f < h_lpStart[lp + 1]; f++) {

@@ -254,6 +254,67 @@ def make_ba_problem(rig_name="euroc", n_local=10, n_fixed=4, n_lm=3000, seed=0xB
                 pair_flags=np.array(pf, np.uint8), pair_uv=np.array(puv, np.float32), pair_oct=np.array(poct, np.int32))
 
 
+def make_ba_problem_c5(n_lm=100000, n_local=62, n_fixed=2, seed=0xBA5E, max_views=12, rig_name="synthetic",
+                       pix_noise=0.5, pose_noise=(0.009, 0.02), point_noise=0.03, outlier_frac=0.02):
+    """The C5 global-BA problem of SURVEY section 8d at full size (64 keyframes on a circle of radius 5 m looking inward,
+    100 000 landmarks uniform in a 4 m cube, <= 12 views each, pixel noise 0.5 px x octave scale, pose noise 2 cm /
+    0.5 deg, point noise 3 cm): the same construction as make_ba_problem(circle=True), vectorised (own random
+    stream) so that 10^5 landmarks take seconds, not minutes."""
+    rig = RIGS[rig_name]
+    rng = np.random.Generator(np.random.PCG64(seed))
+    K = n_local + n_fixed
+    poses = np.zeros((K, 4, 4))
+    for k in range(K):
+        a = 2 * np.pi * k / K
+        c = np.array([5 * np.sin(a), 0.0, -5 * np.cos(a)])
+        z = -c / np.linalg.norm(c)
+        x = np.cross([0, 1.0, 0], z); x /= np.linalg.norm(x)
+        y = np.cross(z, x)
+        T = np.eye(4); T[:3, 0], T[:3, 1], T[:3, 2], T[:3, 3] = x, y, z, c
+        poses[k] = T
+    lm = rng.uniform(-2, 2, (n_lm, 3))
+    Tcw = np.linalg.inv(poses)
+    pk, pl, pf, puv, poct = [], [], [], [], []
+    scale = 1.2 ** np.arange(8)
+    step = 20000
+    for l0 in range(0, n_lm, step):
+        P = lm[l0:l0 + step]
+        q = np.einsum("kij,nj->nki", Tcw[:, :3, :3], P) + Tcw[None, :, :3, 3]          # (n, K, 3)
+        zc = q[..., 2]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            u = rig["fx"] * q[..., 0] / zc + rig["cx"]; v = rig["fy"] * q[..., 1] / zc + rig["cy"]
+            uR = rig["fx"] * (q[..., 0] - rig["bl"]) / zc + rig["cx"]
+        vis = (zc > 0.3) & (u >= 20) & (u < rig["w"] - 20) & (v >= 20) & (v < rig["h"] - 20) & (uR >= 20)
+        pri = rng.random(vis.shape)
+        pri[~vis] = 2.0
+        order = np.argsort(pri, axis=1)[:, :max_views]                                 # random subset of the visible views
+        take = np.take_along_axis(vis, order, 1)
+        li, ci = np.nonzero(take)
+        kk = order[li, ci]
+        zz = zc[li, kk]
+        oct_ = np.clip(np.round(np.log(np.maximum(zz, 1e-3) / 2.0) / np.log(1.2)), 0, 7).astype(np.int32)
+        sg = pix_noise * scale[oct_]
+        close = zz < 40 * rig["bl"]
+        kind = rng.random(len(li))
+        flags = np.where(kind < 0.07, 2, np.where(close, 3, 1)).astype(np.uint8)
+        nz = rng.normal(0, 1, (len(li), 4)) * sg[:, None]
+        outl = rng.random(len(li)) < outlier_frac
+        nz[outl] += rng.normal(0, 25, (int(outl.sum()), 4))
+        uv = np.stack([u[li, kk], v[li, kk], uR[li, kk], v[li, kk]], 1) + nz
+        pk.append(kk.astype(np.int32)); pl.append((li + l0).astype(np.int32)); pf.append(flags)
+        puv.append(uv.astype(np.float32)); poct.append(np.stack([oct_, oct_], 1))
+    kf_fixed = np.zeros(K, np.uint8); kf_fixed[n_local:] = 1
+    kf_local = np.ones(K, np.uint8); kf_local[n_local:] = 0
+    init_poses = poses.copy()
+    for k in range(n_local):
+        init_poses[k] = poses[k] @ _small_pose(rng, pose_noise[0], pose_noise[1])
+    init_lm = lm + rng.normal(0, point_noise, lm.shape)
+    kf_id = np.concatenate([np.arange(n_fixed, K), np.arange(0, n_fixed)]).astype(np.int64)
+    return dict(rig=rig, kf_pose=init_poses, kf_pose_true=poses, kf_id=kf_id, kf_fixed=kf_fixed, kf_local=kf_local,
+                lm=init_lm, lm_true=lm, pair_kf=np.concatenate(pk), pair_lm=np.concatenate(pl),
+                pair_flags=np.concatenate(pf), pair_uv=np.concatenate(puv), pair_oct=np.concatenate(poct).astype(np.int32))
+
+
 # T_bc1 of the EuRoC configs (config/config_MH_01.yaml T_bc1.data): body_P_sensor of the IMU factor
 T_BC1 = np.array([[0.0148655429818, -0.999880929698, 0.00414029679422, -0.0216401454975],
                   [0.999557249008, 0.0149672133247, 0.025715529948, -0.064676986768],

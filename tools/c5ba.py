@@ -2,10 +2,10 @@
 import sys, os, time
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "gtsam-vslam_amd"))
 import numpy as np, synth, vslam_capi as vc
-nlm = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+nlm = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 nloc = int(sys.argv[2]) if len(sys.argv) > 2 else 62
 t = time.perf_counter()
-prob = synth.make_ba_problem("synthetic", n_local=nloc, n_fixed=2, n_lm=nlm, seed=0xBA5E, circle=True, max_views=12)
+prob = synth.make_ba_problem_c5(n_lm=nlm, n_local=nloc, n_fixed=2)
 print("problem built in %.1f s: pairs %d" % (time.perf_counter() - t, len(prob["pair_kf"])))
 fe = vc.Extractor(752, 480, 1500)
 rig = synth.RIGS["synthetic"]
