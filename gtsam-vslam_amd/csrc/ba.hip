@@ -652,7 +652,8 @@ __global__ __launch_bounds__(256) void k_ba_reduce(BaDev D, int nPart) {
 // per lambda candidate - lives in LDS; a landmark adds the 6x6 blocks of its (slot, slot) pairs that fall inside
 // it.  Partial windows are written out once and summed in a fixed order by k_ba_reduce_win.  No fp64 global atomics.
 struct BaWin {
-    int TB, T, tileDoubles, nWin;          // T = 6 TB; tile = T x T (+ T right-hand-side entries on diagonal windows)
+    int TB, T, TP, tileDoubles, nWin;      // T = 6 TB; tile = T rows of pitch TP = T + 1 (rows 6 apart must not share an
+                                           // LDS bank pair) followed by T right-hand-side entries (diagonal windows)
     const int* winA; const int* winB;      // [nWin] block row / block column of a window
     const int* winFirstWg;                 // [nWin + 1] first workgroup (= partial) of each window
     const int* wgWin; const int* wgBegin; const int* wgEnd;   // [nWg] window and range of winLm of a workgroup
@@ -664,6 +665,7 @@ struct BaWin {
 // Landmark blocks of the current linearisation, once per trial round: a landmark that is seen from several block rows
 // sits in several windows' lists, which then only fetch the W blocks of their own rows / columns (144 B each) instead of
 // rebuilding everything from the landmark's factors.
+constexpr int BA_WIN_HG = 9 + 6 * BA_MAX_NB;      // doubles per landmark: Hll (6) | bl (3) | per candidate the 6 unique entries of (Hll + lambda I)^-1
 __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_lm_prep(BaDev D, BaWin Wn, int maxSlots) {
     extern __shared__ int smi[];
     if (!ba_enter(D, BA_TRY, 0)) return;
@@ -674,106 +676,119 @@ __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_lm_prep(BaDev D, BaW
         double h[9];
         int ns = 0;
         ba_lm_blocks<BA_LPL>(D, lp, true, Wn.Wg + (size_t)D.lpSlotStart[lp] * 18, sfi, h, ns);
+        double* Hl = Wn.Hg + (size_t)lp * BA_WIN_HG;
         if (lane < 9) {
             double v = h[0];
 #pragma unroll
             for (int k = 1; k < 9; k++) if (lane == k) v = h[k];
-            Wn.Hg[(size_t)lp * 9 + lane] = v;
+            Hl[lane] = v;
+        } else if (lane >= 16 && lane < 16 + D.NB) {        // (Hll + lambda_k I)^-1 of every candidate: 6 unique entries
+            double lamk = D.lambda;
+            for (int k = 16; k < lane; k++) lamk *= 10.0;
+            double Hi[9];
+            ba_hll_inverse(h, lamk, Hi);
+            double* o = Hl + 9 + 6 * (lane - 16);
+            o[0] = Hi[0]; o[1] = Hi[1]; o[2] = Hi[2]; o[3] = Hi[4]; o[4] = Hi[5]; o[5] = Hi[8];
         }
     }
 }
 
-__global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_schur_win(BaDev D, BaWin Wn, int maxSlots) {
+// Work decomposition: PAIR-parallel.  A wave takes 64 list entries at a time; every lane resolves one entry's slot
+// ranges (64 independent chains of dependent loads in flight), a wave-wide prefix sum of the pair counts flattens
+// (entry, pair) into one index space, and 6 lanes serve one pair (lane = row i of the 6x6 block: the W row of its own
+// slot, the 18 W entries of the partner slot and Hll | bl come straight from HBM / L2, 6 LDS atomics per candidate).
+// No staging, no per-landmark barriers or fences: the atomics are fire-and-forget until the final flush.
+constexpr int BA_WIN_META = 5 * 64 + 65;       // ints of LDS per wave: lp, seR, nR, seC, nC per entry + prefix
+__global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_schur_win(BaDev D, BaWin Wn) {
     extern __shared__ double sm[];
     if (!ba_enter(D, BA_TRY, 0)) return;
-    const int nc = D.NB, T = Wn.T, tile = Wn.tileDoubles;
+    const int nc = D.NB, T = Wn.T, TP = Wn.TP, tile = Wn.tileDoubles;
     const int win = Wn.wgWin[blockIdx.x], wa = Wn.winA[win], wb = Wn.winB[win];
     const int r0 = wa * Wn.TB, r1 = min(D.F, r0 + Wn.TB), c0 = wb * Wn.TB, c1 = min(D.F, c0 + Wn.TB);
     const bool diag = wa == wb;
-    constexpr int BA_LPL = BA_LPL_SCHUR;
     double* Sloc = sm;                                        // nc copies of the window
-    double* wbase = sm + (size_t)nc * tile;
-    const int lane = threadIdx.x & (BA_LPL - 1), unit = threadIdx.x / BA_LPL;
-    double* W = wbase + (size_t)unit * (2 * maxSlots * 18);
-    double* WH = W + maxSlots * 18;
-    const int nu = blockDim.x / BA_LPL, nt = blockDim.x;
-    int* sfi = (int*)(wbase + (size_t)nu * (2 * maxSlots * 18)) + unit * maxSlots;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6, nt = blockDim.x;
+    int* meta = (int*)(sm + (size_t)nc * tile) + wave * BA_WIN_META;
+    int* mLp = meta; int* mSeR = meta + 64; int* mNR = meta + 128; int* mSeC = meta + 192; int* mNC = meta + 256; int* pref = meta + 320;
     for (int i = threadIdx.x; i < nc * tile; i += nt) Sloc[i] = 0;
     __syncthreads();
     const int i0 = Wn.wgBegin[blockIdx.x], i1 = Wn.wgEnd[blockIdx.x];
-    for (int idx = i0 + unit; idx < i1; idx += nu) {
-        const int lp = Wn.winLm[idx];
-        const int se0 = D.lpSlotStart[lp], ns = D.lpSlotStart[lp + 1] - se0 - 1;
-        for (int q = lane; q < ns; q += BA_LPL) sfi[q] = D.slotFi[se0 + q];
-        ba_wave_fence();
-        // slots (ascending free index) inside the window's row / column range
-        int sr0 = ns, sr1 = 0, sc0 = ns, sc1 = 0;
-        for (int q = 0; q < ns; q++) {
-            const int fi = sfi[q];
-            if (fi >= r0 && fi < r1) { sr0 = min(sr0, q); sr1 = q + 1; }
-            if (fi >= c0 && fi < c1) { sc0 = min(sc0, q); sc1 = q + 1; }
-        }
-        if (sr1 <= sr0 || sc1 <= sc0) continue;
-        double h[9];
+    const int g = lane / 6, ri = lane - 6 * g;              // pair group of the lane (10 per pass), row of the 6x6 block
+    for (int base = i0 + wave * 64; base < i1; base += nw * 64) {
+        // ---- phase 1: lane = list entry ----------------------------------------------------------------
+        {
+            const int idx = base + lane;
+            const bool valid = idx < i1;
+            const int lp = valid ? Wn.winLm[idx] : 0;
+            const int se0 = valid ? D.lpSlotStart[lp] : 0;
+            const int ns = valid ? D.lpSlotStart[lp + 1] - se0 - 1 : 0;
+            int sr0 = ns, sr1 = 0, sc0 = ns, sc1 = 0;
+            for (int q = 0; q < ns; q++) {
+                const int fi = D.slotFi[se0 + q];
+                if (fi >= r0 && fi < r1) { sr0 = min(sr0, q); sr1 = q + 1; }
+                if (fi >= c0 && fi < c1) { sc0 = min(sc0, q); sc1 = q + 1; }
+            }
+            const int nr = max(sr1 - sr0, 0), ncs = max(sc1 - sc0, 0);
+            const int np = (nr > 0 && ncs > 0) ? (diag ? nr * (nr + 1) / 2 : nr * ncs) : 0;
+            int incl = np;
 #pragma unroll
-        for (int k = 0; k < 9; k++) h[k] = Wn.Hg[(size_t)lp * 9 + k];
-        for (int e = lane; e < (sr1 - sr0) * 18; e += BA_LPL) W[sr0 * 18 + e] = Wn.Wg[(size_t)(se0 + sr0) * 18 + e];
-        if (!diag) for (int e = lane; e < (sc1 - sc0) * 18; e += BA_LPL) W[sc0 * 18 + e] = Wn.Wg[(size_t)(se0 + sc0) * 18 + e];
+            for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+            mLp[lane] = lp; mSeR[lane] = se0 + sr0; mNR[lane] = nr; mSeC[lane] = se0 + sc0; mNC[lane] = ncs;
+            pref[lane] = incl - np;
+            if (lane == 63) pref[64] = incl;
+        }
         ba_wave_fence();
-        double lamk = D.lambda;
-        for (int k = 0; k < nc; k++, lamk *= 10.0) {
-            double* Sacc = Sloc + (size_t)k * tile;
-            double* racc = Sacc + (size_t)T * T;
-            double Hi[9];
-            ba_hll_inverse(h, lamk, Hi);
-            for (int e = lane; e < (sr1 - sr0) * 18; e += BA_LPL) {
-                const int q = sr0 * 18 + e, sidx = q / 18, ij = q - sidx * 18, i = ij / 3, j = ij - i * 3;
-                const double* w = W + sidx * 18 + i * 3;
-                WH[q] = w[0] * Hi[j] + w[1] * Hi[3 + j] + w[2] * Hi[6 + j];
+        const int P = pref[64];
+        // ---- phase 2: 6 lanes = one (slot, slot) pair ------------------------------------------------------
+        for (int pb = 0; pb < P; pb += 10) {
+            const int pi = pb + g;
+            if (g >= 10 || pi >= P) continue;
+            int lo = 0, hi = 64;
+#pragma unroll
+            for (int it = 0; it < 6; it++) { const int mid = (lo + hi) >> 1; if (pref[mid] <= pi) lo = mid; else hi = mid; }
+            int p = pi - pref[lo];
+            const int nR_ = mNR[lo], nC_ = mNC[lo], lp = mLp[lo];
+            int as = 0, bs;
+            if (diag) { while (p >= nR_ - as) { p -= nR_ - as; as++; } bs = as + p; }
+            else { as = p / nC_; bs = p - as * nC_; }
+            const int e1 = mSeR[lo] + as, e2 = mSeC[lo] + bs;
+            const int k1 = D.slotFi[e1] - r0, k2 = D.slotFi[e2] - c0;
+            const double* w1p = Wn.Wg + (size_t)e1 * 18 + ri * 3;
+            const double* w2p = Wn.Wg + (size_t)e2 * 18;
+            const double* hp = Wn.Hg + (size_t)lp * BA_WIN_HG;
+            const double w1[3] = {w1p[0], w1p[1], w1p[2]};
+            double w2[18];
+#pragma unroll
+            for (int q = 0; q < 18; q++) w2[q] = w2p[q];
+            const bool same = diag && e1 == e2;
+            const double bl[3] = {same ? hp[6] : 0.0, same ? hp[7] : 0.0, same ? hp[8] : 0.0};
+            for (int k = 0; k < nc; k++) {
+#pragma clang fp contract(fast)
+                double* Sacc = Sloc + (size_t)k * tile;
+                const double* hi = hp + 9 + 6 * k;         // (Hll + lambda_k I)^-1: xx xy xz yy yz zz
+                const double h0 = hi[0], h1 = hi[1], h2 = hi[2], h3 = hi[3], h4 = hi[4], h5 = hi[5];
+                const double wh[3] = {w1[0] * h0 + w1[1] * h1 + w1[2] * h2, w1[0] * h1 + w1[1] * h3 + w1[2] * h4,
+                                      w1[0] * h2 + w1[1] * h4 + w1[2] * h5};
+                double* row = Sacc + (size_t)(6 * k1 + ri) * TP + 6 * k2;
+#pragma unroll
+                for (int j = 0; j < 6; j++) atomicAdd(&row[j], -(wh[0] * w2[3 * j] + wh[1] * w2[3 * j + 1] + wh[2] * w2[3 * j + 2]));
+                if (same) atomicAdd(&Sacc[(size_t)T * TP + 6 * k1 + ri], -(wh[0] * bl[0] + wh[1] * bl[1] + wh[2] * bl[2]));
             }
-            ba_wave_fence();
-            for (int s1 = sr0; s1 < sr1; s1++) {
-                const int k1 = sfi[s1] - r0;
-                const int sb = max(s1, sc0);
-                const int cnt = (sc1 - sb) * 36;
-                for (int e = lane; e < cnt; e += BA_LPL) {
-                    const int s2 = sb + e / 36, ij = e % 36, i = ij / 6, j = ij - i * 6;
-                    const double* a = WH + s1 * 18 + i * 3;
-                    const double* bb = W + s2 * 18 + j * 3;
-                    const double val = a[0] * bb[0] + a[1] * bb[1] + a[2] * bb[2];
-                    atomicAdd(&Sacc[(size_t)(6 * k1 + i) * T + 6 * (sfi[s2] - c0) + j], -val);
+            if (same) {
+                // Hpp and bp of this slot's factors (the same for every candidate): row ri, columns >= ri
+                for (int f = D.slotStart[e1]; f < D.slotStart[e1 + 1]; f++) {
+                    const double* o = D.facJ + (size_t)f * 20;
+                    const double a0 = o[2 + ri], a1 = o[8 + ri];
+                    const double bp = -(a0 * o[0] + a1 * o[1]);
+                    for (int k = 0; k < nc; k++) {
+                        double* Sacc = Sloc + (size_t)k * tile;
+                        for (int j = ri; j < 6; j++) atomicAdd(&Sacc[(size_t)(6 * k1 + ri) * TP + 6 * k1 + j], a0 * o[2 + j] + a1 * o[8 + j]);
+                        atomicAdd(&Sacc[(size_t)T * TP + 6 * k1 + ri], bp);
+                    }
                 }
-                if (diag && lane < 6) {
-                    const double* a = WH + s1 * 18 + lane * 3;
-                    atomicAdd(&racc[6 * k1 + lane], -(a[0] * h[6] + a[1] * h[7] + a[2] * h[8]));
-                }
-            }
-            ba_wave_fence();        // WH is rewritten for the next candidate
-        }
-        if (diag) {
-            // Hpp and bp from this landmark's observations of the window's free keyframes (the same for every candidate)
-            const int f0 = D.slotStart[D.lpSlotStart[lp] + sr0], f1 = D.slotStart[D.lpSlotStart[lp] + sr1];
-            for (int e = lane; e < (f1 - f0) * 27; e += BA_LPL) {
-                const int f = f0 + e / 27, q = e % 27;
-                const int fi = D.facFi[f] - r0;
-                const double* o = D.facJ + (size_t)f * 20;
-                size_t idx2;
-                double val;
-                if (q < 21) {
-                    int i = 0, rem = q;
-                    while (rem >= 6 - i) { rem -= 6 - i; i++; }
-                    const int j = i + rem;
-                    idx2 = (size_t)(6 * fi + i) * T + 6 * fi + j;
-                    val = o[2 + i] * o[2 + j] + o[8 + i] * o[8 + j];
-                } else {
-                    const int i = q - 21;
-                    idx2 = (size_t)T * T + 6 * fi + i;
-                    val = -(o[2 + i] * o[0] + o[8 + i] * o[1]);
-                }
-                for (int k = 0; k < nc; k++) atomicAdd(Sloc + (size_t)k * tile + idx2, val);
             }
         }
-        ba_wave_fence();            // W / sfi are rewritten for the next landmark
+        ba_wave_fence();            // the entry table is rewritten for the next batch
     }
     __syncthreads();
     double* dst = Wn.part + (size_t)blockIdx.x * nc * tile;
@@ -784,19 +799,19 @@ __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_schur_win(BaDev D, B
 // grid (window, candidate).  Entries of the lower block triangle are never written nor read (the solvers mirror the upper one).
 __global__ __launch_bounds__(256) void k_ba_reduce_win(BaDev D, BaWin Wn) {
     if (!ba_enter(D, BA_TRY, blockIdx.y)) return;
-    const int win = blockIdx.x, cand = blockIdx.y, nc = D.NB, T = Wn.T, tile = Wn.tileDoubles, n = D.n;
+    const int win = blockIdx.x, cand = blockIdx.y, nc = D.NB, T = Wn.T, TP = Wn.TP, tile = Wn.tileDoubles, n = D.n;
     const int wa = Wn.winA[win], wb = Wn.winB[win];
     const int g0 = Wn.winFirstWg[win], g1 = Wn.winFirstWg[win + 1];
     const int rows = 6 * (min(D.F, (wa + 1) * Wn.TB) - wa * Wn.TB), cols = 6 * (min(D.F, (wb + 1) * Wn.TB) - wb * Wn.TB);
-    const int lim = wa == wb ? T * T + T : T * T;
+    const int lim = wa == wb ? T * TP + T : T * TP;
     for (int e = threadIdx.x; e < lim; e += 256) {
         size_t dst;
-        if (e < T * T) {
-            const int r = e / T, c = e - r * T;
+        if (e < T * TP) {
+            const int r = e / TP, c = e - r * TP;
             if (r >= rows || c >= cols) continue;
             dst = (size_t)(6 * wa * Wn.TB + r) * n + 6 * wb * Wn.TB + c;
         } else {
-            const int r = e - T * T;
+            const int r = e - T * TP;
             if (r >= rows) continue;
             dst = (size_t)n * n + 6 * wa * Wn.TB + r;
         }
@@ -2137,18 +2152,18 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         } else if (n > 0) {
             // ---- windowed accumulation: tile size, work lists -------------------------------------------------
             // TB keyframes per block row: the largest tile whose NB copies leave room for >= 8 waves of staging
+            const size_t metaB = (size_t)BA_SCHUR_WAVES * BA_WIN_META * sizeof(int) + 16;
             int TB = 4;
             for (int tb : {32, 24, 16, 12, 8, 6, 4}) {
-                const size_t tileB = ((size_t)36 * tb * tb + 6 * tb) * sizeof(double) * NB;
-                if (tileB + stage_lds(8) <= 150 * 1024) { TB = tb; break; }
+                const size_t tileB = ((size_t)6 * tb * (6 * tb + 1) + 6 * tb) * sizeof(double) * NB;
+                if (tileB + metaB <= 150 * 1024) { TB = tb; break; }
             }
             if (const char* e = getenv("VSLAM_BA_WINDOW_TB")) TB = std::max(1, std::min(32, atoi(e)));
             const int nBR = (F + TB - 1) / TB, nWin = nBR * (nBR + 1) / 2;
-            Wn.TB = TB; Wn.T = 6 * TB; Wn.tileDoubles = Wn.T * Wn.T + Wn.T; Wn.nWin = nWin;
+            Wn.TB = TB; Wn.T = 6 * TB; Wn.TP = Wn.T + 1; Wn.tileDoubles = Wn.T * Wn.TP + Wn.T; Wn.nWin = nWin;
             schurWaves = BA_SCHUR_WAVES;
-            while (schurWaves > 2 && (size_t)Wn.tileDoubles * sizeof(double) * NB + stage_lds(schurWaves) > 150 * 1024) schurWaves /= 2;
-            schurLds = (size_t)Wn.tileDoubles * sizeof(double) * NB + stage_lds(schurWaves);
-            if (schurLds > 160 * 1024) { set_error("local BA: landmark with too many views for the LDS staging"); return VSLAM_ERR_CAPACITY; }
+            schurLds = (size_t)Wn.tileDoubles * sizeof(double) * NB + metaB;
+            if (schurLds > 160 * 1024) { set_error("local BA: window tile does not fit LDS"); return VSLAM_ERR_CAPACITY; }
             auto win_of = [nBR](int a, int b2) { return a * nBR - a * (a - 1) / 2 + (b2 - a); };     // a <= b2
             std::vector<int> winA(nWin), winB(nWin), winCnt((size_t)nWin + 1, 0);
             for (int a2 = 0; a2 < nBR; a2++) for (int b2 = a2; b2 < nBR; b2++) { winA[win_of(a2, b2)] = a2; winB[win_of(a2, b2)] = b2; }
@@ -2174,8 +2189,8 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
             for (int lp = 0; lp < Lp; lp++)
                 for (int i = lmRowStart[lp]; i < lmRowStart[lp + 1]; i++)
                     for (int j = i; j < lmRowStart[lp + 1]; j++) winLm[fill[win_of(lmRows[i], lmRows[j])]++] = lp;
-            // workgroups: a window's list is cut into chunks of >= 4 landmarks per wave, ~2 workgroups per CU overall
-            const int chunk = std::max(4 * schurWaves, (total + 2 * nCU - 1) / (2 * nCU));
+            // workgroups: a window's list is cut into chunks of >= 256 entries, ~2 workgroups per CU overall
+            const int chunk = std::max(256, (total + 2 * nCU - 1) / (2 * nCU));
             std::vector<int> wgWin, wgBegin, wgEnd, winFirst((size_t)nWin + 1, 0);
             for (int w = 0; w < nWin; w++) {
                 winFirst[w] = (int)wgWin.size();
@@ -2202,7 +2217,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
             Wn.winLm = Wn.wgEnd + std::max(nWinWg, 1);
             VS_HIP(d_Spart.alloc((size_t)std::max(nWinWg, 1) * NB * Wn.tileDoubles));
             Wn.part = d_Spart.p;
-            VS_HIP(ws->d_winW.alloc((size_t)std::max(nSlotEntries, 1) * 18)); VS_HIP(ws->d_winH.alloc((size_t)std::max(Lp, 1) * 9));
+            VS_HIP(ws->d_winW.alloc((size_t)std::max(nSlotEntries, 1) * 18)); VS_HIP(ws->d_winH.alloc((size_t)std::max(Lp, 1) * BA_WIN_HG));
             Wn.Wg = ws->d_winW.p; Wn.Hg = ws->d_winH.p;
             VS_HIP(hipFuncSetAttribute((const void*)k_ba_schur_win, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurLds));
             // the lower block triangle is never written (nor read by a solver): keep it at zero for the all-reduce
@@ -2272,7 +2287,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
                 else if (nWinWg) {
                     hipLaunchKernelGGL(k_ba_lm_prep, dim3(std::max(1, std::min((Lp + BA_SCHUR_WAVES - 1) / BA_SCHUR_WAVES, 4 * nCU))), dim3(64 * BA_SCHUR_WAVES),
                                        (size_t)BA_SCHUR_WAVES * maxSlots * sizeof(int), stream, D, Wn, maxSlots);
-                    hipLaunchKernelGGL(k_ba_schur_win, dim3(nWinWg), dim3(64 * schurWaves), schurLds, stream, D, Wn, maxSlots);
+                    hipLaunchKernelGGL(k_ba_schur_win, dim3(nWinWg), dim3(64 * schurWaves), schurLds, stream, D, Wn);
                 }
             }
             g_baTimer.end(t);
