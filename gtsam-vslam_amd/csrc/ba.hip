@@ -69,6 +69,10 @@ struct BaDev {
     // With specLin every candidate also linearises at its trial values into its slot's facJ / edge buffers, so
     // an accepted step needs no linearisation launch of its own.
     int NB, specLin, cand;
+    // Large problems: the look-ahead is ADAPTIVE - a round evaluates only nAct candidates (control block, CI_NACT): one
+    // while steps are being accepted, all NB after a round that ended in rejections (a rejection chain is then walked in
+    // one round as before).  The sequential policy is replayed unchanged; candidates that are not evaluated cost nothing.
+    int adaptive, nAct;                  // nAct: set by ba_enter
     double lambda;                       // set by ba_enter: damping of this workgroup's candidate
     DPose* poseBase; double* lmBase; size_t lmStride;
     double* facJBase; size_t facJStride; double* SedgeBase; BaEdge* edgesBase;
@@ -81,7 +85,7 @@ struct BaDev {
 // buffers by `sel`.  The host enqueues a few speculative steps at a time and only reads the
 // block back to learn whether the pass has finished - no host round trip per lambda trial.
 enum { CTL_LAMBDA = 0, CTL_ERROR = 1, CTL_CUR = 2, CTL_INIT_ERR = 3, CTL_INTS = 8, CTL_DOUBLES = 16 };
-enum { CI_STATE = 0, CI_SEL = 1, CI_ITER = 2, CI_INNER = 3, CI_MAXIT = 4, CI_FIRST = 5 };
+enum { CI_STATE = 0, CI_SEL = 1, CI_ITER = 2, CI_INNER = 3, CI_MAXIT = 4, CI_FIRST = 5, CI_NACT = 6 };
 enum { BA_LINEARIZE = 0, BA_TRY = 1, BA_DONE = 2 };
 enum { BA_MAX_NB = 4, SUMS_CAND = 16, FLAG_COUNT = 1, FLAG_FAIL = 4 };   // sums[16 + 2c | 17 + 2c], flags[4 + c] per candidate
 __device__ __forceinline__ int ba_slot(int sel, int c, int NB) {
@@ -91,6 +95,8 @@ __device__ __forceinline__ int ba_slot(int sel, int c, int NB) {
 __device__ __forceinline__ bool ba_enter(BaDev& D, int state, int c = 0) {
     const int* ci = (const int*)(D.ctl + CTL_INTS);
     if (ci[CI_STATE] != state) return false;
+    D.nAct = ci[CI_NACT];
+    if (c >= D.nAct) return false;
     const int sel = ci[CI_SEL], ts = ba_slot(sel, c, D.NB);
     D.cand = c;
     D.poseCur = D.poseBase + (size_t)sel * D.K; D.poseTrial = D.poseBase + (size_t)ts * D.K;
@@ -274,7 +280,8 @@ __device__ __forceinline__ void ba_ctl(const BaDev& D, int mode, double relTol, 
     }
     if (ci[CI_STATE] != BA_TRY) return;
     // walk the candidates in the order the sequential policy would have tried them
-    for (int cand = 0; cand < D.NB; cand++) {
+    const int nAct = ci[CI_NACT];
+    for (int cand = 0; cand < nAct; cand++) {
         const double error = c[CTL_ERROR];
         double lambda = c[CTL_LAMBDA];
         bool stepOk = false, stop = false;
@@ -313,8 +320,10 @@ __device__ __forceinline__ void ba_ctl(const BaDev& D, int mode, double relTol, 
             c[CTL_CUR] = c[CTL_ERROR];
             ci[CI_STATE] = BA_TRY;
         }
+        ci[CI_NACT] = D.adaptive ? 1 : D.NB;
         return;
     }
+    ci[CI_NACT] = D.NB;          // every evaluated candidate was rejected: the chain continues with the full look-ahead
 }
 
 // The control step as its own launch: the multi-GPU path, where the cost sums are all-reduced between the
@@ -430,11 +439,12 @@ __global__ __launch_bounds__(256) void k_ba_factors(BaDev D, int obsBlocks, int 
     // the per-XCD L2), each publisher waits for its stores to complete before it bumps the arrival counter.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) sLast = (__hip_atomic_fetch_add(&D.flags[FLAG_COUNT], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)(gridDim.x * gridDim.y) - 1);
+    const int nCandRun = MODE == 0 ? 1 : D.nAct;        // (workgroups of candidates beyond nAct left at ba_enter)
+    if (tid == 0) sLast = (__hip_atomic_fetch_add(&D.flags[FLAG_COUNT], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x * nCandRun - 1);
     __syncthreads();
     if (!sLast) return;
     const int nPart = obsBlocks + D.NE;         // (edge partials follow the observation partials)
-    for (int c = 0; c < (int)gridDim.y; c++) {
+    for (int c = 0; c < nCandRun; c++) {
         const double* part = partialBase + (size_t)c * D.partialStride;
         double t[2] = {0, 0};
         for (int i = tid; i < nPart; i += 256) { t[0] += ba_collect(&part[2 * i]); t[1] += ba_collect(&part[2 * i + 1]); }
@@ -524,7 +534,7 @@ __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_schur(BaDev D, int m
     (void)SBase;
     const int c0 = sharedW ? 0 : (int)blockIdx.y;
     if (!ba_enter(D, BA_TRY, c0)) return;
-    const int nc = sharedW ? D.NB : 1;
+    const int nc = sharedW ? D.nAct : 1;
     const int n = D.n;
     const size_t sys = (size_t)n * n + n;
     constexpr int BA_LPL = BA_LPL_SCHUR;
@@ -682,7 +692,7 @@ __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_lm_prep(BaDev D, BaW
 #pragma unroll
             for (int k = 1; k < 9; k++) if (lane == k) v = h[k];
             Hl[lane] = v;
-        } else if (lane >= 16 && lane < 16 + D.NB) {        // (Hll + lambda_k I)^-1 of every candidate: 6 unique entries
+        } else if (lane >= 16 && lane < 16 + D.nAct) {        // (Hll + lambda_k I)^-1 of every candidate: 6 unique entries
             double lamk = D.lambda;
             for (int k = 16; k < lane; k++) lamk *= 10.0;
             double Hi[9];
@@ -702,7 +712,7 @@ constexpr int BA_WIN_META = 5 * 64 + 65;       // ints of LDS per wave: lp, seR,
 __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_schur_win(BaDev D, BaWin Wn) {
     extern __shared__ double sm[];
     if (!ba_enter(D, BA_TRY, 0)) return;
-    const int nc = D.NB, T = Wn.T, TP = Wn.TP, tile = Wn.tileDoubles;
+    const int nc = D.nAct, T = Wn.T, TP = Wn.TP, tile = Wn.tileDoubles;
     const int win = Wn.wgWin[blockIdx.x], wa = Wn.winA[win], wb = Wn.winB[win];
     const int r0 = wa * Wn.TB, r1 = min(D.F, r0 + Wn.TB), c0 = wb * Wn.TB, c1 = min(D.F, c0 + Wn.TB);
     const bool diag = wa == wb;
@@ -791,7 +801,7 @@ __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_schur_win(BaDev D, B
         ba_wave_fence();            // the entry table is rewritten for the next batch
     }
     __syncthreads();
-    double* dst = Wn.part + (size_t)blockIdx.x * nc * tile;
+    double* dst = Wn.part + (size_t)blockIdx.x * D.NB * tile;
     for (int i = threadIdx.x; i < nc * tile; i += nt) dst[i] = Sloc[i];
 }
 
@@ -1635,7 +1645,7 @@ __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_back(BaDev D, int ma
     extern __shared__ double sm[];
     const int c0 = allCand ? 0 : (int)blockIdx.y;
     if (!ba_enter(D, BA_TRY, c0)) return;
-    const int nc = allCand ? D.NB : 1;
+    const int nc = allCand ? D.nAct : 1;
     const int sel = ((const int*)(D.ctl + CTL_INTS))[CI_SEL];
     constexpr int BA_LPL = BA_LPL_BACK;
     const int lane = threadIdx.x & (BA_LPL - 1), unit = threadIdx.x / BA_LPL;
@@ -2091,11 +2101,15 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         }
         // ---- LM control block (GTSAM 4.2 policy; k_ba_ctl) ---------------------------------------------
         const double relTol = 1e-5, absTol = 1e-5;
+        // adaptive look-ahead for large problems (every candidate costs a full Schur / back-substitution / evaluation pass)
+        const int adaptEnv = [] { const char* e = getenv("VSLAM_BA_ADAPTIVE"); return e ? atoi(e) : -1; }();
+        const bool adaptive = NB > 1 && (adaptEnv >= 0 ? adaptEnv != 0 : NF > 200000);
         auto init_ctl = [&](int ps) {
             for (int i = 0; i < CTL_DOUBLES; i++) h_ctl[i] = 0;
             h_ctl[CTL_LAMBDA] = 1e-5;
             int* ci = (int*)(h_ctl + CTL_INTS);
             ci[CI_STATE] = BA_LINEARIZE; ci[CI_SEL] = 0; ci[CI_ITER] = 0; ci[CI_INNER] = 0; ci[CI_MAXIT] = ps == 0 ? 5 : 10; ci[CI_FIRST] = 1;
+            ci[CI_NACT] = adaptive ? 1 : NB;
         };
         init_ctl(pass);
         BHS("prep");
@@ -2123,7 +2137,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         D.S = d_S.p; D.rhs = d_S.p + (size_t)n * n; D.Sedge = d_Sedge.p; D.dP = d_dP.p; D.dL = d_dL.p; D.sums = d_sums.p; D.flags = d_flags.p;
         D.fx = P->rig.fx; D.fy = P->rig.fy; D.cx = P->rig.cx; D.cy = P->rig.cy; D.b = (double)P->rig.baseline;
         D.ctl = A.dev(h_ctl);
-        D.NB = NB; D.specLin = specLin ? 1 : 0;
+        D.NB = NB; D.specLin = specLin ? 1 : 0; D.adaptive = adaptive ? 1 : 0;
         D.poseBase = d_poseS.p; D.lmBase = d_lmS.p; D.lmStride = (size_t)3 * L;
         D.facJBase = d_facJ.p; D.facJStride = (size_t)20 * NF; D.SedgeBase = d_Sedge.p; D.edgesBase = A.dev(h_edges);
         D.sysStride = sysStride; D.dLStride = (size_t)3 * Lp;
@@ -2482,31 +2496,35 @@ vslam_status vslam_ba_refresh_depth(const vslam_rig* rig, int32_t n_kf, const do
     VS_HIP(hipSetDevice(device));
     std::vector<DPose> Tcw(n_kf);
     for (int k = 0; k < n_kf; k++) { DPose T; pose_from_rm16(kf_pose_wc + 16 * (size_t)k, T); pose_inverse(T, Tcw[k]); }
-    // one device allocation for all operands (released on every exit path)
-    struct Scoped { uint8_t* p = nullptr; ~Scoped() { if (p) hipFree(p); } } mem;
+    // one device block for all operands, from the calling thread's block cache (no hipMalloc / hipFree in the steady state)
+    DevPool* pool = thread_pool(device);
+    if (!pool) { set_error("no device pool"); return VSLAM_ERR_HIP; }
+    hipStream_t ps = pool->stream;
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
     const size_t oT = take(n_kf * sizeof(DPose)), oLm = take((size_t)3 * std::max(n_lm, 1) * sizeof(double)), oO = take(std::max(n_lm, 1)),
                  oKf = take(n_pairs * sizeof(int)), oL = take(n_pairs * sizeof(int)), oW = take(n_pairs), oCur = take(n_pairs * sizeof(float)),
                  oD = take(n_pairs * sizeof(float)), oC = take(n_pairs), oU = take(n_pairs);
-    VS_HIP(hipMalloc((void**)&mem.p, off));
-    VS_HIP(hipMemcpy(mem.p + oT, Tcw.data(), n_kf * sizeof(DPose), hipMemcpyHostToDevice));
+    PoolBuf<uint8_t> mem(pool);
+    VS_HIP(mem.alloc(off));
+    VS_HIP(hipMemcpyAsync(mem.p + oT, Tcw.data(), n_kf * sizeof(DPose), hipMemcpyHostToDevice, ps));
     if (n_lm) {
-        VS_HIP(hipMemcpy(mem.p + oLm, lm_xyz, (size_t)3 * n_lm * sizeof(double), hipMemcpyHostToDevice));
-        VS_HIP(hipMemcpy(mem.p + oO, lm_outlier, n_lm, hipMemcpyHostToDevice));
+        VS_HIP(hipMemcpyAsync(mem.p + oLm, lm_xyz, (size_t)3 * n_lm * sizeof(double), hipMemcpyHostToDevice, ps));
+        VS_HIP(hipMemcpyAsync(mem.p + oO, lm_outlier, n_lm, hipMemcpyHostToDevice, ps));
     }
-    VS_HIP(hipMemcpy(mem.p + oKf, pair_kf, n_pairs * sizeof(int), hipMemcpyHostToDevice));
-    VS_HIP(hipMemcpy(mem.p + oL, pair_lm, n_pairs * sizeof(int), hipMemcpyHostToDevice));
-    VS_HIP(hipMemcpy(mem.p + oW, pair_wrong, n_pairs, hipMemcpyHostToDevice));
-    VS_HIP(hipMemcpy(mem.p + oCur, cur_depth, n_pairs * sizeof(float), hipMemcpyHostToDevice));
+    VS_HIP(hipMemcpyAsync(mem.p + oKf, pair_kf, n_pairs * sizeof(int), hipMemcpyHostToDevice, ps));
+    VS_HIP(hipMemcpyAsync(mem.p + oL, pair_lm, n_pairs * sizeof(int), hipMemcpyHostToDevice, ps));
+    VS_HIP(hipMemcpyAsync(mem.p + oW, pair_wrong, n_pairs, hipMemcpyHostToDevice, ps));
+    VS_HIP(hipMemcpyAsync(mem.p + oCur, cur_depth, n_pairs * sizeof(float), hipMemcpyHostToDevice, ps));
     const float closeTh = rig->baseline * 40;
-    hipLaunchKernelGGL(k_ba_refresh_depth, dim3((n_pairs + 255) / 256), dim3(256), 0, nullptr, n_pairs, (const int*)(mem.p + oKf),
+    hipLaunchKernelGGL(k_ba_refresh_depth, dim3((n_pairs + 255) / 256), dim3(256), 0, ps, n_pairs, (const int*)(mem.p + oKf),
                        (const int*)(mem.p + oL), (const uint8_t*)(mem.p + oW), (const uint8_t*)(mem.p + oO), (const float*)(mem.p + oCur),
                        (const DPose*)(mem.p + oT), (const double*)(mem.p + oLm), closeTh, (float*)(mem.p + oD), mem.p + oC, mem.p + oU);
     VS_HIP(hipGetLastError());
-    VS_HIP(hipMemcpy(depth_out, mem.p + oD, n_pairs * sizeof(float), hipMemcpyDeviceToHost));
-    VS_HIP(hipMemcpy(close_out, mem.p + oC, n_pairs, hipMemcpyDeviceToHost));
-    VS_HIP(hipMemcpy(updated_out, mem.p + oU, n_pairs, hipMemcpyDeviceToHost));
+    VS_HIP(hipMemcpyAsync(depth_out, mem.p + oD, n_pairs * sizeof(float), hipMemcpyDeviceToHost, ps));
+    VS_HIP(hipMemcpyAsync(close_out, mem.p + oC, n_pairs, hipMemcpyDeviceToHost, ps));
+    VS_HIP(hipMemcpyAsync(updated_out, mem.p + oU, n_pairs, hipMemcpyDeviceToHost, ps));
+    VS_HIP(hipStreamSynchronize(ps));
     return VSLAM_OK;
 }
 

@@ -42,6 +42,66 @@ static inline int cv_ceil_d(double v) { int i = (int)v; return i + (i < v); }
 
 constexpr int MAX_LEVELS = 12;
 
+// Per host thread: a helper stream and a cache of device blocks for the keyframe-rate entry points (new points,
+// descriptor selection, depth refresh, keyframe pose update).  Blocks go back to the cache instead of hipFree, so the
+// steady state of a session makes no hipMalloc / hipFree / hipStreamCreate call (each of which synchronises the device
+// and would stall every other session sharing the GPU).
+struct DevPool {
+    struct Blk { void* p; size_t cap; bool used; };
+    std::vector<Blk> blks;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    void* get(size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        int best = -1;
+        for (size_t i = 0; i < blks.size(); i++)
+            if (!blks[i].used && blks[i].cap >= bytes && (best < 0 || blks[i].cap < blks[best].cap)) best = (int)i;
+        if (best >= 0) { blks[best].used = true; return blks[best].p; }
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes + bytes / 4) != hipSuccess) return nullptr;
+        blks.push_back({p, bytes + bytes / 4, true});
+        return p;
+    }
+    void put(void* p) { for (auto& b : blks) if (b.p == p) { b.used = false; return; } }
+    void release() {
+        if (device < 0 || hipSetDevice(device) != hipSuccess) return;
+        if (stream) { hipStreamSynchronize(stream); hipStreamDestroy(stream); stream = nullptr; }
+        for (auto& b : blks) hipFree(b.p);
+        blks.clear();
+    }
+    ~DevPool() { release(); }
+};
+// the calling thread's pool for `device` (switching devices releases the previous pool's blocks)
+inline DevPool* thread_pool(int device) {
+    static thread_local DevPool pool;
+    if (pool.device != device) {
+        pool.release();
+        pool.device = device;
+        if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&pool.stream, hipStreamNonBlocking) != hipSuccess) { pool.device = -1; return nullptr; }
+    }
+    return &pool;
+}
+// RAII device array drawn from the thread's pool
+template <class T>
+struct PoolBuf {
+    T* p = nullptr;
+    DevPool* pool = nullptr;
+    explicit PoolBuf(DevPool* pl = nullptr) : pool(pl) {}
+    PoolBuf(const PoolBuf&) = delete;
+    PoolBuf& operator=(const PoolBuf&) = delete;
+    ~PoolBuf() { if (p && pool) pool->put(p); }
+    hipError_t alloc(size_t n) {
+        if (p) { pool->put(p); p = nullptr; }
+        p = (T*)pool->get((n > 0 ? n : 1) * sizeof(T));
+        return p ? hipSuccess : hipErrorOutOfMemory;
+    }
+    hipError_t up(const T* h, size_t n) {
+        hipError_t e = alloc(n);
+        if (e != hipSuccess || !n) return e;
+        return hipMemcpyAsync(p, h, n * sizeof(T), hipMemcpyHostToDevice, pool->stream);
+    }
+};
+
 // Named per-stage device timers (HIP events on the object's stream).  In `multi` mode every
 // invocation gets its own event pair (pairs are pooled and reused after reset()); read-out sums by name.
 struct StageTimer {

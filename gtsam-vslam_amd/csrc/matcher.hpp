@@ -88,6 +88,10 @@ struct vslam_matcher {
     // next to stereo / projection matching, the pose solve waits for evImu (imu_join)
     hipStream_t imuStream = nullptr; hipEvent_t evImu = nullptr; bool imuPending = false;
     vslam_status imu_join();
+    vslam_status imu_rechain();      // bias of the solve just enqueued -> integration bias / b0 of the next one
+    hipEvent_t evSolve = nullptr;
+    int imuN = 0;                    // samples of the current bucket
+    double* imuBiasDev = nullptr;    // integration bias / b0 (view into d_imuBuf)
     vslam_status estimate_pose_imu(vslam_pose_problem* prob, const vslam_imu_input* imu, vslam_imu_output* out,
                                    int* nIn, int* nStereo, vslam_lm_report* rep, int monoOnly = 0);
     vslam_status imu_predict(const vslam_imu_input* imu, const double* predVelocity, double lastDt, double* T_wc_out, double* vel_out);
@@ -100,6 +104,7 @@ struct vslam_matcher {
     float* d_trMsd = nullptr;        // [N] MapPoint::maxScaleDist
     uint8_t* d_trOutlier = nullptr;  // [N] MapPoint::GetIsOutlier
     int* d_trAct = nullptr;          // [N] source index of each active map point of the current frame
+    uint8_t* d_trVisL = nullptr;     // [N] left-camera visibility under the predicted pose (MapPoint::inFrame after removeOutOfFrameMPs)
     int* d_trCount = nullptr;        // {trN, actN}
     int actN = 0;
     int trNub = 0;                   // host-side upper bound of trN (the real count stays on the device)

@@ -495,13 +495,10 @@ __global__ __launch_bounds__(256) void k_calc_descriptor(int nMp, const uint8_t*
 using namespace vslam;
 
 namespace {
-template <class T>
-struct Dev {
-    T* p = nullptr;
-    ~Dev() { if (p) hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T)); }
-    hipError_t up(const T* h, size_t n, hipStream_t s) { hipError_t e = alloc(n); if (e != hipSuccess || !n) return e; return hipMemcpyAsync(p, h, n * sizeof(T), hipMemcpyHostToDevice, s); }
-};
+// device arrays of these entry points come from the calling thread's block cache (common.hpp): no hipMalloc / hipFree /
+// stream creation in the steady state
+template <class T> using Dev = PoolBuf<T>;
+#define NP_POOL(var) DevPool* var = thread_pool(device); if (!var) { set_error("no device pool"); return VSLAM_ERR_HIP; }
 }  // namespace
 
 extern "C" vslam_status vslam_find_new_points(const vslam_new_points_problem* P, vslam_new_points_result* R, int32_t device) {
@@ -516,15 +513,16 @@ extern "C" vslam_status vslam_find_new_points(const vslam_new_points_problem* P,
     VS_HIP(hipSetDevice(device));
     const vslam_kf_view& K0 = P->kfs[0];
     if (K0.n_left > 0 && (!P->estimated_depth || !P->has_mp || !K0.right_idxs || !K0.unmatched_f)) { set_error("vslam_find_new_points: last keyframe arrays missing"); return VSLAM_ERR_INVALID; }
-    hipStream_t stream;
-    VS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    struct StreamGuard { hipStream_t s; ~StreamGuard() { hipStreamSynchronize(s); hipStreamDestroy(s); } } guard{stream};
+    NP_POOL(pool);
+    hipStream_t stream = pool->stream;
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { hipStreamSynchronize(s); } } guard{stream};   // before the blocks go back
     const int cap = std::max(K0.n_left, 1);
     NpArgs A{};
     A.nKf = P->n_kf;
-    std::vector<Dev<vslam_keypoint>> dKL(P->n_kf), dKR(P->n_kf);
-    std::vector<Dev<uint8_t>> dDL(P->n_kf), dDR(P->n_kf);
-    std::vector<Dev<int>> dRi(P->n_kf), dLi(P->n_kf), dUf(P->n_kf), dUfr(P->n_kf);
+    Dev<vslam_keypoint> dKL[NP_MAX_KF], dKR[NP_MAX_KF];
+    Dev<uint8_t> dDL[NP_MAX_KF], dDR[NP_MAX_KF];
+    Dev<int> dRi[NP_MAX_KF], dLi[NP_MAX_KF], dUf[NP_MAX_KF], dUfr[NP_MAX_KF];
+    for (int k = 0; k < NP_MAX_KF; k++) dKL[k].pool = dKR[k].pool = dDL[k].pool = dDR[k].pool = dRi[k].pool = dLi[k].pool = dUf[k].pool = dUfr[k].pool = pool;
     for (int k = 0; k < P->n_kf; k++) {
         const vslam_kf_view& V = P->kfs[k];
         if (V.n_left < 0 || V.n_right < 0 || !V.T_wc || (V.n_left > 0 && (!V.kps_l || !V.desc_l || !V.right_idxs || !V.unmatched_f)) ||
@@ -535,20 +533,20 @@ extern "C" vslam_status vslam_find_new_points(const vslam_new_points_problem* P,
         NpKf& D = A.kf[k];
         pose_from_rm16(V.T_wc, D.Twc);
         pose_inverse(D.Twc, D.Tcw);
-        VS_HIP(dKL[k].up(V.kps_l, V.n_left, stream)); VS_HIP(dKR[k].up(V.kps_r, V.n_right, stream));
-        VS_HIP(dDL[k].up(V.desc_l, (size_t)V.n_left * 32, stream)); VS_HIP(dDR[k].up(V.desc_r, (size_t)V.n_right * 32, stream));
-        VS_HIP(dRi[k].up(V.right_idxs, V.n_left, stream)); VS_HIP(dLi[k].up(V.left_idxs, V.n_right, stream));
-        VS_HIP(dUf[k].up(V.unmatched_f, V.n_left, stream)); VS_HIP(dUfr[k].up(V.unmatched_fr, V.n_right, stream));
+        VS_HIP(dKL[k].up(V.kps_l, V.n_left)); VS_HIP(dKR[k].up(V.kps_r, V.n_right));
+        VS_HIP(dDL[k].up(V.desc_l, (size_t)V.n_left * 32)); VS_HIP(dDR[k].up(V.desc_r, (size_t)V.n_right * 32));
+        VS_HIP(dRi[k].up(V.right_idxs, V.n_left)); VS_HIP(dLi[k].up(V.left_idxs, V.n_right));
+        VS_HIP(dUf[k].up(V.unmatched_f, V.n_left)); VS_HIP(dUfr[k].up(V.unmatched_fr, V.n_right));
         D.kpsL = dKL[k].p; D.kpsR = dKR[k].p; D.descL = dDL[k].p; D.descR = dDR[k].p;
         D.rightIdxs = dRi[k].p; D.leftIdxs = dLi[k].p; D.unF = dUf[k].p; D.unFR = dUfr[k].p;
         D.nL = V.n_left; D.nR = V.n_right;
         D.skip = (k > 0 && V.id == P->kfs[0].id) ? 1 : 0;
     }
-    Dev<float> dDepth; Dev<uint8_t> dHas, dMpDesc, dCdesc, dAcc; Dev<double> dMpXyz, dWpos, dXyz; Dev<int> dKey, dCount, dMatch, dNobs, dObs; Dev<float> dMds;
-    std::vector<uint8_t> zeroDesc;
-    VS_HIP(dDepth.up(P->estimated_depth, K0.n_left, stream)); VS_HIP(dHas.up(P->has_mp, K0.n_left, stream));
-    if (P->mp_xyz) VS_HIP(dMpXyz.up(P->mp_xyz, (size_t)3 * K0.n_left, stream)); else VS_HIP(dMpXyz.alloc((size_t)3 * cap));
-    if (P->mp_desc) VS_HIP(dMpDesc.up(P->mp_desc, (size_t)32 * K0.n_left, stream)); else VS_HIP(dMpDesc.alloc((size_t)32 * cap));
+    Dev<float> dDepth(pool), dMds(pool); Dev<uint8_t> dHas(pool), dMpDesc(pool), dCdesc(pool), dAcc(pool); Dev<double> dMpXyz(pool), dWpos(pool), dXyz(pool);
+    Dev<int> dKey(pool), dCount(pool), dMatch(pool), dNobs(pool), dObs(pool);
+    VS_HIP(dDepth.up(P->estimated_depth, K0.n_left)); VS_HIP(dHas.up(P->has_mp, K0.n_left));
+    if (P->mp_xyz) VS_HIP(dMpXyz.up(P->mp_xyz, (size_t)3 * K0.n_left)); else VS_HIP(dMpXyz.alloc((size_t)3 * cap));
+    if (P->mp_desc) VS_HIP(dMpDesc.up(P->mp_desc, (size_t)32 * K0.n_left)); else VS_HIP(dMpDesc.alloc((size_t)32 * cap));
     VS_HIP(dWpos.alloc((size_t)3 * cap)); VS_HIP(dKey.alloc((size_t)2 * cap)); VS_HIP(dMds.alloc(cap)); VS_HIP(dCdesc.alloc((size_t)32 * cap));
     VS_HIP(dCount.alloc(4)); VS_HIP(dMatch.alloc((size_t)cap * NP_MAX_KF * 2)); VS_HIP(dAcc.alloc(cap)); VS_HIP(dXyz.alloc((size_t)3 * cap));
     VS_HIP(dNobs.alloc(cap)); VS_HIP(dObs.alloc((size_t)cap * NP_MAX_KF * 3));
@@ -579,13 +577,14 @@ extern "C" vslam_status vslam_find_new_points(const vslam_new_points_problem* P,
     if (n > R->capacity) { set_error("vslam_find_new_points: result capacity %d < %d candidates", R->capacity, n); return VSLAM_ERR_CAPACITY; }
     if (n) {
         std::vector<int> key((size_t)2 * n);
-        VS_HIP(hipMemcpy(key.data(), dKey.p, key.size() * sizeof(int), hipMemcpyDeviceToHost));
-        for (int i = 0; i < n; i++) { R->cand_left[i] = key[2 * i]; R->cand_right[i] = key[2 * i + 1]; }
-        VS_HIP(hipMemcpy(R->accepted, dAcc.p, n, hipMemcpyDeviceToHost));
-        VS_HIP(hipMemcpy(R->xyz, dXyz.p, (size_t)3 * n * sizeof(double), hipMemcpyDeviceToHost));
-        VS_HIP(hipMemcpy(R->n_obs, dNobs.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+        VS_HIP(hipMemcpyAsync(key.data(), dKey.p, key.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
+        VS_HIP(hipMemcpyAsync(R->accepted, dAcc.p, n, hipMemcpyDeviceToHost, stream));
+        VS_HIP(hipMemcpyAsync(R->xyz, dXyz.p, (size_t)3 * n * sizeof(double), hipMemcpyDeviceToHost, stream));
+        VS_HIP(hipMemcpyAsync(R->n_obs, dNobs.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, stream));
         std::vector<int> obs((size_t)n * NP_MAX_KF * 3);
-        VS_HIP(hipMemcpy(obs.data(), dObs.p, obs.size() * sizeof(int), hipMemcpyDeviceToHost));
+        VS_HIP(hipMemcpyAsync(obs.data(), dObs.p, obs.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
+        VS_HIP(hipStreamSynchronize(stream));
+        for (int i = 0; i < n; i++) { R->cand_left[i] = key[2 * i]; R->cand_right[i] = key[2 * i + 1]; }
         for (int i = 0; i < n; i++)
             for (int e = 0; e < P->n_kf; e++)
                 for (int q = 0; q < 3; q++) R->obs[((size_t)i * P->n_kf + e) * 3 + q] = e < R->n_obs[i] ? obs[((size_t)i * NP_MAX_KF + e) * 3 + q] : -1;
@@ -603,12 +602,14 @@ extern "C" vslam_status vslam_calc_descriptors(const uint8_t* descs, const int32
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available (no CPU fallback)"); return VSLAM_ERR_NO_DEVICE; }
     if (device < 0 || device >= ndev) return VSLAM_ERR_INVALID;
     VS_HIP(hipSetDevice(device));
-    Dev<uint8_t> dD; Dev<int> dS, dB;
+    NP_POOL(pool);
+    Dev<uint8_t> dD(pool); Dev<int> dS(pool), dB(pool);
     const size_t total = (size_t)start[n_mp];
-    VS_HIP(dD.up(descs, total * 32, nullptr)); VS_HIP(dS.up(start, (size_t)n_mp + 1, nullptr)); VS_HIP(dB.alloc(n_mp));
-    hipLaunchKernelGGL(k_calc_descriptor, dim3((n_mp + 3) / 4), dim3(256), 0, nullptr, n_mp, dD.p, dS.p, dB.p);
+    VS_HIP(dD.up(descs, total * 32)); VS_HIP(dS.up(start, (size_t)n_mp + 1)); VS_HIP(dB.alloc(n_mp));
+    hipLaunchKernelGGL(k_calc_descriptor, dim3((n_mp + 3) / 4), dim3(256), 0, pool->stream, n_mp, dD.p, dS.p, dB.p);
     VS_HIP(hipGetLastError());
-    VS_HIP(hipMemcpy(best_out, dB.p, (size_t)n_mp * sizeof(int), hipMemcpyDeviceToHost));
+    VS_HIP(hipMemcpyAsync(best_out, dB.p, (size_t)n_mp * sizeof(int), hipMemcpyDeviceToHost, pool->stream));
+    VS_HIP(hipStreamSynchronize(pool->stream));
     return VSLAM_OK;
 }
 
@@ -637,21 +638,24 @@ extern "C" vslam_status vslam_mono_new_points(const vslam_mono_points_problem* P
     for (int k = 0; k < nK; k++) { pose_from_rm16(P->kf_pose_wc + 16 * (size_t)k, A.Twc[k]); pose_inverse(A.Twc[k], A.Tcw[k]); A.kfId[k] = P->kf_id[k]; }
     A.fx = P->rig.fx; A.fy = P->rig.fy; A.cx = P->rig.cx; A.cy = P->rig.cy;
     for (int l = 0; l < P->n_levels; l++) A.sigma[l] = P->sigma_factor[l];
-    Dev<int> dNv, dVk, dVo, dNo; Dev<float> dXy; Dev<uint8_t> dAcc, dKeep; Dev<double> dXyz;
-    VS_HIP(dNv.up(P->n_views, (size_t)nP, nullptr)); VS_HIP(dVk.up(P->view_kf, (size_t)nP * nK, nullptr));
-    VS_HIP(dVo.up(P->view_octave, (size_t)nP * nK, nullptr)); VS_HIP(dXy.up(P->view_xy, (size_t)nP * nK * 2, nullptr));
+    NP_POOL(pool);
+    hipStream_t ps = pool->stream;
+    Dev<int> dNv(pool), dVk(pool), dVo(pool), dNo(pool); Dev<float> dXy(pool); Dev<uint8_t> dAcc(pool), dKeep(pool); Dev<double> dXyz(pool);
+    VS_HIP(dNv.up(P->n_views, (size_t)nP)); VS_HIP(dVk.up(P->view_kf, (size_t)nP * nK));
+    VS_HIP(dVo.up(P->view_octave, (size_t)nP * nK)); VS_HIP(dXy.up(P->view_xy, (size_t)nP * nK * 2));
     VS_HIP(dAcc.alloc(nP)); VS_HIP(dKeep.alloc((size_t)nP * nK)); VS_HIP(dXyz.alloc((size_t)nP * 3)); VS_HIP(dNo.alloc(nP));
-    VS_HIP(hipMemset(dXyz.p, 0, (size_t)nP * 3 * sizeof(double)));
+    VS_HIP(hipMemsetAsync(dXyz.p, 0, (size_t)nP * 3 * sizeof(double), ps));
     A.nViews = dNv.p; A.viewKf = dVk.p; A.viewXy = dXy.p; A.viewOct = dVo.p;
     A.accepted = dAcc.p; A.xyz = dXyz.p; A.nObs = dNo.p; A.keep = dKeep.p;
     const size_t lds = (size_t)2 * nK * 4 * 64 * sizeof(double);
     VS_HIP(hipFuncSetAttribute((const void*)k_np_mono_points, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_np_mono_points, dim3((nP + 63) / 64), dim3(64), lds, nullptr, A);
+    hipLaunchKernelGGL(k_np_mono_points, dim3((nP + 63) / 64), dim3(64), lds, ps, A);
     VS_HIP(hipGetLastError());
-    VS_HIP(hipMemcpy(R->accepted, dAcc.p, nP, hipMemcpyDeviceToHost));
-    VS_HIP(hipMemcpy(R->keep, dKeep.p, (size_t)nP * nK, hipMemcpyDeviceToHost));
-    VS_HIP(hipMemcpy(R->xyz, dXyz.p, (size_t)nP * 3 * sizeof(double), hipMemcpyDeviceToHost));
-    VS_HIP(hipMemcpy(R->n_obs, dNo.p, (size_t)nP * sizeof(int), hipMemcpyDeviceToHost));
+    VS_HIP(hipMemcpyAsync(R->accepted, dAcc.p, nP, hipMemcpyDeviceToHost, ps));
+    VS_HIP(hipMemcpyAsync(R->keep, dKeep.p, (size_t)nP * nK, hipMemcpyDeviceToHost, ps));
+    VS_HIP(hipMemcpyAsync(R->xyz, dXyz.p, (size_t)nP * 3 * sizeof(double), hipMemcpyDeviceToHost, ps));
+    VS_HIP(hipMemcpyAsync(R->n_obs, dNo.p, (size_t)nP * sizeof(int), hipMemcpyDeviceToHost, ps));
+    VS_HIP(hipStreamSynchronize(ps));
     return VSLAM_OK;
 }
 
@@ -682,19 +686,22 @@ extern "C" vslam_status vslam_keyframe_update_pose(const vslam_kf_update_problem
     A.fx = P->rig.fx; A.fy = P->rig.fy; A.cx = P->rig.cx; A.cy = P->rig.cy;
     for (int l = 0; l < P->n_levels; l++) A.invSigma[l] = P->inv_sigma_factor[l];
     if (A.nL + A.nR == 0) return VSLAM_OK;
-    Dev<vslam_keypoint> dKl, dKr; Dev<int> dSl, dSr; Dev<double> dLm; Dev<long long> dKdx; Dev<uint8_t> dOut, dDl, dDr;
-    VS_HIP(dKl.up(P->kps_left, (size_t)A.nL, nullptr)); VS_HIP(dKr.up(P->kps_right, (size_t)A.nR, nullptr));
-    VS_HIP(dSl.up(P->slot_lm_l, (size_t)A.nL, nullptr)); VS_HIP(dSr.up(P->slot_lm_r, (size_t)A.nR, nullptr));
-    VS_HIP(dLm.up(P->lm_xyz, (size_t)3 * P->n_lm, nullptr));
+    NP_POOL(pool);
+    hipStream_t ps = pool->stream;
+    Dev<vslam_keypoint> dKl(pool), dKr(pool); Dev<int> dSl(pool), dSr(pool); Dev<double> dLm(pool); Dev<long long> dKdx(pool); Dev<uint8_t> dOut(pool), dDl(pool), dDr(pool);
+    VS_HIP(dKl.up(P->kps_left, (size_t)A.nL)); VS_HIP(dKr.up(P->kps_right, (size_t)A.nR));
+    VS_HIP(dSl.up(P->slot_lm_l, (size_t)A.nL)); VS_HIP(dSr.up(P->slot_lm_r, (size_t)A.nR));
+    VS_HIP(dLm.up(P->lm_xyz, (size_t)3 * P->n_lm));
     std::vector<long long> kdx(P->lm_kdx, P->lm_kdx + P->n_lm);
-    VS_HIP(dKdx.up(kdx.data(), (size_t)P->n_lm, nullptr)); VS_HIP(dOut.up(P->lm_outlier, (size_t)P->n_lm, nullptr));
+    VS_HIP(dKdx.up(kdx.data(), (size_t)P->n_lm)); VS_HIP(dOut.up(P->lm_outlier, (size_t)P->n_lm));
     VS_HIP(dDl.alloc(std::max(A.nL, 1))); VS_HIP(dDr.alloc(std::max(A.nR, 1)));
     A.kpsL = dKl.p; A.kpsR = dKr.p; A.slotL = dSl.p; A.slotR = dSr.p; A.lm = dLm.p; A.kdx = dKdx.p; A.outlier = dOut.p;
     A.dropL = dDl.p; A.dropR = dDr.p;
-    hipLaunchKernelGGL(k_kf_update_pose, dim3((std::max(A.nL, A.nR) + 255) / 256, 2), dim3(256), 0, nullptr, A);
+    hipLaunchKernelGGL(k_kf_update_pose, dim3((std::max(A.nL, A.nR) + 255) / 256, 2), dim3(256), 0, ps, A);
     VS_HIP(hipGetLastError());
-    if (A.nL) VS_HIP(hipMemcpy(drop_l, dDl.p, A.nL, hipMemcpyDeviceToHost));
-    if (A.nR) VS_HIP(hipMemcpy(drop_r, dDr.p, A.nR, hipMemcpyDeviceToHost));
-    if (P->n_lm) VS_HIP(hipMemcpy(P->lm_xyz, dLm.p, (size_t)3 * P->n_lm * sizeof(double), hipMemcpyDeviceToHost));
+    if (A.nL) VS_HIP(hipMemcpyAsync(drop_l, dDl.p, A.nL, hipMemcpyDeviceToHost, ps));
+    if (A.nR) VS_HIP(hipMemcpyAsync(drop_r, dDr.p, A.nR, hipMemcpyDeviceToHost, ps));
+    if (P->n_lm) VS_HIP(hipMemcpyAsync(P->lm_xyz, dLm.p, (size_t)3 * P->n_lm * sizeof(double), hipMemcpyDeviceToHost, ps));
+    VS_HIP(hipStreamSynchronize(ps));
     return VSLAM_OK;
 }

@@ -91,7 +91,7 @@ struct ImuLmArgs {
     int ldsFactors;          // capacity (factors) of the dynamic LDS buffer
     const DPim* pim; const double* Lam;
     const DNav* pred;        // state predicted from (x0, v0, b0) by k_imu_preintegrate
-    double biasPrev[6];      // b0
+    const double* biasPrev;  // b0 (device: the integration bias of k_imu_preintegrate)
     double* io;              // out: vel(3), bias(6)
 };
 
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I
     __shared__ double red[(POSE_NT / 64) * 29];
     __shared__ double acc[29];
     __shared__ DPose sT, sT2, sPT, sTcw;
-    __shared__ double sV[3], sB[6], sV2[3], sB2[6], sPV[3];
+    __shared__ double sV[3], sB[6], sV2[3], sB2[6], sPV[3], sB0[6];      // sB0: b0 = the bias the bucket was integrated with
     __shared__ DNav sPred;
     __shared__ double sJ[225], sLJ[225], sH[225], sLam[225], sR15[15], sLr[15], sG[15], sDelta[15], sRp[6], sJp[36];
     __shared__ double sError, sLambda, sNewErr, sCurErr, sLin, sNV;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I
         sPred = *I.pred;                                         // prop_state: initial values, priors, factor prediction
         for (int i = 0; i < 9; i++) { sT.R[i] = sPred.R[i]; sPT.R[i] = sPred.R[i]; }
         for (int i = 0; i < 3; i++) { sT.t[i] = sPred.t[i]; sPT.t[i] = sPred.t[i]; sV[i] = sPred.v[i]; sPV[i] = sPred.v[i]; }
-        for (int i = 0; i < 6; i++) sB[i] = I.biasPrev[i];
+        for (int i = 0; i < 6; i++) { sB[i] = I.biasPrev[i]; sB0[i] = I.biasPrev[i]; }
         sLambda = 1e-5; sIter = 0; sInner = 0; sCnt[0] = sCnt[1] = 0;
     }
     __syncthreads();
@@ -247,13 +247,13 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I
                 for (int i = 0; i < 15; i++) s -= sJ[i * 15 + a] * sLr[i];
                 if (a < 6) { s += acc[21 + a]; for (int i = 0; i < 6; i++) s -= sJp[i * 6 + a] * sRp[i]; }
                 else if (a < 9) s -= sV[a - 6] - sPV[a - 6];
-                else s -= 1e6 * (sB[a - 9] - I.biasPrev[a - 9]);
+                else s -= 1e6 * (sB[a - 9] - sB0[a - 9]);
                 sG[a] = s;
             } else if (tid == 240 && sFirst) {
                 // error(x0) of the non-vision factors, term by term in the order of the trial evaluation (imu_error_head, prior, velocity)
                 double e = 0;
                 for (int i = 0; i < 15; i++) e += sR15[i] * sLr[i];
-                for (int i = 0; i < 6; i++) { const double rb = (sB[i] - I.biasPrev[i]) * 1e3; e += rb * rb; }
+                for (int i = 0; i < 6; i++) { const double rb = (sB[i] - sB0[i]) * 1e3; e += rb * rb; }
                 for (int i = 0; i < 6; i++) e += sRp[i] * sRp[i];
                 for (int i = 0; i < 3; i++) { const double rv = sV[i] - sPV[i]; e += rv * rv; }
                 sNV = e;
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I
         PS_ACC(6);
         __syncthreads();
         if (sEval) {
-            if (tid == TIMU) sNV = imu_error_head(&sPred, I.pim->biasHat, sLam, I.biasPrev, &sT2, sV2, sB2);   // wave 3 and
+            if (tid == TIMU) sNV = imu_error_head(&sPred, I.pim->biasHat, sLam, sB0, &sT2, sV2, sB2);   // wave 3 and
             else if (tid == TPRIOR) prior_residual_serial(&sT2, &sPT, sRpT);                                  // wave 2, under the vision pass
             double v1[1] = {vision_error(sT2)};
             block_reduce<1>(v1, red, acc);
@@ -407,6 +407,7 @@ vslam_status vslam_matcher::imu_setup(const vslam_imu_input* imu, double lastDt)
     double* d_samples = d_imuBuf;
     double* d_dts = d_samples + (size_t)6 * n;
     double* d_bias = d_dts + n;
+    imuBiasDev = d_bias; imuN = n;
     imuPim = (void*)(d_bias + 6);
     imuLam = (double*)imuPim + pimD;
     imuPred = imuLam + 225;
@@ -442,6 +443,36 @@ vslam_status vslam_matcher::imu_join() {
     return VSLAM_OK;
 }
 
+__global__ void k_imu_take_bias(const double* __restrict__ io, double* __restrict__ bias) {
+    if (threadIdx.x < 6) bias[threadIdx.x] = io[3 + threadIdx.x];
+}
+
+// After an IMU solve has been enqueued: its bias result (io[3..8], device) becomes the integration bias / b0 of the next
+// solve of this frame (reference: initialBias = result b1, src/FeatureTracker.cpp:405, and every estimatePoseGTSAM call
+// re-integrates the bucket with the current initialBias).  Runs on the side stream behind an event on the solve, so it
+// overlaps the matching pass that precedes the next solve; pose_imu_enqueue joins it.  x0 / v0 stay the frame's.
+vslam_status vslam_matcher::imu_rechain() {
+    if (!evSolve) VS_HIP(hipEventCreateWithFlags(&evSolve, hipEventDisableTiming));
+    static const bool sideOff = getenv("VSLAM_IMU_MAIN_STREAM") != nullptr;
+    hipStream_t is = (timer.enabled || sideOff) ? stream : imuStream;
+    if (is != stream) { VS_HIP(hipEventRecord(evSolve, stream)); VS_HIP(hipStreamWaitEvent(is, evSolve, 0)); }
+    DImuParams P;
+    memcpy(&P, imuParams, sizeof(P));
+    DNav si0;
+    for (int k = 0; k < 9; k++) si0.R[k] = imuSi[k];
+    for (int k = 0; k < 3; k++) { si0.t[k] = imuSi[9 + k]; si0.v[k] = imuSi[12 + k]; }
+    double* d_samples = d_imuBuf;
+    double* d_dts = d_samples + (size_t)6 * imuN;
+    hipLaunchKernelGGL(k_imu_take_bias, dim3(1), dim3(64), 0, is, (const double*)imuIo, imuBiasDev);
+    int t = timer.begin("imu_preintegrate");
+    hipLaunchKernelGGL(k_imu_preintegrate, dim3(1), dim3(256), 0, is, P, d_samples, d_dts, imuN, imuBiasDev, (DPim*)imuPim, imuLam, si0, (DNav*)imuPred);
+    timer.end(t);
+    VS_HIP(hipGetLastError());
+    imuPending = is != stream;
+    if (imuPending) VS_HIP(hipEventRecord(evImu, imuStream));
+    return VSLAM_OK;
+}
+
 // device-resident form of the IMU solve (inputs as for pose_enqueue, plus a completed imu_setup)
 vslam_status vslam_matcher::pose_imu_enqueue(int M, const int* Mdev, const int* gate, int gateMin, int outSlot, int monoOnly) {
     uint8_t* fl = d_flags;
@@ -459,7 +490,7 @@ vslam_status vslam_matcher::pose_imu_enqueue(int M, const int* Mdev, const int* 
     ImuLmArgs I{};
     I.pim = (const DPim*)imuPim; I.Lam = imuLam; I.io = imuIo;
     I.pred = (const DNav*)imuPred;
-    for (int k = 0; k < 6; k++) I.biasPrev[k] = imuBiasPrev[k];
+    I.biasPrev = imuBiasDev;
     VS_CHECK(imu_join());
     int t = timer.begin("pose_imu_lm");
 #ifdef VSLAM_POSE_STAMPS

@@ -451,6 +451,8 @@ void vslam_matcher::release() {
     if (h_imuStage) hipHostFree(h_imuStage);
     if (imuStream) { (void)hipStreamSynchronize(imuStream); (void)hipStreamDestroy(imuStream); }
     if (evImu) (void)hipEventDestroy(evImu);
+    if (evSolve) (void)hipEventDestroy(evSolve);
+    hipFree(d_trVisL);
     hipFree(d_mpv); hipFree(d_topk); hipFree(d_matches); hipFree(d_matchedL); hipFree(d_matchedR); hipFree(d_projOut);
     if (stream) hipStreamDestroy(stream);
     stream = nullptr;

@@ -97,7 +97,8 @@ __global__ __launch_bounds__(1024) void k_track_predict(int N, const double* __r
                                                         int* __restrict__ act, int* __restrict__ count,
                                                         int* __restrict__ matchedL, int nL,
                                                         int* __restrict__ matchedR, int nR,
-                                                        double* __restrict__ poseIO, int leftOnly) {
+                                                        double* __restrict__ poseIO, int leftOnly,
+                                                        uint8_t* __restrict__ visLeft) {
     __shared__ int wsum[16];
     int run = 0;
     N = min(N, count[0]);          // N is the host's upper bound; the map size stays on the device
@@ -116,6 +117,7 @@ __global__ __launch_bounds__(1024) void k_track_predict(int N, const double* __r
             l = world_to_frame(pc, false, G.fx, G.fy, G.cx, G.cy, G.b, G.w, G.h, msd[i], G.logScale, G.nLev);
             r = world_to_frame(pc, true, G.fx, G.fy, G.cx, G.cy, G.b, G.w, G.h, msd[i], G.logScale, G.nLev);
             keep = l.vis && (leftOnly || r.vis);     // removeOutOfFrameMPs / removeOutOfFrameMPsMono (:910-968)
+            if (visLeft) visLeft[i] = l.vis ? 1 : 0; // MapPoint::inFrame as worldToFrame(left) leaves it (read by localBA :566)
         }
         int tot;
         const int pos = run + block_excl_scan_1024(keep, wsum, tot);
@@ -196,15 +198,17 @@ using namespace vslam;
 vslam_status vslam_matcher::ensure_track_cap(int n) {
     if (n <= trCap && d_trCount) return VSLAM_OK;
     if (n > trCap) {
-        double* nx = nullptr; uint8_t* nd = nullptr; float* nm = nullptr; uint8_t* no = nullptr; int* na = nullptr;
+        double* nx = nullptr; uint8_t* nd = nullptr; float* nm = nullptr; uint8_t* no = nullptr; int* na = nullptr; uint8_t* nv = nullptr;
         const int cap = vslam::align_up(std::max(n, 1), 1024);
         VS_HIP(hipMalloc(&nx, (size_t)cap * 24));
         VS_HIP(hipMalloc(&nd, (size_t)cap * 32));
         VS_HIP(hipMalloc(&nm, (size_t)cap * 4));
         VS_HIP(hipMalloc(&no, (size_t)cap));
         VS_HIP(hipMalloc(&na, (size_t)cap * 4));
-        hipFree(d_trXyz); hipFree(d_trDesc); hipFree(d_trMsd); hipFree(d_trOutlier); hipFree(d_trAct);
-        d_trXyz = nx; d_trDesc = nd; d_trMsd = nm; d_trOutlier = no; d_trAct = na;
+        VS_HIP(hipMalloc(&nv, (size_t)cap));
+        VS_HIP(hipMemset(nv, 1, (size_t)cap));
+        hipFree(d_trXyz); hipFree(d_trDesc); hipFree(d_trMsd); hipFree(d_trOutlier); hipFree(d_trAct); hipFree(d_trVisL);
+        d_trXyz = nx; d_trDesc = nd; d_trMsd = nm; d_trOutlier = no; d_trAct = na; d_trVisL = nv;
         trCap = cap;
     }
     VS_CHECK(ensure_res());
@@ -264,12 +268,19 @@ vslam_status vslam_matcher::track_frame(const double* T_wc_pred, int frameNumber
     // when the first round fails (fewer than minInliers) does it step through the reference's retry rule.
     int t = timer.begin("track_predict");
     hipLaunchKernelGGL(k_track_predict, dim3(1), dim3(1024), 0, stream, trNub, d_trXyz, d_trDesc, d_trMsd, d_trOutlier, Tcw, G,
-                       d_mpv, d_points, fl, pc, d_matches, d_trAct, d_trCount, d_matchedL, nL, d_matchedR, nR, d_poseIO, 0);
+                       d_mpv, d_points, fl, pc, d_matches, d_trAct, d_trCount, d_matchedL, nL, d_matchedR, nR, d_poseIO, 0, d_trVisL);
     timer.end(t);
     VS_HIP(hipGetLastError());
 
     float rad = frameNumber == 1 ? 120.f : 10.f;
-    auto solve = [&](const int* g, int slot) { return imu ? pose_imu_enqueue(Nub, Mdev, g, minInliers, slot) : pose_enqueue(Nub, Mdev, g, minInliers, slot); };
+    // IMU mode: estimatePoseGTSAM stores initialBias = b1 after EVERY solve (src/FeatureTracker.cpp:405), so the next solve
+    // of the same frame integrates the bucket with, and pins b0 to, the bias the previous one found: imu_rechain()
+    // re-runs the pre-integration from the device-resident result (on the side stream, under the next matching pass)
+    auto solve = [&](const int* g, int slot, bool chain = true) -> vslam_status {
+        if (!imu) return pose_enqueue(Nub, Mdev, g, minInliers, slot);
+        VS_CHECK(pose_imu_enqueue(Nub, Mdev, g, minInliers, slot));
+        return chain ? imu_rechain() : VSLAM_OK;      // (the frame's last solve: nothing left to chain into)
+    };
     auto refine = [&](const int* g) -> vslam_status {
         // refine with the estimated pose (:1236-1241)
         int tt = timer.begin("track_repredict");
@@ -277,7 +288,7 @@ vslam_status vslam_matcher::track_frame(const double* T_wc_pred, int frameNumber
                            d_trMsd, d_trAct, d_poseIO, G, d_mpv, fl, pc, d_matches, d_matchedL, d_matchedR);
         timer.end(tt);
         VS_CHECK(proj_enqueue(Nub, 4.f, Mdev, g, minInliers));
-        VS_CHECK(solve(g, 1));
+        VS_CHECK(solve(g, 1, false));
         return VSLAM_OK;
     };
     auto fetch = [&]() -> vslam_status {
@@ -365,7 +376,7 @@ vslam_status vslam_matcher::track_frame_mono(const vslam_imu_input* imu, const d
     int* h_out = (int*)(h_res + 48);
     int* h_cnt = (int*)(h_res + 52);
     hipLaunchKernelGGL(k_track_predict, dim3(1), dim3(1024), 0, stream, trNub, d_trXyz, d_trDesc, d_trMsd, d_trOutlier, Tcw, G,
-                       d_mpv, d_points, fl, pc, d_matches, d_trAct, d_trCount, d_matchedL, nL, d_matchedR, 0, d_poseIO, 1);
+                       d_mpv, d_points, fl, pc, d_matches, d_trAct, d_trCount, d_matchedL, nL, d_matchedR, 0, d_poseIO, 1, d_trVisL);
     VS_HIP(hipGetLastError());
     float rad = 1200.f;                // :1398 overrides the 10 / 120 choice
     int nIn = -1, prevIn = -1, rounds = 0, lmIters = 0, M = 0;

@@ -181,13 +181,17 @@ def test_ba_lookahead_matches_sequential_trials(capi, oracle, kind):
     else:      # F > 20: windowed accumulation
         prob = synth.make_ba_problem("synthetic", n_local=28, n_fixed=2, n_lm=1500, seed=21, circle=True, max_views=10)
     ex = oracle.Extractor(1500)
+    import os
     outs = []
     try:
-        for nb, spec, mask in ((1, 0, 0), (4, 1, 1), (2, 0, 1), (3, 1, 0)):
+        # (adaptive = the large-problem mode: one candidate per round while steps are accepted, all after a rejection)
+        for nb, spec, mask, adaptive in ((1, 0, 0, 0), (4, 1, 1, 0), (2, 0, 1, 0), (3, 1, 0, 0), (4, 1, 1, 1), (3, 0, 0, 1)):
             capi.local_ba_set_lookahead(nb, spec, mask)
+            os.environ["VSLAM_BA_ADAPTIVE"] = str(adaptive)
             outs.append(capi.local_ba(prob["rig"], ex.sigmaFactor, ex.InvSigmaFactor, prob))
     finally:
         capi.local_ba_set_lookahead(0, -1, 1)
+        os.environ.pop("VSLAM_BA_ADAPTIVE", None)
     base = outs[0]
     assert base["reports"][0]["inner"] + base["reports"][1]["inner"] > 4
     for o in outs[1:]:

@@ -54,10 +54,13 @@ def oracle_track(oracle, rig, ex, keys, st, mp, T_wc_pred, frame_number, imu=Non
     rad = 120.0 if frame_number == 1 else 10.0
     nIn, prevIn, prevrad, toBreak, rounds, iters = -1, -1, rad, False, 0, 0
 
+    imu_state = list(imu) if imu is not None else None
+
     def solve(est, mt, outl, state):
         if imu is not None:     # IMU branch: the initial pose comes from the IMU prediction, `est` is ignored
             r = oracle.estimate_pose_imu(rig, ex.InvSigmaFactor, pts, mps["inFrame"], mps["inFrameR"], mpo, mt, outl, kL, kR,
-                                         state["rightIdxs"], state["leftIdxs"], state["depth"], state["close"], *imu)
+                                         state["rightIdxs"], state["leftIdxs"], state["depth"], state["close"], *imu_state)
+            imu_state[3] = r["bias"].copy()   # initialBias = b1 after every solve (src/FeatureTracker.cpp:405)
         else:
             r = oracle.estimate_pose(rig, ex.InvSigmaFactor, pts, mps["inFrame"], mps["inFrameR"], mpo, mt, outl, kL, kR,
                                      state["rightIdxs"], state["leftIdxs"], state["depth"], state["close"], est)
