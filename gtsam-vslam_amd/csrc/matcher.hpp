@@ -116,6 +116,8 @@ struct vslam_matcher {
     vslam_status track_frame_mono(const vslam_imu_input* imu, const double* predVelocity, double fps, double* T_cw_out,
                                   vslam_track_report* rep, vslam_imu_output* imuOut, double* T_wc_pred_out, double* predVelOut);
     vslam_status track_set_map(const double* xyz, const uint8_t* desc, const float* msd, const uint8_t* outlier, int n);
+    vslam_status track_upload_map(const double* xyz, const uint8_t* desc, const float* msd, int n);
+    vslam_status track_fetch_state(uint8_t* dst, int M, int nL, int N);
 
     vslam_status init(const vslam_rig* r, vslam_extractor* l, int il, vslam_extractor* rr, int ir);
     void release();

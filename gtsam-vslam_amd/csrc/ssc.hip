@@ -1,5 +1,5 @@
 // K3 on the device: FeatureExtractor::ssc (reference src/FeatureExtractor.cpp:368-468, ANMS "SSC") for every
-// (image, level) of a frame, bit-exact with the reference loop (the CPU restatement lives with the tests).
+// (image, level) of a frame, bit-exact with the reference loop.
 //
 // The two sequential pieces of the reference are reproduced exactly, in parallel:
 //  (1) cv::sortIdx = libstdc++ std::sort on indices (+ reversal): the TIE ORDER of introsort decides which of

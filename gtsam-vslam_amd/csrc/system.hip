@@ -1,0 +1,975 @@
+// vslam_system: the closed tracking <-> local-mapping loop of the reference behind ONE handle - what VSlamSystem wires
+// together (src/System.cpp:6-60): FeatureTracker::TrackImage as the per-frame entry point (include/FeatureTracker.h:87-96,
+// src/FeatureTracker.cpp:1108-1278) and LocalMapper::beginLocalMapping as the optimizer thread (include/OptimizationBA.h:
+// 54-87, src/OptimizationBA.cpp:955-982), sharing a Map (include/Map.h).
+//
+// Split of the work:
+//   * every numerical stage runs in the HIP kernels of this library (extraction, stereo match, projection match, pose
+//     solve with / without the IMU factor, new-point matching + triangulation, local BA, depth refresh, descriptor
+//     selection, keyframe pose propagation);
+//   * the Map / KeyFrame / MapPoint bookkeeping the reference keeps in pointer graphs (insertKeyFrame :743-842,
+//     calcConnections src/KeyFrame.cpp:103-145, window collection src/OptimizationBA.cpp:438-516, write-back :875-938,
+//     setActiveOutliers :1016-1034, updatePoses :1699-1708, changePosesLCA :884-908) is host C++ here too, on index-based
+//     SoA records; it is the flattening layer between the reference's objects and the kernels' arrays.
+//
+// Determinism notes (the same choices are made by the test-side restatement this file is checked against): unordered_map
+// iteration orders of the reference are replaced by insertion order, sort ties on KeyFrame* by keyframe number; the
+// unpaired Matrix4d::inverse() calls of the constant-velocity feedback are true inverses (m4_affine_inv) - taking them as
+// rigid transposes makes the round-off defect of the rotation block grow by 1 + sqrt(2) per frame.
+#include "matcher.hpp"
+#include "dmath.hpp"
+#include <algorithm>
+#include <array>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+
+namespace {
+
+using M4 = std::array<double, 16>;
+
+M4 m4_identity() { M4 r{}; r[0] = r[5] = r[10] = r[15] = 1.0; return r; }
+M4 m4_from(const double* p) { M4 r; for (int i = 0; i < 16; i++) r[i] = p[i]; return r; }
+M4 m4_mul(const M4& a, const M4& b) {
+    M4 r;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            double s = 0;
+            for (int k = 0; k < 4; k++) s += a[4 * i + k] * b[4 * k + j];
+            r[4 * i + j] = s;
+        }
+    return r;
+}
+// general inverse of [A t; 0 1]: A^-1 by cofactors, -A^-1 t  (Eigen's Matrix4d::inverse() on an affine matrix)
+M4 m4_affine_inv(const M4& T) {
+    const double a = T[0], b = T[1], c = T[2], d = T[4], e = T[5], f = T[6], g = T[8], h = T[9], i = T[10];
+    const double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+    const double det = a * A + b * B + c * C;
+    const double inv[9] = {A / det, -(b * i - c * h) / det, (b * f - c * e) / det,
+                           B / det, (a * i - c * g) / det, -(a * f - c * d) / det,
+                           C / det, -(a * h - b * g) / det, (a * e - b * d) / det};
+    M4 r = m4_identity();
+    for (int q = 0; q < 3; q++) {
+        for (int p = 0; p < 3; p++) r[4 * q + p] = inv[3 * q + p];
+        r[4 * q + 3] = -(inv[3 * q] * T[3] + inv[3 * q + 1] * T[7] + inv[3 * q + 2] * T[11]);
+    }
+    return r;
+}
+// (R^T, -R^T t): the form the pose kernels use for the paired inversions around a solve
+M4 m4_rigid_inv(const M4& T) {
+    M4 r = m4_identity();
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) r[4 * i + j] = T[4 * j + i];
+        r[4 * i + 3] = -(T[i] * T[3] + T[4 + i] * T[7] + T[8 + i] * T[11]);
+    }
+    return r;
+}
+
+struct SysKeys {                       // TrackedKeys (include/FeatureExtractor.h:18-50), host copy of a keyframe's frame
+    std::vector<vslam_keypoint> kL, kR;
+    std::vector<uint8_t> dL, dR;       // n x 32
+    std::vector<int> rightIdxs, leftIdxs;
+    std::vector<float> depth;
+    std::vector<uint8_t> close;
+};
+
+struct KfMatch { int kf, l, r; };      // one entry of MapPoint::kFMatches (keyframe number, left idx, right idx)
+
+struct SysMP {                         // MapPoint (include/Map.h:22-98)
+    double wp[3];
+    uint8_t desc[32];
+    std::vector<KfMatch> kfm;          // insertion ordered
+    float maxScaleDist = 0, minScaleDist = 0;
+    int unMCnt = 0;
+    bool isOutlier = false, inFrame = true;
+    long long kdx = 0, idx = 0;
+    int lastObsKF = -1, LBAID = -1;
+    int find(int kf) const { for (size_t i = 0; i < kfm.size(); i++) if (kfm[i].kf == kf) return (int)i; return -1; }
+};
+
+struct SysKF {                         // KeyFrame (include/KeyFrame.h) - keyframes only; plain frames live in SysFrame
+    int numb = 0, frameIdx = 0;
+    M4 pose, poseInv, refPose;
+    bool fixed = false;
+    int prevKF = -1, nextKF = -1;
+    SysKeys keys;
+    std::vector<int> unF, unFR, lmpL, lmpR;            // unMatchedF / unMatchedFR, localMapPoints(R) as map-point indices
+    std::vector<std::pair<int, int>> sortedKFWeights;   // (weight, keyframe number)
+    int LBAID = -1, nKeysTracked = 0;
+    void setPose(const M4& T) { pose = T; poseInv = m4_affine_inv(T); }      // CameraPose::setPose (src/Camera.cpp:10-15)
+};
+
+struct SysFrame { bool isKF; int kf; int prevKF; M4 refPose; };   // allFramesPoses entry (trajectory output)
+
+}  // namespace
+
+using namespace vslam;
+
+struct vslam_system {
+    vslam_system_config cfg{};
+    vslam_extractor* fe = nullptr;
+    vslam_matcher* fm = nullptr;
+    std::vector<float> scalePyr, sigmaF, invSigmaF;
+    int nLev = 8;
+    // zedPtr->mCameraPose, prediction state (include/FeatureTracker.h:34-43)
+    M4 camPose, camPoseInv, camRefPose, predNPose, predNPoseInv, predNPoseRef, lastKFPoseInv;
+    int latestKF = -1;
+    float precCheckMatches = 0.9f;
+    int lastKFTrackedNumb = 0, insertKeyFrameCount = 0;
+    std::deque<SysKF> keyFrames;       // map->keyFrames (kIdx = size)
+    std::deque<SysMP> mapPoints;       // map->mapPoints (pIdx = size)
+    std::vector<int> active;           // map->activeMapPoints
+    std::vector<SysFrame> allFrames;
+    std::atomic<bool> keyFrameAdded{false}, LBADone{false};     // Map::keyFrameAdded / LBADone (plain bools in the reference)
+    std::atomic<int> endLBAIdx{0};
+    long long mpIdx = -1;              // LocalMapper's function-static mpIdx (src/OptimizationBA.cpp:93)
+    double velocity[3] = {0, 0, 0}, bias[6] = {0, 0, 0, 0, 0, 0};
+    // last frame (test taps)
+    std::vector<int> lastMatches; std::vector<uint8_t> lastOutliers;
+    vslam_frame_report lastMapping{};  // mapping fields of the most recent local-mapping pass
+    std::atomic<bool> mappingReportFresh{false};
+    // pinned staging
+    uint8_t* h_up = nullptr; size_t upCap = 0;
+    uint8_t* h_dn = nullptr; size_t dnCap = 0;
+    // optimizer thread (local_mapping == 2)
+    std::mutex mapMutex;
+    std::thread worker;
+    std::mutex wMu; std::condition_variable wCv;
+    bool stopRequested = false, mappingBusy = false;
+    vslam_status workerStatus = VSLAM_OK;
+    char workerError[256] = "";
+
+    vslam_status init(const vslam_system_config* c);
+    void release();
+    vslam_status track(const uint8_t* L, const uint8_t* R, int stride, bool onDevice, int frame, const vslam_imu_bucket* imu,
+                       double* T_wc_out, vslam_frame_report* rep);
+    vslam_status fetch_keys(SysKeys& k);
+    void mp_update(SysMP& mp, int kfNumb, std::vector<int>& needDesc, int mpIndex);
+    vslam_status calc_descriptors(const std::vector<int>& mps);
+    void backproject(const SysKeys& k, int i, const M4& pose, double* out) const;
+    vslam_status initialize_map(const SysKeys& keys, int frame);
+    vslam_status insert_keyframe(SysKeys& keys, const std::vector<int>& matchedL, const std::vector<int>& matches,
+                                 int nStereo, const M4& estimPose, const std::vector<uint8_t>& outl, const std::vector<int>& act, int frame);
+    void calc_connections(SysKF& kf);
+    vslam_status change_poses_lca(int endIdx);
+    vslam_status kf_update_pose(SysKF& kf, const M4& keyPose);
+    vslam_status local_mapping();
+    vslam_status find_new_points(const std::vector<int>& actKeyF, int& nNew);
+    vslam_status local_ba(const std::vector<int>& actKeyF);
+    void worker_loop();
+};
+
+void vslam_system::backproject(const SysKeys& k, int i, const M4& pose, double* out) const {
+    const double zp = (double)k.depth[i];
+    const double xp = ((double)k.kL[i].x - cfg.rig.cx) * zp / cfg.rig.fx;
+    const double yp = ((double)k.kL[i].y - cfg.rig.cy) * zp / cfg.rig.fy;
+    for (int c = 0; c < 3; c++) out[c] = (pose[4 * c] * xp + pose[4 * c + 1] * yp + pose[4 * c + 2] * zp) + pose[4 * c + 3];
+}
+
+vslam_status vslam_system::init(const vslam_system_config* c) {
+    if (!c) return VSLAM_ERR_INVALID;
+    cfg = *c;
+    if (cfg.window <= 0) cfg.window = 10;
+    if (cfg.window > 16) { set_error("vslam_system: window > 16 keyframes is not supported by the new-point pipeline"); return VSLAM_ERR_INVALID; }
+    VS_CHECK(vslam_extractor_create(&cfg.fe, cfg.rig.width, cfg.rig.height, 2, cfg.device, &fe));
+    VS_CHECK(vslam_matcher_create(&cfg.rig, fe, 0, fe, 1, &fm));
+    nLev = cfg.fe.n_levels;
+    scalePyr.resize(nLev); sigmaF.resize(nLev); invSigmaF.resize(nLev);
+    VS_CHECK(vslam_extractor_tables(fe, scalePyr.data(), nullptr, sigmaF.data(), invSigmaF.data(), nullptr, nullptr));
+    bool zero = true;
+    for (int i = 0; i < 16; i++) zero &= cfg.T_wc_init[i] == 0.0;
+    const M4 T0 = zero ? m4_identity() : m4_from(cfg.T_wc_init);
+    camPose = T0; camPoseInv = m4_affine_inv(T0); camRefPose = m4_identity();
+    predNPose = T0; predNPoseInv = camPoseInv; predNPoseRef = m4_identity(); lastKFPoseInv = m4_identity();
+    for (int k = 0; k < 3; k++) velocity[k] = cfg.velocity_init[k];
+    if (cfg.local_mapping == 2) worker = std::thread([this]() { worker_loop(); });
+    return VSLAM_OK;
+}
+
+void vslam_system::release() {
+    if (worker.joinable()) {
+        { std::lock_guard<std::mutex> lk(wMu); stopRequested = true; }
+        wCv.notify_all();
+        worker.join();
+    }
+    if (fm) vslam_matcher_destroy(fm);
+    if (fe) vslam_extractor_destroy(fe);
+    fm = nullptr; fe = nullptr;
+    if (h_up) hipHostFree(h_up);
+    if (h_dn) hipHostFree(h_dn);
+    h_up = h_dn = nullptr;
+}
+
+// the current frame's TrackedKeys as the device holds them (after findOutliersR's mutations)
+vslam_status vslam_system::fetch_keys(SysKeys& k) {
+    int nL = 0, nR = 0;
+    VS_CHECK(vslam_extractor_count(fe, 0, &nL)); VS_CHECK(vslam_extractor_count(fe, 1, &nR));
+    k.kL.resize(nL); k.kR.resize(nR); k.dL.resize((size_t)nL * 32); k.dR.resize((size_t)nR * 32);
+    int n = 0;
+    VS_CHECK(vslam_extractor_fetch(fe, 0, k.kL.data(), k.dL.data(), std::max(nL, 1), &n));
+    VS_CHECK(vslam_extractor_fetch(fe, 1, k.kR.data(), k.dR.data(), std::max(nR, 1), &n));
+    k.rightIdxs.assign(std::max(nL, 1), -1); k.leftIdxs.assign(std::max(nR, 1), -1); k.depth.assign(std::max(nL, 1), -1.f); k.close.assign(std::max(nL, 1), 0);
+    VS_CHECK(vslam_stereo_fetch(fm, k.rightIdxs.data(), k.leftIdxs.data(), k.depth.data(), k.close.data(), std::max(nL, 1), std::max(nR, 1), nullptr));
+    k.rightIdxs.resize(nL); k.leftIdxs.resize(nR); k.depth.resize(nL); k.close.resize(nL);
+    return VSLAM_OK;
+}
+
+// MapPoint::update(KeyFrame*) (src/Map.cpp:58-100) minus calcDescriptor, which is batched (needDesc)
+void vslam_system::mp_update(SysMP& mp, int kfNumb, std::vector<int>& needDesc, int mpIndex) {
+    const SysKF& kf = keyFrames[kfNumb];
+    mp.lastObsKF = kfNumb;
+    const double dx = mp.wp[0] - kf.pose[3], dy = mp.wp[1] - kf.pose[7], dz = mp.wp[2] - kf.pose[11];
+    const float dist = (float)std::sqrt(dx * dx + dy * dy + dz * dz);
+    const int e = mp.find(kfNumb);
+    int level = 0;
+    if (e >= 0) {
+        if (mp.kfm[e].r >= 0) level = kf.keys.kR[mp.kfm[e].r].octave;
+        if (mp.kfm[e].l >= 0) level = kf.keys.kL[mp.kfm[e].l].octave;
+    }
+    mp.maxScaleDist = dist * scalePyr[level];
+    mp.minScaleDist = mp.maxScaleDist / scalePyr[nLev - 1];
+    needDesc.push_back(mpIndex);
+}
+
+// MapPoint::calcDescriptor (src/Map.cpp:145-210) for a batch of map points: k_calc_descriptor
+vslam_status vslam_system::calc_descriptors(const std::vector<int>& mps) {
+    if (mps.empty()) return VSLAM_OK;
+    std::vector<uint8_t> descs;
+    std::vector<int> start(1, 0), best(mps.size(), -1);
+    std::vector<const uint8_t*> src;
+    for (int m : mps) {
+        const SysMP& mp = mapPoints[m];
+        for (const KfMatch& o : mp.kfm) {
+            const SysKeys& k = keyFrames[o.kf].keys;
+            if (o.l != -1) src.push_back(k.dL.data() + (size_t)o.l * 32);
+            if (o.r != -1) src.push_back(k.dR.data() + (size_t)o.r * 32);
+        }
+        start.push_back((int)src.size());
+    }
+    descs.resize(src.size() * 32);
+    for (size_t i = 0; i < src.size(); i++) memcpy(descs.data() + i * 32, src[i], 32);
+    if (!src.empty()) VS_CHECK(vslam_calc_descriptors(descs.data(), start.data(), (int)mps.size(), cfg.device, best.data()));
+    for (size_t q = 0; q < mps.size(); q++)
+        if (start[q + 1] > start[q] && best[q] >= 0) memcpy(mapPoints[mps[q]].desc, src[start[q] + best[q]], 32);
+    return VSLAM_OK;
+}
+
+static void new_keyframe(SysKF& kf, int numb, int frame, const M4& pose, const M4& refPose, SysKeys& keys) {
+    kf.numb = numb; kf.frameIdx = frame; kf.refPose = refPose; kf.setPose(pose);
+    kf.keys = keys;                                       // TrackedKeys::getKeys deep copy
+    kf.unF.assign(keys.kL.size(), -1); kf.unFR.assign(keys.kR.size(), -1);
+    kf.lmpL.assign(keys.kL.size(), -1); kf.lmpR.assign(keys.kR.size(), -1);
+}
+
+// initializeMap (src/FeatureTracker.cpp:72-123)
+vslam_status vslam_system::initialize_map(const SysKeys& keysIn, int frame) {
+    SysKeys keys = keysIn;
+    keyFrames.emplace_back();
+    SysKF& kf = keyFrames.back();
+    const int numb = (int)keyFrames.size() - 1;
+    new_keyframe(kf, numb, frame, camPose, m4_identity(), keys);
+    kf.fixed = true;
+    std::vector<int> need;
+    int tracked = 0;
+    for (int i = 0; i < (int)keys.kL.size(); i++) {
+        if (!(keys.depth[i] > 0)) continue;
+        const int r = keys.rightIdxs[i];
+        mapPoints.emplace_back();
+        const int mi = (int)mapPoints.size() - 1;
+        SysMP& mp = mapPoints.back();
+        backproject(keys, i, camPose, mp.wp);
+        memcpy(mp.desc, keys.dL.data() + (size_t)i * 32, 32);
+        mp.kdx = numb; mp.idx = mi;
+        mp.kfm.push_back({numb, i, r});
+        mp_update(mp, numb, need, mi);
+        active.push_back(mi);
+        kf.lmpL[i] = mi; kf.unF[i] = numb;
+        if (r >= 0) { kf.lmpR[r] = mi; kf.unFR[r] = numb; }
+        tracked++;
+    }
+    VS_CHECK(calc_descriptors(need));
+    lastKFTrackedNumb = tracked;
+    latestKF = numb;
+    allFrames.push_back({true, numb, -1, m4_identity()});
+    lastKFPoseInv = m4_affine_inv(camPose);
+    return VSLAM_OK;
+}
+
+// KeyFrame::calcConnections (src/KeyFrame.cpp:103-145)
+void vslam_system::calc_connections(SysKF& kf) {
+    std::vector<int> w(keyFrames.size(), 0);
+    for (int m : kf.lmpL) { if (m < 0) continue; for (const KfMatch& o : mapPoints[m].kfm) w[o.kf]++; }
+    for (int m : kf.lmpR) {
+        if (m < 0) continue;
+        for (const KfMatch& o : mapPoints[m].kfm) { if (o.l >= 0 || o.r < 0) continue; w[o.kf]++; }
+    }
+    kf.sortedKFWeights.clear();
+    for (int k = 0; k < (int)w.size(); k++) if (w[k] >= 15) kf.sortedKFWeights.push_back({w[k], k});
+    std::sort(kf.sortedKFWeights.begin(), kf.sortedKFWeights.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) {
+        return a.first != b.first ? a.first > b.first : a.second > b.second; });
+}
+
+// insertKeyFrame (src/FeatureTracker.cpp:743-842)
+vslam_status vslam_system::insert_keyframe(SysKeys& keys, const std::vector<int>& matchedL, const std::vector<int>& matches,
+                                           int nStereo, const M4& estimPose, const std::vector<uint8_t>& outl, const std::vector<int>& act, int frame) {
+    const M4 refPose = m4_mul(keyFrames[latestKF].poseInv, estimPose);
+    keyFrames.emplace_back();
+    SysKF& kf = keyFrames.back();
+    const int numb = (int)keyFrames.size() - 1;
+    new_keyframe(kf, numb, frame, estimPose, refPose, keys);
+    kf.prevKF = latestKF; keyFrames[latestKF].nextKF = numb;
+    std::vector<int> need;
+    int tracked = 0;
+    for (size_t i = 0; i < act.size(); i++) {
+        const int l = matches[2 * i], r = matches[2 * i + 1];
+        if ((l < 0 && r < 0) || outl[i]) continue;
+        SysMP& mp = mapPoints[act[i]];
+        if (mp.find(numb) < 0) mp.kfm.push_back({numb, l, r});
+        mp_update(mp, numb, need, act[i]);
+        if (l >= 0) { kf.lmpL[l] = act[i]; kf.unF[l] = (int)mp.kdx; }
+        if (r >= 0) { kf.lmpR[r] = act[i]; kf.unFR[r] = (int)mp.kdx; }
+        tracked++;
+    }
+    if (nStereo < 80) {                                   // minNStereo: refill with the frame's own stereo points, nearest first
+        std::vector<std::pair<float, int>> allDepths;
+        for (int i = 0; i < (int)keys.kL.size(); i++) if (keys.depth[i] > 0 && matchedL[i] < 0) allDepths.push_back({keys.depth[i], i});
+        std::sort(allDepths.begin(), allDepths.end());
+        int count = 0;
+        for (const auto& d : allDepths) {
+            const int lIdx = d.second, rIdx = keys.rightIdxs[lIdx];
+            if (count >= 100 && !keys.close[lIdx]) break;   // maxAddedStereo
+            count++;
+            mapPoints.emplace_back();
+            const int mi = (int)mapPoints.size() - 1;
+            SysMP& mp = mapPoints.back();
+            backproject(keys, lIdx, estimPose, mp.wp);
+            memcpy(mp.desc, keys.dL.data() + (size_t)lIdx * 32, 32);
+            mp.kdx = numb; mp.idx = mi;
+            mp.kfm.push_back({numb, lIdx, rIdx});
+            mp_update(mp, numb, need, mi);
+            kf.lmpL[lIdx] = mi;
+            if (rIdx >= 0) kf.lmpR[rIdx] = mi;             // (unMatchedF is not set on this path: reference behaviour)
+            active.push_back(mi);
+            tracked++;
+        }
+    }
+    VS_CHECK(calc_descriptors(need));
+    calc_connections(kf);
+    lastKFTrackedNumb = tracked; kf.nKeysTracked = tracked;
+    precCheckMatches = tracked > 350 ? 0.7f : 0.9f;
+    latestKF = numb;
+    lastKFPoseInv = m4_affine_inv(estimPose);
+    allFrames.push_back({true, numb, -1, m4_identity()});
+    if (keyFrames.size() > 3) keyFrameAdded = true;
+    return VSLAM_OK;
+}
+
+// KeyFrame::updatePose (src/KeyFrame.cpp:6-76): k_kf_update_pose
+vslam_status vslam_system::kf_update_pose(SysKF& kf, const M4& keyPose) {
+    std::vector<int> lms, slotL(kf.lmpL.size(), -1), slotR(kf.lmpR.size(), -1), index;
+    auto slot = [&](const std::vector<int>& src, std::vector<int>& dst) {
+        for (size_t i = 0; i < src.size(); i++) {
+            if (src[i] < 0) continue;
+            int j = -1;
+            for (size_t q = 0; q < lms.size(); q++) if (lms[q] == src[i]) { j = (int)q; break; }
+            if (j < 0) { j = (int)lms.size(); lms.push_back(src[i]); }
+            dst[i] = j;
+        }
+    };
+    // (linear search is fine for a test-sized chain; keyed lookup for long ones)
+    std::vector<int> where(mapPoints.size(), -1);
+    auto slotFast = [&](const std::vector<int>& src, std::vector<int>& dst) {
+        for (size_t i = 0; i < src.size(); i++) {
+            if (src[i] < 0) continue;
+            if (where[src[i]] < 0) { where[src[i]] = (int)lms.size(); lms.push_back(src[i]); }
+            dst[i] = where[src[i]];
+        }
+    };
+    (void)slot;
+    slotFast(kf.lmpL, slotL); slotFast(kf.lmpR, slotR);
+    std::vector<double> xyz(std::max<size_t>(lms.size(), 1) * 3);
+    std::vector<int64_t> kdx(std::max<size_t>(lms.size(), 1));
+    std::vector<uint8_t> ol(std::max<size_t>(lms.size(), 1));
+    for (size_t j = 0; j < lms.size(); j++) {
+        const SysMP& m = mapPoints[lms[j]];
+        xyz[3 * j] = m.wp[0]; xyz[3 * j + 1] = m.wp[1]; xyz[3 * j + 2] = m.wp[2]; kdx[j] = m.kdx; ol[j] = m.isOutlier;
+    }
+    vslam_kf_update_problem P{};
+    P.rig = cfg.rig; P.n_levels = nLev; P.inv_sigma_factor = invSigmaF.data(); P.numb = kf.numb;
+    P.key_pose = keyPose.data(); P.ref_pose = kf.refPose.data(); P.cur_pose_inv = kf.poseInv.data();
+    P.n_left = (int)kf.keys.kL.size(); P.n_right = (int)kf.keys.kR.size();
+    P.kps_left = kf.keys.kL.data(); P.kps_right = kf.keys.kR.data(); P.slot_lm_l = slotL.data(); P.slot_lm_r = slotR.data();
+    P.n_lm = (int)lms.size(); P.lm_xyz = xyz.data(); P.lm_kdx = kdx.data(); P.lm_outlier = ol.data();
+    std::vector<uint8_t> dl(std::max<size_t>(slotL.size(), 1)), dr(std::max<size_t>(slotR.size(), 1));
+    double poseOut[16];
+    VS_CHECK(vslam_keyframe_update_pose(&P, cfg.device, dl.data(), dr.data(), poseOut));
+    for (size_t j = 0; j < lms.size(); j++) { SysMP& m = mapPoints[lms[j]]; m.wp[0] = xyz[3 * j]; m.wp[1] = xyz[3 * j + 1]; m.wp[2] = xyz[3 * j + 2]; }
+    auto drop = [&](std::vector<int>& lmp, std::vector<int>& un, const std::vector<uint8_t>& d) {
+        for (size_t i = 0; i < lmp.size(); i++) {
+            if (!d[i] || lmp[i] < 0) continue;
+            SysMP& m = mapPoints[lmp[i]];
+            const int e = m.find(kf.numb);
+            if (e >= 0) m.kfm.erase(m.kfm.begin() + e);
+            lmp[i] = -1; un[i] = -1;
+        }
+    };
+    drop(kf.lmpL, kf.unF, dl); drop(kf.lmpR, kf.unFR, dr);
+    kf.setPose(m4_mul(keyPose, kf.refPose));               // pose.changePose(keyPose)
+    return VSLAM_OK;
+}
+
+// changePosesLCA (src/FeatureTracker.cpp:884-908)
+vslam_status vslam_system::change_poses_lca(int endIdx) {
+    int k = endIdx;
+    while (keyFrames[k].nextKF >= 0) {
+        const M4 keyPose = keyFrames[k].pose;
+        VS_CHECK(kf_update_pose(keyFrames[keyFrames[k].nextKF], keyPose));
+        k = keyFrames[k].nextKF;
+    }
+    const M4 keyPose = keyFrames[k].pose;
+    camPose = m4_mul(keyPose, camRefPose); camPoseInv = m4_affine_inv(camPose);
+    lastKFPoseInv = m4_affine_inv(keyPose);
+    predNPose = m4_mul(camPose, predNPoseRef);
+    predNPoseInv = m4_affine_inv(predNPose);
+    return VSLAM_OK;
+}
+
+// FeatureTracker::TrackImage (src/FeatureTracker.cpp:1108-1278)
+vslam_status vslam_system::track(const uint8_t* L, const uint8_t* R, int stride, bool onDevice, int frame,
+                                 const vslam_imu_bucket* imu, double* T_wc_out, vslam_frame_report* rep) {
+    if (!L || !R || !T_wc_out) return VSLAM_ERR_INVALID;
+    if (cfg.use_imu && frame > 0 && (!imu || imu->n <= 0)) { set_error("vslam_system: IMU mode needs the frame's IMU bucket"); return VSLAM_ERR_INVALID; }
+    {
+        std::lock_guard<std::mutex> lk(wMu);
+        if (workerStatus != VSLAM_OK) { set_error("local mapping thread failed: %s", workerError); return workerStatus; }
+    }
+    vslam_frame_report out{};
+    out.frame = frame;
+    VS_HIP(hipSetDevice(cfg.device));
+    if (LBADone) {                                         // :1115-1122
+        std::lock_guard<std::mutex> lk(mapMutex);
+        VS_CHECK(change_poses_lca(endLBAIdx));
+        LBADone = false;
+    }
+    // images -> pyramid level 0, extraction, stereo match (extractORBAndStereoMatch :56-70); nothing here depends on the map
+    if (onDevice) { VS_CHECK(vslam_extractor_set_image_device(fe, 0, L, stride)); VS_CHECK(vslam_extractor_set_image_device(fe, 1, R, stride)); }
+    else { VS_CHECK(vslam_extractor_set_image_host(fe, 0, L, stride)); VS_CHECK(vslam_extractor_set_image_host(fe, 1, R, stride)); }
+    VS_CHECK(vslam_extractor_run(fe));
+    VS_CHECK(fm->stereo_match());
+    if (frame == 0) {
+        SysKeys keys;
+        VS_CHECK(fetch_keys(keys));
+        std::lock_guard<std::mutex> lk(mapMutex);
+        VS_CHECK(initialize_map(keys, frame));
+        memcpy(T_wc_out, camPose.data(), sizeof(double) * 16);
+        out.keyframe_inserted = 1; out.n_keyframes = (int)keyFrames.size(); out.n_map_points = (int)mapPoints.size();
+        out.n_active_after = (int)active.size();
+        if (rep) *rep = out;
+        return VSLAM_OK;
+    }
+    // ---- activeMapPoints -> the tracker's device arrays (the kernel compacts them: removeOutOfFrameMPs :910-939) ----
+    std::vector<int> cand;
+    {
+        std::lock_guard<std::mutex> lk(mapMutex);
+        cand.reserve(active.size());
+        for (int m : active) if (!mapPoints[m].isOutlier) cand.push_back(m);
+    }
+    const int N = (int)cand.size();
+    {
+        const size_t need = (size_t)std::max(N, 1) * (24 + 32 + 4);
+        if (need > upCap) { if (h_up) hipHostFree(h_up); upCap = need + need / 2; VS_HIP(hipHostMalloc((void**)&h_up, upCap, hipHostMallocDefault)); }
+        double* xyz = (double*)h_up; uint8_t* desc = h_up + (size_t)N * 24; float* msd = (float*)(h_up + (size_t)N * 56);
+        for (int j = 0; j < N; j++) {
+            const SysMP& mp = mapPoints[cand[j]];
+            xyz[3 * j] = mp.wp[0]; xyz[3 * j + 1] = mp.wp[1]; xyz[3 * j + 2] = mp.wp[2];
+            memcpy(desc + (size_t)j * 32, mp.desc, 32);
+            msd[j] = mp.maxScaleDist;
+        }
+        VS_CHECK(fm->track_upload_map(xyz, desc, msd, N));
+    }
+    // ---- the frame's tracking block on the device (:1168-1241) -------------------------------------------------------
+    vslam_imu_input in{};
+    vslam_imu_output imuOut{};
+    if (cfg.use_imu) {
+        for (int k = 0; k < 3; k++) in.gravity[k] = cfg.gravity[k];
+        in.gyro_noise_density = cfg.gyro_noise_density; in.gyro_random_walk = cfg.gyro_random_walk;
+        in.accel_noise_density = cfg.accel_noise_density; in.accel_random_walk = cfg.accel_random_walk;
+        memcpy(in.T_body_sensor, cfg.T_body_sensor, sizeof(in.T_body_sensor));
+        memcpy(in.T_wc_prev, camPose.data(), sizeof(in.T_wc_prev));
+        for (int k = 0; k < 3; k++) in.velocity_prev[k] = velocity[k];
+        for (int k = 0; k < 6; k++) in.bias_prev[k] = bias[k];
+        in.n_samples = imu->n; in.hz = cfg.imu_hz; in.acceleration = imu->acceleration; in.angular_velocity = imu->angular_velocity;
+        in.timestamps_ns = imu->timestamps_ns;
+    }
+    double T_cw[16];
+    vslam_track_report tr{};
+    VS_CHECK(fm->track_frame(predNPose.data(), frame, T_cw, &tr, cfg.use_imu ? &in : nullptr, cfg.use_imu ? &imuOut : nullptr));
+    const int M = tr.n_active;
+    int nL = 0, nR = 0;
+    VS_CHECK(vslam_extractor_count(fe, 0, &nL)); VS_CHECK(vslam_extractor_count(fe, 1, &nR));
+    // matches, MPsOutliers, source index, inFrame of the active points; matchedIdxsL; left visibility of every uploaded point
+    std::vector<int> matches((size_t)std::max(M, 1) * 2), actIdx(std::max(M, 1)), matchedL(std::max(nL, 1));
+    std::vector<uint8_t> outl(std::max(M, 1)), inF(std::max(M, 1)), visL(std::max(N, 1));
+    {
+        const size_t need = (size_t)std::max(M, 1) * 14 + (size_t)std::max(nL, 1) * 4 + (size_t)std::max(N, 1) + 64;
+        if (need > dnCap) { if (h_dn) hipHostFree(h_dn); dnCap = need + need / 2; VS_HIP(hipHostMalloc((void**)&h_dn, dnCap, hipHostMallocDefault)); }
+        VS_CHECK(fm->track_fetch_state(h_dn, M, nL, N));
+        const uint8_t* p = h_dn;
+        memcpy(matches.data(), p, (size_t)M * 8); p += (size_t)M * 8;
+        memcpy(actIdx.data(), p, (size_t)M * 4); p += (size_t)M * 4;
+        memcpy(matchedL.data(), p, (size_t)nL * 4); p += (size_t)nL * 4;
+        memcpy(outl.data(), p, M); p += M;
+        memcpy(inF.data(), p, M); p += M;
+        memcpy(visL.data(), p, N);
+    }
+    matches.resize((size_t)M * 2); actIdx.resize(M); outl.resize(M); inF.resize(M);
+    const M4 estimPose = m4_from(T_cw);
+    const M4 poseEst = m4_rigid_inv(estimPose);            // (paired with the solve's own T_wc -> T_cw inversion)
+    std::vector<int> act(M);
+    bool isKF = false;
+    {
+        std::lock_guard<std::mutex> lk(mapMutex);
+        // host side of removeOutOfFrameMPs / PredictMPsPosition: MapPoint::inFrame, the compacted active list.  Points the
+        // optimizer thread appended to activeMapPoints while this frame was on the device stay behind the compacted ones.
+        for (int j = 0; j < N; j++) mapPoints[cand[j]].inFrame = visL[j] != 0;
+        std::vector<int> tail;
+        {
+            std::vector<uint8_t> wasCand(mapPoints.size(), 0);
+            for (int m : cand) wasCand[m] = 1;
+            for (int m : active) if (!wasCand[m] && !mapPoints[m].isOutlier) tail.push_back(m);
+        }
+        for (int i = 0; i < M; i++) { act[i] = cand[actIdx[i]]; mapPoints[act[i]].inFrame = inF[i] != 0; }
+        active = act;
+        active.insert(active.end(), tail.begin(), tail.end());
+        // keyframe rule (:1260-1270)
+        insertKeyFrameCount++;
+        isKF = (tr.n_stereo < 80 || insertKeyFrameCount >= 5) && (float)tr.n_inliers < precCheckMatches * (float)lastKFTrackedNumb;
+        if (isKF) {
+            insertKeyFrameCount = 0;
+            SysKeys keys;
+            VS_CHECK(fetch_keys(keys));
+            VS_CHECK(insert_keyframe(keys, matchedL, matches, tr.n_stereo, poseEst, outl, act, frame));
+        } else {                                           // addFrame (:871-882)
+            allFrames.push_back({false, -1, latestKF, m4_mul(keyFrames[latestKF].poseInv, poseEst)});
+        }
+        // updatePoses (:1699-1708)
+        const M4 prevWPoseInv = camPoseInv;
+        camRefPose = m4_mul(lastKFPoseInv, poseEst);
+        camPose = poseEst; camPoseInv = m4_affine_inv(poseEst);
+        predNPoseRef = m4_mul(prevWPoseInv, poseEst);
+        predNPose = m4_mul(poseEst, predNPoseRef);
+        predNPoseInv = m4_affine_inv(predNPose);
+        // setActiveOutliers (:1016-1034)
+        for (int i = 0; i < M; i++) {
+            SysMP& mp = mapPoints[act[i]];
+            if ((matches[2 * i] >= 0 || matches[2 * i + 1] >= 0) && !outl[i]) mp.unMCnt = 0; else mp.unMCnt++;
+            if (!outl[i] && mp.unMCnt < 20) continue;
+            mp.isOutlier = true;
+        }
+        if (cfg.use_imu) {
+            for (int k = 0; k < 3; k++) velocity[k] = imuOut.velocity[k];       // mVelocity = mNewVelocity (:1277)
+            for (int k = 0; k < 6; k++) bias[k] = imuOut.bias[k];               // initialBias as the frame's last solve left it
+        }
+        lastMatches = matches; lastOutliers = outl;
+        out.n_keyframes = (int)keyFrames.size(); out.n_map_points = (int)mapPoints.size(); out.n_active_after = (int)active.size();
+    }
+    memcpy(T_wc_out, poseEst.data(), sizeof(double) * 16);
+    out.keyframe_inserted = isKF ? 1 : 0; out.n_active = M; out.n_inliers = tr.n_inliers; out.n_stereo = tr.n_stereo;
+    out.rounds = tr.rounds; out.lm_iterations = tr.lm_iterations;
+    // ---- LocalMapper::beginLocalMapping: one pass of its loop body -------------------------------------------------------
+    if (cfg.local_mapping == 1 && keyFrameAdded && !LBADone) {
+        VS_CHECK(local_mapping());
+    } else if (cfg.local_mapping == 2 && keyFrameAdded && !LBADone) {
+        { std::lock_guard<std::mutex> lk(wMu); mappingBusy = true; }
+        wCv.notify_all();
+    }
+    if (mappingReportFresh) {
+        std::lock_guard<std::mutex> lk(mapMutex);
+        out.mapping_ran = 1; out.new_points = lastMapping.new_points; out.ba_keyframes = lastMapping.ba_keyframes;
+        out.ba_local = lastMapping.ba_local; out.ba_landmarks = lastMapping.ba_landmarks; out.ba_pairs = lastMapping.ba_pairs;
+        out.ba_wrong = lastMapping.ba_wrong; out.ba_outliers = lastMapping.ba_outliers;
+        out.ba_report[0] = lastMapping.ba_report[0]; out.ba_report[1] = lastMapping.ba_report[1];
+        mappingReportFresh = false;
+    }
+    if (rep) *rep = out;
+    return VSLAM_OK;
+}
+
+void vslam_system::worker_loop() {
+    hipSetDevice(cfg.device);
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(wMu);
+            wCv.wait(lk, [&] { return stopRequested || mappingBusy; });
+            if (stopRequested) return;
+        }
+        vslam_status s = VSLAM_OK;
+        if (keyFrameAdded && !LBADone) s = local_mapping();
+        {
+            std::lock_guard<std::mutex> lk(wMu);
+            if (s != VSLAM_OK && workerStatus == VSLAM_OK) { workerStatus = s; snprintf(workerError, sizeof(workerError), "%s", vslam_last_error()); }
+            mappingBusy = false;
+        }
+        wCv.notify_all();
+    }
+}
+
+// one pass of beginLocalMapping's loop body (src/OptimizationBA.cpp:960-975)
+vslam_status vslam_system::local_mapping() {
+    std::vector<int> actKeyF;
+    {
+        std::lock_guard<std::mutex> lk(mapMutex);
+        const int last = (int)keyFrames.size() - 1;
+        actKeyF.push_back(last);
+        int count = 1;
+        for (const auto& c : keyFrames[last].sortedKFWeights) {     // KeyFrame::getConnectedKFs (src/KeyFrame.cpp:87-101)
+            if (c.second != last) { actKeyF.push_back(c.second); count++; }
+            if (count >= cfg.window) break;
+        }
+    }
+    vslam_frame_report r{};
+    int nNew = 0;
+    VS_CHECK(find_new_points(actKeyF, nNew));
+    lastMapping = r;
+    lastMapping.new_points = nNew;
+    VS_CHECK(local_ba(actKeyF));
+    mappingReportFresh = true;
+    return VSLAM_OK;
+}
+
+// findNewPoints + addMultiViewMapPointsR + addNewMapPoints (src/OptimizationBA.cpp:90-125, 211-232, 340-391)
+vslam_status vslam_system::find_new_points(const std::vector<int>& actKeyF, int& nNew) {
+    nNew = 0;
+    const int nk = (int)actKeyF.size();
+    std::vector<vslam_kf_view> views(nk);
+    std::vector<uint8_t> has, mpd;
+    std::vector<double> mpx;
+    std::vector<int> cL, cR, nObs, obs;
+    std::vector<uint8_t> acc;
+    std::vector<double> xyz;
+    int n0 = 0;
+    // the keyframes' arrays are read in place: a keyframe's keys never move (deque), only depth / close / unMatchedF change
+    // under mapMutex, which is held while the problem is uploaded
+    {
+        std::lock_guard<std::mutex> lk(mapMutex);
+        for (int k = 0; k < nk; k++) {
+            const SysKF& kf = keyFrames[actKeyF[k]];
+            vslam_kf_view& v = views[k];
+            v.T_wc = kf.pose.data(); v.id = kf.numb; v.n_left = (int)kf.keys.kL.size(); v.n_right = (int)kf.keys.kR.size();
+            v.kps_l = kf.keys.kL.data(); v.desc_l = kf.keys.dL.data(); v.kps_r = kf.keys.kR.data(); v.desc_r = kf.keys.dR.data();
+            v.right_idxs = kf.keys.rightIdxs.data(); v.left_idxs = kf.keys.leftIdxs.data();
+            v.unmatched_f = kf.unF.data(); v.unmatched_fr = kf.unFR.data();
+        }
+        const SysKF& last = keyFrames[actKeyF[0]];
+        n0 = (int)last.keys.kL.size();
+        has.assign(std::max(n0, 1), 0); mpx.assign((size_t)std::max(n0, 1) * 3, 0.0); mpd.assign((size_t)std::max(n0, 1) * 32, 0);
+        for (int i = 0; i < n0; i++) {
+            const int m = last.lmpL[i];
+            if (m < 0) continue;
+            has[i] = 1;
+            for (int c = 0; c < 3; c++) mpx[3 * (size_t)i + c] = mapPoints[m].wp[c];
+            memcpy(mpd.data() + (size_t)i * 32, mapPoints[m].desc, 32);
+        }
+        vslam_new_points_problem P{};
+        P.rig = cfg.rig; P.n_levels = nLev; P.scale_pyramid = scalePyr.data(); P.sigma_factor = sigmaF.data();
+        P.log_scale = (float)std::log((double)cfg.fe.scale); P.n_kf = nk; P.kfs = views.data();
+        P.estimated_depth = last.keys.depth.data(); P.has_mp = has.data(); P.mp_xyz = mpx.data(); P.mp_desc = mpd.data();
+        const int cap = std::max(n0, 1);
+        cL.assign(cap, -1); cR.assign(cap, -1); acc.assign(cap, 0); xyz.assign((size_t)cap * 3, 0.0); nObs.assign(cap, 0);
+        obs.assign((size_t)cap * nk * 3, -1);
+        vslam_new_points_result R{};
+        R.capacity = cap; R.cand_left = cL.data(); R.cand_right = cR.data(); R.accepted = acc.data(); R.xyz = xyz.data();
+        R.n_obs = nObs.data(); R.obs = obs.data();
+        VS_CHECK(vslam_find_new_points(&P, &R, cfg.device));
+        const int nc = R.n_candidates;
+        if (mpIdx < 0) mpIdx = (long long)mapPoints.size();
+        const int lastNumb = last.numb;
+        std::vector<int> created, need;
+        for (int c = 0; c < nc; c++) {
+            if (!acc[c]) continue;
+            const int no = nObs[c];
+            int dl = -1, dr = -1;
+            bool found = false;
+            for (int e = 0; e < no && !found; e++) {
+                const int* o = &obs[((size_t)c * nk + e) * 3];
+                if (actKeyF[o[0]] == lastNumb) { dl = o[1]; dr = o[2]; found = true; }
+            }
+            if (!found || (dl < 0 && dr < 0)) continue;
+            mapPoints.emplace_back();
+            const int mi = (int)mapPoints.size() - 1;
+            SysMP& mp = mapPoints.back();
+            for (int q = 0; q < 3; q++) mp.wp[q] = xyz[3 * (size_t)c + q];
+            const SysKeys& lk0 = keyFrames[lastNumb].keys;
+            memcpy(mp.desc, dl >= 0 ? lk0.dL.data() + (size_t)dl * 32 : lk0.dR.data() + (size_t)dr * 32, 32);
+            mp.kdx = lastNumb; mp.idx = mpIdx++;
+            for (int e = 0; e < no; e++) {
+                const int* o = &obs[((size_t)c * nk + e) * 3];
+                if (mp.find(actKeyF[o[0]]) < 0) mp.kfm.push_back({actKeyF[o[0]], o[1], o[2]});
+            }
+            mp_update(mp, lastNumb, need, mi);
+            created.push_back(mi);
+        }
+        VS_CHECK(calc_descriptors(need));
+        for (int mi : created) {                           // addNewMapPoints: MapPoint::addConnection on every observing keyframe
+            SysMP& mp = mapPoints[mi];
+            for (const KfMatch& o : mp.kfm) {
+                SysKF& kf = keyFrames[o.kf];
+                if (o.l >= 0) { kf.lmpL[o.l] = mi; kf.unF[o.l] = (int)mp.kdx; }
+                if (o.r >= 0) { kf.lmpR[o.r] = mi; kf.unFR[o.r] = (int)mp.kdx; }
+            }
+            active.push_back(mi);
+        }
+        nNew = (int)created.size();
+    }
+    return VSLAM_OK;
+}
+
+// LocalMapper::localBA: window collection (:438-516), graph membership (:556-745), vslam_local_ba, write-back (:875-938)
+vslam_status vslam_system::local_ba(const std::vector<int>& actKeyF) {
+    struct Pair { int kf, mp, l, r; };
+    std::vector<int> kfs, local;           // keyframe numbers: local first, then fixed
+    std::vector<int> allMps;
+    std::vector<uint8_t> mpOut;
+    std::vector<int> pk, pl, poct; std::vector<uint8_t> pf; std::vector<float> puv; std::vector<Pair> pobj;
+    std::vector<double> kfPose, lm;
+    std::vector<int64_t> kfId; std::vector<uint8_t> kfFixed, kfLocal;
+    std::vector<int> kfIndex;
+    int lastActKF;
+    {
+        std::lock_guard<std::mutex> lk(mapMutex);
+        lastActKF = keyFrames[actKeyF[0]].numb;
+        local = actKeyF;
+        std::vector<uint8_t> isLocal(keyFrames.size(), 0);
+        for (int k : local) { keyFrames[k].LBAID = lastActKF; isLocal[k] = 1; }
+        std::vector<int> fixedKFs;
+        bool fixedKF = false;
+        for (int k : local) {
+            SysKF& kf = keyFrames[k];
+            if (kf.fixed) fixedKF = true;
+            for (int side = 0; side < 2; side++) {
+                const std::vector<int>& lst = side ? kf.lmpR : kf.lmpL;
+                for (int m : lst) {
+                    if (m < 0) continue;
+                    SysMP& mp = mapPoints[m];
+                    if (mp.isOutlier || mp.LBAID == lastActKF) continue;
+                    for (const KfMatch& o : mp.kfm) {
+                        if (side && (o.l >= 0 || o.r < 0)) continue;
+                        SysKF& c = keyFrames[o.kf];
+                        if (c.numb > lastActKF || c.LBAID == lastActKF) continue;
+                        if (!isLocal[o.kf]) { fixedKFs.push_back(o.kf); c.LBAID = lastActKF; }
+                    }
+                    allMps.push_back(m); mp.LBAID = lastActKF;
+                }
+            }
+        }
+        if (fixedKFs.empty() && !fixedKF) { const int lastK = local.back(); local.pop_back(); isLocal[lastK] = 0; fixedKFs.push_back(lastK); }
+        kfs = local; kfs.insert(kfs.end(), fixedKFs.begin(), fixedKFs.end());
+        kfIndex.assign(keyFrames.size(), -1);
+        for (size_t i = 0; i < kfs.size(); i++) kfIndex[kfs[i]] = (int)i;
+        mpOut.assign(allMps.size(), 0);
+        for (size_t m = 0; m < allMps.size(); m++) {
+            const SysMP& mp = mapPoints[allMps[m]];
+            bool out = true;
+            for (const KfMatch& o : mp.kfm) {
+                if (!mp.inFrame && (int)mp.kfm.size() < 3) { mpOut[m] = 1; break; }
+                if (mp.isOutlier) break;
+                out = false;
+                const SysKF& c = keyFrames[o.kf];
+                if (c.numb > lastActKF || kfIndex[o.kf] < 0) continue;
+                const SysKeys& keys = c.keys;
+                int flags;
+                if (o.l >= 0) flags = (keys.close[o.l] && o.r >= 0) ? 3 : 1;
+                else if (o.r >= 0) flags = 2;
+                else continue;
+                pk.push_back(kfIndex[o.kf]); pl.push_back((int)m); pf.push_back((uint8_t)flags);
+                puv.push_back(o.l >= 0 ? keys.kL[o.l].x : 0.f); puv.push_back(o.l >= 0 ? keys.kL[o.l].y : 0.f);
+                puv.push_back(o.r >= 0 ? keys.kR[o.r].x : 0.f); puv.push_back(o.r >= 0 ? keys.kR[o.r].y : 0.f);
+                poct.push_back(o.l >= 0 ? keys.kL[o.l].octave : 0); poct.push_back(o.r >= 0 ? keys.kR[o.r].octave : 0);
+                pobj.push_back({o.kf, allMps[m], o.l, o.r});
+            }
+            if (out) mpOut[m] = 1;
+        }
+        for (size_t p = 0; p < pk.size(); p++) if (mpOut[pl[p]]) pf[p] = 0;     // flagged landmarks contribute no factor
+        kfPose.resize(kfs.size() * 16); kfId.resize(kfs.size()); kfFixed.resize(kfs.size()); kfLocal.resize(kfs.size());
+        for (size_t i = 0; i < kfs.size(); i++) {
+            const SysKF& k = keyFrames[kfs[i]];
+            memcpy(&kfPose[16 * i], k.pose.data(), 16 * sizeof(double));
+            kfId[i] = k.numb; kfLocal[i] = isLocal[kfs[i]]; kfFixed[i] = (k.fixed || !isLocal[kfs[i]]) ? 1 : 0;
+        }
+        lm.resize(std::max<size_t>(allMps.size(), 1) * 3);
+        for (size_t m = 0; m < allMps.size(); m++) for (int c = 0; c < 3; c++) lm[3 * m + c] = mapPoints[allMps[m]].wp[c];
+    }
+    // ---- the numerical core on the device ------------------------------------------------------------------------
+    const int K = (int)kfs.size(), Lm = (int)allMps.size(), NP = (int)pk.size();
+    vslam_ba_problem P{};
+    P.rig = cfg.rig; P.n_levels = nLev; P.sigma_factor = sigmaF.data(); P.inv_sigma_factor = invSigmaF.data();
+    P.n_kf = K; P.kf_pose_wc = kfPose.data(); P.kf_id = kfId.data(); P.kf_fixed = kfFixed.data(); P.kf_local = kfLocal.data();
+    P.n_lm = Lm; P.lm_xyz = lm.data(); P.n_pairs = NP; P.pair_kf = pk.data(); P.pair_lm = pl.data(); P.pair_flags = pf.data();
+    P.pair_uv = puv.data(); P.pair_octave = poct.data();
+    std::vector<double> kfOut((size_t)std::max(K, 1) * 16), lmOut((size_t)std::max(Lm, 1) * 3);
+    std::vector<uint8_t> wrong(std::max(NP, 1), 0), wrong1(std::max(NP, 1), 0);
+    vslam_ba_result Rr{};
+    Rr.kf_pose_wc = kfOut.data(); Rr.lm_xyz = lmOut.data(); Rr.pair_wrong = wrong.data(); Rr.pair_wrong_pass1 = wrong1.data();
+    VS_CHECK(vslam_local_ba(&P, &Rr, cfg.device, nullptr));
+    // ---- write-back (:875-938) -----------------------------------------------------------------------------------------
+    {
+        std::lock_guard<std::mutex> lk(mapMutex);
+        // second graph build (:566-575): a landmark whose every keyframe observation was rejected after pass 1 is flagged
+        std::vector<int> nUsable(allMps.size(), 0);
+        for (int p = 0; p < NP; p++) if (pf[p] && !wrong1[p]) nUsable[pl[p]]++;
+        for (size_t m = 0; m < allMps.size(); m++) {
+            if (mpOut[m] || nUsable[m]) continue;
+            int later = 0;
+            for (const KfMatch& o : mapPoints[allMps[m]].kfm) if (keyFrames[o.kf].numb > lastActKF || kfIndex[o.kf] < 0) later++;
+            if (!later) mpOut[m] = 1;
+        }
+        int nWrong = 0;
+        for (int p = 0; p < NP; p++) {
+            if (!wrong[p]) continue;
+            nWrong++;
+            SysKF& c = keyFrames[pobj[p].kf];
+            SysMP& mp = mapPoints[pobj[p].mp];
+            const int e = mp.find(pobj[p].kf);
+            if (e < 0) continue;
+            const int l = mp.kfm[e].l, r = mp.kfm[e].r;
+            if (l >= 0) { c.lmpL[l] = -1; c.unF[l] = -1; }              // KeyFrame::eraseMPConnection
+            if (r >= 0) { c.lmpR[r] = -1; c.unFR[r] = -1; }
+            mp.kfm.erase(mp.kfm.begin() + e);                            // MapPoint::eraseKFConnection
+        }
+        std::vector<uint8_t> presentKf(K, 0), presentLm(std::max(Lm, 1), 0);
+        for (int p = 0; p < NP; p++) if (pf[p] && !wrong1[p]) { presentKf[pk[p]] = 1; presentLm[pl[p]] = 1; }
+        for (int i = 0; i < K; i++) if (kfLocal[i] && presentKf[i]) keyFrames[kfs[i]].setPose(m4_from(&kfOut[16 * (size_t)i]));
+        std::vector<int> upd;
+        int nOut = 0;
+        for (size_t m = 0; m < allMps.size(); m++) {
+            SysMP& mp = mapPoints[allMps[m]];
+            if (mpOut[m] || (!mp.inFrame && (int)mp.kfm.size() < 3)) { mp.isOutlier = true; nOut++; }
+            else if (presentLm[m]) { for (int c = 0; c < 3; c++) mp.wp[c] = lmOut[3 * m + c]; upd.push_back(allMps[m]); }
+        }
+        // MapPoint::updatePos (src/Map.cpp:212-234): depth / close refresh of every observing keyframe (k_ba_refresh_depth),
+        // then calcDescriptor
+        if (!upd.empty()) {
+            std::vector<int> rk, rl; std::vector<float> cur; std::vector<std::pair<int, int>> where;     // (kf numb, left idx)
+            std::vector<double> rpose; std::vector<int> kfSlot(keyFrames.size(), -1); std::vector<int> rkfs;
+            std::vector<double> rlm(upd.size() * 3);
+            for (size_t u = 0; u < upd.size(); u++) {
+                const SysMP& mp = mapPoints[upd[u]];
+                for (int c = 0; c < 3; c++) rlm[3 * u + c] = mp.wp[c];
+                for (const KfMatch& o : mp.kfm) {
+                    if (o.l < 0) continue;                 // (the reference indexes estimatedDepth[-1] here; skipped)
+                    if (kfSlot[o.kf] < 0) { kfSlot[o.kf] = (int)rkfs.size(); rkfs.push_back(o.kf); }
+                    rk.push_back(kfSlot[o.kf]); rl.push_back((int)u); cur.push_back(keyFrames[o.kf].keys.depth[o.l]);
+                    where.push_back({o.kf, o.l});
+                }
+            }
+            if (!rk.empty()) {
+                rpose.resize(rkfs.size() * 16);
+                for (size_t i = 0; i < rkfs.size(); i++) memcpy(&rpose[16 * i], keyFrames[rkfs[i]].pose.data(), 16 * sizeof(double));
+                std::vector<uint8_t> zeroW(rk.size(), 0), zeroO(upd.size(), 0), clo(rk.size()), up(rk.size());
+                std::vector<float> dep(rk.size());
+                VS_CHECK(vslam_ba_refresh_depth(&cfg.rig, (int)rkfs.size(), rpose.data(), (int)upd.size(), rlm.data(), zeroO.data(), (int)rk.size(),
+                                                rk.data(), rl.data(), zeroW.data(), cur.data(), cfg.device, dep.data(), clo.data(), up.data()));
+                for (size_t q = 0; q < rk.size(); q++) {
+                    if (!up[q]) continue;
+                    SysKeys& keys = keyFrames[where[q].first].keys;
+                    keys.depth[where[q].second] = dep[q];
+                    if (clo[q]) keys.close[where[q].second] = 1;
+                }
+            }
+            VS_CHECK(calc_descriptors(upd));
+        }
+        endLBAIdx = actKeyF[0];
+        keyFrameAdded = false;
+        LBADone = true;
+        lastMapping.ba_keyframes = K; lastMapping.ba_local = (int)local.size(); lastMapping.ba_landmarks = Lm; lastMapping.ba_pairs = NP;
+        lastMapping.ba_wrong = nWrong; lastMapping.ba_outliers = nOut;
+        lastMapping.ba_report[0] = Rr.report[0]; lastMapping.ba_report[1] = Rr.report[1];
+    }
+    return VSLAM_OK;
+}
+
+extern "C" {
+
+vslam_status vslam_system_create(const vslam_system_config* config, vslam_system** out) {
+    if (!out || !config) return VSLAM_ERR_INVALID;
+    *out = nullptr;
+    vslam_system* s = new (std::nothrow) vslam_system();
+    if (!s) return VSLAM_ERR_INVALID;
+    const vslam_status st = s->init(config);
+    if (st != VSLAM_OK) { s->release(); delete s; return st; }
+    *out = s;
+    return VSLAM_OK;
+}
+
+void vslam_system_destroy(vslam_system* s) {
+    if (!s) return;
+    s->release();
+    delete s;
+}
+
+vslam_status vslam_system_track_stereo(vslam_system* s, const uint8_t* left, const uint8_t* right, int32_t stride, int32_t on_device,
+                                       int32_t frame_number, const vslam_imu_bucket* imu, double* T_wc_out, vslam_frame_report* report) {
+    if (!s) return VSLAM_ERR_INVALID;
+    return s->track(left, right, stride, on_device != 0, frame_number, imu, T_wc_out, report);
+}
+
+vslam_status vslam_system_wait_mapping(vslam_system* s) {
+    if (!s) return VSLAM_ERR_INVALID;
+    std::unique_lock<std::mutex> lk(s->wMu);
+    s->wCv.wait(lk, [&] { return !s->mappingBusy; });
+    if (s->workerStatus != VSLAM_OK) { set_error("local mapping thread failed: %s", s->workerError); return s->workerStatus; }
+    return VSLAM_OK;
+}
+
+vslam_status vslam_system_counts(vslam_system* s, int32_t* n_keyframes, int32_t* n_map_points, int32_t* n_active, int32_t* n_frames) {
+    if (!s) return VSLAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(s->mapMutex);
+    if (n_keyframes) *n_keyframes = (int)s->keyFrames.size();
+    if (n_map_points) *n_map_points = (int)s->mapPoints.size();
+    if (n_active) *n_active = (int)s->active.size();
+    if (n_frames) *n_frames = (int)s->allFrames.size();
+    return VSLAM_OK;
+}
+
+vslam_status vslam_system_keyframes(vslam_system* s, int32_t cap, int32_t* n_out, int32_t* frame_idx, double* poses_wc) {
+    if (!s || !n_out) return VSLAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(s->mapMutex);
+    const int n = (int)s->keyFrames.size();
+    *n_out = n;
+    if (n > cap) return VSLAM_ERR_CAPACITY;
+    for (int k = 0; k < n; k++) {
+        if (frame_idx) frame_idx[k] = s->keyFrames[k].frameIdx;
+        if (poses_wc) memcpy(poses_wc + 16 * (size_t)k, s->keyFrames[k].pose.data(), 16 * sizeof(double));
+    }
+    return VSLAM_OK;
+}
+
+vslam_status vslam_system_last_frame(vslam_system* s, int32_t cap, int32_t* n_out, int32_t* matches, uint8_t* mps_outliers) {
+    if (!s || !n_out) return VSLAM_ERR_INVALID;
+    const int n = (int)s->lastOutliers.size();
+    *n_out = n;
+    if (n > cap) return VSLAM_ERR_CAPACITY;
+    if (matches && n) memcpy(matches, s->lastMatches.data(), (size_t)n * 8);
+    if (mps_outliers && n) memcpy(mps_outliers, s->lastOutliers.data(), n);
+    return VSLAM_OK;
+}
+
+// VSlamSystem::saveTrajectoryAndPosition (src/System.cpp:87-124) over allFramesPoses
+vslam_status vslam_system_save_trajectory(vslam_system* s, const char* path_trajectory, const char* path_positions) {
+    if (!s || !path_trajectory) return VSLAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(s->mapMutex);
+    const int n = (int)s->allFrames.size();
+    std::vector<uint8_t> isKf(std::max(n, 1));
+    std::vector<double> por((size_t)std::max(n, 1) * 16);
+    for (int i = 0; i < n; i++) {
+        const SysFrame& f = s->allFrames[i];
+        isKf[i] = f.isKF;
+        const M4& T = f.isKF ? s->keyFrames[f.kf].pose : f.refPose;
+        memcpy(&por[16 * (size_t)i], T.data(), 16 * sizeof(double));
+    }
+    return vslam_save_trajectory(path_trajectory, path_positions, n, isKf.data(), por.data());
+}
+
+}  // extern "C"

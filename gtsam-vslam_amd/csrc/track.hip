@@ -428,6 +428,46 @@ vslam_status vslam_matcher::track_set_map(const double* xyz, const uint8_t* desc
     return VSLAM_OK;
 }
 
+// activeMapPoints of the closed loop (vslam_system): pinned host arrays -> the tracker's device arrays, asynchronously on
+// the matcher's stream (the previous frame has completed: every tracking call ends with a stream synchronisation)
+vslam_status vslam_matcher::track_upload_map(const double* xyz, const uint8_t* desc, const float* msd, int n) {
+    VS_HIP(hipSetDevice(device));
+    VS_CHECK(ensure_track_cap(std::max(n, 1)));
+    if (n) {
+        VS_HIP(hipMemcpyAsync(d_trXyz, xyz, (size_t)n * 24, hipMemcpyHostToDevice, stream));
+        VS_HIP(hipMemcpyAsync(d_trDesc, desc, (size_t)n * 32, hipMemcpyHostToDevice, stream));
+        VS_HIP(hipMemcpyAsync(d_trMsd, msd, (size_t)n * 4, hipMemcpyHostToDevice, stream));
+        VS_HIP(hipMemsetAsync(d_trOutlier, 0, (size_t)n, stream));
+    }
+    int* hc = (int*)(h_res + 56);                       // (pinned; slot of the result block no kernel writes)
+    hc[0] = n;
+    VS_HIP(hipMemcpyAsync(d_trCount, hc, sizeof(int), hipMemcpyHostToDevice, stream));
+    trNub = n; trN = n;
+    return VSLAM_OK;
+}
+
+// per-frame state of the tracking block for the closed loop, one synchronisation: matches (M x 2 int), source index of
+// every active point (M int), matchedIdxsL (nL int), MPsOutliers (M), inFrame after PredictMPsPosition (M), left
+// visibility under the predicted pose of all N uploaded points - packed in this order into `dst` (pinned)
+vslam_status vslam_matcher::track_fetch_state(uint8_t* dst, int M, int nL, int N) {
+    VS_HIP(hipSetDevice(device));
+    const size_t pc = (size_t)poseCap;
+    uint8_t* p = dst;
+    if (M) VS_HIP(hipMemcpyAsync(p, d_matches, (size_t)M * 8, hipMemcpyDeviceToHost, stream));
+    p += (size_t)M * 8;
+    if (M) VS_HIP(hipMemcpyAsync(p, d_trAct, (size_t)M * 4, hipMemcpyDeviceToHost, stream));
+    p += (size_t)M * 4;
+    if (nL) VS_HIP(hipMemcpyAsync(p, d_matchedL, (size_t)nL * 4, hipMemcpyDeviceToHost, stream));
+    p += (size_t)nL * 4;
+    if (M) VS_HIP(hipMemcpyAsync(p, d_flags + 3 * pc, M, hipMemcpyDeviceToHost, stream));
+    p += M;
+    if (M) VS_HIP(hipMemcpyAsync(p, d_flags, M, hipMemcpyDeviceToHost, stream));
+    p += M;
+    if (N) VS_HIP(hipMemcpyAsync(p, d_trVisL, N, hipMemcpyDeviceToHost, stream));
+    VS_HIP(hipStreamSynchronize(stream));
+    return VSLAM_OK;
+}
+
 extern "C" {
 
 vslam_status vslam_tracker_init_map(vslam_matcher* m, const double* T_wc) {

@@ -716,3 +716,101 @@ def calc_descriptors(desc_lists, device=0):
     best = np.full(max(len(desc_lists), 1), -1, np.int32)
     _chk(lib().vslam_calc_descriptors(_p(descs), _p(start), len(desc_lists), int(device), _p(best)))
     return best[:len(desc_lists)]
+
+
+# ---- closed loop: vslam_system (VSlamSystem::TrackStereo[IMU] + the optimizer thread) ---------------------------------
+class SystemConfig(C.Structure):
+    _fields_ = [("fe", FeParams), ("rig", Rig), ("device", C.c_int32), ("use_imu", C.c_int32), ("local_mapping", C.c_int32),
+                ("window", C.c_int32), ("T_wc_init", C.c_double * 16), ("gravity", C.c_double * 3),
+                ("gyro_noise_density", C.c_double), ("gyro_random_walk", C.c_double), ("accel_noise_density", C.c_double),
+                ("accel_random_walk", C.c_double), ("T_body_sensor", C.c_double * 16), ("imu_hz", C.c_int32),
+                ("velocity_init", C.c_double * 3)]
+
+
+class ImuBucket(C.Structure):
+    _fields_ = [("n", C.c_int32), ("acceleration", C.c_void_p), ("angular_velocity", C.c_void_p), ("timestamps_ns", C.c_void_p)]
+
+
+class FrameReport(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("frame", "keyframe_inserted", "n_active", "n_inliers", "n_stereo", "rounds", "lm_iterations",
+                                         "n_keyframes", "n_map_points", "n_active_after", "mapping_ran", "new_points", "ba_keyframes",
+                                         "ba_local", "ba_landmarks", "ba_pairs", "ba_wrong", "ba_outliers")] + [("ba_report", LmReport * 2)]
+
+
+class System:
+    """vslam_system: one stereo (+ IMU) session with its map, tracker and local mapper."""
+
+    def __init__(self, rig, nfeatures, T0=None, imu=None, local_mapping=1, window=10, device=0, nlevels=8, scale=1.2):
+        self.L = lib()
+        cfg = SystemConfig()
+        cfg.fe = FeParams(nfeatures, nlevels, scale, 19, 31, 20, 7)
+        cfg.rig = make_rig(rig)
+        cfg.device = device; cfg.local_mapping = local_mapping; cfg.window = window
+        if T0 is not None:
+            cfg.T_wc_init = (C.c_double * 16)(*np.asarray(T0, np.float64).reshape(16))
+        if imu is not None:     # dict(gravity, noise=(gyro density, gyro walk, acc density, acc walk), T_bs, hz)
+            cfg.use_imu = 1
+            cfg.gravity = (C.c_double * 3)(*imu["gravity"])
+            cfg.gyro_noise_density, cfg.gyro_random_walk, cfg.accel_noise_density, cfg.accel_random_walk = imu["noise"]
+            cfg.T_body_sensor = (C.c_double * 16)(*np.asarray(imu["T_bs"], np.float64).reshape(16))
+            cfg.imu_hz = int(imu["hz"])
+            if "velocity" in imu:
+                cfg.velocity_init = (C.c_double * 3)(*imu["velocity"])
+        self.w, self.h = rig["w"], rig["h"]
+        self.h_sys = C.c_void_p()
+        _chk(self.L.vslam_system_create(C.byref(cfg), C.byref(self.h_sys)))
+
+    def close(self):
+        if self.h_sys:
+            self.L.vslam_system_destroy(self.h_sys)
+            self.h_sys = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def track(self, left, right, frame_number, imu_bucket=None, on_device=False, stride=None):
+        """left / right: u8 arrays (host) or device pointers (on_device).  imu_bucket: (acc (n,3), gyro (n,3), timestamps_ns (n))."""
+        T = np.zeros((4, 4))
+        rep = FrameReport()
+        b = None
+        keep = []
+        if imu_bucket is not None:
+            acc, gyr, ts = (np.ascontiguousarray(a, np.float64) for a in imu_bucket)
+            keep = [acc, gyr, ts]
+            b = ImuBucket(len(ts), _p(acc), _p(gyr), _p(ts))
+        if on_device:
+            lp, rp, st = C.c_void_p(left), C.c_void_p(right), stride or self.w
+        else:
+            left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8)
+            keep += [left, right]
+            lp, rp, st = _p(left), _p(right), left.shape[1]
+        _chk(self.L.vslam_system_track_stereo(self.h_sys, lp, rp, st, int(on_device), int(frame_number),
+                                              C.byref(b) if b is not None else None, _p(T), C.byref(rep)))
+        d = {f[0]: getattr(rep, f[0]) for f in FrameReport._fields_ if f[0] != "ba_report"}
+        d["ba_report"] = [dict(iterations=r.iterations, inner=r.inner_iterations, initialError=r.initial_error,
+                               finalError=r.final_error, lam=r.lam) for r in rep.ba_report]
+        return T, d
+
+    def wait_mapping(self):
+        _chk(self.L.vslam_system_wait_mapping(self.h_sys))
+
+    def counts(self):
+        v = [C.c_int32() for _ in range(4)]
+        _chk(self.L.vslam_system_counts(self.h_sys, *[C.byref(x) for x in v]))
+        return dict(keyframes=v[0].value, map_points=v[1].value, active=v[2].value, frames=v[3].value)
+
+    def keyframes(self, cap=4096):
+        n = C.c_int32(); fi = np.zeros(cap, np.int32); P = np.zeros((cap, 4, 4))
+        _chk(self.L.vslam_system_keyframes(self.h_sys, cap, C.byref(n), _p(fi), _p(P)))
+        return fi[:n.value].copy(), P[:n.value].copy()
+
+    def last_frame(self, cap=65536):
+        n = C.c_int32(); mt = np.zeros((cap, 2), np.int32); ol = np.zeros(cap, np.uint8)
+        _chk(self.L.vslam_system_last_frame(self.h_sys, cap, C.byref(n), _p(mt), _p(ol)))
+        return mt[:n.value].copy(), ol[:n.value].copy()
+
+    def save_trajectory(self, path, path_positions=None):
+        _chk(self.L.vslam_system_save_trajectory(self.h_sys, path.encode(), path_positions.encode() if path_positions else None))

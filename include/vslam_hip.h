@@ -535,6 +535,73 @@ vslam_status vslam_tracker_set_map(vslam_matcher* m, const double* xyz, const ui
 vslam_status vslam_tracker_fetch(vslam_matcher* m, int32_t* matches, uint8_t* mps_outliers,
                                  int32_t* active_index, int32_t cap, int32_t* n_active);
 
+/* ---------------------------------------------------------------------------
+ * The closed loop behind one handle - what VSlamSystem wires together (include/System.h:28-35, src/System.cpp:6-85):
+ *   vslam_system_track_stereo  = VSlamSystem::TrackStereo / TrackStereoIMU -> FeatureTracker::TrackImage
+ *                                (include/FeatureTracker.h:87-96, src/FeatureTracker.cpp:1108-1278): changePosesLCA when a
+ *                                local BA has finished, extraction + stereo match, removeOutOfFrameMPs, the match / pose
+ *                                retry loop, refinement, the keyframe rule (:1262) with insertKeyFrame (:743-842) or
+ *                                addFrame, updatePoses, setActiveOutliers;
+ *   the optimizer thread       = LocalMapper::beginLocalMapping (include/OptimizationBA.h:54-87, src/OptimizationBA.cpp:
+ *                                955-982): getConnectedKFs window, findNewPoints, localBA on THAT window, write-back,
+ *                                LBADone hand-over.  local_mapping = 2 runs it on its own host thread like the reference
+ *                                (results arrive whenever it finishes); 1 runs it to completion right after the frame that
+ *                                inserted the keyframe (reproducible runs); 0 disables it.
+ * Map / KeyFrame / MapPoint live inside the handle (index-based records); every numerical stage is a kernel of this
+ * library.  Images: u8, `stride` bytes per row, host pointers (on_device = 0) or device pointers (1).
+ * ------------------------------------------------------------------------- */
+typedef struct vslam_system vslam_system;
+
+typedef struct vslam_system_config {
+    vslam_fe_params fe;
+    vslam_rig rig;
+    int32_t device;
+    int32_t use_imu;              /* 0: slamMode 1 (stereo), 1: slamMode 0 (stereo + IMU: the IMU branch of estimatePoseGTSAM) */
+    int32_t local_mapping;        /* 0 off, 1 synchronous, 2 own thread */
+    int32_t window;               /* actvKFMaxSize (include/OptimizationBA.h:46); 0 = 10, at most 16 */
+    double T_wc_init[16];         /* zedPtr->mCameraPose at start, row-major; all zero = identity (the reference) */
+    /* IMU constants (Camera::mIMUGravity, IMUData noise terms, Camera::TBodyToCam, IMUData::mHz) */
+    double gravity[3];
+    double gyro_noise_density, gyro_random_walk, accel_noise_density, accel_random_walk;
+    double T_body_sensor[16];
+    int32_t imu_hz;
+    double velocity_init[3];      /* Camera::mVelocity at start (zero in the reference) */
+} vslam_system_config;
+
+/* the IMU samples between the previous frame and this one (IMUData filled in src/VIOSlam.cpp:238-272) */
+typedef struct vslam_imu_bucket {
+    int32_t n;
+    const double* acceleration;       /* n x 3 */
+    const double* angular_velocity;   /* n x 3 */
+    const double* timestamps_ns;      /* n */
+} vslam_imu_bucket;
+
+typedef struct vslam_frame_report {
+    int32_t frame, keyframe_inserted;
+    int32_t n_active;                 /* activeMpsTemp.size() after removeOutOfFrameMPs */
+    int32_t n_inliers, n_stereo;      /* pair returned by the frame's last estimatePoseGTSAM */
+    int32_t rounds, lm_iterations;
+    int32_t n_keyframes, n_map_points, n_active_after;
+    /* local mapping that completed since the previous report (synchronous mode: the one this frame triggered) */
+    int32_t mapping_ran, new_points, ba_keyframes, ba_local, ba_landmarks, ba_pairs, ba_wrong, ba_outliers;
+    vslam_lm_report ba_report[2];
+} vslam_frame_report;
+
+vslam_status vslam_system_create(const vslam_system_config* config, vslam_system** out);
+void vslam_system_destroy(vslam_system* sys);
+vslam_status vslam_system_track_stereo(vslam_system* sys, const uint8_t* left, const uint8_t* right, int32_t stride,
+                                       int32_t on_device, int32_t frame_number, const vslam_imu_bucket* imu,
+                                       double* T_wc_out, vslam_frame_report* report);
+/* blocks until the optimizer thread (local_mapping = 2) is idle; reports its failure, if any */
+vslam_status vslam_system_wait_mapping(vslam_system* sys);
+/* VSlamSystem::saveTrajectoryAndPosition (src/System.cpp:87-124) over the frames tracked so far */
+vslam_status vslam_system_save_trajectory(vslam_system* sys, const char* path_trajectory, const char* path_positions);
+/* test taps: sizes of the map; keyframe poses (world <- camera) and frame indices; matchesIdxs / MPsOutliers of the last frame */
+vslam_status vslam_system_counts(vslam_system* sys, int32_t* n_keyframes, int32_t* n_map_points, int32_t* n_active,
+                                 int32_t* n_frames);
+vslam_status vslam_system_keyframes(vslam_system* sys, int32_t cap, int32_t* n_out, int32_t* frame_idx, double* poses_wc);
+vslam_status vslam_system_last_frame(vslam_system* sys, int32_t cap, int32_t* n_out, int32_t* matches, uint8_t* mps_outliers);
+
 /* device time per kernel group since the previous call (summed over launches; read-and-reset) */
 vslam_status vslam_matcher_timings(const vslam_matcher* m, const char** names, float* ms,
                                    int32_t cap, int32_t* n_out);

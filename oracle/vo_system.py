@@ -593,7 +593,8 @@ class System:
             for c, (l, r) in mp.kFMatches.items():
                 if l < 0 or c.keys["depth"][l] <= 0:
                     continue
-                z = c.poseInv[2, 0] * mp.wp[0] + c.poseInv[2, 1] * mp.wp[1] + c.poseInv[2, 2] * mp.wp[2] + c.poseInv[2, 3] * 1.0
+                Ti = rigid_inv(c.pose)         # (the stage function inverts the keyframe pose in the rigid form)
+                z = Ti[2, 0] * mp.wp[0] + Ti[2, 1] * mp.wp[1] + Ti[2, 2] * mp.wp[2] + Ti[2, 3] * 1.0
                 c.keys["depth"][l] = F32(z)
                 if z <= float(F32(self.rig["bl"]) * F32(40)):
                     c.keys["close"][l] = 1

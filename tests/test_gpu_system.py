@@ -1,0 +1,114 @@
+"""Sequence-level GPU parity of the closed tracking <-> local-mapping loop (vslam_system: TrackImage with the keyframe rule
+and insertKeyFrame, covisibility window, findNewPoints, localBA on the tracker's own window, write-back, changePosesLCA)
+against the oracle's restatement of the same loop (oracle/vo_system.py), frame by frame on rendered stereo sequences:
+identical keyframe decisions, active-set sizes, inlier counts, match tables, map sizes, window and BA statistics; poses to 1e-7.
+And the accuracy statement: with local mapping the trajectory error is not worse than without."""
+import numpy as np
+import pytest
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _imu_setup(oracle):
+    G = (0.0, 9.81, 0.0); NOISE = (1.6968e-4, 1.9393e-5, 2.0e-3, 3.0e-3)
+    prm = oracle.imu_params(G, NOISE[0], NOISE[2], NOISE[1], NOISE[3], synth.T_BC1)
+    return dict(prm=prm), dict(gravity=G, noise=NOISE, T_bs=synth.T_BC1, hz=200)
+
+
+def _run(oracle, capi, rig_name, nfeat, frames, use_imu=False, local_mapping=True):
+    import vo_system
+    rig = synth.RIGS[rig_name]
+    T0 = synth.pose_at(frames[0], rig["fps"])
+    oimu, gimu = _imu_setup(oracle) if use_imu else (None, None)
+    if use_imu:                              # start with the true velocity (the reference starts from a standstill)
+        h = 1e-4
+        v0 = (synth.pose_at(frames[0] + h * rig["fps"], rig["fps"])[:3, 3] - synth.pose_at(frames[0] - h * rig["fps"], rig["fps"])[:3, 3]) / (2 * h)
+        gimu["velocity"] = v0
+    ref = vo_system.System(rig, nfeat, T0=T0, imu=oimu, local_mapping=local_mapping)
+    got = capi.System(rig, nfeat, T0=T0, imu=gimu, local_mapping=1 if local_mapping else 0)
+    if use_imu:
+        ref.velocity = v0.copy()
+    out = []
+    for n, f in enumerate(frames):
+        L, R, T = synth.stereo_frame(f, rig_name)
+        bucket_o = bucket_g = None
+        if use_imu and n > 0:
+            S, dts, _ = synth.imu_samples(frames[n - 1], f, rig["fps"], noise_seed=0x1A00 + f)
+            bucket_o = (S, dts)
+            bucket_g = (S[:, :3], S[:, 3:], np.arange(len(dts)) * 5e6)
+        Pr = ref.track(L, R, n, imu_bucket=bucket_o)
+        Pg, rep = got.track(L, R, n, imu_bucket=bucket_g)
+        out.append((f, T, Pr, Pg, ref.log[-1], rep, got.last_frame() if n > 0 else None))
+    return ref, got, out
+
+
+def _check(ref, got, out, pose_tol=1e-7):
+    nBA = 0
+    for (f, T, Pr, Pg, lg, rep, last) in out:
+        assert bool(rep["keyframe_inserted"]) == bool(lg["keyframe"]), f
+        assert np.abs(Pg - Pr).max() < pose_tol, (f, np.abs(Pg - Pr).max())
+        if last is None:
+            continue
+        assert (rep["n_active"], rep["n_inliers"], rep["n_stereo"], rep["rounds"]) == (lg["nActive"], lg["nIn"], lg["nStereo"], lg["rounds"]), f
+        assert np.array_equal(last[0], lg["matches"]) and np.array_equal(last[1], lg["outliers"]), f
+        m = lg.get("mapping")
+        assert bool(rep["mapping_ran"]) == (m is not None), f
+        if m is not None:
+            nBA += 1
+            assert (rep["new_points"], rep["ba_keyframes"], rep["ba_local"], rep["ba_landmarks"], rep["ba_pairs"], rep["ba_wrong"], rep["ba_outliers"]) == \
+                   (m["new_points"], m["n_kf"], m["n_local"], m["n_lm"], m["n_pairs"], m["n_wrong"], m["n_outlier"]), (f, rep, m)
+            for s in range(2):
+                assert (rep["ba_report"][s]["iterations"], rep["ba_report"][s]["inner"]) == (m["reports"][s]["iterations"], m["reports"][s]["inner"])
+                assert abs(rep["ba_report"][s]["finalError"] - m["reports"][s]["finalError"]) <= 1e-6 * max(1.0, m["reports"][s]["finalError"])
+    c = got.counts()
+    assert (c["keyframes"], c["map_points"], c["active"]) == (len(ref.keyFrames), len(ref.mapPoints), len(ref.active))
+    fi, P = got.keyframes()
+    assert list(fi) == [k.frameIdx for k in ref.keyFrames]
+    for k, kf in enumerate(ref.keyFrames):
+        assert np.abs(P[k] - kf.pose).max() < pose_tol
+    return nBA
+
+
+def test_closed_loop_parity_stereo(oracle, capi, tmp_path):
+    """EuRoC rig, every second rendered frame (the larger inter-frame motion makes keyframes - and local BAs - frequent)."""
+    frames = list(range(0, 56, 2))
+    ref, got, out = _run(oracle, capi, "euroc", 1500, frames)
+    nBA = _check(ref, got, out)
+    assert nBA >= 1 and len(ref.keyFrames) >= 4
+    # the whole trajectory through the reference's writer, scored against ground truth
+    import trajectory as tj
+    p = str(tmp_path / "traj.txt")
+    got.save_trajectory(p)
+    est = tj.read_kitti(p)
+    gt = np.stack([o[1] for o in out])
+    assert len(est) == len(gt)
+    assert tj.ate_rmse(est, gt) < 0.01
+
+
+def test_closed_loop_parity_stereo_imu(oracle, capi):
+    """C2: the same loop with the CombinedImuFactor in every pose solve (bias chained from solve to solve as in the reference)."""
+    frames = list(range(0, 24))
+    ref, got, out = _run(oracle, capi, "euroc", 1500, frames, use_imu=True)
+    _check(ref, got, out, pose_tol=1e-6)
+    assert np.abs(out[-1][3] - out[-1][1]).max() < 0.02
+
+
+def test_local_mapping_does_not_hurt_accuracy(capi):
+    """ATE with local mapping (new points + local BA on the tracker's own windows) <= ATE of pure tracking on the same frames."""
+    import trajectory as tj
+    rig = synth.RIGS["euroc"]
+    frames = list(range(0, 70, 2))
+    ates = []
+    for lm in (1, 0):
+        s = capi.System(rig, 1500, T0=synth.pose_at(frames[0]), local_mapping=lm)
+        est, gt, nba = [], [], 0
+        for n, f in enumerate(frames):
+            L, R, T = synth.stereo_frame(f)
+            P, rep = s.track(L, R, n)
+            est.append(P); gt.append(T); nba += rep["mapping_ran"]
+        ates.append(tj.ate_rmse(np.stack(est), np.stack(gt)))
+        if lm:
+            assert nba >= 2
+    print("ATE with local mapping %.5f m, without %.5f m" % tuple(ates))
+    assert ates[0] <= ates[1] * 1.05 + 1e-4
