@@ -130,6 +130,11 @@ struct vslam_system {
     std::vector<int> lastMatches; std::vector<uint8_t> lastOutliers;
     vslam_frame_report lastMapping{};  // mapping fields of the most recent local-mapping pass
     std::atomic<bool> mappingReportFresh{false};
+    // per-kernel-group device time (HIP events), summed since the last read; BA groups are collected on the thread that runs it
+    std::atomic<int> timingOn{0};
+    std::mutex tMu;
+    std::vector<std::pair<const char*, float>> baTimes;
+    int baTimedCalls = 0;
     // pinned staging
     uint8_t* h_up = nullptr; size_t upCap = 0;
     uint8_t* h_dn = nullptr; size_t dnCap = 0;
@@ -591,6 +596,8 @@ vslam_status vslam_system::track(const uint8_t* L, const uint8_t* R, int stride,
         out.ba_local = lastMapping.ba_local; out.ba_landmarks = lastMapping.ba_landmarks; out.ba_pairs = lastMapping.ba_pairs;
         out.ba_wrong = lastMapping.ba_wrong; out.ba_outliers = lastMapping.ba_outliers;
         out.ba_report[0] = lastMapping.ba_report[0]; out.ba_report[1] = lastMapping.ba_report[1];
+        out.ba_residuals = lastMapping.ba_residuals; out.ba_free_kf = lastMapping.ba_free_kf; out.ba_sum_k2 = lastMapping.ba_sum_k2;
+        out.ba_trials = lastMapping.ba_trials;
         mappingReportFresh = false;
     }
     if (rep) *rep = out;
@@ -812,7 +819,21 @@ vslam_status vslam_system::local_ba(const std::vector<int>& actKeyF) {
     std::vector<uint8_t> wrong(std::max(NP, 1), 0), wrong1(std::max(NP, 1), 0);
     vslam_ba_result Rr{};
     Rr.kf_pose_wc = kfOut.data(); Rr.lm_xyz = lmOut.data(); Rr.pair_wrong = wrong.data(); Rr.pair_wrong_pass1 = wrong1.data();
+    vslam_local_ba_set_timing(timingOn.load());
     VS_CHECK(vslam_local_ba(&P, &Rr, cfg.device, nullptr));
+    if (timingOn.load()) {
+        const char* nm[32]; float ms[32]; int n = 0;
+        if (vslam_local_ba_timings(nm, ms, 32, &n) == VSLAM_OK) {
+            std::lock_guard<std::mutex> lk(tMu);
+            baTimedCalls++;
+            for (int i = 0; i < n; i++) {
+                size_t j = 0;
+                for (; j < baTimes.size(); j++) if (!strcmp(baTimes[j].first, nm[i])) break;
+                if (j == baTimes.size()) baTimes.push_back({nm[i], 0.f});
+                baTimes[j].second += ms[i];
+            }
+        }
+    }
     // ---- write-back (:875-938) -----------------------------------------------------------------------------------------
     {
         std::lock_guard<std::mutex> lk(mapMutex);
@@ -886,6 +907,8 @@ vslam_status vslam_system::local_ba(const std::vector<int>& actKeyF) {
         lastMapping.ba_keyframes = K; lastMapping.ba_local = (int)local.size(); lastMapping.ba_landmarks = Lm; lastMapping.ba_pairs = NP;
         lastMapping.ba_wrong = nWrong; lastMapping.ba_outliers = nOut;
         lastMapping.ba_report[0] = Rr.report[0]; lastMapping.ba_report[1] = Rr.report[1];
+        lastMapping.ba_residuals = (int)Rr.n_residuals; lastMapping.ba_free_kf = (int)Rr.n_free_kf; lastMapping.ba_sum_k2 = (int)Rr.sum_k2;
+        lastMapping.ba_trials = Rr.report[0].inner_iterations + Rr.report[1].inner_iterations;
     }
     return VSLAM_OK;
 }
@@ -953,6 +976,30 @@ vslam_status vslam_system_last_frame(vslam_system* s, int32_t cap, int32_t* n_ou
     if (n > cap) return VSLAM_ERR_CAPACITY;
     if (matches && n) memcpy(matches, s->lastMatches.data(), (size_t)n * 8);
     if (mps_outliers && n) memcpy(mps_outliers, s->lastOutliers.data(), n);
+    return VSLAM_OK;
+}
+
+vslam_status vslam_system_set_timing(vslam_system* s, int32_t on) {
+    if (!s) return VSLAM_ERR_INVALID;
+    s->timingOn = on ? 1 : 0;
+    VS_CHECK(vslam_extractor_set_timing(s->fe, on));
+    return vslam_matcher_set_timing(s->fm, on);
+}
+
+// device time per kernel group of the LAST frame (extraction, matching / tracking) and, summed over the local BAs that
+// finished since the previous call, of the BA groups (ba_calls_out of them); read-and-reset
+vslam_status vslam_system_timings(vslam_system* s, const char** names, float* ms, int32_t cap, int32_t* n_out, int32_t* ba_calls_out) {
+    if (!s || !n_out || !names || !ms) return VSLAM_ERR_INVALID;
+    int n = 0, k = 0;
+    VS_CHECK(vslam_extractor_timings(s->fe, names, ms, cap, &k));
+    n = k;
+    VS_CHECK(vslam_matcher_timings(s->fm, names + n, ms + n, cap - n, &k));
+    n += k;
+    std::lock_guard<std::mutex> lk(s->tMu);
+    for (auto& b : s->baTimes) if (n < cap) { names[n] = b.first; ms[n] = b.second; n++; }
+    if (ba_calls_out) *ba_calls_out = s->baTimedCalls;
+    s->baTimes.clear(); s->baTimedCalls = 0;
+    *n_out = n;
     return VSLAM_OK;
 }
 

@@ -323,7 +323,7 @@ T_BC1 = np.array([[0.0148655429818, -0.999880929698, 0.00414029679422, -0.021640
 IMU_NOISE = dict(gyro_density=1.6968e-04, gyro_walk=1.9393e-05, acc_density=2.0e-3, acc_walk=3.0e-3, hz=200)
 
 
-def imu_samples(t0, t1, fps=20.0, hz=200, T_bs=T_BC1, gravity=(0.0, 9.81, 0.0), noise_seed=None, bias=None):
+def imu_samples(t0, t1, fps=20.0, hz=200, T_bs=T_BC1, gravity=(0.0, 9.81, 0.0), noise_seed=None, bias=None, pose_fn=None):
     """IMU samples (acc, gyro in the SENSOR frame) strictly between frame times t0 < t1 (in frame units), generated
     from the pose_at() spline by central differences; returns (samples [n,6], dts [n]) with the reference's dt rule
     (dt_i = t_{i+1} - t_i, the last sample reuses the previous dt; src/FeatureTracker.cpp:338-353)."""
@@ -334,7 +334,8 @@ def imu_samples(t0, t1, fps=20.0, hz=200, T_bs=T_BC1, gravity=(0.0, 9.81, 0.0), 
     Rbs, tbs = T_bs[:3, :3], T_bs[:3, 3]
     for s in ts:
         f = s * fps
-        Tm, T0, Tp = pose_at(f - h * fps, fps), pose_at(f, fps), pose_at(f + h * fps, fps)
+        pf = pose_fn if pose_fn is not None else pose_at
+        Tm, T0, Tp = pf(f - h * fps, fps), pf(f, fps), pf(f + h * fps, fps)
         R = T0[:3, :3]
         Rdot = (Tp[:3, :3] - Tm[:3, :3]) / (2 * h)
         Wm = R.T @ Rdot

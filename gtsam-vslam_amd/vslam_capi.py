@@ -734,7 +734,8 @@ class ImuBucket(C.Structure):
 class FrameReport(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("frame", "keyframe_inserted", "n_active", "n_inliers", "n_stereo", "rounds", "lm_iterations",
                                          "n_keyframes", "n_map_points", "n_active_after", "mapping_ran", "new_points", "ba_keyframes",
-                                         "ba_local", "ba_landmarks", "ba_pairs", "ba_wrong", "ba_outliers")] + [("ba_report", LmReport * 2)]
+                                         "ba_local", "ba_landmarks", "ba_pairs", "ba_wrong", "ba_outliers", "ba_residuals", "ba_free_kf",
+                                         "ba_sum_k2", "ba_trials")] + [("ba_report", LmReport * 2)]
 
 
 class System:
@@ -814,3 +815,91 @@ class System:
 
     def save_trajectory(self, path, path_positions=None):
         _chk(self.L.vslam_system_save_trajectory(self.h_sys, path.encode(), path_positions.encode() if path_positions else None))
+
+
+# ---- vslam_fleet: S sessions on S library threads ------------------------------------------------------------------------
+class FleetSequence(C.Structure):
+    _fields_ = [("n_frames", C.c_int32), ("left", C.c_void_p), ("right", C.c_void_p), ("stride", C.c_int32), ("on_device", C.c_int32),
+                ("imu_forward", C.c_void_p), ("imu_backward", C.c_void_p), ("T_wc_true", C.c_void_p), ("velocity_true", C.c_void_p)]
+
+
+class FleetReport(C.Structure):
+    _fields_ = [("n_sessions", C.c_int32)] + [(n, C.c_int64) for n in ("frames", "keyframes", "mappings", "new_points", "ba_landmarks",
+                                                                      "ba_pairs", "ba_residuals", "ba_free_kf", "ba_sum_k2", "ba_trials", "ba_iterations",
+                                                                      "sum_inliers", "sum_rounds", "lost_frames")] + \
+               [("min_inliers", C.c_int32), ("seconds", C.c_double), ("max_session_seconds", C.c_double),
+                ("max_position_error", C.c_double), ("sum_sq_position_error", C.c_double)]
+
+
+def system_config(rig, nfeatures, imu=None, local_mapping=2, window=10, device=0, nlevels=8, scale=1.2):
+    cfg = SystemConfig()
+    cfg.fe = FeParams(nfeatures, nlevels, scale, 19, 31, 20, 7)
+    cfg.rig = make_rig(rig)
+    cfg.device = device; cfg.local_mapping = local_mapping; cfg.window = window
+    if imu is not None:
+        cfg.use_imu = 1
+        cfg.gravity = (C.c_double * 3)(*imu["gravity"])
+        cfg.gyro_noise_density, cfg.gyro_random_walk, cfg.accel_noise_density, cfg.accel_random_walk = imu["noise"]
+        cfg.T_body_sensor = (C.c_double * 16)(*np.asarray(imu["T_bs"], np.float64).reshape(16))
+        cfg.imu_hz = int(imu["hz"])
+    return cfg
+
+
+class Fleet:
+    """S independent sessions replaying one stereo sequence (device or pinned-host image pointers) as a ping-pong."""
+
+    def __init__(self, cfg, n_sessions, left_ptrs, right_ptrs, stride, on_device, poses=None, velocities=None,
+                 imu_forward=None, imu_backward=None):
+        self.L = lib()
+        n = len(left_ptrs)
+        self._keep = []
+        seq = FleetSequence()
+        seq.n_frames = n; seq.stride = stride; seq.on_device = int(on_device)
+        la = (C.c_void_p * n)(*left_ptrs); ra = (C.c_void_p * n)(*right_ptrs)
+        self._keep += [la, ra]
+        seq.left = C.cast(la, C.c_void_p); seq.right = C.cast(ra, C.c_void_p)
+
+        def buckets(lst):
+            arr = (ImuBucket * n)()
+            for i, b in enumerate(lst):
+                if b is None:
+                    continue
+                acc, gyr, ts = (np.ascontiguousarray(a, np.float64) for a in b)
+                self._keep += [acc, gyr, ts]
+                arr[i] = ImuBucket(len(ts), _p(acc), _p(gyr), _p(ts))
+            self._keep.append(arr)
+            return C.cast(arr, C.c_void_p)
+
+        if imu_forward is not None:
+            seq.imu_forward = buckets(imu_forward); seq.imu_backward = buckets(imu_backward)
+        if poses is not None:
+            P = np.ascontiguousarray(poses, np.float64).reshape(n, 16); self._keep.append(P); seq.T_wc_true = _p(P)
+        if velocities is not None:
+            V = np.ascontiguousarray(velocities, np.float64).reshape(n, 3); self._keep.append(V); seq.velocity_true = _p(V)
+        self.h = C.c_void_p()
+        _chk(self.L.vslam_fleet_create(C.byref(cfg), int(n_sessions), C.byref(seq), C.byref(self.h)))
+        self.n_sessions = n_sessions
+
+    def run(self, n_steps):
+        rep = FleetReport()
+        _chk(self.L.vslam_fleet_run(self.h, int(n_steps), C.byref(rep)))
+        return {f[0]: getattr(rep, f[0]) for f in FleetReport._fields_}
+
+    def set_sampling(self, every):
+        _chk(self.L.vslam_fleet_set_sampling(self.h, int(every)))
+
+    def timings(self):
+        names = (C.c_char_p * 64)(); ms = (C.c_float * 64)(); n = C.c_int32(); cnt = (C.c_int64 * 3)()
+        _chk(self.L.vslam_fleet_timings(self.h, names, ms, 64, C.byref(n), cnt))
+        return {names[i].decode(): float(ms[i]) for i in range(n.value)}, dict(frames=cnt[0], solves=cnt[1], ba=cnt[2])
+
+    def close(self):
+        if self.h:
+            self.L.vslam_fleet_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -584,6 +584,7 @@ typedef struct vslam_frame_report {
     int32_t n_keyframes, n_map_points, n_active_after;
     /* local mapping that completed since the previous report (synchronous mode: the one this frame triggered) */
     int32_t mapping_ran, new_points, ba_keyframes, ba_local, ba_landmarks, ba_pairs, ba_wrong, ba_outliers;
+    int32_t ba_residuals, ba_free_kf, ba_sum_k2, ba_trials;   /* work figures of that local BA (vslam_ba_result), lambda trials of both passes */
     vslam_lm_report ba_report[2];
 } vslam_frame_report;
 
@@ -601,6 +602,56 @@ vslam_status vslam_system_counts(vslam_system* sys, int32_t* n_keyframes, int32_
                                  int32_t* n_frames);
 vslam_status vslam_system_keyframes(vslam_system* sys, int32_t cap, int32_t* n_out, int32_t* frame_idx, double* poses_wc);
 vslam_status vslam_system_last_frame(vslam_system* sys, int32_t cap, int32_t* n_out, int32_t* matches, uint8_t* mps_outliers);
+
+/* per-kernel-group HIP-event timing of a session: extraction and tracking groups of the LAST frame, local-BA groups summed
+ * over the ba_calls local BAs that completed since the previous read */
+vslam_status vslam_system_set_timing(vslam_system* sys, int32_t on);
+vslam_status vslam_system_timings(vslam_system* sys, const char** names, float* ms, int32_t cap, int32_t* n_out, int32_t* ba_calls_out);
+
+/* ---------------------------------------------------------------------------
+ * vslam_fleet - the frame driver inside the library: S independent sessions (vslam_system each: own rig / sequence, map,
+ * tracker, optimizer thread) on S host threads sharing one GPU.  Replaces the frame loop of the reference's main()
+ * (src/VIOSlam.cpp:289-316) for throughput runs: the path has no cross-sequence exchange, sessions are
+ * the unit that fills the chip.  The sequence is a set of stereo pairs resident in HBM (on_device = 1) or in host memory
+ * (0: every frame pays its host-to-device copy inside the step); a session replays it as a ping-pong (0..n-1, n-2..0, ...),
+ * i.e. one continuous camera motion of any length - map, keyframes and local BAs are the tracker's own.
+ * ------------------------------------------------------------------------- */
+typedef struct vslam_fleet vslam_fleet;
+
+typedef struct vslam_fleet_sequence {
+    int32_t n_frames;
+    const void* const* left;              /* n_frames image pointers (u8, `stride` bytes per row) */
+    const void* const* right;
+    int32_t stride;
+    int32_t on_device;
+    const vslam_imu_bucket* imu_forward;  /* [n_frames] samples between frame i-1 and i (entry 0 unused); IMU mode only */
+    const vslam_imu_bucket* imu_backward; /* [n_frames] samples of the reversed motion from frame i+1 to i (last unused) */
+    const double* T_wc_true;              /* [n_frames][16] ground-truth poses: a session starts at the pose of its first frame;
+                                             the run reports the position error against them (may be NULL without IMU) */
+    const double* velocity_true;          /* [n_frames][3] forward-motion velocity at each frame (IMU mode start value; may be NULL) */
+} vslam_fleet_sequence;
+
+typedef struct vslam_fleet_report {
+    int32_t n_sessions;
+    int64_t frames, keyframes, mappings, new_points, ba_landmarks, ba_pairs;   /* summed over sessions */
+    int64_t ba_residuals, ba_free_kf, ba_sum_k2, ba_trials, ba_iterations;
+    int64_t sum_inliers, sum_rounds, lost_frames;                               /* lost: fewer than 50 inliers after the frame */
+    int32_t min_inliers;
+    double seconds, max_session_seconds;
+    double max_position_error, sum_sq_position_error;                           /* against T_wc_true */
+} vslam_fleet_report;
+
+vslam_status vslam_fleet_create(const vslam_system_config* config, int32_t n_sessions, const vslam_fleet_sequence* sequence,
+                                vslam_fleet** out);
+void vslam_fleet_destroy(vslam_fleet* fleet);
+/* every session tracks its next n_steps frames; returns when all of them - and every local BA they triggered - are done */
+vslam_status vslam_fleet_run(vslam_fleet* fleet, int32_t n_steps, vslam_fleet_report* report);
+vslam_status vslam_fleet_system(vslam_fleet* fleet, int32_t session, vslam_system** out);
+/* HIP-event timing of session 0 on every `every`-th frame (0 = off; two event records per launch are a real cost on this
+ * launch-bound path); timings: per kernel group the device milliseconds summed over the sampled frames, counts3 =
+ * {sampled frames, pose solves in them, local BAs timed}; read-and-reset */
+vslam_status vslam_fleet_set_sampling(vslam_fleet* fleet, int32_t every);
+vslam_status vslam_fleet_timings(vslam_fleet* fleet, const char** names, float* ms, int32_t cap, int32_t* n_out, int64_t* counts3);
 
 /* device time per kernel group since the previous call (summed over launches; read-and-reset) */
 vslam_status vslam_matcher_timings(const vslam_matcher* m, const char** names, float* ms,

@@ -20,6 +20,27 @@ def build():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
 
+def use_native_build():
+    """bench.py's cpu_baseline leg: the same sources built -O3 -march=native -ffp-contract=off FOR THE MACHINE IT RUNS ON
+    (SURVEY section 8d), into a scratch directory; must be called before the first lib() use of the process."""
+    global _LIB
+    import tempfile
+    assert _LIB is None, "use_native_build() must come before any other oracle call"
+    d = os.path.join(tempfile.gettempdir(), "vslam_oracle_native_%d" % os.getuid())
+    os.makedirs(d, exist_ok=True)
+    so = os.path.join(d, "liboracle_native.so")
+    srcs = sorted(os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.startswith("vo_") and f.endswith(".cpp"))
+    subprocess.check_call(["g++", "-O3", "-march=native", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-shared",
+                           "-o", so] + srcs + ["-lm", "-lpthread"])
+    _LIB = C.CDLL(so)
+    _LIB.vo_extractor_create.restype = C.c_void_p
+    _LIB.vo_extractor_create.argtypes = [C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int]
+    _LIB.vo_fast_atan2.restype = C.c_float
+    _LIB.vo_fast_atan2.argtypes = [C.c_float, C.c_float]
+    _LIB.vo_orientation.restype = C.c_float
+    return so
+
+
 def lib():
     global _LIB
     if _LIB is None:
