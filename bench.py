@@ -26,10 +26,10 @@ import os
 import sys
 import time
 
-# Every session uses 3 HIP streams (extractor, matcher, IMU side stream) + the optimizer thread's; the HIP runtime multiplexes
-# streams onto 4 hardware queues by default, which serialises independent sessions behind each other's single-workgroup
-# kernels.  Must be set before the runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+# Measured with tools/launchrate.hip: at most ~4 kernels of different streams run concurrently on this part, and asking
+# the runtime for more hardware queues only slows the launch path (22-38 us per launch at 8 threads with 32 queues).
+# 4 is the runtime's default; stated here so that the environment cannot silently change it.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "gtsam-vslam_amd"))
@@ -59,6 +59,22 @@ def level_pixels(w, h, nlevels=8, scale=1.2):
     return px
 
 
+def _render_one(a):
+    import synth
+    return synth.stereo_frame(a[0], a[1])
+
+
+def render_frames(idx, rig_name):
+    """the rendered stereo pairs (about two seconds per pair on one core; numpy releases the GIL): spread over threads.
+    Threads, not processes: under a profiler the GPU is initialised before main() and a fork would inherit it."""
+    from concurrent.futures import ThreadPoolExecutor
+    n = min(len(idx), max(1, (os.cpu_count() or 2) // max(int(os.environ.get("WORLD_SIZE", "1")), 1)), 16)
+    if n <= 1:
+        return [_render_one((f, rig_name)) for f in idx]
+    with ThreadPoolExecutor(n) as pool:
+        return list(pool.map(_render_one, [(f, rig_name) for f in idx]))
+
+
 def make_sequence(cfg, n_frames, step, rank):
     """n_frames rendered stereo pairs `step` source frames apart, ground truth, velocities, IMU buckets of both directions."""
     import synth
@@ -66,7 +82,7 @@ def make_sequence(cfg, n_frames, step, rank):
     fps = rig["fps"]
     f0 = 7 * rank
     idx = [f0 + step * j for j in range(n_frames)]
-    frames = [synth.stereo_frame(f, cfg["rig"]) for f in idx]
+    frames = render_frames(idx, cfg["rig"])
     poses = np.stack([fr[2] for fr in frames])
     h = 1e-4
     vel = np.stack([(synth.pose_at(f + h * fps, fps)[:3, 3] - synth.pose_at(f - h * fps, fps)[:3, 3]) / (2 * h) for f in idx])
@@ -182,18 +198,23 @@ def main():
     ap.add_argument("--mapping", type=int, default=2, help="local mapping: 2 = optimizer thread per session (reference), 1 = synchronous, 0 = off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency-line", action="store_true", help="skip the extra single-session run")
+    ap.add_argument("--sweep", default="", help="comma-separated session counts: throughput of each in the \"sweep\" field (one process, same frames)")
     ap.add_argument("--c5-landmarks", type=int, default=100000)
     ap.add_argument("--c5-steps", type=int, default=5)
     ap.add_argument("--c5-warmup", type=int, default=1)
     args = ap.parse_args()
 
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    seq = None
+    if args.config != "c5":      # rendered before torch / HIP start (the renderer forks worker processes)
+        seq = make_sequence(CONFIGS[args.config], args.frames, args.frame_step, rank)
+
     import torch
     import torch.distributed as dist
     import vslam_capi as vc
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     # VSLAM_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow with several ranks on ONE GPU (RCCL refuses two
     # ranks on the same device); the driver's runs use nccl (= RCCL), one rank per GPU
     backend = os.environ.get("VSLAM_BENCH_BACKEND", "nccl")
@@ -221,7 +242,7 @@ def main():
         return
 
     cfg = CONFIGS[args.config]
-    rig, frames, poses, vel, fwd, bwd = make_sequence(cfg, args.frames, args.frame_step, rank)
+    rig, frames, poses, vel, fwd, bwd = seq
     w, h = rig["w"], rig["h"]
     if args.host_images:
         bufs = [(torch.from_numpy(L).pin_memory(), torch.from_numpy(R).pin_memory()) for (L, R, _) in frames]
@@ -271,6 +292,25 @@ def main():
         latency = {"sessions": 1, "frames_per_s": n1 / e1, "ms_per_frame": 1e3 * e1 / n1, "keyframes": r1["keyframes"], "local_bas": r1["mappings"],
                    "note": "one session alone on the GPU: the per-frame latency of the closed loop (same workload, same threads)"}
         f1.close()
+
+    sweep = []
+    if rank == 0 and args.sweep:
+        try:
+            fleet.close()
+        except Exception:      # noqa: BLE001
+            pass
+        for Sx in [int(v) for v in args.sweep.split(",") if v]:
+            fx = make_fleet(Sx)
+            fx.run(max(5, args.warmup // 2))
+            torch.cuda.synchronize()
+            nx = max(20, min(args.steps, 4000 // Sx))
+            tx = time.perf_counter()
+            rx = fx.run(nx)
+            torch.cuda.synchronize()
+            ex = time.perf_counter() - tx
+            sweep.append({"sessions": Sx, "frames_per_s": Sx * nx / ex, "ms_per_step": 1e3 * ex / nx, "keyframes": rx["keyframes"],
+                          "local_bas": rx["mappings"], "lost_frames": rx["lost_frames"], "max_session_s": rx["max_session_seconds"]})
+            fx.close()
 
     c5 = None
     if world > 1 and not os.environ.get("VSLAM_BENCH_SKIP_C5"):
@@ -381,6 +421,8 @@ def main():
                                                 "(6F)^3/3 flops per candidate - << 1 % of the fp64 MFMA peak by construction"}
         if latency:
             out["latency_single_session"] = latency
+        if sweep:
+            out["sweep"] = sweep
         if c5 is not None:
             out["c5_sharded_ba"] = c5
         if not args.no_cpu_baseline and world == 1:

@@ -1886,7 +1886,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         // released when the owning host thread ends (or switches device): a short-lived optimizer thread must not
         // leak its stream, pinned buffers and pool threads
         ~Workspace() {
-            if (device < 0 || hipSetDevice(device) != hipSuccess) return;
+            if (device < 0 || exiting_main_thread() || hipSetDevice(device) != hipSuccess) return;
             if (stream) { hipStreamSynchronize(stream); hipStreamDestroy(stream); }
             for (void* p : {(void*)d_pose0.p, (void*)d_poseS.p, (void*)d_lm0.p, (void*)d_lmS.p, (void*)d_facJ.p, (void*)d_S.p, (void*)d_Spart.p,
                             (void*)d_Sedge.p, (void*)d_dP.p, (void*)d_dL.p, (void*)d_lmDiff.p, (void*)d_sums.p, (void*)d_partial.p, (void*)d_Lg.p,

@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <cstring>
 #include <vector>
+#include <unistd.h>
+#include <sys/syscall.h>
 #include "../../include/vslam_hip.h"
 
 namespace vslam {
@@ -46,6 +48,10 @@ constexpr int MAX_LEVELS = 12;
 // descriptor selection, depth refresh, keyframe pose update).  Blocks go back to the cache instead of hipFree, so the
 // steady state of a session makes no hipMalloc / hipFree / hipStreamCreate call (each of which synchronises the device
 // and would stall every other session sharing the GPU).
+// True in the main thread: its thread_local destructors run during process exit, when a profiler's
+// tool library may already have finalised the runtime; the process's device memory is reclaimed by the driver anyway.
+inline bool exiting_main_thread() { return (long)getpid() == (long)syscall(SYS_gettid); }
+
 struct DevPool {
     struct Blk { void* p; size_t cap; bool used; };
     std::vector<Blk> blks;
@@ -69,7 +75,7 @@ struct DevPool {
         for (auto& b : blks) hipFree(b.p);
         blks.clear();
     }
-    ~DevPool() { release(); }
+    ~DevPool() { if (!exiting_main_thread()) release(); }
 };
 // the calling thread's pool for `device` (switching devices releases the previous pool's blocks)
 inline DevPool* thread_pool(int device) {
