@@ -1,0 +1,502 @@
+// vslam_batch: B independent sequences ("lanes") tracked in lockstep, one kernel launch per stage for ALL lanes.
+//
+// Why: a frame of one sequence is a chain of ~25 small kernels, most of them one workgroup wide (SSC per level, the
+// ordered claim resolution of the projection match, the pose LM, the pre-integration) - it cannot fill 256 CUs, and the
+// part runs at most ~4 kernels of different streams concurrently (tools/launchrate.hip), so independent sessions on
+// their own streams stop scaling at about two sessions' worth.  Here every stage kernel is launched once with the
+// lane as a grid dimension and a per-lane argument table (common.hpp lane_entry): the one-workgroup stages become
+// B-workgroup launches of the same duration.
+//
+// Each lane is a complete vslam_system (system.hpp: the reference's Map / KeyFrame / MapPoint bookkeeping, keyframe rule,
+// local mapping) bound to images 2b / 2b+1 of ONE shared extractor and to the batch's stream.  A step is
+//   host  (thread pool, per lane)  frame_begin, candidate list                      [FeatureTracker::TrackImage :1115-1122]
+//   device                         images -> pyramid, extraction of 2B images, stereo match of B pairs
+//   host  (thread pool, per lane)  upload block: active map points, IMU bucket      (overlaps the extraction)
+//   device                         one H2D, then predict / pre-integrate / project / solve / re-chain / re-predict /
+//                                  project / solve / pack for all lanes, one D2H, one synchronisation
+//   host  (per lane)               retry rule on lanes whose first round failed (their own launches, rare), then
+//   host  (thread pool, per lane)  frame_post: bookkeeping, keyframe insertion, hand-off to the mapping threads
+// Local mapping (find new points + local BA) of a lane runs on one of the batch's few mapping threads, so the number
+// of streams competing for the hardware queues stays small.
+//
+// A lane's results are bit-identical to the same sequence run through a single vslam_system (tests/test_gpu_batch.py):
+// the batched kernels are the one-session kernels' bodies, fed per-lane argument blocks built by the same host code.
+#include "system.hpp"
+#include "pose_dev.hpp"
+#include "imu_dev.hpp"
+#include "track_dev.hpp"
+#include "ba_pool.hpp"
+#include <chrono>
+
+namespace vslam {
+void launch_pose_batch(hipStream_t s, const PoseLane* dLanes, int B);
+void launch_pose_imu_batch(hipStream_t s, const PoseLane* dLanes, int B, int ldsFactors);
+void launch_imu_batch(hipStream_t s, const ImuLane* dLanes, int B);
+}
+
+using namespace vslam;
+using namespace vslam_sys;
+
+namespace {
+inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+}
+
+struct vslam_batch {
+    int B = 0, device = 0;
+    bool useImu = false;
+    vslam_extractor* fe = nullptr;
+    hipStream_t stream = nullptr;
+    std::vector<vslam_system*> sys;
+    // per-lane argument tables of one step: pinned host block + device mirror (one H2D per step)
+    struct Tables {
+        StereoLane* stereo; PredictLane* predict; ImuLane* imu0; ProjLane* proj0; PoseLane* pose0; ImuLane* imu1;
+        RepredictLane* repredict; ProjLane* proj1; PoseLane* pose1; PackLane* pack;
+    } ht{}, dt{};
+    uint8_t* h_tab = nullptr; uint8_t* d_tab = nullptr; size_t tabBytes = 0;
+    uint8_t* h_up = nullptr; uint8_t* d_up = nullptr; size_t upCap = 0;      // upload block (map points, IMU buckets)
+    uint8_t* h_dn = nullptr; uint8_t* d_dn = nullptr; size_t dnCap = 0;      // download block (per-lane tracking state)
+    double* d_res = nullptr; double* h_res = nullptr;                        // [B][64] result blocks
+    uint8_t* d_zero = nullptr; size_t zeroCap = 0;                           // MapPoint::GetIsOutlier of uploaded points: all 0
+    BaPool pool;                                                             // host phases
+    // mapping threads
+    std::vector<std::thread> mapThreads;
+    std::deque<vslam_system*> mapQueue;
+    std::mutex mqMu; std::condition_variable mqCv;
+    bool mqStop = false;
+    // per-step scratch
+    struct LaneStep { bool on = false, first = false, failed = false; vslam_status st = VSLAM_OK; char err[200] = ""; size_t upOff = 0, dnOff = 0; int N = 0, nL = 0, nR = 0; };
+    std::vector<LaneStep> ls;
+    StageTimer timer;
+    // host-side phase times of the last step (seconds): pre, extract enqueue, fill, tables + enqueue, wait, finish, post
+    double phase[8] = {0};
+
+    vslam_status init(const vslam_system_config* cfgs, int n, int hostThreads, int mapThreads);
+    void release();
+    vslam_status ensure_up(size_t bytes);
+    vslam_status ensure_dn(size_t bytes);
+    vslam_status step(const uint8_t* const* L, const uint8_t* const* R, int stride, bool onDevice, const int* frames,
+                      const vslam_imu_bucket* imu, const uint8_t* mask, double* T_wc_out, vslam_frame_report* reps);
+    static void submit_mapping(void* self, vslam_system* s) {
+        vslam_batch* b = (vslam_batch*)self;
+        { std::lock_guard<std::mutex> lk(b->mqMu); b->mapQueue.push_back(s); }
+        b->mqCv.notify_one();
+    }
+    void map_loop() {
+        for (;;) {
+            vslam_system* s = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(mqMu);
+                mqCv.wait(lk, [&] { return mqStop || !mapQueue.empty(); });
+                if (mapQueue.empty()) return;       // (stop requested and nothing left)
+                s = mapQueue.front(); mapQueue.pop_front();
+            }
+            s->run_mapping();
+        }
+    }
+};
+
+vslam_status vslam_batch::init(const vslam_system_config* cfgs, int n, int hostThreads, int nMapThreads) {
+    if (!cfgs || n <= 0 || n > 256) { set_error("vslam_batch: 1..256 lanes"); return VSLAM_ERR_INVALID; }
+    B = n; device = cfgs[0].device; useImu = cfgs[0].use_imu != 0;
+    for (int b = 1; b < B; b++) {
+        const vslam_system_config& c = cfgs[b];
+        if (c.device != device || (c.use_imu != 0) != useImu || memcmp(&c.rig, &cfgs[0].rig, sizeof(c.rig)) || memcmp(&c.fe, &cfgs[0].fe, sizeof(c.fe)) ||
+            c.local_mapping != cfgs[0].local_mapping) {
+            set_error("vslam_batch: lanes must share device, rig, extractor parameters, IMU mode and mapping mode");
+            return VSLAM_ERR_INVALID;
+        }
+    }
+    VS_HIP(hipSetDevice(device));
+    VS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    timer.stream = stream; timer.multi = true;
+    VS_CHECK(vslam_extractor_create(&cfgs[0].fe, cfgs[0].rig.width, cfgs[0].rig.height, 2 * B, device, &fe));
+    VS_HIP(hipMalloc(&d_res, (size_t)B * 64 * sizeof(double)));
+    VS_HIP(vslam::memset_sync(d_res, 0, (size_t)B * 64 * sizeof(double)));
+    VS_HIP(hipHostMalloc(&h_res, (size_t)B * 64 * sizeof(double), hipHostMallocDefault));
+    sys.assign(B, nullptr);
+    ls.assign(B, LaneStep{});
+    for (int b = 0; b < B; b++) {
+        vslam_system* s = new (std::nothrow) vslam_system();
+        if (!s) return VSLAM_ERR_INVALID;
+        sys[b] = s;
+        VS_CHECK(s->init(&cfgs[b], fe, 2 * b, stream));
+        vslam_matcher* m = s->fm;
+        m->resExternal = true;
+        m->d_res = d_res + (size_t)b * 64; m->h_res = h_res + (size_t)b * 64;
+        m->d_poseIO = m->d_res; m->imuIo = m->d_res + 32; m->d_poseOut = (int*)(m->d_res + 48); m->d_trCount = (int*)(m->d_res + 52);
+        m->trExternal = true;
+        s->mapExec = &vslam_batch::submit_mapping; s->mapExecArg = this;
+    }
+    // argument tables
+    size_t off = 0;
+    auto place = [&](size_t elem) { const size_t o = off; off = up256(off + elem * (size_t)B); return o; };
+    const size_t oStereo = place(sizeof(StereoLane)), oPredict = place(sizeof(PredictLane)), oImu0 = place(sizeof(ImuLane)),
+                 oProj0 = place(sizeof(ProjLane)), oPose0 = place(sizeof(PoseLane)), oImu1 = place(sizeof(ImuLane)),
+                 oRep = place(sizeof(RepredictLane)), oProj1 = place(sizeof(ProjLane)), oPose1 = place(sizeof(PoseLane)), oPack = place(sizeof(PackLane));
+    tabBytes = off;
+    VS_HIP(hipHostMalloc((void**)&h_tab, tabBytes, hipHostMallocDefault));
+    VS_HIP(hipMalloc((void**)&d_tab, tabBytes));
+    memset(h_tab, 0, tabBytes);
+    auto bindT = [&](Tables& t, uint8_t* base) {
+        t.stereo = (StereoLane*)(base + oStereo); t.predict = (PredictLane*)(base + oPredict); t.imu0 = (ImuLane*)(base + oImu0);
+        t.proj0 = (ProjLane*)(base + oProj0); t.pose0 = (PoseLane*)(base + oPose0); t.imu1 = (ImuLane*)(base + oImu1);
+        t.repredict = (RepredictLane*)(base + oRep); t.proj1 = (ProjLane*)(base + oProj1); t.pose1 = (PoseLane*)(base + oPose1);
+        t.pack = (PackLane*)(base + oPack);
+    };
+    bindT(ht, h_tab); bindT(dt, d_tab);
+    if (hostThreads < 0) hostThreads = std::min(B, 8);
+    if (hostThreads > 1) pool.start(hostThreads - 1);
+    if (cfgs[0].local_mapping == 2) {
+        if (nMapThreads <= 0) nMapThreads = std::min(B, 3);
+        for (int t = 0; t < nMapThreads; t++) mapThreads.emplace_back([this]() { map_loop(); });
+    }
+    return VSLAM_OK;
+}
+
+void vslam_batch::release() {
+    // sessions first (each waits for its mapping job), then the mapping threads, then the shared objects
+    for (vslam_system* s : sys) if (s) { s->release(); delete s; }
+    sys.clear();
+    { std::lock_guard<std::mutex> lk(mqMu); mqStop = true; }
+    mqCv.notify_all();
+    for (auto& t : mapThreads) t.join();
+    mapThreads.clear();
+    if (stream) hipStreamSynchronize(stream);
+    timer.destroy();
+    if (fe) vslam_extractor_destroy(fe);
+    fe = nullptr;
+    hipFree(d_res); hipFree(d_tab); hipFree(d_up); hipFree(d_dn); hipFree(d_zero);
+    if (h_res) hipHostFree(h_res);
+    if (h_tab) hipHostFree(h_tab);
+    if (h_up) hipHostFree(h_up);
+    if (h_dn) hipHostFree(h_dn);
+    if (stream) hipStreamDestroy(stream);
+    stream = nullptr;
+}
+
+vslam_status vslam_batch::ensure_up(size_t bytes) {
+    if (bytes <= upCap) return VSLAM_OK;
+    VS_HIP(hipStreamSynchronize(stream));
+    if (h_up) hipHostFree(h_up);
+    hipFree(d_up);
+    upCap = bytes + bytes / 2;
+    VS_HIP(hipHostMalloc((void**)&h_up, upCap, hipHostMallocDefault));
+    VS_HIP(hipMalloc((void**)&d_up, upCap));
+    return VSLAM_OK;
+}
+vslam_status vslam_batch::ensure_dn(size_t bytes) {
+    if (bytes <= dnCap) return VSLAM_OK;
+    VS_HIP(hipStreamSynchronize(stream));
+    if (h_dn) hipHostFree(h_dn);
+    hipFree(d_dn);
+    dnCap = bytes + bytes / 2;
+    VS_HIP(hipHostMalloc((void**)&h_dn, dnCap, hipHostMallocDefault));
+    VS_HIP(hipMalloc((void**)&d_dn, dnCap));
+    return VSLAM_OK;
+}
+
+#define LANE_TRY(expr)                                                                                  \
+    do {                                                                                                \
+        vslam_status s_ = (expr);                                                                       \
+        if (s_ != VSLAM_OK) { q.st = s_; q.failed = true; snprintf(q.err, sizeof(q.err), "%s", vslam_last_error()); return; } \
+    } while (0)
+
+vslam_status vslam_batch::step(const uint8_t* const* L, const uint8_t* const* R, int stride, bool onDevice, const int* frames,
+                               const vslam_imu_bucket* imu, const uint8_t* mask, double* T_wc_out, vslam_frame_report* reps) {
+    if (!L || !R || !frames || !T_wc_out) return VSLAM_ERR_INVALID;
+    VS_HIP(hipSetDevice(device));
+    using clk = std::chrono::steady_clock;
+    auto t0 = clk::now();
+    auto lap = [&](int k) { const auto t1 = clk::now(); phase[k] = std::chrono::duration<double>(t1 - t0).count(); t0 = t1; };
+    int nOn = 0;
+    for (int b = 0; b < B; b++) {
+        LaneStep& q = ls[b];
+        q = LaneStep{};
+        q.on = !mask || mask[b];
+        if (!q.on) continue;
+        if (!L[b] || !R[b]) { set_error("vslam_batch: lane %d has no images", b); return VSLAM_ERR_INVALID; }
+        q.first = frames[b] == 0;
+        nOn++;
+    }
+    if (!nOn) return VSLAM_OK;
+    auto first_error = [&]() -> vslam_status {
+        for (int b = 0; b < B; b++) if (ls[b].failed) { set_error("lane %d: %s", b, ls[b].err); return ls[b].st; }
+        return VSLAM_OK;
+    };
+
+    // ---- host: frame_begin + candidate lists --------------------------------------------------------------------------------
+    pool.run(B, [&](int b) {
+        LaneStep& q = ls[b];
+        if (!q.on) return;
+        hipSetDevice(device);
+        vslam_system* s = sys[b];
+        LANE_TRY(s->frame_begin(s->ctx, frames[b], imu ? &imu[b] : nullptr));
+        if (!q.first) q.N = s->frame_candidates(s->ctx);
+    });
+    VS_CHECK(first_error());
+    lap(0);
+
+    // ---- device: images, extraction ------------------------------------------------------------------------------------------
+    for (int b = 0; b < B; b++) {
+        if (!ls[b].on) continue;
+        VS_CHECK(fe->set_image_async(2 * b, L[b], stride, onDevice));
+        VS_CHECK(fe->set_image_async(2 * b + 1, R[b], stride, onDevice));
+    }
+    if (!onDevice) VS_HIP(hipStreamSynchronize(fe->stream));      // callers may reuse their buffers
+    VS_CHECK(fe->run());
+    lap(1);
+
+    // ---- host, under the extraction: the upload block -----------------------------------------------------------------------
+    size_t upBytes = 0;
+    for (int b = 0; b < B; b++) {
+        LaneStep& q = ls[b];
+        if (!q.on || q.first) continue;
+        q.upOff = upBytes;
+        const int n = std::max(q.N, 1);
+        upBytes += up256((size_t)n * 24) + up256((size_t)n * 32) + up256((size_t)n * 4);
+        if (useImu) upBytes += up256((size_t)(7 * std::max(imu ? imu[b].n : 0, 0) + 6) * sizeof(double));
+    }
+    VS_CHECK(ensure_up(std::max<size_t>(upBytes, 256)));
+    {
+        size_t zneed = 0;
+        for (int b = 0; b < B; b++) zneed = std::max(zneed, (size_t)ls[b].N);
+        if (zneed > zeroCap) {
+            VS_HIP(hipStreamSynchronize(stream));
+            hipFree(d_zero);
+            zeroCap = up256(zneed + zneed / 2 + 1024);
+            VS_HIP(hipMalloc((void**)&d_zero, zeroCap));
+            VS_HIP(vslam::memset_sync(d_zero, 0, zeroCap));
+        }
+    }
+    pool.run(B, [&](int b) {
+        LaneStep& q = ls[b];
+        if (!q.on || q.first) return;
+        vslam_system* s = sys[b];
+        vslam_matcher* m = s->fm;
+        const int n = std::max(q.N, 1);
+        uint8_t* h = h_up + q.upOff;
+        uint8_t* d = d_up + q.upOff;
+        const size_t oDesc = up256((size_t)n * 24), oMsd = oDesc + up256((size_t)n * 32), oImu = oMsd + up256((size_t)n * 4);
+        s->frame_fill_upload(s->ctx, (double*)h, h + oDesc, (float*)(h + oMsd));
+        m->track_bind_map((double*)d, d + oDesc, (float*)(d + oMsd), d_zero, q.N);
+        if (useImu) {
+            s->frame_imu_input(s->ctx);
+            LANE_TRY(m->imu_stage(&s->ctx.in, 0.0, (double*)(h + oImu), (double*)(d + oImu), ht.imu0[b]));
+        }
+    });
+    VS_CHECK(first_error());
+    if (upBytes) VS_HIP(hipMemcpyAsync(d_up, h_up, upBytes, hipMemcpyHostToDevice, stream));
+    lap(2);
+
+    // ---- keys of the new frames (waits for the extraction's totals) -----------------------------------------------------------
+    VS_HIP(hipStreamWaitEvent(stream, fe->evDone, 0));
+    VS_CHECK(fe->wait_counts());
+    int maxL = 0, maxR = 0, maxN = 0, nTrack = 0, ldsFactors = 0;
+    size_t dnBytes = 0;
+    for (int b = 0; b < B; b++) {
+        LaneStep& q = ls[b];
+        if (!q.on) continue;
+        vslam_matcher* m = sys[b]->fm;
+        VS_CHECK(m->refresh_keys(false));
+        q.nL = m->nKeys[0]; q.nR = m->nKeys[1];
+        maxL = std::max(maxL, q.nL); maxR = std::max(maxR, q.nR);
+        if (q.first) continue;
+        nTrack++;
+        maxN = std::max(maxN, std::max(q.N, 1));
+        q.dnOff = dnBytes;
+        dnBytes += up256((size_t)std::max(q.N, 1) * 15 + (size_t)q.nL * 4 + 16);
+    }
+    VS_CHECK(ensure_dn(std::max<size_t>(dnBytes, 256)));
+
+    // ---- per-lane argument tables ---------------------------------------------------------------------------------------------
+    for (int b = 0; b < B; b++) {
+        LaneStep& q = ls[b];
+        StereoLane& S = ht.stereo[b];
+        if (!q.on) { S.A.nL = 0; S.A.nR = 0; }
+        else VS_CHECK(sys[b]->fm->stereo_lane(S));
+        if (q.on) sys[b]->fm->stereoDone = true;
+        const bool tr = q.on && !q.first;
+        vslam_matcher* m = sys[b]->fm;
+        if (!tr) {
+            // idle lanes: every kernel's lane test fails on these entries (count 0 / gate closed)
+            ht.predict[b] = PredictLane{};
+            ht.predict[b].count = m->d_trCount; ht.predict[b].poseIO = m->d_poseIO + 24;      // (scratch slot of the result block)
+            ht.predict[b].setCount = 1;
+            ht.imu0[b].n = 0; ht.imu1[b].n = 0;
+            ht.proj0[b].A = ProjArgs{}; ht.proj1[b].A = ProjArgs{};
+            ht.proj0[b].A.gate = ht.proj1[b].A.gate = m->d_trCount + 2; ht.proj0[b].A.gateMin = ht.proj1[b].A.gateMin = 1;     // (an int that stays 0)
+            ht.pose0[b].A = PoseArgs{}; ht.pose1[b].A = PoseArgs{};
+            ht.pose0[b].A.gate = ht.pose1[b].A.gate = m->d_trCount + 2; ht.pose0[b].A.gateMin = ht.pose1[b].A.gateMin = 1;
+            ht.repredict[b] = RepredictLane{};
+            ht.pack[b] = PackLane{};
+            ht.pack[b].count = m->d_trCount;
+            continue;
+        }
+        vslam_system* s = sys[b];
+        VS_CHECK(m->track_begin(s->predNPose.data(), frames[b], useImu));
+        const int Nub = std::max(m->trNub, 1);
+        const int* Mdev = m->d_trCount + 1;
+        const int* gate = m->d_poseOut;          // inlier count of the first round
+        const int minIn = vslam_matcher::TRACK_MIN_INLIERS;
+        m->predict_lane(ht.predict[b], 0);
+        ht.predict[b].setCount = 1;
+        m->proj_lane(ht.proj0[b], Nub, m->trRad, Mdev, nullptr, 0, PROJ_STEREO);
+        m->proj_lane(ht.proj1[b], Nub, 4.f, Mdev, gate, minIn, PROJ_STEREO);
+        m->repredict_lane(ht.repredict[b], gate, minIn);
+        if (useImu) {
+            m->pose_imu_lane(ht.pose0[b], Nub, Mdev, nullptr, minIn, 0, 0);
+            m->pose_imu_lane(ht.pose1[b], Nub, Mdev, gate, minIn, 1, 0);
+            m->imu_lane(ht.imu1[b], true);
+            ldsFactors = std::max(ldsFactors, std::max(ht.pose0[b].I.ldsFactors, ht.pose1[b].I.ldsFactors));
+        } else {
+            m->pose_lane(ht.pose0[b].A, Nub, Mdev, nullptr, minIn, 0, 0);
+            m->pose_lane(ht.pose1[b].A, Nub, Mdev, gate, minIn, 1, 0);
+        }
+        PackLane& K = ht.pack[b];
+        K.N = q.N; K.nL = q.nL; K.count = m->d_trCount; K.matches = m->d_matches; K.act = m->d_trAct; K.matchedL = m->d_matchedL;
+        K.flags = m->d_flags; K.flagStride = (size_t)m->poseCap; K.visLeft = m->d_trVisL; K.out = d_dn + q.dnOff;
+    }
+    VS_HIP(hipMemcpyAsync(d_tab, h_tab, tabBytes, hipMemcpyHostToDevice, stream));
+
+    // ---- device: every stage once for all lanes --------------------------------------------------------------------------------
+    int t = timer.begin("stereo");
+    launch_stereo_batch(stream, dt.stereo, B, maxL, maxR);
+    timer.end(t);
+    if (nTrack) {
+        t = timer.begin("track_predict"); launch_track_predict_batch(stream, dt.predict, B); timer.end(t);
+        if (useImu) { t = timer.begin("imu_preintegrate"); launch_imu_batch(stream, dt.imu0, B); timer.end(t); }
+        t = timer.begin("proj_match"); launch_proj_batch(stream, dt.proj0, B, maxN, maxL, maxR); timer.end(t);
+        t = timer.begin("pose_solve");
+        if (useImu) launch_pose_imu_batch(stream, dt.pose0, B, ldsFactors); else launch_pose_batch(stream, dt.pose0, B);
+        timer.end(t);
+        if (useImu) { t = timer.begin("imu_preintegrate"); launch_imu_batch(stream, dt.imu1, B); timer.end(t); }
+        t = timer.begin("track_repredict"); launch_track_repredict_batch(stream, dt.repredict, B, maxN); timer.end(t);
+        t = timer.begin("proj_match"); launch_proj_batch(stream, dt.proj1, B, maxN, maxL, maxR); timer.end(t);
+        t = timer.begin("pose_solve");
+        if (useImu) launch_pose_imu_batch(stream, dt.pose1, B, ldsFactors); else launch_pose_batch(stream, dt.pose1, B);
+        timer.end(t);
+        t = timer.begin("pack"); launch_track_pack_batch(stream, dt.pack, B, maxN); timer.end(t);
+        VS_HIP(hipGetLastError());
+        VS_HIP(hipMemcpyAsync(h_res, d_res, (size_t)B * 64 * sizeof(double), hipMemcpyDeviceToHost, stream));
+        if (dnBytes) VS_HIP(hipMemcpyAsync(h_dn, d_dn, dnBytes, hipMemcpyDeviceToHost, stream));
+    }
+    VS_HIP(hipGetLastError());
+    lap(3);
+    VS_HIP(hipStreamSynchronize(stream));
+    lap(4);
+
+    // ---- host: the reference's retry rule per lane (launches only for lanes whose first round failed) ------------------------
+    std::vector<SysTrackState> st(B);
+    for (int b = 0; b < B; b++) {
+        LaneStep& q = ls[b];
+        if (!q.on || q.first) continue;
+        vslam_system* s = sys[b];
+        vslam_matcher* m = s->fm;
+        SysFrameCtx& c = s->ctx;
+        VS_CHECK(m->track_finish(c.T_cw, &c.tr, useImu ? &c.imuOut : nullptr));
+        const int M = c.tr.n_active, N = q.N, nL = q.nL;
+        uint8_t* p = h_dn + q.dnOff;
+        SysTrackState& v = st[b];
+        if (!m->trRetried) {
+            v.matches = (const int*)p; v.actIdx = v.matches + 2 * (size_t)N; v.matchedL = v.actIdx + N;
+            v.outl = (const uint8_t*)(v.matchedL + nL); v.inF = v.outl + N; v.visL = v.inF + N;
+        } else {
+            // the slice is large enough for the one-session layout (M <= N)
+            VS_CHECK(m->track_fetch_state(p, M, nL, N));
+            v.matches = (const int*)p; p += (size_t)M * 8;
+            v.actIdx = (const int*)p; p += (size_t)M * 4;
+            v.matchedL = (const int*)p; p += (size_t)nL * 4;
+            v.outl = p; p += M;
+            v.inF = p; p += M;
+            v.visL = p;
+        }
+        v.nL = nL;
+    }
+    lap(5);
+
+    // ---- host: frame_post (first frames: the one-session path on their own stereo result) ------------------------------------
+    pool.run(B, [&](int b) {
+        LaneStep& q = ls[b];
+        if (!q.on) return;
+        hipSetDevice(device);
+        vslam_system* s = sys[b];
+        if (q.first) LANE_TRY(s->frame_first(s->ctx, T_wc_out + 16 * (size_t)b, reps ? &reps[b] : nullptr));
+        else LANE_TRY(s->frame_post(s->ctx, st[b], T_wc_out + 16 * (size_t)b, reps ? &reps[b] : nullptr));
+    });
+    VS_CHECK(first_error());
+    lap(6);
+    return VSLAM_OK;
+}
+
+extern "C" {
+
+vslam_status vslam_batch_create(const vslam_system_config* configs, int32_t lanes, int32_t host_threads, int32_t mapping_threads,
+                                vslam_batch** out) {
+    if (!out) return VSLAM_ERR_INVALID;
+    *out = nullptr;
+    vslam_batch* b = new (std::nothrow) vslam_batch();
+    if (!b) return VSLAM_ERR_INVALID;
+    vslam_status s = b->init(configs, lanes, host_threads, mapping_threads);
+    if (s != VSLAM_OK) { b->release(); delete b; return s; }
+    *out = b;
+    return VSLAM_OK;
+}
+
+void vslam_batch_destroy(vslam_batch* b) {
+    if (!b) return;
+    b->release();
+    delete b;
+}
+
+vslam_status vslam_batch_track_stereo(vslam_batch* b, const uint8_t* const* left, const uint8_t* const* right, int32_t stride,
+                                      int32_t on_device, const int32_t* frame_numbers, const vslam_imu_bucket* imu,
+                                      const uint8_t* lane_mask, double* T_wc_out, vslam_frame_report* reports) {
+    if (!b) return VSLAM_ERR_INVALID;
+    return b->step(left, right, stride, on_device != 0, frame_numbers, imu, lane_mask, T_wc_out, reports);
+}
+
+vslam_system* vslam_batch_system(vslam_batch* b, int32_t lane) {
+    if (!b || lane < 0 || lane >= b->B) return nullptr;
+    return b->sys[lane];
+}
+
+int32_t vslam_batch_lanes(const vslam_batch* b) { return b ? b->B : 0; }
+
+vslam_status vslam_batch_wait_mapping(vslam_batch* b) {
+    if (!b) return VSLAM_ERR_INVALID;
+    for (vslam_system* s : b->sys) VS_CHECK(vslam_system_wait_mapping(s));
+    return VSLAM_OK;
+}
+
+vslam_status vslam_batch_set_timing(vslam_batch* b, int32_t on) {
+    if (!b) return VSLAM_ERR_INVALID;
+    b->timer.enabled = on != 0;
+    b->fe->timer.enabled = on != 0;
+    return VSLAM_OK;
+}
+
+// device time per stage (batched launches: all lanes) since the last read, then the host phases of the last step
+vslam_status vslam_batch_timings(vslam_batch* b, const char** names, float* ms, int32_t cap, int32_t* n_out, double* host_phases7) {
+    if (!b || !n_out) return VSLAM_ERR_INVALID;
+    VS_HIP(hipSetDevice(b->device));
+    VS_HIP(hipStreamSynchronize(b->stream));
+    VS_HIP(hipStreamSynchronize(b->fe->stream));
+    const char* nm[64];
+    float tv[64];
+    int n = 0;
+    {
+        const int k = b->fe->timer.read(nm, tv, 64);
+        b->fe->timer.reset();
+        for (int i = 0; i < k && n < cap; i++, n++) { if (names) names[n] = nm[i]; if (ms) ms[n] = tv[i]; }
+    }
+    {
+        const int k = b->timer.read(nm, tv, 64);
+        b->timer.reset();
+        for (int i = 0; i < k && n < cap; i++, n++) { if (names) names[n] = nm[i]; if (ms) ms[n] = tv[i]; }
+    }
+    *n_out = n;
+    if (host_phases7) for (int i = 0; i < 7; i++) host_phases7[i] = b->phase[i];
+    return VSLAM_OK;
+}
+
+}  // extern "C"

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <vector>
+#include <cstdlib>
 #include <unistd.h>
 #include <sys/syscall.h>
 #include "../../include/vslam_hip.h"
@@ -13,6 +14,26 @@
 namespace vslam {
 
 void set_error(const char* fmt, ...);
+
+// hipMemset on device memory returns before the fill has run (it is queued on the null stream), and this library's streams
+// are non-blocking ones that do not order themselves after the null stream: a fill that must precede stream work waits here.
+inline hipError_t memset_sync(void* p, int v, size_t n) {
+    hipError_t e = hipMemset(p, v, n);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    return e;
+}
+
+// Debug aid: vslam_debug_poison(byte) / VSLAM_POISON=<byte> fills every fresh device allocation (and every reused pool
+// block) with that byte, so that a kernel reading memory nobody initialised shows up as a result that changes with the
+// byte (tests/test_gpu_poison.py) instead of as a rare difference that depends on what the allocator hands out.
+int poison_byte();           // -1 = off
+inline hipError_t poison_malloc(void** p, size_t n) {
+    hipError_t e = hipMalloc(p, n);
+    const int pb = poison_byte();
+    if (e == hipSuccess && pb >= 0 && n) e = memset_sync(*p, pb, n);
+    return e;
+}
+template <class T> inline hipError_t poison_malloc(T** p, size_t n) { return poison_malloc((void**)p, n); }
 
 #define VS_HIP(expr)                                                                       \
     do {                                                                                   \
@@ -48,6 +69,15 @@ constexpr int MAX_LEVELS = 12;
 // descriptor selection, depth refresh, keyframe pose update).  Blocks go back to the cache instead of hipFree, so the
 // steady state of a session makes no hipMalloc / hipFree / hipStreamCreate call (each of which synchronises the device
 // and would stall every other session sharing the GPU).
+// Entry `i` of a per-lane argument table of a batched launch (blockIdx = lane).  The table is written by the host before
+// the launch and never by a kernel, so it is addressed through the constant address space: its fields are then fetched
+// with scalar loads on demand, exactly like by-value kernel arguments.
+template <class T>
+__device__ __forceinline__ const T* lane_entry(const T* table, unsigned i) {
+    typedef const T __attribute__((address_space(4))) * CP;
+    return (const T*)(CP)(uintptr_t)(table + i);
+}
+
 // True in the main thread: its thread_local destructors run during process exit, when a profiler's
 // tool library may already have finalised the runtime; the process's device memory is reclaimed by the driver anyway.
 inline bool exiting_main_thread() { return (long)getpid() == (long)syscall(SYS_gettid); }
@@ -62,9 +92,13 @@ struct DevPool {
         int best = -1;
         for (size_t i = 0; i < blks.size(); i++)
             if (!blks[i].used && blks[i].cap >= bytes && (best < 0 || blks[i].cap < blks[best].cap)) best = (int)i;
-        if (best >= 0) { blks[best].used = true; return blks[best].p; }
+        if (best >= 0) {
+            blks[best].used = true;
+            if (poison_byte() >= 0) (void)memset_sync(blks[best].p, poison_byte(), blks[best].cap);    // (reused block: debug aid)
+            return blks[best].p;
+        }
         void* p = nullptr;
-        if (hipMalloc(&p, bytes + bytes / 4) != hipSuccess) return nullptr;
+        if (poison_malloc(&p, bytes + bytes / 4) != hipSuccess) return nullptr;
         blks.push_back({p, bytes + bytes / 4, true});
         return p;
     }
@@ -156,3 +190,5 @@ struct StageTimer {
 };
 
 }  // namespace vslam
+
+#define hipMalloc(p, n) ::vslam::poison_malloc((p), (n))

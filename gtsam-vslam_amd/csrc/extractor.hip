@@ -1,6 +1,7 @@
 // vslam_extractor: host side of the HIP feature extractor (tables, buffers, launch order)
 // and the extraction part of the C ABI (include/vslam_hip.h).
 #include "extractor.hpp"
+#include <atomic>
 #include <algorithm>
 #include <cmath>
 #include <mutex>
@@ -180,8 +181,8 @@ vslam_status vslam_extractor::init(const vslam_fe_params* p, int w, int h, int b
     timer.stream = stream;
     VS_HIP(hipMalloc(&d_pyr, (size_t)nimg * P.imgStride));
     VS_HIP(hipMalloc(&d_blur, (size_t)nimg * P.imgStride));
-    VS_HIP(hipMemset(d_pyr, 0, (size_t)nimg * P.imgStride));
-    VS_HIP(hipMemset(d_blur, 0, (size_t)nimg * P.imgStride));
+    VS_HIP(vslam::memset_sync(d_pyr, 0, (size_t)nimg * P.imgStride));
+    VS_HIP(vslam::memset_sync(d_blur, 0, (size_t)nimg * P.imgStride));
 
     // resize tables
     std::vector<int2> allx, ally;
@@ -259,7 +260,7 @@ vslam_status vslam_extractor::init(const vslam_fe_params* p, int w, int h, int b
     }
     VS_HIP(hipMalloc(&d_taskCount, (size_t)nimg * MAX_LEVELS * sizeof(int) + (size_t)nimg * MAX_LEVELS * 8 * sizeof(long long)));
     VS_HIP(hipMalloc(&d_sscFlags, (size_t)nimg * 2 * sizeof(int)));
-    VS_HIP(hipMemset(d_sscFlags, 0, (size_t)nimg * 2 * sizeof(int)));
+    VS_HIP(vslam::memset_sync(d_sscFlags, 0, (size_t)nimg * 2 * sizeof(int)));
     VS_HIP(hipHostMalloc(&h_counts, (size_t)nimg * 3 * sizeof(int), hipHostMallocMapped));
     VS_HIP(hipHostGetDevicePointer((void**)&d_counts, h_counts, 0));
     memset(h_counts, 0, (size_t)nimg * 3 * sizeof(int));
@@ -306,6 +307,14 @@ vslam_status vslam_extractor::set_image(int idx, const void* src, int stride, bo
     VS_HIP(hipMemcpy2DAsync(d_pyr + (size_t)idx * P.imgStride + P.off[0], P.pitch[0], src, stride, width,
                             height, srcOnDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
     if (!srcOnDevice) VS_HIP(hipStreamSynchronize(stream));  // caller may reuse its buffer
+    return VSLAM_OK;
+}
+
+// batch form: no host synchronisation (the caller synchronises once after queuing all its host images)
+vslam_status vslam_extractor::set_image_async(int idx, const void* src, int stride, bool srcOnDevice) {
+    if (idx < 0 || idx >= nimg || !src || stride < width) { set_error("set_image: bad argument"); return VSLAM_ERR_INVALID; }
+    VS_HIP(hipMemcpy2DAsync(d_pyr + (size_t)idx * P.imgStride + P.off[0], P.pitch[0], src, stride, width,
+                            height, srcOnDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
     return VSLAM_OK;
 }
 
@@ -397,8 +406,21 @@ vslam_status vslam_extractor::run() {
     return VSLAM_OK;
 }
 
+static std::atomic<int> g_poison{-2};      // -2: not read from the environment yet
+int vslam::poison_byte() {
+    int v = g_poison.load(std::memory_order_relaxed);
+    if (v == -2) {
+        const char* e = getenv("VSLAM_POISON");
+        v = e ? ((int)strtol(e, nullptr, 0) & 0xff) : -1;
+        g_poison.store(v);
+    }
+    return v;
+}
+
 // --------------------------------------------------------------------------- C ABI
 extern "C" {
+
+void vslam_debug_poison(int32_t byte) { g_poison.store(byte < 0 ? -1 : (byte & 0xff)); }
 
 const char* vslam_last_error(void) { return vslam::g_err; }
 

@@ -70,5 +70,6 @@ struct vslam_extractor {
     vslam_status init(const vslam_fe_params* p, int w, int h, int batch, int dev);
     void release();
     vslam_status set_image(int idx, const void* src, int stride, bool srcOnDevice);
+    vslam_status set_image_async(int idx, const void* src, int stride, bool srcOnDevice);
     vslam_status run();
 };

@@ -294,4 +294,13 @@ VS_HD void imu_factor_eval(const DNav& pred, const double* biasHat, const double
     for (int i = 0; i < 6; i++) J[(9 + i) * 15 + 9 + i] = -1.0;
 }
 
+// one lane of the batched pre-integration (k_imu_preintegrate_b); takeFrom != null: the bias of the solve that just ran
+// (its io block) becomes the integration bias first (initialBias = b1, src/FeatureTracker.cpp:405)
+struct ImuLane {
+    DImuParams P;
+    const double* samples; const double* dts; int n;
+    double* bias; DPim* pim; double* Lam; DNav si; DNav* pred;
+    const double* takeFrom;
+};
+
 }  // namespace vslam

@@ -3,13 +3,17 @@
 #pragma once
 #include "extractor.hpp"
 
+namespace vslam { struct PoseArgs; struct StereoLane; struct ProjLane; struct PoseLane; struct PredictLane; struct RepredictLane; struct ImuLane; struct PackLane; }
+
 struct vslam_matcher {
     vslam_rig rig{};
     vslam_extractor* feL = nullptr;
     vslam_extractor* feR = nullptr;
     int imgL = 0, imgR = 0;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr; bool ownsStream = true;
+    vslam_status adopt_stream(hipStream_t s);      // run on a stream owned by someone else (vslam_batch: all lanes on one)
+    bool resExternal = false;                      // d_res / h_res are slices of the batch's result block
     vslam::StageTimer timer;
     // "last read of extractor X's buffers" events, one per extractor this matcher has been bound to: recorded after
     // every operation on the currently bound pair, so that only THAT pair's next frame waits for it
@@ -57,6 +61,7 @@ struct vslam_matcher {
     int* d_projOut = nullptr;    // {nMatches}
     vslam_status ensure_proj_cap(int M);
     vslam_status proj_enqueue(int M, float rad, const int* Mdev = nullptr, const int* gate = nullptr, int gateMin = 0, int mode = 0);
+    void proj_lane(vslam::ProjLane& L, int M, float rad, const int* Mdev, const int* gate, int gateMin, int mode);
     bool mono = false;               // created without a right extractor: left-only operations
     vslam_status match_projection(const vslam_mappoint_view* mps, int M, float rad, int* mL, int* mR,
                                   int* matches, int* nMatches, long long* nCand, int mode = 0);
@@ -82,6 +87,11 @@ struct vslam_matcher {
     double imuParams[64] = {0};      // DImuParams of the current frame
     double imuSi[15] = {0}, imuBiasPrev[6] = {0};
     vslam_status imu_setup(const vslam_imu_input* imu, double lastDt = 0.0);
+    vslam_status imu_stage(const vslam_imu_input* imu, double lastDt, double* h, double* dSamples, vslam::ImuLane& L);
+    void imu_lane(vslam::ImuLane& L, bool rechain);
+    double* d_imuStage = nullptr; double* imuSamplesDev = nullptr;   // device mirror of the staged bucket (own or the batch's)
+    void pose_lane(vslam::PoseArgs& A, int M, const int* Mdev, const int* gate, int gateMin, int outSlot, int monoOnly);
+    void pose_imu_lane(vslam::PoseLane& L, int M, const int* Mdev, const int* gate, int gateMin, int outSlot, int monoOnly);
     vslam_status pose_imu_enqueue(int M, const int* Mdev = nullptr, const int* gate = nullptr, int gateMin = 0, int outSlot = 0, int monoOnly = 0);
     double* h_imuStage = nullptr; int imuStageCap = 0;     // pinned upload staging
     // the bucket upload + pre-integration depend on nothing the frame's matching produces: they run on a side stream
@@ -109,9 +119,22 @@ struct vslam_matcher {
     int actN = 0;
     int trNub = 0;                   // host-side upper bound of trN (the real count stays on the device)
     vslam_status ensure_track_cap(int n);
+    bool trExternal = false;
+    void track_bind_map(const double* xyz, const uint8_t* desc, const float* msd, const uint8_t* zeros, int n);
     vslam_status track_init_map(const double* T_wc);
     vslam_status track_frame(const double* T_wc_pred, int frameNumber, double* T_cw_out, vslam_track_report* rep,
                              const vslam_imu_input* imu = nullptr, vslam_imu_output* imuOut = nullptr);
+
+    static constexpr int TRACK_MIN_INLIERS = 50;
+    double trPredInv[16] = {0}; float trRad = 10.f; bool trImu = false, trRetried = false;     // the current frame's constants
+    vslam_status track_begin(const double* T_wc_pred, int frameNumber, bool useImu);
+    void predict_lane(vslam::PredictLane& L, int leftOnly);
+    void repredict_lane(vslam::RepredictLane& L, const int* gate, int gateMin);
+    vslam_status track_solve(const int* g, int slot, bool chain);
+    vslam_status track_refine(const int* g);
+    vslam_status track_fetch_result();
+    vslam_status track_first_pass();
+    vslam_status track_finish(double* T_cw_out, vslam_track_report* rep, vslam_imu_output* imuOut);
 
     vslam_status track_frame_mono(const vslam_imu_input* imu, const double* predVelocity, double fps, double* T_cw_out,
                                   vslam_track_report* rep, vslam_imu_output* imuOut, double* T_wc_pred_out, double* predVelOut);
@@ -122,8 +145,9 @@ struct vslam_matcher {
     vslam_status init(const vslam_rig* r, vslam_extractor* l, int il, vslam_extractor* rr, int ir);
     void release();
     vslam_status ensure_cap(int n);
-    vslam_status refresh_keys();
+    vslam_status refresh_keys(bool waitStream = true);
     vslam_status stereo_match();
+    vslam_status stereo_lane(vslam::StereoLane& L);
 };
 
 namespace vslam {
@@ -139,6 +163,12 @@ struct StereoArgs {
     float baseline;
     int imageHeight;
 };
+struct StereoLane {          // one lane (stereo pair) of the batched stereo kernels
+    StereoArgs A;
+    int* mBest; float* mDepth; int* mSad; unsigned long long* stats;
+    float closeDepth; int* rightIdxs; int* leftIdxs; float* depth; uint8_t* closef;
+};
+void launch_stereo_batch(hipStream_t s, const StereoLane* dLanes, int B, int maxL, int maxR);
 void launch_stereo_match(hipStream_t s, const StereoArgs& A, int* mBest, float* mDepth, int* mSad,
                          unsigned long long* stats);
 void launch_stereo_finalize(hipStream_t s, int nL, int nR, const int* mBest, const float* mDepth,
@@ -157,6 +187,11 @@ struct ProjArgs {
     int mode;            // 0 matchByProjectionRPred, 1 matchByProjectionMono, 2 matchByRadius (left side only in 1 / 2)
 };
 enum { PROJ_STEREO = 0, PROJ_MONO = 1, PROJ_RADIUS = 2 };
+struct ProjLane {            // one lane of the batched projection matching
+    ProjArgs A;
+    int* matches; unsigned long long* topk; unsigned long long* stats; int* matchedL; int* matchedR; int* out;
+};
+void launch_proj_batch(hipStream_t s, const ProjLane* dLanes, int B, int maxM, int maxL, int maxR);
 void launch_proj_candidates(hipStream_t s, const ProjArgs& A, const int* matches,
                             unsigned long long* topk, unsigned long long* stats);
 void launch_proj_resolve(hipStream_t s, const ProjArgs& A, const unsigned long long* topk, int* matchedL, int* matchedR,

@@ -16,7 +16,7 @@
 
 namespace vslam {
 
-__global__ __launch_bounds__(POSE_NT) void k_pose_lm(PoseArgs A) {
+__device__ __forceinline__ void pose_lm_body(const PoseArgs& A) {
     __shared__ double red[(POSE_NT / 64) * 28];
     __shared__ double acc[28];
     __shared__ DPose sCur, sTrial;
@@ -25,12 +25,14 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_lm(PoseArgs A) {
     __shared__ int sPhase, sEval, sIter, sInner, sCnt[2];
     const int tid = threadIdx.x;
     if (A.gate && *A.gate < A.gateMin) return;
-    if (A.Mdev) A.M = min(A.M, *A.Mdev);
+    int M = A.M;
+    if (A.Mdev) M = min(M, *A.Mdev);
+    double* const facs = A.factors;
 
     __shared__ float sLvl[MAX_LEVELS];
     __shared__ int sCntTab[2 * POSE_BATCH * (POSE_NT / 64)];
     pose_stage_levels(A, sLvl);
-    const int nF = pose_build_factors(A, sLvl, sCntTab);
+    const int nF = pose_build_factors(A, M, facs, sLvl, sCntTab);
     if (tid == 0) {
         DPose Tcw;
         pose_from_rm16(A.poseIO, Tcw);
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_lm(PoseArgs A) {
     auto local_error = [&](const DPose& T) {
         double e = 0;
         for (int i = tid; i < nF; i += POSE_NT) {
-            const double* f = A.factors + (size_t)i * 8;
+            const double* f = facs + (size_t)i * 8;
             double r[3];
             pose_factor_eval(f, T, A, r, nullptr);
             e += r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_lm(PoseArgs A) {
             for (int k = 0; k < 28; k++) v[k] = 0;
             const DPose T = sCur;
             for (int i = tid; i < nF; i += POSE_NT) {
-                const double* f = A.factors + (size_t)i * 8;
+                const double* f = facs + (size_t)i * 8;
                 PoseLin L;
                 pose_factor_lin(f, T, A, L);
                 pose_acc_factor(L, v);
@@ -161,8 +163,16 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_lm(PoseArgs A) {
     }
     __syncthreads();
 
-    pose_find_outliers(A, sTcw, sCnt, sLvl);
+    pose_find_outliers(A, M, sTcw, sCnt, sLvl);
     if (tid == 0) { A.out[0] = sCnt[0]; A.out[1] = sCnt[1]; }
+}
+
+__global__ __launch_bounds__(POSE_NT) void k_pose_lm(PoseArgs A) { pose_lm_body(A); }
+// batched form: blockIdx.x = lane
+__global__ __launch_bounds__(POSE_NT) void k_pose_lm_b(const PoseLane* __restrict__ lanes) { pose_lm_body(lane_entry(lanes, blockIdx.x)->A); }
+
+void launch_pose_batch(hipStream_t s, const PoseLane* dLanes, int B) {
+    hipLaunchKernelGGL(k_pose_lm_b, dim3(B), dim3(POSE_NT), 0, s, dLanes);
 }
 
 // worldToFrame for both cameras (src/FeatureTracker.cpp:685-741, src/Map.cpp:13-23)
@@ -222,7 +232,7 @@ vslam_status vslam_matcher::ensure_pose_cap(int M) {
 vslam_status vslam_matcher::ensure_res() {
     if (d_res) return VSLAM_OK;
     VS_HIP(hipMalloc(&d_res, 64 * sizeof(double)));
-    VS_HIP(hipMemset(d_res, 0, 64 * sizeof(double)));
+    VS_HIP(vslam::memset_sync(d_res, 0, 64 * sizeof(double)));
     VS_HIP(hipHostMalloc(&h_res, 64 * sizeof(double), hipHostMallocDefault));
     d_poseIO = d_res;
     imuIo = d_res + 32;
@@ -232,11 +242,12 @@ vslam_status vslam_matcher::ensure_res() {
 }
 
 // device-resident form: d_points / d_flags / d_matches / d_poseIO already hold the inputs
-vslam_status vslam_matcher::pose_enqueue(int M, const int* Mdev, const int* gate, int gateMin, int outSlot) {
+// arguments of one pose solve on this matcher's device-resident buffers
+void vslam_matcher::pose_lane(vslam::PoseArgs& A, int M, const int* Mdev, const int* gate, int gateMin, int outSlot, int monoOnly) {
     uint8_t* fl = d_flags;
     const size_t pc = (size_t)poseCap;
-    PoseArgs A{};
-    A.Mdev = Mdev; A.gate = gate; A.gateMin = gateMin;
+    A = PoseArgs{};
+    A.Mdev = Mdev; A.gate = gate; A.gateMin = gateMin; A.monoOnly = monoOnly;
     A.M = M; A.points = d_points; A.inFrame = fl; A.inFrameR = fl + pc; A.mpOut = fl + 2 * pc; A.mpsOut = fl + 3 * pc;
     A.matches = d_matches; A.kpsL = d_kps[0]; A.kpsR = d_kps[1];
     A.closef = d_close; A.depth = d_depth; A.rightIdxs = d_rightIdxs; A.leftIdxs = d_leftIdxs;
@@ -245,6 +256,12 @@ vslam_status vslam_matcher::pose_enqueue(int M, const int* Mdev, const int* gate
     A.closeTh = rig.baseline * 40;
     A.factors = d_factors; A.firstFail = d_firstFail; A.code = (int*)(fl + 4 * pc); A.poseIO = d_poseIO; A.out = d_poseOut + 4 * outSlot;
     A.maxIterations = 100; A.relTol = 1e-5; A.absTol = 1e-5; A.thres = 7.815;
+}
+
+// device-resident form: d_points / d_flags / d_matches / d_poseIO already hold the inputs
+vslam_status vslam_matcher::pose_enqueue(int M, const int* Mdev, const int* gate, int gateMin, int outSlot) {
+    PoseArgs A;
+    pose_lane(A, M, Mdev, gate, gateMin, outSlot, 0);
     int t = timer.begin("pose_lm");
     hipLaunchKernelGGL(k_pose_lm, dim3(1), dim3(POSE_NT), 0, stream, A);
     timer.end(t);

@@ -29,6 +29,15 @@ struct PoseArgs {
     const int* Mdev; const int* gate; int gateMin;     // device-side control, as in ProjArgs
     int monoOnly;         // estimatePoseGTSAMMono / findOutliersMono: left GenericProjectionFactors only
 };
+struct DPim; struct DNav;
+struct ImuLmArgs {
+    int ldsFactors;          // capacity (factors) of the dynamic LDS buffer
+    const DPim* pim; const double* Lam;
+    const DNav* pred;        // state predicted from (x0, v0, b0) by k_imu_preintegrate
+    const double* biasPrev;  // b0 (device: the integration bias of k_imu_preintegrate)
+    double* io;              // out: vel(3), bias(6)
+};
+struct PoseLane { PoseArgs A; ImuLmArgs I; };      // one lane of the batched pose solves (I unused by the 6-dof kernel)
 
 // whitened residual (and Jacobian rows wrt [omega, v]) of one factor at T (world <- camera)
 __device__ __forceinline__ int pose_factor_eval(const double* f, const DPose& T, const PoseArgs& A,
@@ -195,9 +204,9 @@ __device__ __forceinline__ void pose_stage_levels(const PoseArgs& A, float* lvl)
 // Only about a third of the active map points carry a factor: the list is COMPACTED (map-point order kept, so the
 // block-wide sums downstream stay deterministic) and the LM loops run over nF factors instead of M slots.
 // cntTab: 2 * POSE_BATCH * (POSE_NT / 64) ints of LDS.  Returns nF (the same value in every thread).
-__device__ __forceinline__ int pose_build_factors(const PoseArgs& A, const float* lvl, int* cntTab) {
+__device__ __forceinline__ int pose_build_factors(const PoseArgs& A, int M, double* factors, const float* lvl, int* cntTab) {
     constexpr int NW = POSE_NT / 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, M = A.M;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int run = 0, trip = 0;
     for (int base0 = 0; base0 < M; base0 += POSE_BATCH * POSE_NT, trip++) {
         const int base = base0 + tid;
@@ -256,7 +265,7 @@ __device__ __forceinline__ int pose_build_factors(const PoseArgs& A, const float
 #pragma unroll
         for (int u = 0; u < POSE_BATCH; u++) {
             if (type[u] < 0) continue;
-            double* f = A.factors + (size_t)(offU[u] + pre[u]) * 8;
+            double* f = factors + (size_t)(offU[u] + pre[u]) * 8;
             f[7] = 1.0 / (1.0 / (double)lvl[oct[u]]);
             if (type[u] == 0) { f[4] = kx[u]; f[5] = rx[u]; f[6] = ky[u]; }
             else { f[4] = kx[u]; f[5] = ky[u]; f[6] = 0; }
@@ -269,8 +278,8 @@ __device__ __forceinline__ int pose_build_factors(const PoseArgs& A, const float
 
 // findOutliersR (src/FeatureTracker.cpp:582-649); sCnt = {inliers, stereo} in LDS, zeroed by the caller;
 // every thread of the workgroup calls it
-__device__ __forceinline__ void pose_find_outliers(const PoseArgs& A, const DPose& Tcw, int* sCnt, const float* lvl) {
-    const int tid = threadIdx.x, M = A.M;
+__device__ __forceinline__ void pose_find_outliers(const PoseArgs& A, int M, const DPose& Tcw, int* sCnt, const float* lvl) {
+    const int tid = threadIdx.x;
     for (int base = tid; base < M; base += POSE_BATCH * POSE_NT) {     // pass A0: reset firstFail for touched keypoints
         int first[POSE_BATCH];
 #pragma unroll

@@ -14,10 +14,10 @@ namespace vslam {
 
 constexpr int PIM_CHUNK = 12;        // samples whose step matrices are held in LDS at once (55 KB)
 
-__global__ __launch_bounds__(256) void k_imu_preintegrate(DImuParams P, const double* __restrict__ samples,
-                                                          const double* __restrict__ dts, int n,
-                                                          const double* __restrict__ biasHat, DPim* __restrict__ pimOut,
-                                                          double* __restrict__ Lam, DNav si, DNav* __restrict__ predOut) {
+__device__ __forceinline__ void imu_preintegrate_body(const DImuParams& P, const double* __restrict__ samples,
+                                                      const double* __restrict__ dts, int n,
+                                                      const double* __restrict__ biasHat, DPim* __restrict__ pimOut,
+                                                      double* __restrict__ Lam, const DNav& si, DNav* __restrict__ predOut) {
     __shared__ DPim pim;
     __shared__ double sA[PIM_CHUNK][81], sB[PIM_CHUNK][27], sC[PIM_CHUNK][27], sF[PIM_CHUNK][225], sG[PIM_CHUNK][225];
     __shared__ double sState[PIM_CHUNK + 1][9];
@@ -87,13 +87,25 @@ __global__ __launch_bounds__(256) void k_imu_preintegrate(DImuParams P, const do
     for (int i = tid; i < (int)(sizeof(DPim) / sizeof(double)); i += 256) ((double*)pimOut)[i] = ((double*)&pim)[i];
 }
 
-struct ImuLmArgs {
-    int ldsFactors;          // capacity (factors) of the dynamic LDS buffer
-    const DPim* pim; const double* Lam;
-    const DNav* pred;        // state predicted from (x0, v0, b0) by k_imu_preintegrate
-    const double* biasPrev;  // b0 (device: the integration bias of k_imu_preintegrate)
-    double* io;              // out: vel(3), bias(6)
-};
+__global__ __launch_bounds__(256) void k_imu_preintegrate(DImuParams P, const double* __restrict__ samples, const double* __restrict__ dts,
+                                                          int n, const double* __restrict__ biasHat, DPim* __restrict__ pimOut,
+                                                          double* __restrict__ Lam, DNav si, DNav* __restrict__ predOut) {
+    imu_preintegrate_body(P, samples, dts, n, biasHat, pimOut, Lam, si, predOut);
+}
+// batched form: blockIdx.x = lane
+__global__ __launch_bounds__(256) void k_imu_preintegrate_b(const ImuLane* __restrict__ lanes) {
+    const ImuLane& L = *lane_entry(lanes, blockIdx.x);
+    if (L.n <= 0) return;
+    if (L.takeFrom) {
+        if (threadIdx.x < 6) L.bias[threadIdx.x] = L.takeFrom[3 + threadIdx.x];
+        __syncthreads();
+    }
+    imu_preintegrate_body(L.P, L.samples, L.dts, L.n, L.bias, L.pim, L.Lam, L.si, L.pred);
+}
+void launch_imu_batch(hipStream_t s, const ImuLane* dLanes, int B) {
+    hipLaunchKernelGGL(k_imu_preintegrate_b, dim3(B), dim3(256), 0, s, dLanes);
+}
+
 
 #ifdef VSLAM_POSE_STAMPS
 __device__ long long g_ps[16];
@@ -141,7 +153,7 @@ __device__ __noinline__ void prior_residual_serial(const DPose* T, const DPose* 
 }
 __device__ __noinline__ void pose_retract_serial(const DPose* T, const double* xi, DPose* r) { pose_retract(*T, xi, *r); }
 
-__global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I) {
+__device__ __forceinline__ void pose_imu_lm_body(const PoseArgs& A, const ImuLmArgs& I) {
     __shared__ double red[(POSE_NT / 64) * 29];
     __shared__ double acc[29];
     __shared__ DPose sT, sT2, sPT, sTcw;
@@ -153,9 +165,9 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I
     extern __shared__ double sFacLds[];
     const int tid = threadIdx.x;
     if (A.gate && *A.gate < A.gateMin) return;
-    if (A.Mdev) A.M = min(A.M, *A.Mdev);
-    const int M = A.M;
-    if (I.ldsFactors >= M) A.factors = sFacLds;      // the factor list is read 6+ times: keep it in LDS when it fits
+    int M = A.M;
+    if (A.Mdev) M = min(M, *A.Mdev);
+    double* const facs = I.ldsFactors >= M ? sFacLds : A.factors;      // the factor list is read 6+ times: keep it in LDS when it fits
     constexpr int VNT = POSE_NT - 128;               // waves 0..1 evaluate vision factors; lane 0 of wave 2: pose-prior algebra,
     constexpr int TPRIOR = VNT, TIMU = VNT + 64;     // lane 0 of wave 3: CombinedImuFactor algebra (all three concurrently)
 #ifdef VSLAM_POSE_STAMPS
@@ -165,7 +177,7 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I
     __shared__ float sLvl[MAX_LEVELS];
     __shared__ int sCntTab[2 * POSE_BATCH * (POSE_NT / 64)];
     pose_stage_levels(A, sLvl);
-    const int nF = pose_build_factors(A, sLvl, sCntTab);
+    const int nF = pose_build_factors(A, M, facs, sLvl, sCntTab);
     PS_ACC(0);
     if (tid < 225) sLam[tid] = I.Lam[tid];
     if (tid == 0) {
@@ -180,7 +192,7 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I
     auto vision_error = [&](const DPose& T) {
         double e = 0;
         for (int i = tid; i < nF && tid < VNT; i += VNT) {
-            const double* f = A.factors + (size_t)i * 8;
+            const double* f = facs + (size_t)i * 8;
             double r[3];
             pose_factor_eval(f, T, A, r, nullptr);
             e += r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
@@ -209,7 +221,7 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I
             if (tid == TIMU) imu_lin_serial(&sPred, I.pim->biasHat, &sT, sV, sB, sR15, sJ);
             else if (tid == TPRIOR) prior_lin_serial(&sT, &sPT, sRp, sJp);
             for (int i = tid; i < nF && tid < VL; i += VL) {
-                const double* f = A.factors + (size_t)i * 8;
+                const double* f = facs + (size_t)i * 8;
                 PoseLin L;
                 pose_factor_lin(f, T, A, L);
                 pose_acc_factor(L, v);
@@ -355,9 +367,29 @@ __global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I
         for (int i = 0; i < 6; i++) I.io[3 + i] = sB[i];
     }
     __syncthreads();
-    pose_find_outliers(A, sTcw, sCnt, sLvl);
+    pose_find_outliers(A, M, sTcw, sCnt, sLvl);
     if (tid == 0) { A.out[0] = sCnt[0]; A.out[1] = sCnt[1]; }
     PS_ACC(9);
+}
+
+__global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm(PoseArgs A, ImuLmArgs I) { pose_imu_lm_body(A, I); }
+// batched form: blockIdx.x = lane
+__global__ __launch_bounds__(POSE_NT) void k_pose_imu_lm_b(const PoseLane* __restrict__ lanes) {
+    const PoseLane& L = *lane_entry(lanes, blockIdx.x);
+    pose_imu_lm_body(L.A, L.I);
+}
+constexpr int POSE_IMU_LDS_FACTORS = 2125;       // factors of 8 doubles kept in LDS: 136 KB next to the kernel's static 10 KB
+static void pose_imu_attrs() {
+    static bool attr = false;
+    if (attr) return;
+    (void)hipFuncSetAttribute((const void*)k_pose_imu_lm, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_pose_imu_lm_b, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+    attr = true;
+}
+// ldsFactors: the LDS factor capacity every lane's I.ldsFactors was set to (0 = factor lists stay in HBM)
+void launch_pose_imu_batch(hipStream_t s, const PoseLane* dLanes, int B, int ldsFactors) {
+    pose_imu_attrs();
+    hipLaunchKernelGGL(k_pose_imu_lm_b, dim3(B), dim3(POSE_NT), (size_t)ldsFactors * 8 * sizeof(double), s, dLanes);
 }
 
 }  // namespace vslam
@@ -366,37 +398,18 @@ using namespace vslam;
 
 // upload the frame's IMU bucket, pre-integrate it once (the reference re-integrates the same samples on every
 // estimatePoseGTSAM call of a frame; the result is identical), remember x0 / v0 / b0
-vslam_status vslam_matcher::imu_setup(const vslam_imu_input* imu, double lastDt) {
+// Host half of the per-frame IMU set-up: the bucket (samples, dts, bias) is written to `h` (7 n + 6 doubles, pinned) whose
+// device mirror is `dSamples`; DPim / Lambda / prediction scratch lives in d_imuBuf.  Fills the pre-integration arguments.
+vslam_status vslam_matcher::imu_stage(const vslam_imu_input* imu, double lastDt, double* h, double* dSamples, vslam::ImuLane& L) {
     const int n = imu->n_samples;
     if (n > 0 && (!imu->acceleration || !imu->angular_velocity || !imu->timestamps_ns)) { set_error("IMU input: null array"); return VSLAM_ERR_INVALID; }
     if (n <= 0 || imu->hz <= 0) { set_error("IMU input: empty bucket"); return VSLAM_ERR_INVALID; }
-    // scratch layout: samples (6n) | dts (n) | biasHat (6) | DPim | Lambda (225) | DNav prediction; the io block lives in d_res
     const size_t pimD = sizeof(DPim) / sizeof(double);
-    const size_t need = (size_t)7 * n + 6 + pimD + 225 + sizeof(DNav) / sizeof(double);
-    VS_CHECK(ensure_res());
-    if (!imuStream) {
-        VS_HIP(hipStreamCreateWithFlags(&imuStream, hipStreamNonBlocking));
-        VS_HIP(hipEventCreateWithFlags(&evImu, hipEventDisableTiming));
-    }
-    // stage timing brackets kernels with events on the main stream: keep the pre-integration there when it is on
-    static const bool sideOff = getenv("VSLAM_IMU_MAIN_STREAM") != nullptr;
-    hipStream_t is = (timer.enabled || sideOff) ? stream : imuStream;
-    if ((int)need > imuCap) {
-        VS_HIP(hipStreamSynchronize(stream));
-        VS_HIP(hipStreamSynchronize(imuStream));
-        hipFree(d_imuBuf);
-        imuCap = (int)need + 1024;
+    const size_t need = pimD + 225 + sizeof(DNav) / sizeof(double);
+    if (!d_imuBuf) {
+        imuCap = (int)need + 64;
         VS_HIP(hipMalloc(&d_imuBuf, (size_t)imuCap * sizeof(double)));
     }
-    const int hn = 7 * n + 6;
-    if (hn > imuStageCap) {
-        VS_HIP(hipStreamSynchronize(stream));
-        if (h_imuStage) hipHostFree(h_imuStage);
-        imuStageCap = hn + 256;
-        VS_HIP(hipHostMalloc(&h_imuStage, (size_t)imuStageCap * sizeof(double), hipHostMallocDefault));
-    }
-    // the previous frame's upload has been consumed: every tracking call ends with a stream synchronisation
-    double* h = h_imuStage;
     double dt = lastDt > 0.0 ? lastDt : 1.0 / imu->hz;          // src/FeatureTracker.cpp:337 (PredictNextPoseIMU :1067 starts from hz / fps)
     for (int i = 0; i < n; i++) {
         for (int k = 0; k < 3; k++) { h[6 * (size_t)i + k] = imu->acceleration[3 * i + k]; h[6 * (size_t)i + 3 + k] = imu->angular_velocity[3 * i + k]; }
@@ -404,14 +417,11 @@ vslam_status vslam_matcher::imu_setup(const vslam_imu_input* imu, double lastDt)
         h[(size_t)6 * n + i] = dt;
     }
     for (int k = 0; k < 6; k++) h[(size_t)7 * n + k] = imu->bias_prev[k];
-    double* d_samples = d_imuBuf;
-    double* d_dts = d_samples + (size_t)6 * n;
-    double* d_bias = d_dts + n;
-    imuBiasDev = d_bias; imuN = n;
-    imuPim = (void*)(d_bias + 6);
+    imuSamplesDev = dSamples;
+    imuBiasDev = dSamples + (size_t)7 * n; imuN = n;
+    imuPim = (void*)d_imuBuf;
     imuLam = (double*)imuPim + pimD;
     imuPred = imuLam + 225;
-    VS_HIP(hipMemcpyAsync(d_samples, h, (size_t)hn * sizeof(double), hipMemcpyHostToDevice, is));
     DImuParams P{};
     for (int k = 0; k < 3; k++) P.gravity[k] = imu->gravity[k];
     P.gyroCov = imu->gyro_noise_density * imu->gyro_noise_density;        // pow(density, 2) (:318-321)
@@ -425,11 +435,46 @@ vslam_status vslam_matcher::imu_setup(const vslam_imu_input* imu, double lastDt)
     memcpy(imuParams, &P, sizeof(P));
     for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) imuSi[3 * r + c] = imu->T_wc_prev[4 * r + c]; imuSi[9 + r] = imu->T_wc_prev[4 * r + 3]; imuSi[12 + r] = imu->velocity_prev[r]; }
     for (int k = 0; k < 6; k++) imuBiasPrev[k] = imu->bias_prev[k];
+    imu_lane(L, false);
+    return VSLAM_OK;
+}
+
+// pre-integration arguments from the staged state (rechain: take the bias of the solve that just ran first)
+void vslam_matcher::imu_lane(vslam::ImuLane& L, bool rechain) {
+    memcpy(&L.P, imuParams, sizeof(L.P));
+    for (int k = 0; k < 9; k++) L.si.R[k] = imuSi[k];
+    for (int k = 0; k < 3; k++) { L.si.t[k] = imuSi[9 + k]; L.si.v[k] = imuSi[12 + k]; }
+    L.samples = imuSamplesDev; L.dts = imuSamplesDev + (size_t)6 * imuN; L.n = imuN;
+    L.bias = imuBiasDev; L.pim = (DPim*)imuPim; L.Lam = imuLam; L.pred = (DNav*)imuPred;
+    L.takeFrom = rechain ? imuIo : nullptr;
+}
+
+vslam_status vslam_matcher::imu_setup(const vslam_imu_input* imu, double lastDt) {
+    const int n = imu->n_samples;
+    VS_CHECK(ensure_res());
+    if (!imuStream) {
+        VS_HIP(hipStreamCreateWithFlags(&imuStream, hipStreamNonBlocking));
+        VS_HIP(hipEventCreateWithFlags(&evImu, hipEventDisableTiming));
+    }
+    // stage timing brackets kernels with events on the main stream: keep the pre-integration there when it is on
+    static const bool sideOff = getenv("VSLAM_IMU_MAIN_STREAM") != nullptr;
+    hipStream_t is = (timer.enabled || sideOff) ? stream : imuStream;
+    const int hn = 7 * std::max(n, 0) + 6;
+    if (hn > imuStageCap) {
+        VS_HIP(hipStreamSynchronize(stream));
+        VS_HIP(hipStreamSynchronize(imuStream));
+        if (h_imuStage) hipHostFree(h_imuStage);
+        hipFree(d_imuStage);
+        imuStageCap = hn + 256;
+        VS_HIP(hipHostMalloc(&h_imuStage, (size_t)imuStageCap * sizeof(double), hipHostMallocDefault));
+        VS_HIP(hipMalloc(&d_imuStage, (size_t)imuStageCap * sizeof(double)));
+    }
+    // the previous frame's upload has been consumed: every tracking call ends with a stream synchronisation
+    ImuLane L;
+    VS_CHECK(imu_stage(imu, lastDt, h_imuStage, d_imuStage, L));
+    VS_HIP(hipMemcpyAsync(d_imuStage, h_imuStage, (size_t)hn * sizeof(double), hipMemcpyHostToDevice, is));
     int t = timer.begin("imu_preintegrate");
-    DNav si0;
-    for (int k = 0; k < 9; k++) si0.R[k] = imuSi[k];
-    for (int k = 0; k < 3; k++) { si0.t[k] = imuSi[9 + k]; si0.v[k] = imuSi[12 + k]; }
-    hipLaunchKernelGGL(k_imu_preintegrate, dim3(1), dim3(256), 0, is, P, d_samples, d_dts, n, d_bias, (DPim*)imuPim, imuLam, si0, (DNav*)imuPred);
+    hipLaunchKernelGGL(k_imu_preintegrate, dim3(1), dim3(256), 0, is, L.P, L.samples, L.dts, L.n, (const double*)L.bias, L.pim, L.Lam, L.si, L.pred);
     timer.end(t);
     VS_HIP(hipGetLastError());
     imuPending = is != stream;
@@ -454,18 +499,13 @@ __global__ void k_imu_take_bias(const double* __restrict__ io, double* __restric
 vslam_status vslam_matcher::imu_rechain() {
     if (!evSolve) VS_HIP(hipEventCreateWithFlags(&evSolve, hipEventDisableTiming));
     static const bool sideOff = getenv("VSLAM_IMU_MAIN_STREAM") != nullptr;
-    hipStream_t is = (timer.enabled || sideOff) ? stream : imuStream;
+    hipStream_t is = (timer.enabled || sideOff || !imuStream) ? stream : imuStream;
     if (is != stream) { VS_HIP(hipEventRecord(evSolve, stream)); VS_HIP(hipStreamWaitEvent(is, evSolve, 0)); }
-    DImuParams P;
-    memcpy(&P, imuParams, sizeof(P));
-    DNav si0;
-    for (int k = 0; k < 9; k++) si0.R[k] = imuSi[k];
-    for (int k = 0; k < 3; k++) { si0.t[k] = imuSi[9 + k]; si0.v[k] = imuSi[12 + k]; }
-    double* d_samples = d_imuBuf;
-    double* d_dts = d_samples + (size_t)6 * imuN;
+    ImuLane L;
+    imu_lane(L, true);
     hipLaunchKernelGGL(k_imu_take_bias, dim3(1), dim3(64), 0, is, (const double*)imuIo, imuBiasDev);
     int t = timer.begin("imu_preintegrate");
-    hipLaunchKernelGGL(k_imu_preintegrate, dim3(1), dim3(256), 0, is, P, d_samples, d_dts, imuN, imuBiasDev, (DPim*)imuPim, imuLam, si0, (DNav*)imuPred);
+    hipLaunchKernelGGL(k_imu_preintegrate, dim3(1), dim3(256), 0, is, L.P, L.samples, L.dts, L.n, (const double*)L.bias, L.pim, L.Lam, L.si, L.pred);
     timer.end(t);
     VS_HIP(hipGetLastError());
     imuPending = is != stream;
@@ -473,35 +513,30 @@ vslam_status vslam_matcher::imu_rechain() {
     return VSLAM_OK;
 }
 
-// device-resident form of the IMU solve (inputs as for pose_enqueue, plus a completed imu_setup)
-vslam_status vslam_matcher::pose_imu_enqueue(int M, const int* Mdev, const int* gate, int gateMin, int outSlot, int monoOnly) {
-    uint8_t* fl = d_flags;
-    const size_t pc = (size_t)poseCap;
-    PoseArgs A{};
-    A.Mdev = Mdev; A.gate = gate; A.gateMin = gateMin; A.monoOnly = monoOnly;
-    A.M = M; A.points = d_points; A.inFrame = fl; A.inFrameR = fl + pc; A.mpOut = fl + 2 * pc; A.mpsOut = fl + 3 * pc;
-    A.matches = d_matches; A.kpsL = d_kps[0]; A.kpsR = d_kps[1];
-    A.closef = d_close; A.depth = d_depth; A.rightIdxs = d_rightIdxs; A.leftIdxs = d_leftIdxs;
-    A.fx = rig.fx; A.fy = rig.fy; A.cx = rig.cx; A.cy = rig.cy; A.b = (double)rig.baseline;
-    for (int l = 0; l < feL->nLevels; l++) A.invSigma[l] = feL->InvSigmaFactor[l];
-    A.closeTh = rig.baseline * 40;
-    A.factors = d_factors; A.firstFail = d_firstFail; A.code = (int*)(fl + 4 * pc); A.poseIO = d_poseIO; A.out = d_poseOut + 4 * outSlot;
-    A.maxIterations = 100; A.relTol = 1e-5; A.absTol = 1e-5; A.thres = 7.815;
-    ImuLmArgs I{};
+// arguments of one IMU solve (inputs as for pose_lane, plus a completed imu_setup)
+void vslam_matcher::pose_imu_lane(vslam::PoseLane& L, int M, const int* Mdev, const int* gate, int gateMin, int outSlot, int monoOnly) {
+    pose_lane(L.A, M, Mdev, gate, gateMin, outSlot, monoOnly);
+    ImuLmArgs& I = L.I;
+    I = ImuLmArgs{};
     I.pim = (const DPim*)imuPim; I.Lam = imuLam; I.io = imuIo;
     I.pred = (const DNav*)imuPred;
     I.biasPrev = imuBiasDev;
+    I.ldsFactors = M <= POSE_IMU_LDS_FACTORS ? M : 0;      // dynamic LDS: the factor list (8 doubles per map point) when it fits
+}
+
+// device-resident form of the IMU solve
+vslam_status vslam_matcher::pose_imu_enqueue(int M, const int* Mdev, const int* gate, int gateMin, int outSlot, int monoOnly) {
+    PoseLane L;
+    pose_imu_lane(L, M, Mdev, gate, gateMin, outSlot, monoOnly);
+    const PoseArgs& A = L.A;
+    const ImuLmArgs& I = L.I;
     VS_CHECK(imu_join());
     int t = timer.begin("pose_imu_lm");
 #ifdef VSLAM_POSE_STAMPS
     { long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ps), z, sizeof(z)); }
 #endif
-    // dynamic LDS: the factor list (8 doubles per map point) when it fits next to the kernel's static 10 KB
-    const int ldsCap = 2125;                        // factors of 8 doubles: 136 KB
-    I.ldsFactors = M <= ldsCap ? M : 0;
     const size_t lds = (size_t)I.ldsFactors * 8 * sizeof(double);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k_pose_imu_lm, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); attr = true; }
+    pose_imu_attrs();
     hipLaunchKernelGGL(k_pose_imu_lm, dim3(1), dim3(POSE_NT), lds, stream, A, I);
     timer.end(t);
 #ifdef VSLAM_POSE_STAMPS

@@ -26,18 +26,19 @@ __device__ __forceinline__ void load_mp_desc(const vslam_mappoint_view* mp, uint
     for (int k = 0; k < 8; k++) md[k] = p[k];
 }
 
-__global__ __launch_bounds__(256) void k_proj_candidates(ProjArgs A, const int* __restrict__ matches,
-                                                         unsigned long long* __restrict__ topk,
-                                                         unsigned long long* __restrict__ stats) {
+__device__ __forceinline__ void proj_candidates_body(const ProjArgs& A, const int* __restrict__ matches,
+                                                     unsigned long long* __restrict__ topk,
+                                                     unsigned long long* __restrict__ stats) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int job = blockIdx.x * 4 + wave;      // job = mp * 2 + side
     __shared__ unsigned int sTests;             // descriptor tests of this workgroup (ONE global atomic: thousands of waves
     if (A.gate && *A.gate < A.gateMin) return;  //  adding to a single address serialise in the L2 and dominated the kernel)
-    if (A.Mdev) A.M = min(A.M, *A.Mdev);
+    int M = A.M;
+    if (A.Mdev) M = min(M, *A.Mdev);
     if (threadIdx.x == 0) sTests = 0;
     __syncthreads();
     int tests = 0;
-    if (job < 2 * A.M) {
+    if (job < 2 * M) {
         const int i = job >> 1, side = job & 1;
         unsigned long long out[PROJ_K];
 #pragma unroll
@@ -62,6 +63,17 @@ __global__ __launch_bounds__(256) void k_proj_candidates(ProjArgs A, const int* 
     if (lane == 0 && tests) atomicAdd(&sTests, (unsigned int)tests);
     __syncthreads();
     if (threadIdx.x == 0 && sTests) atomicAdd(&stats[3], (unsigned long long)sTests);
+}
+
+__global__ __launch_bounds__(256) void k_proj_candidates(ProjArgs A, const int* __restrict__ matches, unsigned long long* __restrict__ topk,
+                                                         unsigned long long* __restrict__ stats) {
+    proj_candidates_body(A, matches, topk, stats);
+}
+// batched form: blockIdx.y = lane
+__global__ __launch_bounds__(256) void k_proj_candidates_b(const ProjLane* __restrict__ lanes) {
+    const ProjLane& L = *lane_entry(lanes, blockIdx.y);
+    if ((int)(blockIdx.x * 4) >= 2 * L.A.M) return;
+    proj_candidates_body(L.A, L.matches, L.topk, L.stats);
 }
 
 void launch_proj_candidates(hipStream_t s, const ProjArgs& A, const int* matches,
@@ -120,9 +132,9 @@ constexpr int PROJ_PAR_ROUNDS = 16;  // fixed-point rounds before the sequential
 
 __device__ __forceinline__ void lds_order() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-__global__ __launch_bounds__(PROJ_NT) void k_proj_resolve(ProjArgs A, const unsigned long long* __restrict__ topk,
-                                                     int* __restrict__ matchedL, int* __restrict__ matchedR,
-                                                     int* __restrict__ matches, int* __restrict__ outp, int forceSeq) {
+__device__ __forceinline__ void proj_resolve_body(const ProjArgs& A, const unsigned long long* __restrict__ topk,
+                                                  int* __restrict__ matchedL, int* __restrict__ matchedR,
+                                                  int* __restrict__ matches, int* __restrict__ outp, int forceSeq) {
     extern __shared__ int claims[];
     int* cl = claims;
     int* cr = claims + A.n[0];
@@ -134,7 +146,8 @@ __global__ __launch_bounds__(PROJ_NT) void k_proj_resolve(ProjArgs A, const unsi
     unsigned long long* skeys = (unsigned long long*)(((uintptr_t)(spair + 2 * PROJ_SUPER) + 15) & ~(uintptr_t)15);   // [PROJ_SUPER][16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (A.gate && *A.gate < A.gateMin) return;
-    if (A.Mdev) A.M = min(A.M, *A.Mdev);
+    int M = A.M;
+    if (A.Mdev) M = min(M, *A.Mdev);
     for (int k = tid; k < A.n[0]; k += PROJ_NT) { cl[k] = matchedL[k]; ri[k] = A.mode == PROJ_STEREO ? A.rightIdxs[k] : -1; tl[k] = INT_MAX; }
     for (int k = tid; k < A.n[1]; k += PROJ_NT) { cr[k] = matchedR[k]; li[k] = A.leftIdxs[k]; tr[k] = INT_MAX; }
     int nMatches = 0;
@@ -150,7 +163,7 @@ __global__ __launch_bounds__(PROJ_NT) void k_proj_resolve(ProjArgs A, const unsi
     // below redoes the whole frame (it also covers M > 1024 and non-convergence); results are identical either way.
     __shared__ int sChanged, sFall, sCount;
     bool solved = false;
-    const int Mtot = A.M;
+    const int Mtot = M;
     int roundsUsed = -1;                                      // diagnostics: outp[1] (-1 = sequential walk)
     if (!forceSeq && Mtot > 0 && Mtot <= PROJ_PAR_PASSES * (PROJ_NT / 4)) {
         int* decT = (int*)skeys;                              // current decision per point (-1 = none)
@@ -250,8 +263,8 @@ __global__ __launch_bounds__(PROJ_NT) void k_proj_resolve(ProjArgs A, const unsi
             nMatches = sCount;
         }
     }
-    for (int sc = 0; sc < (solved ? 0 : A.M); sc += PROJ_SUPER) {
-        const int n = min(PROJ_SUPER, A.M - sc);
+    for (int sc = 0; sc < (solved ? 0 : M); sc += PROJ_SUPER) {
+        const int n = min(PROJ_SUPER, M - sc);
         __syncthreads();
         // all four waves stage this super-step's key lists and current pairs in LDS (deep, coalesced loads):
         // the serial walk below then never waits on HBM / L2
@@ -400,11 +413,40 @@ __global__ __launch_bounds__(PROJ_NT) void k_proj_resolve(ProjArgs A, const unsi
     if (tid == 0) { outp[0] = nMatches; outp[1] = roundsUsed; }
 }
 
+__global__ __launch_bounds__(PROJ_NT) void k_proj_resolve(ProjArgs A, const unsigned long long* __restrict__ topk, int* __restrict__ matchedL,
+                                                     int* __restrict__ matchedR, int* __restrict__ matches, int* __restrict__ outp, int forceSeq) {
+    proj_resolve_body(A, topk, matchedL, matchedR, matches, outp, forceSeq);
+}
+// batched form: blockIdx.x = lane
+__global__ __launch_bounds__(PROJ_NT) void k_proj_resolve_b(const ProjLane* __restrict__ lanes, int forceSeq) {
+    const ProjLane& L = *lane_entry(lanes, blockIdx.x);
+    proj_resolve_body(L.A, L.topk, L.matchedL, L.matchedR, L.matches, L.out, forceSeq);
+}
+
+static size_t proj_resolve_lds(int nL, int nR) {
+    return (size_t)(3 * (nL + nR) + 2 * PROJ_SUPER) * sizeof(int) + 32 + (size_t)PROJ_SUPER * 16 * sizeof(unsigned long long);
+}
+static void proj_attrs() {
+    static bool attr = false;
+    if (attr) return;
+    (void)hipFuncSetAttribute((const void*)k_proj_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_proj_resolve_b, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    attr = true;
+}
+
+// all lanes' projection matching in two launches; maxM / maxL / maxR: the largest counts over the lanes
+void launch_proj_batch(hipStream_t s, const ProjLane* dLanes, int B, int maxM, int maxL, int maxR) {
+    if (B <= 0 || maxM <= 0) return;
+    proj_attrs();
+    const int forceSeq = getenv("VSLAM_PROJ_SEQUENTIAL") ? 1 : 0;
+    hipLaunchKernelGGL(k_proj_candidates_b, dim3((2 * maxM + 3) / 4, B), dim3(256), 0, s, dLanes);
+    hipLaunchKernelGGL(k_proj_resolve_b, dim3(B), dim3(PROJ_NT), proj_resolve_lds(maxL, maxR), s, dLanes, forceSeq);
+}
+
 void launch_proj_resolve(hipStream_t s, const ProjArgs& A, const unsigned long long* topk, int* matchedL, int* matchedR,
                          int* matches, int* out) {
-    const size_t sh = (size_t)(3 * (A.n[0] + A.n[1]) + 2 * PROJ_SUPER) * sizeof(int) + 32 + (size_t)PROJ_SUPER * 16 * sizeof(unsigned long long);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k_proj_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); attr = true; }
+    const size_t sh = proj_resolve_lds(A.n[0], A.n[1]);
+    proj_attrs();
     const int forceSeq = getenv("VSLAM_PROJ_SEQUENTIAL") ? 1 : 0;     // A/B and fallback testing (read per launch)
     hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(PROJ_NT), sh, s, A, topk, matchedL, matchedR, matches, out, forceSeq);
 #ifdef VSLAM_PROJ_STAMPS
@@ -433,9 +475,10 @@ vslam_status vslam_matcher::ensure_proj_cap(int M) {
     return VSLAM_OK;
 }
 
-// device-resident form: d_mpv / d_matches / d_matchedL / d_matchedR already hold the inputs
-vslam_status vslam_matcher::proj_enqueue(int M, float rad, const int* Mdev, const int* gate, int gateMin, int mode) {
-    ProjArgs A{};
+// arguments of one projection-matching pass on this matcher's device-resident buffers
+void vslam_matcher::proj_lane(vslam::ProjLane& L, int M, float rad, const int* Mdev, const int* gate, int gateMin, int mode) {
+    ProjArgs& A = L.A;
+    A = ProjArgs{};
     A.Mdev = Mdev; A.gate = gate; A.gateMin = gateMin; A.mode = mode;
     for (int s = 0; s < 2; s++) { A.kps[s] = d_kps[s]; A.desc[s] = d_desc[s]; A.n[s] = nKeys[s]; }
     A.mpv = d_mpv; A.M = M; A.rad = rad;
@@ -447,6 +490,14 @@ vslam_status vslam_matcher::proj_enqueue(int M, float rad, const int* Mdev, cons
     A.xMult = (float)A.xGrids / (float)rig.width;
     A.yMult = (float)A.yGrids / (float)rig.height;
     A.rightIdxs = d_rightIdxs; A.leftIdxs = d_leftIdxs;
+    L.matches = d_matches; L.topk = d_topk; L.stats = d_stats; L.matchedL = d_matchedL; L.matchedR = d_matchedR; L.out = d_projOut;
+}
+
+// device-resident form: d_mpv / d_matches / d_matchedL / d_matchedR already hold the inputs
+vslam_status vslam_matcher::proj_enqueue(int M, float rad, const int* Mdev, const int* gate, int gateMin, int mode) {
+    ProjLane L;
+    proj_lane(L, M, rad, Mdev, gate, gateMin, mode);
+    const ProjArgs& A = L.A;
     int t = timer.begin("proj_candidates");
     launch_proj_candidates(stream, A, d_matches, d_topk, d_stats);
     timer.end(t);

@@ -25,10 +25,10 @@ __device__ long long g_sm[8];
 #define SM_ACC(k) do {} while (0)
 #endif
 
-__global__ __launch_bounds__(256) void k_stereo_match(StereoArgs A, int* __restrict__ mBest,
-                                                      float* __restrict__ mDepth,
-                                                      int* __restrict__ mSad,
-                                                      unsigned long long* __restrict__ stats) {
+__device__ __forceinline__ void stereo_match_body(const StereoArgs& A, int* __restrict__ mBest,
+                                                  float* __restrict__ mDepth,
+                                                  int* __restrict__ mSad,
+                                                  unsigned long long* __restrict__ stats) {
     extern __shared__ unsigned char smem[];
     const int nR = A.nR, nRp = (nR + 3) & ~3;
     float* yR = (float*)smem;
@@ -199,6 +199,17 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs A, int* __restr
     SM_ACC(5);
 }
 
+__global__ __launch_bounds__(256) void k_stereo_match(StereoArgs A, int* __restrict__ mBest, float* __restrict__ mDepth,
+                                                      int* __restrict__ mSad, unsigned long long* __restrict__ stats) {
+    stereo_match_body(A, mBest, mDepth, mSad, stats);
+}
+// batched form: blockIdx.y = lane (one stereo pair each), arguments from the lane table
+__global__ __launch_bounds__(256) void k_stereo_match_b(const StereoLane* __restrict__ lanes) {
+    const StereoLane& L = *lane_entry(lanes, blockIdx.y);
+    if (blockIdx.x * 4 >= (unsigned)L.A.nL) return;
+    stereo_match_body(L.A, L.mBest, L.mDepth, L.mSad, L.stats);
+}
+
 void launch_stereo_match(hipStream_t s, const StereoArgs& A, int* mBest, float* mDepth, int* mSad,
                          unsigned long long* stats) {
     if (A.nL <= 0) return;
@@ -272,13 +283,13 @@ __device__ long long g_st[8];
 // plus every pair whose SAD is not below 2.1 x the median SAD (src/FeatureMatcher.cpp:674-705).
 // Both order statistics come from radix selects (the cut-off depth + the index tie-break among equal depths, and the
 // value of rank n / 2 of the SADs) instead of an all-pairs rank count.
-__global__ __launch_bounds__(1024) void k_stereo_finalize(int nL, int nR, const int* __restrict__ mBest,
-                                                          const float* __restrict__ mDepth,
-                                                          const int* __restrict__ mSad, float closeDepth,
-                                                          int* __restrict__ rightIdxs,
-                                                          int* __restrict__ leftIdxs,
-                                                          float* __restrict__ depth,
-                                                          uint8_t* __restrict__ closef) {
+__device__ __forceinline__ void stereo_finalize_body(int nL, int nR, const int* __restrict__ mBest,
+                                                     const float* __restrict__ mDepth,
+                                                     const int* __restrict__ mSad, float closeDepth,
+                                                     int* __restrict__ rightIdxs,
+                                                     int* __restrict__ leftIdxs,
+                                                     float* __restrict__ depth,
+                                                     uint8_t* __restrict__ closef) {
     extern __shared__ unsigned char smem[];
     int* vIdx = (int*)smem;
     float* vDepth = (float*)(vIdx + nL);
@@ -353,6 +364,17 @@ __global__ __launch_bounds__(1024) void k_stereo_finalize(int nL, int nR, const 
     ST_ACC(4);
 }
 
+__global__ __launch_bounds__(1024) void k_stereo_finalize(int nL, int nR, const int* __restrict__ mBest, const float* __restrict__ mDepth,
+                                                          const int* __restrict__ mSad, float closeDepth, int* __restrict__ rightIdxs,
+                                                          int* __restrict__ leftIdxs, float* __restrict__ depth, uint8_t* __restrict__ closef) {
+    stereo_finalize_body(nL, nR, mBest, mDepth, mSad, closeDepth, rightIdxs, leftIdxs, depth, closef);
+}
+__global__ __launch_bounds__(1024) void k_stereo_finalize_b(const StereoLane* __restrict__ lanes) {
+    const StereoLane& L = *lane_entry(lanes, blockIdx.x);
+    if (L.A.nL <= 0 && L.A.nR <= 0) return;
+    stereo_finalize_body(L.A.nL, L.A.nR, L.mBest, L.mDepth, L.mSad, L.closeDepth, L.rightIdxs, L.leftIdxs, L.depth, L.closef);
+}
+
 void launch_stereo_finalize(hipStream_t s, int nL, int nR, const int* mBest, const float* mDepth,
                             const int* mSad, float closeDepth, int* rightIdxs, int* leftIdxs,
                             float* depth, uint8_t* closef) {
@@ -371,6 +393,28 @@ void launch_stereo_finalize(hipStream_t s, int nL, int nR, const int* mBest, con
         fprintf(stderr, "stereo_finalize nL=%d: init+compact %lld  median %lld  depth cut %lld  apply %lld  kill %lld\n", nL, z[0], z[1], z[2], z[3], z[4]);
     }
 #endif
+}
+
+constexpr int STEREO_LDS = 150 * 1024, STEREO_MAX_R = (STEREO_LDS - 16) / 9 - 4, STEREO_MAX_L = STEREO_LDS / 20;
+static vslam_status stereo_attrs() {
+    static bool attr = false;
+    if (!attr) {
+        VS_HIP(hipFuncSetAttribute((const void*)k_stereo_match, hipFuncAttributeMaxDynamicSharedMemorySize, STEREO_LDS));
+        VS_HIP(hipFuncSetAttribute((const void*)k_stereo_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, STEREO_LDS));
+        VS_HIP(hipFuncSetAttribute((const void*)k_stereo_match_b, hipFuncAttributeMaxDynamicSharedMemorySize, STEREO_LDS));
+        VS_HIP(hipFuncSetAttribute((const void*)k_stereo_finalize_b, hipFuncAttributeMaxDynamicSharedMemorySize, STEREO_LDS));
+        attr = true;
+    }
+    return VSLAM_OK;
+}
+
+// all lanes' stereo matches in two launches (maxL / maxR: the largest key counts over the lanes)
+void launch_stereo_batch(hipStream_t s, const StereoLane* dLanes, int B, int maxL, int maxR) {
+    if (B <= 0 || (maxL <= 0 && maxR <= 0)) return;
+    (void)stereo_attrs();
+    const size_t shM = (size_t)((maxR + 3) & ~3) * 9 + 16, shF = (size_t)(maxL > 0 ? maxL : 1) * 20;
+    if (maxL > 0) hipLaunchKernelGGL(k_stereo_match_b, dim3((maxL + 3) / 4, B), dim3(256), shM, s, dLanes);
+    hipLaunchKernelGGL(k_stereo_finalize_b, dim3(B), dim3(1024), shF, s, dLanes);
 }
 
 }  // namespace vslam
@@ -444,26 +488,38 @@ void vslam_matcher::release() {
     hipFree(d_mBest); hipFree(d_mDepth); hipFree(d_mSad); hipFree(d_rightIdxs); hipFree(d_leftIdxs);
     hipFree(d_depth); hipFree(d_close); hipFree(d_stats);
     for (int s = 0; s < 2; s++) { hipFree(d_okps[s]); hipFree(d_odesc[s]); }
-    hipFree(d_trXyz); hipFree(d_trDesc); hipFree(d_trMsd); hipFree(d_trOutlier); hipFree(d_trAct);
-    hipFree(d_imuBuf);
-    hipFree(d_points); hipFree(d_flags); hipFree(d_factors); hipFree(d_firstFail); hipFree(d_res);
-    if (h_res) hipHostFree(h_res);
+    if (!trExternal) { hipFree(d_trXyz); hipFree(d_trDesc); hipFree(d_trMsd); hipFree(d_trOutlier); }
+    hipFree(d_trAct);
+    hipFree(d_imuBuf); hipFree(d_imuStage);
+    hipFree(d_points); hipFree(d_flags); hipFree(d_factors); hipFree(d_firstFail);
+    if (!resExternal) { hipFree(d_res); if (h_res) hipHostFree(h_res); }
     if (h_imuStage) hipHostFree(h_imuStage);
     if (imuStream) { (void)hipStreamSynchronize(imuStream); (void)hipStreamDestroy(imuStream); }
     if (evImu) (void)hipEventDestroy(evImu);
     if (evSolve) (void)hipEventDestroy(evSolve);
     hipFree(d_trVisL);
     hipFree(d_mpv); hipFree(d_topk); hipFree(d_matches); hipFree(d_matchedL); hipFree(d_matchedR); hipFree(d_projOut);
-    if (stream) hipStreamDestroy(stream);
+    if (stream && ownsStream) hipStreamDestroy(stream);
     stream = nullptr;
 }
 
-vslam_status vslam_matcher::refresh_keys() {
+vslam_status vslam_matcher::adopt_stream(hipStream_t s) {
+    if (!s) return VSLAM_ERR_INVALID;
+    VS_HIP(hipSetDevice(device));
+    if (stream && ownsStream) { VS_HIP(hipStreamSynchronize(stream)); VS_HIP(hipStreamDestroy(stream)); }
+    stream = s; ownsStream = false;
+    timer.stream = s;
+    return VSLAM_OK;
+}
+
+vslam_status vslam_matcher::refresh_keys(bool waitStream) {
     vslam_extractor* fe[2] = {feL, feR};
     const int img[2] = {imgL, imgR};
     // order this stream after the extractors' last run (keys, descriptors and pyramids complete)
-    if (feL->evDone) hipStreamWaitEvent(stream, feL->evDone, 0);
-    if (feR != feL && feR->evDone) hipStreamWaitEvent(stream, feR->evDone, 0);
+    if (waitStream) {
+        if (feL->evDone) hipStreamWaitEvent(stream, feL->evDone, 0);
+        if (feR != feL && feR->evDone) hipStreamWaitEvent(stream, feR->evDone, 0);
+    }
     for (int s = 0; s < 2; s++) {
         if (overridden[s]) continue;
         if (!fe[s]->ran) { set_error("matcher: extractor has not run"); return VSLAM_ERR_INVALID; }
@@ -475,12 +531,10 @@ vslam_status vslam_matcher::refresh_keys() {
     return ensure_cap(std::max(nKeys[0], nKeys[1]));
 }
 
-vslam_status vslam_matcher::stereo_match() {
-    if (mono) { set_error("stereo_match on a mono matcher"); return VSLAM_ERR_INVALID; }
-    VS_HIP(hipSetDevice(device));
-    UseMark mark{this};
-    VS_CHECK(refresh_keys());
-    StereoArgs A{};
+// arguments of this pair's stereo match (keys refreshed by the caller)
+vslam_status vslam_matcher::stereo_lane(vslam::StereoLane& L) {
+    StereoArgs& A = L.A;
+    A = StereoArgs{};
     A.kpsL = d_kps[0]; A.descL = d_desc[0]; A.nL = nKeys[0];
     A.kpsR = d_kps[1]; A.descR = d_desc[1]; A.nR = nKeys[1];
     A.pyrL = feL->d_pyr + (size_t)imgL * feL->P.imgStride;
@@ -494,24 +548,31 @@ vslam_status vslam_matcher::stereo_match() {
     A.maxD = (float)rig.fx; A.fx = rig.fx; A.fxf = (float)rig.fx; A.baseline = rig.baseline;
     A.imageHeight = rig.height;
     // dynamic LDS of the two kernels: 9 B per right key (row band, octave, y) / 20 B per left key (accepted-pair lists)
-    constexpr int STEREO_LDS = 150 * 1024, STEREO_MAX_R = (STEREO_LDS - 16) / 9 - 4, STEREO_MAX_L = STEREO_LDS / 20;
     if (A.nR > STEREO_MAX_R || A.nL > STEREO_MAX_L) {
         set_error("stereo_match: %d left / %d right keypoints exceed the LDS staging (%d / %d)", A.nL, A.nR, STEREO_MAX_L, STEREO_MAX_R);
         return VSLAM_ERR_CAPACITY;
     }
-    static bool attr = false;
-    if (!attr) {
-        VS_HIP(hipFuncSetAttribute((const void*)k_stereo_match, hipFuncAttributeMaxDynamicSharedMemorySize, STEREO_LDS));
-        VS_HIP(hipFuncSetAttribute((const void*)k_stereo_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, STEREO_LDS));
-        attr = true;
-    }
+    L.mBest = d_mBest; L.mDepth = d_mDepth; L.mSad = d_mSad; L.stats = d_stats;
+    L.closeDepth = rig.baseline * 40;   // closeNumber, include/FeatureMatcher.h:36
+    L.rightIdxs = d_rightIdxs; L.leftIdxs = d_leftIdxs; L.depth = d_depth; L.closef = d_close;
+    return VSLAM_OK;
+}
+
+vslam_status vslam_matcher::stereo_match() {
+    if (mono) { set_error("stereo_match on a mono matcher"); return VSLAM_ERR_INVALID; }
+    VS_HIP(hipSetDevice(device));
+    UseMark mark{this};
+    VS_CHECK(refresh_keys());
+    StereoLane L;
+    VS_CHECK(stereo_lane(L));
+    const StereoArgs& A = L.A;
+    VS_CHECK(stereo_attrs());
     VS_HIP(hipMemsetAsync(d_stats, 0, 4 * sizeof(unsigned long long), stream));
     int t = timer.begin("stereo_match");
     launch_stereo_match(stream, A, d_mBest, d_mDepth, d_mSad, d_stats);
     timer.end(t);
     t = timer.begin("stereo_finalize");
-    const float closeDepth = rig.baseline * 40;   // closeNumber, include/FeatureMatcher.h:36
-    launch_stereo_finalize(stream, A.nL, A.nR, d_mBest, d_mDepth, d_mSad, closeDepth, d_rightIdxs,
+    launch_stereo_finalize(stream, A.nL, A.nR, d_mBest, d_mDepth, d_mSad, L.closeDepth, d_rightIdxs,
                            d_leftIdxs, d_depth, d_close);
     timer.end(t);
     VS_HIP(hipGetLastError());

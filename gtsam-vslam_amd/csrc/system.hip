@@ -16,155 +16,10 @@
 // iteration orders of the reference are replaced by insertion order, sort ties on KeyFrame* by keyframe number; the
 // unpaired Matrix4d::inverse() calls of the constant-velocity feedback are true inverses (m4_affine_inv) - taking them as
 // rigid transposes makes the round-off defect of the rotation block grow by 1 + sqrt(2) per frame.
-#include "matcher.hpp"
-#include "dmath.hpp"
-#include <algorithm>
-#include <array>
-#include <atomic>
-#include <condition_variable>
-#include <deque>
-#include <mutex>
-#include <thread>
-
-namespace {
-
-using M4 = std::array<double, 16>;
-
-M4 m4_identity() { M4 r{}; r[0] = r[5] = r[10] = r[15] = 1.0; return r; }
-M4 m4_from(const double* p) { M4 r; for (int i = 0; i < 16; i++) r[i] = p[i]; return r; }
-M4 m4_mul(const M4& a, const M4& b) {
-    M4 r;
-    for (int i = 0; i < 4; i++)
-        for (int j = 0; j < 4; j++) {
-            double s = 0;
-            for (int k = 0; k < 4; k++) s += a[4 * i + k] * b[4 * k + j];
-            r[4 * i + j] = s;
-        }
-    return r;
-}
-// general inverse of [A t; 0 1]: A^-1 by cofactors, -A^-1 t  (Eigen's Matrix4d::inverse() on an affine matrix)
-M4 m4_affine_inv(const M4& T) {
-    const double a = T[0], b = T[1], c = T[2], d = T[4], e = T[5], f = T[6], g = T[8], h = T[9], i = T[10];
-    const double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
-    const double det = a * A + b * B + c * C;
-    const double inv[9] = {A / det, -(b * i - c * h) / det, (b * f - c * e) / det,
-                           B / det, (a * i - c * g) / det, -(a * f - c * d) / det,
-                           C / det, -(a * h - b * g) / det, (a * e - b * d) / det};
-    M4 r = m4_identity();
-    for (int q = 0; q < 3; q++) {
-        for (int p = 0; p < 3; p++) r[4 * q + p] = inv[3 * q + p];
-        r[4 * q + 3] = -(inv[3 * q] * T[3] + inv[3 * q + 1] * T[7] + inv[3 * q + 2] * T[11]);
-    }
-    return r;
-}
-// (R^T, -R^T t): the form the pose kernels use for the paired inversions around a solve
-M4 m4_rigid_inv(const M4& T) {
-    M4 r = m4_identity();
-    for (int i = 0; i < 3; i++) {
-        for (int j = 0; j < 3; j++) r[4 * i + j] = T[4 * j + i];
-        r[4 * i + 3] = -(T[i] * T[3] + T[4 + i] * T[7] + T[8 + i] * T[11]);
-    }
-    return r;
-}
-
-struct SysKeys {                       // TrackedKeys (include/FeatureExtractor.h:18-50), host copy of a keyframe's frame
-    std::vector<vslam_keypoint> kL, kR;
-    std::vector<uint8_t> dL, dR;       // n x 32
-    std::vector<int> rightIdxs, leftIdxs;
-    std::vector<float> depth;
-    std::vector<uint8_t> close;
-};
-
-struct KfMatch { int kf, l, r; };      // one entry of MapPoint::kFMatches (keyframe number, left idx, right idx)
-
-struct SysMP {                         // MapPoint (include/Map.h:22-98)
-    double wp[3];
-    uint8_t desc[32];
-    std::vector<KfMatch> kfm;          // insertion ordered
-    float maxScaleDist = 0, minScaleDist = 0;
-    int unMCnt = 0;
-    bool isOutlier = false, inFrame = true;
-    long long kdx = 0, idx = 0;
-    int lastObsKF = -1, LBAID = -1;
-    int find(int kf) const { for (size_t i = 0; i < kfm.size(); i++) if (kfm[i].kf == kf) return (int)i; return -1; }
-};
-
-struct SysKF {                         // KeyFrame (include/KeyFrame.h) - keyframes only; plain frames live in SysFrame
-    int numb = 0, frameIdx = 0;
-    M4 pose, poseInv, refPose;
-    bool fixed = false;
-    int prevKF = -1, nextKF = -1;
-    SysKeys keys;
-    std::vector<int> unF, unFR, lmpL, lmpR;            // unMatchedF / unMatchedFR, localMapPoints(R) as map-point indices
-    std::vector<std::pair<int, int>> sortedKFWeights;   // (weight, keyframe number)
-    int LBAID = -1, nKeysTracked = 0;
-    void setPose(const M4& T) { pose = T; poseInv = m4_affine_inv(T); }      // CameraPose::setPose (src/Camera.cpp:10-15)
-};
-
-struct SysFrame { bool isKF; int kf; int prevKF; M4 refPose; };   // allFramesPoses entry (trajectory output)
-
-}  // namespace
+#include "system.hpp"
 
 using namespace vslam;
-
-struct vslam_system {
-    vslam_system_config cfg{};
-    vslam_extractor* fe = nullptr;
-    vslam_matcher* fm = nullptr;
-    std::vector<float> scalePyr, sigmaF, invSigmaF;
-    int nLev = 8;
-    // zedPtr->mCameraPose, prediction state (include/FeatureTracker.h:34-43)
-    M4 camPose, camPoseInv, camRefPose, predNPose, predNPoseInv, predNPoseRef, lastKFPoseInv;
-    int latestKF = -1;
-    float precCheckMatches = 0.9f;
-    int lastKFTrackedNumb = 0, insertKeyFrameCount = 0;
-    std::deque<SysKF> keyFrames;       // map->keyFrames (kIdx = size)
-    std::deque<SysMP> mapPoints;       // map->mapPoints (pIdx = size)
-    std::vector<int> active;           // map->activeMapPoints
-    std::vector<SysFrame> allFrames;
-    std::atomic<bool> keyFrameAdded{false}, LBADone{false};     // Map::keyFrameAdded / LBADone (plain bools in the reference)
-    std::atomic<int> endLBAIdx{0};
-    long long mpIdx = -1;              // LocalMapper's function-static mpIdx (src/OptimizationBA.cpp:93)
-    double velocity[3] = {0, 0, 0}, bias[6] = {0, 0, 0, 0, 0, 0};
-    // last frame (test taps)
-    std::vector<int> lastMatches; std::vector<uint8_t> lastOutliers;
-    vslam_frame_report lastMapping{};  // mapping fields of the most recent local-mapping pass
-    std::atomic<bool> mappingReportFresh{false};
-    // per-kernel-group device time (HIP events), summed since the last read; BA groups are collected on the thread that runs it
-    std::atomic<int> timingOn{0};
-    std::mutex tMu;
-    std::vector<std::pair<const char*, float>> baTimes;
-    int baTimedCalls = 0;
-    // pinned staging
-    uint8_t* h_up = nullptr; size_t upCap = 0;
-    uint8_t* h_dn = nullptr; size_t dnCap = 0;
-    // optimizer thread (local_mapping == 2)
-    std::mutex mapMutex;
-    std::thread worker;
-    std::mutex wMu; std::condition_variable wCv;
-    bool stopRequested = false, mappingBusy = false;
-    vslam_status workerStatus = VSLAM_OK;
-    char workerError[256] = "";
-
-    vslam_status init(const vslam_system_config* c);
-    void release();
-    vslam_status track(const uint8_t* L, const uint8_t* R, int stride, bool onDevice, int frame, const vslam_imu_bucket* imu,
-                       double* T_wc_out, vslam_frame_report* rep);
-    vslam_status fetch_keys(SysKeys& k);
-    void mp_update(SysMP& mp, int kfNumb, std::vector<int>& needDesc, int mpIndex);
-    vslam_status calc_descriptors(const std::vector<int>& mps);
-    void backproject(const SysKeys& k, int i, const M4& pose, double* out) const;
-    vslam_status initialize_map(const SysKeys& keys, int frame);
-    vslam_status insert_keyframe(SysKeys& keys, const std::vector<int>& matchedL, const std::vector<int>& matches,
-                                 int nStereo, const M4& estimPose, const std::vector<uint8_t>& outl, const std::vector<int>& act, int frame);
-    void calc_connections(SysKF& kf);
-    vslam_status change_poses_lca(int endIdx);
-    vslam_status kf_update_pose(SysKF& kf, const M4& keyPose);
-    vslam_status local_mapping();
-    vslam_status find_new_points(const std::vector<int>& actKeyF, int& nNew);
-    vslam_status local_ba(const std::vector<int>& actKeyF);
-    void worker_loop();
-};
+using namespace vslam_sys;
 
 void vslam_system::backproject(const SysKeys& k, int i, const M4& pose, double* out) const {
     const double zp = (double)k.depth[i];
@@ -173,13 +28,15 @@ void vslam_system::backproject(const SysKeys& k, int i, const M4& pose, double* 
     for (int c = 0; c < 3; c++) out[c] = (pose[4 * c] * xp + pose[4 * c + 1] * yp + pose[4 * c + 2] * zp) + pose[4 * c + 3];
 }
 
-vslam_status vslam_system::init(const vslam_system_config* c) {
+vslam_status vslam_system::init(const vslam_system_config* c, vslam_extractor* sharedFe, int imgBase, hipStream_t sharedStream) {
     if (!c) return VSLAM_ERR_INVALID;
     cfg = *c;
     if (cfg.window <= 0) cfg.window = 10;
     if (cfg.window > 16) { set_error("vslam_system: window > 16 keyframes is not supported by the new-point pipeline"); return VSLAM_ERR_INVALID; }
-    VS_CHECK(vslam_extractor_create(&cfg.fe, cfg.rig.width, cfg.rig.height, 2, cfg.device, &fe));
-    VS_CHECK(vslam_matcher_create(&cfg.rig, fe, 0, fe, 1, &fm));
+    if (sharedFe) { fe = sharedFe; ownsFe = false; img0 = imgBase; }
+    else VS_CHECK(vslam_extractor_create(&cfg.fe, cfg.rig.width, cfg.rig.height, 2, cfg.device, &fe));
+    VS_CHECK(vslam_matcher_create(&cfg.rig, fe, img0, fe, img0 + 1, &fm));
+    if (sharedStream) VS_CHECK(fm->adopt_stream(sharedStream));
     nLev = cfg.fe.n_levels;
     scalePyr.resize(nLev); sigmaF.resize(nLev); invSigmaF.resize(nLev);
     VS_CHECK(vslam_extractor_tables(fe, scalePyr.data(), nullptr, sigmaF.data(), invSigmaF.data(), nullptr, nullptr));
@@ -189,7 +46,7 @@ vslam_status vslam_system::init(const vslam_system_config* c) {
     camPose = T0; camPoseInv = m4_affine_inv(T0); camRefPose = m4_identity();
     predNPose = T0; predNPoseInv = camPoseInv; predNPoseRef = m4_identity(); lastKFPoseInv = m4_identity();
     for (int k = 0; k < 3; k++) velocity[k] = cfg.velocity_init[k];
-    if (cfg.local_mapping == 2) worker = std::thread([this]() { worker_loop(); });
+    if (cfg.local_mapping == 2 && !sharedFe) worker = std::thread([this]() { worker_loop(); });
     return VSLAM_OK;
 }
 
@@ -199,8 +56,12 @@ void vslam_system::release() {
         wCv.notify_all();
         worker.join();
     }
+    {   // a mapping job of this session still running on one of the batch's threads
+        std::unique_lock<std::mutex> lk(wMu);
+        wCv.wait(lk, [&] { return !mappingBusy || !mapExec; });
+    }
     if (fm) vslam_matcher_destroy(fm);
-    if (fe) vslam_extractor_destroy(fe);
+    if (fe && ownsFe) vslam_extractor_destroy(fe);
     fm = nullptr; fe = nullptr;
     if (h_up) hipHostFree(h_up);
     if (h_dn) hipHostFree(h_dn);
@@ -210,11 +71,11 @@ void vslam_system::release() {
 // the current frame's TrackedKeys as the device holds them (after findOutliersR's mutations)
 vslam_status vslam_system::fetch_keys(SysKeys& k) {
     int nL = 0, nR = 0;
-    VS_CHECK(vslam_extractor_count(fe, 0, &nL)); VS_CHECK(vslam_extractor_count(fe, 1, &nR));
+    VS_CHECK(vslam_extractor_count(fe, img0, &nL)); VS_CHECK(vslam_extractor_count(fe, img0 + 1, &nR));
     k.kL.resize(nL); k.kR.resize(nR); k.dL.resize((size_t)nL * 32); k.dR.resize((size_t)nR * 32);
     int n = 0;
-    VS_CHECK(vslam_extractor_fetch(fe, 0, k.kL.data(), k.dL.data(), std::max(nL, 1), &n));
-    VS_CHECK(vslam_extractor_fetch(fe, 1, k.kR.data(), k.dR.data(), std::max(nR, 1), &n));
+    VS_CHECK(vslam_extractor_fetch(fe, img0, k.kL.data(), k.dL.data(), std::max(nL, 1), &n));
+    VS_CHECK(vslam_extractor_fetch(fe, img0 + 1, k.kR.data(), k.dR.data(), std::max(nR, 1), &n));
     k.rightIdxs.assign(std::max(nL, 1), -1); k.leftIdxs.assign(std::max(nR, 1), -1); k.depth.assign(std::max(nL, 1), -1.f); k.close.assign(std::max(nL, 1), 0);
     VS_CHECK(vslam_stereo_fetch(fm, k.rightIdxs.data(), k.leftIdxs.data(), k.depth.data(), k.close.data(), std::max(nL, 1), std::max(nR, 1), nullptr));
     k.rightIdxs.resize(nL); k.leftIdxs.resize(nR); k.depth.resize(nL); k.close.resize(nL);
@@ -441,96 +302,91 @@ vslam_status vslam_system::change_poses_lca(int endIdx) {
     return VSLAM_OK;
 }
 
-// FeatureTracker::TrackImage (src/FeatureTracker.cpp:1108-1278)
-vslam_status vslam_system::track(const uint8_t* L, const uint8_t* R, int stride, bool onDevice, int frame,
-                                 const vslam_imu_bucket* imu, double* T_wc_out, vslam_frame_report* rep) {
-    if (!L || !R || !T_wc_out) return VSLAM_ERR_INVALID;
+// ---- FeatureTracker::TrackImage (src/FeatureTracker.cpp:1108-1278), in phases ---------------------------------------------
+// One session runs them back to back (track()); vslam_batch runs the host phases of its lanes on a thread pool and
+// the device phase of all lanes in batched launches.
+//   frame_begin     worker status, changePosesLCA when a local BA finished (:1115-1122)
+//   frame_first     frame 0: initializeMap from the fetched keys
+//   frame_candidates / frame_fill_upload   activeMapPoints -> the tracker's upload arrays
+//   frame_imu_input the frame's IMU problem
+//   frame_post      everything after the device: bookkeeping, keyframe rule, insertKeyFrame, updatePoses, local mapping
+vslam_status vslam_system::frame_begin(SysFrameCtx& c, int frame, const vslam_imu_bucket* imu) {
     if (cfg.use_imu && frame > 0 && (!imu || imu->n <= 0)) { set_error("vslam_system: IMU mode needs the frame's IMU bucket"); return VSLAM_ERR_INVALID; }
     {
         std::lock_guard<std::mutex> lk(wMu);
         if (workerStatus != VSLAM_OK) { set_error("local mapping thread failed: %s", workerError); return workerStatus; }
     }
-    vslam_frame_report out{};
-    out.frame = frame;
+    c.frame = frame; c.imu = imu;
+    c.out = vslam_frame_report{};
+    c.out.frame = frame;
     VS_HIP(hipSetDevice(cfg.device));
     if (LBADone) {                                         // :1115-1122
         std::lock_guard<std::mutex> lk(mapMutex);
         VS_CHECK(change_poses_lca(endLBAIdx));
         LBADone = false;
     }
-    // images -> pyramid level 0, extraction, stereo match (extractORBAndStereoMatch :56-70); nothing here depends on the map
-    if (onDevice) { VS_CHECK(vslam_extractor_set_image_device(fe, 0, L, stride)); VS_CHECK(vslam_extractor_set_image_device(fe, 1, R, stride)); }
-    else { VS_CHECK(vslam_extractor_set_image_host(fe, 0, L, stride)); VS_CHECK(vslam_extractor_set_image_host(fe, 1, R, stride)); }
-    VS_CHECK(vslam_extractor_run(fe));
-    VS_CHECK(fm->stereo_match());
-    if (frame == 0) {
-        SysKeys keys;
-        VS_CHECK(fetch_keys(keys));
-        std::lock_guard<std::mutex> lk(mapMutex);
-        VS_CHECK(initialize_map(keys, frame));
-        memcpy(T_wc_out, camPose.data(), sizeof(double) * 16);
-        out.keyframe_inserted = 1; out.n_keyframes = (int)keyFrames.size(); out.n_map_points = (int)mapPoints.size();
-        out.n_active_after = (int)active.size();
-        if (rep) *rep = out;
-        return VSLAM_OK;
+    return VSLAM_OK;
+}
+
+vslam_status vslam_system::frame_first(SysFrameCtx& c, double* T_wc_out, vslam_frame_report* rep) {
+    SysKeys keys;
+    VS_CHECK(fetch_keys(keys));
+    std::lock_guard<std::mutex> lk(mapMutex);
+    VS_CHECK(initialize_map(keys, c.frame));
+    memcpy(T_wc_out, camPose.data(), sizeof(double) * 16);
+    c.out.keyframe_inserted = 1; c.out.n_keyframes = (int)keyFrames.size(); c.out.n_map_points = (int)mapPoints.size();
+    c.out.n_active_after = (int)active.size();
+    if (rep) *rep = c.out;
+    return VSLAM_OK;
+}
+
+// activeMapPoints that are not outliers (the kernel compacts them: removeOutOfFrameMPs :910-939)
+int vslam_system::frame_candidates(SysFrameCtx& c) {
+    std::lock_guard<std::mutex> lk(mapMutex);
+    c.cand.clear();
+    c.cand.reserve(active.size());
+    for (int m : active) if (!mapPoints[m].isOutlier) c.cand.push_back(m);
+    c.N = (int)c.cand.size();
+    return c.N;
+}
+
+void vslam_system::frame_fill_upload(const SysFrameCtx& c, double* xyz, uint8_t* desc, float* msd) {
+    for (int j = 0; j < c.N; j++) {
+        const SysMP& mp = mapPoints[c.cand[j]];      // (positions change only under change_poses_lca / the BA write-back,
+        xyz[3 * j] = mp.wp[0]; xyz[3 * j + 1] = mp.wp[1]; xyz[3 * j + 2] = mp.wp[2];   //  both serialised with this thread's frame)
+        memcpy(desc + (size_t)j * 32, mp.desc, 32);
+        msd[j] = mp.maxScaleDist;
     }
-    // ---- activeMapPoints -> the tracker's device arrays (the kernel compacts them: removeOutOfFrameMPs :910-939) ----
-    std::vector<int> cand;
-    {
-        std::lock_guard<std::mutex> lk(mapMutex);
-        cand.reserve(active.size());
-        for (int m : active) if (!mapPoints[m].isOutlier) cand.push_back(m);
-    }
-    const int N = (int)cand.size();
-    {
-        const size_t need = (size_t)std::max(N, 1) * (24 + 32 + 4);
-        if (need > upCap) { if (h_up) hipHostFree(h_up); upCap = need + need / 2; VS_HIP(hipHostMalloc((void**)&h_up, upCap, hipHostMallocDefault)); }
-        double* xyz = (double*)h_up; uint8_t* desc = h_up + (size_t)N * 24; float* msd = (float*)(h_up + (size_t)N * 56);
-        for (int j = 0; j < N; j++) {
-            const SysMP& mp = mapPoints[cand[j]];
-            xyz[3 * j] = mp.wp[0]; xyz[3 * j + 1] = mp.wp[1]; xyz[3 * j + 2] = mp.wp[2];
-            memcpy(desc + (size_t)j * 32, mp.desc, 32);
-            msd[j] = mp.maxScaleDist;
-        }
-        VS_CHECK(fm->track_upload_map(xyz, desc, msd, N));
-    }
-    // ---- the frame's tracking block on the device (:1168-1241) -------------------------------------------------------
-    vslam_imu_input in{};
-    vslam_imu_output imuOut{};
-    if (cfg.use_imu) {
-        for (int k = 0; k < 3; k++) in.gravity[k] = cfg.gravity[k];
-        in.gyro_noise_density = cfg.gyro_noise_density; in.gyro_random_walk = cfg.gyro_random_walk;
-        in.accel_noise_density = cfg.accel_noise_density; in.accel_random_walk = cfg.accel_random_walk;
-        memcpy(in.T_body_sensor, cfg.T_body_sensor, sizeof(in.T_body_sensor));
-        memcpy(in.T_wc_prev, camPose.data(), sizeof(in.T_wc_prev));
-        for (int k = 0; k < 3; k++) in.velocity_prev[k] = velocity[k];
-        for (int k = 0; k < 6; k++) in.bias_prev[k] = bias[k];
-        in.n_samples = imu->n; in.hz = cfg.imu_hz; in.acceleration = imu->acceleration; in.angular_velocity = imu->angular_velocity;
-        in.timestamps_ns = imu->timestamps_ns;
-    }
-    double T_cw[16];
-    vslam_track_report tr{};
-    VS_CHECK(fm->track_frame(predNPose.data(), frame, T_cw, &tr, cfg.use_imu ? &in : nullptr, cfg.use_imu ? &imuOut : nullptr));
-    const int M = tr.n_active;
-    int nL = 0, nR = 0;
-    VS_CHECK(vslam_extractor_count(fe, 0, &nL)); VS_CHECK(vslam_extractor_count(fe, 1, &nR));
-    // matches, MPsOutliers, source index, inFrame of the active points; matchedIdxsL; left visibility of every uploaded point
-    std::vector<int> matches((size_t)std::max(M, 1) * 2), actIdx(std::max(M, 1)), matchedL(std::max(nL, 1));
-    std::vector<uint8_t> outl(std::max(M, 1)), inF(std::max(M, 1)), visL(std::max(N, 1));
-    {
-        const size_t need = (size_t)std::max(M, 1) * 14 + (size_t)std::max(nL, 1) * 4 + (size_t)std::max(N, 1) + 64;
-        if (need > dnCap) { if (h_dn) hipHostFree(h_dn); dnCap = need + need / 2; VS_HIP(hipHostMalloc((void**)&h_dn, dnCap, hipHostMallocDefault)); }
-        VS_CHECK(fm->track_fetch_state(h_dn, M, nL, N));
-        const uint8_t* p = h_dn;
-        memcpy(matches.data(), p, (size_t)M * 8); p += (size_t)M * 8;
-        memcpy(actIdx.data(), p, (size_t)M * 4); p += (size_t)M * 4;
-        memcpy(matchedL.data(), p, (size_t)nL * 4); p += (size_t)nL * 4;
-        memcpy(outl.data(), p, M); p += M;
-        memcpy(inF.data(), p, M); p += M;
-        memcpy(visL.data(), p, N);
-    }
-    matches.resize((size_t)M * 2); actIdx.resize(M); outl.resize(M); inF.resize(M);
-    const M4 estimPose = m4_from(T_cw);
+}
+
+void vslam_system::frame_imu_input(SysFrameCtx& c) {
+    vslam_imu_input& in = c.in;
+    in = vslam_imu_input{};
+    for (int k = 0; k < 3; k++) in.gravity[k] = cfg.gravity[k];
+    in.gyro_noise_density = cfg.gyro_noise_density; in.gyro_random_walk = cfg.gyro_random_walk;
+    in.accel_noise_density = cfg.accel_noise_density; in.accel_random_walk = cfg.accel_random_walk;
+    memcpy(in.T_body_sensor, cfg.T_body_sensor, sizeof(in.T_body_sensor));
+    memcpy(in.T_wc_prev, camPose.data(), sizeof(in.T_wc_prev));
+    for (int k = 0; k < 3; k++) in.velocity_prev[k] = velocity[k];
+    for (int k = 0; k < 6; k++) in.bias_prev[k] = bias[k];
+    in.n_samples = c.imu->n; in.hz = cfg.imu_hz; in.acceleration = c.imu->acceleration; in.angular_velocity = c.imu->angular_velocity;
+    in.timestamps_ns = c.imu->timestamps_ns;
+}
+
+// st: the device's per-frame state (matches [M][2], source index [M], matchedIdxsL [nL], MPsOutliers [M], inFrame [M],
+// left visibility of every uploaded point [N]); c.tr / c.T_cw / c.imuOut: the tracking block's result
+vslam_status vslam_system::frame_post(SysFrameCtx& c, const SysTrackState& st, double* T_wc_out, vslam_frame_report* rep) {
+    const vslam_track_report& tr = c.tr;
+    const int M = tr.n_active, N = c.N, nL = st.nL;
+    const std::vector<int>& cand = c.cand;
+    std::vector<int> matches(st.matches, st.matches + (size_t)M * 2), matchedL(st.matchedL, st.matchedL + nL);
+    std::vector<uint8_t> outl(st.outl, st.outl + M);
+    const int* actIdx = st.actIdx;
+    const uint8_t* inF = st.inF;
+    const uint8_t* visL = st.visL;
+    vslam_frame_report& out = c.out;
+    const int frame = c.frame;
+    const M4 estimPose = m4_from(c.T_cw);
     const M4 poseEst = m4_rigid_inv(estimPose);            // (paired with the solve's own T_wc -> T_cw inversion)
     std::vector<int> act(M);
     bool isKF = false;
@@ -574,8 +430,8 @@ vslam_status vslam_system::track(const uint8_t* L, const uint8_t* R, int stride,
             mp.isOutlier = true;
         }
         if (cfg.use_imu) {
-            for (int k = 0; k < 3; k++) velocity[k] = imuOut.velocity[k];       // mVelocity = mNewVelocity (:1277)
-            for (int k = 0; k < 6; k++) bias[k] = imuOut.bias[k];               // initialBias as the frame's last solve left it
+            for (int k = 0; k < 3; k++) velocity[k] = c.imuOut.velocity[k];       // mVelocity = mNewVelocity (:1277)
+            for (int k = 0; k < 6; k++) bias[k] = c.imuOut.bias[k];               // initialBias as the frame's last solve left it
         }
         lastMatches = matches; lastOutliers = outl;
         out.n_keyframes = (int)keyFrames.size(); out.n_map_points = (int)mapPoints.size(); out.n_active_after = (int)active.size();
@@ -587,8 +443,12 @@ vslam_status vslam_system::track(const uint8_t* L, const uint8_t* R, int stride,
     if (cfg.local_mapping == 1 && keyFrameAdded && !LBADone) {
         VS_CHECK(local_mapping());
     } else if (cfg.local_mapping == 2 && keyFrameAdded && !LBADone) {
-        { std::lock_guard<std::mutex> lk(wMu); mappingBusy = true; }
-        wCv.notify_all();
+        bool submit = false;
+        { std::lock_guard<std::mutex> lk(wMu); if (!mappingBusy) { mappingBusy = true; submit = true; } }
+        if (submit) {
+            if (mapExec) mapExec(mapExecArg, this);       // the batch's mapping threads
+            else wCv.notify_all();
+        }
     }
     if (mappingReportFresh) {
         std::lock_guard<std::mutex> lk(mapMutex);
@@ -604,22 +464,70 @@ vslam_status vslam_system::track(const uint8_t* L, const uint8_t* R, int stride,
     return VSLAM_OK;
 }
 
-void vslam_system::worker_loop() {
+vslam_status vslam_system::track(const uint8_t* L, const uint8_t* R, int stride, bool onDevice, int frame,
+                                 const vslam_imu_bucket* imu, double* T_wc_out, vslam_frame_report* rep) {
+    if (!L || !R || !T_wc_out) return VSLAM_ERR_INVALID;
+    SysFrameCtx& c = ctx;
+    VS_CHECK(frame_begin(c, frame, imu));
+    // images -> pyramid level 0, extraction, stereo match (extractORBAndStereoMatch :56-70); nothing here depends on the map
+    if (onDevice) { VS_CHECK(vslam_extractor_set_image_device(fe, img0, L, stride)); VS_CHECK(vslam_extractor_set_image_device(fe, img0 + 1, R, stride)); }
+    else { VS_CHECK(vslam_extractor_set_image_host(fe, img0, L, stride)); VS_CHECK(vslam_extractor_set_image_host(fe, img0 + 1, R, stride)); }
+    VS_CHECK(vslam_extractor_run(fe));
+    VS_CHECK(fm->stereo_match());
+    if (frame == 0) return frame_first(c, T_wc_out, rep);
+    // ---- activeMapPoints -> the tracker's device arrays ---------------------------------------------------------------------
+    const int N = frame_candidates(c);
+    {
+        const size_t need = (size_t)std::max(N, 1) * (24 + 32 + 4);
+        if (need > upCap) { if (h_up) hipHostFree(h_up); upCap = need + need / 2; VS_HIP(hipHostMalloc((void**)&h_up, upCap, hipHostMallocDefault)); }
+        double* xyz = (double*)h_up; uint8_t* desc = h_up + (size_t)N * 24; float* msd = (float*)(h_up + (size_t)N * 56);
+        frame_fill_upload(c, xyz, desc, msd);
+        VS_CHECK(fm->track_upload_map(xyz, desc, msd, N));
+    }
+    // ---- the frame's tracking block on the device (:1168-1241) -------------------------------------------------------
+    if (cfg.use_imu) frame_imu_input(c);
+    VS_CHECK(fm->track_frame(predNPose.data(), frame, c.T_cw, &c.tr, cfg.use_imu ? &c.in : nullptr, cfg.use_imu ? &c.imuOut : nullptr));
+    const int M = c.tr.n_active;
+    int nL = 0;
+    VS_CHECK(vslam_extractor_count(fe, img0, &nL));
+    SysTrackState st{};
+    {
+        const size_t need = (size_t)std::max(M, 1) * 14 + (size_t)std::max(nL, 1) * 4 + (size_t)std::max(N, 1) + 64;
+        if (need > dnCap) { if (h_dn) hipHostFree(h_dn); dnCap = need + need / 2; VS_HIP(hipHostMalloc((void**)&h_dn, dnCap, hipHostMallocDefault)); }
+        VS_CHECK(fm->track_fetch_state(h_dn, M, nL, N));
+        const uint8_t* p = h_dn;
+        st.matches = (const int*)p; p += (size_t)M * 8;
+        st.actIdx = (const int*)p; p += (size_t)M * 4;
+        st.matchedL = (const int*)p; p += (size_t)nL * 4;
+        st.outl = p; p += M;
+        st.inF = p; p += M;
+        st.visL = p;
+        st.nL = nL;
+    }
+    return frame_post(c, st, T_wc_out, rep);
+}
+
+// one mapping job on the calling thread (the session's own worker, or one of the batch's mapping threads)
+void vslam_system::run_mapping() {
     hipSetDevice(cfg.device);
+    vslam_status s = VSLAM_OK;
+    if (keyFrameAdded && !LBADone) s = local_mapping();
+    {
+        std::lock_guard<std::mutex> lk(wMu);
+        if (s != VSLAM_OK && workerStatus == VSLAM_OK) { workerStatus = s; snprintf(workerError, sizeof(workerError), "%s", vslam_last_error()); }
+        mappingBusy = false;
+    }
+    wCv.notify_all();
+}
+
+void vslam_system::worker_loop() {
     for (;;) {
         {
             std::unique_lock<std::mutex> lk(wMu);
             wCv.wait(lk, [&] { return stopRequested || mappingBusy; });
             if (stopRequested) return;
         }
-        vslam_status s = VSLAM_OK;
-        if (keyFrameAdded && !LBADone) s = local_mapping();
-        {
-            std::lock_guard<std::mutex> lk(wMu);
-            if (s != VSLAM_OK && workerStatus == VSLAM_OK) { workerStatus = s; snprintf(workerError, sizeof(workerError), "%s", vslam_last_error()); }
-            mappingBusy = false;
-        }
-        wCv.notify_all();
+        run_mapping();
     }
 }
 

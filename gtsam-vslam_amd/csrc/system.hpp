@@ -1,0 +1,174 @@
+// Declarations of the closed tracking <-> local-mapping loop (system.hip), shared with the lockstep batch driver (batch.hip).
+#pragma once
+#include "matcher.hpp"
+#include "dmath.hpp"
+#include <algorithm>
+#include <array>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+
+namespace vslam_sys {
+
+using M4 = std::array<double, 16>;
+
+inline M4 m4_identity() { M4 r{}; r[0] = r[5] = r[10] = r[15] = 1.0; return r; }
+inline M4 m4_from(const double* p) { M4 r; for (int i = 0; i < 16; i++) r[i] = p[i]; return r; }
+inline M4 m4_mul(const M4& a, const M4& b) {
+    M4 r;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            double s = 0;
+            for (int k = 0; k < 4; k++) s += a[4 * i + k] * b[4 * k + j];
+            r[4 * i + j] = s;
+        }
+    return r;
+}
+// general inverse of [A t; 0 1]: A^-1 by cofactors, -A^-1 t  (Eigen's Matrix4d::inverse() on an affine matrix)
+inline M4 m4_affine_inv(const M4& T) {
+    const double a = T[0], b = T[1], c = T[2], d = T[4], e = T[5], f = T[6], g = T[8], h = T[9], i = T[10];
+    const double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+    const double det = a * A + b * B + c * C;
+    const double inv[9] = {A / det, -(b * i - c * h) / det, (b * f - c * e) / det,
+                           B / det, (a * i - c * g) / det, -(a * f - c * d) / det,
+                           C / det, -(a * h - b * g) / det, (a * e - b * d) / det};
+    M4 r = m4_identity();
+    for (int q = 0; q < 3; q++) {
+        for (int p = 0; p < 3; p++) r[4 * q + p] = inv[3 * q + p];
+        r[4 * q + 3] = -(inv[3 * q] * T[3] + inv[3 * q + 1] * T[7] + inv[3 * q + 2] * T[11]);
+    }
+    return r;
+}
+// (R^T, -R^T t): the form the pose kernels use for the paired inversions around a solve
+inline M4 m4_rigid_inv(const M4& T) {
+    M4 r = m4_identity();
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) r[4 * i + j] = T[4 * j + i];
+        r[4 * i + 3] = -(T[i] * T[3] + T[4 + i] * T[7] + T[8 + i] * T[11]);
+    }
+    return r;
+}
+
+struct SysKeys {                       // TrackedKeys (include/FeatureExtractor.h:18-50), host copy of a keyframe's frame
+    std::vector<vslam_keypoint> kL, kR;
+    std::vector<uint8_t> dL, dR;       // n x 32
+    std::vector<int> rightIdxs, leftIdxs;
+    std::vector<float> depth;
+    std::vector<uint8_t> close;
+};
+
+struct KfMatch { int kf, l, r; };      // one entry of MapPoint::kFMatches (keyframe number, left idx, right idx)
+
+struct SysMP {                         // MapPoint (include/Map.h:22-98)
+    double wp[3];
+    uint8_t desc[32];
+    std::vector<KfMatch> kfm;          // insertion ordered
+    float maxScaleDist = 0, minScaleDist = 0;
+    int unMCnt = 0;
+    bool isOutlier = false, inFrame = true;
+    long long kdx = 0, idx = 0;
+    int lastObsKF = -1, LBAID = -1;
+    int find(int kf) const { for (size_t i = 0; i < kfm.size(); i++) if (kfm[i].kf == kf) return (int)i; return -1; }
+};
+
+struct SysKF {                         // KeyFrame (include/KeyFrame.h) - keyframes only; plain frames live in SysFrame
+    int numb = 0, frameIdx = 0;
+    M4 pose, poseInv, refPose;
+    bool fixed = false;
+    int prevKF = -1, nextKF = -1;
+    SysKeys keys;
+    std::vector<int> unF, unFR, lmpL, lmpR;            // unMatchedF / unMatchedFR, localMapPoints(R) as map-point indices
+    std::vector<std::pair<int, int>> sortedKFWeights;   // (weight, keyframe number)
+    int LBAID = -1, nKeysTracked = 0;
+    void setPose(const M4& T) { pose = T; poseInv = m4_affine_inv(T); }      // CameraPose::setPose (src/Camera.cpp:10-15)
+};
+
+// per-frame context handed between the phases of vslam_system::track
+struct SysFrameCtx {
+    int frame = 0; const vslam_imu_bucket* imu = nullptr;
+    std::vector<int> cand; int N = 0;               // uploaded candidates (map-point indices)
+    vslam_imu_input in{}; vslam_imu_output imuOut{};
+    vslam_track_report tr{}; double T_cw[16] = {0};
+    vslam_frame_report out{};
+};
+// the device's per-frame tracking state, as host pointers (layouts differ between the one-session and the batched fetch)
+struct SysTrackState { const int* matches; const int* actIdx; const int* matchedL; const uint8_t* outl; const uint8_t* inF; const uint8_t* visL; int nL; };
+
+struct SysFrame { bool isKF; int kf; int prevKF; M4 refPose; };   // allFramesPoses entry (trajectory output)
+
+}  // namespace vslam_sys
+
+using namespace vslam_sys;
+
+struct vslam_system {
+    vslam_system_config cfg{};
+    vslam_extractor* fe = nullptr;
+    vslam_matcher* fm = nullptr;
+    std::vector<float> scalePyr, sigmaF, invSigmaF;
+    int nLev = 8;
+    // zedPtr->mCameraPose, prediction state (include/FeatureTracker.h:34-43)
+    M4 camPose, camPoseInv, camRefPose, predNPose, predNPoseInv, predNPoseRef, lastKFPoseInv;
+    int latestKF = -1;
+    float precCheckMatches = 0.9f;
+    int lastKFTrackedNumb = 0, insertKeyFrameCount = 0;
+    std::deque<SysKF> keyFrames;       // map->keyFrames (kIdx = size)
+    std::deque<SysMP> mapPoints;       // map->mapPoints (pIdx = size)
+    std::vector<int> active;           // map->activeMapPoints
+    std::vector<SysFrame> allFrames;
+    std::atomic<bool> keyFrameAdded{false}, LBADone{false};     // Map::keyFrameAdded / LBADone (plain bools in the reference)
+    std::atomic<int> endLBAIdx{0};
+    long long mpIdx = -1;              // LocalMapper's function-static mpIdx (src/OptimizationBA.cpp:93)
+    double velocity[3] = {0, 0, 0}, bias[6] = {0, 0, 0, 0, 0, 0};
+    // last frame (test taps)
+    std::vector<int> lastMatches; std::vector<uint8_t> lastOutliers;
+    vslam_frame_report lastMapping{};  // mapping fields of the most recent local-mapping pass
+    std::atomic<bool> mappingReportFresh{false};
+    // per-kernel-group device time (HIP events), summed since the last read; BA groups are collected on the thread that runs it
+    std::atomic<int> timingOn{0};
+    std::mutex tMu;
+    std::vector<std::pair<const char*, float>> baTimes;
+    int baTimedCalls = 0;
+    // pinned staging
+    uint8_t* h_up = nullptr; size_t upCap = 0;
+    uint8_t* h_dn = nullptr; size_t dnCap = 0;
+    // optimizer thread (local_mapping == 2)
+    std::mutex mapMutex;
+    std::thread worker;
+    std::mutex wMu; std::condition_variable wCv;
+    bool stopRequested = false, mappingBusy = false;
+    vslam_status workerStatus = VSLAM_OK;
+    char workerError[256] = "";
+
+    // shared-extractor form (vslam_batch): images img0 / img0 + 1 of `sharedFe`, everything on `sharedStream`
+    bool ownsFe = true; int img0 = 0;
+    void (*mapExec)(void*, vslam_system*) = nullptr; void* mapExecArg = nullptr;      // mapping jobs go to the batch's threads
+    SysFrameCtx ctx;
+    vslam_status init(const vslam_system_config* c, vslam_extractor* sharedFe = nullptr, int imgBase = 0, hipStream_t sharedStream = nullptr);
+    void release();
+    vslam_status frame_begin(SysFrameCtx& c, int frame, const vslam_imu_bucket* imu);
+    vslam_status frame_first(SysFrameCtx& c, double* T_wc_out, vslam_frame_report* rep);
+    int frame_candidates(SysFrameCtx& c);
+    void frame_fill_upload(const SysFrameCtx& c, double* xyz, uint8_t* desc, float* msd);
+    void frame_imu_input(SysFrameCtx& c);
+    vslam_status frame_post(SysFrameCtx& c, const SysTrackState& st, double* T_wc_out, vslam_frame_report* rep);
+    void run_mapping();
+    vslam_status track(const uint8_t* L, const uint8_t* R, int stride, bool onDevice, int frame, const vslam_imu_bucket* imu,
+                       double* T_wc_out, vslam_frame_report* rep);
+    vslam_status fetch_keys(SysKeys& k);
+    void mp_update(SysMP& mp, int kfNumb, std::vector<int>& needDesc, int mpIndex);
+    vslam_status calc_descriptors(const std::vector<int>& mps);
+    void backproject(const SysKeys& k, int i, const M4& pose, double* out) const;
+    vslam_status initialize_map(const SysKeys& keys, int frame);
+    vslam_status insert_keyframe(SysKeys& keys, const std::vector<int>& matchedL, const std::vector<int>& matches,
+                                 int nStereo, const M4& estimPose, const std::vector<uint8_t>& outl, const std::vector<int>& act, int frame);
+    void calc_connections(SysKF& kf);
+    vslam_status change_poses_lca(int endIdx);
+    vslam_status kf_update_pose(SysKF& kf, const M4& keyPose);
+    vslam_status local_mapping();
+    vslam_status find_new_points(const std::vector<int>& actKeyF, int& nNew);
+    vslam_status local_ba(const std::vector<int>& actKeyF);
+    void worker_loop();
+};
+

@@ -7,6 +7,7 @@
 // reference's own retry rule inspects (inlier count per round).
 #include "matcher.hpp"
 #include "dmath.hpp"
+#include "track_dev.hpp"
 
 namespace vslam {
 
@@ -83,28 +84,25 @@ __device__ __forceinline__ W2F world_to_frame(const double* pc, bool right, doub
     return r;
 }
 
-struct TrackGeom { double fx, fy, cx, cy, b; int w, h; double logScale; int nLev; };
 
 // removeOutOfFrameMPs: keep the map points visible in BOTH cameras under the predicted pose,
 // order preserved; fills every per-frame buffer of the matching / pose kernels.
-__global__ __launch_bounds__(1024) void k_track_predict(int N, const double* __restrict__ xyz,
-                                                        const uint8_t* __restrict__ desc,
-                                                        const float* __restrict__ msd,
-                                                        const uint8_t* __restrict__ outl, DPose Tcw,
-                                                        TrackGeom G, vslam_mappoint_view* __restrict__ mpv,
-                                                        double* __restrict__ points, uint8_t* __restrict__ flags,
-                                                        size_t flagStride, int* __restrict__ matches,
-                                                        int* __restrict__ act, int* __restrict__ count,
-                                                        int* __restrict__ matchedL, int nL,
-                                                        int* __restrict__ matchedR, int nR,
-                                                        double* __restrict__ poseIO, int leftOnly,
-                                                        uint8_t* __restrict__ visLeft) {
+__device__ __forceinline__ void track_predict_body(const PredictLane& L) {
     __shared__ int wsum[16];
     int run = 0;
-    N = min(N, count[0]);          // N is the host's upper bound; the map size stays on the device
-    for (int k = threadIdx.x; k < nL; k += 1024) matchedL[k] = -1;
-    for (int k = threadIdx.x; k < nR; k += 1024) matchedR[k] = -1;
-    if (threadIdx.x == 0) pose_to_rm16(Tcw, poseIO);      // predNPoseInv: initial estimPose
+    const int N = L.setCount ? L.N : min(L.N, L.count[0]);   // (upper bound: the map size stays on the device)
+    if (L.setCount && threadIdx.x == 0) L.count[0] = L.N;
+    const double* __restrict__ xyz = L.xyz;
+    const uint8_t* __restrict__ desc = L.desc;
+    const float* __restrict__ msd = L.msd;
+    const uint8_t* __restrict__ outl = L.outl;
+    const TrackGeom& G = L.G;
+    const DPose& Tcw = L.Tcw;
+    uint8_t* __restrict__ flags = L.flags;
+    const size_t flagStride = L.flagStride;
+    for (int k = threadIdx.x; k < L.nL; k += 1024) L.matchedL[k] = -1;
+    for (int k = threadIdx.x; k < L.nR; k += 1024) L.matchedR[k] = -1;
+    if (threadIdx.x == 0 && L.poseIO) pose_to_rm16(Tcw, L.poseIO);      // predNPoseInv: initial estimPose
     for (int base = 0; base < N; base += 1024) {
         const int i = base + threadIdx.x;
         bool keep = false;
@@ -116,8 +114,8 @@ __global__ __launch_bounds__(1024) void k_track_predict(int N, const double* __r
             for (int c = 0; c < 3; c++) pc[c] += Tcw.t[c];
             l = world_to_frame(pc, false, G.fx, G.fy, G.cx, G.cy, G.b, G.w, G.h, msd[i], G.logScale, G.nLev);
             r = world_to_frame(pc, true, G.fx, G.fy, G.cx, G.cy, G.b, G.w, G.h, msd[i], G.logScale, G.nLev);
-            keep = l.vis && (leftOnly || r.vis);     // removeOutOfFrameMPs / removeOutOfFrameMPsMono (:910-968)
-            if (visLeft) visLeft[i] = l.vis ? 1 : 0; // MapPoint::inFrame as worldToFrame(left) leaves it (read by localBA :566)
+            keep = l.vis && (L.leftOnly || r.vis);     // removeOutOfFrameMPs / removeOutOfFrameMPsMono (:910-968)
+            if (L.visLeft) L.visLeft[i] = l.vis ? 1 : 0; // MapPoint::inFrame as worldToFrame(left) leaves it (read by localBA :566)
         }
         int tot;
         const int pos = run + block_excl_scan_1024(keep, wsum, tot);
@@ -129,18 +127,21 @@ __global__ __launch_bounds__(1024) void k_track_predict(int N, const double* __r
             v.pred_lx = l.u; v.pred_ly = l.v; v.pred_rx = r.u; v.pred_ry = r.v;
             v.scale_level_l = l.lvl; v.scale_level_r = r.lvl;
             v.in_frame = 1; v.in_frame_r = r.vis ? 1 : 0; v.pad_[0] = v.pad_[1] = 0;
-            mpv[pos] = v;
-            points[3 * (size_t)pos] = xyz[3 * (size_t)i];
-            points[3 * (size_t)pos + 1] = xyz[3 * (size_t)i + 1];
-            points[3 * (size_t)pos + 2] = xyz[3 * (size_t)i + 2];
+            L.mpv[pos] = v;
+            L.points[3 * (size_t)pos] = xyz[3 * (size_t)i];
+            L.points[3 * (size_t)pos + 1] = xyz[3 * (size_t)i + 1];
+            L.points[3 * (size_t)pos + 2] = xyz[3 * (size_t)i + 2];
             flags[pos] = 1; flags[flagStride + pos] = r.vis ? 1 : 0; flags[2 * flagStride + pos] = 0; flags[3 * flagStride + pos] = 0;
-            matches[2 * pos] = -1; matches[2 * pos + 1] = -1;
-            act[pos] = i;
+            L.matches[2 * pos] = -1; L.matches[2 * pos + 1] = -1;
+            L.act[pos] = i;
         }
         run += tot;
     }
-    if (threadIdx.x == 0) count[1] = run;
+    if (threadIdx.x == 0) L.count[1] = run;
 }
+__global__ __launch_bounds__(1024) void k_track_predict(PredictLane L) { track_predict_body(L); }
+// batched form: blockIdx.x = lane
+__global__ __launch_bounds__(1024) void k_track_predict_b(const PredictLane* __restrict__ lanes) { track_predict_body(*lane_entry(lanes, blockIdx.x)); }
 
 __global__ __launch_bounds__(256) void k_fill_int(int* p, int n, int v) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -154,41 +155,71 @@ __global__ __launch_bounds__(256) void k_track_reset(int M, int* matches, uint8_
 }
 
 // PredictMPsPosition with the estimated pose (src/FeatureTracker.cpp:969-1014)
-__global__ __launch_bounds__(256) void k_track_repredict(int M, const int* __restrict__ Mdev, const int* __restrict__ gate,
-                                                         int gateMin, const double* __restrict__ points,
-                                                         const float* __restrict__ msd,
-                                                         const int* __restrict__ act, const double* __restrict__ poseIO,
-                                                         TrackGeom G, vslam_mappoint_view* __restrict__ mpv,
-                                                         uint8_t* __restrict__ flags, size_t flagStride,
-                                                         int* __restrict__ matches, int* __restrict__ matchedL,
-                                                         int* __restrict__ matchedR) {
+__device__ __forceinline__ void track_repredict_body(const RepredictLane& L) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (gate && *gate < gateMin) return;
-    if (Mdev) M = min(M, *Mdev);
+    if (L.gate && *L.gate < L.gateMin) return;
+    int M = L.M;
+    if (L.Mdev) M = min(M, *L.Mdev);
     if (i >= M) return;
+    const TrackGeom& G = L.G;
+    uint8_t* flags = L.flags;
+    const size_t flagStride = L.flagStride;
+    int* matches = L.matches;
     DPose Tcw;
-    pose_from_rm16(poseIO, Tcw);
-    const double p[3] = {points[3 * (size_t)i], points[3 * (size_t)i + 1], points[3 * (size_t)i + 2]};
+    pose_from_rm16(L.poseIO, Tcw);
+    const double p[3] = {L.points[3 * (size_t)i], L.points[3 * (size_t)i + 1], L.points[3 * (size_t)i + 2]};
     double pc[3];
     mat3_vec(Tcw.R, p, pc);
     for (int c = 0; c < 3; c++) pc[c] += Tcw.t[c];
-    const float m = msd[act[i]];
+    const float m = L.msd[L.act[i]];
     const W2F l = world_to_frame(pc, false, G.fx, G.fy, G.cx, G.cy, G.b, G.w, G.h, m, G.logScale, G.nLev);
     const W2F r = world_to_frame(pc, true, G.fx, G.fy, G.cx, G.cy, G.b, G.w, G.h, m, G.logScale, G.nLev);
-    vslam_mappoint_view* v = mpv + i;
+    vslam_mappoint_view* v = L.mpv + i;
     int first = matches[2 * i], second = matches[2 * i + 1];
     v->in_frame = l.vis; flags[i] = l.vis;
     if (l.vis) { v->pred_lx = l.u; v->pred_ly = l.v; v->scale_level_l = l.lvl; }
-    else if (first >= 0) { matchedL[first] = -1; first = -1; }
+    else if (first >= 0) { L.matchedL[first] = -1; first = -1; }
     v->in_frame_r = r.vis; flags[flagStride + i] = r.vis;
     if (r.vis) { v->pred_rx = r.u; v->pred_ry = r.v; v->scale_level_r = r.lvl; }
-    else if (second >= 0) { matchedR[second] = -1; second = -1; }
+    else if (second >= 0) { L.matchedR[second] = -1; second = -1; }
     if (flags[3 * flagStride + i]) {
         flags[3 * flagStride + i] = 0;
-        if (first >= 0) { matchedL[first] = -1; first = -1; }
-        if (second >= 0) { matchedR[second] = -1; second = -1; }
+        if (first >= 0) { L.matchedL[first] = -1; first = -1; }
+        if (second >= 0) { L.matchedR[second] = -1; second = -1; }
     }
     matches[2 * i] = first; matches[2 * i + 1] = second;
+}
+__global__ __launch_bounds__(256) void k_track_repredict(RepredictLane L) { track_repredict_body(L); }
+// batched form: blockIdx.y = lane
+__global__ __launch_bounds__(256) void k_track_repredict_b(const RepredictLane* __restrict__ lanes) { track_repredict_body(*lane_entry(lanes, blockIdx.y)); }
+
+// per-frame state of every lane packed for ONE device-to-host copy (layout: vslam_matcher::track_fetch_state)
+__global__ __launch_bounds__(256) void k_track_pack_b(const PackLane* __restrict__ lanes) {
+    const PackLane& L = *lane_entry(lanes, blockIdx.y);
+    const int M = min(L.N, L.count[1]), N = L.N, nL = L.nL;
+    uint8_t* o = L.out;
+    int* oMatches = (int*)o;                       // [N][2]
+    int* oAct = oMatches + 2 * (size_t)N;          // [N]
+    int* oMatchedL = oAct + N;                     // [nL]
+    uint8_t* oOut = (uint8_t*)(oMatchedL + nL);    // [N] MPsOutliers
+    uint8_t* oInF = oOut + N;                      // [N] inFrame
+    uint8_t* oVis = oInF + N;                      // [N] left visibility under the predicted pose
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+        if (i < M) {
+            oMatches[2 * i] = L.matches[2 * i]; oMatches[2 * i + 1] = L.matches[2 * i + 1];
+            oAct[i] = L.act[i]; oOut[i] = L.flags[3 * L.flagStride + i]; oInF[i] = L.flags[i];
+        }
+        oVis[i] = L.visLeft[i];
+    }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nL; i += gridDim.x * 256) oMatchedL[i] = L.matchedL[i];
+}
+
+void launch_track_predict_batch(hipStream_t s, const PredictLane* d, int B) { hipLaunchKernelGGL(k_track_predict_b, dim3(B), dim3(1024), 0, s, d); }
+void launch_track_repredict_batch(hipStream_t s, const RepredictLane* d, int B, int maxM) {
+    if (maxM > 0) hipLaunchKernelGGL(k_track_repredict_b, dim3((maxM + 255) / 256, B), dim3(256), 0, s, d);
+}
+void launch_track_pack_batch(hipStream_t s, const PackLane* d, int B, int maxN) {
+    hipLaunchKernelGGL(k_track_pack_b, dim3(std::max(1, std::min(16, (maxN + 255) / 256)), B), dim3(256), 0, s, d);
 }
 
 }  // namespace vslam
@@ -198,21 +229,33 @@ using namespace vslam;
 vslam_status vslam_matcher::ensure_track_cap(int n) {
     if (n <= trCap && d_trCount) return VSLAM_OK;
     if (n > trCap) {
-        double* nx = nullptr; uint8_t* nd = nullptr; float* nm = nullptr; uint8_t* no = nullptr; int* na = nullptr; uint8_t* nv = nullptr;
         const int cap = vslam::align_up(std::max(n, 1), 1024);
-        VS_HIP(hipMalloc(&nx, (size_t)cap * 24));
-        VS_HIP(hipMalloc(&nd, (size_t)cap * 32));
-        VS_HIP(hipMalloc(&nm, (size_t)cap * 4));
-        VS_HIP(hipMalloc(&no, (size_t)cap));
+        int* na = nullptr; uint8_t* nv = nullptr;
         VS_HIP(hipMalloc(&na, (size_t)cap * 4));
         VS_HIP(hipMalloc(&nv, (size_t)cap));
-        VS_HIP(hipMemset(nv, 1, (size_t)cap));
-        hipFree(d_trXyz); hipFree(d_trDesc); hipFree(d_trMsd); hipFree(d_trOutlier); hipFree(d_trAct); hipFree(d_trVisL);
-        d_trXyz = nx; d_trDesc = nd; d_trMsd = nm; d_trOutlier = no; d_trAct = na; d_trVisL = nv;
+        VS_HIP(vslam::memset_sync(nv, 1, (size_t)cap));
+        hipFree(d_trAct); hipFree(d_trVisL);
+        d_trAct = na; d_trVisL = nv;
+        if (!trExternal) {       // (external: position / descriptor / scale arrays are views into the batch's upload block)
+            double* nx = nullptr; uint8_t* nd = nullptr; float* nm = nullptr; uint8_t* no = nullptr;
+            VS_HIP(hipMalloc(&nx, (size_t)cap * 24));
+            VS_HIP(hipMalloc(&nd, (size_t)cap * 32));
+            VS_HIP(hipMalloc(&nm, (size_t)cap * 4));
+            VS_HIP(hipMalloc(&no, (size_t)cap));
+            hipFree(d_trXyz); hipFree(d_trDesc); hipFree(d_trMsd); hipFree(d_trOutlier);
+            d_trXyz = nx; d_trDesc = nd; d_trMsd = nm; d_trOutlier = no;
+        }
         trCap = cap;
     }
     VS_CHECK(ensure_res());
     return VSLAM_OK;
+}
+
+// the frame's active map points live in someone else's device block (vslam_batch's upload block): n points, none an outlier
+void vslam_matcher::track_bind_map(const double* xyz, const uint8_t* desc, const float* msd, const uint8_t* zeros, int n) {
+    d_trXyz = const_cast<double*>(xyz); d_trDesc = const_cast<uint8_t*>(desc); d_trMsd = const_cast<float*>(msd);
+    d_trOutlier = const_cast<uint8_t*>(zeros);
+    trNub = n; trN = n;
 }
 
 vslam_status vslam_matcher::track_init_map(const double* T_wc) {
@@ -235,85 +278,120 @@ vslam_status vslam_matcher::track_init_map(const double* T_wc) {
     return VSLAM_OK;
 }
 
-vslam_status vslam_matcher::track_frame(const double* T_wc_pred, int frameNumber, double* T_cw_out,
-                                        vslam_track_report* rep, const vslam_imu_input* imu, vslam_imu_output* imuOut) {
-    if (!T_wc_pred || !T_cw_out) return VSLAM_ERR_INVALID;
+// ---- one stereo frame, in three parts so that vslam_batch can run the middle one for many lanes per launch -----------
+// (1) track_begin: capacities, the frame's constants;  (2) the first pass - predict, matching round + pose solve and,
+// gated on the device by the first round's inlier count, the refinement pass - enqueued here (track_first_pass) or by
+// the batch's per-lane tables (predict_lane / proj_lane / pose_lane / repredict_lane);  (3) track_finish: the reference's
+// retry rule on the fetched result block (host-driven rounds only when the first round failed) and the report.
+vslam_status vslam_matcher::track_begin(const double* T_wc_pred, int frameNumber, bool useImu) {
+    if (!T_wc_pred) return VSLAM_ERR_INVALID;
     if (!stereoDone) { set_error("tracker_track needs a completed stereo match of the new frame"); return VSLAM_ERR_INVALID; }
-    VS_HIP(hipSetDevice(device));
-    UseMark mark{this};
-    VS_CHECK(refresh_keys());
     const int Nub = std::max(trNub, 1);
     VS_CHECK(ensure_track_cap(Nub));
     VS_CHECK(ensure_pose_cap(Nub));
     VS_CHECK(ensure_proj_cap(Nub));
-    if (imu) VS_CHECK(imu_setup(imu));      // currentIMUData: every pose solve of this frame uses the IMU branch
-    const int nL = nKeys[0], nR = nKeys[1];
     DPose Twc, Tcw;
     pose_from_rm16(T_wc_pred, Twc);
     pose_inverse(Twc, Tcw);
-    double predInv[16];
-    pose_to_rm16(Tcw, predInv);                       // predNPoseInv: initial estimPose
-    TrackGeom G{rig.fx, rig.fy, rig.cx, rig.cy, (double)rig.baseline, rig.width, rig.height,
-                (double)(float)std::log((double)feL->prm.scale), feL->nLevels};   // KeyFrame::logScale is a float
-    uint8_t* fl = d_flags;
-    const size_t pc = (size_t)poseCap;
-    const int minInliers = 50;
-    const int* Mdev = d_trCount + 1;
-    const int* gate = d_poseOut;        // inlier count of the first round
-    int* h_out = (int*)(h_res + 48);    // host mirror: poseOut slots 0 / 1
-    int* h_cnt = (int*)(h_res + 52);
+    pose_to_rm16(Tcw, trPredInv);                       // predNPoseInv: initial estimPose
+    trRad = frameNumber == 1 ? 120.f : 10.f;
+    trImu = useImu;
+    return VSLAM_OK;
+}
 
-    // The whole frame is enqueued in one go: predict, first matching round + pose solve, and - gated on the
-    // device by the first round's inlier count - the refinement pass.  The host looks at the result once; only
-    // when the first round fails (fewer than minInliers) does it step through the reference's retry rule.
+static TrackGeom track_geom(const vslam_matcher* m) {
+    return TrackGeom{m->rig.fx, m->rig.fy, m->rig.cx, m->rig.cy, (double)m->rig.baseline, m->rig.width, m->rig.height,
+                     (double)(float)std::log((double)m->feL->prm.scale), m->feL->nLevels};   // KeyFrame::logScale is a float
+}
+
+void vslam_matcher::predict_lane(vslam::PredictLane& L, int leftOnly) {
+    L = PredictLane{};
+    L.N = trNub; L.xyz = d_trXyz; L.desc = d_trDesc; L.msd = d_trMsd; L.outl = d_trOutlier;
+    pose_from_rm16(trPredInv, L.Tcw);
+    L.G = track_geom(this);
+    L.mpv = d_mpv; L.points = d_points; L.flags = d_flags; L.flagStride = (size_t)poseCap; L.matches = d_matches; L.act = d_trAct;
+    L.count = d_trCount; L.matchedL = d_matchedL; L.nL = nKeys[0]; L.matchedR = d_matchedR; L.nR = leftOnly ? 0 : nKeys[1];
+    L.poseIO = d_poseIO; L.leftOnly = leftOnly; L.visLeft = d_trVisL;
+}
+
+void vslam_matcher::repredict_lane(vslam::RepredictLane& L, const int* gate, int gateMin) {
+    L = RepredictLane{};
+    L.M = std::max(trNub, 1); L.Mdev = d_trCount + 1; L.gate = gate; L.gateMin = gateMin;
+    L.points = d_points; L.msd = d_trMsd; L.act = d_trAct; L.poseIO = d_poseIO; L.G = track_geom(this);
+    L.mpv = d_mpv; L.flags = d_flags; L.flagStride = (size_t)poseCap; L.matches = d_matches; L.matchedL = d_matchedL; L.matchedR = d_matchedR;
+}
+
+// IMU mode: estimatePoseGTSAM stores initialBias = b1 after EVERY solve (src/FeatureTracker.cpp:405), so the next solve
+// of the same frame integrates the bucket with, and pins b0 to, the bias the previous one found: imu_rechain()
+// re-runs the pre-integration from the device-resident result (on the side stream, under the next matching pass)
+vslam_status vslam_matcher::track_solve(const int* g, int slot, bool chain) {
+    const int Nub = std::max(trNub, 1);
+    const int* Mdev = d_trCount + 1;
+    if (!trImu) return pose_enqueue(Nub, Mdev, g, TRACK_MIN_INLIERS, slot);
+    VS_CHECK(pose_imu_enqueue(Nub, Mdev, g, TRACK_MIN_INLIERS, slot));
+    return chain ? imu_rechain() : VSLAM_OK;      // (the frame's last solve: nothing left to chain into)
+}
+
+// refine with the estimated pose (:1236-1241)
+vslam_status vslam_matcher::track_refine(const int* g) {
+    const int Nub = std::max(trNub, 1);
+    RepredictLane R;
+    repredict_lane(R, g, TRACK_MIN_INLIERS);
+    int tt = timer.begin("track_repredict");
+    hipLaunchKernelGGL(k_track_repredict, dim3((Nub + 255) / 256), dim3(256), 0, stream, R);
+    timer.end(tt);
+    VS_CHECK(proj_enqueue(Nub, 4.f, d_trCount + 1, g, TRACK_MIN_INLIERS));
+    return track_solve(g, 1, false);
+}
+
+vslam_status vslam_matcher::track_fetch_result() {
+    VS_HIP(hipMemcpyAsync(h_res, d_res, 64 * sizeof(double), hipMemcpyDeviceToHost, stream));
+    VS_HIP(hipStreamSynchronize(stream));
+    return VSLAM_OK;
+}
+
+// The whole frame is enqueued in one go: predict, first matching round + pose solve, and - gated on the
+// device by the first round's inlier count - the refinement pass.  The host looks at the result once; only
+// when the first round fails (fewer than minInliers) does it step through the reference's retry rule.
+vslam_status vslam_matcher::track_first_pass() {
+    const int Nub = std::max(trNub, 1);
+    PredictLane P;
+    predict_lane(P, 0);
     int t = timer.begin("track_predict");
-    hipLaunchKernelGGL(k_track_predict, dim3(1), dim3(1024), 0, stream, trNub, d_trXyz, d_trDesc, d_trMsd, d_trOutlier, Tcw, G,
-                       d_mpv, d_points, fl, pc, d_matches, d_trAct, d_trCount, d_matchedL, nL, d_matchedR, nR, d_poseIO, 0, d_trVisL);
+    hipLaunchKernelGGL(k_track_predict, dim3(1), dim3(1024), 0, stream, P);
     timer.end(t);
     VS_HIP(hipGetLastError());
+    VS_CHECK(proj_enqueue(Nub, trRad, d_trCount + 1));
+    VS_CHECK(track_solve(nullptr, 0, true));
+    return track_refine(d_poseOut);       // gate: inlier count of the first round
+}
 
-    float rad = frameNumber == 1 ? 120.f : 10.f;
-    // IMU mode: estimatePoseGTSAM stores initialBias = b1 after EVERY solve (src/FeatureTracker.cpp:405), so the next solve
-    // of the same frame integrates the bucket with, and pins b0 to, the bias the previous one found: imu_rechain()
-    // re-runs the pre-integration from the device-resident result (on the side stream, under the next matching pass)
-    auto solve = [&](const int* g, int slot, bool chain = true) -> vslam_status {
-        if (!imu) return pose_enqueue(Nub, Mdev, g, minInliers, slot);
-        VS_CHECK(pose_imu_enqueue(Nub, Mdev, g, minInliers, slot));
-        return chain ? imu_rechain() : VSLAM_OK;      // (the frame's last solve: nothing left to chain into)
-    };
-    auto refine = [&](const int* g) -> vslam_status {
-        // refine with the estimated pose (:1236-1241)
-        int tt = timer.begin("track_repredict");
-        hipLaunchKernelGGL(k_track_repredict, dim3((Nub + 255) / 256), dim3(256), 0, stream, Nub, Mdev, g, minInliers, d_points,
-                           d_trMsd, d_trAct, d_poseIO, G, d_mpv, fl, pc, d_matches, d_matchedL, d_matchedR);
-        timer.end(tt);
-        VS_CHECK(proj_enqueue(Nub, 4.f, Mdev, g, minInliers));
-        VS_CHECK(solve(g, 1, false));
-        return VSLAM_OK;
-    };
-    auto fetch = [&]() -> vslam_status {
-        VS_HIP(hipMemcpyAsync(h_res, d_res, 64 * sizeof(double), hipMemcpyDeviceToHost, stream));
-        VS_HIP(hipStreamSynchronize(stream));
-        return VSLAM_OK;
-    };
-    VS_CHECK(proj_enqueue(Nub, rad, Mdev));
-    VS_CHECK(solve(nullptr, 0));
-    VS_CHECK(refine(gate));
-    VS_CHECK(fetch());
+vslam_status vslam_matcher::track_finish(double* T_cw_out, vslam_track_report* rep, vslam_imu_output* imuOut) {
+    const int Nub = std::max(trNub, 1);
+    const int nL = nKeys[0], nR = nKeys[1];
+    const int minInliers = TRACK_MIN_INLIERS;
+    const int* Mdev = d_trCount + 1;
+    int* h_out = (int*)(h_res + 48);    // host mirror: poseOut slots 0 / 1
+    int* h_cnt = (int*)(h_res + 52);
+    const size_t pc = (size_t)poseCap;
+    uint8_t* fl = d_flags;
+    float rad = trRad;
     const int M = h_cnt[1];
     trN = h_cnt[0];
     actN = M;
     int rounds = 1, nIn = h_out[0], lmIters = h_out[2];
+    trRetried = false;
 
     if (nIn < minInliers) {
         // retry loop (src/FeatureTracker.cpp:1184-1233); the gated refinement above did nothing
+        trRetried = true;
         int prevIn = -1;
         float prevrad = rad;
         bool toBreak = false;
         for (;;) {
             // tail of the failed round: reset, widen or fall back
             if (toBreak) break;
-            VS_HIP(hipMemcpyAsync(d_poseIO, predInv, sizeof(predInv), hipMemcpyHostToDevice, stream));
+            VS_HIP(hipMemcpyAsync(d_poseIO, trPredInv, sizeof(trPredInv), hipMemcpyHostToDevice, stream));
             if (nL) hipLaunchKernelGGL(k_fill_int, dim3((nL + 255) / 256), dim3(256), 0, stream, d_matchedL, nL, -1);
             if (nR) hipLaunchKernelGGL(k_fill_int, dim3((nR + 255) / 256), dim3(256), 0, stream, d_matchedR, nR, -1);
             if (M) hipLaunchKernelGGL(k_track_reset, dim3((M + 255) / 256), dim3(256), 0, stream, M, d_matches, fl + 3 * pc);
@@ -323,22 +401,35 @@ vslam_status vslam_matcher::track_frame(const double* T_wc_pred, int frameNumber
             // next round
             rounds++;
             VS_CHECK(proj_enqueue(Nub, rad, Mdev));
-            VS_CHECK(solve(nullptr, 0));
-            VS_CHECK(fetch());
+            VS_CHECK(track_solve(nullptr, 0, true));
+            VS_CHECK(track_fetch_result());
             nIn = h_out[0]; lmIters += h_out[2];
             if (nIn >= minInliers) break;
         }
-        VS_CHECK(refine(nullptr));
-        VS_CHECK(fetch());
+        VS_CHECK(track_refine(nullptr));
+        VS_CHECK(track_fetch_result());
     }
     const float lastRad = rad;
-    memcpy(T_cw_out, h_res, 16 * sizeof(double));
-    if (imu && imuOut) { for (int k = 0; k < 3; k++) imuOut->velocity[k] = h_res[32 + k]; for (int k = 0; k < 6; k++) imuOut->bias[k] = h_res[35 + k]; }
+    if (T_cw_out) memcpy(T_cw_out, h_res, 16 * sizeof(double));
+    if (trImu && imuOut) { for (int k = 0; k < 3; k++) imuOut->velocity[k] = h_res[32 + k]; for (int k = 0; k < 6; k++) imuOut->bias[k] = h_res[35 + k]; }
     if (rep) {
         rep->n_map_points = trN; rep->n_active = M; rep->rounds = rounds; rep->n_inliers = h_out[4]; rep->n_stereo = h_out[5];
         rep->lm_iterations = lmIters + h_out[6]; rep->last_radius = lastRad;
     }
     return VSLAM_OK;
+}
+
+vslam_status vslam_matcher::track_frame(const double* T_wc_pred, int frameNumber, double* T_cw_out,
+                                        vslam_track_report* rep, const vslam_imu_input* imu, vslam_imu_output* imuOut) {
+    if (!T_wc_pred || !T_cw_out) return VSLAM_ERR_INVALID;
+    VS_HIP(hipSetDevice(device));
+    UseMark mark{this};
+    VS_CHECK(refresh_keys());
+    VS_CHECK(track_begin(T_wc_pred, frameNumber, imu != nullptr));
+    if (imu) VS_CHECK(imu_setup(imu));      // currentIMUData: every pose solve of this frame uses the IMU branch
+    VS_CHECK(track_first_pass());
+    VS_CHECK(track_fetch_result());
+    return track_finish(T_cw_out, rep, imuOut);
 }
 
 
@@ -367,16 +458,18 @@ vslam_status vslam_matcher::track_frame_mono(const vslam_imu_input* imu, const d
     pose_inverse(Twc, Tcw);
     double predInv[16];
     pose_to_rm16(Tcw, predInv);
-    TrackGeom G{rig.fx, rig.fy, rig.cx, rig.cy, (double)rig.baseline, rig.width, rig.height,
-                (double)(float)std::log((double)feL->prm.scale), feL->nLevels};
     uint8_t* fl = d_flags;
     const size_t pc = (size_t)poseCap;
     const int minInliers = 50;
     const int* Mdev = d_trCount + 1;
     int* h_out = (int*)(h_res + 48);
     int* h_cnt = (int*)(h_res + 52);
-    hipLaunchKernelGGL(k_track_predict, dim3(1), dim3(1024), 0, stream, trNub, d_trXyz, d_trDesc, d_trMsd, d_trOutlier, Tcw, G,
-                       d_mpv, d_points, fl, pc, d_matches, d_trAct, d_trCount, d_matchedL, nL, d_matchedR, 0, d_poseIO, 1, d_trVisL);
+    memcpy(trPredInv, predInv, sizeof(predInv));
+    {
+        PredictLane P;
+        predict_lane(P, 1);
+        hipLaunchKernelGGL(k_track_predict, dim3(1), dim3(1024), 0, stream, P);
+    }
     VS_HIP(hipGetLastError());
     float rad = 1200.f;                // :1398 overrides the 10 / 120 choice
     int nIn = -1, prevIn = -1, rounds = 0, lmIters = 0, M = 0;
@@ -421,7 +514,7 @@ vslam_status vslam_matcher::track_set_map(const double* xyz, const uint8_t* desc
         VS_HIP(hipMemcpy(d_trDesc, desc, (size_t)n * 32, hipMemcpyHostToDevice));
         VS_HIP(hipMemcpy(d_trMsd, msd, (size_t)n * 4, hipMemcpyHostToDevice));
         if (outlier) VS_HIP(hipMemcpy(d_trOutlier, outlier, (size_t)n, hipMemcpyHostToDevice));
-        else VS_HIP(hipMemset(d_trOutlier, 0, (size_t)n));
+        else VS_HIP(vslam::memset_sync(d_trOutlier, 0, (size_t)n));
     }
     VS_HIP(hipMemcpy(d_trCount, &n, sizeof(int), hipMemcpyHostToDevice));
     trNub = n; trN = n;

@@ -817,6 +817,111 @@ class System:
         _chk(self.L.vslam_system_save_trajectory(self.h_sys, path.encode(), path_positions.encode() if path_positions else None))
 
 
+# ---- vslam_batch: B lanes in lockstep, one launch per stage for all lanes --------------------------------------------------
+def _report_dict(rep):
+    d = {f[0]: getattr(rep, f[0]) for f in FrameReport._fields_ if f[0] != "ba_report"}
+    d["ba_report"] = [dict(iterations=r.iterations, inner=r.inner_iterations, initialError=r.initial_error,
+                           finalError=r.final_error, lam=r.lam) for r in rep.ba_report]
+    return d
+
+
+class _BorrowedSystem(System):
+    """a lane's vslam_system (owned by the batch): the read-out methods of System"""
+
+    def __init__(self, L, handle):      # noqa: super().__init__ creates a session; this one is borrowed
+        self.L = L
+        self.h_sys = C.c_void_p(handle)
+
+    def close(self):
+        self.h_sys = C.c_void_p()
+
+
+class Batch:
+    """vslam_batch: `lanes` sessions tracked in lockstep.  T0s: per-lane initial poses (or None), velocities: per-lane (IMU)."""
+
+    def __init__(self, rig, nfeatures, lanes, T0s=None, imu=None, velocities=None, local_mapping=1, window=10, device=0,
+                 host_threads=-1, mapping_threads=0):
+        self.L = lib()
+        self.L.vslam_batch_system.restype = C.c_void_p
+        self.lanes = lanes
+        cfgs = (SystemConfig * lanes)()
+        for b in range(lanes):
+            im = None
+            if imu is not None:
+                im = dict(imu)
+                if velocities is not None:
+                    im["velocity"] = velocities[b]
+            c = system_config(rig, nfeatures, imu=im, local_mapping=local_mapping, window=window, device=device)
+            if T0s is not None and T0s[b] is not None:
+                c.T_wc_init = (C.c_double * 16)(*np.asarray(T0s[b], np.float64).reshape(16))
+            cfgs[b] = c
+        self.w, self.h = rig["w"], rig["h"]
+        self.h_b = C.c_void_p()
+        _chk(self.L.vslam_batch_create(cfgs, lanes, host_threads, mapping_threads, C.byref(self.h_b)))
+
+    def close(self):
+        if self.h_b:
+            self.L.vslam_batch_destroy(self.h_b)
+            self.h_b = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def track(self, lefts, rights, frame_numbers, imu_buckets=None, mask=None, on_device=False, stride=None):
+        """lefts / rights: per-lane u8 arrays (host) or device pointers; imu_buckets: per-lane (acc, gyro, ts) or None entries."""
+        B = self.lanes
+        T = np.zeros((B, 4, 4))
+        reps = (FrameReport * B)()
+        keep = []
+        lp = (C.c_void_p * B)(); rp = (C.c_void_p * B)()
+        st = stride or self.w
+        for b in range(B):
+            if mask is not None and not mask[b]:
+                continue
+            if on_device:
+                lp[b], rp[b] = lefts[b], rights[b]
+            else:
+                l = np.ascontiguousarray(lefts[b], np.uint8); r = np.ascontiguousarray(rights[b], np.uint8)
+                keep += [l, r]
+                lp[b], rp[b] = l.ctypes.data, r.ctypes.data
+                st = l.shape[1]
+        bk = None
+        if imu_buckets is not None:
+            bk = (ImuBucket * B)()
+            for b in range(B):
+                if imu_buckets[b] is None:
+                    continue
+                acc, gyr, ts = (np.ascontiguousarray(a, np.float64) for a in imu_buckets[b])
+                keep += [acc, gyr, ts]
+                bk[b] = ImuBucket(len(ts), acc.ctypes.data, gyr.ctypes.data, ts.ctypes.data)
+        fr = np.ascontiguousarray(frame_numbers, np.int32)
+        mk = np.ascontiguousarray(mask, np.uint8) if mask is not None else None
+        _chk(self.L.vslam_batch_track_stereo(self.h_b, lp, rp, int(st), int(on_device), _p(fr), bk, _p(mk) if mk is not None else None,
+                                             _p(T), reps))
+        return T, [_report_dict(reps[b]) for b in range(B)]
+
+    def system(self, lane):
+        return _BorrowedSystem(self.L, self.L.vslam_batch_system(self.h_b, lane))
+
+    def wait_mapping(self):
+        _chk(self.L.vslam_batch_wait_mapping(self.h_b))
+
+    def set_timing(self, on):
+        _chk(self.L.vslam_batch_set_timing(self.h_b, int(on)))
+
+    def timings(self):
+        names = (C.c_char_p * 64)(); ms = (C.c_float * 64)(); n = C.c_int32(); ph = (C.c_double * 7)()
+        _chk(self.L.vslam_batch_timings(self.h_b, names, ms, 64, C.byref(n), ph))
+        out = {}
+        for i in range(n.value):
+            k = names[i].decode()
+            out[k] = out.get(k, 0.0) + ms[i]
+        return out, list(ph)
+
+
 # ---- vslam_fleet: S sessions on S library threads ------------------------------------------------------------------------
 class FleetSequence(C.Structure):
     _fields_ = [("n_frames", C.c_int32), ("left", C.c_void_p), ("right", C.c_void_p), ("stride", C.c_int32), ("on_device", C.c_int32),
@@ -842,6 +947,8 @@ def system_config(rig, nfeatures, imu=None, local_mapping=2, window=10, device=0
         cfg.gyro_noise_density, cfg.gyro_random_walk, cfg.accel_noise_density, cfg.accel_random_walk = imu["noise"]
         cfg.T_body_sensor = (C.c_double * 16)(*np.asarray(imu["T_bs"], np.float64).reshape(16))
         cfg.imu_hz = int(imu["hz"])
+        if "velocity" in imu:
+            cfg.velocity_init = (C.c_double * 3)(*imu["velocity"])
     return cfg
 
 

@@ -609,6 +609,36 @@ vslam_status vslam_system_set_timing(vslam_system* sys, int32_t on);
 vslam_status vslam_system_timings(vslam_system* sys, const char** names, float* ms, int32_t cap, int32_t* n_out, int32_t* ba_calls_out);
 
 /* ---------------------------------------------------------------------------
+ * vslam_batch - B independent sequences ("lanes") tracked in lockstep: every stage of FeatureTracker::TrackImage
+ * (src/FeatureTracker.cpp:1108-1278) is ONE kernel launch for all lanes (lane = a grid dimension, arguments from a
+ * per-lane table), because one sequence's frame is a chain of mostly one-workgroup kernels that cannot fill the GPU.
+ * Each lane is a complete vslam_system (own map, keyframes, local mapping); its results are identical to the same
+ * sequence run through vslam_system_track_stereo.  Local mapping of the lanes runs on `mapping_threads` library threads
+ * (local_mapping = 2) or inside the step (1).  All lanes share rig, extractor parameters, device, IMU and mapping mode;
+ * T_wc_init / velocity_init may differ.
+ * ------------------------------------------------------------------------- */
+typedef struct vslam_batch vslam_batch;
+/* host_threads: threads for the per-lane host phases (< 0: min(lanes, 8)); mapping_threads: <= 0: min(lanes, 3) */
+vslam_status vslam_batch_create(const vslam_system_config* configs, int32_t lanes, int32_t host_threads, int32_t mapping_threads,
+                                vslam_batch** out);
+void vslam_batch_destroy(vslam_batch* batch);
+/* one frame per lane.  left / right: [lanes] image pointers; frame_numbers: [lanes] (0 initialises that lane's map);
+ * imu: [lanes] buckets (IMU mode, frames > 0) or NULL; lane_mask: [lanes] 0 = lane idle this step, NULL = all lanes;
+ * T_wc_out: [lanes][16]; reports: [lanes] or NULL */
+vslam_status vslam_batch_track_stereo(vslam_batch* batch, const uint8_t* const* left, const uint8_t* const* right, int32_t stride,
+                                      int32_t on_device, const int32_t* frame_numbers, const vslam_imu_bucket* imu,
+                                      const uint8_t* lane_mask, double* T_wc_out, vslam_frame_report* reports);
+/* a lane's session (borrowed: valid until vslam_batch_destroy) for the vslam_system_* read-outs */
+vslam_system* vslam_batch_system(vslam_batch* batch, int32_t lane);
+int32_t vslam_batch_lanes(const vslam_batch* batch);
+vslam_status vslam_batch_wait_mapping(vslam_batch* batch);
+/* HIP-event timing of the batched launches (device milliseconds per stage for ALL lanes, summed since the last read) and
+ * the host-side phases of the last step in seconds: {begin, images + extraction enqueue, upload block, tables + enqueue,
+ * wait, retry, post} */
+vslam_status vslam_batch_set_timing(vslam_batch* batch, int32_t on);
+vslam_status vslam_batch_timings(vslam_batch* batch, const char** names, float* ms, int32_t cap, int32_t* n_out, double* host_phases7);
+
+/* ---------------------------------------------------------------------------
  * vslam_fleet - the frame driver inside the library: S independent sessions (vslam_system each: own rig / sequence, map,
  * tracker, optimizer thread) on S host threads sharing one GPU.  Replaces the frame loop of the reference's main()
  * (src/VIOSlam.cpp:289-316) for throughput runs: the path has no cross-sequence exchange, sessions are
@@ -652,6 +682,10 @@ vslam_status vslam_fleet_system(vslam_fleet* fleet, int32_t session, vslam_syste
  * {sampled frames, pose solves in them, local BAs timed}; read-and-reset */
 vslam_status vslam_fleet_set_sampling(vslam_fleet* fleet, int32_t every);
 vslam_status vslam_fleet_timings(vslam_fleet* fleet, const char** names, float* ms, int32_t cap, int32_t* n_out, int64_t* counts3);
+
+/* debug aid: fill every device allocation made from now on (and every reused scratch block) with `byte` (< 0: off; the
+ * VSLAM_POISON environment variable sets the start value) - results must not depend on it */
+void vslam_debug_poison(int32_t byte);
 
 /* device time per kernel group since the previous call (summed over launches; read-and-reset) */
 vslam_status vslam_matcher_timings(const vslam_matcher* m, const char** names, float* ms,

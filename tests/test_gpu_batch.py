@@ -1,0 +1,128 @@
+"""vslam_batch (B sequences in lockstep, one launch per stage for all lanes) against vslam_system (one sequence, its own
+launches) on the same inputs: every lane must reproduce the single-session run of its sequence - same keyframe decisions,
+inlier counts, match tables, map sizes, local-BA statistics, poses.  The batched kernels are the one-session kernels'
+bodies fed per-lane argument tables, so the only tolerated difference is the summation order of the local BA's LDS
+atomics (poses compared to 1e-9).  Lanes start at different source frames, one lane joins late (idle lane + a map
+initialisation in the middle of a run), and the schedule makes keyframes / local BAs fall on different steps per lane."""
+import numpy as np
+import pytest
+import synth
+
+pytestmark = pytest.mark.gpu
+
+G = (0.0, 9.81, 0.0)
+NOISE = (1.6968e-4, 1.9393e-5, 2.0e-3, 3.0e-3)
+
+
+def _velocity(f, fps):
+    h = 1e-4
+    return (synth.pose_at(f + h * fps, fps)[:3, 3] - synth.pose_at(f - h * fps, fps)[:3, 3]) / (2 * h)
+
+
+def _bucket(f0, f1, fps):
+    S, dts, _ = synth.imu_samples(f0, f1, fps, noise_seed=0x1A00 + f1)
+    return (S[:, :3], S[:, 3:], np.arange(len(dts)) * 5e6)
+
+
+def _single(capi, rig_name, nfeat, frames, use_imu, mapping):
+    rig = synth.RIGS[rig_name]
+    imu = dict(gravity=G, noise=NOISE, T_bs=synth.T_BC1, hz=200, velocity=_velocity(frames[0], rig["fps"])) if use_imu else None
+    s = capi.System(rig, nfeat, T0=synth.pose_at(frames[0], rig["fps"]), imu=imu, local_mapping=mapping)
+    out = []
+    for n, f in enumerate(frames):
+        L, R, _ = synth.stereo_frame(f, rig_name)
+        b = _bucket(frames[n - 1], f, rig["fps"]) if (use_imu and n > 0) else None
+        P, rep = s.track(L, R, n, imu_bucket=b)
+        out.append((P, rep, s.last_frame() if n > 0 else None))
+    res = (out, s.counts(), s.keyframes())
+    s.close()
+    return res
+
+
+def _batched(capi, rig_name, nfeat, schedules, starts, use_imu, mapping):
+    """schedules[b]: source frames of lane b; starts[b]: the step at which lane b begins"""
+    rig = synth.RIGS[rig_name]
+    B = len(schedules)
+    imu = dict(gravity=G, noise=NOISE, T_bs=synth.T_BC1, hz=200) if use_imu else None
+    bt = capi.Batch(rig, nfeat, B, T0s=[synth.pose_at(sc[0], rig["fps"]) for sc in schedules], imu=imu,
+                    velocities=[_velocity(sc[0], rig["fps"]) for sc in schedules] if use_imu else None, local_mapping=mapping,
+                    host_threads=3)
+    nSteps = max(starts[b] + len(schedules[b]) for b in range(B))
+    out = [[] for _ in range(B)]
+    for step in range(nSteps):
+        Ls, Rs, fn, bk, mask = [None] * B, [None] * B, [0] * B, [None] * B, [0] * B
+        for b in range(B):
+            n = step - starts[b]
+            if n < 0 or n >= len(schedules[b]):
+                continue
+            f = schedules[b][n]
+            Ls[b], Rs[b], _ = synth.stereo_frame(f, rig_name)
+            fn[b] = n; mask[b] = 1
+            if use_imu and n > 0:
+                bk[b] = _bucket(schedules[b][n - 1], f, rig["fps"])
+        T, reps = bt.track(Ls, Rs, fn, imu_buckets=bk if use_imu else None, mask=mask)
+        for b in range(B):
+            if mask[b]:
+                out[b].append((T[b].copy(), reps[b], bt.system(b).last_frame() if fn[b] > 0 else None))
+    res = [(out[b], bt.system(b).counts(), bt.system(b).keyframes()) for b in range(B)]
+    bt.close()
+    return res
+
+
+INT_KEYS = ("keyframe_inserted", "n_active", "n_inliers", "n_stereo", "rounds", "lm_iterations", "n_keyframes", "n_map_points",
+            "n_active_after", "mapping_ran", "new_points", "ba_keyframes", "ba_local", "ba_landmarks", "ba_pairs", "ba_wrong", "ba_outliers")
+
+
+def _same(one, lane, tol=1e-9):
+    (o1, c1, k1), (o2, c2, k2) = one, lane
+    assert len(o1) == len(o2)
+    nKF = nBA = 0
+    for n, ((P1, r1, l1), (P2, r2, l2)) in enumerate(zip(o1, o2)):
+        for k in INT_KEYS:
+            assert r1[k] == r2[k], (n, k, r1[k], r2[k])
+        assert np.abs(P1 - P2).max() <= tol, (n, np.abs(P1 - P2).max())
+        if l1 is not None:
+            assert np.array_equal(l1[0], l2[0]) and np.array_equal(l1[1], l2[1]), n
+        nKF += r1["keyframe_inserted"]; nBA += r1["mapping_ran"]
+        for s in range(2):
+            assert r1["ba_report"][s]["iterations"] == r2["ba_report"][s]["iterations"], n
+    assert c1 == c2
+    assert list(k1[0]) == list(k2[0]) and np.abs(k1[1] - k2[1]).max() <= tol
+    return nKF, nBA
+
+
+@pytest.mark.parametrize("use_imu", [False, True])
+def test_batch_lanes_equal_single_sessions(capi, use_imu):
+    schedules = [list(range(0, 52, 2)), list(range(6, 58, 2)), list(range(12, 56, 2))]
+    starts = [0, 0, 3]
+    lanes = _batched(capi, "euroc", 1500, schedules, starts, use_imu, 1)
+    tot = [0, 0]
+    for b, sc in enumerate(schedules):
+        nKF, nBA = _same(_single(capi, "euroc", 1500, sc, use_imu, 1), lanes[b])
+        tot[0] += nKF; tot[1] += nBA
+    assert tot[0] >= 4 and tot[1] >= 2      # the comparison covered keyframe insertions and local BAs
+
+
+def test_batch_mapping_threads(capi):
+    """local_mapping = 2: the lanes' local BAs run on the batch's mapping threads; the run completes, every lane keeps
+    tracking (>= 50 inliers) and its map grows through the mapper."""
+    rig = synth.RIGS["euroc"]
+    B = 4
+    schedules = [list(range(2 * b, 2 * b + 48, 2)) for b in range(B)]
+    bt = capi.Batch(rig, 1500, B, T0s=[synth.pose_at(sc[0], rig["fps"]) for sc in schedules], local_mapping=2, mapping_threads=2)
+    ran = 0
+    for n in range(len(schedules[0])):
+        fr = [synth.stereo_frame(sc[n], "euroc") for sc in schedules]
+        T, reps = bt.track([f[0] for f in fr], [f[1] for f in fr], [n] * B)
+        for b in range(B):
+            if n > 0:
+                assert reps[b]["n_inliers"] >= 50, (n, b, reps[b])
+            err = np.abs(T[b][:3, 3] - synth.pose_at(schedules[b][n], rig["fps"])[:3, 3]).max()
+            assert err < 0.05, (n, b, err)
+            ran += reps[b]["mapping_ran"]
+    bt.wait_mapping()
+    for b in range(B):
+        c = bt.system(b).counts()
+        assert c["keyframes"] >= 2 and c["frames"] == len(schedules[b])
+    assert ran >= B
+    bt.close()

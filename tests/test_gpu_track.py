@@ -199,7 +199,7 @@ def test_pipelined_two_extractor_pairs_match_serial(capi):
         if i > 0:
             T, rep = capi.tracker_track(m, preds[i], 5)
             mt, outl, act = capi.tracker_fetch(m)
-            out = (T.copy(), rep["n_inliers"], rep["n_stereo"], rep["lm_iterations"], mt.copy(), outl.copy())
+            out = (T.copy(), rep["n_inliers"], rep["n_stereo"], rep["lm_iterations"], mt.copy(), outl.copy(), dict(rep, keys=(len(fe.fetch(0)[0]), len(fe.fetch(1)[0]))))
         capi.tracker_init_map(m, frames[i][2])
         return out
 
@@ -239,12 +239,12 @@ def test_pipelined_two_extractor_pairs_match_serial(capi):
         free.release()
     th.join(timeout=60)
     assert all(f.ssc_stats() == (1, 0) for f in fes)
-    for a, b in zip(ref, got):
+    for n, (a, b) in enumerate(zip(ref, got)):
         assert (a is None) == (b is None)
         if a is None:
             continue
-        assert np.array_equal(a[0], b[0]) and a[1:4] == b[1:4]
-        assert np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
+        assert np.array_equal(a[0], b[0]) and a[1:4] == b[1:4], (n, a[6], b[6], np.abs(a[0] - b[0]).max())
+        assert np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5]), n
 
 
 def test_sequence_odometry_accuracy(capi, tmp_path):
