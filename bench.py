@@ -191,14 +191,17 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c5"])
-    ap.add_argument("--sessions", type=int, default=16, help="independent SLAM sessions (sequences) sharing each GPU")
-    ap.add_argument("--frames", type=int, default=20, help="distinct rendered stereo frames of the replayed sequence")
-    ap.add_argument("--frame-step", type=int, default=1, help="source frames between two sequence frames")
+    ap.add_argument("--sessions", type=int, default=64, help="independent SLAM sessions (sequences) sharing each GPU")
+    ap.add_argument("--lanes", type=int, default=32, help="sessions per lockstep group (vslam_batch: one launch per stage for all lanes of a group); "
+                                                          "0 = one host thread and one set of launches per session")
+    ap.add_argument("--frames", type=int, default=100, help="distinct rendered stereo frames of the replayed sequence")
+    ap.add_argument("--frame-step", type=int, default=2, help="source frames between two sequence frames")
     ap.add_argument("--host-images", action="store_true", help="frames in pinned host memory: every frame pays its H2D copy inside the step")
     ap.add_argument("--mapping", type=int, default=2, help="local mapping: 2 = optimizer thread per session (reference), 1 = synchronous, 0 = off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency-line", action="store_true", help="skip the extra single-session run")
-    ap.add_argument("--sweep", default="", help="comma-separated session counts: throughput of each in the \"sweep\" field (one process, same frames)")
+    ap.add_argument("--sweep", default="", help="comma-separated SESSIONSxLANES shapes (e.g. 1x0,1x1,8x8,32x32,64x32): throughput of each in the "
+                                                "\"sweep\" field (one process, same frames)")
     ap.add_argument("--c5-landmarks", type=int, default=100000)
     ap.add_argument("--c5-steps", type=int, default=5)
     ap.add_argument("--c5-warmup", type=int, default=1)
@@ -253,17 +256,18 @@ def main():
     imu = dict(gravity=GRAVITY, noise=IMU_NOISE, T_bs=__import__("synth").T_BC1, hz=200) if cfg["imu"] else None
     scfg = vc.system_config(rig, cfg["nfeat"], imu=imu, local_mapping=args.mapping, device=local)
 
-    def make_fleet(S):
+    def make_fleet(S, lanes):
         return vc.Fleet(scfg, S, lp, rp, w, not args.host_images, poses=poses, velocities=vel,
-                        imu_forward=fwd if cfg["imu"] else None, imu_backward=bwd if cfg["imu"] else None)
+                        imu_forward=fwd if cfg["imu"] else None, imu_backward=bwd if cfg["imu"] else None, lanes=lanes)
 
-    fleet = make_fleet(args.sessions)
+    lanes = min(args.lanes, args.sessions)
+    fleet = make_fleet(args.sessions, lanes)
     fleet.run(args.warmup)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    fleet.set_sampling(3)            # per-kernel HIP events on every 3rd frame of session 0 (two event records per launch cost ~3 %)
+    fleet.set_sampling(3)            # per-stage HIP events on every 3rd step of group / session 0
     t0 = time.perf_counter()
     rep = fleet.run(args.steps)      # every frame and every local BA of the timed steps completes inside
     torch.cuda.synchronize()
@@ -281,7 +285,7 @@ def main():
     latency = None
     if rank == 0 and not args.no_latency_line and args.sessions > 1:
         fleet.close()
-        f1 = make_fleet(1)
+        f1 = make_fleet(1, 0)
         f1.run(min(args.warmup, 20))
         torch.cuda.synchronize()
         n1 = min(args.steps, 200)
@@ -299,19 +303,21 @@ def main():
             fleet.close()
         except Exception:      # noqa: BLE001
             pass
-        for Sx in [int(v) for v in args.sweep.split(",") if v]:
-            fx = make_fleet(Sx)
+        for shape in [v for v in args.sweep.split(",") if v]:
+            Sx, Lx = (int(v) for v in shape.split("x"))
+            fx = make_fleet(Sx, Lx)
             fx.run(max(5, args.warmup // 2))
             torch.cuda.synchronize()
-            nx = max(20, min(args.steps, 4000 // Sx))
+            nx = max(20, min(args.steps, 8000 // Sx))
             tx = time.perf_counter()
             rx = fx.run(nx)
             torch.cuda.synchronize()
             ex = time.perf_counter() - tx
-            sweep.append({"sessions": Sx, "frames_per_s": Sx * nx / ex, "ms_per_step": 1e3 * ex / nx, "keyframes": rx["keyframes"],
-                          "local_bas": rx["mappings"], "lost_frames": rx["lost_frames"], "max_session_s": rx["max_session_seconds"]})
+            sweep.append({"sessions": Sx, "lanes_per_group": Lx, "frames_per_s": Sx * nx / ex, "ms_per_step": 1e3 * ex / nx, "keyframes": rx["keyframes"],
+                          "local_bas": rx["mappings"], "lost_frames": rx["lost_frames"]})
             fx.close()
 
+    fleet.close()      # (idempotent) library threads joined before the process winds down
     c5 = None
     if world > 1 and not os.environ.get("VSLAM_BENCH_SKIP_C5"):
         c5 = run_c5(args, rank, world, local, dist, torch, backend)
@@ -320,7 +326,7 @@ def main():
         S = args.sessions
         px = level_pixels(w, h)
         sumP, nimg, nfeat = sum(px), 2, cfg["nfeat"]
-        nS, nSolve, nBA = max(cnt["frames"], 1), max(cnt["solves"], 1), max(cnt["ba"], 1)
+        nBA = max(cnt["ba"], 1)
         nBAall = max(rep["mappings"], 1)
         R_, L_, k2, Fk = rep["ba_residuals"] / nBAall, rep["ba_landmarks"] / nBAall, rep["ba_sum_k2"] / nBAall, rep["ba_free_kf"] / nBAall
         trialsPerBA = rep["ba_trials"] / nBAall
@@ -329,23 +335,33 @@ def main():
         nk = float(nfeat)
         Mact = 600.0    # active map points per tracked frame (order of magnitude; the byte formulas are linear in it)
         frames_per_ba = rep["frames"] / nBAall
+        # One launch of a tracking / extraction stage serves `lb` sessions (the lanes of a lockstep group; 1 without batching).
+        lb = max(lanes, 1)
+        nStep = max(cnt["frames"] / lb, 1)         # sampled steps
         # kernel group -> (launches over the sampled region, algorithmic bytes per launch, algorithmic flops per launch)
+        b_stereo = nk * (28 + 32) * 2 + nk * 16 + nk * 24
+        b_cand, b_res = Mact * 60 + 2 * nk * 60 + Mact * 128, Mact * (128 + 8 + 8) + 2 * nk * 8
+        b_pose = Mact * (24 + 8 + 4) + 2 * nk * 28 + (8 * 514 if cfg["imu"] else 0)
         groups = {
-            "pyramid": (7 * nS, nimg * (sum(px[:-1]) + sum(px[1:])) / 7.0, 0),     # read level l-1, write level l
-            "fast": (nS, nimg * (sumP + 4 * 3.3 * nfeat), 0),                      # every level read once + packed candidates
-            "gather": (nS, nimg * (8 * 3.3 * nfeat), 0),
-            "ssc": (nS, nimg * (8 * 3.3 * nfeat + 4 * nk), 0),                      # candidates in, picks out
-            "blur": (nS, nimg * (2 * sumP), 0),                                    # read + write every level
-            "orient_desc": (nS, nimg * nk * (28 + 32 + 709 + 512), 0),             # keypoint + descriptor + disc + BRIEF taps
-            "stereo_match": (nS, nk * (28 + 32) * 2 + nk * 16, 0),
-            "stereo_finalize": (nS, nk * 24, 0),
-            "track_predict": (nS, nk * (24 + 32 + 5) + Mact * (60 + 24 + 12), 0),
-            "track_repredict": (nS, Mact * (24 + 60 + 12), 0),
-            "imu_preintegrate": (nSolve, 10 * 56 + 8 * (289 + 225), 10 * 2 * 2 * 15 ** 3 + 15 ** 3),
-            "proj_candidates": (nSolve, Mact * 60 + 2 * nk * 60 + Mact * 128, 0),
-            "proj_resolve": (nSolve, Mact * (128 + 8 + 8) + 2 * nk * 8, 0),
-            "pose_imu_lm": (nSolve, Mact * (24 + 8 + 4) + 2 * nk * 28 + 8 * 514, 0),
-            "pose_lm": (nSolve, Mact * (24 + 8 + 4) + 2 * nk * 28, 0),
+            "pyramid": (7 * nStep, lb * nimg * (sum(px[:-1]) + sum(px[1:])) / 7.0, 0),     # read level l-1, write level l
+            "fast": (nStep, lb * nimg * (sumP + 4 * 3.3 * nfeat), 0),                      # every level read once + packed candidates
+            "gather": (nStep, lb * nimg * (8 * 3.3 * nfeat), 0),
+            "ssc": (nStep, lb * nimg * (8 * 3.3 * nfeat + 4 * nk), 0),                      # candidates in, picks out
+            "blur": (nStep, lb * nimg * (2 * sumP), 0),                                    # read + write every level
+            "orient_desc": (nStep, lb * nimg * nk * (28 + 32 + 709 + 512), 0),             # keypoint + descriptor + disc + BRIEF taps
+            "stereo": (nStep, lb * b_stereo, 0),                                           # match + finalize (batched: one timer)
+            "stereo_match": (nStep, nk * (28 + 32) * 2 + nk * 16, 0),
+            "stereo_finalize": (nStep, nk * 24, 0),
+            "track_predict": (nStep, lb * (nk * (24 + 32 + 5) + Mact * (60 + 24 + 12)), 0),
+            "track_repredict": (nStep, lb * Mact * (24 + 60 + 12), 0),
+            "pack": (nStep, lb * (Mact * 30 + nk * 8), 0),
+            "imu_preintegrate": (2 * nStep, lb * (10 * 56 + 8 * (289 + 225)), lb * (10 * 2 * 2 * 15 ** 3 + 15 ** 3)),
+            "proj_match": (2 * nStep, lb * (b_cand + b_res), 0),                           # candidates + resolve, two passes per frame
+            "pose_solve": (2 * nStep, lb * b_pose, 0),                                     # two solves per frame
+            "proj_candidates": (2 * nStep, b_cand, 0),
+            "proj_resolve": (2 * nStep, b_res, 0),
+            "pose_imu_lm": (2 * nStep, b_pose, 0),
+            "pose_lm": (2 * nStep, b_pose, 0),
             "ba_linearize": (nBA * linPerBA, R_ * (8 + 16 + 8 + 96 + 24 + 160), 0),          # idx, uv, sigma, pose, point, stored J
             "ba_schur": (nBA * trialsPerBA, R_ * 160 + L_ * 24, 2 * 36 * k2),                 # stored J read once (S stays in LDS)
             "ba_solve": (nBA * trialsPerBA, 8 * (nBA6 * nBA6 + nBA6) * 2, nBA6 ** 3 / 3.0),   # reduced system in, delta out
@@ -353,9 +369,10 @@ def main():
             "ba_eval": (nBA * trialsPerBA, R_ * (160 + 16 + 8 + 96 + 24), 0),
             "ba_chi2": (2 * nBA, R_ * (16 + 8 + 96 + 24), 0),
         }
+        nS = nStep * lb
         per_frame = {}
         for k, v in stage_ms.items():
-            per_frame[k] = v / (nBA * frames_per_ba) if k.startswith("ba_") else v / nS
+            per_frame[k] = v / (nBA * frames_per_ba) if k.startswith("ba_") else v / nS      # device ms per tracked frame
         out = {
             "metric": "frames/sec (extract+match+localBA), %d feat stereo %dx%d" % (nfeat, w, h),
             "value": world * S * args.steps / el, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -368,9 +385,11 @@ def main():
                                    "residual blocks, %.1f free keyframes on average)"
                                    % (args.frames, "in pinned host memory (H2D inside the step)" if args.host_images else "resident in HBM",
                                       rep["frames"] / max(rep["keyframes"], 1), frames_per_ba, L_, R_, Fk),
-                       "sessions_per_gpu": S,
+                       "sessions_per_gpu": S, "lanes_per_group": lanes,
                        "step": "one stereo frame of each of the %d sessions" % S,
-                       "threads": "one host thread per session inside the library (vslam_fleet) + one optimizer thread per session",
+                       "threads": ("%d lockstep groups of %d sessions (vslam_batch: one launch per stage for all lanes), one driver thread + a "
+                                   "host-phase pool + 3 mapping threads per group" % ((S + lanes - 1) // lanes, lanes)) if lanes > 0 else
+                                  "one host thread per session inside the library (vslam_fleet) + one optimizer thread per session",
                        "parallelism": "replicas x%d, %d sessions per GPU" % (world, S)},
             "tracking": {"mean_inliers": rep["sum_inliers"] / max(rep["frames"] - 0, 1), "min_inliers": rep["min_inliers"],
                          "lost_frames": rep["lost_frames"], "mean_rounds": rep["sum_rounds"] / max(rep["frames"], 1),
@@ -378,8 +397,9 @@ def main():
                          "rms_position_error_m": float(np.sqrt(rep["sum_sq_position_error"] / max(rep["frames"], 1))),
                          "max_position_error_m": rep["max_position_error"]},
             "stage_ms_per_frame": {k: v for k, v in sorted(per_frame.items())},
-            "stage_sampling": "HIP events on every 3rd frame of session 0 and on the local BAs that complete in those frames (%d frames, %d BAs); "
-                              "BA stages amortised over %.1f frames per BA" % (cnt["frames"], cnt["ba"], frames_per_ba),
+            "stage_sampling": "HIP events on every 3rd step of group 0 (all its lanes per launch) and on the local BAs of its first session that "
+                              "complete in those steps (%d frames, %d BAs); per tracked frame; BA stages amortised over %.1f frames per BA"
+                              % (cnt["frames"], cnt["ba"], frames_per_ba),
         }
         if per_frame:
             dom = max(per_frame, key=lambda k: per_frame[k])
@@ -394,12 +414,13 @@ def main():
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launch_ms": dom_ms, "algorithmic_bytes": alg_bytes,
                     "launches_timed": n_launch,
                     "aggregate_GBps_all_sessions": agg, "aggregate_frac": agg / HBM_PEAK_GBS,
-                    "note": "per-launch figure of the dominant kernel group (one launch serves one session: a latency-bound kernel, one "
-                            "workgroup per problem instance); aggregate_* = the same kernel's algorithmic bytes over all concurrent sessions / "
-                            "wall time - what the chip sustains for this kernel while everything else runs beside it"}
+                    "lanes_per_launch": lb if not dom.startswith("ba_") else 1,
+                    "note": "per-launch figure of the dominant kernel group (one launch serves all lanes of a lockstep group; local-BA kernels "
+                            "serve one session); aggregate_* = the same group's algorithmic bytes over all sessions / wall time"}
             try:
                 pmc = json.load(open(PMC_FILE))
-                kname = {"proj_resolve": "k_proj_resolve", "pose_imu_lm": "k_pose_imu_lm", "ba_solve": "k_ba_solve_mfma64", "ssc": "k_ssc<false>",
+                kname = {"proj_resolve": "k_proj_resolve", "pose_imu_lm": "k_pose_imu_lm", "pose_solve": "k_pose_imu_lm_b" if cfg["imu"] else "k_pose_lm_b",
+                         "stereo": "k_stereo_match_b", "proj_match": "k_proj_candidates_b", "imu_preintegrate": "k_imu_preintegrate_b", "ba_solve": "k_ba_solve_mfma64", "ssc": "k_ssc<false>",
                          "ba_schur": "k_ba_schur", "ba_back": "k_ba_back", "ba_eval": "k_ba_factors<1>", "ba_linearize": "k_ba_factors<0>",
                          "fast": "k_fast", "blur": "k_blur", "gather": "k_gather", "stereo_match": "k_stereo_match",
                          "orient_desc": "k_orient_desc", "proj_candidates": "k_proj_candidates", "pose_lm": "k_pose_lm"}.get(dom)

@@ -1794,6 +1794,8 @@ struct DevBuf {
 };
 
 thread_local StageTimer g_baTimer;
+static thread_local void (*g_baRelease)() = nullptr;      // frees the calling thread's local-BA workspace
+
 
 // Pinned host arena with a device mirror: the per-pass index / measurement arrays are written straight into
 // pinned memory and travel in ONE copy.
@@ -1834,6 +1836,11 @@ thread_local int g_baLookahead = -1, g_baSpecLin = -1, g_baMask = 1;
 struct HostFac { int pair, kf, lm, fi, lp; bool right; double z[2], is; };
 
 }  // namespace
+
+void vslam::thread_release() {
+    if (g_baRelease) { g_baRelease(); g_baRelease = nullptr; }
+    thread_pool_release();
+}
 
 #define BA_UP(dst, vec) VS_HIP(hipMemcpyAsync((dst).p, (vec).data(), (vec).size() * sizeof((vec)[0]), hipMemcpyHostToDevice, stream))
 
@@ -1885,8 +1892,9 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         uint8_t* h_wrong = nullptr; size_t wrongCap = 0;
         // released when the owning host thread ends (or switches device): a short-lived optimizer thread must not
         // leak its stream, pinned buffers and pool threads
-        ~Workspace() {
-            if (device < 0 || exiting_main_thread() || hipSetDevice(device) != hipSuccess) return;
+        ~Workspace() {}          // (no HIP calls from a thread_local destructor: see DevPool)
+        void release() {
+            if (device < 0 || hipSetDevice(device) != hipSuccess) return;
             if (stream) { hipStreamSynchronize(stream); hipStreamDestroy(stream); }
             for (void* p : {(void*)d_pose0.p, (void*)d_poseS.p, (void*)d_lm0.p, (void*)d_lmS.p, (void*)d_facJ.p, (void*)d_S.p, (void*)d_Spart.p,
                             (void*)d_Sedge.p, (void*)d_dP.p, (void*)d_dL.p, (void*)d_lmDiff.p, (void*)d_sums.p, (void*)d_partial.p, (void*)d_Lg.p,
@@ -1900,7 +1908,9 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
     };
     static thread_local std::unique_ptr<Workspace> ws;
     if (!ws || ws->device != device) {
+        if (ws) ws->release();
         ws.reset(new Workspace()); ws->device = device;
+        g_baRelease = []() { if (ws) { ws->release(); ws.reset(); } g_baTimer.destroy(); };
         VS_HIP(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));
         VS_HIP(hipHostMalloc((void**)&ws->h_ctlOut, CTL_DOUBLES * sizeof(double), hipHostMallocDefault));
         {

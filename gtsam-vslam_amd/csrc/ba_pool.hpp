@@ -28,6 +28,7 @@ struct BaPool {
     std::shared_ptr<Run> cur;              // guarded by mu
     uint64_t generation = 0;               // guarded by mu
     bool stop = false;
+    std::function<void()> onExit;          // run by every worker as its last action (set before start())
     void start(int n) {
         for (int t = 0; t < n; t++)
             workers.emplace_back([this]() {
@@ -37,12 +38,13 @@ struct BaPool {
                     {
                         std::unique_lock<std::mutex> lk(mu);
                         cvStart.wait(lk, [&] { return stop || generation != seen; });
-                        if (stop) return;
+                        if (stop) break;
                         seen = generation;
                         r = cur;
                     }
                     if (r) work(*r);
                 }
+                if (onExit) onExit();
             });
     }
     void work(Run& r) {

@@ -66,9 +66,11 @@ struct vslam_batch {
     // per-step scratch
     struct LaneStep { bool on = false, first = false, failed = false; vslam_status st = VSLAM_OK; char err[200] = ""; size_t upOff = 0, dnOff = 0; int N = 0, nL = 0, nR = 0; };
     std::vector<LaneStep> ls;
+    std::vector<const uint8_t*> imgPtrs;
     StageTimer timer;
     // host-side phase times of the last step (seconds): pre, extract enqueue, fill, tables + enqueue, wait, finish, post
-    double phase[8] = {0};
+    double phase[8] = {0}, phaseSum[8] = {0};
+    long long nSteps = 0;
 
     vslam_status init(const vslam_system_config* cfgs, int n, int hostThreads, int mapThreads);
     void release();
@@ -87,11 +89,12 @@ struct vslam_batch {
             {
                 std::unique_lock<std::mutex> lk(mqMu);
                 mqCv.wait(lk, [&] { return mqStop || !mapQueue.empty(); });
-                if (mapQueue.empty()) return;       // (stop requested and nothing left)
+                if (mapQueue.empty()) break;        // (stop requested and nothing left)
                 s = mapQueue.front(); mapQueue.pop_front();
             }
             s->run_mapping();
         }
+        vslam::thread_release();
     }
 };
 
@@ -145,6 +148,7 @@ vslam_status vslam_batch::init(const vslam_system_config* cfgs, int n, int hostT
     };
     bindT(ht, h_tab); bindT(dt, d_tab);
     if (hostThreads < 0) hostThreads = std::min(B, 8);
+    pool.onExit = []() { vslam::thread_release(); };
     if (hostThreads > 1) pool.start(hostThreads - 1);
     if (cfgs[0].local_mapping == 2) {
         if (nMapThreads <= 0) nMapThreads = std::min(B, 3);
@@ -154,6 +158,10 @@ vslam_status vslam_batch::init(const vslam_system_config* cfgs, int n, int hostT
 }
 
 void vslam_batch::release() {
+    if (getenv("VSLAM_BATCH_PHASES") && nSteps)
+        fprintf(stderr, "vslam_batch %d lanes, %lld steps, host phases (us / step): begin %.1f | images + extract enqueue %.1f | upload block %.1f | "
+                        "tables + enqueue %.1f | wait %.1f | retry %.1f | post %.1f\n", B, nSteps, 1e6 * phaseSum[0] / nSteps, 1e6 * phaseSum[1] / nSteps,
+                1e6 * phaseSum[2] / nSteps, 1e6 * phaseSum[3] / nSteps, 1e6 * phaseSum[4] / nSteps, 1e6 * phaseSum[5] / nSteps, 1e6 * phaseSum[6] / nSteps);
     // sessions first (each waits for its mapping job), then the mapping threads, then the shared objects
     for (vslam_system* s : sys) if (s) { s->release(); delete s; }
     sys.clear();
@@ -207,7 +215,8 @@ vslam_status vslam_batch::step(const uint8_t* const* L, const uint8_t* const* R,
     VS_HIP(hipSetDevice(device));
     using clk = std::chrono::steady_clock;
     auto t0 = clk::now();
-    auto lap = [&](int k) { const auto t1 = clk::now(); phase[k] = std::chrono::duration<double>(t1 - t0).count(); t0 = t1; };
+    auto lap = [&](int k) { const auto t1 = clk::now(); phase[k] = std::chrono::duration<double>(t1 - t0).count(); phaseSum[k] += phase[k]; t0 = t1; };
+    nSteps++;
     int nOn = 0;
     for (int b = 0; b < B; b++) {
         LaneStep& q = ls[b];
@@ -237,12 +246,18 @@ vslam_status vslam_batch::step(const uint8_t* const* L, const uint8_t* const* R,
     lap(0);
 
     // ---- device: images, extraction ------------------------------------------------------------------------------------------
-    for (int b = 0; b < B; b++) {
-        if (!ls[b].on) continue;
-        VS_CHECK(fe->set_image_async(2 * b, L[b], stride, onDevice));
-        VS_CHECK(fe->set_image_async(2 * b + 1, R[b], stride, onDevice));
+    if (onDevice) {
+        imgPtrs.assign((size_t)2 * B, nullptr);
+        for (int b = 0; b < B; b++) if (ls[b].on) { imgPtrs[2 * b] = L[b]; imgPtrs[2 * b + 1] = R[b]; }
+        VS_CHECK(fe->set_images_device(imgPtrs.data(), stride));
+    } else {
+        for (int b = 0; b < B; b++) {
+            if (!ls[b].on) continue;
+            VS_CHECK(fe->set_image_async(2 * b, L[b], stride, false));
+            VS_CHECK(fe->set_image_async(2 * b + 1, R[b], stride, false));
+        }
+        VS_HIP(hipStreamSynchronize(fe->stream));      // callers may reuse their buffers
     }
-    if (!onDevice) VS_HIP(hipStreamSynchronize(fe->stream));      // callers may reuse their buffers
     VS_CHECK(fe->run());
     lap(1);
 
@@ -360,7 +375,7 @@ vslam_status vslam_batch::step(const uint8_t* const* L, const uint8_t* const* R,
 
     // ---- device: every stage once for all lanes --------------------------------------------------------------------------------
     int t = timer.begin("stereo");
-    launch_stereo_batch(stream, dt.stereo, B, maxL, maxR);
+    launch_stereo_batch(stream, dt.stereo, B, maxL, maxR, sys[0]->cfg.rig.height);
     timer.end(t);
     if (nTrack) {
         t = timer.begin("track_predict"); launch_track_predict_batch(stream, dt.predict, B); timer.end(t);

@@ -109,11 +109,15 @@ struct DevPool {
         for (auto& b : blks) hipFree(b.p);
         blks.clear();
     }
-    ~DevPool() { if (!exiting_main_thread()) release(); }
+    // No HIP calls from a thread_local destructor: tool libraries (rocprofv3) have torn down their own per-thread state by
+    // then and abort on stream calls.  Library threads call thread_release() before they end; other threads may call
+    // vslam_thread_release(); what is left at thread exit is reclaimed with the process.
+    ~DevPool() {}
 };
 // the calling thread's pool for `device` (switching devices releases the previous pool's blocks)
+inline DevPool& thread_pool_slot() { static thread_local DevPool pool; return pool; }
 inline DevPool* thread_pool(int device) {
-    static thread_local DevPool pool;
+    DevPool& pool = thread_pool_slot();
     if (pool.device != device) {
         pool.release();
         pool.device = device;
@@ -121,6 +125,10 @@ inline DevPool* thread_pool(int device) {
     }
     return &pool;
 }
+// Frees the calling thread's cached device resources (scratch-block cache and its stream, the local-BA workspace): the
+// last thing every library thread does; exported as vslam_thread_release() for threads the caller owns.
+void thread_release();
+inline void thread_pool_release() { DevPool& p = thread_pool_slot(); if (p.device >= 0) { p.release(); p.device = -1; } }
 // RAII device array drawn from the thread's pool
 template <class T>
 struct PoolBuf {

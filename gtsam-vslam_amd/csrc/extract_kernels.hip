@@ -60,6 +60,26 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, PyrDe
     *(uchar4*)(D + (size_t)y * dp + x0) = o;
 }
 
+// level 0 of every image from the caller's device buffers in one launch (src[i] == nullptr: image i keeps its content)
+__global__ __launch_bounds__(256) void k_load_images(const uint8_t* const* __restrict__ src, int stride, uint8_t* __restrict__ pyr,
+                                                     PyrDesc P) {
+    const int img = blockIdx.z;
+    const uint8_t* __restrict__ S = src[img];
+    if (!S) return;
+    uint8_t* __restrict__ D = pyr + (size_t)img * P.imgStride + P.off[0];
+    const int w = P.w[0], h = P.h[0], dp = P.pitch[0];
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 16;
+    if (y >= h || x0 >= w) return;
+    const uint8_t* sp = S + (size_t)y * stride + x0;
+    uint8_t* dq = D + (size_t)y * dp + x0;
+    if (x0 + 16 <= w && ((((uintptr_t)sp) | ((uintptr_t)dq)) & 15) == 0) *(uint4*)dq = *(const uint4*)sp;
+    else for (int i = 0; i < 16 && x0 + i < w; i++) dq[i] = sp[i];
+}
+void launch_load_images(hipStream_t s, const uint8_t* const* dSrc, int stride, uint8_t* pyr, const PyrDesc& P, int nimg) {
+    hipLaunchKernelGGL(k_load_images, dim3((P.w[0] + 1023) / 1024, (P.h[0] + 3) / 4, nimg), dim3(64, 4), 0, s, dSrc, stride, pyr, P);
+}
+
 void launch_resize(hipStream_t s, uint8_t* pyr, const PyrDesc& P, int level, const int2* xtab,
                    const int2* ytab, int nimg) {
     dim3 block(64, 4);

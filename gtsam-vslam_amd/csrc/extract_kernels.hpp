@@ -48,6 +48,7 @@ constexpr int FAST_TILE_PITCH = 80;   // >= max sub-image width (gridW + 6)
 constexpr int FAST_TILE_MAX = 76;     // max sub-image side supported
 constexpr int BLUR_TW = 64, BLUR_TH = 16;
 
+void launch_load_images(hipStream_t s, const uint8_t* const* dSrc, int stride, uint8_t* pyr, const PyrDesc& P, int nimg);
 void launch_resize(hipStream_t s, uint8_t* pyr, const PyrDesc& P, int level, const int2* xtab,
                    const int2* ytab, int nimg);
 void launch_fast(hipStream_t s, const uint8_t* pyr, const PyrDesc& P, const FastDesc& F,

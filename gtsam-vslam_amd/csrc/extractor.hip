@@ -278,6 +278,8 @@ void vslam_extractor::release() {
     hipFree(d_sscTmp); hipFree(d_sscPicks); hipFree(d_taskCount); hipFree(d_sscFlags); hipFree(d_sscGrid); hipFree(d_sscGridOff);
     d_sscGrid = nullptr; d_sscGridOff = nullptr; d_sscPicks = nullptr;
     if (h_counts) hipHostFree(h_counts);
+    if (h_imgPtrs) hipHostFree(h_imgPtrs);
+    hipFree(d_imgPtrs); h_imgPtrs = nullptr; d_imgPtrs = nullptr;
     d_sscTmp = nullptr; d_taskCount = nullptr; d_sscFlags = nullptr; h_counts = nullptr;
     if (evGather) hipEventDestroy(evGather);
     if (evDone) hipEventDestroy(evDone);
@@ -315,6 +317,22 @@ vslam_status vslam_extractor::set_image_async(int idx, const void* src, int stri
     if (idx < 0 || idx >= nimg || !src || stride < width) { set_error("set_image: bad argument"); return VSLAM_ERR_INVALID; }
     VS_HIP(hipMemcpy2DAsync(d_pyr + (size_t)idx * P.imgStride + P.off[0], P.pitch[0], src, stride, width,
                             height, srcOnDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
+    return VSLAM_OK;
+}
+
+vslam_status vslam_extractor::set_images_device(const uint8_t* const* ptrs, int stride) {
+    if (!ptrs || stride < width) { set_error("set_images_device: bad argument"); return VSLAM_ERR_INVALID; }
+    VS_HIP(hipSetDevice(device));
+    if (!h_imgPtrs) {
+        VS_HIP(hipHostMalloc((void**)&h_imgPtrs, (size_t)nimg * sizeof(void*), hipHostMallocDefault));
+        VS_HIP(hipMalloc((void**)&d_imgPtrs, (size_t)nimg * sizeof(void*)));
+    }
+    wait_consumers();
+    // (the previous table upload has completed: every user of this path synchronises with the extraction it fed)
+    for (int i = 0; i < nimg; i++) h_imgPtrs[i] = ptrs[i];
+    VS_HIP(hipMemcpyAsync(d_imgPtrs, h_imgPtrs, (size_t)nimg * sizeof(void*), hipMemcpyHostToDevice, stream));
+    launch_load_images(stream, d_imgPtrs, stride, d_pyr, P, nimg);
+    VS_HIP(hipGetLastError());
     return VSLAM_OK;
 }
 
@@ -419,6 +437,8 @@ int vslam::poison_byte() {
 
 // --------------------------------------------------------------------------- C ABI
 extern "C" {
+
+void vslam_thread_release(void) { vslam::thread_release(); }
 
 void vslam_debug_poison(int32_t byte) { g_poison.store(byte < 0 ? -1 : (byte & 0xff)); }
 

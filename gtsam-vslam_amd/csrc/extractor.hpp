@@ -71,5 +71,8 @@ struct vslam_extractor {
     void release();
     vslam_status set_image(int idx, const void* src, int stride, bool srcOnDevice);
     vslam_status set_image_async(int idx, const void* src, int stride, bool srcOnDevice);
+    // all images at once from device buffers (ptrs[i] == nullptr: unchanged): one pointer-table upload + one launch
+    vslam_status set_images_device(const uint8_t* const* ptrs, int stride);
+    const uint8_t** h_imgPtrs = nullptr; const uint8_t** d_imgPtrs = nullptr;
     vslam_status run();
 };

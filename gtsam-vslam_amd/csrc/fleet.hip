@@ -4,6 +4,10 @@
 // cross-sequence exchange ("replicas only"), so sessions are the unit that fills the chip: one 752x480
 // stereo pair keeps a handful of the 256 CUs busy, S sessions on S streams keep S handfuls busy.
 //
+// Batched mode (vslam_fleet_create_batched): the sessions are the lanes of G lockstep groups (vslam_batch, batch.hip) - one
+// kernel launch per stage for all lanes of a group, one driver thread per group, so that one group's host phases run
+// under another group's kernels.  Same sequences, same per-session results as the one-thread-per-session mode.
+//
 // The frames of a (short) rendered sequence live in HBM (or pinned host memory); a session replays them as a PING-PONG
 // (0 .. n-1, n-2 .. 0, 1 ...): a continuous camera motion of any length whose map, keyframes and local BAs are the
 // tracker's own - nothing is re-seeded from ground truth.
@@ -33,6 +37,8 @@ struct vslam_fleet {
         char error[256] = "";
     };
     std::vector<Session> ses;
+    struct Group { vslam_batch* b = nullptr; std::thread th; int first = 0, count = 0; };
+    std::vector<Group> groups;        // batched mode (empty: one thread per session)
     int nFrames = 0, stride = 0, onDevice = 1;
     std::vector<const uint8_t*> left, right;
     std::vector<Bucket> fwd, bwd;
@@ -57,7 +63,101 @@ struct vslam_fleet {
         return m < n ? m : period - m;
     }
     void loop(int s);
+    void group_loop(int g);
+    void account(Session& S, int si, long long k, int idx, const vslam_frame_report& rep, const double* T);
+    void add_times(const char* const* nm, const float* ms, int n) {
+        for (int i = 0; i < n; i++) {
+            size_t j = 0;
+            for (; j < times.size(); j++) if (!strcmp(times[j].first, nm[i])) break;
+            if (j == times.size()) times.push_back({nm[i], 0.f});
+            times[j].second += ms[i];
+        }
+    }
 };
+
+void vslam_fleet::account(Session& S, int si, long long k, int idx, const vslam_frame_report& rep, const double* T) {
+    S.step++; S.frames++;
+    S.keyframes += rep.keyframe_inserted; S.mappings += rep.mapping_ran; S.newPoints += rep.new_points;
+    S.baLandmarks += rep.ba_landmarks; S.baPairs += rep.ba_pairs;
+    if (rep.mapping_ran) {
+        S.baRes += rep.ba_residuals; S.baFree += rep.ba_free_kf; S.baK2 += rep.ba_sum_k2; S.baTrials += rep.ba_trials;
+        S.baIters += rep.ba_report[0].iterations + rep.ba_report[1].iterations;
+    }
+    if (k > 0) {
+        S.inliers += rep.n_inliers; S.rounds += rep.rounds;
+        S.minInliers = std::min(S.minInliers, rep.n_inliers);
+        if (rep.n_inliers < 50) S.lost++;
+    }
+    if (!Ttrue.empty()) {
+        const double* G = &Ttrue[16 * (size_t)idx];
+        const double dx = T[3] - G[3], dy = T[7] - G[7], dz = T[11] - G[11];
+        const double e2 = dx * dx + dy * dy + dz * dz;
+        S.sumSqPosErr += e2; S.maxPosErr = std::max(S.maxPosErr, std::sqrt(e2));
+    }
+}
+
+// driver thread of one lockstep group: all its sessions advance one frame per vslam_batch step
+void vslam_fleet::group_loop(int gi) {
+    Group& Gp = groups[gi];
+    hipSetDevice(device);
+    const int Bn = Gp.count;
+    std::vector<const uint8_t*> L(Bn), R(Bn);
+    std::vector<int> fr(Bn), idxs(Bn);
+    std::vector<vslam_imu_bucket> bk(Bn);
+    std::vector<double> T((size_t)Bn * 16);
+    std::vector<vslam_frame_report> reps(Bn);
+    long long seen = 0;
+    for (;;) {
+        int steps;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cvGo.wait(lk, [&] { return stop || generation != seen; });
+            if (stop) break;
+            seen = generation;
+            steps = jobSteps;
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        vslam_status st = VSLAM_OK;
+        for (int q = 0; q < steps && st == VSLAM_OK; q++) {
+            const long long k = ses[Gp.first].step;          // (lockstep: the same for every session of the group)
+            for (int b = 0; b < Bn; b++) {
+                Session& S = ses[Gp.first + b];
+                const int idx = tri(k + S.offset, nFrames);
+                const int prev = k > 0 ? tri(k - 1 + S.offset, nFrames) : idx;
+                idxs[b] = idx; L[b] = left[idx]; R[b] = right[idx]; fr[b] = (int)std::min<long long>(k, 1 << 30);
+                bk[b] = vslam_imu_bucket{};
+                if (useImu && k > 0) {
+                    const Bucket& B = idx > prev ? fwd[idx] : bwd[idx];
+                    bk[b].n = (int)B.ts.size(); bk[b].acceleration = B.acc.data(); bk[b].angular_velocity = B.gyr.data(); bk[b].timestamps_ns = B.ts.data();
+                }
+            }
+            const bool sample = gi == 0 && sampleEvery > 0 && k > 0 && (k % sampleEvery) == 0;
+            if (gi == 0 && sampleEvery > 0) { vslam_batch_set_timing(Gp.b, sample ? 1 : 0); vslam_system_set_ba_timing(ses[Gp.first].sys, sample ? 1 : 0); }
+            st = vslam_batch_track_stereo(Gp.b, L.data(), R.data(), stride, onDevice, fr.data(), useImu ? bk.data() : nullptr, nullptr, T.data(), reps.data());
+            if (st != VSLAM_OK) break;
+            if (sample) {
+                const char* nm[64]; float ms[64]; int n = 0, nba = 0;
+                if (vslam_batch_timings(Gp.b, nm, ms, 64, &n, nullptr) == VSLAM_OK) add_times(nm, ms, n);
+                if (vslam_system_ba_timings(ses[Gp.first].sys, nm, ms, 64, &n, &nba) == VSLAM_OK) { add_times(nm, ms, n); sampledBa += nba; }
+                sampledFrames += Bn;
+                for (int b = 0; b < Bn; b++) sampledSolves += reps[b].rounds + 1;
+            }
+            for (int b = 0; b < Bn; b++) account(ses[Gp.first + b], Gp.first + b, k, idxs[b], reps[b], &T[16 * (size_t)b]);
+        }
+        if (st == VSLAM_OK) st = vslam_batch_wait_mapping(Gp.b);      // every local BA of these frames completes inside the run
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        for (int b = 0; b < Bn; b++) {
+            Session& S = ses[Gp.first + b];
+            S.seconds = sec;
+            if (st != VSLAM_OK && S.status == VSLAM_OK) { S.status = st; snprintf(S.error, sizeof(S.error), "%s", vslam_last_error()); }
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (--running == 0) cvDone.notify_all();
+        }
+    }
+    vslam::thread_release();
+}
 
 void vslam_fleet::loop(int si) {
     Session& S = ses[si];
@@ -68,7 +168,7 @@ void vslam_fleet::loop(int si) {
         {
             std::unique_lock<std::mutex> lk(mu);
             cvGo.wait(lk, [&] { return stop || generation != seen; });
-            if (stop) return;
+            if (stop) break;
             seen = generation;
             steps = jobSteps;
         }
@@ -93,33 +193,11 @@ void vslam_fleet::loop(int si) {
             if (sample) {
                 const char* nm[64]; float ms[64]; int n = 0, nba = 0;
                 if (vslam_system_timings(S.sys, nm, ms, 64, &n, &nba) == VSLAM_OK) {
-                    for (int i = 0; i < n; i++) {
-                        size_t j = 0;
-                        for (; j < times.size(); j++) if (!strcmp(times[j].first, nm[i])) break;
-                        if (j == times.size()) times.push_back({nm[i], 0.f});
-                        times[j].second += ms[i];
-                    }
+                    add_times(nm, ms, n);
                     sampledFrames++; sampledSolves += rep.rounds + 1; sampledBa += nba;
                 }
             }
-            S.step++; S.frames++;
-            S.keyframes += rep.keyframe_inserted; S.mappings += rep.mapping_ran; S.newPoints += rep.new_points;
-            S.baLandmarks += rep.ba_landmarks; S.baPairs += rep.ba_pairs;
-            if (rep.mapping_ran) {
-                S.baRes += rep.ba_residuals; S.baFree += rep.ba_free_kf; S.baK2 += rep.ba_sum_k2; S.baTrials += rep.ba_trials;
-                S.baIters += rep.ba_report[0].iterations + rep.ba_report[1].iterations;
-            }
-            if (k > 0) {
-                S.inliers += rep.n_inliers; S.rounds += rep.rounds;
-                S.minInliers = std::min(S.minInliers, rep.n_inliers);
-                if (rep.n_inliers < 50) S.lost++;
-            }
-            if (!Ttrue.empty()) {
-                const double* G = &Ttrue[16 * (size_t)idx];
-                const double dx = T[3] - G[3], dy = T[7] - G[7], dz = T[11] - G[11];
-                const double e2 = dx * dx + dy * dy + dz * dz;
-                S.sumSqPosErr += e2; S.maxPosErr = std::max(S.maxPosErr, std::sqrt(e2));
-            }
+            account(S, si, k, idx, rep, T);
         }
         if (S.status == VSLAM_OK) {               // every local BA of these frames completes inside the run
             const vslam_status st = vslam_system_wait_mapping(S.sys);
@@ -131,11 +209,12 @@ void vslam_fleet::loop(int si) {
             if (--running == 0) cvDone.notify_all();
         }
     }
+    vslam::thread_release();
 }
 
 extern "C" {
 
-vslam_status vslam_fleet_create(const vslam_system_config* config, int32_t n_sessions, const vslam_fleet_sequence* seq, vslam_fleet** out) {
+static vslam_status fleet_create(const vslam_system_config* config, int32_t n_sessions, const vslam_fleet_sequence* seq, int lanes, vslam_fleet** out) {
     if (!config || !seq || !out || n_sessions < 1 || n_sessions > 256 || seq->n_frames < 2 || !seq->left || !seq->right || seq->stride < config->rig.width) {
         set_error("vslam_fleet_create: invalid arguments");
         return VSLAM_ERR_INVALID;
@@ -161,23 +240,50 @@ vslam_status vslam_fleet_create(const vslam_system_config* config, int32_t n_ses
     if (F->useImu) { copyB(seq->imu_forward, F->fwd); copyB(seq->imu_backward, F->bwd); }
     F->ses.resize(n_sessions);
     vslam_status st = VSLAM_OK;
-    for (int s = 0; s < n_sessions && st == VSLAM_OK; s++) {
-        vslam_system_config c = *config;
+    std::vector<vslam_system_config> cfgs(n_sessions, *config);
+    for (int s = 0; s < n_sessions; s++) {
+        vslam_system_config& c = cfgs[s];
         // sessions start at different phases of the forward leg, each at the true pose / velocity of its first frame
         const int off = (int)(((long long)s * 5) % std::max(1, seq->n_frames - 1));
         F->ses[s].offset = off;
         if (seq->T_wc_true) memcpy(c.T_wc_init, seq->T_wc_true + 16 * (size_t)off, sizeof(c.T_wc_init));
         if (seq->velocity_true) for (int k = 0; k < 3; k++) c.velocity_init[k] = seq->velocity_true[3 * (size_t)off + k];
-        st = vslam_system_create(&c, &F->ses[s].sys);
+    }
+    if (lanes <= 0) {
+        for (int s = 0; s < n_sessions && st == VSLAM_OK; s++) st = vslam_system_create(&cfgs[s], &F->ses[s].sys);
+    } else {
+        const int nG = (n_sessions + lanes - 1) / lanes;
+        F->groups.resize(nG);
+        // host threads per group: the groups share the machine's cores
+        const int hw = (int)std::max(2u, std::thread::hardware_concurrency());
+        const int hostThreads = std::max(1, std::min(8, hw / std::max(nG, 1) - 1));
+        for (int g = 0; g < nG && st == VSLAM_OK; g++) {
+            vslam_fleet::Group& G = F->groups[g];
+            G.first = g * lanes; G.count = std::min(lanes, n_sessions - G.first);
+            st = vslam_batch_create(&cfgs[G.first], G.count, hostThreads, 0, &G.b);
+            if (st == VSLAM_OK) for (int b = 0; b < G.count; b++) F->ses[G.first + b].sys = vslam_batch_system(G.b, b);
+        }
     }
     if (st != VSLAM_OK) {
-        for (auto& S : F->ses) if (S.sys) vslam_system_destroy(S.sys);
+        if (F->groups.empty()) { for (auto& S : F->ses) if (S.sys) vslam_system_destroy(S.sys); }
+        else for (auto& G : F->groups) if (G.b) vslam_batch_destroy(G.b);
         delete F;
         return st;
     }
-    for (int s = 0; s < n_sessions; s++) F->ses[s].th = std::thread([F, s]() { F->loop(s); });
+    if (F->groups.empty()) for (int s = 0; s < n_sessions; s++) F->ses[s].th = std::thread([F, s]() { F->loop(s); });
+    else for (int g = 0; g < (int)F->groups.size(); g++) F->groups[g].th = std::thread([F, g]() { F->group_loop(g); });
     *out = F;
     return VSLAM_OK;
+}
+
+vslam_status vslam_fleet_create(const vslam_system_config* config, int32_t n_sessions, const vslam_fleet_sequence* seq, vslam_fleet** out) {
+    return fleet_create(config, n_sessions, seq, 0, out);
+}
+
+vslam_status vslam_fleet_create_batched(const vslam_system_config* config, int32_t n_sessions, const vslam_fleet_sequence* seq,
+                                        int32_t lanes_per_group, vslam_fleet** out) {
+    if (lanes_per_group < 1) { set_error("vslam_fleet_create_batched: lanes_per_group >= 1"); return VSLAM_ERR_INVALID; }
+    return fleet_create(config, n_sessions, seq, lanes_per_group, out);
 }
 
 void vslam_fleet_destroy(vslam_fleet* F) {
@@ -185,7 +291,9 @@ void vslam_fleet_destroy(vslam_fleet* F) {
     { std::lock_guard<std::mutex> lk(F->mu); F->stop = true; }
     F->cvGo.notify_all();
     for (auto& S : F->ses) if (S.th.joinable()) S.th.join();
-    for (auto& S : F->ses) if (S.sys) vslam_system_destroy(S.sys);
+    for (auto& G : F->groups) if (G.th.joinable()) G.th.join();
+    if (F->groups.empty()) { for (auto& S : F->ses) if (S.sys) vslam_system_destroy(S.sys); }
+    else for (auto& G : F->groups) if (G.b) vslam_batch_destroy(G.b);
     delete F;
 }
 
@@ -199,7 +307,7 @@ vslam_status vslam_fleet_run(vslam_fleet* F, int32_t n_steps, vslam_fleet_report
     const auto t0 = std::chrono::steady_clock::now();
     {
         std::unique_lock<std::mutex> lk(F->mu);
-        F->jobSteps = n_steps; F->running = (int)F->ses.size(); F->generation++;
+        F->jobSteps = n_steps; F->running = F->groups.empty() ? (int)F->ses.size() : (int)F->groups.size(); F->generation++;
         F->cvGo.notify_all();
         F->cvDone.wait(lk, [&] { return F->running == 0; });
     }
@@ -224,7 +332,10 @@ vslam_status vslam_fleet_run(vslam_fleet* F, int32_t n_steps, vslam_fleet_report
 vslam_status vslam_fleet_set_sampling(vslam_fleet* F, int32_t every) {
     if (!F || every < 0) return VSLAM_ERR_INVALID;
     F->sampleEvery = every;
-    if (!every) vslam_system_set_timing(F->ses[0].sys, 0);
+    if (!every) {
+        if (F->groups.empty()) vslam_system_set_timing(F->ses[0].sys, 0);
+        else { vslam_batch_set_timing(F->groups[0].b, 0); vslam_system_set_ba_timing(F->ses[0].sys, 0); }
+    }
     return VSLAM_OK;
 }
 

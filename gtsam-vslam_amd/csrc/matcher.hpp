@@ -43,6 +43,7 @@ struct vslam_matcher {
     int* d_mBest = nullptr;      // chosen right index or -1
     float* d_mDepth = nullptr;
     int* d_mSad = nullptr;
+    int* d_rowStart = nullptr; int* d_rowIdx = nullptr; int rowCap = 0;   // right keypoints by row
     // TrackedKeys stereo outputs
     int* d_rightIdxs = nullptr;
     int* d_leftIdxs = nullptr;
@@ -162,13 +163,15 @@ struct StereoArgs {
     float fxf;           // (float)fx
     float baseline;
     int imageHeight;
+    const int* rowStart; const int* rowIdx;   // right keypoints bucketed by row (k_stereo_rows): [imageHeight + 1], [nR]
+    int bandMax;                              // rows on either side of a left keypoint's row that can hold a match
 };
 struct StereoLane {          // one lane (stereo pair) of the batched stereo kernels
     StereoArgs A;
     int* mBest; float* mDepth; int* mSad; unsigned long long* stats;
     float closeDepth; int* rightIdxs; int* leftIdxs; float* depth; uint8_t* closef;
 };
-void launch_stereo_batch(hipStream_t s, const StereoLane* dLanes, int B, int maxL, int maxR);
+void launch_stereo_batch(hipStream_t s, const StereoLane* dLanes, int B, int maxL, int maxR, int imageHeight);
 void launch_stereo_match(hipStream_t s, const StereoArgs& A, int* mBest, float* mDepth, int* mSad,
                          unsigned long long* stats);
 void launch_stereo_finalize(hipStream_t s, int nL, int nR, const int* mBest, const float* mDepth,

@@ -445,9 +445,12 @@ __global__ __launch_bounds__(256) void k_kf_update_pose(KfUpdArgs A) {
     (right ? A.dropR : A.dropL)[idx] = drop;
 }
 
-// MapPoint::calcDescriptor: wave = one map point with n <= 64 observation descriptors (lane = descriptor)
+// MapPoint::calcDescriptor: wave = one map point with n <= 64 observation descriptors (lane = descriptor).
+// The n x n Hamming distances go through LDS (column-major: lane-contiguous, conflict-free); every loop runs to n, which
+// is 2 .. 10 for almost every map point - the kernel used to walk all 64 x 64 slots whatever n was.
 __global__ __launch_bounds__(256) void k_calc_descriptor(int nMp, const uint8_t* __restrict__ descs, const int* __restrict__ start,
                                                          int* __restrict__ best) {
+    __shared__ unsigned short sd[4][64 * 64];       // sd[wave][j * 64 + lane] = d(lane, j)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = blockIdx.x * 4 + wave;
     if (m >= nMp) return;
@@ -459,26 +462,22 @@ __global__ __launch_bounds__(256) void k_calc_descriptor(int nMp, const uint8_t*
 #pragma unroll
         for (int q = 0; q < 8; q++) mine[q] = p[q];
     }
-    // dist[j] for j < n in registers is too much for n = 64; the median only needs a rank selection:
-    // k-th smallest of {d(lane, j)} = smallest v with #{d <= v} > k, found by counting over the 257 values
-    int d[64];
-#pragma unroll
-    for (int j = 0; j < 64; j++) {
+    unsigned short* D = sd[wave];
+    for (int j = 0; j < n; j++) {                   // (n is uniform over the wave)
         int dd = 0;
 #pragma unroll
         for (int q = 0; q < 8; q++) dd += __popc(mine[q] ^ (uint32_t)__shfl((int)mine[q], j));
-        d[j] = (j < n && j != lane) ? dd : (j == lane ? 0 : 1 << 20);
+        D[j * 64 + lane] = (unsigned short)(j == lane ? 0 : dd);
     }
+    // (each lane reads back only what it wrote itself: no barrier needed)
     const int kth = (int)(0.5 * (n - 1));
     int median = 1 << 20;
     if (lane < n) {
         // selection by counting: the kth order statistic is the value v = d[j] with #{d < v} <= kth < #{d <= v}
-#pragma unroll
-        for (int j = 0; j < 64; j++) {
-            const int v = d[j];
+        for (int j = 0; j < n; j++) {
+            const int v = D[j * 64 + lane];
             int lt = 0, le = 0;
-#pragma unroll
-            for (int i = 0; i < 64; i++) { lt += d[i] < v; le += d[i] <= v; }
+            for (int i = 0; i < n; i++) { const int di = D[i * 64 + lane]; lt += di < v; le += di <= v; }
             if (lt <= kth && kth < le) median = v;
         }
     }

@@ -25,15 +25,57 @@ __device__ long long g_sm[8];
 #define SM_ACC(k) do {} while (0)
 #endif
 
+// Right keypoints bucketed by (rounded) row, one workgroup per stereo pair: rowStart[r] .. rowStart[r + 1] index rowIdx.
+// Replaces the reference's per-row lists (destributeRightKeys, src/FeatureMatcher.cpp:728-752): there a right keypoint is
+// entered into every row of its band; here it is stored once at its own row and a left keypoint scans the rows that can
+// reach it.  Rows outside the image are clamped to the border rows (the exact band test decides).  Order inside a row
+// does not matter: the match is the minimum of (distance, index).
+__device__ __forceinline__ void stereo_rows_body(const StereoArgs& A, int* __restrict__ rowStart, int* __restrict__ rowIdx) {
+    extern __shared__ int hist[];              // [H + 1] counts -> exclusive starts -> running cursors
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = A.imageHeight, nR = A.nR;
+    for (int r = tid; r <= H; r += 1024) hist[r] = 0;
+    __syncthreads();
+    for (int i = tid; i < nR; i += 1024) {
+        const int yk = min(max(__float2int_rn(A.kpsR[i].y), 0), H - 1);
+        atomicAdd(&hist[yk], 1);
+    }
+    __syncthreads();
+    // exclusive scan over the H rows: every thread owns a run of consecutive rows
+    const int per = (H + 1023) / 1024;
+    const int r0 = tid * per, r1 = min(r0 + per, H);
+    int local = 0;
+    for (int r = r0; r < r1; r++) local += hist[r];
+    int incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int off = 0;
+    for (int k = 0; k < wave; k++) off += wsum[k];
+    int run = off + incl - local;
+    for (int r = r0; r < r1; r++) { const int c = hist[r]; hist[r] = run; rowStart[r] = run; run += c; }
+    if (tid == 0) rowStart[H] = nR;
+    __syncthreads();
+    for (int i = tid; i < nR; i += 1024) {
+        const int yk = min(max(__float2int_rn(A.kpsR[i].y), 0), H - 1);
+        rowIdx[atomicAdd(&hist[yk], 1)] = i;
+    }
+}
+__global__ __launch_bounds__(1024) void k_stereo_rows(StereoArgs A, int* __restrict__ rowStart, int* __restrict__ rowIdx) {
+    stereo_rows_body(A, rowStart, rowIdx);
+}
+__global__ __launch_bounds__(1024) void k_stereo_rows_b(const StereoLane* __restrict__ lanes) {
+    const StereoLane& L = *lane_entry(lanes, blockIdx.x);
+    if (L.A.nL <= 0 && L.A.nR <= 0) return;
+    stereo_rows_body(L.A, const_cast<int*>(L.A.rowStart), const_cast<int*>(L.A.rowIdx));
+}
+
 __device__ __forceinline__ void stereo_match_body(const StereoArgs& A, int* __restrict__ mBest,
                                                   float* __restrict__ mDepth,
                                                   int* __restrict__ mSad,
                                                   unsigned long long* __restrict__ stats) {
-    extern __shared__ unsigned char smem[];
-    const int nR = A.nR, nRp = (nR + 3) & ~3;
-    float* yR = (float*)smem;
-    int* mm = (int*)(yR + nRp);
-    uint8_t* oc = (uint8_t*)(mm + nRp);
     __shared__ uint8_t winL[4][11 * 12];
     __shared__ uint8_t winR[4][11 * 24];
     __shared__ int sadp[4][5 * 11];
@@ -43,17 +85,6 @@ __device__ __forceinline__ void stereo_match_body(const StereoArgs& A, int* __re
     long long sm_t = clock64();
 #endif
     if (tid < 3) sStat[tid] = 0;
-
-    for (int i = tid; i < nR; i += 256) {
-        const float y = A.kpsR[i].y;
-        const int oct = A.kpsR[i].octave;
-        const int yKey = __float2int_rn(y);
-        const float r = 2.0f * A.scalePyrR[oct];
-        const int mn = d_cvFloor((float)yKey - r), mx = d_cvCeil((float)yKey + r);
-        yR[i] = y;
-        mm[i] = (mn & 0xffff) | (mx << 16);
-        oc[i] = (uint8_t)oct;
-    }
     __syncthreads();
     SM_ACC(0);
 
@@ -74,13 +105,19 @@ __device__ __forceinline__ void stereo_match_body(const StereoArgs& A, int* __re
         const uint32_t* pl = (const uint32_t*)(A.descL + (size_t)left * 32);
 #pragma unroll
         for (int k = 0; k < 8; k++) dl[k] = pl[k];
-        for (int idx = lane; idx < nR; idx += 64) {
-            const int m = mm[idx];
-            const int mn = (short)(m & 0xffff), mx = m >> 16;
+        // right keypoints whose row band [mn, mx] contains yKey sit in the row buckets yKey - bandMax .. yKey + bandMax
+        // (k_stereo_rows; the band half-width is 2 * scale[octave] <= bandMax - 1)
+        const int rlo = max(0, yKey - A.bandMax), rhi = min(A.imageHeight - 1, yKey + A.bandMax);
+        const int pBeg = A.rowStart[rlo], pEnd = A.rowStart[rhi + 1];
+        for (int p = pBeg + lane; p < pEnd; p += 64) {
+            const int idx = A.rowIdx[p];
+            const float uR = A.kpsR[idx].y;
+            const int octR = A.kpsR[idx].octave;
+            const int yKeyR = __float2int_rn(uR);
+            const float rb = 2.0f * A.scalePyrR[octR];
+            const int mn = d_cvFloor((float)yKeyR - rb), mx = d_cvCeil((float)yKeyR + rb);
             if (yKey < mn || yKey > mx) continue;
-            const int octR = oc[idx];
             if (octR < octL - 1 || octR > octL + 1) continue;
-            const float uR = yR[idx];
             if (!(uR >= minU && uR <= maxU)) continue;
             const uint4* pr = (const uint4*)(A.descR + (size_t)idx * 32);
             const uint4 r0 = pr[0], r1 = pr[1];
@@ -213,12 +250,11 @@ __global__ __launch_bounds__(256) void k_stereo_match_b(const StereoLane* __rest
 void launch_stereo_match(hipStream_t s, const StereoArgs& A, int* mBest, float* mDepth, int* mSad,
                          unsigned long long* stats) {
     if (A.nL <= 0) return;
-    const int nRp = (A.nR + 3) & ~3;
-    const size_t sh = (size_t)nRp * 9 + 16;
 #ifdef VSLAM_STEREO_STAMPS
     { long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sm), z, sizeof(z)); }
 #endif
-    hipLaunchKernelGGL(k_stereo_match, dim3((A.nL + 3) / 4), dim3(256), sh, s, A, mBest, mDepth, mSad, stats);
+    hipLaunchKernelGGL(k_stereo_rows, dim3(1), dim3(1024), (size_t)(A.imageHeight + 1) * sizeof(int), s, A, const_cast<int*>(A.rowStart), const_cast<int*>(A.rowIdx));
+    hipLaunchKernelGGL(k_stereo_match, dim3((A.nL + 3) / 4), dim3(256), 0, s, A, mBest, mDepth, mSad, stats);
 #ifdef VSLAM_STEREO_STAMPS
     {
         long long z[8];
@@ -395,13 +431,13 @@ void launch_stereo_finalize(hipStream_t s, int nL, int nR, const int* mBest, con
 #endif
 }
 
-constexpr int STEREO_LDS = 150 * 1024, STEREO_MAX_R = (STEREO_LDS - 16) / 9 - 4, STEREO_MAX_L = STEREO_LDS / 20;
+constexpr int STEREO_LDS = 150 * 1024, STEREO_MAX_L = STEREO_LDS / 20, STEREO_MAX_H = STEREO_LDS / 4 - 64;
 static vslam_status stereo_attrs() {
     static bool attr = false;
     if (!attr) {
-        VS_HIP(hipFuncSetAttribute((const void*)k_stereo_match, hipFuncAttributeMaxDynamicSharedMemorySize, STEREO_LDS));
+        VS_HIP(hipFuncSetAttribute((const void*)k_stereo_rows, hipFuncAttributeMaxDynamicSharedMemorySize, STEREO_LDS));
+        VS_HIP(hipFuncSetAttribute((const void*)k_stereo_rows_b, hipFuncAttributeMaxDynamicSharedMemorySize, STEREO_LDS));
         VS_HIP(hipFuncSetAttribute((const void*)k_stereo_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, STEREO_LDS));
-        VS_HIP(hipFuncSetAttribute((const void*)k_stereo_match_b, hipFuncAttributeMaxDynamicSharedMemorySize, STEREO_LDS));
         VS_HIP(hipFuncSetAttribute((const void*)k_stereo_finalize_b, hipFuncAttributeMaxDynamicSharedMemorySize, STEREO_LDS));
         attr = true;
     }
@@ -409,11 +445,12 @@ static vslam_status stereo_attrs() {
 }
 
 // all lanes' stereo matches in two launches (maxL / maxR: the largest key counts over the lanes)
-void launch_stereo_batch(hipStream_t s, const StereoLane* dLanes, int B, int maxL, int maxR) {
+void launch_stereo_batch(hipStream_t s, const StereoLane* dLanes, int B, int maxL, int maxR, int imageHeight) {
     if (B <= 0 || (maxL <= 0 && maxR <= 0)) return;
     (void)stereo_attrs();
-    const size_t shM = (size_t)((maxR + 3) & ~3) * 9 + 16, shF = (size_t)(maxL > 0 ? maxL : 1) * 20;
-    if (maxL > 0) hipLaunchKernelGGL(k_stereo_match_b, dim3((maxL + 3) / 4, B), dim3(256), shM, s, dLanes);
+    const size_t shF = (size_t)(maxL > 0 ? maxL : 1) * 20;
+    hipLaunchKernelGGL(k_stereo_rows_b, dim3(B), dim3(1024), (size_t)(imageHeight + 1) * sizeof(int), s, dLanes);
+    if (maxL > 0) hipLaunchKernelGGL(k_stereo_match_b, dim3((maxL + 3) / 4, B), dim3(256), 0, s, dLanes);
     hipLaunchKernelGGL(k_stereo_finalize_b, dim3(B), dim3(1024), shF, s, dLanes);
 }
 
@@ -467,8 +504,9 @@ vslam_status vslam_matcher::ensure_cap(int n) {
     if (n <= cap) return VSLAM_OK;
     if (n > 65535) { set_error("more than 65535 keypoints per image is not supported"); return VSLAM_ERR_CAPACITY; }
     hipFree(d_mBest); hipFree(d_mDepth); hipFree(d_mSad); hipFree(d_rightIdxs); hipFree(d_leftIdxs);
-    hipFree(d_depth); hipFree(d_close);
+    hipFree(d_depth); hipFree(d_close); hipFree(d_rowIdx);
     cap = vslam::align_up(n, 256);
+    VS_HIP(hipMalloc(&d_rowIdx, cap * sizeof(int)));
     VS_HIP(hipMalloc(&d_mBest, cap * sizeof(int)));
     VS_HIP(hipMalloc(&d_mDepth, cap * sizeof(float)));
     VS_HIP(hipMalloc(&d_mSad, cap * sizeof(int)));
@@ -486,7 +524,7 @@ void vslam_matcher::release() {
     useEvents.clear();
     timer.destroy();
     hipFree(d_mBest); hipFree(d_mDepth); hipFree(d_mSad); hipFree(d_rightIdxs); hipFree(d_leftIdxs);
-    hipFree(d_depth); hipFree(d_close); hipFree(d_stats);
+    hipFree(d_depth); hipFree(d_close); hipFree(d_stats); hipFree(d_rowStart); hipFree(d_rowIdx);
     for (int s = 0; s < 2; s++) { hipFree(d_okps[s]); hipFree(d_odesc[s]); }
     if (!trExternal) { hipFree(d_trXyz); hipFree(d_trDesc); hipFree(d_trMsd); hipFree(d_trOutlier); }
     hipFree(d_trAct);
@@ -547,11 +585,20 @@ vslam_status vslam_matcher::stereo_lane(vslam::StereoLane& L) {
     }
     A.maxD = (float)rig.fx; A.fx = rig.fx; A.fxf = (float)rig.fx; A.baseline = rig.baseline;
     A.imageHeight = rig.height;
-    // dynamic LDS of the two kernels: 9 B per right key (row band, octave, y) / 20 B per left key (accepted-pair lists)
-    if (A.nR > STEREO_MAX_R || A.nL > STEREO_MAX_L) {
-        set_error("stereo_match: %d left / %d right keypoints exceed the LDS staging (%d / %d)", A.nL, A.nR, STEREO_MAX_L, STEREO_MAX_R);
+    // dynamic LDS: 20 B per left key (accepted-pair lists of the finalize kernel), 4 B per image row (row buckets)
+    if (A.nL > STEREO_MAX_L || A.imageHeight > STEREO_MAX_H) {
+        set_error("stereo_match: %d left keypoints / %d rows exceed the LDS staging (%d / %d)", A.nL, A.imageHeight, STEREO_MAX_L, STEREO_MAX_H);
         return VSLAM_ERR_CAPACITY;
     }
+    float maxScale = 1.f;
+    for (int l = 0; l < feR->nLevels; l++) maxScale = std::max(maxScale, feR->scalePyramid[l]);
+    A.bandMax = (int)std::ceil(2.0f * maxScale) + 1;
+    if (rowCap < rig.height + 2) {
+        hipFree(d_rowStart);
+        rowCap = rig.height + 2;
+        VS_HIP(hipMalloc(&d_rowStart, (size_t)rowCap * sizeof(int)));
+    }
+    A.rowStart = d_rowStart; A.rowIdx = d_rowIdx;
     L.mBest = d_mBest; L.mDepth = d_mDepth; L.mSad = d_mSad; L.stats = d_stats;
     L.closeDepth = rig.baseline * 40;   // closeNumber, include/FeatureMatcher.h:36
     L.rightIdxs = d_rightIdxs; L.leftIdxs = d_leftIdxs; L.depth = d_depth; L.closef = d_close;

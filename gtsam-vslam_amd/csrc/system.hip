@@ -525,10 +525,11 @@ void vslam_system::worker_loop() {
         {
             std::unique_lock<std::mutex> lk(wMu);
             wCv.wait(lk, [&] { return stopRequested || mappingBusy; });
-            if (stopRequested) return;
+            if (stopRequested) break;
         }
         run_mapping();
     }
+    vslam::thread_release();
 }
 
 // one pass of beginLocalMapping's loop body (src/OptimizationBA.cpp:960-975)
@@ -892,6 +893,23 @@ vslam_status vslam_system_set_timing(vslam_system* s, int32_t on) {
     s->timingOn = on ? 1 : 0;
     VS_CHECK(vslam_extractor_set_timing(s->fe, on));
     return vslam_matcher_set_timing(s->fm, on);
+}
+
+// local-BA timing only (the session's extractor / matcher timers untouched: lanes of a vslam_batch share them)
+vslam_status vslam_system_set_ba_timing(vslam_system* s, int32_t on) {
+    if (!s) return VSLAM_ERR_INVALID;
+    s->timingOn = on ? 1 : 0;
+    return VSLAM_OK;
+}
+vslam_status vslam_system_ba_timings(vslam_system* s, const char** names, float* ms, int32_t cap, int32_t* n_out, int32_t* ba_calls_out) {
+    if (!s || !n_out || !names || !ms) return VSLAM_ERR_INVALID;
+    int n = 0;
+    std::lock_guard<std::mutex> lk(s->tMu);
+    for (auto& b : s->baTimes) if (n < cap) { names[n] = b.first; ms[n] = b.second; n++; }
+    if (ba_calls_out) *ba_calls_out = s->baTimedCalls;
+    s->baTimes.clear(); s->baTimedCalls = 0;
+    *n_out = n;
+    return VSLAM_OK;
 }
 
 // device time per kernel group of the LAST frame (extraction, matching / tracking) and, summed over the local BAs that

@@ -956,7 +956,8 @@ class Fleet:
     """S independent sessions replaying one stereo sequence (device or pinned-host image pointers) as a ping-pong."""
 
     def __init__(self, cfg, n_sessions, left_ptrs, right_ptrs, stride, on_device, poses=None, velocities=None,
-                 imu_forward=None, imu_backward=None):
+                 imu_forward=None, imu_backward=None, lanes=0):
+        """lanes > 0: the sessions are the lanes of ceil(n_sessions / lanes) lockstep groups (vslam_batch)"""
         self.L = lib()
         n = len(left_ptrs)
         self._keep = []
@@ -984,7 +985,10 @@ class Fleet:
         if velocities is not None:
             V = np.ascontiguousarray(velocities, np.float64).reshape(n, 3); self._keep.append(V); seq.velocity_true = _p(V)
         self.h = C.c_void_p()
-        _chk(self.L.vslam_fleet_create(C.byref(cfg), int(n_sessions), C.byref(seq), C.byref(self.h)))
+        if lanes > 0:
+            _chk(self.L.vslam_fleet_create_batched(C.byref(cfg), int(n_sessions), C.byref(seq), int(lanes), C.byref(self.h)))
+        else:
+            _chk(self.L.vslam_fleet_create(C.byref(cfg), int(n_sessions), C.byref(seq), C.byref(self.h)))
         self.n_sessions = n_sessions
 
     def run(self, n_steps):

@@ -607,6 +607,9 @@ vslam_status vslam_system_last_frame(vslam_system* sys, int32_t cap, int32_t* n_
  * over the ba_calls local BAs that completed since the previous read */
 vslam_status vslam_system_set_timing(vslam_system* sys, int32_t on);
 vslam_status vslam_system_timings(vslam_system* sys, const char** names, float* ms, int32_t cap, int32_t* n_out, int32_t* ba_calls_out);
+/* the local-BA part alone (a vslam_batch lane: the extraction / tracking timers belong to the batch) */
+vslam_status vslam_system_set_ba_timing(vslam_system* sys, int32_t on);
+vslam_status vslam_system_ba_timings(vslam_system* sys, const char** names, float* ms, int32_t cap, int32_t* n_out, int32_t* ba_calls_out);
 
 /* ---------------------------------------------------------------------------
  * vslam_batch - B independent sequences ("lanes") tracked in lockstep: every stage of FeatureTracker::TrackImage
@@ -673,6 +676,9 @@ typedef struct vslam_fleet_report {
 
 vslam_status vslam_fleet_create(const vslam_system_config* config, int32_t n_sessions, const vslam_fleet_sequence* sequence,
                                 vslam_fleet** out);
+/* the same sessions as the lanes of ceil(n_sessions / lanes_per_group) lockstep groups (vslam_batch), one driver thread each */
+vslam_status vslam_fleet_create_batched(const vslam_system_config* config, int32_t n_sessions, const vslam_fleet_sequence* sequence,
+                                        int32_t lanes_per_group, vslam_fleet** out);
 void vslam_fleet_destroy(vslam_fleet* fleet);
 /* every session tracks its next n_steps frames; returns when all of them - and every local BA they triggered - are done */
 vslam_status vslam_fleet_run(vslam_fleet* fleet, int32_t n_steps, vslam_fleet_report* report);
@@ -682,6 +688,12 @@ vslam_status vslam_fleet_system(vslam_fleet* fleet, int32_t session, vslam_syste
  * {sampled frames, pose solves in them, local BAs timed}; read-and-reset */
 vslam_status vslam_fleet_set_sampling(vslam_fleet* fleet, int32_t every);
 vslam_status vslam_fleet_timings(vslam_fleet* fleet, const char** names, float* ms, int32_t cap, int32_t* n_out, int64_t* counts3);
+
+/* The library caches device scratch memory, a stream and the local-BA workspace per calling thread.  Its own threads free
+ * theirs; a thread of the caller that used vslam_local_ba / the new-point functions / vslam_system_* may call this before
+ * it ends (otherwise the cache lives until the process exits - nothing is freed from thread-exit hooks, where profiler
+ * libraries no longer tolerate HIP calls). */
+void vslam_thread_release(void);
 
 /* debug aid: fill every device allocation made from now on (and every reused scratch block) with `byte` (< 0: off; the
  * VSLAM_POISON environment variable sets the start value) - results must not depend on it */
