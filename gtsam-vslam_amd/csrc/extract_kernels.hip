@@ -107,15 +107,59 @@ __device__ __forceinline__ bool has9(unsigned m) {
     return (t & 0xffffu) != 0;
 }
 
+// One 64-lane wave per cell (four cells per workgroup, no workgroup barriers).  The cell's sub-image is staged in LDS with
+// aligned dword loads.  Pixels pass three stages, each run on FULL waves through small in-wave queues (ballot
+// compaction), so the expensive stage only ever sees pixels that need it:
+//   1  every detection pixel: two ADJACENT cardinal ring pixels (0/4/8/12) both darker or both brighter than the
+//      quick-reject threshold - a necessary condition for any 9-arc;
+//   2  survivors: the 16-pixel ring masks and the 9-contiguous test at the quick-reject threshold;
+//   3  survivors: the exact score M (max over arcs of the min difference) -> score plane in LDS.
+// Then, per threshold, 3x3 strict-maximum suppression and the ordered emission (row-major) by ballot prefix.
+constexpr int FQ_MASK = 255;          // queue capacity (entries) - 1: at most 64 + 63 entries are ever pending
+
+__device__ __forceinline__ int fast_score(const uint8_t* p, const int* ro) {
+    const int v = p[0];
+    int d[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) d[k] = v - (int)p[ro[k]];
+    int mn[16], mx[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {  // width-2 windows
+        mn[k] = min(d[k], d[(k + 1) & 15]);
+        mx[k] = max(d[k], d[(k + 1) & 15]);
+    }
+    int mn4[16], mx4[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        mn4[k] = min(mn[k], mn[(k + 2) & 15]);
+        mx4[k] = max(mx[k], mx[(k + 2) & 15]);
+    }
+    int A = -512, B = 512;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int m9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
+        const int x9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
+        A = max(A, m9);
+        B = min(B, x9);
+    }
+    const int M = max(A, -B);
+    return M < 0 ? 0 : M;
+}
+
 __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, PyrDesc P,
                                               FastDesc F, uint32_t* __restrict__ cellSlots,
                                               int* __restrict__ cellCount, int maxThr, int minThr) {
-    __shared__ uint8_t tile[FAST_TILE_MAX * FAST_TILE_PITCH];
-    __shared__ uint8_t sc[(FAST_TILE_MAX - 4) * FAST_TILE_PITCH];
-    __shared__ int wsum[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cell = blockIdx.x, img = blockIdx.y;
+    extern __shared__ unsigned char fsm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int TP = F.tilePitch;                                    // bytes per LDS row (multiple of 4)
+    const int perWave = F.tileRows * TP * 2 + 2 * (FQ_MASK + 1) * 2;
+    uint8_t* tile = fsm + (size_t)wave * perWave;                  // [tileRows][TP] sub-image
+    uint8_t* sc = tile + F.tileRows * TP;                          // [tileRows][TP] scores (row / col 0 = border)
+    unsigned short* q1 = (unsigned short*)(sc + F.tileRows * TP);  // stage 1 -> 2
+    unsigned short* q2 = q1 + (FQ_MASK + 1);                       // stage 2 -> 3
+    const int cell = blockIdx.x * 4 + wave, img = blockIdx.y;
     const int nCellsTotal = F.cellBase[P.nLevels];
+    if (cell >= nCellsTotal) return;
     int level = 0;
     while (level + 1 < P.nLevels && cell >= F.cellBase[level + 1]) level++;
     const int local = cell - F.cellBase[level];
@@ -127,7 +171,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, P
     const int cStart = F.minXY + iC * F.gridW[level];
     int* outCount = cellCount + (size_t)img * nCellsTotal + cell;
     if (rStart >= maxY - 6 || cStart >= maxX - 6) {
-        if (tid == 0) *outCount = 0;
+        if (lane == 0) *outCount = 0;
         return;
     }
     int rEnd = rStart + F.gridH[level] + 6;
@@ -137,82 +181,115 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, P
     const int subW = cEnd - cStart, subH = rEnd - rStart;
     const int detW = subW - 6, detH = subH - 6;
     if (detW <= 0 || detH <= 0) {
-        if (tid == 0) *outCount = 0;
+        if (lane == 0) *outCount = 0;
         return;
     }
-    const uint8_t* __restrict__ src =
-        pyr + (size_t)img * P.imgStride + P.off[level] + (size_t)rStart * pitch + cStart;
-    for (int i = tid; i < subW * subH; i += 256) {
-        const int r = i / subW, c = i - r * subW;
-        tile[r * FAST_TILE_PITCH + c] = src[(size_t)r * pitch + c];
+    // ---- sub-image -> LDS: aligned dwords (LDS column 0 = image column cStart & ~3) --------------------------------------
+    const int xoff = cStart & 3;
+    {
+        const uint8_t* __restrict__ src = pyr + (size_t)img * P.imgStride + P.off[level] + (size_t)rStart * pitch + (cStart - xoff);
+        const int nd = (xoff + subW + 3) >> 2;
+        int r = 0, c = lane;
+        while (c >= nd) { c -= nd; r++; }
+        for (; r < subH;) {
+            *(unsigned*)(tile + r * TP + 4 * c) = *(const unsigned*)(src + (size_t)r * pitch + 4 * c);
+            c += 64;
+            while (c >= nd) { c -= nd; r++; }
+        }
     }
-    for (int i = tid; i < (detH + 2) * FAST_TILE_PITCH; i += 256) sc[i] = 0;
-    __syncthreads();
+    // score-plane border (NMS reads one pixel beyond the detection area: those count as 0)
+    for (int i = lane; i < detW + 2; i += 64) { sc[i] = 0; sc[(detH + 1) * TP + i] = 0; }
+    for (int i = lane; i < detH + 2; i += 64) { sc[i * TP] = 0; sc[i * TP + detW + 1] = 0; }
 
     const int tq = minThr < maxThr ? minThr : maxThr;  // quick-reject threshold
-    constexpr int TP = FAST_TILE_PITCH;
-    constexpr int ro[16] = {3 * TP,      3 * TP + 1,  2 * TP + 2,  TP + 3,  3,       -TP + 3,
-                            -2 * TP + 2, -3 * TP + 1, -3 * TP,     -3 * TP - 1, -2 * TP - 2, -TP - 3,
-                            -3,          TP - 3,      2 * TP - 2,  3 * TP - 1};
-    const int npix = detW * detH;
-    for (int idx = tid; idx < npix; idx += 256) {
-        const int r = idx / detW, c = idx - r * detW;
-        const uint8_t* p = &tile[(r + 3) * TP + (c + 3)];
-        const int v = p[0];
-        int q[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) q[k] = p[ro[k]];
-        unsigned dm = 0, bm = 0;
-        const int lo = v - tq, hi = v + tq;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            dm |= (unsigned)(q[k] < lo) << k;
-            bm |= (unsigned)(q[k] > hi) << k;
-        }
-        int M = 0;
-        if (has9(dm) || has9(bm)) {
-            int d[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) d[k] = v - q[k];
-            int mn[16], mx[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) {  // width-2 windows
-                mn[k] = min(d[k], d[(k + 1) & 15]);
-                mx[k] = max(d[k], d[(k + 1) & 15]);
-            }
-            int mn4[16], mx4[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                mn4[k] = min(mn[k], mn[(k + 2) & 15]);
-                mx4[k] = max(mx[k], mx[(k + 2) & 15]);
-            }
-            int A = -512, B = 512;
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const int m9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
-                const int x9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
-                A = max(A, m9);
-                B = min(B, x9);
-            }
-            M = max(A, -B);
-            M = M < 0 ? 0 : M;
-        }
-        sc[(r + 1) * TP + (c + 1)] = (uint8_t)M;
-    }
-    __syncthreads();
+    const int ro[16] = {3 * TP,      3 * TP + 1,  2 * TP + 2,  TP + 3,  3,       -TP + 3,
+                        -2 * TP + 2, -3 * TP + 1, -3 * TP,     -3 * TP - 1, -2 * TP - 2, -TP - 3,
+                        -3,          TP - 3,      2 * TP - 2,  3 * TP - 1};
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int h1 = 0, t1 = 0, h2 = 0, t2 = 0;                // queue heads / tails (wave-uniform)
 
+    auto stage3 = [&](int rc, bool valid) {
+        if (valid) {
+            const int r = rc >> 7, c = rc & 127;
+            sc[(r + 1) * TP + (c + 1)] = (uint8_t)fast_score(&tile[(r + 3) * TP + (c + 3 + xoff)], ro);
+        }
+    };
+    auto drain2 = [&](bool all) {
+        while (t2 - h2 >= 64 || (all && t2 > h2)) {
+            const bool valid = lane < t2 - h2;
+            const int rc = valid ? q2[(h2 + lane) & FQ_MASK] : 0;
+            h2 += min(64, t2 - h2);
+            stage3(rc, valid);
+        }
+    };
+    auto stage2 = [&](int rc, bool valid) {
+        bool pass = false;
+        if (valid) {
+            const int r = rc >> 7, c = rc & 127;
+            const uint8_t* p = &tile[(r + 3) * TP + (c + 3 + xoff)];
+            const int v = p[0], lo = v - tq, hi = v + tq;
+            unsigned dm = 0, bm = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int q = p[ro[k]];
+                dm |= (unsigned)(q < lo) << k;
+                bm |= (unsigned)(q > hi) << k;
+            }
+            pass = has9(dm) || has9(bm);
+        }
+        const unsigned long long bal = __ballot(pass);
+        if (pass) q2[(t2 + __popcll(bal & lt)) & FQ_MASK] = (unsigned short)rc;
+        t2 += __popcll(bal);
+        drain2(false);
+    };
+    auto drain1 = [&](bool all) {
+        while (t1 - h1 >= 64 || (all && t1 > h1)) {
+            const bool valid = lane < t1 - h1;
+            const int rc = valid ? q1[(h1 + lane) & FQ_MASK] : 0;
+            h1 += min(64, t1 - h1);
+            stage2(rc, valid);
+        }
+    };
+
+    const int npix = detW * detH;
+    {
+        int r = 0, c = lane;
+        while (c >= detW) { c -= detW; r++; }
+        for (int base = 0; base < npix; base += 64) {
+            const bool valid = base + lane < npix;
+            bool pass = false;
+            if (valid) {
+                const uint8_t* p = &tile[(r + 3) * TP + (c + 3 + xoff)];
+                const int v = p[0], lo = v - tq, hi = v + tq;
+                const int c0 = p[3 * TP], c4 = p[3], c8 = p[-3 * TP], c12 = p[-3];
+                const bool d0 = c0 < lo, d4 = c4 < lo, d8 = c8 < lo, d12 = c12 < lo;
+                const bool b0 = c0 > hi, b4 = c4 > hi, b8 = c8 > hi, b12 = c12 > hi;
+                pass = (d0 && d4) || (d4 && d8) || (d8 && d12) || (d12 && d0) || (b0 && b4) || (b4 && b8) || (b8 && b12) || (b12 && b0);
+                sc[(r + 1) * TP + (c + 1)] = 0;
+            }
+            const unsigned long long bal = __ballot(pass);
+            if (pass) q1[(t1 + __popcll(bal & lt)) & FQ_MASK] = (unsigned short)((r << 7) | c);
+            t1 += __popcll(bal);
+            drain1(false);
+            c += 64;
+            while (c >= detW) { c -= detW; r++; }
+        }
+    }
+    drain1(true);
+    drain2(true);
+
+    // ---- 3x3 suppression + ordered emission --------------------------------------------------------------------------------
     uint32_t* slots = cellSlots + ((size_t)img * nCellsTotal + cell) * F.cellCap;
     int total = 0;
     for (int pass = 0; pass < 2; pass++) {
         const int t = pass == 0 ? maxThr : minThr;
         total = 0;
-        for (int base = 0; base < npix; base += 256) {
-            const int idx = base + tid;
+        int r = 0, c = lane;
+        while (c >= detW) { c -= detW; r++; }
+        for (int base = 0; base < npix; base += 64) {
             bool flag = false;
-            int r = 0, c = 0, s = 0;
-            if (idx < npix) {
-                r = idx / detW;
-                c = idx - r * detW;
+            int s = 0;
+            if (base + lane < npix) {
                 const uint8_t* z = &sc[(r + 1) * TP + (c + 1)];
                 s = z[0];
                 if (s > t) {
@@ -229,32 +306,24 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, P
                 }
             }
             const unsigned long long bal = __ballot(flag);
-            const int lanePrefix = __popcll(bal & ((1ull << lane) - 1ull));
-            if (lane == 0) wsum[wave] = __popcll(bal);
-            __syncthreads();
-            int woff = 0, chunk = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int v2 = wsum[k];
-                if (k < wave) woff += v2;
-                chunk += v2;
-            }
             if (flag) {
-                const int pos = total + woff + lanePrefix;
+                const int pos = total + __popcll(bal & lt);
                 if (pos < F.cellCap) slots[pos] = pack_cand(cStart + 3 + c, rStart + 3 + r, s - 1);
             }
-            total += chunk;
-            __syncthreads();
+            total += __popcll(bal);
+            c += 64;
+            while (c >= detW) { c -= detW; r++; }
         }
         if (total > 0) break;
     }
-    if (tid == 0) *outCount = total;
+    if (lane == 0) *outCount = total;
 }
 
 void launch_fast(hipStream_t s, const uint8_t* pyr, const PyrDesc& P, const FastDesc& F,
                  uint32_t* cellSlots, int* cellCount, int maxThr, int minThr, int nimg) {
-    dim3 grid(F.cellBase[P.nLevels], nimg);
-    hipLaunchKernelGGL(k_fast, grid, dim3(256), 0, s, pyr, P, F, cellSlots, cellCount, maxThr, minThr);
+    dim3 grid((F.cellBase[P.nLevels] + 3) / 4, nimg);
+    const size_t lds = (size_t)4 * ((size_t)F.tileRows * F.tilePitch * 2 + 2 * (FQ_MASK + 1) * 2);
+    hipLaunchKernelGGL(k_fast, grid, dim3(256), lds, s, pyr, P, F, cellSlots, cellCount, maxThr, minThr);
 }
 
 // ---------------------------------------------------------------------------
@@ -328,7 +397,7 @@ void launch_gather(hipStream_t s, const uint32_t* cellSlots, const int* cellCoun
 // K5: cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) on every pyramid level
 // (reference src/FeatureExtractor.cpp:512-515).  Fixed-point 8.8 taps; the horizontal
 // pass is exact in 16 bits, the vertical pass rounds once: (acc + 32768) >> 16.
-// 64x16 output tile per workgroup staged through LDS with its 3-px halo.
+// 256 x 64 output tile per workgroup (BLUR_TW x BLUR_TH), 4 x 16 pixels per thread.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int reflect101(int p, int len) {
     if (len == 1) return 0;
@@ -336,42 +405,72 @@ __device__ __forceinline__ int reflect101(int p, int len) {
     return p;
 }
 
+// One thread = 4 horizontally adjacent pixels x BLUR_RPT rows: three aligned dword loads per input row give the 10 source
+// bytes; the horizontal pass is two v_dot4_u32_u8 per pixel (the taps are 8-bit), the 7 row sums of the vertical pass
+// roll through registers.  No LDS, no barrier; only the threads at the left / right image border take the byte-wise
+// REFLECT_101 path.  (Bit-identical to the LDS-tiled form it replaces: all sums are exact integers.)
 __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr,
                                               uint8_t* __restrict__ blur, PyrDesc P, BlurDesc B) {
-    constexpr int IW = BLUR_TW + 6, IH = BLUR_TH + 6, IP = 72;
-    __shared__ uint8_t in[IH * IP];
-    __shared__ uint16_t hb[IH * BLUR_TW];
-    const int tid = threadIdx.x, img = blockIdx.y;
+    const int img = blockIdx.y;
     int level = 0;
     const int t = blockIdx.x;
     while (level + 1 < P.nLevels && t >= B.tileBase[level + 1]) level++;
     const int lt = t - B.tileBase[level];
-    const int ty = lt / B.tilesX[level], tx = lt - ty * B.tilesX[level];
+    const int tyb = lt / B.tilesX[level], txb = lt - tyb * B.tilesX[level];
     const int w = P.w[level], h = P.h[level], pitch = P.pitch[level];
     const uint8_t* __restrict__ S = pyr + (size_t)img * P.imgStride + P.off[level];
     uint8_t* __restrict__ D = blur + (size_t)img * P.imgStride + P.off[level];
-    const int x0 = tx * BLUR_TW, y0 = ty * BLUR_TH;
-    for (int i = tid; i < IH * IW; i += 256) {
-        const int r = i / IW, c = i - r * IW;
-        const int sx = reflect101(x0 + c - 3, w), sy = reflect101(y0 + r - 3, h);
-        in[r * IP + c] = S[(size_t)sy * pitch + sx];
-    }
-    __syncthreads();
-    for (int i = tid; i < IH * BLUR_TW; i += 256) {
-        const int r = i / BLUR_TW, c = i - r * BLUR_TW;
-        const uint8_t* p = &in[r * IP + c];
-        unsigned acc = 0;
+    const int x = txb * BLUR_TW + (threadIdx.x & 63) * 4;
+    const int yb = tyb * BLUR_TH + (threadIdx.x >> 6) * BLUR_RPT;
+    if (x >= w || yb >= h) return;
+    const unsigned tA = (unsigned)B.taps[0] | ((unsigned)B.taps[1] << 8) | ((unsigned)B.taps[2] << 16) | ((unsigned)B.taps[3] << 24);
+    const unsigned tB = (unsigned)B.taps[4] | ((unsigned)B.taps[5] << 8) | ((unsigned)B.taps[6] << 16);
+    const int t0 = B.taps[0], t1 = B.taps[1], t2 = B.taps[2], t3 = B.taps[3];      // (symmetric: taps[6 - j] == taps[j])
+    const bool interior = x >= 4 && x + 8 <= w;
+    unsigned hb[7][4];
 #pragma unroll
-        for (int j = 0; j < 7; j++) acc += (unsigned)B.taps[j] * p[j];
-        hb[i] = (uint16_t)acc;
-    }
-    __syncthreads();
-    for (int i = tid; i < BLUR_TH * BLUR_TW; i += 256) {
-        const int r = i / BLUR_TW, c = i - r * BLUR_TW;
-        unsigned acc = 0;
+    for (int rr = 0; rr < BLUR_RPT + 6; rr++) {
+        const int sy = reflect101(yb + rr - 3, h);
+        const uint8_t* row = S + (size_t)sy * pitch;
+        unsigned d0, d1, d2;
+        if (interior) {
+            d0 = *(const unsigned*)(row + x - 4); d1 = *(const unsigned*)(row + x); d2 = *(const unsigned*)(row + x + 4);
+        } else {
+            d0 = d1 = d2 = 0;
 #pragma unroll
-        for (int j = 0; j < 7; j++) acc += (unsigned)B.taps[j] * hb[(r + j) * BLUR_TW + c];
-        if (x0 + c < w && y0 + r < h) D[(size_t)(y0 + r) * pitch + x0 + c] = (uint8_t)((acc + 32768u) >> 16);
+            for (int k = 0; k < 4; k++) {
+                d0 |= (unsigned)row[reflect101(x - 4 + k, w)] << (8 * k);
+                d1 |= (unsigned)row[reflect101(x + k, w)] << (8 * k);
+                d2 |= (unsigned)row[reflect101(x + 4 + k, w)] << (8 * k);
+            }
+        }
+        // pixel i of the four: source bytes i + 1 .. i + 7 of the 12-byte window d0 | d1 | d2
+        unsigned nh[4];
+        nh[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), tA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), tB, 0u, false), false);
+        nh[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), tA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), tB, 0u, false), false);
+        nh[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), tA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), tB, 0u, false), false);
+        nh[3] = __builtin_amdgcn_udot4(d1, tA, __builtin_amdgcn_udot4(d2, tB, 0u, false), false);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) hb[k][i] = hb[k + 1][i];
+            hb[6][i] = nh[i] & 0xffffu;
+        }
+        if (rr >= 6) {
+            const int y = yb + rr - 6;
+            if (y < h) {
+                unsigned o = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const unsigned acc = (unsigned)t0 * (hb[0][i] + hb[6][i]) + (unsigned)t1 * (hb[1][i] + hb[5][i]) +
+                                         (unsigned)t2 * (hb[2][i] + hb[4][i]) + (unsigned)t3 * hb[3][i];
+                    o |= ((acc + 32768u) >> 16) << (8 * i);
+                }
+                uint8_t* dq = D + (size_t)y * pitch + x;
+                if (x + 4 <= w) *(unsigned*)dq = o;
+                else for (int i = 0; i < 4 && x + i < w; i++) dq[i] = (uint8_t)(o >> (8 * i));
+            }
+        }
     }
 }
 

@@ -23,6 +23,7 @@ struct FastDesc {
     int nCols[MAX_LEVELS], nRows[MAX_LEVELS], gridW[MAX_LEVELS], gridH[MAX_LEVELS];
     int cellBase[MAX_LEVELS + 1];    // prefix of cell counts
     int cellCap;                     // slots per cell
+    int tileRows, tilePitch;         // LDS tile of k_fast: rows (largest sub-image height), bytes per row (largest width + 3, x4)
 };
 
 struct BlurDesc {
@@ -46,7 +47,8 @@ __host__ __device__ static inline int cand_s(uint32_t p) { return p & 0xff; }
 
 constexpr int FAST_TILE_PITCH = 80;   // >= max sub-image width (gridW + 6)
 constexpr int FAST_TILE_MAX = 76;     // max sub-image side supported
-constexpr int BLUR_TW = 64, BLUR_TH = 16;
+constexpr int BLUR_RPT = 16;              // rows per thread of k_blur
+constexpr int BLUR_TW = 256, BLUR_TH = 4 * BLUR_RPT;   // output tile of one 256-thread workgroup
 
 void launch_load_images(hipStream_t s, const uint8_t* const* dSrc, int stride, uint8_t* pyr, const PyrDesc& P, int nimg);
 void launch_resize(hipStream_t s, uint8_t* pyr, const PyrDesc& P, int level, const int2* xtab,

@@ -144,7 +144,7 @@ vslam_status vslam_extractor::init(const vslam_fe_params* p, int w, int h, int b
     // FAST cell grid (src/FeatureExtractor.cpp:540-560)
     F.minXY = p->edge_threshold - 3;
     F.edge3 = p->edge_threshold - 3;
-    int cells = 0, cap = 1;
+    int cells = 0, cap = 1, tRows = 8, tCols = 8;
     for (int l = 0; l < nLevels; l++) {
         const int maxX = P.w[l] - F.edge3, maxY = P.h[l] - F.edge3;
         const int wid = maxX - F.minXY, hig = maxY - F.minXY;
@@ -159,7 +159,10 @@ vslam_status vslam_extractor::init(const vslam_fe_params* p, int w, int h, int b
         F.cellBase[l] = cells;
         cells += nC * nR;
         cap = std::max(cap, ((F.gridW[l] + 1) / 2) * ((F.gridH[l] + 1) / 2));
+        tRows = std::max(tRows, F.gridH[l] + 6); tCols = std::max(tCols, F.gridW[l] + 6);
     }
+    F.tileRows = tRows;
+    F.tilePitch = align_up(tCols + 3, 4);      // (+3: the tile starts at the aligned column left of the cell)
     F.cellBase[nLevels] = cells;
     for (int l = nLevels + 1; l <= MAX_LEVELS; l++) F.cellBase[l] = cells;
     F.cellCap = cap;   // strict 3x3 maxima: at most one per 2x2 block
