@@ -1,0 +1,29 @@
+#!/bin/bash
+# One measurement set for profiles/: bench lines, kernel stats, PMC passes.  usage (on the GPU box, repo root): tools/measure_set.sh r02_a
+set -o pipefail
+TAG=${1:-r02_x}
+OUT=$PWD/gpurun_out/$TAG
+mkdir -p $OUT
+REPO=$PWD
+PROF_SHAPE="--sessions 32 --lanes 32"      # under rocprofv3: one lockstep group (the tool has crashed inside hipLaunchKernel with 8+ launching threads)
+if [ -z "$SKIP_BENCH" ]; then
+python3 bench.py > $OUT/${TAG}_c2_bench.json 2> $OUT/c2.err || exit 1
+echo "c2 bench done"; cut -c1-160 $OUT/${TAG}_c2_bench.json
+python3 bench.py --config c3 > $OUT/${TAG}_c3_bench.json 2> $OUT/c3.err || exit 1
+echo "c3 bench done"
+python3 bench.py --host-images --no-cpu-baseline --no-latency-line > $OUT/${TAG}_c2_bench_host_images.json 2> $OUT/hi.err || exit 1
+echo "host-images bench done"
+python3 bench.py --no-cpu-baseline --no-latency-line --steps 100 --sweep 1x0,1x1,2x2,4x4,8x8,16x16,32x32,64x32,96x32,128x32 > $OUT/${TAG}_c2_sweep.json 2> $OUT/sw.err || exit 1
+echo "sweep done"
+fi
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 $REPO/bench.py --no-cpu-baseline --no-latency-line --steps 100 --warmup 10 $PROF_SHAPE > $OUT/${TAG}_c2_bench_under_rocprof.json 2> $OUT/kt.err || exit 1
+cp $OUT/kt/kt_kernel_stats.csv $OUT/${TAG}_c2_kernel_stats.csv
+echo "kernel trace done"
+for C in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CYCLES SQ_WAVES"; do
+  N=$(echo $C | cut -d' ' -f1)
+  timeout -k 10 500 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$N -o p -- python3 $REPO/bench.py --no-cpu-baseline --no-latency-line --steps 60 --warmup 10 $PROF_SHAPE > $OUT/pmc_$N.json 2> $OUT/pmc_$N.err || exit 1
+  echo "pmc $N done"
+done
+cd $REPO
+python3 tools/pmc_summary.py $OUT/${TAG}_pmc_summary.json $OUT/pmc_*/p_counter_collection.csv
