@@ -305,9 +305,9 @@ class BaResult(C.Structure):
                 ("n_landmarks", C.c_int64), ("n_free_kf", C.c_int64), ("sum_k2", C.c_int64)]
 
 
-def local_ba(rig, sigma_factor, inv_sigma_factor, prob, device=0, comm=None):
-    """LocalMapper::localBA numerical core through the C ABI."""
-    L = lib()
+def ba_problem_structs(rig, sigma_factor, inv_sigma_factor, prob):
+    """(vslam_ba_problem, vslam_ba_result, keep) for a flattened problem dict; keep["read"]() turns the filled result into the
+    dict local_ba returns (keep also holds the arrays the structs point into)."""
     kfPose = np.ascontiguousarray(prob["kf_pose"], np.float64).reshape(-1, 16)
     kfId = np.ascontiguousarray(prob["kf_id"], np.int64)
     kfFixed = np.ascontiguousarray(prob["kf_fixed"], np.uint8); kfLocal = np.ascontiguousarray(prob["kf_local"], np.uint8)
@@ -329,13 +329,23 @@ def local_ba(rig, sigma_factor, inv_sigma_factor, prob, device=0, comm=None):
     wrong = np.zeros(max(len(pk), 1), np.uint8); wrong1 = np.zeros(max(len(pk), 1), np.uint8)
     R = BaResult()
     R.kf_pose_wc, R.lm_xyz, R.pair_wrong, R.pair_wrong_pass1 = _p(kfOut), _p(lmOut), _p(wrong), _p(wrong1)
-    _chk(L.vslam_local_ba(C.byref(P), C.byref(R), device, comm.h if comm is not None else None))
-    reps = [dict(iterations=R.report[s].iterations, inner=R.report[s].inner_iterations,
-                 initialError=R.report[s].initial_error, finalError=R.report[s].final_error, lam=R.report[s].lam)
-            for s in range(2)]
-    return dict(kf_pose=kfOut.reshape(-1, 4, 4), lm=lmOut[:len(lm)], pair_wrong=wrong[:len(pk)],
-                pair_wrong1=wrong1[:len(pk)], reports=reps, residuals=R.n_residuals, landmarks=R.n_landmarks,
-                free_kf=R.n_free_kf, sum_k2=R.sum_k2)
+
+    def read():
+        reps = [dict(iterations=R.report[s].iterations, inner=R.report[s].inner_iterations,
+                     initialError=R.report[s].initial_error, finalError=R.report[s].final_error, lam=R.report[s].lam)
+                for s in range(2)]
+        return dict(kf_pose=kfOut.reshape(-1, 4, 4), lm=lmOut[:len(lm)], pair_wrong=wrong[:len(pk)],
+                    pair_wrong1=wrong1[:len(pk)], reports=reps, residuals=R.n_residuals, landmarks=R.n_landmarks,
+                    free_kf=R.n_free_kf, sum_k2=R.sum_k2)
+    keep = dict(arrays=[kfPose, kfId, kfFixed, kfLocal, lm, pk, pl, pf, puv, poct, sf, isf, kfOut, lmOut, wrong, wrong1], read=read)
+    return P, R, keep
+
+
+def local_ba(rig, sigma_factor, inv_sigma_factor, prob, device=0, comm=None):
+    """LocalMapper::localBA numerical core through the C ABI."""
+    P, R, keep = ba_problem_structs(rig, sigma_factor, inv_sigma_factor, prob)
+    _chk(lib().vslam_local_ba(C.byref(P), C.byref(R), device, comm.h if comm is not None else None))
+    return keep["read"]()
 
 
 def local_ba_timings():

@@ -1,6 +1,8 @@
 // vslam_adapter.hpp — header-only C++ shim that puts the reference's class surfaces
-// (include/FeatureExtractor.h:53-98, include/FeatureMatcher.h:22-63, include/OptimizationBA.h:30-87)
-// on top of the C ABI in vslam_hip.h, so System.cpp keeps constructing and calling the same names.
+// (include/FeatureExtractor.h:53-98, include/FeatureMatcher.h:22-63, include/FeatureTracker.h:85-96,
+// include/OptimizationBA.h:54-87, include/Map.h) on top of the C ABI in vslam_hip.h, so System.cpp keeps constructing
+// and calling the same names.  tests/native/adapter_link.cpp is a g++ translation unit that uses every class below
+// and is linked against libvslam_hip.so (CPU test: it links; GPU test: its results equal the ctypes path's).
 //
 // Two flavours:
 //   * default              : POD containers (std::vector<vslam_keypoint>, std::vector<uint8_t>) — compiles
@@ -148,6 +150,95 @@ class FeatureMatcher {
 inline void localBA(const vslam_ba_problem& problem, vslam_ba_result& result, int device = 0,
                     const vslam_comm* comm = nullptr) {
     vs_check(vslam_local_ba(&problem, &result, device, comm), "vslam_local_ba");
+}
+
+// IMUData (include/Camera.h): the samples between the previous frame and this one
+struct IMUData {
+    std::vector<double> mvAccelBuffer, mvGyroBuffer;     // n x 3 each
+    std::vector<double> mvTimestamps;                    // n, nanoseconds
+    vslam_imu_bucket bucket() const {
+        vslam_imu_bucket b{};
+        b.n = (int32_t)mvTimestamps.size(); b.acceleration = mvAccelBuffer.data(); b.angular_velocity = mvGyroBuffer.data();
+        b.timestamps_ns = mvTimestamps.data();
+        return b;
+    }
+};
+
+// Map (include/Map.h) + the state FeatureTracker and LocalMapper share: here ONE device-side session (vslam_system) holds
+// the map, the tracker state and - with local_mapping = 2 - the optimizer thread, so the two class shims below are
+// views of the same handle, the way the reference's objects share std::shared_ptr<Map>.
+class Map {
+  public:
+    explicit Map(const vslam_system_config& cfg) { vs_check(vslam_system_create(&cfg, &h_), "vslam_system_create"); }
+    ~Map() { vslam_system_destroy(h_); }
+    Map(const Map&) = delete;
+    Map& operator=(const Map&) = delete;
+    vslam_system* handle() const { return h_; }
+    // sizes of keyFrames / mapPoints / activeMapPoints, frames tracked
+    void counts(int& keyFrames, int& mapPoints, int& activeMapPoints, int& frames) const {
+        int32_t a = 0, b = 0, c = 0, d = 0;
+        vs_check(vslam_system_counts(h_, &a, &b, &c, &d), "vslam_system_counts");
+        keyFrames = a; mapPoints = b; activeMapPoints = c; frames = d;
+    }
+
+  private:
+    vslam_system* h_ = nullptr;
+};
+
+// FeatureTracker (include/FeatureTracker.h:85-96)
+class FeatureTracker {
+  public:
+    explicit FeatureTracker(std::shared_ptr<Map> _map) : map(std::move(_map)) {}
+    std::shared_ptr<Map> map;
+    double lastPose[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};    // zedPtr->mCameraPose->pose after the last frame
+    vslam_frame_report lastReport{};
+
+    // TrackImage (include/FeatureTracker.h:90): u8 row-major rectified images; IMUDataptr as in the reference (nullptr
+    // in stereo-only mode).  Extraction, stereo match, projection matching, the pose solves, the keyframe rule and
+    // insertKeyFrame all happen behind this call; local mapping follows on the optimizer thread (or inline).
+    void TrackImage(const uint8_t* leftRect, const uint8_t* rightRect, int stride, const int frameNumb,
+                    std::shared_ptr<IMUData> IMUDataptr = nullptr, bool onDevice = false) {
+        vslam_imu_bucket b{};
+        if (IMUDataptr) b = IMUDataptr->bucket();
+        vs_check(vslam_system_track_stereo(map->handle(), leftRect, rightRect, stride, onDevice ? 1 : 0, frameNumb,
+                                           IMUDataptr ? &b : nullptr, lastPose, &lastReport), "vslam_system_track_stereo");
+    }
+#ifdef VSLAM_WITH_OPENCV
+    void TrackImage(const cv::Mat& leftRect, const cv::Mat& rightRect, const int frameNumb, std::shared_ptr<IMUData> IMUDataptr = nullptr) {
+        TrackImage(leftRect.ptr<uint8_t>(), rightRect.ptr<uint8_t>(), (int)leftRect.step, frameNumb, IMUDataptr);
+    }
+#endif
+    // matchesIdxs / MPsOutliers of the last tracked frame (FeatureTracker's locals that System.cpp draws)
+    int lastMatches(std::vector<int32_t>& matchesIdxs, std::vector<uint8_t>& MPsOutliers) const {
+        int32_t n = 0;
+        matchesIdxs.assign((size_t)2 * 65536, -1); MPsOutliers.assign(65536, 0);
+        vs_check(vslam_system_last_frame(map->handle(), 65536, &n, matchesIdxs.data(), MPsOutliers.data()), "vslam_system_last_frame");
+        matchesIdxs.resize((size_t)2 * n); MPsOutliers.resize(n);
+        return n;
+    }
+};
+
+// LocalMapper (include/OptimizationBA.h:54-87)
+class LocalMapper {
+  public:
+    explicit LocalMapper(std::shared_ptr<Map> _map) : map(std::move(_map)) {}
+    std::shared_ptr<Map> map;
+    // beginLocalMapping (:87): the reference starts its loop on a std::thread; the session already runs that loop on its
+    // own thread (vslam_system_config::local_mapping = 2) - this waits until it is idle and reports its failure, if any
+    void beginLocalMapping() { vs_check(vslam_system_wait_mapping(map->handle()), "vslam_system_wait_mapping"); }
+    // findNewPoints (:60) / localBA (:75) on flattened problems, for callers that keep their own Map
+    void findNewPoints(const vslam_new_points_problem& problem, vslam_new_points_result& result, int device = 0) {
+        vs_check(vslam_find_new_points(&problem, &result, device), "vslam_find_new_points");
+    }
+    void localBA(const vslam_ba_problem& problem, vslam_ba_result& result, int device = 0, const vslam_comm* comm = nullptr) {
+        vs_check(vslam_local_ba(&problem, &result, device, comm), "vslam_local_ba");
+    }
+};
+
+// VSlamSystem::saveTrajectoryAndPosition (src/System.cpp:87-124)
+inline void saveTrajectoryAndPosition(const Map& map, const std::string& filepath, const std::string& filepathPosition) {
+    vs_check(vslam_system_save_trajectory(map.handle(), filepath.c_str(), filepathPosition.empty() ? nullptr : filepathPosition.c_str()),
+             "vslam_system_save_trajectory");
 }
 
 }  // namespace GTSAM_VIOSLAM_HIP

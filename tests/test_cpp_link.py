@@ -1,0 +1,74 @@
+"""The boundary linked from C++: tests/native/adapter_link.cpp uses the reference's class names through
+include/vslam_adapter.hpp (FeatureExtractor, FeatureMatcher, Map, FeatureTracker, LocalMapper) and is built by g++
+against libvslam_hip.so.  CPU: it compiles and links (shared wrapper and stand-alone program), every undefined
+vslam_* symbol resolved by the library.  GPU: adapter_run() reproduces the ctypes path on the same frames."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "native", "adapter_link.cpp")
+LIBDIR = os.path.join(ROOT, "gtsam-vslam_amd")
+
+
+def _build(tmp, shared):
+    out = os.path.join(str(tmp), "libadapter_link.so" if shared else "adapter_link")
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), SRC, "-o", out,
+           "-L", LIBDIR, "-lvslam_hip", "-Wl,-rpath," + LIBDIR]
+    cmd += ["-shared", "-fPIC"] if shared else ["-DVSLAM_LINK_MAIN"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    return out
+
+
+def test_adapter_compiles_and_links_against_the_library(capi, tmp_path):
+    for shared in (True, False):
+        out = _build(tmp_path, shared)
+        nm = subprocess.run(["nm", "-D", "--undefined-only", out], stdout=subprocess.PIPE, text=True).stdout
+        used = sorted({l.split()[-1] for l in nm.splitlines() if " vslam_" in l or l.strip().startswith("U vslam_")})
+        assert {"vslam_system_track_stereo", "vslam_extractor_create", "vslam_stereo_match", "vslam_local_ba"} <= set(used), used
+        lib = subprocess.run(["nm", "-D", "--defined-only", os.path.join(LIBDIR, "libvslam_hip.so")], stdout=subprocess.PIPE, text=True).stdout
+        defined = {l.split()[-1] for l in lib.splitlines()}
+        assert set(used) <= defined, sorted(set(used) - defined)
+        ldd = subprocess.run(["ldd", out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout
+        assert "libvslam_hip.so" in ldd and "not found" not in ldd.split("libvslam_hip.so")[1].splitlines()[0], ldd
+
+
+@pytest.mark.gpu
+def test_adapter_run_matches_ctypes_path(oracle, capi, tmp_path):
+    import synth
+    so = _build(tmp_path, True)
+    L = C.CDLL(so)
+    rig = synth.RIGS["euroc"]
+    w, h = rig["w"], rig["h"]
+    fr = list(range(0, 40, 2))
+    frames = np.stack([np.stack(synth.stereo_frame(f, "euroc")[:2]) for f in fr]).astype(np.uint8)     # n x 2 x h x w
+    T0 = np.ascontiguousarray(synth.pose_at(fr[0], rig["fps"]))
+    # a flattened BA problem for LocalMapper::localBA
+    prob = synth.make_ba_problem(n_local=6, n_fixed=2, n_lm=800, seed=5)
+    ex = oracle.Extractor(1500)
+    ref_ba = capi.local_ba(prob["rig"], ex.sigmaFactor, ex.InvSigmaFactor, prob)
+    P, R, keep = capi.ba_problem_structs(prob["rig"], ex.sigmaFactor, ex.InvSigmaFactor, prob)
+    out = np.zeros((len(fr), 20)); st = np.zeros(3, np.int32)
+    crig = capi.make_rig(rig)
+    L.adapter_run.restype = C.c_int
+    kf = L.adapter_run(frames.ctypes.data_as(C.c_void_p), len(fr), w, h, C.byref(crig), 1500, T0.ctypes.data_as(C.c_void_p),
+                       out.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p), C.byref(P), C.byref(R))
+    assert kf >= 2
+    # the ctypes path on the same frames
+    s = capi.System(rig, 1500, T0=T0, local_mapping=1)
+    for n in range(len(fr)):
+        Pg, rep = s.track(frames[n, 0], frames[n, 1], n)
+        assert np.abs(Pg.reshape(16) - out[n, :16]).max() <= 1e-9, n      # (bit-equal until a local BA: its LDS atomics sum in any order)
+        assert (rep["n_inliers"], rep["keyframe_inserted"], rep["mapping_ran"], rep["n_map_points"]) == tuple(int(v) for v in out[n, 16:20]), n
+    assert s.counts()["keyframes"] == kf
+    fe = capi.Extractor(w, h, 1500, batch=2)
+    m = capi.Matcher(rig, fe, 0, fe, 1)
+    fe.set_image(0, frames[0, 0]); fe.set_image(1, frames[0, 1]); fe.run(); m.stereo_match()
+    nL, nR = len(fe.fetch(0)[0]), len(fe.fetch(1)[0])
+    sf = m.stereo_fetch(nL, nR)
+    assert (nL, nR, int((sf["rightIdxs"] >= 0).sum())) == tuple(st)
+    got = keep["read"]()
+    assert np.abs(got["kf_pose"] - ref_ba["kf_pose"]).max() < 1e-10 and np.array_equal(got["pair_wrong"], ref_ba["pair_wrong"])
