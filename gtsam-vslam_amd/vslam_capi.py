@@ -827,6 +827,96 @@ class System:
         _chk(self.L.vslam_system_save_trajectory(self.h_sys, path.encode(), path_positions.encode() if path_positions else None))
 
 
+# ---- N3: rectification and dataset bookkeeping -----------------------------------------------------------------------
+class Rectifier:
+    """vslam_rectifier: initUndistortRectifyMap once, remap(INTER_LINEAR) per frame (device images)."""
+
+    def __init__(self, K, D, R, Pnew, src_size, size, device=0):
+        self.L = lib()
+        K = np.ascontiguousarray(K, np.float64).reshape(9); Pn = np.ascontiguousarray(Pnew, np.float64).reshape(9)
+        Dv = np.ascontiguousarray(D if D is not None else [], np.float64).ravel()
+        Rv = np.ascontiguousarray(R, np.float64).reshape(9) if R is not None else None
+        self.w, self.h = size
+        self.sw, self.sh = src_size
+        self.h_r = C.c_void_p()
+        _chk(self.L.vslam_rectifier_create(_p(K), _p(Dv) if len(Dv) else None, len(Dv), _p(Rv) if Rv is not None else None, _p(Pn),
+                                           self.sw, self.sh, self.w, self.h, device, C.byref(self.h_r)))
+
+    def maps(self):
+        mx = np.zeros((self.h, self.w), np.float32); my = np.zeros((self.h, self.w), np.float32)
+        _chk(self.L.vslam_rectifier_maps(self.h_r, _p(mx), _p(my)))
+        return mx, my
+
+    def remap(self, images):
+        """host u8 images (sh x sw each) -> list of rectified host images (h x w)"""
+        n = len(images)
+        src = [np.ascontiguousarray(i, np.uint8) for i in images]
+        dst = [np.zeros((self.h, self.w), np.uint8) for _ in range(n)]
+        sp = (C.c_void_p * n)(*[a.ctypes.data for a in src]); dp = (C.c_void_p * n)(*[a.ctypes.data for a in dst])
+        _chk(self.L.vslam_rectifier_remap_host(self.h_r, sp, self.sw, dp, self.w, n))
+        return dst
+
+    def remap_device(self, src_ptrs, src_stride, dst_ptrs, dst_stride):
+        n = len(src_ptrs)
+        sp = (C.c_void_p * n)(*src_ptrs); dp = (C.c_void_p * n)(*dst_ptrs)
+        _chk(self.L.vslam_rectifier_remap(self.h_r, sp, int(src_stride), dp, int(dst_stride), n))
+
+    def close(self):
+        if self.h_r:
+            self.L.vslam_rectifier_destroy(self.h_r)
+            self.h_r = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Dataset:
+    """vslam_dataset: EuRoC (kind 0) / KITTI (kind 1) frame lists, IMU buckets per frame, gravity guess."""
+
+    def __init__(self, kind, images_path, imu_path=None):
+        self.L = lib()
+        self.h_d = C.c_void_p()
+        _chk(self.L.vslam_dataset_open(int(kind), images_path.encode(), imu_path.encode() if imu_path else None, C.byref(self.h_d)))
+
+    def __len__(self):
+        return self.L.vslam_dataset_frames(self.h_d)
+
+    def frame(self, i):
+        l = C.c_char_p(); r = C.c_char_p(); t = C.c_double()
+        _chk(self.L.vslam_dataset_frame(self.h_d, i, C.byref(l), C.byref(r), C.byref(t)))
+        return l.value.decode(), r.value.decode(), t.value
+
+    def imu_bucket(self, i):
+        b = ImuBucket()
+        _chk(self.L.vslam_dataset_imu_bucket(self.h_d, i, C.byref(b)))
+        n = b.n
+        if n == 0:
+            return np.zeros((0, 3)), np.zeros((0, 3)), np.zeros(0)
+        acc = np.ctypeslib.as_array(C.cast(b.acceleration, C.POINTER(C.c_double)), (n, 3)).copy()
+        gyr = np.ctypeslib.as_array(C.cast(b.angular_velocity, C.POINTER(C.c_double)), (n, 3)).copy()
+        ts = np.ctypeslib.as_array(C.cast(b.timestamps_ns, C.POINTER(C.c_double)), (n,)).copy()
+        return acc, gyr, ts
+
+    def gravity(self):
+        v = C.c_int32(); g = (C.c_double * 3)()
+        _chk(self.L.vslam_dataset_gravity(self.h_d, C.byref(v), g))
+        return bool(v.value), tuple(g)
+
+    def close(self):
+        if self.h_d:
+            self.L.vslam_dataset_close(self.h_d)
+            self.h_d = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ---- vslam_batch: B lanes in lockstep, one launch per stage for all lanes --------------------------------------------------
 def _report_dict(rep):
     d = {f[0]: getattr(rep, f[0]) for f in FrameReport._fields_ if f[0] != "ba_report"}

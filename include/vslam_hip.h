@@ -689,6 +689,36 @@ vslam_status vslam_fleet_system(vslam_fleet* fleet, int32_t session, vslam_syste
 vslam_status vslam_fleet_set_sampling(vslam_fleet* fleet, int32_t every);
 vslam_status vslam_fleet_timings(vslam_fleet* fleet, const char** names, float* ms, int32_t cap, int32_t* n_out, int64_t* counts3);
 
+/* ---------------------------------------------------------------------------
+ * N3 - the step before the hot path in the reference's frame loop (src/VIOSlam.cpp:278-306) and the dataset bookkeeping
+ * of its main() (:23-139, 176-272).
+ * vslam_rectifier: cv::initUndistortRectifyMap(K, D, R, P[0:3,0:3], size, CV_32F) once, then cv::remap(INTER_LINEAR,
+ * BORDER_CONSTANT 0) of n gray images per launch.  K, R, P_new: 3x3 row-major (R NULL = identity); D: n_dist of
+ * (k1 k2 p1 p2 k3 k4 k5 k6 s1 s2 s3 s4).  OpenCV's published fixed-point semantics; parity against OpenCV itself unpinned.
+ * ------------------------------------------------------------------------- */
+typedef struct vslam_rectifier vslam_rectifier;
+vslam_status vslam_rectifier_create(const double* K, const double* D, int32_t n_dist, const double* R, const double* P_new,
+                                    int32_t src_width, int32_t src_height, int32_t width, int32_t height, int32_t device,
+                                    vslam_rectifier** out);
+void vslam_rectifier_destroy(vslam_rectifier* r);
+vslam_status vslam_rectifier_maps(vslam_rectifier* r, float* map_x, float* map_y);           /* test tap: the CV_32F maps */
+/* src / dst: n DEVICE image pointers each (u8, strides in bytes); synchronous */
+vslam_status vslam_rectifier_remap(vslam_rectifier* r, const uint8_t* const* src, int32_t src_stride, uint8_t* const* dst,
+                                   int32_t dst_stride, int32_t n);
+/* the same with HOST images (upload, one launch, download) */
+vslam_status vslam_rectifier_remap_host(vslam_rectifier* r, const uint8_t* const* src, int32_t src_stride, uint8_t* const* dst,
+                                        int32_t dst_stride, int32_t n);
+
+/* vslam_dataset: EuRoC (kind 0: <images_path>cam0/data.csv + cam0/data/, cam1/data/) or KITTI (kind 1: image_0/, image_1/,
+ * names by .png count); imu_path: directory with data.csv (timestamp, w_xyz, a_xyz) or NULL.  Host only. */
+typedef struct vslam_dataset vslam_dataset;
+vslam_status vslam_dataset_open(int32_t kind, const char* images_path, const char* imu_path, vslam_dataset** out);
+void vslam_dataset_close(vslam_dataset* d);
+int32_t vslam_dataset_frames(const vslam_dataset* d);
+vslam_status vslam_dataset_frame(const vslam_dataset* d, int32_t i, const char** left_path, const char** right_path, double* timestamp);
+vslam_status vslam_dataset_imu_bucket(const vslam_dataset* d, int32_t i, vslam_imu_bucket* bucket);
+vslam_status vslam_dataset_gravity(const vslam_dataset* d, int32_t* imu_valid, double* gravity3);
+
 /* The library caches device scratch memory, a stream and the local-BA workspace per calling thread.  Its own threads free
  * theirs; a thread of the caller that used vslam_local_ba / the new-point functions / vslam_system_* may call this before
  * it ends (otherwise the cache lives until the process exits - nothing is freed from thread-exit hooks, where profiler
