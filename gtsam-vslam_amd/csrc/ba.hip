@@ -1680,7 +1680,11 @@ __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_back(BaDev D, int ma
             }
             if (act && lane < 3) {
                 const double u[3] = {h[6] - t[0], h[7] - t[1], h[8] - t[2]};
-                const double dl = Hi[3 * lane] * u[0] + Hi[3 * lane + 1] * u[1] + Hi[3 * lane + 2] * u[2];
+                // (row `lane` of Hi picked by selects: indexing the register array by the lane would put it in scratch)
+                const double h0 = lane == 0 ? Hi[0] : (lane == 1 ? Hi[3] : Hi[6]);
+                const double h1 = lane == 0 ? Hi[1] : (lane == 1 ? Hi[4] : Hi[7]);
+                const double h2 = lane == 0 ? Hi[2] : (lane == 1 ? Hi[5] : Hi[8]);
+                const double dl = h0 * u[0] + h1 * u[1] + h2 * u[2];
                 D.dL[(size_t)k * D.dLStride + 3 * (size_t)lp + lane] = dl;
                 double* lmT = D.lmBase + (size_t)ba_slot(sel, c0 + k, D.NB) * D.lmStride;
                 lmT[3 * (size_t)l + lane] = D.lmCur[3 * (size_t)l + lane] + dl;
@@ -2486,6 +2490,7 @@ vslam_status vslam_local_ba_set_timing(int32_t on) {
     g_baTimer.enabled = on != 0;
     return VSLAM_OK;
 }
+int32_t vslam_local_ba_get_timing(void) { return g_baTimer.enabled ? 1 : 0; }
 
 vslam_status vslam_ba_refresh_depth(const vslam_rig* rig, int32_t n_kf, const double* kf_pose_wc, int32_t n_lm,
                                     const double* lm_xyz, const uint8_t* lm_outlier, int32_t n_pairs,

@@ -134,7 +134,11 @@ __global__ __launch_bounds__(256) void k_np_match(NpArgs A) {
 #pragma unroll
         for (int q = 0; q < 8; q++) md[q] = pd[q];
     }
-    ProjArgs S{};
+    // scan_side indexes the level table dynamically: a per-thread ProjArgs would live in scratch, so the wave's copy sits in
+    // LDS (every lane stores the same values; a wave's LDS accesses are ordered)
+    __shared__ ProjArgs sS[4];
+    ProjArgs& S = sS[threadIdx.x >> 6];
+    S.Mdev = nullptr; S.gate = nullptr; S.gateMin = 0; S.mpv = nullptr; S.M = 0; S.rightIdxs = nullptr; S.leftIdxs = nullptr;
     S.kps[0] = K.kpsL; S.kps[1] = K.kpsR; S.desc[0] = K.descL; S.desc[1] = K.descR; S.n[0] = K.nL; S.n[1] = K.nR;
     S.rad = 4.f;
 #pragma unroll

@@ -728,8 +728,10 @@ vslam_status vslam_system::local_ba(const std::vector<int>& actKeyF) {
     std::vector<uint8_t> wrong(std::max(NP, 1), 0), wrong1(std::max(NP, 1), 0);
     vslam_ba_result Rr{};
     Rr.kf_pose_wc = kfOut.data(); Rr.lm_xyz = lmOut.data(); Rr.pair_wrong = wrong.data(); Rr.pair_wrong_pass1 = wrong1.data();
+    const int timingBefore = vslam_local_ba_get_timing();      // (thread-scoped switch: left as the caller had it)
     vslam_local_ba_set_timing(timingOn.load());
-    VS_CHECK(vslam_local_ba(&P, &Rr, cfg.device, nullptr));
+    const vslam_status baSt = vslam_local_ba(&P, &Rr, cfg.device, nullptr);
+    if (baSt != VSLAM_OK) { vslam_local_ba_set_timing(timingBefore); return baSt; }
     if (timingOn.load()) {
         const char* nm[32]; float ms[32]; int n = 0;
         if (vslam_local_ba_timings(nm, ms, 32, &n) == VSLAM_OK) {
@@ -743,6 +745,7 @@ vslam_status vslam_system::local_ba(const std::vector<int>& actKeyF) {
             }
         }
     }
+    vslam_local_ba_set_timing(timingBefore);
     // ---- write-back (:875-938) -----------------------------------------------------------------------------------------
     {
         std::lock_guard<std::mutex> lk(mapMutex);

@@ -390,6 +390,7 @@ vslam_status vslam_local_ba(const vslam_ba_problem* problem, vslam_ba_result* re
 vslam_status vslam_local_ba_timings(const char** names, float* ms, int32_t cap, int32_t* n_out);
 /* event timing on (default) / off for the following vslam_local_ba calls of the calling thread */
 vslam_status vslam_local_ba_set_timing(int32_t on);
+int32_t vslam_local_ba_get_timing(void);      /* the calling thread's switch */
 /* Scheduling knobs of the single-GPU path.  They do not change the algorithm (same LM trajectory; values equal up
  * to the summation order of fp64 atomics, which already varies from run to run):
  *   candidates (1..4, <= 0: default 4)  damping values lambda, 10 lambda, ... evaluated per trial round and then
