@@ -77,7 +77,11 @@ struct vslam_batch {
     vslam_status ensure_up(size_t bytes);
     vslam_status ensure_dn(size_t bytes);
     vslam_status step(const uint8_t* const* L, const uint8_t* const* R, int stride, bool onDevice, const int* frames,
-                      const vslam_imu_bucket* imu, const uint8_t* mask, double* T_wc_out, vslam_frame_report* reps);
+                      const vslam_imu_bucket* imu, const uint8_t* mask, double* T_wc_out, vslam_frame_report* reps,
+                      const uint8_t* const* nextL = nullptr, const uint8_t* const* nextR = nullptr, const uint8_t* nextMask = nullptr);
+    // images of the NEXT step whose extraction was enqueued at the end of the previous one (prefetch)
+    std::vector<const uint8_t*> prefetched;
+    vslam_status enqueue_extraction(const uint8_t* const* L, const uint8_t* const* R, const uint8_t* mask, int stride, bool onDevice);
     static void submit_mapping(void* self, vslam_system* s) {
         vslam_batch* b = (vslam_batch*)self;
         { std::lock_guard<std::mutex> lk(b->mqMu); b->mapQueue.push_back(s); }
@@ -113,6 +117,7 @@ vslam_status vslam_batch::init(const vslam_system_config* cfgs, int n, int hostT
     VS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     timer.stream = stream; timer.multi = true;
     VS_CHECK(vslam_extractor_create(&cfgs[0].fe, cfgs[0].rig.width, cfgs[0].rig.height, 2 * B, device, &fe));
+    VS_CHECK(fe->enable_double_output());
     VS_HIP(hipMalloc(&d_res, (size_t)B * 64 * sizeof(double)));
     VS_HIP(vslam::memset_sync(d_res, 0, (size_t)B * 64 * sizeof(double)));
     VS_HIP(hipHostMalloc(&h_res, (size_t)B * 64 * sizeof(double), hipHostMallocDefault));
@@ -209,8 +214,26 @@ vslam_status vslam_batch::ensure_dn(size_t bytes) {
         if (s_ != VSLAM_OK) { q.st = s_; q.failed = true; snprintf(q.err, sizeof(q.err), "%s", vslam_last_error()); return; } \
     } while (0)
 
+// level 0 of every active lane's pair + the whole extraction, on the extractor's stream
+vslam_status vslam_batch::enqueue_extraction(const uint8_t* const* L, const uint8_t* const* R, const uint8_t* mask, int stride, bool onDevice) {
+    if (onDevice) {
+        imgPtrs.assign((size_t)2 * B, nullptr);
+        for (int b = 0; b < B; b++) if (!mask || mask[b]) { imgPtrs[2 * b] = L[b]; imgPtrs[2 * b + 1] = R[b]; }
+        VS_CHECK(fe->set_images_device(imgPtrs.data(), stride));
+    } else {
+        for (int b = 0; b < B; b++) {
+            if (mask && !mask[b]) continue;
+            VS_CHECK(fe->set_image_async(2 * b, L[b], stride, false));
+            VS_CHECK(fe->set_image_async(2 * b + 1, R[b], stride, false));
+        }
+        VS_HIP(hipStreamSynchronize(fe->stream));      // callers may reuse their buffers
+    }
+    return fe->run();
+}
+
 vslam_status vslam_batch::step(const uint8_t* const* L, const uint8_t* const* R, int stride, bool onDevice, const int* frames,
-                               const vslam_imu_bucket* imu, const uint8_t* mask, double* T_wc_out, vslam_frame_report* reps) {
+                               const vslam_imu_bucket* imu, const uint8_t* mask, double* T_wc_out, vslam_frame_report* reps,
+                               const uint8_t* const* nextL, const uint8_t* const* nextR, const uint8_t* nextMask) {
     if (!L || !R || !frames || !T_wc_out) return VSLAM_ERR_INVALID;
     VS_HIP(hipSetDevice(device));
     using clk = std::chrono::steady_clock;
@@ -245,20 +268,19 @@ vslam_status vslam_batch::step(const uint8_t* const* L, const uint8_t* const* R,
     VS_CHECK(first_error());
     lap(0);
 
-    // ---- device: images, extraction ------------------------------------------------------------------------------------------
-    if (onDevice) {
-        imgPtrs.assign((size_t)2 * B, nullptr);
-        for (int b = 0; b < B; b++) if (ls[b].on) { imgPtrs[2 * b] = L[b]; imgPtrs[2 * b + 1] = R[b]; }
-        VS_CHECK(fe->set_images_device(imgPtrs.data(), stride));
-    } else {
-        for (int b = 0; b < B; b++) {
-            if (!ls[b].on) continue;
-            VS_CHECK(fe->set_image_async(2 * b, L[b], stride, false));
-            VS_CHECK(fe->set_image_async(2 * b + 1, R[b], stride, false));
+    // ---- device: images, extraction (already in flight when the previous step prefetched exactly these images) -----------
+    {
+        bool hit = onDevice && prefetched.size() == (size_t)2 * B;
+        for (int b = 0; b < B && hit; b++) {
+            const bool on = ls[b].on;
+            hit = prefetched[2 * b] == (on ? L[b] : nullptr) && prefetched[2 * b + 1] == (on ? R[b] : nullptr);
         }
-        VS_HIP(hipStreamSynchronize(fe->stream));      // callers may reuse their buffers
+        prefetched.clear();
+        if (!hit) {
+            if (fe->countsPending) VS_CHECK(fe->wait_counts());      // (a prefetch for other images: let it finish first)
+            VS_CHECK(enqueue_extraction(L, R, mask, stride, onDevice));
+        }
     }
-    VS_CHECK(fe->run());
     lap(1);
 
     // ---- host, under the extraction: the upload block -----------------------------------------------------------------------
@@ -399,6 +421,13 @@ vslam_status vslam_batch::step(const uint8_t* const* L, const uint8_t* const* R,
     lap(3);
     VS_HIP(hipStreamSynchronize(stream));
     lap(4);
+    // ---- prefetch: the next frames' extraction runs under this step's host phases and the next step's begin ----------------
+    // (the extractor alternates between two output sets, so this frame's keys stay readable for keyframe insertion)
+    if (nextL && nextR && onDevice) {
+        VS_CHECK(enqueue_extraction(nextL, nextR, nextMask, stride, true));
+        prefetched.assign((size_t)2 * B, nullptr);
+        for (int b = 0; b < B; b++) if (!nextMask || nextMask[b]) { prefetched[2 * b] = nextL[b]; prefetched[2 * b + 1] = nextR[b]; }
+    }
 
     // ---- host: the reference's retry rule per lane (launches only for lanes whose first round failed) ------------------------
     std::vector<SysTrackState> st(B);
@@ -468,6 +497,14 @@ vslam_status vslam_batch_track_stereo(vslam_batch* b, const uint8_t* const* left
                                       const uint8_t* lane_mask, double* T_wc_out, vslam_frame_report* reports) {
     if (!b) return VSLAM_ERR_INVALID;
     return b->step(left, right, stride, on_device != 0, frame_numbers, imu, lane_mask, T_wc_out, reports);
+}
+
+vslam_status vslam_batch_track_stereo_prefetch(vslam_batch* b, const uint8_t* const* left, const uint8_t* const* right, int32_t stride,
+                                               const int32_t* frame_numbers, const vslam_imu_bucket* imu, const uint8_t* lane_mask,
+                                               double* T_wc_out, vslam_frame_report* reports, const uint8_t* const* next_left,
+                                               const uint8_t* const* next_right, const uint8_t* next_mask) {
+    if (!b) return VSLAM_ERR_INVALID;
+    return b->step(left, right, stride, true, frame_numbers, imu, lane_mask, T_wc_out, reports, next_left, next_right, next_mask);
 }
 
 vslam_system* vslam_batch_system(vslam_batch* b, int32_t lane) {

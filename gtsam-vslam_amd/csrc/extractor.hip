@@ -277,7 +277,9 @@ void vslam_extractor::release() {
     hipFree(d_pyr); hipFree(d_blur); hipFree(d_xtab); hipFree(d_ytab);
     hipFree(d_cellSlots); hipFree(d_cellCount); hipFree(d_cellOff);
     hipFree(d_cand); hipFree(d_levelCount);
-    hipFree(d_kept); hipFree(d_keptOff); hipFree(d_kps); hipFree(d_desc); hipFree(d_disc);
+    if (doubleOut) { hipFree(d_kpsBuf[0]); hipFree(d_kpsBuf[1]); hipFree(d_descBuf[0]); hipFree(d_descBuf[1]); }
+    else { hipFree(d_kps); hipFree(d_desc); }
+    hipFree(d_kept); hipFree(d_keptOff); hipFree(d_disc);
     hipFree(d_sscTmp); hipFree(d_sscPicks); hipFree(d_taskCount); hipFree(d_sscFlags); hipFree(d_sscGrid); hipFree(d_sscGridOff);
     d_sscGrid = nullptr; d_sscGridOff = nullptr; d_sscPicks = nullptr;
     if (h_counts) hipHostFree(h_counts);
@@ -320,6 +322,16 @@ vslam_status vslam_extractor::set_image_async(int idx, const void* src, int stri
     if (idx < 0 || idx >= nimg || !src || stride < width) { set_error("set_image: bad argument"); return VSLAM_ERR_INVALID; }
     VS_HIP(hipMemcpy2DAsync(d_pyr + (size_t)idx * P.imgStride + P.off[0], P.pitch[0], src, stride, width,
                             height, srcOnDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
+    return VSLAM_OK;
+}
+
+vslam_status vslam_extractor::enable_double_output() {
+    if (doubleOut) return VSLAM_OK;
+    VS_HIP(hipSetDevice(device));
+    d_kpsBuf[0] = d_kps; d_descBuf[0] = d_desc;
+    VS_HIP(hipMalloc(&d_kpsBuf[1], (size_t)nimg * keptCap * sizeof(vslam_keypoint)));
+    VS_HIP(hipMalloc(&d_descBuf[1], (size_t)nimg * keptCap * 32));
+    outSel = 0; doubleOut = true;
     return VSLAM_OK;
 }
 
@@ -417,6 +429,7 @@ vslam_status vslam_extractor::run() {
     launch_blur(stream, d_pyr, d_blur, P, B, nimg);
     timer.end(t);
     t = timer.begin("orient_desc");
+    if (doubleOut) { outSel ^= 1; d_kps = d_kpsBuf[outSel]; d_desc = d_descBuf[outSel]; }
     launch_orient_desc(stream, d_pyr, d_blur, P, T, d_kept, d_keptOff, keptCap, d_disc, ndisc, d_kps,
                        d_desc, keptCap, keptCap, nimg);
     timer.end(t);
@@ -442,6 +455,29 @@ int vslam::poison_byte() {
 extern "C" {
 
 void vslam_thread_release(void) { vslam::thread_release(); }
+
+// plain device buffers for callers without a HIP binding of their own (tests, tools): hipMalloc / hipMemcpy / hipFree
+vslam_status vslam_device_alloc(int32_t device, size_t bytes, void** out) {
+    if (!out || !bytes) return VSLAM_ERR_INVALID;
+    VS_HIP(hipSetDevice(device));
+    VS_HIP(hipMalloc(out, bytes));
+    return VSLAM_OK;
+}
+vslam_status vslam_device_upload(int32_t device, void* dst, const void* src, size_t bytes) {
+    if (!dst || !src) return VSLAM_ERR_INVALID;
+    VS_HIP(hipSetDevice(device));
+    VS_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return VSLAM_OK;
+}
+vslam_status vslam_device_download(int32_t device, void* dst, const void* src, size_t bytes) {
+    if (!dst || !src) return VSLAM_ERR_INVALID;
+    VS_HIP(hipSetDevice(device));
+    VS_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return VSLAM_OK;
+}
+void vslam_device_free(int32_t device, void* p) {
+    if (p && hipSetDevice(device) == hipSuccess) hipFree(p);
+}
 
 void vslam_debug_poison(int32_t byte) { g_poison.store(byte < 0 ? -1 : (byte & 0xff)); }
 

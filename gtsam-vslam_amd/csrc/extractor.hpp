@@ -47,8 +47,12 @@ struct vslam_extractor {
     int* d_keptOff = nullptr;
     int8_t* d_disc = nullptr;
     int ndisc = 0;
-    vslam_keypoint* d_kps = nullptr;  // nimg * keptCap
+    vslam_keypoint* d_kps = nullptr;  // nimg * keptCap   (the buffer the last run() wrote / is writing)
     uint8_t* d_desc = nullptr;        // nimg * keptCap * 32
+    // optional second output set (vslam_batch): run() alternates between the two, so that the keys of frame k stay readable
+    // while the extraction of frame k + 1 is already in flight
+    vslam_keypoint* d_kpsBuf[2] = {nullptr, nullptr}; uint8_t* d_descBuf[2] = {nullptr, nullptr}; int outSel = 0; bool doubleOut = false;
+    vslam_status enable_double_output();
     std::vector<int> nKept;           // per image, after the last run (valid after wait_counts())
     bool ran = false;
     // SSC (FeatureExtractor::ssc) runs in k_ssc, on the device only: picks, per-task counts, flags, and the per-image

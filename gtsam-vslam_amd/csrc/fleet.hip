@@ -101,7 +101,7 @@ void vslam_fleet::group_loop(int gi) {
     Group& Gp = groups[gi];
     hipSetDevice(device);
     const int Bn = Gp.count;
-    std::vector<const uint8_t*> L(Bn), R(Bn);
+    std::vector<const uint8_t*> L(Bn), R(Bn), nL(Bn), nR(Bn);
     std::vector<int> fr(Bn), idxs(Bn);
     std::vector<vslam_imu_bucket> bk(Bn);
     std::vector<double> T((size_t)Bn * 16);
@@ -133,7 +133,12 @@ void vslam_fleet::group_loop(int gi) {
             }
             const bool sample = gi == 0 && sampleEvery > 0 && k > 0 && (k % sampleEvery) == 0;
             if (gi == 0 && sampleEvery > 0) { vslam_batch_set_timing(Gp.b, sample ? 1 : 0); vslam_system_set_ba_timing(ses[Gp.first].sys, sample ? 1 : 0); }
-            st = vslam_batch_track_stereo(Gp.b, L.data(), R.data(), stride, onDevice, fr.data(), useImu ? bk.data() : nullptr, nullptr, T.data(), reps.data());
+            if (onDevice) {       // the next step's images: their extraction overlaps this step's host phases
+                for (int b = 0; b < Bn; b++) { const int ni = tri(k + 1 + ses[Gp.first + b].offset, nFrames); nL[b] = left[ni]; nR[b] = right[ni]; }
+                st = vslam_batch_track_stereo_prefetch(Gp.b, L.data(), R.data(), stride, fr.data(), useImu ? bk.data() : nullptr, nullptr, T.data(),
+                                                       reps.data(), nL.data(), nR.data(), nullptr);
+            } else
+                st = vslam_batch_track_stereo(Gp.b, L.data(), R.data(), stride, onDevice, fr.data(), useImu ? bk.data() : nullptr, nullptr, T.data(), reps.data());
             if (st != VSLAM_OK) break;
             if (sample) {
                 const char* nm[64]; float ms[64]; int n = 0, nba = 0;

@@ -71,11 +71,27 @@ void vslam_system::release() {
 // the current frame's TrackedKeys as the device holds them (after findOutliersR's mutations)
 vslam_status vslam_system::fetch_keys(SysKeys& k) {
     int nL = 0, nR = 0;
+    if (!ownsFe) {
+        // lane of a vslam_batch: the shared extractor may already be writing the NEXT frame into its other output set; this
+        // frame's keys are the matcher's view (set when the frame's totals were read), copied on the group's stream
+        nL = fm->nKeys[0]; nR = fm->nKeys[1];
+        k.kL.resize(nL); k.kR.resize(nR); k.dL.resize((size_t)nL * 32); k.dR.resize((size_t)nR * 32);
+        VS_HIP(hipSetDevice(cfg.device));
+        if (nL) {
+            VS_HIP(hipMemcpyAsync(k.kL.data(), fm->d_kps[0], (size_t)nL * sizeof(vslam_keypoint), hipMemcpyDeviceToHost, fm->stream));
+            VS_HIP(hipMemcpyAsync(k.dL.data(), fm->d_desc[0], (size_t)nL * 32, hipMemcpyDeviceToHost, fm->stream));
+        }
+        if (nR) {
+            VS_HIP(hipMemcpyAsync(k.kR.data(), fm->d_kps[1], (size_t)nR * sizeof(vslam_keypoint), hipMemcpyDeviceToHost, fm->stream));
+            VS_HIP(hipMemcpyAsync(k.dR.data(), fm->d_desc[1], (size_t)nR * 32, hipMemcpyDeviceToHost, fm->stream));
+        }
+    } else {
     VS_CHECK(vslam_extractor_count(fe, img0, &nL)); VS_CHECK(vslam_extractor_count(fe, img0 + 1, &nR));
     k.kL.resize(nL); k.kR.resize(nR); k.dL.resize((size_t)nL * 32); k.dR.resize((size_t)nR * 32);
     int n = 0;
     VS_CHECK(vslam_extractor_fetch(fe, img0, k.kL.data(), k.dL.data(), std::max(nL, 1), &n));
     VS_CHECK(vslam_extractor_fetch(fe, img0 + 1, k.kR.data(), k.dR.data(), std::max(nR, 1), &n));
+    }
     k.rightIdxs.assign(std::max(nL, 1), -1); k.leftIdxs.assign(std::max(nR, 1), -1); k.depth.assign(std::max(nL, 1), -1.f); k.close.assign(std::max(nL, 1), 0);
     VS_CHECK(vslam_stereo_fetch(fm, k.rightIdxs.data(), k.leftIdxs.data(), k.depth.data(), k.close.data(), std::max(nL, 1), std::max(nR, 1), nullptr));
     k.rightIdxs.resize(nL); k.leftIdxs.resize(nR); k.depth.resize(nL); k.close.resize(nL);

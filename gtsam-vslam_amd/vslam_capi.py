@@ -827,6 +827,34 @@ class System:
         _chk(self.L.vslam_system_save_trajectory(self.h_sys, path.encode(), path_positions.encode() if path_positions else None))
 
 
+class DeviceImage:
+    """a u8 image uploaded into a device buffer of the library's allocator (vslam_device_alloc); .ptr for the *_device calls"""
+
+    def __init__(self, img, device=0):
+        self.L = lib()
+        self.L.vslam_device_alloc.argtypes = [C.c_int32, C.c_size_t, C.POINTER(C.c_void_p)]
+        self.L.vslam_device_upload.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t]
+        self.L.vslam_device_free.argtypes = [C.c_int32, C.c_void_p]
+        self.L.vslam_device_free.restype = None
+        a = np.ascontiguousarray(img, np.uint8)
+        self.device = device
+        p = C.c_void_p()
+        _chk(self.L.vslam_device_alloc(device, a.nbytes, C.byref(p)))
+        self.ptr = p.value
+        _chk(self.L.vslam_device_upload(device, self.ptr, a.ctypes.data, a.nbytes))
+
+    def free(self):
+        if self.ptr:
+            self.L.vslam_device_free(self.device, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 # ---- N3: rectification and dataset bookkeeping -----------------------------------------------------------------------
 class Rectifier:
     """vslam_rectifier: initUndistortRectifyMap once, remap(INTER_LINEAR) per frame (device images)."""

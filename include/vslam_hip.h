@@ -632,6 +632,13 @@ void vslam_batch_destroy(vslam_batch* batch);
 vslam_status vslam_batch_track_stereo(vslam_batch* batch, const uint8_t* const* left, const uint8_t* const* right, int32_t stride,
                                       int32_t on_device, const int32_t* frame_numbers, const vslam_imu_bucket* imu,
                                       const uint8_t* lane_mask, double* T_wc_out, vslam_frame_report* reports);
+/* the same for DEVICE images, and the images of the NEXT step (next_left / next_right / next_mask, may be NULL): their
+ * extraction is enqueued as soon as this step's kernels have finished, so that it runs under this step's host phases; the
+ * next call must then pass exactly those pointers (anything else is extracted afresh) */
+vslam_status vslam_batch_track_stereo_prefetch(vslam_batch* batch, const uint8_t* const* left, const uint8_t* const* right, int32_t stride,
+                                               const int32_t* frame_numbers, const vslam_imu_bucket* imu, const uint8_t* lane_mask,
+                                               double* T_wc_out, vslam_frame_report* reports, const uint8_t* const* next_left,
+                                               const uint8_t* const* next_right, const uint8_t* next_mask);
 /* a lane's session (borrowed: valid until vslam_batch_destroy) for the vslam_system_* read-outs */
 vslam_system* vslam_batch_system(vslam_batch* batch, int32_t lane);
 int32_t vslam_batch_lanes(const vslam_batch* batch);
@@ -725,6 +732,12 @@ vslam_status vslam_dataset_gravity(const vslam_dataset* d, int32_t* imu_valid, d
  * it ends (otherwise the cache lives until the process exits - nothing is freed from thread-exit hooks, where profiler
  * libraries no longer tolerate HIP calls). */
 void vslam_thread_release(void);
+
+/* plain device buffers for callers that have no HIP binding of their own (the *_device entry points take such pointers) */
+vslam_status vslam_device_alloc(int32_t device, size_t bytes, void** out);
+vslam_status vslam_device_upload(int32_t device, void* dst, const void* src, size_t bytes);
+vslam_status vslam_device_download(int32_t device, void* dst, const void* src, size_t bytes);
+void vslam_device_free(int32_t device, void* p);
 
 /* debug aid: fill every device allocation made from now on (and every reused scratch block) with `byte` (< 0: off; the
  * VSLAM_POISON environment variable sets the start value) - results must not depend on it */

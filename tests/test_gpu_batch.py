@@ -126,3 +126,30 @@ def test_batch_mapping_threads(capi):
         assert c["keyframes"] >= 2 and c["frames"] == len(schedules[b])
     assert ran >= B
     bt.close()
+
+
+def test_fleet_batched_with_prefetch_equals_one_thread_per_session(capi):
+    """vslam_fleet on device-resident frames: the lockstep groups (whose driver prefetches the next frames' extraction into the
+    extractor's second output set while a step's host phases run) must add up to the same run as one thread + one set of
+    launches per session: same keyframes, inlier sums, lost frames; position error sums equal to round-off of the local BAs."""
+    rig = synth.RIGS["euroc"]
+    n = 24
+    frames = [synth.stereo_frame(2 * i, "euroc") for i in range(n)]
+    imgs = [(capi.DeviceImage(f[0]), capi.DeviceImage(f[1])) for f in frames]
+    poses = np.stack([f[2] for f in frames])
+    cfg = capi.system_config(rig, 1500, local_mapping=1)
+    out = []
+    for lanes in (0, 3, 5):            # 5 sessions: one group of 5; two groups (3 + 2); unbatched
+        fl = capi.Fleet(cfg, 5, [a.ptr for a, _ in imgs], [b.ptr for _, b in imgs], rig["w"], True, poses=poses, lanes=lanes)
+        r1 = fl.run(30)
+        r2 = fl.run(17)                # a second job continues the sequences (and the prefetch chain)
+        fl.close()
+        out.append((r1, r2))
+    for k in ("frames", "keyframes", "mappings", "new_points", "sum_inliers", "min_inliers", "lost_frames", "sum_rounds", "ba_landmarks", "ba_pairs"):
+        for j in (1, 2):
+            assert out[j][0][k] == out[0][0][k] and out[j][1][k] == out[0][1][k], (k, j, out[j][0][k], out[0][0][k])
+    for j in (1, 2):
+        assert abs(out[j][1]["sum_sq_position_error"] - out[0][1]["sum_sq_position_error"]) < 1e-9
+    assert out[0][0]["keyframes"] >= 10 and out[0][1]["mappings"] + out[0][0]["mappings"] >= 3
+    for a, b in imgs:
+        a.free(); b.free()
