@@ -64,7 +64,7 @@ struct vslam_batch {
     std::mutex mqMu; std::condition_variable mqCv;
     bool mqStop = false;
     // per-step scratch
-    struct LaneStep { bool on = false, first = false, failed = false; vslam_status st = VSLAM_OK; char err[200] = ""; size_t upOff = 0, dnOff = 0; int N = 0, nL = 0, nR = 0; };
+    struct LaneStep { bool on = false, first = false, failed = false; vslam_status st = VSLAM_OK; char err[200] = ""; size_t upOff = 0, dnOff = 0, keyOff = 0; int N = 0, nL = 0, nR = 0; bool wantKeys = false; };
     std::vector<LaneStep> ls;
     std::vector<const uint8_t*> imgPtrs;
     StageTimer timer;
@@ -167,6 +167,13 @@ void vslam_batch::release() {
         fprintf(stderr, "vslam_batch %d lanes, %lld steps, host phases (us / step): begin %.1f | images + extract enqueue %.1f | upload block %.1f | "
                         "tables + enqueue %.1f | wait %.1f | retry %.1f | post %.1f\n", B, nSteps, 1e6 * phaseSum[0] / nSteps, 1e6 * phaseSum[1] / nSteps,
                 1e6 * phaseSum[2] / nSteps, 1e6 * phaseSum[3] / nSteps, 1e6 * phaseSum[4] / nSteps, 1e6 * phaseSum[5] / nSteps, 1e6 * phaseSum[6] / nSteps);
+    if (getenv("VSLAM_BATCH_PHASES")) {
+        SysProf& p = sys_prof();
+        auto avg = [](std::atomic<long long>& ns, std::atomic<long long>& n) { return n.load() ? 1e-3 * (double)ns.load() / (double)n.load() : 0.0; };
+        fprintf(stderr, "  per-lane host work so far (us per call x calls): changePosesLCA %.1f x %lld | keyframe insertion %.1f x %lld | calcDescriptor round trip "
+                        "%.1f x %lld | frame_post %.1f x %lld\n", avg(p.lcaNs, p.lcaN), p.lcaN.load(), avg(p.kfNs, p.kfN), p.kfN.load(), avg(p.descNs, p.descN),
+                p.descN.load(), avg(p.postNs, p.postN), p.postN.load());
+    }
     // sessions first (each waits for its mapping job), then the mapping threads, then the shared objects
     for (vslam_system* s : sys) if (s) { s->release(); delete s; }
     sys.clear();
@@ -342,6 +349,10 @@ vslam_status vslam_batch::step(const uint8_t* const* L, const uint8_t* const* R,
         maxN = std::max(maxN, std::max(q.N, 1));
         q.dnOff = dnBytes;
         dnBytes += up256((size_t)std::max(q.N, 1) * 15 + (size_t)q.nL * 4 + 16);
+        // a lane whose keyframe counter allows an insertion this frame (src/FeatureTracker.cpp:1262: count >= 5) gets its
+        // TrackedKeys in the same download; the rarer nStereo < 80 branch falls back to fetch_keys()
+        q.wantKeys = sys[b]->insertKeyFrameCount + 1 >= 5;
+        if (q.wantKeys) { q.keyOff = dnBytes; dnBytes += up256(key_block_layout(q.nL, q.nR).total); }
     }
     VS_CHECK(ensure_dn(std::max<size_t>(dnBytes, 256)));
 
@@ -392,6 +403,9 @@ vslam_status vslam_batch::step(const uint8_t* const* L, const uint8_t* const* R,
         PackLane& K = ht.pack[b];
         K.N = q.N; K.nL = q.nL; K.count = m->d_trCount; K.matches = m->d_matches; K.act = m->d_trAct; K.matchedL = m->d_matchedL;
         K.flags = m->d_flags; K.flagStride = (size_t)m->poseCap; K.visLeft = m->d_trVisL; K.out = d_dn + q.dnOff;
+        K.keyOut = q.wantKeys ? d_dn + q.keyOff : nullptr; K.nR = q.nR;
+        K.kps[0] = m->d_kps[0]; K.kps[1] = m->d_kps[1]; K.desc[0] = m->d_desc[0]; K.desc[1] = m->d_desc[1];
+        K.rightIdxs = m->d_rightIdxs; K.leftIdxs = m->d_leftIdxs; K.depth = m->d_depth; K.closef = m->d_close;
     }
     VS_HIP(hipMemcpyAsync(d_tab, h_tab, tabBytes, hipMemcpyHostToDevice, stream));
 
@@ -455,6 +469,7 @@ vslam_status vslam_batch::step(const uint8_t* const* L, const uint8_t* const* R,
             v.visL = p;
         }
         v.nL = nL;
+        v.keys = (q.wantKeys && !m->trRetried) ? h_dn + q.keyOff : nullptr; v.nR = q.nR;      // (retry rounds ran after the pack)
     }
     lap(5);
 

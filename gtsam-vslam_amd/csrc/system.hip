@@ -17,9 +17,12 @@
 // unpaired Matrix4d::inverse() calls of the constant-velocity feedback are true inverses (m4_affine_inv) - taking them as
 // rigid transposes makes the round-off defect of the rotation block grow by 1 + sqrt(2) per frame.
 #include "system.hpp"
+#include "track_dev.hpp"
 
 using namespace vslam;
 using namespace vslam_sys;
+
+SysProf& vslam_sys::sys_prof() { static SysProf p; return p; }
 
 void vslam_system::backproject(const SysKeys& k, int i, const M4& pose, double* out) const {
     const double zp = (double)k.depth[i];
@@ -98,6 +101,22 @@ vslam_status vslam_system::fetch_keys(SysKeys& k) {
     return VSLAM_OK;
 }
 
+// the same from the packed block a vslam_batch step downloaded with the tracking state
+static void keys_from_block(const uint8_t* blk, int nL, int nR, SysKeys& k) {
+    const KeyBlockLayout o = key_block_layout(nL, nR);
+    k.kL.resize(nL); k.kR.resize(nR); k.dL.resize((size_t)nL * 32); k.dR.resize((size_t)nR * 32);
+    k.rightIdxs.resize(nL); k.leftIdxs.resize(nR); k.depth.resize(nL); k.close.resize(nL);
+    if (nL) {
+        memcpy(k.kL.data(), blk + o.kpsL, (size_t)nL * sizeof(vslam_keypoint)); memcpy(k.dL.data(), blk + o.descL, (size_t)nL * 32);
+        memcpy(k.rightIdxs.data(), blk + o.rightIdxs, (size_t)nL * 4); memcpy(k.depth.data(), blk + o.depth, (size_t)nL * 4);
+        memcpy(k.close.data(), blk + o.closef, nL);
+    }
+    if (nR) {
+        memcpy(k.kR.data(), blk + o.kpsR, (size_t)nR * sizeof(vslam_keypoint)); memcpy(k.dR.data(), blk + o.descR, (size_t)nR * 32);
+        memcpy(k.leftIdxs.data(), blk + o.leftIdxs, (size_t)nR * 4);
+    }
+}
+
 // MapPoint::update(KeyFrame*) (src/Map.cpp:58-100) minus calcDescriptor, which is batched (needDesc)
 void vslam_system::mp_update(SysMP& mp, int kfNumb, std::vector<int>& needDesc, int mpIndex) {
     const SysKF& kf = keyFrames[kfNumb];
@@ -116,13 +135,19 @@ void vslam_system::mp_update(SysMP& mp, int kfNumb, std::vector<int>& needDesc, 
 }
 
 // MapPoint::calcDescriptor (src/Map.cpp:145-210) for a batch of map points: k_calc_descriptor
-vslam_status vslam_system::calc_descriptors(const std::vector<int>& mps) {
+// lk (optional): the caller's hold on mapMutex; it is released for the duration of the GPU round trip.  A point whose
+// observation list changed meanwhile (the other thread added a keyframe match and recomputed its descriptor from the longer
+// list) keeps that newer result.
+vslam_status vslam_system::calc_descriptors(const std::vector<int>& mps, std::unique_lock<std::mutex>* lk) {
     if (mps.empty()) return VSLAM_OK;
+    SysProfScope ps(sys_prof().descNs, sys_prof().descN);
     std::vector<uint8_t> descs;
     std::vector<int> start(1, 0), best(mps.size(), -1);
     std::vector<const uint8_t*> src;
-    for (int m : mps) {
-        const SysMP& mp = mapPoints[m];
+    std::vector<size_t> nObsAt(mps.size());
+    for (size_t q = 0; q < mps.size(); q++) {
+        const SysMP& mp = mapPoints[mps[q]];
+        nObsAt[q] = mp.kfm.size();
         for (const KfMatch& o : mp.kfm) {
             const SysKeys& k = keyFrames[o.kf].keys;
             if (o.l != -1) src.push_back(k.dL.data() + (size_t)o.l * 32);
@@ -132,9 +157,15 @@ vslam_status vslam_system::calc_descriptors(const std::vector<int>& mps) {
     }
     descs.resize(src.size() * 32);
     for (size_t i = 0; i < src.size(); i++) memcpy(descs.data() + i * 32, src[i], 32);
-    if (!src.empty()) VS_CHECK(vslam_calc_descriptors(descs.data(), start.data(), (int)mps.size(), cfg.device, best.data()));
+    if (!src.empty()) {
+        if (lk) lk->unlock();
+        const vslam_status st = vslam_calc_descriptors(descs.data(), start.data(), (int)mps.size(), cfg.device, best.data());
+        if (lk) lk->lock();
+        if (st != VSLAM_OK) return st;
+    }
     for (size_t q = 0; q < mps.size(); q++)
-        if (start[q + 1] > start[q] && best[q] >= 0) memcpy(mapPoints[mps[q]].desc, src[start[q] + best[q]], 32);
+        if (start[q + 1] > start[q] && best[q] >= 0 && mapPoints[mps[q]].kfm.size() == nObsAt[q])
+            memcpy(mapPoints[mps[q]].desc, descs.data() + (size_t)(start[q] + best[q]) * 32, 32);
     return VSLAM_OK;
 }
 
@@ -195,7 +226,8 @@ void vslam_system::calc_connections(SysKF& kf) {
 
 // insertKeyFrame (src/FeatureTracker.cpp:743-842)
 vslam_status vslam_system::insert_keyframe(SysKeys& keys, const std::vector<int>& matchedL, const std::vector<int>& matches,
-                                           int nStereo, const M4& estimPose, const std::vector<uint8_t>& outl, const std::vector<int>& act, int frame) {
+                                           int nStereo, const M4& estimPose, const std::vector<uint8_t>& outl, const std::vector<int>& act, int frame,
+                                           std::unique_lock<std::mutex>* lk) {
     const M4 refPose = m4_mul(keyFrames[latestKF].poseInv, estimPose);
     keyFrames.emplace_back();
     SysKF& kf = keyFrames.back();
@@ -237,8 +269,8 @@ vslam_status vslam_system::insert_keyframe(SysKeys& keys, const std::vector<int>
             tracked++;
         }
     }
-    VS_CHECK(calc_descriptors(need));
-    calc_connections(kf);
+    VS_CHECK(calc_descriptors(need, lk));
+    calc_connections(keyFrames[numb]);
     lastKFTrackedNumb = tracked; kf.nKeysTracked = tracked;
     precCheckMatches = tracked > 350 ? 0.7f : 0.9f;
     latestKF = numb;
@@ -337,6 +369,7 @@ vslam_status vslam_system::frame_begin(SysFrameCtx& c, int frame, const vslam_im
     c.out.frame = frame;
     VS_HIP(hipSetDevice(cfg.device));
     if (LBADone) {                                         // :1115-1122
+        SysProfScope ps(sys_prof().lcaNs, sys_prof().lcaN);
         std::lock_guard<std::mutex> lk(mapMutex);
         VS_CHECK(change_poses_lca(endLBAIdx));
         LBADone = false;
@@ -392,6 +425,7 @@ void vslam_system::frame_imu_input(SysFrameCtx& c) {
 // st: the device's per-frame state (matches [M][2], source index [M], matchedIdxsL [nL], MPsOutliers [M], inFrame [M],
 // left visibility of every uploaded point [N]); c.tr / c.T_cw / c.imuOut: the tracking block's result
 vslam_status vslam_system::frame_post(SysFrameCtx& c, const SysTrackState& st, double* T_wc_out, vslam_frame_report* rep) {
+    SysProfScope pps(sys_prof().postNs, sys_prof().postN);
     const vslam_track_report& tr = c.tr;
     const int M = tr.n_active, N = c.N, nL = st.nL;
     const std::vector<int>& cand = c.cand;
@@ -407,7 +441,7 @@ vslam_status vslam_system::frame_post(SysFrameCtx& c, const SysTrackState& st, d
     std::vector<int> act(M);
     bool isKF = false;
     {
-        std::lock_guard<std::mutex> lk(mapMutex);
+        std::unique_lock<std::mutex> lk(mapMutex);
         // host side of removeOutOfFrameMPs / PredictMPsPosition: MapPoint::inFrame, the compacted active list.  Points the
         // optimizer thread appended to activeMapPoints while this frame was on the device stay behind the compacted ones.
         for (int j = 0; j < N; j++) mapPoints[cand[j]].inFrame = visL[j] != 0;
@@ -424,10 +458,12 @@ vslam_status vslam_system::frame_post(SysFrameCtx& c, const SysTrackState& st, d
         insertKeyFrameCount++;
         isKF = (tr.n_stereo < 80 || insertKeyFrameCount >= 5) && (float)tr.n_inliers < precCheckMatches * (float)lastKFTrackedNumb;
         if (isKF) {
+            SysProfScope ps(sys_prof().kfNs, sys_prof().kfN);
             insertKeyFrameCount = 0;
             SysKeys keys;
-            VS_CHECK(fetch_keys(keys));
-            VS_CHECK(insert_keyframe(keys, matchedL, matches, tr.n_stereo, poseEst, outl, act, frame));
+            if (st.keys) keys_from_block(st.keys, nL, st.nR, keys);
+            else VS_CHECK(fetch_keys(keys));
+            VS_CHECK(insert_keyframe(keys, matchedL, matches, tr.n_stereo, poseEst, outl, act, frame, &lk));
         } else {                                           // addFrame (:871-882)
             allFrames.push_back({false, -1, latestKF, m4_mul(keyFrames[latestKF].poseInv, poseEst)});
         }
@@ -583,9 +619,11 @@ vslam_status vslam_system::find_new_points(const std::vector<int>& actKeyF, int&
     std::vector<double> xyz;
     int n0 = 0;
     // the keyframes' arrays are read in place: a keyframe's keys never move (deque), only depth / close / unMatchedF change
-    // under mapMutex, which is held while the problem is uploaded
+    // under mapMutex.  The lock is RELEASED around the device call: the tracker thread does not write what it reads in place
+    // (a window keyframe's keys, unMatchedF / unMatchedFR - only a NEW keyframe's are written at insertion, changePosesLCA
+    // does not run while a mapping pass is pending), and the map-point values it needs are copied first.
     {
-        std::lock_guard<std::mutex> lk(mapMutex);
+        std::unique_lock<std::mutex> lk(mapMutex);
         for (int k = 0; k < nk; k++) {
             const SysKF& kf = keyFrames[actKeyF[k]];
             vslam_kf_view& v = views[k];
@@ -614,7 +652,10 @@ vslam_status vslam_system::find_new_points(const std::vector<int>& actKeyF, int&
         vslam_new_points_result R{};
         R.capacity = cap; R.cand_left = cL.data(); R.cand_right = cR.data(); R.accepted = acc.data(); R.xyz = xyz.data();
         R.n_obs = nObs.data(); R.obs = obs.data();
-        VS_CHECK(vslam_find_new_points(&P, &R, cfg.device));
+        lk.unlock();
+        const vslam_status fst = vslam_find_new_points(&P, &R, cfg.device);
+        lk.lock();
+        if (fst != VSLAM_OK) return fst;
         const int nc = R.n_candidates;
         if (mpIdx < 0) mpIdx = (long long)mapPoints.size();
         const int lastNumb = last.numb;
@@ -643,7 +684,7 @@ vslam_status vslam_system::find_new_points(const std::vector<int>& actKeyF, int&
             mp_update(mp, lastNumb, need, mi);
             created.push_back(mi);
         }
-        VS_CHECK(calc_descriptors(need));
+        VS_CHECK(calc_descriptors(need, &lk));
         for (int mi : created) {                           // addNewMapPoints: MapPoint::addConnection on every observing keyframe
             SysMP& mp = mapPoints[mi];
             for (const KfMatch& o : mp.kfm) {
@@ -763,8 +804,9 @@ vslam_status vslam_system::local_ba(const std::vector<int>& actKeyF) {
     }
     vslam_local_ba_set_timing(timingBefore);
     // ---- write-back (:875-938) -----------------------------------------------------------------------------------------
+    // (mapMutex is released around the two device round trips below; their inputs are copies)
     {
-        std::lock_guard<std::mutex> lk(mapMutex);
+        std::unique_lock<std::mutex> lk(mapMutex);
         // second graph build (:566-575): a landmark whose every keyframe observation was rejected after pass 1 is flagged
         std::vector<int> nUsable(allMps.size(), 0);
         for (int p = 0; p < NP; p++) if (pf[p] && !wrong1[p]) nUsable[pl[p]]++;
@@ -818,8 +860,11 @@ vslam_status vslam_system::local_ba(const std::vector<int>& actKeyF) {
                 for (size_t i = 0; i < rkfs.size(); i++) memcpy(&rpose[16 * i], keyFrames[rkfs[i]].pose.data(), 16 * sizeof(double));
                 std::vector<uint8_t> zeroW(rk.size(), 0), zeroO(upd.size(), 0), clo(rk.size()), up(rk.size());
                 std::vector<float> dep(rk.size());
-                VS_CHECK(vslam_ba_refresh_depth(&cfg.rig, (int)rkfs.size(), rpose.data(), (int)upd.size(), rlm.data(), zeroO.data(), (int)rk.size(),
-                                                rk.data(), rl.data(), zeroW.data(), cur.data(), cfg.device, dep.data(), clo.data(), up.data()));
+                lk.unlock();
+                const vslam_status rst = vslam_ba_refresh_depth(&cfg.rig, (int)rkfs.size(), rpose.data(), (int)upd.size(), rlm.data(), zeroO.data(), (int)rk.size(),
+                                                                rk.data(), rl.data(), zeroW.data(), cur.data(), cfg.device, dep.data(), clo.data(), up.data());
+                lk.lock();
+                if (rst != VSLAM_OK) return rst;
                 for (size_t q = 0; q < rk.size(); q++) {
                     if (!up[q]) continue;
                     SysKeys& keys = keyFrames[where[q].first].keys;
@@ -827,7 +872,7 @@ vslam_status vslam_system::local_ba(const std::vector<int>& actKeyF) {
                     if (clo[q]) keys.close[where[q].second] = 1;
                 }
             }
-            VS_CHECK(calc_descriptors(upd));
+            VS_CHECK(calc_descriptors(upd, &lk));
         }
         endLBAIdx = actKeyF[0];
         keyFrameAdded = false;

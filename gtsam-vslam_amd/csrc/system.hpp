@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <array>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -94,7 +95,19 @@ struct SysFrameCtx {
     vslam_frame_report out{};
 };
 // the device's per-frame tracking state, as host pointers (layouts differ between the one-session and the batched fetch)
-struct SysTrackState { const int* matches; const int* actIdx; const int* matchedL; const uint8_t* outl; const uint8_t* inF; const uint8_t* visL; int nL; };
+struct SysTrackState {
+    const int* matches; const int* actIdx; const int* matchedL; const uint8_t* outl; const uint8_t* inF; const uint8_t* visL; int nL;
+    const uint8_t* keys = nullptr; int nR = 0;      // the frame's TrackedKeys, packed (track_dev.hpp key_block_layout), or null: fetch_keys()
+};
+
+// VSLAM_BATCH_PHASES diagnostics: where the per-lane host phases spend their time (nanoseconds / calls, process-wide)
+struct SysProf { std::atomic<long long> lcaNs{0}, lcaN{0}, kfNs{0}, kfN{0}, descNs{0}, descN{0}, postNs{0}, postN{0}; };
+SysProf& sys_prof();
+struct SysProfScope {
+    std::atomic<long long>& ns; std::atomic<long long>& n; std::chrono::steady_clock::time_point t0;
+    SysProfScope(std::atomic<long long>& a, std::atomic<long long>& b) : ns(a), n(b), t0(std::chrono::steady_clock::now()) {}
+    ~SysProfScope() { ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); n++; }
+};
 
 struct SysFrame { bool isKF; int kf; int prevKF; M4 refPose; };   // allFramesPoses entry (trajectory output)
 
@@ -158,11 +171,12 @@ struct vslam_system {
                        double* T_wc_out, vslam_frame_report* rep);
     vslam_status fetch_keys(SysKeys& k);
     void mp_update(SysMP& mp, int kfNumb, std::vector<int>& needDesc, int mpIndex);
-    vslam_status calc_descriptors(const std::vector<int>& mps);
+    vslam_status calc_descriptors(const std::vector<int>& mps, std::unique_lock<std::mutex>* lk = nullptr);
     void backproject(const SysKeys& k, int i, const M4& pose, double* out) const;
     vslam_status initialize_map(const SysKeys& keys, int frame);
     vslam_status insert_keyframe(SysKeys& keys, const std::vector<int>& matchedL, const std::vector<int>& matches,
-                                 int nStereo, const M4& estimPose, const std::vector<uint8_t>& outl, const std::vector<int>& act, int frame);
+                                 int nStereo, const M4& estimPose, const std::vector<uint8_t>& outl, const std::vector<int>& act, int frame,
+                                 std::unique_lock<std::mutex>* lk = nullptr);
     void calc_connections(SysKF& kf);
     vslam_status change_poses_lca(int endIdx);
     vslam_status kf_update_pose(SysKF& kf, const M4& keyPose);

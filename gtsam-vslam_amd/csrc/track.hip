@@ -212,6 +212,19 @@ __global__ __launch_bounds__(256) void k_track_pack_b(const PackLane* __restrict
         oVis[i] = L.visLeft[i];
     }
     for (int i = blockIdx.x * 256 + threadIdx.x; i < nL; i += gridDim.x * 256) oMatchedL[i] = L.matchedL[i];
+    if (L.keyOut) {
+        const KeyBlockLayout K = key_block_layout(nL, L.nR);
+        const int t0 = blockIdx.x * 256 + threadIdx.x, ts = gridDim.x * 256;
+        auto copy4 = [&](size_t off, const void* src, size_t bytes) {      // (every source / section is 4-byte aligned)
+            const unsigned* s = (const unsigned*)src;
+            unsigned* d = (unsigned*)(L.keyOut + off);
+            for (size_t i = t0; i < bytes / 4; i += ts) d[i] = s[i];
+        };
+        copy4(K.kpsL, L.kps[0], (size_t)nL * sizeof(vslam_keypoint)); copy4(K.descL, L.desc[0], (size_t)nL * 32);
+        copy4(K.kpsR, L.kps[1], (size_t)L.nR * sizeof(vslam_keypoint)); copy4(K.descR, L.desc[1], (size_t)L.nR * 32);
+        copy4(K.rightIdxs, L.rightIdxs, (size_t)nL * 4); copy4(K.depth, L.depth, (size_t)nL * 4); copy4(K.leftIdxs, L.leftIdxs, (size_t)L.nR * 4);
+        for (int i = t0; i < nL; i += ts) L.keyOut[K.closef + i] = L.closef[i];
+    }
 }
 
 void launch_track_predict_batch(hipStream_t s, const PredictLane* d, int B) { hipLaunchKernelGGL(k_track_predict_b, dim3(B), dim3(1024), 0, s, d); }

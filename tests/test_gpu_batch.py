@@ -111,7 +111,10 @@ def test_batch_mapping_threads(capi):
     schedules = [list(range(2 * b, 2 * b + 48, 2)) for b in range(B)]
     bt = capi.Batch(rig, 1500, B, T0s=[synth.pose_at(sc[0], rig["fps"]) for sc in schedules], local_mapping=2, mapping_threads=2)
     ran = 0
-    for n in range(len(schedules[0])):
+    nF = len(schedules[0])
+    for n in range(nF):
+        if n == nF - 1:
+            bt.wait_mapping()       # passes still running are reported by the frame after they finish: let them finish first
         fr = [synth.stereo_frame(sc[n], "euroc") for sc in schedules]
         T, reps = bt.track([f[0] for f in fr], [f[1] for f in fr], [n] * B)
         for b in range(B):
@@ -123,8 +126,8 @@ def test_batch_mapping_threads(capi):
     bt.wait_mapping()
     for b in range(B):
         c = bt.system(b).counts()
-        assert c["keyframes"] >= 2 and c["frames"] == len(schedules[b])
-    assert ran >= B
+        assert c["keyframes"] >= 4 and c["frames"] == len(schedules[b])
+    assert ran >= B          # every lane's mapper ran (tracking does not wait for it: the count depends on timing, not its lower bound)
     bt.close()
 
 
