@@ -2522,24 +2522,24 @@ vslam_status vslam_ba_refresh_depth(const vslam_rig* rig, int32_t n_kf, const do
                  oD = take(n_pairs * sizeof(float)), oC = take(n_pairs), oU = take(n_pairs);
     PoolBuf<uint8_t> mem(pool);
     VS_HIP(mem.alloc(off));
-    VS_HIP(hipMemcpyAsync(mem.p + oT, Tcw.data(), n_kf * sizeof(DPose), hipMemcpyHostToDevice, ps));
+    VS_HIP(pool->h2d(mem.p + oT, Tcw.data(), n_kf * sizeof(DPose)));
     if (n_lm) {
-        VS_HIP(hipMemcpyAsync(mem.p + oLm, lm_xyz, (size_t)3 * n_lm * sizeof(double), hipMemcpyHostToDevice, ps));
-        VS_HIP(hipMemcpyAsync(mem.p + oO, lm_outlier, n_lm, hipMemcpyHostToDevice, ps));
+        VS_HIP(pool->h2d(mem.p + oLm, lm_xyz, (size_t)3 * n_lm * sizeof(double)));
+        VS_HIP(pool->h2d(mem.p + oO, lm_outlier, n_lm));
     }
-    VS_HIP(hipMemcpyAsync(mem.p + oKf, pair_kf, n_pairs * sizeof(int), hipMemcpyHostToDevice, ps));
-    VS_HIP(hipMemcpyAsync(mem.p + oL, pair_lm, n_pairs * sizeof(int), hipMemcpyHostToDevice, ps));
-    VS_HIP(hipMemcpyAsync(mem.p + oW, pair_wrong, n_pairs, hipMemcpyHostToDevice, ps));
-    VS_HIP(hipMemcpyAsync(mem.p + oCur, cur_depth, n_pairs * sizeof(float), hipMemcpyHostToDevice, ps));
+    VS_HIP(pool->h2d(mem.p + oKf, pair_kf, n_pairs * sizeof(int)));
+    VS_HIP(pool->h2d(mem.p + oL, pair_lm, n_pairs * sizeof(int)));
+    VS_HIP(pool->h2d(mem.p + oW, pair_wrong, n_pairs));
+    VS_HIP(pool->h2d(mem.p + oCur, cur_depth, n_pairs * sizeof(float)));
     const float closeTh = rig->baseline * 40;
     hipLaunchKernelGGL(k_ba_refresh_depth, dim3((n_pairs + 255) / 256), dim3(256), 0, ps, n_pairs, (const int*)(mem.p + oKf),
                        (const int*)(mem.p + oL), (const uint8_t*)(mem.p + oW), (const uint8_t*)(mem.p + oO), (const float*)(mem.p + oCur),
                        (const DPose*)(mem.p + oT), (const double*)(mem.p + oLm), closeTh, (float*)(mem.p + oD), mem.p + oC, mem.p + oU);
     VS_HIP(hipGetLastError());
-    VS_HIP(hipMemcpyAsync(depth_out, mem.p + oD, n_pairs * sizeof(float), hipMemcpyDeviceToHost, ps));
-    VS_HIP(hipMemcpyAsync(close_out, mem.p + oC, n_pairs, hipMemcpyDeviceToHost, ps));
-    VS_HIP(hipMemcpyAsync(updated_out, mem.p + oU, n_pairs, hipMemcpyDeviceToHost, ps));
-    VS_HIP(hipStreamSynchronize(ps));
+    VS_HIP(pool->d2h(depth_out, mem.p + oD, n_pairs * sizeof(float)));
+    VS_HIP(pool->d2h(close_out, mem.p + oC, n_pairs));
+    VS_HIP(pool->d2h(updated_out, mem.p + oU, n_pairs));
+    VS_HIP(pool->sync());
     return VSLAM_OK;
 }
 

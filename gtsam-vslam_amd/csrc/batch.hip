@@ -46,6 +46,9 @@ struct vslam_batch {
     bool useImu = false;
     vslam_extractor* fe = nullptr;
     hipStream_t stream = nullptr;
+    // the two pre-integrations of a step run beside the matching passes that do not depend on them (one-workgroup-per-lane
+    // kernels of ~90 us each): side stream + events, as the one-session path does
+    hipStream_t imuStream = nullptr; hipEvent_t evTab = nullptr, evImu0 = nullptr, evSolve0 = nullptr, evImu1 = nullptr;
     std::vector<vslam_system*> sys;
     // per-lane argument tables of one step: pinned host block + device mirror (one H2D per step)
     struct Tables {
@@ -116,6 +119,8 @@ vslam_status vslam_batch::init(const vslam_system_config* cfgs, int n, int hostT
     VS_HIP(hipSetDevice(device));
     VS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     timer.stream = stream; timer.multi = true;
+    VS_HIP(hipStreamCreateWithFlags(&imuStream, hipStreamNonBlocking));
+    for (hipEvent_t* e : {&evTab, &evImu0, &evSolve0, &evImu1}) VS_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     VS_CHECK(vslam_extractor_create(&cfgs[0].fe, cfgs[0].rig.width, cfgs[0].rig.height, 2 * B, device, &fe));
     VS_CHECK(fe->enable_double_output());
     VS_HIP(hipMalloc(&d_res, (size_t)B * 64 * sizeof(double)));
@@ -182,6 +187,9 @@ void vslam_batch::release() {
     for (auto& t : mapThreads) t.join();
     mapThreads.clear();
     if (stream) hipStreamSynchronize(stream);
+    if (imuStream) { hipStreamSynchronize(imuStream); hipStreamDestroy(imuStream); imuStream = nullptr; }
+    for (hipEvent_t e : {evTab, evImu0, evSolve0, evImu1}) if (e) hipEventDestroy(e);
+    evTab = evImu0 = evSolve0 = evImu1 = nullptr;
     timer.destroy();
     if (fe) vslam_extractor_destroy(fe);
     fe = nullptr;
@@ -413,16 +421,32 @@ vslam_status vslam_batch::step(const uint8_t* const* L, const uint8_t* const* R,
     int t = timer.begin("stereo");
     launch_stereo_batch(stream, dt.stereo, B, maxL, maxR, sys[0]->cfg.rig.height);
     timer.end(t);
+    // (stage timing brackets launches with events on the main stream: keep the pre-integrations there when it is on)
+    static const bool sideEnv = getenv("VSLAM_BATCH_IMU_SIDE") ? atoi(getenv("VSLAM_BATCH_IMU_SIDE")) != 0 : true;
+    const bool side = useImu && !timer.enabled && sideEnv;
     if (nTrack) {
+        if (side) {
+            VS_HIP(hipEventRecord(evTab, stream));                 // tables + upload block are on the device
+            VS_HIP(hipStreamWaitEvent(imuStream, evTab, 0));
+            launch_imu_batch(imuStream, dt.imu0, B);
+            VS_HIP(hipEventRecord(evImu0, imuStream));
+        }
         t = timer.begin("track_predict"); launch_track_predict_batch(stream, dt.predict, B); timer.end(t);
-        if (useImu) { t = timer.begin("imu_preintegrate"); launch_imu_batch(stream, dt.imu0, B); timer.end(t); }
+        if (useImu && !side) { t = timer.begin("imu_preintegrate"); launch_imu_batch(stream, dt.imu0, B); timer.end(t); }
         t = timer.begin("proj_match"); launch_proj_batch(stream, dt.proj0, B, maxN, maxL, maxR); timer.end(t);
+        if (side) VS_HIP(hipStreamWaitEvent(stream, evImu0, 0));
         t = timer.begin("pose_solve");
         if (useImu) launch_pose_imu_batch(stream, dt.pose0, B, ldsFactors); else launch_pose_batch(stream, dt.pose0, B);
         timer.end(t);
-        if (useImu) { t = timer.begin("imu_preintegrate"); launch_imu_batch(stream, dt.imu1, B); timer.end(t); }
+        if (side) {
+            VS_HIP(hipEventRecord(evSolve0, stream));
+            VS_HIP(hipStreamWaitEvent(imuStream, evSolve0, 0));
+            launch_imu_batch(imuStream, dt.imu1, B);
+            VS_HIP(hipEventRecord(evImu1, imuStream));
+        } else if (useImu) { t = timer.begin("imu_preintegrate"); launch_imu_batch(stream, dt.imu1, B); timer.end(t); }
         t = timer.begin("track_repredict"); launch_track_repredict_batch(stream, dt.repredict, B, maxN); timer.end(t);
         t = timer.begin("proj_match"); launch_proj_batch(stream, dt.proj1, B, maxN, maxL, maxR); timer.end(t);
+        if (side) VS_HIP(hipStreamWaitEvent(stream, evImu1, 0));
         t = timer.begin("pose_solve");
         if (useImu) launch_pose_imu_batch(stream, dt.pose1, B, ldsFactors); else launch_pose_batch(stream, dt.pose1, B);
         timer.end(t);

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <vector>
+#include <algorithm>
 #include <cstdlib>
 #include <unistd.h>
 #include <sys/syscall.h>
@@ -103,11 +104,51 @@ struct DevPool {
         return p;
     }
     void put(void* p) { for (auto& b : blks) if (b.p == p) { b.used = false; return; } }
+    // Pinned staging: callers hand over pageable host arrays (std::vector storage); copying them through a pinned arena keeps
+    // every transfer asynchronous on the pool's stream (a pageable hipMemcpyAsync is staged and synchronised by the runtime,
+    // 50-100 us a piece when the queues are busy).  h2d() copies into the arena and enqueues; d2h() enqueues into the arena
+    // and remembers the destination; sync() waits, delivers the downloads and recycles the arena.
+    uint8_t* pin = nullptr; size_t pinCap = 0, pinOff = 0, pinWant = 0;
+    struct Pending { void* dst; const uint8_t* src; size_t bytes; };
+    std::vector<Pending> pending;
+    uint8_t* stage(size_t bytes) {
+        static const bool off = getenv("VSLAM_POOL_PINNED") && atoi(getenv("VSLAM_POOL_PINNED")) == 0;
+        if (off) return nullptr;
+        const size_t at = (pinOff + 63) & ~(size_t)63;
+        if (!pin || at + bytes > pinCap) { pinWant = std::max(pinWant, 2 * (at + bytes)); return nullptr; }
+        pinOff = at + bytes;
+        return pin + at;
+    }
+    hipError_t h2d(void* dst, const void* src, size_t bytes) {
+        if (!bytes) return hipSuccess;
+        if (uint8_t* s = stage(bytes)) { memcpy(s, src, bytes); return hipMemcpyAsync(dst, s, bytes, hipMemcpyHostToDevice, stream); }
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream);
+    }
+    hipError_t d2h(void* dst, const void* src, size_t bytes) {
+        if (!bytes) return hipSuccess;
+        if (uint8_t* s = stage(bytes)) { pending.push_back({dst, s, bytes}); return hipMemcpyAsync(s, src, bytes, hipMemcpyDeviceToHost, stream); }
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream);
+    }
+    hipError_t sync() {
+        const hipError_t e = hipStreamSynchronize(stream);
+        for (const Pending& p : pending) memcpy(p.dst, p.src, p.bytes);
+        pending.clear();
+        pinOff = 0;
+        if (pinWant > pinCap || !pin) {          // grow between uses (nothing is in flight now)
+            const size_t want = std::max<size_t>(std::max(pinWant, pinCap), (size_t)4 << 20);
+            uint8_t* np = nullptr;
+            if (hipHostMalloc((void**)&np, want, hipHostMallocDefault) == hipSuccess) { if (pin) hipHostFree(pin); pin = np; pinCap = want; }
+            pinWant = 0;
+        }
+        return e;
+    }
     void release() {
         if (device < 0 || hipSetDevice(device) != hipSuccess) return;
         if (stream) { hipStreamSynchronize(stream); hipStreamDestroy(stream); stream = nullptr; }
         for (auto& b : blks) hipFree(b.p);
         blks.clear();
+        if (pin) hipHostFree(pin);
+        pin = nullptr; pinCap = pinOff = pinWant = 0; pending.clear();
     }
     // No HIP calls from a thread_local destructor: tool libraries (rocprofv3) have torn down their own per-thread state by
     // then and abort on stream calls.  Library threads call thread_release() before they end; other threads may call
@@ -146,7 +187,7 @@ struct PoolBuf {
     hipError_t up(const T* h, size_t n) {
         hipError_t e = alloc(n);
         if (e != hipSuccess || !n) return e;
-        return hipMemcpyAsync(p, h, n * sizeof(T), hipMemcpyHostToDevice, pool->stream);
+        return pool->h2d(p, h, n * sizeof(T));
     }
 };
 

@@ -501,7 +501,7 @@ namespace {
 // device arrays of these entry points come from the calling thread's block cache (common.hpp): no hipMalloc / hipFree /
 // stream creation in the steady state
 template <class T> using Dev = PoolBuf<T>;
-#define NP_POOL(var) DevPool* var = thread_pool(device); if (!var) { set_error("no device pool"); return VSLAM_ERR_HIP; }
+#define NP_POOL(var) DevPool* var = thread_pool(device); if (!var) { set_error("no device pool"); return VSLAM_ERR_HIP; } var->pending.clear();
 }  // namespace
 
 extern "C" vslam_status vslam_find_new_points(const vslam_new_points_problem* P, vslam_new_points_result* R, int32_t device) {
@@ -518,7 +518,7 @@ extern "C" vslam_status vslam_find_new_points(const vslam_new_points_problem* P,
     if (K0.n_left > 0 && (!P->estimated_depth || !P->has_mp || !K0.right_idxs || !K0.unmatched_f)) { set_error("vslam_find_new_points: last keyframe arrays missing"); return VSLAM_ERR_INVALID; }
     NP_POOL(pool);
     hipStream_t stream = pool->stream;
-    struct StreamGuard { hipStream_t s; ~StreamGuard() { hipStreamSynchronize(s); } } guard{stream};   // before the blocks go back
+    struct StreamGuard { DevPool* p; ~StreamGuard() { (void)p->sync(); } } guard{pool};   // before the blocks go back
     const int cap = std::max(K0.n_left, 1);
     NpArgs A{};
     A.nKf = P->n_kf;
@@ -574,19 +574,19 @@ extern "C" vslam_status vslam_find_new_points(const vslam_new_points_problem* P,
     hipLaunchKernelGGL(k_np_triangulate, dim3((cap + 63) / 64), dim3(64), lds, stream, A);
     VS_HIP(hipGetLastError());
     int n = 0;
-    VS_HIP(hipMemcpyAsync(&n, dCount.p, sizeof(int), hipMemcpyDeviceToHost, stream));
-    VS_HIP(hipStreamSynchronize(stream));
+    VS_HIP(pool->d2h(&n, dCount.p, sizeof(int)));
+    VS_HIP(pool->sync());
     R->n_candidates = n;
     if (n > R->capacity) { set_error("vslam_find_new_points: result capacity %d < %d candidates", R->capacity, n); return VSLAM_ERR_CAPACITY; }
     if (n) {
         std::vector<int> key((size_t)2 * n);
-        VS_HIP(hipMemcpyAsync(key.data(), dKey.p, key.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
-        VS_HIP(hipMemcpyAsync(R->accepted, dAcc.p, n, hipMemcpyDeviceToHost, stream));
-        VS_HIP(hipMemcpyAsync(R->xyz, dXyz.p, (size_t)3 * n * sizeof(double), hipMemcpyDeviceToHost, stream));
-        VS_HIP(hipMemcpyAsync(R->n_obs, dNobs.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, stream));
+        VS_HIP(pool->d2h(key.data(), dKey.p, key.size() * sizeof(int)));
+        VS_HIP(pool->d2h(R->accepted, dAcc.p, n));
+        VS_HIP(pool->d2h(R->xyz, dXyz.p, (size_t)3 * n * sizeof(double)));
+        VS_HIP(pool->d2h(R->n_obs, dNobs.p, (size_t)n * sizeof(int)));
         std::vector<int> obs((size_t)n * NP_MAX_KF * 3);
-        VS_HIP(hipMemcpyAsync(obs.data(), dObs.p, obs.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
-        VS_HIP(hipStreamSynchronize(stream));
+        VS_HIP(pool->d2h(obs.data(), dObs.p, obs.size() * sizeof(int)));
+        VS_HIP(pool->sync());
         for (int i = 0; i < n; i++) { R->cand_left[i] = key[2 * i]; R->cand_right[i] = key[2 * i + 1]; }
         for (int i = 0; i < n; i++)
             for (int e = 0; e < P->n_kf; e++)
@@ -611,8 +611,8 @@ extern "C" vslam_status vslam_calc_descriptors(const uint8_t* descs, const int32
     VS_HIP(dD.up(descs, total * 32)); VS_HIP(dS.up(start, (size_t)n_mp + 1)); VS_HIP(dB.alloc(n_mp));
     hipLaunchKernelGGL(k_calc_descriptor, dim3((n_mp + 3) / 4), dim3(256), 0, pool->stream, n_mp, dD.p, dS.p, dB.p);
     VS_HIP(hipGetLastError());
-    VS_HIP(hipMemcpyAsync(best_out, dB.p, (size_t)n_mp * sizeof(int), hipMemcpyDeviceToHost, pool->stream));
-    VS_HIP(hipStreamSynchronize(pool->stream));
+    VS_HIP(pool->d2h(best_out, dB.p, (size_t)n_mp * sizeof(int)));
+    VS_HIP(pool->sync());
     return VSLAM_OK;
 }
 
@@ -654,11 +654,11 @@ extern "C" vslam_status vslam_mono_new_points(const vslam_mono_points_problem* P
     VS_HIP(hipFuncSetAttribute((const void*)k_np_mono_points, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_np_mono_points, dim3((nP + 63) / 64), dim3(64), lds, ps, A);
     VS_HIP(hipGetLastError());
-    VS_HIP(hipMemcpyAsync(R->accepted, dAcc.p, nP, hipMemcpyDeviceToHost, ps));
-    VS_HIP(hipMemcpyAsync(R->keep, dKeep.p, (size_t)nP * nK, hipMemcpyDeviceToHost, ps));
-    VS_HIP(hipMemcpyAsync(R->xyz, dXyz.p, (size_t)nP * 3 * sizeof(double), hipMemcpyDeviceToHost, ps));
-    VS_HIP(hipMemcpyAsync(R->n_obs, dNo.p, (size_t)nP * sizeof(int), hipMemcpyDeviceToHost, ps));
-    VS_HIP(hipStreamSynchronize(ps));
+    VS_HIP(pool->d2h(R->accepted, dAcc.p, nP));
+    VS_HIP(pool->d2h(R->keep, dKeep.p, (size_t)nP * nK));
+    VS_HIP(pool->d2h(R->xyz, dXyz.p, (size_t)nP * 3 * sizeof(double)));
+    VS_HIP(pool->d2h(R->n_obs, dNo.p, (size_t)nP * sizeof(int)));
+    VS_HIP(pool->sync());
     return VSLAM_OK;
 }
 
@@ -702,9 +702,9 @@ extern "C" vslam_status vslam_keyframe_update_pose(const vslam_kf_update_problem
     A.dropL = dDl.p; A.dropR = dDr.p;
     hipLaunchKernelGGL(k_kf_update_pose, dim3((std::max(A.nL, A.nR) + 255) / 256, 2), dim3(256), 0, ps, A);
     VS_HIP(hipGetLastError());
-    if (A.nL) VS_HIP(hipMemcpyAsync(drop_l, dDl.p, A.nL, hipMemcpyDeviceToHost, ps));
-    if (A.nR) VS_HIP(hipMemcpyAsync(drop_r, dDr.p, A.nR, hipMemcpyDeviceToHost, ps));
-    if (P->n_lm) VS_HIP(hipMemcpyAsync(P->lm_xyz, dLm.p, (size_t)3 * P->n_lm * sizeof(double), hipMemcpyDeviceToHost, ps));
-    VS_HIP(hipStreamSynchronize(ps));
+    if (A.nL) VS_HIP(pool->d2h(drop_l, dDl.p, A.nL));
+    if (A.nR) VS_HIP(pool->d2h(drop_r, dDr.p, A.nR));
+    if (P->n_lm) VS_HIP(pool->d2h(P->lm_xyz, dLm.p, (size_t)3 * P->n_lm * sizeof(double)));
+    VS_HIP(pool->sync());
     return VSLAM_OK;
 }
