@@ -199,6 +199,10 @@ def main():
                                                               "synthetic scene's extent in units of the rig's baseline bounds the camera speed)")
     ap.add_argument("--host-images", action="store_true", help="frames in pinned host memory: every frame pays its H2D copy inside the step")
     ap.add_argument("--mapping", type=int, default=2, help="local mapping: 2 = optimizer thread per session (reference), 1 = synchronous, 0 = off")
+    ap.add_argument("--mapping-max-lag", type=int, default=4, help="--mapping 2: a frame waits for a local-mapping pass handed over this many "
+                    "frames ago (default 4: keyframes are at least 5 frames apart, so every keyframe's pass finishes before the next keyframe - "
+                    "the reference's steady state at camera rate); 0 = never wait: at this frame rate the mapper then falls behind and half "
+                    "of the keyframes are never optimised")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency-line", action="store_true", help="skip the extra single-session run")
     ap.add_argument("--sweep", default="", help="comma-separated SESSIONSxLANES shapes (e.g. 1x0,1x1,8x8,32x32,64x32): throughput of each in the "
@@ -259,7 +263,7 @@ def main():
     lp = [b[0].data_ptr() for b in bufs]
     rp = [b[1].data_ptr() for b in bufs]
     imu = dict(gravity=GRAVITY, noise=IMU_NOISE, T_bs=__import__("synth").T_BC1, hz=200) if cfg["imu"] else None
-    scfg = vc.system_config(rig, cfg["nfeat"], imu=imu, local_mapping=args.mapping, device=local)
+    scfg = vc.system_config(rig, cfg["nfeat"], imu=imu, local_mapping=args.mapping, device=local, mapping_max_lag=args.mapping_max_lag)
 
     def make_fleet(S, lanes):
         return vc.Fleet(scfg, S, lp, rp, w, not args.host_images, poses=poses, velocities=vel,
@@ -391,6 +395,9 @@ def main():
                                    % (args.frames, "in pinned host memory (H2D inside the step)" if args.host_images else "resident in HBM",
                                       rep["frames"] / max(rep["keyframes"], 1), frames_per_ba, L_, R_, Fk),
                        "sessions_per_gpu": S, "lanes_per_group": lanes,
+                       "local_mapping": {0: "off", 1: "inside the frame (synchronous)", 2: "optimizer threads"}.get(args.mapping, "?") +
+                                        ("; a frame waits for a pass handed over >= %d frames ago" % args.mapping_max_lag
+                                         if args.mapping == 2 and args.mapping_max_lag > 0 else ""),
                        "step": "one stereo frame of each of the %d sessions" % S,
                        "threads": ("%d lockstep groups of %d sessions (vslam_batch: one launch per stage for all lanes), one driver thread + a "
                                    "host-phase pool + 3 mapping threads per group" % ((S + lanes - 1) // lanes, lanes)) if lanes > 0 else

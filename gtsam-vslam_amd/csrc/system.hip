@@ -361,7 +361,10 @@ vslam_status vslam_system::change_poses_lca(int endIdx) {
 vslam_status vslam_system::frame_begin(SysFrameCtx& c, int frame, const vslam_imu_bucket* imu) {
     if (cfg.use_imu && frame > 0 && (!imu || imu->n <= 0)) { set_error("vslam_system: IMU mode needs the frame's IMU bucket"); return VSLAM_ERR_INVALID; }
     {
-        std::lock_guard<std::mutex> lk(wMu);
+        std::unique_lock<std::mutex> lk(wMu);
+        // bounded mapper lag (vslam_system_config::mapping_max_lag): a pass handed over d or more frames ago must have finished
+        if (cfg.local_mapping == 2 && cfg.mapping_max_lag > 0 && mappingBusy && frame - mappingSubmittedFrame >= cfg.mapping_max_lag)
+            wCv.wait(lk, [&] { return !mappingBusy; });
         if (workerStatus != VSLAM_OK) { set_error("local mapping thread failed: %s", workerError); return workerStatus; }
     }
     c.frame = frame; c.imu = imu;
@@ -496,7 +499,7 @@ vslam_status vslam_system::frame_post(SysFrameCtx& c, const SysTrackState& st, d
         VS_CHECK(local_mapping());
     } else if (cfg.local_mapping == 2 && keyFrameAdded && !LBADone) {
         bool submit = false;
-        { std::lock_guard<std::mutex> lk(wMu); if (!mappingBusy) { mappingBusy = true; submit = true; } }
+        { std::lock_guard<std::mutex> lk(wMu); if (!mappingBusy) { mappingBusy = true; submit = true; mappingSubmittedFrame = frame; } }
         if (submit) {
             if (mapExec) mapExec(mapExecArg, this);       // the batch's mapping threads
             else wCv.notify_all();

@@ -151,6 +151,7 @@ struct vslam_system {
     std::thread worker;
     std::mutex wMu; std::condition_variable wCv;
     bool stopRequested = false, mappingBusy = false;
+    int mappingSubmittedFrame = 0;     // frame whose post phase handed the running / queued pass to the optimizer thread
     vslam_status workerStatus = VSLAM_OK;
     char workerError[256] = "";
 

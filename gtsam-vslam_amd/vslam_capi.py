@@ -734,7 +734,7 @@ class SystemConfig(C.Structure):
                 ("window", C.c_int32), ("T_wc_init", C.c_double * 16), ("gravity", C.c_double * 3),
                 ("gyro_noise_density", C.c_double), ("gyro_random_walk", C.c_double), ("accel_noise_density", C.c_double),
                 ("accel_random_walk", C.c_double), ("T_body_sensor", C.c_double * 16), ("imu_hz", C.c_int32),
-                ("velocity_init", C.c_double * 3)]
+                ("velocity_init", C.c_double * 3), ("mapping_max_lag", C.c_int32)]
 
 
 class ImuBucket(C.Structure):
@@ -1064,8 +1064,9 @@ class FleetReport(C.Structure):
                 ("max_position_error", C.c_double), ("sum_sq_position_error", C.c_double)]
 
 
-def system_config(rig, nfeatures, imu=None, local_mapping=2, window=10, device=0, nlevels=8, scale=1.2):
+def system_config(rig, nfeatures, imu=None, local_mapping=2, window=10, device=0, nlevels=8, scale=1.2, mapping_max_lag=0):
     cfg = SystemConfig()
+    cfg.mapping_max_lag = mapping_max_lag
     cfg.fe = FeParams(nfeatures, nlevels, scale, 19, 31, 20, 7)
     cfg.rig = make_rig(rig)
     cfg.device = device; cfg.local_mapping = local_mapping; cfg.window = window

@@ -567,6 +567,11 @@ typedef struct vslam_system_config {
     double T_body_sensor[16];
     int32_t imu_hz;
     double velocity_init[3];      /* Camera::mVelocity at start (zero in the reference) */
+    int32_t mapping_max_lag;      /* local_mapping = 2 only.  0: the tracker never waits for the optimizer thread (the reference's
+                                     threads; at the reference's camera rate a pass ends within a frame or two, at thousands of
+                                     frames per second it would fall ever further behind and most keyframes would never be
+                                     optimised).  d > 0: a frame waits for a pass that was started d or more frames ago - the
+                                     optimizer thread of a system whose local mapping takes at most d frame times. */
 } vslam_system_config;
 
 /* the IMU samples between the previous frame and this one (IMUData filled in src/VIOSlam.cpp:238-272) */
