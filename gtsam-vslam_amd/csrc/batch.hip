@@ -161,7 +161,7 @@ vslam_status vslam_batch::init(const vslam_system_config* cfgs, int n, int hostT
     pool.onExit = []() { vslam::thread_release(); };
     if (hostThreads > 1) pool.start(hostThreads - 1);
     if (cfgs[0].local_mapping == 2) {
-        if (nMapThreads <= 0) nMapThreads = std::min(B, 3);
+        if (nMapThreads <= 0) nMapThreads = std::min(B, getenv("VSLAM_BATCH_MAP_THREADS") ? std::max(1, atoi(getenv("VSLAM_BATCH_MAP_THREADS"))) : 3);
         for (int t = 0; t < nMapThreads; t++) mapThreads.emplace_back([this]() { map_loop(); });
     }
     return VSLAM_OK;
@@ -178,6 +178,8 @@ void vslam_batch::release() {
         fprintf(stderr, "  per-lane host work so far (us per call x calls): changePosesLCA %.1f x %lld | keyframe insertion %.1f x %lld | calcDescriptor round trip "
                         "%.1f x %lld | frame_post %.1f x %lld\n", avg(p.lcaNs, p.lcaN), p.lcaN.load(), avg(p.kfNs, p.kfN), p.kfN.load(), avg(p.descNs, p.descN),
                 p.descN.load(), avg(p.postNs, p.postN), p.postN.load());
+        fprintf(stderr, "  mapping passes: %.1f us x %lld (find new points %.1f, vslam_local_ba %.1f) | frames that waited for their mapper: %.1f us x %lld\n",
+                avg(p.mapNs, p.mapN), p.mapN.load(), avg(p.npNs, p.npN), avg(p.baNs, p.baN), avg(p.waitNs, p.waitN), p.waitN.load());
     }
     // sessions first (each waits for its mapping job), then the mapping threads, then the shared objects
     for (vslam_system* s : sys) if (s) { s->release(); delete s; }

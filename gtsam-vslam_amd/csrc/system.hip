@@ -363,8 +363,10 @@ vslam_status vslam_system::frame_begin(SysFrameCtx& c, int frame, const vslam_im
     {
         std::unique_lock<std::mutex> lk(wMu);
         // bounded mapper lag (vslam_system_config::mapping_max_lag): a pass handed over d or more frames ago must have finished
-        if (cfg.local_mapping == 2 && cfg.mapping_max_lag > 0 && mappingBusy && frame - mappingSubmittedFrame >= cfg.mapping_max_lag)
+        if (cfg.local_mapping == 2 && cfg.mapping_max_lag > 0 && mappingBusy && frame - mappingSubmittedFrame >= cfg.mapping_max_lag) {
+            SysProfScope pw(sys_prof().waitNs, sys_prof().waitN);
             wCv.wait(lk, [&] { return !mappingBusy; });
+        }
         if (workerStatus != VSLAM_OK) { set_error("local mapping thread failed: %s", workerError); return workerStatus; }
     }
     c.frame = frame; c.imu = imu;
@@ -602,7 +604,8 @@ vslam_status vslam_system::local_mapping() {
     }
     vslam_frame_report r{};
     int nNew = 0;
-    VS_CHECK(find_new_points(actKeyF, nNew));
+    SysProfScope pm(sys_prof().mapNs, sys_prof().mapN);
+    { SysProfScope pn(sys_prof().npNs, sys_prof().npN); VS_CHECK(find_new_points(actKeyF, nNew)); }
     lastMapping = r;
     lastMapping.new_points = nNew;
     VS_CHECK(local_ba(actKeyF));
@@ -790,7 +793,8 @@ vslam_status vslam_system::local_ba(const std::vector<int>& actKeyF) {
     Rr.kf_pose_wc = kfOut.data(); Rr.lm_xyz = lmOut.data(); Rr.pair_wrong = wrong.data(); Rr.pair_wrong_pass1 = wrong1.data();
     const int timingBefore = vslam_local_ba_get_timing();      // (thread-scoped switch: left as the caller had it)
     vslam_local_ba_set_timing(timingOn.load());
-    const vslam_status baSt = vslam_local_ba(&P, &Rr, cfg.device, nullptr);
+    vslam_status baSt;
+    { SysProfScope pb(sys_prof().baNs, sys_prof().baN); baSt = vslam_local_ba(&P, &Rr, cfg.device, nullptr); }
     if (baSt != VSLAM_OK) { vslam_local_ba_set_timing(timingBefore); return baSt; }
     if (timingOn.load()) {
         const char* nm[32]; float ms[32]; int n = 0;
