@@ -46,7 +46,7 @@ CONFIGS = {
                                                        "200 Hz IMU pre-integration factor in every pose solve"),
     "c3": dict(rig="kitti", nfeat=2000, imu=False, name="C3-class: KITTI-00-like stereo 1241x376, 2000 features/image"),
 }
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_a_pmc_summary.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_b_pmc_summary.json")
 
 
 def level_pixels(w, h, nlevels=8, scale=1.2):

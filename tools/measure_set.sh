@@ -13,7 +13,7 @@ python3 bench.py --config c3 > $OUT/${TAG}_c3_bench.json 2> $OUT/c3.err || exit 
 echo "c3 bench done"
 python3 bench.py --host-images --no-cpu-baseline --no-latency-line > $OUT/${TAG}_c2_bench_host_images.json 2> $OUT/hi.err || exit 1
 echo "host-images bench done"
-python3 bench.py --no-cpu-baseline --no-latency-line --steps 100 --sweep 1x0,1x1,2x2,4x4,8x8,16x16,32x32,64x32,96x32,128x32 > $OUT/${TAG}_c2_sweep.json 2> $OUT/sw.err || exit 1
+python3 bench.py --no-cpu-baseline --no-latency-line --steps 100 --sweep 1x0,1x1,2x2,4x4,8x8,16x16,32x32,64x32,96x48,128x64 > $OUT/${TAG}_c2_sweep.json 2> $OUT/sw.err || exit 1
 echo "sweep done"
 fi
 cd /tmp && export TMPDIR=/tmp
