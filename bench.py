@@ -203,6 +203,9 @@ def main():
                     "frames ago (default 4: keyframes are at least 5 frames apart, so every keyframe's pass finishes before the next keyframe - "
                     "the reference's steady state at camera rate); 0 = never wait: at this frame rate the mapper then falls behind and half "
                     "of the keyframes are never optimised")
+    ap.add_argument("--prime", type=int, default=60, help="untimed frames every session tracks BEFORE the warm-up steps, so that the timed "
+                    "steps see sessions in their steady state (a map with more than three keyframes, the local mapper running) "
+                    "whatever --warmup / --steps are; part of the set-up like rendering the frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency-line", action="store_true", help="skip the extra single-session run")
     ap.add_argument("--sweep", default="", help="comma-separated SESSIONSxLANES shapes (e.g. 1x0,1x1,8x8,32x32,64x32): throughput of each in the "
@@ -271,6 +274,8 @@ def main():
 
     lanes = min(args.lanes, args.sessions)
     fleet = make_fleet(args.sessions, lanes)
+    if args.prime > 0:
+        fleet.run(args.prime)        # set-up: the sessions' first frames (map initialisation, the first keyframes)
     fleet.run(args.warmup)
     torch.cuda.synchronize()
     if world > 1:
@@ -295,7 +300,7 @@ def main():
     if rank == 0 and not args.no_latency_line and args.sessions > 1:
         fleet.close()
         f1 = make_fleet(1, 0)
-        f1.run(min(args.warmup, 20))
+        f1.run(max(args.prime, 1) + min(args.warmup, 20))
         torch.cuda.synchronize()
         n1 = min(args.steps, 200)
         t1 = time.perf_counter()
@@ -315,7 +320,7 @@ def main():
         for shape in [v for v in args.sweep.split(",") if v]:
             Sx, Lx = (int(v) for v in shape.split("x"))
             fx = make_fleet(Sx, Lx)
-            fx.run(max(5, args.warmup // 2))
+            fx.run(max(args.prime, 5))
             torch.cuda.synchronize()
             nx = max(20, min(args.steps, 8000 // Sx))
             tx = time.perf_counter()
@@ -394,7 +399,7 @@ def main():
                                    "residual blocks, %.1f free keyframes on average)"
                                    % (args.frames, "in pinned host memory (H2D inside the step)" if args.host_images else "resident in HBM",
                                       rep["frames"] / max(rep["keyframes"], 1), frames_per_ba, L_, R_, Fk),
-                       "sessions_per_gpu": S, "lanes_per_group": lanes,
+                       "sessions_per_gpu": S, "lanes_per_group": lanes, "prime_frames": args.prime,
                        "local_mapping": {0: "off", 1: "inside the frame (synchronous)", 2: "optimizer threads"}.get(args.mapping, "?") +
                                         ("; a frame waits for a pass handed over >= %d frames ago" % args.mapping_max_lag
                                          if args.mapping == 2 and args.mapping_max_lag > 0 else ""),
