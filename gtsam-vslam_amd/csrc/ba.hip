@@ -1883,16 +1883,16 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
     struct Workspace {
         hipStream_t stream = nullptr;
         int device = -1;
-        DevBuf<DPose> d_pose0, d_poseS;
-        DevBuf<double> d_lm0, d_lmS, d_facJ, d_S, d_Spart, d_Sedge, d_dP, d_dL, d_lmDiff, d_sums, d_partial, d_Lg;
-        DevBuf<int> d_flags, d_pairKf, d_pairLm, d_pairOct, d_win, d_cholFail;
+        DevBuf<DPose> d_poseS;
+        DevBuf<double> d_lmS, d_facJ, d_S, d_Spart, d_Sedge, d_dP, d_dL, d_lmDiff, d_sums, d_partial, d_Lg;
+        DevBuf<int> d_flags, d_win, d_cholFail;
         DevBuf<double> d_cholY, d_winW, d_winH;
-        DevBuf<uint8_t> d_pairFlags, d_kfLocal, d_wrong;
-        DevBuf<float> d_pairUv;
+        DevBuf<uint8_t> d_wrong;
         PinnedArena arena;
         BaHostTmp tmp;
         BaPool pool;
         double* h_ctlOut = nullptr;
+        DevBuf<uint8_t> d_const; uint8_t* h_const = nullptr; size_t constCap = 0;      // the call's constant inputs, one block
         uint8_t* h_wrong = nullptr; size_t wrongCap = 0;
         // released when the owning host thread ends (or switches device): a short-lived optimizer thread must not
         // leak its stream, pinned buffers and pool threads
@@ -1900,13 +1900,15 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         void release() {
             if (device < 0 || hipSetDevice(device) != hipSuccess) return;
             if (stream) { hipStreamSynchronize(stream); hipStreamDestroy(stream); }
-            for (void* p : {(void*)d_pose0.p, (void*)d_poseS.p, (void*)d_lm0.p, (void*)d_lmS.p, (void*)d_facJ.p, (void*)d_S.p, (void*)d_Spart.p,
+            for (void* p : {(void*)d_poseS.p, (void*)d_lmS.p, (void*)d_facJ.p, (void*)d_S.p, (void*)d_Spart.p,
                             (void*)d_Sedge.p, (void*)d_dP.p, (void*)d_dL.p, (void*)d_lmDiff.p, (void*)d_sums.p, (void*)d_partial.p, (void*)d_Lg.p,
-                            (void*)d_win.p, (void*)d_cholFail.p, (void*)d_cholY.p, (void*)d_winW.p, (void*)d_winH.p, (void*)d_flags.p, (void*)d_pairKf.p, (void*)d_pairLm.p, (void*)d_pairOct.p, (void*)d_pairFlags.p,
-                            (void*)d_kfLocal.p, (void*)d_wrong.p, (void*)d_pairUv.p, (void*)arena.d})
+                            (void*)d_win.p, (void*)d_cholFail.p, (void*)d_cholY.p, (void*)d_winW.p, (void*)d_winH.p, (void*)d_flags.p,
+                            (void*)d_wrong.p, (void*)arena.d})
                 if (p) hipFree(p);
             if (arena.h) hipHostFree(arena.h);
             if (h_ctlOut) hipHostFree(h_ctlOut);
+            if (h_const) hipHostFree(h_const);
+            if (d_const.p) hipFree(d_const.p);
             if (h_wrong) hipHostFree(h_wrong);
         }
     };
@@ -1932,14 +1934,13 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
     g_baTimer.reset();
     g_baTimer.stream = stream;
     g_baTimer.multi = true;
-    auto &d_pose0 = ws->d_pose0, &d_poseS = ws->d_poseS;
-    auto &d_lm0 = ws->d_lm0, &d_lmS = ws->d_lmS, &d_facJ = ws->d_facJ, &d_S = ws->d_S, &d_Spart = ws->d_Spart,
+    auto &d_poseS = ws->d_poseS;
+    auto &d_lmS = ws->d_lmS, &d_facJ = ws->d_facJ, &d_S = ws->d_S, &d_Spart = ws->d_Spart,
          &d_Sedge = ws->d_Sedge, &d_dP = ws->d_dP, &d_dL = ws->d_dL, &d_lmDiff = ws->d_lmDiff, &d_sums = ws->d_sums, &d_partial = ws->d_partial, &d_Lg = ws->d_Lg,
          &d_cholY = ws->d_cholY;
     auto &d_win = ws->d_win, &d_cholFail = ws->d_cholFail;
-    auto &d_flags = ws->d_flags, &d_pairKf = ws->d_pairKf, &d_pairLm = ws->d_pairLm, &d_pairOct = ws->d_pairOct;
-    auto &d_pairFlags = ws->d_pairFlags, &d_kfLocal = ws->d_kfLocal, &d_wrong = ws->d_wrong;
-    auto &d_pairUv = ws->d_pairUv;
+    auto &d_flags = ws->d_flags;
+    auto &d_wrong = ws->d_wrong;
 
     std::vector<DPose> pose0(K);
     for (int k = 0; k < K; k++) pose_from_rm16(P->kf_pose_wc + 16 * (size_t)k, pose0[k]);
@@ -1951,27 +1952,48 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
     // travel in one all-reduce, the control step walks them identically on every rank)
     const int NB = nbSet > 0 ? std::min(nbSet, (int)BA_MAX_NB) : nbEnv, nSlots = NB + 1;
     const bool specLin = specSet >= 0 ? specSet != 0 : specEnv;
-    VS_HIP(d_pose0.alloc(K)); VS_HIP(d_poseS.alloc((size_t)nSlots * K));
-    VS_HIP(d_lm0.alloc((size_t)3 * L)); VS_HIP(d_lmS.alloc((size_t)nSlots * 3 * L));
-    VS_HIP(hipMemcpyAsync(d_pose0.p, pose0.data(), K * sizeof(DPose), hipMemcpyHostToDevice, stream));
-    if (L) VS_HIP(hipMemcpyAsync(d_lm0.p, P->lm_xyz, (size_t)3 * L * sizeof(double), hipMemcpyHostToDevice, stream));
-    VS_HIP(d_pairKf.alloc(NP)); VS_HIP(d_pairLm.alloc(NP)); VS_HIP(d_pairOct.alloc((size_t)2 * NP));
-    VS_HIP(d_pairFlags.alloc(NP)); VS_HIP(d_pairUv.alloc((size_t)4 * NP)); VS_HIP(d_wrong.alloc(NP));
-    VS_HIP(d_kfLocal.alloc(K));
-    if (NP) {
-        VS_HIP(hipMemcpyAsync(d_pairKf.p, P->pair_kf, NP * sizeof(int), hipMemcpyHostToDevice, stream));
-        VS_HIP(hipMemcpyAsync(d_pairLm.p, P->pair_lm, NP * sizeof(int), hipMemcpyHostToDevice, stream));
-        VS_HIP(hipMemcpyAsync(d_pairOct.p, P->pair_octave, (size_t)2 * NP * sizeof(int), hipMemcpyHostToDevice, stream));
-        VS_HIP(hipMemcpyAsync(d_pairFlags.p, P->pair_flags, NP, hipMemcpyHostToDevice, stream));
-        VS_HIP(hipMemcpyAsync(d_pairUv.p, P->pair_uv, (size_t)4 * NP * sizeof(float), hipMemcpyHostToDevice, stream));
+    // the call's constant inputs (initial poses / landmarks, the pair arrays, kf_local) travel in ONE copy through a pinned
+    // staging block into one device block (they used to be eight pageable copies)
+    VS_HIP(d_poseS.alloc((size_t)nSlots * K));
+    VS_HIP(d_lmS.alloc((size_t)nSlots * 3 * L));
+    VS_HIP(d_wrong.alloc(NP));
+    size_t cBytes = 0;
+    auto cOff = [&](size_t bytes) { const size_t at = cBytes; cBytes = (cBytes + std::max<size_t>(bytes, 8) + 255) & ~(size_t)255; return at; };
+    const size_t oPose0 = cOff((size_t)K * sizeof(DPose)), oLm0 = cOff((size_t)3 * L * sizeof(double)), oPairKf = cOff((size_t)NP * 4),
+                 oPairLm = cOff((size_t)NP * 4), oPairOct = cOff((size_t)2 * NP * 4), oPairFlags = cOff((size_t)NP), oPairUv = cOff((size_t)4 * NP * 4),
+                 oKfLocal = cOff((size_t)K);
+    if (cBytes > ws->constCap) {
+        VS_HIP(hipStreamSynchronize(stream));
+        if (ws->h_const) hipHostFree(ws->h_const);
+        ws->h_const = nullptr;
+        ws->constCap = cBytes + cBytes / 4;
+        VS_HIP(hipHostMalloc((void**)&ws->h_const, ws->constCap, hipHostMallocDefault));
+        VS_HIP(ws->d_const.alloc(ws->constCap));
     }
-    VS_HIP(hipMemcpyAsync(d_kfLocal.p, P->kf_local, K, hipMemcpyHostToDevice, stream));
+    {
+        uint8_t* h = ws->h_const;
+        memcpy(h + oPose0, pose0.data(), (size_t)K * sizeof(DPose));
+        if (L) memcpy(h + oLm0, P->lm_xyz, (size_t)3 * L * sizeof(double));
+        if (NP) {
+            memcpy(h + oPairKf, P->pair_kf, (size_t)NP * 4); memcpy(h + oPairLm, P->pair_lm, (size_t)NP * 4);
+            memcpy(h + oPairOct, P->pair_octave, (size_t)2 * NP * 4); memcpy(h + oPairFlags, P->pair_flags, NP);
+            memcpy(h + oPairUv, P->pair_uv, (size_t)4 * NP * 4);
+        }
+        memcpy(h + oKfLocal, P->kf_local, K);
+        VS_HIP(hipMemcpyAsync(ws->d_const.p, h, cBytes, hipMemcpyHostToDevice, stream));
+    }
+    uint8_t* const dc = ws->d_const.p;
+    DPose* const p_pose0 = (DPose*)(dc + oPose0);
+    double* const p_lm0 = (double*)(dc + oLm0);
+    const int* const p_pairKf = (const int*)(dc + oPairKf); const int* const p_pairLm = (const int*)(dc + oPairLm);
+    const int* const p_pairOct = (const int*)(dc + oPairOct); const uint8_t* const p_pairFlags = dc + oPairFlags;
+    const float* const p_pairUv = (const float*)(dc + oPairUv); const uint8_t* const p_kfLocal = dc + oKfLocal;
     VS_HIP(d_sums.alloc(32));
     if (!d_flags.p) { VS_HIP(d_flags.alloc(16)); VS_HIP(hipMemsetAsync(d_flags.p, 0, 16 * sizeof(int), stream)); }
 
     std::vector<uint8_t> wrong(NP, 0);
-    DPose* poseFinal = d_pose0.p;
-    double* lmFinal = d_lm0.p;
+    DPose* poseFinal = p_pose0;
+    double* lmFinal = p_lm0;
     const int nCU = 256;
     auto& A = ws->arena;
     auto& T = ws->tmp;
@@ -2138,7 +2160,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         {
             const int nPose = K * (int)(sizeof(DPose) / sizeof(double)), nLm = 3 * L;
             hipLaunchKernelGGL(k_ba_init_slots, dim3((std::max(nPose, nLm) + 255) / 256, nSlots), dim3(256), 0, stream,
-                               nPose, (const double*)d_pose0.p, (double*)d_poseS.p, nLm, d_lm0.p, d_lmS.p);
+                               nPose, (const double*)p_pose0, (double*)d_poseS.p, nLm, p_lm0, d_lmS.p);
         }
 
         BaDev D{};
@@ -2373,9 +2395,9 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
             const int tc = g_baTimer.begin("ba_allreduce");
             if (L) {
                 VS_HIP(d_lmDiff.alloc((size_t)3 * L));
-                hipLaunchKernelGGL(k_ba_lm_diff, dim3((3 * L + 255) / 256), dim3(256), 0, stream, 3 * L, D.lmCur, d_lm0.p, d_lmDiff.p, 0);
+                hipLaunchKernelGGL(k_ba_lm_diff, dim3((3 * L + 255) / 256), dim3(256), 0, stream, 3 * L, D.lmCur, p_lm0, d_lmDiff.p, 0);
                 VS_CHECK(comm_allreduce(comm, d_lmDiff.p, (size_t)3 * L, stream));
-                hipLaunchKernelGGL(k_ba_lm_apply, dim3((3 * L + 255) / 256), dim3(256), 0, stream, 3 * L, D.lmCur, d_lm0.p, d_lmDiff.p);
+                hipLaunchKernelGGL(k_ba_lm_apply, dim3((3 * L + 255) / 256), dim3(256), 0, stream, 3 * L, D.lmCur, p_lm0, d_lmDiff.p);
             }
             double st[4] = {(double)nfStat, (double)lpStat, (double)k2Stat, 0.0};
             VS_HIP(hipMemcpyAsync(d_sums.p + 4, st, sizeof(st), hipMemcpyHostToDevice, stream));
@@ -2388,8 +2410,8 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         BHS("lm");
         // ---- chi2 re-check with the optimised values ---------------------------------------------
         BaChi C{};
-        C.NP = NP; C.pairKf = d_pairKf.p; C.pairLm = d_pairLm.p; C.pairFlags = d_pairFlags.p; C.pairUv = d_pairUv.p;
-        C.pairOct = d_pairOct.p; C.kfLocal = d_kfLocal.p; C.kfPresent = A.dev(h_kfPresent); C.lmPresent = A.dev(h_lmPresent);
+        C.NP = NP; C.pairKf = p_pairKf; C.pairLm = p_pairLm; C.pairFlags = p_pairFlags; C.pairUv = p_pairUv;
+        C.pairOct = p_pairOct; C.kfLocal = p_kfLocal; C.kfPresent = A.dev(h_kfPresent); C.lmPresent = A.dev(h_lmPresent);
         C.pose = D.poseCur; C.lm = D.lmCur; C.wrong = d_wrong.p;
         for (int l = 0; l < P->n_levels; l++) C.thr[l] = (float)((double)7.815f * (double)P->sigma_factor[l]);
         C.fx = D.fx; C.fy = D.fy; C.cx = D.cx; C.cy = D.cy; C.b = D.b;
@@ -2444,7 +2466,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
                 {
                     const int nPose = K * (int)(sizeof(DPose) / sizeof(double)), nLm = 3 * L;
                     hipLaunchKernelGGL(k_ba_init_slots, dim3((std::max(nPose, nLm) + 255) / 256, nSlots), dim3(256), 0, stream,
-                                       nPose, (const double*)d_pose0.p, (double*)d_poseS.p, nLm, d_lm0.p, d_lmS.p);
+                                       nPose, (const double*)p_pose0, (double*)d_poseS.p, nLm, p_lm0, d_lmS.p);
                 }
                 VS_CHECK(run_lm(1, NF2, Lp2, k2));
                 break;

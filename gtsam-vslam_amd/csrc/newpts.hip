@@ -522,10 +522,11 @@ extern "C" vslam_status vslam_find_new_points(const vslam_new_points_problem* P,
     const int cap = std::max(K0.n_left, 1);
     NpArgs A{};
     A.nKf = P->n_kf;
-    Dev<vslam_keypoint> dKL[NP_MAX_KF], dKR[NP_MAX_KF];
-    Dev<uint8_t> dDL[NP_MAX_KF], dDR[NP_MAX_KF];
-    Dev<int> dRi[NP_MAX_KF], dLi[NP_MAX_KF], dUf[NP_MAX_KF], dUfr[NP_MAX_KF];
-    for (int k = 0; k < NP_MAX_KF; k++) dKL[k].pool = dKR[k].pool = dDL[k].pool = dDR[k].pool = dRi[k].pool = dLi[k].pool = dUf[k].pool = dUfr[k].pool = pool;
+    // every keyframe's arrays travel in ONE copy (one device block, one pinned staging area) when the pool's staging has room:
+    // eight uploads per keyframe were ~70 small blit launches per call
+    size_t packBytes = 0;
+    auto packOff = [&](size_t bytes) { const size_t at = packBytes; packBytes = (packBytes + bytes + 63) & ~(size_t)63; return at; };
+    struct KfOff { size_t kl, kr, dl, dr, ri, li, uf, ufr; } off[NP_MAX_KF];
     for (int k = 0; k < P->n_kf; k++) {
         const vslam_kf_view& V = P->kfs[k];
         if (V.n_left < 0 || V.n_right < 0 || !V.T_wc || (V.n_left > 0 && (!V.kps_l || !V.desc_l || !V.right_idxs || !V.unmatched_f)) ||
@@ -533,18 +534,36 @@ extern "C" vslam_status vslam_find_new_points(const vslam_new_points_problem* P,
             set_error("vslam_find_new_points: keyframe %d arrays missing", k);
             return VSLAM_ERR_INVALID;
         }
+        off[k].kl = packOff((size_t)V.n_left * sizeof(vslam_keypoint)); off[k].kr = packOff((size_t)V.n_right * sizeof(vslam_keypoint));
+        off[k].dl = packOff((size_t)V.n_left * 32); off[k].dr = packOff((size_t)V.n_right * 32);
+        off[k].ri = packOff((size_t)V.n_left * 4); off[k].li = packOff((size_t)V.n_right * 4);
+        off[k].uf = packOff((size_t)V.n_left * 4); off[k].ufr = packOff((size_t)V.n_right * 4);
+    }
+    Dev<uint8_t> dPack(pool);
+    VS_HIP(dPack.alloc(std::max<size_t>(packBytes, 64)));
+    uint8_t* hPack = pool->stage(packBytes);
+    for (int k = 0; k < P->n_kf; k++) {
+        const vslam_kf_view& V = P->kfs[k];
         NpKf& D = A.kf[k];
         pose_from_rm16(V.T_wc, D.Twc);
         pose_inverse(D.Twc, D.Tcw);
-        VS_HIP(dKL[k].up(V.kps_l, V.n_left)); VS_HIP(dKR[k].up(V.kps_r, V.n_right));
-        VS_HIP(dDL[k].up(V.desc_l, (size_t)V.n_left * 32)); VS_HIP(dDR[k].up(V.desc_r, (size_t)V.n_right * 32));
-        VS_HIP(dRi[k].up(V.right_idxs, V.n_left)); VS_HIP(dLi[k].up(V.left_idxs, V.n_right));
-        VS_HIP(dUf[k].up(V.unmatched_f, V.n_left)); VS_HIP(dUfr[k].up(V.unmatched_fr, V.n_right));
-        D.kpsL = dKL[k].p; D.kpsR = dKR[k].p; D.descL = dDL[k].p; D.descR = dDR[k].p;
-        D.rightIdxs = dRi[k].p; D.leftIdxs = dLi[k].p; D.unF = dUf[k].p; D.unFR = dUfr[k].p;
+        auto put = [&](size_t at, const void* src, size_t bytes) -> hipError_t {
+            if (!bytes) return hipSuccess;
+            if (hPack) { memcpy(hPack + at, src, bytes); return hipSuccess; }
+            return pool->h2d(dPack.p + at, src, bytes);          // (no staging room: one copy per array, as before)
+        };
+        VS_HIP(put(off[k].kl, V.kps_l, (size_t)V.n_left * sizeof(vslam_keypoint))); VS_HIP(put(off[k].kr, V.kps_r, (size_t)V.n_right * sizeof(vslam_keypoint)));
+        VS_HIP(put(off[k].dl, V.desc_l, (size_t)V.n_left * 32)); VS_HIP(put(off[k].dr, V.desc_r, (size_t)V.n_right * 32));
+        VS_HIP(put(off[k].ri, V.right_idxs, (size_t)V.n_left * 4)); VS_HIP(put(off[k].li, V.left_idxs, (size_t)V.n_right * 4));
+        VS_HIP(put(off[k].uf, V.unmatched_f, (size_t)V.n_left * 4)); VS_HIP(put(off[k].ufr, V.unmatched_fr, (size_t)V.n_right * 4));
+        D.kpsL = (const vslam_keypoint*)(dPack.p + off[k].kl); D.kpsR = (const vslam_keypoint*)(dPack.p + off[k].kr);
+        D.descL = dPack.p + off[k].dl; D.descR = dPack.p + off[k].dr;
+        D.rightIdxs = (const int*)(dPack.p + off[k].ri); D.leftIdxs = (const int*)(dPack.p + off[k].li);
+        D.unF = (const int*)(dPack.p + off[k].uf); D.unFR = (const int*)(dPack.p + off[k].ufr);
         D.nL = V.n_left; D.nR = V.n_right;
         D.skip = (k > 0 && V.id == P->kfs[0].id) ? 1 : 0;
     }
+    if (hPack && packBytes) VS_HIP(hipMemcpyAsync(dPack.p, hPack, packBytes, hipMemcpyHostToDevice, stream));
     Dev<float> dDepth(pool), dMds(pool); Dev<uint8_t> dHas(pool), dMpDesc(pool), dCdesc(pool), dAcc(pool); Dev<double> dMpXyz(pool), dWpos(pool), dXyz(pool);
     Dev<int> dKey(pool), dCount(pool), dMatch(pool), dNobs(pool), dObs(pool);
     VS_HIP(dDepth.up(P->estimated_depth, K0.n_left)); VS_HIP(dHas.up(P->has_mp, K0.n_left));
