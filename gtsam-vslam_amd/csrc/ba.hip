@@ -2375,8 +2375,9 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         const int* co = (const int*)(h_ctlOut + CTL_INTS);
         int enq = 0;
         for (;;) {
-            for (int b = 0; b < 4; b++) VS_CHECK(step(enq + b == 0));
-            enq += 4;
+            static const int perPoll = getenv("VSLAM_BA_STEPS_PER_POLL") ? std::max(1, atoi(getenv("VSLAM_BA_STEPS_PER_POLL"))) : 4;
+            for (int b = 0; b < perPoll; b++) VS_CHECK(step(enq + b == 0));
+            enq += perPoll;
             VS_HIP(hipMemcpyAsync(h_ctlOut, D.ctl, CTL_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, stream));
             VS_HIP(hipStreamSynchronize(stream));
             if (co[CI_STATE] == BA_DONE) break;
