@@ -460,6 +460,7 @@ __global__ __launch_bounds__(256) void k_calc_descriptor(int nMp, const uint8_t*
     if (m >= nMp) return;
     const int s0 = start[m], n = start[m + 1] - s0;
     if (n <= 0) { if (lane == 0) best[m] = -1; return; }
+    if (n > 64) return;                             // k_calc_descriptor_big
     uint32_t mine[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (lane < n) {
         const uint32_t* p = (const uint32_t*)(descs + (size_t)(s0 + lane) * 32);
@@ -491,6 +492,45 @@ __global__ __launch_bounds__(256) void k_calc_descriptor(int nMp, const uint8_t*
     for (int o = 32; o >= 1; o >>= 1) bm = min(bm, __shfl_xor(bm, o));
     const unsigned long long bal = __ballot(median == bm);
     if (lane == 0) best[m] = __ffsll((long long)bal) - 1;
+}
+
+// The same for a map point with MORE than 64 observation descriptors (long sessions that keep revisiting a place): one wave
+// per map point, lane = descriptor i (strided); the median of row i comes from a 257-bin histogram of its distances in LDS
+// (distances are 0 .. 256), the winner is the first i with the least median.
+__global__ __launch_bounds__(64) void k_calc_descriptor_big(int nMp, const uint8_t* __restrict__ descs, const int* __restrict__ start,
+                                                           int* __restrict__ best) {
+    __shared__ unsigned short hist[64][258];
+    const int lane = threadIdx.x, m = blockIdx.x;
+    if (m >= nMp) return;
+    const int s0 = start[m], n = start[m + 1] - s0;
+    if (n <= 64) return;
+    const int kth = (int)(0.5 * (n - 1));
+    int bestMed = 1 << 20, bestI = 1 << 30;
+    for (int i = lane; i < n; i += 64) {
+        unsigned short* h = hist[lane];
+        for (int v = 0; v < 258; v++) h[v] = 0;
+        uint32_t mine[8];
+        const uint32_t* p = (const uint32_t*)(descs + (size_t)(s0 + i) * 32);
+#pragma unroll
+        for (int q = 0; q < 8; q++) mine[q] = p[q];
+        for (int j = 0; j < n; j++) {
+            const uint32_t* o = (const uint32_t*)(descs + (size_t)(s0 + j) * 32);
+            int dd = 0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) dd += __popc(mine[q] ^ o[q]);
+            h[j == i ? 0 : dd]++;
+        }
+        int cum = 0, med = 256;
+        for (int v = 0; v <= 256; v++) { cum += h[v]; if (cum > kth) { med = v; break; } }
+        if (med < bestMed) { bestMed = med; bestI = i; }      // (i ascends within a lane: the first i of the least median stays)
+    }
+    // least (median, index) over the lanes
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const int om = __shfl_xor(bestMed, o), oi = __shfl_xor(bestI, o);
+        if (om < bestMed || (om == bestMed && oi < bestI)) { bestMed = om; bestI = oi; }
+    }
+    if (lane == 0) best[m] = bestI;
 }
 
 }  // namespace vslam
@@ -618,8 +658,11 @@ extern "C" vslam_status vslam_find_new_points(const vslam_new_points_problem* P,
 extern "C" vslam_status vslam_calc_descriptors(const uint8_t* descs, const int32_t* start, int32_t n_mp, int32_t device, int32_t* best_out) {
     if (n_mp < 0 || (n_mp > 0 && (!descs || !start || !best_out))) return VSLAM_ERR_INVALID;
     if (n_mp == 0) return VSLAM_OK;
-    for (int m = 0; m < n_mp; m++)
-        if (start[m + 1] < start[m] || start[m + 1] - start[m] > 64) { set_error("vslam_calc_descriptors: a map point has more than 64 observations"); return VSLAM_ERR_CAPACITY; }
+    bool anyBig = false;
+    for (int m = 0; m < n_mp; m++) {
+        if (start[m + 1] < start[m]) { set_error("vslam_calc_descriptors: start offsets must ascend"); return VSLAM_ERR_INVALID; }
+        anyBig |= start[m + 1] - start[m] > 64;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available (no CPU fallback)"); return VSLAM_ERR_NO_DEVICE; }
     if (device < 0 || device >= ndev) return VSLAM_ERR_INVALID;
@@ -629,6 +672,7 @@ extern "C" vslam_status vslam_calc_descriptors(const uint8_t* descs, const int32
     const size_t total = (size_t)start[n_mp];
     VS_HIP(dD.up(descs, total * 32)); VS_HIP(dS.up(start, (size_t)n_mp + 1)); VS_HIP(dB.alloc(n_mp));
     hipLaunchKernelGGL(k_calc_descriptor, dim3((n_mp + 3) / 4), dim3(256), 0, pool->stream, n_mp, dD.p, dS.p, dB.p);
+    if (anyBig) hipLaunchKernelGGL(k_calc_descriptor_big, dim3(n_mp), dim3(64), 0, pool->stream, n_mp, dD.p, dS.p, dB.p);
     VS_HIP(hipGetLastError());
     VS_HIP(pool->d2h(best_out, dB.p, (size_t)n_mp * sizeof(int)));
     VS_HIP(pool->sync());
