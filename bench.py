@@ -46,7 +46,7 @@ CONFIGS = {
                                                        "200 Hz IMU pre-integration factor in every pose solve"),
     "c3": dict(rig="kitti", nfeat=2000, imu=False, name="C3-class: KITTI-00-like stereo 1241x376, 2000 features/image"),
 }
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_b_pmc_summary.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_c_pmc_summary.json")
 
 
 def level_pixels(w, h, nlevels=8, scale=1.2):
@@ -191,8 +191,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c5"])
-    ap.add_argument("--sessions", type=int, default=64, help="independent SLAM sessions (sequences) sharing each GPU")
-    ap.add_argument("--lanes", type=int, default=32, help="sessions per lockstep group (vslam_batch: one launch per stage for all lanes of a group); "
+    ap.add_argument("--sessions", type=int, default=128, help="independent SLAM sessions (sequences) sharing each GPU")
+    ap.add_argument("--lanes", type=int, default=64, help="sessions per lockstep group (vslam_batch: one launch per stage for all lanes of a group); "
                                                           "0 = one host thread and one set of launches per session")
     ap.add_argument("--frames", type=int, default=0, help="distinct rendered stereo frames of the replayed sequence (0: 100 for c1 / c2, 60 for c3)")
     ap.add_argument("--frame-step", type=int, default=0, help="source frames between two sequence frames (0: 2 for c1 / c2, 1 for c3: the "

@@ -5,7 +5,7 @@ TAG=${1:-r02_x}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 REPO=$PWD
-PROF_SHAPE="--sessions 32 --lanes 32"      # under rocprofv3: one lockstep group (the tool has crashed inside hipLaunchKernel with 8+ launching threads)
+PROF_SHAPE="--sessions 64 --lanes 64"      # under rocprofv3: one lockstep group (the tool has crashed inside hipLaunchKernel with 8+ launching threads)
 if [ -z "$SKIP_BENCH" ]; then
 python3 bench.py > $OUT/${TAG}_c2_bench.json 2> $OUT/c2.err || exit 1
 echo "c2 bench done"; cut -c1-160 $OUT/${TAG}_c2_bench.json
@@ -13,7 +13,7 @@ python3 bench.py --config c3 > $OUT/${TAG}_c3_bench.json 2> $OUT/c3.err || exit 
 echo "c3 bench done"
 python3 bench.py --host-images --no-cpu-baseline --no-latency-line > $OUT/${TAG}_c2_bench_host_images.json 2> $OUT/hi.err || exit 1
 echo "host-images bench done"
-python3 bench.py --no-cpu-baseline --no-latency-line --steps 100 --sweep 1x0,1x1,2x2,4x4,8x8,16x16,32x32,64x32,96x48,128x64 > $OUT/${TAG}_c2_sweep.json 2> $OUT/sw.err || exit 1
+python3 bench.py --no-cpu-baseline --no-latency-line --steps 100 --sweep 1x0,1x1,2x2,4x4,8x8,16x16,32x32,64x64,64x32,128x64,256x128 > $OUT/${TAG}_c2_sweep.json 2> $OUT/sw.err || exit 1
 echo "sweep done"
 fi
 cd /tmp && export TMPDIR=/tmp
