@@ -46,7 +46,7 @@ CONFIGS = {
                                                        "200 Hz IMU pre-integration factor in every pose solve"),
     "c3": dict(rig="kitti", nfeat=2000, imu=False, name="C3-class: KITTI-00-like stereo 1241x376, 2000 features/image"),
 }
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_c_pmc_summary.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_d_pmc_summary.json")
 
 
 def level_pixels(w, h, nlevels=8, scale=1.2):
@@ -353,7 +353,6 @@ def main():
         lb = max(lanes, 1)
         nStep = max(cnt["frames"] / lb, 1)         # sampled steps
         # kernel group -> (launches over the sampled region, algorithmic bytes per launch, algorithmic flops per launch)
-        b_stereo = nk * (28 + 32) * 2 + nk * 16 + nk * 24
         b_cand, b_res = Mact * 60 + 2 * nk * 60 + Mact * 128, Mact * (128 + 8 + 8) + 2 * nk * 8
         b_pose = Mact * (24 + 8 + 4) + 2 * nk * 28 + (8 * 514 if cfg["imu"] else 0)
         groups = {
@@ -363,19 +362,17 @@ def main():
             "ssc": (nStep, lb * nimg * (8 * 3.3 * nfeat + 4 * nk), 0),                      # candidates in, picks out
             "blur": (nStep, lb * nimg * (2 * sumP), 0),                                    # read + write every level
             "orient_desc": (nStep, lb * nimg * nk * (28 + 32 + 709 + 512), 0),             # keypoint + descriptor + disc + BRIEF taps
-            "stereo": (nStep, lb * b_stereo, 0),                                           # match + finalize (batched: one timer)
-            "stereo_match": (nStep, nk * (28 + 32) * 2 + nk * 16, 0),
-            "stereo_finalize": (nStep, nk * 24, 0),
+            "stereo_rows": (nStep, lb * nk * 28, 0),
+            "stereo_match": (nStep, lb * (nk * (28 + 32) * 2 + nk * 16), 0),
+            "stereo_finalize": (nStep, lb * nk * 24, 0),
             "track_predict": (nStep, lb * (nk * (24 + 32 + 5) + Mact * (60 + 24 + 12)), 0),
             "track_repredict": (nStep, lb * Mact * (24 + 60 + 12), 0),
             "pack": (nStep, lb * (Mact * 30 + nk * 8), 0),
             "imu_preintegrate": (2 * nStep, lb * (10 * 56 + 8 * (289 + 225)), lb * (10 * 2 * 2 * 15 ** 3 + 15 ** 3)),
-            "proj_match": (2 * nStep, lb * (b_cand + b_res), 0),                           # candidates + resolve, two passes per frame
-            "pose_solve": (2 * nStep, lb * b_pose, 0),                                     # two solves per frame
-            "proj_candidates": (2 * nStep, b_cand, 0),
-            "proj_resolve": (2 * nStep, b_res, 0),
-            "pose_imu_lm": (2 * nStep, b_pose, 0),
-            "pose_lm": (2 * nStep, b_pose, 0),
+            "proj_candidates": (2 * nStep, lb * b_cand, 0),                                # two passes per frame
+            "proj_resolve": (2 * nStep, lb * b_res, 0),
+            "pose_imu_lm": (2 * nStep, lb * b_pose, 0),                                    # two solves per frame
+            "pose_lm": (2 * nStep, lb * b_pose, 0),
             "ba_linearize": (nBA * linPerBA, R_ * (8 + 16 + 8 + 96 + 24 + 160), 0),          # idx, uv, sigma, pose, point, stored J
             "ba_schur": (nBA * trialsPerBA, R_ * 160 + L_ * 24, 2 * 36 * k2),                 # stored J read once (S stays in LDS)
             "ba_solve": (nBA * trialsPerBA, 8 * (nBA6 * nBA6 + nBA6) * 2, nBA6 ** 3 / 3.0),   # reduced system in, delta out
@@ -436,11 +433,13 @@ def main():
                             "serve one session); aggregate_* = the same group's algorithmic bytes over all sessions / wall time"}
             try:
                 pmc = json.load(open(PMC_FILE))
-                kname = {"proj_resolve": "k_proj_resolve", "pose_imu_lm": "k_pose_imu_lm", "pose_solve": "k_pose_imu_lm_b" if cfg["imu"] else "k_pose_lm_b",
-                         "stereo": "k_stereo_match_b", "proj_match": "k_proj_candidates_b", "imu_preintegrate": "k_imu_preintegrate_b", "ba_solve": "k_ba_solve_mfma64", "ssc": "k_ssc<false>",
+                bsfx = "_b" if lanes > 0 else ""
+                kname = {"proj_resolve": "k_proj_resolve" + bsfx, "pose_imu_lm": "k_pose_imu_lm" + bsfx, "pose_lm": "k_pose_lm" + bsfx,
+                         "stereo_match": "k_stereo_match" + bsfx, "stereo_finalize": "k_stereo_finalize" + bsfx, "stereo_rows": "k_stereo_rows" + bsfx,
+                         "proj_candidates": "k_proj_candidates" + bsfx, "imu_preintegrate": "k_imu_preintegrate" + bsfx,
+                         "track_predict": "k_track_predict" + bsfx, "pyramid": "k_resize", "ba_solve": "k_ba_solve_mfma64", "ssc": "k_ssc<false>",
                          "ba_schur": "k_ba_schur", "ba_back": "k_ba_back", "ba_eval": "k_ba_factors<1>", "ba_linearize": "k_ba_factors<0>",
-                         "fast": "k_fast", "blur": "k_blur", "gather": "k_gather", "stereo_match": "k_stereo_match",
-                         "orient_desc": "k_orient_desc", "proj_candidates": "k_proj_candidates", "pose_lm": "k_pose_lm"}.get(dom)
+                         "fast": "k_fast", "blur": "k_blur", "gather": "k_gather", "orient_desc": "k_orient_desc"}.get(dom)
                 if kname in pmc:
                     roof["traffic"] = (2.0 * pmc[kname]["FETCH_SIZE_avg"] + pmc[kname]["WRITE_SIZE_avg"]) * 1024.0
                     roof["traffic_source"] = os.path.relpath(PMC_FILE, ROOT) + " (2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, per launch)"

@@ -420,9 +420,8 @@ vslam_status vslam_batch::step(const uint8_t* const* L, const uint8_t* const* R,
     VS_HIP(hipMemcpyAsync(d_tab, h_tab, tabBytes, hipMemcpyHostToDevice, stream));
 
     // ---- device: every stage once for all lanes --------------------------------------------------------------------------------
-    int t = timer.begin("stereo");
-    launch_stereo_batch(stream, dt.stereo, B, maxL, maxR, sys[0]->cfg.rig.height);
-    timer.end(t);
+    int t;
+    launch_stereo_batch(stream, dt.stereo, B, maxL, maxR, sys[0]->cfg.rig.height, &timer);
     // (stage timing brackets launches with events on the main stream: keep the pre-integrations there when it is on)
     static const bool sideEnv = getenv("VSLAM_BATCH_IMU_SIDE") ? atoi(getenv("VSLAM_BATCH_IMU_SIDE")) != 0 : true;
     const bool side = useImu && !timer.enabled && sideEnv;
@@ -435,9 +434,9 @@ vslam_status vslam_batch::step(const uint8_t* const* L, const uint8_t* const* R,
         }
         t = timer.begin("track_predict"); launch_track_predict_batch(stream, dt.predict, B); timer.end(t);
         if (useImu && !side) { t = timer.begin("imu_preintegrate"); launch_imu_batch(stream, dt.imu0, B); timer.end(t); }
-        t = timer.begin("proj_match"); launch_proj_batch(stream, dt.proj0, B, maxN, maxL, maxR); timer.end(t);
+        launch_proj_batch(stream, dt.proj0, B, maxN, maxL, maxR, &timer);
         if (side) VS_HIP(hipStreamWaitEvent(stream, evImu0, 0));
-        t = timer.begin("pose_solve");
+        t = timer.begin(useImu ? "pose_imu_lm" : "pose_lm");
         if (useImu) launch_pose_imu_batch(stream, dt.pose0, B, ldsFactors); else launch_pose_batch(stream, dt.pose0, B);
         timer.end(t);
         if (side) {
@@ -447,9 +446,9 @@ vslam_status vslam_batch::step(const uint8_t* const* L, const uint8_t* const* R,
             VS_HIP(hipEventRecord(evImu1, imuStream));
         } else if (useImu) { t = timer.begin("imu_preintegrate"); launch_imu_batch(stream, dt.imu1, B); timer.end(t); }
         t = timer.begin("track_repredict"); launch_track_repredict_batch(stream, dt.repredict, B, maxN); timer.end(t);
-        t = timer.begin("proj_match"); launch_proj_batch(stream, dt.proj1, B, maxN, maxL, maxR); timer.end(t);
+        launch_proj_batch(stream, dt.proj1, B, maxN, maxL, maxR, &timer);
         if (side) VS_HIP(hipStreamWaitEvent(stream, evImu1, 0));
-        t = timer.begin("pose_solve");
+        t = timer.begin(useImu ? "pose_imu_lm" : "pose_lm");
         if (useImu) launch_pose_imu_batch(stream, dt.pose1, B, ldsFactors); else launch_pose_batch(stream, dt.pose1, B);
         timer.end(t);
         t = timer.begin("pack"); launch_track_pack_batch(stream, dt.pack, B, maxN); timer.end(t);

@@ -171,7 +171,7 @@ struct StereoLane {          // one lane (stereo pair) of the batched stereo ker
     int* mBest; float* mDepth; int* mSad; unsigned long long* stats;
     float closeDepth; int* rightIdxs; int* leftIdxs; float* depth; uint8_t* closef;
 };
-void launch_stereo_batch(hipStream_t s, const StereoLane* dLanes, int B, int maxL, int maxR, int imageHeight);
+void launch_stereo_batch(hipStream_t s, const StereoLane* dLanes, int B, int maxL, int maxR, int imageHeight, StageTimer* tm = nullptr);
 void launch_stereo_match(hipStream_t s, const StereoArgs& A, int* mBest, float* mDepth, int* mSad,
                          unsigned long long* stats);
 void launch_stereo_finalize(hipStream_t s, int nL, int nR, const int* mBest, const float* mDepth,
@@ -194,7 +194,7 @@ struct ProjLane {            // one lane of the batched projection matching
     ProjArgs A;
     int* matches; unsigned long long* topk; unsigned long long* stats; int* matchedL; int* matchedR; int* out;
 };
-void launch_proj_batch(hipStream_t s, const ProjLane* dLanes, int B, int maxM, int maxL, int maxR);
+void launch_proj_batch(hipStream_t s, const ProjLane* dLanes, int B, int maxM, int maxL, int maxR, StageTimer* tm = nullptr);
 void launch_proj_candidates(hipStream_t s, const ProjArgs& A, const int* matches,
                             unsigned long long* topk, unsigned long long* stats);
 void launch_proj_resolve(hipStream_t s, const ProjArgs& A, const unsigned long long* topk, int* matchedL, int* matchedR,

@@ -435,12 +435,15 @@ static void proj_attrs() {
 }
 
 // all lanes' projection matching in two launches; maxM / maxL / maxR: the largest counts over the lanes
-void launch_proj_batch(hipStream_t s, const ProjLane* dLanes, int B, int maxM, int maxL, int maxR) {
+void launch_proj_batch(hipStream_t s, const ProjLane* dLanes, int B, int maxM, int maxL, int maxR, StageTimer* tm) {
     if (B <= 0 || maxM <= 0) return;
     proj_attrs();
     const int forceSeq = getenv("VSLAM_PROJ_SEQUENTIAL") ? 1 : 0;
+    int t = tm ? tm->begin("proj_candidates") : -1;
     hipLaunchKernelGGL(k_proj_candidates_b, dim3((2 * maxM + 3) / 4, B), dim3(256), 0, s, dLanes);
+    if (tm) { tm->end(t); t = tm->begin("proj_resolve"); }
     hipLaunchKernelGGL(k_proj_resolve_b, dim3(B), dim3(PROJ_NT), proj_resolve_lds(maxL, maxR), s, dLanes, forceSeq);
+    if (tm) tm->end(t);
 }
 
 void launch_proj_resolve(hipStream_t s, const ProjArgs& A, const unsigned long long* topk, int* matchedL, int* matchedR,

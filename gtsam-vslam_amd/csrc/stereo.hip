@@ -445,13 +445,17 @@ static vslam_status stereo_attrs() {
 }
 
 // all lanes' stereo matches in two launches (maxL / maxR: the largest key counts over the lanes)
-void launch_stereo_batch(hipStream_t s, const StereoLane* dLanes, int B, int maxL, int maxR, int imageHeight) {
+void launch_stereo_batch(hipStream_t s, const StereoLane* dLanes, int B, int maxL, int maxR, int imageHeight, StageTimer* tm) {
     if (B <= 0 || (maxL <= 0 && maxR <= 0)) return;
     (void)stereo_attrs();
     const size_t shF = (size_t)(maxL > 0 ? maxL : 1) * 20;
+    int t = tm ? tm->begin("stereo_rows") : -1;
     hipLaunchKernelGGL(k_stereo_rows_b, dim3(B), dim3(1024), (size_t)(imageHeight + 1) * sizeof(int), s, dLanes);
+    if (tm) { tm->end(t); t = tm->begin("stereo_match"); }
     if (maxL > 0) hipLaunchKernelGGL(k_stereo_match_b, dim3((maxL + 3) / 4, B), dim3(256), 0, s, dLanes);
+    if (tm) { tm->end(t); t = tm->begin("stereo_finalize"); }
     hipLaunchKernelGGL(k_stereo_finalize_b, dim3(B), dim3(1024), shF, s, dLanes);
+    if (tm) tm->end(t);
 }
 
 }  // namespace vslam

@@ -5,7 +5,8 @@ TAG=${1:-r02_x}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 REPO=$PWD
-PROF_SHAPE="--sessions 64 --lanes 64"      # under rocprofv3: one lockstep group (the tool has crashed inside hipLaunchKernel with 8+ launching threads)
+PROF_SHAPE=""                                   # kernel trace: the default command (two lockstep groups)
+PMC_SHAPE="--sessions 64 --lanes 64"            # counter passes: ONE group (rocprofv3 --pmc segfaults with two groups' launching threads)
 if [ -z "$SKIP_BENCH" ]; then
 python3 bench.py > $OUT/${TAG}_c2_bench.json 2> $OUT/c2.err || exit 1
 echo "c2 bench done"; cut -c1-160 $OUT/${TAG}_c2_bench.json
@@ -17,12 +18,14 @@ python3 bench.py --no-cpu-baseline --no-latency-line --steps 100 --sweep 1x0,1x1
 echo "sweep done"
 fi
 cd /tmp && export TMPDIR=/tmp
+if [ -z "$SKIP_TRACE" ]; then
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 $REPO/bench.py --no-cpu-baseline --no-latency-line --steps 100 --warmup 10 $PROF_SHAPE > $OUT/${TAG}_c2_bench_under_rocprof.json 2> $OUT/kt.err || exit 1
 cp $OUT/kt/kt_kernel_stats.csv $OUT/${TAG}_c2_kernel_stats.csv
 echo "kernel trace done"
+fi
 for C in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CYCLES SQ_WAVES"; do
   N=$(echo $C | cut -d' ' -f1)
-  timeout -k 10 500 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$N -o p -- python3 $REPO/bench.py --no-cpu-baseline --no-latency-line --steps 60 --warmup 10 $PROF_SHAPE > $OUT/pmc_$N.json 2> $OUT/pmc_$N.err || exit 1
+  timeout -k 10 500 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$N -o p -- python3 $REPO/bench.py --no-cpu-baseline --no-latency-line --steps 60 --warmup 10 $PMC_SHAPE > $OUT/pmc_$N.json 2> $OUT/pmc_$N.err || exit 1
   echo "pmc $N done"
 done
 cd $REPO
