@@ -201,88 +201,91 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, P
     for (int i = lane; i < detW + 2; i += 64) { sc[i] = 0; sc[(detH + 1) * TP + i] = 0; }
     for (int i = lane; i < detH + 2; i += 64) { sc[i * TP] = 0; sc[i * TP + detW + 1] = 0; }
 
-    const int tq = minThr < maxThr ? minThr : maxThr;  // quick-reject threshold
     const int ro[16] = {3 * TP,      3 * TP + 1,  2 * TP + 2,  TP + 3,  3,       -TP + 3,
                         -2 * TP + 2, -3 * TP + 1, -3 * TP,     -3 * TP - 1, -2 * TP - 2, -TP - 3,
                         -3,          TP - 3,      2 * TP - 2,  3 * TP - 1};
     const unsigned long long lt = (1ull << lane) - 1ull;
-    int h1 = 0, t1 = 0, h2 = 0, t2 = 0;                // queue heads / tails (wave-uniform)
-
-    auto stage3 = [&](int rc, bool valid) {
-        if (valid) {
-            const int r = rc >> 7, c = rc & 127;
-            sc[(r + 1) * TP + (c + 1)] = (uint8_t)fast_score(&tile[(r + 3) * TP + (c + 3 + xoff)], ro);
-        }
-    };
-    auto drain2 = [&](bool all) {
-        while (t2 - h2 >= 64 || (all && t2 > h2)) {
-            const bool valid = lane < t2 - h2;
-            const int rc = valid ? q2[(h2 + lane) & FQ_MASK] : 0;
-            h2 += min(64, t2 - h2);
-            stage3(rc, valid);
-        }
-    };
-    auto stage2 = [&](int rc, bool valid) {
-        bool pass = false;
-        if (valid) {
-            const int r = rc >> 7, c = rc & 127;
-            const uint8_t* p = &tile[(r + 3) * TP + (c + 3 + xoff)];
-            const int v = p[0], lo = v - tq, hi = v + tq;
-            unsigned dm = 0, bm = 0;
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const int q = p[ro[k]];
-                dm |= (unsigned)(q < lo) << k;
-                bm |= (unsigned)(q > hi) << k;
-            }
-            pass = has9(dm) || has9(bm);
-        }
-        const unsigned long long bal = __ballot(pass);
-        if (pass) q2[(t2 + __popcll(bal & lt)) & FQ_MASK] = (unsigned short)rc;
-        t2 += __popcll(bal);
-        drain2(false);
-    };
-    auto drain1 = [&](bool all) {
-        while (t1 - h1 >= 64 || (all && t1 > h1)) {
-            const bool valid = lane < t1 - h1;
-            const int rc = valid ? q1[(h1 + lane) & FQ_MASK] : 0;
-            h1 += min(64, t1 - h1);
-            stage2(rc, valid);
-        }
-    };
-
     const int npix = detW * detH;
-    {
-        int r = 0, c = lane;
-        while (c >= detW) { c -= detW; r++; }
-        for (int base = 0; base < npix; base += 64) {
-            const bool valid = base + lane < npix;
-            bool pass = false;
-            if (valid) {
-                const uint8_t* p = &tile[(r + 3) * TP + (c + 3 + xoff)];
-                const int v = p[0], lo = v - tq, hi = v + tq;
-                const int c0 = p[3 * TP], c4 = p[3], c8 = p[-3 * TP], c12 = p[-3];
-                const bool d0 = c0 < lo, d4 = c4 < lo, d8 = c8 < lo, d12 = c12 < lo;
-                const bool b0 = c0 > hi, b4 = c4 > hi, b8 = c8 > hi, b12 = c12 > hi;
-                pass = (d0 && d4) || (d4 && d8) || (d8 && d12) || (d12 && d0) || (b0 && b4) || (b4 && b8) || (b8 && b12) || (b12 && b0);
-                sc[(r + 1) * TP + (c + 1)] = 0;
-            }
-            const unsigned long long bal = __ballot(pass);
-            if (pass) q1[(t1 + __popcll(bal & lt)) & FQ_MASK] = (unsigned short)((r << 7) | c);
-            t1 += __popcll(bal);
-            drain1(false);
-            c += 64;
-            while (c >= detW) { c -= detW; r++; }
-        }
-    }
-    drain1(true);
-    drain2(true);
-
-    // ---- 3x3 suppression + ordered emission --------------------------------------------------------------------------------
     uint32_t* slots = cellSlots + ((size_t)img * nCellsTotal + cell) * F.cellCap;
     int total = 0;
+    // The cell is processed at the high threshold first: only pixels that are corners at THAT threshold need a score (the
+    // suppression treats every other pixel as 0), which is a few per cent of the pixels instead of the ~18 % that pass the
+    // ring test at the low threshold.  Only a cell that stays empty is redone at the low threshold (the reference's second
+    // cv::FAST call, :586-594).
     for (int pass = 0; pass < 2; pass++) {
-        const int t = pass == 0 ? maxThr : minThr;
+        const int tq = pass == 0 ? maxThr : minThr;        // ring / cardinal tests and the suppression threshold of this pass
+        int h1 = 0, t1 = 0, h2 = 0, t2 = 0;                // queue heads / tails (wave-uniform)
+
+        auto stage3 = [&](int rc, bool valid) {
+            if (valid) {
+                const int r = rc >> 7, c = rc & 127;
+                sc[(r + 1) * TP + (c + 1)] = (uint8_t)fast_score(&tile[(r + 3) * TP + (c + 3 + xoff)], ro);
+            }
+        };
+        auto drain2 = [&](bool all) {
+            while (t2 - h2 >= 64 || (all && t2 > h2)) {
+                const bool valid = lane < t2 - h2;
+                const int rc = valid ? q2[(h2 + lane) & FQ_MASK] : 0;
+                h2 += min(64, t2 - h2);
+                stage3(rc, valid);
+            }
+        };
+        auto stage2 = [&](int rc, bool valid) {
+            bool ok = false;
+            if (valid) {
+                const int r = rc >> 7, c = rc & 127;
+                const uint8_t* p = &tile[(r + 3) * TP + (c + 3 + xoff)];
+                const int v = p[0], lo = v - tq, hi = v + tq;
+                unsigned dm = 0, bm = 0;
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int q = p[ro[k]];
+                    dm |= (unsigned)(q < lo) << k;
+                    bm |= (unsigned)(q > hi) << k;
+                }
+                ok = has9(dm) || has9(bm);
+            }
+            const unsigned long long bal = __ballot(ok);
+            if (ok) q2[(t2 + __popcll(bal & lt)) & FQ_MASK] = (unsigned short)rc;
+            t2 += __popcll(bal);
+            drain2(false);
+        };
+        auto drain1 = [&](bool all) {
+            while (t1 - h1 >= 64 || (all && t1 > h1)) {
+                const bool valid = lane < t1 - h1;
+                const int rc = valid ? q1[(h1 + lane) & FQ_MASK] : 0;
+                h1 += min(64, t1 - h1);
+                stage2(rc, valid);
+            }
+        };
+        {
+            int r = 0, c = lane;
+            while (c >= detW) { c -= detW; r++; }
+            for (int base = 0; base < npix; base += 64) {
+                const bool valid = base + lane < npix;
+                bool ok = false;
+                if (valid) {
+                    const uint8_t* p = &tile[(r + 3) * TP + (c + 3 + xoff)];
+                    const int v = p[0], lo = v - tq, hi = v + tq;
+                    const int c0 = p[3 * TP], c4 = p[3], c8 = p[-3 * TP], c12 = p[-3];
+                    const bool d0 = c0 < lo, d4 = c4 < lo, d8 = c8 < lo, d12 = c12 < lo;
+                    const bool b0 = c0 > hi, b4 = c4 > hi, b8 = c8 > hi, b12 = c12 > hi;
+                    ok = (d0 && d4) || (d4 && d8) || (d8 && d12) || (d12 && d0) || (b0 && b4) || (b4 && b8) || (b8 && b12) || (b12 && b0);
+                    sc[(r + 1) * TP + (c + 1)] = 0;
+                }
+                const unsigned long long bal = __ballot(ok);
+                if (ok) q1[(t1 + __popcll(bal & lt)) & FQ_MASK] = (unsigned short)((r << 7) | c);
+                t1 += __popcll(bal);
+                drain1(false);
+                c += 64;
+                while (c >= detW) { c -= detW; r++; }
+            }
+        }
+        drain1(true);
+        drain2(true);
+
+        // ---- 3x3 suppression + ordered emission at this pass's threshold ---------------------------------------------------
+        const int t = tq;
         total = 0;
         int r = 0, c = lane;
         while (c >= detW) { c -= detW; r++; }
