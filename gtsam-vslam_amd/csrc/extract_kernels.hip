@@ -188,13 +188,24 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, P
     const int xoff = cStart & 3;
     {
         const uint8_t* __restrict__ src = pyr + (size_t)img * P.imgStride + P.off[level] + (size_t)rStart * pitch + (cStart - xoff);
-        const int nd = (xoff + subW + 3) >> 2;
-        int r = 0, c = lane;
-        while (c >= nd) { c -= nd; r++; }
-        for (; r < subH;) {
-            *(unsigned*)(tile + r * TP + 4 * c) = *(const unsigned*)(src + (size_t)r * pitch + 4 * c);
-            c += 64;
-            while (c >= nd) { c -= nd; r++; }
+        const int nd = (xoff + subW + 3) >> 2, ndw = subH * nd;
+        const unsigned inv = 0xffffffffu / (unsigned)nd + 1u;  // i / nd == umulhi(i, inv), exact for i * nd < 2^32
+        // all of a lane's loads are issued before the first LDS store: one global round trip per 8 dwords instead of one each
+        for (int base = 0; base < ndw; base += 64 * 8) {
+            unsigned v[8];
+            int at[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int i = base + k * 64 + lane;
+                at[k] = -1;
+                if (i < ndw) {
+                    const int r = (int)__umulhi((unsigned)i, inv), c = i - r * nd;
+                    v[k] = *(const unsigned*)(src + (size_t)r * pitch + 4 * c);
+                    at[k] = r * TP + 4 * c;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) if (at[k] >= 0) *(unsigned*)(tile + at[k]) = v[k];
         }
     }
     // score-plane border (NMS reads one pixel beyond the detection area: those count as 0)

@@ -1,7 +1,7 @@
 """Per-kernel device time of the extractor for a batch of images (HIP events, average over repeated runs).
 usage: python tools/extract_rate.py [nimg] [repeats]"""
-import sys
-sys.path.insert(0, 'gtsam-vslam_amd')
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gtsam-vslam_amd'))
 import numpy as np, synth, vslam_capi as vc
 nimg = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 rep = int(sys.argv[2]) if len(sys.argv) > 2 else 20
