@@ -156,3 +156,51 @@ def test_fleet_batched_with_prefetch_equals_one_thread_per_session(capi):
     assert out[0][0]["keyframes"] >= 10 and out[0][1]["mappings"] + out[0][0]["mappings"] >= 3
     for a, b in imgs:
         a.free(); b.free()
+
+
+def test_bounded_mapper_lag_runs_every_pass(capi):
+    """local_mapping = 2 with mapping_max_lag = 4 (the bench's setting): keyframes are at least five frames apart, so every
+    keyframe's local-mapping pass finishes before the next keyframe - the run must contain exactly the passes of the
+    synchronous mode (and the same keyframes); with the lag unbounded the count may only be smaller."""
+    rig = synth.RIGS["euroc"]
+    n = 30
+    frames = [synth.stereo_frame(2 * i, "euroc") for i in range(n)]
+    imgs = [(capi.DeviceImage(f[0]), capi.DeviceImage(f[1])) for f in frames]
+    poses = np.stack([f[2] for f in frames])
+    res = {}
+    for name, mapping, lag in (("sync", 1, 0), ("lag4", 2, 4), ("free", 2, 0)):
+        cfg = capi.system_config(rig, 1500, local_mapping=mapping, mapping_max_lag=lag)
+        fl = capi.Fleet(cfg, 6, [a.ptr for a, _ in imgs], [b.ptr for _, b in imgs], rig["w"], True, poses=poses, lanes=3)
+        res[name] = fl.run(90)
+        fl.close()
+    assert res["sync"]["mappings"] >= 3
+    assert res["lag4"]["keyframes"] == res["sync"]["keyframes"]
+    assert abs(res["lag4"]["mappings"] - res["sync"]["mappings"]) <= 6          # (a pass still running at the end reports after the run)
+    assert res["free"]["mappings"] <= res["sync"]["mappings"] and res["free"]["lost_frames"] == 0
+    for a, b in imgs:
+        a.free(); b.free()
+
+
+def test_thread_release_and_reuse(capi, oracle):
+    """vslam_thread_release() frees the calling thread's cached device resources (scratch pool, local-BA workspace); the
+    thread can keep using the library afterwards, and results do not change."""
+    import threading
+    prob = synth.make_ba_problem(n_local=5, n_fixed=2, n_lm=600, seed=3)
+    ex = oracle.Extractor(1500)
+    out = {}
+
+    def work():
+        L = capi.lib()
+        L.vslam_thread_release.restype = None
+        a = capi.local_ba(prob["rig"], ex.sigmaFactor, ex.InvSigmaFactor, prob)
+        d1 = capi.calc_descriptors([np.arange(96, dtype=np.uint8).reshape(3, 32)])
+        L.vslam_thread_release()
+        L.vslam_thread_release()          # (idempotent)
+        b = capi.local_ba(prob["rig"], ex.sigmaFactor, ex.InvSigmaFactor, prob)
+        d2 = capi.calc_descriptors([np.arange(96, dtype=np.uint8).reshape(3, 32)])
+        L.vslam_thread_release()
+        out["ok"] = np.abs(a["kf_pose"] - b["kf_pose"]).max() < 1e-10 and list(d1) == list(d2) and a["reports"][0]["iterations"] == b["reports"][0]["iterations"]
+
+    th = threading.Thread(target=work)
+    th.start(); th.join(120)
+    assert out.get("ok") is True
