@@ -213,6 +213,7 @@ def main():
     ap.add_argument("--c5-landmarks", type=int, default=100000)
     ap.add_argument("--c5-steps", type=int, default=5)
     ap.add_argument("--c5-warmup", type=int, default=1)
+    ap.add_argument("--c5-timeout", type=int, default=180, help="N > 1: seconds the sharded-BA section may take before the line is printed without it")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -332,9 +333,24 @@ def main():
             fx.close()
 
     fleet.close()      # (idempotent) library threads joined before the process winds down
+    # N > 1: the landmark-sharded 64-keyframe / 100 k-landmark BA over RCCL as an extra section of the line.  It is the
+    # only collective of the path and cannot be rehearsed on the one-GPU development box, so it runs under a watchdog: if
+    # it has not finished in time (or raises), the closed-loop line is still printed, with the failure recorded.
     c5 = None
+    c5_done = [False]
+    emit_box = {}
     if world > 1 and not os.environ.get("VSLAM_BENCH_SKIP_C5"):
-        c5 = run_c5(args, rank, world, local, dist, torch, backend)
+        import threading
+
+        def _watchdog():
+            if c5_done[0]:
+                return
+            if rank == 0 and "emit" in emit_box:
+                emit_box["emit"]({"error": "the sharded-BA section did not finish within %d s" % args.c5_timeout})
+            os._exit(0)
+        wd = threading.Timer(args.c5_timeout, _watchdog)
+        wd.daemon = True
+        emit_box["timer"] = wd
 
     if rank == 0:
         S = args.sessions
@@ -468,11 +484,24 @@ def main():
             out["latency_single_session"] = latency
         if sweep:
             out["sweep"] = sweep
-        if c5 is not None:
-            out["c5_sharded_ba"] = c5
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, frames, poses, vel, fwd)
-        print(json.dumps(out))
+
+        def emit(c5res):
+            if c5res is not None:
+                out["c5_sharded_ba"] = c5res
+            print(json.dumps(out), flush=True)
+        emit_box["emit"] = emit
+    if "timer" in emit_box:
+        emit_box["timer"].start()
+        try:
+            c5 = run_c5(args, rank, world, local, dist, torch, backend)
+        except Exception as e:      # noqa: BLE001
+            c5 = {"error": "%s: %s" % (type(e).__name__, e)}
+        c5_done[0] = True
+        emit_box["timer"].cancel()
+    if rank == 0:
+        emit_box["emit"](c5)
     if world > 1:
         dist.destroy_process_group()
 
