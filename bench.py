@@ -473,6 +473,10 @@ def main():
                              "why_small": "a %.0f-unknown system (%.1f free keyframes) is %.0f flops per candidate: one workgroup, latency-bound; "
                                           "launch_ms is measured with the other sessions' kernels sharing the GPU" % (nBA6, Fk, alg_flops)})
             out["roofline"] = roof
+            if "ba_solve" not in stage_ms:   # no local BA of the sampled sessions fell into this (short) timed region
+                out["ba_solve_mfma"] = {"launch_ms": None, "unknowns": nBA6, "flops": groups["ba_solve"][2], "achieved_gflops": None, "fp64_frac": None,
+                                        "note": "no sampled local BA in the timed region; profiles/r02_d_c2_kernel_stats.csv has the kernel "
+                                                "(k_ba_solve_mfma64, ~35-40 us per launch): (6F)^3/3 flops per candidate - << 1 % of the fp64 MFMA peak"}
             if "ba_solve" in stage_ms:       # the only MFMA-eligible term of the path: always reported
                 n_l, _, fl = groups["ba_solve"]
                 ms_l = stage_ms["ba_solve"] / max(n_l, 1)

@@ -132,7 +132,13 @@ void vslam_fleet::group_loop(int gi) {
                 }
             }
             const bool sample = gi == 0 && sampleEvery > 0 && k > 0 && (k % sampleEvery) == 0;
-            if (gi == 0 && sampleEvery > 0) { vslam_batch_set_timing(Gp.b, sample ? 1 : 0); vslam_system_set_ba_timing(ses[Gp.first].sys, sample ? 1 : 0); }
+            // tracking stages: the sampled steps; local BAs: every pass of the group's first sessions while sampling is on (passes
+            // are rare - one per ~40 frames per session - and run on the mapping threads, whenever they get to them)
+            const int nBaTimed = std::min(Bn, 8);
+            if (gi == 0 && sampleEvery > 0) {
+                vslam_batch_set_timing(Gp.b, sample ? 1 : 0);
+                for (int b = 0; b < nBaTimed; b++) vslam_system_set_ba_timing(ses[Gp.first + b].sys, 1);
+            }
             if (onDevice) {       // the next step's images: their extraction overlaps this step's host phases
                 for (int b = 0; b < Bn; b++) { const int ni = tri(k + 1 + ses[Gp.first + b].offset, nFrames); nL[b] = left[ni]; nR[b] = right[ni]; }
                 st = vslam_batch_track_stereo_prefetch(Gp.b, L.data(), R.data(), stride, fr.data(), useImu ? bk.data() : nullptr, nullptr, T.data(),
@@ -143,7 +149,8 @@ void vslam_fleet::group_loop(int gi) {
             if (sample) {
                 const char* nm[64]; float ms[64]; int n = 0, nba = 0;
                 if (vslam_batch_timings(Gp.b, nm, ms, 64, &n, nullptr) == VSLAM_OK) add_times(nm, ms, n);
-                if (vslam_system_ba_timings(ses[Gp.first].sys, nm, ms, 64, &n, &nba) == VSLAM_OK) { add_times(nm, ms, n); sampledBa += nba; }
+                for (int b = 0; b < nBaTimed; b++)
+                    if (vslam_system_ba_timings(ses[Gp.first + b].sys, nm, ms, 64, &n, &nba) == VSLAM_OK) { add_times(nm, ms, n); sampledBa += nba; }
                 sampledFrames += Bn;
                 for (int b = 0; b < Bn; b++) sampledSolves += reps[b].rounds + 1;
             }
@@ -339,7 +346,10 @@ vslam_status vslam_fleet_set_sampling(vslam_fleet* F, int32_t every) {
     F->sampleEvery = every;
     if (!every) {
         if (F->groups.empty()) vslam_system_set_timing(F->ses[0].sys, 0);
-        else { vslam_batch_set_timing(F->groups[0].b, 0); vslam_system_set_ba_timing(F->ses[0].sys, 0); }
+        else {
+            vslam_batch_set_timing(F->groups[0].b, 0);
+            for (int b = 0; b < std::min(F->groups[0].count, 8); b++) vslam_system_set_ba_timing(F->ses[b].sys, 0);
+        }
     }
     return VSLAM_OK;
 }
