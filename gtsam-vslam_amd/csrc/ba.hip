@@ -1962,25 +1962,32 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
     const size_t oPose0 = cOff((size_t)K * sizeof(DPose)), oLm0 = cOff((size_t)3 * L * sizeof(double)), oPairKf = cOff((size_t)NP * 4),
                  oPairLm = cOff((size_t)NP * 4), oPairOct = cOff((size_t)2 * NP * 4), oPairFlags = cOff((size_t)NP), oPairUv = cOff((size_t)4 * NP * 4),
                  oKfLocal = cOff((size_t)K);
-    if (cBytes > ws->constCap) {
+    // small problems (a tracker's local window): through the pinned block, one copy.  Large ones (the 100 k-landmark window:
+    // 40 MB of pair arrays): straight from the caller's arrays - staging them would cost a host memcpy of the same size.
+    const bool staged = cBytes <= ((size_t)8 << 20);
+    if (ws->d_const.n < cBytes) VS_HIP(ws->d_const.alloc(cBytes + cBytes / 4));
+    if (staged && cBytes > ws->constCap) {
         VS_HIP(hipStreamSynchronize(stream));
         if (ws->h_const) hipHostFree(ws->h_const);
         ws->h_const = nullptr;
         ws->constCap = cBytes + cBytes / 4;
         VS_HIP(hipHostMalloc((void**)&ws->h_const, ws->constCap, hipHostMallocDefault));
-        VS_HIP(ws->d_const.alloc(ws->constCap));
     }
     {
-        uint8_t* h = ws->h_const;
-        memcpy(h + oPose0, pose0.data(), (size_t)K * sizeof(DPose));
-        if (L) memcpy(h + oLm0, P->lm_xyz, (size_t)3 * L * sizeof(double));
-        if (NP) {
-            memcpy(h + oPairKf, P->pair_kf, (size_t)NP * 4); memcpy(h + oPairLm, P->pair_lm, (size_t)NP * 4);
-            memcpy(h + oPairOct, P->pair_octave, (size_t)2 * NP * 4); memcpy(h + oPairFlags, P->pair_flags, NP);
-            memcpy(h + oPairUv, P->pair_uv, (size_t)4 * NP * 4);
-        }
-        memcpy(h + oKfLocal, P->kf_local, K);
-        VS_HIP(hipMemcpyAsync(ws->d_const.p, h, cBytes, hipMemcpyHostToDevice, stream));
+        uint8_t* h = staged ? ws->h_const : nullptr;
+        uint8_t* d = ws->d_const.p;
+        auto put = [&](size_t at, const void* src, size_t bytes) -> hipError_t {
+            if (!bytes) return hipSuccess;
+            if (h) { memcpy(h + at, src, bytes); return hipSuccess; }
+            return hipMemcpyAsync(d + at, src, bytes, hipMemcpyHostToDevice, stream);
+        };
+        VS_HIP(put(oPose0, pose0.data(), (size_t)K * sizeof(DPose)));
+        VS_HIP(put(oLm0, P->lm_xyz, (size_t)3 * L * sizeof(double)));
+        VS_HIP(put(oPairKf, P->pair_kf, (size_t)NP * 4)); VS_HIP(put(oPairLm, P->pair_lm, (size_t)NP * 4));
+        VS_HIP(put(oPairOct, P->pair_octave, (size_t)2 * NP * 4)); VS_HIP(put(oPairFlags, P->pair_flags, (size_t)NP));
+        VS_HIP(put(oPairUv, P->pair_uv, (size_t)4 * NP * 4));
+        VS_HIP(put(oKfLocal, P->kf_local, (size_t)K));
+        if (h) VS_HIP(hipMemcpyAsync(d, h, cBytes, hipMemcpyHostToDevice, stream));
     }
     uint8_t* const dc = ws->d_const.p;
     DPose* const p_pose0 = (DPose*)(dc + oPose0);
