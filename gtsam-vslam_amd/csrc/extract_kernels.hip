@@ -13,7 +13,7 @@
 
 namespace vslam {
 
-__constant__ signed char c_pattern[1024];
+__constant__ __attribute__((aligned(16))) signed char c_pattern[1024];
 
 void upload_pattern() {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), VSLAM_ORB_PATTERN, 1024);
@@ -22,9 +22,19 @@ void upload_pattern() {
 // ---------------------------------------------------------------------------
 // K1: resize (reference computePyramid, src/FeatureExtractor.cpp:342-366;
 // cv::resize 8UC1 INTER_LINEAR fixed-point semantics).
-// xtab[dx] = { sx | sx1<<16, a0 | a1<<16 }, ytab[dy] = { sy, b0 | b1<<16 }.
-// Each thread produces 4 horizontally adjacent pixels and stores one uchar4.
+// xtab[dx] = { sx | sx1<<16, a0 | a1<<16 }, ytab[dy] = { sy, b0 | b1<<16 }; a level's xtab is padded to a multiple of 4
+// entries (copies of its last entry).  Each thread produces 4 horizontally adjacent pixels and stores one uchar4.
+// The kernel is bound by its memory instructions, so a thread reads its four table entries with two 16-byte loads and
+// each source row with three aligned dwords (the taps of four neighbours span < 12 bytes for any scale below ~2.3);
+// v_perm_b32 picks the two taps of a pixel into the halves of a register and v_dot2_i32_i16 applies the packed
+// coefficients.  Threads whose taps do not fit the 12-byte window take the byte-wise path.
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ int resize_hsum(unsigned d0, unsigned d1, unsigned d2, bool upper, unsigned sel, int coef) {
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    const unsigned taps = __builtin_amdgcn_perm(upper ? d2 : d1, upper ? d1 : d0, sel);   // { tap(sx), 0, tap(sx1), 0 }
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, taps), __builtin_bit_cast(s16x2, coef), 0, false);
+}
+
 __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, PyrDesc P, int level,
                                                 const int2* __restrict__ xtab,
                                                 const int2* __restrict__ ytab) {
@@ -43,21 +53,46 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, PyrDe
     const int b0 = (short)(yt.y & 0xffff), b1 = (short)(yt.y >> 16);
     const uint8_t* r0 = S + (size_t)sy0 * sp;
     const uint8_t* r1 = S + (size_t)sy1 * sp;
-    uchar4 o = make_uchar4(0, 0, 0, 0);
-    uint8_t* op = (uint8_t*)&o;
+    const int4 ta = *(const int4*)(xtab + x0), tb = *(const int4*)(xtab + x0 + 2);
+    const int xs[4] = {ta.x, ta.z, tb.x, tb.z}, xc[4] = {ta.y, ta.w, tb.y, tb.w};
+    const int base = (xs[0] & 0xffff) & ~3;
+    int o0[4], o1[4];
+    bool fits = true;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const int dx = x0 + i;
-        if (dx < dw) {
-            const int2 xt = xtab[dx];
-            const int sx = xt.x & 0xffff, sx1 = xt.x >> 16;
-            const int a0 = (short)(xt.y & 0xffff), a1 = (short)(xt.y >> 16);
-            const int h0 = r0[sx] * a0 + r0[sx1] * a1;
-            const int h1 = r1[sx] * a0 + r1[sx1] * a1;
-            op[i] = (uint8_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+        o0[i] = (xs[i] & 0xffff) - base;
+        o1[i] = (int)((unsigned)xs[i] >> 16) - base;
+        fits = fits && (unsigned)o0[i] < 12u && (unsigned)o1[i] < 12u && (unsigned)(o1[i] - o0[i]) <= 1u;
+    }
+    unsigned o = 0;
+    if (fits) {
+        const unsigned a0 = *(const unsigned*)(r0 + base), a1 = *(const unsigned*)(r0 + base + 4), a2 = *(const unsigned*)(r0 + base + 8);
+        const unsigned c0 = *(const unsigned*)(r1 + base), c1 = *(const unsigned*)(r1 + base + 4), c2 = *(const unsigned*)(r1 + base + 8);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const bool upper = o1[i] > 7 || o0[i] > 7;             // window bytes 4..11 instead of 0..7
+            const int sh4 = upper ? 4 : 0;
+            // (o1 - o0 is 0 or 1, so both taps lie in the chosen window)
+            const unsigned sel = (unsigned)(o0[i] - sh4) | ((unsigned)(o1[i] - sh4) << 16) | 0x0c000c00u;
+            const int h0 = resize_hsum(a0, a1, a2, upper, sel, xc[i]);
+            const int h1 = resize_hsum(c0, c1, c2, upper, sel, xc[i]);
+            const unsigned v = (unsigned)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
+            o |= (x0 + i < dw ? v : 0u) << (8 * i);
+        }
+    } else {
+        uint8_t* op = (uint8_t*)&o;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (x0 + i < dw) {
+                const int sx = xs[i] & 0xffff, sx1 = (int)((unsigned)xs[i] >> 16);
+                const int c0 = (short)(xc[i] & 0xffff), c1 = (short)(xc[i] >> 16);
+                const int h0 = r0[sx] * c0 + r0[sx1] * c1;
+                const int h1 = r1[sx] * c0 + r1[sx1] * c1;
+                op[i] = (uint8_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+            }
         }
     }
-    *(uchar4*)(D + (size_t)y * dp + x0) = o;
+    *(unsigned*)(D + (size_t)y * dp + x0) = o;
 }
 
 // level 0 of every image from the caller's device buffers in one launch (src[i] == nullptr: image i keeps its content)
@@ -116,6 +151,7 @@ __device__ __forceinline__ bool has9(unsigned m) {
 //   3  survivors: the exact score M (max over arcs of the min difference) -> score plane in LDS.
 // Then, per threshold, 3x3 strict-maximum suppression and the ordered emission (row-major) by ballot prefix.
 constexpr int FQ_MASK = 255;          // queue capacity (entries) - 1: at most 64 + 63 entries are ever pending
+constexpr int FQ3_CAP = 512;          // corner list of a cell (pixels whose score passes the threshold), row-major order
 
 __device__ __forceinline__ int fast_score(const uint8_t* p, const int* ro) {
     const int v = p[0];
@@ -152,11 +188,12 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, P
     extern __shared__ unsigned char fsm[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int TP = F.tilePitch;                                    // bytes per LDS row (multiple of 4)
-    const int perWave = F.tileRows * TP * 2 + 2 * (FQ_MASK + 1) * 2;
+    const int perWave = F.tileRows * TP * 2 + 2 * (FQ_MASK + 1) * 2 + FQ3_CAP * 2;
     uint8_t* tile = fsm + (size_t)wave * perWave;                  // [tileRows][TP] sub-image
     uint8_t* sc = tile + F.tileRows * TP;                          // [tileRows][TP] scores (row / col 0 = border)
     unsigned short* q1 = (unsigned short*)(sc + F.tileRows * TP);  // stage 1 -> 2
     unsigned short* q2 = q1 + (FQ_MASK + 1);                       // stage 2 -> 3
+    unsigned short* q3 = q2 + (FQ_MASK + 1);                       // stage 3 -> suppression (corners at the pass's threshold)
     const int cell = blockIdx.x * 4 + wave, img = blockIdx.y;
     const int nCellsTotal = F.cellBase[P.nLevels];
     if (cell >= nCellsTotal) return;
@@ -226,12 +263,20 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, P
     for (int pass = 0; pass < 2; pass++) {
         const int tq = pass == 0 ? maxThr : minThr;        // ring / cardinal tests and the suppression threshold of this pass
         int h1 = 0, t1 = 0, h2 = 0, t2 = 0;                // queue heads / tails (wave-uniform)
+        int n3 = 0;                                        // corners listed in q3 (may exceed FQ3_CAP: then the full scan runs)
 
         auto stage3 = [&](int rc, bool valid) {
+            bool corner = false;
             if (valid) {
                 const int r = rc >> 7, c = rc & 127;
-                sc[(r + 1) * TP + (c + 1)] = (uint8_t)fast_score(&tile[(r + 3) * TP + (c + 3 + xoff)], ro);
+                const int s = fast_score(&tile[(r + 3) * TP + (c + 3 + xoff)], ro);
+                sc[(r + 1) * TP + (c + 1)] = (uint8_t)s;
+                corner = s > tq;
             }
+            const unsigned long long bal = __ballot(corner);
+            const int at = n3 + __popcll(bal & lt);
+            if (corner && at < FQ3_CAP) q3[at] = (unsigned short)rc;
+            n3 += __popcll(bal);
         };
         auto drain2 = [&](bool all) {
             while (t2 - h2 >= 64 || (all && t2 > h2)) {
@@ -296,17 +341,19 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, P
         drain2(true);
 
         // ---- 3x3 suppression + ordered emission at this pass's threshold ---------------------------------------------------
+        // Only pixels whose score passes the threshold can be kept, and stage 3 listed them in row-major order (every queue
+        // preserves the pixel order), so the suppression visits that list - a few dozen pixels - instead of the whole cell.
         const int t = tq;
         total = 0;
-        int r = 0, c = lane;
-        while (c >= detW) { c -= detW; r++; }
-        for (int base = 0; base < npix; base += 64) {
-            bool flag = false;
-            int s = 0;
-            if (base + lane < npix) {
-                const uint8_t* z = &sc[(r + 1) * TP + (c + 1)];
-                s = z[0];
-                if (s > t) {
+        if (n3 <= FQ3_CAP) {
+            for (int base = 0; base < n3; base += 64) {
+                bool flag = false;
+                int s = 0, r = 0, c = 0;
+                if (base + lane < n3) {
+                    const int rc = q3[base + lane];
+                    r = rc >> 7; c = rc & 127;
+                    const uint8_t* z = &sc[(r + 1) * TP + (c + 1)];
+                    s = z[0];
                     flag = true;
 #pragma unroll
                     for (int dy = -1; dy <= 1; dy++)
@@ -318,15 +365,44 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, P
                             flag = flag && (s > nv);
                         }
                 }
+                const unsigned long long bal = __ballot(flag);
+                if (flag) {
+                    const int pos = total + __popcll(bal & lt);
+                    if (pos < F.cellCap) slots[pos] = pack_cand(cStart + 3 + c, rStart + 3 + r, s - 1);
+                }
+                total += __popcll(bal);
             }
-            const unsigned long long bal = __ballot(flag);
-            if (flag) {
-                const int pos = total + __popcll(bal & lt);
-                if (pos < F.cellCap) slots[pos] = pack_cand(cStart + 3 + c, rStart + 3 + r, s - 1);
-            }
-            total += __popcll(bal);
-            c += 64;
+        } else {
+            int r = 0, c = lane;
             while (c >= detW) { c -= detW; r++; }
+            for (int base = 0; base < npix; base += 64) {
+                bool flag = false;
+                int s = 0;
+                if (base + lane < npix) {
+                    const uint8_t* z = &sc[(r + 1) * TP + (c + 1)];
+                    s = z[0];
+                    if (s > t) {
+                        flag = true;
+#pragma unroll
+                        for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+                            for (int dx = -1; dx <= 1; dx++) {
+                                if (dy == 0 && dx == 0) continue;
+                                int nv = z[dy * TP + dx];
+                                nv = nv > t ? nv : 0;
+                                flag = flag && (s > nv);
+                            }
+                    }
+                }
+                const unsigned long long bal = __ballot(flag);
+                if (flag) {
+                    const int pos = total + __popcll(bal & lt);
+                    if (pos < F.cellCap) slots[pos] = pack_cand(cStart + 3 + c, rStart + 3 + r, s - 1);
+                }
+                total += __popcll(bal);
+                c += 64;
+                while (c >= detW) { c -= detW; r++; }
+            }
         }
         if (total > 0) break;
     }
@@ -336,7 +412,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, P
 void launch_fast(hipStream_t s, const uint8_t* pyr, const PyrDesc& P, const FastDesc& F,
                  uint32_t* cellSlots, int* cellCount, int maxThr, int minThr, int nimg) {
     dim3 grid((F.cellBase[P.nLevels] + 3) / 4, nimg);
-    const size_t lds = (size_t)4 * ((size_t)F.tileRows * F.tilePitch * 2 + 2 * (FQ_MASK + 1) * 2);
+    const size_t lds = (size_t)4 * ((size_t)F.tileRows * F.tilePitch * 2 + 2 * (FQ_MASK + 1) * 2 + FQ3_CAP * 2);
     hipLaunchKernelGGL(k_fast, grid, dim3(256), lds, s, pyr, P, F, cellSlots, cellCount, maxThr, minThr);
 }
 
@@ -523,29 +599,79 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     return a;
 }
 
+// float(cos(double(x))), float(sin(double(x))) for x in [0, ~2 pi]: Cody-Waite reduction by pi/2 (k <= 4, so k * pio2_1
+// is exact and the difference is exact) and the fdlibm kernel polynomials (< 1 ulp in double).  Replaces the library
+// cos() + sin() calls (two separate range reductions, ~4x the instructions); wave-uniform work.
+__device__ __forceinline__ void sincos_deg_range(float xf, float& s_out, float& c_out) {
+    const double x = (double)xf;
+    const double kd = rint(x * 6.36619772367581382433e-01);
+    const int k = (int)kd;
+    double r = fma(-kd, 1.57079632673412561417e+00, x);
+    r = fma(-kd, 6.07710050650619224932e-11, r);
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    const double sn = fma(z * r, fma(z, ps, -1.66666666666666324348e-01), r);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double cs = 1.0 - fma(0.5, z, -(z * (z * pc)));
+    const double sq = (k & 1) ? cs : sn, cq = (k & 1) ? sn : cs;
+    s_out = (float)((k & 2) ? -sq : sq);
+    c_out = (float)(((k + 1) & 2) ? -cq : cq);
+}
+
+// Moments: lane = (half, u): lanes 0..30 walk the rows v = 0..15 of column u = lane - 15, lanes 32..62 the rows
+// -1..-15; a row's loads are contiguous bytes.  m10 = sum_u u * (column sum), m01 = sum v * I: integer sums, order-free.
 __global__ __launch_bounds__(256) void k_orient_desc(
     const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur, PyrDesc P, LevelTables T,
     const uint32_t* __restrict__ kept, const int* __restrict__ keptOff, int keptCap,
-    const int8_t* __restrict__ disc, int ndisc, vslam_keypoint* __restrict__ kps,
+    DiscRows R, vslam_keypoint* __restrict__ kps,
     uint8_t* __restrict__ desc, int outCap) {
-    const int img = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int img = blockIdx.y, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (tells the compiler the keypoint is wave-uniform)
     const int g = blockIdx.x * 4 + wave;
     const int* koff = keptOff + img * (MAX_LEVELS + 1);
     const int total = koff[P.nLevels];
     if (g >= total || g >= outCap) return;
+    const int4 pat4 = *(const int4*)(c_pattern + 16 * lane);      // the lane's four point pairs (used after the angle)
     int level = 0;
     while (level + 1 < P.nLevels && g >= koff[level + 1]) level++;
     const uint32_t pk = kept[(size_t)img * keptCap + g];
     const int x = cand_x(pk), y = cand_y(pk), score = cand_s(pk);
     const int pitch = P.pitch[level];
     const size_t lvlOff = (size_t)img * P.imgStride + P.off[level];
-    const uint8_t* __restrict__ c0 = pyr + lvlOff + (size_t)y * pitch + x;
-    int m10 = 0, m01 = 0;
-    for (int i = lane; i < ndisc; i += 64) {
-        const int du = disc[2 * i], dv = disc[2 * i + 1];
-        const int I = c0[dv * pitch + du];
-        m10 += du * I;
-        m01 += dv * I;
+    // wave-uniform bases moved to the top-left corner of the patch, so that the per-lane offsets are unsigned
+    const uint8_t* __restrict__ mb = pyr + lvlOff + (size_t)(y - 15) * pitch + (x - 15);
+    int m10, m01 = 0;
+    {
+        const unsigned lu = lane & 31;
+        const int u = (int)lu - 15, au = u < 0 ? -u : u;
+        const bool neg = lane >= 32;
+        const unsigned centre = 15u * (unsigned)pitch + 15u;
+        const unsigned step = neg ? 0u - (unsigned)pitch : (unsigned)pitch;
+        unsigned off = 15u * (unsigned)pitch + lu;
+        int I[16];
+        bool act[16];
+#pragma unroll
+        for (int v = 0; v < 16; v++) {           // all 16 loads are in flight together (inactive lanes read the centre)
+            act[v] = au <= R.umax[v] && lu != 31u && !(neg && v == 0);
+            I[v] = mb[act[v] ? off : centre];
+            off += step;
+        }
+        int colSum = 0;
+#pragma unroll
+        for (int v = 0; v < 16; v++) {
+            const int Iv = act[v] ? I[v] : 0;
+            colSum += Iv;
+            m01 += v * Iv;
+        }
+        m10 = u * colSum;
+        if (neg) m01 = -m01;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -556,19 +682,21 @@ __global__ __launch_bounds__(256) void k_orient_desc(
 
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     const float ang = angle * factorPI;
-    // correctly-rounded float cos/sin via the double routines (matches libm's cosf/sinf
-    // on every input the parity tests cover; see DESIGN.md "float trig")
-    const float a = (float)cos((double)ang), b = (float)sin((double)ang);
-    const uint8_t* __restrict__ bc = blur + lvlOff + (size_t)y * pitch + x;
+    // correctly-rounded float cos/sin through double (matches libm's cosf/sinf on every input the parity tests cover;
+    // see DESIGN.md "float trig")
+    float a, b;
+    sincos_deg_range(ang, b, a);
+    const uint8_t* __restrict__ bb = blur + lvlOff + (size_t)(y - 20) * pitch + (x - 20);   // taps lie within +-19 px
+    const int pw[4] = {pat4.x, pat4.y, pat4.z, pat4.w};
     int nib = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const int pair = lane * 4 + j;
-        const float x0 = (float)c_pattern[4 * pair], y0 = (float)c_pattern[4 * pair + 1];
-        const float x1 = (float)c_pattern[4 * pair + 2], y1 = (float)c_pattern[4 * pair + 3];
+        const float x0 = (float)(signed char)(pw[j] & 0xff), y0 = (float)(signed char)((pw[j] >> 8) & 0xff);
+        const float x1 = (float)(signed char)((pw[j] >> 16) & 0xff), y1 = (float)(pw[j] >> 24);
         const int ry0 = __float2int_rn(x0 * b + y0 * a), rx0 = __float2int_rn(x0 * a - y0 * b);
         const int ry1 = __float2int_rn(x1 * b + y1 * a), rx1 = __float2int_rn(x1 * a - y1 * b);
-        const int t0 = bc[ry0 * pitch + rx0], t1 = bc[ry1 * pitch + rx1];
+        const int t0 = bb[(unsigned)(ry0 + 20) * (unsigned)pitch + (unsigned)(rx0 + 20)];
+        const int t1 = bb[(unsigned)(ry1 + 20) * (unsigned)pitch + (unsigned)(rx1 + 20)];
         nib |= (t0 < t1) << j;
     }
     const int other = __shfl_xor(nib, 1);
@@ -591,11 +719,11 @@ __global__ __launch_bounds__(256) void k_orient_desc(
 
 void launch_orient_desc(hipStream_t s, const uint8_t* pyr, const uint8_t* blur, const PyrDesc& P,
                         const LevelTables& T, const uint32_t* kept, const int* keptOff, int keptCap,
-                        const int8_t* disc, int ndisc, vslam_keypoint* kps, uint8_t* desc, int outCap,
+                        const DiscRows& disc, vslam_keypoint* kps, uint8_t* desc, int outCap,
                         int maxKept, int nimg) {
     if (maxKept <= 0) return;
     hipLaunchKernelGGL(k_orient_desc, dim3((maxKept + 3) / 4, nimg), dim3(256), 0, s, pyr, blur, P, T,
-                       kept, keptOff, keptCap, disc, ndisc, kps, desc, outCap);
+                       kept, keptOff, keptCap, disc, kps, desc, outCap);
 }
 
 }  // namespace vslam

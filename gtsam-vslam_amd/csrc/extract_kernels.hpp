@@ -59,9 +59,11 @@ void launch_gather(hipStream_t s, const uint32_t* cellSlots, const int* cellCoun
                    int nLevels, int* cellOff, uint32_t* cand, int candCap, int* levelCount, int nimg);
 void launch_blur(hipStream_t s, const uint8_t* pyr, uint8_t* blur, const PyrDesc& P,
                  const BlurDesc& B, int nimg);
+// half-widths of the rows of the radius-15 intensity-centroid disc (umax[v], v = 0..15; src/FeatureExtractor.cpp:321-336)
+struct DiscRows { int umax[16]; };
 void launch_orient_desc(hipStream_t s, const uint8_t* pyr, const uint8_t* blur, const PyrDesc& P,
                         const LevelTables& T, const uint32_t* kept, const int* keptOff, int keptCap,
-                        const int8_t* disc, int ndisc, vslam_keypoint* kps, uint8_t* desc, int outCap,
+                        const DiscRows& disc, vslam_keypoint* kps, uint8_t* desc, int outCap,
                         int maxKept, int nimg);
 void upload_pattern();
 

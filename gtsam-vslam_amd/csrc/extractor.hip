@@ -194,6 +194,7 @@ vslam_status vslam_extractor::init(const vslam_fe_params* p, int w, int h, int b
     for (int l = 1; l < nLevels; l++) {
         std::vector<int2> xt, yt;
         build_resize_tables(P.w[l - 1], P.h[l - 1], P.w[l], P.h[l], xt, yt);
+        while (xt.size() % 4) xt.push_back(xt.back());   // k_resize reads four entries per thread (two 16-byte loads)
         xtabOff[l] = (int)allx.size();
         ytabOff[l] = (int)ally.size();
         allx.insert(allx.end(), xt.begin(), xt.end());
@@ -221,17 +222,8 @@ vslam_status vslam_extractor::init(const vslam_fe_params* p, int w, int h, int b
     VS_HIP(hipMalloc(&d_kps, (size_t)nimg * keptCap * sizeof(vslam_keypoint)));
     VS_HIP(hipMalloc(&d_desc, (size_t)nimg * keptCap * 32));
 
-    // radius-15 disc of the intensity centroid (src/FeatureExtractor.cpp:321-336)
-    std::vector<int8_t> disc;
-    for (int u = -15; u <= 15; u++) { disc.push_back((int8_t)u); disc.push_back(0); }
-    for (int v = 1; v <= 15; v++)
-        for (int u = -umax[v]; u <= umax[v]; u++) {
-            disc.push_back((int8_t)u); disc.push_back((int8_t)v);
-            disc.push_back((int8_t)u); disc.push_back((int8_t)-v);
-        }
-    ndisc = (int)disc.size() / 2;
-    VS_HIP(hipMalloc(&d_disc, disc.size()));
-    VS_HIP(hipMemcpy(d_disc, disc.data(), disc.size(), hipMemcpyHostToDevice));
+    // radius-15 disc of the intensity centroid (src/FeatureExtractor.cpp:321-336): row half-widths
+    for (int v = 0; v < 16; v++) discRows.umax[v] = umax[v];
     nKept.assign(nimg, 0);
     // SSC: per-level constants of the binary search (src/FeatureExtractor.cpp:382-406: the closed-form upper bound of the
     // suppression width, round(K -+ K * tolerance))
@@ -279,7 +271,7 @@ void vslam_extractor::release() {
     hipFree(d_cand); hipFree(d_levelCount);
     if (doubleOut) { hipFree(d_kpsBuf[0]); hipFree(d_kpsBuf[1]); hipFree(d_descBuf[0]); hipFree(d_descBuf[1]); }
     else { hipFree(d_kps); hipFree(d_desc); }
-    hipFree(d_kept); hipFree(d_keptOff); hipFree(d_disc);
+    hipFree(d_kept); hipFree(d_keptOff);
     hipFree(d_sscTmp); hipFree(d_sscPicks); hipFree(d_taskCount); hipFree(d_sscFlags); hipFree(d_sscGrid); hipFree(d_sscGridOff);
     d_sscGrid = nullptr; d_sscGridOff = nullptr; d_sscPicks = nullptr;
     if (h_counts) hipHostFree(h_counts);
@@ -430,7 +422,7 @@ vslam_status vslam_extractor::run() {
     timer.end(t);
     t = timer.begin("orient_desc");
     if (doubleOut) { outSel ^= 1; d_kps = d_kpsBuf[outSel]; d_desc = d_descBuf[outSel]; }
-    launch_orient_desc(stream, d_pyr, d_blur, P, T, d_kept, d_keptOff, keptCap, d_disc, ndisc, d_kps,
+    launch_orient_desc(stream, d_pyr, d_blur, P, T, d_kept, d_keptOff, keptCap, discRows, d_kps,
                        d_desc, keptCap, keptCap, nimg);
     timer.end(t);
     VS_HIP(hipGetLastError());

@@ -45,8 +45,7 @@ struct vslam_extractor {
     int keptCap = 0;             // per image
     uint32_t* d_kept = nullptr;
     int* d_keptOff = nullptr;
-    int8_t* d_disc = nullptr;
-    int ndisc = 0;
+    vslam::DiscRows discRows{};
     vslam_keypoint* d_kps = nullptr;  // nimg * keptCap   (the buffer the last run() wrote / is writing)
     uint8_t* d_desc = nullptr;        // nimg * keptCap * 32
     // optional second output set (vslam_batch): run() alternates between the two, so that the keys of frame k stay readable

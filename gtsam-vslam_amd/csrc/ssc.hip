@@ -30,10 +30,14 @@ constexpr int SSC_NT = 1024, SSC_NW = SSC_NT / 64;      // 16 waves
 constexpr int SSC_NPROBE = 8;                           // speculative probes per round (waves 0..6 are used: a depth-3 tree)
 constexpr int SSC_COOP_MIN = 1024;                      // longer segments: block-cooperative partition
 constexpr int SSC_ARENA_WORDS = 20 * 1024;              // 80 KB of cover-grid bits (10 KB per speculating wave)
+constexpr int SSC_NMAX_SMALL = 6144;                    // levels up to this size: the 67 KB form, two workgroups per CU
 
-template <bool G> struct SscCfg;
-template <> struct SscCfg<false> { static constexpr int NMAX = SSC_NMAX_LDS, SEGMAX = 1088, PICKW = SSC_NMAX_LDS / 32; };
-template <> struct SscCfg<true> { static constexpr int NMAX = SSC_NMAX, SEGMAX = 4096, PICKW = SSC_PICKW_G; };
+// M = 0: sort arrays in LDS (<= SSC_NMAX_LDS candidates), M = 1: in HBM scratch, M = 2: in LDS, small level (<= SSC_NMAX_SMALL:
+// half the LDS and <= 64 VGPRs, so that two tasks share a CU - the tasks are latency-bound chains)
+template <int M> struct SscCfg;
+template <> struct SscCfg<0> { static constexpr int NMAX = SSC_NMAX_LDS, SEGMAX = 1088, PICKW = SSC_NMAX_LDS / 32, ARENA = SSC_ARENA_WORDS; };
+template <> struct SscCfg<1> { static constexpr int NMAX = SSC_NMAX, SEGMAX = 4096, PICKW = SSC_PICKW_G, ARENA = SSC_ARENA_WORDS; };
+template <> struct SscCfg<2> { static constexpr int NMAX = SSC_NMAX_SMALL, SEGMAX = 1088, PICKW = SSC_NMAX_SMALL / 32, ARENA = 10 * 1024; };
 
 // ordering of a wave's own accesses to the sort arrays: LDS traffic of a wave is processed in order (lgkmcnt);
 // the HBM instantiation also waits for its vector-memory operations
@@ -325,9 +329,10 @@ __device__ __forceinline__ void ssc_partition_coop(uint32_t* a, uint16_t* Lp, ui
     __syncthreads();
 }
 
-template <bool G>
-__global__ __launch_bounds__(SSC_NT) void k_ssc(SscArgs A) {
-    using C = SscCfg<G>;
+template <int M>
+__global__ __launch_bounds__(SSC_NT, (M == 2 ? 8 : 4)) void k_ssc(SscArgs A) {
+    using C = SscCfg<M>;
+    constexpr bool G = M == 1;
     extern __shared__ uint32_t lds[];
     // LDS instantiation:  [sorted = Lp | Rp : NMAX u32] [a : NMAX u32] [seg : 2 x SEGMAX x 2 u32]; after the sort the
     //                     cover-grid arena reuses a | seg (80 KB), the counting-sort histogram the seg lists (16 KB)
@@ -338,8 +343,8 @@ __global__ __launch_bounds__(SSC_NT) void k_ssc(SscArgs A) {
     int coff = 0;
     for (int q = 0; q < l; q++) coff += lc[q];
     const int n = lc[l];
-    const bool big = A.forceGlobal || n > SSC_NMAX_LDS;
-    if (big != G) return;                                // the other instantiation's task
+    const int mode = (A.forceGlobal || n > SSC_NMAX_LDS) ? 1 : (n > SSC_NMAX_SMALL ? 0 : 2);
+    if (mode != M) return;                               // another instantiation's task
     uint32_t* sortedU = G ? A.sortedG + (size_t)img * A.candCap + coff : lds;
     uint32_t* a = G ? A.aG + (size_t)img * A.candCap + coff : lds + C::NMAX;
     uint16_t* Lp = (uint16_t*)sortedU;
@@ -513,13 +518,13 @@ __global__ __launch_bounds__(SSC_NT) void k_ssc(SscArgs A) {
     const int kmin = A.kmin[l], kmax = A.kmax[l];
     const int cols = A.cols[l], rows = A.rows[l];
     uint32_t* gridG = A.gridG + A.gridOff[task];
-    constexpr int SLICE = SSC_ARENA_WORDS / SSC_NPROBE;
+    constexpr int SLICE = C::ARENA / SSC_NPROBE;
     // pick bitmasks: LDS instantiation at the top of the probing wave's arena slice; HBM instantiation in the task's scratch
     uint32_t* picksG = G ? A.picksG + (size_t)task * SSC_NPROBE * SSC_PICKW_G : nullptr;
     constexpr int PICKW_L = G ? 0 : C::PICKW;
     auto picks_of = [&](int slot) -> uint32_t* {         // slot < 0: the solo probe
         if (G) return picksG + (size_t)(slot < 0 ? SSC_NPROBE - 1 : slot) * SSC_PICKW_G;
-        return slot < 0 ? arena + SSC_ARENA_WORDS - PICKW_L : arena + slot * SLICE + SLICE - PICKW_L;
+        return slot < 0 ? arena + C::ARENA - PICKW_L : arena + slot * SLICE + SLICE - PICKW_L;
     };
     for (int round = 0; round < 64; round++) {
         if (tid == 0) {
@@ -567,7 +572,7 @@ __global__ __launch_bounds__(SSC_NT) void k_ssc(SscArgs A) {
         uint32_t* picks = picks_of(solo ? -1 : wave);
         if (wave < ns) {
             uint32_t* grid = solo ? arena : arena + wave * SLICE;
-            cnt = ssc_eval<G>(sc, n, sched[wave], cols, rows, grid, (solo ? SSC_ARENA_WORDS : SLICE) - PICKW_L, picks, fits, kmax);
+            cnt = ssc_eval<G>(sc, n, sched[wave], cols, rows, grid, (solo ? C::ARENA : SLICE) - PICKW_L, picks, fits, kmax);
             // a probe whose bit grid exceeds even the whole LDS arena (width 1-2 on a large level) uses the task's HBM grid
             if (solo && !fits) cnt = ssc_eval<G>(sc, n, sched[wave], cols, rows, gridG, 1 << 30, picks, fits, kmax);
         }
@@ -604,7 +609,7 @@ __global__ __launch_bounds__(SSC_NT) void k_ssc(SscArgs A) {
             if (wave == 0) {
                 uint32_t* pk = picks_of(-1);
                 bool fits;
-                int cnt = ssc_eval<G>(sc, n, sFinal, cols, rows, arena, SSC_ARENA_WORDS - PICKW_L, pk, fits, -1);
+                int cnt = ssc_eval<G>(sc, n, sFinal, cols, rows, arena, C::ARENA - PICKW_L, pk, fits, -1);
                 if (!fits) cnt = ssc_eval<G>(sc, n, sFinal, cols, rows, gridG, 1 << 30, pk, fits, -1);
                 if (lane == 0) sCnt[0] = cnt;
             }
@@ -663,17 +668,22 @@ __global__ __launch_bounds__(256) void k_ssc_pack(SscArgs A, uint32_t* __restric
 }
 
 void launch_ssc(hipStream_t s, const SscArgs& A, uint32_t* kept, int keptCap, int* keptOff, int* hostCounts) {
-    const size_t ldsL = ((size_t)2 * SscCfg<false>::NMAX + (size_t)4 * SscCfg<false>::SEGMAX) * 4;
-    const size_t ldsG = ((size_t)4 * SscCfg<true>::SEGMAX + (size_t)SSC_ARENA_WORDS) * 4;
-    static_assert((size_t)SscCfg<false>::NMAX + 4 * SscCfg<false>::SEGMAX >= (size_t)SSC_ARENA_WORDS, "arena must fit a | seg");
+    const size_t ldsL = ((size_t)2 * SscCfg<0>::NMAX + (size_t)4 * SscCfg<0>::SEGMAX) * 4;
+    const size_t ldsS = ((size_t)2 * SscCfg<2>::NMAX + (size_t)4 * SscCfg<2>::SEGMAX) * 4;
+    const size_t ldsG = ((size_t)4 * SscCfg<1>::SEGMAX + (size_t)SscCfg<1>::ARENA) * 4;
+    static_assert((size_t)SscCfg<0>::NMAX + 4 * SscCfg<0>::SEGMAX >= (size_t)SscCfg<0>::ARENA, "arena must fit a | seg");
+    static_assert((size_t)SscCfg<2>::NMAX + 4 * SscCfg<2>::SEGMAX >= (size_t)SscCfg<2>::ARENA, "arena must fit a | seg");
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)k_ssc<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsL);
-        (void)hipFuncSetAttribute((const void*)k_ssc<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsG);
+        (void)hipFuncSetAttribute((const void*)k_ssc<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsL);
+        (void)hipFuncSetAttribute((const void*)k_ssc<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsS);
+        (void)hipFuncSetAttribute((const void*)k_ssc<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsG);
         attr = true;
     }
-    hipLaunchKernelGGL(k_ssc<false>, dim3(A.nimg * A.nLevels), dim3(SSC_NT), ldsL, s, A);
-    hipLaunchKernelGGL(k_ssc<true>, dim3(A.nimg * A.nLevels), dim3(SSC_NT), ldsG, s, A);
+    // every (image, level) task is taken by exactly one of the three; the workgroups of the other two return at once
+    hipLaunchKernelGGL(k_ssc<2>, dim3(A.nimg * A.nLevels), dim3(SSC_NT), ldsS, s, A);
+    hipLaunchKernelGGL(k_ssc<0>, dim3(A.nimg * A.nLevels), dim3(SSC_NT), ldsL, s, A);
+    hipLaunchKernelGGL(k_ssc<1>, dim3(A.nimg * A.nLevels), dim3(SSC_NT), ldsG, s, A);
     hipLaunchKernelGGL(k_ssc_pack, dim3(A.nimg), dim3(256), 0, s, A, kept, keptCap, keptOff, hostCounts);
 }
 
