@@ -385,6 +385,7 @@ def main():
             "track_repredict": (nStep, lb * Mact * (24 + 60 + 12), 0),
             "pack": (nStep, lb * (Mact * 30 + nk * 8), 0),
             "imu_preintegrate": (2 * nStep, lb * (10 * 56 + 8 * (289 + 225)), lb * (10 * 2 * 2 * 15 ** 3 + 15 ** 3)),
+            "proj_cells": (2 * nStep, lb * 2 * nk * (28 + 2 + 2), 0),                       # keypoints in, bucketed indices out
             "proj_candidates": (2 * nStep, lb * b_cand, 0),                                # two passes per frame
             "proj_resolve": (2 * nStep, lb * b_res, 0),
             "pose_imu_lm": (2 * nStep, lb * b_pose, 0),                                    # two solves per frame
@@ -453,7 +454,7 @@ def main():
                 kname = {"proj_resolve": "k_proj_resolve" + bsfx, "pose_imu_lm": "k_pose_imu_lm" + bsfx, "pose_lm": "k_pose_lm" + bsfx,
                          "stereo_match": "k_stereo_match" + bsfx, "stereo_finalize": "k_stereo_finalize" + bsfx, "stereo_rows": "k_stereo_rows" + bsfx,
                          "proj_candidates": "k_proj_candidates" + bsfx, "imu_preintegrate": "k_imu_preintegrate" + bsfx,
-                         "track_predict": "k_track_predict" + bsfx, "pyramid": "k_resize", "ba_solve": "k_ba_solve_mfma64", "ssc": "k_ssc<false>",
+                         "track_predict": "k_track_predict" + bsfx, "pyramid": "k_resize", "ba_solve": "k_ba_solve_mfma64", "ssc": "k_ssc<2>",
                          "ba_schur": "k_ba_schur", "ba_back": "k_ba_back", "ba_eval": "k_ba_factors<1>", "ba_linearize": "k_ba_factors<0>",
                          "fast": "k_fast", "blur": "k_blur", "gather": "k_gather", "orient_desc": "k_orient_desc"}.get(dom)
                 if kname in pmc:
@@ -473,6 +474,16 @@ def main():
                              "why_small": "a %.0f-unknown system (%.1f free keyframes) is %.0f flops per candidate: one workgroup, latency-bound; "
                                           "launch_ms is measured with the other sessions' kernels sharing the GPU" % (nBA6, Fk, alg_flops)})
             out["roofline"] = roof
+            # the same per-launch pricing for the five groups with the most device time per tracked frame (context for `roofline`:
+            # which kernels move bytes and which are latency- / instruction-bound chains)
+            top = []
+            for k in sorted(per_frame, key=lambda q: -per_frame[q])[:5]:
+                n_l, ab, _ = groups.get(k, (nS, 0, 0))
+                ms_l = stage_ms[k] / max(n_l, 1)
+                gbs = ab / (ms_l * 1e-3) / 1e9 if ms_l > 0 else 0.0
+                top.append({"kernel": k, "ms_per_frame": per_frame[k], "launch_ms": ms_l, "algorithmic_bytes": ab,
+                            "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS})
+            out["roofline_top5"] = top
             if "ba_solve" not in stage_ms:   # no local BA of the sampled sessions fell into this (short) timed region
                 out["ba_solve_mfma"] = {"launch_ms": None, "unknowns": nBA6, "flops": groups["ba_solve"][2], "achieved_gflops": None, "fp64_frac": None,
                                         "note": "no sampled local BA in the timed region; profiles/r02_d_c2_kernel_stats.csv has the kernel "

@@ -495,10 +495,15 @@ __device__ __forceinline__ int reflect101(int p, int len) {
     return p;
 }
 
-// One thread = 4 horizontally adjacent pixels x BLUR_RPT rows: three aligned dword loads per input row give the 10 source
-// bytes; the horizontal pass is two v_dot4_u32_u8 per pixel (the taps are 8-bit), the 7 row sums of the vertical pass
-// roll through registers.  No LDS, no barrier; only the threads at the left / right image border take the byte-wise
-// REFLECT_101 path.  (Bit-identical to the LDS-tiled form it replaces: all sums are exact integers.)
+// One thread = 4 horizontally adjacent pixels x BLUR_RPT rows: three aligned dwords per input row give the 12-byte
+// window x-4 .. x+7 (the pixels need bytes 1 .. 10 of it); the horizontal pass is two v_dot4_u32_u8 per pixel (the taps
+// are 8-bit), the 7 row sums of the vertical pass roll through registers.  No LDS, no barrier, and NO divergent path:
+// REFLECT_101 is applied to the loaded window by byte permutes whose selectors a thread computes once (identity for
+// interior threads) - at the left border bytes 0..3 are the mirror of bytes 5..8, at the right border (m = w - x < 7)
+// bytes m+4 .. m+6 are the mirror of bytes m+2 .. m; the rows are wave-uniform (scalar reflect, scalar row pointers),
+// so all loads of a thread are independent and issue back to back.  (A first form branched per row between a dword
+// path and a byte-wise border path: every wave that held one border thread ran both, and the per-row branches
+// serialised the loads - 2.5x slower.)  Bit-identical to the LDS-tiled round-1 form: all sums are exact integers.
 __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr,
                                               uint8_t* __restrict__ blur, PyrDesc P, BlurDesc B) {
     const int img = blockIdx.y;
@@ -511,28 +516,42 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr,
     const uint8_t* __restrict__ S = pyr + (size_t)img * P.imgStride + P.off[level];
     uint8_t* __restrict__ D = blur + (size_t)img * P.imgStride + P.off[level];
     const int x = txb * BLUR_TW + (threadIdx.x & 63) * 4;
-    const int yb = tyb * BLUR_TH + (threadIdx.x >> 6) * BLUR_RPT;
-    if (x >= w || yb >= h) return;
+    const int yb = tyb * BLUR_TH + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * BLUR_RPT;
+    if (yb >= h || x >= w) return;
     const unsigned tA = (unsigned)B.taps[0] | ((unsigned)B.taps[1] << 8) | ((unsigned)B.taps[2] << 16) | ((unsigned)B.taps[3] << 24);
     const unsigned tB = (unsigned)B.taps[4] | ((unsigned)B.taps[5] << 8) | ((unsigned)B.taps[6] << 16);
     const int t0 = B.taps[0], t1 = B.taps[1], t2 = B.taps[2], t3 = B.taps[3];      // (symmetric: taps[6 - j] == taps[j])
-    const bool interior = x >= 4 && x + 8 <= w;
+    // border selectors (v_perm_b32(hi, lo, sel): selector bytes 0..3 pick from lo, 4..7 from hi)
+    const int m = w - x;                                   // 1 .. 7 at the right border
+    unsigned s1 = 0x07060504u;                             // d1' = perm(d1, d0, s1)
+    unsigned sA = 0x03020100u, sB = 0x07060504u;           // d2' = perm(d2, perm(d1, d0, sA), sB)
+    if (m == 1) s1 = 0x01020304u;
+    else if (m == 2) { s1 = 0x03040504u; sA = 0x00000002u; sB = 0x07060500u; }
+    else if (m == 3) { s1 = 0x05060504u; sA = 0x00000304u; sB = 0x07060100u; }
+    else if (m == 4) { sA = 0x00040506u; sB = 0x07020100u; }
+    else if (m == 5) { sA = 0x05060700u; sB = 0x03020104u; }
+    else if (m == 6) sB = 0x07040504u;
+    const bool leftEdge = x == 0;
+    const unsigned xo0 = leftEdge ? 0u : (unsigned)(x - 4), xo1 = (unsigned)x;
     unsigned hb[7][4];
 #pragma unroll
     for (int rr = 0; rr < BLUR_RPT + 6; rr++) {
-        const int sy = reflect101(yb + rr - 3, h);
+        // REFLECT_101 of the row, once (h >= 7); rows further below the image only feed output rows >= h, which are skipped
+        int sy = yb + rr - 3;
+        sy = sy < 0 ? -sy : sy;
+        sy = sy >= h ? 2 * h - 2 - sy : sy;
+        sy = sy < 0 ? 0 : sy;
         const uint8_t* row = S + (size_t)sy * pitch;
-        unsigned d0, d1, d2;
-        if (interior) {
-            d0 = *(const unsigned*)(row + x - 4); d1 = *(const unsigned*)(row + x); d2 = *(const unsigned*)(row + x + 4);
-        } else {
-            d0 = d1 = d2 = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                d0 |= (unsigned)row[reflect101(x - 4 + k, w)] << (8 * k);
-                d1 |= (unsigned)row[reflect101(x + k, w)] << (8 * k);
-                d2 |= (unsigned)row[reflect101(x + 4 + k, w)] << (8 * k);
-            }
+        unsigned d0 = *(const unsigned*)(row + xo0);
+        const uint2 d12 = *(const uint2*)(row + xo1);
+        unsigned d1 = d12.x, d2 = d12.y;
+        {
+            const unsigned mir = __builtin_amdgcn_perm(d2, d1, 0x01020304u);       // pixels 4, 3, 2, 1 of the row
+            const unsigned tmp = __builtin_amdgcn_perm(d1, d0, sA);
+            const unsigned n1 = __builtin_amdgcn_perm(d1, d0, s1);
+            d2 = __builtin_amdgcn_perm(d2, tmp, sB);
+            d1 = n1;
+            d0 = leftEdge ? mir : d0;
         }
         // pixel i of the four: source bytes i + 1 .. i + 7 of the 12-byte window d0 | d1 | d2
         unsigned nh[4];

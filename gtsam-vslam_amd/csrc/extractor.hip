@@ -182,8 +182,9 @@ vslam_status vslam_extractor::init(const vslam_fe_params* p, int w, int h, int b
     VS_HIP(hipEventCreateWithFlags(&evGather, hipEventDisableTiming));
     VS_HIP(hipEventCreateWithFlags(&evDone, hipEventDisableTiming));
     timer.stream = stream;
-    VS_HIP(hipMalloc(&d_pyr, (size_t)nimg * P.imgStride));
-    VS_HIP(hipMalloc(&d_blur, (size_t)nimg * P.imgStride));
+    // (+256: k_blur / k_resize read whole dwords up to 8 bytes past the last pixel of a row)
+    VS_HIP(hipMalloc(&d_pyr, (size_t)nimg * P.imgStride + 256));
+    VS_HIP(hipMalloc(&d_blur, (size_t)nimg * P.imgStride + 256));
     VS_HIP(vslam::memset_sync(d_pyr, 0, (size_t)nimg * P.imgStride));
     VS_HIP(vslam::memset_sync(d_blur, 0, (size_t)nimg * P.imgStride));
 

@@ -60,6 +60,8 @@ struct vslam_matcher {
     int* d_matchedL = nullptr;   // [cap]
     int* d_matchedR = nullptr;
     int* d_projOut = nullptr;    // {nMatches}
+    int* d_cellStart[2] = {nullptr, nullptr};             // [PROJ_MAX_CELLS + 1] matching-grid buckets of the current keys
+    unsigned short* d_cellIdx[2] = {nullptr, nullptr};    // [65536]
     vslam_status ensure_proj_cap(int M);
     vslam_status proj_enqueue(int M, float rad, const int* Mdev = nullptr, const int* gate = nullptr, int gateMin = 0, int mode = 0);
     void proj_lane(vslam::ProjLane& L, int M, float rad, const int* Mdev, const int* gate, int gateMin, int mode);
@@ -184,6 +186,9 @@ struct ProjArgs {
     float rad; float scalePyr[MAX_LEVELS];
     float xMult, yMult; int xGrids, yGrids;
     const int* rightIdxs; const int* leftIdxs;
+    // keypoints bucketed by matching-grid cell (k_proj_cells; null: scan_side tests every keypoint of the side):
+    // cellStart[side][cell .. cell + 1] delimits the cell's slice of cellIdx[side] (keypoint indices, any order)
+    int* cellStart[2]; unsigned short* cellIdx[2];
     // device-side control (tracking loop without host round trips): M is an upper bound (grid size) when
     // Mdev is set, the kernel reads the real count; with a gate the kernel is a no-op unless *gate >= gateMin
     const int* Mdev; const int* gate; int gateMin;
@@ -195,6 +200,8 @@ struct ProjLane {            // one lane of the batched projection matching
     int* matches; unsigned long long* topk; unsigned long long* stats; int* matchedL; int* matchedR; int* out;
 };
 void launch_proj_batch(hipStream_t s, const ProjLane* dLanes, int B, int maxM, int maxL, int maxR, StageTimer* tm = nullptr);
+constexpr int PROJ_MAX_CELLS = 64 * 64;      // xGrids = 64, yGrids = ceil(64 / aspect) <= 64 for landscape images
+void launch_proj_cells(hipStream_t s, const ProjArgs& A);
 void launch_proj_candidates(hipStream_t s, const ProjArgs& A, const int* matches,
                             unsigned long long* topk, unsigned long long* stats);
 void launch_proj_resolve(hipStream_t s, const ProjArgs& A, const unsigned long long* topk, int* matchedL, int* matchedR,

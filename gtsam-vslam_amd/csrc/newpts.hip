@@ -141,6 +141,7 @@ __global__ __launch_bounds__(256) void k_np_match(NpArgs A) {
     S.Mdev = nullptr; S.gate = nullptr; S.gateMin = 0; S.mpv = nullptr; S.M = 0; S.rightIdxs = nullptr; S.leftIdxs = nullptr;
     S.kps[0] = K.kpsL; S.kps[1] = K.kpsR; S.desc[0] = K.descL; S.desc[1] = K.descR; S.n[0] = K.nL; S.n[1] = K.nR;
     S.rad = 4.f;
+    S.cellStart[0] = S.cellStart[1] = nullptr; S.cellIdx[0] = S.cellIdx[1] = nullptr;      // (no buckets for a keyframe's keys)
 #pragma unroll
     for (int l = 0; l < MAX_LEVELS; l++) S.scalePyr[l] = A.scalePyr[l];
     S.xMult = A.xMult; S.yMult = A.yMult; S.xGrids = A.xGrids; S.yGrids = A.yGrids; S.mode = PROJ_STEREO;

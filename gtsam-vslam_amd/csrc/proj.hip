@@ -26,6 +26,60 @@ __device__ __forceinline__ void load_mp_desc(const vslam_mappoint_view* mp, uint
     for (int k = 0; k < 8; k++) md[k] = p[k];
 }
 
+// Keypoints of one side bucketed by matching-grid cell (the tracker's assignKeysToGrids, src/FeatureTracker.cpp:28-54, as a
+// counting sort): histogram of the cells in LDS, exclusive scan, scatter.  The order inside a cell is whatever the atomics
+// give - scan_side's keys carry (cell, index), so it never matters.  One workgroup per (side, lane).
+constexpr int PROJ_CELLS_NT = 1024;
+__device__ __forceinline__ void proj_cells_body(const ProjArgs& A, int side) {
+    extern __shared__ int cellHist[];                 // [nCells] counts -> running cursors
+    __shared__ int wsum[PROJ_CELLS_NT / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int* cs = A.cellStart[side];
+    unsigned short* ci = A.cellIdx[side];
+    if (!cs || !ci) return;
+    const int nCells = A.xGrids * A.yGrids, n = A.n[side];
+    const vslam_keypoint* kps = A.kps[side];
+    for (int c = tid; c < nCells; c += PROJ_CELLS_NT) cellHist[c] = 0;
+    __syncthreads();
+    for (int idx = tid; idx < n; idx += PROJ_CELLS_NT) {
+        int cx = __float2int_rn(kps[idx].x * A.xMult), cy = __float2int_rn(kps[idx].y * A.yMult);
+        cx = cx < 0 ? 0 : (cx >= A.xGrids ? A.xGrids - 1 : cx);
+        cy = cy < 0 ? 0 : (cy >= A.yGrids ? A.yGrids - 1 : cy);
+        atomicAdd(&cellHist[cy * A.xGrids + cx], 1);
+    }
+    __syncthreads();
+    // exclusive scan: a thread owns `per` consecutive cells
+    const int per = (nCells + PROJ_CELLS_NT - 1) / PROJ_CELLS_NT;
+    const int c0 = min(tid * per, nCells), c1 = min(c0 + per, nCells);
+    int mine = 0;
+    for (int c = c0; c < c1; c++) mine += cellHist[c];
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int run = incl - mine;
+    for (int k = 0; k < wave; k++) run += wsum[k];
+    for (int c = c0; c < c1; c++) { const int v = cellHist[c]; cs[c] = run; cellHist[c] = run; run += v; }
+    if (tid == PROJ_CELLS_NT - 1) cs[nCells] = run;       // (== n)
+    __syncthreads();
+    for (int idx = tid; idx < n; idx += PROJ_CELLS_NT) {
+        int cx = __float2int_rn(kps[idx].x * A.xMult), cy = __float2int_rn(kps[idx].y * A.yMult);
+        cx = cx < 0 ? 0 : (cx >= A.xGrids ? A.xGrids - 1 : cx);
+        cy = cy < 0 ? 0 : (cy >= A.yGrids ? A.yGrids - 1 : cy);
+        ci[atomicAdd(&cellHist[cy * A.xGrids + cx], 1)] = (unsigned short)idx;
+    }
+}
+__global__ __launch_bounds__(PROJ_CELLS_NT) void k_proj_cells(ProjArgs A) { proj_cells_body(A, blockIdx.x); }
+__global__ __launch_bounds__(PROJ_CELLS_NT) void k_proj_cells_b(const ProjLane* __restrict__ lanes) {
+    const ProjLane& L = *lane_entry(lanes, blockIdx.y);
+    proj_cells_body(L.A, blockIdx.x);
+}
+void launch_proj_cells(hipStream_t s, const ProjArgs& A) {
+    if (!A.cellStart[0]) return;
+    hipLaunchKernelGGL(k_proj_cells, dim3(A.mode == PROJ_STEREO ? 2 : 1), dim3(PROJ_CELLS_NT), (size_t)PROJ_MAX_CELLS * sizeof(int), s, A);
+}
+
 __device__ __forceinline__ void proj_candidates_body(const ProjArgs& A, const int* __restrict__ matches,
                                                      unsigned long long* __restrict__ topk,
                                                      unsigned long long* __restrict__ stats) {
@@ -439,7 +493,9 @@ void launch_proj_batch(hipStream_t s, const ProjLane* dLanes, int B, int maxM, i
     if (B <= 0 || maxM <= 0) return;
     proj_attrs();
     const int forceSeq = getenv("VSLAM_PROJ_SEQUENTIAL") ? 1 : 0;
-    int t = tm ? tm->begin("proj_candidates") : -1;
+    int t = tm ? tm->begin("proj_cells") : -1;
+    hipLaunchKernelGGL(k_proj_cells_b, dim3(2, B), dim3(PROJ_CELLS_NT), (size_t)PROJ_MAX_CELLS * sizeof(int), s, dLanes);
+    if (tm) { tm->end(t); t = tm->begin("proj_candidates"); }
     hipLaunchKernelGGL(k_proj_candidates_b, dim3((2 * maxM + 3) / 4, B), dim3(256), 0, s, dLanes);
     if (tm) { tm->end(t); t = tm->begin("proj_resolve"); }
     hipLaunchKernelGGL(k_proj_resolve_b, dim3(B), dim3(PROJ_NT), proj_resolve_lds(maxL, maxR), s, dLanes, forceSeq);
@@ -475,6 +531,10 @@ vslam_status vslam_matcher::ensure_proj_cap(int M) {
         VS_HIP(hipMalloc(&d_matchedL, (size_t)65536 * sizeof(int)));
         VS_HIP(hipMalloc(&d_matchedR, (size_t)65536 * sizeof(int)));
     }
+    for (int s = 0; s < 2; s++) {
+        if (!d_cellStart[s]) VS_HIP(hipMalloc(&d_cellStart[s], (size_t)(PROJ_MAX_CELLS + 1) * sizeof(int)));
+        if (!d_cellIdx[s]) VS_HIP(hipMalloc(&d_cellIdx[s], (size_t)65536 * sizeof(unsigned short)));
+    }
     return VSLAM_OK;
 }
 
@@ -493,6 +553,8 @@ void vslam_matcher::proj_lane(vslam::ProjLane& L, int M, float rad, const int* M
     A.xMult = (float)A.xGrids / (float)rig.width;
     A.yMult = (float)A.yGrids / (float)rig.height;
     A.rightIdxs = d_rightIdxs; A.leftIdxs = d_leftIdxs;
+    if (A.xGrids * A.yGrids <= PROJ_MAX_CELLS)
+        for (int s = 0; s < 2; s++) { A.cellStart[s] = d_cellStart[s]; A.cellIdx[s] = d_cellIdx[s]; }
     L.matches = d_matches; L.topk = d_topk; L.stats = d_stats; L.matchedL = d_matchedL; L.matchedR = d_matchedR; L.out = d_projOut;
 }
 
@@ -501,7 +563,10 @@ vslam_status vslam_matcher::proj_enqueue(int M, float rad, const int* Mdev, cons
     ProjLane L;
     proj_lane(L, M, rad, Mdev, gate, gateMin, mode);
     const ProjArgs& A = L.A;
-    int t = timer.begin("proj_candidates");
+    int t = timer.begin("proj_cells");
+    launch_proj_cells(stream, A);
+    timer.end(t);
+    t = timer.begin("proj_candidates");
     launch_proj_candidates(stream, A, d_matches, d_topk, d_stats);
     timer.end(t);
     t = timer.begin("proj_resolve");

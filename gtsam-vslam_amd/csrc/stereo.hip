@@ -76,8 +76,8 @@ __device__ __forceinline__ void stereo_match_body(const StereoArgs& A, int* __re
                                                   float* __restrict__ mDepth,
                                                   int* __restrict__ mSad,
                                                   unsigned long long* __restrict__ stats) {
-    __shared__ uint8_t winL[4][11 * 12];
-    __shared__ uint8_t winR[4][11 * 24];
+    __shared__ __attribute__((aligned(4))) uint8_t winL[4][11 * 12];
+    __shared__ __attribute__((aligned(4))) uint8_t winR[4][11 * 24];
     __shared__ int sadp[4][5 * 11];
     __shared__ unsigned int sStat[3];                 // tests, refined, accepted of this workgroup (one global atomic each)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -173,41 +173,50 @@ __device__ __forceinline__ void stereo_match_body(const StereoArgs& A, int* __re
     __syncthreads();
     SM_ACC(2);
     if (refine && lane < 55) {
+        // lane = (shift s, row group g): rows g, g + 5, g + 10; an 11-byte row is three dwords (v_sad_u8, last byte masked)
         const int s = lane % 11, g = lane / 11;
-        int acc = 0;
+        const int q = s >> 2;
+        const unsigned sh = (unsigned)(s & 3);
+        unsigned acc = 0;
         for (int r = g; r < 11; r += 5) {
-            const uint8_t* a = &winL[wave][r * 12];
-            const uint8_t* b = &winR[wave][r * 24 + s];
-#pragma unroll
-            for (int c = 0; c < 11; c++) acc += abs((int)a[c] - (int)b[c]);
+            const unsigned* a = (const unsigned*)&winL[wave][r * 12];
+            const unsigned* b = (const unsigned*)&winR[wave][r * 24] + q;
+            const unsigned b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+            acc = __builtin_amdgcn_sad_u8(a[0], __builtin_amdgcn_alignbyte(b1, b0, sh), acc);
+            acc = __builtin_amdgcn_sad_u8(a[1], __builtin_amdgcn_alignbyte(b2, b1, sh), acc);
+            acc = __builtin_amdgcn_sad_u8(a[2] & 0x00ffffffu, __builtin_amdgcn_alignbyte(b3, b2, sh) & 0x00ffffffu, acc);
         }
-        sadp[wave][g * 11 + s] = acc;
+        sadp[wave][g * 11 + s] = (int)acc;
     }
     __syncthreads();
     SM_ACC(3);
-    if (refine && lane == 0) {
-        float allDists[11];
-        int bestDistW = INT_MAX, bestX = 0;
-#pragma unroll
-        for (int s = 0; s < 11; s++) {
-            const int xMov = s - 5;
-            const float startW = scuR + xMov - 5;
-            const float endW = scuR + xMov + 5 + 1;
-            allDists[s] = 0.f;
-            if (startW < 0 || endW >= cols) continue;
-            const int tot = sadp[wave][s] + sadp[wave][11 + s] + sadp[wave][22 + s] +
-                            sadp[wave][33 + s] + sadp[wave][44 + s];
-            const float dist = (float)tot;
-            if ((float)bestDistW > dist) { bestX = xMov; bestDistW = (int)dist; }
-            allDists[s] = dist;
+    // the 11 shifts on lanes 0..10: total SAD of a shift, the first minimum (the reference loop's strict '>' keeps the
+    // earliest), its neighbours by shuffles (executed by every lane: no divergent shuffle)
+    float myDist = 0.f;
+    int myKey = INT_MAX;
+    if (refine && lane < 11) {
+        const int xMov = lane - 5;
+        const float startW = scuR + xMov - 5;
+        const float endW = scuR + xMov + 5 + 1;
+        if (!(startW < 0 || endW >= cols)) {
+            const int tot = sadp[wave][lane] + sadp[wave][11 + lane] + sadp[wave][22 + lane] +
+                            sadp[wave][33 + lane] + sadp[wave][44 + lane];
+            myDist = (float)tot;
+            myKey = (tot << 4) | lane;
         }
+    }
+    int minKey = myKey;
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) minKey = min(minKey, __shfl_xor(minKey, d));
+    const int bestX = minKey == INT_MAX ? 0 : (minKey & 15) - 5;
+    const int bestDistW = minKey == INT_MAX ? INT_MAX : (minKey >> 4);
+    const int ctr = (5 + bestX) & 15;
+    const float dist1 = __shfl(myDist, (ctr + 15) & 15), dist2 = __shfl(myDist, ctr), dist3 = __shfl(myDist, (ctr + 1) & 15);
+    if (refine && lane == 0) {
         int outBest = -1;
         float outDepth = -1.f;
         unsigned long long accepted = 0;
         if (!(bestX == -5 || bestX == 5)) {
-            const float dist1 = allDists[5 + bestX - 1];
-            const float dist2 = allDists[5 + bestX];
-            const float dist3 = allDists[5 + bestX + 1];
             const float delta = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
             if (!(delta > 1 || delta < -1)) {
                 accepted = 1;
@@ -541,6 +550,7 @@ void vslam_matcher::release() {
     if (evSolve) (void)hipEventDestroy(evSolve);
     hipFree(d_trVisL);
     hipFree(d_mpv); hipFree(d_topk); hipFree(d_matches); hipFree(d_matchedL); hipFree(d_matchedR); hipFree(d_projOut);
+    for (int s = 0; s < 2; s++) { hipFree(d_cellStart[s]); hipFree(d_cellIdx[s]); }
     if (stream && ownsStream) hipStreamDestroy(stream);
     stream = nullptr;
 }
