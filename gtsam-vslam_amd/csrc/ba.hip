@@ -1917,7 +1917,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         if (ws) ws->release();
         ws.reset(new Workspace()); ws->device = device;
         g_baRelease = []() { if (ws) { ws->release(); ws.reset(); } g_baTimer.destroy(); };
-        VS_HIP(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));
+        VS_HIP(vslam::create_side_stream(&ws->stream));
         VS_HIP(hipHostMalloc((void**)&ws->h_ctlOut, CTL_DOUBLES * sizeof(double), hipHostMallocDefault));
         {
             int nt = 3;      // + the calling thread; VSLAM_BA_HOST_THREADS overrides (0 = none)

@@ -117,9 +117,9 @@ vslam_status vslam_batch::init(const vslam_system_config* cfgs, int n, int hostT
         }
     }
     VS_HIP(hipSetDevice(device));
-    VS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    VS_HIP(vslam::create_main_stream(&stream));
     timer.stream = stream; timer.multi = true;
-    VS_HIP(hipStreamCreateWithFlags(&imuStream, hipStreamNonBlocking));
+    VS_HIP(vslam::create_main_stream(&imuStream));
     for (hipEvent_t* e : {&evTab, &evImu0, &evSolve0, &evImu1}) VS_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     VS_CHECK(vslam_extractor_create(&cfgs[0].fe, cfgs[0].rig.width, cfgs[0].rig.height, 2 * B, device, &fe));
     VS_CHECK(fe->enable_double_output());

@@ -155,6 +155,23 @@ struct DevPool {
     // vslam_thread_release(); what is left at thread exit is reclaimed with the process.
     ~DevPool() {}
 };
+// Streams.  MAIN streams carry the lockstep groups' wide kernels (extraction, matching, pose solves of all lanes); SIDE
+// streams carry keyframe-rate work (local BA, new points, descriptor selection, pose write-back): small launches with
+// large LDS footprints that wait behind the wide kernels for a CU with enough free LDS - a mapping pass of ~1.5 ms of
+// kernels takes ~7.8 ms of wall time at 128 sessions.  Two remedies were measured and rejected (128 sessions, 2 groups,
+// 24.5 k frames/s without them):
+//  * highest stream priority for the side streams (VSLAM_STREAM_PRIORITY=1, kept as a switch): mapping passes no shorter
+//    (7.96 vs 7.79 ms), the groups' own enqueue slower (0.62 -> 1.1-1.6 ms per step): 21.9 k frames/s;
+//  * a CU partition (hipExtStreamCreateWithCUMask: 240 CUs for the main streams, 16 or 32 for the side streams): every
+//    stream became ~4x slower, main and side alike (6.1 k frames/s) - removed.
+inline hipError_t create_side_stream(hipStream_t* s) {
+    static const bool high = []() { const char* e = getenv("VSLAM_STREAM_PRIORITY"); return e && atoi(e) != 0; }();
+    int least = 0, greatest = 0;
+    if (high && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+        return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+inline hipError_t create_main_stream(hipStream_t* s) { return hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
 // the calling thread's pool for `device` (switching devices releases the previous pool's blocks)
 inline DevPool& thread_pool_slot() { static thread_local DevPool pool; return pool; }
 inline DevPool* thread_pool(int device) {
@@ -162,7 +179,7 @@ inline DevPool* thread_pool(int device) {
     if (pool.device != device) {
         pool.release();
         pool.device = device;
-        if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&pool.stream, hipStreamNonBlocking) != hipSuccess) { pool.device = -1; return nullptr; }
+        if (hipSetDevice(device) != hipSuccess || create_side_stream(&pool.stream) != hipSuccess) { pool.device = -1; return nullptr; }
     }
     return &pool;
 }

@@ -178,7 +178,7 @@ vslam_status vslam_extractor::init(const vslam_fe_params* p, int w, int h, int b
     B.tileBase[nLevels] = tiles;
     build_gauss_taps(B.taps);
 
-    VS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    VS_HIP(vslam::create_main_stream(&stream));
     VS_HIP(hipEventCreateWithFlags(&evGather, hipEventDisableTiming));
     VS_HIP(hipEventCreateWithFlags(&evDone, hipEventDisableTiming));
     timer.stream = stream;
