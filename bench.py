@@ -26,10 +26,11 @@ import os
 import sys
 import time
 
-# Measured with tools/launchrate.hip: at most ~4 kernels of different streams run concurrently on this part, and asking
-# the runtime for more hardware queues only slows the launch path (22-38 us per launch at 8 threads with 32 queues).
-# 4 is the runtime's default; stated here so that the environment cannot silently change it.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
+# Hardware queues: the runtime's default is 4, and every stream of the process is mapped onto them - the small launches of
+# the mapping threads then sit behind a lockstep group's wide kernels in the same queue.  8 queues: +4-6 % frames/s and
+# shorter mapping passes (7.8 -> 7.4 ms) at 128 sessions; 16: no further gain; 32: slower launches (22-38 us per launch at
+# 8 launching threads, tools/launchrate.hip).  Stated here so that the environment cannot silently change it.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "gtsam-vslam_amd"))

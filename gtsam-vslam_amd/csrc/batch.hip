@@ -85,9 +85,10 @@ struct vslam_batch {
     // images of the NEXT step whose extraction was enqueued at the end of the previous one (prefetch)
     std::vector<const uint8_t*> prefetched;
     vslam_status enqueue_extraction(const uint8_t* const* L, const uint8_t* const* R, const uint8_t* mask, int stride, bool onDevice);
+    std::deque<std::chrono::steady_clock::time_point> mapQueuedAt;      // (parallel to mapQueue, under mqMu)
     static void submit_mapping(void* self, vslam_system* s) {
         vslam_batch* b = (vslam_batch*)self;
-        { std::lock_guard<std::mutex> lk(b->mqMu); b->mapQueue.push_back(s); }
+        { std::lock_guard<std::mutex> lk(b->mqMu); b->mapQueue.push_back(s); b->mapQueuedAt.push_back(std::chrono::steady_clock::now()); }
         b->mqCv.notify_one();
     }
     void map_loop() {
@@ -98,8 +99,22 @@ struct vslam_batch {
                 mqCv.wait(lk, [&] { return mqStop || !mapQueue.empty(); });
                 if (mapQueue.empty()) break;        // (stop requested and nothing left)
                 s = mapQueue.front(); mapQueue.pop_front();
+                const auto now = std::chrono::steady_clock::now();
+                const long long d = std::chrono::duration_cast<std::chrono::nanoseconds>(now - mapQueuedAt.front()).count();
+                mapQueuedAt.pop_front();
+                SysProf& p = sys_prof();
+                p.mqNs += d; p.mqN++;
+                if (d > 5000000) p.mqLate++;
+                long long m = p.mqMaxNs.load(); while (d > m && !p.mqMaxNs.compare_exchange_weak(m, d)) {}
             }
+            const auto t0 = std::chrono::steady_clock::now();
             s->run_mapping();
+            {
+                const long long d = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+                SysProf& p = sys_prof();
+                if (d > 15000000) p.mapLate++;
+                long long m = p.mapMaxNs.load(); while (d > m && !p.mapMaxNs.compare_exchange_weak(m, d)) {}
+            }
         }
         vslam::thread_release();
     }
@@ -180,6 +195,8 @@ void vslam_batch::release() {
                 p.descN.load(), avg(p.postNs, p.postN), p.postN.load());
         fprintf(stderr, "  mapping passes: %.1f us x %lld (find new points %.1f, vslam_local_ba %.1f) | frames that waited for their mapper: %.1f us x %lld\n",
                 avg(p.mapNs, p.mapN), p.mapN.load(), avg(p.npNs, p.npN), avg(p.baNs, p.baN), avg(p.waitNs, p.waitN), p.waitN.load());
+        fprintf(stderr, "  mapping queue: %.1f us average delay before a pass starts (%lld of %lld above 5 ms, longest %.1f ms) | passes above 15 ms: %lld, longest %.1f ms\n",
+                avg(p.mqNs, p.mqN), p.mqLate.load(), p.mqN.load(), 1e-6 * (double)p.mqMaxNs.load(), p.mapLate.load(), 1e-6 * (double)p.mapMaxNs.load());
     }
     // sessions first (each waits for its mapping job), then the mapping threads, then the shared objects
     for (vslam_system* s : sys) if (s) { s->release(); delete s; }
@@ -366,12 +383,13 @@ vslam_status vslam_batch::step(const uint8_t* const* L, const uint8_t* const* R,
     }
     VS_CHECK(ensure_dn(std::max<size_t>(dnBytes, 256)));
 
-    // ---- per-lane argument tables ---------------------------------------------------------------------------------------------
-    for (int b = 0; b < B; b++) {
+    // ---- per-lane argument tables (each lane fills its own entries: on the host-phase pool) ---------------------------------
+    std::vector<int> laneLds((size_t)B, 0);
+    pool.run(B, [&](int b) {
         LaneStep& q = ls[b];
         StereoLane& S = ht.stereo[b];
         if (!q.on) { S.A.nL = 0; S.A.nR = 0; }
-        else VS_CHECK(sys[b]->fm->stereo_lane(S));
+        else LANE_TRY(sys[b]->fm->stereo_lane(S));
         if (q.on) sys[b]->fm->stereoDone = true;
         const bool tr = q.on && !q.first;
         vslam_matcher* m = sys[b]->fm;
@@ -388,10 +406,11 @@ vslam_status vslam_batch::step(const uint8_t* const* L, const uint8_t* const* R,
             ht.repredict[b] = RepredictLane{};
             ht.pack[b] = PackLane{};
             ht.pack[b].count = m->d_trCount;
-            continue;
+            return;
         }
         vslam_system* s = sys[b];
-        VS_CHECK(m->track_begin(s->predNPose.data(), frames[b], useImu));
+        hipSetDevice(device);
+        LANE_TRY(m->track_begin(s->predNPose.data(), frames[b], useImu));
         const int Nub = std::max(m->trNub, 1);
         const int* Mdev = m->d_trCount + 1;
         const int* gate = m->d_poseOut;          // inlier count of the first round
@@ -405,7 +424,7 @@ vslam_status vslam_batch::step(const uint8_t* const* L, const uint8_t* const* R,
             m->pose_imu_lane(ht.pose0[b], Nub, Mdev, nullptr, minIn, 0, 0);
             m->pose_imu_lane(ht.pose1[b], Nub, Mdev, gate, minIn, 1, 0);
             m->imu_lane(ht.imu1[b], true);
-            ldsFactors = std::max(ldsFactors, std::max(ht.pose0[b].I.ldsFactors, ht.pose1[b].I.ldsFactors));
+            laneLds[b] = std::max(ht.pose0[b].I.ldsFactors, ht.pose1[b].I.ldsFactors);
         } else {
             m->pose_lane(ht.pose0[b].A, Nub, Mdev, nullptr, minIn, 0, 0);
             m->pose_lane(ht.pose1[b].A, Nub, Mdev, gate, minIn, 1, 0);
@@ -416,7 +435,9 @@ vslam_status vslam_batch::step(const uint8_t* const* L, const uint8_t* const* R,
         K.keyOut = q.wantKeys ? d_dn + q.keyOff : nullptr; K.nR = q.nR;
         K.kps[0] = m->d_kps[0]; K.kps[1] = m->d_kps[1]; K.desc[0] = m->d_desc[0]; K.desc[1] = m->d_desc[1];
         K.rightIdxs = m->d_rightIdxs; K.leftIdxs = m->d_leftIdxs; K.depth = m->d_depth; K.closef = m->d_close;
-    }
+    });
+    VS_CHECK(first_error());
+    for (int b = 0; b < B; b++) ldsFactors = std::max(ldsFactors, laneLds[b]);
     VS_HIP(hipMemcpyAsync(d_tab, h_tab, tabBytes, hipMemcpyHostToDevice, stream));
 
     // ---- device: every stage once for all lanes --------------------------------------------------------------------------------

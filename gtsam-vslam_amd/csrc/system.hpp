@@ -101,7 +101,8 @@ struct SysTrackState {
 };
 
 // VSLAM_BATCH_PHASES diagnostics: where the per-lane host phases spend their time (nanoseconds / calls, process-wide)
-struct SysProf { std::atomic<long long> lcaNs{0}, lcaN{0}, kfNs{0}, kfN{0}, descNs{0}, descN{0}, postNs{0}, postN{0}, mapNs{0}, mapN{0}, npNs{0}, npN{0}, baNs{0}, baN{0}, waitNs{0}, waitN{0}; };
+struct SysProf { std::atomic<long long> lcaNs{0}, lcaN{0}, kfNs{0}, kfN{0}, descNs{0}, descN{0}, postNs{0}, postN{0}, mapNs{0}, mapN{0}, npNs{0}, npN{0}, baNs{0}, baN{0}, waitNs{0}, waitN{0},
+                                            mqNs{0}, mqN{0}, mqLate{0}, mqMaxNs{0}, mapLate{0}, mapMaxNs{0}; };      // mapping queue delay / long passes
 SysProf& sys_prof();
 struct SysProfScope {
     std::atomic<long long>& ns; std::atomic<long long>& n; std::chrono::steady_clock::time_point t0;
