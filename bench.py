@@ -47,7 +47,7 @@ CONFIGS = {
                                                        "200 Hz IMU pre-integration factor in every pose solve"),
     "c3": dict(rig="kitti", nfeat=2000, imu=False, name="C3-class: KITTI-00-like stereo 1241x376, 2000 features/image"),
 }
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_d_pmc_summary.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_e_pmc_summary.json")
 
 
 def level_pixels(w, h, nlevels=8, scale=1.2):
@@ -454,7 +454,7 @@ def main():
                 bsfx = "_b" if lanes > 0 else ""
                 kname = {"proj_resolve": "k_proj_resolve" + bsfx, "pose_imu_lm": "k_pose_imu_lm" + bsfx, "pose_lm": "k_pose_lm" + bsfx,
                          "stereo_match": "k_stereo_match" + bsfx, "stereo_finalize": "k_stereo_finalize" + bsfx, "stereo_rows": "k_stereo_rows" + bsfx,
-                         "proj_candidates": "k_proj_candidates" + bsfx, "imu_preintegrate": "k_imu_preintegrate" + bsfx,
+                         "proj_candidates": "k_proj_candidates" + bsfx, "proj_cells": "k_proj_cells" + bsfx, "imu_preintegrate": "k_imu_preintegrate" + bsfx,
                          "track_predict": "k_track_predict" + bsfx, "pyramid": "k_resize", "ba_solve": "k_ba_solve_mfma64", "ssc": "k_ssc<2>",
                          "ba_schur": "k_ba_schur", "ba_back": "k_ba_back", "ba_eval": "k_ba_factors<1>", "ba_linearize": "k_ba_factors<0>",
                          "fast": "k_fast", "blur": "k_blur", "gather": "k_gather", "orient_desc": "k_orient_desc"}.get(dom)
@@ -487,7 +487,7 @@ def main():
             out["roofline_top5"] = top
             if "ba_solve" not in stage_ms:   # no local BA of the sampled sessions fell into this (short) timed region
                 out["ba_solve_mfma"] = {"launch_ms": None, "unknowns": nBA6, "flops": groups["ba_solve"][2], "achieved_gflops": None, "fp64_frac": None,
-                                        "note": "no sampled local BA in the timed region; profiles/r02_d_c2_kernel_stats.csv has the kernel "
+                                        "note": "no sampled local BA in the timed region; profiles/r02_e_c2_kernel_stats.csv has the kernel "
                                                 "(k_ba_solve_mfma64, ~35-40 us per launch): (6F)^3/3 flops per candidate - << 1 % of the fp64 MFMA peak"}
             if "ba_solve" in stage_ms:       # the only MFMA-eligible term of the path: always reported
                 n_l, _, fl = groups["ba_solve"]

@@ -2188,7 +2188,11 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         const int obsBlocks = std::max(1, std::min((NF + 255) / 256, 4 * nCU));
         const bool ldsS = F <= BA_LDS_MAX_F;
         const size_t sysDoubles = (size_t)n * n + n;
-        int schurWaves = BA_SCHUR_WAVES;
+        // waves per workgroup of the landmark kernels.  VSLAM_BA_SCHUR_WAVES / VSLAM_BA_BACK_WAVES cap them: a 16-wave workgroup
+        // with ~100 KB of LDS is the fastest form on an idle GPU, but it must find a whole CU's worth of free wave slots and LDS
+        // when the lockstep groups' wide kernels fill the chip; slimmer workgroups slot in between them.
+        static const int schurWavesCap = getenv("VSLAM_BA_SCHUR_WAVES") ? std::max(2, std::min(BA_SCHUR_WAVES, atoi(getenv("VSLAM_BA_SCHUR_WAVES")))) : BA_SCHUR_WAVES;
+        int schurWaves = schurWavesCap;
         constexpr int SCHUR_LPW = 64 / BA_LPL_SCHUR, BACK_LPW = 64 / BA_LPL_BACK;      // landmarks per wave
         // (nw waves = nw * LPW landmark units per workgroup)
         auto stage_lds = [&](int nw) { return (size_t)nw * SCHUR_LPW * 2 * maxSlots * 18 * sizeof(double) + (size_t)nw * SCHUR_LPW * maxSlots * sizeof(int) + 16; };
@@ -2201,8 +2205,8 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         size_t schurLds = 0;
         if (ldsS) {
             if (NB > 1 && sharedEnv) {
-                for (int nw : {16, 12, 8, 6, 4})
-                    if (schur_lds(nw, NB) <= 150 * 1024) { sharedW = 1; schurWaves = nw; break; }
+                for (int nw : {16, 12, 8, 6, 4, 2})
+                    if (nw <= schurWavesCap && schur_lds(nw, NB) <= 150 * 1024) { sharedW = 1; schurWaves = nw; break; }
             }
             if (!sharedW) while (schurWaves > 2 && schur_lds(schurWaves, 1) > 150 * 1024) schurWaves /= 2;
             schurLds = schur_lds(schurWaves, sharedW ? NB : 1);
@@ -2283,6 +2287,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         const int schurUnits = schurWaves * SCHUR_LPW;
         const int lmBlocks = std::max(1, std::min((Lp + schurUnits - 1) / schurUnits, nCU));
         int backWaves = BA_SCHUR_WAVES / BACK_LPW;
+        { static const int cap = getenv("VSLAM_BA_BACK_WAVES") ? std::max(1, atoi(getenv("VSLAM_BA_BACK_WAVES"))) : 64; backWaves = std::min(backWaves, cap); }
         auto back_lds = [&](int nw) { return (size_t)nw * BACK_LPW * maxSlots * 18 * sizeof(double) + (size_t)nw * BACK_LPW * maxSlots * sizeof(int) + 16; };
         while (backWaves > 1 && back_lds(backWaves) > 150 * 1024) backWaves /= 2;
         const int backBlocks = std::max(1, std::min((Lp + backWaves * BACK_LPW - 1) / (backWaves * BACK_LPW), nCU));
