@@ -1791,8 +1791,11 @@ struct DevBuf {
     size_t n = 0;
     hipError_t alloc(size_t count) {
         if (count <= n && p) return hipSuccess;
+        // grow with headroom: a mapping thread serves sessions whose windows differ a little from call to call, and every
+        // new maximum used to cost a hipFree (a device-wide synchronisation: it waits for the lockstep groups' kernels) +
+        // hipMalloc - 1.6 ms per local BA on average at 128 sessions
         if (p) hipFree(p);
-        n = std::max<size_t>(count, 1);
+        n = std::max<size_t>(2 * count, (size_t)1 << 20);      // (>= 1 M elements: the windows of a tracker never re-allocate)
         return hipMalloc(&p, n * sizeof(T));
     }
 };
@@ -1813,7 +1816,7 @@ struct PinnedArena {
         if (h) hipHostFree(h);
         if (d) hipFree(d);
         h = nullptr; d = nullptr;
-        cap = bytes + bytes / 4 + 4096;
+        cap = 2 * bytes + (64 << 10);       // (re-growing costs a synchronisation + two device-synchronising frees)
         e = hipHostMalloc((void**)&h, cap, hipHostMallocDefault);
         if (e != hipSuccess) return e;
         return hipMalloc((void**)&d, cap);
@@ -1854,11 +1857,21 @@ static double bhs_now() { return std::chrono::duration<double, std::micro>(std::
 #define BHS(name) do { hipStreamSynchronize(stream); const double t_ = bhs_now(); fprintf(stderr, "  ba host: %-12s %8.1f us\n", name, t_ - bhs_t); bhs_t = t_; } while (0)
 #define BHS2(name) do { const double t_ = bhs_now(); fprintf(stderr, "     prep: %-12s %8.1f us\n", name, t_ - bhs_t2); bhs_t2 = t_; } while (0)
 #else
-#define BHS(name) do {} while (0)
+// cumulative wall time between the section marks of ba_run (no synchronisation added): VSLAM_BATCH_PHASES diagnostics
+#include <chrono>
+#include <atomic>
+static std::atomic<long long> g_bhsNs[16], g_bhsCalls{0};
+static const char* g_bhsName[16] = {"s_check", "s_ws", "s_alloc", "s_const", "setup", "prep", "u_arena", "u_alloc", "u_attr", "upload", "lm", "chi2", "fetch", nullptr, nullptr, nullptr};
+static int bhs_slot(const char* name) { for (int i = 0; i < 16 && g_bhsName[i]; i++) if (!strcmp(g_bhsName[i], name)) return i; return 15; }
+#define BHS(name) do { const auto t_ = std::chrono::steady_clock::now(); g_bhsNs[bhs_slot(name)] += std::chrono::duration_cast<std::chrono::nanoseconds>(t_ - bhs_t).count(); bhs_t = t_; } while (0)
 #define BHS2(name) do {} while (0)
 #endif
 
 static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int device, const vslam_comm* comm) {
+#ifndef VSLAM_HOST_STAMPS
+    auto bhs_t = std::chrono::steady_clock::now();
+    g_bhsCalls++;
+#endif
     if (!P || !R || P->n_kf < 1 || P->n_lm < 0 || P->n_pairs < 0 || P->n_levels < 1 || P->n_levels > MAX_LEVELS ||
         !P->kf_pose_wc || !P->kf_id || !P->kf_fixed || !P->kf_local || !P->sigma_factor || !P->inv_sigma_factor ||
         !R->kf_pose_wc || !R->lm_xyz || !R->pair_wrong ||
@@ -1878,6 +1891,9 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
             P->pair_octave[2 * p] < 0 || P->pair_octave[2 * p] >= P->n_levels || P->pair_octave[2 * p + 1] < 0 ||
             P->pair_octave[2 * p + 1] >= P->n_levels) { set_error("vslam_local_ba: pair index out of range"); return VSLAM_ERR_INVALID; }
 
+#ifndef VSLAM_HOST_STAMPS
+    BHS("s_check");
+#endif
     // grow-only device workspace + stream, kept per host thread across calls (one local BA per keyframe:
     // re-allocating ~40 buffers every call cost more than the solve itself)
     struct Workspace {
@@ -1894,6 +1910,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         double* h_ctlOut = nullptr;
         DevBuf<uint8_t> d_const; uint8_t* h_const = nullptr; size_t constCap = 0;      // the call's constant inputs, one block
         uint8_t* h_wrong = nullptr; size_t wrongCap = 0;
+        uint8_t* h_out = nullptr; size_t outCap = 0;                     // pinned landing area of the result (poses | landmarks)
         // released when the owning host thread ends (or switches device): a short-lived optimizer thread must not
         // leak its stream, pinned buffers and pool threads
         ~Workspace() {}          // (no HIP calls from a thread_local destructor: see DevPool)
@@ -1910,6 +1927,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
             if (h_const) hipHostFree(h_const);
             if (d_const.p) hipFree(d_const.p);
             if (h_wrong) hipHostFree(h_wrong);
+            if (h_out) hipHostFree(h_out);
         }
     };
     static thread_local std::unique_ptr<Workspace> ws;
@@ -1927,9 +1945,20 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
     }
     if ((size_t)P->n_pairs > ws->wrongCap) {
         if (ws->h_wrong) hipHostFree(ws->h_wrong);
-        ws->wrongCap = (size_t)P->n_pairs + 4096;
+        ws->wrongCap = 2 * (size_t)P->n_pairs + 4096;
         VS_HIP(hipHostMalloc((void**)&ws->h_wrong, ws->wrongCap, hipHostMallocDefault));
     }
+    {
+        const size_t need = (size_t)P->n_kf * sizeof(DPose) + 64 + (size_t)3 * P->n_lm * sizeof(double);
+        if (need > ws->outCap) {
+            if (ws->h_out) hipHostFree(ws->h_out);
+            ws->outCap = need + need / 2 + 4096;
+            VS_HIP(hipHostMalloc((void**)&ws->h_out, ws->outCap, hipHostMallocDefault));
+        }
+    }
+#ifndef VSLAM_HOST_STAMPS
+    BHS("s_ws");
+#endif
     hipStream_t stream = ws->stream;
     g_baTimer.reset();
     g_baTimer.stream = stream;
@@ -1957,6 +1986,9 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
     VS_HIP(d_poseS.alloc((size_t)nSlots * K));
     VS_HIP(d_lmS.alloc((size_t)nSlots * 3 * L));
     VS_HIP(d_wrong.alloc(NP));
+#ifndef VSLAM_HOST_STAMPS
+    BHS("s_alloc");
+#endif
     size_t cBytes = 0;
     auto cOff = [&](size_t bytes) { const size_t at = cBytes; cBytes = (cBytes + std::max<size_t>(bytes, 8) + 255) & ~(size_t)255; return at; };
     const size_t oPose0 = cOff((size_t)K * sizeof(DPose)), oLm0 = cOff((size_t)3 * L * sizeof(double)), oPairKf = cOff((size_t)NP * 4),
@@ -1965,12 +1997,12 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
     // small problems (a tracker's local window): through the pinned block, one copy.  Large ones (the 100 k-landmark window:
     // 40 MB of pair arrays): straight from the caller's arrays - staging them would cost a host memcpy of the same size.
     const bool staged = cBytes <= ((size_t)8 << 20);
-    if (ws->d_const.n < cBytes) VS_HIP(ws->d_const.alloc(cBytes + cBytes / 4));
+    if (ws->d_const.n < cBytes) VS_HIP(ws->d_const.alloc(cBytes));     // (DevBuf adds its own headroom)
     if (staged && cBytes > ws->constCap) {
         VS_HIP(hipStreamSynchronize(stream));
         if (ws->h_const) hipHostFree(ws->h_const);
         ws->h_const = nullptr;
-        ws->constCap = cBytes + cBytes / 4;
+        ws->constCap = 2 * cBytes + (64 << 10);
         VS_HIP(hipHostMalloc((void**)&ws->h_const, ws->constCap, hipHostMallocDefault));
     }
     {
@@ -1989,6 +2021,9 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         VS_HIP(put(oKfLocal, P->kf_local, (size_t)K));
         if (h) VS_HIP(hipMemcpyAsync(d, h, cBytes, hipMemcpyHostToDevice, stream));
     }
+#ifndef VSLAM_HOST_STAMPS
+    BHS("s_const");
+#endif
     uint8_t* const dc = ws->d_const.p;
     DPose* const p_pose0 = (DPose*)(dc + oPose0);
     double* const p_lm0 = (double*)(dc + oLm0);
@@ -2000,6 +2035,10 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
 
     std::vector<uint8_t> wrong(NP, 0);
     DPose* poseFinal = p_pose0;
+    // pinned landing area of the result (see the end of this function)
+    DPose* poseOut = (DPose*)ws->h_out;
+    double* lmOut = (double*)(ws->h_out + (((size_t)K * sizeof(DPose) + 63) & ~(size_t)63));
+    bool resultFetched = false;
     double* lmFinal = p_lm0;
     const int nCU = 256;
     auto& A = ws->arena;
@@ -2159,6 +2198,9 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
 
         // ---- upload ------------------------------------------------------------------------------
         VS_HIP(A.upload(stream));
+#ifndef VSLAM_HOST_STAMPS
+        BHS("u_arena");
+#endif
         const size_t sysStride = (size_t)n * n + 2 * n + 8, seDoubles = (size_t)n * n + n;
         VS_HIP(d_facJ.alloc((size_t)20 * NF * (specLin ? nSlots : 1)));
         VS_HIP(d_dP.alloc((size_t)NB * n)); VS_HIP(d_dL.alloc((size_t)NB * 3 * Lp));
@@ -2301,6 +2343,9 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         const int ldA = ((n + 31) / 32) * 32 + 1;     // row stride = 1 (mod 32) doubles: conflict-free row-per-lane access
         const size_t solveLdsBytes = ((size_t)n * ldA + n + 8) * sizeof(double);
         const bool solveLds = solveLdsBytes <= 150 * 1024;
+#ifndef VSLAM_HOST_STAMPS
+        BHS("u_alloc");
+#endif
         if (n > 1024) { set_error("local BA: more than 170 free keyframes is not supported"); return VSLAM_ERR_CAPACITY; }
         if (schurLds > 160 * 1024) { set_error("local BA: landmark with too many views for the LDS staging"); return VSLAM_ERR_CAPACITY; }
         if (ldsS) VS_HIP(hipFuncSetAttribute((const void*)k_ba_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurLds));
@@ -2324,10 +2369,14 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
             VS_HIP(hipFuncSetAttribute((const void*)k_ba_chol_col, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cholColLds));
             VS_HIP(hipFuncSetAttribute((const void*)k_ba_chol_back, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cholBackLds));
         }
+#ifndef VSLAM_HOST_STAMPS
+        BHS("u_attr");
+#endif
         BHS("upload");
 
         // ---- LM: speculative steps, the device decides (k_ba_ctl) -----------------------------------
         auto run_lm = [&](int ps, long long nfStat, long long lpStat, long long k2Stat) -> vslam_status {
+        (void)poseOut; (void)lmOut;
         // One step = [linearise if the state asks for it] + one lambda trial.  Kernels that are not due
         // return at once, so the host may enqueue a few steps ahead and only then look at the state.
         const int fuseCtl = comm ? 0 : 1;
@@ -2433,6 +2482,11 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         g_baTimer.end(t);
         VS_HIP(hipGetLastError());
         if (NP) VS_HIP(hipMemcpyAsync(ws->h_wrong, d_wrong.p, NP, hipMemcpyDeviceToHost, stream));
+        if (ps == 1) {      // the second pass is the last one: its values ride behind the flags, one synchronisation for both
+            VS_HIP(hipMemcpyAsync(poseOut, D.poseCur, K * sizeof(DPose), hipMemcpyDeviceToHost, stream));
+            if (L) VS_HIP(hipMemcpyAsync(lmOut, D.lmCur, (size_t)3 * L * sizeof(double), hipMemcpyDeviceToHost, stream));
+            resultFetched = true;
+        }
         VS_HIP(hipStreamSynchronize(stream));
         if (NP) memcpy(wrong.data(), ws->h_wrong, NP);
         if (ps == 0 && R->pair_wrong_pass1 && NP) memcpy(R->pair_wrong_pass1, wrong.data(), NP);
@@ -2487,14 +2541,32 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         }
     }
     BHS("chi2");
-    std::vector<DPose> poseOut(K);
-    VS_HIP(hipMemcpyAsync(poseOut.data(), poseFinal, K * sizeof(DPose), hipMemcpyDeviceToHost, stream));
-    if (L) VS_HIP(hipMemcpyAsync(R->lm_xyz, lmFinal, (size_t)3 * L * sizeof(double), hipMemcpyDeviceToHost, stream));
-    VS_HIP(hipStreamSynchronize(stream));
+    // results land in pinned memory (a copy into the caller's pageable arrays is staged and synchronised by the runtime)
+    BHS("fetch");
+    if (!resultFetched) {
+        VS_HIP(hipMemcpyAsync(poseOut, poseFinal, K * sizeof(DPose), hipMemcpyDeviceToHost, stream));
+        if (L) VS_HIP(hipMemcpyAsync(lmOut, lmFinal, (size_t)3 * L * sizeof(double), hipMemcpyDeviceToHost, stream));
+        VS_HIP(hipStreamSynchronize(stream));
+    }
     for (int k = 0; k < K; k++) pose_to_rm16(poseOut[k], R->kf_pose_wc + 16 * (size_t)k);
+    if (L) memcpy(R->lm_xyz, lmOut, (size_t)3 * L * sizeof(double));
     if (NP) memcpy(R->pair_wrong, wrong.data(), NP);
     return VSLAM_OK;
 }
+
+namespace vslam {
+// VSLAM_BATCH_PHASES: where ba_run's wall time goes (averages per call; the marks do not synchronise, so "lm" holds the
+// polls of both LM loops, "chi2" the re-check + second-pass preparation + result fetch)
+void ba_host_profile_print() {
+#ifndef VSLAM_HOST_STAMPS
+    const long long n = g_bhsCalls.load();
+    if (!n) return;
+    fprintf(stderr, "  vslam_local_ba host sections (us per call, %lld calls):", n);
+    for (int i = 0; i < 16; i++) if (g_bhsName[i] || g_bhsNs[i].load()) fprintf(stderr, " %s %.1f |", g_bhsName[i] ? g_bhsName[i] : "other", 1e-3 * (double)g_bhsNs[i].load() / (double)n);
+    fprintf(stderr, "\n");
+#endif
+}
+}  // namespace vslam
 
 extern "C" {
 
@@ -2557,24 +2629,43 @@ vslam_status vslam_ba_refresh_depth(const vslam_rig* rig, int32_t n_kf, const do
                  oD = take(n_pairs * sizeof(float)), oC = take(n_pairs), oU = take(n_pairs);
     PoolBuf<uint8_t> mem(pool);
     VS_HIP(mem.alloc(off));
-    VS_HIP(pool->h2d(mem.p + oT, Tcw.data(), n_kf * sizeof(DPose)));
-    if (n_lm) {
-        VS_HIP(pool->h2d(mem.p + oLm, lm_xyz, (size_t)3 * n_lm * sizeof(double)));
-        VS_HIP(pool->h2d(mem.p + oO, lm_outlier, n_lm));
+    // ONE upload for the seven inputs (they are laid out back to back, oT .. oCur: staged in the pool's pinned arena in the
+    // device layout) and ONE download for the three outputs (oD .. oU): every copy is a blit launch that queues behind the
+    // lockstep groups' wide kernels, and a mapping pass had ~37 of them
+    {
+        const size_t inBytes = oD;
+        uint8_t* st = pool->stage(inBytes);
+        auto put = [&](size_t at, const void* src, size_t bytes) -> hipError_t {
+            if (!bytes) return hipSuccess;
+            if (st) { memcpy(st + at, src, bytes); return hipSuccess; }
+            return pool->h2d(mem.p + at, src, bytes);      // (no staging room yet: one copy per array)
+        };
+        VS_HIP(put(oT, Tcw.data(), n_kf * sizeof(DPose)));
+        if (n_lm) { VS_HIP(put(oLm, lm_xyz, (size_t)3 * n_lm * sizeof(double))); VS_HIP(put(oO, lm_outlier, n_lm)); }
+        VS_HIP(put(oKf, pair_kf, n_pairs * sizeof(int))); VS_HIP(put(oL, pair_lm, n_pairs * sizeof(int)));
+        VS_HIP(put(oW, pair_wrong, n_pairs)); VS_HIP(put(oCur, cur_depth, n_pairs * sizeof(float)));
+        if (st) VS_HIP(hipMemcpyAsync(mem.p, st, inBytes, hipMemcpyHostToDevice, ps));
     }
-    VS_HIP(pool->h2d(mem.p + oKf, pair_kf, n_pairs * sizeof(int)));
-    VS_HIP(pool->h2d(mem.p + oL, pair_lm, n_pairs * sizeof(int)));
-    VS_HIP(pool->h2d(mem.p + oW, pair_wrong, n_pairs));
-    VS_HIP(pool->h2d(mem.p + oCur, cur_depth, n_pairs * sizeof(float)));
     const float closeTh = rig->baseline * 40;
     hipLaunchKernelGGL(k_ba_refresh_depth, dim3((n_pairs + 255) / 256), dim3(256), 0, ps, n_pairs, (const int*)(mem.p + oKf),
                        (const int*)(mem.p + oL), (const uint8_t*)(mem.p + oW), (const uint8_t*)(mem.p + oO), (const float*)(mem.p + oCur),
                        (const DPose*)(mem.p + oT), (const double*)(mem.p + oLm), closeTh, (float*)(mem.p + oD), mem.p + oC, mem.p + oU);
     VS_HIP(hipGetLastError());
-    VS_HIP(pool->d2h(depth_out, mem.p + oD, n_pairs * sizeof(float)));
-    VS_HIP(pool->d2h(close_out, mem.p + oC, n_pairs));
-    VS_HIP(pool->d2h(updated_out, mem.p + oU, n_pairs));
-    VS_HIP(pool->sync());
+    {
+        const size_t outBytes = off - oD;
+        uint8_t* st = pool->stage(outBytes);
+        if (st) {
+            VS_HIP(hipMemcpyAsync(st, mem.p + oD, outBytes, hipMemcpyDeviceToHost, ps));
+            VS_HIP(hipStreamSynchronize(ps));
+            memcpy(depth_out, st, n_pairs * sizeof(float)); memcpy(close_out, st + (oC - oD), n_pairs); memcpy(updated_out, st + (oU - oD), n_pairs);
+            VS_HIP(pool->sync());       // (recycles the arena - and may re-allocate it, hence after the copies)
+        } else {
+            VS_HIP(pool->d2h(depth_out, mem.p + oD, n_pairs * sizeof(float)));
+            VS_HIP(pool->d2h(close_out, mem.p + oC, n_pairs));
+            VS_HIP(pool->d2h(updated_out, mem.p + oU, n_pairs));
+            VS_HIP(pool->sync());
+        }
+    }
     return VSLAM_OK;
 }
 

@@ -34,6 +34,7 @@ void launch_pose_imu_batch(hipStream_t s, const PoseLane* dLanes, int B, int lds
 void launch_imu_batch(hipStream_t s, const ImuLane* dLanes, int B);
 }
 
+namespace vslam { void ba_host_profile_print(); }
 using namespace vslam;
 using namespace vslam_sys;
 
@@ -195,6 +196,7 @@ void vslam_batch::release() {
                 p.descN.load(), avg(p.postNs, p.postN), p.postN.load());
         fprintf(stderr, "  mapping passes: %.1f us x %lld (find new points %.1f, vslam_local_ba %.1f) | frames that waited for their mapper: %.1f us x %lld\n",
                 avg(p.mapNs, p.mapN), p.mapN.load(), avg(p.npNs, p.npN), avg(p.baNs, p.baN), avg(p.waitNs, p.waitN), p.waitN.load());
+        vslam::ba_host_profile_print();
         fprintf(stderr, "  mapping queue: %.1f us average delay before a pass starts (%lld of %lld above 5 ms, longest %.1f ms) | passes above 15 ms: %lld, longest %.1f ms\n",
                 avg(p.mqNs, p.mqN), p.mqLate.load(), p.mqN.load(), 1e-6 * (double)p.mqMaxNs.load(), p.mapLate.load(), 1e-6 * (double)p.mapMaxNs.load());
     }

@@ -580,6 +580,9 @@ extern "C" vslam_status vslam_find_new_points(const vslam_new_points_problem* P,
         off[k].ri = packOff((size_t)V.n_left * 4); off[k].li = packOff((size_t)V.n_right * 4);
         off[k].uf = packOff((size_t)V.n_left * 4); off[k].ufr = packOff((size_t)V.n_right * 4);
     }
+    // (... and the first keyframe's per-keypoint inputs ride in the same copy)
+    const size_t oDepth = packOff((size_t)cap * sizeof(float)), oHas = packOff((size_t)cap), oMpXyz = packOff((size_t)3 * cap * sizeof(double)),
+                 oMpDesc = packOff((size_t)32 * cap);
     Dev<uint8_t> dPack(pool);
     VS_HIP(dPack.alloc(std::max<size_t>(packBytes, 64)));
     uint8_t* hPack = pool->stage(packBytes);
@@ -604,27 +607,38 @@ extern "C" vslam_status vslam_find_new_points(const vslam_new_points_problem* P,
         D.nL = V.n_left; D.nR = V.n_right;
         D.skip = (k > 0 && V.id == P->kfs[0].id) ? 1 : 0;
     }
+    {
+        auto put = [&](size_t at, const void* src, size_t bytes) -> hipError_t {
+            if (!bytes || !src) return hipSuccess;
+            if (hPack) { memcpy(hPack + at, src, bytes); return hipSuccess; }
+            return pool->h2d(dPack.p + at, src, bytes);
+        };
+        VS_HIP(put(oDepth, P->estimated_depth, (size_t)K0.n_left * sizeof(float))); VS_HIP(put(oHas, P->has_mp, (size_t)K0.n_left));
+        VS_HIP(put(oMpXyz, P->mp_xyz, (size_t)3 * K0.n_left * sizeof(double))); VS_HIP(put(oMpDesc, P->mp_desc, (size_t)32 * K0.n_left));
+    }
     if (hPack && packBytes) VS_HIP(hipMemcpyAsync(dPack.p, hPack, packBytes, hipMemcpyHostToDevice, stream));
-    Dev<float> dDepth(pool), dMds(pool); Dev<uint8_t> dHas(pool), dMpDesc(pool), dCdesc(pool), dAcc(pool); Dev<double> dMpXyz(pool), dWpos(pool), dXyz(pool);
-    Dev<int> dKey(pool), dCount(pool), dMatch(pool), dNobs(pool), dObs(pool);
-    VS_HIP(dDepth.up(P->estimated_depth, K0.n_left)); VS_HIP(dHas.up(P->has_mp, K0.n_left));
-    if (P->mp_xyz) VS_HIP(dMpXyz.up(P->mp_xyz, (size_t)3 * K0.n_left)); else VS_HIP(dMpXyz.alloc((size_t)3 * cap));
-    if (P->mp_desc) VS_HIP(dMpDesc.up(P->mp_desc, (size_t)32 * K0.n_left)); else VS_HIP(dMpDesc.alloc((size_t)32 * cap));
-    VS_HIP(dWpos.alloc((size_t)3 * cap)); VS_HIP(dKey.alloc((size_t)2 * cap)); VS_HIP(dMds.alloc(cap)); VS_HIP(dCdesc.alloc((size_t)32 * cap));
-    VS_HIP(dCount.alloc(4)); VS_HIP(dMatch.alloc((size_t)cap * NP_MAX_KF * 2)); VS_HIP(dAcc.alloc(cap)); VS_HIP(dXyz.alloc((size_t)3 * cap));
-    VS_HIP(dNobs.alloc(cap)); VS_HIP(dObs.alloc((size_t)cap * NP_MAX_KF * 3));
-    VS_HIP(hipMemsetAsync(dAcc.p, 0, cap, stream)); VS_HIP(hipMemsetAsync(dXyz.p, 0, (size_t)3 * cap * sizeof(double), stream));
-    VS_HIP(hipMemsetAsync(dNobs.p, 0, (size_t)cap * sizeof(int), stream));
-    VS_HIP(hipMemsetAsync(dObs.p, 0xff, (size_t)cap * NP_MAX_KF * 3 * sizeof(int), stream));
-    A.depth = dDepth.p; A.hasMp = dHas.p; A.mpXyz = dMpXyz.p; A.mpDesc = dMpDesc.p;
+    Dev<float> dMds(pool); Dev<uint8_t> dCdesc(pool), dRes(pool); Dev<double> dWpos(pool);
+    Dev<int> dMatch(pool);
+    VS_HIP(dWpos.alloc((size_t)3 * cap)); VS_HIP(dMds.alloc(cap)); VS_HIP(dCdesc.alloc((size_t)32 * cap));
+    VS_HIP(dMatch.alloc((size_t)cap * NP_MAX_KF * 2));
+    // ONE result block, fetched by one copy at capacity: [xyz | nObs | accepted] (zero-filled) [obs] (0xff-filled) [key | count]
+    size_t resBytes = 0;
+    auto resOff = [&](size_t bytes) { const size_t at = resBytes; resBytes = (resBytes + bytes + 63) & ~(size_t)63; return at; };
+    const size_t rXyz = resOff((size_t)3 * cap * sizeof(double)), rNobs = resOff((size_t)cap * sizeof(int)), rAcc = resOff((size_t)cap);
+    const size_t rObs = resOff((size_t)cap * NP_MAX_KF * 3 * sizeof(int));
+    const size_t rKey = resOff((size_t)2 * cap * sizeof(int)), rCount = resOff(4 * sizeof(int));
+    VS_HIP(dRes.alloc(resBytes));
+    VS_HIP(hipMemsetAsync(dRes.p, 0, rObs, stream));
+    VS_HIP(hipMemsetAsync(dRes.p + rObs, 0xff, rKey - rObs, stream));
+    A.depth = (const float*)(dPack.p + oDepth); A.hasMp = dPack.p + oHas; A.mpXyz = (double*)(dPack.p + oMpXyz); A.mpDesc = dPack.p + oMpDesc;
     A.fx = P->rig.fx; A.fy = P->rig.fy; A.cx = P->rig.cx; A.cy = P->rig.cy; A.b = (double)P->rig.baseline; A.w = P->rig.width; A.h = P->rig.height;
     for (int l = 0; l < P->n_levels; l++) { A.scalePyr[l] = P->scale_pyramid[l]; A.sigma[l] = P->sigma_factor[l]; }
     A.logScale = P->log_scale; A.nLev = P->n_levels;
     const float imageRatio = (float)P->rig.width / (float)P->rig.height;      // assignKeysToGrids (src/FeatureTracker.cpp:30-35)
     A.xGrids = 64; A.yGrids = cv_ceil_f((float)A.xGrids / imageRatio);
     A.xMult = (float)A.xGrids / (float)P->rig.width; A.yMult = (float)A.yGrids / (float)P->rig.height;
-    A.wPos = dWpos.p; A.key = dKey.p; A.mds = dMds.p; A.cdesc = dCdesc.p; A.count = dCount.p; A.cap = cap; A.match = dMatch.p;
-    A.accepted = dAcc.p; A.xyz = dXyz.p; A.nObs = dNobs.p; A.obs = dObs.p;
+    A.wPos = dWpos.p; A.key = (int*)(dRes.p + rKey); A.mds = dMds.p; A.cdesc = dCdesc.p; A.count = (int*)(dRes.p + rCount); A.cap = cap; A.match = dMatch.p;
+    A.accepted = dRes.p + rAcc; A.xyz = (double*)(dRes.p + rXyz); A.nObs = (int*)(dRes.p + rNobs); A.obs = (int*)(dRes.p + rObs);
 
     hipLaunchKernelGGL(k_np_candidates, dim3(1), dim3(1024), 0, stream, A);
     if (P->n_kf > 1) hipLaunchKernelGGL(k_np_match, dim3((cap + 3) / 4, P->n_kf - 1), dim3(256), 0, stream, A);
@@ -633,20 +647,18 @@ extern "C" vslam_status vslam_find_new_points(const vslam_new_points_problem* P,
     VS_HIP(hipFuncSetAttribute((const void*)k_np_triangulate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_np_triangulate, dim3((cap + 63) / 64), dim3(64), lds, stream, A);
     VS_HIP(hipGetLastError());
-    int n = 0;
-    VS_HIP(pool->d2h(&n, dCount.p, sizeof(int)));
+    std::vector<uint8_t> res(resBytes);
+    VS_HIP(pool->d2h(res.data(), dRes.p, resBytes));
     VS_HIP(pool->sync());
+    const int n = *(const int*)(res.data() + rCount);
     R->n_candidates = n;
     if (n > R->capacity) { set_error("vslam_find_new_points: result capacity %d < %d candidates", R->capacity, n); return VSLAM_ERR_CAPACITY; }
     if (n) {
-        std::vector<int> key((size_t)2 * n);
-        VS_HIP(pool->d2h(key.data(), dKey.p, key.size() * sizeof(int)));
-        VS_HIP(pool->d2h(R->accepted, dAcc.p, n));
-        VS_HIP(pool->d2h(R->xyz, dXyz.p, (size_t)3 * n * sizeof(double)));
-        VS_HIP(pool->d2h(R->n_obs, dNobs.p, (size_t)n * sizeof(int)));
-        std::vector<int> obs((size_t)n * NP_MAX_KF * 3);
-        VS_HIP(pool->d2h(obs.data(), dObs.p, obs.size() * sizeof(int)));
-        VS_HIP(pool->sync());
+        const int* key = (const int*)(res.data() + rKey);
+        const int* obs = (const int*)(res.data() + rObs);
+        memcpy(R->accepted, res.data() + rAcc, n);
+        memcpy(R->xyz, res.data() + rXyz, (size_t)3 * n * sizeof(double));
+        memcpy(R->n_obs, res.data() + rNobs, (size_t)n * sizeof(int));
         for (int i = 0; i < n; i++) { R->cand_left[i] = key[2 * i]; R->cand_right[i] = key[2 * i + 1]; }
         for (int i = 0; i < n; i++)
             for (int e = 0; e < P->n_kf; e++)
@@ -669,11 +681,21 @@ extern "C" vslam_status vslam_calc_descriptors(const uint8_t* descs, const int32
     if (device < 0 || device >= ndev) return VSLAM_ERR_INVALID;
     VS_HIP(hipSetDevice(device));
     NP_POOL(pool);
-    Dev<uint8_t> dD(pool); Dev<int> dS(pool), dB(pool);
+    // descriptors and offsets in ONE upload (staged back to back in the pool's pinned arena)
+    Dev<uint8_t> dIn(pool); Dev<int> dB(pool);
     const size_t total = (size_t)start[n_mp];
-    VS_HIP(dD.up(descs, total * 32)); VS_HIP(dS.up(start, (size_t)n_mp + 1)); VS_HIP(dB.alloc(n_mp));
-    hipLaunchKernelGGL(k_calc_descriptor, dim3((n_mp + 3) / 4), dim3(256), 0, pool->stream, n_mp, dD.p, dS.p, dB.p);
-    if (anyBig) hipLaunchKernelGGL(k_calc_descriptor_big, dim3(n_mp), dim3(64), 0, pool->stream, n_mp, dD.p, dS.p, dB.p);
+    const size_t oStart = (total * 32 + 63) & ~(size_t)63, inBytes = oStart + ((size_t)n_mp + 1) * sizeof(int);
+    VS_HIP(dIn.alloc(inBytes)); VS_HIP(dB.alloc(n_mp));
+    if (uint8_t* st = pool->stage(inBytes)) {
+        memcpy(st, descs, total * 32); memcpy(st + oStart, start, ((size_t)n_mp + 1) * sizeof(int));
+        VS_HIP(hipMemcpyAsync(dIn.p, st, inBytes, hipMemcpyHostToDevice, pool->stream));
+    } else {
+        VS_HIP(pool->h2d(dIn.p, descs, total * 32)); VS_HIP(pool->h2d(dIn.p + oStart, start, ((size_t)n_mp + 1) * sizeof(int)));
+    }
+    const uint8_t* dDp = dIn.p;
+    const int* dSp = (const int*)(dIn.p + oStart);
+    hipLaunchKernelGGL(k_calc_descriptor, dim3((n_mp + 3) / 4), dim3(256), 0, pool->stream, n_mp, dDp, dSp, dB.p);
+    if (anyBig) hipLaunchKernelGGL(k_calc_descriptor_big, dim3(n_mp), dim3(64), 0, pool->stream, n_mp, dDp, dSp, dB.p);
     VS_HIP(hipGetLastError());
     VS_HIP(pool->d2h(best_out, dB.p, (size_t)n_mp * sizeof(int)));
     VS_HIP(pool->sync());
