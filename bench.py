@@ -47,7 +47,7 @@ CONFIGS = {
                                                        "200 Hz IMU pre-integration factor in every pose solve"),
     "c3": dict(rig="kitti", nfeat=2000, imu=False, name="C3-class: KITTI-00-like stereo 1241x376, 2000 features/image"),
 }
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_e_pmc_summary.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_f_pmc_summary.json")
 
 
 def level_pixels(w, h, nlevels=8, scale=1.2):
@@ -386,7 +386,7 @@ def main():
             "track_repredict": (nStep, lb * Mact * (24 + 60 + 12), 0),
             "pack": (nStep, lb * (Mact * 30 + nk * 8), 0),
             "imu_preintegrate": (2 * nStep, lb * (10 * 56 + 8 * (289 + 225)), lb * (10 * 2 * 2 * 15 ** 3 + 15 ** 3)),
-            "proj_cells": (2 * nStep, lb * 2 * nk * (28 + 2 + 2), 0),                       # keypoints in, bucketed indices out
+            "proj_cells": (nStep, lb * 2 * nk * (28 + 2 + 2), 0),                             # keypoints in, bucketed indices out
             "proj_candidates": (2 * nStep, lb * b_cand, 0),                                # two passes per frame
             "proj_resolve": (2 * nStep, lb * b_res, 0),
             "pose_imu_lm": (2 * nStep, lb * b_pose, 0),                                    # two solves per frame
@@ -434,7 +434,30 @@ def main():
                               % (cnt["frames"], cnt["ba"], frames_per_ba),
         }
         if per_frame:
-            dom = max(per_frame, key=lambda k: per_frame[k])
+            # Which kernel dominates a GPU that runs several streams at once?  Elapsed time alone over-counts narrow launches: a
+            # one-wave Cholesky (k_ba_solve_mfma64) that waits 150 us for a free CU occupies 4 of the GPU's 8192 wave slots.  A
+            # group's weight is therefore its device time per tracked frame x the share of the wave slots one launch can fill
+            # (SQ_WAVES per launch from the committed PMC pass, same launch shape; 256 CUs x 32 waves).  `roofline` prices that
+            # kernel; `roofline_top5` lists the five largest groups by the same weight.
+            bsfx = "_b" if lanes > 0 else ""
+            KNAME = {"proj_resolve": "k_proj_resolve" + bsfx, "pose_imu_lm": "k_pose_imu_lm" + bsfx, "pose_lm": "k_pose_lm" + bsfx,
+                     "stereo_match": "k_stereo_match" + bsfx, "stereo_finalize": "k_stereo_finalize" + bsfx, "stereo_rows": "k_stereo_rows" + bsfx,
+                     "proj_candidates": "k_proj_candidates" + bsfx, "proj_cells": "k_proj_cells" + bsfx, "imu_preintegrate": "k_imu_preintegrate" + bsfx,
+                     "track_predict": "k_track_predict" + bsfx, "track_repredict": "k_track_repredict" + bsfx, "pack": "k_track_pack" + bsfx,
+                     "pyramid": "k_resize", "ba_solve": "k_ba_solve_mfma64", "ssc": "k_ssc<2>",
+                     "ba_schur": "k_ba_schur", "ba_back": "k_ba_back", "ba_eval": "k_ba_factors<1>", "ba_linearize": "k_ba_factors<0>", "ba_chi2": "k_ba_chi2",
+                     "fast": "k_fast", "blur": "k_blur", "gather": "k_gather", "orient_desc": "k_orient_desc"}
+            try:
+                pmc_all = json.load(open(PMC_FILE))
+            except Exception:      # noqa: BLE001
+                pmc_all = {}
+            WAVE_SLOTS = 256 * 32
+
+            def slot_share(k):
+                w = pmc_all.get(KNAME.get(k, ""), {}).get("SQ_WAVES_avg")
+                return min(1.0, w / WAVE_SLOTS) if w else 1.0
+            dom = max(per_frame, key=lambda k: per_frame[k] * slot_share(k))
+            dom_elapsed = max(per_frame, key=lambda k: per_frame[k])
             n_launch, alg_bytes, alg_flops = groups.get(dom, (nS, 0, 0))
             dom_ms = stage_ms[dom] / max(n_launch, 1)
             achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -447,22 +470,15 @@ def main():
                     "launches_timed": n_launch,
                     "aggregate_GBps_all_sessions": agg, "aggregate_frac": agg / HBM_PEAK_GBS,
                     "lanes_per_launch": lb if not dom.startswith("ba_") else 1,
-                    "note": "per-launch figure of the dominant kernel group (one launch serves all lanes of a lockstep group; local-BA kernels "
-                            "serve one session); aggregate_* = the same group's algorithmic bytes over all sessions / wall time"}
-            try:
-                pmc = json.load(open(PMC_FILE))
-                bsfx = "_b" if lanes > 0 else ""
-                kname = {"proj_resolve": "k_proj_resolve" + bsfx, "pose_imu_lm": "k_pose_imu_lm" + bsfx, "pose_lm": "k_pose_lm" + bsfx,
-                         "stereo_match": "k_stereo_match" + bsfx, "stereo_finalize": "k_stereo_finalize" + bsfx, "stereo_rows": "k_stereo_rows" + bsfx,
-                         "proj_candidates": "k_proj_candidates" + bsfx, "proj_cells": "k_proj_cells" + bsfx, "imu_preintegrate": "k_imu_preintegrate" + bsfx,
-                         "track_predict": "k_track_predict" + bsfx, "pyramid": "k_resize", "ba_solve": "k_ba_solve_mfma64", "ssc": "k_ssc<2>",
-                         "ba_schur": "k_ba_schur", "ba_back": "k_ba_back", "ba_eval": "k_ba_factors<1>", "ba_linearize": "k_ba_factors<0>",
-                         "fast": "k_fast", "blur": "k_blur", "gather": "k_gather", "orient_desc": "k_orient_desc"}.get(dom)
-                if kname in pmc:
-                    roof["traffic"] = (2.0 * pmc[kname]["FETCH_SIZE_avg"] + pmc[kname]["WRITE_SIZE_avg"]) * 1024.0
-                    roof["traffic_source"] = os.path.relpath(PMC_FILE, ROOT) + " (2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, per launch)"
-            except Exception:      # noqa: BLE001
-                pass
+                    "wave_slot_share": slot_share(dom), "largest_by_elapsed_time": dom_elapsed,
+                    "note": "per-launch figure of the dominant kernel group = the largest (device time per tracked frame x share of the GPU's "
+                            "8192 wave slots one launch fills, SQ_WAVES of the PMC pass); one launch serves all lanes of a lockstep group, local-BA "
+                            "kernels serve one session; aggregate_* = the same group's algorithmic bytes over all sessions / wall time; "
+                            "roofline_top5 = the five largest groups by that weight, largest_by_elapsed_time = by elapsed time alone (a narrow local-BA launch)"}
+            kname = KNAME.get(dom)
+            if kname in pmc_all:
+                roof["traffic"] = (2.0 * pmc_all[kname]["FETCH_SIZE_avg"] + pmc_all[kname]["WRITE_SIZE_avg"]) * 1024.0
+                roof["traffic_source"] = os.path.relpath(PMC_FILE, ROOT) + " (2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, per launch)"
             if alg_flops:
                 roof["achieved_gflops"] = alg_flops / (dom_ms * 1e-3) / 1e9
                 roof["fp64_frac"] = roof["achieved_gflops"] / (FP64_PEAK_TFLOPS * 1e3)
@@ -475,19 +491,19 @@ def main():
                              "why_small": "a %.0f-unknown system (%.1f free keyframes) is %.0f flops per candidate: one workgroup, latency-bound; "
                                           "launch_ms is measured with the other sessions' kernels sharing the GPU" % (nBA6, Fk, alg_flops)})
             out["roofline"] = roof
-            # the same per-launch pricing for the five groups with the most device time per tracked frame (context for `roofline`:
-            # which kernels move bytes and which are latency- / instruction-bound chains)
+            # the same per-launch pricing for the five largest groups by the same weight (context for `roofline`: which kernels move
+            # bytes and which are latency- / instruction-bound chains); the largest by elapsed time alone is named in `roofline`
             top = []
-            for k in sorted(per_frame, key=lambda q: -per_frame[q])[:5]:
+            for k in sorted(per_frame, key=lambda q: -per_frame[q] * slot_share(q))[:5]:
                 n_l, ab, _ = groups.get(k, (nS, 0, 0))
                 ms_l = stage_ms[k] / max(n_l, 1)
                 gbs = ab / (ms_l * 1e-3) / 1e9 if ms_l > 0 else 0.0
                 top.append({"kernel": k, "ms_per_frame": per_frame[k], "launch_ms": ms_l, "algorithmic_bytes": ab,
-                            "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS})
+                            "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS, "wave_slot_share": slot_share(k)})
             out["roofline_top5"] = top
             if "ba_solve" not in stage_ms:   # no local BA of the sampled sessions fell into this (short) timed region
                 out["ba_solve_mfma"] = {"launch_ms": None, "unknowns": nBA6, "flops": groups["ba_solve"][2], "achieved_gflops": None, "fp64_frac": None,
-                                        "note": "no sampled local BA in the timed region; profiles/r02_e_c2_kernel_stats.csv has the kernel "
+                                        "note": "no sampled local BA in the timed region; profiles/r02_f_c2_kernel_stats.csv has the kernel "
                                                 "(k_ba_solve_mfma64, ~35-40 us per launch): (6F)^3/3 flops per candidate - << 1 % of the fp64 MFMA peak"}
             if "ba_solve" in stage_ms:       # the only MFMA-eligible term of the path: always reported
                 n_l, _, fl = groups["ba_solve"]

@@ -469,7 +469,7 @@ vslam_status vslam_batch::step(const uint8_t* const* L, const uint8_t* const* R,
             VS_HIP(hipEventRecord(evImu1, imuStream));
         } else if (useImu) { t = timer.begin("imu_preintegrate"); launch_imu_batch(stream, dt.imu1, B); timer.end(t); }
         t = timer.begin("track_repredict"); launch_track_repredict_batch(stream, dt.repredict, B, maxN); timer.end(t);
-        launch_proj_batch(stream, dt.proj1, B, maxN, maxL, maxR, &timer);
+        launch_proj_batch(stream, dt.proj1, B, maxN, maxL, maxR, &timer, false);
         if (side) VS_HIP(hipStreamWaitEvent(stream, evImu1, 0));
         t = timer.begin(useImu ? "pose_imu_lm" : "pose_lm");
         if (useImu) launch_pose_imu_batch(stream, dt.pose1, B, ldsFactors); else launch_pose_batch(stream, dt.pose1, B);

@@ -199,7 +199,7 @@ struct ProjLane {            // one lane of the batched projection matching
     ProjArgs A;
     int* matches; unsigned long long* topk; unsigned long long* stats; int* matchedL; int* matchedR; int* out;
 };
-void launch_proj_batch(hipStream_t s, const ProjLane* dLanes, int B, int maxM, int maxL, int maxR, StageTimer* tm = nullptr);
+void launch_proj_batch(hipStream_t s, const ProjLane* dLanes, int B, int maxM, int maxL, int maxR, StageTimer* tm = nullptr, bool buildCells = true);
 constexpr int PROJ_MAX_CELLS = 64 * 64;      // xGrids = 64, yGrids = ceil(64 / aspect) <= 64 for landscape images
 void launch_proj_cells(hipStream_t s, const ProjArgs& A);
 void launch_proj_candidates(hipStream_t s, const ProjArgs& A, const int* matches,

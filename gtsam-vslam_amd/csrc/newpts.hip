@@ -681,17 +681,28 @@ extern "C" vslam_status vslam_calc_descriptors(const uint8_t* descs, const int32
     if (device < 0 || device >= ndev) return VSLAM_ERR_INVALID;
     VS_HIP(hipSetDevice(device));
     NP_POOL(pool);
-    // descriptors and offsets in ONE upload (staged back to back in the pool's pinned arena)
-    Dev<uint8_t> dIn(pool); Dev<int> dB(pool);
+    // Zero-copy: descriptors, offsets and the result live in the pool's PINNED arena, which the device addresses directly
+    // (hipHostMalloc memory is mapped): one launch + one synchronisation instead of upload, launch, download - three
+    // dependent operations that each queue behind the lockstep groups' kernels (this call sits on the tracker's critical
+    // path at every keyframe insertion).  ~50 KB read over the host link by coalesced loads.
     const size_t total = (size_t)start[n_mp];
-    const size_t oStart = (total * 32 + 63) & ~(size_t)63, inBytes = oStart + ((size_t)n_mp + 1) * sizeof(int);
-    VS_HIP(dIn.alloc(inBytes)); VS_HIP(dB.alloc(n_mp));
+    const size_t oStart = (total * 32 + 63) & ~(size_t)63, oBest = (oStart + ((size_t)n_mp + 1) * sizeof(int) + 63) & ~(size_t)63;
+    const size_t inBytes = oBest + (size_t)n_mp * sizeof(int);
     if (uint8_t* st = pool->stage(inBytes)) {
         memcpy(st, descs, total * 32); memcpy(st + oStart, start, ((size_t)n_mp + 1) * sizeof(int));
-        VS_HIP(hipMemcpyAsync(dIn.p, st, inBytes, hipMemcpyHostToDevice, pool->stream));
-    } else {
-        VS_HIP(pool->h2d(dIn.p, descs, total * 32)); VS_HIP(pool->h2d(dIn.p + oStart, start, ((size_t)n_mp + 1) * sizeof(int)));
+        int* hb = (int*)(st + oBest);
+        for (int m = 0; m < n_mp; m++) hb[m] = -1;
+        hipLaunchKernelGGL(k_calc_descriptor, dim3((n_mp + 3) / 4), dim3(256), 0, pool->stream, n_mp, (const uint8_t*)st, (const int*)(st + oStart), hb);
+        if (anyBig) hipLaunchKernelGGL(k_calc_descriptor_big, dim3(n_mp), dim3(64), 0, pool->stream, n_mp, (const uint8_t*)st, (const int*)(st + oStart), hb);
+        VS_HIP(hipGetLastError());
+        VS_HIP(hipStreamSynchronize(pool->stream));
+        memcpy(best_out, hb, (size_t)n_mp * sizeof(int));
+        VS_HIP(pool->sync());       // (recycles the arena; may re-allocate it - after the copy)
+        return VSLAM_OK;
     }
+    Dev<uint8_t> dIn(pool); Dev<int> dB(pool);
+    VS_HIP(dIn.alloc(oBest)); VS_HIP(dB.alloc(n_mp));
+    VS_HIP(pool->h2d(dIn.p, descs, total * 32)); VS_HIP(pool->h2d(dIn.p + oStart, start, ((size_t)n_mp + 1) * sizeof(int)));
     const uint8_t* dDp = dIn.p;
     const int* dSp = (const int*)(dIn.p + oStart);
     hipLaunchKernelGGL(k_calc_descriptor, dim3((n_mp + 3) / 4), dim3(256), 0, pool->stream, n_mp, dDp, dSp, dB.p);

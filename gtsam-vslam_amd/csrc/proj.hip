@@ -489,13 +489,17 @@ static void proj_attrs() {
 }
 
 // all lanes' projection matching in two launches; maxM / maxL / maxR: the largest counts over the lanes
-void launch_proj_batch(hipStream_t s, const ProjLane* dLanes, int B, int maxM, int maxL, int maxR, StageTimer* tm) {
+void launch_proj_batch(hipStream_t s, const ProjLane* dLanes, int B, int maxM, int maxL, int maxR, StageTimer* tm, bool buildCells) {
     if (B <= 0 || maxM <= 0) return;
     proj_attrs();
     const int forceSeq = getenv("VSLAM_PROJ_SEQUENTIAL") ? 1 : 0;
-    int t = tm ? tm->begin("proj_cells") : -1;
-    hipLaunchKernelGGL(k_proj_cells_b, dim3(2, B), dim3(PROJ_CELLS_NT), (size_t)PROJ_MAX_CELLS * sizeof(int), s, dLanes);
-    if (tm) { tm->end(t); t = tm->begin("proj_candidates"); }
+    int t = -1;
+    if (buildCells) {       // (the refinement pass of a frame matches against the same keys: the first pass's buckets stand)
+        t = tm ? tm->begin("proj_cells") : -1;
+        hipLaunchKernelGGL(k_proj_cells_b, dim3(2, B), dim3(PROJ_CELLS_NT), (size_t)PROJ_MAX_CELLS * sizeof(int), s, dLanes);
+        if (tm) tm->end(t);
+    }
+    t = tm ? tm->begin("proj_candidates") : -1;
     hipLaunchKernelGGL(k_proj_candidates_b, dim3((2 * maxM + 3) / 4, B), dim3(256), 0, s, dLanes);
     if (tm) { tm->end(t); t = tm->begin("proj_resolve"); }
     hipLaunchKernelGGL(k_proj_resolve_b, dim3(B), dim3(PROJ_NT), proj_resolve_lds(maxL, maxR), s, dLanes, forceSeq);
