@@ -18,7 +18,7 @@
 //      covers the 5x5 cells around it), marks them.  The search is speculated three probes deep (7 waves evaluate
 //      both outcomes of the next probes), the decision logic replays the reference loop on the cached counts.
 //
-// Two instantiations of the same code: k_ssc<false> keeps the sort arrays of a level in LDS (<= 16 384 candidates:
+// Three instantiations of the same code (SscCfg below; 512-thread tasks): k_ssc<0> keeps the sort arrays of a level in LDS (<= 16 384 candidates:
 // every level of the 752x480 / 1241x376 rigs and of a 1920x1200 frame); k_ssc<true> keeps them in HBM scratch
 // (up to 65 535 candidates per level, the width of the index field).  Each (image, level) task is taken by exactly
 // one of them; the other returns at once.  There is no host path.
@@ -26,7 +26,7 @@
 
 namespace vslam {
 
-constexpr int SSC_NT = 1024, SSC_NW = SSC_NT / 64;      // 16 waves
+constexpr int SSC_NT = 512, SSC_NW = SSC_NT / 64;       // 8 waves
 constexpr int SSC_NPROBE = 8;                           // speculative probes per round (waves 0..6 are used: a depth-3 tree)
 constexpr int SSC_COOP_MIN = 1024;                      // longer segments: block-cooperative partition
 constexpr int SSC_ARENA_WORDS = 20 * 1024;              // 80 KB of cover-grid bits (10 KB per speculating wave)
@@ -330,7 +330,7 @@ __device__ __forceinline__ void ssc_partition_coop(uint32_t* a, uint16_t* Lp, ui
 }
 
 template <int M>
-__global__ __launch_bounds__(SSC_NT, (M == 2 ? 8 : 4)) void k_ssc(SscArgs A) {
+__global__ __launch_bounds__(SSC_NT, 4) void k_ssc(SscArgs A) {
     using C = SscCfg<M>;
     constexpr bool G = M == 1;
     extern __shared__ uint32_t lds[];
