@@ -47,7 +47,7 @@ CONFIGS = {
                                                        "200 Hz IMU pre-integration factor in every pose solve"),
     "c3": dict(rig="kitti", nfeat=2000, imu=False, name="C3-class: KITTI-00-like stereo 1241x376, 2000 features/image"),
 }
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_f_pmc_summary.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_g_pmc_summary.json")
 
 
 def level_pixels(w, h, nlevels=8, scale=1.2):
@@ -200,7 +200,7 @@ def main():
                                                               "synthetic scene's extent in units of the rig's baseline bounds the camera speed)")
     ap.add_argument("--host-images", action="store_true", help="frames in pinned host memory: every frame pays its H2D copy inside the step")
     ap.add_argument("--mapping", type=int, default=2, help="local mapping: 2 = optimizer thread per session (reference), 1 = synchronous, 0 = off")
-    ap.add_argument("--mapping-max-lag", type=int, default=4, help="--mapping 2: a frame waits for a local-mapping pass handed over this many "
+    ap.add_argument("--mapping-max-lag", type=int, default=-1, help="(default: 4 frames, 2 for c3) --mapping 2: a frame waits for a local-mapping pass handed over this many "
                     "frames ago (default 4: keyframes are at least 5 frames apart, so every keyframe's pass finishes before the next keyframe - "
                     "the reference's steady state at camera rate); 0 = never wait: at this frame rate the mapper then falls behind and half "
                     "of the keyframes are never optimised")
@@ -268,6 +268,12 @@ def main():
     lp = [b[0].data_ptr() for b in bufs]
     rp = [b[1].data_ptr() for b in bufs]
     imu = dict(gravity=GRAVITY, noise=IMU_NOISE, T_bs=__import__("synth").T_BC1, hz=200) if cfg["imu"] else None
+    if args.mapping_max_lag < 0:
+        # The reference's optimizer thread ends a pass within a frame or two of camera time.  4 frames keeps every keyframe's pass
+        # ahead of the next keyframe on the EuRoC-like sequences; the KITTI-like sequence moves ~10x faster per frame, its tracker
+        # lives on the mapper's new points: with 4 frames of lag sessions lose track (4-21 lost frames per run, 9-14 k frames/s),
+        # with 2 they do not (2-4 lost frames as with synchronous mapping, 21-22 k frames/s).
+        args.mapping_max_lag = 2 if args.config == "c3" else 4
     scfg = vc.system_config(rig, cfg["nfeat"], imu=imu, local_mapping=args.mapping, device=local, mapping_max_lag=args.mapping_max_lag)
 
     def make_fleet(S, lanes):
@@ -503,7 +509,7 @@ def main():
             out["roofline_top5"] = top
             if "ba_solve" not in stage_ms:   # no local BA of the sampled sessions fell into this (short) timed region
                 out["ba_solve_mfma"] = {"launch_ms": None, "unknowns": nBA6, "flops": groups["ba_solve"][2], "achieved_gflops": None, "fp64_frac": None,
-                                        "note": "no sampled local BA in the timed region; profiles/r02_f_c2_kernel_stats.csv has the kernel "
+                                        "note": "no sampled local BA in the timed region; profiles/r02_g_c2_kernel_stats.csv has the kernel "
                                                 "(k_ba_solve_mfma64, ~35-40 us per launch): (6F)^3/3 flops per candidate - << 1 % of the fp64 MFMA peak"}
             if "ba_solve" in stage_ms:       # the only MFMA-eligible term of the path: always reported
                 n_l, _, fl = groups["ba_solve"]

@@ -14,7 +14,7 @@ python3 bench.py --config c3 > $OUT/${TAG}_c3_bench.json 2> $OUT/c3.err || exit 
 echo "c3 bench done"
 python3 bench.py --host-images --no-cpu-baseline --no-latency-line > $OUT/${TAG}_c2_bench_host_images.json 2> $OUT/hi.err || exit 1
 echo "host-images bench done"
-python3 bench.py --no-cpu-baseline --no-latency-line --steps 100 --sweep 1x0,1x1,4x4,16x16,32x32,64x64,128x64,192x64,256x64 > $OUT/${TAG}_c2_sweep.json 2> $OUT/sw.err || exit 1
+python3 bench.py --no-cpu-baseline --no-latency-line --steps 100 --sweep 1x0,1x1,4x4,16x16,32x32,64x64,128x64,192x64,192x96,256x128 > $OUT/${TAG}_c2_sweep.json 2> $OUT/sw.err || exit 1
 echo "sweep done"
 # what the bounded mapper lag costs: unbounded (0) and a looser bound (8 frames)
 python3 bench.py --no-cpu-baseline --no-latency-line --mapping-max-lag 0 > $OUT/${TAG}_c2_bench_lag0.json 2> $OUT/lag0.err || exit 1
