@@ -186,8 +186,8 @@ vslam_status vslam_batch::init(const vslam_system_config* cfgs, int n, int hostT
 void vslam_batch::release() {
     if (getenv("VSLAM_BATCH_PHASES") && nSteps)
         fprintf(stderr, "vslam_batch %d lanes, %lld steps, host phases (us / step): begin %.1f | images + extract enqueue %.1f | upload block %.1f | "
-                        "tables + enqueue %.1f | wait %.1f | retry %.1f | post %.1f\n", B, nSteps, 1e6 * phaseSum[0] / nSteps, 1e6 * phaseSum[1] / nSteps,
-                1e6 * phaseSum[2] / nSteps, 1e6 * phaseSum[3] / nSteps, 1e6 * phaseSum[4] / nSteps, 1e6 * phaseSum[5] / nSteps, 1e6 * phaseSum[6] / nSteps);
+                        "tables + enqueue %.1f (of which waiting for the extraction %.1f) | wait %.1f | retry %.1f | post %.1f\n", B, nSteps, 1e6 * phaseSum[0] / nSteps, 1e6 * phaseSum[1] / nSteps,
+                1e6 * phaseSum[2] / nSteps, 1e6 * phaseSum[3] / nSteps, 1e6 * phaseSum[7] / nSteps, 1e6 * phaseSum[4] / nSteps, 1e6 * phaseSum[5] / nSteps, 1e6 * phaseSum[6] / nSteps);
     if (getenv("VSLAM_BATCH_PHASES")) {
         SysProf& p = sys_prof();
         auto avg = [](std::atomic<long long>& ns, std::atomic<long long>& n) { return n.load() ? 1e-3 * (double)ns.load() / (double)n.load() : 0.0; };
@@ -363,7 +363,11 @@ vslam_status vslam_batch::step(const uint8_t* const* L, const uint8_t* const* R,
 
     // ---- keys of the new frames (waits for the extraction's totals) -----------------------------------------------------------
     VS_HIP(hipStreamWaitEvent(stream, fe->evDone, 0));
-    VS_CHECK(fe->wait_counts());
+    {
+        const auto w0 = clk::now();
+        VS_CHECK(fe->wait_counts());
+        phaseSum[7] += std::chrono::duration<double>(clk::now() - w0).count();      // (part of phase 3: the extraction still running)
+    }
     int maxL = 0, maxR = 0, maxN = 0, nTrack = 0, ldsFactors = 0;
     size_t dnBytes = 0;
     for (int b = 0; b < B; b++) {
