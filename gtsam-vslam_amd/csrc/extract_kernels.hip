@@ -186,7 +186,8 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, P
                                               FastDesc F, uint32_t* __restrict__ cellSlots,
                                               int* __restrict__ cellCount, int maxThr, int minThr) {
     extern __shared__ unsigned char fsm[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (the cell is wave-uniform: its geometry stays in SGPRs)
     const int TP = F.tilePitch;                                    // bytes per LDS row (multiple of 4)
     const int perWave = F.tileRows * TP * 2 + 2 * (FQ_MASK + 1) * 2 + FQ3_CAP * 2;
     uint8_t* tile = fsm + (size_t)wave * perWave;                  // [tileRows][TP] sub-image
@@ -228,6 +229,24 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, P
         const int nd = (xoff + subW + 3) >> 2, ndw = subH * nd;
         const unsigned inv = 0xffffffffu / (unsigned)nd + 1u;  // i / nd == umulhi(i, inv), exact for i * nd < 2^32
         // all of a lane's loads are issued before the first LDS store: one global round trip per 8 dwords instead of one each
+        if (nd <= 16) {
+            // lane = (row mod 4, dword column): offsets advance by constants (no division per dword); 8 rows x 4 in flight
+            const int rr = lane >> 4, c = lane & 15;
+            const bool colOk = c < nd;
+            unsigned goff = (unsigned)rr * (unsigned)pitch + 4u * (unsigned)c;
+            int at = rr * TP + 4 * c;
+            for (int r = rr; r < subH; r += 32) {
+                unsigned v[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    if (colOk && r + 4 * k < subH) v[k] = *(const unsigned*)(src + goff + (unsigned)(4 * k) * (unsigned)pitch);
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    if (colOk && r + 4 * k < subH) *(unsigned*)(tile + at + 4 * k * TP) = v[k];
+                goff += 32u * (unsigned)pitch;
+                at += 32 * TP;
+            }
+        } else
         for (int base = 0; base < ndw; base += 64 * 8) {
             unsigned v[8];
             int at[8];
