@@ -540,7 +540,9 @@ __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_schur(BaDev D, int m
     constexpr int BA_LPL = BA_LPL_SCHUR;
     double* Sloc = sm;                                        // LDS_S: nc copies of n*n + n
     double* wbase = sm + (LDS_S ? (size_t)nc * sys : 0);
-    const int lane = threadIdx.x & (BA_LPL - 1), unit = threadIdx.x / BA_LPL;    // unit = landmark lane group of the workgroup
+    static_assert(BA_LPL == 64, "one wave per landmark: the landmark index is wave-uniform");
+    const int lane = threadIdx.x & (BA_LPL - 1);
+    const int unit = __builtin_amdgcn_readfirstlane(threadIdx.x / BA_LPL);    // unit = landmark lane group (= wave) of the workgroup
     double* W = wbase + (size_t)unit * (2 * maxSlots * 18);
     double* WH = W + maxSlots * 18;
     const int nu = blockDim.x / BA_LPL, nt = blockDim.x;

@@ -456,7 +456,8 @@ __global__ __launch_bounds__(256) void k_kf_update_pose(KfUpdArgs A) {
 __global__ __launch_bounds__(256) void k_calc_descriptor(int nMp, const uint8_t* __restrict__ descs, const int* __restrict__ start,
                                                          int* __restrict__ best) {
     __shared__ unsigned short sd[4][64 * 64];       // sd[wave][j * 64 + lane] = d(lane, j)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m = blockIdx.x * 4 + wave;
     if (m >= nMp) return;
     const int s0 = start[m], n = start[m + 1] - s0;

@@ -83,7 +83,8 @@ void launch_proj_cells(hipStream_t s, const ProjArgs& A) {
 __device__ __forceinline__ void proj_candidates_body(const ProjArgs& A, const int* __restrict__ matches,
                                                      unsigned long long* __restrict__ topk,
                                                      unsigned long long* __restrict__ stats) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (the map point is wave-uniform: scalar loads / SGPRs)
     const int job = blockIdx.x * 4 + wave;      // job = mp * 2 + side
     __shared__ unsigned int sTests;             // descriptor tests of this workgroup (ONE global atomic: thousands of waves
     if (A.gate && *A.gate < A.gateMin) return;  //  adding to a single address serialise in the L2 and dominated the kernel)

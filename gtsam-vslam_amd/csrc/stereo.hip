@@ -80,7 +80,8 @@ __device__ __forceinline__ void stereo_match_body(const StereoArgs& A, int* __re
     __shared__ __attribute__((aligned(4))) uint8_t winR[4][11 * 24];
     __shared__ int sadp[4][5 * 11];
     __shared__ unsigned int sStat[3];                 // tests, refined, accepted of this workgroup (one global atomic each)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (the left keypoint is wave-uniform: scalar loads / SGPRs)
 #ifdef VSLAM_STEREO_STAMPS
     long long sm_t = clock64();
 #endif
