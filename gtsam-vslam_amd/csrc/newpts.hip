@@ -101,7 +101,8 @@ __global__ __launch_bounds__(1024) void k_np_candidates(NpArgs A) {
 
 // predictKeysPosR + matchByProjectionRPredLBA for (candidate = blockIdx.x * 4 + wave, keyframe = blockIdx.y + 1)
 __global__ __launch_bounds__(256) void k_np_match(NpArgs A) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (candidate and keyframe are wave-uniform)
     const int c = blockIdx.x * 4 + wave, k = blockIdx.y + 1;
     if (c >= A.count[0]) return;
     const NpKf& K = A.kf[k];

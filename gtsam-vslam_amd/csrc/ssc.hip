@@ -356,7 +356,8 @@ __global__ __launch_bounds__(SSC_NT, 4) void k_ssc(SscArgs A) {
     __shared__ int cacheW[64], cacheC[64], cacheSlot[64], nCache, sched[8], nSched, sFinal, sDone, sSolo;
     __shared__ int sLow, sHigh, sPrev, sLast;
     __shared__ int pre[C::PICKW];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (a wave's segment / probe is wave-uniform: SGPR loop control)
 #ifdef VSLAM_SSC_STAMPS
     long long st_t = clock64();
     long long* st = (long long*)(A.taskCount + A.nimg * MAX_LEVELS) + (size_t)task * 8;
@@ -403,7 +404,8 @@ __global__ __launch_bounds__(SSC_NT, 4) void k_ssc(SscArgs A) {
             ssc_partition_coop<G>(a, Lp, Rp, f, e, depth, sW, segN, cntN, C::SEGMAX, &sFail);
         }
         for (int s = wave; s < nseg; s += SSC_NW) {
-            const int f = (int)(segC[2 * s] & 0xffffu), e = (int)(segC[2 * s] >> 16), depth = (int)segC[2 * s + 1];
+            const uint32_t sfe = (uint32_t)__builtin_amdgcn_readfirstlane((int)segC[2 * s]);          // (LDS words read at a uniform address)
+            const int f = (int)(sfe & 0xffffu), e = (int)(sfe >> 16), depth = __builtin_amdgcn_readfirstlane((int)segC[2 * s + 1]);
             if (depth == 0) { if (lane == 0) ssc_heapsort<G>(a + f, e - f); continue; }      // libstdc++ switches to heapsort here
             if (e - f <= 64) {                            // the whole subtree of a short segment, in registers
                 ssc_small_segment<G>(a, f, e, depth, Lp, Rp, segN, cntN, C::SEGMAX, &sFail);
