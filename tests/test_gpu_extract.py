@@ -91,3 +91,23 @@ def test_extract_capacity_and_bad_args(capi):
     with pytest.raises(capi.VslamError) as e:
         ge.fetch(0, cap=10)
     assert e.value.status == capi.ERR_CAPACITY
+
+
+@pytest.mark.parametrize("w,h,nlevels,scale", [(752, 480, 3, 2.5), (1024, 640, 4, 1.6), (800, 600, 5, 1.44)])
+def test_extract_parity_other_scale_factors(oracle, capi, w, h, nlevels, scale):
+    """Other pyramid scale factors: at 2.5 the four taps of a k_resize thread span more than its 12-byte window, so the
+    byte-wise path runs; the level widths also give k_blur's right-border fix-up other residues (w - x of the last thread)."""
+    img = synth.random_image(w, h, 23)
+    oe = oracle.Extractor(1200, nlevels=nlevels, scale=scale)
+    ok, od = oe.extract(img)
+    ge = capi.Extractor(w, h, 1200, nlevels=nlevels, scale=scale)
+    (gk, gd), = ge.extract([img])
+    for l in range(nlevels):
+        assert np.array_equal(ge.level(0, l), oe.level(l)), "pyramid level %d" % l
+        if len(ok) and (ok["octave"] == l).any():
+            assert np.array_equal(ge.level(0, l, blurred=True), oe.level(l, blurred=True)), "blur level %d" % l
+    assert len(ok) == len(gk) and len(ok) > 200
+    for f in ok.dtype.names:
+        assert np.array_equal(ok[f], gk[f]), "keypoint field %s" % f
+    assert np.array_equal(od, gd)
+    ge.close()
