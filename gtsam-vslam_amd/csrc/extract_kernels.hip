@@ -184,7 +184,7 @@ __device__ __forceinline__ int fast_score(const uint8_t* p, const int* ro) {
 
 __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, PyrDesc P,
                                               FastDesc F, uint32_t* __restrict__ cellSlots,
-                                              int* __restrict__ cellCount, int maxThr, int minThr) {
+                                              int* __restrict__ cellCount, int maxThr, int minThr, int listCap) {
     extern __shared__ unsigned char fsm[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (the cell is wave-uniform: its geometry stays in SGPRs)
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, P
             }
             const unsigned long long bal = __ballot(corner);
             const int at = n3 + __popcll(bal & lt);
-            if (corner && at < FQ3_CAP) q3[at] = (unsigned short)rc;
+            if (corner && at < listCap) q3[at] = (unsigned short)rc;
             n3 += __popcll(bal);
         };
         auto drain2 = [&](bool all) {
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, P
         // preserves the pixel order), so the suppression visits that list - a few dozen pixels - instead of the whole cell.
         const int t = tq;
         total = 0;
-        if (n3 <= FQ3_CAP) {
+        if (n3 <= listCap) {
             for (int base = 0; base < n3; base += 64) {
                 bool flag = false;
                 int s = 0, r = 0, c = 0;
@@ -432,7 +432,10 @@ void launch_fast(hipStream_t s, const uint8_t* pyr, const PyrDesc& P, const Fast
                  uint32_t* cellSlots, int* cellCount, int maxThr, int minThr, int nimg) {
     dim3 grid((F.cellBase[P.nLevels] + 3) / 4, nimg);
     const size_t lds = (size_t)4 * ((size_t)F.tileRows * F.tilePitch * 2 + 2 * (FQ_MASK + 1) * 2 + FQ3_CAP * 2);
-    hipLaunchKernelGGL(k_fast, grid, dim3(256), lds, s, pyr, P, F, cellSlots, cellCount, maxThr, minThr);
+    // VSLAM_FAST_LIST_CAP (read per launch): a smaller corner list forces the full-scan suppression - fallback testing
+    int listCap = FQ3_CAP;
+    if (const char* e = getenv("VSLAM_FAST_LIST_CAP")) listCap = std::max(0, std::min(FQ3_CAP, atoi(e)));
+    hipLaunchKernelGGL(k_fast, grid, dim3(256), lds, s, pyr, P, F, cellSlots, cellCount, maxThr, minThr, listCap);
 }
 
 // ---------------------------------------------------------------------------

@@ -111,3 +111,10 @@ def test_extract_parity_other_scale_factors(oracle, capi, w, h, nlevels, scale):
         assert np.array_equal(ok[f], gk[f]), "keypoint field %s" % f
     assert np.array_equal(od, gd)
     ge.close()
+
+
+def test_fast_full_scan_suppression_fallback(oracle, capi, monkeypatch):
+    """k_fast lists the corners of a cell (at most 512) and suppresses over that list; a cell with more falls back to the scan of
+    every pixel.  VSLAM_FAST_LIST_CAP=4 sends (almost) every cell down that path: identical candidates and keypoints."""
+    monkeypatch.setenv("VSLAM_FAST_LIST_CAP", "4")
+    _compare(oracle, capi, synth.random_image(752, 480, 55), 1500)
