@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, PyrDe
     const int sp = P.pitch[level - 1], dp = P.pitch[level];
     const int dw = P.w[level], dh = P.h[level], sh = P.h[level - 1];
     const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int y = blockIdx.y * 4 + threadIdx.y;
+    const int y = blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y);     // (a wave = one output row: scalar row math)
     if (y >= dh || x0 >= dw) return;
     const int2 yt = ytab[y];
     int sy0 = yt.x, sy1 = yt.x + 1;
