@@ -47,7 +47,7 @@ CONFIGS = {
                                                        "200 Hz IMU pre-integration factor in every pose solve"),
     "c3": dict(rig="kitti", nfeat=2000, imu=False, name="C3-class: KITTI-00-like stereo 1241x376, 2000 features/image"),
 }
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_h_pmc_summary.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_i_pmc_summary.json")
 
 
 def level_pixels(w, h, nlevels=8, scale=1.2):
@@ -192,8 +192,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c5"])
-    ap.add_argument("--sessions", type=int, default=128, help="independent SLAM sessions (sequences) sharing each GPU")
-    ap.add_argument("--lanes", type=int, default=64, help="sessions per lockstep group (vslam_batch: one launch per stage for all lanes of a group); "
+    ap.add_argument("--sessions", type=int, default=192, help="independent SLAM sessions (sequences) sharing each GPU")
+    ap.add_argument("--lanes", type=int, default=96, help="sessions per lockstep group (vslam_batch: one launch per stage for all lanes of a group); "
                                                           "0 = one host thread and one set of launches per session")
     ap.add_argument("--frames", type=int, default=0, help="distinct rendered stereo frames of the replayed sequence (0: 100 for c1 / c2, 60 for c3)")
     ap.add_argument("--frame-step", type=int, default=0, help="source frames between two sequence frames (0: 2 for c1 / c2, 1 for c3: the "
@@ -509,7 +509,7 @@ def main():
             out["roofline_top5"] = top
             if "ba_solve" not in stage_ms:   # no local BA of the sampled sessions fell into this (short) timed region
                 out["ba_solve_mfma"] = {"launch_ms": None, "unknowns": nBA6, "flops": groups["ba_solve"][2], "achieved_gflops": None, "fp64_frac": None,
-                                        "note": "no sampled local BA in the timed region; profiles/r02_h_c2_kernel_stats.csv has the kernel "
+                                        "note": "no sampled local BA in the timed region; profiles/r02_i_c2_kernel_stats.csv has the kernel "
                                                 "(k_ba_solve_mfma64, ~35-40 us per launch): (6F)^3/3 flops per candidate - << 1 % of the fp64 MFMA peak"}
             if "ba_solve" in stage_ms:       # the only MFMA-eligible term of the path: always reported
                 n_l, _, fl = groups["ba_solve"]

@@ -5,8 +5,8 @@ TAG=${1:-r02_x}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 REPO=$PWD
-PROF_SHAPE=""                                   # kernel trace: the default command (two lockstep groups)
-PMC_SHAPE="--sessions 64 --lanes 64"            # counter passes: ONE group (rocprofv3 --pmc segfaults with two groups' launching threads)
+PROF_SHAPE="${PROF_SHAPE:-}"                                   # kernel trace: the default command (two lockstep groups)
+PMC_SHAPE="${PMC_SHAPE:---sessions 64 --lanes 64}"            # counter passes: ONE group (rocprofv3 --pmc segfaults with two groups' launching threads)
 if [ -z "$SKIP_BENCH" ]; then
 python3 bench.py > $OUT/${TAG}_c2_bench.json 2> $OUT/c2.err || exit 1
 echo "c2 bench done"; cut -c1-160 $OUT/${TAG}_c2_bench.json
@@ -29,6 +29,7 @@ timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k
 cp $OUT/kt/kt_kernel_stats.csv $OUT/${TAG}_c2_kernel_stats.csv
 echo "kernel trace done"
 fi
+if [ -n "$SKIP_PMC" ]; then exit 0; fi
 for C in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CYCLES SQ_WAVES"; do
   N=$(echo $C | cut -d' ' -f1)
   timeout -k 10 500 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$N -o p -- python3 $REPO/bench.py --no-cpu-baseline --no-latency-line --steps 60 --warmup 10 $PMC_SHAPE > $OUT/pmc_$N.json 2> $OUT/pmc_$N.err || exit 1
