@@ -6,7 +6,7 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 REPO=$PWD
 PROF_SHAPE="${PROF_SHAPE:-}"                                   # kernel trace: the default command (two lockstep groups)
-PMC_SHAPE="${PMC_SHAPE:---sessions 64 --lanes 64}"            # counter passes: ONE group (rocprofv3 --pmc segfaults with two groups' launching threads)
+PMC_SHAPE="${PMC_SHAPE:---sessions 96 --lanes 96}"            # counter passes: ONE group (rocprofv3 --pmc segfaults with two groups' launching threads)
 if [ -z "$SKIP_BENCH" ]; then
 python3 bench.py > $OUT/${TAG}_c2_bench.json 2> $OUT/c2.err || exit 1
 echo "c2 bench done"; cut -c1-160 $OUT/${TAG}_c2_bench.json
