@@ -284,12 +284,16 @@ def main():
     fleet = make_fleet(args.sessions, lanes)
     if args.prime > 0:
         fleet.run(args.prime)        # set-up: the sessions' first frames (map initialisation, the first keyframes)
+    # per-stage HIP events on every 3rd step of group / session 0 (every step of a short timed region).  The warm-up steps are
+    # sampled too, so that the first timed sample does not carry the timers' one-time set-up; their readings are discarded.
+    sample_every = 1 if args.steps < 60 else 3
+    fleet.set_sampling(sample_every)
     fleet.run(args.warmup)
+    fleet.timings()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    fleet.set_sampling(3)            # per-stage HIP events on every 3rd step of group / session 0
     t0 = time.perf_counter()
     rep = fleet.run(args.steps)      # every frame and every local BA of the timed steps completes inside
     torch.cuda.synchronize()
@@ -435,15 +439,16 @@ def main():
                          "rms_position_error_m": float(np.sqrt(rep["sum_sq_position_error"] / max(rep["frames"], 1))),
                          "max_position_error_m": rep["max_position_error"]},
             "stage_ms_per_frame": {k: v for k, v in sorted(per_frame.items())},
-            "stage_sampling": "HIP events on every 3rd step of group 0 (all its lanes per launch) and on the local BAs of its first session that "
+            "stage_sampling": "HIP events on every %s step of group 0 (all its lanes per launch) and on the local BAs of its first sessions that "
                               "complete in those steps (%d frames, %d BAs); per tracked frame; BA stages amortised over %.1f frames per BA"
-                              % (cnt["frames"], cnt["ba"], frames_per_ba),
+                              % ("3rd" if sample_every == 3 else "single", cnt["frames"], cnt["ba"], frames_per_ba),
         }
         if per_frame:
             # Which kernel dominates a GPU that runs several streams at once?  Elapsed time alone over-counts narrow launches: a
             # one-wave Cholesky (k_ba_solve_mfma64) that waits 150 us for a free CU occupies 4 of the GPU's 8192 wave slots.  A
             # group's weight is therefore its device time per tracked frame x the share of the wave slots one launch can fill
-            # (SQ_WAVES per launch from the committed PMC pass, same launch shape; 256 CUs x 32 waves).  `roofline` prices that
+            # (SQ_WAVES per launch from the committed PMC pass, same launch shape, against 256 CUs x 32 waves; x the kernel's
+            # resident-wave limit where registers or LDS cap it).  `roofline` prices that
             # kernel; `roofline_top5` lists the five largest groups by the same weight.
             bsfx = "_b" if lanes > 0 else ""
             KNAME = {"proj_resolve": "k_proj_resolve" + bsfx, "pose_imu_lm": "k_pose_imu_lm" + bsfx, "pose_lm": "k_pose_lm" + bsfx,
@@ -459,9 +464,13 @@ def main():
                 pmc_all = {}
             WAVE_SLOTS = 256 * 32
 
+            # resident-wave limit of a kernel, as a fraction of a CU's 32 wave slots (-Rpass-analysis=kernel-resource-usage /
+            # LDS per workgroup): k_ssc<2> = two 8-wave tasks per CU (67 KB of LDS each), k_fast = 7 waves per SIMD (71 VGPRs)
+            OCC_LIMIT = {"ssc": 16 / 32.0, "fast": 28 / 32.0}
+
             def slot_share(k):
                 w = pmc_all.get(KNAME.get(k, ""), {}).get("SQ_WAVES_avg")
-                return min(1.0, w / WAVE_SLOTS) if w else 1.0
+                return (min(1.0, w / WAVE_SLOTS) if w else 1.0) * OCC_LIMIT.get(k, 1.0)
             dom = max(per_frame, key=lambda k: per_frame[k] * slot_share(k))
             dom_elapsed = max(per_frame, key=lambda k: per_frame[k])
             n_launch, alg_bytes, alg_flops = groups.get(dom, (nS, 0, 0))
