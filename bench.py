@@ -200,10 +200,10 @@ def main():
                                                               "synthetic scene's extent in units of the rig's baseline bounds the camera speed)")
     ap.add_argument("--host-images", action="store_true", help="frames in pinned host memory: every frame pays its H2D copy inside the step")
     ap.add_argument("--mapping", type=int, default=2, help="local mapping: 2 = optimizer thread per session (reference), 1 = synchronous, 0 = off")
-    ap.add_argument("--mapping-max-lag", type=int, default=-1, help="(default: 4 frames, 2 for c3) --mapping 2: a frame waits for a local-mapping pass handed over this many "
-                    "frames ago (default 4: keyframes are at least 5 frames apart, so every keyframe's pass finishes before the next keyframe - "
-                    "the reference's steady state at camera rate); 0 = never wait: at this frame rate the mapper then falls behind and half "
-                    "of the keyframes are never optimised")
+    ap.add_argument("--mapping-delay", type=int, default=-1, help="(default: 4 frames, 2 for c3) --mapping 2: the fixed schedule of the optimizer "
+                    "thread's hand-over (vslam_system_config::mapping_delay): new points arrive with the frame after the keyframe, the "
+                    "local BA's write-back + changePosesLCA k frames after it.  Keyframes are at least 5 frames apart, so with k <= 5 every "
+                    "keyframe gets its pass - the reference's steady state at camera rate")
     ap.add_argument("--prime", type=int, default=60, help="untimed frames every session tracks BEFORE the warm-up steps, so that the timed "
                     "steps see sessions in their steady state (a map with more than three keyframes, the local mapper running) "
                     "whatever --warmup / --steps are; part of the set-up like rendering the frames")
@@ -268,13 +268,12 @@ def main():
     lp = [b[0].data_ptr() for b in bufs]
     rp = [b[1].data_ptr() for b in bufs]
     imu = dict(gravity=GRAVITY, noise=IMU_NOISE, T_bs=__import__("synth").T_BC1, hz=200) if cfg["imu"] else None
-    if args.mapping_max_lag < 0:
-        # The reference's optimizer thread ends a pass within a frame or two of camera time.  4 frames keeps every keyframe's pass
-        # ahead of the next keyframe on the EuRoC-like sequences; the KITTI-like sequence moves ~10x faster per frame, its tracker
-        # lives on the mapper's new points: with 4 frames of lag sessions lose track (4-21 lost frames per run, 9-14 k frames/s),
-        # with 2 they do not (2-4 lost frames as with synchronous mapping, 21-22 k frames/s).
-        args.mapping_max_lag = 2 if args.config == "c3" else 4
-    scfg = vc.system_config(rig, cfg["nfeat"], imu=imu, local_mapping=args.mapping, device=local, mapping_max_lag=args.mapping_max_lag)
+    if args.mapping_delay < 0:
+        # The reference's optimizer thread ends a pass within a frame or two of camera time: k = 2 for the KITTI-like sequence
+        # (10 fps, ~10x the motion per frame), k = 4 for the EuRoC-like ones (20 fps).  The mode is parity-tested frame by frame
+        # against the oracle's restatement of the same schedule (tests/test_gpu_system.py).
+        args.mapping_delay = 2 if args.config == "c3" else 4
+    scfg = vc.system_config(rig, cfg["nfeat"], imu=imu, local_mapping=args.mapping, device=local, mapping_delay=args.mapping_delay)
 
     def make_fleet(S, lanes):
         return vc.Fleet(scfg, S, lp, rp, w, not args.host_images, poses=poses, velocities=vel,
@@ -425,9 +424,10 @@ def main():
                                    % (args.frames, "in pinned host memory (H2D inside the step)" if args.host_images else "resident in HBM",
                                       rep["frames"] / max(rep["keyframes"], 1), frames_per_ba, L_, R_, Fk),
                        "sessions_per_gpu": S, "lanes_per_group": lanes, "prime_frames": args.prime,
-                       "local_mapping": {0: "off", 1: "inside the frame (synchronous)", 2: "optimizer threads"}.get(args.mapping, "?") +
-                                        ("; a frame waits for a pass handed over >= %d frames ago" % args.mapping_max_lag
-                                         if args.mapping == 2 and args.mapping_max_lag > 0 else ""),
+                       "local_mapping": {0: "off", 1: "inside the frame (synchronous)", 2: "device work beside tracking, fixed schedule"}.get(args.mapping, "?") +
+                                        ("; mapping_delay = %d: new points with the next frame, the BA's write-back + changePosesLCA %d frames after "
+                                         "the hand-over (the mode of tests/test_gpu_system.py::test_closed_loop_parity_async_*)" % (args.mapping_delay, args.mapping_delay)
+                                         if args.mapping == 2 else ""),
                        "step": "one stereo frame of each of the %d sessions" % S,
                        "threads": ("%d lockstep groups of %d sessions (vslam_batch: one launch per stage for all lanes), one driver thread + a "
                                    "host-phase pool + 3 mapping threads per group" % ((S + lanes - 1) // lanes, lanes)) if lanes > 0 else

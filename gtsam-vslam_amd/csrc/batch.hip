@@ -127,8 +127,8 @@ vslam_status vslam_batch::init(const vslam_system_config* cfgs, int n, int hostT
     for (int b = 1; b < B; b++) {
         const vslam_system_config& c = cfgs[b];
         if (c.device != device || (c.use_imu != 0) != useImu || memcmp(&c.rig, &cfgs[0].rig, sizeof(c.rig)) || memcmp(&c.fe, &cfgs[0].fe, sizeof(c.fe)) ||
-            c.local_mapping != cfgs[0].local_mapping) {
-            set_error("vslam_batch: lanes must share device, rig, extractor parameters, IMU mode and mapping mode");
+            c.local_mapping != cfgs[0].local_mapping || c.mapping_delay != cfgs[0].mapping_delay) {
+            set_error("vslam_batch: lanes must share device, rig, extractor parameters, IMU mode and mapping mode / delay");
             return VSLAM_ERR_INVALID;
         }
     }

@@ -135,19 +135,14 @@ void vslam_system::mp_update(SysMP& mp, int kfNumb, std::vector<int>& needDesc, 
 }
 
 // MapPoint::calcDescriptor (src/Map.cpp:145-210) for a batch of map points: k_calc_descriptor
-// lk (optional): the caller's hold on mapMutex; it is released for the duration of the GPU round trip.  A point whose
-// observation list changed meanwhile (the other thread added a keyframe match and recomputed its descriptor from the longer
-// list) keeps that newer result.
-vslam_status vslam_system::calc_descriptors(const std::vector<int>& mps, std::unique_lock<std::mutex>* lk) {
+vslam_status vslam_system::calc_descriptors(const std::vector<int>& mps) {
     if (mps.empty()) return VSLAM_OK;
     SysProfScope ps(sys_prof().descNs, sys_prof().descN);
     std::vector<uint8_t> descs;
     std::vector<int> start(1, 0), best(mps.size(), -1);
     std::vector<const uint8_t*> src;
-    std::vector<size_t> nObsAt(mps.size());
     for (size_t q = 0; q < mps.size(); q++) {
         const SysMP& mp = mapPoints[mps[q]];
-        nObsAt[q] = mp.kfm.size();
         for (const KfMatch& o : mp.kfm) {
             const SysKeys& k = keyFrames[o.kf].keys;
             if (o.l != -1) src.push_back(k.dL.data() + (size_t)o.l * 32);
@@ -157,14 +152,9 @@ vslam_status vslam_system::calc_descriptors(const std::vector<int>& mps, std::un
     }
     descs.resize(src.size() * 32);
     for (size_t i = 0; i < src.size(); i++) memcpy(descs.data() + i * 32, src[i], 32);
-    if (!src.empty()) {
-        if (lk) lk->unlock();
-        const vslam_status st = vslam_calc_descriptors(descs.data(), start.data(), (int)mps.size(), cfg.device, best.data());
-        if (lk) lk->lock();
-        if (st != VSLAM_OK) return st;
-    }
+    if (!src.empty()) VS_CHECK(vslam_calc_descriptors(descs.data(), start.data(), (int)mps.size(), cfg.device, best.data()));
     for (size_t q = 0; q < mps.size(); q++)
-        if (start[q + 1] > start[q] && best[q] >= 0 && mapPoints[mps[q]].kfm.size() == nObsAt[q])
+        if (start[q + 1] > start[q] && best[q] >= 0)
             memcpy(mapPoints[mps[q]].desc, descs.data() + (size_t)(start[q] + best[q]) * 32, 32);
     return VSLAM_OK;
 }
@@ -226,8 +216,7 @@ void vslam_system::calc_connections(SysKF& kf) {
 
 // insertKeyFrame (src/FeatureTracker.cpp:743-842)
 vslam_status vslam_system::insert_keyframe(SysKeys& keys, const std::vector<int>& matchedL, const std::vector<int>& matches,
-                                           int nStereo, const M4& estimPose, const std::vector<uint8_t>& outl, const std::vector<int>& act, int frame,
-                                           std::unique_lock<std::mutex>* lk) {
+                                           int nStereo, const M4& estimPose, const std::vector<uint8_t>& outl, const std::vector<int>& act, int frame) {
     const M4 refPose = m4_mul(keyFrames[latestKF].poseInv, estimPose);
     keyFrames.emplace_back();
     SysKF& kf = keyFrames.back();
@@ -269,7 +258,7 @@ vslam_status vslam_system::insert_keyframe(SysKeys& keys, const std::vector<int>
             tracked++;
         }
     }
-    VS_CHECK(calc_descriptors(need, lk));
+    VS_CHECK(calc_descriptors(need));
     calc_connections(keyFrames[numb]);
     lastKFTrackedNumb = tracked; kf.nKeysTracked = tracked;
     precCheckMatches = tracked > 350 ? 0.7f : 0.9f;
@@ -282,27 +271,18 @@ vslam_status vslam_system::insert_keyframe(SysKeys& keys, const std::vector<int>
 
 // KeyFrame::updatePose (src/KeyFrame.cpp:6-76): k_kf_update_pose
 vslam_status vslam_system::kf_update_pose(SysKF& kf, const M4& keyPose) {
-    std::vector<int> lms, slotL(kf.lmpL.size(), -1), slotR(kf.lmpR.size(), -1), index;
-    auto slot = [&](const std::vector<int>& src, std::vector<int>& dst) {
+    std::vector<int> lms, slotL(kf.lmpL.size(), -1), slotR(kf.lmpR.size(), -1);
+    if (lcaWhere.size() < mapPoints.size()) lcaWhere.resize(mapPoints.size() + mapPoints.size() / 2 + 64, -1);     // (grows with the map, reset below)
+    auto slots = [&](const std::vector<int>& src, std::vector<int>& dst) {
         for (size_t i = 0; i < src.size(); i++) {
             if (src[i] < 0) continue;
-            int j = -1;
-            for (size_t q = 0; q < lms.size(); q++) if (lms[q] == src[i]) { j = (int)q; break; }
-            if (j < 0) { j = (int)lms.size(); lms.push_back(src[i]); }
-            dst[i] = j;
+            int& w = lcaWhere[src[i]];
+            if (w < 0) { w = (int)lms.size(); lms.push_back(src[i]); }
+            dst[i] = w;
         }
     };
-    // (linear search is fine for a test-sized chain; keyed lookup for long ones)
-    std::vector<int> where(mapPoints.size(), -1);
-    auto slotFast = [&](const std::vector<int>& src, std::vector<int>& dst) {
-        for (size_t i = 0; i < src.size(); i++) {
-            if (src[i] < 0) continue;
-            if (where[src[i]] < 0) { where[src[i]] = (int)lms.size(); lms.push_back(src[i]); }
-            dst[i] = where[src[i]];
-        }
-    };
-    (void)slot;
-    slotFast(kf.lmpL, slotL); slotFast(kf.lmpR, slotR);
+    slots(kf.lmpL, slotL); slots(kf.lmpR, slotR);
+    for (int m : lms) lcaWhere[m] = -1;
     std::vector<double> xyz(std::max<size_t>(lms.size(), 1) * 3);
     std::vector<int64_t> kdx(std::max<size_t>(lms.size(), 1));
     std::vector<uint8_t> ol(std::max<size_t>(lms.size(), 1));
@@ -360,22 +340,14 @@ vslam_status vslam_system::change_poses_lca(int endIdx) {
 //   frame_post      everything after the device: bookkeeping, keyframe rule, insertKeyFrame, updatePoses, local mapping
 vslam_status vslam_system::frame_begin(SysFrameCtx& c, int frame, const vslam_imu_bucket* imu) {
     if (cfg.use_imu && frame > 0 && (!imu || imu->n <= 0)) { set_error("vslam_system: IMU mode needs the frame's IMU bucket"); return VSLAM_ERR_INVALID; }
-    {
-        std::unique_lock<std::mutex> lk(wMu);
-        // bounded mapper lag (vslam_system_config::mapping_max_lag): a pass handed over d or more frames ago must have finished
-        if (cfg.local_mapping == 2 && cfg.mapping_max_lag > 0 && mappingBusy && frame - mappingSubmittedFrame >= cfg.mapping_max_lag) {
-            SysProfScope pw(sys_prof().waitNs, sys_prof().waitN);
-            wCv.wait(lk, [&] { return !mappingBusy; });
-        }
-        if (workerStatus != VSLAM_OK) { set_error("local mapping thread failed: %s", workerError); return workerStatus; }
-    }
     c.frame = frame; c.imu = imu;
     c.out = vslam_frame_report{};
     c.out.frame = frame;
     VS_HIP(hipSetDevice(cfg.device));
+    std::lock_guard<std::mutex> lk(mapMutex);
+    VS_CHECK(mapping_begin(frame));                         // the optimizer thread's writes that the schedule places here
     if (LBADone) {                                         // :1115-1122
         SysProfScope ps(sys_prof().lcaNs, sys_prof().lcaN);
-        std::lock_guard<std::mutex> lk(mapMutex);
         VS_CHECK(change_poses_lca(endLBAIdx));
         LBADone = false;
     }
@@ -446,19 +418,12 @@ vslam_status vslam_system::frame_post(SysFrameCtx& c, const SysTrackState& st, d
     std::vector<int> act(M);
     bool isKF = false;
     {
-        std::unique_lock<std::mutex> lk(mapMutex);
-        // host side of removeOutOfFrameMPs / PredictMPsPosition: MapPoint::inFrame, the compacted active list.  Points the
-        // optimizer thread appended to activeMapPoints while this frame was on the device stay behind the compacted ones.
+        std::lock_guard<std::mutex> lk(mapMutex);
+        // host side of removeOutOfFrameMPs / PredictMPsPosition: MapPoint::inFrame, the compacted active list (nothing is
+        // appended to activeMapPoints while a frame is on the device: the mapper's points arrive in frame_begin)
         for (int j = 0; j < N; j++) mapPoints[cand[j]].inFrame = visL[j] != 0;
-        std::vector<int> tail;
-        {
-            std::vector<uint8_t> wasCand(mapPoints.size(), 0);
-            for (int m : cand) wasCand[m] = 1;
-            for (int m : active) if (!wasCand[m] && !mapPoints[m].isOutlier) tail.push_back(m);
-        }
         for (int i = 0; i < M; i++) { act[i] = cand[actIdx[i]]; mapPoints[act[i]].inFrame = inF[i] != 0; }
         active = act;
-        active.insert(active.end(), tail.begin(), tail.end());
         // keyframe rule (:1260-1270)
         insertKeyFrameCount++;
         isKF = (tr.n_stereo < 80 || insertKeyFrameCount >= 5) && (float)tr.n_inliers < precCheckMatches * (float)lastKFTrackedNumb;
@@ -468,7 +433,7 @@ vslam_status vslam_system::frame_post(SysFrameCtx& c, const SysTrackState& st, d
             SysKeys keys;
             if (st.keys) keys_from_block(st.keys, nL, st.nR, keys);
             else VS_CHECK(fetch_keys(keys));
-            VS_CHECK(insert_keyframe(keys, matchedL, matches, tr.n_stereo, poseEst, outl, act, frame, &lk));
+            VS_CHECK(insert_keyframe(keys, matchedL, matches, tr.n_stereo, poseEst, outl, act, frame));
         } else {                                           // addFrame (:871-882)
             allFrames.push_back({false, -1, latestKF, m4_mul(keyFrames[latestKF].poseInv, poseEst)});
         }
@@ -496,26 +461,20 @@ vslam_status vslam_system::frame_post(SysFrameCtx& c, const SysTrackState& st, d
     memcpy(T_wc_out, poseEst.data(), sizeof(double) * 16);
     out.keyframe_inserted = isKF ? 1 : 0; out.n_active = M; out.n_inliers = tr.n_inliers; out.n_stereo = tr.n_stereo;
     out.rounds = tr.rounds; out.lm_iterations = tr.lm_iterations;
-    // ---- LocalMapper::beginLocalMapping: one pass of its loop body -------------------------------------------------------
-    if (cfg.local_mapping == 1 && keyFrameAdded && !LBADone) {
-        VS_CHECK(local_mapping());
-    } else if (cfg.local_mapping == 2 && keyFrameAdded && !LBADone) {
-        bool submit = false;
-        { std::lock_guard<std::mutex> lk(wMu); if (!mappingBusy) { mappingBusy = true; submit = true; mappingSubmittedFrame = frame; } }
-        if (submit) {
-            if (mapExec) mapExec(mapExecArg, this);       // the batch's mapping threads
-            else wCv.notify_all();
-        }
-    }
-    if (mappingReportFresh) {
+    // ---- LocalMapper::beginLocalMapping: one pass of its loop body, on the schedule of cfg.mapping_delay ---------------------
+    {
         std::lock_guard<std::mutex> lk(mapMutex);
-        out.mapping_ran = 1; out.new_points = lastMapping.new_points; out.ba_keyframes = lastMapping.ba_keyframes;
-        out.ba_local = lastMapping.ba_local; out.ba_landmarks = lastMapping.ba_landmarks; out.ba_pairs = lastMapping.ba_pairs;
-        out.ba_wrong = lastMapping.ba_wrong; out.ba_outliers = lastMapping.ba_outliers;
-        out.ba_report[0] = lastMapping.ba_report[0]; out.ba_report[1] = lastMapping.ba_report[1];
-        out.ba_residuals = lastMapping.ba_residuals; out.ba_free_kf = lastMapping.ba_free_kf; out.ba_sum_k2 = lastMapping.ba_sum_k2;
-        out.ba_trials = lastMapping.ba_trials;
-        mappingReportFresh = false;
+        VS_CHECK(mapping_post(frame));
+        if (mappingReportFresh) {
+            out.mapping_ran = 1; out.new_points = lastMapping.new_points; out.ba_keyframes = lastMapping.ba_keyframes;
+            out.ba_local = lastMapping.ba_local; out.ba_landmarks = lastMapping.ba_landmarks; out.ba_pairs = lastMapping.ba_pairs;
+            out.ba_wrong = lastMapping.ba_wrong; out.ba_outliers = lastMapping.ba_outliers;
+            out.ba_report[0] = lastMapping.ba_report[0]; out.ba_report[1] = lastMapping.ba_report[1];
+            out.ba_residuals = lastMapping.ba_residuals; out.ba_free_kf = lastMapping.ba_free_kf; out.ba_sum_k2 = lastMapping.ba_sum_k2;
+            out.ba_trials = lastMapping.ba_trials;
+            out.n_keyframes = (int)keyFrames.size(); out.n_map_points = (int)mapPoints.size(); out.n_active_after = (int)active.size();
+            mappingReportFresh = false;
+        }
     }
     if (rep) *rep = out;
     return VSLAM_OK;
@@ -564,11 +523,22 @@ vslam_status vslam_system::track(const uint8_t* L, const uint8_t* R, int stride,
     return frame_post(c, st, T_wc_out, rep);
 }
 
-// one mapping job on the calling thread (the session's own worker, or one of the batch's mapping threads)
+// ---- the local-mapping pass on its schedule ---------------------------------------------------------------------------------
+// local_mapping = 1: the whole pass inside frame_post of the frame that inserted the keyframe.
+// local_mapping = 2, mapping_delay = k:   frame_post(f)       window, np_collect, NEW_POINTS job submitted
+//                                         frame_begin(f + 1)  wait, np_commit, ba_collect, LOCAL_BA job submitted
+//                                         frame_begin(f + k)  wait, ba_commit (LBADone: changePosesLCA runs in the same begin)
+// The jobs (vslam_find_new_points / vslam_local_ba on job-private arrays) run on the session's worker thread or on the
+// batch's mapping threads; the map itself is only touched here, on the tracker's timeline.
+
+// one job on the calling thread (the session's own worker, or one of the batch's mapping threads)
 void vslam_system::run_mapping() {
     hipSetDevice(cfg.device);
     vslam_status s = VSLAM_OK;
-    if (keyFrameAdded && !LBADone) s = local_mapping();
+    if (pass.stage == MapPass::NEW_POINTS) {
+        SysProfScope pn(sys_prof().npNs, sys_prof().npN);
+        s = vslam_find_new_points(&pass.np.P, &pass.np.R, cfg.device);
+    } else if (pass.stage == MapPass::LOCAL_BA) s = ba_device(pass);
     {
         std::lock_guard<std::mutex> lk(wMu);
         if (s != VSLAM_OK && workerStatus == VSLAM_OK) { workerStatus = s; snprintf(workerError, sizeof(workerError), "%s", vslam_last_error()); }
@@ -589,214 +559,253 @@ void vslam_system::worker_loop() {
     vslam::thread_release();
 }
 
-// one pass of beginLocalMapping's loop body (src/OptimizationBA.cpp:960-975)
-vslam_status vslam_system::local_mapping() {
-    std::vector<int> actKeyF;
-    {
-        std::lock_guard<std::mutex> lk(mapMutex);
-        const int last = (int)keyFrames.size() - 1;
-        actKeyF.push_back(last);
-        int count = 1;
-        for (const auto& c : keyFrames[last].sortedKFWeights) {     // KeyFrame::getConnectedKFs (src/KeyFrame.cpp:87-101)
-            if (c.second != last) { actKeyF.push_back(c.second); count++; }
-            if (count >= cfg.window) break;
-        }
+vslam_status vslam_system::submit_job(int stage) {
+    pass.stage = stage;
+    if (cfg.local_mapping != 2) {                          // synchronous: on this thread
+        if (stage == MapPass::NEW_POINTS) { SysProfScope pn(sys_prof().npNs, sys_prof().npN); return vslam_find_new_points(&pass.np.P, &pass.np.R, cfg.device); }
+        return ba_device(pass);
     }
-    vslam_frame_report r{};
-    int nNew = 0;
+    { std::lock_guard<std::mutex> lk(wMu); mappingBusy = true; }
+    if (mapExec) mapExec(mapExecArg, this);               // the batch's mapping threads
+    else wCv.notify_all();
+    return VSLAM_OK;
+}
+
+vslam_status vslam_system::wait_job() {
+    std::unique_lock<std::mutex> lk(wMu);
+    if (mappingBusy) {
+        SysProfScope pw(sys_prof().waitNs, sys_prof().waitN);
+        wCv.wait(lk, [&] { return !mappingBusy; });
+    }
+    if (workerStatus != VSLAM_OK) { set_error("local mapping thread failed: %s", workerError); return workerStatus; }
+    return VSLAM_OK;
+}
+
+// KeyFrame::getConnectedKFs (src/KeyFrame.cpp:87-101) of the newest keyframe: the pass's window
+void vslam_system::mapping_window(std::vector<int>& actKeyF) {
+    actKeyF.clear();
+    const int last = (int)keyFrames.size() - 1;
+    actKeyF.push_back(last);
+    int count = 1;
+    for (const auto& c : keyFrames[last].sortedKFWeights) {
+        if (c.second != last) { actKeyF.push_back(c.second); count++; }
+        if (count >= cfg.window) break;
+    }
+}
+
+vslam_status vslam_system::mapping_post(int frame) {
+    if (cfg.local_mapping == 0 || !keyFrameAdded || LBADone || pass.stage != MapPass::IDLE) return VSLAM_OK;
     SysProfScope pm(sys_prof().mapNs, sys_prof().mapN);
-    { SysProfScope pn(sys_prof().npNs, sys_prof().npN); VS_CHECK(find_new_points(actKeyF, nNew)); }
-    lastMapping = r;
-    lastMapping.new_points = nNew;
-    VS_CHECK(local_ba(actKeyF));
-    mappingReportFresh = true;
-    return VSLAM_OK;
-}
-
-// findNewPoints + addMultiViewMapPointsR + addNewMapPoints (src/OptimizationBA.cpp:90-125, 211-232, 340-391)
-vslam_status vslam_system::find_new_points(const std::vector<int>& actKeyF, int& nNew) {
-    nNew = 0;
-    const int nk = (int)actKeyF.size();
-    std::vector<vslam_kf_view> views(nk);
-    std::vector<uint8_t> has, mpd;
-    std::vector<double> mpx;
-    std::vector<int> cL, cR, nObs, obs;
-    std::vector<uint8_t> acc;
-    std::vector<double> xyz;
-    int n0 = 0;
-    // the keyframes' arrays are read in place: a keyframe's keys never move (deque), only depth / close / unMatchedF change
-    // under mapMutex.  The lock is RELEASED around the device call: the tracker thread does not write what it reads in place
-    // (a window keyframe's keys, unMatchedF / unMatchedFR - only a NEW keyframe's are written at insertion, changePosesLCA
-    // does not run while a mapping pass is pending), and the map-point values it needs are copied first.
-    {
-        std::unique_lock<std::mutex> lk(mapMutex);
-        for (int k = 0; k < nk; k++) {
-            const SysKF& kf = keyFrames[actKeyF[k]];
-            vslam_kf_view& v = views[k];
-            v.T_wc = kf.pose.data(); v.id = kf.numb; v.n_left = (int)kf.keys.kL.size(); v.n_right = (int)kf.keys.kR.size();
-            v.kps_l = kf.keys.kL.data(); v.desc_l = kf.keys.dL.data(); v.kps_r = kf.keys.kR.data(); v.desc_r = kf.keys.dR.data();
-            v.right_idxs = kf.keys.rightIdxs.data(); v.left_idxs = kf.keys.leftIdxs.data();
-            v.unmatched_f = kf.unF.data(); v.unmatched_fr = kf.unFR.data();
-        }
-        const SysKF& last = keyFrames[actKeyF[0]];
-        n0 = (int)last.keys.kL.size();
-        has.assign(std::max(n0, 1), 0); mpx.assign((size_t)std::max(n0, 1) * 3, 0.0); mpd.assign((size_t)std::max(n0, 1) * 32, 0);
-        for (int i = 0; i < n0; i++) {
-            const int m = last.lmpL[i];
-            if (m < 0) continue;
-            has[i] = 1;
-            for (int c = 0; c < 3; c++) mpx[3 * (size_t)i + c] = mapPoints[m].wp[c];
-            memcpy(mpd.data() + (size_t)i * 32, mapPoints[m].desc, 32);
-        }
-        vslam_new_points_problem P{};
-        P.rig = cfg.rig; P.n_levels = nLev; P.scale_pyramid = scalePyr.data(); P.sigma_factor = sigmaF.data();
-        P.log_scale = (float)std::log((double)cfg.fe.scale); P.n_kf = nk; P.kfs = views.data();
-        P.estimated_depth = last.keys.depth.data(); P.has_mp = has.data(); P.mp_xyz = mpx.data(); P.mp_desc = mpd.data();
-        const int cap = std::max(n0, 1);
-        cL.assign(cap, -1); cR.assign(cap, -1); acc.assign(cap, 0); xyz.assign((size_t)cap * 3, 0.0); nObs.assign(cap, 0);
-        obs.assign((size_t)cap * nk * 3, -1);
-        vslam_new_points_result R{};
-        R.capacity = cap; R.cand_left = cL.data(); R.cand_right = cR.data(); R.accepted = acc.data(); R.xyz = xyz.data();
-        R.n_obs = nObs.data(); R.obs = obs.data();
-        lk.unlock();
-        const vslam_status fst = vslam_find_new_points(&P, &R, cfg.device);
-        lk.lock();
-        if (fst != VSLAM_OK) return fst;
-        const int nc = R.n_candidates;
-        if (mpIdx < 0) mpIdx = (long long)mapPoints.size();
-        const int lastNumb = last.numb;
-        std::vector<int> created, need;
-        for (int c = 0; c < nc; c++) {
-            if (!acc[c]) continue;
-            const int no = nObs[c];
-            int dl = -1, dr = -1;
-            bool found = false;
-            for (int e = 0; e < no && !found; e++) {
-                const int* o = &obs[((size_t)c * nk + e) * 3];
-                if (actKeyF[o[0]] == lastNumb) { dl = o[1]; dr = o[2]; found = true; }
-            }
-            if (!found || (dl < 0 && dr < 0)) continue;
-            mapPoints.emplace_back();
-            const int mi = (int)mapPoints.size() - 1;
-            SysMP& mp = mapPoints.back();
-            for (int q = 0; q < 3; q++) mp.wp[q] = xyz[3 * (size_t)c + q];
-            const SysKeys& lk0 = keyFrames[lastNumb].keys;
-            memcpy(mp.desc, dl >= 0 ? lk0.dL.data() + (size_t)dl * 32 : lk0.dR.data() + (size_t)dr * 32, 32);
-            mp.kdx = lastNumb; mp.idx = mpIdx++;
-            for (int e = 0; e < no; e++) {
-                const int* o = &obs[((size_t)c * nk + e) * 3];
-                if (mp.find(actKeyF[o[0]]) < 0) mp.kfm.push_back({actKeyF[o[0]], o[1], o[2]});
-            }
-            mp_update(mp, lastNumb, need, mi);
-            created.push_back(mi);
-        }
-        VS_CHECK(calc_descriptors(need, &lk));
-        for (int mi : created) {                           // addNewMapPoints: MapPoint::addConnection on every observing keyframe
-            SysMP& mp = mapPoints[mi];
-            for (const KfMatch& o : mp.kfm) {
-                SysKF& kf = keyFrames[o.kf];
-                if (o.l >= 0) { kf.lmpL[o.l] = mi; kf.unF[o.l] = (int)mp.kdx; }
-                if (o.r >= 0) { kf.lmpR[o.r] = mi; kf.unFR[o.r] = (int)mp.kdx; }
-            }
-            active.push_back(mi);
-        }
-        nNew = (int)created.size();
+    mapping_window(pass.actKeyF);
+    pass.handFrame = frame;
+    pass.commitFrame = frame + std::max(cfg.mapping_delay, 1);
+    np_collect(pass);
+    VS_CHECK(submit_job(MapPass::NEW_POINTS));
+    if (cfg.local_mapping == 1) {                          // the whole pass now
+        VS_CHECK(np_commit(pass));
+        ba_collect(pass);
+        VS_CHECK(submit_job(MapPass::LOCAL_BA));
+        VS_CHECK(ba_commit(pass));
+        pass.stage = MapPass::IDLE;
     }
     return VSLAM_OK;
 }
 
-// LocalMapper::localBA: window collection (:438-516), graph membership (:556-745), vslam_local_ba, write-back (:875-938)
-vslam_status vslam_system::local_ba(const std::vector<int>& actKeyF) {
-    struct Pair { int kf, mp, l, r; };
-    std::vector<int> kfs, local;           // keyframe numbers: local first, then fixed
-    std::vector<int> allMps;
-    std::vector<uint8_t> mpOut;
-    std::vector<int> pk, pl, poct; std::vector<uint8_t> pf; std::vector<float> puv; std::vector<Pair> pobj;
-    std::vector<double> kfPose, lm;
-    std::vector<int64_t> kfId; std::vector<uint8_t> kfFixed, kfLocal;
-    std::vector<int> kfIndex;
-    int lastActKF;
-    {
-        std::lock_guard<std::mutex> lk(mapMutex);
-        lastActKF = keyFrames[actKeyF[0]].numb;
-        local = actKeyF;
-        std::vector<uint8_t> isLocal(keyFrames.size(), 0);
-        for (int k : local) { keyFrames[k].LBAID = lastActKF; isLocal[k] = 1; }
-        std::vector<int> fixedKFs;
-        bool fixedKF = false;
-        for (int k : local) {
-            SysKF& kf = keyFrames[k];
-            if (kf.fixed) fixedKF = true;
-            for (int side = 0; side < 2; side++) {
-                const std::vector<int>& lst = side ? kf.lmpR : kf.lmpL;
-                for (int m : lst) {
-                    if (m < 0) continue;
-                    SysMP& mp = mapPoints[m];
-                    if (mp.isOutlier || mp.LBAID == lastActKF) continue;
-                    for (const KfMatch& o : mp.kfm) {
-                        if (side && (o.l >= 0 || o.r < 0)) continue;
-                        SysKF& c = keyFrames[o.kf];
-                        if (c.numb > lastActKF || c.LBAID == lastActKF) continue;
-                        if (!isLocal[o.kf]) { fixedKFs.push_back(o.kf); c.LBAID = lastActKF; }
-                    }
-                    allMps.push_back(m); mp.LBAID = lastActKF;
+vslam_status vslam_system::mapping_begin(int frame) {
+    if (cfg.local_mapping != 2) return VSLAM_OK;
+    { std::lock_guard<std::mutex> lk(wMu); if (workerStatus != VSLAM_OK) { set_error("local mapping thread failed: %s", workerError); return workerStatus; } }
+    if (pass.stage == MapPass::NEW_POINTS) {               // the first frame after the hand-over
+        VS_CHECK(wait_job());
+        SysProfScope pm(sys_prof().mapNs, sys_prof().mapN);
+        VS_CHECK(np_commit(pass));
+        ba_collect(pass);
+        VS_CHECK(submit_job(MapPass::LOCAL_BA));
+    }
+    if (pass.stage == MapPass::LOCAL_BA && frame >= pass.commitFrame) {
+        VS_CHECK(wait_job());
+        SysProfScope pm(sys_prof().mapNs, sys_prof().mapN);
+        VS_CHECK(ba_commit(pass));
+        pass.stage = MapPass::IDLE;
+    }
+    return VSLAM_OK;
+}
+
+// findNewPoints (src/OptimizationBA.cpp:340-391), read side: the window keyframes' arrays are read IN PLACE by the job (a
+// keyframe's records never move - deque - and nothing writes them while the job is in flight: unMatchedF / localMapPoints of
+// window keyframes change only in np_commit / ba_commit, depth / close only in ba_commit); map-point values are copied.
+void vslam_system::np_collect(MapPass& p) {
+    NpJob& J = p.np;
+    const std::vector<int>& actKeyF = p.actKeyF;
+    const int nk = J.nk = (int)actKeyF.size();
+    J.views.assign(nk, vslam_kf_view{});
+    for (int k = 0; k < nk; k++) {
+        const SysKF& kf = keyFrames[actKeyF[k]];
+        vslam_kf_view& v = J.views[k];
+        v.T_wc = kf.pose.data(); v.id = kf.numb; v.n_left = (int)kf.keys.kL.size(); v.n_right = (int)kf.keys.kR.size();
+        v.kps_l = kf.keys.kL.data(); v.desc_l = kf.keys.dL.data(); v.kps_r = kf.keys.kR.data(); v.desc_r = kf.keys.dR.data();
+        v.right_idxs = kf.keys.rightIdxs.data(); v.left_idxs = kf.keys.leftIdxs.data();
+        v.unmatched_f = kf.unF.data(); v.unmatched_fr = kf.unFR.data();
+    }
+    const SysKF& last = keyFrames[actKeyF[0]];
+    const int n0 = J.n0 = (int)last.keys.kL.size();
+    J.has.assign(std::max(n0, 1), 0); J.mpx.assign((size_t)std::max(n0, 1) * 3, 0.0); J.mpd.assign((size_t)std::max(n0, 1) * 32, 0);
+    for (int i = 0; i < n0; i++) {
+        const int m = last.lmpL[i];
+        if (m < 0) continue;
+        J.has[i] = 1;
+        for (int c = 0; c < 3; c++) J.mpx[3 * (size_t)i + c] = mapPoints[m].wp[c];
+        memcpy(J.mpd.data() + (size_t)i * 32, mapPoints[m].desc, 32);
+    }
+    vslam_new_points_problem& P = J.P;
+    P = vslam_new_points_problem{};
+    P.rig = cfg.rig; P.n_levels = nLev; P.scale_pyramid = scalePyr.data(); P.sigma_factor = sigmaF.data();
+    P.log_scale = (float)std::log((double)cfg.fe.scale); P.n_kf = nk; P.kfs = J.views.data();
+    P.estimated_depth = last.keys.depth.data(); P.has_mp = J.has.data(); P.mp_xyz = J.mpx.data(); P.mp_desc = J.mpd.data();
+    const int cap = std::max(n0, 1);
+    J.cL.assign(cap, -1); J.cR.assign(cap, -1); J.acc.assign(cap, 0); J.xyz.assign((size_t)cap * 3, 0.0); J.nObs.assign(cap, 0);
+    J.obs.assign((size_t)cap * nk * 3, -1);
+    vslam_new_points_result& R = J.R;
+    R = vslam_new_points_result{};
+    R.capacity = cap; R.cand_left = J.cL.data(); R.cand_right = J.cR.data(); R.accepted = J.acc.data(); R.xyz = J.xyz.data();
+    R.n_obs = J.nObs.data(); R.obs = J.obs.data();
+}
+
+// addMultiViewMapPointsR + addNewMapPoints (src/OptimizationBA.cpp:90-125, 211-232) from the job's result
+vslam_status vslam_system::np_commit(MapPass& p) {
+    NpJob& J = p.np;
+    const std::vector<int>& actKeyF = p.actKeyF;
+    const int nk = J.nk, nc = J.R.n_candidates;
+    if (mpIdx < 0) mpIdx = (long long)mapPoints.size();
+    const int lastNumb = keyFrames[actKeyF[0]].numb;
+    std::vector<int> created, need;
+    for (int c = 0; c < nc; c++) {
+        if (!J.acc[c]) continue;
+        const int no = J.nObs[c];
+        int dl = -1, dr = -1;
+        bool found = false;
+        for (int e = 0; e < no && !found; e++) {
+            const int* o = &J.obs[((size_t)c * nk + e) * 3];
+            if (actKeyF[o[0]] == lastNumb) { dl = o[1]; dr = o[2]; found = true; }
+        }
+        if (!found || (dl < 0 && dr < 0)) continue;
+        mapPoints.emplace_back();
+        const int mi = (int)mapPoints.size() - 1;
+        SysMP& mp = mapPoints.back();
+        for (int q = 0; q < 3; q++) mp.wp[q] = J.xyz[3 * (size_t)c + q];
+        const SysKeys& lk0 = keyFrames[lastNumb].keys;
+        memcpy(mp.desc, dl >= 0 ? lk0.dL.data() + (size_t)dl * 32 : lk0.dR.data() + (size_t)dr * 32, 32);
+        mp.kdx = lastNumb; mp.idx = mpIdx++;
+        for (int e = 0; e < no; e++) {
+            const int* o = &J.obs[((size_t)c * nk + e) * 3];
+            if (mp.find(actKeyF[o[0]]) < 0) mp.kfm.push_back({actKeyF[o[0]], o[1], o[2]});
+        }
+        mp_update(mp, lastNumb, need, mi);
+        created.push_back(mi);
+    }
+    VS_CHECK(calc_descriptors(need));
+    for (int mi : created) {                               // addNewMapPoints: MapPoint::addConnection on every observing keyframe
+        SysMP& mp = mapPoints[mi];
+        for (const KfMatch& o : mp.kfm) {
+            SysKF& kf = keyFrames[o.kf];
+            if (o.l >= 0) { kf.lmpL[o.l] = mi; kf.unF[o.l] = (int)mp.kdx; }
+            if (o.r >= 0) { kf.lmpR[o.r] = mi; kf.unFR[o.r] = (int)mp.kdx; }
+        }
+        active.push_back(mi);
+    }
+    p.newPoints = (int)created.size();
+    return VSLAM_OK;
+}
+
+// LocalMapper::localBA: window collection (:438-516) and graph membership (:556-745) into the job's problem
+void vslam_system::ba_collect(MapPass& p) {
+    BaJob& J = p.ba;
+    const std::vector<int>& actKeyF = p.actKeyF;
+    J.kfs.clear(); J.allMps.clear(); J.pk.clear(); J.pl.clear(); J.poct.clear(); J.pf.clear(); J.puv.clear(); J.pobj.clear();
+    const int lastActKF = J.lastActKF = keyFrames[actKeyF[0]].numb;
+    J.local = actKeyF;
+    std::vector<int>& local = J.local;
+    std::vector<uint8_t> isLocal(keyFrames.size(), 0);
+    for (int k : local) { keyFrames[k].LBAID = lastActKF; isLocal[k] = 1; }
+    std::vector<int> fixedKFs;
+    bool fixedKF = false;
+    for (int k : local) {
+        SysKF& kf = keyFrames[k];
+        if (kf.fixed) fixedKF = true;
+        for (int side = 0; side < 2; side++) {
+            const std::vector<int>& lst = side ? kf.lmpR : kf.lmpL;
+            for (int m : lst) {
+                if (m < 0) continue;
+                SysMP& mp = mapPoints[m];
+                if (mp.isOutlier || mp.LBAID == lastActKF) continue;
+                for (const KfMatch& o : mp.kfm) {
+                    if (side && (o.l >= 0 || o.r < 0)) continue;
+                    SysKF& c = keyFrames[o.kf];
+                    if (c.numb > lastActKF || c.LBAID == lastActKF) continue;
+                    if (!isLocal[o.kf]) { fixedKFs.push_back(o.kf); c.LBAID = lastActKF; }
                 }
+                J.allMps.push_back(m); mp.LBAID = lastActKF;
             }
         }
-        if (fixedKFs.empty() && !fixedKF) { const int lastK = local.back(); local.pop_back(); isLocal[lastK] = 0; fixedKFs.push_back(lastK); }
-        kfs = local; kfs.insert(kfs.end(), fixedKFs.begin(), fixedKFs.end());
-        kfIndex.assign(keyFrames.size(), -1);
-        for (size_t i = 0; i < kfs.size(); i++) kfIndex[kfs[i]] = (int)i;
-        mpOut.assign(allMps.size(), 0);
-        for (size_t m = 0; m < allMps.size(); m++) {
-            const SysMP& mp = mapPoints[allMps[m]];
-            bool out = true;
-            for (const KfMatch& o : mp.kfm) {
-                if (!mp.inFrame && (int)mp.kfm.size() < 3) { mpOut[m] = 1; break; }
-                if (mp.isOutlier) break;
-                out = false;
-                const SysKF& c = keyFrames[o.kf];
-                if (c.numb > lastActKF || kfIndex[o.kf] < 0) continue;
-                const SysKeys& keys = c.keys;
-                int flags;
-                if (o.l >= 0) flags = (keys.close[o.l] && o.r >= 0) ? 3 : 1;
-                else if (o.r >= 0) flags = 2;
-                else continue;
-                pk.push_back(kfIndex[o.kf]); pl.push_back((int)m); pf.push_back((uint8_t)flags);
-                puv.push_back(o.l >= 0 ? keys.kL[o.l].x : 0.f); puv.push_back(o.l >= 0 ? keys.kL[o.l].y : 0.f);
-                puv.push_back(o.r >= 0 ? keys.kR[o.r].x : 0.f); puv.push_back(o.r >= 0 ? keys.kR[o.r].y : 0.f);
-                poct.push_back(o.l >= 0 ? keys.kL[o.l].octave : 0); poct.push_back(o.r >= 0 ? keys.kR[o.r].octave : 0);
-                pobj.push_back({o.kf, allMps[m], o.l, o.r});
-            }
-            if (out) mpOut[m] = 1;
-        }
-        for (size_t p = 0; p < pk.size(); p++) if (mpOut[pl[p]]) pf[p] = 0;     // flagged landmarks contribute no factor
-        kfPose.resize(kfs.size() * 16); kfId.resize(kfs.size()); kfFixed.resize(kfs.size()); kfLocal.resize(kfs.size());
-        for (size_t i = 0; i < kfs.size(); i++) {
-            const SysKF& k = keyFrames[kfs[i]];
-            memcpy(&kfPose[16 * i], k.pose.data(), 16 * sizeof(double));
-            kfId[i] = k.numb; kfLocal[i] = isLocal[kfs[i]]; kfFixed[i] = (k.fixed || !isLocal[kfs[i]]) ? 1 : 0;
-        }
-        lm.resize(std::max<size_t>(allMps.size(), 1) * 3);
-        for (size_t m = 0; m < allMps.size(); m++) for (int c = 0; c < 3; c++) lm[3 * m + c] = mapPoints[allMps[m]].wp[c];
     }
-    // ---- the numerical core on the device ------------------------------------------------------------------------
-    const int K = (int)kfs.size(), Lm = (int)allMps.size(), NP = (int)pk.size();
-    vslam_ba_problem P{};
+    if (fixedKFs.empty() && !fixedKF) { const int lastK = local.back(); local.pop_back(); isLocal[lastK] = 0; fixedKFs.push_back(lastK); }
+    J.kfs = local; J.kfs.insert(J.kfs.end(), fixedKFs.begin(), fixedKFs.end());
+    const std::vector<int>& kfs = J.kfs;
+    const std::vector<int>& allMps = J.allMps;
+    J.kfIndex.assign(keyFrames.size(), -1);
+    for (size_t i = 0; i < kfs.size(); i++) J.kfIndex[kfs[i]] = (int)i;
+    J.mpOut.assign(allMps.size(), 0);
+    for (size_t m = 0; m < allMps.size(); m++) {
+        const SysMP& mp = mapPoints[allMps[m]];
+        bool out = true;
+        for (const KfMatch& o : mp.kfm) {
+            if (!mp.inFrame && (int)mp.kfm.size() < 3) { J.mpOut[m] = 1; break; }
+            if (mp.isOutlier) break;
+            out = false;
+            const SysKF& c = keyFrames[o.kf];
+            if (c.numb > lastActKF || J.kfIndex[o.kf] < 0) continue;
+            const SysKeys& keys = c.keys;
+            int flags;
+            if (o.l >= 0) flags = (keys.close[o.l] && o.r >= 0) ? 3 : 1;
+            else if (o.r >= 0) flags = 2;
+            else continue;
+            J.pk.push_back(J.kfIndex[o.kf]); J.pl.push_back((int)m); J.pf.push_back((uint8_t)flags);
+            J.puv.push_back(o.l >= 0 ? keys.kL[o.l].x : 0.f); J.puv.push_back(o.l >= 0 ? keys.kL[o.l].y : 0.f);
+            J.puv.push_back(o.r >= 0 ? keys.kR[o.r].x : 0.f); J.puv.push_back(o.r >= 0 ? keys.kR[o.r].y : 0.f);
+            J.poct.push_back(o.l >= 0 ? keys.kL[o.l].octave : 0); J.poct.push_back(o.r >= 0 ? keys.kR[o.r].octave : 0);
+            J.pobj.push_back({o.kf, allMps[m], o.l, o.r});
+        }
+        if (out) J.mpOut[m] = 1;
+    }
+    for (size_t q = 0; q < J.pk.size(); q++) if (J.mpOut[J.pl[q]]) J.pf[q] = 0;     // flagged landmarks contribute no factor
+    J.kfPose.resize(kfs.size() * 16); J.kfId.resize(kfs.size()); J.kfFixed.resize(kfs.size()); J.kfLocal.resize(kfs.size());
+    for (size_t i = 0; i < kfs.size(); i++) {
+        const SysKF& k = keyFrames[kfs[i]];
+        memcpy(&J.kfPose[16 * i], k.pose.data(), 16 * sizeof(double));
+        J.kfId[i] = k.numb; J.kfLocal[i] = isLocal[kfs[i]]; J.kfFixed[i] = (k.fixed || !isLocal[kfs[i]]) ? 1 : 0;
+    }
+    J.lm.resize(std::max<size_t>(allMps.size(), 1) * 3);
+    for (size_t m = 0; m < allMps.size(); m++) for (int c = 0; c < 3; c++) J.lm[3 * m + c] = mapPoints[allMps[m]].wp[c];
+    const int K = (int)kfs.size(), Lm = (int)allMps.size(), NP = (int)J.pk.size();
+    vslam_ba_problem& P = J.P;
+    P = vslam_ba_problem{};
     P.rig = cfg.rig; P.n_levels = nLev; P.sigma_factor = sigmaF.data(); P.inv_sigma_factor = invSigmaF.data();
-    P.n_kf = K; P.kf_pose_wc = kfPose.data(); P.kf_id = kfId.data(); P.kf_fixed = kfFixed.data(); P.kf_local = kfLocal.data();
-    P.n_lm = Lm; P.lm_xyz = lm.data(); P.n_pairs = NP; P.pair_kf = pk.data(); P.pair_lm = pl.data(); P.pair_flags = pf.data();
-    P.pair_uv = puv.data(); P.pair_octave = poct.data();
-    std::vector<double> kfOut((size_t)std::max(K, 1) * 16), lmOut((size_t)std::max(Lm, 1) * 3);
-    std::vector<uint8_t> wrong(std::max(NP, 1), 0), wrong1(std::max(NP, 1), 0);
-    vslam_ba_result Rr{};
-    Rr.kf_pose_wc = kfOut.data(); Rr.lm_xyz = lmOut.data(); Rr.pair_wrong = wrong.data(); Rr.pair_wrong_pass1 = wrong1.data();
+    P.n_kf = K; P.kf_pose_wc = J.kfPose.data(); P.kf_id = J.kfId.data(); P.kf_fixed = J.kfFixed.data(); P.kf_local = J.kfLocal.data();
+    P.n_lm = Lm; P.lm_xyz = J.lm.data(); P.n_pairs = NP; P.pair_kf = J.pk.data(); P.pair_lm = J.pl.data(); P.pair_flags = J.pf.data();
+    P.pair_uv = J.puv.data(); P.pair_octave = J.poct.data();
+    J.kfOut.assign((size_t)std::max(K, 1) * 16, 0.0); J.lmOut.assign((size_t)std::max(Lm, 1) * 3, 0.0);
+    J.wrong.assign(std::max(NP, 1), 0); J.wrong1.assign(std::max(NP, 1), 0);
+    vslam_ba_result& Rr = J.R;
+    Rr = vslam_ba_result{};
+    Rr.kf_pose_wc = J.kfOut.data(); Rr.lm_xyz = J.lmOut.data(); Rr.pair_wrong = J.wrong.data(); Rr.pair_wrong_pass1 = J.wrong1.data();
+}
+
+// the numerical core on the device (the calling thread's local-BA context: stream, workspace, timers)
+vslam_status vslam_system::ba_device(MapPass& p) {
     const int timingBefore = vslam_local_ba_get_timing();      // (thread-scoped switch: left as the caller had it)
     vslam_local_ba_set_timing(timingOn.load());
     vslam_status baSt;
-    { SysProfScope pb(sys_prof().baNs, sys_prof().baN); baSt = vslam_local_ba(&P, &Rr, cfg.device, nullptr); }
-    if (baSt != VSLAM_OK) { vslam_local_ba_set_timing(timingBefore); return baSt; }
-    if (timingOn.load()) {
+    { SysProfScope pb(sys_prof().baNs, sys_prof().baN); baSt = vslam_local_ba(&p.ba.P, &p.ba.R, cfg.device, nullptr); }
+    if (baSt == VSLAM_OK && timingOn.load()) {
         const char* nm[32]; float ms[32]; int n = 0;
         if (vslam_local_ba_timings(nm, ms, 32, &n) == VSLAM_OK) {
             std::lock_guard<std::mutex> lk(tMu);
@@ -810,86 +819,94 @@ vslam_status vslam_system::local_ba(const std::vector<int>& actKeyF) {
         }
     }
     vslam_local_ba_set_timing(timingBefore);
-    // ---- write-back (:875-938) -----------------------------------------------------------------------------------------
-    // (mapMutex is released around the two device round trips below; their inputs are copies)
-    {
-        std::unique_lock<std::mutex> lk(mapMutex);
-        // second graph build (:566-575): a landmark whose every keyframe observation was rejected after pass 1 is flagged
-        std::vector<int> nUsable(allMps.size(), 0);
-        for (int p = 0; p < NP; p++) if (pf[p] && !wrong1[p]) nUsable[pl[p]]++;
-        for (size_t m = 0; m < allMps.size(); m++) {
-            if (mpOut[m] || nUsable[m]) continue;
-            int later = 0;
-            for (const KfMatch& o : mapPoints[allMps[m]].kfm) if (keyFrames[o.kf].numb > lastActKF || kfIndex[o.kf] < 0) later++;
-            if (!later) mpOut[m] = 1;
-        }
-        int nWrong = 0;
-        for (int p = 0; p < NP; p++) {
-            if (!wrong[p]) continue;
-            nWrong++;
-            SysKF& c = keyFrames[pobj[p].kf];
-            SysMP& mp = mapPoints[pobj[p].mp];
-            const int e = mp.find(pobj[p].kf);
-            if (e < 0) continue;
-            const int l = mp.kfm[e].l, r = mp.kfm[e].r;
-            if (l >= 0) { c.lmpL[l] = -1; c.unF[l] = -1; }              // KeyFrame::eraseMPConnection
-            if (r >= 0) { c.lmpR[r] = -1; c.unFR[r] = -1; }
-            mp.kfm.erase(mp.kfm.begin() + e);                            // MapPoint::eraseKFConnection
-        }
-        std::vector<uint8_t> presentKf(K, 0), presentLm(std::max(Lm, 1), 0);
-        for (int p = 0; p < NP; p++) if (pf[p] && !wrong1[p]) { presentKf[pk[p]] = 1; presentLm[pl[p]] = 1; }
-        for (int i = 0; i < K; i++) if (kfLocal[i] && presentKf[i]) keyFrames[kfs[i]].setPose(m4_from(&kfOut[16 * (size_t)i]));
-        std::vector<int> upd;
-        int nOut = 0;
-        for (size_t m = 0; m < allMps.size(); m++) {
-            SysMP& mp = mapPoints[allMps[m]];
-            if (mpOut[m] || (!mp.inFrame && (int)mp.kfm.size() < 3)) { mp.isOutlier = true; nOut++; }
-            else if (presentLm[m]) { for (int c = 0; c < 3; c++) mp.wp[c] = lmOut[3 * m + c]; upd.push_back(allMps[m]); }
-        }
-        // MapPoint::updatePos (src/Map.cpp:212-234): depth / close refresh of every observing keyframe (k_ba_refresh_depth),
-        // then calcDescriptor
-        if (!upd.empty()) {
-            std::vector<int> rk, rl; std::vector<float> cur; std::vector<std::pair<int, int>> where;     // (kf numb, left idx)
-            std::vector<double> rpose; std::vector<int> kfSlot(keyFrames.size(), -1); std::vector<int> rkfs;
-            std::vector<double> rlm(upd.size() * 3);
-            for (size_t u = 0; u < upd.size(); u++) {
-                const SysMP& mp = mapPoints[upd[u]];
-                for (int c = 0; c < 3; c++) rlm[3 * u + c] = mp.wp[c];
-                for (const KfMatch& o : mp.kfm) {
-                    if (o.l < 0) continue;                 // (the reference indexes estimatedDepth[-1] here; skipped)
-                    if (kfSlot[o.kf] < 0) { kfSlot[o.kf] = (int)rkfs.size(); rkfs.push_back(o.kf); }
-                    rk.push_back(kfSlot[o.kf]); rl.push_back((int)u); cur.push_back(keyFrames[o.kf].keys.depth[o.l]);
-                    where.push_back({o.kf, o.l});
-                }
-            }
-            if (!rk.empty()) {
-                rpose.resize(rkfs.size() * 16);
-                for (size_t i = 0; i < rkfs.size(); i++) memcpy(&rpose[16 * i], keyFrames[rkfs[i]].pose.data(), 16 * sizeof(double));
-                std::vector<uint8_t> zeroW(rk.size(), 0), zeroO(upd.size(), 0), clo(rk.size()), up(rk.size());
-                std::vector<float> dep(rk.size());
-                lk.unlock();
-                const vslam_status rst = vslam_ba_refresh_depth(&cfg.rig, (int)rkfs.size(), rpose.data(), (int)upd.size(), rlm.data(), zeroO.data(), (int)rk.size(),
-                                                                rk.data(), rl.data(), zeroW.data(), cur.data(), cfg.device, dep.data(), clo.data(), up.data());
-                lk.lock();
-                if (rst != VSLAM_OK) return rst;
-                for (size_t q = 0; q < rk.size(); q++) {
-                    if (!up[q]) continue;
-                    SysKeys& keys = keyFrames[where[q].first].keys;
-                    keys.depth[where[q].second] = dep[q];
-                    if (clo[q]) keys.close[where[q].second] = 1;
-                }
-            }
-            VS_CHECK(calc_descriptors(upd, &lk));
-        }
-        endLBAIdx = actKeyF[0];
-        keyFrameAdded = false;
-        LBADone = true;
-        lastMapping.ba_keyframes = K; lastMapping.ba_local = (int)local.size(); lastMapping.ba_landmarks = Lm; lastMapping.ba_pairs = NP;
-        lastMapping.ba_wrong = nWrong; lastMapping.ba_outliers = nOut;
-        lastMapping.ba_report[0] = Rr.report[0]; lastMapping.ba_report[1] = Rr.report[1];
-        lastMapping.ba_residuals = (int)Rr.n_residuals; lastMapping.ba_free_kf = (int)Rr.n_free_kf; lastMapping.ba_sum_k2 = (int)Rr.sum_k2;
-        lastMapping.ba_trials = Rr.report[0].inner_iterations + Rr.report[1].inner_iterations;
+    return baSt;
+}
+
+// second-graph flags (:566-575) and the write-back (:875-938) on the map AS IT IS NOW (keyframes / observations the tracker
+// added since the collection count as "later" ones)
+vslam_status vslam_system::ba_commit(MapPass& p) {
+    BaJob& J = p.ba;
+    const std::vector<int>& kfs = J.kfs;
+    const std::vector<int>& allMps = J.allMps;
+    const int K = (int)kfs.size(), Lm = (int)allMps.size(), NP = (int)J.pk.size(), lastActKF = J.lastActKF;
+    const std::vector<uint8_t>& wrong = J.wrong;
+    const std::vector<uint8_t>& wrong1 = J.wrong1;
+    auto in_window = [&](int kf) { return kf < (int)J.kfIndex.size() && J.kfIndex[kf] >= 0; };
+    std::vector<int> nUsable(allMps.size(), 0);
+    for (int q = 0; q < NP; q++) if (J.pf[q] && !wrong1[q]) nUsable[J.pl[q]]++;
+    for (size_t m = 0; m < allMps.size(); m++) {
+        if (J.mpOut[m] || nUsable[m]) continue;
+        int later = 0;
+        for (const KfMatch& o : mapPoints[allMps[m]].kfm) if (keyFrames[o.kf].numb > lastActKF || !in_window(o.kf)) later++;
+        if (!later) J.mpOut[m] = 1;
     }
+    int nWrong = 0;
+    for (int q = 0; q < NP; q++) {
+        if (!wrong[q]) continue;
+        nWrong++;
+        SysKF& c = keyFrames[J.pobj[q].kf];
+        SysMP& mp = mapPoints[J.pobj[q].mp];
+        const int e = mp.find(J.pobj[q].kf);
+        if (e < 0) continue;
+        const int l = mp.kfm[e].l, r = mp.kfm[e].r;
+        if (l >= 0) { c.lmpL[l] = -1; c.unF[l] = -1; }              // KeyFrame::eraseMPConnection
+        if (r >= 0) { c.lmpR[r] = -1; c.unFR[r] = -1; }
+        mp.kfm.erase(mp.kfm.begin() + e);                            // MapPoint::eraseKFConnection
+    }
+    std::vector<uint8_t> presentKf(std::max(K, 1), 0), presentLm(std::max(Lm, 1), 0);
+    for (int q = 0; q < NP; q++) if (J.pf[q] && !wrong1[q]) { presentKf[J.pk[q]] = 1; presentLm[J.pl[q]] = 1; }
+    for (int i = 0; i < K; i++) if (J.kfLocal[i] && presentKf[i]) keyFrames[kfs[i]].setPose(m4_from(&J.kfOut[16 * (size_t)i]));
+    std::vector<int> upd;
+    int nOut = 0;
+    for (size_t m = 0; m < allMps.size(); m++) {
+        SysMP& mp = mapPoints[allMps[m]];
+        if (J.mpOut[m] || (!mp.inFrame && (int)mp.kfm.size() < 3)) { mp.isOutlier = true; nOut++; }
+        else if (presentLm[m]) { for (int c = 0; c < 3; c++) mp.wp[c] = J.lmOut[3 * m + c]; upd.push_back(allMps[m]); }
+    }
+    // MapPoint::updatePos (src/Map.cpp:212-234): depth / close refresh of every observing keyframe (k_ba_refresh_depth),
+    // then calcDescriptor
+    if (!upd.empty()) {
+        std::vector<int> rk, rl; std::vector<float> cur; std::vector<std::pair<int, int>> where;     // (kf numb, left idx)
+        std::vector<double> rpose; std::vector<int> kfSlot(keyFrames.size(), -1); std::vector<int> rkfs;
+        std::vector<double> rlm(upd.size() * 3);
+        for (size_t u = 0; u < upd.size(); u++) {
+            const SysMP& mp = mapPoints[upd[u]];
+            for (int c = 0; c < 3; c++) rlm[3 * u + c] = mp.wp[c];
+            for (const KfMatch& o : mp.kfm) {
+                if (o.l < 0) continue;                 // (the reference indexes estimatedDepth[-1] here; skipped)
+                if (kfSlot[o.kf] < 0) { kfSlot[o.kf] = (int)rkfs.size(); rkfs.push_back(o.kf); }
+                rk.push_back(kfSlot[o.kf]); rl.push_back((int)u); cur.push_back(keyFrames[o.kf].keys.depth[o.l]);
+                where.push_back({o.kf, o.l});
+            }
+        }
+        if (!rk.empty()) {
+            rpose.resize(rkfs.size() * 16);
+            for (size_t i = 0; i < rkfs.size(); i++) memcpy(&rpose[16 * i], keyFrames[rkfs[i]].pose.data(), 16 * sizeof(double));
+            std::vector<uint8_t> zeroW(rk.size(), 0), zeroO(upd.size(), 0), clo(rk.size()), up(rk.size());
+            std::vector<float> dep(rk.size());
+            VS_CHECK(vslam_ba_refresh_depth(&cfg.rig, (int)rkfs.size(), rpose.data(), (int)upd.size(), rlm.data(), zeroO.data(), (int)rk.size(),
+                                            rk.data(), rl.data(), zeroW.data(), cur.data(), cfg.device, dep.data(), clo.data(), up.data()));
+            for (size_t q = 0; q < rk.size(); q++) {
+                if (!up[q]) continue;
+                SysKeys& keys = keyFrames[where[q].first].keys;
+                keys.depth[where[q].second] = dep[q];
+                if (clo[q]) keys.close[where[q].second] = 1;
+            }
+        }
+        VS_CHECK(calc_descriptors(upd));
+    }
+    endLBAIdx = p.actKeyF[0];
+    keyFrameAdded = false;
+    LBADone = true;
+    const vslam_ba_result& Rr = J.R;
+    lastMapping = vslam_frame_report{};
+    lastMapping.new_points = p.newPoints;
+    lastMapping.ba_keyframes = K; lastMapping.ba_local = (int)J.local.size(); lastMapping.ba_landmarks = Lm; lastMapping.ba_pairs = NP;
+    lastMapping.ba_wrong = nWrong; lastMapping.ba_outliers = nOut;
+    lastMapping.ba_report[0] = Rr.report[0]; lastMapping.ba_report[1] = Rr.report[1];
+    lastMapping.ba_residuals = (int)Rr.n_residuals; lastMapping.ba_free_kf = (int)Rr.n_free_kf; lastMapping.ba_sum_k2 = (int)Rr.sum_k2;
+    lastMapping.ba_trials = Rr.report[0].inner_iterations + Rr.report[1].inner_iterations;
+    mappingReportFresh = true;
     return VSLAM_OK;
 }
 

@@ -112,6 +112,36 @@ struct SysProfScope {
 
 struct SysFrame { bool isKF; int kf; int prevKF; M4 refPose; };   // allFramesPoses entry (trajectory output)
 
+// One local-mapping pass (LocalMapper::beginLocalMapping's loop body, src/OptimizationBA.cpp:960-975) in flight.  The map is
+// read and written ONLY on the tracker's timeline (frame_begin / frame_post); what runs beside tracking is the device work
+// on these job-private buffers (keyframe key arrays are read in place: nothing writes them while a job is in flight).
+struct NpJob {                        // findNewPoints (:340-391): problem + result of vslam_find_new_points
+    std::vector<vslam_kf_view> views;
+    std::vector<uint8_t> has, mpd, acc;
+    std::vector<double> mpx, xyz;
+    std::vector<int> cL, cR, nObs, obs;
+    vslam_new_points_problem P{}; vslam_new_points_result R{};
+    int n0 = 0, nk = 0;
+};
+struct BaJob {                        // localBA (:426-940): window + graph of vslam_local_ba, its result
+    struct Pair { int kf, mp, l, r; };
+    std::vector<int> kfs, local, allMps, pk, pl, poct, kfIndex;
+    std::vector<uint8_t> mpOut, pf, kfFixed, kfLocal, wrong, wrong1;
+    std::vector<float> puv; std::vector<Pair> pobj;
+    std::vector<double> kfPose, lm, kfOut, lmOut;
+    std::vector<int64_t> kfId;
+    int lastActKF = 0;
+    vslam_ba_problem P{}; vslam_ba_result R{};
+};
+struct MapPass {
+    enum { IDLE = 0, NEW_POINTS = 1, LOCAL_BA = 2 };
+    int stage = IDLE;                 // which job is in flight / was last submitted
+    int handFrame = 0, commitFrame = 0;
+    int newPoints = 0;
+    std::vector<int> actKeyF;         // lastKF + its best covisible keyframes (KeyFrame::getConnectedKFs)
+    NpJob np; BaJob ba;
+};
+
 }  // namespace vslam_sys
 
 using namespace vslam_sys;
@@ -147,12 +177,15 @@ struct vslam_system {
     // pinned staging
     uint8_t* h_up = nullptr; size_t upCap = 0;
     uint8_t* h_dn = nullptr; size_t dnCap = 0;
-    // optimizer thread (local_mapping == 2)
+    // local mapping.  mapMutex: the map against the API's readers on other threads (counts / keyframes / save_trajectory);
+    // the mapping thread never touches the map.
     std::mutex mapMutex;
+    MapPass pass;
+    std::vector<int> lcaWhere;         // scratch of kf_update_pose: map-point index -> slot (entries reset after use)
+    // device work of the pass in flight (local_mapping == 2): the session's own thread, or the batch's mapping threads
     std::thread worker;
     std::mutex wMu; std::condition_variable wCv;
     bool stopRequested = false, mappingBusy = false;
-    int mappingSubmittedFrame = 0;     // frame whose post phase handed the running / queued pass to the optimizer thread
     vslam_status workerStatus = VSLAM_OK;
     char workerError[256] = "";
 
@@ -173,18 +206,25 @@ struct vslam_system {
                        double* T_wc_out, vslam_frame_report* rep);
     vslam_status fetch_keys(SysKeys& k);
     void mp_update(SysMP& mp, int kfNumb, std::vector<int>& needDesc, int mpIndex);
-    vslam_status calc_descriptors(const std::vector<int>& mps, std::unique_lock<std::mutex>* lk = nullptr);
+    vslam_status calc_descriptors(const std::vector<int>& mps);
     void backproject(const SysKeys& k, int i, const M4& pose, double* out) const;
     vslam_status initialize_map(const SysKeys& keys, int frame);
     vslam_status insert_keyframe(SysKeys& keys, const std::vector<int>& matchedL, const std::vector<int>& matches,
-                                 int nStereo, const M4& estimPose, const std::vector<uint8_t>& outl, const std::vector<int>& act, int frame,
-                                 std::unique_lock<std::mutex>* lk = nullptr);
+                                 int nStereo, const M4& estimPose, const std::vector<uint8_t>& outl, const std::vector<int>& act, int frame);
     void calc_connections(SysKF& kf);
     vslam_status change_poses_lca(int endIdx);
     vslam_status kf_update_pose(SysKF& kf, const M4& keyPose);
-    vslam_status local_mapping();
-    vslam_status find_new_points(const std::vector<int>& actKeyF, int& nNew);
-    vslam_status local_ba(const std::vector<int>& actKeyF);
+    // the pass, in the order of the schedule (vslam_hip.h, vslam_system_config::mapping_delay)
+    void mapping_window(std::vector<int>& actKeyF);
+    void np_collect(MapPass& p);
+    vslam_status np_commit(MapPass& p);
+    void ba_collect(MapPass& p);
+    vslam_status ba_device(MapPass& p);
+    vslam_status ba_commit(MapPass& p);
+    vslam_status submit_job(int stage);
+    vslam_status wait_job();
+    vslam_status mapping_begin(int frame);        // frame_begin's share
+    vslam_status mapping_post(int frame);         // frame_post's share
     void worker_loop();
 };
 

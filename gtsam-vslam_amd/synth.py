@@ -138,11 +138,26 @@ def stereo_frame(i, rig_name="euroc", scene_seed=7, tex_seed=0xC0FFEE, noise=Tru
     seconds on the host)."""
     key = (i, rig_name, scene_seed, tex_seed, noise)
     if key not in _FRAME_CACHE:
-        if len(_FRAME_CACHE) > 64:
+        if len(_FRAME_CACHE) > 96:
             _FRAME_CACHE.clear()
         _FRAME_CACHE[key] = _render_stereo_frame(i, rig_name, scene_seed, tex_seed, noise)
     L, R, T = _FRAME_CACHE[key]
     return L.copy(), R.copy(), T.copy()
+
+
+def prerender(frames, rig_name="euroc", workers=0):
+    """Render several frames into the cache on `workers` threads (numpy releases the GIL in the heavy parts)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    todo = [i for i in frames if (i, rig_name, 7, 0xC0FFEE, True) not in _FRAME_CACHE]
+    if not todo:
+        return
+    texture(0xC0FFEE)                       # (built once, before the threads race for it)
+    n = workers if workers > 0 else min(len(todo), max(1, (os.cpu_count() or 2) - 1), 16)
+    with ThreadPoolExecutor(n) as pool:
+        res = list(pool.map(lambda i: _render_stereo_frame(i, rig_name, 7, 0xC0FFEE, True), todo))
+    for i, r in zip(todo, res):
+        _FRAME_CACHE[(i, rig_name, 7, 0xC0FFEE, True)] = r
 
 
 def _render_stereo_frame(i, rig_name, scene_seed, tex_seed, noise):
@@ -431,3 +446,111 @@ def make_kf_update_problem(rig_name="euroc", n_left=1500, n_right=1400, n_lm=250
     sr, xr, yr, orr = side(n_right, True)
     return dict(rig=rig, numb=7, key_pose=key_new, ref_pose=ref, cur_pose_inv=np.linalg.inv(cur), slotL=sl, slotR=sr,
                 kL=(xl, yl, ol), kR=(xr, yr, orr), lm=lm, kdx=kdx, outlier=outlier, cur=cur)
+
+
+# ---- bench workload: a long corridor, rendered on the GPU ----------------------------------------------------------------
+# The parity tests use the small scene above (numpy renderer, identical on every host).  The benchmark needs hundreds of
+# DISTINCT poses (a session must not revisit the places its map already covers), which the small scene cannot hold and the
+# numpy renderer cannot produce in a bench's set-up time: the same plane model, extended along z, rendered by the same
+# arithmetic on torch tensors.  Bench data generation only - nothing of the product or of the parity tests goes through it.
+
+def make_corridor(seed=11, length=48.0, boxes_per_m=2.2):
+    """Planes of a corridor along +z: floor, ceiling, two side walls, end wall, textured boxes every ~0.45 m of depth."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    L2 = length + 20.0
+    planes = [(np.array([0, 0, L2]), np.array([1.0, 0, 0]), np.array([0, 1.0, 0]), 30, 30, (100, 100), 14.0),
+              (np.array([0, 1.6, L2 / 2]), np.array([1.0, 0, 0]), np.array([0, 0.0, 1.0]), 30, L2, (900, 300), 150.0),
+              (np.array([0, -2.6, L2 / 2]), np.array([1.0, 0, 0]), np.array([0, 0.0, 1.0]), 30, L2, (500, 1500), 130.0),
+              (np.array([-6.0, 0, L2 / 2]), np.array([0, 0, 1.0]), np.array([0, 1.0, 0]), L2, 30, (300, 1200), 140.0),
+              (np.array([6.0, 0, L2 / 2]), np.array([0, 0, 1.0]), np.array([0, 1.0, 0]), L2, 30, (1300, 800), 140.0)]
+    for _ in range(int(length * boxes_per_m)):
+        z = rng.uniform(1.8, length)
+        c = np.array([rng.uniform(-4.5, 4.5), rng.uniform(-1.6, 1.3), z])
+        yaw = rng.uniform(-0.5, 0.5)
+        ex = np.array([np.cos(yaw), 0, np.sin(yaw)])
+        planes.append((c, ex, np.array([0, 1.0, 0]), rng.uniform(0.25, 0.8), rng.uniform(0.25, 0.8),
+                       (int(rng.integers(0, 1500)), int(rng.integers(0, 1500))), rng.uniform(250, 450)))
+    return planes
+
+
+def corridor_pose(i, fps=20.0, speed=0.5):
+    """world <- left camera at frame i: `speed` m/s along the corridor, yaw sweeping at up to ~20 deg/s, small pitch / roll and
+    lateral motion (smooth 6-DoF, 0.5 m/s, <= 20 deg/s)."""
+    s = i / fps
+    yaw = 0.70 * np.sin(0.5 * s)
+    pitch = 0.05 * np.sin(0.45 * s + 0.3)
+    roll = 0.04 * np.sin(0.6 * s + 1.0)
+    cy_, sy_ = np.cos(yaw), np.sin(yaw)
+    cp, sp = np.cos(pitch), np.sin(pitch)
+    cr, sr = np.cos(roll), np.sin(roll)
+    Ry = np.array([[cy_, 0, sy_], [0, 1, 0], [-sy_, 0, cy_]])
+    Rx = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
+    Rz = np.array([[cr, -sr, 0], [sr, cr, 0], [0, 0, 1]])
+    T = np.eye(4)
+    T[:3, :3] = Ry @ Rx @ Rz
+    T[:3, 3] = [0.6 * np.sin(0.35 * s), 0.08 * np.sin(0.9 * s), speed * s + 0.10 * np.sin(0.4 * s)]
+    return T
+
+
+def render_torch(planes, tex_t, rig, T_wc, device, noise_seed=None, noise_sigma=2.0):
+    """render() on torch tensors (float64 geometry, float32 texture taps), one u8 [h, w] image on `device`."""
+    import torch
+    w, h = rig["w"], rig["h"]
+    fx, fy, cx, cy = rig["fx"], rig["fy"], rig["cx"], rig["cy"]
+    f64 = torch.float64
+    v, u = torch.meshgrid(torch.arange(h, dtype=f64, device=device), torch.arange(w, dtype=f64, device=device), indexing="ij")
+    R = torch.as_tensor(T_wc[:3, :3], dtype=f64, device=device)
+    t = torch.as_tensor(T_wc[:3, 3], dtype=f64, device=device)
+    d_c = torch.stack([(u - cx) / fx, (v - cy) / fy, torch.ones_like(u)], -1)
+    d_w = d_c @ R.T
+    best = torch.full((h, w), float("inf"), dtype=f64, device=device)
+    out = torch.zeros((h, w), dtype=torch.float32, device=device)
+    ts = tex_t.shape[0]
+    tz = float(T_wc[2, 3])
+    for (o, ex, ey, hw, hh, toff, tsc) in planes:
+        if len(planes) > 40 and hw < 5 and not (tz - 1.0 < o[2] < tz + 30.0):      # boxes behind the camera or far down the corridor
+            continue
+        n = np.cross(ex, ey)
+        n_t = torch.as_tensor(n, dtype=f64, device=device)
+        o_t = torch.as_tensor(o, dtype=f64, device=device)
+        lam = float((o - T_wc[:3, 3]) @ n) / (d_w @ n_t)
+        p = t + lam[..., None] * d_w - o_t
+        a = p @ torch.as_tensor(ex, dtype=f64, device=device)
+        b = p @ torch.as_tensor(ey, dtype=f64, device=device)
+        hit = (lam > 0.05) & (a.abs() <= hw) & (b.abs() <= hh) & (lam < best) & torch.isfinite(lam)
+        if not bool(hit.any()):
+            continue
+        tu = torch.remainder(toff[0] + (a + hw) * tsc, ts - 1)
+        tv = torch.remainder(toff[1] + (b + hh) * tsc, ts - 1)
+        tu = torch.where(hit, tu, torch.zeros_like(tu)); tv = torch.where(hit, tv, torch.zeros_like(tv))
+        x0 = tu.floor().long(); y0 = tv.floor().long()
+        fxr = (tu - x0).float(); fyr = (tv - y0).float()
+        x1 = torch.clamp(x0 + 1, max=ts - 1); y1 = torch.clamp(y0 + 1, max=ts - 1)
+        val = (tex_t[y0, x0] * (1 - fxr) * (1 - fyr) + tex_t[y0, x1] * fxr * (1 - fyr)
+               + tex_t[y1, x0] * (1 - fxr) * fyr + tex_t[y1, x1] * fxr * fyr)
+        out = torch.where(hit, val, out)
+        best = torch.where(hit, lam, best)
+    if noise_seed is not None and noise_sigma > 0:
+        g = torch.Generator(device=device)
+        g.manual_seed(int(noise_seed))
+        out = out + torch.randn(out.shape, generator=g, device=device, dtype=torch.float32) * noise_sigma
+    return torch.clamp(torch.round(out), 0, 255).to(torch.uint8)
+
+
+def corridor_sequence(rig_name, n_frames, device, frame_step=1, speed=0.5, first=0, scene_seed=11, tex_seed=0xC0FFEE):
+    """n_frames stereo pairs along the corridor on `device`: (left [n, h, w] u8, right [n, h, w] u8, poses [n, 4, 4], frame indices)."""
+    import torch
+    rig = RIGS[rig_name]
+    planes = make_corridor(scene_seed)
+    tex_t = torch.from_numpy(texture(tex_seed).astype(np.float32)).to(device)
+    ext = np.eye(4); ext[0, 3] = rig["bl"]
+    idx = [first + frame_step * j for j in range(n_frames)]
+    Ls = torch.empty((n_frames, rig["h"], rig["w"]), dtype=torch.uint8, device=device)
+    Rs = torch.empty_like(Ls)
+    poses = np.zeros((n_frames, 4, 4))
+    for j, i in enumerate(idx):
+        T = corridor_pose(i, rig["fps"], speed)
+        poses[j] = T
+        Ls[j] = render_torch(planes, tex_t, rig, T, device, noise_seed=1000 + 2 * i)
+        Rs[j] = render_torch(planes, tex_t, rig, T @ ext, device, noise_seed=1001 + 2 * i)
+    return Ls, Rs, poses, idx

@@ -545,9 +545,16 @@ vslam_status vslam_tracker_fetch(vslam_matcher* m, int32_t* matches, uint8_t* mp
  *                                addFrame, updatePoses, setActiveOutliers;
  *   the optimizer thread       = LocalMapper::beginLocalMapping (include/OptimizationBA.h:54-87, src/OptimizationBA.cpp:
  *                                955-982): getConnectedKFs window, findNewPoints, localBA on THAT window, write-back,
- *                                LBADone hand-over.  local_mapping = 2 runs it on its own host thread like the reference
- *                                (results arrive whenever it finishes); 1 runs it to completion right after the frame that
- *                                inserted the keyframe (reproducible runs); 0 disables it.
+ *                                LBADone hand-over.  local_mapping = 1 runs a pass to completion right after the frame
+ *                                that inserted the keyframe; local_mapping = 2 runs its device work on a library thread
+ *                                beside tracking, on ONE FIXED interleaving of the reference's two threads
+ *                                (mapping_delay = k): for a pass handed over after frame f, findNewPoints has written
+ *                                its points before frame f + 1 is tracked, localBA collects its window at that moment,
+ *                                and its write-back + LBADone land at the beginning of frame f + k (TrackImage :1115-1122
+ *                                then runs changePosesLCA).  Frames f + 1 .. f + k - 1 track against the map with the new
+ *                                points but without the BA's result, as the reference's tracker does while the optimizer
+ *                                thread is inside LevenbergMarquardt.  Runs are reproducible and equal the test-side
+ *                                restatement of the same schedule frame by frame; 0 disables local mapping.
  * Map / KeyFrame / MapPoint live inside the handle (index-based records); every numerical stage is a kernel of this
  * library.  Images: u8, `stride` bytes per row, host pointers (on_device = 0) or device pointers (1).
  * ------------------------------------------------------------------------- */
@@ -558,7 +565,7 @@ typedef struct vslam_system_config {
     vslam_rig rig;
     int32_t device;
     int32_t use_imu;              /* 0: slamMode 1 (stereo), 1: slamMode 0 (stereo + IMU: the IMU branch of estimatePoseGTSAM) */
-    int32_t local_mapping;        /* 0 off, 1 synchronous, 2 own thread */
+    int32_t local_mapping;        /* 0 off, 1 synchronous, 2 library thread, fixed schedule (mapping_delay) */
     int32_t window;               /* actvKFMaxSize (include/OptimizationBA.h:46); 0 = 10, at most 16 */
     double T_wc_init[16];         /* zedPtr->mCameraPose at start, row-major; all zero = identity (the reference) */
     /* IMU constants (Camera::mIMUGravity, IMUData noise terms, Camera::TBodyToCam, IMUData::mHz) */
@@ -567,11 +574,10 @@ typedef struct vslam_system_config {
     double T_body_sensor[16];
     int32_t imu_hz;
     double velocity_init[3];      /* Camera::mVelocity at start (zero in the reference) */
-    int32_t mapping_max_lag;      /* local_mapping = 2 only.  0: the tracker never waits for the optimizer thread (the reference's
-                                     threads; at the reference's camera rate a pass ends within a frame or two, at thousands of
-                                     frames per second it would fall ever further behind and most keyframes would never be
-                                     optimised).  d > 0: a frame waits for a pass that was started d or more frames ago - the
-                                     optimizer thread of a system whose local mapping takes at most d frame times. */
+    int32_t mapping_delay;        /* local_mapping = 2 only: k of the schedule above (0 = 1).  The tracker waits at frame f + 1 for
+                                     the new-point search and at frame f + k for the local BA if they have not finished; a pass
+                                     that finishes early is held back until then.  At the reference's camera rate a pass ends
+                                     within a frame or two, i.e. k = 1..2. */
 } vslam_system_config;
 
 /* the IMU samples between the previous frame and this one (IMUData filled in src/VIOSlam.cpp:238-272) */
@@ -599,7 +605,8 @@ void vslam_system_destroy(vslam_system* sys);
 vslam_status vslam_system_track_stereo(vslam_system* sys, const uint8_t* left, const uint8_t* right, int32_t stride,
                                        int32_t on_device, int32_t frame_number, const vslam_imu_bucket* imu,
                                        double* T_wc_out, vslam_frame_report* report);
-/* blocks until the optimizer thread (local_mapping = 2) is idle; reports its failure, if any */
+/* blocks until the device work of the pass in flight (local_mapping = 2) has finished; reports its failure, if any.
+ * (Its results are still applied at the frames the schedule names.) */
 vslam_status vslam_system_wait_mapping(vslam_system* sys);
 /* VSlamSystem::saveTrajectoryAndPosition (src/System.cpp:87-124) over the frames tracked so far */
 vslam_status vslam_system_save_trajectory(vslam_system* sys, const char* path_trajectory, const char* path_positions);

@@ -14,10 +14,19 @@ Follows, function by function:
   LocalMapper::findNewPoints / addMultiViewMapPointsR / addNewMapPoints   :90-125, 211-232, 340-391
   LocalMapper::localBA window collection :438-516, graph membership :556-745, write-back :875-938
 
-Scheduling: the reference's optimizer thread runs concurrently with tracking and hands its result over through
-map->LBADone whenever it happens to finish; here local mapping runs to completion right after the frame that inserted
-the keyframe (what the reference does whenever a local BA takes less than one frame interval), which makes a run
-reproducible.
+Scheduling: the reference's optimizer thread (src/System.cpp:18-19, src/OptimizationBA.cpp:955-982) runs concurrently with
+tracking and hands its result over through map->LBADone (src/FeatureTracker.cpp:1115-1122) whenever it happens to finish.
+Two reproducible schedules of that hand-over are restated here:
+  mapping_delay = 0   the whole pass runs to completion right after the frame that inserted the keyframe (what the
+                      reference does whenever a pass takes less than one frame interval);
+  mapping_delay = k   (k >= 1) one fixed interleaving of the two threads: for a pass handed over after frame f
+                      (keyFrameAdded seen by the optimizer loop :960), findNewPoints reads and writes the map before frame
+                      f + 1 is tracked (addNewMapPoints under the mutex :211-232), localBA collects its window and graph at
+                      the same moment (:438-745), and its write-back (:875-938: poses, points, wrong matches, LBADone)
+                      lands at the beginning of frame f + k, where TrackImage sees LBADone and runs changePosesLCA.  Frames
+                      f + 1 .. f + k - 1 are tracked against the map with the new points but without the BA's result -
+                      exactly what the tracking thread sees while the optimizer thread is still inside LevenbergMarquardt.
+                      The pass is reported with frame f + k.
 
 Where the reference iterates an unordered_map keyed by pointers (kFMatches, allMapPoints, localKFs; ties of
 calcConnections' sort on (weight, KeyFrame*)) the order is pointer-hash dependent and not reproducible even between two
@@ -93,7 +102,7 @@ class KeyFrame:
 class System:
     """FeatureTracker + LocalMapper + Map of one stereo (or stereo + IMU) session."""
 
-    def __init__(self, rig, nfeat, T0=None, imu=None, window=10, local_mapping=True):
+    def __init__(self, rig, nfeat, T0=None, imu=None, window=10, local_mapping=True, mapping_delay=0, threads=False):
         self.rig = rig
         self.exL, self.exR = po.Extractor(nfeat), po.Extractor(nfeat)
         self.scale = self.exL.scalePyramid; self.sigma = self.exL.sigmaFactor; self.invSigma = self.exL.InvSigmaFactor
@@ -112,6 +121,14 @@ class System:
         self.active = []                   # map->activeMapPoints
         self.keyFrameAdded = False; self.LBADone = False; self.endLBAIdx = 0
         self.window = window; self.local_mapping_enabled = local_mapping
+        self.mapping_delay = int(mapping_delay); self.pending = None; self._mapping_report = None
+        # threads = True: the reference's threading (src/FeatureTracker.cpp:58-61 left || right extraction threads,
+        # src/System.cpp:18-19 optimizer thread: the local BA's numerical core runs beside tracking until its write-back is
+        # due; needs mapping_delay >= 1).  Same results as threads = False; used by bench.py's CPU baseline only.
+        self.threads = bool(threads); self._pool = None
+        if self.threads:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(3)
         self.mpIdx = None                  # LocalMapper's static mpIdx (seeded from map->pIdx on first use, :93)
         # IMU mode (slamMode 0): imu = dict(prm, gravity, ...) ; velocity / bias state of the camera
         self.imu = imu
@@ -155,7 +172,12 @@ class System:
 
     # ---- frame front end ------------------------------------------------------------------------------------
     def _frontend(self, L, R):                # extractORBAndStereoMatch (:56-70)
-        kL, dL = self.exL.extract(L); kR, dR = self.exR.extract(R)
+        if self._pool is not None:
+            fr = self._pool.submit(self.exR.extract, R)
+            kL, dL = self.exL.extract(L)
+            kR, dR = fr.result()
+        else:
+            kL, dL = self.exL.extract(L); kR, dR = self.exR.extract(R)
         st = po.stereo_match(self.exL, self.exR, self.rig, kL, dL, kR, dR)
         return dict(kpsL=kL, descL=dL, kpsR=kR, descR=dR, rightIdxs=st["rightIdxs"], leftIdxs=st["leftIdxs"],
                     depth=st["depth"], close=st["close"])
@@ -198,6 +220,10 @@ class System:
     # ---- TrackImage --------------------------------------------------------------------------------------------
     def track(self, L, R, frame_number, imu_bucket=None):
         rig = self.rig
+        if self.pending is not None and frame_number >= self.pending["commit"]:
+            # the optimizer thread's write-back (:875-938) lands here; LBADone is then seen by this very frame
+            self._mapping_report = self.local_ba_writeback(self.pending["ctx"])
+            self.pending = None
         if self.LBADone:                      # :1115-1122
             self.change_poses_lca(self.endLBAIdx)
             self.LBADone = False
@@ -331,8 +357,10 @@ class System:
             self.velocity = r["vel"].copy()       # mVelocity = mNewVelocity (:1277)
         self.log.append(dict(frame=frame_number, pose=poseEst.copy(), keyframe=bool(isKF), nIn=int(nInF), nStereo=int(nStereo),
                              nActive=M, rounds=rounds, matches=mt.copy(), outliers=outl.copy()))
-        if self.local_mapping_enabled and self.keyFrameAdded and not self.LBADone:
-            self.local_mapping()
+        if self._mapping_report is not None:
+            self.log[-1]["mapping"] = self._mapping_report; self._mapping_report = None
+        if self.local_mapping_enabled and self.keyFrameAdded and not self.LBADone and self.pending is None:
+            self.local_mapping(frame_number)
         return poseEst
 
     def insert_keyframe(self, keys, matchedIdxsL, matchesIdxs, nStereo, estimPose, MPsOutliers, act, frameIdx):   # :743-842
@@ -434,7 +462,7 @@ class System:
         kf.changePose(keyPose)
 
     # ---- LocalMapper --------------------------------------------------------------------------------------------
-    def local_mapping(self):                  # one pass of beginLocalMapping's loop body (:960-975)
+    def local_mapping(self, frame_number=0):  # one pass of beginLocalMapping's loop body (:960-975)
         lastKF = self.keyFrames[-1]
         actKeyF = [lastKF]
         count = 1
@@ -444,9 +472,12 @@ class System:
             if count >= self.window:
                 break
         nNew = self.find_new_points(actKeyF)
-        rep = self.local_ba(actKeyF)
-        rep["new_points"] = nNew; rep["window"] = [k.numb for k in actKeyF]
-        self.log[-1]["mapping"] = rep
+        ctx = self.local_ba_solve(actKeyF)
+        ctx["new_points"] = nNew
+        if self.mapping_delay <= 0:
+            self.log[-1]["mapping"] = self.local_ba_writeback(ctx)
+        else:
+            self.pending = dict(commit=frame_number + self.mapping_delay, ctx=ctx)
 
     def find_new_points(self, actKeyF):       # :340-391
         lastKF = actKeyF[0]
@@ -490,6 +521,9 @@ class System:
         return len(new)
 
     def local_ba(self, actKeyF):              # localBA (:426-940) around the numerical core (po.local_ba)
+        return self.local_ba_writeback(self.local_ba_solve(actKeyF))
+
+    def local_ba_solve(self, actKeyF):        # window collection (:438-516), graph (:556-745), both LM passes + chi2 (po.local_ba)
         lastActKF = actKeyF[0].numb
         local = list(actKeyF)
         localSet = set(local)
@@ -554,7 +588,18 @@ class System:
                     pair_uv=np.array(puv, np.float32).reshape(-1, 4), pair_oct=np.array(poct, np.int32).reshape(-1, 2))
         for m in np.nonzero(mpOut)[0]:        # landmarks flagged at graph build contribute no factor
             prob["pair_flags"][prob["pair_lm"] == m] = 0
-        res = po.local_ba(self.rig, self.sigma, self.invSigma, prob)
+        if self._pool is not None and self.mapping_delay >= 1:
+            res = self._pool.submit(po.local_ba, self.rig, self.sigma, self.invSigma, prob)      # joined by the write-back
+        else:
+            res = po.local_ba(self.rig, self.sigma, self.invSigma, prob)
+        return dict(actKeyF=actKeyF, lastActKF=lastActKF, local=local, localSet=localSet, kfs=kfs, kfIndex=kfIndex, allMps=allMps,
+                    mpOut=mpOut, pk=pk, pl=pl, pobj=pobj, prob=prob, res=res, new_points=0)
+
+    def local_ba_writeback(self, ctx):        # second-graph flags (:566-575) + write-back (:875-938) on the map as it is NOW
+        actKeyF, lastActKF, local, localSet, kfs, kfIndex = (ctx[k] for k in ("actKeyF", "lastActKF", "local", "localSet", "kfs", "kfIndex"))
+        allMps, mpOut, pk, pl, pobj, prob, res = (ctx[k] for k in ("allMps", "mpOut", "pk", "pl", "pobj", "prob", "res"))
+        if hasattr(res, "result"):
+            res = res.result()
         # second graph build (:566-575): a landmark all of whose keyframe observations were rejected after pass 1 is flagged
         w1 = res["pair_wrong1"]
         nUsable = np.zeros(len(allMps), np.int32); nLater = np.zeros(len(allMps), np.int32)
@@ -582,9 +627,10 @@ class System:
             if k in localSet and present_kf[i]:
                 k.setPose(res["kf_pose"][i])
         upd = []
+        nOutlier = 0
         for m, mp in enumerate(allMps):
             if mpOut[m] or (not mp.inFrame and len(mp.kFMatches) < 3):
-                mp.isOutlier = True
+                mp.isOutlier = True; nOutlier += 1
             elif present_lm[m]:
                 mp.wp = res["lm"][m].copy()
                 upd.append(mp)
@@ -603,5 +649,5 @@ class System:
         self.keyFrameAdded = False
         self.LBADone = True
         return dict(reports=res["reports"], n_kf=len(kfs), n_local=len(local), n_lm=len(allMps), n_pairs=len(pk),
-                    n_wrong=int(wrong.sum()), n_outlier=int(mpOut.sum()), kf_numbs=[k.numb for k in kfs],
-                    kf_pose=res["kf_pose"].copy())
+                    n_wrong=int(wrong.sum()), n_outlier=nOutlier, kf_numbs=[k.numb for k in kfs],
+                    kf_pose=res["kf_pose"].copy(), new_points=ctx["new_points"], window=[k.numb for k in actKeyF])

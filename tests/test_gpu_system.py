@@ -16,17 +16,20 @@ def _imu_setup(oracle):
     return dict(prm=prm), dict(gravity=G, noise=NOISE, T_bs=synth.T_BC1, hz=200)
 
 
-def _run(oracle, capi, rig_name, nfeat, frames, use_imu=False, local_mapping=True):
+def _run(oracle, capi, rig_name, nfeat, frames, use_imu=False, local_mapping=True, delay=0):
+    """delay = 0: the pass inside the frame (local_mapping = 1); delay = k >= 1: the fixed two-thread schedule
+    (local_mapping = 2, mapping_delay = k) on both sides"""
     import vo_system
     rig = synth.RIGS[rig_name]
+    synth.prerender(frames, rig_name)
     T0 = synth.pose_at(frames[0], rig["fps"])
     oimu, gimu = _imu_setup(oracle) if use_imu else (None, None)
     if use_imu:                              # start with the true velocity (the reference starts from a standstill)
         h = 1e-4
         v0 = (synth.pose_at(frames[0] + h * rig["fps"], rig["fps"])[:3, 3] - synth.pose_at(frames[0] - h * rig["fps"], rig["fps"])[:3, 3]) / (2 * h)
         gimu["velocity"] = v0
-    ref = vo_system.System(rig, nfeat, T0=T0, imu=oimu, local_mapping=local_mapping)
-    got = capi.System(rig, nfeat, T0=T0, imu=gimu, local_mapping=1 if local_mapping else 0)
+    ref = vo_system.System(rig, nfeat, T0=T0, imu=oimu, local_mapping=local_mapping, mapping_delay=delay)
+    got = capi.System(rig, nfeat, T0=T0, imu=gimu, local_mapping=(2 if delay else 1) if local_mapping else 0, mapping_delay=delay)
     if use_imu:
         ref.velocity = v0.copy()
     out = []
@@ -92,6 +95,52 @@ def test_closed_loop_parity_stereo_imu(oracle, capi):
     ref, got, out = _run(oracle, capi, "euroc", 1500, frames, use_imu=True)
     _check(ref, got, out, pose_tol=1e-6)
     assert np.abs(out[-1][3] - out[-1][1]).max() < 0.02
+
+
+def test_closed_loop_parity_async_stereo(oracle, capi):
+    """The mode bench.py times: the optimizer's device work beside tracking on the fixed schedule mapping_delay = 4 (new points
+    one frame after the hand-over, the BA's write-back + changePosesLCA four frames after it) - frame by frame against the
+    oracle's restatement of the same schedule."""
+    frames = list(range(0, 76, 2))
+    ref, got, out = _run(oracle, capi, "euroc", 1500, frames, delay=4)
+    nBA = _check(ref, got, out)
+    assert nBA >= 2 and len(ref.keyFrames) >= 5
+    # the hand-over really is late: no pass is reported by the frame that inserted its keyframe
+    for (f, T, Pr, Pg, lg, rep, last) in out:
+        assert not (lg["keyframe"] and "mapping" in lg)
+
+
+def test_closed_loop_parity_async_stereo_imu(oracle, capi):
+    """C2 in the timed mode: IMU factor in every pose solve + mapping_delay = 4."""
+    frames = list(range(0, 60, 2))
+    ref, got, out = _run(oracle, capi, "euroc", 1500, frames, use_imu=True, delay=4)
+    nBA = _check(ref, got, out, pose_tol=1e-6)
+    assert nBA >= 1
+
+
+def test_closed_loop_parity_async_delay1(oracle, capi):
+    """mapping_delay = 1: new points and the BA's result both arrive with the next frame."""
+    frames = list(range(0, 50, 2))
+    ref, got, out = _run(oracle, capi, "euroc", 1500, frames, delay=1)
+    assert _check(ref, got, out) >= 1
+
+
+def test_closed_loop_parity_kitti(oracle, capi):
+    """C3 rig (1241x376, 2000 features, 64x20 grid) as a closed loop, mapping_delay = 2 (bench.py's setting for C3); every
+    third source frame: the synthetic scene is small in units of this rig's baseline."""
+    frames = list(range(0, 120, 3))
+    ref, got, out = _run(oracle, capi, "kitti", 2000, frames, delay=2)
+    nBA = _check(ref, got, out)
+    assert nBA >= 1 and len(ref.keyFrames) >= 4
+    assert all(o[4]["nIn"] >= 50 for o in out[1:])          # no lost frame
+
+
+def test_closed_loop_parity_synthetic_1920(oracle, capi):
+    """C5 rig (1920x1200, 4000 features) as a closed loop with mapping_delay = 2."""
+    frames = list(range(0, 130, 5))
+    ref, got, out = _run(oracle, capi, "synthetic", 4000, frames, delay=2)
+    nBA = _check(ref, got, out)
+    assert nBA >= 1 and len(ref.keyFrames) >= 4
 
 
 def test_local_mapping_does_not_hurt_accuracy(capi):

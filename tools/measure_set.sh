@@ -16,9 +16,9 @@ python3 bench.py --host-images --no-cpu-baseline --no-latency-line > $OUT/${TAG}
 echo "host-images bench done"
 python3 bench.py --no-cpu-baseline --no-latency-line --steps 100 --sweep 1x0,1x1,4x4,16x16,32x32,64x64,128x64,192x64,192x96,256x128 > $OUT/${TAG}_c2_sweep.json 2> $OUT/sw.err || exit 1
 echo "sweep done"
-# what the bounded mapper lag costs: unbounded (0) and a looser bound (8 frames)
-python3 bench.py --no-cpu-baseline --no-latency-line --mapping-max-lag 0 > $OUT/${TAG}_c2_bench_lag0.json 2> $OUT/lag0.err || exit 1
-python3 bench.py --no-cpu-baseline --no-latency-line --mapping-max-lag 8 > $OUT/${TAG}_c2_bench_lag8.json 2> $OUT/lag8.err || exit 1
+# what the hand-over delay costs: 2 and 8 frames instead of 4
+python3 bench.py --no-cpu-baseline --no-latency-line --mapping-delay 2 > $OUT/${TAG}_c2_bench_delay2.json 2> $OUT/delay2.err || exit 1
+python3 bench.py --no-cpu-baseline --no-latency-line --mapping-delay 8 > $OUT/${TAG}_c2_bench_delay8.json 2> $OUT/delay8.err || exit 1
 echo "lag variants done"
 python3 tools/extract_rate.py 128 20 > $OUT/${TAG}_extract_rate.txt 2> $OUT/er.err || exit 1
 echo "extract rate done"
