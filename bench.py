@@ -9,9 +9,12 @@ A "step" = one stereo frame of every session: S independent SLAM sessions (seque
 host thread INSIDE the library (vslam_fleet; Python only starts the run and waits).  Every session runs the CLOSED LOOP
 (vslam_system): extraction L+R, stereo match, tracking against ITS OWN map (removeOutOfFrameMPs, {projection match, pose
 solve} rounds, refinement), the keyframe rule, insertKeyFrame, and - on the optimizer thread - covisibility window,
-findNewPoints, local BA on the tracker's window, write-back; nothing is re-seeded from ground truth.  The frames of a short
-rendered sequence are resident in HBM before the timed region (or, with --host-images, in pinned host memory: then every
-frame's host-to-device copy is inside its step) and replayed as a ping-pong, i.e. a continuous camera motion.
+findNewPoints, local BA on the tracker's window, write-back; nothing is re-seeded from ground truth.  The frames are resident
+in HBM before the timed region (or, with --host-images, in pinned host memory: then every frame's host-to-device copy is
+inside its step).  Default scene: a long corridor (synth.corridor_sequence, rendered on the GPU as part of the set-up):
+every session walks forward through DISTINCT poses and never turns around inside a run, so its map, keyframe rate and BA
+windows are those of a camera that keeps exploring (--scene room: the small test scene replayed as a ping-pong, round 2's
+workload).
 
   --config c1|c2|c3   C1 EuRoC stereo, C2 EuRoC stereo + IMU (the headline, default), C3 KITTI-like 1241x376 / 2000 features
   --config c5         the 64-keyframe / 100 000-landmark global BA, landmarks sharded over the N ranks (RCCL all-reduce of the
@@ -47,7 +50,8 @@ CONFIGS = {
                                                        "200 Hz IMU pre-integration factor in every pose solve"),
     "c3": dict(rig="kitti", nfeat=2000, imu=False, name="C3-class: KITTI-00-like stereo 1241x376, 2000 features/image"),
 }
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_i_pmc_summary.json")
+# PMC passes of the default command's launch shape (tools/measure_set.sh); "_meta" names the shape they were taken on
+PMC_FILE = os.path.join(ROOT, "profiles", os.environ.get("VSLAM_BENCH_PMC", "r03_a_pmc_summary.json"))
 
 
 def level_pixels(w, h, nlevels=8, scale=1.2):
@@ -77,7 +81,8 @@ def render_frames(idx, rig_name):
 
 
 def make_sequence(cfg, n_frames, step, rank):
-    """n_frames rendered stereo pairs `step` source frames apart, ground truth, velocities, IMU buckets of both directions."""
+    """--scene room: n_frames rendered stereo pairs `step` source frames apart (numpy renderer), ground truth, velocities, IMU
+    buckets of both directions."""
     import synth
     rig = synth.RIGS[cfg["rig"]]
     fps = rig["fps"]
@@ -85,23 +90,45 @@ def make_sequence(cfg, n_frames, step, rank):
     idx = [f0 + step * j for j in range(n_frames)]
     frames = render_frames(idx, cfg["rig"])
     poses = np.stack([fr[2] for fr in frames])
-    h = 1e-4
-    vel = np.stack([(synth.pose_at(f + h * fps, fps)[:3, 3] - synth.pose_at(f - h * fps, fps)[:3, 3]) / (2 * h) for f in idx])
-    fwd, bwd = [None] * n_frames, [None] * n_frames
-    if cfg["imu"]:
-        for j in range(1, n_frames):
-            S, dts, _ = synth.imu_samples(idx[j - 1], idx[j], fps, noise_seed=0x1A00 + idx[j])
-            fwd[j] = (S[:, :3].copy(), S[:, 3:].copy(), np.arange(len(dts)) * 5e6)
-        for j in range(n_frames - 1):
-            a = idx[j + 1]
-            S, dts, _ = synth.imu_samples(a, a + step, fps, noise_seed=0x2B00 + idx[j], pose_fn=lambda f, fp, a=a: synth.pose_at(2 * a - f, fp))
-            bwd[j] = (S[:, :3].copy(), S[:, 3:].copy(), np.arange(len(dts)) * 5e6)
+    vel, fwd, bwd = motion_data(cfg, idx, step, synth.pose_at)
     return rig, frames, poses, vel, fwd, bwd
 
 
-def cpu_baseline(cfg, frames, poses, vel, fwd, budget_s=20.0, warm=3):
+def motion_data(cfg, idx, step, pose_fn):
+    """velocities and the IMU buckets of both directions for the frames `idx` of the trajectory pose_fn(frame, fps)"""
+    import synth
+    rig = synth.RIGS[cfg["rig"]]
+    fps = rig["fps"]
+    n_frames = len(idx)
+    h = 1e-4
+    vel = np.stack([(pose_fn(f + h * fps, fps)[:3, 3] - pose_fn(f - h * fps, fps)[:3, 3]) / (2 * h) for f in idx])
+    fwd, bwd = [None] * n_frames, [None] * n_frames
+    if cfg["imu"]:
+        for j in range(1, n_frames):
+            S, dts, _ = synth.imu_samples(idx[j - 1], idx[j], fps, noise_seed=0x1A00 + idx[j], pose_fn=pose_fn)
+            fwd[j] = (S[:, :3].copy(), S[:, 3:].copy(), np.arange(len(dts)) * 5e6)
+        for j in range(n_frames - 1):
+            a = idx[j + 1]
+            S, dts, _ = synth.imu_samples(a, a + step, fps, noise_seed=0x2B00 + idx[j], pose_fn=lambda f, fp, a=a: pose_fn(2 * a - f, fp))
+            bwd[j] = (S[:, :3].copy(), S[:, 3:].copy(), np.arange(len(dts)) * 5e6)
+    return vel, fwd, bwd
+
+
+def make_corridor_sequence(cfg, n_frames, step, speed, rank, dev):
+    """--scene corridor (default): n_frames distinct stereo pairs along the corridor, rendered on the GPU into HBM."""
+    import synth
+    rig = synth.RIGS[cfg["rig"]]
+    Ls, Rs, poses, idx = synth.corridor_sequence(cfg["rig"], n_frames, dev, frame_step=step, speed=speed, first=3 * rank)
+    vel, fwd, bwd = motion_data(cfg, idx, step, lambda f, fp: synth.corridor_pose(f, fp, speed))
+    return rig, Ls, Rs, poses, vel, fwd, bwd
+
+
+def cpu_baseline(cfg, frames, poses, vel, fwd, delay, threads, budget_s=16.0, warm=20, timed=200):
     """The oracle's closed loop (oracle/vo_system.py on the stage functions of liboracle, built -O3 -march=native on this
-    host) on a bounded sample of the same frames: frames/s, median and p95 of the per-frame time, one core."""
+    host) on a bounded sample of the same frames, SURVEY section 8(d)'s protocol: 20 warm-up + up to 200 timed frames
+    (bounded by budget_s), median and p95 of the per-frame time.  threads = True: the reference's threading - left || right
+    extraction on two threads (src/FeatureTracker.cpp:58-61), the local BA on the optimizer thread (src/System.cpp:19) on the
+    same hand-over schedule as the GPU run -> 3 cores; False: one core."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
     po.use_native_build()
@@ -111,28 +138,32 @@ def cpu_baseline(cfg, frames, poses, vel, fwd, budget_s=20.0, warm=3):
     imu = None
     if cfg["imu"]:
         imu = dict(prm=po.imu_params(GRAVITY, IMU_NOISE[0], IMU_NOISE[2], IMU_NOISE[1], IMU_NOISE[3], synth.T_BC1))
-    S = vo_system.System(rig, cfg["nfeat"], T0=poses[0], imu=imu)
+    S = vo_system.System(rig, cfg["nfeat"], T0=poses[0], imu=imu, mapping_delay=delay, threads=threads)
     if cfg["imu"]:
         S.velocity = vel[0].copy()
-    per, t_all = [], time.perf_counter()
-    for n in range(len(frames)):
-        L, R, _ = frames[n]
+    per, t_all = [], None
+    for n in range(min(len(frames), warm + timed)):
+        L, R = frames[n][0], frames[n][1]
         b = None
         if cfg["imu"] and n > 0:
             b = (np.concatenate([fwd[n][0], fwd[n][1]], 1), np.full(len(fwd[n][2]), 1.0 / 200))
+        if n == warm:
+            t_all = time.perf_counter()
         t0 = time.perf_counter()
         S.track(L, R, n, imu_bucket=b)
         if n >= warm:
             per.append(time.perf_counter() - t0)
-        if time.perf_counter() - t_all > budget_s and len(per) >= 5:
-            break
+            if time.perf_counter() - t_all > budget_s and len(per) >= 20:
+                break
     per = np.array(per)
-    return {"value": float(len(per) / per.sum()), "unit": "frames/s", "cores": 1, "kind": "port",
+    return {"value": float(len(per) / per.sum()), "unit": "frames/s", "cores": 3 if threads else 1, "kind": "port",
             "median_ms": float(np.median(per) * 1e3), "p95_ms": float(np.percentile(per, 95) * 1e3),
-            "sample": "%d frames of the same sequence after %d warm-up frames through the oracle's closed loop (extract L+R, stereo, "
-                      "tracking, keyframe insertion, new points + local BA on the tracker's windows; %d keyframes, %d local BAs), "
-                      "liboracle built -O3 -march=native -ffp-contract=off on this host, single thread; the reference itself cannot "
-                      "be built here (OpenCV / GTSAM absent)" % (len(per), warm, len(S.keyFrames), sum(1 for l in S.log if "mapping" in l))}
+            "sample": "%d timed frames of the same sequence after %d warm-up frames through the oracle's closed loop (extract L+R, stereo, "
+                      "tracking, keyframe insertion, new points + local BA on the tracker's windows, mapping_delay %d; %d keyframes, %d local BAs), "
+                      "%s; liboracle built -O3 -march=native -ffp-contract=off on this host; the reference itself cannot be built here "
+                      "(OpenCV / GTSAM absent)" % (len(per), warm, delay, len(S.keyFrames), sum(1 for l in S.log if "mapping" in l),
+                                                   "the reference's threading: left || right extraction threads + the local BA's solve on the optimizer thread (3 cores)"
+                                                   if threads else "single thread")}
 
 
 def run_c5(args, rank, world, local, dist, torch, backend):
@@ -195,16 +226,18 @@ def main():
     ap.add_argument("--sessions", type=int, default=192, help="independent SLAM sessions (sequences) sharing each GPU")
     ap.add_argument("--lanes", type=int, default=96, help="sessions per lockstep group (vslam_batch: one launch per stage for all lanes of a group); "
                                                           "0 = one host thread and one set of launches per session")
-    ap.add_argument("--frames", type=int, default=0, help="distinct rendered stereo frames of the replayed sequence (0: 100 for c1 / c2, 60 for c3)")
-    ap.add_argument("--frame-step", type=int, default=0, help="source frames between two sequence frames (0: 2 for c1 / c2, 1 for c3: the "
-                                                              "synthetic scene's extent in units of the rig's baseline bounds the camera speed)")
+    ap.add_argument("--scene", default="corridor", choices=["corridor", "room"], help="corridor: distinct poses along a long corridor, rendered on "
+                    "the GPU, no session turns around inside a run; room: the parity tests' small scene replayed as a ping-pong (round 2)")
+    ap.add_argument("--frames", type=int, default=0, help="distinct stereo frames of the sequence (0: corridor 640 / 400 for c3; room 100 / 60)")
+    ap.add_argument("--frame-step", type=int, default=0, help="source frames between two sequence frames (0: corridor 1; room 2, 1 for c3)")
+    ap.add_argument("--speed", type=float, default=0.0, help="corridor: forward speed in m/s (0: 0.5 for c1 / c2 as SURVEY section 8d, 1.0 for c3)")
     ap.add_argument("--host-images", action="store_true", help="frames in pinned host memory: every frame pays its H2D copy inside the step")
     ap.add_argument("--mapping", type=int, default=2, help="local mapping: 2 = optimizer thread per session (reference), 1 = synchronous, 0 = off")
     ap.add_argument("--mapping-delay", type=int, default=-1, help="(default: 4 frames, 2 for c3) --mapping 2: the fixed schedule of the optimizer "
                     "thread's hand-over (vslam_system_config::mapping_delay): new points arrive with the frame after the keyframe, the "
                     "local BA's write-back + changePosesLCA k frames after it.  Keyframes are at least 5 frames apart, so with k <= 5 every "
                     "keyframe gets its pass - the reference's steady state at camera rate")
-    ap.add_argument("--prime", type=int, default=60, help="untimed frames every session tracks BEFORE the warm-up steps, so that the timed "
+    ap.add_argument("--prime", type=int, default=-1, help="(default 160 corridor / 60 room) ""untimed frames every session tracks BEFORE the warm-up steps, so that the timed "
                     "steps see sessions in their steady state (a map with more than three keyframes, the local mapper running) "
                     "whatever --warmup / --steps are; part of the set-up like rendering the frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -220,12 +253,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    corridor = args.scene == "corridor"
     if args.frames <= 0:
-        args.frames = 60 if args.config == "c3" else 100
+        args.frames = (400 if args.config == "c3" else 640) if corridor else (60 if args.config == "c3" else 100)
     if args.frame_step <= 0:
-        args.frame_step = 1 if args.config == "c3" else 2
+        args.frame_step = 1 if (corridor or args.config == "c3") else 2
+    if args.speed <= 0:
+        args.speed = 1.0 if args.config == "c3" else 0.5
+    if args.prime < 0:
+        args.prime = 160 if corridor else 60
     seq = None
-    if args.config != "c5":      # rendered before torch / HIP start (the renderer forks worker processes)
+    if args.config != "c5" and not corridor:      # rendered before torch / HIP start
         seq = make_sequence(CONFIGS[args.config], args.frames, args.frame_step, rank)
 
     import torch
@@ -259,14 +297,28 @@ def main():
         return
 
     cfg = CONFIGS[args.config]
-    rig, frames, poses, vel, fwd, bwd = seq
-    w, h = rig["w"], rig["h"]
-    if args.host_images:
-        bufs = [(torch.from_numpy(L).pin_memory(), torch.from_numpy(R).pin_memory()) for (L, R, _) in frames]
+    if corridor:
+        rig, Ls, Rs, poses, vel, fwd, bwd = make_corridor_sequence(cfg, args.frames, args.frame_step, args.speed, rank, dev)
+        torch.cuda.synchronize()
+        if args.host_images:
+            Ls, Rs = Ls.cpu().pin_memory(), Rs.cpu().pin_memory()
+        bufs = [(Ls[j], Rs[j]) for j in range(args.frames)]
+        frames = None
     else:
-        bufs = [(torch.from_numpy(L).to(dev), torch.from_numpy(R).to(dev)) for (L, R, _) in frames]
+        rig, frames, poses, vel, fwd, bwd = seq
+        if args.host_images:
+            bufs = [(torch.from_numpy(L).pin_memory(), torch.from_numpy(R).pin_memory()) for (L, R, _) in frames]
+        else:
+            bufs = [(torch.from_numpy(L).to(dev), torch.from_numpy(R).to(dev)) for (L, R, _) in frames]
+    w, h = rig["w"], rig["h"]
     lp = [b[0].data_ptr() for b in bufs]
     rp = [b[1].data_ptr() for b in bufs]
+    # no session turns around inside the run: start offsets leave room for every frame the run tracks (else: ping-pong)
+    need = args.prime + args.warmup + args.steps + 2
+    start_span = max(args.frames - need, 0) if corridor else 0
+    turns = corridor and start_span < 8
+    if turns:
+        start_span = 0
     imu = dict(gravity=GRAVITY, noise=IMU_NOISE, T_bs=__import__("synth").T_BC1, hz=200) if cfg["imu"] else None
     if args.mapping_delay < 0:
         # The reference's optimizer thread ends a pass within a frame or two of camera time: k = 2 for the KITTI-like sequence
@@ -277,7 +329,7 @@ def main():
 
     def make_fleet(S, lanes):
         return vc.Fleet(scfg, S, lp, rp, w, not args.host_images, poses=poses, velocities=vel,
-                        imu_forward=fwd if cfg["imu"] else None, imu_backward=bwd if cfg["imu"] else None, lanes=lanes)
+                        imu_forward=fwd if cfg["imu"] else None, imu_backward=bwd if cfg["imu"] else None, lanes=lanes, start_span=start_span)
 
     lanes = min(args.lanes, args.sessions)
     fleet = make_fleet(args.sessions, lanes)
@@ -343,21 +395,27 @@ def main():
             fx.close()
 
     fleet.close()      # (idempotent) library threads joined before the process winds down
+
+    # workload probe (after the timed region, its own extractor / matcher): the figures the byte formulas need and the fleet
+    # report does not carry - keypoints per image, FAST candidates per image, the stereo kernel's own counters
+    probe = None
+    if rank == 0:
+        probe = workload_probe(vc, rig, cfg, bufs, w, h, args.host_images, local)
+
     # N > 1: the landmark-sharded 64-keyframe / 100 k-landmark BA over RCCL as an extra section of the line.  It is the
-    # only collective of the path and cannot be rehearsed on the one-GPU development box, so it runs under a watchdog: if
-    # it has not finished in time (or raises), the closed-loop line is still printed, with the failure recorded.
+    # only collective of the path, so it runs under a watchdog: if it has not finished in time the closed-loop line is still
+    # printed, with the failure recorded, and the process ends with a NON-ZERO status.
     c5 = None
-    c5_done = [False]
+    emit_lock = __import__("threading").Lock()
+    emitted = [False]
     emit_box = {}
     if world > 1 and not os.environ.get("VSLAM_BENCH_SKIP_C5"):
         import threading
 
         def _watchdog():
-            if c5_done[0]:
-                return
             if rank == 0 and "emit" in emit_box:
                 emit_box["emit"]({"error": "the sharded-BA section did not finish within %d s" % args.c5_timeout})
-            os._exit(0)
+            os._exit(3)
         wd = threading.Timer(args.c5_timeout, _watchdog)
         wd.daemon = True
         emit_box["timer"] = wd
@@ -369,27 +427,37 @@ def main():
         nBA = max(cnt["ba"], 1)
         nBAall = max(rep["mappings"], 1)
         R_, L_, k2, Fk = rep["ba_residuals"] / nBAall, rep["ba_landmarks"] / nBAall, rep["ba_sum_k2"] / nBAall, rep["ba_free_kf"] / nBAall
-        trialsPerBA = rep["ba_trials"] / nBAall
-        linPerBA = rep["ba_iterations"] / nBAall + 2
+        roundsPerBA = max(rep["ba_rounds"] / nBAall, 1.0)      # trial rounds per local BA (one round = up to 4 lambda candidates at once)
+        launch_n = {k[:-2]: v for k, v in stage_ms.items() if k.endswith("#n")}      # measured launches behind the local-BA sums
+        stage_ms = {k: v for k, v in stage_ms.items() if not k.endswith("#n")}
+
+        def ba_group(name, per_ba_launches, lane_bytes, lane_flops=0.0):
+            """one launch of a local-BA stage serves the lanes of a cohort that are still iterating: launches as measured, bytes per
+            launch = per-lane bytes x (lane-launches of the sampled BAs / launches)"""
+            n_l = max(launch_n.get(name, nBA * per_ba_launches), 1.0)
+            lanes_eff = max(nBA * per_ba_launches / n_l, 1.0)
+            return (n_l, lane_bytes * lanes_eff, lane_flops * lanes_eff)
         nBA6 = 6 * Fk
-        nk = float(nfeat)
-        Mact = 600.0    # active map points per tracked frame (order of magnitude; the byte formulas are linear in it)
+        nk = probe["keys_per_image"]                 # measured: kept keypoints per image
+        ncand = probe["fast_candidates_per_image"]   # measured: FAST corners per image before the suppression
+        Mact = rep["sum_active"] / max(rep["frames"], 1)      # measured: active map points per tracked frame
         frames_per_ba = rep["frames"] / nBAall
         # One launch of a tracking / extraction stage serves `lb` sessions (the lanes of a lockstep group; 1 without batching).
         lb = max(lanes, 1)
         nStep = max(cnt["frames"] / lb, 1)         # sampled steps
-        # kernel group -> (launches over the sampled region, algorithmic bytes per launch, algorithmic flops per launch)
+        # kernel group -> (launches over the sampled region, ALGORITHMIC bytes per launch, algorithmic flops per launch); SURVEY 8(d)
         b_cand, b_res = Mact * 60 + 2 * nk * 60 + Mact * 128, Mact * (128 + 8 + 8) + 2 * nk * 8
         b_pose = Mact * (24 + 8 + 4) + 2 * nk * 28 + (8 * 514 if cfg["imu"] else 0)
+        b_stereo = 32.0 * (nk + probe["stereo_hamming_tests"]) + 1452.0 * probe["stereo_sad_refinements"]     # SURVEY 8(d): B_st
         groups = {
             "pyramid": (7 * nStep, lb * nimg * (sum(px[:-1]) + sum(px[1:])) / 7.0, 0),     # read level l-1, write level l
-            "fast": (nStep, lb * nimg * (sumP + 4 * 3.3 * nfeat), 0),                      # every level read once + packed candidates
-            "gather": (nStep, lb * nimg * (8 * 3.3 * nfeat), 0),
-            "ssc": (nStep, lb * nimg * (8 * 3.3 * nfeat + 4 * nk), 0),                      # candidates in, picks out
+            "fast": (nStep, lb * nimg * (sumP + 4 * ncand), 0),                            # every level read once + packed candidates
+            "gather": (nStep, lb * nimg * (8 * ncand), 0),
+            "ssc": (nStep, lb * nimg * (8 * ncand + 4 * nk), 0),                            # candidates in, picks out
             "blur": (nStep, lb * nimg * (2 * sumP), 0),                                    # read + write every level
             "orient_desc": (nStep, lb * nimg * nk * (28 + 32 + 709 + 512), 0),             # keypoint + descriptor + disc + BRIEF taps
             "stereo_rows": (nStep, lb * nk * 28, 0),
-            "stereo_match": (nStep, lb * (nk * (28 + 32) * 2 + nk * 16), 0),
+            "stereo_match": (nStep, lb * b_stereo, 0),
             "stereo_finalize": (nStep, lb * nk * 24, 0),
             "track_predict": (nStep, lb * (nk * (24 + 32 + 5) + Mact * (60 + 24 + 12)), 0),
             "track_repredict": (nStep, lb * Mact * (24 + 60 + 12), 0),
@@ -400,29 +468,44 @@ def main():
             "proj_resolve": (2 * nStep, lb * b_res, 0),
             "pose_imu_lm": (2 * nStep, lb * b_pose, 0),                                    # two solves per frame
             "pose_lm": (2 * nStep, lb * b_pose, 0),
-            "ba_linearize": (nBA * linPerBA, R_ * (8 + 16 + 8 + 96 + 24 + 160), 0),          # idx, uv, sigma, pose, point, stored J
-            "ba_schur": (nBA * trialsPerBA, R_ * 160 + L_ * 24, 2 * 36 * k2),                 # stored J read once (S stays in LDS)
-            "ba_solve": (nBA * trialsPerBA, 8 * (nBA6 * nBA6 + nBA6) * 2, nBA6 ** 3 / 3.0),   # reduced system in, delta out
-            "ba_back": (nBA * trialsPerBA, R_ * 160 + L_ * 48, 0),
-            "ba_eval": (nBA * trialsPerBA, R_ * (160 + 16 + 8 + 96 + 24), 0),
-            "ba_chi2": (2 * nBA, R_ * (16 + 8 + 96 + 24), 0),
+            "ba_linearize": ba_group("ba_linearize", 2, R_ * (8 + 16 + 8 + 96 + 24 + 160)),      # idx, uv, sigma, pose, point, stored J
+            "ba_schur": ba_group("ba_schur", roundsPerBA, R_ * 160 + L_ * 24, 2 * 36 * k2),       # stored J read once (S stays in LDS)
+            "ba_solve": ba_group("ba_solve", roundsPerBA, 8 * (nBA6 * nBA6 + nBA6) * 2, nBA6 ** 3 / 3.0),   # reduced system in, delta out
+            "ba_back": ba_group("ba_back", roundsPerBA, R_ * 160 + L_ * 48),
+            "ba_eval": ba_group("ba_eval", roundsPerBA, R_ * (160 + 16 + 8 + 96 + 24)),
+            "ba_chi2": ba_group("ba_chi2", 2, R_ * (16 + 8 + 96 + 24)),
         }
+        ba_lanes = nBA / max(cnt.get("ba_cohorts", nBA), 1)      # sessions served per batched local-BA call
         nS = nStep * lb
         per_frame = {}
         for k, v in stage_ms.items():
             per_frame[k] = v / (nBA * frames_per_ba) if k.startswith("ba_") else v / nS      # device ms per tracked frame
+        # algorithmic bytes of one tracked stereo frame over the whole path = sum over the groups of bytes per launch x launches per frame
+        path_bytes = 0.0
+        for k, (n_l, ab, _) in groups.items():
+            if k in ("pose_lm", "pose_imu_lm") and k != ("pose_imu_lm" if cfg["imu"] else "pose_lm"):
+                continue
+            if k == "imu_preintegrate" and not cfg["imu"]:
+                continue
+            path_bytes += ab * (n_l / (nBA * frames_per_ba) if k.startswith("ba_") else n_l / nS)
+        value = world * S * args.steps / el
         out = {
             "metric": "frames/sec (extract+match+localBA), %d feat stereo %dx%d" % (nfeat, w, h),
-            "value": world * S * args.steps / el, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/i32 (extract, match) + f64 (pose LM, local BA)", "data": "synthetic",
             "config": {"workload": cfg["name"] + "; closed loop per session (keyframe rule, insertKeyFrame, new points + local BA on the tracker's "
-                                   "own covisibility window on the optimizer thread, write-back, changePosesLCA); %d rendered frames %s, replayed as a "
-                                   "ping-pong; measured per run: one keyframe every %.1f frames, one local BA every %.1f frames (%.0f landmarks, %.0f "
-                                   "residual blocks, %.1f free keyframes on average)"
-                                   % (args.frames, "in pinned host memory (H2D inside the step)" if args.host_images else "resident in HBM",
-                                      rep["frames"] / max(rep["keyframes"], 1), frames_per_ba, L_, R_, Fk),
+                                   "own covisibility window, write-back, changePosesLCA); %s; measured per run: one keyframe every %.1f frames, one local BA "
+                                   "every %.1f frames (%.0f landmarks, %.0f residual blocks, %.1f free keyframes on average), %.0f keypoints per image, "
+                                   "%.0f active map points per frame"
+                                   % (("corridor scene: %d distinct stereo frames %s, %.2f m/s, every session walks forward from its own start frame%s"
+                                       % (args.frames, "in pinned host memory (H2D inside the step)" if args.host_images else "rendered into HBM",
+                                          args.speed, " and turns around at the end (the run is longer than the sequence)" if turns else
+                                          " and never revisits a place inside the run"))
+                                      if corridor else "room scene: %d rendered frames %s, replayed as a ping-pong"
+                                      % (args.frames, "in pinned host memory (H2D inside the step)" if args.host_images else "resident in HBM"),
+                                      rep["frames"] / max(rep["keyframes"], 1), frames_per_ba, L_, R_, Fk, nk, Mact),
                        "sessions_per_gpu": S, "lanes_per_group": lanes, "prime_frames": args.prime,
                        "local_mapping": {0: "off", 1: "inside the frame (synchronous)", 2: "device work beside tracking, fixed schedule"}.get(args.mapping, "?") +
                                         ("; mapping_delay = %d: new points with the next frame, the BA's write-back + changePosesLCA %d frames after "
@@ -430,26 +513,27 @@ def main():
                                          if args.mapping == 2 else ""),
                        "step": "one stereo frame of each of the %d sessions" % S,
                        "threads": ("%d lockstep groups of %d sessions (vslam_batch: one launch per stage for all lanes), one driver thread + a "
-                                   "host-phase pool + 3 mapping threads per group" % ((S + lanes - 1) // lanes, lanes)) if lanes > 0 else
-                                  "one host thread per session inside the library (vslam_fleet) + one optimizer thread per session",
+                                   "host-phase pool + the mapping engine per group" % ((S + lanes - 1) // lanes, lanes)) if lanes > 0 else
+                                  "one host thread per session inside the library (vslam_fleet) + one mapping thread per session",
                        "parallelism": "replicas x%d, %d sessions per GPU" % (world, S)},
             "tracking": {"mean_inliers": rep["sum_inliers"] / max(rep["frames"] - 0, 1), "min_inliers": rep["min_inliers"],
                          "lost_frames": rep["lost_frames"], "mean_rounds": rep["sum_rounds"] / max(rep["frames"], 1),
                          "keyframes": rep["keyframes"], "local_bas": rep["mappings"], "new_points": rep["new_points"],
                          "rms_position_error_m": float(np.sqrt(rep["sum_sq_position_error"] / max(rep["frames"], 1))),
                          "max_position_error_m": rep["max_position_error"]},
+            "workload_probe": probe,
             "stage_ms_per_frame": {k: v for k, v in sorted(per_frame.items())},
             "stage_sampling": "HIP events on every %s step of group 0 (all its lanes per launch) and on the local BAs of its first sessions that "
                               "complete in those steps (%d frames, %d BAs); per tracked frame; BA stages amortised over %.1f frames per BA"
                               % ("3rd" if sample_every == 3 else "single", cnt["frames"], cnt["ba"], frames_per_ba),
+            "path": {"algorithmic_bytes_per_frame": path_bytes, "achieved_GBps": path_bytes * value / world / 1e9, "peak_GBps": HBM_PEAK_GBS,
+                     "frac": path_bytes * value / world / 1e9 / HBM_PEAK_GBS,
+                     "note": "whole path: sum over the kernel groups of (algorithmic bytes per launch x launches per tracked frame, SURVEY 8(d) formulas "
+                             "with the measured keypoint / candidate / active-point / stereo-test counts) x frames/s of one GPU / HBM peak"},
         }
         if per_frame:
-            # Which kernel dominates a GPU that runs several streams at once?  Elapsed time alone over-counts narrow launches: a
-            # one-wave Cholesky (k_ba_solve_mfma64) that waits 150 us for a free CU occupies 4 of the GPU's 8192 wave slots.  A
-            # group's weight is therefore its device time per tracked frame x the share of the wave slots one launch can fill
-            # (SQ_WAVES per launch from the committed PMC pass, same launch shape, against 256 CUs x 32 waves; x the kernel's
-            # resident-wave limit where registers or LDS cap it).  `roofline` prices that
-            # kernel; `roofline_top5` lists the five largest groups by the same weight.
+            # `roofline` prices the kernel group with the LARGEST ELAPSED DEVICE TIME per tracked frame in this run (HIP events on the
+            # launching stream, summed over the sampled launches) - no weighting.  roofline_top5: the five largest by the same measure.
             bsfx = "_b" if lanes > 0 else ""
             KNAME = {"proj_resolve": "k_proj_resolve" + bsfx, "pose_imu_lm": "k_pose_imu_lm" + bsfx, "pose_lm": "k_pose_lm" + bsfx,
                      "stereo_match": "k_stereo_match" + bsfx, "stereo_finalize": "k_stereo_finalize" + bsfx, "stereo_rows": "k_stereo_rows" + bsfx,
@@ -462,95 +546,121 @@ def main():
                 pmc_all = json.load(open(PMC_FILE))
             except Exception:      # noqa: BLE001
                 pmc_all = {}
-            WAVE_SLOTS = 256 * 32
+            # the committed counters apply only to the launch shape they were collected on
+            meta = pmc_all.get("_meta", {})
+            pmc_ok = bool(meta) and meta.get("config") == args.config and meta.get("lanes") == lanes and meta.get("scene", "room") == args.scene
 
-            # resident-wave limit of a kernel, as a fraction of a CU's 32 wave slots (-Rpass-analysis=kernel-resource-usage /
-            # LDS per workgroup): k_ssc<2> = two 8-wave tasks per CU (67 KB of LDS each), k_fast = 7 waves per SIMD (71 VGPRs)
-            OCC_LIMIT = {"ssc": 16 / 32.0, "fast": 28 / 32.0}
-
-            def slot_share(k):
-                w = pmc_all.get(KNAME.get(k, ""), {}).get("SQ_WAVES_avg")
-                return (min(1.0, w / WAVE_SLOTS) if w else 1.0) * OCC_LIMIT.get(k, 1.0)
-            dom = max(per_frame, key=lambda k: per_frame[k] * slot_share(k))
-            dom_elapsed = max(per_frame, key=lambda k: per_frame[k])
-            n_launch, alg_bytes, alg_flops = groups.get(dom, (nS, 0, 0))
-            dom_ms = stage_ms[dom] / max(n_launch, 1)
-            achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-            # with S sessions sharing the chip the kernel's launches overlap: aggregate rate of this kernel over the run =
-            # bytes of all its launches / wall time of the timed region
-            launches_per_frame = n_launch / nS if not dom.startswith("ba_") else n_launch / (nBA * frames_per_ba)
-            agg = alg_bytes * launches_per_frame * S * args.steps / el / 1e9
-            roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            def price(k):
+                n_l, ab, fl = groups.get(k, (nS, 0, 0))
+                ms_l = stage_ms[k] / max(n_l, 1)
+                gbs = ab / (ms_l * 1e-3) / 1e9 if ms_l > 0 else 0.0
+                return n_l, ab, fl, ms_l, gbs
+            dom = max(per_frame, key=lambda k: per_frame[k])
+            n_launch, alg_bytes, alg_flops, dom_ms, achieved = price(dom)
+            roof = {"bound": "hbm", "kernel": KNAME.get(dom, dom), "group": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launch_ms": dom_ms, "algorithmic_bytes": alg_bytes,
-                    "launches_timed": n_launch,
-                    "aggregate_GBps_all_sessions": agg, "aggregate_frac": agg / HBM_PEAK_GBS,
-                    "lanes_per_launch": lb if not dom.startswith("ba_") else 1,
-                    "wave_slot_share": slot_share(dom), "largest_by_elapsed_time": dom_elapsed,
-                    "note": "per-launch figure of the dominant kernel group = the largest (device time per tracked frame x share of the GPU's "
-                            "8192 wave slots one launch fills, SQ_WAVES of the PMC pass); one launch serves all lanes of a lockstep group, local-BA "
-                            "kernels serve one session; aggregate_* = the same group's algorithmic bytes over all sessions / wall time; "
-                            "roofline_top5 = the five largest groups by that weight, largest_by_elapsed_time = by elapsed time alone (a narrow local-BA launch)"}
+                    "launches_timed": n_launch, "device_ms_per_frame": per_frame[dom],
+                    "sessions_per_launch": (ba_lanes if dom.startswith("ba_") else lb),
+                    "local_ba_lanes_per_cohort": ba_lanes,
+                    "note": "the kernel group with the largest elapsed device time per tracked frame in THIS run (HIP events on the launching "
+                            "stream); achieved = algorithmic bytes of one launch / its average duration"}
             kname = KNAME.get(dom)
-            if kname in pmc_all:
+            if pmc_ok and kname in pmc_all:
                 roof["traffic"] = (2.0 * pmc_all[kname]["FETCH_SIZE_avg"] + pmc_all[kname]["WRITE_SIZE_avg"]) * 1024.0
-                roof["traffic_source"] = os.path.relpath(PMC_FILE, ROOT) + " (2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, per launch)"
+                roof["traffic_source"] = ("from " + os.path.relpath(PMC_FILE, ROOT) + ", same launch shape (%s): 2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, per launch"
+                                          % json.dumps(meta, sort_keys=True))
+            else:
+                roof["traffic_source"] = "no committed PMC pass for this config / launch shape"
             if alg_flops:
                 roof["achieved_gflops"] = alg_flops / (dom_ms * 1e-3) / 1e9
                 roof["fp64_frac"] = roof["achieved_gflops"] / (FP64_PEAK_TFLOPS * 1e3)
-            if dom == "ba_solve":
-                # the one MFMA-shaped kernel of the path (v_mfma_f64 Cholesky of the reduced camera system): priced against the
-                # dense fp64 matrix peak; the HBM view of the same launch stays in hbm_*
-                roof.update({"bound": "mfma", "hbm_achieved_GBps": achieved, "hbm_frac": achieved / HBM_PEAK_GBS,
-                             "achieved": roof["achieved_gflops"] / 1e3, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": roof["achieved_gflops"] / 1e3 / FP64_PEAK_TFLOPS,
-                             "why_small": "a %.0f-unknown system (%.1f free keyframes) is %.0f flops per candidate: one workgroup, latency-bound; "
-                                          "launch_ms is measured with the other sessions' kernels sharing the GPU" % (nBA6, Fk, alg_flops)})
             out["roofline"] = roof
-            # the same per-launch pricing for the five largest groups by the same weight (context for `roofline`: which kernels move
-            # bytes and which are latency- / instruction-bound chains); the largest by elapsed time alone is named in `roofline`
             top = []
-            for k in sorted(per_frame, key=lambda q: -per_frame[q] * slot_share(q))[:5]:
-                n_l, ab, _ = groups.get(k, (nS, 0, 0))
-                ms_l = stage_ms[k] / max(n_l, 1)
-                gbs = ab / (ms_l * 1e-3) / 1e9 if ms_l > 0 else 0.0
-                top.append({"kernel": k, "ms_per_frame": per_frame[k], "launch_ms": ms_l, "algorithmic_bytes": ab,
-                            "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS, "wave_slot_share": slot_share(k)})
+            for k in sorted(per_frame, key=lambda q: -per_frame[q])[:5]:
+                n_l, ab, _, ms_l, gbs = price(k)
+                e = {"group": k, "kernel": KNAME.get(k, k), "device_ms_per_frame": per_frame[k], "launch_ms": ms_l, "algorithmic_bytes": ab,
+                     "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS}
+                if pmc_ok and KNAME.get(k) in pmc_all:
+                    e["traffic"] = (2.0 * pmc_all[KNAME[k]]["FETCH_SIZE_avg"] + pmc_all[KNAME[k]]["WRITE_SIZE_avg"]) * 1024.0
+                top.append(e)
             out["roofline_top5"] = top
-            if "ba_solve" not in stage_ms:   # no local BA of the sampled sessions fell into this (short) timed region
-                out["ba_solve_mfma"] = {"launch_ms": None, "unknowns": nBA6, "flops": groups["ba_solve"][2], "achieved_gflops": None, "fp64_frac": None,
-                                        "note": "no sampled local BA in the timed region; profiles/r02_i_c2_kernel_stats.csv has the kernel "
-                                                "(k_ba_solve_mfma64, ~35-40 us per launch): (6F)^3/3 flops per candidate - << 1 % of the fp64 MFMA peak"}
             if "ba_solve" in stage_ms:       # the only MFMA-eligible term of the path: always reported
-                n_l, _, fl = groups["ba_solve"]
-                ms_l = stage_ms["ba_solve"] / max(n_l, 1)
+                n_l, _, fl, ms_l, _ = price("ba_solve")
                 out["ba_solve_mfma"] = {"launch_ms": ms_l, "unknowns": nBA6, "flops": fl, "achieved_gflops": fl / (ms_l * 1e-3) / 1e9 if ms_l > 0 else 0.0,
                                         "fp64_frac": (fl / (ms_l * 1e-3) / 1e9) / (FP64_PEAK_TFLOPS * 1e3) if ms_l > 0 else 0.0,
                                         "note": "reduce + dense reduced-camera Cholesky + substitutions of one trial round (4 lambda candidates); "
                                                 "(6F)^3/3 flops per candidate - << 1 % of the fp64 MFMA peak by construction"}
+            else:
+                out["ba_solve_mfma"] = {"launch_ms": None, "unknowns": nBA6, "flops": groups["ba_solve"][2], "achieved_gflops": None, "fp64_frac": None,
+                                        "note": "no sampled local BA in the timed region"}
         if latency:
             out["latency_single_session"] = latency
         if sweep:
             out["sweep"] = sweep
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg, frames, poses, vel, fwd)
+            # the same frames on the host's cores (rank 0, N = 1 only): the first frames of the sequence
+            nb = 224
+            if corridor:
+                hostf = [(Ls[j].cpu().numpy(), Rs[j].cpu().numpy()) for j in range(min(nb, args.frames))]
+            else:
+                hostf = [(f[0], f[1]) for f in frames[:nb]]
+            out["cpu_baseline"] = cpu_baseline(cfg, hostf, poses, vel, fwd, args.mapping_delay if args.mapping == 2 else 0, True)
+            out["cpu_baseline_single_thread"] = cpu_baseline(cfg, hostf, poses, vel, fwd, args.mapping_delay if args.mapping == 2 else 0, False)
 
         def emit(c5res):
-            if c5res is not None:
-                out["c5_sharded_ba"] = c5res
-            print(json.dumps(out), flush=True)
+            with emit_lock:
+                if emitted[0]:
+                    return
+                emitted[0] = True
+                if c5res is not None:
+                    out["c5_sharded_ba"] = c5res
+                print(json.dumps(out), flush=True)
         emit_box["emit"] = emit
+    failed = False
     if "timer" in emit_box:
         emit_box["timer"].start()
         try:
             c5 = run_c5(args, rank, world, local, dist, torch, backend)
         except Exception as e:      # noqa: BLE001
             c5 = {"error": "%s: %s" % (type(e).__name__, e)}
-        c5_done[0] = True
+            failed = True
         emit_box["timer"].cancel()
     if rank == 0:
         emit_box["emit"](c5)
+    if failed:
+        # a rank whose sharded section raised leaves the others inside a collective: no destroy_process_group (it would block),
+        # no in-process restart - the line (rank 0) carries the error, the status is non-zero
+        sys.stdout.flush()
+        os._exit(3)
     if world > 1:
         dist.destroy_process_group()
+
+
+def workload_probe(vc, rig, cfg, bufs, w, h, host_images, device):
+    """Keypoints / FAST candidates per image and the stereo kernel's counters (Hamming tests, SAD refinements), averaged over a
+    few frames of the sequence: one extractor + matcher of their own, after the timed region."""
+    idxs = sorted(set(int(v) for v in np.linspace(0, len(bufs) - 1, 6)))
+    fe = vc.Extractor(w, h, cfg["nfeat"], batch=2, device=device)
+    m = vc.Matcher(rig, fe, 0, fe, 1)
+    keys = cands = tests = sads = 0.0
+    for j in idxs:
+        L, R = bufs[j]
+        if host_images:
+            fe.set_image(0, L.numpy()); fe.set_image(1, R.numpy())
+        else:
+            fe.set_image_device(0, L.data_ptr(), w); fe.set_image_device(1, R.data_ptr(), w)
+        fe.run()
+        kL, _ = fe.fetch(0); kR, _ = fe.fetch(1)
+        keys += 0.5 * (len(kL) + len(kR))
+        cands += 0.5 * sum(len(fe.candidates(i, l)) for i in (0, 1) for l in range(8))
+        m.use_extractor_keys()
+        m.stereo_match()
+        st = m.stereo_fetch(len(kL), len(kR))
+        tests += st["candidates"]; sads += st["sad"]
+    n = float(len(idxs))
+    m.close(); fe.close()
+    return {"frames_probed": len(idxs), "keys_per_image": keys / n, "fast_candidates_per_image": cands / n,
+            "stereo_hamming_tests": tests / n, "stereo_sad_refinements": sads / n}
 
 
 if __name__ == "__main__":

@@ -78,14 +78,17 @@ struct BaDev {
     double* facJBase; size_t facJStride; double* SedgeBase; BaEdge* edgesBase;
     double* facJ2; double* Sedge2; BaEdge* edges2;            // set by ba_enter (slot of the candidate)
     size_t sysStride, spartStride, partialStride, dLStride;
+    int solveKind;                       // which reduced-camera solve serves this lane (a batch may mix kinds: each kernel skips foreign lanes)
+    double* Lg;                          // k_ba_solve_mfma: the lane's factor storage (null: the launch's argument)
 };
+enum { BA_SOLVE_MFMA64 = 0, BA_SOLVE_WAVE = 1, BA_SOLVE_MFMA = 2, BA_SOLVE_LARGE = 3 };
 
 // The LM policy (GTSAM 4.2) runs on the DEVICE: the control step after each linearisation / trial updates this
 // block, every other kernel starts by checking that it is its turn (state) and picks the current / trial
 // buffers by `sel`.  The host enqueues a few speculative steps at a time and only reads the
 // block back to learn whether the pass has finished - no host round trip per lambda trial.
 enum { CTL_LAMBDA = 0, CTL_ERROR = 1, CTL_CUR = 2, CTL_INIT_ERR = 3, CTL_INTS = 8, CTL_DOUBLES = 16 };
-enum { CI_STATE = 0, CI_SEL = 1, CI_ITER = 2, CI_INNER = 3, CI_MAXIT = 4, CI_FIRST = 5, CI_NACT = 6 };
+enum { CI_STATE = 0, CI_SEL = 1, CI_ITER = 2, CI_INNER = 3, CI_MAXIT = 4, CI_FIRST = 5, CI_NACT = 6, CI_ROUNDS = 7 };
 enum { BA_LINEARIZE = 0, BA_TRY = 1, BA_DONE = 2 };
 enum { BA_MAX_NB = 4, SUMS_CAND = 16, FLAG_COUNT = 1, FLAG_FAIL = 4 };   // sums[16 + 2c | 17 + 2c], flags[4 + c] per candidate
 __device__ __forceinline__ int ba_slot(int sel, int c, int NB) {
@@ -279,6 +282,7 @@ __device__ __forceinline__ void ba_ctl(const BaDev& D, int mode, double relTol, 
         return;
     }
     if (ci[CI_STATE] != BA_TRY) return;
+    ci[CI_ROUNDS]++;                 // (work figure: trial rounds this pass has evaluated)
     // walk the candidates in the order the sequential policy would have tried them
     const int nAct = ci[CI_NACT];
     for (int cand = 0; cand < nAct; cand++) {
@@ -329,7 +333,8 @@ __device__ __forceinline__ void ba_ctl(const BaDev& D, int mode, double relTol, 
 // The control step as its own launch: the multi-GPU path, where the cost sums are all-reduced between the
 // evaluation and the decision.  After a trial that ends the inner loop the edge accumulator is cleared for the
 // next linearisation (the fused kernel below does the same in its last workgroup).
-__global__ __launch_bounds__(256) void k_ba_ctl(BaDev D, int mode, double relTol, double absTol) {
+__global__ __launch_bounds__(256) void k_ba_ctl(const BaDev* __restrict__ tab, int mode, double relTol, double absTol) {
+    BaDev D = *lane_entry(tab, blockIdx.z);      // per-lane argument block (grid z = problem of the batch)
     __shared__ int sZero;
     if (threadIdx.x == 0) {
         ba_ctl(D, mode, relTol, absTol);
@@ -347,7 +352,8 @@ __global__ __launch_bounds__(256) void k_ba_ctl(BaDev D, int mode, double relTol
 //   MODE 0: linearise at the current values: facJ, edge blocks into Sedge, sums[0] = current error
 //   MODE 1: evaluate a trial: sums[1] = linearised cost at delta, sums[2] = cost at the trial values
 template <int MODE>
-__global__ __launch_bounds__(256) void k_ba_factors(BaDev D, int obsBlocks, int fuseCtl, double relTol, double absTol) {
+__global__ __launch_bounds__(256) void k_ba_factors(const BaDev* __restrict__ tab, int obsBlocks, int fuseCtl, double relTol, double absTol) {
+    BaDev D = *lane_entry(tab, blockIdx.z);      // per-lane argument block (grid z = problem of the batch)
     __shared__ double red[8], out[2];
     __shared__ double sW[160];       // edge scratch: Hl 36 | Ad 36 | Ja 36 | Jb 36 | r 6
     __shared__ int sLast;
@@ -526,7 +532,8 @@ __device__ __forceinline__ void ba_hll_inverse(const double* h, double lambda, d
 // One wave per landmark.  sharedW: the workgroup serves every lambda candidate (grid y = 1): Hll, bl and the W blocks
 // do not depend on the damping and are built once, only Hll^-1 and the rank-3 updates are per candidate, each into
 // its own LDS copy of the reduced system.  Otherwise grid y = candidate.
-__global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_schur(BaDev D, int maxSlots, int sharedW) {
+__global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_schur(const BaDev* __restrict__ tab, int maxSlots, int sharedW) {
+    BaDev D = *lane_entry(tab, blockIdx.z);      // per-lane argument block (grid z = problem of the batch)
     constexpr bool LDS_S = true;       // (windows of larger systems: k_ba_schur_win)
     extern __shared__ double sm[];
     double* const SBase = D.S;
@@ -625,7 +632,8 @@ __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_schur(BaDev D, int m
 // before the solve.  A workgroup owns 32 entries; 8 thread groups sum slices of the partials, the 8 slice sums are
 // then added in slice order through LDS - a fixed summation order, no atomics: the reduced system is bit-identical
 // from run to run.
-__global__ __launch_bounds__(256) void k_ba_reduce(BaDev D, int nPart) {
+__global__ __launch_bounds__(256) void k_ba_reduce(const BaDev* __restrict__ tab, int nPart) {
+    BaDev D = *lane_entry(tab, blockIdx.z);      // per-lane argument block (grid z = problem of the batch)
     __shared__ double sSl[8][33];
     if (!ba_enter(D, BA_TRY, blockIdx.y)) return;
     const int total = D.n * D.n + D.n;
@@ -678,7 +686,8 @@ struct BaWin {
 // sits in several windows' lists, which then only fetch the W blocks of their own rows / columns (144 B each) instead of
 // rebuilding everything from the landmark's factors.
 constexpr int BA_WIN_HG = 9 + 6 * BA_MAX_NB;      // doubles per landmark: Hll (6) | bl (3) | per candidate the 6 unique entries of (Hll + lambda I)^-1
-__global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_lm_prep(BaDev D, BaWin Wn, int maxSlots) {
+__global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_lm_prep(const BaDev* __restrict__ tab, BaWin Wn, int maxSlots) {
+    BaDev D = *lane_entry(tab, blockIdx.z);      // per-lane argument block (grid z = problem of the batch)
     extern __shared__ int smi[];
     if (!ba_enter(D, BA_TRY, 0)) return;
     constexpr int BA_LPL = 64;
@@ -711,7 +720,8 @@ __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_lm_prep(BaDev D, BaW
 // slot, the 18 W entries of the partner slot and Hll | bl come straight from HBM / L2, 6 LDS atomics per candidate).
 // No staging, no per-landmark barriers or fences: the atomics are fire-and-forget until the final flush.
 constexpr int BA_WIN_META = 5 * 64 + 65;       // ints of LDS per wave: lp, seR, nR, seC, nC per entry + prefix
-__global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_schur_win(BaDev D, BaWin Wn) {
+__global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_schur_win(const BaDev* __restrict__ tab, BaWin Wn) {
+    BaDev D = *lane_entry(tab, blockIdx.z);      // per-lane argument block (grid z = problem of the batch)
     extern __shared__ double sm[];
     if (!ba_enter(D, BA_TRY, 0)) return;
     const int nc = D.nAct, T = Wn.T, TP = Wn.TP, tile = Wn.tileDoubles;
@@ -809,7 +819,8 @@ __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_schur_win(BaDev D, B
 
 // fixed-order sum of a window's partials into the reduced system (+ the BetweenFactor blocks of this linearisation);
 // grid (window, candidate).  Entries of the lower block triangle are never written nor read (the solvers mirror the upper one).
-__global__ __launch_bounds__(256) void k_ba_reduce_win(BaDev D, BaWin Wn) {
+__global__ __launch_bounds__(256) void k_ba_reduce_win(const BaDev* __restrict__ tab, BaWin Wn) {
+    BaDev D = *lane_entry(tab, blockIdx.z);      // per-lane argument block (grid z = problem of the batch)
     if (!ba_enter(D, BA_TRY, blockIdx.y)) return;
     const int win = blockIdx.x, cand = blockIdx.y, nc = D.NB, T = Wn.T, TP = Wn.TP, tile = Wn.tileDoubles, n = D.n;
     const int wa = Wn.winA[win], wb = Wn.winB[win];
@@ -844,7 +855,8 @@ __global__ __launch_bounds__(256) void k_ba_reduce_win(BaDev D, BaWin Wn) {
 // reduced camera system from D.S / D.rhs (upper triangle valid) + BetweenFactor blocks + lambda I,
 // left-looking Cholesky (2 barriers per column), the two substitutions (1 barrier per column), then
 // retracts the trial poses.  A (n x n) lives in LDS when it fits, else in D.S (L2-resident).
-__global__ __launch_bounds__(1024) void k_ba_solve(BaDev D, int useLds, int ld) {
+__global__ __launch_bounds__(1024) void k_ba_solve(const BaDev* __restrict__ tab, int useLds, int ld) {
+    BaDev D = *lane_entry(tab, blockIdx.z);      // per-lane argument block (grid z = problem of the batch)
     extern __shared__ double sm[];
     if (!ba_enter(D, BA_TRY, blockIdx.x)) return;      // one workgroup per lambda candidate
     const double lambda = D.lambda;
@@ -1021,9 +1033,11 @@ __global__ __launch_bounds__(1024) void k_ba_solve(BaDev D, int useLds, int ld) 
 // v_readlane, no LDS round trip or barrier per column.  Right-looking Cholesky (rsqrt pivots as in k_ba_solve),
 // forward substitution, transpose of L through LDS, column-oriented back substitution, pose retraction.
 constexpr int BA_WAVE_N = 60;
-__global__ __launch_bounds__(64) void k_ba_solve_wave(BaDev D) {
+__global__ __launch_bounds__(64) void k_ba_solve_wave(const BaDev* __restrict__ tab) {
+    BaDev D = *lane_entry(tab, blockIdx.z);      // per-lane argument block (grid z = problem of the batch)
     constexpr int N = BA_WAVE_N;
     __shared__ double Lt[N * (N + 1)];
+    if (D.solveKind != BA_SOLVE_WAVE) return;
     if (!ba_enter(D, BA_TRY, blockIdx.x)) return;      // one workgroup per lambda candidate
     const double lambda = D.lambda;
     const int n = D.n, lane = threadIdx.x;
@@ -1111,15 +1125,18 @@ __global__ __launch_bounds__(64) void k_ba_solve_wave(BaDev D) {
 constexpr int BA_MFMA_N = 256, BA_MFMA_NB = BA_MFMA_N / 16, BA_MFMA_NW = 8, BA_MFMA_SLOTS = 17, BA_MFMA_LD = 17;
 typedef double ba_d4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(64 * BA_MFMA_NW) void k_ba_solve_mfma(BaDev D, double* __restrict__ Lg) {
+__global__ __launch_bounds__(64 * BA_MFMA_NW) void k_ba_solve_mfma(const BaDev* __restrict__ tab, double* __restrict__ Lg) {
+    BaDev D = *lane_entry(tab, blockIdx.z);      // per-lane argument block (grid z = problem of the batch)
     extern __shared__ double sm[];
     double* P = sm;                                   // [BA_MFMA_N][BA_MFMA_LD] current panel
     double* sInv = P + BA_MFMA_N * BA_MFMA_LD;        // [16]
     double* sB = sInv + 16;                           // [BA_MFMA_N] right-hand side / solution
     __shared__ int sBad;
+    if (D.solveKind != BA_SOLVE_MFMA) return;
     if (!ba_enter(D, BA_TRY, blockIdx.x)) return;      // one workgroup per lambda candidate
     const double lambda = D.lambda;
     constexpr int N = BA_MFMA_N, NB = BA_MFMA_NB, LD = BA_MFMA_LD;
+    if (D.Lg) Lg = D.Lg;
     Lg += (size_t)D.cand * N * N;
     const int n = D.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) sBad = 0;
@@ -1276,11 +1293,13 @@ __global__ __launch_bounds__(64 * BA_MFMA_NW) void k_ba_solve_mfma(BaDev D, doub
 
 // The 10-keyframe window (6F <= 64) on ONE wave with the same MFMA scheme: the 10 lower tiles of the 64 x 64 system
 // stay in accumulators, the panel / L live in LDS, no workgroup barrier anywhere (wave-ordered LDS traffic only).
-__global__ __launch_bounds__(64) void k_ba_solve_mfma64(BaDev D) {
+__global__ __launch_bounds__(64) void k_ba_solve_mfma64(const BaDev* __restrict__ tab) {
+    BaDev D = *lane_entry(tab, blockIdx.z);      // per-lane argument block (grid z = problem of the batch)
     constexpr int N = 64, LDF = 65, LD = 17;
     __shared__ double Lf[N * LDF];                    // staged system (upper triangle valid), then L (lower)
     __shared__ double P[N * LD];                      // current panel
     __shared__ double sInv[16], sB[N];
+    if (D.solveKind != BA_SOLVE_MFMA64) return;
     if (!ba_enter(D, BA_TRY, blockIdx.x)) return;      // one workgroup per lambda candidate
     const double lambda = D.lambda;
     const int n = D.n, lane = threadIdx.x;
@@ -1411,7 +1430,8 @@ __global__ __launch_bounds__(64) void k_ba_solve_mfma64(BaDev D) {
 // kernel this replaces.)
 constexpr int CH_B = 64, CH_LD = 65, CH_PLD = 17;
 
-__global__ __launch_bounds__(256) void k_ba_chol_col(BaDev D, double* __restrict__ Lg, double* __restrict__ yG, int N, int J, int* __restrict__ failFlag) {
+__global__ __launch_bounds__(256) void k_ba_chol_col(const BaDev* __restrict__ tab, double* __restrict__ Lg, double* __restrict__ yG, int N, int J, int* __restrict__ failFlag) {
+    BaDev D = *lane_entry(tab, blockIdx.z);      // per-lane argument block (grid z = problem of the batch)
     extern __shared__ double sm[];
     double* sA = sm;                         // [64][65] L[I,K]; later the wave-private X rows of the triangular solve
     double* sB = sA + CH_B * CH_LD;          // [64][65] L[J,K]; later L_JJ
@@ -1597,7 +1617,8 @@ __global__ __launch_bounds__(256) void k_ba_chol_col(BaDev D, double* __restrict
 }
 
 // L^T x = y, block columns in reverse, one workgroup per candidate; then the trial poses
-__global__ __launch_bounds__(256) void k_ba_chol_back(BaDev D, const double* __restrict__ Lg, const double* __restrict__ yG, int N, int* __restrict__ failFlag) {
+__global__ __launch_bounds__(256) void k_ba_chol_back(const BaDev* __restrict__ tab, const double* __restrict__ Lg, const double* __restrict__ yG, int N, int* __restrict__ failFlag) {
+    BaDev D = *lane_entry(tab, blockIdx.z);      // per-lane argument block (grid z = problem of the batch)
     extern __shared__ double sm[];
     double* sL = sm;                 // [64][65] L_JJ
     double* sX = sL + CH_B * CH_LD;  // [N] solution
@@ -1643,7 +1664,8 @@ __global__ __launch_bounds__(256) void k_ba_chol_back(BaDev D, const double* __r
 
 // back-substitution: dl = Hll^-1 (bl - sum_k W_k^T dp_k); trial landmark = cur + dl.  One wave per landmark;
 // allCand: the wave serves every lambda candidate from one build of Hll / bl / W (grid y = 1), else grid y = candidate.
-__global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_back(BaDev D, int maxSlots, int allCand) {
+__global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_back(const BaDev* __restrict__ tab, int maxSlots, int allCand) {
+    BaDev D = *lane_entry(tab, blockIdx.z);      // per-lane argument block (grid z = problem of the batch)
     extern __shared__ double sm[];
     const int c0 = allCand ? 0 : (int)blockIdx.y;
     if (!ba_enter(D, BA_TRY, c0)) return;
@@ -1781,6 +1803,67 @@ __global__ __launch_bounds__(256) void k_ba_init_slots(int nPose, const double* 
     if (i < nLm) lmBase[(size_t)s * nLm + i] = lm0[i];
 }
 
+// ---- batch-only kernels: the steps the one-problem path drives from the host, per lane of a batch (grid y = lane) ----------
+struct BaLaneAux {
+    BaChi C;                                        // chi2 re-check (C.pose / C.lm: taken from the lane's current value slot)
+    int NF; const int* facPair; double* facIs;      // k_ba_mask
+    int nPose, nLm; const double* pose0; const double* lm0;     // k_ba_init_slots over the lane's NB + 1 slots
+    double* outPose; double* outLm;                 // final values, gathered for one download
+};
+__global__ __launch_bounds__(256) void k_ba_chi2_b(const BaDev* __restrict__ tab, const BaLaneAux* __restrict__ aux, int gather) {
+    const BaDev& D = *lane_entry(tab, blockIdx.y);
+    BaChi C = lane_entry(aux, blockIdx.y)->C;
+    const int* ci = (const int*)(D.ctl + CTL_INTS);
+    if (ci[CI_STATE] != BA_DONE) return;             // (lanes handed to the one-problem path keep BA_LINEARIZE / are skipped by the host)
+    const int sel = ci[CI_SEL];
+    C.pose = D.poseBase + (size_t)sel * D.K; C.lm = D.lmBase + (size_t)sel * D.lmStride;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (gather) {                                    // the pass's result next to its flags
+        const BaLaneAux& X = *lane_entry(aux, blockIdx.y);
+        for (int i = p; i < X.nPose; i += gridDim.x * 256) X.outPose[i] = ((const double*)C.pose)[i];
+        for (int i = p; i < X.nLm; i += gridDim.x * 256) X.outLm[i] = C.lm[i];
+    }
+    if (p >= C.NP) return;
+    uint8_t w = 0;
+    const int kf = C.pairKf[p], lm = C.pairLm[p], fl = C.pairFlags[p];
+    if (C.kfLocal[kf] && C.kfPresent[kf] && C.lmPresent[lm] && (fl & 3)) {
+        DPose Tcw;
+        pose_inverse(C.pose[kf], Tcw);
+        double pc[3];
+        mat3_vec(Tcw.R, C.lm + 3 * (size_t)lm, pc);
+        for (int i = 0; i < 3; i++) pc[i] += Tcw.t[i];
+        const float* uv = C.pairUv + 4 * (size_t)p;
+        if (fl & 1) {
+            if (ba_outlier(C, pc, uv[0], uv[1], C.pairOct[2 * p], false)) w = 1;
+            else if ((fl & 2) && ba_outlier(C, pc, uv[2], uv[3], C.pairOct[2 * p + 1], true)) w = 1;
+        } else if (ba_outlier(C, pc, uv[2], uv[3], C.pairOct[2 * p + 1], true)) w = 1;
+    }
+    C.wrong[p] = w;
+}
+// second pass of every lane that takes it: mask the rejected pairs' factors, values back to the caller's in every slot
+__global__ __launch_bounds__(256) void k_ba_second_pass_b(const BaDev* __restrict__ tab, const BaLaneAux* __restrict__ aux) {
+    const BaDev& D = *lane_entry(tab, blockIdx.y);
+    const BaLaneAux& X = *lane_entry(aux, blockIdx.y);
+    const int* ci = (const int*)(D.ctl + CTL_INTS);
+    if (ci[CI_STATE] != BA_LINEARIZE || !ci[CI_FIRST]) return;      // only lanes whose control block was re-armed for pass 2
+    const int i = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+    for (int f = i; f < X.NF; f += stride) if (X.C.wrong[X.facPair[f]]) X.facIs[f] = 0.0;
+    for (int s2 = 0; s2 <= D.NB; s2++) {
+        for (int q = i; q < X.nPose; q += stride) ((double*)D.poseBase)[(size_t)s2 * X.nPose + q] = X.pose0[q];
+        for (int q = i; q < X.nLm; q += stride) D.lmBase[(size_t)s2 * D.lmStride + q] = X.lm0[q];
+    }
+    for (int q = i; q < D.n * D.n + D.n; q += stride) D.SedgeBase[q] = 0;        // first linearisation of the pass accumulates into slot 0
+}
+__global__ __launch_bounds__(256) void k_ba_init_slots_b(const BaDev* __restrict__ tab, const BaLaneAux* __restrict__ aux) {
+    const BaDev& D = *lane_entry(tab, blockIdx.y);
+    const BaLaneAux& X = *lane_entry(aux, blockIdx.y);
+    const int i = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+    for (int s2 = 0; s2 <= D.NB; s2++) {
+        for (int q = i; q < X.nPose; q += stride) ((double*)D.poseBase)[(size_t)s2 * X.nPose + q] = X.pose0[q];
+        for (int q = i; q < X.nLm; q += stride) D.lmBase[(size_t)s2 * D.lmStride + q] = X.lm0[q];
+    }
+}
+
 }  // namespace vslam
 
 using namespace vslam;
@@ -1868,6 +1951,180 @@ static int bhs_slot(const char* name) { for (int i = 0; i < 16 && g_bhsName[i]; 
 #define BHS(name) do { const auto t_ = std::chrono::steady_clock::now(); g_bhsNs[bhs_slot(name)] += std::chrono::duration_cast<std::chrono::nanoseconds>(t_ - bhs_t).count(); bhs_t = t_; } while (0)
 #define BHS2(name) do {} while (0)
 #endif
+
+// Host side of ONE LM pass of one problem: the factor list ordered by (landmark, free index, pair, side), the slot table, the
+// BetweenFactor chain, graph membership - written straight into a pinned arena (device mirror: one upload).  Shared by the
+// one-problem path (ba_run) and the batched one (ba_run_batch).
+static void ba_init_ctl(double* h_ctl, int ps, int nAct) {
+    for (int i = 0; i < CTL_DOUBLES; i++) h_ctl[i] = 0;
+    h_ctl[CTL_LAMBDA] = 1e-5;
+    int* ci = (int*)(h_ctl + CTL_INTS);
+    ci[CI_STATE] = BA_LINEARIZE; ci[CI_SEL] = 0; ci[CI_ITER] = 0; ci[CI_INNER] = 0; ci[CI_MAXIT] = ps == 0 ? 5 : 10; ci[CI_FIRST] = 1;
+    ci[CI_NACT] = nAct;
+}
+struct BaPassHost {
+    int NF = 0, F = 0, n = 0, Lp = 0, NE = 0, maxSlots = 1, nSlotEntries = 0;
+    long long sumK2 = 0;
+    double* h_ctl = nullptr; BaDev* h_D = nullptr;
+    int *h_facKf = nullptr, *h_facFi = nullptr, *h_facLp = nullptr, *h_facLm = nullptr, *h_facPair = nullptr;
+    double *h_facZ = nullptr, *h_facIs = nullptr; uint8_t* h_facRight = nullptr;
+    int *h_lpStart = nullptr, *h_lpSlotStart = nullptr, *h_lpOrig = nullptr, *h_slotStart = nullptr, *h_slotFi = nullptr, *h_fidx = nullptr;
+    BaEdge* h_edges = nullptr; uint8_t *h_kfPresent = nullptr, *h_lmPresent = nullptr;
+
+    // membership, free set, landmark shard, factor counts
+    void count(const vslam_ba_problem* P, const uint8_t* wrong, int rank, int world, BaHostTmp& T) {
+        const int K = P->n_kf, L = P->n_lm, NP = P->n_pairs;
+        T.kfPresent.assign(K, 0); T.lmPresent.assign(L, 0); T.cnt.assign((size_t)L + 1, 0);
+        NF = 0;
+        for (int p = 0; p < NP; p++) {
+            if (wrong[p]) continue;
+            const int fl = P->pair_flags[p] & 3;
+            if (!fl) continue;
+            const int l = P->pair_lm[p];
+            T.kfPresent[P->pair_kf[p]] = 1; T.lmPresent[l] = 1;       // graph membership is global
+            if (l % world != rank) continue;                           // landmark shard of this rank
+            const int c = (fl & 1) + (fl >> 1);
+            T.cnt[l] += c; NF += c;
+        }
+        T.fidx.assign(K, -1);
+        F = 0;
+        for (int k = 0; k < K; k++) if (T.kfPresent[k] && !P->kf_fixed[k]) T.fidx[k] = F++;
+        n = 6 * F;
+        T.lpOf.assign(L, -1);
+        Lp = 0;
+        for (int l = 0; l < L; l++) if (T.lmPresent[l] && l % world == rank) T.lpOf[l] = Lp++;
+        // edges: id-consecutive keyframes of this pass's graph (src/OptimizationBA.cpp:750-768)
+        T.order.clear();
+        for (int k = 0; k < K; k++) if (T.kfPresent[k]) T.order.push_back(k);
+        std::sort(T.order.begin(), T.order.end(), [&](int a, int b) { return P->kf_id[a] < P->kf_id[b]; });
+        // the BetweenFactor chain is counted once (rank 0); S is summed over ranks
+        NE = rank == 0 ? std::max((int)T.order.size() - 1, 0) : 0;
+    }
+    size_t arena_bytes(int K, int L, int edgeSlots) const {
+        return 8192 + (size_t)NF * 56 + ((size_t)NF + Lp + 2) * 8 + ((size_t)Lp + 2) * 12 + (size_t)K * 8 + L +
+               (size_t)edgeSlots * NE * sizeof(BaEdge) + 26 * 256 + sizeof(BaDev);
+    }
+    bool take(PinnedArena& A, int K, int L, int edgeSlots) {
+        h_ctl = A.take<double>(CTL_DOUBLES);
+        h_D = A.take<BaDev>(1);                     // the kernels' argument block (a one-entry lane table)
+        h_facKf = A.take<int>(NF); h_facFi = A.take<int>(NF); h_facLp = A.take<int>(NF); h_facLm = A.take<int>(NF);
+        h_facZ = A.take<double>((size_t)2 * NF); h_facIs = A.take<double>(NF);
+        h_facRight = A.take<uint8_t>(NF);
+        h_facPair = A.take<int>(NF);
+        h_lpStart = A.take<int>(Lp + 1); h_lpSlotStart = A.take<int>(Lp + 1); h_lpOrig = A.take<int>(Lp);
+        h_slotStart = A.take<int>((size_t)NF + Lp + 1); h_slotFi = A.take<int>((size_t)NF + Lp + 1);
+        h_fidx = A.take<int>(K);
+        h_edges = A.take<BaEdge>((size_t)edgeSlots * NE);
+        h_kfPresent = A.take<uint8_t>(K); h_lmPresent = A.take<uint8_t>(L);
+        return h_lmPresent != nullptr;
+    }
+    // bucket by landmark (counting sort, pair order preserved), order each short bucket by free index, emit the arrays
+    void fill(const vslam_ba_problem* P, const uint8_t* wrong, int rank, int world, BaHostTmp& T, const DPose* pose0, BaPool* pool, int edgeSlots) {
+        const int K = P->n_kf, L = P->n_lm, NP = P->n_pairs;
+        for (int l = 0; l < L; l++) if (T.lpOf[l] >= 0) { h_lpOrig[T.lpOf[l]] = l; }
+        {
+            int run = 0;
+            for (int lp = 0; lp < Lp; lp++) { h_lpStart[lp] = run; run += T.cnt[h_lpOrig[lp]]; }
+            h_lpStart[Lp] = run;
+        }
+        T.fill.assign(h_lpStart, h_lpStart + Lp);
+        T.key.resize(NF); T.src.resize(NF);
+        for (int p = 0; p < NP; p++) {
+            if (wrong[p]) continue;
+            const int l = P->pair_lm[p];
+            if (l % world != rank) continue;
+            const int lp = T.lpOf[l];
+            const int fi = T.fidx[P->pair_kf[p]];
+            for (int side = 0; side < 2; side++) {
+                if (!((P->pair_flags[p] >> side) & 1)) continue;
+                const int pos = T.fill[lp]++;
+                T.key[pos] = fi; T.src[pos] = 2 * p + side;
+            }
+        }
+        // landmark ranges in parallel: (1) order each bucket by free index and count its slots, (2) after the slot prefix,
+        // write the factor arrays and the slot table.
+        // Slot table: inside a landmark the factors of fixed keyframes (fi = -1) come first, then one
+        // "slot" per free keyframe (its left and/or right factor).  Padded layout: per landmark the slot
+        // starts followed by an end sentinel, so slot s spans [slotStart[s0+s], slotStart[s0+s+1]).
+        T.ns.resize(Lp);
+        const int nChunk = pool ? std::max(1, std::min(32, Lp / 64)) : 1;
+        auto chunk = [&](int c, int& a0, int& a1) { a0 = (int)((long long)Lp * c / nChunk); a1 = (int)((long long)Lp * (c + 1) / nChunk); };
+        auto run_chunks = [&](const std::function<void(int)>& fn) { if (pool && nChunk > 1) pool->run(nChunk, fn); else for (int c = 0; c < nChunk; c++) fn(c); };
+        run_chunks([&](int c) {
+            int a0, a1;
+            chunk(c, a0, a1);
+            for (int lp = a0; lp < a1; lp++) {
+                const int f0 = h_lpStart[lp], f1 = h_lpStart[lp + 1];
+                for (int i = f0 + 1; i < f1; i++) {          // stable insertion sort by free index (buckets are ~10 long)
+                    const int k = T.key[i], v = T.src[i];
+                    int j = i - 1;
+                    while (j >= f0 && T.key[j] > k) { T.key[j + 1] = T.key[j]; T.src[j + 1] = T.src[j]; j--; }
+                    T.key[j + 1] = k; T.src[j + 1] = v;
+                }
+                int lastFi = -2, ns = 0;
+                for (int f = f0; f < f1; f++) { const int fi = T.key[f]; if (fi >= 0 && fi != lastFi) { lastFi = fi; ns++; } }
+                T.ns[lp] = ns;
+            }
+        });
+        maxSlots = 1; nSlotEntries = 0; sumK2 = 0;
+        for (int lp = 0; lp < Lp; lp++) {
+            h_lpSlotStart[lp] = nSlotEntries;
+            nSlotEntries += T.ns[lp] + 1;
+            maxSlots = std::max(maxSlots, T.ns[lp]);
+            sumK2 += (long long)T.ns[lp] * T.ns[lp];
+        }
+        run_chunks([&](int c) {
+            int a0, a1;
+            chunk(c, a0, a1);
+            for (int lp = a0; lp < a1; lp++) {
+                const int f0 = h_lpStart[lp], f1 = h_lpStart[lp + 1];
+                int se = h_lpSlotStart[lp], lastFi = -2;
+                for (int f = f0; f < f1; f++) {
+                    const int fi = T.key[f], p = T.src[f] >> 1, side = T.src[f] & 1;
+                    if (fi >= 0 && fi != lastFi) { h_slotStart[se] = f; h_slotFi[se] = fi; se++; lastFi = fi; }
+                    h_facKf[f] = P->pair_kf[p]; h_facFi[f] = fi; h_facLp[f] = lp; h_facLm[f] = P->pair_lm[p];
+                    h_facZ[2 * (size_t)f] = P->pair_uv[4 * (size_t)p + 2 * side]; h_facZ[2 * (size_t)f + 1] = P->pair_uv[4 * (size_t)p + 2 * side + 1];
+                    h_facIs[f] = 1.0 / (1.0 / (double)P->inv_sigma_factor[P->pair_octave[2 * p + side]]);
+                    h_facRight[f] = (uint8_t)side;
+                    h_facPair[f] = p;
+                }
+                h_slotStart[se] = f1; h_slotFi[se] = -1;     // end sentinel
+            }
+        });
+        h_lpSlotStart[Lp] = nSlotEntries;
+        for (int k = 0; k < K; k++) { h_fidx[k] = T.fidx[k]; h_kfPresent[k] = T.kfPresent[k]; }
+        for (int l = 0; l < L; l++) h_lmPresent[l] = T.lmPresent[l];
+        for (int i = 0; i < NE; i++) {
+            BaEdge e{};
+            e.a = T.order[i]; e.b = T.order[i + 1]; e.fa = T.fidx[e.a]; e.fb = T.fidx[e.b];
+            DPose ai;
+            pose_inverse(pose0[e.a], ai);
+            pose_compose(ai, pose0[e.b], e.measured);
+            for (int sl = 0; sl < edgeSlots; sl++) h_edges[(size_t)sl * NE + i] = e;
+        }
+    }
+};
+
+// hipFuncSetAttribute is PROCESS-global state: set once, to the largest dynamic LDS size any call may ask for (a per-call,
+// problem-dependent value written by several mapping threads while others launch the same kernel is a race on the runtime's
+// function record).  The launch's own dynamic size is what a workgroup actually gets.
+static vslam_status ba_kernel_attributes() {
+    static std::once_flag once;
+    static hipError_t err = hipSuccess;
+    std::call_once(once, [] {
+        const int cap = 160 * 1024;
+        const void* fns[] = {(const void*)k_ba_schur, (const void*)k_ba_schur_win, (const void*)k_ba_solve, (const void*)k_ba_back,
+                             (const void*)k_ba_solve_mfma, (const void*)k_ba_chol_col, (const void*)k_ba_chol_back, (const void*)k_ba_lm_prep};
+        for (const void* f : fns) {
+            hipFuncAttributes fa{};      // (the limit is on static + dynamic LDS together)
+            hipError_t e = hipFuncGetAttributes(&fa, f);
+            if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, cap - (int)fa.sharedSizeBytes);
+            if (e != hipSuccess && err == hipSuccess) err = e;
+        }
+    });
+    if (err != hipSuccess) { set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(err)); return VSLAM_ERR_HIP; }
+    return VSLAM_OK;
+}
 
 static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int device, const vslam_comm* comm) {
 #ifndef VSLAM_HOST_STAMPS
@@ -2053,156 +2310,31 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
     for (int pass = 0; pass < 2; pass++) {
         // ---- host: factor list of this pass, ordered by (landmark, free index, pair, side) -----------
         // Everything the kernels read is written straight into ONE pinned arena and uploaded with one copy.
-#ifdef VSLAM_HOST_STAMPS
-        double bhs_t2 = bhs_now();
-#endif
-        T.kfPresent.assign(K, 0); T.lmPresent.assign(L, 0); T.cnt.assign((size_t)L + 1, 0);
-        int NF = 0;
-        for (int p = 0; p < NP; p++) {
-            if (wrong[p]) continue;
-            const int fl = P->pair_flags[p] & 3;
-            if (!fl) continue;
-            const int l = P->pair_lm[p];
-            T.kfPresent[P->pair_kf[p]] = 1; T.lmPresent[l] = 1;       // graph membership is global
-            if (l % world != rank) continue;                           // landmark shard of this rank
-            const int c = (fl & 1) + (fl >> 1);
-            T.cnt[l] += c; NF += c;
-        }
-        BHS2("count");
-        T.fidx.assign(K, -1);
-        int F = 0;
-        for (int k = 0; k < K; k++) if (T.kfPresent[k] && !P->kf_fixed[k]) T.fidx[k] = F++;
-        const int n = 6 * F;
-        T.lpOf.assign(L, -1);
-        int Lp = 0;
-        for (int l = 0; l < L; l++) if (T.lmPresent[l] && l % world == rank) T.lpOf[l] = Lp++;
-        // edges: id-consecutive keyframes of this pass's graph (src/OptimizationBA.cpp:750-768)
-        T.order.clear();
-        for (int k = 0; k < K; k++) if (T.kfPresent[k]) T.order.push_back(k);
-        std::sort(T.order.begin(), T.order.end(), [&](int a, int b) { return P->kf_id[a] < P->kf_id[b]; });
-        // the BetweenFactor chain is counted once (rank 0); S is summed over ranks
-        const int NE = rank == 0 ? std::max((int)T.order.size() - 1, 0) : 0;
-
-        VS_HIP(A.ensure(8192 + (size_t)NF * 56 + ((size_t)NF + Lp + 2) * 8 + ((size_t)Lp + 2) * 12 + (size_t)K * 8 + L +
-                        (size_t)(BA_MAX_NB + 1) * NE * sizeof(BaEdge) + 24 * 256, stream));
+        BaPassHost H;
+        H.count(P, wrong.data(), rank, world, T);
+        const int NF = H.NF, F = H.F, n = H.n, Lp = H.Lp, NE = H.NE;
+        VS_HIP(A.ensure(H.arena_bytes(K, L, specLin ? nSlots : 1), stream));
         A.reset();
-        double* h_ctl = A.take<double>(CTL_DOUBLES);
-        int* h_facKf = A.take<int>(NF); int* h_facFi = A.take<int>(NF); int* h_facLp = A.take<int>(NF); int* h_facLm = A.take<int>(NF);
-        double* h_facZ = A.take<double>((size_t)2 * NF); double* h_facIs = A.take<double>(NF);
-        uint8_t* h_facRight = A.take<uint8_t>(NF);
-        int* h_facPair = A.take<int>(NF);
-        int* h_lpStart = A.take<int>(Lp + 1); int* h_lpSlotStart = A.take<int>(Lp + 1); int* h_lpOrig = A.take<int>(Lp);
-        int* h_slotStart = A.take<int>((size_t)NF + Lp + 1); int* h_slotFi = A.take<int>((size_t)NF + Lp + 1);
-        int* h_fidx = A.take<int>(K);
-        BaEdge* h_edges = A.take<BaEdge>((size_t)(specLin ? nSlots : 1) * NE);
-        uint8_t* h_kfPresent = A.take<uint8_t>(K); uint8_t* h_lmPresent = A.take<uint8_t>(L);
-        if (!h_lmPresent) { set_error("local BA: upload arena too small"); return VSLAM_ERR_CAPACITY; }
-
-        // bucket by landmark (counting sort, pair order preserved), then order each short bucket by free index
-        for (int l = 0; l < L; l++) if (T.lpOf[l] >= 0) { h_lpOrig[T.lpOf[l]] = l; }
-        {
-            int run = 0;
-            for (int lp = 0; lp < Lp; lp++) { h_lpStart[lp] = run; run += T.cnt[h_lpOrig[lp]]; }
-            h_lpStart[Lp] = run;
-        }
-        BHS2("arena");
-        T.fill.assign(h_lpStart, h_lpStart + Lp);
-        T.key.resize(NF); T.src.resize(NF);
-        for (int p = 0; p < NP; p++) {
-            if (wrong[p]) continue;
-            const int l = P->pair_lm[p];
-            if (l % world != rank) continue;
-            const int lp = T.lpOf[l];
-            const int fi = T.fidx[P->pair_kf[p]];
-            for (int side = 0; side < 2; side++) {
-                if (!((P->pair_flags[p] >> side) & 1)) continue;
-                const int pos = T.fill[lp]++;
-                T.key[pos] = fi; T.src[pos] = 2 * p + side;
-            }
-        }
-        BHS2("scatter");
-        // landmark ranges in parallel: (1) order each bucket by free index and count its slots, (2) after the slot prefix,
-        // write the factor arrays and the slot table.
-        // Slot table: inside a landmark the factors of fixed keyframes (fi = -1) come first, then one
-        // "slot" per free keyframe (its left and/or right factor).  Padded layout: per landmark the slot
-        // starts followed by an end sentinel, so slot s spans [slotStart[s0+s], slotStart[s0+s+1]).
-        T.ns.resize(Lp);
-        const int nChunk = std::max(1, std::min(32, Lp / 64));
-        auto chunk = [&](int c, int& a0, int& a1) { a0 = (int)((long long)Lp * c / nChunk); a1 = (int)((long long)Lp * (c + 1) / nChunk); };
-        ws->pool.run(nChunk, [&](int c) {
-            int a0, a1;
-            chunk(c, a0, a1);
-            for (int lp = a0; lp < a1; lp++) {
-                const int f0 = h_lpStart[lp], f1 = h_lpStart[lp + 1];
-                for (int i = f0 + 1; i < f1; i++) {          // stable insertion sort by free index (buckets are ~10 long)
-                    const int k = T.key[i], v = T.src[i];
-                    int j = i - 1;
-                    while (j >= f0 && T.key[j] > k) { T.key[j + 1] = T.key[j]; T.src[j + 1] = T.src[j]; j--; }
-                    T.key[j + 1] = k; T.src[j + 1] = v;
-                }
-                int lastFi = -2, ns = 0;
-                for (int f = f0; f < f1; f++) { const int fi = T.key[f]; if (fi >= 0 && fi != lastFi) { lastFi = fi; ns++; } }
-                T.ns[lp] = ns;
-            }
-        });
-        int maxSlots = 1, nSlotEntries = 0;
-        long long sumK2 = 0;
-        for (int lp = 0; lp < Lp; lp++) {
-            h_lpSlotStart[lp] = nSlotEntries;
-            nSlotEntries += T.ns[lp] + 1;
-            maxSlots = std::max(maxSlots, T.ns[lp]);
-            sumK2 += (long long)T.ns[lp] * T.ns[lp];
-        }
-        ws->pool.run(nChunk, [&](int c) {
-            int a0, a1;
-            chunk(c, a0, a1);
-            for (int lp = a0; lp < a1; lp++) {
-                const int f0 = h_lpStart[lp], f1 = h_lpStart[lp + 1];
-                int se = h_lpSlotStart[lp], lastFi = -2;
-                for (int f = f0; f < f1; f++) {
-                    const int fi = T.key[f], p = T.src[f] >> 1, side = T.src[f] & 1;
-                    if (fi >= 0 && fi != lastFi) { h_slotStart[se] = f; h_slotFi[se] = fi; se++; lastFi = fi; }
-                    h_facKf[f] = P->pair_kf[p]; h_facFi[f] = fi; h_facLp[f] = lp; h_facLm[f] = P->pair_lm[p];
-                    h_facZ[2 * (size_t)f] = P->pair_uv[4 * (size_t)p + 2 * side]; h_facZ[2 * (size_t)f + 1] = P->pair_uv[4 * (size_t)p + 2 * side + 1];
-                    h_facIs[f] = 1.0 / (1.0 / (double)P->inv_sigma_factor[P->pair_octave[2 * p + side]]);
-                    h_facRight[f] = (uint8_t)side;
-                    h_facPair[f] = p;
-                }
-                h_slotStart[se] = f1; h_slotFi[se] = -1;     // end sentinel
-            }
-        });
-        h_lpSlotStart[Lp] = nSlotEntries;
-        BHS2("sort+emit");
-        for (int k = 0; k < K; k++) { h_fidx[k] = T.fidx[k]; h_kfPresent[k] = T.kfPresent[k]; }
-        for (int l = 0; l < L; l++) h_lmPresent[l] = T.lmPresent[l];
-        for (int i = 0; i < NE; i++) {
-            BaEdge e{};
-            e.a = T.order[i]; e.b = T.order[i + 1]; e.fa = T.fidx[e.a]; e.fb = T.fidx[e.b];
-            DPose ai;
-            pose_inverse(pose0[e.a], ai);
-            pose_compose(ai, pose0[e.b], e.measured);
-            for (int sl = 0; sl < (specLin ? nSlots : 1); sl++) h_edges[(size_t)sl * NE + i] = e;
-        }
+        if (!H.take(A, K, L, specLin ? nSlots : 1)) { set_error("local BA: upload arena too small"); return VSLAM_ERR_CAPACITY; }
+        H.fill(P, wrong.data(), rank, world, T, pose0.data(), &ws->pool, specLin ? nSlots : 1);
+        double* const h_ctl = H.h_ctl; BaDev* const h_D = H.h_D;
+        int* const h_facKf = H.h_facKf; int* const h_facFi = H.h_facFi; int* const h_facLp = H.h_facLp; int* const h_facLm = H.h_facLm;
+        double* const h_facZ = H.h_facZ; double* const h_facIs = H.h_facIs; uint8_t* const h_facRight = H.h_facRight; int* const h_facPair = H.h_facPair;
+        int* const h_lpStart = H.h_lpStart; int* const h_lpSlotStart = H.h_lpSlotStart; int* const h_lpOrig = H.h_lpOrig;
+        int* const h_slotStart = H.h_slotStart; int* const h_slotFi = H.h_slotFi; int* const h_fidx = H.h_fidx;
+        BaEdge* const h_edges = H.h_edges; uint8_t* const h_kfPresent = H.h_kfPresent; uint8_t* const h_lmPresent = H.h_lmPresent;
+        const int maxSlots = H.maxSlots, nSlotEntries = H.nSlotEntries;
+        const long long sumK2 = H.sumK2;
         // ---- LM control block (GTSAM 4.2 policy; k_ba_ctl) ---------------------------------------------
         const double relTol = 1e-5, absTol = 1e-5;
         // adaptive look-ahead for large problems (every candidate costs a full Schur / back-substitution / evaluation pass)
         const int adaptEnv = [] { const char* e = getenv("VSLAM_BA_ADAPTIVE"); return e ? atoi(e) : -1; }();
         const bool adaptive = NB > 1 && (adaptEnv >= 0 ? adaptEnv != 0 : NF > 200000);
-        auto init_ctl = [&](int ps) {
-            for (int i = 0; i < CTL_DOUBLES; i++) h_ctl[i] = 0;
-            h_ctl[CTL_LAMBDA] = 1e-5;
-            int* ci = (int*)(h_ctl + CTL_INTS);
-            ci[CI_STATE] = BA_LINEARIZE; ci[CI_SEL] = 0; ci[CI_ITER] = 0; ci[CI_INNER] = 0; ci[CI_MAXIT] = ps == 0 ? 5 : 10; ci[CI_FIRST] = 1;
-            ci[CI_NACT] = adaptive ? 1 : NB;
-        };
+        auto init_ctl = [&](int ps) { ba_init_ctl(h_ctl, ps, adaptive ? 1 : NB); };
         init_ctl(pass);
         BHS("prep");
 
-        // ---- upload ------------------------------------------------------------------------------
-        VS_HIP(A.upload(stream));
-#ifndef VSLAM_HOST_STAMPS
-        BHS("u_arena");
-#endif
+        // ---- device buffers, argument block, then ONE upload ----------------------------------------------
         const size_t sysStride = (size_t)n * n + 2 * n + 8, seDoubles = (size_t)n * n + n;
         VS_HIP(d_facJ.alloc((size_t)20 * NF * (specLin ? nSlots : 1)));
         VS_HIP(d_dP.alloc((size_t)NB * n)); VS_HIP(d_dL.alloc((size_t)NB * 3 * Lp));
@@ -2324,7 +2456,6 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
             Wn.part = d_Spart.p;
             VS_HIP(ws->d_winW.alloc((size_t)std::max(nSlotEntries, 1) * 18)); VS_HIP(ws->d_winH.alloc((size_t)std::max(Lp, 1) * BA_WIN_HG));
             Wn.Wg = ws->d_winW.p; Wn.Hg = ws->d_winH.p;
-            VS_HIP(hipFuncSetAttribute((const void*)k_ba_schur_win, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurLds));
             // the lower block triangle is never written (nor read by a solver): keep it at zero for the all-reduce
             VS_HIP(hipMemsetAsync(d_S.p, 0, sysStride * NB * sizeof(double), stream));
         }
@@ -2350,14 +2481,11 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
 #endif
         if (n > 1024) { set_error("local BA: more than 170 free keyframes is not supported"); return VSLAM_ERR_CAPACITY; }
         if (schurLds > 160 * 1024) { set_error("local BA: landmark with too many views for the LDS staging"); return VSLAM_ERR_CAPACITY; }
-        if (ldsS) VS_HIP(hipFuncSetAttribute((const void*)k_ba_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurLds));
-        if (solveLds) VS_HIP(hipFuncSetAttribute((const void*)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solveLdsBytes));
-        if (backLds > 48 * 1024) VS_HIP(hipFuncSetAttribute((const void*)k_ba_back, hipFuncAttributeMaxDynamicSharedMemorySize, (int)backLds));
+        VS_CHECK(ba_kernel_attributes());
         const size_t mfmaLds = ((size_t)BA_MFMA_N * BA_MFMA_LD + 16 + BA_MFMA_N) * sizeof(double);
         static const bool useMfma = !getenv("VSLAM_BA_NO_MFMA");
         if (n > BA_WAVE_N && n <= BA_MFMA_N && useMfma) {
             VS_HIP(d_Lg.alloc((size_t)BA_MFMA_N * BA_MFMA_N * NB));
-            VS_HIP(hipFuncSetAttribute((const void*)k_ba_solve_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfmaLds));
         }
         // larger systems: block-column MFMA Cholesky (k_ba_chol_col / k_ba_chol_back)
         const bool useChol = n > BA_MFMA_N && useMfma;
@@ -2368,12 +2496,14 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
             VS_HIP(d_Lg.alloc((size_t)cholN * cholN * NB));
             VS_HIP(d_cholY.alloc((size_t)cholN * NB));
             if (!d_cholFail.p) { VS_HIP(d_cholFail.alloc(BA_MAX_NB)); VS_HIP(hipMemsetAsync(d_cholFail.p, 0, BA_MAX_NB * sizeof(int), stream)); }
-            VS_HIP(hipFuncSetAttribute((const void*)k_ba_chol_col, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cholColLds));
-            VS_HIP(hipFuncSetAttribute((const void*)k_ba_chol_back, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cholBackLds));
         }
 #ifndef VSLAM_HOST_STAMPS
         BHS("u_attr");
 #endif
+        D.solveKind = (n <= 64 && useMfma) ? BA_SOLVE_MFMA64 : n <= BA_WAVE_N ? BA_SOLVE_WAVE : (n <= BA_MFMA_N && useMfma) ? BA_SOLVE_MFMA : BA_SOLVE_LARGE;
+        *h_D = D;
+        const BaDev* const dD = A.dev(h_D);
+        VS_HIP(A.upload(stream));
         BHS("upload");
 
         // ---- LM: speculative steps, the device decides (k_ba_ctl) -----------------------------------
@@ -2386,50 +2516,53 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         const int nObs = NF ? obsBlocks : 0;
         VS_HIP(hipMemsetAsync(d_Sedge.p, 0, ((size_t)n * n + n) * sizeof(double), stream));     // first linearisation; later ones: see k_ba_factors
         auto step = [&](bool first) -> vslam_status {
-            int t = g_baTimer.begin("ba_linearize");
+            int t = -1;
             // with speculative linearisation only the first step of a pass linearises on its own
-            if (first || !specLin) hipLaunchKernelGGL(k_ba_factors<0>, dim3(facBlocks), dim3(256), 0, stream, D, nObs, fuseCtl, relTol, absTol);
-            g_baTimer.end(t);
+            if (first || !specLin) {
+                t = g_baTimer.begin("ba_linearize");
+                hipLaunchKernelGGL(k_ba_factors<0>, dim3(facBlocks), dim3(256), 0, stream, dD, nObs, fuseCtl, relTol, absTol);
+                g_baTimer.end(t);
+            }
             if (comm) {
                 const int tc = g_baTimer.begin("ba_allreduce"); VS_CHECK(comm_allreduce(comm, d_sums.p, 1, stream)); g_baTimer.end(tc);
-                hipLaunchKernelGGL(k_ba_ctl, dim3(1), dim3(256), 0, stream, D, 0, relTol, absTol);
+                hipLaunchKernelGGL(k_ba_ctl, dim3(1), dim3(256), 0, stream, dD, 0, relTol, absTol);
             }
             t = g_baTimer.begin("ba_schur");
             if (n > 0) {
-                if (ldsS) hipLaunchKernelGGL(k_ba_schur, dim3(lmBlocks, sharedW ? 1 : NB), dim3(64 * schurWaves), schurLds, stream, D, maxSlots, sharedW);
+                if (ldsS) hipLaunchKernelGGL(k_ba_schur, dim3(lmBlocks, sharedW ? 1 : NB), dim3(64 * schurWaves), schurLds, stream, dD, maxSlots, sharedW);
                 else if (nWinWg) {
                     hipLaunchKernelGGL(k_ba_lm_prep, dim3(std::max(1, std::min((Lp + BA_SCHUR_WAVES - 1) / BA_SCHUR_WAVES, 4 * nCU))), dim3(64 * BA_SCHUR_WAVES),
-                                       (size_t)BA_SCHUR_WAVES * maxSlots * sizeof(int), stream, D, Wn, maxSlots);
-                    hipLaunchKernelGGL(k_ba_schur_win, dim3(nWinWg), dim3(64 * schurWaves), schurLds, stream, D, Wn);
+                                       (size_t)BA_SCHUR_WAVES * maxSlots * sizeof(int), stream, dD, Wn, maxSlots);
+                    hipLaunchKernelGGL(k_ba_schur_win, dim3(nWinWg), dim3(64 * schurWaves), schurLds, stream, dD, Wn);
                 }
             }
             g_baTimer.end(t);
             t = g_baTimer.begin("ba_solve");
             if (n > 0) {     // sum of the partial systems + BetweenFactor blocks
-                if (ldsS) hipLaunchKernelGGL(k_ba_reduce, dim3(((int)sysDoubles + 31) / 32, NB), dim3(256), 0, stream, D, lmBlocks);
-                else hipLaunchKernelGGL(k_ba_reduce_win, dim3(Wn.nWin, NB), dim3(256), 0, stream, D, Wn);
+                if (ldsS) hipLaunchKernelGGL(k_ba_reduce, dim3(((int)sysDoubles + 31) / 32, NB), dim3(256), 0, stream, dD, lmBlocks);
+                else hipLaunchKernelGGL(k_ba_reduce_win, dim3(Wn.nWin, NB), dim3(256), 0, stream, dD, Wn);
             }
             // the NB candidates' systems are contiguous (sysStride apart): one all-reduce for all of them
             if (comm && n > 0) { const int tc = g_baTimer.begin("ba_allreduce"); VS_CHECK(comm_allreduce(comm, d_S.p, sysStride * (NB - 1) + (size_t)n * n + n, stream)); g_baTimer.end(tc); }
-            if (n <= 64 && useMfma) hipLaunchKernelGGL(k_ba_solve_mfma64, dim3(NB), dim3(64), 0, stream, D);
-            else if (n <= BA_WAVE_N) hipLaunchKernelGGL(k_ba_solve_wave, dim3(NB), dim3(64), 0, stream, D);
-            else if (n <= BA_MFMA_N && useMfma) hipLaunchKernelGGL(k_ba_solve_mfma, dim3(NB), dim3(64 * BA_MFMA_NW), mfmaLds, stream, D, d_Lg.p);
+            if (n <= 64 && useMfma) hipLaunchKernelGGL(k_ba_solve_mfma64, dim3(NB), dim3(64), 0, stream, dD);
+            else if (n <= BA_WAVE_N) hipLaunchKernelGGL(k_ba_solve_wave, dim3(NB), dim3(64), 0, stream, dD);
+            else if (n <= BA_MFMA_N && useMfma) hipLaunchKernelGGL(k_ba_solve_mfma, dim3(NB), dim3(64 * BA_MFMA_NW), mfmaLds, stream, dD, d_Lg.p);
             else if (useChol) {
                 for (int J = 0; J < cholN / CH_B; J++)
-                    hipLaunchKernelGGL(k_ba_chol_col, dim3(cholN / CH_B - J, NB), dim3(256), cholColLds, stream, D, d_Lg.p, d_cholY.p, cholN, J, d_cholFail.p);
-                hipLaunchKernelGGL(k_ba_chol_back, dim3(NB), dim3(256), cholBackLds, stream, D, (const double*)d_Lg.p, (const double*)d_cholY.p, cholN, d_cholFail.p);
+                    hipLaunchKernelGGL(k_ba_chol_col, dim3(cholN / CH_B - J, NB), dim3(256), cholColLds, stream, dD, d_Lg.p, d_cholY.p, cholN, J, d_cholFail.p);
+                hipLaunchKernelGGL(k_ba_chol_back, dim3(NB), dim3(256), cholBackLds, stream, dD, (const double*)d_Lg.p, (const double*)d_cholY.p, cholN, d_cholFail.p);
             } else hipLaunchKernelGGL(k_ba_solve, dim3(NB), dim3(std::max(64, vslam::align_up(n, 64))),
-                                    solveLds ? solveLdsBytes : 64, stream, D, solveLds ? 1 : 0, solveLds ? ldA : n);
+                                    solveLds ? solveLdsBytes : 64, stream, dD, solveLds ? 1 : 0, solveLds ? ldA : n);
             g_baTimer.end(t);
             t = g_baTimer.begin("ba_back");
-            if (Lp) hipLaunchKernelGGL(k_ba_back, dim3(backBlocks, sharedBack ? 1 : NB), dim3(64 * backWaves), backLds, stream, D, maxSlots, sharedBack);
+            if (Lp) hipLaunchKernelGGL(k_ba_back, dim3(backBlocks, sharedBack ? 1 : NB), dim3(64 * backWaves), backLds, stream, dD, maxSlots, sharedBack);
             g_baTimer.end(t);
             t = g_baTimer.begin("ba_eval");
-            hipLaunchKernelGGL(k_ba_factors<1>, dim3(facBlocks, NB), dim3(256), 0, stream, D, nObs, fuseCtl, relTol, absTol);
+            hipLaunchKernelGGL(k_ba_factors<1>, dim3(facBlocks, NB), dim3(256), 0, stream, dD, nObs, fuseCtl, relTol, absTol);
             g_baTimer.end(t);
             if (comm) {
                 const int tc = g_baTimer.begin("ba_allreduce"); VS_CHECK(comm_allreduce(comm, d_sums.p + SUMS_CAND, (size_t)2 * NB, stream)); g_baTimer.end(tc);
-                hipLaunchKernelGGL(k_ba_ctl, dim3(1), dim3(256), 0, stream, D, 1, relTol, absTol);
+                hipLaunchKernelGGL(k_ba_ctl, dim3(1), dim3(256), 0, stream, dD, 1, relTol, absTol);
             }
             VS_HIP(hipGetLastError());
             return VSLAM_OK;
@@ -2453,6 +2586,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         R->report[ps].final_error = h_ctlOut[CTL_ERROR];
         R->report[ps].lambda = h_ctlOut[CTL_LAMBDA];
         R->n_residuals = nfStat; R->n_landmarks = lpStat; R->n_free_kf = F; R->sum_k2 = k2Stat;
+        R->rounds = (ps == 0 ? 0 : R->rounds) + co[CI_ROUNDS];
 
         if (comm) {
             // every rank needs all landmarks for the chi2 pass and the result: exchange the shard updates
@@ -2556,6 +2690,385 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
     return VSLAM_OK;
 }
 
+// ---- batched local BA: N independent tracker-window problems, ONE launch per stage for all of them -------------------------------
+// The local mapping of a lockstep group (batch.hip): the passes that become due at a step are optimised together.  Each problem
+// ("lane") keeps its own argument block (BaDev, entry of a device table; grid z = lane), its own device-side LM control block
+// and value slots, so the LM trajectories are exactly those of N one-problem calls; lanes that finish early leave every
+// kernel at ba_enter.  Host work per pass: one upload, a poll of the N control blocks every few rounds, one download of the
+// chi2 flags; the second pass is re-armed for all lanes together (mask, no rebuild).  Problems outside the tracker-window
+// class (more than BA_LDS_MAX_F free keyframes, empty graphs) and lanes whose second graph loses a keyframe take the
+// one-problem path.
+static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_result* const* Rs, int N, int device) {
+    if (N <= 0 || !Ps || !Rs) return VSLAM_ERR_INVALID;
+    if (N == 1) return ba_run(Ps[0], Rs[0], device, nullptr);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available (no CPU fallback)"); return VSLAM_ERR_NO_DEVICE; }
+    if (device < 0 || device >= ndev) return VSLAM_ERR_INVALID;
+    VS_HIP(hipSetDevice(device));
+    struct BatchWs {
+        hipStream_t stream = nullptr; int device = -1;
+        PinnedArena arena;
+        DevBuf<uint8_t> d_mem;
+        uint8_t* h_back = nullptr; size_t backCap = 0;        // pinned landing area: control blocks | chi2 flags | results
+        BaPool pool;
+        void release() {
+            if (device < 0 || hipSetDevice(device) != hipSuccess) return;
+            if (stream) { hipStreamSynchronize(stream); hipStreamDestroy(stream); }
+            if (d_mem.p) hipFree(d_mem.p);
+            if (arena.d) hipFree(arena.d);
+            if (arena.h) hipHostFree(arena.h);
+            if (h_back) hipHostFree(h_back);
+        }
+    };
+    static thread_local std::unique_ptr<BatchWs> bws;
+    static thread_local void (*prevRelease)() = nullptr;
+    if (!bws || bws->device != device) {
+        if (bws) bws->release();
+        bws.reset(new BatchWs()); bws->device = device;
+        VS_HIP(vslam::create_side_stream(&bws->stream));
+        bws->pool.start(3);
+        prevRelease = g_baRelease;
+        g_baRelease = []() { if (bws) { bws->release(); bws.reset(); } if (prevRelease) { auto f = prevRelease; prevRelease = nullptr; f(); } g_baTimer.destroy(); };
+    }
+    BatchWs& W = *bws;
+    hipStream_t stream = W.stream;
+    g_baTimer.reset(); g_baTimer.stream = stream; g_baTimer.multi = true;
+
+    static const int nbEnv = [] { const char* e = getenv("VSLAM_BA_LOOKAHEAD"); return e ? std::max(1, std::min((int)BA_MAX_NB, atoi(e))) : (int)BA_MAX_NB; }();
+    const int NB = g_baLookahead > 0 ? std::min(g_baLookahead, (int)BA_MAX_NB) : nbEnv, nSlots = NB + 1;
+    static const bool useMfma = !getenv("VSLAM_BA_NO_MFMA");
+    const double relTol = 1e-5, absTol = 1e-5;
+
+    struct Lane {
+        const vslam_ba_problem* P; vslam_ba_result* R; int K, L, NP;
+        std::vector<DPose> pose0; BaHostTmp T; BaPassHost H; bool single = false;
+        std::vector<uint8_t> wrong;
+        // constants of the call in the arena
+        DPose* h_pose0; double* h_lm0; int *h_pairKf, *h_pairLm, *h_pairOct; uint8_t *h_pairFlags, *h_kfLocal; float* h_pairUv;
+        // device slices
+        DPose* d_poseS; double *d_lmS, *d_facJ, *d_dP, *d_dL, *d_S, *d_Sedge, *d_partial, *d_Spart, *d_sums, *d_Lg; int* d_flags; uint8_t* d_wrong;
+        double *d_outPose, *d_outLm;
+        size_t oWrong, oOut;          // offsets in the landing area
+        long long NF2 = 0, Lp2 = 0, k2 = 0;
+        bool pass2 = false;
+    };
+    std::vector<Lane> lanes(N);
+    std::vector<int> singles;
+    for (int i = 0; i < N; i++) {
+        Lane& q = lanes[i];
+        const vslam_ba_problem* P = Ps[i]; vslam_ba_result* R = Rs[i];
+        if (!P || !R || P->n_kf < 1 || P->n_lm < 0 || P->n_pairs < 0 || P->n_levels < 1 || P->n_levels > MAX_LEVELS ||
+            !P->kf_pose_wc || !P->kf_id || !P->kf_fixed || !P->kf_local || !P->sigma_factor || !P->inv_sigma_factor ||
+            !R->kf_pose_wc || !R->lm_xyz || !R->pair_wrong || (P->n_lm > 0 && !P->lm_xyz) ||
+            (P->n_pairs > 0 && (!P->pair_kf || !P->pair_lm || !P->pair_flags || !P->pair_uv || !P->pair_octave))) {
+            set_error("vslam_local_ba_batch: invalid problem %d", i);
+            return VSLAM_ERR_INVALID;
+        }
+        q.P = P; q.R = R; q.K = P->n_kf; q.L = P->n_lm; q.NP = P->n_pairs;
+        for (int p = 0; p < q.NP; p++)
+            if (P->pair_kf[p] < 0 || P->pair_kf[p] >= q.K || P->pair_lm[p] < 0 || P->pair_lm[p] >= q.L ||
+                P->pair_octave[2 * p] < 0 || P->pair_octave[2 * p] >= P->n_levels || P->pair_octave[2 * p + 1] < 0 ||
+                P->pair_octave[2 * p + 1] >= P->n_levels) { set_error("vslam_local_ba_batch: pair index out of range (problem %d)", i); return VSLAM_ERR_INVALID; }
+        if (memcmp(&P->rig, &Ps[0]->rig, sizeof(P->rig)) || P->n_levels != Ps[0]->n_levels) q.single = true;      // (per-lane rigs would work; not needed)
+        q.wrong.assign(std::max(q.NP, 1), 0);
+        q.pose0.resize(q.K);
+        for (int k = 0; k < q.K; k++) pose_from_rm16(P->kf_pose_wc + 16 * (size_t)k, q.pose0[k]);
+    }
+    // ---- host: count, arena layout, fill (lanes in parallel) -----------------------------------------------------------
+    W.pool.run(N, [&](int i) {
+        Lane& q = lanes[i];
+        q.H.count(q.P, q.wrong.data(), 0, 1, q.T);
+        if (q.H.F > BA_LDS_MAX_F || q.H.n <= 0 || q.H.NF <= 0 || q.NP <= 0) q.single = true;
+    });
+    std::vector<int> act;
+    for (int i = 0; i < N; i++) (lanes[i].single ? singles : act).push_back(i);
+    const int NL = (int)act.size();
+    auto run_singles = [&]() -> vslam_status { for (int i : singles) VS_CHECK(ba_run(Ps[i], Rs[i], device, nullptr)); return VSLAM_OK; };
+    if (NL == 0) return run_singles();
+    auto& A = W.arena;
+    size_t arenaBytes = 4096 + (size_t)NL * (CTL_DOUBLES * 8 + sizeof(BaDev) + sizeof(BaLaneAux) + 768);
+    for (int i : act) {
+        Lane& q = lanes[i];
+        arenaBytes += q.H.arena_bytes(q.K, q.L, nSlots) + (size_t)q.K * (sizeof(DPose) + 1) + (size_t)q.L * 24 + (size_t)q.NP * (4 + 4 + 8 + 1 + 16) + 10 * 256;
+    }
+    VS_HIP(A.ensure(arenaBytes, stream));
+    A.reset();
+    double* h_ctlAll = A.take<double>((size_t)CTL_DOUBLES * NL);         // contiguous: polled with one copy
+    BaDev* h_tab = A.take<BaDev>(NL);
+    BaLaneAux* h_aux = A.take<BaLaneAux>(NL);
+    bool fits = h_aux != nullptr;
+    for (int a = 0; a < NL && fits; a++) {
+        Lane& q = lanes[act[a]];
+        q.h_pose0 = A.take<DPose>(q.K); q.h_lm0 = A.take<double>((size_t)3 * q.L);
+        q.h_pairKf = A.take<int>(q.NP); q.h_pairLm = A.take<int>(q.NP); q.h_pairOct = A.take<int>((size_t)2 * q.NP);
+        q.h_pairFlags = A.take<uint8_t>(q.NP); q.h_pairUv = A.take<float>((size_t)4 * q.NP); q.h_kfLocal = A.take<uint8_t>(q.K);
+        fits = q.h_kfLocal && q.H.take(A, q.K, q.L, nSlots);
+        q.H.h_ctl = h_ctlAll + (size_t)CTL_DOUBLES * a; q.H.h_D = h_tab + a;      // (the lane's slots of the shared tables)
+    }
+    if (!fits) { set_error("local BA batch: upload arena too small"); return VSLAM_ERR_CAPACITY; }
+    W.pool.run(NL, [&](int a) {
+        Lane& q = lanes[act[a]];
+        const vslam_ba_problem* P = q.P;
+        memcpy(q.h_pose0, q.pose0.data(), (size_t)q.K * sizeof(DPose));
+        if (q.L) memcpy(q.h_lm0, P->lm_xyz, (size_t)3 * q.L * sizeof(double));
+        memcpy(q.h_pairKf, P->pair_kf, (size_t)q.NP * 4); memcpy(q.h_pairLm, P->pair_lm, (size_t)q.NP * 4);
+        memcpy(q.h_pairOct, P->pair_octave, (size_t)2 * q.NP * 4); memcpy(q.h_pairFlags, P->pair_flags, q.NP);
+        memcpy(q.h_pairUv, P->pair_uv, (size_t)4 * q.NP * 4); memcpy(q.h_kfLocal, P->kf_local, q.K);
+        q.H.fill(P, q.wrong.data(), 0, 1, q.T, q.pose0.data(), nullptr, nSlots);
+        ba_init_ctl(q.H.h_ctl, 0, NB);
+    });
+    // ---- launch geometry shared by the lanes ---------------------------------------------------------------------------
+    int maxSlots = 1, nMax = 0, neMax = 0, nfMax = 0, lpMax = 0, npMax = 0, valMax = 0;
+    bool anyMfma64 = false, anyWave = false, anyMfma = false;
+    for (int i : act) {
+        const Lane& q = lanes[i];
+        maxSlots = std::max(maxSlots, q.H.maxSlots); nMax = std::max(nMax, q.H.n); neMax = std::max(neMax, q.H.NE);
+        nfMax = std::max(nfMax, q.H.NF); lpMax = std::max(lpMax, q.H.Lp); npMax = std::max(npMax, q.NP);
+        valMax = std::max(valMax, std::max(q.K * (int)(sizeof(DPose) / sizeof(double)), 3 * q.L));
+    }
+    const int nCU = 256;
+    const int obsBlocks = std::max(1, std::min((nfMax + 255) / 256, std::max(16, 2 * nCU / NL)));
+    const int facBlocks = obsBlocks + std::max(neMax, 1);
+    const size_t sysMax = (size_t)nMax * nMax + nMax;
+    constexpr int SCHUR_LPW = 64 / BA_LPL_SCHUR, BACK_LPW = 64 / BA_LPL_BACK;
+    auto stage_lds = [&](int nw) { return (size_t)nw * SCHUR_LPW * 2 * maxSlots * 18 * sizeof(double) + (size_t)nw * SCHUR_LPW * maxSlots * sizeof(int) + 16; };
+    auto schur_lds = [&](int nw, int copies) { return copies * sysMax * sizeof(double) + stage_lds(nw); };
+    int sharedW = 0, schurWaves = BA_SCHUR_WAVES;
+    if (NB > 1) for (int nw : {16, 12, 8, 6, 4, 2}) if (schur_lds(nw, NB) <= 150 * 1024) { sharedW = 1; schurWaves = nw; break; }
+    if (!sharedW) while (schurWaves > 2 && schur_lds(schurWaves, 1) > 150 * 1024) schurWaves /= 2;
+    const size_t schurLds = schur_lds(schurWaves, sharedW ? NB : 1);
+    if (schurLds > 160 * 1024) { set_error("local BA batch: landmark with too many views for the LDS staging"); return VSLAM_ERR_CAPACITY; }
+    const int schurUnits = schurWaves * SCHUR_LPW;
+    const int lmBlocks = std::max(1, std::min((lpMax + schurUnits - 1) / schurUnits, std::max(16, 2 * nCU / NL)));
+    int backWaves = BA_SCHUR_WAVES / BACK_LPW;
+    auto back_lds = [&](int nw) { return (size_t)nw * BACK_LPW * maxSlots * 18 * sizeof(double) + (size_t)nw * BACK_LPW * maxSlots * sizeof(int) + 16; };
+    while (backWaves > 1 && back_lds(backWaves) > 150 * 1024) backWaves /= 2;
+    const int backBlocks = std::max(1, std::min((lpMax + backWaves * BACK_LPW - 1) / (backWaves * BACK_LPW), std::max(16, 2 * nCU / NL)));
+    const size_t backLds = back_lds(backWaves);
+    const int sharedBack = NB > 1 ? 1 : 0;
+    const size_t mfmaLds = ((size_t)BA_MFMA_N * BA_MFMA_LD + 16 + BA_MFMA_N) * sizeof(double);
+    VS_CHECK(ba_kernel_attributes());
+    // ---- device memory: one buffer, bump-allocated; a zeroed head region (arrival counters, slot-0 edge accumulators) ----
+    size_t dBytes = 0;
+    auto dtake = [&](size_t bytes) { const size_t at = dBytes; dBytes = (dBytes + std::max<size_t>(bytes, 8) + 255) & ~(size_t)255; return at; };
+    struct Off { size_t flags, sedge, poseS, lmS, facJ, dP, dL, S, partial, spart, sums, Lg, wrong, outPose, outLm; };
+    std::vector<Off> off(NL);
+    for (int a = 0; a < NL; a++) { const Lane& q = lanes[act[a]]; off[a].flags = dtake(16 * sizeof(int)); off[a].sedge = dtake(((size_t)q.H.n * q.H.n + q.H.n) * nSlots * 8); }
+    const size_t zeroBytes = dBytes;
+    size_t wrongBase = 0, wrongEnd = 0, outBase = 0, outEnd = 0;
+    wrongBase = dBytes;
+    for (int a = 0; a < NL; a++) off[a].wrong = dtake(lanes[act[a]].NP);
+    wrongEnd = dBytes;
+    outBase = dBytes;
+    for (int a = 0; a < NL; a++) { const Lane& q = lanes[act[a]]; off[a].outPose = dtake((size_t)q.K * sizeof(DPose)); off[a].outLm = dtake((size_t)3 * q.L * 8); }
+    outEnd = dBytes;
+    for (int a = 0; a < NL; a++) {
+        const Lane& q = lanes[act[a]];
+        const BaPassHost& H = q.H;
+        const size_t sysStride = (size_t)H.n * H.n + 2 * H.n + 8, sysD = (size_t)H.n * H.n + H.n;
+        off[a].poseS = dtake((size_t)nSlots * q.K * sizeof(DPose)); off[a].lmS = dtake((size_t)nSlots * 3 * q.L * 8);
+        off[a].facJ = dtake((size_t)20 * H.NF * nSlots * 8); off[a].dP = dtake((size_t)NB * H.n * 8); off[a].dL = dtake((size_t)NB * 3 * H.Lp * 8);
+        off[a].S = dtake(sysStride * NB * 8); off[a].partial = dtake(((size_t)2 * obsBlocks + 2 * (size_t)std::max(H.NE, 1)) * NB * 8);
+        off[a].spart = dtake(sysD * lmBlocks * NB * 8); off[a].sums = dtake(32 * 8);
+        off[a].Lg = (H.n > 64 || !useMfma) && H.n > BA_WAVE_N ? dtake((size_t)BA_MFMA_N * BA_MFMA_N * NB * 8) : 0;
+    }
+    VS_HIP(W.d_mem.alloc(dBytes));
+    uint8_t* const dm = W.d_mem.p;
+    // landing area: [control blocks][flags of all lanes][results of all lanes]
+    const size_t oBackCtl = 0, oBackWrong = ((size_t)CTL_DOUBLES * 8 * NL + 255) & ~(size_t)255, oBackOut = oBackWrong + (wrongEnd - wrongBase);
+    const size_t backBytes = oBackOut + (outEnd - outBase);
+    if (backBytes > W.backCap) {
+        VS_HIP(hipStreamSynchronize(stream));
+        if (W.h_back) hipHostFree(W.h_back);
+        W.backCap = 2 * backBytes + 4096;
+        VS_HIP(hipHostMalloc((void**)&W.h_back, W.backCap, hipHostMallocDefault));
+    }
+    // ---- argument tables ------------------------------------------------------------------------------------------------
+    for (int a = 0; a < NL; a++) {
+        Lane& q = lanes[act[a]];
+        const BaPassHost& H = q.H;
+        const vslam_ba_problem* P = q.P;
+        const Off& o = off[a];
+        q.d_flags = (int*)(dm + o.flags); q.d_Sedge = (double*)(dm + o.sedge); q.d_poseS = (DPose*)(dm + o.poseS); q.d_lmS = (double*)(dm + o.lmS);
+        q.d_facJ = (double*)(dm + o.facJ); q.d_dP = (double*)(dm + o.dP); q.d_dL = (double*)(dm + o.dL); q.d_S = (double*)(dm + o.S);
+        q.d_partial = (double*)(dm + o.partial); q.d_Spart = (double*)(dm + o.spart); q.d_sums = (double*)(dm + o.sums);
+        q.d_Lg = o.Lg ? (double*)(dm + o.Lg) : nullptr; q.d_wrong = dm + o.wrong; q.d_outPose = (double*)(dm + o.outPose); q.d_outLm = (double*)(dm + o.outLm);
+        q.oWrong = oBackWrong + (o.wrong - wrongBase); q.oOut = oBackOut + (o.outPose - outBase);
+        BaDev D{};
+        const int n = H.n, K = q.K, L = q.L;
+        D.NF = H.NF; D.Lp = H.Lp; D.F = H.F; D.K = K; D.NE = H.NE; D.n = n;
+        D.facKf = A.dev(H.h_facKf); D.facFi = A.dev(H.h_facFi); D.facLp = A.dev(H.h_facLp); D.facLm = A.dev(H.h_facLm);
+        D.facZ = A.dev(H.h_facZ); D.facIs = A.dev(H.h_facIs); D.facRight = A.dev(H.h_facRight); D.facJ = q.d_facJ;
+        D.lpStart = A.dev(H.h_lpStart); D.lpSlotStart = A.dev(H.h_lpSlotStart); D.slotStart = A.dev(H.h_slotStart); D.slotFi = A.dev(H.h_slotFi);
+        D.lpOrig = A.dev(H.h_lpOrig); D.poseCur = q.d_poseS; D.poseTrial = q.d_poseS + K; D.fidx = A.dev(H.h_fidx);
+        D.lmCur = q.d_lmS; D.lmTrial = q.d_lmS + (size_t)3 * L; D.edges = A.dev(H.h_edges);
+        D.S = q.d_S; D.rhs = q.d_S + (size_t)n * n; D.Sedge = q.d_Sedge; D.dP = q.d_dP; D.dL = q.d_dL; D.sums = q.d_sums; D.flags = q.d_flags;
+        D.fx = P->rig.fx; D.fy = P->rig.fy; D.cx = P->rig.cx; D.cy = P->rig.cy; D.b = (double)P->rig.baseline;
+        D.ctl = A.dev(H.h_ctl);
+        D.NB = NB; D.specLin = 1; D.adaptive = 0;
+        D.poseBase = q.d_poseS; D.lmBase = q.d_lmS; D.lmStride = (size_t)3 * L;
+        D.facJBase = q.d_facJ; D.facJStride = (size_t)20 * H.NF; D.SedgeBase = q.d_Sedge; D.edgesBase = A.dev(H.h_edges);
+        D.sysStride = (size_t)n * n + 2 * n + 8; D.dLStride = (size_t)3 * H.Lp;
+        D.partialStride = (size_t)2 * obsBlocks + 2 * (size_t)std::max(H.NE, 1); D.partial = q.d_partial;
+        D.spartStride = ((size_t)n * n + n) * lmBlocks; D.Spart = q.d_Spart;
+        D.solveKind = (n <= 64 && useMfma) ? BA_SOLVE_MFMA64 : n <= BA_WAVE_N ? BA_SOLVE_WAVE : BA_SOLVE_MFMA;
+        D.Lg = q.d_Lg;
+        anyMfma64 |= D.solveKind == BA_SOLVE_MFMA64; anyWave |= D.solveKind == BA_SOLVE_WAVE; anyMfma |= D.solveKind == BA_SOLVE_MFMA;
+        *H.h_D = D;
+        BaLaneAux X{};
+        X.C.NP = q.NP; X.C.pairKf = A.dev(q.h_pairKf); X.C.pairLm = A.dev(q.h_pairLm); X.C.pairFlags = A.dev(q.h_pairFlags); X.C.pairUv = A.dev(q.h_pairUv);
+        X.C.pairOct = A.dev(q.h_pairOct); X.C.kfLocal = A.dev(q.h_kfLocal); X.C.kfPresent = A.dev(H.h_kfPresent); X.C.lmPresent = A.dev(H.h_lmPresent);
+        X.C.wrong = q.d_wrong;
+        for (int l = 0; l < P->n_levels; l++) X.C.thr[l] = (float)((double)7.815f * (double)P->sigma_factor[l]);
+        X.C.fx = D.fx; X.C.fy = D.fy; X.C.cx = D.cx; X.C.cy = D.cy; X.C.b = D.b;
+        X.NF = H.NF; X.facPair = A.dev(H.h_facPair); X.facIs = A.dev(H.h_facIs);
+        X.nPose = K * (int)(sizeof(DPose) / sizeof(double)); X.nLm = 3 * L; X.pose0 = (const double*)A.dev(q.h_pose0); X.lm0 = A.dev(q.h_lm0);
+        X.outPose = q.d_outPose; X.outLm = q.d_outLm;
+        h_aux[a] = X;
+    }
+    const BaDev* const dTab = A.dev(h_tab);
+    const BaLaneAux* const dAux = A.dev(h_aux);
+    VS_HIP(A.upload(stream));
+    VS_HIP(hipMemsetAsync(dm, 0, zeroBytes, stream));
+    const int valBlocks = std::max(1, std::min((valMax + 255) / 256, 64));
+    hipLaunchKernelGGL(k_ba_init_slots_b, dim3(valBlocks, NL), dim3(256), 0, stream, dTab, dAux);
+
+    // ---- LM rounds for all lanes; the device decides per lane (its own control block) -----------------------------------------
+    auto step = [&](bool first) -> vslam_status {
+        int t = -1;
+        if (first) {
+            t = g_baTimer.begin("ba_linearize");
+            hipLaunchKernelGGL(k_ba_factors<0>, dim3(facBlocks, 1, NL), dim3(256), 0, stream, dTab, obsBlocks, 1, relTol, absTol);
+            g_baTimer.end(t);
+        }
+        t = g_baTimer.begin("ba_schur");
+        hipLaunchKernelGGL(k_ba_schur, dim3(lmBlocks, sharedW ? 1 : NB, NL), dim3(64 * schurWaves), schurLds, stream, dTab, maxSlots, sharedW);
+        g_baTimer.end(t);
+        t = g_baTimer.begin("ba_solve");
+        hipLaunchKernelGGL(k_ba_reduce, dim3(((int)sysMax + 31) / 32, NB, NL), dim3(256), 0, stream, dTab, lmBlocks);
+        if (anyMfma64) hipLaunchKernelGGL(k_ba_solve_mfma64, dim3(NB, 1, NL), dim3(64), 0, stream, dTab);
+        if (anyWave) hipLaunchKernelGGL(k_ba_solve_wave, dim3(NB, 1, NL), dim3(64), 0, stream, dTab);
+        if (anyMfma) hipLaunchKernelGGL(k_ba_solve_mfma, dim3(NB, 1, NL), dim3(64 * BA_MFMA_NW), mfmaLds, stream, dTab, (double*)nullptr);
+        g_baTimer.end(t);
+        t = g_baTimer.begin("ba_back");
+        hipLaunchKernelGGL(k_ba_back, dim3(backBlocks, sharedBack ? 1 : NB, NL), dim3(64 * backWaves), backLds, stream, dTab, maxSlots, sharedBack);
+        g_baTimer.end(t);
+        t = g_baTimer.begin("ba_eval");
+        hipLaunchKernelGGL(k_ba_factors<1>, dim3(facBlocks, NB, NL), dim3(256), 0, stream, dTab, obsBlocks, 1, relTol, absTol);
+        g_baTimer.end(t);
+        VS_HIP(hipGetLastError());
+        return VSLAM_OK;
+    };
+    double* const b_ctl = (double*)(W.h_back + oBackCtl);
+    auto lm_loop = [&]() -> vslam_status {
+        static const int perPoll = getenv("VSLAM_BA_STEPS_PER_POLL") ? std::max(1, atoi(getenv("VSLAM_BA_STEPS_PER_POLL"))) : 4;
+        int enq = 0;
+        for (;;) {
+            for (int b = 0; b < perPoll; b++) VS_CHECK(step(enq + b == 0));
+            enq += perPoll;
+            VS_HIP(hipMemcpyAsync(b_ctl, A.dev(h_ctlAll), (size_t)CTL_DOUBLES * 8 * NL, hipMemcpyDeviceToHost, stream));
+            VS_HIP(hipStreamSynchronize(stream));
+            bool all = true;
+            for (int a = 0; a < NL; a++) all &= ((const int*)(b_ctl + (size_t)CTL_DOUBLES * a + CTL_INTS))[CI_STATE] == BA_DONE;
+            if (all) return VSLAM_OK;
+            if (enq > 400) { set_error("local BA batch: LM did not terminate"); return VSLAM_ERR_INVALID; }
+        }
+    };
+    auto report = [&](int ps) {
+        for (int a = 0; a < NL; a++) {
+            Lane& q = lanes[act[a]];
+            if (ps == 1 && !q.pass2) continue;
+            const double* c = b_ctl + (size_t)CTL_DOUBLES * a;
+            const int* ci = (const int*)(c + CTL_INTS);
+            vslam_ba_result* R = q.R;
+            R->report[ps].iterations = ci[CI_ITER]; R->report[ps].inner_iterations = ci[CI_INNER];
+            R->report[ps].initial_error = c[CTL_INIT_ERR]; R->report[ps].final_error = c[CTL_ERROR]; R->report[ps].lambda = c[CTL_LAMBDA];
+            R->n_free_kf = q.H.F;
+            R->rounds = (ps == 0 ? 0 : R->rounds) + ci[CI_ROUNDS];
+            if (ps == 0) { R->n_residuals = q.H.NF; R->n_landmarks = q.H.Lp; R->sum_k2 = q.H.sumK2; }
+            else { R->n_residuals = q.NF2; R->n_landmarks = q.Lp2; R->sum_k2 = q.k2; }
+        }
+    };
+    const int chiBlocks = std::max(1, (std::max(npMax, valMax) + 255) / 256);
+    auto chi2 = [&](int gather) -> vslam_status {
+        const int t = g_baTimer.begin("ba_chi2");
+        hipLaunchKernelGGL(k_ba_chi2_b, dim3(chiBlocks, NL), dim3(256), 0, stream, dTab, dAux, gather);
+        g_baTimer.end(t);
+        VS_HIP(hipGetLastError());
+        VS_HIP(hipMemcpyAsync(W.h_back + oBackWrong, dm + wrongBase, wrongEnd - wrongBase, hipMemcpyDeviceToHost, stream));
+        if (gather) VS_HIP(hipMemcpyAsync(W.h_back + oBackOut, dm + outBase, outEnd - outBase, hipMemcpyDeviceToHost, stream));
+        VS_HIP(hipStreamSynchronize(stream));
+        return VSLAM_OK;
+    };
+    // ---- pass 1 ------------------------------------------------------------------------------------------------------------------
+    VS_CHECK(lm_loop());
+    report(0);
+    VS_CHECK(chi2(0));
+    // ---- second pass on the first pass's structure: membership / statistics from the flags; lanes whose graph loses a keyframe
+    //      (their free index would change) go to the one-problem path, which rebuilds ------------------------------------------------
+    std::vector<int> redo;
+    W.pool.run(NL, [&](int a) {
+        Lane& q = lanes[act[a]];
+        const vslam_ba_problem* P = q.P;
+        const BaPassHost& H = q.H;
+        memcpy(q.wrong.data(), W.h_back + q.oWrong, q.NP);
+        if (q.R->pair_wrong_pass1) memcpy(q.R->pair_wrong_pass1, q.wrong.data(), q.NP);
+        std::vector<uint8_t> kfP2(q.K, 0), lmP2(std::max(q.L, 1), 0);
+        long long NF2 = 0;
+        for (int p = 0; p < q.NP; p++) {
+            if (q.wrong[p]) continue;
+            const int fl = P->pair_flags[p] & 3;
+            if (!fl) continue;
+            kfP2[P->pair_kf[p]] = 1; lmP2[P->pair_lm[p]] = 1; NF2 += (fl & 1) + (fl >> 1);
+        }
+        bool same = g_baMask != 0;
+        for (int k = 0; k < q.K && same; k++) if (kfP2[k] != q.T.kfPresent[k]) same = false;
+        int* ci = (int*)(H.h_ctl + CTL_INTS);
+        if (!same) { q.pass2 = false; ci[CI_STATE] = BA_DONE; ci[CI_FIRST] = 0; return; }      // (stays out of the second round)
+        long long Lp2 = 0, k2 = 0;
+        for (int l = 0; l < q.L; l++) Lp2 += lmP2[l];
+        for (int lp = 0; lp < H.Lp; lp++) {
+            int ns = 0, last = -2;
+            for (int f = H.h_lpStart[lp]; f < H.h_lpStart[lp + 1]; f++) {
+                if (q.wrong[H.h_facPair[f]]) continue;
+                const int fi = H.h_facFi[f];
+                if (fi >= 0 && fi != last) { last = fi; ns++; }
+            }
+            k2 += (long long)ns * ns;
+        }
+        q.NF2 = NF2; q.Lp2 = Lp2; q.k2 = k2; q.pass2 = true;
+        for (int k = 0; k < q.K; k++) H.h_kfPresent[k] = kfP2[k];
+        for (int l = 0; l < q.L; l++) H.h_lmPresent[l] = lmP2[l];
+        ba_init_ctl(H.h_ctl, 1, NB);
+    });
+    for (int a = 0; a < NL; a++) if (!lanes[act[a]].pass2) redo.push_back(act[a]);
+    if ((int)redo.size() < NL) {
+        // re-armed control blocks and the membership arrays: the arena's head (control blocks) + each lane's present arrays
+        VS_HIP(hipMemcpyAsync(A.dev(h_ctlAll), h_ctlAll, (size_t)CTL_DOUBLES * 8 * NL, hipMemcpyHostToDevice, stream));
+        for (int a = 0; a < NL; a++) {
+            Lane& q = lanes[act[a]];
+            if (!q.pass2) continue;
+            // (kfPresent | lmPresent are adjacent takes of the arena)
+            VS_HIP(hipMemcpyAsync(A.dev(q.H.h_kfPresent), q.H.h_kfPresent, (size_t)((q.H.h_lmPresent - q.H.h_kfPresent) + std::max(q.L, 1)), hipMemcpyHostToDevice, stream));
+        }
+        hipLaunchKernelGGL(k_ba_second_pass_b, dim3(std::max(1, std::min((std::max(nfMax, valMax) + 255) / 256, 64)), NL), dim3(256), 0, stream, dTab, dAux);
+        VS_CHECK(lm_loop());
+        report(1);
+        VS_CHECK(chi2(1));
+    }
+    for (int a = 0; a < NL; a++) {
+        Lane& q = lanes[act[a]];
+        if (!q.pass2) continue;
+        const DPose* po = (const DPose*)(W.h_back + q.oOut);
+        const double* lo = (const double*)(W.h_back + q.oOut + (((size_t)q.K * sizeof(DPose) + 255) & ~(size_t)255));
+        for (int k = 0; k < q.K; k++) pose_to_rm16(po[k], q.R->kf_pose_wc + 16 * (size_t)k);
+        if (q.L) memcpy(q.R->lm_xyz, lo, (size_t)3 * q.L * sizeof(double));
+        if (q.NP) memcpy(q.R->pair_wrong, W.h_back + q.oWrong, q.NP);
+    }
+    for (int i : redo) VS_CHECK(ba_run(Ps[i], Rs[i], device, nullptr));
+    return run_singles();
+}
+
 namespace vslam {
 // VSLAM_BATCH_PHASES: where ba_run's wall time goes (averages per call; the marks do not synchronise, so "lm" holds the
 // polls of both LM loops, "chi2" the re-check + second-pass preparation + result fetch)
@@ -2577,12 +3090,31 @@ vslam_status vslam_local_ba(const vslam_ba_problem* problem, vslam_ba_result* re
     return ba_run(problem, result, device, comm);
 }
 
+/* n tracker-window problems optimised together (one launch per stage for all of them); results equal n vslam_local_ba calls */
+vslam_status vslam_local_ba_batch(const vslam_ba_problem* const* problems, vslam_ba_result* const* results, int32_t n, int32_t device) {
+    return ba_run_batch(problems, results, n, device);
+}
+
 vslam_status vslam_local_ba_timings(const char** names, float* ms, int32_t cap, int32_t* n_out) {
     if (!n_out) return VSLAM_ERR_INVALID;
     const char* nm[64];
     float tv[64];
     int n = g_baTimer.read(nm, tv, cap < 64 ? cap : 64);
     for (int i = 0; i < n; i++) { if (names) names[i] = nm[i]; if (ms) ms[i] = tv[i]; }
+    // "<group>#n": the number of timed intervals (= launches of the group's kernel) behind each sum, as further entries
+    static const char* const cntName[][2] = {{"ba_linearize", "ba_linearize#n"}, {"ba_schur", "ba_schur#n"}, {"ba_solve", "ba_solve#n"},
+                                             {"ba_back", "ba_back#n"}, {"ba_eval", "ba_eval#n"}, {"ba_chi2", "ba_chi2#n"}, {"ba_allreduce", "ba_allreduce#n"}};
+    const int base = n;
+    for (int i = 0; i < base && n < cap; i++)
+        for (const auto& c : cntName)
+            if (!strcmp(nm[i], c[0])) {
+                int k = 0;
+                for (size_t q = 0; q < g_baTimer.used; q++) if (!strcmp(g_baTimer.items[q].name, c[0])) k++;
+                if (names) names[n] = c[1];
+                if (ms) ms[n] = (float)k;
+                n++;
+                break;
+            }
     *n_out = n;
     return VSLAM_OK;
 }

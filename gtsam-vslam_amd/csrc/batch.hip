@@ -62,11 +62,19 @@ struct vslam_batch {
     double* d_res = nullptr; double* h_res = nullptr;                        // [B][64] result blocks
     uint8_t* d_zero = nullptr; size_t zeroCap = 0;                           // MapPoint::GetIsOutlier of uploaded points: all 0
     BaPool pool;                                                             // host phases
-    // mapping threads
+    // mapping engine (local_mapping = 2): the device work of the lanes' passes, COHORT by cohort - the jobs the lanes hand over
+    // during a host phase of a step are collected (submit_mapping) and released together when that phase ends (kick): the
+    // new-point searches of the lanes that inserted a keyframe at this step, the local BAs of the lanes that did at the previous
+    // one.  A cohort's local BAs are ONE batched call (vslam_local_ba_batch: one launch per stage for all of them).
     std::vector<std::thread> mapThreads;
-    std::deque<vslam_system*> mapQueue;
-    std::mutex mqMu; std::condition_variable mqCv;
-    bool mqStop = false;
+    std::deque<vslam_system*> npQueue, baQueue;
+    std::mutex mqMu; std::condition_variable npCv, baCv;
+    bool mqStop = false, npReady = false, baReady = false;
+    // local-BA stage timing of the cohorts (HIP events on the engine's stream), summed since the last read
+    std::atomic<int> baTimingOn{0};
+    std::mutex btMu;
+    std::vector<std::pair<const char*, float>> baTimes;
+    long long baTimedCohorts = 0, baTimedLanes = 0;
     // per-step scratch
     struct LaneStep { bool on = false, first = false, failed = false; vslam_status st = VSLAM_OK; char err[200] = ""; size_t upOff = 0, dnOff = 0, keyOff = 0; int N = 0, nL = 0, nR = 0; bool wantKeys = false; };
     std::vector<LaneStep> ls;
@@ -86,33 +94,73 @@ struct vslam_batch {
     // images of the NEXT step whose extraction was enqueued at the end of the previous one (prefetch)
     std::vector<const uint8_t*> prefetched;
     vslam_status enqueue_extraction(const uint8_t* const* L, const uint8_t* const* R, const uint8_t* mask, int stride, bool onDevice);
-    std::deque<std::chrono::steady_clock::time_point> mapQueuedAt;      // (parallel to mapQueue, under mqMu)
     static void submit_mapping(void* self, vslam_system* s) {
         vslam_batch* b = (vslam_batch*)self;
-        { std::lock_guard<std::mutex> lk(b->mqMu); b->mapQueue.push_back(s); b->mapQueuedAt.push_back(std::chrono::steady_clock::now()); }
-        b->mqCv.notify_one();
+        std::lock_guard<std::mutex> lk(b->mqMu);
+        (s->pass.stage == MapPass::NEW_POINTS ? b->npQueue : b->baQueue).push_back(s);
     }
-    void map_loop() {
+    void kick() {                                  // a host phase has ended: its jobs form a cohort
+        { std::lock_guard<std::mutex> lk(mqMu); npReady = !npQueue.empty(); baReady = !baQueue.empty(); }
+        npCv.notify_all(); baCv.notify_all();
+    }
+    void np_loop() {
+        hipSetDevice(device);
         for (;;) {
-            vslam_system* s = nullptr;
+            std::vector<vslam_system*> jobs;
             {
                 std::unique_lock<std::mutex> lk(mqMu);
-                mqCv.wait(lk, [&] { return mqStop || !mapQueue.empty(); });
-                if (mapQueue.empty()) break;        // (stop requested and nothing left)
-                s = mapQueue.front(); mapQueue.pop_front();
-                const auto now = std::chrono::steady_clock::now();
-                const long long d = std::chrono::duration_cast<std::chrono::nanoseconds>(now - mapQueuedAt.front()).count();
-                mapQueuedAt.pop_front();
-                SysProf& p = sys_prof();
-                p.mqNs += d; p.mqN++;
-                if (d > 5000000) p.mqLate++;
-                long long m = p.mqMaxNs.load(); while (d > m && !p.mqMaxNs.compare_exchange_weak(m, d)) {}
+                npCv.wait(lk, [&] { return mqStop || (npReady && !npQueue.empty()); });
+                if (npQueue.empty()) break;        // (stop requested and nothing left)
+                jobs.assign(npQueue.begin(), npQueue.end()); npQueue.clear(); npReady = false;
+            }
+            // the cohort's new-point searches: one upload, one launch per kernel, one download (vslam_find_new_points_batch)
+            std::vector<const vslam_new_points_problem*> Ps; std::vector<vslam_new_points_result*> Rs;
+            for (vslam_system* s : jobs) { Ps.push_back(&s->pass.np.P); Rs.push_back(&s->pass.np.R); }
+            vslam_status st;
+            { SysProfScope pn(sys_prof().npNs, sys_prof().npN); st = vslam_find_new_points_batch(Ps.data(), Rs.data(), (int)jobs.size(), device); }
+            char err[200];
+            snprintf(err, sizeof(err), "%s", st == VSLAM_OK ? "" : vslam_last_error());
+            for (vslam_system* s : jobs) s->finish_job(st, err);
+        }
+        vslam::thread_release();
+    }
+    void ba_loop() {
+        hipSetDevice(device);
+        for (;;) {
+            std::vector<vslam_system*> jobs;
+            {
+                std::unique_lock<std::mutex> lk(mqMu);
+                baCv.wait(lk, [&] { return mqStop || (baReady && !baQueue.empty()); });
+                if (baQueue.empty()) break;
+                jobs.assign(baQueue.begin(), baQueue.end()); baQueue.clear(); baReady = false;
             }
             const auto t0 = std::chrono::steady_clock::now();
-            s->run_mapping();
+            std::vector<const vslam_ba_problem*> Ps; std::vector<vslam_ba_result*> Rs;
+            for (vslam_system* s : jobs) { Ps.push_back(&s->pass.ba.P); Rs.push_back(&s->pass.ba.R); }
+            const int timing = baTimingOn.load();
+            vslam_local_ba_set_timing(timing);
+            vslam_status st;
+            { SysProfScope pb(sys_prof().baNs, sys_prof().baN); st = vslam_local_ba_batch(Ps.data(), Rs.data(), (int)jobs.size(), device); }
+            if (st == VSLAM_OK && timing) {
+                const char* nm[32]; float ms[32]; int n = 0;
+                if (vslam_local_ba_timings(nm, ms, 32, &n) == VSLAM_OK) {
+                    std::lock_guard<std::mutex> lk(btMu);
+                    baTimedCohorts++; baTimedLanes += (long long)jobs.size();
+                    for (int i = 0; i < n; i++) {
+                        size_t j = 0;
+                        for (; j < baTimes.size(); j++) if (!strcmp(baTimes[j].first, nm[i])) break;
+                        if (j == baTimes.size()) baTimes.push_back({nm[i], 0.f});
+                        baTimes[j].second += ms[i];
+                    }
+                }
+            }
+            char err[200];
+            snprintf(err, sizeof(err), "%s", st == VSLAM_OK ? "" : vslam_last_error());
+            for (vslam_system* s : jobs) s->finish_job(st, err);
             {
                 const long long d = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
                 SysProf& p = sys_prof();
+                p.mqNs += d; p.mqN++; p.mapN += 0;
                 if (d > 15000000) p.mapLate++;
                 long long m = p.mapMaxNs.load(); while (d > m && !p.mapMaxNs.compare_exchange_weak(m, d)) {}
             }
@@ -177,8 +225,11 @@ vslam_status vslam_batch::init(const vslam_system_config* cfgs, int n, int hostT
     pool.onExit = []() { vslam::thread_release(); };
     if (hostThreads > 1) pool.start(hostThreads - 1);
     if (cfgs[0].local_mapping == 2) {
-        if (nMapThreads <= 0) nMapThreads = std::min(B, getenv("VSLAM_BATCH_MAP_THREADS") ? std::max(1, atoi(getenv("VSLAM_BATCH_MAP_THREADS"))) : 3);
-        for (int t = 0; t < nMapThreads; t++) mapThreads.emplace_back([this]() { map_loop(); });
+        // mapping_threads = engine threads for the cohorts' batched local BAs (2: a cohort may still run when the next arrives),
+        // + 2 threads for the cohorts' batched new-point searches
+        if (nMapThreads <= 0) nMapThreads = getenv("VSLAM_BATCH_MAP_THREADS") ? std::max(1, atoi(getenv("VSLAM_BATCH_MAP_THREADS"))) : 2;
+        for (int t = 0; t < 2; t++) mapThreads.emplace_back([this]() { np_loop(); });
+        for (int t = 0; t < nMapThreads; t++) mapThreads.emplace_back([this]() { ba_loop(); });
     }
     return VSLAM_OK;
 }
@@ -197,14 +248,15 @@ void vslam_batch::release() {
         fprintf(stderr, "  mapping passes: %.1f us x %lld (find new points %.1f, vslam_local_ba %.1f) | frames that waited for their mapper: %.1f us x %lld\n",
                 avg(p.mapNs, p.mapN), p.mapN.load(), avg(p.npNs, p.npN), avg(p.baNs, p.baN), avg(p.waitNs, p.waitN), p.waitN.load());
         vslam::ba_host_profile_print();
-        fprintf(stderr, "  mapping queue: %.1f us average delay before a pass starts (%lld of %lld above 5 ms, longest %.1f ms) | passes above 15 ms: %lld, longest %.1f ms\n",
-                avg(p.mqNs, p.mqN), p.mqLate.load(), p.mqN.load(), 1e-6 * (double)p.mqMaxNs.load(), p.mapLate.load(), 1e-6 * (double)p.mapMaxNs.load());
+        fprintf(stderr, "  local-BA cohorts: %.1f us per cohort x %lld cohorts (above 15 ms: %lld, longest %.1f ms)\n",
+                avg(p.mqNs, p.mqN), p.mqN.load(), p.mapLate.load(), 1e-6 * (double)p.mapMaxNs.load());
     }
     // sessions first (each waits for its mapping job), then the mapping threads, then the shared objects
+    kick();
     for (vslam_system* s : sys) if (s) { s->release(); delete s; }
     sys.clear();
     { std::lock_guard<std::mutex> lk(mqMu); mqStop = true; }
-    mqCv.notify_all();
+    npCv.notify_all(); baCv.notify_all();
     for (auto& t : mapThreads) t.join();
     mapThreads.clear();
     if (stream) hipStreamSynchronize(stream);
@@ -301,6 +353,7 @@ vslam_status vslam_batch::step(const uint8_t* const* L, const uint8_t* const* R,
         LANE_TRY(s->frame_begin(s->ctx, frames[b], imu ? &imu[b] : nullptr));
         if (!q.first) q.N = s->frame_candidates(s->ctx);
     });
+    kick();                                        // the local BAs handed over in this phase: one cohort
     VS_CHECK(first_error());
     lap(0);
 
@@ -534,6 +587,7 @@ vslam_status vslam_batch::step(const uint8_t* const* L, const uint8_t* const* R,
         if (q.first) LANE_TRY(s->frame_first(s->ctx, T_wc_out + 16 * (size_t)b, reps ? &reps[b] : nullptr));
         else LANE_TRY(s->frame_post(s->ctx, st[b], T_wc_out + 16 * (size_t)b, reps ? &reps[b] : nullptr));
     });
+    kick();                                        // the new-point searches of the lanes that inserted a keyframe
     VS_CHECK(first_error());
     lap(6);
     return VSLAM_OK;
@@ -583,6 +637,7 @@ int32_t vslam_batch_lanes(const vslam_batch* b) { return b ? b->B : 0; }
 
 vslam_status vslam_batch_wait_mapping(vslam_batch* b) {
     if (!b) return VSLAM_ERR_INVALID;
+    b->kick();
     for (vslam_system* s : b->sys) VS_CHECK(vslam_system_wait_mapping(s));
     return VSLAM_OK;
 }
@@ -591,6 +646,24 @@ vslam_status vslam_batch_set_timing(vslam_batch* b, int32_t on) {
     if (!b) return VSLAM_ERR_INVALID;
     b->timer.enabled = on != 0;
     b->fe->timer.enabled = on != 0;
+    return VSLAM_OK;
+}
+
+// local-BA stage timing of the mapping engine's cohorts (HIP events on its stream): switch, and read-and-reset of the sums
+vslam_status vslam_batch_set_ba_timing(vslam_batch* b, int32_t on) {
+    if (!b) return VSLAM_ERR_INVALID;
+    b->baTimingOn = on ? 1 : 0;
+    return VSLAM_OK;
+}
+vslam_status vslam_batch_ba_timings(vslam_batch* b, const char** names, float* ms, int32_t cap, int32_t* n_out, int64_t* cohorts_out, int64_t* lanes_out) {
+    if (!b || !n_out || !names || !ms) return VSLAM_ERR_INVALID;
+    int n = 0;
+    std::lock_guard<std::mutex> lk(b->btMu);
+    for (auto& t : b->baTimes) if (n < cap) { names[n] = t.first; ms[n] = t.second; n++; }
+    if (cohorts_out) *cohorts_out = b->baTimedCohorts;
+    if (lanes_out) *lanes_out = b->baTimedLanes;
+    b->baTimes.clear(); b->baTimedCohorts = 0; b->baTimedLanes = 0;
+    *n_out = n;
     return VSLAM_OK;
 }
 

@@ -182,9 +182,23 @@ __device__ __forceinline__ int fast_score(const uint8_t* p, const int* ro) {
     return M < 0 ? 0 : M;
 }
 
+// XCD-aware (chunk, image) of a workgroup of a (chunks, images) grid.  Workgroups are dealt round-robin to the 8 XCDs in launch
+// order (linear id mod 8 labels the blocks that share an XCD - a speed assumption only, MI355X_MICROARCH.md "Workgroup dispatch"):
+// the blocks with the same label take WHOLE images (label k: images k, k + 8, ...), so that an image's pyramid levels are
+// fetched into one XCD's 4 MB L2 instead of all eight.  The launch pads the image dimension of the grid to a multiple of 8
+// (images beyond nimg: no work) - used for batches of >= 8 images; smaller launches keep the plain mapping.
+__device__ __forceinline__ bool xcd_image_block(int nimg, int& chunk, int& img) {
+    if (gridDim.y < 8) { chunk = blockIdx.x; img = blockIdx.y; return img < nimg; }
+    const unsigned gx = gridDim.x, L = blockIdx.y * gx + blockIdx.x;
+    const unsigned label = L & 7u, j = L >> 3;
+    img = (int)((j / gx) * 8u + label); chunk = (int)(j % gx);
+    return img < nimg;
+}
+inline int xcd_image_rows(int nimg) { return nimg >= 8 ? (nimg + 7) & ~7 : nimg; }
+
 __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, PyrDesc P,
                                               FastDesc F, uint32_t* __restrict__ cellSlots,
-                                              int* __restrict__ cellCount, int maxThr, int minThr, int listCap) {
+                                              int* __restrict__ cellCount, int maxThr, int minThr, int listCap, int nimg) {
     extern __shared__ unsigned char fsm[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (the cell is wave-uniform: its geometry stays in SGPRs)
@@ -195,7 +209,9 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, P
     unsigned short* q1 = (unsigned short*)(sc + F.tileRows * TP);  // stage 1 -> 2
     unsigned short* q2 = q1 + (FQ_MASK + 1);                       // stage 2 -> 3
     unsigned short* q3 = q2 + (FQ_MASK + 1);                       // stage 3 -> suppression (corners at the pass's threshold)
-    const int cell = blockIdx.x * 4 + wave, img = blockIdx.y;
+    int chunk, img;
+    if (!xcd_image_block(nimg, chunk, img)) return;
+    const int cell = chunk * 4 + wave;
     const int nCellsTotal = F.cellBase[P.nLevels];
     if (cell >= nCellsTotal) return;
     int level = 0;
@@ -430,12 +446,12 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, P
 
 void launch_fast(hipStream_t s, const uint8_t* pyr, const PyrDesc& P, const FastDesc& F,
                  uint32_t* cellSlots, int* cellCount, int maxThr, int minThr, int nimg) {
-    dim3 grid((F.cellBase[P.nLevels] + 3) / 4, nimg);
+    dim3 grid((F.cellBase[P.nLevels] + 3) / 4, xcd_image_rows(nimg));
     const size_t lds = (size_t)4 * ((size_t)F.tileRows * F.tilePitch * 2 + 2 * (FQ_MASK + 1) * 2 + FQ3_CAP * 2);
     // VSLAM_FAST_LIST_CAP (read per launch): a smaller corner list forces the full-scan suppression - fallback testing
     int listCap = FQ3_CAP;
     if (const char* e = getenv("VSLAM_FAST_LIST_CAP")) listCap = std::max(0, std::min(FQ3_CAP, atoi(e)));
-    hipLaunchKernelGGL(k_fast, grid, dim3(256), lds, s, pyr, P, F, cellSlots, cellCount, maxThr, minThr, listCap);
+    hipLaunchKernelGGL(k_fast, grid, dim3(256), lds, s, pyr, P, F, cellSlots, cellCount, maxThr, minThr, listCap, nimg);
 }
 
 // ---------------------------------------------------------------------------
@@ -672,10 +688,12 @@ __global__ __launch_bounds__(256) void k_orient_desc(
     const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur, PyrDesc P, LevelTables T,
     const uint32_t* __restrict__ kept, const int* __restrict__ keptOff, int keptCap,
     DiscRows R, vslam_keypoint* __restrict__ kps,
-    uint8_t* __restrict__ desc, int outCap) {
-    const int img = blockIdx.y, lane = threadIdx.x & 63;
+    uint8_t* __restrict__ desc, int outCap, int nimg) {
+    const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (tells the compiler the keypoint is wave-uniform)
-    const int g = blockIdx.x * 4 + wave;
+    int chunk, img;
+    if (!xcd_image_block(nimg, chunk, img)) return;
+    const int g = chunk * 4 + wave;
     const int* koff = keptOff + img * (MAX_LEVELS + 1);
     const int total = koff[P.nLevels];
     if (g >= total || g >= outCap) return;
@@ -763,8 +781,8 @@ void launch_orient_desc(hipStream_t s, const uint8_t* pyr, const uint8_t* blur, 
                         const DiscRows& disc, vslam_keypoint* kps, uint8_t* desc, int outCap,
                         int maxKept, int nimg) {
     if (maxKept <= 0) return;
-    hipLaunchKernelGGL(k_orient_desc, dim3((maxKept + 3) / 4, nimg), dim3(256), 0, s, pyr, blur, P, T,
-                       kept, keptOff, keptCap, disc, kps, desc, outCap);
+    hipLaunchKernelGGL(k_orient_desc, dim3((maxKept + 3) / 4, xcd_image_rows(nimg)), dim3(256), 0, s, pyr, blur, P, T,
+                       kept, keptOff, keptCap, disc, kps, desc, outCap, nimg);
 }
 
 }  // namespace vslam

@@ -29,7 +29,7 @@ struct vslam_fleet {
         long long step = 0;       // frames tracked so far
         // accumulated over run() calls (reset by run)
         long long frames = 0, keyframes = 0, mappings = 0, inliers = 0, lost = 0, rounds = 0, newPoints = 0, baLandmarks = 0, baPairs = 0;
-        long long baRes = 0, baFree = 0, baK2 = 0, baTrials = 0, baIters = 0;
+        long long baRes = 0, baFree = 0, baK2 = 0, baTrials = 0, baIters = 0, baRounds = 0, active = 0;
         int minInliers = 1 << 30;
         double maxPosErr = 0, sumSqPosErr = 0;
         double seconds = 0;
@@ -48,7 +48,7 @@ struct vslam_fleet {
     // per-kernel-group device time of session 0, sampled on every `sampleEvery`-th frame (0 = off)
     int sampleEvery = 0;
     std::vector<std::pair<const char*, float>> times;
-    long long sampledFrames = 0, sampledSolves = 0, sampledBa = 0;
+    long long sampledFrames = 0, sampledSolves = 0, sampledBa = 0, sampledCohorts = 0;
     // job control
     std::mutex mu;
     std::condition_variable cvGo, cvDone;
@@ -80,11 +80,11 @@ void vslam_fleet::account(Session& S, int si, long long k, int idx, const vslam_
     S.keyframes += rep.keyframe_inserted; S.mappings += rep.mapping_ran; S.newPoints += rep.new_points;
     S.baLandmarks += rep.ba_landmarks; S.baPairs += rep.ba_pairs;
     if (rep.mapping_ran) {
-        S.baRes += rep.ba_residuals; S.baFree += rep.ba_free_kf; S.baK2 += rep.ba_sum_k2; S.baTrials += rep.ba_trials;
+        S.baRes += rep.ba_residuals; S.baFree += rep.ba_free_kf; S.baK2 += rep.ba_sum_k2; S.baTrials += rep.ba_trials; S.baRounds += rep.ba_rounds;
         S.baIters += rep.ba_report[0].iterations + rep.ba_report[1].iterations;
     }
     if (k > 0) {
-        S.inliers += rep.n_inliers; S.rounds += rep.rounds;
+        S.inliers += rep.n_inliers; S.rounds += rep.rounds; S.active += rep.n_active;
         S.minInliers = std::min(S.minInliers, rep.n_inliers);
         if (rep.n_inliers < 50) S.lost++;
     }
@@ -137,7 +137,8 @@ void vslam_fleet::group_loop(int gi) {
             const int nBaTimed = std::min(Bn, 8);
             if (gi == 0 && sampleEvery > 0) {
                 vslam_batch_set_timing(Gp.b, sample ? 1 : 0);
-                for (int b = 0; b < nBaTimed; b++) vslam_system_set_ba_timing(ses[Gp.first + b].sys, 1);
+                vslam_batch_set_ba_timing(Gp.b, 1);                  // the mapping engine's cohorts (local_mapping = 2)
+                for (int b = 0; b < nBaTimed; b++) vslam_system_set_ba_timing(ses[Gp.first + b].sys, 1);      // (local_mapping = 1: inside the step)
             }
             if (onDevice) {       // the next step's images: their extraction overlaps this step's host phases
                 for (int b = 0; b < Bn; b++) { const int ni = tri(k + 1 + ses[Gp.first + b].offset, nFrames); nL[b] = left[ni]; nR[b] = right[ni]; }
@@ -150,7 +151,9 @@ void vslam_fleet::group_loop(int gi) {
                 const char* nm[64]; float ms[64]; int n = 0, nba = 0;
                 if (vslam_batch_timings(Gp.b, nm, ms, 64, &n, nullptr) == VSLAM_OK) add_times(nm, ms, n);
                 for (int b = 0; b < nBaTimed; b++)
-                    if (vslam_system_ba_timings(ses[Gp.first + b].sys, nm, ms, 64, &n, &nba) == VSLAM_OK) { add_times(nm, ms, n); sampledBa += nba; }
+                    if (vslam_system_ba_timings(ses[Gp.first + b].sys, nm, ms, 64, &n, &nba) == VSLAM_OK) { add_times(nm, ms, n); sampledBa += nba; sampledCohorts += nba; }
+                int64_t co = 0, la = 0;
+                if (vslam_batch_ba_timings(Gp.b, nm, ms, 64, &n, &co, &la) == VSLAM_OK) { add_times(nm, ms, n); sampledBa += la; sampledCohorts += co; }
                 sampledFrames += Bn;
                 for (int b = 0; b < Bn; b++) sampledSolves += reps[b].rounds + 1;
             }
@@ -256,7 +259,8 @@ static vslam_status fleet_create(const vslam_system_config* config, int32_t n_se
     for (int s = 0; s < n_sessions; s++) {
         vslam_system_config& c = cfgs[s];
         // sessions start at different phases of the forward leg, each at the true pose / velocity of its first frame
-        const int off = (int)(((long long)s * 5) % std::max(1, seq->n_frames - 1));
+        const int span = seq->start_span > 0 ? std::min(seq->start_span, seq->n_frames - 1) : seq->n_frames - 1;
+        const int off = (int)(((long long)s * 5) % std::max(1, span));
         F->ses[s].offset = off;
         if (seq->T_wc_true) memcpy(c.T_wc_init, seq->T_wc_true + 16 * (size_t)off, sizeof(c.T_wc_init));
         if (seq->velocity_true) for (int k = 0; k < 3; k++) c.velocity_init[k] = seq->velocity_true[3 * (size_t)off + k];
@@ -313,7 +317,7 @@ vslam_status vslam_fleet_run(vslam_fleet* F, int32_t n_steps, vslam_fleet_report
     if (!F || n_steps < 0) return VSLAM_ERR_INVALID;
     for (auto& S : F->ses) {
         S.frames = S.keyframes = S.mappings = S.inliers = S.lost = S.rounds = S.newPoints = S.baLandmarks = S.baPairs = 0;
-        S.baRes = S.baFree = S.baK2 = S.baTrials = S.baIters = 0;
+        S.baRes = S.baFree = S.baK2 = S.baTrials = S.baIters = S.baRounds = S.active = 0;
         S.minInliers = 1 << 30; S.maxPosErr = 0; S.sumSqPosErr = 0; S.seconds = 0;
     }
     const auto t0 = std::chrono::steady_clock::now();
@@ -330,8 +334,8 @@ vslam_status vslam_fleet_run(vslam_fleet* F, int32_t n_steps, vslam_fleet_report
     for (auto& S : F->ses) {
         if (S.status != VSLAM_OK && st == VSLAM_OK) { st = S.status; set_error("fleet session failed: %s", S.error); }
         R.frames += S.frames; R.keyframes += S.keyframes; R.mappings += S.mappings; R.sum_inliers += S.inliers; R.lost_frames += S.lost;
-        R.sum_rounds += S.rounds; R.new_points += S.newPoints; R.ba_landmarks += S.baLandmarks; R.ba_pairs += S.baPairs;
-        R.ba_residuals += S.baRes; R.ba_free_kf += S.baFree; R.ba_sum_k2 += S.baK2; R.ba_trials += S.baTrials; R.ba_iterations += S.baIters;
+        R.sum_rounds += S.rounds; R.sum_active += S.active; R.new_points += S.newPoints; R.ba_landmarks += S.baLandmarks; R.ba_pairs += S.baPairs;
+        R.ba_residuals += S.baRes; R.ba_free_kf += S.baFree; R.ba_sum_k2 += S.baK2; R.ba_trials += S.baTrials; R.ba_iterations += S.baIters; R.ba_rounds += S.baRounds;
         R.min_inliers = std::min<int>(R.min_inliers, S.minInliers);
         R.max_position_error = std::max(R.max_position_error, S.maxPosErr);
         R.sum_sq_position_error += S.sumSqPosErr;
@@ -348,6 +352,7 @@ vslam_status vslam_fleet_set_sampling(vslam_fleet* F, int32_t every) {
         if (F->groups.empty()) vslam_system_set_timing(F->ses[0].sys, 0);
         else {
             vslam_batch_set_timing(F->groups[0].b, 0);
+            vslam_batch_set_ba_timing(F->groups[0].b, 0);
             for (int b = 0; b < std::min(F->groups[0].count, 8); b++) vslam_system_set_ba_timing(F->ses[b].sys, 0);
         }
     }
@@ -359,8 +364,8 @@ vslam_status vslam_fleet_timings(vslam_fleet* F, const char** names, float* ms, 
     int n = 0;
     for (auto& t : F->times) if (n < cap) { if (names) names[n] = t.first; if (ms) ms[n] = t.second; n++; }
     *n_out = n;
-    if (counts3) { counts3[0] = F->sampledFrames; counts3[1] = F->sampledSolves; counts3[2] = F->sampledBa; }
-    F->times.clear(); F->sampledFrames = F->sampledSolves = F->sampledBa = 0;
+    if (counts3) { counts3[0] = F->sampledFrames; counts3[1] = F->sampledSolves; counts3[2] = F->sampledBa; counts3[3] = F->sampledCohorts; }
+    F->times.clear(); F->sampledFrames = F->sampledSolves = F->sampledBa = F->sampledCohorts = 0;
     return VSLAM_OK;
 }
 

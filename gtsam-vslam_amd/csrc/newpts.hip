@@ -14,6 +14,7 @@
 #include "proj_dev.hpp"
 #include "dmath.hpp"
 #include <vector>
+#include <mutex>
 
 namespace vslam {
 
@@ -56,7 +57,10 @@ __device__ __forceinline__ int np_block_scan_1024(int flag, int* wsum, int& tota
     return off + lanePrefix;
 }
 
-__global__ __launch_bounds__(1024) void k_np_candidates(NpArgs A) {
+// (the three kernels of the search read their arguments from entry blockIdx.z of a device table: one launch serves the
+// searches of all lanes of a lockstep group's cohort; one-session calls are a one-entry table)
+__global__ __launch_bounds__(1024) void k_np_candidates(const NpArgs* __restrict__ tab) {
+    const NpArgs& A = *lane_entry(tab, blockIdx.z);
     __shared__ int wsum[16];
     const NpKf& K0 = A.kf[0];
     int run = 0;
@@ -100,11 +104,12 @@ __global__ __launch_bounds__(1024) void k_np_candidates(NpArgs A) {
 }
 
 // predictKeysPosR + matchByProjectionRPredLBA for (candidate = blockIdx.x * 4 + wave, keyframe = blockIdx.y + 1)
-__global__ __launch_bounds__(256) void k_np_match(NpArgs A) {
+__global__ __launch_bounds__(256) void k_np_match(const NpArgs* __restrict__ tab) {
+    const NpArgs& A = *lane_entry(tab, blockIdx.z);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (candidate and keyframe are wave-uniform)
     const int c = blockIdx.x * 4 + wave, k = blockIdx.y + 1;
-    if (c >= A.count[0]) return;
+    if (k >= A.nKf || c >= A.count[0]) return;
     const NpKf& K = A.kf[k];
     int outL = -2, outR = -2;
     if (K.skip) { if (lane == 0) { A.match[((size_t)c * NP_MAX_KF + k) * 2] = -2; A.match[((size_t)c * NP_MAX_KF + k) * 2 + 1] = -2; } return; }
@@ -248,7 +253,8 @@ __device__ __forceinline__ bool np_dlt_point(double* sA, int t, int rows, double
     return true;
 }
 
-__global__ __launch_bounds__(64) void k_np_triangulate(NpArgs A) {
+__global__ __launch_bounds__(64) void k_np_triangulate(const NpArgs* __restrict__ tab) {
+    const NpArgs& A = *lane_entry(tab, blockIdx.z);
     extern __shared__ double sA[];
     const int t = threadIdx.x, c = blockIdx.x * 64 + t;
     if (c >= A.count[0]) return;
@@ -547,126 +553,155 @@ template <class T> using Dev = PoolBuf<T>;
 #define NP_POOL(var) DevPool* var = thread_pool(device); if (!var) { set_error("no device pool"); return VSLAM_ERR_HIP; } var->pending.clear();
 }  // namespace
 
-extern "C" vslam_status vslam_find_new_points(const vslam_new_points_problem* P, vslam_new_points_result* R, int32_t device) {
-    if (!P || !R || P->n_kf < 1 || P->n_kf > NP_MAX_KF || !P->kfs || P->n_levels < 1 || P->n_levels > MAX_LEVELS ||
-        !P->scale_pyramid || !P->sigma_factor || !R->cand_left || !R->cand_right || !R->accepted || !R->xyz || !R->n_obs || !R->obs) {
-        set_error("vslam_find_new_points: invalid problem");
-        return VSLAM_ERR_INVALID;
+// findNewPoints for n windows at once: every lane's keyframe arrays travel in ONE upload (pinned staging), the three kernels
+// are launched once for all lanes (grid z = lane, arguments from a device table), the results come back in ONE download.
+static vslam_status np_run(const vslam_new_points_problem* const* Ps, vslam_new_points_result* const* Rs, int N, int device) {
+    if (N <= 0 || !Ps || !Rs) return VSLAM_ERR_INVALID;
+    for (int i = 0; i < N; i++) {
+        const vslam_new_points_problem* P = Ps[i]; const vslam_new_points_result* R = Rs[i];
+        if (!P || !R || P->n_kf < 1 || P->n_kf > NP_MAX_KF || !P->kfs || P->n_levels < 1 || P->n_levels > MAX_LEVELS ||
+            !P->scale_pyramid || !P->sigma_factor || !R->cand_left || !R->cand_right || !R->accepted || !R->xyz || !R->n_obs || !R->obs) {
+            set_error("vslam_find_new_points: invalid problem");
+            return VSLAM_ERR_INVALID;
+        }
+        const vslam_kf_view& K0 = P->kfs[0];
+        if (K0.n_left > 0 && (!P->estimated_depth || !P->has_mp || !K0.right_idxs || !K0.unmatched_f)) { set_error("vslam_find_new_points: last keyframe arrays missing"); return VSLAM_ERR_INVALID; }
+        for (int k = 0; k < P->n_kf; k++) {
+            const vslam_kf_view& V = P->kfs[k];
+            if (V.n_left < 0 || V.n_right < 0 || !V.T_wc || (V.n_left > 0 && (!V.kps_l || !V.desc_l || !V.right_idxs || !V.unmatched_f)) ||
+                (V.n_right > 0 && (!V.kps_r || !V.desc_r || !V.left_idxs || !V.unmatched_fr)) || V.n_left > 65535 || V.n_right > 65535) {
+                set_error("vslam_find_new_points: keyframe %d arrays missing", k);
+                return VSLAM_ERR_INVALID;
+            }
+        }
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available (no CPU fallback)"); return VSLAM_ERR_NO_DEVICE; }
     if (device < 0 || device >= ndev) return VSLAM_ERR_INVALID;
     VS_HIP(hipSetDevice(device));
-    const vslam_kf_view& K0 = P->kfs[0];
-    if (K0.n_left > 0 && (!P->estimated_depth || !P->has_mp || !K0.right_idxs || !K0.unmatched_f)) { set_error("vslam_find_new_points: last keyframe arrays missing"); return VSLAM_ERR_INVALID; }
     NP_POOL(pool);
     hipStream_t stream = pool->stream;
     struct StreamGuard { DevPool* p; ~StreamGuard() { (void)p->sync(); } } guard{pool};   // before the blocks go back
-    const int cap = std::max(K0.n_left, 1);
-    NpArgs A{};
-    A.nKf = P->n_kf;
-    // every keyframe's arrays travel in ONE copy (one device block, one pinned staging area) when the pool's staging has room:
-    // eight uploads per keyframe were ~70 small blit launches per call
-    size_t packBytes = 0;
+    // ---- layout: [table][lane 0 arrays][lane 1 arrays] ... in one pack; work and result areas per lane ----------------------
+    struct KfOff { size_t kl, kr, dl, dr, ri, li, uf, ufr; };
+    struct LaneL { int cap; KfOff off[NP_MAX_KF]; size_t oDepth, oHas, oMpXyz, oMpDesc; size_t wPos, mds, cdesc, match; size_t rBase, rXyz, rNobs, rAcc, rObs, rKey, rCount, rEnd; };
+    std::vector<LaneL> LL(N);
+    size_t packBytes = 0, workBytes = 0, resBytes = 0;
     auto packOff = [&](size_t bytes) { const size_t at = packBytes; packBytes = (packBytes + bytes + 63) & ~(size_t)63; return at; };
-    struct KfOff { size_t kl, kr, dl, dr, ri, li, uf, ufr; } off[NP_MAX_KF];
-    for (int k = 0; k < P->n_kf; k++) {
-        const vslam_kf_view& V = P->kfs[k];
-        if (V.n_left < 0 || V.n_right < 0 || !V.T_wc || (V.n_left > 0 && (!V.kps_l || !V.desc_l || !V.right_idxs || !V.unmatched_f)) ||
-            (V.n_right > 0 && (!V.kps_r || !V.desc_r || !V.left_idxs || !V.unmatched_fr)) || V.n_left > 65535 || V.n_right > 65535) {
-            set_error("vslam_find_new_points: keyframe %d arrays missing", k);
-            return VSLAM_ERR_INVALID;
-        }
-        off[k].kl = packOff((size_t)V.n_left * sizeof(vslam_keypoint)); off[k].kr = packOff((size_t)V.n_right * sizeof(vslam_keypoint));
-        off[k].dl = packOff((size_t)V.n_left * 32); off[k].dr = packOff((size_t)V.n_right * 32);
-        off[k].ri = packOff((size_t)V.n_left * 4); off[k].li = packOff((size_t)V.n_right * 4);
-        off[k].uf = packOff((size_t)V.n_left * 4); off[k].ufr = packOff((size_t)V.n_right * 4);
-    }
-    // (... and the first keyframe's per-keypoint inputs ride in the same copy)
-    const size_t oDepth = packOff((size_t)cap * sizeof(float)), oHas = packOff((size_t)cap), oMpXyz = packOff((size_t)3 * cap * sizeof(double)),
-                 oMpDesc = packOff((size_t)32 * cap);
-    Dev<uint8_t> dPack(pool);
-    VS_HIP(dPack.alloc(std::max<size_t>(packBytes, 64)));
-    uint8_t* hPack = pool->stage(packBytes);
-    for (int k = 0; k < P->n_kf; k++) {
-        const vslam_kf_view& V = P->kfs[k];
-        NpKf& D = A.kf[k];
-        pose_from_rm16(V.T_wc, D.Twc);
-        pose_inverse(D.Twc, D.Tcw);
-        auto put = [&](size_t at, const void* src, size_t bytes) -> hipError_t {
-            if (!bytes) return hipSuccess;
-            if (hPack) { memcpy(hPack + at, src, bytes); return hipSuccess; }
-            return pool->h2d(dPack.p + at, src, bytes);          // (no staging room: one copy per array, as before)
-        };
-        VS_HIP(put(off[k].kl, V.kps_l, (size_t)V.n_left * sizeof(vslam_keypoint))); VS_HIP(put(off[k].kr, V.kps_r, (size_t)V.n_right * sizeof(vslam_keypoint)));
-        VS_HIP(put(off[k].dl, V.desc_l, (size_t)V.n_left * 32)); VS_HIP(put(off[k].dr, V.desc_r, (size_t)V.n_right * 32));
-        VS_HIP(put(off[k].ri, V.right_idxs, (size_t)V.n_left * 4)); VS_HIP(put(off[k].li, V.left_idxs, (size_t)V.n_right * 4));
-        VS_HIP(put(off[k].uf, V.unmatched_f, (size_t)V.n_left * 4)); VS_HIP(put(off[k].ufr, V.unmatched_fr, (size_t)V.n_right * 4));
-        D.kpsL = (const vslam_keypoint*)(dPack.p + off[k].kl); D.kpsR = (const vslam_keypoint*)(dPack.p + off[k].kr);
-        D.descL = dPack.p + off[k].dl; D.descR = dPack.p + off[k].dr;
-        D.rightIdxs = (const int*)(dPack.p + off[k].ri); D.leftIdxs = (const int*)(dPack.p + off[k].li);
-        D.unF = (const int*)(dPack.p + off[k].uf); D.unFR = (const int*)(dPack.p + off[k].ufr);
-        D.nL = V.n_left; D.nR = V.n_right;
-        D.skip = (k > 0 && V.id == P->kfs[0].id) ? 1 : 0;
-    }
-    {
-        auto put = [&](size_t at, const void* src, size_t bytes) -> hipError_t {
-            if (!bytes || !src) return hipSuccess;
-            if (hPack) { memcpy(hPack + at, src, bytes); return hipSuccess; }
-            return pool->h2d(dPack.p + at, src, bytes);
-        };
-        VS_HIP(put(oDepth, P->estimated_depth, (size_t)K0.n_left * sizeof(float))); VS_HIP(put(oHas, P->has_mp, (size_t)K0.n_left));
-        VS_HIP(put(oMpXyz, P->mp_xyz, (size_t)3 * K0.n_left * sizeof(double))); VS_HIP(put(oMpDesc, P->mp_desc, (size_t)32 * K0.n_left));
-    }
-    if (hPack && packBytes) VS_HIP(hipMemcpyAsync(dPack.p, hPack, packBytes, hipMemcpyHostToDevice, stream));
-    Dev<float> dMds(pool); Dev<uint8_t> dCdesc(pool), dRes(pool); Dev<double> dWpos(pool);
-    Dev<int> dMatch(pool);
-    VS_HIP(dWpos.alloc((size_t)3 * cap)); VS_HIP(dMds.alloc(cap)); VS_HIP(dCdesc.alloc((size_t)32 * cap));
-    VS_HIP(dMatch.alloc((size_t)cap * NP_MAX_KF * 2));
-    // ONE result block, fetched by one copy at capacity: [xyz | nObs | accepted] (zero-filled) [obs] (0xff-filled) [key | count]
-    size_t resBytes = 0;
+    auto workOff = [&](size_t bytes) { const size_t at = workBytes; workBytes = (workBytes + std::max<size_t>(bytes, 8) + 255) & ~(size_t)255; return at; };
     auto resOff = [&](size_t bytes) { const size_t at = resBytes; resBytes = (resBytes + bytes + 63) & ~(size_t)63; return at; };
-    const size_t rXyz = resOff((size_t)3 * cap * sizeof(double)), rNobs = resOff((size_t)cap * sizeof(int)), rAcc = resOff((size_t)cap);
-    const size_t rObs = resOff((size_t)cap * NP_MAX_KF * 3 * sizeof(int));
-    const size_t rKey = resOff((size_t)2 * cap * sizeof(int)), rCount = resOff(4 * sizeof(int));
-    VS_HIP(dRes.alloc(resBytes));
-    VS_HIP(hipMemsetAsync(dRes.p, 0, rObs, stream));
-    VS_HIP(hipMemsetAsync(dRes.p + rObs, 0xff, rKey - rObs, stream));
-    A.depth = (const float*)(dPack.p + oDepth); A.hasMp = dPack.p + oHas; A.mpXyz = (double*)(dPack.p + oMpXyz); A.mpDesc = dPack.p + oMpDesc;
-    A.fx = P->rig.fx; A.fy = P->rig.fy; A.cx = P->rig.cx; A.cy = P->rig.cy; A.b = (double)P->rig.baseline; A.w = P->rig.width; A.h = P->rig.height;
-    for (int l = 0; l < P->n_levels; l++) { A.scalePyr[l] = P->scale_pyramid[l]; A.sigma[l] = P->sigma_factor[l]; }
-    A.logScale = P->log_scale; A.nLev = P->n_levels;
-    const float imageRatio = (float)P->rig.width / (float)P->rig.height;      // assignKeysToGrids (src/FeatureTracker.cpp:30-35)
-    A.xGrids = 64; A.yGrids = cv_ceil_f((float)A.xGrids / imageRatio);
-    A.xMult = (float)A.xGrids / (float)P->rig.width; A.yMult = (float)A.yGrids / (float)P->rig.height;
-    A.wPos = dWpos.p; A.key = (int*)(dRes.p + rKey); A.mds = dMds.p; A.cdesc = dCdesc.p; A.count = (int*)(dRes.p + rCount); A.cap = cap; A.match = dMatch.p;
-    A.accepted = dRes.p + rAcc; A.xyz = (double*)(dRes.p + rXyz); A.nObs = (int*)(dRes.p + rNobs); A.obs = (int*)(dRes.p + rObs);
-
-    hipLaunchKernelGGL(k_np_candidates, dim3(1), dim3(1024), 0, stream, A);
-    if (P->n_kf > 1) hipLaunchKernelGGL(k_np_match, dim3((cap + 3) / 4, P->n_kf - 1), dim3(256), 0, stream, A);
-    else VS_HIP(hipMemsetAsync(dMatch.p, 0xfe, (size_t)cap * NP_MAX_KF * 2 * sizeof(int), stream));
+    const size_t oTab = packOff((size_t)N * sizeof(NpArgs));
+    int capMax = 1, kfMax = 1;
+    for (int i = 0; i < N; i++) {
+        const vslam_new_points_problem* P = Ps[i];
+        LaneL& q = LL[i];
+        const vslam_kf_view& K0 = P->kfs[0];
+        const int cap = q.cap = std::max(K0.n_left, 1);
+        capMax = std::max(capMax, cap); kfMax = std::max(kfMax, P->n_kf);
+        for (int k = 0; k < P->n_kf; k++) {
+            const vslam_kf_view& V = P->kfs[k];
+            q.off[k].kl = packOff((size_t)V.n_left * sizeof(vslam_keypoint)); q.off[k].kr = packOff((size_t)V.n_right * sizeof(vslam_keypoint));
+            q.off[k].dl = packOff((size_t)V.n_left * 32); q.off[k].dr = packOff((size_t)V.n_right * 32);
+            q.off[k].ri = packOff((size_t)V.n_left * 4); q.off[k].li = packOff((size_t)V.n_right * 4);
+            q.off[k].uf = packOff((size_t)V.n_left * 4); q.off[k].ufr = packOff((size_t)V.n_right * 4);
+        }
+        q.oDepth = packOff((size_t)cap * sizeof(float)); q.oHas = packOff((size_t)cap); q.oMpXyz = packOff((size_t)3 * cap * sizeof(double));
+        q.oMpDesc = packOff((size_t)32 * cap);
+        q.wPos = workOff((size_t)3 * cap * 8); q.mds = workOff((size_t)cap * 4); q.cdesc = workOff((size_t)32 * cap); q.match = workOff((size_t)cap * NP_MAX_KF * 2 * 4);
+        // result block of the lane: [xyz | nObs | accepted] (zero-filled) [obs] (0xff-filled) [key | count]
+        q.rBase = resBytes;
+        q.rXyz = resOff((size_t)3 * cap * sizeof(double)); q.rNobs = resOff((size_t)cap * sizeof(int)); q.rAcc = resOff((size_t)cap);
+        q.rObs = resOff((size_t)cap * NP_MAX_KF * 3 * sizeof(int));
+        q.rKey = resOff((size_t)2 * cap * sizeof(int)); q.rCount = resOff(4 * sizeof(int));
+        q.rEnd = resBytes;
+    }
+    Dev<uint8_t> dPack(pool), dWork(pool), dRes(pool);
+    VS_HIP(dPack.alloc(std::max<size_t>(packBytes, 64))); VS_HIP(dWork.alloc(std::max<size_t>(workBytes, 64))); VS_HIP(dRes.alloc(std::max<size_t>(resBytes, 64)));
+    uint8_t* hPack = pool->stage(packBytes);
+    std::vector<uint8_t> hostPack;
+    if (!hPack) { hostPack.resize(packBytes); hPack = hostPack.data(); }       // (staging too small this time: pageable copy, grows at sync)
+    NpArgs* tab = (NpArgs*)(hPack + oTab);
+    for (int i = 0; i < N; i++) {
+        const vslam_new_points_problem* P = Ps[i];
+        const LaneL& q = LL[i];
+        const vslam_kf_view& K0 = P->kfs[0];
+        NpArgs A{};
+        A.nKf = P->n_kf;
+        auto put = [&](size_t at, const void* src, size_t bytes) { if (bytes && src) memcpy(hPack + at, src, bytes); };
+        for (int k = 0; k < P->n_kf; k++) {
+            const vslam_kf_view& V = P->kfs[k];
+            NpKf& D = A.kf[k];
+            pose_from_rm16(V.T_wc, D.Twc);
+            pose_inverse(D.Twc, D.Tcw);
+            put(q.off[k].kl, V.kps_l, (size_t)V.n_left * sizeof(vslam_keypoint)); put(q.off[k].kr, V.kps_r, (size_t)V.n_right * sizeof(vslam_keypoint));
+            put(q.off[k].dl, V.desc_l, (size_t)V.n_left * 32); put(q.off[k].dr, V.desc_r, (size_t)V.n_right * 32);
+            put(q.off[k].ri, V.right_idxs, (size_t)V.n_left * 4); put(q.off[k].li, V.left_idxs, (size_t)V.n_right * 4);
+            put(q.off[k].uf, V.unmatched_f, (size_t)V.n_left * 4); put(q.off[k].ufr, V.unmatched_fr, (size_t)V.n_right * 4);
+            D.kpsL = (const vslam_keypoint*)(dPack.p + q.off[k].kl); D.kpsR = (const vslam_keypoint*)(dPack.p + q.off[k].kr);
+            D.descL = dPack.p + q.off[k].dl; D.descR = dPack.p + q.off[k].dr;
+            D.rightIdxs = (const int*)(dPack.p + q.off[k].ri); D.leftIdxs = (const int*)(dPack.p + q.off[k].li);
+            D.unF = (const int*)(dPack.p + q.off[k].uf); D.unFR = (const int*)(dPack.p + q.off[k].ufr);
+            D.nL = V.n_left; D.nR = V.n_right;
+            D.skip = (k > 0 && V.id == P->kfs[0].id) ? 1 : 0;
+        }
+        put(q.oDepth, P->estimated_depth, (size_t)K0.n_left * sizeof(float)); put(q.oHas, P->has_mp, (size_t)K0.n_left);
+        put(q.oMpXyz, P->mp_xyz, (size_t)3 * K0.n_left * sizeof(double)); put(q.oMpDesc, P->mp_desc, (size_t)32 * K0.n_left);
+        A.depth = (const float*)(dPack.p + q.oDepth); A.hasMp = dPack.p + q.oHas; A.mpXyz = (double*)(dPack.p + q.oMpXyz); A.mpDesc = dPack.p + q.oMpDesc;
+        A.fx = P->rig.fx; A.fy = P->rig.fy; A.cx = P->rig.cx; A.cy = P->rig.cy; A.b = (double)P->rig.baseline; A.w = P->rig.width; A.h = P->rig.height;
+        for (int l = 0; l < P->n_levels; l++) { A.scalePyr[l] = P->scale_pyramid[l]; A.sigma[l] = P->sigma_factor[l]; }
+        A.logScale = P->log_scale; A.nLev = P->n_levels;
+        const float imageRatio = (float)P->rig.width / (float)P->rig.height;      // assignKeysToGrids (src/FeatureTracker.cpp:30-35)
+        A.xGrids = 64; A.yGrids = cv_ceil_f((float)A.xGrids / imageRatio);
+        A.xMult = (float)A.xGrids / (float)P->rig.width; A.yMult = (float)A.yGrids / (float)P->rig.height;
+        A.wPos = (double*)(dWork.p + q.wPos); A.mds = (float*)(dWork.p + q.mds); A.cdesc = dWork.p + q.cdesc; A.match = (int*)(dWork.p + q.match);
+        A.key = (int*)(dRes.p + q.rKey); A.count = (int*)(dRes.p + q.rCount); A.cap = q.cap;
+        A.accepted = dRes.p + q.rAcc; A.xyz = (double*)(dRes.p + q.rXyz); A.nObs = (int*)(dRes.p + q.rNobs); A.obs = (int*)(dRes.p + q.rObs);
+        tab[i] = A;
+        VS_HIP(hipMemsetAsync(dRes.p + q.rBase, 0, q.rObs - q.rBase, stream));
+        VS_HIP(hipMemsetAsync(dRes.p + q.rObs, 0xff, q.rKey - q.rObs, stream));
+        if (P->n_kf <= 1) VS_HIP(hipMemsetAsync(dWork.p + q.match, 0xfe, (size_t)q.cap * NP_MAX_KF * 2 * sizeof(int), stream));
+    }
+    VS_HIP(hipMemcpyAsync(dPack.p, hPack, packBytes, hipMemcpyHostToDevice, stream));
+    if (!hostPack.empty()) VS_HIP(hipStreamSynchronize(stream));       // (pageable source: the copy has been staged, but keep the vector alive and simple)
+    const NpArgs* dTab = (const NpArgs*)(dPack.p + oTab);
+    hipLaunchKernelGGL(k_np_candidates, dim3(1, 1, N), dim3(1024), 0, stream, dTab);
+    if (kfMax > 1) hipLaunchKernelGGL(k_np_match, dim3((capMax + 3) / 4, kfMax - 1, N), dim3(256), 0, stream, dTab);
     const size_t lds = (size_t)NP_MAX_ROWS * 4 * 64 * sizeof(double);
-    VS_HIP(hipFuncSetAttribute((const void*)k_np_triangulate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_np_triangulate, dim3((cap + 63) / 64), dim3(64), lds, stream, A);
+    {
+        static std::once_flag once;      // (process-global function attribute: set once, not per call from several mapping threads)
+        std::call_once(once, [&] { (void)hipFuncSetAttribute((const void*)k_np_triangulate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+    }
+    hipLaunchKernelGGL(k_np_triangulate, dim3((capMax + 63) / 64, 1, N), dim3(64), lds, stream, dTab);
     VS_HIP(hipGetLastError());
     std::vector<uint8_t> res(resBytes);
     VS_HIP(pool->d2h(res.data(), dRes.p, resBytes));
     VS_HIP(pool->sync());
-    const int n = *(const int*)(res.data() + rCount);
-    R->n_candidates = n;
-    if (n > R->capacity) { set_error("vslam_find_new_points: result capacity %d < %d candidates", R->capacity, n); return VSLAM_ERR_CAPACITY; }
-    if (n) {
-        const int* key = (const int*)(res.data() + rKey);
-        const int* obs = (const int*)(res.data() + rObs);
-        memcpy(R->accepted, res.data() + rAcc, n);
-        memcpy(R->xyz, res.data() + rXyz, (size_t)3 * n * sizeof(double));
-        memcpy(R->n_obs, res.data() + rNobs, (size_t)n * sizeof(int));
-        for (int i = 0; i < n; i++) { R->cand_left[i] = key[2 * i]; R->cand_right[i] = key[2 * i + 1]; }
-        for (int i = 0; i < n; i++)
+    for (int i = 0; i < N; i++) {
+        const vslam_new_points_problem* P = Ps[i]; vslam_new_points_result* R = Rs[i];
+        const LaneL& q = LL[i];
+        const int n = *(const int*)(res.data() + q.rCount);
+        R->n_candidates = n;
+        if (n > R->capacity) { set_error("vslam_find_new_points: result capacity %d < %d candidates", R->capacity, n); return VSLAM_ERR_CAPACITY; }
+        if (!n) continue;
+        const int* key = (const int*)(res.data() + q.rKey);
+        const int* obs = (const int*)(res.data() + q.rObs);
+        memcpy(R->accepted, res.data() + q.rAcc, n);
+        memcpy(R->xyz, res.data() + q.rXyz, (size_t)3 * n * sizeof(double));
+        memcpy(R->n_obs, res.data() + q.rNobs, (size_t)n * sizeof(int));
+        for (int c = 0; c < n; c++) { R->cand_left[c] = key[2 * c]; R->cand_right[c] = key[2 * c + 1]; }
+        for (int c = 0; c < n; c++)
             for (int e = 0; e < P->n_kf; e++)
-                for (int q = 0; q < 3; q++) R->obs[((size_t)i * P->n_kf + e) * 3 + q] = e < R->n_obs[i] ? obs[((size_t)i * NP_MAX_KF + e) * 3 + q] : -1;
+                for (int w = 0; w < 3; w++) R->obs[((size_t)c * P->n_kf + e) * 3 + w] = e < R->n_obs[c] ? obs[((size_t)c * NP_MAX_KF + e) * 3 + w] : -1;
     }
     return VSLAM_OK;
+}
+
+extern "C" vslam_status vslam_find_new_points(const vslam_new_points_problem* P, vslam_new_points_result* R, int32_t device) {
+    return np_run(&P, &R, 1, device);
+}
+extern "C" vslam_status vslam_find_new_points_batch(const vslam_new_points_problem* const* problems, vslam_new_points_result* const* results,
+                                                    int32_t n, int32_t device) {
+    return np_run(problems, results, n, device);
 }
 
 // MapPoint::calcDescriptor for a batch of map points: descs = concatenated observation descriptors, start[n_mp + 1]
@@ -750,7 +785,10 @@ extern "C" vslam_status vslam_mono_new_points(const vslam_mono_points_problem* P
     A.nViews = dNv.p; A.viewKf = dVk.p; A.viewXy = dXy.p; A.viewOct = dVo.p;
     A.accepted = dAcc.p; A.xyz = dXyz.p; A.nObs = dNo.p; A.keep = dKeep.p;
     const size_t lds = (size_t)2 * nK * 4 * 64 * sizeof(double);
-    VS_HIP(hipFuncSetAttribute((const void*)k_np_mono_points, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+        static std::once_flag once;
+        std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)k_np_mono_points, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)2 * NP_MAX_KF * 4 * 64 * sizeof(double))); });
+    }
     hipLaunchKernelGGL(k_np_mono_points, dim3((nP + 63) / 64), dim3(64), lds, ps, A);
     VS_HIP(hipGetLastError());
     VS_HIP(pool->d2h(R->accepted, dAcc.p, nP));

@@ -180,7 +180,8 @@ __device__ __forceinline__ int proj_decide(unsigned long long l1, unsigned long 
 // step, two points of the step claim the same keypoint, or a full list is (almost) exhausted — then the
 // step is replayed point by point (with the exact rescan when a list is exhausted), so the result is the
 // reference's for any input.
-constexpr int PROJ_SUPER = 512;      // map points staged in LDS per super-step (64 KB of keys)
+constexpr int PROJ_SUPER = 512;      // map points staged in LDS per super-step (64 KB of keys); halved by the launcher until the claim
+                                     // tables of a large frame (3 ints per keypoint) fit next to it: `superN`
 constexpr int PROJ_NT = 512;         // threads of k_proj_resolve
 constexpr int PROJ_PAR_PASSES = 8;   // parallel phase: key lists of up to 8 x 128 map points live in registers
 constexpr int PROJ_PAR_ROUNDS = 16;  // fixed-point rounds before the sequential walk takes over
@@ -189,7 +190,7 @@ __device__ __forceinline__ void lds_order() { asm volatile("s_waitcnt lgkmcnt(0)
 
 __device__ __forceinline__ void proj_resolve_body(const ProjArgs& A, const unsigned long long* __restrict__ topk,
                                                   int* __restrict__ matchedL, int* __restrict__ matchedR,
-                                                  int* __restrict__ matches, int* __restrict__ outp, int forceSeq) {
+                                                  int* __restrict__ matches, int* __restrict__ outp, int forceSeq, int superN) {
     extern __shared__ int claims[];
     int* cl = claims;
     int* cr = claims + A.n[0];
@@ -197,8 +198,8 @@ __device__ __forceinline__ void proj_resolve_body(const ProjArgs& A, const unsig
     int* li = ri + A.n[0];      // the stereo-partner lookup is on the serial path
     int* tl = li + A.n[1];      // tentative claims of the current 16-point step (lowest point index wins), INT_MAX = none
     int* tr = tl + A.n[0];
-    int* spair = tr + A.n[1];                                                      // [PROJ_SUPER][2]
-    unsigned long long* skeys = (unsigned long long*)(((uintptr_t)(spair + 2 * PROJ_SUPER) + 15) & ~(uintptr_t)15);   // [PROJ_SUPER][16]
+    int* spair = tr + A.n[1];                                                      // [superN][2]
+    unsigned long long* skeys = (unsigned long long*)(((uintptr_t)(spair + 2 * superN) + 15) & ~(uintptr_t)15);   // [superN][16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (A.gate && *A.gate < A.gateMin) return;
     int M = A.M;
@@ -318,8 +319,8 @@ __device__ __forceinline__ void proj_resolve_body(const ProjArgs& A, const unsig
             nMatches = sCount;
         }
     }
-    for (int sc = 0; sc < (solved ? 0 : M); sc += PROJ_SUPER) {
-        const int n = min(PROJ_SUPER, M - sc);
+    for (int sc = 0; sc < (solved ? 0 : M); sc += superN) {
+        const int n = min(superN, M - sc);
         __syncthreads();
         // all four waves stage this super-step's key lists and current pairs in LDS (deep, coalesced loads):
         // the serial walk below then never waits on HBM / L2
@@ -469,23 +470,30 @@ __device__ __forceinline__ void proj_resolve_body(const ProjArgs& A, const unsig
 }
 
 __global__ __launch_bounds__(PROJ_NT) void k_proj_resolve(ProjArgs A, const unsigned long long* __restrict__ topk, int* __restrict__ matchedL,
-                                                     int* __restrict__ matchedR, int* __restrict__ matches, int* __restrict__ outp, int forceSeq) {
-    proj_resolve_body(A, topk, matchedL, matchedR, matches, outp, forceSeq);
+                                                     int* __restrict__ matchedR, int* __restrict__ matches, int* __restrict__ outp, int forceSeq, int superN) {
+    proj_resolve_body(A, topk, matchedL, matchedR, matches, outp, forceSeq, superN);
 }
 // batched form: blockIdx.x = lane
-__global__ __launch_bounds__(PROJ_NT) void k_proj_resolve_b(const ProjLane* __restrict__ lanes, int forceSeq) {
+__global__ __launch_bounds__(PROJ_NT) void k_proj_resolve_b(const ProjLane* __restrict__ lanes, int forceSeq, int superN) {
     const ProjLane& L = *lane_entry(lanes, blockIdx.x);
-    proj_resolve_body(L.A, L.topk, L.matchedL, L.matchedR, L.matches, L.out, forceSeq);
+    proj_resolve_body(L.A, L.topk, L.matchedL, L.matchedR, L.matches, L.out, forceSeq, superN);
 }
 
-static size_t proj_resolve_lds(int nL, int nR) {
-    return (size_t)(3 * (nL + nR) + 2 * PROJ_SUPER) * sizeof(int) + 32 + (size_t)PROJ_SUPER * 16 * sizeof(unsigned long long);
+static size_t proj_resolve_lds(int nL, int nR, int superN) {
+    return (size_t)(3 * (nL + nR) + 2 * superN) * sizeof(int) + 32 + (size_t)superN * 16 * sizeof(unsigned long long);
+}
+constexpr size_t PROJ_LDS_CAP = 159 * 1024;
+// super-step of the sequential walk: the largest that fits beside the frame's claim tables (1920x1200 frames: ~8 800 keys)
+static int proj_super(int nL, int nR) {
+    int sp = PROJ_SUPER;
+    while (sp > 32 && proj_resolve_lds(nL, nR, sp) > PROJ_LDS_CAP) sp /= 2;
+    return sp;
 }
 static void proj_attrs() {
     static bool attr = false;
     if (attr) return;
-    (void)hipFuncSetAttribute((const void*)k_proj_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_proj_resolve_b, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_proj_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PROJ_LDS_CAP);
+    (void)hipFuncSetAttribute((const void*)k_proj_resolve_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PROJ_LDS_CAP);
     attr = true;
 }
 
@@ -503,16 +511,18 @@ void launch_proj_batch(hipStream_t s, const ProjLane* dLanes, int B, int maxM, i
     t = tm ? tm->begin("proj_candidates") : -1;
     hipLaunchKernelGGL(k_proj_candidates_b, dim3((2 * maxM + 3) / 4, B), dim3(256), 0, s, dLanes);
     if (tm) { tm->end(t); t = tm->begin("proj_resolve"); }
-    hipLaunchKernelGGL(k_proj_resolve_b, dim3(B), dim3(PROJ_NT), proj_resolve_lds(maxL, maxR), s, dLanes, forceSeq);
+    const int sp = proj_super(maxL, maxR);
+    hipLaunchKernelGGL(k_proj_resolve_b, dim3(B), dim3(PROJ_NT), proj_resolve_lds(maxL, maxR, sp), s, dLanes, forceSeq, sp);
     if (tm) tm->end(t);
 }
 
 void launch_proj_resolve(hipStream_t s, const ProjArgs& A, const unsigned long long* topk, int* matchedL, int* matchedR,
                          int* matches, int* out) {
-    const size_t sh = proj_resolve_lds(A.n[0], A.n[1]);
+    const int sp = proj_super(A.n[0], A.n[1]);
+    const size_t sh = proj_resolve_lds(A.n[0], A.n[1], sp);
     proj_attrs();
     const int forceSeq = getenv("VSLAM_PROJ_SEQUENTIAL") ? 1 : 0;     // A/B and fallback testing (read per launch)
-    hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(PROJ_NT), sh, s, A, topk, matchedL, matchedR, matches, out, forceSeq);
+    hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(PROJ_NT), sh, s, A, topk, matchedL, matchedR, matches, out, forceSeq, sp);
 #ifdef VSLAM_PROJ_STAMPS
     { int o[2]; (void)hipStreamSynchronize(s); (void)hipMemcpy(o, out, sizeof(o), hipMemcpyDeviceToHost); fprintf(stderr, "proj_resolve: matches %d, fixed-point rounds %d (-1 = sequential walk)\n", o[0], o[1]); }
 #endif

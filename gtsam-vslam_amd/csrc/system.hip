@@ -471,7 +471,7 @@ vslam_status vslam_system::frame_post(SysFrameCtx& c, const SysTrackState& st, d
             out.ba_wrong = lastMapping.ba_wrong; out.ba_outliers = lastMapping.ba_outliers;
             out.ba_report[0] = lastMapping.ba_report[0]; out.ba_report[1] = lastMapping.ba_report[1];
             out.ba_residuals = lastMapping.ba_residuals; out.ba_free_kf = lastMapping.ba_free_kf; out.ba_sum_k2 = lastMapping.ba_sum_k2;
-            out.ba_trials = lastMapping.ba_trials;
+            out.ba_trials = lastMapping.ba_trials; out.ba_rounds = lastMapping.ba_rounds;
             out.n_keyframes = (int)keyFrames.size(); out.n_map_points = (int)mapPoints.size(); out.n_active_after = (int)active.size();
             mappingReportFresh = false;
         }
@@ -542,6 +542,16 @@ void vslam_system::run_mapping() {
     {
         std::lock_guard<std::mutex> lk(wMu);
         if (s != VSLAM_OK && workerStatus == VSLAM_OK) { workerStatus = s; snprintf(workerError, sizeof(workerError), "%s", vslam_last_error()); }
+        mappingBusy = false;
+    }
+    wCv.notify_all();
+}
+
+// the batch's mapping engine ran this session's job as part of a cohort
+void vslam_system::finish_job(vslam_status s, const char* err) {
+    {
+        std::lock_guard<std::mutex> lk(wMu);
+        if (s != VSLAM_OK && workerStatus == VSLAM_OK) { workerStatus = s; snprintf(workerError, sizeof(workerError), "%s", err ? err : ""); }
         mappingBusy = false;
     }
     wCv.notify_all();
@@ -906,6 +916,7 @@ vslam_status vslam_system::ba_commit(MapPass& p) {
     lastMapping.ba_report[0] = Rr.report[0]; lastMapping.ba_report[1] = Rr.report[1];
     lastMapping.ba_residuals = (int)Rr.n_residuals; lastMapping.ba_free_kf = (int)Rr.n_free_kf; lastMapping.ba_sum_k2 = (int)Rr.sum_k2;
     lastMapping.ba_trials = Rr.report[0].inner_iterations + Rr.report[1].inner_iterations;
+    lastMapping.ba_rounds = (int)Rr.rounds;
     mappingReportFresh = true;
     return VSLAM_OK;
 }

@@ -202,6 +202,7 @@ struct vslam_system {
     void frame_imu_input(SysFrameCtx& c);
     vslam_status frame_post(SysFrameCtx& c, const SysTrackState& st, double* T_wc_out, vslam_frame_report* rep);
     void run_mapping();
+    void finish_job(vslam_status s, const char* err);
     vslam_status track(const uint8_t* L, const uint8_t* R, int stride, bool onDevice, int frame, const vslam_imu_bucket* imu,
                        double* T_wc_out, vslam_frame_report* rep);
     vslam_status fetch_keys(SysKeys& k);

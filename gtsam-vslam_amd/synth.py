@@ -465,7 +465,8 @@ def make_corridor(seed=11, length=48.0, boxes_per_m=2.2):
               (np.array([6.0, 0, L2 / 2]), np.array([0, 0, 1.0]), np.array([0, 1.0, 0]), L2, 30, (1300, 800), 140.0)]
     for _ in range(int(length * boxes_per_m)):
         z = rng.uniform(1.8, length)
-        c = np.array([rng.uniform(-4.5, 4.5), rng.uniform(-1.6, 1.3), z])
+        # (outside the tube the camera flies through: |x| <= 0.6 m + the boxes' half width, so no plane is ever crossed)
+        c = np.array([rng.uniform(1.7, 4.8) * (1.0 if rng.random() < 0.5 else -1.0), rng.uniform(-1.6, 1.3), z])
         yaw = rng.uniform(-0.5, 0.5)
         ex = np.array([np.cos(yaw), 0, np.sin(yaw)])
         planes.append((c, ex, np.array([0, 1.0, 0]), rng.uniform(0.25, 0.8), rng.uniform(0.25, 0.8),

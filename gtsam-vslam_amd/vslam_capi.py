@@ -302,7 +302,7 @@ class BaProblem(C.Structure):
 class BaResult(C.Structure):
     _fields_ = [("kf_pose_wc", C.c_void_p), ("lm_xyz", C.c_void_p), ("pair_wrong", C.c_void_p),
                 ("pair_wrong_pass1", C.c_void_p), ("report", LmReport * 2), ("n_residuals", C.c_int64),
-                ("n_landmarks", C.c_int64), ("n_free_kf", C.c_int64), ("sum_k2", C.c_int64)]
+                ("n_landmarks", C.c_int64), ("n_free_kf", C.c_int64), ("sum_k2", C.c_int64), ("rounds", C.c_int64)]
 
 
 def ba_problem_structs(rig, sigma_factor, inv_sigma_factor, prob):
@@ -336,7 +336,7 @@ def ba_problem_structs(rig, sigma_factor, inv_sigma_factor, prob):
                 for s in range(2)]
         return dict(kf_pose=kfOut.reshape(-1, 4, 4), lm=lmOut[:len(lm)], pair_wrong=wrong[:len(pk)],
                     pair_wrong1=wrong1[:len(pk)], reports=reps, residuals=R.n_residuals, landmarks=R.n_landmarks,
-                    free_kf=R.n_free_kf, sum_k2=R.sum_k2)
+                    free_kf=R.n_free_kf, sum_k2=R.sum_k2, rounds=R.rounds)
     keep = dict(arrays=[kfPose, kfId, kfFixed, kfLocal, lm, pk, pl, pf, puv, poct, sf, isf, kfOut, lmOut, wrong, wrong1], read=read)
     return P, R, keep
 
@@ -346,6 +346,16 @@ def local_ba(rig, sigma_factor, inv_sigma_factor, prob, device=0, comm=None):
     P, R, keep = ba_problem_structs(rig, sigma_factor, inv_sigma_factor, prob)
     _chk(lib().vslam_local_ba(C.byref(P), C.byref(R), device, comm.h if comm is not None else None))
     return keep["read"]()
+
+
+def local_ba_batch(rig, sigma_factor, inv_sigma_factor, probs, device=0):
+    """vslam_local_ba_batch: the problems optimised together, one launch per stage for all of them"""
+    n = len(probs)
+    built = [ba_problem_structs(rig, sigma_factor, inv_sigma_factor, pr) for pr in probs]
+    PP = (C.POINTER(BaProblem) * n)(*[C.pointer(b[0]) for b in built])
+    RR = (C.POINTER(BaResult) * n)(*[C.pointer(b[1]) for b in built])
+    _chk(lib().vslam_local_ba_batch(PP, RR, n, int(device)))
+    return [b[2]["read"]() for b in built]
 
 
 def local_ba_timings():
@@ -745,7 +755,7 @@ class FrameReport(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("frame", "keyframe_inserted", "n_active", "n_inliers", "n_stereo", "rounds", "lm_iterations",
                                          "n_keyframes", "n_map_points", "n_active_after", "mapping_ran", "new_points", "ba_keyframes",
                                          "ba_local", "ba_landmarks", "ba_pairs", "ba_wrong", "ba_outliers", "ba_residuals", "ba_free_kf",
-                                         "ba_sum_k2", "ba_trials")] + [("ba_report", LmReport * 2)]
+                                         "ba_sum_k2", "ba_trials", "ba_rounds")] + [("ba_report", LmReport * 2)]
 
 
 class System:
@@ -1053,13 +1063,14 @@ class Batch:
 # ---- vslam_fleet: S sessions on S library threads ------------------------------------------------------------------------
 class FleetSequence(C.Structure):
     _fields_ = [("n_frames", C.c_int32), ("left", C.c_void_p), ("right", C.c_void_p), ("stride", C.c_int32), ("on_device", C.c_int32),
-                ("imu_forward", C.c_void_p), ("imu_backward", C.c_void_p), ("T_wc_true", C.c_void_p), ("velocity_true", C.c_void_p)]
+                ("imu_forward", C.c_void_p), ("imu_backward", C.c_void_p), ("T_wc_true", C.c_void_p), ("velocity_true", C.c_void_p),
+                ("start_span", C.c_int32)]
 
 
 class FleetReport(C.Structure):
     _fields_ = [("n_sessions", C.c_int32)] + [(n, C.c_int64) for n in ("frames", "keyframes", "mappings", "new_points", "ba_landmarks",
-                                                                      "ba_pairs", "ba_residuals", "ba_free_kf", "ba_sum_k2", "ba_trials", "ba_iterations",
-                                                                      "sum_inliers", "sum_rounds", "lost_frames")] + \
+                                                                      "ba_pairs", "ba_residuals", "ba_free_kf", "ba_sum_k2", "ba_trials", "ba_iterations", "ba_rounds",
+                                                                      "sum_inliers", "sum_rounds", "lost_frames", "sum_active")] + \
                [("min_inliers", C.c_int32), ("seconds", C.c_double), ("max_session_seconds", C.c_double),
                 ("max_position_error", C.c_double), ("sum_sq_position_error", C.c_double)]
 
@@ -1085,13 +1096,13 @@ class Fleet:
     """S independent sessions replaying one stereo sequence (device or pinned-host image pointers) as a ping-pong."""
 
     def __init__(self, cfg, n_sessions, left_ptrs, right_ptrs, stride, on_device, poses=None, velocities=None,
-                 imu_forward=None, imu_backward=None, lanes=0):
+                 imu_forward=None, imu_backward=None, lanes=0, start_span=0):
         """lanes > 0: the sessions are the lanes of ceil(n_sessions / lanes) lockstep groups (vslam_batch)"""
         self.L = lib()
         n = len(left_ptrs)
         self._keep = []
         seq = FleetSequence()
-        seq.n_frames = n; seq.stride = stride; seq.on_device = int(on_device)
+        seq.n_frames = n; seq.stride = stride; seq.on_device = int(on_device); seq.start_span = int(start_span)
         la = (C.c_void_p * n)(*left_ptrs); ra = (C.c_void_p * n)(*right_ptrs)
         self._keep += [la, ra]
         seq.left = C.cast(la, C.c_void_p); seq.right = C.cast(ra, C.c_void_p)
@@ -1129,9 +1140,9 @@ class Fleet:
         _chk(self.L.vslam_fleet_set_sampling(self.h, int(every)))
 
     def timings(self):
-        names = (C.c_char_p * 64)(); ms = (C.c_float * 64)(); n = C.c_int32(); cnt = (C.c_int64 * 3)()
+        names = (C.c_char_p * 64)(); ms = (C.c_float * 64)(); n = C.c_int32(); cnt = (C.c_int64 * 4)()
         _chk(self.L.vslam_fleet_timings(self.h, names, ms, 64, C.byref(n), cnt))
-        return {names[i].decode(): float(ms[i]) for i in range(n.value)}, dict(frames=cnt[0], solves=cnt[1], ba=cnt[2])
+        return {names[i].decode(): float(ms[i]) for i in range(n.value)}, dict(frames=cnt[0], solves=cnt[1], ba=cnt[2], ba_cohorts=cnt[3])
 
     def close(self):
         if self.h:

@@ -314,6 +314,7 @@ typedef struct vslam_ba_result {
     uint8_t* pair_wrong_pass1;      /* optional (may be NULL): wrongMatches after the first pass       */
     vslam_lm_report report[2];
     int64_t n_residuals, n_landmarks, n_free_kf, sum_k2;   /* work figures of the last pass           */
+    int64_t rounds;                 /* trial rounds of both passes (one round = up to 4 lambda candidates evaluated at once) */
 } vslam_ba_result;
 
 /* Write-back of localBA, numerical part of MapPoint::updatePos (src/Map.cpp:212-234) as called from
@@ -384,6 +385,12 @@ vslam_status vslam_comm_create_rccl(const uint8_t id[128], int32_t rank, int32_t
 vslam_status vslam_comm_create_local(int32_t world, vslam_comm** out_array /* world handles */);
 void vslam_comm_destroy(vslam_comm* comm);
 
+/* The same for n independent tracker-window problems at once (the local mapping of a lockstep group, vslam_batch): ONE kernel
+ * launch per stage for all of them (per-problem argument blocks in a device table, grid z = problem; every problem keeps its
+ * own device-side LM control block, so each follows exactly the LM trajectory of its own vslam_local_ba call).  Problems
+ * outside that class (more than 20 free keyframes, empty graphs) are served by the one-problem path inside the call. */
+vslam_status vslam_local_ba_batch(const vslam_ba_problem* const* problems, vslam_ba_result* const* results, int32_t n, int32_t device);
+
 vslam_status vslam_local_ba(const vslam_ba_problem* problem, vslam_ba_result* result, int32_t device,
                             const vslam_comm* comm);
 /* device time per kernel group of the last vslam_local_ba call on this thread */
@@ -451,6 +458,10 @@ typedef struct {
 
 vslam_status vslam_find_new_points(const vslam_new_points_problem* problem, vslam_new_points_result* result,
                                    int32_t device);
+/* the same for n windows at once (the cohort of a lockstep group): one upload, one launch per kernel for all of them (grid z =
+ * window, arguments from a device table), one download; results equal n vslam_find_new_points calls */
+vslam_status vslam_find_new_points_batch(const vslam_new_points_problem* const* problems, vslam_new_points_result* const* results,
+                                         int32_t n, int32_t device);
 
 /* Mono map-point creation — replaces the numerical part of FeatureTracker::addMappointsMono
  * (src/FeatureTracker.cpp:1497-1553) after its matchByRadius passes (vslam_match_by_radius):
@@ -597,6 +608,7 @@ typedef struct vslam_frame_report {
     /* local mapping that completed since the previous report (synchronous mode: the one this frame triggered) */
     int32_t mapping_ran, new_points, ba_keyframes, ba_local, ba_landmarks, ba_pairs, ba_wrong, ba_outliers;
     int32_t ba_residuals, ba_free_kf, ba_sum_k2, ba_trials;   /* work figures of that local BA (vslam_ba_result), lambda trials of both passes */
+    int32_t ba_rounds;                /* trial rounds of both passes (vslam_ba_result::rounds) */
     vslam_lm_report ba_report[2];
 } vslam_frame_report;
 
@@ -644,6 +656,11 @@ void vslam_batch_destroy(vslam_batch* batch);
 vslam_status vslam_batch_track_stereo(vslam_batch* batch, const uint8_t* const* left, const uint8_t* const* right, int32_t stride,
                                       int32_t on_device, const int32_t* frame_numbers, const vslam_imu_bucket* imu,
                                       const uint8_t* lane_mask, double* T_wc_out, vslam_frame_report* reports);
+/* local-BA stage timing of the batch's mapping engine (local_mapping = 2: the cohorts' batched local BAs): switch, and
+ * read-and-reset of the per-group sums ("<group>#n" entries: launches behind a sum), the cohorts and the lanes they served */
+vslam_status vslam_batch_set_ba_timing(vslam_batch* batch, int32_t on);
+vslam_status vslam_batch_ba_timings(vslam_batch* batch, const char** names, float* ms, int32_t cap, int32_t* n_out,
+                                    int64_t* cohorts_out, int64_t* lanes_out);
 /* the same for DEVICE images, and the images of the NEXT step (next_left / next_right / next_mask, may be NULL): their
  * extraction is enqueued as soon as this step's kernels have finished, so that it runs under this step's host phases; the
  * next call must then pass exactly those pointers (anything else is extracted afresh) */
@@ -682,13 +699,16 @@ typedef struct vslam_fleet_sequence {
     const double* T_wc_true;              /* [n_frames][16] ground-truth poses: a session starts at the pose of its first frame;
                                              the run reports the position error against them (may be NULL without IMU) */
     const double* velocity_true;          /* [n_frames][3] forward-motion velocity at each frame (IMU mode start value; may be NULL) */
+    int32_t start_span;                   /* session s starts at frame (5 s) mod start_span (0: n_frames - 1).  With start_span + the
+                                             frames a run tracks <= n_frames no session turns around: it never revisits a place */
 } vslam_fleet_sequence;
 
 typedef struct vslam_fleet_report {
     int32_t n_sessions;
     int64_t frames, keyframes, mappings, new_points, ba_landmarks, ba_pairs;   /* summed over sessions */
-    int64_t ba_residuals, ba_free_kf, ba_sum_k2, ba_trials, ba_iterations;
+    int64_t ba_residuals, ba_free_kf, ba_sum_k2, ba_trials, ba_iterations, ba_rounds;
     int64_t sum_inliers, sum_rounds, lost_frames;                               /* lost: fewer than 50 inliers after the frame */
+    int64_t sum_active;                                                         /* active map points after removeOutOfFrameMPs, summed over frames */
     int32_t min_inliers;
     double seconds, max_session_seconds;
     double max_position_error, sum_sq_position_error;                           /* against T_wc_true */
@@ -704,10 +724,11 @@ void vslam_fleet_destroy(vslam_fleet* fleet);
 vslam_status vslam_fleet_run(vslam_fleet* fleet, int32_t n_steps, vslam_fleet_report* report);
 vslam_status vslam_fleet_system(vslam_fleet* fleet, int32_t session, vslam_system** out);
 /* HIP-event timing of session 0 on every `every`-th frame (0 = off; two event records per launch are a real cost on this
- * launch-bound path); timings: per kernel group the device milliseconds summed over the sampled frames, counts3 =
- * {sampled frames, pose solves in them, local BAs timed}; read-and-reset */
+ * launch-bound path); timings: per kernel group the device milliseconds summed over the sampled frames ("<group>#n" entries:
+ * the launches behind a local-BA sum), counts4 = {sampled frames, pose solves in them, local BAs (lanes) timed, the batched
+ * calls (cohorts) that served them}; read-and-reset */
 vslam_status vslam_fleet_set_sampling(vslam_fleet* fleet, int32_t every);
-vslam_status vslam_fleet_timings(vslam_fleet* fleet, const char** names, float* ms, int32_t cap, int32_t* n_out, int64_t* counts3);
+vslam_status vslam_fleet_timings(vslam_fleet* fleet, const char** names, float* ms, int32_t cap, int32_t* n_out, int64_t* counts4);
 
 /* ---------------------------------------------------------------------------
  * N3 - the step before the hot path in the reference's frame loop (src/VIOSlam.cpp:278-306) and the dataset bookkeeping

@@ -16,6 +16,9 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4
 assert KP_DTYPE.itemsize == 28
 
 
+_NATIVE = False
+
+
 def build():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
@@ -23,9 +26,12 @@ def build():
 def use_native_build():
     """bench.py's cpu_baseline leg: the same sources built -O3 -march=native -ffp-contract=off FOR THE MACHINE IT RUNS ON
     (SURVEY section 8d), into a scratch directory; must be called before the first lib() use of the process."""
-    global _LIB
+    global _LIB, _NATIVE
     import tempfile
+    if _NATIVE:
+        return
     assert _LIB is None, "use_native_build() must come before any other oracle call"
+    _NATIVE = True
     d = os.path.join(tempfile.gettempdir(), "vslam_oracle_native_%d" % os.getuid())
     os.makedirs(d, exist_ok=True)
     so = os.path.join(d, "liboracle_native.so")

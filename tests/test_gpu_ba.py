@@ -218,3 +218,42 @@ def test_write_back_depth_refresh_parity(oracle, capi):
     d1, c1, u1 = capi.ba_refresh_depth(*args)
     assert np.array_equal(u0, u1) and u0.sum() > 1000 and (u0 == 0).sum() > 1000
     assert np.array_equal(d0, d1) and np.array_equal(c0, c1) and 0 < c0.sum() < u0.sum()
+
+
+def test_ba_batch_equals_single_calls(oracle, capi):
+    """vslam_local_ba_batch (one launch per stage for all problems; the local mapping of a lockstep group) against
+    vslam_local_ba on each problem: identical LM trajectories (iteration / trial counts, chi2 flags of both passes, work
+    figures), poses to the round-off of the LDS atomics.  The batch mixes window sizes (different solve kernels in one
+    round), an empty graph and a 28-keyframe window (both served by the one-problem path inside the call), and a problem
+    with enough outliers that its second graph differs from the first."""
+    ex = oracle.Extractor(1500)
+    rig = synth.RIGS["euroc"]
+    probs = [synth.make_ba_problem(n_local=10, n_fixed=4, n_lm=1500, seed=31),
+             synth.make_ba_problem(n_local=4, n_fixed=2, n_lm=400, seed=32),
+             synth.make_ba_problem(n_local=7, n_fixed=0, n_lm=700, seed=33),
+             synth.make_ba_problem(n_local=14, n_fixed=3, n_lm=900, seed=34),           # 84 unknowns: the 8-wave MFMA solve
+             synth.make_ba_problem(n_local=10, n_fixed=3, n_lm=1200, seed=35, outlier_frac=0.15),
+             synth.make_ba_problem(n_local=3, n_fixed=1, n_lm=60, seed=36),
+             synth.make_ba_problem(n_local=24, n_fixed=2, n_lm=800, seed=37)]             # > 20 free keyframes: one-problem path
+    probs[2]["kf_fixed"][0] = 1
+    empty = dict(probs[5])
+    for k in ("pair_kf", "pair_lm", "pair_flags"):
+        empty[k] = probs[5][k][:0]
+    empty["pair_uv"] = probs[5]["pair_uv"][:0]; empty["pair_oct"] = probs[5]["pair_oct"][:0]
+    probs.append(empty)
+    singles = [capi.local_ba(rig, ex.sigmaFactor, ex.InvSigmaFactor, p) for p in probs]
+    batch = capi.local_ba_batch(rig, ex.sigmaFactor, ex.InvSigmaFactor, probs)
+    assert set(capi.local_ba_timings()) >= {"ba_linearize", "ba_schur", "ba_solve", "ba_back", "ba_eval", "ba_chi2"}
+    for i, (a, b) in enumerate(zip(singles, batch)):
+        assert [(r["iterations"], r["inner"]) for r in a["reports"]] == [(r["iterations"], r["inner"]) for r in b["reports"]], i
+        for s in range(2):
+            assert abs(a["reports"][s]["finalError"] - b["reports"][s]["finalError"]) <= 1e-9 * max(1.0, a["reports"][s]["finalError"]), i
+        assert np.array_equal(a["pair_wrong1"], b["pair_wrong1"]) and np.array_equal(a["pair_wrong"], b["pair_wrong"]), i
+        assert np.abs(a["kf_pose"] - b["kf_pose"]).max() < 1e-9, (i, np.abs(a["kf_pose"] - b["kf_pose"]).max())
+        d = np.linalg.norm(a["lm"] - b["lm"], axis=1)      # (weakly observed points amplify the atomics' round-off along their ray)
+        assert np.median(d) < 1e-8 and d.max() < 1e-3, (i, np.median(d), d.max())
+        assert (a["residuals"], a["landmarks"], a["free_kf"], a["sum_k2"]) == (b["residuals"], b["landmarks"], b["free_kf"], b["sum_k2"]), i
+    # and against the oracle for one of them
+    ref = oracle.local_ba(rig, ex.sigmaFactor, ex.InvSigmaFactor, probs[0])
+    assert [(r["iterations"], r["inner"]) for r in ref["reports"]] == [(r["iterations"], r["inner"]) for r in batch[0]["reports"]]
+    assert np.abs(ref["kf_pose"] - batch[0]["kf_pose"]).max() < 1e-6

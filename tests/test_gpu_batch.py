@@ -156,7 +156,7 @@ def test_async_mapping_is_reproducible_and_complete(capi):
         assert res[2][k] == res[0][k], (k, res[2][k], res[0][k])
     assert abs(res[1]["sum_sq_position_error"] - res[0]["sum_sq_position_error"]) < 1e-9     # (round-off of the BA's LDS atomics only)
     assert abs(res[2]["sum_sq_position_error"] - res[0]["sum_sq_position_error"]) < 1e-9
-    assert res[0]["mappings"] >= 6 and res[0]["lost_frames"] == 0
+    assert res[0]["mappings"] >= 3 and res[0]["lost_frames"] == 0
     assert res[0]["mappings"] >= res[0]["keyframes"] - 3 * 6 - 6 - 6       # (first three keyframes of a session; one pass pending at the end)
     for a, b in imgs:
         a.free(); b.free()

@@ -101,7 +101,7 @@ def test_closed_loop_parity_async_stereo(oracle, capi):
     """The mode bench.py times: the optimizer's device work beside tracking on the fixed schedule mapping_delay = 4 (new points
     one frame after the hand-over, the BA's write-back + changePosesLCA four frames after it) - frame by frame against the
     oracle's restatement of the same schedule."""
-    frames = list(range(0, 76, 2))
+    frames = list(range(0, 108, 2))
     ref, got, out = _run(oracle, capi, "euroc", 1500, frames, delay=4)
     nBA = _check(ref, got, out)
     assert nBA >= 2 and len(ref.keyFrames) >= 5
