@@ -2738,6 +2738,10 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
     const int NB = g_baLookahead > 0 ? std::min(g_baLookahead, (int)BA_MAX_NB) : nbEnv, nSlots = NB + 1;
     static const bool useMfma = !getenv("VSLAM_BA_NO_MFMA");
     const double relTol = 1e-5, absTol = 1e-5;
+    // adaptive look-ahead (BaDev::adaptive): a round evaluates ONE lambda candidate while steps are being accepted and all NB only
+    // after a rejection - the same LM trajectory; in a batch the cost of a round is the candidates it evaluates (throughput, not latency)
+    static const int adaptEnv = [] { const char* e = getenv("VSLAM_BA_ADAPTIVE"); return e ? atoi(e) : -1; }();
+    const bool adaptive = NB > 1 && (adaptEnv >= 0 ? adaptEnv != 0 : true);
 
     struct Lane {
         const vslam_ba_problem* P; vslam_ba_result* R; int K, L, NP;
@@ -2815,7 +2819,7 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
         memcpy(q.h_pairOct, P->pair_octave, (size_t)2 * q.NP * 4); memcpy(q.h_pairFlags, P->pair_flags, q.NP);
         memcpy(q.h_pairUv, P->pair_uv, (size_t)4 * q.NP * 4); memcpy(q.h_kfLocal, P->kf_local, q.K);
         q.H.fill(P, q.wrong.data(), 0, 1, q.T, q.pose0.data(), nullptr, nSlots);
-        ba_init_ctl(q.H.h_ctl, 0, NB);
+        ba_init_ctl(q.H.h_ctl, 0, adaptive ? 1 : NB);
     });
     // ---- launch geometry shared by the lanes ---------------------------------------------------------------------------
     int maxSlots = 1, nMax = 0, neMax = 0, nfMax = 0, lpMax = 0, npMax = 0, valMax = 0;
@@ -2905,7 +2909,7 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
         D.S = q.d_S; D.rhs = q.d_S + (size_t)n * n; D.Sedge = q.d_Sedge; D.dP = q.d_dP; D.dL = q.d_dL; D.sums = q.d_sums; D.flags = q.d_flags;
         D.fx = P->rig.fx; D.fy = P->rig.fy; D.cx = P->rig.cx; D.cy = P->rig.cy; D.b = (double)P->rig.baseline;
         D.ctl = A.dev(H.h_ctl);
-        D.NB = NB; D.specLin = 1; D.adaptive = 0;
+        D.NB = NB; D.specLin = 1; D.adaptive = adaptive ? 1 : 0;
         D.poseBase = q.d_poseS; D.lmBase = q.d_lmS; D.lmStride = (size_t)3 * L;
         D.facJBase = q.d_facJ; D.facJStride = (size_t)20 * H.NF; D.SedgeBase = q.d_Sedge; D.edgesBase = A.dev(H.h_edges);
         D.sysStride = (size_t)n * n + 2 * n + 8; D.dLStride = (size_t)3 * H.Lp;
@@ -3039,7 +3043,7 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
         q.NF2 = NF2; q.Lp2 = Lp2; q.k2 = k2; q.pass2 = true;
         for (int k = 0; k < q.K; k++) H.h_kfPresent[k] = kfP2[k];
         for (int l = 0; l < q.L; l++) H.h_lmPresent[l] = lmP2[l];
-        ba_init_ctl(H.h_ctl, 1, NB);
+        ba_init_ctl(H.h_ctl, 1, adaptive ? 1 : NB);
     });
     for (int a = 0; a < NL; a++) if (!lanes[act[a]].pass2) redo.push_back(act[a]);
     if ((int)redo.size() < NL) {

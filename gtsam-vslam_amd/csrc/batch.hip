@@ -76,18 +76,20 @@ struct vslam_batch {
     std::vector<std::pair<const char*, float>> baTimes;
     long long baTimedCohorts = 0, baTimedLanes = 0;
     // per-step scratch
-    struct LaneStep { bool on = false, first = false, failed = false; vslam_status st = VSLAM_OK; char err[200] = ""; size_t upOff = 0, dnOff = 0, keyOff = 0; int N = 0, nL = 0, nR = 0; bool wantKeys = false; };
+    struct LaneStep { bool on = false, first = false, failed = false; vslam_status st = VSLAM_OK; char err[200] = ""; size_t upOff = 0, dnOff = 0, keyOff = 0; int N = 0, nL = 0, nR = 0; bool wantKeys = false; void* keySlot = nullptr; };
     std::vector<LaneStep> ls;
     std::vector<const uint8_t*> imgPtrs;
     StageTimer timer;
     // host-side phase times of the last step (seconds): pre, extract enqueue, fill, tables + enqueue, wait, finish, post
-    double phase[8] = {0}, phaseSum[8] = {0};
+    double phase[8] = {0}, phaseSum[8] = {0}, subSum[6] = {0};      // subSum: begin a / serve / b, post a / serve / b
     long long nSteps = 0;
 
     vslam_status init(const vslam_system_config* cfgs, int n, int hostThreads, int mapThreads);
     void release();
     vslam_status ensure_up(size_t bytes);
     vslam_status ensure_dn(size_t bytes);
+    vslam_status serve_requests();
+    std::vector<uint8_t> rqDescs; std::vector<int> rqStart, rqBest;
     vslam_status step(const uint8_t* const* L, const uint8_t* const* R, int stride, bool onDevice, const int* frames,
                       const vslam_imu_bucket* imu, const uint8_t* mask, double* T_wc_out, vslam_frame_report* reps,
                       const uint8_t* const* nextL = nullptr, const uint8_t* const* nextR = nullptr, const uint8_t* nextMask = nullptr);
@@ -239,6 +241,10 @@ void vslam_batch::release() {
         fprintf(stderr, "vslam_batch %d lanes, %lld steps, host phases (us / step): begin %.1f | images + extract enqueue %.1f | upload block %.1f | "
                         "tables + enqueue %.1f (of which waiting for the extraction %.1f) | wait %.1f | retry %.1f | post %.1f\n", B, nSteps, 1e6 * phaseSum[0] / nSteps, 1e6 * phaseSum[1] / nSteps,
                 1e6 * phaseSum[2] / nSteps, 1e6 * phaseSum[3] / nSteps, 1e6 * phaseSum[7] / nSteps, 1e6 * phaseSum[4] / nSteps, 1e6 * phaseSum[5] / nSteps, 1e6 * phaseSum[6] / nSteps);
+    if (getenv("VSLAM_BATCH_PHASES") && nSteps)
+        fprintf(stderr, "  begin = first half (waits for the jobs that are due + commits) %.1f + requests %.1f + second half (BA collection, changePosesLCA, candidates) %.1f | "
+                        "post = first half %.1f + requests %.1f + second half (new-point collection, reports) %.1f\n", 1e6 * subSum[0] / nSteps, 1e6 * subSum[1] / nSteps,
+                1e6 * subSum[2] / nSteps, 1e6 * subSum[3] / nSteps, 1e6 * subSum[4] / nSteps, 1e6 * subSum[5] / nSteps);
     if (getenv("VSLAM_BATCH_PHASES")) {
         SysProf& p = sys_prof();
         auto avg = [](std::atomic<long long>& ns, std::atomic<long long>& n) { return n.load() ? 1e-3 * (double)ns.load() / (double)n.load() : 0.0; };
@@ -273,6 +279,63 @@ void vslam_batch::release() {
     if (h_dn) hipHostFree(h_dn);
     if (stream) hipStreamDestroy(stream);
     stream = nullptr;
+}
+
+// The lanes' pending device requests of a host phase (descriptor selection after a keyframe insertion / new points / a local BA's
+// write-back; the write-back's depth refresh), served together: ONE launch + one synchronisation per kind instead of one round
+// trip per lane on the pool threads.
+vslam_status vslam_batch::serve_requests() {
+    // ---- MapPoint::calcDescriptor ------------------------------------------------------------------------------------------
+    size_t nMp = 0, nDesc = 0;
+    for (vslam_system* s : sys) if (s->descReq.pending) { nMp += s->descReq.mps.size(); nDesc += s->descReq.descs.size() / 32; }
+    if (nMp) {
+        SysProfScope ps(sys_prof().descNs, sys_prof().descN);
+        rqDescs.resize(nDesc * 32); rqStart.assign(1, 0); rqBest.assign(nMp, -1);
+        size_t at = 0;
+        for (vslam_system* s : sys) {
+            DescReq& q = s->descReq;
+            if (!q.pending) continue;
+            if (!q.descs.empty()) memcpy(rqDescs.data() + at * 32, q.descs.data(), q.descs.size());
+            for (size_t i = 0; i < q.mps.size(); i++) rqStart.push_back((int)at + q.start[i + 1]);
+            at += q.descs.size() / 32;
+        }
+        if (nDesc) VS_CHECK(vslam_calc_descriptors(rqDescs.data(), rqStart.data(), (int)nMp, device, rqBest.data()));
+        size_t m = 0;
+        for (vslam_system* s : sys) {
+            DescReq& q = s->descReq;
+            if (!q.pending) continue;
+            q.best.assign(rqBest.begin() + m, rqBest.begin() + m + q.mps.size());
+            m += q.mps.size();
+        }
+    }
+    // ---- MapPoint::updatePos depth / close refresh ---------------------------------------------------------------------------
+    size_t nPair = 0; int nKf = 0, nLm = 0;
+    for (vslam_system* s : sys) if (s->refReq.pending) { nPair += s->refReq.rk.size(); nKf += s->refReq.nKf; nLm += s->refReq.nLm; }
+    if (nPair) {
+        std::vector<int> rk, rl; std::vector<float> cur(nPair), dep(nPair); std::vector<double> pose((size_t)nKf * 16), lm((size_t)nLm * 3);
+        std::vector<uint8_t> zeroW(nPair, 0), zeroO(std::max(nLm, 1), 0), clo(nPair), up(nPair);
+        rk.reserve(nPair); rl.reserve(nPair);
+        size_t ap = 0; int ak = 0, al = 0;
+        for (vslam_system* s : sys) {
+            RefreshReq& r = s->refReq;
+            if (!r.pending) continue;
+            for (size_t i = 0; i < r.rk.size(); i++) { rk.push_back(r.rk[i] + ak); rl.push_back(r.rl[i] + al); cur[ap + i] = r.cur[i]; }
+            memcpy(pose.data() + (size_t)ak * 16, r.rpose.data(), (size_t)r.nKf * 16 * sizeof(double));
+            memcpy(lm.data() + (size_t)al * 3, r.rlm.data(), (size_t)r.nLm * 3 * sizeof(double));
+            ap += r.rk.size(); ak += r.nKf; al += r.nLm;
+        }
+        VS_CHECK(vslam_ba_refresh_depth(&sys[0]->cfg.rig, nKf, pose.data(), nLm, lm.data(), zeroO.data(), (int)nPair, rk.data(), rl.data(), zeroW.data(),
+                                        cur.data(), device, dep.data(), clo.data(), up.data()));
+        ap = 0;
+        for (vslam_system* s : sys) {
+            RefreshReq& r = s->refReq;
+            if (!r.pending) continue;
+            const size_t n = r.rk.size();
+            r.dep.assign(dep.begin() + ap, dep.begin() + ap + n); r.clo.assign(clo.begin() + ap, clo.begin() + ap + n); r.up.assign(up.begin() + ap, up.begin() + ap + n);
+            ap += n;
+        }
+    }
+    return VSLAM_OK;
 }
 
 vslam_status vslam_batch::ensure_up(size_t bytes) {
@@ -327,6 +390,7 @@ vslam_status vslam_batch::step(const uint8_t* const* L, const uint8_t* const* R,
     using clk = std::chrono::steady_clock;
     auto t0 = clk::now();
     auto lap = [&](int k) { const auto t1 = clk::now(); phase[k] = std::chrono::duration<double>(t1 - t0).count(); phaseSum[k] += phase[k]; t0 = t1; };
+    auto sub = [&](int k, clk::time_point& ts) { const auto t1 = clk::now(); subSum[k] += std::chrono::duration<double>(t1 - ts).count(); ts = t1; };
     nSteps++;
     int nOn = 0;
     for (int b = 0; b < B; b++) {
@@ -345,16 +409,32 @@ vslam_status vslam_batch::step(const uint8_t* const* L, const uint8_t* const* R,
     };
 
     // ---- host: frame_begin + candidate lists --------------------------------------------------------------------------------
+    auto ts = clk::now();
     pool.run(B, [&](int b) {
         LaneStep& q = ls[b];
         if (!q.on) return;
         hipSetDevice(device);
         vslam_system* s = sys[b];
-        LANE_TRY(s->frame_begin(s->ctx, frames[b], imu ? &imu[b] : nullptr));
+        s->deferDevice = true;
+        const vslam_status bs = s->frame_begin_a(s->ctx, frames[b], imu ? &imu[b] : nullptr);
+        s->deferDevice = false;
+        LANE_TRY(bs);
+    });
+    VS_CHECK(first_error());
+    sub(0, ts);
+    VS_CHECK(serve_requests());                    // descriptor selection / depth refresh of every lane that committed a job
+    sub(1, ts);
+    pool.run(B, [&](int b) {
+        LaneStep& q = ls[b];
+        if (!q.on) return;
+        hipSetDevice(device);
+        vslam_system* s = sys[b];
+        LANE_TRY(s->frame_begin_b(s->ctx));
         if (!q.first) q.N = s->frame_candidates(s->ctx);
     });
     kick();                                        // the local BAs handed over in this phase: one cohort
     VS_CHECK(first_error());
+    sub(2, ts);
     lap(0);
 
     // ---- device: images, extraction (already in flight when the previous step prefetched exactly these images) -----------
@@ -492,6 +572,8 @@ vslam_status vslam_batch::step(const uint8_t* const* L, const uint8_t* const* R,
         K.N = q.N; K.nL = q.nL; K.count = m->d_trCount; K.matches = m->d_matches; K.act = m->d_trAct; K.matchedL = m->d_matchedL;
         K.flags = m->d_flags; K.flagStride = (size_t)m->poseCap; K.visLeft = m->d_trVisL; K.out = d_dn + q.dnOff;
         K.keyOut = q.wantKeys ? d_dn + q.keyOff : nullptr; K.nR = q.nR;
+        q.keySlot = (q.wantKeys && s->cfg.local_mapping) ? s->reserve_key_slot(q.nL, q.nR) : nullptr;
+        K.keyOut2 = (uint8_t*)q.keySlot;
         K.kps[0] = m->d_kps[0]; K.kps[1] = m->d_kps[1]; K.desc[0] = m->d_desc[0]; K.desc[1] = m->d_desc[1];
         K.rightIdxs = m->d_rightIdxs; K.leftIdxs = m->d_leftIdxs; K.depth = m->d_depth; K.closef = m->d_close;
     });
@@ -575,20 +657,38 @@ vslam_status vslam_batch::step(const uint8_t* const* L, const uint8_t* const* R,
         }
         v.nL = nL;
         v.keys = (q.wantKeys && !m->trRetried) ? h_dn + q.keyOff : nullptr; v.nR = q.nR;      // (retry rounds ran after the pack)
+        v.keySlot = v.keys ? q.keySlot : nullptr;
     }
     lap(5);
 
     // ---- host: frame_post (first frames: the one-session path on their own stereo result) ------------------------------------
+    ts = clk::now();
     pool.run(B, [&](int b) {
         LaneStep& q = ls[b];
         if (!q.on) return;
         hipSetDevice(device);
         vslam_system* s = sys[b];
         if (q.first) LANE_TRY(s->frame_first(s->ctx, T_wc_out + 16 * (size_t)b, reps ? &reps[b] : nullptr));
-        else LANE_TRY(s->frame_post(s->ctx, st[b], T_wc_out + 16 * (size_t)b, reps ? &reps[b] : nullptr));
+        else {
+            s->deferDevice = true;
+            const vslam_status ps = s->frame_post_a(s->ctx, st[b]);
+            s->deferDevice = false;
+            LANE_TRY(ps);
+        }
+    });
+    VS_CHECK(first_error());
+    sub(3, ts);
+    VS_CHECK(serve_requests());                    // descriptor selection of the lanes that inserted a keyframe
+    sub(4, ts);
+    pool.run(B, [&](int b) {
+        LaneStep& q = ls[b];
+        if (!q.on || q.first) return;
+        hipSetDevice(device);
+        LANE_TRY(sys[b]->frame_post_b(sys[b]->ctx, T_wc_out + 16 * (size_t)b, reps ? &reps[b] : nullptr));
     });
     kick();                                        // the new-point searches of the lanes that inserted a keyframe
     VS_CHECK(first_error());
+    sub(5, ts);
     lap(6);
     return VSLAM_OK;
 }

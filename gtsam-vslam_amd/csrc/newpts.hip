@@ -12,6 +12,7 @@
 //                     rank / cheirality tests, the reprojection filter (sequential by definition, a few entries)
 //   k_calc_descriptor wave = map point: N x N Hamming distances, rank-selected median, first minimum
 #include "proj_dev.hpp"
+#include "track_dev.hpp"
 #include "dmath.hpp"
 #include <vector>
 #include <mutex>
@@ -553,6 +554,43 @@ template <class T> using Dev = PoolBuf<T>;
 #define NP_POOL(var) DevPool* var = thread_pool(device); if (!var) { set_error("no device pool"); return VSLAM_ERR_HIP; } var->pending.clear();
 }  // namespace
 
+// layout of a keyframe's device block (vslam_kf_keys_upload / vslam_kf_view::device_keys) = key_block_layout (track_dev.hpp): the block
+// the lockstep step's pack kernel writes for a lane that may insert a keyframe, so that a keyframe's arrays reach their slot in
+// HBM without a host round trip
+namespace {
+struct KfKeysLayout { size_t kl, kr, dl, dr, ri, li, total; };
+inline KfKeysLayout kf_keys_layout(int nL, int nR) {
+    const KeyBlockLayout k = key_block_layout(nL, nR);
+    KfKeysLayout o{k.kpsL, k.kpsR, k.descL, k.descR, k.rightIdxs, k.leftIdxs, std::max<size_t>(k.total, 64)};
+    return o;
+}
+}  // namespace
+extern "C" size_t vslam_kf_keys_bytes(int32_t n_left, int32_t n_right) { return kf_keys_layout(std::max(n_left, 0), std::max(n_right, 0)).total; }
+extern "C" vslam_status vslam_kf_keys_upload(const vslam_kf_view* V, int32_t device, void* device_block) {
+    if (!V || !device_block || V->n_left < 0 || V->n_right < 0 || (V->n_left > 0 && (!V->kps_l || !V->desc_l || !V->right_idxs)) ||
+        (V->n_right > 0 && (!V->kps_r || !V->desc_r || !V->left_idxs))) { set_error("vslam_kf_keys_upload: invalid arguments"); return VSLAM_ERR_INVALID; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available (no CPU fallback)"); return VSLAM_ERR_NO_DEVICE; }
+    if (device < 0 || device >= ndev) return VSLAM_ERR_INVALID;
+    VS_HIP(hipSetDevice(device));
+    NP_POOL(pool);
+    const KfKeysLayout o = kf_keys_layout(V->n_left, V->n_right);
+    uint8_t* st = pool->stage(o.total);
+    std::vector<uint8_t> tmp;
+    if (!st) { tmp.resize(o.total); st = tmp.data(); }
+    const int nL = V->n_left, nR = V->n_right;
+    if (nL) { memcpy(st + o.kl, V->kps_l, (size_t)nL * sizeof(vslam_keypoint)); memcpy(st + o.dl, V->desc_l, (size_t)nL * 32); memcpy(st + o.ri, V->right_idxs, (size_t)nL * 4); }
+    if (nR) { memcpy(st + o.kr, V->kps_r, (size_t)nR * sizeof(vslam_keypoint)); memcpy(st + o.dr, V->desc_r, (size_t)nR * 32); memcpy(st + o.li, V->left_idxs, (size_t)nR * 4); }
+    {
+        const KeyBlockLayout k = key_block_layout(nL, nR);
+        if (nL && V->estimated_depth) memcpy(st + k.depth, V->estimated_depth, (size_t)nL * 4);
+        if (nL && V->close_flags) memcpy(st + k.closef, V->close_flags, nL);
+    }
+    VS_HIP(hipMemcpyAsync(device_block, st, o.total, hipMemcpyHostToDevice, pool->stream));
+    VS_HIP(pool->sync());
+    return VSLAM_OK;
+}
+
 // findNewPoints for n windows at once: every lane's keyframe arrays travel in ONE upload (pinned staging), the three kernels
 // are launched once for all lanes (grid z = lane, arguments from a device table), the results come back in ONE download.
 static vslam_status np_run(const vslam_new_points_problem* const* Ps, vslam_new_points_result* const* Rs, int N, int device) {
@@ -584,7 +622,7 @@ static vslam_status np_run(const vslam_new_points_problem* const* Ps, vslam_new_
     struct StreamGuard { DevPool* p; ~StreamGuard() { (void)p->sync(); } } guard{pool};   // before the blocks go back
     // ---- layout: [table][lane 0 arrays][lane 1 arrays] ... in one pack; work and result areas per lane ----------------------
     struct KfOff { size_t kl, kr, dl, dr, ri, li, uf, ufr; };
-    struct LaneL { int cap; KfOff off[NP_MAX_KF]; size_t oDepth, oHas, oMpXyz, oMpDesc; size_t wPos, mds, cdesc, match; size_t rBase, rXyz, rNobs, rAcc, rObs, rKey, rCount, rEnd; };
+    struct LaneL { int cap; KfOff off[NP_MAX_KF]; size_t oDepth, oHas, oMpXyz, oMpDesc; size_t wPos, mds, cdesc, match; size_t rXyz, rNobs, rAcc, rObs, rKey, rCount; };
     std::vector<LaneL> LL(N);
     size_t packBytes = 0, workBytes = 0, resBytes = 0;
     auto packOff = [&](size_t bytes) { const size_t at = packBytes; packBytes = (packBytes + bytes + 63) & ~(size_t)63; return at; };
@@ -600,21 +638,27 @@ static vslam_status np_run(const vslam_new_points_problem* const* Ps, vslam_new_
         capMax = std::max(capMax, cap); kfMax = std::max(kfMax, P->n_kf);
         for (int k = 0; k < P->n_kf; k++) {
             const vslam_kf_view& V = P->kfs[k];
-            q.off[k].kl = packOff((size_t)V.n_left * sizeof(vslam_keypoint)); q.off[k].kr = packOff((size_t)V.n_right * sizeof(vslam_keypoint));
-            q.off[k].dl = packOff((size_t)V.n_left * 32); q.off[k].dr = packOff((size_t)V.n_right * 32);
-            q.off[k].ri = packOff((size_t)V.n_left * 4); q.off[k].li = packOff((size_t)V.n_right * 4);
+            if (!V.device_keys) {      // (resident keyframes: only the two mutable tables travel)
+                q.off[k].kl = packOff((size_t)V.n_left * sizeof(vslam_keypoint)); q.off[k].kr = packOff((size_t)V.n_right * sizeof(vslam_keypoint));
+                q.off[k].dl = packOff((size_t)V.n_left * 32); q.off[k].dr = packOff((size_t)V.n_right * 32);
+                q.off[k].ri = packOff((size_t)V.n_left * 4); q.off[k].li = packOff((size_t)V.n_right * 4);
+            }
             q.off[k].uf = packOff((size_t)V.n_left * 4); q.off[k].ufr = packOff((size_t)V.n_right * 4);
         }
         q.oDepth = packOff((size_t)cap * sizeof(float)); q.oHas = packOff((size_t)cap); q.oMpXyz = packOff((size_t)3 * cap * sizeof(double));
         q.oMpDesc = packOff((size_t)32 * cap);
         q.wPos = workOff((size_t)3 * cap * 8); q.mds = workOff((size_t)cap * 4); q.cdesc = workOff((size_t)32 * cap); q.match = workOff((size_t)cap * NP_MAX_KF * 2 * 4);
-        // result block of the lane: [xyz | nObs | accepted] (zero-filled) [obs] (0xff-filled) [key | count]
-        q.rBase = resBytes;
-        q.rXyz = resOff((size_t)3 * cap * sizeof(double)); q.rNobs = resOff((size_t)cap * sizeof(int)); q.rAcc = resOff((size_t)cap);
-        q.rObs = resOff((size_t)cap * NP_MAX_KF * 3 * sizeof(int));
-        q.rKey = resOff((size_t)2 * cap * sizeof(int)); q.rCount = resOff(4 * sizeof(int));
-        q.rEnd = resBytes;
     }
+    // result area: [xyz | nObs | accepted of every lane] (zero-filled by ONE memset) [obs of every lane] (0xff-filled by one) [key | count
+    // of every lane] - fetched by one copy
+    for (int i = 0; i < N; i++) {
+        LaneL& q = LL[i];
+        q.rXyz = resOff((size_t)3 * q.cap * sizeof(double)); q.rNobs = resOff((size_t)q.cap * sizeof(int)); q.rAcc = resOff((size_t)q.cap);
+    }
+    const size_t resZeroEnd = resBytes;
+    for (int i = 0; i < N; i++) LL[i].rObs = resOff((size_t)LL[i].cap * NP_MAX_KF * 3 * sizeof(int));
+    const size_t resFfEnd = resBytes;
+    for (int i = 0; i < N; i++) { LL[i].rKey = resOff((size_t)2 * LL[i].cap * sizeof(int)); LL[i].rCount = resOff(4 * sizeof(int)); }
     Dev<uint8_t> dPack(pool), dWork(pool), dRes(pool);
     VS_HIP(dPack.alloc(std::max<size_t>(packBytes, 64))); VS_HIP(dWork.alloc(std::max<size_t>(workBytes, 64))); VS_HIP(dRes.alloc(std::max<size_t>(resBytes, 64)));
     uint8_t* hPack = pool->stage(packBytes);
@@ -633,13 +677,20 @@ static vslam_status np_run(const vslam_new_points_problem* const* Ps, vslam_new_
             NpKf& D = A.kf[k];
             pose_from_rm16(V.T_wc, D.Twc);
             pose_inverse(D.Twc, D.Tcw);
-            put(q.off[k].kl, V.kps_l, (size_t)V.n_left * sizeof(vslam_keypoint)); put(q.off[k].kr, V.kps_r, (size_t)V.n_right * sizeof(vslam_keypoint));
-            put(q.off[k].dl, V.desc_l, (size_t)V.n_left * 32); put(q.off[k].dr, V.desc_r, (size_t)V.n_right * 32);
-            put(q.off[k].ri, V.right_idxs, (size_t)V.n_left * 4); put(q.off[k].li, V.left_idxs, (size_t)V.n_right * 4);
             put(q.off[k].uf, V.unmatched_f, (size_t)V.n_left * 4); put(q.off[k].ufr, V.unmatched_fr, (size_t)V.n_right * 4);
-            D.kpsL = (const vslam_keypoint*)(dPack.p + q.off[k].kl); D.kpsR = (const vslam_keypoint*)(dPack.p + q.off[k].kr);
-            D.descL = dPack.p + q.off[k].dl; D.descR = dPack.p + q.off[k].dr;
-            D.rightIdxs = (const int*)(dPack.p + q.off[k].ri); D.leftIdxs = (const int*)(dPack.p + q.off[k].li);
+            if (V.device_keys) {
+                const KfKeysLayout o = kf_keys_layout(V.n_left, V.n_right);
+                const uint8_t* b = (const uint8_t*)V.device_keys;
+                D.kpsL = (const vslam_keypoint*)(b + o.kl); D.kpsR = (const vslam_keypoint*)(b + o.kr);
+                D.descL = b + o.dl; D.descR = b + o.dr; D.rightIdxs = (const int*)(b + o.ri); D.leftIdxs = (const int*)(b + o.li);
+            } else {
+                put(q.off[k].kl, V.kps_l, (size_t)V.n_left * sizeof(vslam_keypoint)); put(q.off[k].kr, V.kps_r, (size_t)V.n_right * sizeof(vslam_keypoint));
+                put(q.off[k].dl, V.desc_l, (size_t)V.n_left * 32); put(q.off[k].dr, V.desc_r, (size_t)V.n_right * 32);
+                put(q.off[k].ri, V.right_idxs, (size_t)V.n_left * 4); put(q.off[k].li, V.left_idxs, (size_t)V.n_right * 4);
+                D.kpsL = (const vslam_keypoint*)(dPack.p + q.off[k].kl); D.kpsR = (const vslam_keypoint*)(dPack.p + q.off[k].kr);
+                D.descL = dPack.p + q.off[k].dl; D.descR = dPack.p + q.off[k].dr;
+                D.rightIdxs = (const int*)(dPack.p + q.off[k].ri); D.leftIdxs = (const int*)(dPack.p + q.off[k].li);
+            }
             D.unF = (const int*)(dPack.p + q.off[k].uf); D.unFR = (const int*)(dPack.p + q.off[k].ufr);
             D.nL = V.n_left; D.nR = V.n_right;
             D.skip = (k > 0 && V.id == P->kfs[0].id) ? 1 : 0;
@@ -657,10 +708,10 @@ static vslam_status np_run(const vslam_new_points_problem* const* Ps, vslam_new_
         A.key = (int*)(dRes.p + q.rKey); A.count = (int*)(dRes.p + q.rCount); A.cap = q.cap;
         A.accepted = dRes.p + q.rAcc; A.xyz = (double*)(dRes.p + q.rXyz); A.nObs = (int*)(dRes.p + q.rNobs); A.obs = (int*)(dRes.p + q.rObs);
         tab[i] = A;
-        VS_HIP(hipMemsetAsync(dRes.p + q.rBase, 0, q.rObs - q.rBase, stream));
-        VS_HIP(hipMemsetAsync(dRes.p + q.rObs, 0xff, q.rKey - q.rObs, stream));
         if (P->n_kf <= 1) VS_HIP(hipMemsetAsync(dWork.p + q.match, 0xfe, (size_t)q.cap * NP_MAX_KF * 2 * sizeof(int), stream));
     }
+    VS_HIP(hipMemsetAsync(dRes.p, 0, resZeroEnd, stream));
+    if (resFfEnd > resZeroEnd) VS_HIP(hipMemsetAsync(dRes.p + resZeroEnd, 0xff, resFfEnd - resZeroEnd, stream));
     VS_HIP(hipMemcpyAsync(dPack.p, hPack, packBytes, hipMemcpyHostToDevice, stream));
     if (!hostPack.empty()) VS_HIP(hipStreamSynchronize(stream));       // (pageable source: the copy has been staged, but keep the vector alive and simple)
     const NpArgs* dTab = (const NpArgs*)(dPack.p + oTab);

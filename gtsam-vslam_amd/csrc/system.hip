@@ -69,6 +69,8 @@ void vslam_system::release() {
     if (h_up) hipHostFree(h_up);
     if (h_dn) hipHostFree(h_dn);
     h_up = h_dn = nullptr;
+    for (uint8_t* slab : keySlabs) hipFree(slab);
+    keySlabs.clear();
 }
 
 // the current frame's TrackedKeys as the device holds them (after findOutliersR's mutations)
@@ -134,28 +136,95 @@ void vslam_system::mp_update(SysMP& mp, int kfNumb, std::vector<int>& needDesc, 
     needDesc.push_back(mpIndex);
 }
 
-// MapPoint::calcDescriptor (src/Map.cpp:145-210) for a batch of map points: k_calc_descriptor
+// MapPoint::calcDescriptor (src/Map.cpp:145-210) for a batch of map points: k_calc_descriptor.  The request is served at once
+// (a single session) or, with deferDevice, together with the other lanes' requests after the host phase (apply_deferred then
+// writes the winners: nothing reads MapPoint::desc between the request and the end of its phase).
 vslam_status vslam_system::calc_descriptors(const std::vector<int>& mps) {
     if (mps.empty()) return VSLAM_OK;
-    SysProfScope ps(sys_prof().descNs, sys_prof().descN);
-    std::vector<uint8_t> descs;
-    std::vector<int> start(1, 0), best(mps.size(), -1);
-    std::vector<const uint8_t*> src;
-    for (size_t q = 0; q < mps.size(); q++) {
-        const SysMP& mp = mapPoints[mps[q]];
+    DescReq& q = descReq;
+    if (!q.pending) { q.mps.clear(); q.descs.clear(); q.start.assign(1, 0); q.best.clear(); }
+    for (size_t i = 0; i < mps.size(); i++) {
+        const SysMP& mp = mapPoints[mps[i]];
         for (const KfMatch& o : mp.kfm) {
             const SysKeys& k = keyFrames[o.kf].keys;
-            if (o.l != -1) src.push_back(k.dL.data() + (size_t)o.l * 32);
-            if (o.r != -1) src.push_back(k.dR.data() + (size_t)o.r * 32);
+            if (o.l != -1) { const uint8_t* d = k.dL.data() + (size_t)o.l * 32; q.descs.insert(q.descs.end(), d, d + 32); }
+            if (o.r != -1) { const uint8_t* d = k.dR.data() + (size_t)o.r * 32; q.descs.insert(q.descs.end(), d, d + 32); }
         }
-        start.push_back((int)src.size());
+        q.mps.push_back(mps[i]);
+        q.start.push_back((int)(q.descs.size() / 32));
     }
-    descs.resize(src.size() * 32);
-    for (size_t i = 0; i < src.size(); i++) memcpy(descs.data() + i * 32, src[i], 32);
-    if (!src.empty()) VS_CHECK(vslam_calc_descriptors(descs.data(), start.data(), (int)mps.size(), cfg.device, best.data()));
-    for (size_t q = 0; q < mps.size(); q++)
-        if (start[q + 1] > start[q] && best[q] >= 0)
-            memcpy(mapPoints[mps[q]].desc, descs.data() + (size_t)(start[q] + best[q]) * 32, 32);
+    q.pending = true;
+    if (deferDevice) return VSLAM_OK;
+    VS_CHECK(run_deferred());
+    apply_deferred();
+    return VSLAM_OK;
+}
+
+vslam_status vslam_system::run_deferred() {
+    if (descReq.pending) {
+        SysProfScope ps(sys_prof().descNs, sys_prof().descN);
+        DescReq& q = descReq;
+        q.best.assign(q.mps.size(), -1);
+        if (!q.descs.empty()) VS_CHECK(vslam_calc_descriptors(q.descs.data(), q.start.data(), (int)q.mps.size(), cfg.device, q.best.data()));
+    }
+    if (refReq.pending) {
+        RefreshReq& r = refReq;
+        const size_t n = r.rk.size();
+        r.dep.assign(n, 0.f); r.clo.assign(n, 0); r.up.assign(n, 0);
+        std::vector<uint8_t> zeroW(n, 0), zeroO(std::max(r.nLm, 1), 0);
+        if (n) VS_CHECK(vslam_ba_refresh_depth(&cfg.rig, r.nKf, r.rpose.data(), r.nLm, r.rlm.data(), zeroO.data(), (int)n, r.rk.data(), r.rl.data(),
+                                               zeroW.data(), r.cur.data(), cfg.device, r.dep.data(), r.clo.data(), r.up.data()));
+    }
+    return VSLAM_OK;
+}
+
+void vslam_system::apply_deferred() {
+    if (descReq.pending) {
+        DescReq& q = descReq;
+        for (size_t i = 0; i < q.mps.size(); i++)
+            if (q.start[i + 1] > q.start[i] && q.best[i] >= 0)
+                memcpy(mapPoints[q.mps[i]].desc, q.descs.data() + (size_t)(q.start[i] + q.best[i]) * 32, 32);
+        q.pending = false;
+    }
+    if (refReq.pending) {
+        RefreshReq& r = refReq;
+        for (size_t i = 0; i < r.rk.size(); i++) {
+            if (!r.up[i]) continue;
+            SysKeys& keys = keyFrames[r.where[i].first].keys;
+            keys.depth[r.where[i].second] = r.dep[i];
+            if (r.clo[i]) keys.close[r.where[i].second] = 1;
+        }
+        r.pending = false;
+    }
+}
+
+// the keyframe's immutable key arrays into a slot of the session's device slab (vslam_kf_view::device_keys of later passes)
+void* vslam_system::reserve_key_slot(int nL, int nR) {
+    const size_t need = vslam_kf_keys_bytes(nL, nR);
+    if (!keySlot) {                    // slot size from the first frame, with room for the +-10 % of the suppression
+        keySlot = (need + need / 4 + 4095) & ~(size_t)4095;
+        keySlotsPerSlab = (int)std::max<size_t>(8, ((size_t)16 << 20) / keySlot);
+        keySlotsUsed = keySlotsPerSlab;
+    }
+    if (need > keySlot) return nullptr;           // (an unusually large frame: its arrays travel with every pass, as before)
+    if (keySlotsUsed == keySlotsPerSlab) {
+        uint8_t* slab = nullptr;
+        if (hipSetDevice(cfg.device) != hipSuccess || hipMalloc((void**)&slab, keySlot * (size_t)keySlotsPerSlab) != hipSuccess) return nullptr;
+        keySlabs.push_back(slab); keySlotsUsed = 0;
+    }
+    return keySlabs.back() + keySlot * (size_t)keySlotsUsed;
+}
+
+vslam_status vslam_system::upload_kf_keys(SysKF& kf) {
+    const int nL = (int)kf.keys.kL.size(), nR = (int)kf.keys.kR.size();
+    void* blk = reserve_key_slot(nL, nR);
+    if (!blk) return VSLAM_OK;
+    vslam_kf_view v{};
+    v.n_left = nL; v.n_right = nR; v.kps_l = kf.keys.kL.data(); v.desc_l = kf.keys.dL.data(); v.kps_r = kf.keys.kR.data(); v.desc_r = kf.keys.dR.data();
+    v.right_idxs = kf.keys.rightIdxs.data(); v.left_idxs = kf.keys.leftIdxs.data();
+    v.estimated_depth = kf.keys.depth.data(); v.close_flags = kf.keys.close.data();
+    VS_CHECK(vslam_kf_keys_upload(&v, cfg.device, blk));
+    adopt_key_slot(kf, blk);
     return VSLAM_OK;
 }
 
@@ -193,6 +262,7 @@ vslam_status vslam_system::initialize_map(const SysKeys& keysIn, int frame) {
         tracked++;
     }
     VS_CHECK(calc_descriptors(need));
+    if (cfg.local_mapping) VS_CHECK(upload_kf_keys(keyFrames[numb]));
     lastKFTrackedNumb = tracked;
     latestKF = numb;
     allFrames.push_back({true, numb, -1, m4_identity()});
@@ -216,7 +286,8 @@ void vslam_system::calc_connections(SysKF& kf) {
 
 // insertKeyFrame (src/FeatureTracker.cpp:743-842)
 vslam_status vslam_system::insert_keyframe(SysKeys& keys, const std::vector<int>& matchedL, const std::vector<int>& matches,
-                                           int nStereo, const M4& estimPose, const std::vector<uint8_t>& outl, const std::vector<int>& act, int frame) {
+                                           int nStereo, const M4& estimPose, const std::vector<uint8_t>& outl, const std::vector<int>& act, int frame,
+                                           void* filledKeySlot) {
     const M4 refPose = m4_mul(keyFrames[latestKF].poseInv, estimPose);
     keyFrames.emplace_back();
     SysKF& kf = keyFrames.back();
@@ -259,6 +330,10 @@ vslam_status vslam_system::insert_keyframe(SysKeys& keys, const std::vector<int>
         }
     }
     VS_CHECK(calc_descriptors(need));
+    if (cfg.local_mapping) {
+        if (filledKeySlot) adopt_key_slot(keyFrames[numb], filledKeySlot);      // (the step's pack kernel wrote the block there)
+        else VS_CHECK(upload_kf_keys(keyFrames[numb]));
+    }
     calc_connections(keyFrames[numb]);
     lastKFTrackedNumb = tracked; kf.nKeysTracked = tracked;
     precCheckMatches = tracked > 350 ? 0.7f : 0.9f;
@@ -338,20 +413,31 @@ vslam_status vslam_system::change_poses_lca(int endIdx) {
 //   frame_candidates / frame_fill_upload   activeMapPoints -> the tracker's upload arrays
 //   frame_imu_input the frame's IMU problem
 //   frame_post      everything after the device: bookkeeping, keyframe rule, insertKeyFrame, updatePoses, local mapping
-vslam_status vslam_system::frame_begin(SysFrameCtx& c, int frame, const vslam_imu_bucket* imu) {
+vslam_status vslam_system::frame_begin_a(SysFrameCtx& c, int frame, const vslam_imu_bucket* imu) {
     if (cfg.use_imu && frame > 0 && (!imu || imu->n <= 0)) { set_error("vslam_system: IMU mode needs the frame's IMU bucket"); return VSLAM_ERR_INVALID; }
     c.frame = frame; c.imu = imu;
     c.out = vslam_frame_report{};
     c.out.frame = frame;
     VS_HIP(hipSetDevice(cfg.device));
     std::lock_guard<std::mutex> lk(mapMutex);
-    VS_CHECK(mapping_begin(frame));                         // the optimizer thread's writes that the schedule places here
+    return mapping_begin_a(frame);                          // the optimizer thread's writes that the schedule places here
+}
+
+vslam_status vslam_system::frame_begin_b(SysFrameCtx& c) {
+    std::lock_guard<std::mutex> lk(mapMutex);
+    VS_CHECK(mapping_begin_b(c.frame));
     if (LBADone) {                                         // :1115-1122
         SysProfScope ps(sys_prof().lcaNs, sys_prof().lcaN);
         VS_CHECK(change_poses_lca(endLBAIdx));
         LBADone = false;
     }
     return VSLAM_OK;
+}
+
+vslam_status vslam_system::frame_begin(SysFrameCtx& c, int frame, const vslam_imu_bucket* imu) {
+    VS_CHECK(frame_begin_a(c, frame, imu));
+    VS_CHECK(run_deferred());
+    return frame_begin_b(c);
 }
 
 vslam_status vslam_system::frame_first(SysFrameCtx& c, double* T_wc_out, vslam_frame_report* rep) {
@@ -402,6 +488,12 @@ void vslam_system::frame_imu_input(SysFrameCtx& c) {
 // st: the device's per-frame state (matches [M][2], source index [M], matchedIdxsL [nL], MPsOutliers [M], inFrame [M],
 // left visibility of every uploaded point [N]); c.tr / c.T_cw / c.imuOut: the tracking block's result
 vslam_status vslam_system::frame_post(SysFrameCtx& c, const SysTrackState& st, double* T_wc_out, vslam_frame_report* rep) {
+    VS_CHECK(frame_post_a(c, st));
+    VS_CHECK(run_deferred());
+    return frame_post_b(c, T_wc_out, rep);
+}
+
+vslam_status vslam_system::frame_post_a(SysFrameCtx& c, const SysTrackState& st) {
     SysProfScope pps(sys_prof().postNs, sys_prof().postN);
     const vslam_track_report& tr = c.tr;
     const int M = tr.n_active, N = c.N, nL = st.nL;
@@ -433,7 +525,7 @@ vslam_status vslam_system::frame_post(SysFrameCtx& c, const SysTrackState& st, d
             SysKeys keys;
             if (st.keys) keys_from_block(st.keys, nL, st.nR, keys);
             else VS_CHECK(fetch_keys(keys));
-            VS_CHECK(insert_keyframe(keys, matchedL, matches, tr.n_stereo, poseEst, outl, act, frame));
+            VS_CHECK(insert_keyframe(keys, matchedL, matches, tr.n_stereo, poseEst, outl, act, frame, st.keys ? st.keySlot : nullptr));
         } else {                                           // addFrame (:871-882)
             allFrames.push_back({false, -1, latestKF, m4_mul(keyFrames[latestKF].poseInv, poseEst)});
         }
@@ -458,12 +550,20 @@ vslam_status vslam_system::frame_post(SysFrameCtx& c, const SysTrackState& st, d
         lastMatches = matches; lastOutliers = outl;
         out.n_keyframes = (int)keyFrames.size(); out.n_map_points = (int)mapPoints.size(); out.n_active_after = (int)active.size();
     }
-    memcpy(T_wc_out, poseEst.data(), sizeof(double) * 16);
     out.keyframe_inserted = isKF ? 1 : 0; out.n_active = M; out.n_inliers = tr.n_inliers; out.n_stereo = tr.n_stereo;
     out.rounds = tr.rounds; out.lm_iterations = tr.lm_iterations;
+    return VSLAM_OK;
+}
+
+// second half: the descriptors the keyframe insertion asked for are in; hand-over to the local mapper, the frame's report
+vslam_status vslam_system::frame_post_b(SysFrameCtx& c, double* T_wc_out, vslam_frame_report* rep) {
+    vslam_frame_report& out = c.out;
+    const int frame = c.frame;
+    memcpy(T_wc_out, camPose.data(), sizeof(double) * 16);      // (= poseEst: updatePoses set it)
     // ---- LocalMapper::beginLocalMapping: one pass of its loop body, on the schedule of cfg.mapping_delay ---------------------
     {
         std::lock_guard<std::mutex> lk(mapMutex);
+        apply_deferred();
         VS_CHECK(mapping_post(frame));
         if (mappingReportFresh) {
             out.mapping_ran = 1; out.new_points = lastMapping.new_points; out.ba_keyframes = lastMapping.ba_keyframes;
@@ -611,32 +711,66 @@ vslam_status vslam_system::mapping_post(int frame) {
     pass.commitFrame = frame + std::max(cfg.mapping_delay, 1);
     np_collect(pass);
     VS_CHECK(submit_job(MapPass::NEW_POINTS));
-    if (cfg.local_mapping == 1) {                          // the whole pass now
-        VS_CHECK(np_commit(pass));
-        ba_collect(pass);
-        VS_CHECK(submit_job(MapPass::LOCAL_BA));
-        VS_CHECK(ba_commit(pass));
+    if (cfg.local_mapping == 1) {                          // the whole pass now (its device calls right away)
+        const bool df = deferDevice;
+        deferDevice = false;
+        vslam_status st = np_commit_a(pass);
+        if (st == VSLAM_OK) {
+            np_commit_b(pass);
+            ba_collect(pass);
+            st = submit_job(MapPass::LOCAL_BA);
+        }
+        if (st == VSLAM_OK) st = ba_commit_a(pass);
+        if (st == VSLAM_OK) ba_commit_b(pass);
+        deferDevice = df;
+        VS_CHECK(st);
         pass.stage = MapPass::IDLE;
     }
     return VSLAM_OK;
 }
 
-vslam_status vslam_system::mapping_begin(int frame) {
+// first half: wait for the job that is due, apply its result to the map up to the device round trips (requests)
+vslam_status vslam_system::mapping_begin_a(int frame) {
+    pass.beginWork = 0;
     if (cfg.local_mapping != 2) return VSLAM_OK;
     { std::lock_guard<std::mutex> lk(wMu); if (workerStatus != VSLAM_OK) { set_error("local mapping thread failed: %s", workerError); return workerStatus; } }
     if (pass.stage == MapPass::NEW_POINTS) {               // the first frame after the hand-over
         VS_CHECK(wait_job());
         SysProfScope pm(sys_prof().mapNs, sys_prof().mapN);
-        VS_CHECK(np_commit(pass));
-        ba_collect(pass);
-        VS_CHECK(submit_job(MapPass::LOCAL_BA));
-    }
-    if (pass.stage == MapPass::LOCAL_BA && frame >= pass.commitFrame) {
+        VS_CHECK(np_commit_a(pass));
+        pass.beginWork = 1;
+    } else if (pass.stage == MapPass::LOCAL_BA && frame >= pass.commitFrame) {
         VS_CHECK(wait_job());
         SysProfScope pm(sys_prof().mapNs, sys_prof().mapN);
-        VS_CHECK(ba_commit(pass));
+        VS_CHECK(ba_commit_a(pass));
+        pass.beginWork = 2;
+    }
+    return VSLAM_OK;
+}
+
+// second half (the requests have been served)
+vslam_status vslam_system::mapping_begin_b(int frame) {
+    apply_deferred();
+    if (pass.beginWork == 1) {
+        SysProfScope pm(sys_prof().mapNs, sys_prof().mapN);
+        np_commit_b(pass);
+        ba_collect(pass);
+        VS_CHECK(submit_job(MapPass::LOCAL_BA));
+        if (frame >= pass.commitFrame) {                   // mapping_delay = 1: the write-back is due in this very frame
+            VS_CHECK(wait_job());
+            const bool df = deferDevice;
+            deferDevice = false;
+            const vslam_status st = ba_commit_a(pass);
+            deferDevice = df;
+            VS_CHECK(st);
+            ba_commit_b(pass);
+            pass.stage = MapPass::IDLE;
+        }
+    } else if (pass.beginWork == 2) {
+        ba_commit_b(pass);
         pass.stage = MapPass::IDLE;
     }
+    pass.beginWork = 0;
     return VSLAM_OK;
 }
 
@@ -655,6 +789,7 @@ void vslam_system::np_collect(MapPass& p) {
         v.kps_l = kf.keys.kL.data(); v.desc_l = kf.keys.dL.data(); v.kps_r = kf.keys.kR.data(); v.desc_r = kf.keys.dR.data();
         v.right_idxs = kf.keys.rightIdxs.data(); v.left_idxs = kf.keys.leftIdxs.data();
         v.unmatched_f = kf.unF.data(); v.unmatched_fr = kf.unFR.data();
+        v.device_keys = kf.dkeys;
     }
     const SysKF& last = keyFrames[actKeyF[0]];
     const int n0 = J.n0 = (int)last.keys.kL.size();
@@ -681,13 +816,15 @@ void vslam_system::np_collect(MapPass& p) {
 }
 
 // addMultiViewMapPointsR + addNewMapPoints (src/OptimizationBA.cpp:90-125, 211-232) from the job's result
-vslam_status vslam_system::np_commit(MapPass& p) {
+vslam_status vslam_system::np_commit_a(MapPass& p) {
     NpJob& J = p.np;
     const std::vector<int>& actKeyF = p.actKeyF;
     const int nk = J.nk, nc = J.R.n_candidates;
     if (mpIdx < 0) mpIdx = (long long)mapPoints.size();
     const int lastNumb = keyFrames[actKeyF[0]].numb;
-    std::vector<int> created, need;
+    std::vector<int>& created = p.created;
+    std::vector<int> need;
+    created.clear();
     for (int c = 0; c < nc; c++) {
         if (!J.acc[c]) continue;
         const int no = J.nObs[c];
@@ -712,7 +849,11 @@ vslam_status vslam_system::np_commit(MapPass& p) {
         mp_update(mp, lastNumb, need, mi);
         created.push_back(mi);
     }
-    VS_CHECK(calc_descriptors(need));
+    return calc_descriptors(need);
+}
+
+void vslam_system::np_commit_b(MapPass& p) {
+    const std::vector<int>& created = p.created;
     for (int mi : created) {                               // addNewMapPoints: MapPoint::addConnection on every observing keyframe
         SysMP& mp = mapPoints[mi];
         for (const KfMatch& o : mp.kfm) {
@@ -723,7 +864,6 @@ vslam_status vslam_system::np_commit(MapPass& p) {
         active.push_back(mi);
     }
     p.newPoints = (int)created.size();
-    return VSLAM_OK;
 }
 
 // LocalMapper::localBA: window collection (:438-516) and graph membership (:556-745) into the job's problem
@@ -834,7 +974,7 @@ vslam_status vslam_system::ba_device(MapPass& p) {
 
 // second-graph flags (:566-575) and the write-back (:875-938) on the map AS IT IS NOW (keyframes / observations the tracker
 // added since the collection count as "later" ones)
-vslam_status vslam_system::ba_commit(MapPass& p) {
+vslam_status vslam_system::ba_commit_a(MapPass& p) {
     BaJob& J = p.ba;
     const std::vector<int>& kfs = J.kfs;
     const std::vector<int>& allMps = J.allMps;
@@ -866,59 +1006,62 @@ vslam_status vslam_system::ba_commit(MapPass& p) {
     std::vector<uint8_t> presentKf(std::max(K, 1), 0), presentLm(std::max(Lm, 1), 0);
     for (int q = 0; q < NP; q++) if (J.pf[q] && !wrong1[q]) { presentKf[J.pk[q]] = 1; presentLm[J.pl[q]] = 1; }
     for (int i = 0; i < K; i++) if (J.kfLocal[i] && presentKf[i]) keyFrames[kfs[i]].setPose(m4_from(&J.kfOut[16 * (size_t)i]));
-    std::vector<int> upd;
+    std::vector<int>& upd = p.upd;
+    upd.clear();
     int nOut = 0;
     for (size_t m = 0; m < allMps.size(); m++) {
         SysMP& mp = mapPoints[allMps[m]];
         if (J.mpOut[m] || (!mp.inFrame && (int)mp.kfm.size() < 3)) { mp.isOutlier = true; nOut++; }
         else if (presentLm[m]) { for (int c = 0; c < 3; c++) mp.wp[c] = J.lmOut[3 * m + c]; upd.push_back(allMps[m]); }
     }
+    p.nWrong = nWrong; p.nOut = nOut;
     // MapPoint::updatePos (src/Map.cpp:212-234): depth / close refresh of every observing keyframe (k_ba_refresh_depth),
-    // then calcDescriptor
+    // then calcDescriptor - both as requests
     if (!upd.empty()) {
-        std::vector<int> rk, rl; std::vector<float> cur; std::vector<std::pair<int, int>> where;     // (kf numb, left idx)
-        std::vector<double> rpose; std::vector<int> kfSlot(keyFrames.size(), -1); std::vector<int> rkfs;
-        std::vector<double> rlm(upd.size() * 3);
+        RefreshReq& r = refReq;
+        r.rk.clear(); r.rl.clear(); r.cur.clear(); r.where.clear();
+        std::vector<int> kfSlot(keyFrames.size(), -1), rkfs;
+        r.rlm.resize(upd.size() * 3);
         for (size_t u = 0; u < upd.size(); u++) {
             const SysMP& mp = mapPoints[upd[u]];
-            for (int c = 0; c < 3; c++) rlm[3 * u + c] = mp.wp[c];
+            for (int c = 0; c < 3; c++) r.rlm[3 * u + c] = mp.wp[c];
             for (const KfMatch& o : mp.kfm) {
                 if (o.l < 0) continue;                 // (the reference indexes estimatedDepth[-1] here; skipped)
                 if (kfSlot[o.kf] < 0) { kfSlot[o.kf] = (int)rkfs.size(); rkfs.push_back(o.kf); }
-                rk.push_back(kfSlot[o.kf]); rl.push_back((int)u); cur.push_back(keyFrames[o.kf].keys.depth[o.l]);
-                where.push_back({o.kf, o.l});
+                r.rk.push_back(kfSlot[o.kf]); r.rl.push_back((int)u); r.cur.push_back(keyFrames[o.kf].keys.depth[o.l]);
+                r.where.push_back({o.kf, o.l});
             }
         }
-        if (!rk.empty()) {
-            rpose.resize(rkfs.size() * 16);
-            for (size_t i = 0; i < rkfs.size(); i++) memcpy(&rpose[16 * i], keyFrames[rkfs[i]].pose.data(), 16 * sizeof(double));
-            std::vector<uint8_t> zeroW(rk.size(), 0), zeroO(upd.size(), 0), clo(rk.size()), up(rk.size());
-            std::vector<float> dep(rk.size());
-            VS_CHECK(vslam_ba_refresh_depth(&cfg.rig, (int)rkfs.size(), rpose.data(), (int)upd.size(), rlm.data(), zeroO.data(), (int)rk.size(),
-                                            rk.data(), rl.data(), zeroW.data(), cur.data(), cfg.device, dep.data(), clo.data(), up.data()));
-            for (size_t q = 0; q < rk.size(); q++) {
-                if (!up[q]) continue;
-                SysKeys& keys = keyFrames[where[q].first].keys;
-                keys.depth[where[q].second] = dep[q];
-                if (clo[q]) keys.close[where[q].second] = 1;
-            }
-        }
-        VS_CHECK(calc_descriptors(upd));
+        r.nKf = (int)rkfs.size(); r.nLm = (int)upd.size();
+        r.rpose.resize(rkfs.size() * 16);
+        for (size_t i = 0; i < rkfs.size(); i++) memcpy(&r.rpose[16 * i], keyFrames[rkfs[i]].pose.data(), 16 * sizeof(double));
+        r.pending = !r.rk.empty();
+        const bool df = deferDevice;
+        deferDevice = true;                    // (both requests are served together: here by run_deferred, in a batch by the group)
+        const vslam_status st = calc_descriptors(upd);
+        deferDevice = df;
+        VS_CHECK(st);
+        if (!deferDevice) { VS_CHECK(run_deferred()); apply_deferred(); }
     }
+    return VSLAM_OK;
+}
+
+void vslam_system::ba_commit_b(MapPass& p) {
+    BaJob& J = p.ba;
     endLBAIdx = p.actKeyF[0];
     keyFrameAdded = false;
     LBADone = true;
     const vslam_ba_result& Rr = J.R;
     lastMapping = vslam_frame_report{};
     lastMapping.new_points = p.newPoints;
-    lastMapping.ba_keyframes = K; lastMapping.ba_local = (int)J.local.size(); lastMapping.ba_landmarks = Lm; lastMapping.ba_pairs = NP;
-    lastMapping.ba_wrong = nWrong; lastMapping.ba_outliers = nOut;
+    lastMapping.ba_keyframes = (int)J.kfs.size(); lastMapping.ba_local = (int)J.local.size(); lastMapping.ba_landmarks = (int)J.allMps.size();
+    lastMapping.ba_pairs = (int)J.pk.size();
+    lastMapping.ba_wrong = p.nWrong; lastMapping.ba_outliers = p.nOut;
     lastMapping.ba_report[0] = Rr.report[0]; lastMapping.ba_report[1] = Rr.report[1];
     lastMapping.ba_residuals = (int)Rr.n_residuals; lastMapping.ba_free_kf = (int)Rr.n_free_kf; lastMapping.ba_sum_k2 = (int)Rr.sum_k2;
     lastMapping.ba_trials = Rr.report[0].inner_iterations + Rr.report[1].inner_iterations;
     lastMapping.ba_rounds = (int)Rr.rounds;
     mappingReportFresh = true;
-    return VSLAM_OK;
 }
 
 extern "C" {

@@ -83,6 +83,7 @@ struct SysKF {                         // KeyFrame (include/KeyFrame.h) - keyfra
     std::vector<int> unF, unFR, lmpL, lmpR;            // unMatchedF / unMatchedFR, localMapPoints(R) as map-point indices
     std::vector<std::pair<int, int>> sortedKFWeights;   // (weight, keyframe number)
     int LBAID = -1, nKeysTracked = 0;
+    void* dkeys = nullptr;                              // the immutable key arrays in HBM (a slot of the session's slab), or null
     void setPose(const M4& T) { pose = T; poseInv = m4_affine_inv(T); }      // CameraPose::setPose (src/Camera.cpp:10-15)
 };
 
@@ -98,6 +99,7 @@ struct SysFrameCtx {
 struct SysTrackState {
     const int* matches; const int* actIdx; const int* matchedL; const uint8_t* outl; const uint8_t* inF; const uint8_t* visL; int nL;
     const uint8_t* keys = nullptr; int nR = 0;      // the frame's TrackedKeys, packed (track_dev.hpp key_block_layout), or null: fetch_keys()
+    void* keySlot = nullptr;                        // != null: the same block is already in this slot of the session's key slab (pack kernel)
 };
 
 // VSLAM_BATCH_PHASES diagnostics: where the per-lane host phases spend their time (nanoseconds / calls, process-wide)
@@ -133,6 +135,23 @@ struct BaJob {                        // localBA (:426-940): window + graph of v
     int lastActKF = 0;
     vslam_ba_problem P{}; vslam_ba_result R{};
 };
+// Device round trips of the host phases (descriptor selection, depth refresh) as REQUESTS: a lockstep group gathers the requests
+// of all its lanes after a phase and serves them with one launch each; a single session serves its own right away.
+struct DescReq {                      // MapPoint::calcDescriptor for a set of map points
+    std::vector<int> mps, start, best;
+    std::vector<uint8_t> descs;
+    bool pending = false;
+};
+struct RefreshReq {                   // MapPoint::updatePos depth / close refresh (vslam_ba_refresh_depth)
+    std::vector<int> rk, rl;
+    std::vector<float> cur, dep;
+    std::vector<std::pair<int, int>> where;     // (keyframe number, left index)
+    std::vector<double> rpose, rlm;
+    std::vector<uint8_t> clo, up;
+    int nKf = 0, nLm = 0;
+    bool pending = false;
+};
+
 struct MapPass {
     enum { IDLE = 0, NEW_POINTS = 1, LOCAL_BA = 2 };
     int stage = IDLE;                 // which job is in flight / was last submitted
@@ -140,6 +159,10 @@ struct MapPass {
     int newPoints = 0;
     std::vector<int> actKeyF;         // lastKF + its best covisible keyframes (KeyFrame::getConnectedKFs)
     NpJob np; BaJob ba;
+    // state between the two halves of a commit (np_commit_a / _b, ba_commit_a / _b)
+    std::vector<int> created, upd;
+    int nWrong = 0, nOut = 0;
+    int beginWork = 0;                // what frame_begin_a did: 1 new points committed, 2 local BA committed
 };
 
 }  // namespace vslam_sys
@@ -181,6 +204,10 @@ struct vslam_system {
     // the mapping thread never touches the map.
     std::mutex mapMutex;
     MapPass pass;
+    DescReq descReq; RefreshReq refReq;
+    bool deferDevice = false;          // (set by vslam_batch around the first half of a host phase)
+    // keyframe key arrays resident in HBM: fixed-size slots carved from slabs (no hipMalloc / hipFree per keyframe)
+    std::vector<uint8_t*> keySlabs; size_t keySlot = 0; int keySlotsPerSlab = 0, keySlotsUsed = 0;
     std::vector<int> lcaWhere;         // scratch of kf_update_pose: map-point index -> slot (entries reset after use)
     // device work of the pass in flight (local_mapping == 2): the session's own thread, or the batch's mapping threads
     std::thread worker;
@@ -195,12 +222,21 @@ struct vslam_system {
     SysFrameCtx ctx;
     vslam_status init(const vslam_system_config* c, vslam_extractor* sharedFe = nullptr, int imgBase = 0, hipStream_t sharedStream = nullptr);
     void release();
-    vslam_status frame_begin(SysFrameCtx& c, int frame, const vslam_imu_bucket* imu);
+    vslam_status frame_begin(SysFrameCtx& c, int frame, const vslam_imu_bucket* imu);      // = _a, the deferred device calls, _b
+    vslam_status frame_begin_a(SysFrameCtx& c, int frame, const vslam_imu_bucket* imu);
+    vslam_status frame_begin_b(SysFrameCtx& c);
+    vslam_status run_deferred();       // serves this session's pending requests (single-session path)
+    void apply_deferred();
+    vslam_status upload_kf_keys(SysKF& kf);
+    void* reserve_key_slot(int nL, int nR);        // the session's next free key slot (HBM) if a frame of this size fits one, else null
+    void adopt_key_slot(SysKF& kf, void* slot) { kf.dkeys = slot; keySlotsUsed++; }
     vslam_status frame_first(SysFrameCtx& c, double* T_wc_out, vslam_frame_report* rep);
     int frame_candidates(SysFrameCtx& c);
     void frame_fill_upload(const SysFrameCtx& c, double* xyz, uint8_t* desc, float* msd);
     void frame_imu_input(SysFrameCtx& c);
-    vslam_status frame_post(SysFrameCtx& c, const SysTrackState& st, double* T_wc_out, vslam_frame_report* rep);
+    vslam_status frame_post(SysFrameCtx& c, const SysTrackState& st, double* T_wc_out, vslam_frame_report* rep);      // = _a, deferred calls, _b
+    vslam_status frame_post_a(SysFrameCtx& c, const SysTrackState& st);
+    vslam_status frame_post_b(SysFrameCtx& c, double* T_wc_out, vslam_frame_report* rep);
     void run_mapping();
     void finish_job(vslam_status s, const char* err);
     vslam_status track(const uint8_t* L, const uint8_t* R, int stride, bool onDevice, int frame, const vslam_imu_bucket* imu,
@@ -211,20 +247,24 @@ struct vslam_system {
     void backproject(const SysKeys& k, int i, const M4& pose, double* out) const;
     vslam_status initialize_map(const SysKeys& keys, int frame);
     vslam_status insert_keyframe(SysKeys& keys, const std::vector<int>& matchedL, const std::vector<int>& matches,
-                                 int nStereo, const M4& estimPose, const std::vector<uint8_t>& outl, const std::vector<int>& act, int frame);
+                                 int nStereo, const M4& estimPose, const std::vector<uint8_t>& outl, const std::vector<int>& act, int frame,
+                                 void* filledKeySlot = nullptr);
     void calc_connections(SysKF& kf);
     vslam_status change_poses_lca(int endIdx);
     vslam_status kf_update_pose(SysKF& kf, const M4& keyPose);
     // the pass, in the order of the schedule (vslam_hip.h, vslam_system_config::mapping_delay)
     void mapping_window(std::vector<int>& actKeyF);
     void np_collect(MapPass& p);
-    vslam_status np_commit(MapPass& p);
+    vslam_status np_commit_a(MapPass& p);
+    void np_commit_b(MapPass& p);
     void ba_collect(MapPass& p);
     vslam_status ba_device(MapPass& p);
-    vslam_status ba_commit(MapPass& p);
+    vslam_status ba_commit_a(MapPass& p);
+    void ba_commit_b(MapPass& p);
     vslam_status submit_job(int stage);
     vslam_status wait_job();
-    vslam_status mapping_begin(int frame);        // frame_begin's share
+    vslam_status mapping_begin_a(int frame);      // frame_begin's share, before / after the deferred device calls
+    vslam_status mapping_begin_b(int frame);
     vslam_status mapping_post(int frame);         // frame_post's share
     void worker_loop();
 };

@@ -215,15 +215,17 @@ __global__ __launch_bounds__(256) void k_track_pack_b(const PackLane* __restrict
     if (L.keyOut) {
         const KeyBlockLayout K = key_block_layout(nL, L.nR);
         const int t0 = blockIdx.x * 256 + threadIdx.x, ts = gridDim.x * 256;
+        uint8_t* const o2 = L.keyOut2;
         auto copy4 = [&](size_t off, const void* src, size_t bytes) {      // (every source / section is 4-byte aligned)
             const unsigned* s = (const unsigned*)src;
             unsigned* d = (unsigned*)(L.keyOut + off);
-            for (size_t i = t0; i < bytes / 4; i += ts) d[i] = s[i];
+            unsigned* d2 = (unsigned*)(o2 + off);
+            for (size_t i = t0; i < bytes / 4; i += ts) { const unsigned v = s[i]; d[i] = v; if (o2) d2[i] = v; }
         };
         copy4(K.kpsL, L.kps[0], (size_t)nL * sizeof(vslam_keypoint)); copy4(K.descL, L.desc[0], (size_t)nL * 32);
         copy4(K.kpsR, L.kps[1], (size_t)L.nR * sizeof(vslam_keypoint)); copy4(K.descR, L.desc[1], (size_t)L.nR * 32);
         copy4(K.rightIdxs, L.rightIdxs, (size_t)nL * 4); copy4(K.depth, L.depth, (size_t)nL * 4); copy4(K.leftIdxs, L.leftIdxs, (size_t)L.nR * 4);
-        for (int i = t0; i < nL; i += ts) L.keyOut[K.closef + i] = L.closef[i];
+        for (int i = t0; i < nL; i += ts) { const uint8_t v = L.closef[i]; L.keyOut[K.closef + i] = v; if (o2) o2[K.closef + i] = v; }
     }
 }
 

@@ -28,6 +28,7 @@ struct PackLane {            // k_track_pack_b: the frame's tracking state of on
     // keyOut != null: the frame's TrackedKeys as well (a lane that may insert a keyframe this step), 16-byte aligned sections
     // in this order: kps L, desc L, kps R, desc R, rightIdxs, depth, close (nL each), leftIdxs (nR)
     uint8_t* keyOut; int nR;
+    uint8_t* keyOut2;        // != null: a second copy of the key block, into the lane's next keyframe slot in HBM (vslam_kf_view::device_keys)
     const vslam_keypoint* kps[2]; const uint8_t* desc[2]; const int* rightIdxs; const int* leftIdxs; const float* depth; const uint8_t* closef;
 };
 // byte offsets of the key sections inside keyOut (host and device use the same function)

@@ -493,44 +493,65 @@ def corridor_pose(i, fps=20.0, speed=0.5):
     return T
 
 
-def render_torch(planes, tex_t, rig, T_wc, device, noise_seed=None, noise_sigma=2.0):
-    """render() on torch tensors (float64 geometry, float32 texture taps), one u8 [h, w] image on `device`."""
+class TorchPlanes:
+    """the plane model as tensors on `device` (built once per sequence)"""
+
+    def __init__(self, planes, device, dtype):
+        import torch
+        def t(v):
+            return torch.as_tensor(np.array(v, np.float64), dtype=dtype, device=device)
+        self.np_planes = planes
+        self.o = t([p[0] for p in planes]); self.ex = t([p[1] for p in planes]); self.ey = t([p[2] for p in planes])
+        self.n = t([np.cross(p[1], p[2]) for p in planes])
+        self.hw = t([p[3] for p in planes]); self.hh = t([p[4] for p in planes])
+        self.toff = t([p[5] for p in planes]); self.tsc = t([p[6] for p in planes])
+        self.z = np.array([p[0][2] for p in planes]); self.small = np.array([p[3] < 5 for p in planes])
+
+
+def render_torch(planes, tex_t, rig, T_wc, device, noise_seed=None, noise_sigma=2.0, chunk=16):
+    """render() on torch tensors: one u8 [h, w] image on `device`.  Planes are intersected `chunk` at a time (elementwise ops on
+    [chunk, h, w] tensors, float32), the nearest hit per pixel kept, ONE bilinear texture fetch per pixel at the end."""
     import torch
+    P = planes if isinstance(planes, TorchPlanes) else TorchPlanes(planes, device, torch.float32)
     w, h = rig["w"], rig["h"]
     fx, fy, cx, cy = rig["fx"], rig["fy"], rig["cx"], rig["cy"]
-    f64 = torch.float64
-    v, u = torch.meshgrid(torch.arange(h, dtype=f64, device=device), torch.arange(w, dtype=f64, device=device), indexing="ij")
-    R = torch.as_tensor(T_wc[:3, :3], dtype=f64, device=device)
-    t = torch.as_tensor(T_wc[:3, 3], dtype=f64, device=device)
-    d_c = torch.stack([(u - cx) / fx, (v - cy) / fy, torch.ones_like(u)], -1)
-    d_w = d_c @ R.T
-    best = torch.full((h, w), float("inf"), dtype=f64, device=device)
-    out = torch.zeros((h, w), dtype=torch.float32, device=device)
+    f32 = torch.float32
+    v, u = torch.meshgrid(torch.arange(h, dtype=torch.float64, device=device), torch.arange(w, dtype=torch.float64, device=device), indexing="ij")
+    R = T_wc[:3, :3]
+    xc, yc = (u - cx) / fx, (v - cy) / fy
+    d = [(R[k, 0] * xc + R[k, 1] * yc + R[k, 2]).to(f32) for k in range(3)]      # world ray directions (camera z = 1)
+    t = [float(T_wc[k, 3]) for k in range(3)]
+    tz = t[2]
+    keep = np.nonzero(~(P.small & ((P.z < tz - 1.0) | (P.z > tz + 30.0))) if len(P.z) > 40 else np.ones(len(P.z), bool))[0]
+    best = torch.full((h, w), float("inf"), dtype=f32, device=device)
+    bA = torch.zeros((h, w), dtype=f32, device=device); bB = torch.zeros_like(bA)
+    bI = torch.zeros((h, w), dtype=torch.long, device=device)
+    tv = torch.as_tensor(t, dtype=f32, device=device)
+    for c0 in range(0, len(keep), chunk):
+        idx = torch.as_tensor(keep[c0:c0 + chunk], device=device)
+        o, n, ex, ey = P.o[idx], P.n[idx], P.ex[idx], P.ey[idx]
+        cc = ((o - tv) * n).sum(1)                                                  # [C]
+        den = d[0] * n[:, 0, None, None] + d[1] * n[:, 1, None, None] + d[2] * n[:, 2, None, None]
+        lam = cc[:, None, None] / den
+        px = tv[0] + lam * d[0] - o[:, 0, None, None]; py = tv[1] + lam * d[1] - o[:, 1, None, None]; pz = tv[2] + lam * d[2] - o[:, 2, None, None]
+        a = px * ex[:, 0, None, None] + py * ex[:, 1, None, None] + pz * ex[:, 2, None, None]
+        b = px * ey[:, 0, None, None] + py * ey[:, 1, None, None] + pz * ey[:, 2, None, None]
+        hit = (lam > 0.05) & (a.abs() <= P.hw[idx][:, None, None]) & (b.abs() <= P.hh[idx][:, None, None]) & torch.isfinite(lam)
+        lam = torch.where(hit, lam, torch.full_like(lam, float("inf")))
+        lc, ic = lam.min(0)
+        upd = lc < best
+        ac = torch.gather(a, 0, ic[None])[0]; bc = torch.gather(b, 0, ic[None])[0]
+        best = torch.where(upd, lc, best); bA = torch.where(upd, ac, bA); bB = torch.where(upd, bc, bB); bI = torch.where(upd, idx[ic], bI)
     ts = tex_t.shape[0]
-    tz = float(T_wc[2, 3])
-    for (o, ex, ey, hw, hh, toff, tsc) in planes:
-        if len(planes) > 40 and hw < 5 and not (tz - 1.0 < o[2] < tz + 30.0):      # boxes behind the camera or far down the corridor
-            continue
-        n = np.cross(ex, ey)
-        n_t = torch.as_tensor(n, dtype=f64, device=device)
-        o_t = torch.as_tensor(o, dtype=f64, device=device)
-        lam = float((o - T_wc[:3, 3]) @ n) / (d_w @ n_t)
-        p = t + lam[..., None] * d_w - o_t
-        a = p @ torch.as_tensor(ex, dtype=f64, device=device)
-        b = p @ torch.as_tensor(ey, dtype=f64, device=device)
-        hit = (lam > 0.05) & (a.abs() <= hw) & (b.abs() <= hh) & (lam < best) & torch.isfinite(lam)
-        if not bool(hit.any()):
-            continue
-        tu = torch.remainder(toff[0] + (a + hw) * tsc, ts - 1)
-        tv = torch.remainder(toff[1] + (b + hh) * tsc, ts - 1)
-        tu = torch.where(hit, tu, torch.zeros_like(tu)); tv = torch.where(hit, tv, torch.zeros_like(tv))
-        x0 = tu.floor().long(); y0 = tv.floor().long()
-        fxr = (tu - x0).float(); fyr = (tv - y0).float()
-        x1 = torch.clamp(x0 + 1, max=ts - 1); y1 = torch.clamp(y0 + 1, max=ts - 1)
-        val = (tex_t[y0, x0] * (1 - fxr) * (1 - fyr) + tex_t[y0, x1] * fxr * (1 - fyr)
-               + tex_t[y1, x0] * (1 - fxr) * fyr + tex_t[y1, x1] * fxr * fyr)
-        out = torch.where(hit, val, out)
-        best = torch.where(hit, lam, best)
+    hitAny = torch.isfinite(best)
+    tu = torch.remainder(P.toff[bI, 0] + (bA + P.hw[bI]) * P.tsc[bI], ts - 1)
+    tw = torch.remainder(P.toff[bI, 1] + (bB + P.hh[bI]) * P.tsc[bI], ts - 1)
+    tu = torch.where(hitAny, tu, torch.zeros_like(tu)); tw = torch.where(hitAny, tw, torch.zeros_like(tw))
+    x0 = tu.floor().long(); y0 = tw.floor().long()
+    fxr = tu - x0; fyr = tw - y0
+    x1 = torch.clamp(x0 + 1, max=ts - 1); y1 = torch.clamp(y0 + 1, max=ts - 1)
+    out = (tex_t[y0, x0] * (1 - fxr) * (1 - fyr) + tex_t[y0, x1] * fxr * (1 - fyr) + tex_t[y1, x0] * (1 - fxr) * fyr + tex_t[y1, x1] * fxr * fyr)
+    out = torch.where(hitAny, out, torch.zeros_like(out))
     if noise_seed is not None and noise_sigma > 0:
         g = torch.Generator(device=device)
         g.manual_seed(int(noise_seed))
@@ -542,7 +563,7 @@ def corridor_sequence(rig_name, n_frames, device, frame_step=1, speed=0.5, first
     """n_frames stereo pairs along the corridor on `device`: (left [n, h, w] u8, right [n, h, w] u8, poses [n, 4, 4], frame indices)."""
     import torch
     rig = RIGS[rig_name]
-    planes = make_corridor(scene_seed)
+    planes = TorchPlanes(make_corridor(scene_seed), device, torch.float32)
     tex_t = torch.from_numpy(texture(tex_seed).astype(np.float32)).to(device)
     ext = np.eye(4); ext[0, 3] = rig["bl"]
     idx = [first + frame_step * j for j in range(n_frames)]

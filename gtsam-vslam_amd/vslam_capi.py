@@ -609,7 +609,8 @@ def tracker_track_mono_imu(matcher, gravity, noise, T_body_sensor, T_wc_prev, ve
 class KfView(C.Structure):
     _fields_ = [("T_wc", C.c_void_p), ("id", C.c_int64), ("n_left", C.c_int32), ("n_right", C.c_int32),
                 ("kps_l", C.c_void_p), ("desc_l", C.c_void_p), ("kps_r", C.c_void_p), ("desc_r", C.c_void_p),
-                ("right_idxs", C.c_void_p), ("left_idxs", C.c_void_p), ("unmatched_f", C.c_void_p), ("unmatched_fr", C.c_void_p)]
+                ("right_idxs", C.c_void_p), ("left_idxs", C.c_void_p), ("unmatched_f", C.c_void_p), ("unmatched_fr", C.c_void_p),
+                ("device_keys", C.c_void_p), ("estimated_depth", C.c_void_p), ("close_flags", C.c_void_p)]
 
 
 class NewPointsProblem(C.Structure):

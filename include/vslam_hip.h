@@ -420,6 +420,12 @@ vslam_status vslam_local_ba_set_lookahead(int32_t candidates, int32_t speculativ
  * objects from the result (addMultiViewMapPointsR / addNewMapPoints) stays with the caller.
  * kfs[0] is lastKF (= actKeyF.front()), the others follow in the window's order.
  * ------------------------------------------------------------------------- */
+/* A keyframe's IMMUTABLE TrackedKeys arrays (keypoints, descriptors, rightIdxs / leftIdxs of both sides) resident in HBM: a
+ * keyframe is searched by the new-point pipeline of every later pass whose window holds it, so its ~200 KB travel to the device
+ * once (at insertion) instead of once per pass.  A block is `vslam_kf_keys_bytes(n_left, n_right)` bytes of device memory owned by
+ * the caller (e.g. a slot of a slab); vslam_kf_keys_upload fills it from host arrays. */
+size_t vslam_kf_keys_bytes(int32_t n_left, int32_t n_right);
+
 typedef struct {
     const double* T_wc;                /* KeyFrame::pose.pose, row-major 4x4 */
     int64_t id;                        /* KeyFrame::numb */
@@ -428,7 +434,13 @@ typedef struct {
     const vslam_keypoint* kps_r; const uint8_t* desc_r;      /* keys.rightKeyPoints / rightDesc */
     const int32_t* right_idxs; const int32_t* left_idxs;     /* keys.rightIdxs / leftIdxs */
     const int32_t* unmatched_f; const int32_t* unmatched_fr; /* KeyFrame::unMatchedF / unMatchedFR (>= 0: has a map point) */
+    const void* device_keys;           /* NULL, or the keyframe's device block (vslam_kf_keys_upload): the six immutable arrays above are
+                                          then read from it and only unmatched_f / unmatched_fr are uploaded */
+    const float* estimated_depth; const uint8_t* close_flags;   /* vslam_kf_keys_upload only (may be NULL): the block also has room for
+                                          keys.estimatedDepth / close as they were at insertion (the layout of a lockstep step's key block) */
 } vslam_kf_view;
+/* fills a device block of vslam_kf_keys_bytes(n_left, n_right) bytes from the view's host arrays (synchronous) */
+vslam_status vslam_kf_keys_upload(const vslam_kf_view* view, int32_t device, void* device_block);
 
 typedef struct {
     vslam_rig rig;
