@@ -138,7 +138,7 @@ def cpu_baseline(cfg, frames, poses, vel, fwd, delay, threads, budget_s=16.0, wa
     imu = None
     if cfg["imu"]:
         imu = dict(prm=po.imu_params(GRAVITY, IMU_NOISE[0], IMU_NOISE[2], IMU_NOISE[1], IMU_NOISE[3], synth.T_BC1))
-    S = vo_system.System(rig, cfg["nfeat"], T0=poses[0], imu=imu, mapping_delay=delay, threads=threads)
+    S = vo_system.System(rig, cfg["nfeat"], T0=poses[0], imu=imu, mapping_delay=delay[0], mapping_np_delay=delay[1], threads=threads)
     if cfg["imu"]:
         S.velocity = vel[0].copy()
     per, t_all = [], None
@@ -159,9 +159,9 @@ def cpu_baseline(cfg, frames, poses, vel, fwd, delay, threads, budget_s=16.0, wa
     return {"value": float(len(per) / per.sum()), "unit": "frames/s", "cores": 3 if threads else 1, "kind": "port",
             "median_ms": float(np.median(per) * 1e3), "p95_ms": float(np.percentile(per, 95) * 1e3),
             "sample": "%d timed frames of the same sequence after %d warm-up frames through the oracle's closed loop (extract L+R, stereo, "
-                      "tracking, keyframe insertion, new points + local BA on the tracker's windows, mapping_delay %d; %d keyframes, %d local BAs), "
+                      "tracking, keyframe insertion, new points + local BA on the tracker's windows, mapping_delay %d / np %d; %d keyframes, %d local BAs), "
                       "%s; liboracle built -O3 -march=native -ffp-contract=off on this host; the reference itself cannot be built here "
-                      "(OpenCV / GTSAM absent)" % (len(per), warm, delay, len(S.keyFrames), sum(1 for l in S.log if "mapping" in l),
+                      "(OpenCV / GTSAM absent)" % (len(per), warm, delay[0], delay[1], len(S.keyFrames), sum(1 for l in S.log if "mapping" in l),
                                                    "the reference's threading: left || right extraction threads + the local BA's solve on the optimizer thread (3 cores)"
                                                    if threads else "single thread")}
 
@@ -237,6 +237,8 @@ def main():
                     "thread's hand-over (vslam_system_config::mapping_delay): new points arrive with the frame after the keyframe, the "
                     "local BA's write-back + changePosesLCA k frames after it.  Keyframes are at least 5 frames apart, so with k <= 5 every "
                     "keyframe gets its pass - the reference's steady state at camera rate")
+    ap.add_argument("--mapping-np-delay", type=int, default=-1, help="(default: 2 frames, 1 for c3) --mapping 2: the new points of a pass are written a "
+                    "frames after the hand-over (vslam_system_config::mapping_np_delay); the local BA collects its window at that moment")
     ap.add_argument("--prime", type=int, default=-1, help="(default 160 corridor / 60 room) ""untimed frames every session tracks BEFORE the warm-up steps, so that the timed "
                     "steps see sessions in their steady state (a map with more than three keyframes, the local mapper running) "
                     "whatever --warmup / --steps are; part of the set-up like rendering the frames")
@@ -325,7 +327,11 @@ def main():
         # (10 fps, ~10x the motion per frame), k = 4 for the EuRoC-like ones (20 fps).  The mode is parity-tested frame by frame
         # against the oracle's restatement of the same schedule (tests/test_gpu_system.py).
         args.mapping_delay = 2 if args.config == "c3" else 4
-    scfg = vc.system_config(rig, cfg["nfeat"], imu=imu, local_mapping=args.mapping, device=local, mapping_delay=args.mapping_delay)
+    if args.mapping_np_delay < 0:
+        args.mapping_np_delay = 1 if args.config == "c3" else 2
+    args.mapping_np_delay = max(1, min(args.mapping_np_delay, args.mapping_delay))
+    scfg = vc.system_config(rig, cfg["nfeat"], imu=imu, local_mapping=args.mapping, device=local, mapping_delay=args.mapping_delay,
+                            mapping_np_delay=args.mapping_np_delay)
 
     def make_fleet(S, lanes):
         return vc.Fleet(scfg, S, lp, rp, w, not args.host_images, poses=poses, velocities=vel,
@@ -508,9 +514,9 @@ def main():
                                       rep["frames"] / max(rep["keyframes"], 1), frames_per_ba, L_, R_, Fk, nk, Mact),
                        "sessions_per_gpu": S, "lanes_per_group": lanes, "prime_frames": args.prime,
                        "local_mapping": {0: "off", 1: "inside the frame (synchronous)", 2: "device work beside tracking, fixed schedule"}.get(args.mapping, "?") +
-                                        ("; mapping_delay = %d: new points with the next frame, the BA's write-back + changePosesLCA %d frames after "
-                                         "the hand-over (the mode of tests/test_gpu_system.py::test_closed_loop_parity_async_*)" % (args.mapping_delay, args.mapping_delay)
-                                         if args.mapping == 2 else ""),
+                                        ("; new points %d frame(s) after the hand-over (mapping_np_delay), the BA's write-back + changePosesLCA %d frames "
+                                         "after it (mapping_delay): the schedule of tests/test_gpu_system.py::test_closed_loop_parity_async_*"
+                                         % (args.mapping_np_delay, args.mapping_delay) if args.mapping == 2 else ""),
                        "step": "one stereo frame of each of the %d sessions" % S,
                        "threads": ("%d lockstep groups of %d sessions (vslam_batch: one launch per stage for all lanes), one driver thread + a "
                                    "host-phase pool + the mapping engine per group" % ((S + lanes - 1) // lanes, lanes)) if lanes > 0 else
@@ -604,8 +610,9 @@ def main():
                 hostf = [(Ls[j].cpu().numpy(), Rs[j].cpu().numpy()) for j in range(min(nb, args.frames))]
             else:
                 hostf = [(f[0], f[1]) for f in frames[:nb]]
-            out["cpu_baseline"] = cpu_baseline(cfg, hostf, poses, vel, fwd, args.mapping_delay if args.mapping == 2 else 0, True)
-            out["cpu_baseline_single_thread"] = cpu_baseline(cfg, hostf, poses, vel, fwd, args.mapping_delay if args.mapping == 2 else 0, False)
+            dl = (args.mapping_delay, args.mapping_np_delay) if args.mapping == 2 else (0, 1)
+            out["cpu_baseline"] = cpu_baseline(cfg, hostf, poses, vel, fwd, dl, True)
+            out["cpu_baseline_single_thread"] = cpu_baseline(cfg, hostf, poses, vel, fwd, dl, False)
 
         def emit(c5res):
             with emit_lock:

@@ -2575,7 +2575,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
             for (int b = 0; b < perPoll; b++) VS_CHECK(step(enq + b == 0));
             enq += perPoll;
             VS_HIP(hipMemcpyAsync(h_ctlOut, D.ctl, CTL_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, stream));
-            VS_HIP(hipStreamSynchronize(stream));
+            VS_HIP(vslam::stream_wait_blocking(stream));
             if (co[CI_STATE] == BA_DONE) break;
             if (enq > 400) { set_error("local BA: LM did not terminate"); return VSLAM_ERR_INVALID; }
         }
@@ -2726,7 +2726,7 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
         if (bws) bws->release();
         bws.reset(new BatchWs()); bws->device = device;
         VS_HIP(vslam::create_side_stream(&bws->stream));
-        bws->pool.start(3);
+        bws->pool.start(2);
         prevRelease = g_baRelease;
         g_baRelease = []() { if (bws) { bws->release(); bws.reset(); } if (prevRelease) { auto f = prevRelease; prevRelease = nullptr; f(); } g_baTimer.destroy(); };
     }
@@ -2971,7 +2971,7 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
             for (int b = 0; b < perPoll; b++) VS_CHECK(step(enq + b == 0));
             enq += perPoll;
             VS_HIP(hipMemcpyAsync(b_ctl, A.dev(h_ctlAll), (size_t)CTL_DOUBLES * 8 * NL, hipMemcpyDeviceToHost, stream));
-            VS_HIP(hipStreamSynchronize(stream));
+            VS_HIP(vslam::stream_wait_blocking(stream));
             bool all = true;
             for (int a = 0; a < NL; a++) all &= ((const int*)(b_ctl + (size_t)CTL_DOUBLES * a + CTL_INTS))[CI_STATE] == BA_DONE;
             if (all) return VSLAM_OK;
@@ -3001,7 +3001,7 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
         VS_HIP(hipGetLastError());
         VS_HIP(hipMemcpyAsync(W.h_back + oBackWrong, dm + wrongBase, wrongEnd - wrongBase, hipMemcpyDeviceToHost, stream));
         if (gather) VS_HIP(hipMemcpyAsync(W.h_back + oBackOut, dm + outBase, outEnd - outBase, hipMemcpyDeviceToHost, stream));
-        VS_HIP(hipStreamSynchronize(stream));
+        VS_HIP(vslam::stream_wait_blocking(stream));
         return VSLAM_OK;
     };
     // ---- pass 1 ------------------------------------------------------------------------------------------------------------------

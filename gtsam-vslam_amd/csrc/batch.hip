@@ -27,6 +27,7 @@
 #include "track_dev.hpp"
 #include "ba_pool.hpp"
 #include <chrono>
+#include <malloc.h>
 
 namespace vslam {
 void launch_pose_batch(hipStream_t s, const PoseLane* dLanes, int B);
@@ -98,8 +99,14 @@ struct vslam_batch {
     vslam_status enqueue_extraction(const uint8_t* const* L, const uint8_t* const* R, const uint8_t* mask, int stride, bool onDevice);
     static void submit_mapping(void* self, vslam_system* s) {
         vslam_batch* b = (vslam_batch*)self;
-        std::lock_guard<std::mutex> lk(b->mqMu);
-        (s->pass.stage == MapPass::NEW_POINTS ? b->npQueue : b->baQueue).push_back(s);
+        bool now = false;
+        {
+            std::lock_guard<std::mutex> lk(b->mqMu);
+            (s->pass.stage == MapPass::NEW_POINTS ? b->npQueue : b->baQueue).push_back(s);
+            // mapping_delay == mapping_np_delay: the lane waits for this local BA inside the same host phase - no cohort to wait for
+            if (s->pass.stage == MapPass::LOCAL_BA && s->pass.commitFrame <= s->pass.npFrame) { b->baReady = true; now = true; }
+        }
+        if (now) b->baCv.notify_all();
     }
     void kick() {                                  // a host phase has ended: its jobs form a cohort
         { std::lock_guard<std::mutex> lk(mqMu); npReady = !npQueue.empty(); baReady = !baQueue.empty(); }
@@ -177,12 +184,25 @@ vslam_status vslam_batch::init(const vslam_system_config* cfgs, int n, int hostT
     for (int b = 1; b < B; b++) {
         const vslam_system_config& c = cfgs[b];
         if (c.device != device || (c.use_imu != 0) != useImu || memcmp(&c.rig, &cfgs[0].rig, sizeof(c.rig)) || memcmp(&c.fe, &cfgs[0].fe, sizeof(c.fe)) ||
-            c.local_mapping != cfgs[0].local_mapping || c.mapping_delay != cfgs[0].mapping_delay) {
+            c.local_mapping != cfgs[0].local_mapping || c.mapping_delay != cfgs[0].mapping_delay || c.mapping_np_delay != cfgs[0].mapping_np_delay) {
             set_error("vslam_batch: lanes must share device, rig, extractor parameters, IMU mode and mapping mode / delay");
             return VSLAM_ERR_INVALID;
         }
     }
     VS_HIP(hipSetDevice(device));
+    {
+        // Every keyframe keeps ~200 KB of key arrays on the host; by default glibc serves blocks of that size with one mmap each,
+        // and a dozen host-phase threads doing that at every step queue on the process's mm lock (the copy of a key block took
+        // 170 - 600 us instead of ~15).  Serve them from the (per-thread) heaps instead.  VSLAM_MALLOC_TUNE=0 leaves malloc alone.
+        static std::once_flag once;
+        std::call_once(once, [] {
+            const char* e = getenv("VSLAM_MALLOC_TUNE");
+            if (e && atoi(e) == 0) return;
+            mallopt(M_MMAP_THRESHOLD, 64 << 20);
+            mallopt(M_TRIM_THRESHOLD, 512 << 20);
+            mallopt(M_TOP_PAD, 64 << 20);
+        });
+    }
     VS_HIP(vslam::create_main_stream(&stream));
     timer.stream = stream; timer.multi = true;
     VS_HIP(vslam::create_main_stream(&imuStream));
@@ -253,6 +273,9 @@ void vslam_batch::release() {
                 p.descN.load(), avg(p.postNs, p.postN), p.postN.load());
         fprintf(stderr, "  mapping passes: %.1f us x %lld (find new points %.1f, vslam_local_ba %.1f) | frames that waited for their mapper: %.1f us x %lld\n",
                 avg(p.mapNs, p.mapN), p.mapN.load(), avg(p.npNs, p.npN), avg(p.baNs, p.baN), avg(p.waitNs, p.waitN), p.waitN.load());
+        fprintf(stderr, "  sections (total ms): KF new_keyframe %.1f | observations %.1f | stereo refill %.1f | descriptor request %.1f | key slot %.1f | connections %.1f | "
+                        "keys from block %.1f || ba_collect %.1f | np_commit_a %.1f | ba_commit_a %.1f | np_collect %.1f\n", 1e-6 * p.sec[0], 1e-6 * p.sec[1], 1e-6 * p.sec[2],
+                1e-6 * p.sec[3], 1e-6 * p.sec[4], 1e-6 * p.sec[5], 1e-6 * p.sec[6], 1e-6 * p.sec[7], 1e-6 * p.sec[8], 1e-6 * p.sec[9], 1e-6 * p.sec[10]);
         vslam::ba_host_profile_print();
         fprintf(stderr, "  local-BA cohorts: %.1f us per cohort x %lld cohorts (above 15 ms: %lld, longest %.1f ms)\n",
                 avg(p.mqNs, p.mqN), p.mqN.load(), p.mapLate.load(), 1e-6 * (double)p.mapMaxNs.load());
@@ -354,7 +377,9 @@ vslam_status vslam_batch::ensure_dn(size_t bytes) {
     if (h_dn) hipHostFree(h_dn);
     hipFree(d_dn);
     dnCap = bytes + bytes / 2;
-    VS_HIP(hipHostMalloc((void**)&h_dn, dnCap, hipHostMallocDefault));
+    // (download block: written by the copy engine, READ by the host phases - keyframe key blocks of 200 KB each: cacheable host memory;
+    //  the default coherent kind read at < 0.5 GB/s here)
+    VS_HIP(hipHostMalloc((void**)&h_dn, dnCap, hipHostMallocNonCoherent));
     VS_HIP(hipMalloc((void**)&d_dn, dnCap));
     return VSLAM_OK;
 }
@@ -432,7 +457,6 @@ vslam_status vslam_batch::step(const uint8_t* const* L, const uint8_t* const* R,
         LANE_TRY(s->frame_begin_b(s->ctx));
         if (!q.first) q.N = s->frame_candidates(s->ctx);
     });
-    kick();                                        // the local BAs handed over in this phase: one cohort
     VS_CHECK(first_error());
     sub(2, ts);
     lap(0);
@@ -620,6 +644,15 @@ vslam_status vslam_batch::step(const uint8_t* const* L, const uint8_t* const* R,
     }
     VS_HIP(hipGetLastError());
     lap(3);
+    // ---- host, under the step's kernels: the local BAs' window collection + hand-over (reads the map as frame_begin left it) ----
+    pool.run(B, [&](int b) {
+        LaneStep& q = ls[b];
+        if (!q.on || !sys[b]->pass.collectDue) return;
+        hipSetDevice(device);
+        LANE_TRY(sys[b]->frame_mid());
+    });
+    kick();                                        // the local BAs handed over: one cohort
+    VS_CHECK(first_error());
     VS_HIP(hipStreamSynchronize(stream));
     lap(4);
     // ---- prefetch: the next frames' extraction runs under this step's host phases and the next step's begin ----------------

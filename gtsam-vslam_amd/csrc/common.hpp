@@ -83,6 +83,27 @@ __device__ __forceinline__ const T* lane_entry(const T* table, unsigned i) {
 // tool library may already have finalised the runtime; the process's device memory is reclaimed by the driver anyway.
 inline bool exiting_main_thread() { return (long)getpid() == (long)syscall(SYS_gettid); }
 
+// hipStreamSynchronize spins on a core until the stream drains.  The threads that wait for milliseconds (the mapping engine's
+// polls of the LM control blocks, the keyframe-rate round trips of the host-phase pool) wait on a BLOCKING event instead: with
+// two lockstep groups a dozen spinning waiters would take more cores than the box has, and the host phases are what bounds a step.
+inline hipError_t stream_wait_blocking(hipStream_t s) {
+    static const bool spin = []() { const char* e = getenv("VSLAM_SPIN_WAIT"); return e && atoi(e) != 0; }();
+    if (spin) return hipStreamSynchronize(s);
+    static thread_local hipEvent_t ev = nullptr;
+    static thread_local int evDev = -1;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!ev || evDev != dev) {
+        ev = nullptr;         // (an event of another device's context is left to that context)
+        hipError_t e = hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming);
+        if (e != hipSuccess) { ev = nullptr; return hipStreamSynchronize(s); }
+        evDev = dev;
+    }
+    hipError_t e = hipEventRecord(ev, s);
+    if (e != hipSuccess) return e;
+    return hipEventSynchronize(ev);
+}
+
 struct DevPool {
     struct Blk { void* p; size_t cap; bool used; };
     std::vector<Blk> blks;
@@ -130,7 +151,7 @@ struct DevPool {
         return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream);
     }
     hipError_t sync() {
-        const hipError_t e = hipStreamSynchronize(stream);
+        const hipError_t e = hipStreamSynchronize(stream);      // (short round trips: spinning is the lower latency)
         for (const Pending& p : pending) memcpy(p.dst, p.src, p.bytes);
         pending.clear();
         pinOff = 0;

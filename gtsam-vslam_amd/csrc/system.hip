@@ -230,9 +230,10 @@ vslam_status vslam_system::upload_kf_keys(SysKF& kf) {
 
 static void new_keyframe(SysKF& kf, int numb, int frame, const M4& pose, const M4& refPose, SysKeys& keys) {
     kf.numb = numb; kf.frameIdx = frame; kf.refPose = refPose; kf.setPose(pose);
-    kf.keys = keys;                                       // TrackedKeys::getKeys deep copy
-    kf.unF.assign(keys.kL.size(), -1); kf.unFR.assign(keys.kR.size(), -1);
-    kf.lmpL.assign(keys.kL.size(), -1); kf.lmpR.assign(keys.kR.size(), -1);
+    kf.keys = std::move(keys);                            // TrackedKeys::getKeys (the frame's copy is the caller's last use: moved)
+    keys = SysKeys{};
+    kf.unF.assign(kf.keys.kL.size(), -1); kf.unFR.assign(kf.keys.kR.size(), -1);
+    kf.lmpL.assign(kf.keys.kL.size(), -1); kf.lmpR.assign(kf.keys.kR.size(), -1);
 }
 
 // initializeMap (src/FeatureTracker.cpp:72-123)
@@ -242,17 +243,17 @@ vslam_status vslam_system::initialize_map(const SysKeys& keysIn, int frame) {
     SysKF& kf = keyFrames.back();
     const int numb = (int)keyFrames.size() - 1;
     new_keyframe(kf, numb, frame, camPose, m4_identity(), keys);
+    const SysKeys& K = kf.keys;
     kf.fixed = true;
     std::vector<int> need;
     int tracked = 0;
-    for (int i = 0; i < (int)keys.kL.size(); i++) {
-        if (!(keys.depth[i] > 0)) continue;
-        const int r = keys.rightIdxs[i];
-        mapPoints.emplace_back();
-        const int mi = (int)mapPoints.size() - 1;
+    for (int i = 0; i < (int)K.kL.size(); i++) {
+        if (!(K.depth[i] > 0)) continue;
+        const int r = K.rightIdxs[i];
+        const int mi = new_map_point();
         SysMP& mp = mapPoints.back();
-        backproject(keys, i, camPose, mp.wp);
-        memcpy(mp.desc, keys.dL.data() + (size_t)i * 32, 32);
+        backproject(K, i, camPose, mp.wp);
+        memcpy(mp.desc, K.dL.data() + (size_t)i * 32, 32);
         mp.kdx = numb; mp.idx = mi;
         mp.kfm.push_back({numb, i, r});
         mp_update(mp, numb, need, mi);
@@ -288,11 +289,14 @@ void vslam_system::calc_connections(SysKF& kf) {
 vslam_status vslam_system::insert_keyframe(SysKeys& keys, const std::vector<int>& matchedL, const std::vector<int>& matches,
                                            int nStereo, const M4& estimPose, const std::vector<uint8_t>& outl, const std::vector<int>& act, int frame,
                                            void* filledKeySlot) {
+    SysSec sec;
     const M4 refPose = m4_mul(keyFrames[latestKF].poseInv, estimPose);
     keyFrames.emplace_back();
     SysKF& kf = keyFrames.back();
     const int numb = (int)keyFrames.size() - 1;
     new_keyframe(kf, numb, frame, estimPose, refPose, keys);
+    sec.mark(0);
+    const SysKeys& K = kf.keys;
     kf.prevKF = latestKF; keyFrames[latestKF].nextKF = numb;
     std::vector<int> need;
     int tracked = 0;
@@ -306,20 +310,20 @@ vslam_status vslam_system::insert_keyframe(SysKeys& keys, const std::vector<int>
         if (r >= 0) { kf.lmpR[r] = act[i]; kf.unFR[r] = (int)mp.kdx; }
         tracked++;
     }
+    sec.mark(1);
     if (nStereo < 80) {                                   // minNStereo: refill with the frame's own stereo points, nearest first
         std::vector<std::pair<float, int>> allDepths;
-        for (int i = 0; i < (int)keys.kL.size(); i++) if (keys.depth[i] > 0 && matchedL[i] < 0) allDepths.push_back({keys.depth[i], i});
+        for (int i = 0; i < (int)K.kL.size(); i++) if (K.depth[i] > 0 && matchedL[i] < 0) allDepths.push_back({K.depth[i], i});
         std::sort(allDepths.begin(), allDepths.end());
         int count = 0;
         for (const auto& d : allDepths) {
-            const int lIdx = d.second, rIdx = keys.rightIdxs[lIdx];
-            if (count >= 100 && !keys.close[lIdx]) break;   // maxAddedStereo
+            const int lIdx = d.second, rIdx = K.rightIdxs[lIdx];
+            if (count >= 100 && !K.close[lIdx]) break;   // maxAddedStereo
             count++;
-            mapPoints.emplace_back();
-            const int mi = (int)mapPoints.size() - 1;
+            const int mi = new_map_point();
             SysMP& mp = mapPoints.back();
-            backproject(keys, lIdx, estimPose, mp.wp);
-            memcpy(mp.desc, keys.dL.data() + (size_t)lIdx * 32, 32);
+            backproject(K, lIdx, estimPose, mp.wp);
+            memcpy(mp.desc, K.dL.data() + (size_t)lIdx * 32, 32);
             mp.kdx = numb; mp.idx = mi;
             mp.kfm.push_back({numb, lIdx, rIdx});
             mp_update(mp, numb, need, mi);
@@ -329,12 +333,16 @@ vslam_status vslam_system::insert_keyframe(SysKeys& keys, const std::vector<int>
             tracked++;
         }
     }
+    sec.mark(2);
     VS_CHECK(calc_descriptors(need));
+    sec.mark(3);
     if (cfg.local_mapping) {
         if (filledKeySlot) adopt_key_slot(keyFrames[numb], filledKeySlot);      // (the step's pack kernel wrote the block there)
         else VS_CHECK(upload_kf_keys(keyFrames[numb]));
     }
+    sec.mark(4);
     calc_connections(keyFrames[numb]);
+    sec.mark(5);
     lastKFTrackedNumb = tracked; kf.nKeysTracked = tracked;
     precCheckMatches = tracked > 350 ? 0.7f : 0.9f;
     latestKF = numb;
@@ -363,7 +371,7 @@ vslam_status vslam_system::kf_update_pose(SysKF& kf, const M4& keyPose) {
     std::vector<uint8_t> ol(std::max<size_t>(lms.size(), 1));
     for (size_t j = 0; j < lms.size(); j++) {
         const SysMP& m = mapPoints[lms[j]];
-        xyz[3 * j] = m.wp[0]; xyz[3 * j + 1] = m.wp[1]; xyz[3 * j + 2] = m.wp[2]; kdx[j] = m.kdx; ol[j] = m.isOutlier;
+        xyz[3 * j] = m.wp[0]; xyz[3 * j + 1] = m.wp[1]; xyz[3 * j + 2] = m.wp[2]; kdx[j] = m.kdx; ol[j] = mpOutlier[lms[j]];
     }
     vslam_kf_update_problem P{};
     P.rig = cfg.rig; P.n_levels = nLev; P.inv_sigma_factor = invSigmaF.data(); P.numb = kf.numb;
@@ -457,7 +465,7 @@ int vslam_system::frame_candidates(SysFrameCtx& c) {
     std::lock_guard<std::mutex> lk(mapMutex);
     c.cand.clear();
     c.cand.reserve(active.size());
-    for (int m : active) if (!mapPoints[m].isOutlier) c.cand.push_back(m);
+    for (int m : active) if (!mpOutlier[m]) c.cand.push_back(m);
     c.N = (int)c.cand.size();
     return c.N;
 }
@@ -513,8 +521,8 @@ vslam_status vslam_system::frame_post_a(SysFrameCtx& c, const SysTrackState& st)
         std::lock_guard<std::mutex> lk(mapMutex);
         // host side of removeOutOfFrameMPs / PredictMPsPosition: MapPoint::inFrame, the compacted active list (nothing is
         // appended to activeMapPoints while a frame is on the device: the mapper's points arrive in frame_begin)
-        for (int j = 0; j < N; j++) mapPoints[cand[j]].inFrame = visL[j] != 0;
-        for (int i = 0; i < M; i++) { act[i] = cand[actIdx[i]]; mapPoints[act[i]].inFrame = inF[i] != 0; }
+        for (int j = 0; j < N; j++) mpInFrame[cand[j]] = visL[j] != 0;
+        for (int i = 0; i < M; i++) { act[i] = cand[actIdx[i]]; mpInFrame[act[i]] = inF[i] != 0; }
         active = act;
         // keyframe rule (:1260-1270)
         insertKeyFrameCount++;
@@ -523,8 +531,10 @@ vslam_status vslam_system::frame_post_a(SysFrameCtx& c, const SysTrackState& st)
             SysProfScope ps(sys_prof().kfNs, sys_prof().kfN);
             insertKeyFrameCount = 0;
             SysKeys keys;
+            SysSec sk;
             if (st.keys) keys_from_block(st.keys, nL, st.nR, keys);
             else VS_CHECK(fetch_keys(keys));
+            sk.mark(6);
             VS_CHECK(insert_keyframe(keys, matchedL, matches, tr.n_stereo, poseEst, outl, act, frame, st.keys ? st.keySlot : nullptr));
         } else {                                           // addFrame (:871-882)
             allFrames.push_back({false, -1, latestKF, m4_mul(keyFrames[latestKF].poseInv, poseEst)});
@@ -541,7 +551,7 @@ vslam_status vslam_system::frame_post_a(SysFrameCtx& c, const SysTrackState& st)
             SysMP& mp = mapPoints[act[i]];
             if ((matches[2 * i] >= 0 || matches[2 * i + 1] >= 0) && !outl[i]) mp.unMCnt = 0; else mp.unMCnt++;
             if (!outl[i] && mp.unMCnt < 20) continue;
-            mp.isOutlier = true;
+            mpOutlier[act[i]] = 1;
         }
         if (cfg.use_imu) {
             for (int k = 0; k < 3; k++) velocity[k] = c.imuOut.velocity[k];       // mVelocity = mNewVelocity (:1277)
@@ -585,6 +595,7 @@ vslam_status vslam_system::track(const uint8_t* L, const uint8_t* R, int stride,
     if (!L || !R || !T_wc_out) return VSLAM_ERR_INVALID;
     SysFrameCtx& c = ctx;
     VS_CHECK(frame_begin(c, frame, imu));
+    VS_CHECK(frame_mid());
     // images -> pyramid level 0, extraction, stereo match (extractORBAndStereoMatch :56-70); nothing here depends on the map
     if (onDevice) { VS_CHECK(vslam_extractor_set_image_device(fe, img0, L, stride)); VS_CHECK(vslam_extractor_set_image_device(fe, img0 + 1, R, stride)); }
     else { VS_CHECK(vslam_extractor_set_image_host(fe, img0, L, stride)); VS_CHECK(vslam_extractor_set_image_host(fe, img0 + 1, R, stride)); }
@@ -709,6 +720,7 @@ vslam_status vslam_system::mapping_post(int frame) {
     mapping_window(pass.actKeyF);
     pass.handFrame = frame;
     pass.commitFrame = frame + std::max(cfg.mapping_delay, 1);
+    pass.npFrame = frame + std::max(1, std::min(cfg.mapping_np_delay, std::max(cfg.mapping_delay, 1)));
     np_collect(pass);
     VS_CHECK(submit_job(MapPass::NEW_POINTS));
     if (cfg.local_mapping == 1) {                          // the whole pass now (its device calls right away)
@@ -734,7 +746,8 @@ vslam_status vslam_system::mapping_begin_a(int frame) {
     pass.beginWork = 0;
     if (cfg.local_mapping != 2) return VSLAM_OK;
     { std::lock_guard<std::mutex> lk(wMu); if (workerStatus != VSLAM_OK) { set_error("local mapping thread failed: %s", workerError); return workerStatus; } }
-    if (pass.stage == MapPass::NEW_POINTS) {               // the first frame after the hand-over
+    if (pass.collectDue) VS_CHECK(frame_mid_locked());     // (a caller that skipped frame_mid)
+    if (pass.stage == MapPass::NEW_POINTS && frame >= pass.npFrame) {      // mapping_np_delay frames after the hand-over
         VS_CHECK(wait_job());
         SysProfScope pm(sys_prof().mapNs, sys_prof().mapN);
         VS_CHECK(np_commit_a(pass));
@@ -754,9 +767,10 @@ vslam_status vslam_system::mapping_begin_b(int frame) {
     if (pass.beginWork == 1) {
         SysProfScope pm(sys_prof().mapNs, sys_prof().mapN);
         np_commit_b(pass);
-        ba_collect(pass);
-        VS_CHECK(submit_job(MapPass::LOCAL_BA));
-        if (frame >= pass.commitFrame) {                   // mapping_delay = 1: the write-back is due in this very frame
+        pass.stage = MapPass::LOCAL_BA;                    // (collection + hand-over: frame_mid, or right here when the write-back is due now)
+        pass.collectDue = true;
+        if (frame >= pass.commitFrame) {                   // mapping_delay = mapping_np_delay: the write-back is due in this very frame
+            VS_CHECK(frame_mid_locked());
             VS_CHECK(wait_job());
             const bool df = deferDevice;
             deferDevice = false;
@@ -774,10 +788,26 @@ vslam_status vslam_system::mapping_begin_b(int frame) {
     return VSLAM_OK;
 }
 
+// localBA's window collection (:438-745) reads the map as it is when frame f + a begins; nothing changes that state until
+// frame_post of the same frame, so it may run while the frame's kernels are on the device
+vslam_status vslam_system::frame_mid() {
+    if (!pass.collectDue) return VSLAM_OK;
+    std::lock_guard<std::mutex> lk(mapMutex);
+    return frame_mid_locked();
+}
+vslam_status vslam_system::frame_mid_locked() {
+    if (!pass.collectDue) return VSLAM_OK;
+    pass.collectDue = false;
+    SysProfScope pm(sys_prof().mapNs, sys_prof().mapN);
+    ba_collect(pass);
+    return submit_job(MapPass::LOCAL_BA);
+}
+
 // findNewPoints (src/OptimizationBA.cpp:340-391), read side: the window keyframes' arrays are read IN PLACE by the job (a
 // keyframe's records never move - deque - and nothing writes them while the job is in flight: unMatchedF / localMapPoints of
 // window keyframes change only in np_commit / ba_commit, depth / close only in ba_commit); map-point values are copied.
 void vslam_system::np_collect(MapPass& p) {
+    SysProfScope pc(sys_prof().sec[10], sys_prof().sec[15]);
     NpJob& J = p.np;
     const std::vector<int>& actKeyF = p.actKeyF;
     const int nk = J.nk = (int)actKeyF.size();
@@ -817,6 +847,7 @@ void vslam_system::np_collect(MapPass& p) {
 
 // addMultiViewMapPointsR + addNewMapPoints (src/OptimizationBA.cpp:90-125, 211-232) from the job's result
 vslam_status vslam_system::np_commit_a(MapPass& p) {
+    SysProfScope pc(sys_prof().sec[8], sys_prof().sec[15]);
     NpJob& J = p.np;
     const std::vector<int>& actKeyF = p.actKeyF;
     const int nk = J.nk, nc = J.R.n_candidates;
@@ -835,8 +866,7 @@ vslam_status vslam_system::np_commit_a(MapPass& p) {
             if (actKeyF[o[0]] == lastNumb) { dl = o[1]; dr = o[2]; found = true; }
         }
         if (!found || (dl < 0 && dr < 0)) continue;
-        mapPoints.emplace_back();
-        const int mi = (int)mapPoints.size() - 1;
+        const int mi = new_map_point();
         SysMP& mp = mapPoints.back();
         for (int q = 0; q < 3; q++) mp.wp[q] = J.xyz[3 * (size_t)c + q];
         const SysKeys& lk0 = keyFrames[lastNumb].keys;
@@ -868,6 +898,7 @@ void vslam_system::np_commit_b(MapPass& p) {
 
 // LocalMapper::localBA: window collection (:438-516) and graph membership (:556-745) into the job's problem
 void vslam_system::ba_collect(MapPass& p) {
+    SysProfScope pc(sys_prof().sec[7], sys_prof().sec[15]);
     BaJob& J = p.ba;
     const std::vector<int>& actKeyF = p.actKeyF;
     J.kfs.clear(); J.allMps.clear(); J.pk.clear(); J.pl.clear(); J.poct.clear(); J.pf.clear(); J.puv.clear(); J.pobj.clear();
@@ -886,14 +917,14 @@ void vslam_system::ba_collect(MapPass& p) {
             for (int m : lst) {
                 if (m < 0) continue;
                 SysMP& mp = mapPoints[m];
-                if (mp.isOutlier || mp.LBAID == lastActKF) continue;
+                if (mpOutlier[m] || mpLBAID[m] == lastActKF) continue;
                 for (const KfMatch& o : mp.kfm) {
                     if (side && (o.l >= 0 || o.r < 0)) continue;
                     SysKF& c = keyFrames[o.kf];
                     if (c.numb > lastActKF || c.LBAID == lastActKF) continue;
                     if (!isLocal[o.kf]) { fixedKFs.push_back(o.kf); c.LBAID = lastActKF; }
                 }
-                J.allMps.push_back(m); mp.LBAID = lastActKF;
+                J.allMps.push_back(m); mpLBAID[m] = lastActKF;
             }
         }
     }
@@ -908,8 +939,8 @@ void vslam_system::ba_collect(MapPass& p) {
         const SysMP& mp = mapPoints[allMps[m]];
         bool out = true;
         for (const KfMatch& o : mp.kfm) {
-            if (!mp.inFrame && (int)mp.kfm.size() < 3) { J.mpOut[m] = 1; break; }
-            if (mp.isOutlier) break;
+            if (!mpInFrame[allMps[m]] && (int)mp.kfm.size() < 3) { J.mpOut[m] = 1; break; }
+            if (mpOutlier[allMps[m]]) break;
             out = false;
             const SysKF& c = keyFrames[o.kf];
             if (c.numb > lastActKF || J.kfIndex[o.kf] < 0) continue;
@@ -975,6 +1006,7 @@ vslam_status vslam_system::ba_device(MapPass& p) {
 // second-graph flags (:566-575) and the write-back (:875-938) on the map AS IT IS NOW (keyframes / observations the tracker
 // added since the collection count as "later" ones)
 vslam_status vslam_system::ba_commit_a(MapPass& p) {
+    SysProfScope pc(sys_prof().sec[9], sys_prof().sec[15]);
     BaJob& J = p.ba;
     const std::vector<int>& kfs = J.kfs;
     const std::vector<int>& allMps = J.allMps;
@@ -1011,7 +1043,7 @@ vslam_status vslam_system::ba_commit_a(MapPass& p) {
     int nOut = 0;
     for (size_t m = 0; m < allMps.size(); m++) {
         SysMP& mp = mapPoints[allMps[m]];
-        if (J.mpOut[m] || (!mp.inFrame && (int)mp.kfm.size() < 3)) { mp.isOutlier = true; nOut++; }
+        if (J.mpOut[m] || (!mpInFrame[allMps[m]] && (int)mp.kfm.size() < 3)) { mpOutlier[allMps[m]] = 1; nOut++; }
         else if (presentLm[m]) { for (int c = 0; c < 3; c++) mp.wp[c] = J.lmOut[3 * m + c]; upd.push_back(allMps[m]); }
     }
     p.nWrong = nWrong; p.nOut = nOut;

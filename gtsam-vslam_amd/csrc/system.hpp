@@ -68,9 +68,8 @@ struct SysMP {                         // MapPoint (include/Map.h:22-98)
     std::vector<KfMatch> kfm;          // insertion ordered
     float maxScaleDist = 0, minScaleDist = 0;
     int unMCnt = 0;
-    bool isOutlier = false, inFrame = true;
     long long kdx = 0, idx = 0;
-    int lastObsKF = -1, LBAID = -1;
+    int lastObsKF = -1;
     int find(int kf) const { for (size_t i = 0; i < kfm.size(); i++) if (kfm[i].kf == kf) return (int)i; return -1; }
 };
 
@@ -104,8 +103,14 @@ struct SysTrackState {
 
 // VSLAM_BATCH_PHASES diagnostics: where the per-lane host phases spend their time (nanoseconds / calls, process-wide)
 struct SysProf { std::atomic<long long> lcaNs{0}, lcaN{0}, kfNs{0}, kfN{0}, descNs{0}, descN{0}, postNs{0}, postN{0}, mapNs{0}, mapN{0}, npNs{0}, npN{0}, baNs{0}, baN{0}, waitNs{0}, waitN{0},
-                                            mqNs{0}, mqN{0}, mqLate{0}, mqMaxNs{0}, mapLate{0}, mapMaxNs{0}; };      // mapping queue delay / long passes
+                                            mqNs{0}, mqN{0}, mqLate{0}, mqMaxNs{0}, mapLate{0}, mapMaxNs{0};
+                 std::atomic<long long> sec[16] = {};      // fine sections (nanoseconds), printed with the phases
+};      // mapping queue delay / long passes
 SysProf& sys_prof();
+struct SysSec {      // accumulates the time since the previous mark into section k
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void mark(int k) { const auto n = std::chrono::steady_clock::now(); sys_prof().sec[k] += std::chrono::duration_cast<std::chrono::nanoseconds>(n - t).count(); t = n; }
+};
 struct SysProfScope {
     std::atomic<long long>& ns; std::atomic<long long>& n; std::chrono::steady_clock::time_point t0;
     SysProfScope(std::atomic<long long>& a, std::atomic<long long>& b) : ns(a), n(b), t0(std::chrono::steady_clock::now()) {}
@@ -155,7 +160,7 @@ struct RefreshReq {                   // MapPoint::updatePos depth / close refre
 struct MapPass {
     enum { IDLE = 0, NEW_POINTS = 1, LOCAL_BA = 2 };
     int stage = IDLE;                 // which job is in flight / was last submitted
-    int handFrame = 0, commitFrame = 0;
+    int handFrame = 0, npFrame = 0, commitFrame = 0;      // hand-over; new points written before npFrame; write-back before commitFrame
     int newPoints = 0;
     std::vector<int> actKeyF;         // lastKF + its best covisible keyframes (KeyFrame::getConnectedKFs)
     NpJob np; BaJob ba;
@@ -163,6 +168,7 @@ struct MapPass {
     std::vector<int> created, upd;
     int nWrong = 0, nOut = 0;
     int beginWork = 0;                // what frame_begin_a did: 1 new points committed, 2 local BA committed
+    bool collectDue = false;          // the local BA's window collection + hand-over is still to do (frame_mid)
 };
 
 }  // namespace vslam_sys
@@ -182,6 +188,11 @@ struct vslam_system {
     int lastKFTrackedNumb = 0, insertKeyFrameCount = 0;
     std::deque<SysKF> keyFrames;       // map->keyFrames (kIdx = size)
     std::deque<SysMP> mapPoints;       // map->mapPoints (pIdx = size)
+    // the map points' HOT flags as compact arrays beside the records (MapPoint::isOutlier / inFrame, the LBAID stamp): the window
+    // collection of a local BA tests ~30 000 (keyframe, keypoint) entries against them - 5 bytes per point instead of a 120-byte
+    // record per test keeps that walk in the L1 / L2
+    std::vector<uint8_t> mpOutlier, mpInFrame; std::vector<int> mpLBAID;
+    int new_map_point() { mapPoints.emplace_back(); mpOutlier.push_back(0); mpInFrame.push_back(1); mpLBAID.push_back(-1); return (int)mapPoints.size() - 1; }
     std::vector<int> active;           // map->activeMapPoints
     std::vector<SysFrame> allFrames;
     std::atomic<bool> keyFrameAdded{false}, LBADone{false};     // Map::keyFrameAdded / LBADone (plain bools in the reference)
@@ -225,6 +236,9 @@ struct vslam_system {
     vslam_status frame_begin(SysFrameCtx& c, int frame, const vslam_imu_bucket* imu);      // = _a, the deferred device calls, _b
     vslam_status frame_begin_a(SysFrameCtx& c, int frame, const vslam_imu_bucket* imu);
     vslam_status frame_begin_b(SysFrameCtx& c);
+    vslam_status frame_mid_locked();
+    vslam_status frame_mid();          // host work that only has to precede frame_post: the local BA's window collection + hand-over (a
+                                       // lockstep group runs it while the step's kernels are on the device)
     vslam_status run_deferred();       // serves this session's pending requests (single-session path)
     void apply_deferred();
     vslam_status upload_kf_keys(SysKF& kf);

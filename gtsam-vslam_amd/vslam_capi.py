@@ -745,7 +745,7 @@ class SystemConfig(C.Structure):
                 ("window", C.c_int32), ("T_wc_init", C.c_double * 16), ("gravity", C.c_double * 3),
                 ("gyro_noise_density", C.c_double), ("gyro_random_walk", C.c_double), ("accel_noise_density", C.c_double),
                 ("accel_random_walk", C.c_double), ("T_body_sensor", C.c_double * 16), ("imu_hz", C.c_int32),
-                ("velocity_init", C.c_double * 3), ("mapping_delay", C.c_int32)]
+                ("velocity_init", C.c_double * 3), ("mapping_delay", C.c_int32), ("mapping_np_delay", C.c_int32)]
 
 
 class ImuBucket(C.Structure):
@@ -762,12 +762,13 @@ class FrameReport(C.Structure):
 class System:
     """vslam_system: one stereo (+ IMU) session with its map, tracker and local mapper."""
 
-    def __init__(self, rig, nfeatures, T0=None, imu=None, local_mapping=1, window=10, device=0, nlevels=8, scale=1.2, mapping_delay=0):
+    def __init__(self, rig, nfeatures, T0=None, imu=None, local_mapping=1, window=10, device=0, nlevels=8, scale=1.2, mapping_delay=0,
+                 mapping_np_delay=0):
         self.L = lib()
         cfg = SystemConfig()
         cfg.fe = FeParams(nfeatures, nlevels, scale, 19, 31, 20, 7)
         cfg.rig = make_rig(rig)
-        cfg.device = device; cfg.local_mapping = local_mapping; cfg.window = window; cfg.mapping_delay = mapping_delay
+        cfg.device = device; cfg.local_mapping = local_mapping; cfg.window = window; cfg.mapping_delay = mapping_delay; cfg.mapping_np_delay = mapping_np_delay
         if T0 is not None:
             cfg.T_wc_init = (C.c_double * 16)(*np.asarray(T0, np.float64).reshape(16))
         if imu is not None:     # dict(gravity, noise=(gyro density, gyro walk, acc density, acc walk), T_bs, hz)
@@ -979,7 +980,7 @@ class Batch:
     """vslam_batch: `lanes` sessions tracked in lockstep.  T0s: per-lane initial poses (or None), velocities: per-lane (IMU)."""
 
     def __init__(self, rig, nfeatures, lanes, T0s=None, imu=None, velocities=None, local_mapping=1, window=10, device=0,
-                 host_threads=-1, mapping_threads=0, mapping_delay=0):
+                 host_threads=-1, mapping_threads=0, mapping_delay=0, mapping_np_delay=0):
         self.L = lib()
         self.L.vslam_batch_system.restype = C.c_void_p
         self.lanes = lanes
@@ -990,7 +991,8 @@ class Batch:
                 im = dict(imu)
                 if velocities is not None:
                     im["velocity"] = velocities[b]
-            c = system_config(rig, nfeatures, imu=im, local_mapping=local_mapping, window=window, device=device, mapping_delay=mapping_delay)
+            c = system_config(rig, nfeatures, imu=im, local_mapping=local_mapping, window=window, device=device, mapping_delay=mapping_delay,
+                              mapping_np_delay=mapping_np_delay)
             if T0s is not None and T0s[b] is not None:
                 c.T_wc_init = (C.c_double * 16)(*np.asarray(T0s[b], np.float64).reshape(16))
             cfgs[b] = c
@@ -1076,9 +1078,9 @@ class FleetReport(C.Structure):
                 ("max_position_error", C.c_double), ("sum_sq_position_error", C.c_double)]
 
 
-def system_config(rig, nfeatures, imu=None, local_mapping=2, window=10, device=0, nlevels=8, scale=1.2, mapping_delay=0):
+def system_config(rig, nfeatures, imu=None, local_mapping=2, window=10, device=0, nlevels=8, scale=1.2, mapping_delay=0, mapping_np_delay=0):
     cfg = SystemConfig()
-    cfg.mapping_delay = mapping_delay
+    cfg.mapping_delay = mapping_delay; cfg.mapping_np_delay = mapping_np_delay
     cfg.fe = FeParams(nfeatures, nlevels, scale, 19, 31, 20, 7)
     cfg.rig = make_rig(rig)
     cfg.device = device; cfg.local_mapping = local_mapping; cfg.window = window

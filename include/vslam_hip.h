@@ -601,6 +601,9 @@ typedef struct vslam_system_config {
                                      the new-point search and at frame f + k for the local BA if they have not finished; a pass
                                      that finishes early is held back until then.  At the reference's camera rate a pass ends
                                      within a frame or two, i.e. k = 1..2. */
+    int32_t mapping_np_delay;     /* local_mapping = 2 only: a of the schedule (0 = 1, at most mapping_delay): findNewPoints reads the map
+                                     right after frame f, its points are written (addNewMapPoints) before frame f + a is tracked, and
+                                     localBA collects its window at that moment. */
 } vslam_system_config;
 
 /* the IMU samples between the previous frame and this one (IMUData filled in src/VIOSlam.cpp:238-272) */

@@ -27,6 +27,9 @@ Two reproducible schedules of that hand-over are restated here:
                       f + 1 .. f + k - 1 are tracked against the map with the new points but without the BA's result -
                       exactly what the tracking thread sees while the optimizer thread is still inside LevenbergMarquardt.
                       The pass is reported with frame f + k.
+  mapping_np_delay = a  (1 <= a <= k, default 1) findNewPoints READS the map right after frame f (its matching and triangulation
+                      take the optimizer thread until then) and its points are written before frame f + a is tracked; localBA collects
+                      at that moment.
 
 Where the reference iterates an unordered_map keyed by pointers (kFMatches, allMapPoints, localKFs; ties of
 calcConnections' sort on (weight, KeyFrame*)) the order is pointer-hash dependent and not reproducible even between two
@@ -102,7 +105,7 @@ class KeyFrame:
 class System:
     """FeatureTracker + LocalMapper + Map of one stereo (or stereo + IMU) session."""
 
-    def __init__(self, rig, nfeat, T0=None, imu=None, window=10, local_mapping=True, mapping_delay=0, threads=False):
+    def __init__(self, rig, nfeat, T0=None, imu=None, window=10, local_mapping=True, mapping_delay=0, threads=False, mapping_np_delay=1):
         self.rig = rig
         self.exL, self.exR = po.Extractor(nfeat), po.Extractor(nfeat)
         self.scale = self.exL.scalePyramid; self.sigma = self.exL.sigmaFactor; self.invSigma = self.exL.InvSigmaFactor
@@ -122,6 +125,7 @@ class System:
         self.keyFrameAdded = False; self.LBADone = False; self.endLBAIdx = 0
         self.window = window; self.local_mapping_enabled = local_mapping
         self.mapping_delay = int(mapping_delay); self.pending = None; self._mapping_report = None
+        self.mapping_np_delay = max(1, min(int(mapping_np_delay), max(self.mapping_delay, 1)))
         # threads = True: the reference's threading (src/FeatureTracker.cpp:58-61 left || right extraction threads,
         # src/System.cpp:18-19 optimizer thread: the local BA's numerical core runs beside tracking until its write-back is
         # due; needs mapping_delay >= 1).  Same results as threads = False; used by bench.py's CPU baseline only.
@@ -220,7 +224,12 @@ class System:
     # ---- TrackImage --------------------------------------------------------------------------------------------
     def track(self, L, R, frame_number, imu_bucket=None):
         rig = self.rig
-        if self.pending is not None and frame_number >= self.pending["commit"]:
+        if self.pending is not None and self.pending["ctx"] is None and frame_number >= self.pending["np_commit"]:
+            # addNewMapPoints (:211-232) lands here; localBA collects its window and graph at this moment
+            nNew = self.find_new_points_commit(self.pending["actKeyF"], self.pending["np"])
+            self.pending["ctx"] = self.local_ba_solve(self.pending["actKeyF"])
+            self.pending["ctx"]["new_points"] = nNew
+        if self.pending is not None and self.pending["ctx"] is not None and frame_number >= self.pending["commit"]:
             # the optimizer thread's write-back (:875-938) lands here; LBADone is then seen by this very frame
             self._mapping_report = self.local_ba_writeback(self.pending["ctx"])
             self.pending = None
@@ -471,15 +480,19 @@ class System:
                 actKeyF.append(c); count += 1
             if count >= self.window:
                 break
-        nNew = self.find_new_points(actKeyF)
-        ctx = self.local_ba_solve(actKeyF)
-        ctx["new_points"] = nNew
         if self.mapping_delay <= 0:
+            nNew = self.find_new_points(actKeyF)
+            ctx = self.local_ba_solve(actKeyF)
+            ctx["new_points"] = nNew
             self.log[-1]["mapping"] = self.local_ba_writeback(ctx)
         else:
-            self.pending = dict(commit=frame_number + self.mapping_delay, ctx=ctx)
+            self.pending = dict(np=self.find_new_points_solve(actKeyF), actKeyF=actKeyF, ctx=None,
+                                np_commit=frame_number + self.mapping_np_delay, commit=frame_number + self.mapping_delay)
 
     def find_new_points(self, actKeyF):       # :340-391
+        return self.find_new_points_commit(actKeyF, self.find_new_points_solve(actKeyF))
+
+    def find_new_points_solve(self, actKeyF):  # read side: candidates, matching, triangulation, reprojection filter
         lastKF = actKeyF[0]
         kfs = [dict(T_wc=k.pose, id=k.numb, kpsL=k.keys["kpsL"], descL=k.keys["descL"], kpsR=k.keys["kpsR"], descR=k.keys["descR"],
                     rightIdxs=k.keys["rightIdxs"], leftIdxs=k.keys["leftIdxs"], unF=k.unMatchedF, unFR=k.unMatchedFR) for k in actKeyF]
@@ -488,7 +501,10 @@ class System:
         for i, mp in enumerate(lastKF.localMapPoints):
             if mp is not None:
                 has[i] = 1; mpx[i] = mp.wp; mpd[i] = mp.desc
-        res = po.find_new_points(self.exL, self.rig, kfs, dict(depth=lastKF.keys["depth"], hasMp=has, mpXyz=mpx, mpDesc=mpd))
+        return po.find_new_points(self.exL, self.rig, kfs, dict(depth=lastKF.keys["depth"], hasMp=has, mpXyz=mpx, mpDesc=mpd))
+
+    def find_new_points_commit(self, actKeyF, res):   # addMultiViewMapPointsR + addNewMapPoints (:90-125, 211-232)
+        lastKF = actKeyF[0]
         if self.mpIdx is None:
             self.mpIdx = len(self.mapPoints)
         new = []

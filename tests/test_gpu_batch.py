@@ -24,10 +24,10 @@ def _bucket(f0, f1, fps):
     return (S[:, :3], S[:, 3:], np.arange(len(dts)) * 5e6)
 
 
-def _single(capi, rig_name, nfeat, frames, use_imu, mapping, delay=0):
+def _single(capi, rig_name, nfeat, frames, use_imu, mapping, delay=0, np_delay=1):
     rig = synth.RIGS[rig_name]
     imu = dict(gravity=G, noise=NOISE, T_bs=synth.T_BC1, hz=200, velocity=_velocity(frames[0], rig["fps"])) if use_imu else None
-    s = capi.System(rig, nfeat, T0=synth.pose_at(frames[0], rig["fps"]), imu=imu, local_mapping=mapping, mapping_delay=delay)
+    s = capi.System(rig, nfeat, T0=synth.pose_at(frames[0], rig["fps"]), imu=imu, local_mapping=mapping, mapping_delay=delay, mapping_np_delay=np_delay)
     out = []
     for n, f in enumerate(frames):
         L, R, _ = synth.stereo_frame(f, rig_name)
@@ -39,14 +39,14 @@ def _single(capi, rig_name, nfeat, frames, use_imu, mapping, delay=0):
     return res
 
 
-def _batched(capi, rig_name, nfeat, schedules, starts, use_imu, mapping, delay=0):
+def _batched(capi, rig_name, nfeat, schedules, starts, use_imu, mapping, delay=0, np_delay=1):
     """schedules[b]: source frames of lane b; starts[b]: the step at which lane b begins"""
     rig = synth.RIGS[rig_name]
     B = len(schedules)
     imu = dict(gravity=G, noise=NOISE, T_bs=synth.T_BC1, hz=200) if use_imu else None
     bt = capi.Batch(rig, nfeat, B, T0s=[synth.pose_at(sc[0], rig["fps"]) for sc in schedules], imu=imu,
                     velocities=[_velocity(sc[0], rig["fps"]) for sc in schedules] if use_imu else None, local_mapping=mapping,
-                    host_threads=3, mapping_delay=delay)
+                    host_threads=3, mapping_delay=delay, mapping_np_delay=np_delay)
     nSteps = max(starts[b] + len(schedules[b]) for b in range(B))
     out = [[] for _ in range(B)]
     for step in range(nSteps):
@@ -91,17 +91,17 @@ def _same(one, lane, tol=1e-9):
     return nKF, nBA
 
 
-@pytest.mark.parametrize("use_imu,mapping,delay", [(False, 1, 0), (True, 1, 0), (False, 2, 3), (True, 2, 4)])
-def test_batch_lanes_equal_single_sessions(capi, use_imu, mapping, delay):
+@pytest.mark.parametrize("use_imu,mapping,delay,np_delay", [(False, 1, 0, 1), (True, 1, 0, 1), (False, 2, 3, 1), (True, 2, 4, 2), (False, 2, 1, 1)])
+def test_batch_lanes_equal_single_sessions(capi, use_imu, mapping, delay, np_delay):
     """mapping 1: the pass inside the step; mapping 2: the lanes' passes run on the batch's mapping engine beside the steps, on
     the fixed schedule (new points at the next frame, write-back `delay` frames after the hand-over) - in both modes a lane
     equals the single session of its sequence."""
     schedules = [list(range(0, 60, 2)), list(range(6, 66, 2)), list(range(12, 64, 2))]
     starts = [0, 0, 3]
-    lanes = _batched(capi, "euroc", 1500, schedules, starts, use_imu, mapping, delay)
+    lanes = _batched(capi, "euroc", 1500, schedules, starts, use_imu, mapping, delay, np_delay)
     tot = [0, 0]
     for b, sc in enumerate(schedules):
-        nKF, nBA = _same(_single(capi, "euroc", 1500, sc, use_imu, mapping, delay), lanes[b])
+        nKF, nBA = _same(_single(capi, "euroc", 1500, sc, use_imu, mapping, delay, np_delay), lanes[b])
         tot[0] += nKF; tot[1] += nBA
     assert tot[0] >= 4 and tot[1] >= 2      # the comparison covered keyframe insertions and local BAs
 
@@ -144,7 +144,7 @@ def test_async_mapping_is_reproducible_and_complete(capi):
     frames = [synth.stereo_frame(2 * i, "euroc") for i in range(n)]
     imgs = [(capi.DeviceImage(f[0]), capi.DeviceImage(f[1])) for f in frames]
     poses = np.stack([f[2] for f in frames])
-    cfg = capi.system_config(rig, 1500, local_mapping=2, mapping_delay=4)
+    cfg = capi.system_config(rig, 1500, local_mapping=2, mapping_delay=4, mapping_np_delay=2)
     res = []
     for lanes in (3, 3, 6):
         fl = capi.Fleet(cfg, 6, [a.ptr for a, _ in imgs], [b.ptr for _, b in imgs], rig["w"], True, poses=poses, lanes=lanes)

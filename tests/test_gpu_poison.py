@@ -45,5 +45,5 @@ def test_closed_loop_and_batch_under_poisoned_allocations(oracle, capi, poison, 
     poison(fill)
     ref, got, out = tsys._run(oracle, capi, "euroc", 1500, list(range(0, 44, 2)), use_imu=True)
     assert tsys._check(ref, got, out) >= 1
-    tb.test_batch_lanes_equal_single_sessions(capi, False, 1, 0)
-    tb.test_batch_lanes_equal_single_sessions(capi, False, 2, 3)
+    tb.test_batch_lanes_equal_single_sessions(capi, False, 1, 0, 1)
+    tb.test_batch_lanes_equal_single_sessions(capi, False, 2, 3, 1)

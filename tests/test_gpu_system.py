@@ -16,7 +16,7 @@ def _imu_setup(oracle):
     return dict(prm=prm), dict(gravity=G, noise=NOISE, T_bs=synth.T_BC1, hz=200)
 
 
-def _run(oracle, capi, rig_name, nfeat, frames, use_imu=False, local_mapping=True, delay=0):
+def _run(oracle, capi, rig_name, nfeat, frames, use_imu=False, local_mapping=True, delay=0, np_delay=1):
     """delay = 0: the pass inside the frame (local_mapping = 1); delay = k >= 1: the fixed two-thread schedule
     (local_mapping = 2, mapping_delay = k) on both sides"""
     import vo_system
@@ -28,8 +28,9 @@ def _run(oracle, capi, rig_name, nfeat, frames, use_imu=False, local_mapping=Tru
         h = 1e-4
         v0 = (synth.pose_at(frames[0] + h * rig["fps"], rig["fps"])[:3, 3] - synth.pose_at(frames[0] - h * rig["fps"], rig["fps"])[:3, 3]) / (2 * h)
         gimu["velocity"] = v0
-    ref = vo_system.System(rig, nfeat, T0=T0, imu=oimu, local_mapping=local_mapping, mapping_delay=delay)
-    got = capi.System(rig, nfeat, T0=T0, imu=gimu, local_mapping=(2 if delay else 1) if local_mapping else 0, mapping_delay=delay)
+    ref = vo_system.System(rig, nfeat, T0=T0, imu=oimu, local_mapping=local_mapping, mapping_delay=delay, mapping_np_delay=np_delay)
+    got = capi.System(rig, nfeat, T0=T0, imu=gimu, local_mapping=(2 if delay else 1) if local_mapping else 0, mapping_delay=delay,
+                      mapping_np_delay=np_delay)
     if use_imu:
         ref.velocity = v0.copy()
     out = []
@@ -114,6 +115,15 @@ def test_closed_loop_parity_async_stereo_imu(oracle, capi):
     """C2 in the timed mode: IMU factor in every pose solve + mapping_delay = 4."""
     frames = list(range(0, 60, 2))
     ref, got, out = _run(oracle, capi, "euroc", 1500, frames, use_imu=True, delay=4)
+    nBA = _check(ref, got, out, pose_tol=1e-6)
+    assert nBA >= 1
+
+
+def test_closed_loop_parity_async_np_delay2(oracle, capi):
+    """bench.py's C2 schedule: the new points of a pass arrive two frames after the hand-over (mapping_np_delay = 2: the
+    new-point search has a whole frame of wall time), the BA's write-back four frames after it; IMU factor in every pose solve."""
+    frames = list(range(0, 64, 2))
+    ref, got, out = _run(oracle, capi, "euroc", 1500, frames, use_imu=True, delay=4, np_delay=2)
     nBA = _check(ref, got, out, pose_tol=1e-6)
     assert nBA >= 1
 
