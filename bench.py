@@ -256,6 +256,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     corridor = args.scene == "corridor"
+    if os.environ.get("VSLAM_DUMP_MAPS"):
+        # diagnostics (tools/resolve_stack.py): keep a fresh copy of this process's address map, so that the raw PCs and the
+        # fault address of a crash trace can be resolved against the mappings of the process that crashed
+        import threading
+
+        def _dump_maps(path=os.environ["VSLAM_DUMP_MAPS"]):
+            while True:
+                try:
+                    data = open("/proc/self/maps").read()
+                    with open(path + ".tmp", "w") as f:
+                        f.write(data)
+                    os.replace(path + ".tmp", path)
+                except Exception:      # noqa: BLE001
+                    pass
+                time.sleep(0.25)
+        threading.Thread(target=_dump_maps, daemon=True).start()
     if args.frames <= 0:
         args.frames = (400 if args.config == "c3" else 640) if corridor else (60 if args.config == "c3" else 100)
     if args.frame_step <= 0:
@@ -344,6 +360,8 @@ def main():
     # per-stage HIP events on every 3rd step of group / session 0 (every step of a short timed region).  The warm-up steps are
     # sampled too, so that the first timed sample does not carry the timers' one-time set-up; their readings are discarded.
     sample_every = 1 if args.steps < 60 else 3
+    if os.environ.get("VSLAM_BENCH_NO_SAMPLING"):
+        sample_every = 0
     fleet.set_sampling(sample_every)
     fleet.run(args.warmup)
     fleet.timings()

@@ -558,6 +558,15 @@ __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_schur(const BaDev* _
         for (int i = threadIdx.x; i < (int)(nc * sys); i += nt) Sloc[i] = 0;
     }
     __syncthreads();
+    // per-lane roles of the accumulation loops (fixed for the kernel)
+    const int bi = lane / 6, bj = lane - bi * 6;
+    const bool isBlk = lane < 36, isRhs = lane >= 36 && lane < 42;
+    const int rr = isRhs ? lane - 36 : 0;
+    const int hHalf = lane >= 27 ? 1 : 0, hq = lane - 27 * hHalf;
+    const bool hRhs = hq >= 21;
+    int hI = 0, hJ = 0;
+    if (hRhs) hI = hq - 21;
+    else { int rem = hq; while (rem >= 6 - hI) { rem -= 6 - hI; hI++; } hJ = hI + rem; }
     const int rounds = (D.Lp + gridDim.x * nu - 1) / (gridDim.x * nu);
     for (int rd = 0; rd < rounds; rd++) {
         const int lp = (rd * gridDim.x + blockIdx.x) * nu + unit;
@@ -578,45 +587,39 @@ __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_schur(const BaDev* _
                 WH[e] = w[0] * Hi[j] + w[1] * Hi[3 + j] + w[2] * Hi[6 + j];
             }
             ba_wave_fence();
-            // S -= W_s1 Hll^-1 W_s2^T for s1 <= s2 (upper block triangle), rhs -= W_s1 Hll^-1 bl
-            for (int s1 = 0; s1 < ns; s1++) {
-                const int k1 = sfi[s1];
-                const int cnt = (ns - s1) * 36;
-                for (int e = lane; e < cnt; e += BA_LPL) {
-                    const int s2 = s1 + e / 36, ij = e % 36, i = ij / 6, j = ij - i * 6;
-                    const double* a = WH + s1 * 18 + i * 3;
-                    const double* bb = W + s2 * 18 + j * 3;
-                    const double val = a[0] * bb[0] + a[1] * bb[1] + a[2] * bb[2];
-                    atomicAdd(&Sacc[(size_t)(6 * k1 + i) * n + 6 * sfi[s2] + j], -val);
-                }
-                if (lane < 6) {
-                    const double* a = WH + s1 * 18 + lane * 3;
-                    atomicAdd(&racc[6 * k1 + lane], -(a[0] * h[6] + a[1] * h[7] + a[2] * h[8]));
-                }
+            // S -= W_s1 Hll^-1 W_s2^T for s1 <= s2 (upper block triangle), rhs -= W_s1 Hll^-1 bl.
+            // Lane (bi, bj) < 36 owns one entry of every 6x6 block, lanes 36..41 the right-hand-side rows; the slot pair (s1, s2) is
+            // wave-uniform, so a block costs three LDS reads of the W row, five fp64 operations and one LDS atomic - no per-entry
+            // division / modulo chains (the PMC pass showed the first form VALU-bound on exactly that index arithmetic: ~2 700 VALU
+            // instructions per landmark for ~100 wave-instructions of arithmetic).
+            const int nsu = __builtin_amdgcn_readfirstlane(ns);
+            for (int s1 = 0; s1 < nsu; s1++) {
+                const int k1 = __builtin_amdgcn_readfirstlane(sfi[s1]);
+                const double* a = WH + s1 * 18 + (isBlk ? bi : rr) * 3;
+                const double a0 = a[0], a1 = a[1], a2 = a[2];
+                if (isBlk) {
+                    double* drow = Sacc + (size_t)(6 * k1 + bi) * n + bj;
+                    for (int s2 = s1; s2 < nsu; s2++) {
+                        const int k2 = __builtin_amdgcn_readfirstlane(sfi[s2]);
+                        const double* bb = W + s2 * 18 + bj * 3;
+                        atomicAdd(drow + 6 * k2, -(a0 * bb[0] + a1 * bb[1] + a2 * bb[2]));
+                    }
+                } else if (isRhs) atomicAdd(&racc[6 * k1 + rr], -(a0 * h[6] + a1 * h[7] + a2 * h[8]));
             }
             ba_wave_fence();        // WH is rewritten for the next candidate
         }
-        // Hpp and bp from this landmark's observations of free keyframes (the same for every candidate)
+        // Hpp and bp from this landmark's observations of free keyframes (the same for every candidate): lanes 0..26 / 27..53
+        // take the 21 + 6 entries of the even / odd factors of the landmark
         const int f0 = act ? D.lpStart[lp] : 0, f1 = act ? D.lpStart[lp + 1] : 0;
-        for (int e = lane; e < (f1 - f0) * 27; e += BA_LPL) {
-            const int f = f0 + e / 27, q = e % 27;
-            const int fi = D.facFi[f];
-            if (fi < 0) continue;
-            const double* o = D.facJ + (size_t)f * 20;
-            size_t idx;
-            double val;
-            if (q < 21) {
-                int i = 0, rem = q;
-                while (rem >= 6 - i) { rem -= 6 - i; i++; }
-                const int j = i + rem;
-                idx = (size_t)(6 * fi + i) * n + 6 * fi + j;
-                val = o[2 + i] * o[2 + j] + o[8 + i] * o[8 + j];
-            } else {
-                const int i = q - 21;
-                idx = (size_t)n * n + 6 * fi + i;
-                val = -(o[2 + i] * o[0] + o[8 + i] * o[1]);
+        if (lane < 54) {
+            for (int f = f0 + hHalf; f < f1; f += 2) {
+                const int fi = D.facFi[f];
+                if (fi < 0) continue;
+                const double* o = D.facJ + (size_t)f * 20;
+                const double val = hRhs ? -(o[2 + hI] * o[0] + o[8 + hI] * o[1]) : o[2 + hI] * o[2 + hJ] + o[8 + hI] * o[8 + hJ];
+                const size_t idx = hRhs ? (size_t)n * n + 6 * fi + hI : (size_t)(6 * fi + hI) * n + 6 * fi + hJ;
+                for (int k = 0; k < nc; k++) atomicAdd((LDS_S ? Sloc + (size_t)k * sys : SBase + (size_t)(c0 + k) * D.sysStride) + idx, val);
             }
-            for (int k = 0; k < nc; k++) atomicAdd((LDS_S ? Sloc + (size_t)k * sys : SBase + (size_t)(c0 + k) * D.sysStride) + idx, val);
         }
     }
     if (LDS_S) {
@@ -1963,7 +1966,7 @@ static void ba_init_ctl(double* h_ctl, int ps, int nAct) {
     ci[CI_NACT] = nAct;
 }
 struct BaPassHost {
-    int NF = 0, F = 0, n = 0, Lp = 0, NE = 0, maxSlots = 1, nSlotEntries = 0;
+    int NF = 0, F = 0, n = 0, Lp = 0, NE = 0, maxSlots = 1, nSlotEntries = 0, maxFac = 1;
     long long sumK2 = 0;
     double* h_ctl = nullptr; BaDev* h_D = nullptr;
     int *h_facKf = nullptr, *h_facFi = nullptr, *h_facLp = nullptr, *h_facLm = nullptr, *h_facPair = nullptr;
@@ -2066,9 +2069,10 @@ struct BaPassHost {
                 T.ns[lp] = ns;
             }
         });
-        maxSlots = 1; nSlotEntries = 0; sumK2 = 0;
+        maxSlots = 1; nSlotEntries = 0; sumK2 = 0; maxFac = 1;
         for (int lp = 0; lp < Lp; lp++) {
             h_lpSlotStart[lp] = nSlotEntries;
+            maxFac = std::max(maxFac, h_lpStart[lp + 1] - h_lpStart[lp]);
             nSlotEntries += T.ns[lp] + 1;
             maxSlots = std::max(maxSlots, T.ns[lp]);
             sumK2 += (long long)T.ns[lp] * T.ns[lp];
@@ -2698,9 +2702,14 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
 // chi2 flags; the second pass is re-armed for all lanes together (mask, no rebuild).  Problems outside the tracker-window
 // class (more than BA_LDS_MAX_F free keyframes, empty graphs) and lanes whose second graph loses a keyframe take the
 // one-problem path.
+static std::atomic<long long> g_bbsNs[12], g_bbsCalls{0}, g_bbsPolls{0};
+static const char* g_bbsName[12] = {"check+count", "arena fill", "tables+upload", "lm pass 1", "chi2 1", "second-pass prep", "lm pass 2", "chi2 2 + fetch", "results", nullptr, nullptr, nullptr};
 static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_result* const* Rs, int N, int device) {
     if (N <= 0 || !Ps || !Rs) return VSLAM_ERR_INVALID;
     if (N == 1) return ba_run(Ps[0], Rs[0], device, nullptr);
+    auto bbs_t = std::chrono::steady_clock::now();
+    g_bbsCalls++;
+    auto BBS = [&](int k) { const auto t_ = std::chrono::steady_clock::now(); g_bbsNs[k] += std::chrono::duration_cast<std::chrono::nanoseconds>(t_ - bbs_t).count(); bbs_t = t_; };
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available (no CPU fallback)"); return VSLAM_ERR_NO_DEVICE; }
     if (device < 0 || device >= ndev) return VSLAM_ERR_INVALID;
@@ -2787,6 +2796,7 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
     std::vector<int> act;
     for (int i = 0; i < N; i++) (lanes[i].single ? singles : act).push_back(i);
     const int NL = (int)act.size();
+    BBS(0);
     auto run_singles = [&]() -> vslam_status { for (int i : singles) VS_CHECK(ba_run(Ps[i], Rs[i], device, nullptr)); return VSLAM_OK; };
     if (NL == 0) return run_singles();
     auto& A = W.arena;
@@ -2821,6 +2831,7 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
         q.H.fill(P, q.wrong.data(), 0, 1, q.T, q.pose0.data(), nullptr, nSlots);
         ba_init_ctl(q.H.h_ctl, 0, adaptive ? 1 : NB);
     });
+    BBS(1);
     // ---- launch geometry shared by the lanes ---------------------------------------------------------------------------
     int maxSlots = 1, nMax = 0, neMax = 0, nfMax = 0, lpMax = 0, npMax = 0, valMax = 0;
     bool anyMfma64 = false, anyWave = false, anyMfma = false;
@@ -2838,12 +2849,15 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
     auto stage_lds = [&](int nw) { return (size_t)nw * SCHUR_LPW * 2 * maxSlots * 18 * sizeof(double) + (size_t)nw * SCHUR_LPW * maxSlots * sizeof(int) + 16; };
     auto schur_lds = [&](int nw, int copies) { return copies * sysMax * sizeof(double) + stage_lds(nw); };
     int sharedW = 0, schurWaves = BA_SCHUR_WAVES;
-    if (NB > 1) for (int nw : {16, 12, 8, 6, 4, 2}) if (schur_lds(nw, NB) <= 150 * 1024) { sharedW = 1; schurWaves = nw; break; }
-    if (!sharedW) while (schurWaves > 2 && schur_lds(schurWaves, 1) > 150 * 1024) schurWaves /= 2;
+    const int shEnv = getenv("VSLAM_BA_SCHUR_SHARED") ? atoi(getenv("VSLAM_BA_SCHUR_SHARED")) : 1;
+    const int swEnv = getenv("VSLAM_BA_SCHUR_WAVES_B") ? atoi(getenv("VSLAM_BA_SCHUR_WAVES_B")) : 0;
+    if (NB > 1 && shEnv) for (int nw : {16, 12, 8, 6, 4, 2}) if (schur_lds(nw, NB) <= 150 * 1024) { sharedW = 1; schurWaves = nw; break; }
+    if (!sharedW) { if (swEnv) schurWaves = swEnv; while (schurWaves > 2 && schur_lds(schurWaves, 1) > 150 * 1024) schurWaves /= 2; }
     const size_t schurLds = schur_lds(schurWaves, sharedW ? NB : 1);
     if (schurLds > 160 * 1024) { set_error("local BA batch: landmark with too many views for the LDS staging"); return VSLAM_ERR_CAPACITY; }
     const int schurUnits = schurWaves * SCHUR_LPW;
-    const int lmBlocks = std::max(1, std::min((lpMax + schurUnits - 1) / schurUnits, std::max(16, 2 * nCU / NL)));
+    const int lbEnv = getenv("VSLAM_BA_LMBLOCKS") ? atoi(getenv("VSLAM_BA_LMBLOCKS")) : 0;
+    int lmBlocks = std::max(1, std::min((lpMax + schurUnits - 1) / schurUnits, lbEnv ? lbEnv : std::max(16, 2 * nCU / NL)));
     int backWaves = BA_SCHUR_WAVES / BACK_LPW;
     auto back_lds = [&](int nw) { return (size_t)nw * BACK_LPW * maxSlots * 18 * sizeof(double) + (size_t)nw * BACK_LPW * maxSlots * sizeof(int) + 16; };
     while (backWaves > 1 && back_lds(backWaves) > 150 * 1024) backWaves /= 2;
@@ -2972,6 +2986,7 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
             enq += perPoll;
             VS_HIP(hipMemcpyAsync(b_ctl, A.dev(h_ctlAll), (size_t)CTL_DOUBLES * 8 * NL, hipMemcpyDeviceToHost, stream));
             VS_HIP(vslam::stream_wait_blocking(stream));
+            g_bbsPolls++;
             bool all = true;
             for (int a = 0; a < NL; a++) all &= ((const int*)(b_ctl + (size_t)CTL_DOUBLES * a + CTL_INTS))[CI_STATE] == BA_DONE;
             if (all) return VSLAM_OK;
@@ -3005,9 +3020,12 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
         return VSLAM_OK;
     };
     // ---- pass 1 ------------------------------------------------------------------------------------------------------------------
+    BBS(2);
     VS_CHECK(lm_loop());
     report(0);
+    BBS(3);
     VS_CHECK(chi2(0));
+    BBS(4);
     // ---- second pass on the first pass's structure: membership / statistics from the flags; lanes whose graph loses a keyframe
     //      (their free index would change) go to the one-problem path, which rebuilds ------------------------------------------------
     std::vector<int> redo;
@@ -3046,6 +3064,7 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
         ba_init_ctl(H.h_ctl, 1, adaptive ? 1 : NB);
     });
     for (int a = 0; a < NL; a++) if (!lanes[act[a]].pass2) redo.push_back(act[a]);
+    BBS(5);
     if ((int)redo.size() < NL) {
         // re-armed control blocks and the membership arrays: the arena's head (control blocks) + each lane's present arrays
         VS_HIP(hipMemcpyAsync(A.dev(h_ctlAll), h_ctlAll, (size_t)CTL_DOUBLES * 8 * NL, hipMemcpyHostToDevice, stream));
@@ -3058,7 +3077,9 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
         hipLaunchKernelGGL(k_ba_second_pass_b, dim3(std::max(1, std::min((std::max(nfMax, valMax) + 255) / 256, 64)), NL), dim3(256), 0, stream, dTab, dAux);
         VS_CHECK(lm_loop());
         report(1);
+        BBS(6);
         VS_CHECK(chi2(1));
+        BBS(7);
     }
     for (int a = 0; a < NL; a++) {
         Lane& q = lanes[act[a]];
@@ -3069,6 +3090,7 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
         if (q.L) memcpy(q.R->lm_xyz, lo, (size_t)3 * q.L * sizeof(double));
         if (q.NP) memcpy(q.R->pair_wrong, W.h_back + q.oWrong, q.NP);
     }
+    BBS(8);
     for (int i : redo) VS_CHECK(ba_run(Ps[i], Rs[i], device, nullptr));
     return run_singles();
 }
@@ -3078,6 +3100,11 @@ namespace vslam {
 // polls of both LM loops, "chi2" the re-check + second-pass preparation + result fetch)
 void ba_host_profile_print() {
 #ifndef VSLAM_HOST_STAMPS
+    if (const long long nb = g_bbsCalls.load()) {
+        fprintf(stderr, "  vslam_local_ba_batch host sections (us per cohort, %lld cohorts, %.1f polls each):", nb, (double)g_bbsPolls.load() / (double)nb);
+        for (int i = 0; i < 12 && g_bbsName[i]; i++) fprintf(stderr, " %s %.1f |", g_bbsName[i], 1e-3 * (double)g_bbsNs[i].load() / (double)nb);
+        fprintf(stderr, "\n");
+    }
     const long long n = g_bhsCalls.load();
     if (!n) return;
     fprintf(stderr, "  vslam_local_ba host sections (us per call, %lld calls):", n);

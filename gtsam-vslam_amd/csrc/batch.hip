@@ -43,84 +43,48 @@ namespace {
 inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 }
 
-struct vslam_batch {
-    int B = 0, device = 0;
-    bool useImu = false;
-    vslam_extractor* fe = nullptr;
-    hipStream_t stream = nullptr;
-    // the two pre-integrations of a step run beside the matching passes that do not depend on them (one-workgroup-per-lane
-    // kernels of ~90 us each): side stream + events, as the one-session path does
-    hipStream_t imuStream = nullptr; hipEvent_t evTab = nullptr, evImu0 = nullptr, evSolve0 = nullptr, evImu1 = nullptr;
-    std::vector<vslam_system*> sys;
-    // per-lane argument tables of one step: pinned host block + device mirror (one H2D per step)
-    struct Tables {
-        StereoLane* stereo; PredictLane* predict; ImuLane* imu0; ProjLane* proj0; PoseLane* pose0; ImuLane* imu1;
-        RepredictLane* repredict; ProjLane* proj1; PoseLane* pose1; PackLane* pack;
-    } ht{}, dt{};
-    uint8_t* h_tab = nullptr; uint8_t* d_tab = nullptr; size_t tabBytes = 0;
-    uint8_t* h_up = nullptr; uint8_t* d_up = nullptr; size_t upCap = 0;      // upload block (map points, IMU buckets)
-    uint8_t* h_dn = nullptr; uint8_t* d_dn = nullptr; size_t dnCap = 0;      // download block (per-lane tracking state)
-    double* d_res = nullptr; double* h_res = nullptr;                        // [B][64] result blocks
-    uint8_t* d_zero = nullptr; size_t zeroCap = 0;                           // MapPoint::GetIsOutlier of uploaded points: all 0
-    BaPool pool;                                                             // host phases
-    // mapping engine (local_mapping = 2): the device work of the lanes' passes, COHORT by cohort - the jobs the lanes hand over
-    // during a host phase of a step are collected (submit_mapping) and released together when that phase ends (kick): the
-    // new-point searches of the lanes that inserted a keyframe at this step, the local BAs of the lanes that did at the previous
-    // one.  A cohort's local BAs are ONE batched call (vslam_local_ba_batch: one launch per stage for all of them).
-    std::vector<std::thread> mapThreads;
-    std::deque<vslam_system*> npQueue, baQueue;
-    std::mutex mqMu; std::condition_variable npCv, baCv;
-    bool mqStop = false, npReady = false, baReady = false;
+
+// ---- the mapping engine (local_mapping = 2) ------------------------------------------------------------------------------------
+// The device work of the lanes' local-mapping passes, COHORT by cohort: the jobs the lanes of a group hand over during a host
+// phase of a step are collected (vslam_batch::submit_mapping) and released together when that phase ends (kick).  An engine
+// thread takes EVERYTHING that has been released when it becomes free - the new-point searches of the lanes that inserted a
+// keyframe, the local BAs of the lanes that did a frames earlier - and runs it as ONE batched call (vslam_find_new_points_batch /
+// vslam_local_ba_batch: one launch per stage for all of them).  One engine per device, shared by the lockstep groups of that
+// device: a cohort then holds the jobs of every group (twice the lanes per launch with two groups, half the launches), and
+// the cohort size adapts to the load - the longer a cohort takes, the more jobs the next one finds.
+// VSLAM_MAP_ENGINE_PRIVATE=1: one engine per group (round-3 first form).
+struct MapEngine {
+    int device = 0;
+    std::vector<std::thread> threads;
+    std::deque<vslam_system*> npQueue, baQueue;      // released jobs
+    std::mutex mu; std::condition_variable npCv, baCv;
+    bool stop = false;
     // local-BA stage timing of the cohorts (HIP events on the engine's stream), summed since the last read
     std::atomic<int> baTimingOn{0};
     std::mutex btMu;
     std::vector<std::pair<const char*, float>> baTimes;
     long long baTimedCohorts = 0, baTimedLanes = 0;
-    // per-step scratch
-    struct LaneStep { bool on = false, first = false, failed = false; vslam_status st = VSLAM_OK; char err[200] = ""; size_t upOff = 0, dnOff = 0, keyOff = 0; int N = 0, nL = 0, nR = 0; bool wantKeys = false; void* keySlot = nullptr; };
-    std::vector<LaneStep> ls;
-    std::vector<const uint8_t*> imgPtrs;
-    StageTimer timer;
-    // host-side phase times of the last step (seconds): pre, extract enqueue, fill, tables + enqueue, wait, finish, post
-    double phase[8] = {0}, phaseSum[8] = {0}, subSum[6] = {0};      // subSum: begin a / serve / b, post a / serve / b
-    long long nSteps = 0;
 
-    vslam_status init(const vslam_system_config* cfgs, int n, int hostThreads, int mapThreads);
-    void release();
-    vslam_status ensure_up(size_t bytes);
-    vslam_status ensure_dn(size_t bytes);
-    vslam_status serve_requests();
-    std::vector<uint8_t> rqDescs; std::vector<int> rqStart, rqBest;
-    vslam_status step(const uint8_t* const* L, const uint8_t* const* R, int stride, bool onDevice, const int* frames,
-                      const vslam_imu_bucket* imu, const uint8_t* mask, double* T_wc_out, vslam_frame_report* reps,
-                      const uint8_t* const* nextL = nullptr, const uint8_t* const* nextR = nullptr, const uint8_t* nextMask = nullptr);
-    // images of the NEXT step whose extraction was enqueued at the end of the previous one (prefetch)
-    std::vector<const uint8_t*> prefetched;
-    vslam_status enqueue_extraction(const uint8_t* const* L, const uint8_t* const* R, const uint8_t* mask, int stride, bool onDevice);
-    static void submit_mapping(void* self, vslam_system* s) {
-        vslam_batch* b = (vslam_batch*)self;
-        bool now = false;
+    void release_jobs(std::deque<vslam_system*>& np, std::deque<vslam_system*>& ba) {
+        bool n = false, b = false;
         {
-            std::lock_guard<std::mutex> lk(b->mqMu);
-            (s->pass.stage == MapPass::NEW_POINTS ? b->npQueue : b->baQueue).push_back(s);
-            // mapping_delay == mapping_np_delay: the lane waits for this local BA inside the same host phase - no cohort to wait for
-            if (s->pass.stage == MapPass::LOCAL_BA && s->pass.commitFrame <= s->pass.npFrame) { b->baReady = true; now = true; }
+            std::lock_guard<std::mutex> lk(mu);
+            for (vslam_system* s : np) { npQueue.push_back(s); n = true; }
+            for (vslam_system* s : ba) { baQueue.push_back(s); b = true; }
         }
-        if (now) b->baCv.notify_all();
-    }
-    void kick() {                                  // a host phase has ended: its jobs form a cohort
-        { std::lock_guard<std::mutex> lk(mqMu); npReady = !npQueue.empty(); baReady = !baQueue.empty(); }
-        npCv.notify_all(); baCv.notify_all();
+        np.clear(); ba.clear();
+        if (n) npCv.notify_one();
+        if (b) baCv.notify_one();
     }
     void np_loop() {
         hipSetDevice(device);
         for (;;) {
             std::vector<vslam_system*> jobs;
             {
-                std::unique_lock<std::mutex> lk(mqMu);
-                npCv.wait(lk, [&] { return mqStop || (npReady && !npQueue.empty()); });
+                std::unique_lock<std::mutex> lk(mu);
+                npCv.wait(lk, [&] { return stop || !npQueue.empty(); });
                 if (npQueue.empty()) break;        // (stop requested and nothing left)
-                jobs.assign(npQueue.begin(), npQueue.end()); npQueue.clear(); npReady = false;
+                jobs.assign(npQueue.begin(), npQueue.end()); npQueue.clear();
             }
             // the cohort's new-point searches: one upload, one launch per kernel, one download (vslam_find_new_points_batch)
             std::vector<const vslam_new_points_problem*> Ps; std::vector<vslam_new_points_result*> Rs;
@@ -138,10 +102,10 @@ struct vslam_batch {
         for (;;) {
             std::vector<vslam_system*> jobs;
             {
-                std::unique_lock<std::mutex> lk(mqMu);
-                baCv.wait(lk, [&] { return mqStop || (baReady && !baQueue.empty()); });
+                std::unique_lock<std::mutex> lk(mu);
+                baCv.wait(lk, [&] { return stop || !baQueue.empty(); });
                 if (baQueue.empty()) break;
-                jobs.assign(baQueue.begin(), baQueue.end()); baQueue.clear(); baReady = false;
+                jobs.assign(baQueue.begin(), baQueue.end()); baQueue.clear();
             }
             const auto t0 = std::chrono::steady_clock::now();
             std::vector<const vslam_ba_problem*> Ps; std::vector<vslam_ba_result*> Rs;
@@ -169,12 +133,100 @@ struct vslam_batch {
             {
                 const long long d = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
                 SysProf& p = sys_prof();
-                p.mqNs += d; p.mqN++; p.mapN += 0;
+                p.mqNs += d; p.mqN++; p.mqLate += (long long)jobs.size();
                 if (d > 15000000) p.mapLate++;
                 long long m = p.mapMaxNs.load(); while (d > m && !p.mapMaxNs.compare_exchange_weak(m, d)) {}
             }
         }
         vslam::thread_release();
+    }
+    void start(int nNp, int nBa) {
+        for (int t = 0; t < nNp; t++) threads.emplace_back([this]() { np_loop(); });
+        for (int t = 0; t < nBa; t++) threads.emplace_back([this]() { ba_loop(); });
+    }
+    ~MapEngine() {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        npCv.notify_all(); baCv.notify_all();
+        for (auto& t : threads) t.join();
+    }
+    // one engine per device, alive while a group of that device holds it
+    static std::shared_ptr<MapEngine> acquire(int device, int nBaThreads) {
+        static std::mutex gMu;
+        static std::weak_ptr<MapEngine> shared[64];
+        static const bool priv = getenv("VSLAM_MAP_ENGINE_PRIVATE") && atoi(getenv("VSLAM_MAP_ENGINE_PRIVATE")) != 0;
+        std::lock_guard<std::mutex> lk(gMu);
+        std::shared_ptr<MapEngine> e = (priv || device < 0 || device >= 64) ? nullptr : shared[device].lock();
+        if (!e) {
+            e = std::make_shared<MapEngine>();
+            e->device = device;
+            const int nNp = getenv("VSLAM_MAP_NP_THREADS") ? std::max(1, atoi(getenv("VSLAM_MAP_NP_THREADS"))) : (priv ? 2 : 1);
+            e->start(nNp, nBaThreads);
+            if (!priv && device >= 0 && device < 64) shared[device] = e;
+        }
+        return e;
+    }
+};
+
+struct vslam_batch {
+    int B = 0, device = 0;
+    bool useImu = false;
+    vslam_extractor* fe = nullptr;
+    hipStream_t stream = nullptr;
+    // the two pre-integrations of a step run beside the matching passes that do not depend on them (one-workgroup-per-lane
+    // kernels of ~90 us each): side stream + events, as the one-session path does
+    hipStream_t imuStream = nullptr; hipEvent_t evTab = nullptr, evImu0 = nullptr, evSolve0 = nullptr, evImu1 = nullptr;
+    std::vector<vslam_system*> sys;
+    // per-lane argument tables of one step: pinned host block + device mirror (one H2D per step)
+    struct Tables {
+        StereoLane* stereo; PredictLane* predict; ImuLane* imu0; ProjLane* proj0; PoseLane* pose0; ImuLane* imu1;
+        RepredictLane* repredict; ProjLane* proj1; PoseLane* pose1; PackLane* pack;
+    } ht{}, dt{};
+    uint8_t* h_tab = nullptr; uint8_t* d_tab = nullptr; size_t tabBytes = 0;
+    uint8_t* h_up = nullptr; uint8_t* d_up = nullptr; size_t upCap = 0;      // upload block (map points, IMU buckets)
+    uint8_t* h_dn = nullptr; uint8_t* d_dn = nullptr; size_t dnCap = 0;      // download block (per-lane tracking state)
+    double* d_res = nullptr; double* h_res = nullptr;                        // [B][64] result blocks
+    uint8_t* d_zero = nullptr; size_t zeroCap = 0;                           // MapPoint::GetIsOutlier of uploaded points: all 0
+    BaPool pool;                                                             // host phases
+    // mapping engine (shared by the groups of this device); the jobs of the current host phase wait here for kick()
+    std::shared_ptr<MapEngine> eng;
+    std::deque<vslam_system*> npPend, baPend;
+    std::mutex pendMu;
+    // per-step scratch
+    struct LaneStep { bool on = false, first = false, failed = false; vslam_status st = VSLAM_OK; char err[200] = ""; size_t upOff = 0, dnOff = 0, keyOff = 0; int N = 0, nL = 0, nR = 0; bool wantKeys = false; void* keySlot = nullptr; };
+    std::vector<LaneStep> ls;
+    std::vector<const uint8_t*> imgPtrs;
+    StageTimer timer;
+    // host-side phase times of the last step (seconds): pre, extract enqueue, fill, tables + enqueue, wait, finish, post
+    double phase[8] = {0}, phaseSum[8] = {0}, subSum[6] = {0};      // subSum: begin a / serve / b, post a / serve / b
+    long long nSteps = 0;
+
+    vslam_status init(const vslam_system_config* cfgs, int n, int hostThreads, int mapThreads);
+    void release();
+    vslam_status ensure_up(size_t bytes);
+    vslam_status ensure_dn(size_t bytes);
+    vslam_status serve_requests();
+    std::vector<uint8_t> rqDescs; std::vector<int> rqStart, rqBest;
+    vslam_status step(const uint8_t* const* L, const uint8_t* const* R, int stride, bool onDevice, const int* frames,
+                      const vslam_imu_bucket* imu, const uint8_t* mask, double* T_wc_out, vslam_frame_report* reps,
+                      const uint8_t* const* nextL = nullptr, const uint8_t* const* nextR = nullptr, const uint8_t* nextMask = nullptr);
+    // images of the NEXT step whose extraction was enqueued at the end of the previous one (prefetch)
+    std::vector<const uint8_t*> prefetched;
+    vslam_status enqueue_extraction(const uint8_t* const* L, const uint8_t* const* R, const uint8_t* mask, int stride, bool onDevice);
+    static void submit_mapping(void* self, vslam_system* s) {
+        vslam_batch* b = (vslam_batch*)self;
+        bool now = false;
+        {
+            std::lock_guard<std::mutex> lk(b->pendMu);
+            (s->pass.stage == MapPass::NEW_POINTS ? b->npPend : b->baPend).push_back(s);
+            // mapping_delay == mapping_np_delay: the lane waits for this local BA inside the same host phase - no cohort to wait for
+            now = s->pass.stage == MapPass::LOCAL_BA && s->pass.commitFrame <= s->pass.npFrame;
+        }
+        if (now) b->kick();
+    }
+    void kick() {                                  // a host phase has ended: its jobs are released to the engine
+        if (!eng) return;
+        std::lock_guard<std::mutex> lk(pendMu);
+        if (!npPend.empty() || !baPend.empty()) eng->release_jobs(npPend, baPend);
     }
 };
 
@@ -247,11 +299,10 @@ vslam_status vslam_batch::init(const vslam_system_config* cfgs, int n, int hostT
     pool.onExit = []() { vslam::thread_release(); };
     if (hostThreads > 1) pool.start(hostThreads - 1);
     if (cfgs[0].local_mapping == 2) {
-        // mapping_threads = engine threads for the cohorts' batched local BAs (2: a cohort may still run when the next arrives),
-        // + 2 threads for the cohorts' batched new-point searches
+        // mapping_threads = the engine's threads for the cohorts' batched local BAs (a second cohort may start while one is in its
+        // last rounds), + its thread(s) for the cohorts' batched new-point searches
         if (nMapThreads <= 0) nMapThreads = getenv("VSLAM_BATCH_MAP_THREADS") ? std::max(1, atoi(getenv("VSLAM_BATCH_MAP_THREADS"))) : 2;
-        for (int t = 0; t < 2; t++) mapThreads.emplace_back([this]() { np_loop(); });
-        for (int t = 0; t < nMapThreads; t++) mapThreads.emplace_back([this]() { ba_loop(); });
+        eng = MapEngine::acquire(device, nMapThreads);
     }
     return VSLAM_OK;
 }
@@ -274,20 +325,18 @@ void vslam_batch::release() {
         fprintf(stderr, "  mapping passes: %.1f us x %lld (find new points %.1f, vslam_local_ba %.1f) | frames that waited for their mapper: %.1f us x %lld\n",
                 avg(p.mapNs, p.mapN), p.mapN.load(), avg(p.npNs, p.npN), avg(p.baNs, p.baN), avg(p.waitNs, p.waitN), p.waitN.load());
         fprintf(stderr, "  sections (total ms): KF new_keyframe %.1f | observations %.1f | stereo refill %.1f | descriptor request %.1f | key slot %.1f | connections %.1f | "
-                        "keys from block %.1f || ba_collect %.1f | np_commit_a %.1f | ba_commit_a %.1f | np_collect %.1f\n", 1e-6 * p.sec[0], 1e-6 * p.sec[1], 1e-6 * p.sec[2],
-                1e-6 * p.sec[3], 1e-6 * p.sec[4], 1e-6 * p.sec[5], 1e-6 * p.sec[6], 1e-6 * p.sec[7], 1e-6 * p.sec[8], 1e-6 * p.sec[9], 1e-6 * p.sec[10]);
+                        "keys from block %.1f (%lld by fetch_keys) || ba_collect %.1f | np_commit_a %.1f | ba_commit_a %.1f | np_collect %.1f\n", 1e-6 * p.sec[0], 1e-6 * p.sec[1], 1e-6 * p.sec[2],
+                1e-6 * p.sec[3], 1e-6 * p.sec[4], 1e-6 * p.sec[5], 1e-6 * p.sec[6], (long long)p.sec[14].load(), 1e-6 * p.sec[7], 1e-6 * p.sec[8], 1e-6 * p.sec[9], 1e-6 * p.sec[10]);
         vslam::ba_host_profile_print();
-        fprintf(stderr, "  local-BA cohorts: %.1f us per cohort x %lld cohorts (above 15 ms: %lld, longest %.1f ms)\n",
-                avg(p.mqNs, p.mqN), p.mqN.load(), p.mapLate.load(), 1e-6 * (double)p.mapMaxNs.load());
+        { extern void kfb_print(); kfb_print(); }
+        fprintf(stderr, "  local-BA cohorts: %.1f us per cohort x %lld cohorts of %.1f lanes (above 15 ms: %lld, longest %.1f ms)\n",
+                avg(p.mqNs, p.mqN), p.mqN.load(), p.mqN.load() ? (double)p.mqLate.load() / (double)p.mqN.load() : 0.0, p.mapLate.load(), 1e-6 * (double)p.mapMaxNs.load());
     }
     // sessions first (each waits for its mapping job), then the mapping threads, then the shared objects
     kick();
     for (vslam_system* s : sys) if (s) { s->release(); delete s; }
     sys.clear();
-    { std::lock_guard<std::mutex> lk(mqMu); mqStop = true; }
-    npCv.notify_all(); baCv.notify_all();
-    for (auto& t : mapThreads) t.join();
-    mapThreads.clear();
+    eng.reset();                                   // (the last group of the device stops the engine's threads)
     if (stream) hipStreamSynchronize(stream);
     if (imuStream) { hipStreamSynchronize(imuStream); hipStreamDestroy(imuStream); imuStream = nullptr; }
     for (hipEvent_t e : {evTab, evImu0, evSolve0, evImu1}) if (e) hipEventDestroy(e);
@@ -412,6 +461,7 @@ vslam_status vslam_batch::step(const uint8_t* const* L, const uint8_t* const* R,
                                const uint8_t* const* nextL, const uint8_t* const* nextR, const uint8_t* nextMask) {
     if (!L || !R || !frames || !T_wc_out) return VSLAM_ERR_INVALID;
     VS_HIP(hipSetDevice(device));
+    vslam::thread_pool_wants_priority() = true;      // this thread's pool serves the group's requests (serve_requests)
     using clk = std::chrono::steady_clock;
     auto t0 = clk::now();
     auto lap = [&](int k) { const auto t1 = clk::now(); phase[k] = std::chrono::duration<double>(t1 - t0).count(); phaseSum[k] += phase[k]; t0 = t1; };
@@ -541,7 +591,9 @@ vslam_status vslam_batch::step(const uint8_t* const* L, const uint8_t* const* R,
         dnBytes += up256((size_t)std::max(q.N, 1) * 15 + (size_t)q.nL * 4 + 16);
         // a lane whose keyframe counter allows an insertion this frame (src/FeatureTracker.cpp:1262: count >= 5) gets its
         // TrackedKeys in the same download; the rarer nStereo < 80 branch falls back to fetch_keys()
-        q.wantKeys = sys[b]->insertKeyFrameCount + 1 >= 5;
+        // (its nStereo < 80 branch can insert at any frame: a lane whose previous frame was near that bound gets them too;
+        //  a keyframe that still arrives without its block falls back to fetch_keys())
+        q.wantKeys = sys[b]->insertKeyFrameCount + 1 >= 5 || sys[b]->lastNStereo < 110;
         if (q.wantKeys) { q.keyOff = dnBytes; dnBytes += up256(key_block_layout(q.nL, q.nR).total); }
     }
     VS_CHECK(ensure_dn(std::max<size_t>(dnBytes, 256)));
@@ -785,17 +837,22 @@ vslam_status vslam_batch_set_timing(vslam_batch* b, int32_t on) {
 // local-BA stage timing of the mapping engine's cohorts (HIP events on its stream): switch, and read-and-reset of the sums
 vslam_status vslam_batch_set_ba_timing(vslam_batch* b, int32_t on) {
     if (!b) return VSLAM_ERR_INVALID;
-    b->baTimingOn = on ? 1 : 0;
+    if (b->eng) b->eng->baTimingOn = on ? 1 : 0;
     return VSLAM_OK;
 }
 vslam_status vslam_batch_ba_timings(vslam_batch* b, const char** names, float* ms, int32_t cap, int32_t* n_out, int64_t* cohorts_out, int64_t* lanes_out) {
     if (!b || !n_out || !names || !ms) return VSLAM_ERR_INVALID;
     int n = 0;
-    std::lock_guard<std::mutex> lk(b->btMu);
-    for (auto& t : b->baTimes) if (n < cap) { names[n] = t.first; ms[n] = t.second; n++; }
-    if (cohorts_out) *cohorts_out = b->baTimedCohorts;
-    if (lanes_out) *lanes_out = b->baTimedLanes;
-    b->baTimes.clear(); b->baTimedCohorts = 0; b->baTimedLanes = 0;
+    if (cohorts_out) *cohorts_out = 0;
+    if (lanes_out) *lanes_out = 0;
+    if (b->eng) {
+        MapEngine& e = *b->eng;
+        std::lock_guard<std::mutex> lk(e.btMu);
+        for (auto& t : e.baTimes) if (n < cap) { names[n] = t.first; ms[n] = t.second; n++; }
+        if (cohorts_out) *cohorts_out = e.baTimedCohorts;
+        if (lanes_out) *lanes_out = e.baTimedLanes;
+        e.baTimes.clear(); e.baTimedCohorts = 0; e.baTimedLanes = 0;
+    }
     *n_out = n;
     return VSLAM_OK;
 }

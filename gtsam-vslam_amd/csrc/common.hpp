@@ -195,12 +195,24 @@ inline hipError_t create_side_stream(hipStream_t* s) {
 inline hipError_t create_main_stream(hipStream_t* s) { return hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
 // the calling thread's pool for `device` (switching devices releases the previous pool's blocks)
 inline DevPool& thread_pool_slot() { static thread_local DevPool pool; return pool; }
+// A thread whose pool serves LATENCY-CRITICAL round trips (the lockstep group's driver: the lanes' descriptor-selection and
+// depth-refresh requests of a host phase, one small launch the whole group waits for) asks for a high-priority stream before
+// its first use of the pool: such a stream gets a hardware queue of its own class, so the launch does not sit in a queue
+// behind a cohort's twenty local-BA launches or another group's tracking chain.  VSLAM_REQ_PRIORITY=0: a normal stream.
+inline bool& thread_pool_wants_priority() { static thread_local bool v = false; return v; }
 inline DevPool* thread_pool(int device) {
     DevPool& pool = thread_pool_slot();
     if (pool.device != device) {
         pool.release();
         pool.device = device;
-        if (hipSetDevice(device) != hipSuccess || create_side_stream(&pool.stream) != hipSuccess) { pool.device = -1; return nullptr; }
+        if (hipSetDevice(device) != hipSuccess) { pool.device = -1; return nullptr; }
+        static const bool reqPrio = !(getenv("VSLAM_REQ_PRIORITY") && atoi(getenv("VSLAM_REQ_PRIORITY")) == 0);
+        int least = 0, greatest = 0;
+        hipError_t e;
+        if (thread_pool_wants_priority() && reqPrio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+            e = hipStreamCreateWithPriority(&pool.stream, hipStreamNonBlocking, greatest);
+        else e = create_side_stream(&pool.stream);
+        if (e != hipSuccess) { pool.device = -1; return nullptr; }
     }
     return &pool;
 }

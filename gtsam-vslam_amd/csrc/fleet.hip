@@ -272,7 +272,8 @@ static vslam_status fleet_create(const vslam_system_config* config, int32_t n_se
         F->groups.resize(nG);
         // host threads per group: the groups share the machine's cores
         const int hw = (int)std::max(2u, std::thread::hardware_concurrency());
-        const int hostThreads = std::max(1, std::min(8, hw / std::max(nG, 1) - 1));
+        int hostThreads = std::max(1, std::min(8, hw / std::max(nG, 1) - 1));
+        if (const char* e = getenv("VSLAM_FLEET_HOST_THREADS")) hostThreads = std::max(1, atoi(e));
         for (int g = 0; g < nG && st == VSLAM_OK; g++) {
             vslam_fleet::Group& G = F->groups[g];
             G.first = g * lanes; G.count = std::min(lanes, n_sessions - G.first);

@@ -104,20 +104,29 @@ vslam_status vslam_system::fetch_keys(SysKeys& k) {
 }
 
 // the same from the packed block a vslam_batch step downloaded with the tracking state
+static std::atomic<long long> g_kfbNs[4];
 static void keys_from_block(const uint8_t* blk, int nL, int nR, SysKeys& k) {
     const KeyBlockLayout o = key_block_layout(nL, nR);
+    auto T0 = std::chrono::steady_clock::now();
+    auto lapk = [&](int i) { auto t = std::chrono::steady_clock::now(); g_kfbNs[i] += std::chrono::duration_cast<std::chrono::nanoseconds>(t - T0).count(); T0 = t; };
     k.kL.resize(nL); k.kR.resize(nR); k.dL.resize((size_t)nL * 32); k.dR.resize((size_t)nR * 32);
     k.rightIdxs.resize(nL); k.leftIdxs.resize(nR); k.depth.resize(nL); k.close.resize(nL);
+    lapk(0);
     if (nL) {
         memcpy(k.kL.data(), blk + o.kpsL, (size_t)nL * sizeof(vslam_keypoint)); memcpy(k.dL.data(), blk + o.descL, (size_t)nL * 32);
         memcpy(k.rightIdxs.data(), blk + o.rightIdxs, (size_t)nL * 4); memcpy(k.depth.data(), blk + o.depth, (size_t)nL * 4);
         memcpy(k.close.data(), blk + o.closef, nL);
     }
+    lapk(1);
     if (nR) {
         memcpy(k.kR.data(), blk + o.kpsR, (size_t)nR * sizeof(vslam_keypoint)); memcpy(k.dR.data(), blk + o.descR, (size_t)nR * 32);
         memcpy(k.leftIdxs.data(), blk + o.leftIdxs, (size_t)nR * 4);
     }
+    lapk(2);
+    { volatile uint8_t sink = 0; for (size_t i = 0; i < (size_t)nL * 32; i += 64) sink += k.dL[i]; }
+    lapk(3);
 }
+void kfb_print() { fprintf(stderr, "  keys_from_block ms: resize %.1f | left %.1f | right %.1f | re-read dL %.1f\n", 1e-6 * g_kfbNs[0], 1e-6 * g_kfbNs[1], 1e-6 * g_kfbNs[2], 1e-6 * g_kfbNs[3]); }
 
 // MapPoint::update(KeyFrame*) (src/Map.cpp:58-100) minus calcDescriptor, which is batched (needDesc)
 void vslam_system::mp_update(SysMP& mp, int kfNumb, std::vector<int>& needDesc, int mpIndex) {
@@ -525,6 +534,7 @@ vslam_status vslam_system::frame_post_a(SysFrameCtx& c, const SysTrackState& st)
         for (int i = 0; i < M; i++) { act[i] = cand[actIdx[i]]; mpInFrame[act[i]] = inF[i] != 0; }
         active = act;
         // keyframe rule (:1260-1270)
+        lastNStereo = tr.n_stereo;
         insertKeyFrameCount++;
         isKF = (tr.n_stereo < 80 || insertKeyFrameCount >= 5) && (float)tr.n_inliers < precCheckMatches * (float)lastKFTrackedNumb;
         if (isKF) {
@@ -533,7 +543,7 @@ vslam_status vslam_system::frame_post_a(SysFrameCtx& c, const SysTrackState& st)
             SysKeys keys;
             SysSec sk;
             if (st.keys) keys_from_block(st.keys, nL, st.nR, keys);
-            else VS_CHECK(fetch_keys(keys));
+            else { VS_CHECK(fetch_keys(keys)); sys_prof().sec[14]++; }
             sk.mark(6);
             VS_CHECK(insert_keyframe(keys, matchedL, matches, tr.n_stereo, poseEst, outl, act, frame, st.keys ? st.keySlot : nullptr));
         } else {                                           // addFrame (:871-882)

@@ -186,6 +186,7 @@ struct vslam_system {
     int latestKF = -1;
     float precCheckMatches = 0.9f;
     int lastKFTrackedNumb = 0, insertKeyFrameCount = 0;
+    int lastNStereo = 1 << 30;         // nStereo of the previous tracked frame (vslam_batch: which lanes get their keys with the step's download)
     std::deque<SysKF> keyFrames;       // map->keyFrames (kIdx = size)
     std::deque<SysMP> mapPoints;       // map->mapPoints (pIdx = size)
     // the map points' HOT flags as compact arrays beside the records (MapPoint::isOutlier / inFrame, the LBAID stamp): the window
