@@ -176,7 +176,13 @@ def run_c5(args, rank, world, local, dist, torch, backend):
     fe = vc.Extractor(752, 480, 1500, device=local)
     sig, isig = fe.sigmaFactor, fe.InvSigmaFactor
     comm = None
-    if world > 1:
+    if world > 1 and backend != "nccl":
+        # rehearsal transport (VSLAM_BENCH_BACKEND=gloo): the same sharded path, the reduced camera systems all-reduced by the
+        # process group on host memory (vslam_comm_create_callback) - ranks may share one GPU
+        def allreduce(a):
+            dist.all_reduce(torch.from_numpy(a), op=dist.ReduceOp.SUM)
+        comm = vc.comm_create_callback(rank, world, local, allreduce)
+    elif world > 1:
         def bcast(b):
             obj = [b if rank == 0 else None]
             dist.broadcast_object_list(obj, src=0)
@@ -211,7 +217,8 @@ def run_c5(args, rank, world, local, dist, torch, backend):
            "allreduce_bytes_per_trial_round": (n6 * n6 + n6) * 8 * 4 + 8 * 8 if world > 1 else 0,
            "allreduce_note": "fp64 sum over xGMI of the 4 look-ahead candidates' [S | rhs] (contiguous, one call) + the cost scalars",
            "device_ms_last_ba": {k: round(v, 3) for k, v in tm.items()},
-           "final_error": r["reports"][1]["finalError"], "transport": "rccl" if world > 1 else "none (single GPU)"}
+           "final_error": r["reports"][1]["finalError"],
+           "transport": ("rccl" if backend == "nccl" else "caller-supplied all-reduce (%s, host-staged)" % backend) if world > 1 else "none (single GPU)"}
     if comm is not None:
         comm.close()
     return out

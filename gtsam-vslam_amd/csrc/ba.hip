@@ -1882,8 +1882,10 @@ struct DevBuf {
         // grow with headroom: a mapping thread serves sessions whose windows differ a little from call to call, and every
         // new maximum used to cost a hipFree (a device-wide synchronisation: it waits for the lockstep groups' kernels) +
         // hipMalloc - 1.6 ms per local BA on average at 128 sessions
+        // The floor is in BYTES (64 KB) and the headroom a factor of two: a 16-int flag block no longer takes 4 MB, a pose-slot
+        // array no longer 96 MB (the first form floored every buffer at 1 M elements: ~230 MB of HBM per optimizer thread).
         if (p) hipFree(p);
-        n = std::max<size_t>(2 * count, (size_t)1 << 20);      // (>= 1 M elements: the windows of a tracker never re-allocate)
+        n = std::max<size_t>(2 * count, ((size_t)64 << 10) / sizeof(T));
         return hipMalloc(&p, n * sizeof(T));
     }
 };
@@ -1926,7 +1928,11 @@ struct BaHostTmp {
 
 // vslam_local_ba_set_lookahead (-1: environment / default).  Like the timing switch and the workspace these belong to
 // the CALLING THREAD (one optimizer thread = one local-BA context): sessions with different settings do not interact.
-thread_local int g_baLookahead = -1, g_baSpecLin = -1, g_baMask = 1;
+thread_local int g_baLookahead = -1, g_baSpecLin = -1, g_baMask = 1, g_baSolver = -1;      // g_baSolver: -1 default (env), 0 MFMA forms, 1 wave / LDS forms
+static bool ba_use_mfma() {
+    static const bool envOff = getenv("VSLAM_BA_NO_MFMA") != nullptr;      // process-wide default; vslam_local_ba_set_solver overrides it per thread
+    return g_baSolver < 0 ? !envOff : g_baSolver == 0;
+}
 
 struct HostFac { int pair, kf, lm, fi, lp; bool right; double z[2], is; };
 
@@ -2487,7 +2493,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         if (schurLds > 160 * 1024) { set_error("local BA: landmark with too many views for the LDS staging"); return VSLAM_ERR_CAPACITY; }
         VS_CHECK(ba_kernel_attributes());
         const size_t mfmaLds = ((size_t)BA_MFMA_N * BA_MFMA_LD + 16 + BA_MFMA_N) * sizeof(double);
-        static const bool useMfma = !getenv("VSLAM_BA_NO_MFMA");
+        const bool useMfma = ba_use_mfma();
         if (n > BA_WAVE_N && n <= BA_MFMA_N && useMfma) {
             VS_HIP(d_Lg.alloc((size_t)BA_MFMA_N * BA_MFMA_N * NB));
         }
@@ -2745,7 +2751,7 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
 
     static const int nbEnv = [] { const char* e = getenv("VSLAM_BA_LOOKAHEAD"); return e ? std::max(1, std::min((int)BA_MAX_NB, atoi(e))) : (int)BA_MAX_NB; }();
     const int NB = g_baLookahead > 0 ? std::min(g_baLookahead, (int)BA_MAX_NB) : nbEnv, nSlots = NB + 1;
-    static const bool useMfma = !getenv("VSLAM_BA_NO_MFMA");
+    const bool useMfma = ba_use_mfma();
     const double relTol = 1e-5, absTol = 1e-5;
     // adaptive look-ahead (BaDev::adaptive): a round evaluates ONE lambda candidate while steps are being accepted and all NB only
     // after a rejection - the same LM trajectory; in a batch the cost of a round is the candidates it evaluates (throughput, not latency)
@@ -2791,7 +2797,7 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
     W.pool.run(N, [&](int i) {
         Lane& q = lanes[i];
         q.H.count(q.P, q.wrong.data(), 0, 1, q.T);
-        if (q.H.F > BA_LDS_MAX_F || q.H.n <= 0 || q.H.NF <= 0 || q.NP <= 0) q.single = true;
+        if (q.H.F > BA_LDS_MAX_F || q.H.n <= 0 || q.H.NF <= 0 || q.NP <= 0 || (!useMfma && q.H.n > BA_WAVE_N)) q.single = true;      // (the LDS solve lives in the one-problem path)
     });
     std::vector<int> act;
     for (int i = 0; i < N; i++) (lanes[i].single ? singles : act).push_back(i);
@@ -2978,12 +2984,16 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
         return VSLAM_OK;
     };
     double* const b_ctl = (double*)(W.h_back + oBackCtl);
-    auto lm_loop = [&]() -> vslam_status {
-        static const int perPoll = getenv("VSLAM_BA_STEPS_PER_POLL") ? std::max(1, atoi(getenv("VSLAM_BA_STEPS_PER_POLL"))) : 4;
+    // Rounds are enqueued ahead of the poll that tells whether every lane has finished: `first` rounds (a pass of m iterations needs
+    // at least m - the device skips the rounds of lanes that are done, a skipped launch costs a few microseconds, a poll a
+    // synchronisation of this stream), then two at a time.
+    auto lm_loop = [&](int first) -> vslam_status {
+        static const int perPollEnv = getenv("VSLAM_BA_STEPS_PER_POLL") ? std::max(1, atoi(getenv("VSLAM_BA_STEPS_PER_POLL"))) : 0;
         int enq = 0;
         for (;;) {
-            for (int b = 0; b < perPoll; b++) VS_CHECK(step(enq + b == 0));
-            enq += perPoll;
+            const int batch = perPollEnv ? perPollEnv : (enq == 0 ? first : 2);
+            for (int b = 0; b < batch; b++) VS_CHECK(step(enq + b == 0));
+            enq += batch;
             VS_HIP(hipMemcpyAsync(b_ctl, A.dev(h_ctlAll), (size_t)CTL_DOUBLES * 8 * NL, hipMemcpyDeviceToHost, stream));
             VS_HIP(vslam::stream_wait_blocking(stream));
             g_bbsPolls++;
@@ -3021,7 +3031,7 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
     };
     // ---- pass 1 ------------------------------------------------------------------------------------------------------------------
     BBS(2);
-    VS_CHECK(lm_loop());
+    VS_CHECK(lm_loop(5));
     report(0);
     BBS(3);
     VS_CHECK(chi2(0));
@@ -3075,7 +3085,7 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
             VS_HIP(hipMemcpyAsync(A.dev(q.H.h_kfPresent), q.H.h_kfPresent, (size_t)((q.H.h_lmPresent - q.H.h_kfPresent) + std::max(q.L, 1)), hipMemcpyHostToDevice, stream));
         }
         hipLaunchKernelGGL(k_ba_second_pass_b, dim3(std::max(1, std::min((std::max(nfMax, valMax) + 255) / 256, 64)), NL), dim3(256), 0, stream, dTab, dAux);
-        VS_CHECK(lm_loop());
+        VS_CHECK(lm_loop(6));
         report(1);
         BBS(6);
         VS_CHECK(chi2(1));
@@ -3155,6 +3165,12 @@ vslam_status vslam_local_ba_set_lookahead(int32_t candidates, int32_t speculativ
     g_baLookahead = candidates > 0 ? candidates : -1;
     g_baSpecLin = speculative_linearize < 0 ? -1 : (speculative_linearize ? 1 : 0);
     g_baMask = mask_second_pass != 0 ? 1 : 0;
+    return VSLAM_OK;
+}
+
+vslam_status vslam_local_ba_set_solver(int32_t kind) {
+    if (kind < -1 || kind > 1) return VSLAM_ERR_INVALID;
+    g_baSolver = kind;
     return VSLAM_OK;
 }
 

@@ -52,6 +52,18 @@ vslam_status comm_allreduce(const vslam_comm* c, double* dbuf, size_t n, hipStre
         if (r != 0) { set_error("ncclAllReduce failed: %s", api.GetErrorString ? api.GetErrorString(r) : "?"); return VSLAM_ERR_COMM; }
         return VSLAM_OK;
     }
+    if (c->kind == 2) {
+        // caller-supplied transport: device -> host, the caller's all-reduce, host -> device (ordered on `stream`)
+        std::vector<double>& st = const_cast<vslam_comm*>(c)->stage;
+        st.resize(n);
+        VS_HIP(hipMemcpyAsync(st.data(), dbuf, n * sizeof(double), hipMemcpyDeviceToHost, stream));
+        VS_HIP(hipStreamSynchronize(stream));
+        const int r = c->cb(c->cbCtx, st.data(), n);
+        if (r != 0) { set_error("caller-supplied all-reduce failed (status %d)", r); return VSLAM_ERR_COMM; }
+        VS_HIP(hipMemcpyAsync(dbuf, st.data(), n * sizeof(double), hipMemcpyHostToDevice, stream));
+        VS_HIP(hipStreamSynchronize(stream));
+        return VSLAM_OK;
+    }
     // local transport: device -> slot, barrier, fixed-order sum, barrier, -> device.
     // Error handling: a rank that fails never leaves early - it raises the group's `failed` flag and still passes BOTH
     // barriers, so its peers are not stranded; every rank then returns VSLAM_ERR_COMM.  (RCCL transport: a failure on
@@ -121,6 +133,14 @@ vslam_status vslam_comm_create_local(int32_t world, vslam_comm** out_array) {
         c->rank = r; c->world = world; c->kind = 1; c->grp = grp;
         out_array[r] = c;
     }
+    return VSLAM_OK;
+}
+
+vslam_status vslam_comm_create_callback(int32_t rank, int32_t world, int32_t device, vslam_allreduce_fn allreduce, void* ctx, vslam_comm** out) {
+    if (!out || !allreduce || world < 1 || rank < 0 || rank >= world) return VSLAM_ERR_INVALID;
+    vslam_comm* c = new vslam_comm();
+    c->rank = rank; c->world = world; c->device = device; c->kind = 2; c->cb = allreduce; c->cbCtx = ctx;
+    *out = c;
     return VSLAM_OK;
 }
 

@@ -1,5 +1,6 @@
-// Communicator of the landmark-sharded bundle adjustment: RCCL (one process per GPU, xGMI) or an
-// in-process "local" transport (host threads sharing one GPU, deterministic rank-order sums).
+// Communicator of the landmark-sharded bundle adjustment: RCCL (one process per GPU, xGMI), an
+// in-process "local" transport (host threads sharing one GPU, deterministic rank-order sums), or a caller-supplied
+// all-reduce on host memory (any process group the caller has: gloo, MPI - ranks in separate processes on any devices).
 #pragma once
 #include "common.hpp"
 #include <atomic>
@@ -24,9 +25,12 @@ struct vslam_local_group {
 
 struct vslam_comm {
     int rank = 0, world = 1, device = 0;
-    int kind = 0;                     // 0 = rccl, 1 = local
+    int kind = 0;                     // 0 = rccl, 1 = local, 2 = caller-supplied all-reduce (host-staged)
     void* nccl = nullptr;             // ncclComm_t
     std::shared_ptr<vslam_local_group> grp;
+    int (*cb)(void* ctx, double* host_buf, size_t n) = nullptr;      // kind 2: in-place fp64 sum over the ranks, 0 = ok
+    void* cbCtx = nullptr;
+    std::vector<double> stage;                                       // kind 2: host staging of one call
 };
 
 namespace vslam {

@@ -86,6 +86,7 @@ struct SscArgs {
     int* flags;             // per image: [2 img] error bits of the suppression, [2 img + 1] capacity overflow
 };
 
-void launch_ssc(hipStream_t s, const SscArgs& A, uint32_t* kept, int keptCap, int* keptOff, int* hostCounts);
+struct SscSide { hipStream_t a, b; hipEvent_t evFork, evA, evB; };
+void launch_ssc(hipStream_t s, const SscArgs& A, uint32_t* kept, int keptCap, int* keptOff, int* hostCounts, const SscSide* side = nullptr);
 
 }  // namespace vslam

@@ -23,6 +23,7 @@
 // (up to 65 535 candidates per level, the width of the index field).  Each (image, level) task is taken by exactly
 // one of them; the other returns at once.  There is no host path.
 #include "extract_kernels.hpp"
+#include <mutex>
 
 namespace vslam {
 
@@ -669,23 +670,37 @@ __global__ __launch_bounds__(256) void k_ssc_pack(SscArgs A, uint32_t* __restric
     }
 }
 
-void launch_ssc(hipStream_t s, const SscArgs& A, uint32_t* kept, int keptCap, int* keptOff, int* hostCounts) {
+// side (optional): two more streams + events.  The three instantiations serve disjoint (image, level) tasks, so they may run side by
+// side: the 148 KB tasks (one per CU, latency-bound chains) beside the 67 KB ones instead of after them.
+void launch_ssc(hipStream_t s, const SscArgs& A, uint32_t* kept, int keptCap, int* keptOff, int* hostCounts, const SscSide* side) {
     const size_t ldsL = ((size_t)2 * SscCfg<0>::NMAX + (size_t)4 * SscCfg<0>::SEGMAX) * 4;
     const size_t ldsS = ((size_t)2 * SscCfg<2>::NMAX + (size_t)4 * SscCfg<2>::SEGMAX) * 4;
     const size_t ldsG = ((size_t)4 * SscCfg<1>::SEGMAX + (size_t)SscCfg<1>::ARENA) * 4;
     static_assert((size_t)SscCfg<0>::NMAX + 4 * SscCfg<0>::SEGMAX >= (size_t)SscCfg<0>::ARENA, "arena must fit a | seg");
     static_assert((size_t)SscCfg<2>::NMAX + 4 * SscCfg<2>::SEGMAX >= (size_t)SscCfg<2>::ARENA, "arena must fit a | seg");
-    static bool attr = false;
-    if (!attr) {
+    static std::once_flag attr;
+    std::call_once(attr, [&] {
         (void)hipFuncSetAttribute((const void*)k_ssc<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsL);
         (void)hipFuncSetAttribute((const void*)k_ssc<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsS);
         (void)hipFuncSetAttribute((const void*)k_ssc<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsG);
-        attr = true;
-    }
+    });
     // every (image, level) task is taken by exactly one of the three; the workgroups of the other two return at once
-    hipLaunchKernelGGL(k_ssc<2>, dim3(A.nimg * A.nLevels), dim3(SSC_NT), ldsS, s, A);
-    hipLaunchKernelGGL(k_ssc<0>, dim3(A.nimg * A.nLevels), dim3(SSC_NT), ldsL, s, A);
-    hipLaunchKernelGGL(k_ssc<1>, dim3(A.nimg * A.nLevels), dim3(SSC_NT), ldsG, s, A);
+    if (side) {
+        (void)hipEventRecord(side->evFork, s);
+        (void)hipStreamWaitEvent(side->a, side->evFork, 0);
+        (void)hipStreamWaitEvent(side->b, side->evFork, 0);
+        hipLaunchKernelGGL(k_ssc<0>, dim3(A.nimg * A.nLevels), dim3(SSC_NT), ldsL, side->a, A);
+        hipLaunchKernelGGL(k_ssc<1>, dim3(A.nimg * A.nLevels), dim3(SSC_NT), ldsG, side->b, A);
+        (void)hipEventRecord(side->evA, side->a);
+        (void)hipEventRecord(side->evB, side->b);
+        hipLaunchKernelGGL(k_ssc<2>, dim3(A.nimg * A.nLevels), dim3(SSC_NT), ldsS, s, A);
+        (void)hipStreamWaitEvent(s, side->evA, 0);
+        (void)hipStreamWaitEvent(s, side->evB, 0);
+    } else {
+        hipLaunchKernelGGL(k_ssc<2>, dim3(A.nimg * A.nLevels), dim3(SSC_NT), ldsS, s, A);
+        hipLaunchKernelGGL(k_ssc<0>, dim3(A.nimg * A.nLevels), dim3(SSC_NT), ldsL, s, A);
+        hipLaunchKernelGGL(k_ssc<1>, dim3(A.nimg * A.nLevels), dim3(SSC_NT), ldsG, s, A);
+    }
     hipLaunchKernelGGL(k_ssc_pack, dim3(A.nimg), dim3(256), 0, s, A, kept, keptCap, keptOff, hostCounts);
 }
 

@@ -384,6 +384,11 @@ def local_ba_set_timing(on):
     _chk(lib().vslam_local_ba_set_timing(int(bool(on))))
 
 
+def local_ba_set_solver(kind=-1):
+    """reduced-camera solve of the calling thread's local BAs: -1 default, 0 MFMA forms, 1 wave / LDS forms"""
+    _chk(lib().vslam_local_ba_set_solver(int(kind)))
+
+
 def local_ba_set_lookahead(candidates=0, speculative_linearize=-1, mask_second_pass=1):
     """Scheduling knobs only: lambda candidates per trial round (1..4, 0 = default), speculative linearisation
     (0 / 1, -1 = default), second pass by masking instead of a host rebuild (0 / 1)."""
@@ -446,6 +451,27 @@ def comm_create_rccl(rank, world, device, broadcast_bytes):
     h = C.c_void_p()
     _chk(lib().vslam_comm_create_rccl(idbuf, rank, world, device, C.byref(h)))
     return Comm(h)
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_t)
+
+
+def comm_create_callback(rank, world, device, allreduce):
+    """Communicator over a caller-supplied collective: allreduce(array) must sum the float64 numpy array IN PLACE over the ranks
+    (e.g. torch.distributed.all_reduce on torch.from_numpy(array) with a gloo group).  The library stages the reduced camera
+    systems through the host around it, so the ranks may be separate processes sharing one GPU."""
+    def _cb(ctx, buf, n):
+        try:
+            allreduce(np.ctypeslib.as_array(buf, shape=(n,)))
+            return 0
+        except Exception:      # noqa: BLE001  (the status crosses the C boundary; the library reports VSLAM_ERR_COMM)
+            return 1
+    fn = ALLREDUCE_FN(_cb)
+    h = C.c_void_p()
+    _chk(lib().vslam_comm_create_callback(int(rank), int(world), int(device), fn, None, C.byref(h)))
+    c = Comm(h)
+    c._keep = fn      # the C side holds the function pointer for the communicator's lifetime
+    return c
 
 
 def landmark_owner(landmark_index, world):

@@ -10,10 +10,12 @@
 //   * -DVSLAM_WITH_OPENCV  : adds the cv::Mat / cv::KeyPoint overloads with the reference's exact
 //                            signatures (needs OpenCV + Eigen, which this image does not have; untested here).
 #pragma once
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 #include "vslam_hip.h"
 #ifdef VSLAM_WITH_OPENCV
@@ -26,6 +28,50 @@ namespace GTSAM_VIOSLAM_HIP {
 inline void vs_check(vslam_status s, const char* what) {
     if (s != VSLAM_OK) throw std::runtime_error(std::string(what) + ": " + vslam_last_error());
 }
+
+
+// ---- Camera / StereoCamera / CameraPose / IMUData (include/Camera.h:17-107): the fields this path reads, as plain data ---------
+// The reference fills them from its yaml ConfigFile (out of scope here: the caller sets them); matrices are row-major 4x4.
+struct CameraPose {
+    double pose[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+};
+// IMUData (include/Camera.h:43-52): noise terms + the samples between the previous frame and this one
+struct IMUData {
+    IMUData(double gyroNoiseDensity = 0, double gyroRandomWalk = 0, double accelNoiseDensity = 0, double accelRandomWalk = 0, int hz = 200)
+        : mGyroNoiseDensity(gyroNoiseDensity), mGyroRandomWalk(gyroRandomWalk), mAccelNoiseDensity(accelNoiseDensity),
+          mAccelRandomWalk(accelRandomWalk), mHz(hz) {}
+    const double mGyroNoiseDensity, mGyroRandomWalk, mAccelNoiseDensity, mAccelRandomWalk;
+    const int mHz;
+    std::vector<double> mvAccelBuffer, mvGyroBuffer;     // n x 3 each (mAcceleration / mAngleVelocity of the reference, flattened)
+    std::vector<double> mvTimestamps;                    // n, nanoseconds (mTimestamps)
+    vslam_imu_bucket bucket() const {
+        vslam_imu_bucket b{};
+        b.n = (int32_t)mvTimestamps.size(); b.acceleration = mvAccelBuffer.data(); b.angular_velocity = mvGyroBuffer.data();
+        b.timestamps_ns = mvTimestamps.data();
+        return b;
+    }
+};
+struct Camera {
+    double fx{}, fy{}, cx{}, cy{};
+    double TBodyToCam[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    std::shared_ptr<IMUData> mIMUData{nullptr};
+    double mVelocity[3] = {0, 0, 0}, mIMUGravity[3] = {0, 0, 0};
+};
+struct StereoCamera {
+    float mBaseline{}, mFps{};
+    int mWidth{}, mHeight{};
+    std::shared_ptr<Camera> mCameraLeft{nullptr}, mCameraRight{nullptr};
+    CameraPose mCameraPose;
+    StereoCamera() {}
+    StereoCamera(std::shared_ptr<Camera> cameraLeft, std::shared_ptr<Camera> cameraRight) : mCameraLeft(cameraLeft), mCameraRight(cameraRight) {}
+    vslam_rig rig() const {
+        vslam_rig r{};
+        if (!mCameraLeft) throw std::runtime_error("StereoCamera: no left camera");
+        r.fx = mCameraLeft->fx; r.fy = mCameraLeft->fy; r.cx = mCameraLeft->cx; r.cy = mCameraLeft->cy;
+        r.baseline = mBaseline; r.width = mWidth; r.height = mHeight;
+        return r;
+    }
+};
 
 // TrackedKeys (include/FeatureExtractor.h:18-50) — flat containers
 struct TrackedKeys {
@@ -61,6 +107,28 @@ class FeatureExtractor {
                                         InvSigmaFactor.data(), scaledPatchSize.data(), featurePerLevel.data()),
                  "vslam_extractor_tables");
     }
+    // The reference's constructor (include/FeatureExtractor.h:80, as src/System.cpp:56-57 calls it): parameters only.  The image
+    // size is not known yet; FeatureMatcher / FeatureTracker bind() the object to the StereoCamera's size, which creates the
+    // device extractor and fills the public tables.  (batch 1: the reference's one object per camera.)
+    FeatureExtractor(int _nfeatures = 2000, int _nLevels = 8, float _imScale = 1.2f, int _edgeThreshold = 19, int _patchSize = 31,
+                     int _maxFastThreshold = 20, int _minFastThreshold = 7)
+        : nFeatures(_nfeatures), nLevels(_nLevels), imScale(_imScale), edgeThreshold(_edgeThreshold),
+          patchSize(_patchSize), maxFastThreshold(_maxFastThreshold), minFastThreshold(_minFastThreshold),
+          width_(0), height_(0), batch_(1) {}
+    void bind(int width, int height, int device = 0) {
+        if (h_) return;
+        width_ = width; height_ = height;
+        const vslam_fe_params p = params();
+        vs_check(vslam_extractor_create(&p, width, height, batch_, device, &h_), "vslam_extractor_create");
+        scalePyramid.resize(nLevels); scaleInvPyramid.resize(nLevels); sigmaFactor.resize(nLevels);
+        InvSigmaFactor.resize(nLevels); scaledPatchSize.resize(nLevels); featurePerLevel.resize(nLevels);
+        vs_check(vslam_extractor_tables(h_, scalePyramid.data(), scaleInvPyramid.data(), sigmaFactor.data(),
+                                        InvSigmaFactor.data(), scaledPatchSize.data(), featurePerLevel.data()),
+                 "vslam_extractor_tables");
+    }
+    vslam_fe_params params() const {
+        return vslam_fe_params{nFeatures, (int32_t)nLevels, imScale, edgeThreshold, patchSize, maxFastThreshold, minFastThreshold};
+    }
     ~FeatureExtractor() { vslam_extractor_destroy(h_); }
     FeatureExtractor(const FeatureExtractor&) = delete;
     FeatureExtractor& operator=(const FeatureExtractor&) = delete;
@@ -68,6 +136,7 @@ class FeatureExtractor {
     // extractKeysNew (include/FeatureExtractor.h:87) for image `index` of the batch, u8 row-major
     void extractKeysNew(const uint8_t* gray, int stride, std::vector<vslam_keypoint>& keypoints,
                         std::vector<uint8_t>& descriptors, int index = 0) {
+        if (!h_) throw std::runtime_error("FeatureExtractor: not bound to an image size yet (FeatureMatcher / FeatureTracker bind it)");
         vs_check(vslam_extractor_set_image_host(h_, index, gray, stride), "set_image");
         if (index == batch_ - 1) vs_check(vslam_extractor_run(h_), "extractor_run");
         else return;   // the last image of the batch triggers the launches for all of them
@@ -112,10 +181,24 @@ class FeatureMatcher {
         vs_check(vslam_matcher_create(&rig, feLeft->handle(), leftIndex, feRight->handle(), rightIndex, &h_),
                  "vslam_matcher_create");
     }
+    // The reference's constructor (include/FeatureMatcher.h:40, src/System.cpp:58): binds both extractors to the camera's image size.
+    // `_imageHeight` is accepted as in the reference (its row buckets are sized from the camera's height here: the reference's
+    // default 360 would index out of range on a 480-row image).
+    FeatureMatcher(std::shared_ptr<StereoCamera> _zed, std::shared_ptr<FeatureExtractor> _feLeft, std::shared_ptr<FeatureExtractor> _feRight,
+                   const int _imageHeight = 360)
+        : feLeft(_feLeft), feRight(_feRight), zedptr(_zed), imageHeight(_imageHeight) {
+        if (!_zed || !_feLeft || !_feRight) throw std::runtime_error("FeatureMatcher: null argument");
+        feLeft->bind(_zed->mWidth, _zed->mHeight);
+        feRight->bind(_zed->mWidth, _zed->mHeight);
+        const vslam_rig rig = _zed->rig();
+        vs_check(vslam_matcher_create(&rig, feLeft->handle(), 0, feRight->handle(), 0, &h_), "vslam_matcher_create");
+    }
     ~FeatureMatcher() { vslam_matcher_destroy(h_); }
     FeatureMatcher(const FeatureMatcher&) = delete;
     FeatureMatcher& operator=(const FeatureMatcher&) = delete;
     std::shared_ptr<FeatureExtractor> feLeft, feRight;
+    std::shared_ptr<StereoCamera> zedptr{nullptr};
+    const int imageHeight{360};
 
     // findStereoMatchesORB2R (include/FeatureMatcher.h:54): fills rightIdxs / leftIdxs / estimatedDepth / close
     void findStereoMatchesORB2R(TrackedKeys& keysLeft) {
@@ -152,24 +235,17 @@ inline void localBA(const vslam_ba_problem& problem, vslam_ba_result& result, in
     vs_check(vslam_local_ba(&problem, &result, device, comm), "vslam_local_ba");
 }
 
-// IMUData (include/Camera.h): the samples between the previous frame and this one
-struct IMUData {
-    std::vector<double> mvAccelBuffer, mvGyroBuffer;     // n x 3 each
-    std::vector<double> mvTimestamps;                    // n, nanoseconds
-    vslam_imu_bucket bucket() const {
-        vslam_imu_bucket b{};
-        b.n = (int32_t)mvTimestamps.size(); b.acceleration = mvAccelBuffer.data(); b.angular_velocity = mvGyroBuffer.data();
-        b.timestamps_ns = mvTimestamps.data();
-        return b;
-    }
-};
-
 // Map (include/Map.h) + the state FeatureTracker and LocalMapper share: here ONE device-side session (vslam_system) holds
 // the map, the tracker state and - with local_mapping = 2 - the optimizer thread, so the two class shims below are
 // views of the same handle, the way the reference's objects share std::shared_ptr<Map>.
 class Map {
   public:
-    explicit Map(const vslam_system_config& cfg) { vs_check(vslam_system_create(&cfg, &h_), "vslam_system_create"); }
+    Map() {}                       // the reference's `std::make_shared<Map>()` (src/System.cpp:9): the session is created by FeatureTracker
+    explicit Map(const vslam_system_config& cfg) { create(cfg); }
+    void create(const vslam_system_config& cfg) {
+        if (h_) throw std::runtime_error("Map: the session exists already");
+        vs_check(vslam_system_create(&cfg, &h_), "vslam_system_create");
+    }
     ~Map() { vslam_system_destroy(h_); }
     Map(const Map&) = delete;
     Map& operator=(const Map&) = delete;
@@ -189,7 +265,37 @@ class Map {
 class FeatureTracker {
   public:
     explicit FeatureTracker(std::shared_ptr<Map> _map) : map(std::move(_map)) {}
+    // The reference's constructor (include/FeatureTracker.h:87, src/System.cpp:59): camera, the two extractors' parameters and the
+    // map.  Creates the map's device session from them: rig and start pose from the StereoCamera, extractor parameters from
+    // _feLeft, the IMU branch when the left camera carries IMUData (slamMode 0), the optimizer thread inside the library
+    // (local_mapping = 2, mapping_delay = k frames: see vslam_system_config; the setters below change them BEFORE construction
+    // through the static defaults, or pass a config to Map yourself).
+    FeatureTracker(std::shared_ptr<StereoCamera> _zedPtr, std::shared_ptr<FeatureExtractor> _feLeft, std::shared_ptr<FeatureExtractor> _feRight,
+                   std::shared_ptr<Map> _map, int localMapping = 2, int mappingDelay = 2, int mappingNpDelay = 1, int device = 0)
+        : map(std::move(_map)), zedPtr(_zedPtr), feLeft(_feLeft), feRight(_feRight) {
+        if (!zedPtr || !feLeft || !map) throw std::runtime_error("FeatureTracker: null argument");
+        if (!map->handle()) {
+            vslam_system_config cfg{};
+            cfg.fe = feLeft->params();
+            cfg.rig = zedPtr->rig();
+            cfg.device = device; cfg.local_mapping = localMapping; cfg.window = 10;
+            cfg.mapping_delay = mappingDelay; cfg.mapping_np_delay = mappingNpDelay;
+            std::memcpy(cfg.T_wc_init, zedPtr->mCameraPose.pose, sizeof(cfg.T_wc_init));
+            const Camera& cl = *zedPtr->mCameraLeft;
+            if (cl.mIMUData) {
+                cfg.use_imu = 1;
+                for (int k = 0; k < 3; k++) { cfg.gravity[k] = cl.mIMUGravity[k]; cfg.velocity_init[k] = cl.mVelocity[k]; }
+                cfg.gyro_noise_density = cl.mIMUData->mGyroNoiseDensity; cfg.gyro_random_walk = cl.mIMUData->mGyroRandomWalk;
+                cfg.accel_noise_density = cl.mIMUData->mAccelNoiseDensity; cfg.accel_random_walk = cl.mIMUData->mAccelRandomWalk;
+                std::memcpy(cfg.T_body_sensor, cl.TBodyToCam, sizeof(cfg.T_body_sensor));
+                cfg.imu_hz = cl.mIMUData->mHz;
+            }
+            map->create(cfg);
+        }
+    }
     std::shared_ptr<Map> map;
+    std::shared_ptr<StereoCamera> zedPtr{nullptr};
+    std::shared_ptr<FeatureExtractor> feLeft{nullptr}, feRight{nullptr};
     double lastPose[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};    // zedPtr->mCameraPose->pose after the last frame
     vslam_frame_report lastReport{};
 
@@ -202,6 +308,7 @@ class FeatureTracker {
         if (IMUDataptr) b = IMUDataptr->bucket();
         vs_check(vslam_system_track_stereo(map->handle(), leftRect, rightRect, stride, onDevice ? 1 : 0, frameNumb,
                                            IMUDataptr ? &b : nullptr, lastPose, &lastReport), "vslam_system_track_stereo");
+        if (zedPtr) std::memcpy(zedPtr->mCameraPose.pose, lastPose, sizeof(lastPose));      // zedPtr->mCameraPose (updatePoses :1699-1708)
     }
 #ifdef VSLAM_WITH_OPENCV
     void TrackImage(const cv::Mat& leftRect, const cv::Mat& rightRect, const int frameNumb, std::shared_ptr<IMUData> IMUDataptr = nullptr) {
@@ -222,10 +329,21 @@ class FeatureTracker {
 class LocalMapper {
   public:
     explicit LocalMapper(std::shared_ptr<Map> _map) : map(std::move(_map)) {}
+    // The reference's constructor (include/OptimizationBA.h:54, src/System.cpp:18)
+    LocalMapper(std::shared_ptr<Map> _map, std::shared_ptr<StereoCamera> _zedPtr, std::shared_ptr<FeatureMatcher> _fm)
+        : map(std::move(_map)), zedPtr(_zedPtr), fm(_fm), threadStyle(true) {}
     std::shared_ptr<Map> map;
-    // beginLocalMapping (:87): the reference starts its loop on a std::thread; the session already runs that loop on its
-    // own thread (vslam_system_config::local_mapping = 2) - this waits until it is idle and reports its failure, if any
-    void beginLocalMapping() { vs_check(vslam_system_wait_mapping(map->handle()), "vslam_system_wait_mapping"); }
+    std::shared_ptr<StereoCamera> zedPtr{nullptr};
+    std::shared_ptr<FeatureMatcher> fm{nullptr};
+    bool stopRequested{false};      // (the reference's flag of the same name, include/OptimizationBA.h:84; set it, then join the thread)
+    // beginLocalMapping (:87).  The session runs the optimizer's passes on its own library thread (local_mapping = 2), so this
+    // has nothing to compute.  Constructed the reference's way it is the body of `std::thread(&LocalMapper::beginLocalMapping,
+    // mLocalMapper)` (src/System.cpp:19): it stays alive like the reference's 20 ms polling loop until stopRequested, then waits
+    // for the pass in flight and reports its failure, if any.  Constructed from a Map alone it only does the latter.
+    void beginLocalMapping() {
+        if (threadStyle) while (!stopRequested) std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        if (map->handle()) vs_check(vslam_system_wait_mapping(map->handle()), "vslam_system_wait_mapping");
+    }
     // findNewPoints (:60) / localBA (:75) on flattened problems, for callers that keep their own Map
     void findNewPoints(const vslam_new_points_problem& problem, vslam_new_points_result& result, int device = 0) {
         vs_check(vslam_find_new_points(&problem, &result, device), "vslam_find_new_points");
@@ -233,6 +351,9 @@ class LocalMapper {
     void localBA(const vslam_ba_problem& problem, vslam_ba_result& result, int device = 0, const vslam_comm* comm = nullptr) {
         vs_check(vslam_local_ba(&problem, &result, device, comm), "vslam_local_ba");
     }
+
+  private:
+    bool threadStyle = false;
 };
 
 // VSlamSystem::saveTrajectoryAndPosition (src/System.cpp:87-124)

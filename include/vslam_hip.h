@@ -377,12 +377,19 @@ vslam_status vslam_save_trajectory(const char* path_trajectory, const char* path
  *   rccl  : one process per GPU, RCCL over xGMI.  Rank 0 calls vslam_comm_unique_id, the host program
  *           broadcasts the 128 bytes (e.g. torch.distributed), every rank calls vslam_comm_create_rccl.
  *   local : `world` host threads of ONE process sharing one GPU, exchanging through host memory in a
- *           fixed rank order (deterministic) — the single-box stand-in used by the tests. */
+ *           fixed rank order (deterministic) — the single-box stand-in used by the tests.
+ *   callback : see vslam_comm_create_callback below. */
 typedef struct vslam_comm vslam_comm;
 vslam_status vslam_comm_unique_id(uint8_t id_out[128]);
 vslam_status vslam_comm_create_rccl(const uint8_t id[128], int32_t rank, int32_t world, int32_t device,
                                     vslam_comm** out);
 vslam_status vslam_comm_create_local(int32_t world, vslam_comm** out_array /* world handles */);
+/* callback: the caller supplies the collective - an in-place fp64 SUM over the ranks of n doubles in HOST memory (return 0 on success);
+ *           the library stages the reduced camera systems through the host around it.  For process groups RCCL cannot serve
+ *           (several ranks on one device, gloo / MPI worlds, mixed hosts): ranks may live in separate processes on any devices. */
+typedef int (*vslam_allreduce_fn)(void* ctx, double* host_buf, size_t n);
+vslam_status vslam_comm_create_callback(int32_t rank, int32_t world, int32_t device, vslam_allreduce_fn allreduce, void* ctx,
+                                        vslam_comm** out);
 void vslam_comm_destroy(vslam_comm* comm);
 
 /* The same for n independent tracker-window problems at once (the local mapping of a lockstep group, vslam_batch): ONE kernel
@@ -410,6 +417,11 @@ int32_t vslam_local_ba_get_timing(void);      /* the calling thread's switch */
  * The settings belong to the CALLING THREAD (like the timing switch and the workspace: one optimizer thread = one
  * local-BA context), so sessions with different settings do not interact. */
 vslam_status vslam_local_ba_set_lookahead(int32_t candidates, int32_t speculative_linearize, int32_t mask_second_pass);
+/* Which reduced-camera solve serves the calling thread's following local BAs: -1 default (the MFMA forms: one wave with the
+ * 16x16 tiles in accumulators up to 64 unknowns, eight waves up to 256, block-column Cholesky beyond; VSLAM_BA_NO_MFMA in the
+ * environment flips the process default), 0 the MFMA forms, 1 the wave / LDS forms (matrix rows in registers with v_readlane
+ * pivots up to 60 unknowns, LDS / L2-resident row-per-thread Cholesky beyond).  Same arithmetic up to the summation order. */
+vslam_status vslam_local_ba_set_solver(int32_t kind);
 
 /* ---------------------------------------------------------------------------
  * New-point pipeline of the optimizer thread — replaces the numerical part of LocalMapper::findNewPoints

@@ -8,6 +8,7 @@
 // caller-supplied flattened problem.
 #include "../../include/vslam_adapter.hpp"
 #include <cstdio>
+#include <thread>
 
 using namespace GTSAM_VIOSLAM_HIP;
 
@@ -50,6 +51,75 @@ extern "C" int adapter_run(const uint8_t* frames /* n x 2 x h x w */, int n, int
         return kf;
     } catch (const std::exception& e) {
         fprintf(stderr, "adapter_run: %s\n", e.what());
+        return -1;
+    }
+}
+
+
+// ---- the reference's own construction sequence (src/System.cpp:7-60, 72-75) on the shim's classes ----------------------------------
+// A VSlamSystem as System.cpp builds it - std::make_shared<Map>(), Camera / StereoCamera, two FeatureExtractor(nFeatures, nLevels,
+// imScale, edgeThreshold, patchSize, maxFastThreshold, minFastThreshold), FeatureMatcher(zed, feL, feR), FeatureTracker(zed, feL, feR,
+// map), LocalMapper(map, zed, fm) on std::thread(&LocalMapper::beginLocalMapping, ...) - with the namespace as the only change.
+struct VSlamSystem {
+    std::shared_ptr<Map> mMap;
+    std::shared_ptr<StereoCamera> mStereoCamera;
+    std::shared_ptr<FeatureExtractor> mFeatureExtractorLeft, mFeatureExtractorRight;
+    std::shared_ptr<FeatureMatcher> mFeatureMatcher;
+    std::shared_ptr<FeatureTracker> mFeatureTracker;
+    std::shared_ptr<LocalMapper> mLocalMapper;
+    std::thread mOptimizerThread;
+    VSlamSystem(const vslam_rig& rig, int nFeatures, const double* T0) {
+        mMap = std::make_shared<Map>();
+        InitializeStereo(rig, nFeatures, T0);
+        mLocalMapper = std::make_shared<LocalMapper>(mMap, mStereoCamera, mFeatureMatcher);
+        mOptimizerThread = std::thread(&LocalMapper::beginLocalMapping, mLocalMapper);
+    }
+    void InitializeStereo(const vslam_rig& rig, int nFeatures, const double* T0) {
+        const int nLevels = 8, edgeThreshold = 19, maxFastThreshold = 20, minFastThreshold = 7, patchSize = 31;      // the "FE" block of the yaml
+        const float imScale = 1.2f;
+        auto cameraLeft = std::make_shared<Camera>();
+        auto cameraRight = std::make_shared<Camera>();
+        cameraLeft->fx = cameraRight->fx = rig.fx; cameraLeft->fy = cameraRight->fy = rig.fy;
+        cameraLeft->cx = cameraRight->cx = rig.cx; cameraLeft->cy = cameraRight->cy = rig.cy;
+        mStereoCamera = std::make_shared<StereoCamera>(cameraLeft, cameraRight);
+        mStereoCamera->mBaseline = rig.baseline; mStereoCamera->mWidth = rig.width; mStereoCamera->mHeight = rig.height;
+        memcpy(mStereoCamera->mCameraPose.pose, T0, sizeof(mStereoCamera->mCameraPose.pose));
+        mFeatureExtractorLeft = std::make_shared<FeatureExtractor>(nFeatures, nLevels, imScale, edgeThreshold, patchSize, maxFastThreshold, minFastThreshold);
+        mFeatureExtractorRight = std::make_shared<FeatureExtractor>(nFeatures, nLevels, imScale, edgeThreshold, patchSize, maxFastThreshold, minFastThreshold);
+        mFeatureMatcher = std::make_shared<FeatureMatcher>(mStereoCamera, mFeatureExtractorLeft, mFeatureExtractorRight);
+        mFeatureTracker = std::make_shared<FeatureTracker>(mStereoCamera, mFeatureExtractorLeft, mFeatureExtractorRight, mMap);
+    }
+    void TrackStereo(const uint8_t* imLRect, const uint8_t* imRRect, int stride, const int frameNumb) {
+        mFeatureTracker->TrackImage(imLRect, imRRect, stride, frameNumb);
+    }
+    void ExitSystem() {
+        mLocalMapper->stopRequested = true;
+        if (mOptimizerThread.joinable()) mOptimizerThread.join();
+    }
+    ~VSlamSystem() { ExitSystem(); }
+};
+
+extern "C" int adapter_system_run(const uint8_t* frames /* n x 2 x h x w */, int n, int w, int h, const vslam_rig* rig, int nfeat,
+                                  const double* T0, double* out /* per frame 20 doubles */, const char* trajPath) {
+    try {
+        const size_t img = (size_t)w * h;
+        VSlamSystem sys(*rig, nfeat, T0);
+        // the extractors' public tables exist after construction (src/FeatureTracker.cpp:75-79 reads them)
+        if (sys.mFeatureExtractorLeft->scalePyramid.size() != 8 || sys.mFeatureExtractorLeft->sigmaFactor[1] <= 1.f) return -2;
+        for (int f = 0; f < n; f++) {
+            sys.TrackStereo(frames + (size_t)(2 * f) * img, frames + (size_t)(2 * f + 1) * img, w, f);
+            double* o = out + (size_t)f * 20;
+            memcpy(o, sys.mStereoCamera->mCameraPose.pose, 16 * sizeof(double));
+            const vslam_frame_report& r = sys.mFeatureTracker->lastReport;
+            o[16] = r.n_inliers; o[17] = r.keyframe_inserted; o[18] = r.mapping_ran; o[19] = r.n_map_points;
+        }
+        sys.ExitSystem();
+        if (trajPath) saveTrajectoryAndPosition(*sys.mMap, trajPath, "");
+        int kf, mp, act, fr;
+        sys.mMap->counts(kf, mp, act, fr);
+        return kf;
+    } catch (const std::exception& e) {
+        fprintf(stderr, "adapter_system_run: %s\n", e.what());
         return -1;
     }
 }

@@ -18,6 +18,7 @@ def _build(tmp, shared):
     cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), SRC, "-o", out,
            "-L", LIBDIR, "-lvslam_hip", "-Wl,-rpath," + LIBDIR]
     cmd += ["-shared", "-fPIC"] if shared else ["-DVSLAM_LINK_MAIN"]
+    cmd += ["-lpthread"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout
     return out
@@ -72,3 +73,35 @@ def test_adapter_run_matches_ctypes_path(oracle, capi, tmp_path):
     assert (nL, nR, int((sf["rightIdxs"] >= 0).sum())) == tuple(st)
     got = keep["read"]()
     assert np.abs(got["kf_pose"] - ref_ba["kf_pose"]).max() < 1e-10 and np.array_equal(got["pair_wrong"], ref_ba["pair_wrong"])
+
+
+@pytest.mark.gpu
+def test_system_cpp_construction_sequence_matches_ctypes_path(capi, tmp_path):
+    """The reference's own construction sequence (src/System.cpp:7-60: make_shared<Map>(), StereoCamera, two FeatureExtractor(nFeatures,
+    nLevels, imScale, ...), FeatureMatcher(zed, feL, feR), FeatureTracker(zed, feL, feR, map), LocalMapper(map, zed, fm) on
+    std::thread(&LocalMapper::beginLocalMapping)) through the shim's reference-signature constructors, tracked frame by frame
+    against the ctypes path in the same mode (optimizer thread inside the library, mapping_delay 2 / 1)."""
+    import synth
+    so = _build(tmp_path, True)
+    L = C.CDLL(so)
+    rig = synth.RIGS["euroc"]
+    w, h = rig["w"], rig["h"]
+    fr = list(range(0, 48, 2))
+    frames = np.stack([np.stack(synth.stereo_frame(f, "euroc")[:2]) for f in fr]).astype(np.uint8)
+    T0 = np.ascontiguousarray(synth.pose_at(fr[0], rig["fps"]))
+    out = np.zeros((len(fr), 20))
+    crig = capi.make_rig(rig)
+    traj = str(tmp_path / "traj.txt")
+    L.adapter_system_run.restype = C.c_int
+    kf = L.adapter_system_run(frames.ctypes.data_as(C.c_void_p), len(fr), w, h, C.byref(crig), 1500, T0.ctypes.data_as(C.c_void_p),
+                              out.ctypes.data_as(C.c_void_p), traj.encode())
+    assert kf >= 2, kf
+    s = capi.System(rig, 1500, T0=T0, local_mapping=2, mapping_delay=2, mapping_np_delay=1)
+    ran = 0
+    for n in range(len(fr)):
+        Pg, rep = s.track(frames[n, 0], frames[n, 1], n)
+        assert np.abs(Pg.reshape(16) - out[n, :16]).max() <= 1e-9, n
+        assert (rep["n_inliers"], rep["keyframe_inserted"], rep["mapping_ran"], rep["n_map_points"]) == tuple(int(v) for v in out[n, 16:20]), n
+        ran += rep["mapping_ran"]
+    assert ran >= 1 and s.counts()["keyframes"] == kf
+    assert len(open(traj).read().splitlines()) == len(fr)

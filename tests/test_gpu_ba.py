@@ -257,3 +257,48 @@ def test_ba_batch_equals_single_calls(oracle, capi):
     ref = oracle.local_ba(rig, ex.sigmaFactor, ex.InvSigmaFactor, probs[0])
     assert [(r["iterations"], r["inner"]) for r in ref["reports"]] == [(r["iterations"], r["inner"]) for r in batch[0]["reports"]]
     assert np.abs(ref["kf_pose"] - batch[0]["kf_pose"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("n_local,n_fixed", [(10, 4), (14, 3), (24, 2)])
+def test_ba_non_mfma_solves_parity(oracle, capi, n_local, n_fixed):
+    """vslam_local_ba_set_solver(1): the reduced camera system solved WITHOUT the MFMA kernels - matrix rows in registers with
+    v_readlane pivots (60 unknowns), the LDS row-per-thread Cholesky (84 unknowns), the L2-resident one (144 unknowns) - against
+    the oracle, and against the MFMA forms of the same call: same LM trajectory, poses within the oracle comparison's bar."""
+    prob = synth.make_ba_problem(n_local=n_local, n_fixed=n_fixed, n_lm=1200, seed=41 + n_local)
+    ex = oracle.Extractor(1500)
+    ref = oracle.local_ba(prob["rig"], ex.sigmaFactor, ex.InvSigmaFactor, prob)
+    try:
+        capi.local_ba_set_solver(1)
+        a = capi.local_ba(prob["rig"], ex.sigmaFactor, ex.InvSigmaFactor, prob)
+        ab = capi.local_ba_batch(prob["rig"], ex.sigmaFactor, ex.InvSigmaFactor, [prob, prob])[1]
+        capi.local_ba_set_solver(0)
+        b = capi.local_ba(prob["rig"], ex.sigmaFactor, ex.InvSigmaFactor, prob)
+    finally:
+        capi.local_ba_set_solver(-1)
+    for o in (a, ab, b):
+        assert [(r["iterations"], r["inner"]) for r in o["reports"]] == [(r["iterations"], r["inner"]) for r in ref["reports"]]
+        assert np.abs(o["kf_pose"] - ref["kf_pose"]).max() < 1e-6
+        assert np.array_equal(o["pair_wrong"], ref["pair_wrong"])
+    assert np.abs(a["kf_pose"] - b["kf_pose"]).max() < 1e-8
+
+
+def test_ba_second_pass_rebuild_equals_masked(oracle, capi):
+    """mask_second_pass = 0 (the second graph re-sorted and re-uploaded by the host, the reference's literal second build) against the
+    default (first pass's arrays with zero weights on the rejected pairs) on a problem whose chi2 check rejects pairs: identical
+    flags of both passes and LM trajectory, poses to round-off; both within the oracle's bar."""
+    prob = synth.make_ba_problem(n_local=10, n_fixed=3, n_lm=1500, seed=77, outlier_frac=0.12)
+    ex = oracle.Extractor(1500)
+    ref = oracle.local_ba(prob["rig"], ex.sigmaFactor, ex.InvSigmaFactor, prob)
+    try:
+        capi.local_ba_set_lookahead(0, -1, 0)
+        a = capi.local_ba(prob["rig"], ex.sigmaFactor, ex.InvSigmaFactor, prob)
+        capi.local_ba_set_lookahead(0, -1, 1)
+        b = capi.local_ba(prob["rig"], ex.sigmaFactor, ex.InvSigmaFactor, prob)
+    finally:
+        capi.local_ba_set_lookahead(0, -1, 1)
+    assert ref["pair_wrong1"].sum() > 0
+    for o in (a, b):
+        assert [(r["iterations"], r["inner"]) for r in o["reports"]] == [(r["iterations"], r["inner"]) for r in ref["reports"]]
+        assert np.array_equal(o["pair_wrong1"], ref["pair_wrong1"]) and np.array_equal(o["pair_wrong"], ref["pair_wrong"])
+        assert np.abs(o["kf_pose"] - ref["kf_pose"]).max() < 1e-6
+    assert np.abs(a["kf_pose"] - b["kf_pose"]).max() < 1e-8

@@ -4,13 +4,19 @@ CPU (gloo, world_size 2): the decomposition the multi-GPU path relies on — the
 systems [S | rhs | cost] of the landmark shards, all-reduced (sum), equal the single-rank system — checked
 with the oracle's shard function over a real torch.distributed all-reduce.
 GPU: the sharded HIP path with the in-process `local` transport (2 and 3 ranks = host threads sharing
-the one GPU of the test box) and with a 1-rank RCCL communicator must reproduce the single-GPU result."""
+the one GPU of the test box), with a 1-rank RCCL communicator, and ACROSS PROCESSES (two spawned ranks sharing the GPU, the
+reduced camera systems all-reduced by torch.distributed / gloo through the caller-supplied transport) must reproduce the
+single-GPU result."""
 import os
 import sys
 import threading
 import numpy as np
 import pytest
 import synth
+# One RCCL per process: PyTorch-ROCm brings its own librccl; if this library's communicator (dlopen of librccl.so.1) comes first and
+# torch is imported afterwards, the process ends up with two copies whose exit handlers collide (glibc: "double free or corruption" at
+# interpreter exit).  Importing torch first makes the loader hand the already-loaded copy to both - bench.py does the same.
+import torch  # noqa: F401,E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -99,3 +105,59 @@ def test_sharded_ba_rccl_single_rank(oracle, capi):
     got = capi.local_ba(prob["rig"], ex.sigmaFactor, ex.InvSigmaFactor, prob, comm=comm)
     assert np.abs(got["kf_pose"] - single["kf_pose"]).max() < 1e-12
     comm.close()
+
+
+def _xproc_worker(rank, world, port, q, window):
+    sys.path.insert(0, os.path.join(ROOT, "gtsam-vslam_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+    import torch.distributed as dist
+    import pyoracle as po
+    import synth as sy
+    import vslam_capi as vc
+    try:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+        ex = po.Extractor(1500)
+        if window == "c5":      # the C5 window shape at a size the test finishes in seconds: 62 free keyframes, windowed Schur + block-column Cholesky
+            prob = sy.make_ba_problem_c5(n_lm=4000)
+        else:
+            prob = sy.make_ba_problem(n_local=10, n_fixed=4, n_lm=1500, seed=31)
+
+        def allreduce(a):
+            t = torch.from_numpy(a)                      # (shares the buffer: summed in place)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        comm = vc.comm_create_callback(rank, world, 0, allreduce)
+        got = vc.local_ba(prob["rig"], ex.sigmaFactor, ex.InvSigmaFactor, prob, comm=comm)
+        comm.close()
+        single = vc.local_ba(prob["rig"], ex.sigmaFactor, ex.InvSigmaFactor, prob) if rank == 0 else None
+        q.put((rank, "ok", got["kf_pose"], got["pair_wrong"], [(r["iterations"], r["inner"], r["finalError"]) for r in got["reports"]],
+               None if single is None else (single["kf_pose"], single["pair_wrong"], [(r["iterations"], r["inner"], r["finalError"]) for r in single["reports"]])))
+        dist.destroy_process_group()
+    except Exception as e:      # noqa: BLE001
+        q.put((rank, "error: %s: %s" % (type(e).__name__, e), None, None, None, None))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("window", ["tracker", "c5"])
+def test_sharded_ba_across_processes_gloo_callback_transport(window):
+    """Two PROCESSES, one GPU: each rank runs the HIP landmark-sharded BA (lm % 2 == rank) and the partial reduced camera systems of
+    every trial round travel through a real process-group all-reduce (gloo, host-staged by vslam_comm_create_callback) - the
+    cross-process execution of the path RCCL serves on a multi-GPU node (RCCL refuses two ranks on one device).  Both ranks must
+    return the identical result, equal to the single-GPU one."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_xproc_worker, args=(r, 2, port, q, window)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in procs), key=lambda v: v[0])
+    for p in procs:
+        p.join(timeout=120)
+    assert [v[1] for v in res] == ["ok", "ok"], [v[1] for v in res]
+    (_, _, pose0, wrong0, rep0, single), (_, _, pose1, wrong1, rep1, _) = res
+    assert np.array_equal(pose0, pose1) and np.array_equal(wrong0, wrong1)          # every rank returns the identical result
+    spose, swrong, srep = single
+    assert [(a, b) for a, b, _ in rep0] == [(a, b) for a, b, _ in srep]
+    for (_, _, e), (_, _, es) in zip(rep0, srep):
+        assert abs(e - es) <= 1e-8 * max(es, 1.0)
+    assert np.abs(pose0 - spose).max() < 1e-8 and np.array_equal(wrong0, swrong)
