@@ -1981,20 +1981,34 @@ struct BaPassHost {
     BaEdge* h_edges = nullptr; uint8_t *h_kfPresent = nullptr, *h_lmPresent = nullptr;
 
     // membership, free set, landmark shard, factor counts
-    void count(const vslam_ba_problem* P, const uint8_t* wrong, int rank, int world, BaHostTmp& T) {
+    // Large problems (the C5 window: 1.2 M pairs) split the pair scans over the pool by LANDMARK RANGE: every worker reads all pairs
+    // and handles those whose landmark falls in its range - no atomics, the pair order inside a landmark is kept.
+    static int par_ranges(const BaPool* pool, int NP, int L) { return (pool && !pool->workers.empty() && NP >= 200000) ? std::min((int)pool->workers.size() + 1, std::max(1, L / 4096)) : 1; }
+    void count(const vslam_ba_problem* P, const uint8_t* wrong, int rank, int world, BaHostTmp& T, BaPool* pool = nullptr) {
         const int K = P->n_kf, L = P->n_lm, NP = P->n_pairs;
         T.kfPresent.assign(K, 0); T.lmPresent.assign(L, 0); T.cnt.assign((size_t)L + 1, 0);
         NF = 0;
-        for (int p = 0; p < NP; p++) {
-            if (wrong[p]) continue;
-            const int fl = P->pair_flags[p] & 3;
-            if (!fl) continue;
-            const int l = P->pair_lm[p];
-            T.kfPresent[P->pair_kf[p]] = 1; T.lmPresent[l] = 1;       // graph membership is global
-            if (l % world != rank) continue;                           // landmark shard of this rank
-            const int c = (fl & 1) + (fl >> 1);
-            T.cnt[l] += c; NF += c;
-        }
+        const int nr = par_ranges(pool, NP, L);
+        std::vector<long long> nfPart(nr, 0);
+        std::vector<std::vector<uint8_t>> kfPart(nr > 1 ? nr : 0);
+        auto scan = [&](int r) {
+            const int l0 = (int)((long long)L * r / nr), l1 = (int)((long long)L * (r + 1) / nr);
+            uint8_t* kfp = nr > 1 ? (kfPart[r].assign(K, 0), kfPart[r].data()) : T.kfPresent.data();
+            long long nf = 0;
+            for (int p = 0; p < NP; p++) {
+                const int l = P->pair_lm[p];
+                if (l < l0 || l >= l1 || wrong[p]) continue;
+                const int fl = P->pair_flags[p] & 3;
+                if (!fl) continue;
+                kfp[P->pair_kf[p]] = 1; T.lmPresent[l] = 1;             // graph membership is global
+                if (l % world != rank) continue;                           // landmark shard of this rank
+                const int c = (fl & 1) + (fl >> 1);
+                T.cnt[l] += c; nf += c;
+            }
+            nfPart[r] = nf;
+        };
+        if (nr > 1) pool->run(nr, scan); else scan(0);
+        for (int r = 0; r < nr; r++) { NF += (int)nfPart[r]; if (nr > 1) for (int k = 0; k < K; k++) T.kfPresent[k] |= kfPart[r][k]; }
         T.fidx.assign(K, -1);
         F = 0;
         for (int k = 0; k < K; k++) if (T.kfPresent[k] && !P->kf_fixed[k]) T.fidx[k] = F++;
@@ -2038,17 +2052,23 @@ struct BaPassHost {
         }
         T.fill.assign(h_lpStart, h_lpStart + Lp);
         T.key.resize(NF); T.src.resize(NF);
-        for (int p = 0; p < NP; p++) {
-            if (wrong[p]) continue;
-            const int l = P->pair_lm[p];
-            if (l % world != rank) continue;
-            const int lp = T.lpOf[l];
-            const int fi = T.fidx[P->pair_kf[p]];
-            for (int side = 0; side < 2; side++) {
-                if (!((P->pair_flags[p] >> side) & 1)) continue;
-                const int pos = T.fill[lp]++;
-                T.key[pos] = fi; T.src[pos] = 2 * p + side;
-            }
+        {
+            const int nr = par_ranges(pool, NP, L);
+            auto scatter = [&](int r) {
+                const int l0 = (int)((long long)L * r / nr), l1 = (int)((long long)L * (r + 1) / nr);
+                for (int p = 0; p < NP; p++) {
+                    const int l = P->pair_lm[p];
+                    if (l < l0 || l >= l1 || wrong[p] || l % world != rank) continue;
+                    const int lp = T.lpOf[l];
+                    const int fi = T.fidx[P->pair_kf[p]];
+                    for (int side = 0; side < 2; side++) {
+                        if (!((P->pair_flags[p] >> side) & 1)) continue;
+                        const int pos = T.fill[lp]++;
+                        T.key[pos] = fi; T.src[pos] = 2 * p + side;
+                    }
+                }
+            };
+            if (nr > 1) pool->run(nr, scatter); else scatter(0);
         }
         // landmark ranges in parallel: (1) order each bucket by free index and count its slots, (2) after the slot prefix,
         // write the factor arrays and the slot table.
@@ -2207,7 +2227,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         VS_HIP(vslam::create_side_stream(&ws->stream));
         VS_HIP(hipHostMalloc((void**)&ws->h_ctlOut, CTL_DOUBLES * sizeof(double), hipHostMallocDefault));
         {
-            int nt = 3;      // + the calling thread; VSLAM_BA_HOST_THREADS overrides (0 = none)
+            int nt = 7;      // + the calling thread; VSLAM_BA_HOST_THREADS overrides (0 = none).  (C5-size problems: 52 -> 43 ms per BA with 4 threads, 35 with 8)
             if (const char* e = getenv("VSLAM_BA_HOST_THREADS")) nt = std::max(0, std::min(15, atoi(e)));
             ws->pool.start(nt);
         }
@@ -2321,7 +2341,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         // ---- host: factor list of this pass, ordered by (landmark, free index, pair, side) -----------
         // Everything the kernels read is written straight into ONE pinned arena and uploaded with one copy.
         BaPassHost H;
-        H.count(P, wrong.data(), rank, world, T);
+        H.count(P, wrong.data(), rank, world, T, &ws->pool);
         const int NF = H.NF, F = H.F, n = H.n, Lp = H.Lp, NE = H.NE;
         VS_HIP(A.ensure(H.arena_bytes(K, L, specLin ? nSlots : 1), stream));
         A.reset();
@@ -2342,6 +2362,9 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         const bool adaptive = NB > 1 && (adaptEnv >= 0 ? adaptEnv != 0 : NF > 200000);
         auto init_ctl = [&](int ps) { ba_init_ctl(h_ctl, ps, adaptive ? 1 : NB); };
         init_ctl(pass);
+        // The arena is complete except for the kernels' argument block (h_D, written after the launch geometry below): its upload
+        // starts now and runs under the host work that follows (the window lists of a large problem); h_D follows as a copy of its own.
+        VS_HIP(A.upload(stream));
         BHS("prep");
 
         // ---- device buffers, argument block, then ONE upload ----------------------------------------------
@@ -2414,28 +2437,51 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
             auto win_of = [nBR](int a, int b2) { return a * nBR - a * (a - 1) / 2 + (b2 - a); };     // a <= b2
             std::vector<int> winA(nWin), winB(nWin), winCnt((size_t)nWin + 1, 0);
             for (int a2 = 0; a2 < nBR; a2++) for (int b2 = a2; b2 < nBR; b2++) { winA[win_of(a2, b2)] = a2; winB[win_of(a2, b2)] = b2; }
-            // block rows touched by every landmark (its slots are sorted by free index)
-            std::vector<int> lmRows;                 // concatenated distinct block rows per landmark
-            std::vector<int> lmRowStart((size_t)Lp + 1, 0);
-            lmRows.reserve((size_t)Lp * 3);
-            for (int lp = 0; lp < Lp; lp++) {
-                lmRowStart[lp] = (int)lmRows.size();
-                int last = -1;
+            // Per landmark the distinct block rows of its slots (sorted by free index); every pair (i <= j) of them is one entry of
+            // window (row_i, row_j).  Landmark chunks run on the pool: each counts its entries per window, a prefix over (window,
+            // chunk) gives every chunk its own segment of every window's list - the same order as one sequential sweep.
+            const int nCh = (!ws->pool.workers.empty() && Lp >= 16384) ? std::min(32, Lp / 2048) : 1;
+            std::vector<int> chCnt((size_t)nCh * nWin, 0);
+            auto lm_rows = [&](int lp, int* rows) {
+                int nr = 0, last = -1;
                 for (int se = h_lpSlotStart[lp]; se < h_lpSlotStart[lp + 1] - 1; se++) {
                     const int br = h_slotFi[se] / TB;
-                    if (br != last) { lmRows.push_back(br); last = br; }
+                    if (br != last) { rows[nr++] = br; last = br; }
                 }
+                return nr;
+            };
+            auto ch_range = [&](int c, int& a0, int& a1) { a0 = (int)((long long)Lp * c / nCh); a1 = (int)((long long)Lp * (c + 1) / nCh); };
+            auto count_chunk = [&](int c) {
+                int a0, a1, rows[64];
+                ch_range(c, a0, a1);
+                int* cnt = &chCnt[(size_t)c * nWin];
+                for (int lp = a0; lp < a1; lp++) {
+                    const int nr = lm_rows(lp, rows);
+                    for (int i = 0; i < nr; i++) for (int j = i; j < nr; j++) cnt[win_of(rows[i], rows[j])]++;
+                }
+            };
+            if (nCh > 1) ws->pool.run(nCh, count_chunk); else count_chunk(0);
+            std::vector<int> chOff((size_t)nCh * nWin);
+            {
+                int run = 0;
+                for (int w = 0; w < nWin; w++) {
+                    winCnt[w] = run;
+                    for (int c = 0; c < nCh; c++) { chOff[(size_t)c * nWin + w] = run; run += chCnt[(size_t)c * nWin + w]; }
+                }
+                winCnt[nWin] = run;
             }
-            lmRowStart[Lp] = (int)lmRows.size();
-            for (int lp = 0; lp < Lp; lp++)
-                for (int i = lmRowStart[lp]; i < lmRowStart[lp + 1]; i++)
-                    for (int j = i; j < lmRowStart[lp + 1]; j++) winCnt[win_of(lmRows[i], lmRows[j]) + 1]++;
-            for (int w = 0; w < nWin; w++) winCnt[w + 1] += winCnt[w];
             const int total = winCnt[nWin];
-            std::vector<int> winLm((size_t)std::max(total, 1)), fill(winCnt.begin(), winCnt.end() - 1);
-            for (int lp = 0; lp < Lp; lp++)
-                for (int i = lmRowStart[lp]; i < lmRowStart[lp + 1]; i++)
-                    for (int j = i; j < lmRowStart[lp + 1]; j++) winLm[fill[win_of(lmRows[i], lmRows[j])]++] = lp;
+            std::vector<int> winLm((size_t)std::max(total, 1));
+            auto fill_chunk = [&](int c) {
+                int a0, a1, rows[64];
+                ch_range(c, a0, a1);
+                int* off = &chOff[(size_t)c * nWin];
+                for (int lp = a0; lp < a1; lp++) {
+                    const int nr = lm_rows(lp, rows);
+                    for (int i = 0; i < nr; i++) for (int j = i; j < nr; j++) winLm[off[win_of(rows[i], rows[j])]++] = lp;
+                }
+            };
+            if (nCh > 1) ws->pool.run(nCh, fill_chunk); else fill_chunk(0);
             // workgroups: a window's list is cut into chunks of >= 256 entries, ~2 workgroups per CU overall
             const int chunk = std::max(256, (total + 2 * nCU - 1) / (2 * nCU));
             std::vector<int> wgWin, wgBegin, wgEnd, winFirst((size_t)nWin + 1, 0);
@@ -2513,7 +2559,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         D.solveKind = (n <= 64 && useMfma) ? BA_SOLVE_MFMA64 : n <= BA_WAVE_N ? BA_SOLVE_WAVE : (n <= BA_MFMA_N && useMfma) ? BA_SOLVE_MFMA : BA_SOLVE_LARGE;
         *h_D = D;
         const BaDev* const dD = A.dev(h_D);
-        VS_HIP(A.upload(stream));
+        VS_HIP(hipMemcpyAsync((void*)dD, h_D, sizeof(BaDev), hipMemcpyHostToDevice, stream));
         BHS("upload");
 
         // ---- LM: speculative steps, the device decides (k_ba_ctl) -----------------------------------
