@@ -631,6 +631,163 @@ __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void k_ba_schur(const BaDev* _
     }
 }
 
+// ---- k_ba_schur2: the accumulation for tracker windows (<= BA2_MAX_F free keyframes), written against the instruction counters -------
+// k_ba_schur above spends ~2 700 VALU wave-instructions per landmark for ~100 of arithmetic (PMC pass): a wave per landmark
+// that walks its factors through dependent global loads, reduces nine values with 108 ds_bpermute, and spreads 36-entry blocks over
+// lanes with division / modulo chains.  This form keeps the wave per landmark but gives every LANE a whole unit of work:
+//   stage   the landmark's factor rows are contiguous in facJ (the host sorts by landmark, then free index): one coalesced copy into a
+//           wave-private LDS region, with the free indices and the slot table - ONE global round trip per landmark;
+//   h       Hll (6) | bl (3): lane 4k + q sums the factors f = q (mod 4) of value k from LDS, two DPP quad steps finish it;
+//   W, WH   lane (s, i) < 6 ns builds row i of the slot's Hpl block and of Hpl (Hll + lambda I)^-1, and adds its right-hand-side entry;
+//   blocks  two lanes own ONE 6x6 block (s1 <= s2), three rows each: the rows of WH_s1 / W_s2 in registers, 54 multiply-adds, 18 LDS
+//           atomics at constant offsets from one base address - no per-entry index arithmetic;
+//   Hpp     lane (f, i) owns row i of the factor's Jp^T Jp (upper part) and its gradient entry.
+// One LDS copy of the reduced system per workgroup; the look-ahead candidates are separate workgroups (grid y; candidates beyond the
+// round's nAct leave at once).
+constexpr int BA2_MAX_F = 10;
+__host__ __device__ inline int ba2_stage_doubles(int maxFac, int maxSlots) {
+    const int ints = maxFac + 2 * (maxSlots + 1);
+    return ((maxFac * 20 + 2 * maxSlots * 18 + 10 + (ints + 1) / 2) + 1) & ~1;        // even: rows are copied as double2
+}
+__device__ __forceinline__ double ba2_dpp_xor(double v, int which) {      // lane ^ 1 (which = 0) / lane ^ 2 (which = 1) inside a quad
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    int l2, h2;
+    if (which == 0) { l2 = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true); h2 = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true); }
+    else { l2 = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true); h2 = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true); }
+    return __hiloint2double(h2, l2);
+}
+__global__ __launch_bounds__(1024) void k_ba_schur2(const BaDev* __restrict__ tab, int maxSlots, int maxFac) {
+    BaDev D = *lane_entry(tab, blockIdx.z);      // per-lane argument block (grid z = problem of the cohort)
+    extern __shared__ double sm[];
+    if (!ba_enter(D, BA_TRY, blockIdx.y)) return;
+    const int n = D.n;
+    const int sys = n * n + n;
+    double* const Sloc = sm;
+    double* const racc = Sloc + (size_t)n * n;
+    const int lane = threadIdx.x & 63;
+    const int unit = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nu = blockDim.x >> 6, nt = blockDim.x;
+    double* const base = sm + sys + (size_t)unit * ba2_stage_doubles(maxFac, maxSlots);
+    double* const F = base;
+    double* const W = F + maxFac * 20;
+    double* const WH = W + maxSlots * 18;
+    double* const hb = WH + maxSlots * 18;               // h[0..8]
+    int* const ffi = (int*)(hb + 10);
+    int* const sst = ffi + maxFac;
+    int* const sfi = sst + maxSlots + 1;
+    const double lam = D.lambda;
+    // ---- per-lane roles (fixed for the kernel) ----
+    // h: lane 4k + q, k < 9
+    const int hk = lane >> 2, hq = lane & 3;
+    const bool hOn = hk < 9;
+    int hx = 0, hy = 0;                    // offsets inside a factor row of the two operand pairs: x at (hx, hx + 3), y at (hy, hy + ...)
+    {
+        // k < 6: (a, b) in (0,0) (0,1) (0,2) (1,1) (1,2) (2,2): Jl[a] Jl[b] + Jl[3 + a] Jl[3 + b];  k >= 6: -(Jl[a] r0 + Jl[3 + a] r1), a = k - 6
+        const int ha = hk < 3 ? 0 : (hk < 5 ? 1 : (hk == 5 ? 2 : hk - 6));
+        const int hbx = hk < 3 ? hk : (hk < 5 ? hk - 2 : 2);
+        hx = 14 + ha;
+        hy = hk < 6 ? 14 + hbx : 0;
+    }
+    const int hyStep = hk < 6 ? 3 : 1;     // second operand of the second product: Jl[3 + b] or r1
+    const double hSign = hk < 6 ? 1.0 : -1.0;
+    // W / WH: lane (s, i)
+    const int ws = lane / 6, wi = lane - ws * 6;
+    // Hpp: lane (f, i), two factors' worth of rows per pass would need 12 lanes each: lane / 6 = factor within the pass
+    const int pf = lane / 6, pi = lane - pf * 6;           // pf < 10: ten factors per pass
+    for (int i = threadIdx.x; i < sys; i += nt) Sloc[i] = 0;
+    __syncthreads();
+    for (int lp = blockIdx.x * nu + unit; lp < D.Lp; lp += gridDim.x * nu) {
+        const int f0 = D.lpStart[lp], s0 = D.lpSlotStart[lp];
+        const int nf = D.lpStart[lp + 1] - f0;
+        const int ns = D.lpSlotStart[lp + 1] - s0 - 1;     // one end sentinel per landmark
+        // ---- stage ----  (prefetching the next landmark's rows into registers under this one's arithmetic was measured: no gain -
+        //                   the kernel is bound by its VALU instruction count, ~1 100 per landmark, not by this round trip)
+        {
+            const double2* src = (const double2*)(D.facJ + (size_t)f0 * 20);
+            double2* dst = (double2*)F;
+            for (int i = lane; i < nf * 10; i += 64) dst[i] = src[i];
+            for (int i = lane; i < nf; i += 64) ffi[i] = D.facFi[f0 + i];
+            for (int i = lane; i <= ns; i += 64) { sst[i] = D.slotStart[s0 + i] - f0; sfi[i] = D.slotFi[s0 + i]; }
+        }
+        ba_wave_fence();
+        // ---- h ----
+        {
+            double acc = 0;
+            if (hOn)
+                for (int f = hq; f < nf; f += 4) {
+                    const double* o = F + f * 20;
+                    acc += o[hx] * o[hy] + o[hx + 3] * o[hy + hyStep];
+                }
+            acc += ba2_dpp_xor(acc, 0);
+            acc += ba2_dpp_xor(acc, 1);
+            if (hOn && hq == 0) hb[hk] = hSign * acc;
+        }
+        ba_wave_fence();
+        double h[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) h[k] = hb[k];
+        double Hi[9];
+        ba_hll_inverse(h, lam, Hi);
+        // ---- W, WH, rhs: lane (s, i) ----
+        if (ws < ns) {
+            double w0 = 0, w1 = 0, w2 = 0;
+            for (int f = sst[ws]; f < sst[ws + 1]; f++) {
+                const double* o = F + f * 20;
+                const double a0 = o[2 + wi], a1 = o[8 + wi];
+                w0 += a0 * o[14] + a1 * o[17];
+                w1 += a0 * o[15] + a1 * o[18];
+                w2 += a0 * o[16] + a1 * o[19];
+            }
+            const double g0 = w0 * Hi[0] + w1 * Hi[3] + w2 * Hi[6], g1 = w0 * Hi[1] + w1 * Hi[4] + w2 * Hi[7], g2 = w0 * Hi[2] + w1 * Hi[5] + w2 * Hi[8];
+            double* wr = W + ws * 18 + wi * 3;
+            wr[0] = w0; wr[1] = w1; wr[2] = w2;
+            double* gr = WH + ws * 18 + wi * 3;
+            gr[0] = g0; gr[1] = g1; gr[2] = g2;
+            atomicAdd(&racc[6 * sfi[ws] + wi], -(g0 * h[6] + g1 * h[7] + g2 * h[8]));
+        }
+        ba_wave_fence();
+        // ---- blocks: two lanes own one 6x6 block (s1 <= s2), three rows each; 32 blocks per pass ----
+        {
+            const int nb = ns * (ns + 1) / 2, half = lane & 1;
+            for (int b0 = 0; b0 < nb; b0 += 32) {
+                int b = b0 + (lane >> 1), s1 = 0;
+                if (b >= nb) continue;
+                while (b >= ns - s1) { b -= ns - s1; s1++; }
+                const int s2 = s1 + b;
+                const double* A = WH + s1 * 18 + half * 9;
+                const double* B = W + s2 * 18;
+                double bb[18];
+#pragma unroll
+                for (int q = 0; q < 18; q++) bb[q] = B[q];
+                double* d0 = Sloc + (6 * sfi[s1] + 3 * half) * n + 6 * sfi[s2];
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    const double a0 = A[3 * i], a1 = A[3 * i + 1], a2 = A[3 * i + 2];
+                    double* dr = d0 + i * n;
+#pragma unroll
+                    for (int j = 0; j < 6; j++) atomicAdd(dr + j, -(a0 * bb[3 * j] + a1 * bb[3 * j + 1] + a2 * bb[3 * j + 2]));
+                }
+            }
+        }
+        // ---- Hpp and bp of the factors of free keyframes: lane (f, i), ten factors per pass ----
+        if (pf < 10)
+            for (int fb = 0; fb < nf; fb += 10) {
+                const int f = fb + pf;
+                if (f >= nf) break;
+                const int fi = ffi[f];
+                if (fi < 0) continue;
+                const double* o = F + f * 20;
+                const double a0 = o[2 + pi], a1 = o[8 + pi];
+                double* dr = Sloc + (6 * fi + pi) * n + 6 * fi;
+                for (int j = pi; j < 6; j++) atomicAdd(dr + j, a0 * o[2 + j] + a1 * o[8 + j]);
+                atomicAdd(&racc[6 * fi + pi], -(a0 * o[0] + a1 * o[1]));
+            }
+        ba_wave_fence();        // the region is rewritten for the next landmark
+    }
+    __syncthreads();
+    double* dst = D.Spart + (size_t)blockIdx.x * sys;
+    for (int i = threadIdx.x; i < sys; i += nt) dst[i] = Sloc[i];
+}
+
 // Sum of the per-workgroup partial systems.  This is the buffer the landmark-sharded multi-GPU path all-reduces (RCCL)
 // before the solve.  A workgroup owns 32 entries; 8 thread groups sum slices of the partials, the 8 slice sums are
 // then added in slice order through LDS - a fixed summation order, no atomics: the reduced system is bit-identical
@@ -1813,37 +1970,46 @@ struct BaLaneAux {
     int nPose, nLm; const double* pose0; const double* lm0;     // k_ba_init_slots over the lane's NB + 1 slots
     double* outPose; double* outLm;                 // final values, gathered for one download
 };
+// (the lane's BaChi block stays in the constant-addressed table - thr[oct] is indexed there: a by-value copy of the struct put its
+//  threshold array in scratch, 192 bytes per lane)
+__device__ __forceinline__ bool ba_outlier_at(const BaChi& C, const double* pc, float ou, float ov, int oct, bool right) {
+    const double x = right ? pc[0] - C.b : pc[0], y = pc[1], z = pc[2];
+    if (z <= 0) return true;
+    const double px = C.fx * x + C.cx * z, py = C.fy * y + C.cy * z;
+    const double eu = (double)ou - px / z, ev = (double)ov - py / z;
+    return (eu * eu + ev * ev) > (double)C.thr[oct];
+}
 __global__ __launch_bounds__(256) void k_ba_chi2_b(const BaDev* __restrict__ tab, const BaLaneAux* __restrict__ aux, int gather) {
     const BaDev& D = *lane_entry(tab, blockIdx.y);
-    BaChi C = lane_entry(aux, blockIdx.y)->C;
+    const BaLaneAux& X = *lane_entry(aux, blockIdx.y);
+    const BaChi& C = X.C;
     const int* ci = (const int*)(D.ctl + CTL_INTS);
     if (ci[CI_STATE] != BA_DONE) return;             // (lanes handed to the one-problem path keep BA_LINEARIZE / are skipped by the host)
     const int sel = ci[CI_SEL];
-    C.pose = D.poseBase + (size_t)sel * D.K; C.lm = D.lmBase + (size_t)sel * D.lmStride;
+    const DPose* const pose = D.poseBase + (size_t)sel * D.K;
+    const double* const lmv = D.lmBase + (size_t)sel * D.lmStride;
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (gather) {                                    // the pass's result next to its flags
-        const BaLaneAux& X = *lane_entry(aux, blockIdx.y);
-        for (int i = p; i < X.nPose; i += gridDim.x * 256) X.outPose[i] = ((const double*)C.pose)[i];
-        for (int i = p; i < X.nLm; i += gridDim.x * 256) X.outLm[i] = C.lm[i];
+        for (int i = p; i < X.nPose; i += gridDim.x * 256) X.outPose[i] = ((const double*)pose)[i];
+        for (int i = p; i < X.nLm; i += gridDim.x * 256) X.outLm[i] = lmv[i];
     }
     if (p >= C.NP) return;
     uint8_t w = 0;
     const int kf = C.pairKf[p], lm = C.pairLm[p], fl = C.pairFlags[p];
     if (C.kfLocal[kf] && C.kfPresent[kf] && C.lmPresent[lm] && (fl & 3)) {
         DPose Tcw;
-        pose_inverse(C.pose[kf], Tcw);
+        pose_inverse(pose[kf], Tcw);
         double pc[3];
-        mat3_vec(Tcw.R, C.lm + 3 * (size_t)lm, pc);
+        mat3_vec(Tcw.R, lmv + 3 * (size_t)lm, pc);
         for (int i = 0; i < 3; i++) pc[i] += Tcw.t[i];
         const float* uv = C.pairUv + 4 * (size_t)p;
         if (fl & 1) {
-            if (ba_outlier(C, pc, uv[0], uv[1], C.pairOct[2 * p], false)) w = 1;
-            else if ((fl & 2) && ba_outlier(C, pc, uv[2], uv[3], C.pairOct[2 * p + 1], true)) w = 1;
-        } else if (ba_outlier(C, pc, uv[2], uv[3], C.pairOct[2 * p + 1], true)) w = 1;
+            if (ba_outlier_at(C, pc, uv[0], uv[1], C.pairOct[2 * p], false)) w = 1;
+            else if ((fl & 2) && ba_outlier_at(C, pc, uv[2], uv[3], C.pairOct[2 * p + 1], true)) w = 1;
+        } else if (ba_outlier_at(C, pc, uv[2], uv[3], C.pairOct[2 * p + 1], true)) w = 1;
     }
     C.wrong[p] = w;
 }
-// second pass of every lane that takes it: mask the rejected pairs' factors, values back to the caller's in every slot
 __global__ __launch_bounds__(256) void k_ba_second_pass_b(const BaDev* __restrict__ tab, const BaLaneAux* __restrict__ aux) {
     const BaDev& D = *lane_entry(tab, blockIdx.y);
     const BaLaneAux& X = *lane_entry(aux, blockIdx.y);
@@ -2144,7 +2310,8 @@ static vslam_status ba_kernel_attributes() {
     std::call_once(once, [] {
         const int cap = 160 * 1024;
         const void* fns[] = {(const void*)k_ba_schur, (const void*)k_ba_schur_win, (const void*)k_ba_solve, (const void*)k_ba_back,
-                             (const void*)k_ba_solve_mfma, (const void*)k_ba_chol_col, (const void*)k_ba_chol_back, (const void*)k_ba_lm_prep};
+                             (const void*)k_ba_solve_mfma, (const void*)k_ba_chol_col, (const void*)k_ba_chol_back, (const void*)k_ba_lm_prep,
+                             (const void*)k_ba_schur2};
         for (const void* f : fns) {
             hipFuncAttributes fa{};      // (the limit is on static + dynamic LDS together)
             hipError_t e = hipFuncGetAttributes(&fa, f);
@@ -2885,10 +3052,11 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
     });
     BBS(1);
     // ---- launch geometry shared by the lanes ---------------------------------------------------------------------------
-    int maxSlots = 1, nMax = 0, neMax = 0, nfMax = 0, lpMax = 0, npMax = 0, valMax = 0;
+    int maxSlots = 1, maxFac = 1, fMax = 0, nMax = 0, neMax = 0, nfMax = 0, lpMax = 0, npMax = 0, valMax = 0;
     bool anyMfma64 = false, anyWave = false, anyMfma = false;
     for (int i : act) {
         const Lane& q = lanes[i];
+        maxFac = std::max(maxFac, q.H.maxFac); fMax = std::max(fMax, q.H.F);
         maxSlots = std::max(maxSlots, q.H.maxSlots); nMax = std::max(nMax, q.H.n); neMax = std::max(neMax, q.H.NE);
         nfMax = std::max(nfMax, q.H.NF); lpMax = std::max(lpMax, q.H.Lp); npMax = std::max(npMax, q.NP);
         valMax = std::max(valMax, std::max(q.K * (int)(sizeof(DPose) / sizeof(double)), 3 * q.L));
@@ -2910,6 +3078,17 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
     const int schurUnits = schurWaves * SCHUR_LPW;
     const int lbEnv = getenv("VSLAM_BA_LMBLOCKS") ? atoi(getenv("VSLAM_BA_LMBLOCKS")) : 0;
     int lmBlocks = std::max(1, std::min((lpMax + schurUnits - 1) / schurUnits, lbEnv ? lbEnv : std::max(16, 2 * nCU / NL)));
+    // k_ba_schur2 (tracker windows): one LDS copy of the system + a staging region per landmark-wave
+    static const bool s2Env = !(getenv("VSLAM_BA_SCHUR2") && atoi(getenv("VSLAM_BA_SCHUR2")) == 0);
+    const int s2WavesEnv = getenv("VSLAM_BA_SCHUR2_WAVES") ? atoi(getenv("VSLAM_BA_SCHUR2_WAVES")) : 16;
+    const size_t s2StageB = (size_t)ba2_stage_doubles(maxFac, maxSlots) * sizeof(double);
+    int s2Waves = std::max(2, std::min(16, s2WavesEnv));
+    while (s2Waves > 2 && sysMax * sizeof(double) + s2Waves * s2StageB > 156 * 1024) s2Waves /= 2;
+    const size_t s2Lds = sysMax * sizeof(double) + (size_t)s2Waves * s2StageB;
+    const bool useSchur2 = s2Env && fMax <= BA2_MAX_F && maxSlots <= BA2_MAX_F && s2Lds <= 156 * 1024;
+    // (the kernel is a latency chain per landmark-wave: every workgroup of the cohort resident at once - one per CU at this LDS size -,
+    //  each wave walks a few landmarks)
+    if (useSchur2) lmBlocks = std::max(1, std::min((lpMax + 2 * s2Waves - 1) / (2 * s2Waves), lbEnv ? lbEnv : std::max(4, nCU / NL)));
     int backWaves = BA_SCHUR_WAVES / BACK_LPW;
     auto back_lds = [&](int nw) { return (size_t)nw * BACK_LPW * maxSlots * 18 * sizeof(double) + (size_t)nw * BACK_LPW * maxSlots * sizeof(int) + 16; };
     while (backWaves > 1 && back_lds(backWaves) > 150 * 1024) backWaves /= 2;
@@ -3012,7 +3191,8 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
             g_baTimer.end(t);
         }
         t = g_baTimer.begin("ba_schur");
-        hipLaunchKernelGGL(k_ba_schur, dim3(lmBlocks, sharedW ? 1 : NB, NL), dim3(64 * schurWaves), schurLds, stream, dTab, maxSlots, sharedW);
+        if (useSchur2) hipLaunchKernelGGL(k_ba_schur2, dim3(lmBlocks, NB, NL), dim3(64 * s2Waves), s2Lds, stream, dTab, maxSlots, maxFac);
+        else hipLaunchKernelGGL(k_ba_schur, dim3(lmBlocks, sharedW ? 1 : NB, NL), dim3(64 * schurWaves), schurLds, stream, dTab, maxSlots, sharedW);
         g_baTimer.end(t);
         t = g_baTimer.begin("ba_solve");
         hipLaunchKernelGGL(k_ba_reduce, dim3(((int)sysMax + 31) / 32, NB, NL), dim3(256), 0, stream, dTab, lmBlocks);
@@ -3225,6 +3405,45 @@ vslam_status vslam_local_ba_set_timing(int32_t on) {
     return VSLAM_OK;
 }
 int32_t vslam_local_ba_get_timing(void) { return g_baTimer.enabled ? 1 : 0; }
+
+}  // extern "C"
+
+namespace vslam {
+// Zero-copy, NOT synchronised form of vslam_ba_refresh_depth for a caller that serves several requests with one wait (the lockstep
+// group's serve_requests): inputs are staged in the calling thread's pinned arena, which the kernel addresses directly, the outputs land
+// there too; `out` points into the arena and is valid once the pool's stream has been synchronised (DevPool::sync recycles the arena,
+// so the caller copies the results out first).  Returns VSLAM_ERR_CAPACITY when the arena has no room yet (it grows at the next sync):
+// the caller then takes the synchronous entry point.  Arguments as vslam_ba_refresh_depth (validated by the caller).
+vslam_status refresh_depth_enqueue(const vslam_rig* rig, int n_kf, const double* kf_pose_wc, int n_lm, const double* lm_xyz,
+                                   const uint8_t* lm_outlier, int n_pairs, const int* pair_kf, const int* pair_lm, const uint8_t* pair_wrong,
+                                   const float* cur_depth, int device, RefreshTicket* out) {
+    if (n_pairs <= 0 || n_kf < 1 || !out) return VSLAM_ERR_INVALID;
+    VS_HIP(hipSetDevice(device));
+    DevPool* pool = thread_pool(device);
+    if (!pool) { set_error("no device pool"); return VSLAM_ERR_HIP; }
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+    const size_t oT = take(n_kf * sizeof(DPose)), oLm = take((size_t)3 * std::max(n_lm, 1) * sizeof(double)), oO = take(std::max(n_lm, 1)),
+                 oKf = take(n_pairs * sizeof(int)), oL = take(n_pairs * sizeof(int)), oW = take(n_pairs), oCur = take(n_pairs * sizeof(float)),
+                 oD = take(n_pairs * sizeof(float)), oC = take(n_pairs), oU = take(n_pairs);
+    uint8_t* st = pool->stage(off);
+    if (!st) return VSLAM_ERR_CAPACITY;
+    DPose* Tcw = (DPose*)(st + oT);
+    for (int k = 0; k < n_kf; k++) { DPose T; pose_from_rm16(kf_pose_wc + 16 * (size_t)k, T); pose_inverse(T, Tcw[k]); }
+    if (n_lm) { memcpy(st + oLm, lm_xyz, (size_t)3 * n_lm * sizeof(double)); memcpy(st + oO, lm_outlier, n_lm); }
+    memcpy(st + oKf, pair_kf, n_pairs * sizeof(int)); memcpy(st + oL, pair_lm, n_pairs * sizeof(int));
+    memcpy(st + oW, pair_wrong, n_pairs); memcpy(st + oCur, cur_depth, n_pairs * sizeof(float));
+    const float closeTh = rig->baseline * 40;
+    hipLaunchKernelGGL(k_ba_refresh_depth, dim3((n_pairs + 255) / 256), dim3(256), 0, pool->stream, n_pairs, (const int*)(st + oKf),
+                       (const int*)(st + oL), (const uint8_t*)(st + oW), (const uint8_t*)(st + oO), (const float*)(st + oCur),
+                       (const DPose*)(st + oT), (const double*)(st + oLm), closeTh, (float*)(st + oD), st + oC, st + oU);
+    VS_HIP(hipGetLastError());
+    out->dep = (const float*)(st + oD); out->clo = st + oC; out->up = st + oU;
+    return VSLAM_OK;
+}
+}  // namespace vslam
+
+extern "C" {
 
 vslam_status vslam_ba_refresh_depth(const vslam_rig* rig, int32_t n_kf, const double* kf_pose_wc, int32_t n_lm,
                                     const double* lm_xyz, const uint8_t* lm_outlier, int32_t n_pairs,

@@ -330,8 +330,9 @@ void vslam_batch::release() {
         fprintf(stderr, "  sections (total ms): KF new_keyframe %.1f | observations %.1f | stereo refill %.1f | descriptor request %.1f | key slot %.1f | connections %.1f | "
                         "keys from block %.1f (%lld by fetch_keys) || ba_collect %.1f | np_commit_a %.1f | ba_commit_a %.1f | np_collect %.1f\n", 1e-6 * p.sec[0], 1e-6 * p.sec[1], 1e-6 * p.sec[2],
                 1e-6 * p.sec[3], 1e-6 * p.sec[4], 1e-6 * p.sec[5], 1e-6 * p.sec[6], (long long)p.sec[14].load(), 1e-6 * p.sec[7], 1e-6 * p.sec[8], 1e-6 * p.sec[9], 1e-6 * p.sec[10]);
+        fprintf(stderr, "  ba_collect parts (total ms): window / landmark sweep %.1f | pairs %.1f | copies %.1f\n", 1e-6 * p.sec[11], 1e-6 * p.sec[12], 1e-6 * p.sec[13]);
         vslam::ba_host_profile_print();
-        { extern void kfb_print(); kfb_print(); }
+        vslam_sys::keys_from_block_profile_print();
         fprintf(stderr, "  local-BA cohorts: %.1f us per cohort x %lld cohorts of %.1f lanes (above 15 ms: %lld, longest %.1f ms)\n",
                 avg(p.mqNs, p.mqN), p.mqN.load(), p.mqN.load() ? (double)p.mqLate.load() / (double)p.mqN.load() : 0.0, p.mapLate.load(), 1e-6 * (double)p.mapMaxNs.load());
     }
@@ -360,11 +361,10 @@ void vslam_batch::release() {
 // write-back; the write-back's depth refresh), served together: ONE launch + one synchronisation per kind instead of one round
 // trip per lane on the pool threads.
 vslam_status vslam_batch::serve_requests() {
-    // ---- MapPoint::calcDescriptor ------------------------------------------------------------------------------------------
+    // ---- gather: MapPoint::calcDescriptor ------------------------------------------------------------------------------------
     size_t nMp = 0, nDesc = 0;
     for (vslam_system* s : sys) if (s->descReq.pending) { nMp += s->descReq.mps.size(); nDesc += s->descReq.descs.size() / 32; }
     if (nMp) {
-        SysProfScope ps(sys_prof().descNs, sys_prof().descN);
         rqDescs.resize(nDesc * 32); rqStart.assign(1, 0); rqBest.assign(nMp, -1);
         size_t at = 0;
         for (vslam_system* s : sys) {
@@ -374,21 +374,15 @@ vslam_status vslam_batch::serve_requests() {
             for (size_t i = 0; i < q.mps.size(); i++) rqStart.push_back((int)at + q.start[i + 1]);
             at += q.descs.size() / 32;
         }
-        if (nDesc) VS_CHECK(vslam_calc_descriptors(rqDescs.data(), rqStart.data(), (int)nMp, device, rqBest.data()));
-        size_t m = 0;
-        for (vslam_system* s : sys) {
-            DescReq& q = s->descReq;
-            if (!q.pending) continue;
-            q.best.assign(rqBest.begin() + m, rqBest.begin() + m + q.mps.size());
-            m += q.mps.size();
-        }
     }
-    // ---- MapPoint::updatePos depth / close refresh ---------------------------------------------------------------------------
+    // ---- gather: MapPoint::updatePos depth / close refresh ----------------------------------------------------------------------
     size_t nPair = 0; int nKf = 0, nLm = 0;
     for (vslam_system* s : sys) if (s->refReq.pending) { nPair += s->refReq.rk.size(); nKf += s->refReq.nKf; nLm += s->refReq.nLm; }
+    std::vector<int> rk, rl; std::vector<float> cur, dep; std::vector<double> pose, lm;
+    std::vector<uint8_t> zeroW, zeroO, clo, up;
     if (nPair) {
-        std::vector<int> rk, rl; std::vector<float> cur(nPair), dep(nPair); std::vector<double> pose((size_t)nKf * 16), lm((size_t)nLm * 3);
-        std::vector<uint8_t> zeroW(nPair, 0), zeroO(std::max(nLm, 1), 0), clo(nPair), up(nPair);
+        cur.resize(nPair); dep.resize(nPair); pose.resize((size_t)nKf * 16); lm.resize((size_t)nLm * 3);
+        zeroW.assign(nPair, 0); zeroO.assign(std::max(nLm, 1), 0); clo.resize(nPair); up.resize(nPair);
         rk.reserve(nPair); rl.reserve(nPair);
         size_t ap = 0; int ak = 0, al = 0;
         for (vslam_system* s : sys) {
@@ -399,9 +393,44 @@ vslam_status vslam_batch::serve_requests() {
             memcpy(lm.data() + (size_t)al * 3, r.rlm.data(), (size_t)r.nLm * 3 * sizeof(double));
             ap += r.rk.size(); ak += r.nKf; al += r.nLm;
         }
-        VS_CHECK(vslam_ba_refresh_depth(&sys[0]->cfg.rig, nKf, pose.data(), nLm, lm.data(), zeroO.data(), (int)nPair, rk.data(), rl.data(), zeroW.data(),
-                                        cur.data(), device, dep.data(), clo.data(), up.data()));
-        ap = 0;
+    }
+    // ---- device: both kinds enqueued on this thread's (high-priority) pool stream, ONE wait - each used to be a round trip of its
+    //      own that queued behind the groups' wide kernels.  No staging room yet (the arena grows at the sync): the synchronous calls.
+    const bool wantDesc = nMp && nDesc, wantRef = nPair > 0;
+    if (wantDesc || wantRef) {
+        SysProfScope ps(sys_prof().descNs, sys_prof().descN);
+        const int* bestP = nullptr;
+        vslam::RefreshTicket tk{};
+        vslam_status sd = wantDesc ? vslam::calc_descriptors_enqueue(rqDescs.data(), rqStart.data(), (int)nMp, device, &bestP) : VSLAM_OK;
+        vslam_status sr = VSLAM_OK;
+        if (wantRef && (sd == VSLAM_OK || sd == VSLAM_ERR_CAPACITY))
+            sr = vslam::refresh_depth_enqueue(&sys[0]->cfg.rig, nKf, pose.data(), nLm, lm.data(), zeroO.data(), (int)nPair, rk.data(), rl.data(), zeroW.data(),
+                                              cur.data(), device, &tk);
+        if (sd != VSLAM_OK && sd != VSLAM_ERR_CAPACITY) return sd;
+        if (sr != VSLAM_OK && sr != VSLAM_ERR_CAPACITY) return sr;
+        vslam::DevPool* pool = vslam::thread_pool(device);
+        if (!pool) return VSLAM_ERR_HIP;
+        VS_HIP(hipStreamSynchronize(pool->stream));
+        if (wantDesc && sd == VSLAM_OK) memcpy(rqBest.data(), bestP, nMp * sizeof(int));
+        if (wantRef && sr == VSLAM_OK) { memcpy(dep.data(), tk.dep, nPair * sizeof(float)); memcpy(clo.data(), tk.clo, nPair); memcpy(up.data(), tk.up, nPair); }
+        VS_HIP(pool->sync());          // (recycles the arena; may re-allocate it - after the copies)
+        if (wantDesc && sd == VSLAM_ERR_CAPACITY) VS_CHECK(vslam_calc_descriptors(rqDescs.data(), rqStart.data(), (int)nMp, device, rqBest.data()));
+        if (wantRef && sr == VSLAM_ERR_CAPACITY)
+            VS_CHECK(vslam_ba_refresh_depth(&sys[0]->cfg.rig, nKf, pose.data(), nLm, lm.data(), zeroO.data(), (int)nPair, rk.data(), rl.data(), zeroW.data(),
+                                            cur.data(), device, dep.data(), clo.data(), up.data()));
+    }
+    // ---- scatter ----------------------------------------------------------------------------------------------------------------
+    if (nMp) {
+        size_t m = 0;
+        for (vslam_system* s : sys) {
+            DescReq& q = s->descReq;
+            if (!q.pending) continue;
+            q.best.assign(rqBest.begin() + m, rqBest.begin() + m + q.mps.size());
+            m += q.mps.size();
+        }
+    }
+    if (nPair) {
+        size_t ap = 0;
         for (vslam_system* s : sys) {
             RefreshReq& r = s->refReq;
             if (!r.pending) continue;

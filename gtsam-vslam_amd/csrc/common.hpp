@@ -219,6 +219,13 @@ inline DevPool* thread_pool(int device) {
 // Frees the calling thread's cached device resources (scratch-block cache and its stream, the local-BA workspace): the
 // last thing every library thread does; exported as vslam_thread_release() for threads the caller owns.
 void thread_release();
+// requests of a lockstep group's host phase served with ONE wait (batch.hip::serve_requests): enqueue-only forms of
+// vslam_calc_descriptors (newpts.hip) and vslam_ba_refresh_depth (ba.hip) on the calling thread's pool stream
+struct RefreshTicket { const float* dep; const uint8_t* clo; const uint8_t* up; };
+vslam_status calc_descriptors_enqueue(const uint8_t* descs, const int32_t* start, int32_t n_mp, int32_t device, const int** best_out);
+vslam_status refresh_depth_enqueue(const vslam_rig* rig, int n_kf, const double* kf_pose_wc, int n_lm, const double* lm_xyz,
+                                   const uint8_t* lm_outlier, int n_pairs, const int* pair_kf, const int* pair_lm, const uint8_t* pair_wrong,
+                                   const float* cur_depth, int device, RefreshTicket* out);
 inline void thread_pool_release() { DevPool& p = thread_pool_slot(); if (p.device >= 0) { p.release(); p.device = -1; } }
 // RAII device array drawn from the thread's pool
 template <class T>

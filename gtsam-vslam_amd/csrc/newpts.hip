@@ -756,6 +756,33 @@ extern "C" vslam_status vslam_find_new_points_batch(const vslam_new_points_probl
 }
 
 // MapPoint::calcDescriptor for a batch of map points: descs = concatenated observation descriptors, start[n_mp + 1]
+namespace vslam {
+// NOT synchronised form of vslam_calc_descriptors (see refresh_depth_enqueue in ba.hip): *best_out points into the calling thread's
+// pinned arena and is valid once the pool's stream has been synchronised.  VSLAM_ERR_CAPACITY: no staging room yet.
+vslam_status calc_descriptors_enqueue(const uint8_t* descs, const int32_t* start, int32_t n_mp, int32_t device, const int** best_out) {
+    if (n_mp <= 0 || !descs || !start || !best_out) return VSLAM_ERR_INVALID;
+    bool anyBig = false;
+    for (int m = 0; m < n_mp; m++) {
+        if (start[m + 1] < start[m]) { set_error("vslam_calc_descriptors: start offsets must ascend"); return VSLAM_ERR_INVALID; }
+        anyBig |= start[m + 1] - start[m] > 64;
+    }
+    VS_HIP(hipSetDevice(device));
+    NP_POOL(pool);
+    const size_t total = (size_t)start[n_mp];
+    const size_t oStart = (total * 32 + 63) & ~(size_t)63, oBest = (oStart + ((size_t)n_mp + 1) * sizeof(int) + 63) & ~(size_t)63;
+    uint8_t* st = pool->stage(oBest + (size_t)n_mp * sizeof(int));
+    if (!st) return VSLAM_ERR_CAPACITY;
+    memcpy(st, descs, total * 32); memcpy(st + oStart, start, ((size_t)n_mp + 1) * sizeof(int));
+    int* hb = (int*)(st + oBest);
+    for (int m = 0; m < n_mp; m++) hb[m] = -1;
+    hipLaunchKernelGGL(k_calc_descriptor, dim3((n_mp + 3) / 4), dim3(256), 0, pool->stream, n_mp, (const uint8_t*)st, (const int*)(st + oStart), hb);
+    if (anyBig) hipLaunchKernelGGL(k_calc_descriptor_big, dim3(n_mp), dim3(64), 0, pool->stream, n_mp, (const uint8_t*)st, (const int*)(st + oStart), hb);
+    VS_HIP(hipGetLastError());
+    *best_out = hb;
+    return VSLAM_OK;
+}
+}  // namespace vslam
+
 extern "C" vslam_status vslam_calc_descriptors(const uint8_t* descs, const int32_t* start, int32_t n_mp, int32_t device, int32_t* best_out) {
     if (n_mp < 0 || (n_mp > 0 && (!descs || !start || !best_out))) return VSLAM_ERR_INVALID;
     if (n_mp == 0) return VSLAM_OK;
@@ -879,6 +906,37 @@ extern "C" vslam_status vslam_keyframe_update_pose(const vslam_kf_update_problem
     if (A.nL + A.nR == 0) return VSLAM_OK;
     NP_POOL(pool);
     hipStream_t ps = pool->stream;
+    {
+        // Zero-copy: inputs and outputs in the pool's PINNED arena, which the device addresses directly - one launch + one
+        // synchronisation instead of seven uploads, the launch and three downloads (eleven queue operations that each waited behind the
+        // lockstep groups' wide kernels; this call sits on the tracker's timeline after every local BA: changePosesLCA).  ~120 KB read
+        // over the host link by coalesced loads.
+        size_t off = 0;
+        auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+        const size_t oKl = take((size_t)A.nL * sizeof(vslam_keypoint)), oKr = take((size_t)A.nR * sizeof(vslam_keypoint)), oSl = take((size_t)A.nL * 4),
+                     oSr = take((size_t)A.nR * 4), oLm = take((size_t)3 * std::max(P->n_lm, 1) * 8), oKdx = take((size_t)std::max(P->n_lm, 1) * 8),
+                     oOut = take(std::max(P->n_lm, 1)), oDl = take(std::max(A.nL, 1)), oDr = take(std::max(A.nR, 1));
+        if (uint8_t* st = pool->stage(off)) {
+            if (A.nL) { memcpy(st + oKl, P->kps_left, (size_t)A.nL * sizeof(vslam_keypoint)); memcpy(st + oSl, P->slot_lm_l, (size_t)A.nL * 4); }
+            if (A.nR) { memcpy(st + oKr, P->kps_right, (size_t)A.nR * sizeof(vslam_keypoint)); memcpy(st + oSr, P->slot_lm_r, (size_t)A.nR * 4); }
+            if (P->n_lm) {
+                memcpy(st + oLm, P->lm_xyz, (size_t)3 * P->n_lm * 8);
+                long long* kd = (long long*)(st + oKdx);
+                for (int i = 0; i < P->n_lm; i++) kd[i] = P->lm_kdx[i];
+                memcpy(st + oOut, P->lm_outlier, P->n_lm);
+            }
+            A.kpsL = (const vslam_keypoint*)(st + oKl); A.kpsR = (const vslam_keypoint*)(st + oKr); A.slotL = (const int*)(st + oSl); A.slotR = (const int*)(st + oSr);
+            A.lm = (double*)(st + oLm); A.kdx = (const long long*)(st + oKdx); A.outlier = st + oOut; A.dropL = st + oDl; A.dropR = st + oDr;
+            hipLaunchKernelGGL(k_kf_update_pose, dim3((std::max(A.nL, A.nR) + 255) / 256, 2), dim3(256), 0, ps, A);
+            VS_HIP(hipGetLastError());
+            VS_HIP(hipStreamSynchronize(ps));
+            if (A.nL) memcpy(drop_l, st + oDl, A.nL);
+            if (A.nR) memcpy(drop_r, st + oDr, A.nR);
+            if (P->n_lm) memcpy(P->lm_xyz, st + oLm, (size_t)3 * P->n_lm * 8);
+            VS_HIP(pool->sync());          // (recycles the arena; may re-allocate it - after the copies)
+            return VSLAM_OK;
+        }
+    }
     Dev<vslam_keypoint> dKl(pool), dKr(pool); Dev<int> dSl(pool), dSr(pool); Dev<double> dLm(pool); Dev<long long> dKdx(pool); Dev<uint8_t> dOut(pool), dDl(pool), dDr(pool);
     VS_HIP(dKl.up(P->kps_left, (size_t)A.nL)); VS_HIP(dKr.up(P->kps_right, (size_t)A.nR));
     VS_HIP(dSl.up(P->slot_lm_l, (size_t)A.nL)); VS_HIP(dSr.up(P->slot_lm_r, (size_t)A.nR));

@@ -123,10 +123,8 @@ static void keys_from_block(const uint8_t* blk, int nL, int nR, SysKeys& k) {
         memcpy(k.leftIdxs.data(), blk + o.leftIdxs, (size_t)nR * 4);
     }
     lapk(2);
-    { volatile uint8_t sink = 0; for (size_t i = 0; i < (size_t)nL * 32; i += 64) sink += k.dL[i]; }
-    lapk(3);
 }
-void kfb_print() { fprintf(stderr, "  keys_from_block ms: resize %.1f | left %.1f | right %.1f | re-read dL %.1f\n", 1e-6 * g_kfbNs[0], 1e-6 * g_kfbNs[1], 1e-6 * g_kfbNs[2], 1e-6 * g_kfbNs[3]); }
+namespace vslam_sys { void keys_from_block_profile_print() { fprintf(stderr, "  keys_from_block ms: resize %.1f | left %.1f | right %.1f\n", 1e-6 * g_kfbNs[0], 1e-6 * g_kfbNs[1], 1e-6 * g_kfbNs[2]); } }
 
 // MapPoint::update(KeyFrame*) (src/Map.cpp:58-100) minus calcDescriptor, which is batched (needDesc)
 void vslam_system::mp_update(SysMP& mp, int kfNumb, std::vector<int>& needDesc, int mpIndex) {
@@ -152,15 +150,21 @@ vslam_status vslam_system::calc_descriptors(const std::vector<int>& mps) {
     if (mps.empty()) return VSLAM_OK;
     DescReq& q = descReq;
     if (!q.pending) { q.mps.clear(); q.descs.clear(); q.start.assign(1, 0); q.best.clear(); }
+    // (one sizing pass, then plain copies: the per-descriptor vector insert was a third of ba_commit's time)
+    size_t nd = 0;
+    for (size_t i = 0; i < mps.size(); i++) for (const KfMatch& o : mapPoints[mps[i]].kfm) nd += (o.l != -1) + (o.r != -1);
+    size_t at = q.descs.size();
+    q.descs.resize(at + nd * 32);
+    q.mps.reserve(q.mps.size() + mps.size()); q.start.reserve(q.start.size() + mps.size());
     for (size_t i = 0; i < mps.size(); i++) {
         const SysMP& mp = mapPoints[mps[i]];
         for (const KfMatch& o : mp.kfm) {
             const SysKeys& k = keyFrames[o.kf].keys;
-            if (o.l != -1) { const uint8_t* d = k.dL.data() + (size_t)o.l * 32; q.descs.insert(q.descs.end(), d, d + 32); }
-            if (o.r != -1) { const uint8_t* d = k.dR.data() + (size_t)o.r * 32; q.descs.insert(q.descs.end(), d, d + 32); }
+            if (o.l != -1) { memcpy(q.descs.data() + at, k.dL.data() + (size_t)o.l * 32, 32); at += 32; }
+            if (o.r != -1) { memcpy(q.descs.data() + at, k.dR.data() + (size_t)o.r * 32, 32); at += 32; }
         }
         q.mps.push_back(mps[i]);
-        q.start.push_back((int)(q.descs.size() / 32));
+        q.start.push_back((int)(at / 32));
     }
     q.pending = true;
     if (deferDevice) return VSLAM_OK;
@@ -909,6 +913,7 @@ void vslam_system::np_commit_b(MapPass& p) {
 // LocalMapper::localBA: window collection (:438-516) and graph membership (:556-745) into the job's problem
 void vslam_system::ba_collect(MapPass& p) {
     SysProfScope pc(sys_prof().sec[7], sys_prof().sec[15]);
+    SysSec dbg;
     BaJob& J = p.ba;
     const std::vector<int>& actKeyF = p.actKeyF;
     J.kfs.clear(); J.allMps.clear(); J.pk.clear(); J.pl.clear(); J.poct.clear(); J.pf.clear(); J.puv.clear(); J.pobj.clear();
@@ -938,6 +943,7 @@ void vslam_system::ba_collect(MapPass& p) {
             }
         }
     }
+    dbg.mark(11);
     if (fixedKFs.empty() && !fixedKF) { const int lastK = local.back(); local.pop_back(); isLocal[lastK] = 0; fixedKFs.push_back(lastK); }
     J.kfs = local; J.kfs.insert(J.kfs.end(), fixedKFs.begin(), fixedKFs.end());
     const std::vector<int>& kfs = J.kfs;
@@ -967,6 +973,7 @@ void vslam_system::ba_collect(MapPass& p) {
         }
         if (out) J.mpOut[m] = 1;
     }
+    dbg.mark(12);
     for (size_t q = 0; q < J.pk.size(); q++) if (J.mpOut[J.pl[q]]) J.pf[q] = 0;     // flagged landmarks contribute no factor
     J.kfPose.resize(kfs.size() * 16); J.kfId.resize(kfs.size()); J.kfFixed.resize(kfs.size()); J.kfLocal.resize(kfs.size());
     for (size_t i = 0; i < kfs.size(); i++) {
@@ -988,6 +995,7 @@ void vslam_system::ba_collect(MapPass& p) {
     vslam_ba_result& Rr = J.R;
     Rr = vslam_ba_result{};
     Rr.kf_pose_wc = J.kfOut.data(); Rr.lm_xyz = J.lmOut.data(); Rr.pair_wrong = J.wrong.data(); Rr.pair_wrong_pass1 = J.wrong1.data();
+    dbg.mark(13);
 }
 
 // the numerical core on the device (the calling thread's local-BA context: stream, workspace, timers)

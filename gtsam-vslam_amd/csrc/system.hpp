@@ -107,6 +107,7 @@ struct SysProf { std::atomic<long long> lcaNs{0}, lcaN{0}, kfNs{0}, kfN{0}, desc
                  std::atomic<long long> sec[16] = {};      // fine sections (nanoseconds), printed with the phases
 };      // mapping queue delay / long passes
 SysProf& sys_prof();
+void keys_from_block_profile_print();      // VSLAM_BATCH_PHASES: where the copy of a keyframe's key block spends its time
 struct SysSec {      // accumulates the time since the previous mark into section k
     std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
     void mark(int k) { const auto n = std::chrono::steady_clock::now(); sys_prof().sec[k] += std::chrono::duration_cast<std::chrono::nanoseconds>(n - t).count(); t = n; }
