@@ -80,6 +80,7 @@ struct BaDev {
     size_t sysStride, spartStride, partialStride, dLStride;
     int solveKind;                       // which reduced-camera solve serves this lane (a batch may mix kinds: each kernel skips foreign lanes)
     double* Lg;                          // k_ba_solve_mfma: the lane's factor storage (null: the launch's argument)
+    double* ctlHost;                     // != null: pinned host mirror of the control block, written by the control step (the host's poll is then a wait, not a copy)
 };
 enum { BA_SOLVE_MFMA64 = 0, BA_SOLVE_WAVE = 1, BA_SOLVE_MFMA = 2, BA_SOLVE_LARGE = 3 };
 
@@ -467,6 +468,7 @@ __global__ __launch_bounds__(256) void k_ba_factors(const BaDev* __restrict__ ta
         if (fuseCtl) {
             ba_ctl(D, MODE, relTol, absTol);
             sLast = MODE == 1 && !D.specLin && ((const int*)(D.ctl + CTL_INTS))[CI_STATE] == BA_LINEARIZE;
+            if (D.ctlHost) for (int i = 0; i < CTL_DOUBLES; i++) D.ctlHost[i] = D.ctl[i];
         }
     }
     __syncthreads();
@@ -3019,7 +3021,8 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
     auto run_singles = [&]() -> vslam_status { for (int i : singles) VS_CHECK(ba_run(Ps[i], Rs[i], device, nullptr)); return VSLAM_OK; };
     if (NL == 0) return run_singles();
     auto& A = W.arena;
-    size_t arenaBytes = 4096 + (size_t)NL * (CTL_DOUBLES * 8 + sizeof(BaDev) + sizeof(BaLaneAux) + 768);
+    size_t arenaBytes = 8192 + (size_t)NL * (CTL_DOUBLES * 8 + sizeof(BaDev) + sizeof(BaLaneAux) + 768);
+    for (int i : act) arenaBytes += (size_t)lanes[i].K + std::max(lanes[i].L, 1) + 64;      // (the shared membership block)
     for (int i : act) {
         Lane& q = lanes[i];
         arenaBytes += q.H.arena_bytes(q.K, q.L, nSlots) + (size_t)q.K * (sizeof(DPose) + 1) + (size_t)q.L * 24 + (size_t)q.NP * (4 + 4 + 8 + 1 + 16) + 10 * 256;
@@ -3037,6 +3040,15 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
         q.h_pairFlags = A.take<uint8_t>(q.NP); q.h_pairUv = A.take<float>((size_t)4 * q.NP); q.h_kfLocal = A.take<uint8_t>(q.K);
         fits = q.h_kfLocal && q.H.take(A, q.K, q.L, nSlots);
         q.H.h_ctl = h_ctlAll + (size_t)CTL_DOUBLES * a; q.H.h_D = h_tab + a;      // (the lane's slots of the shared tables)
+    }
+    // the lanes' membership arrays (rewritten for the second pass) side by side: ONE re-upload instead of one per lane
+    size_t presentBytes = 0;
+    for (int a = 0; a < NL; a++) presentBytes += (size_t)lanes[act[a]].K + std::max(lanes[act[a]].L, 1);
+    uint8_t* const h_present = fits ? A.take<uint8_t>(presentBytes) : nullptr;
+    fits = fits && h_present;
+    if (fits) {
+        uint8_t* pp = h_present;
+        for (int a = 0; a < NL; a++) { Lane& q = lanes[act[a]]; q.H.h_kfPresent = pp; pp += q.K; q.H.h_lmPresent = pp; pp += std::max(q.L, 1); }
     }
     if (!fits) { set_error("local BA batch: upload arena too small"); return VSLAM_ERR_CAPACITY; }
     W.pool.run(NL, [&](int a) {
@@ -3141,8 +3153,11 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
         q.d_flags = (int*)(dm + o.flags); q.d_Sedge = (double*)(dm + o.sedge); q.d_poseS = (DPose*)(dm + o.poseS); q.d_lmS = (double*)(dm + o.lmS);
         q.d_facJ = (double*)(dm + o.facJ); q.d_dP = (double*)(dm + o.dP); q.d_dL = (double*)(dm + o.dL); q.d_S = (double*)(dm + o.S);
         q.d_partial = (double*)(dm + o.partial); q.d_Spart = (double*)(dm + o.spart); q.d_sums = (double*)(dm + o.sums);
-        q.d_Lg = o.Lg ? (double*)(dm + o.Lg) : nullptr; q.d_wrong = dm + o.wrong; q.d_outPose = (double*)(dm + o.outPose); q.d_outLm = (double*)(dm + o.outLm);
-        q.oWrong = oBackWrong + (o.wrong - wrongBase); q.oOut = oBackOut + (o.outPose - outBase);
+        q.d_Lg = o.Lg ? (double*)(dm + o.Lg) : nullptr; q.oWrong = oBackWrong + (o.wrong - wrongBase); q.oOut = oBackOut + (o.outPose - outBase);
+        // the chi2 kernel writes its flags and the pass's final values STRAIGHT into the pinned landing area (device-addressable host
+        // memory): no download copies behind it - each was a blit launch of its own that queued behind the groups' wide kernels
+        q.d_wrong = W.h_back + q.oWrong; q.d_outPose = (double*)(W.h_back + q.oOut);
+        q.d_outLm = (double*)(W.h_back + q.oOut + (o.outLm - o.outPose));
         BaDev D{};
         const int n = H.n, K = q.K, L = q.L;
         D.NF = H.NF; D.Lp = H.Lp; D.F = H.F; D.K = K; D.NE = H.NE; D.n = n;
@@ -3162,6 +3177,7 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
         D.spartStride = ((size_t)n * n + n) * lmBlocks; D.Spart = q.d_Spart;
         D.solveKind = (n <= 64 && useMfma) ? BA_SOLVE_MFMA64 : n <= BA_WAVE_N ? BA_SOLVE_WAVE : BA_SOLVE_MFMA;
         D.Lg = q.d_Lg;
+        D.ctlHost = (double*)(W.h_back + oBackCtl) + (size_t)CTL_DOUBLES * a;
         anyMfma64 |= D.solveKind == BA_SOLVE_MFMA64; anyWave |= D.solveKind == BA_SOLVE_WAVE; anyMfma |= D.solveKind == BA_SOLVE_MFMA;
         *H.h_D = D;
         BaLaneAux X{};
@@ -3210,6 +3226,10 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
         return VSLAM_OK;
     };
     double* const b_ctl = (double*)(W.h_back + oBackCtl);
+    // The host's copy of the lanes' control blocks is written by the control steps themselves (BaDev::ctlHost).  It starts every pass as
+    // the ARMED block, so that a poll can only ever see "not done" until a lane's own control step has said otherwise - a block left
+    // over from the previous pass (BA_DONE) would end the pass before it began and leave the chi2 kernel with lanes it skips.
+    memcpy(b_ctl, h_ctlAll, (size_t)CTL_DOUBLES * 8 * NL);
     // Rounds are enqueued ahead of the poll that tells whether every lane has finished: `first` rounds (a pass of m iterations needs
     // at least m - the device skips the rounds of lanes that are done, a skipped launch costs a few microseconds, a poll a
     // synchronisation of this stream), then two at a time.
@@ -3220,8 +3240,9 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
             const int batch = perPollEnv ? perPollEnv : (enq == 0 ? first : 2);
             for (int b = 0; b < batch; b++) VS_CHECK(step(enq + b == 0));
             enq += batch;
-            VS_HIP(hipMemcpyAsync(b_ctl, A.dev(h_ctlAll), (size_t)CTL_DOUBLES * 8 * NL, hipMemcpyDeviceToHost, stream));
-            VS_HIP(vslam::stream_wait_blocking(stream));
+            static const bool mirrorOff = getenv("VSLAM_BA_CTL_MIRROR") && atoi(getenv("VSLAM_BA_CTL_MIRROR")) == 0;
+            if (mirrorOff) VS_HIP(hipMemcpyAsync(b_ctl, A.dev(h_ctlAll), (size_t)CTL_DOUBLES * 8 * NL, hipMemcpyDeviceToHost, stream));
+            VS_HIP(vslam::stream_wait_blocking(stream));      // (every control step mirrors its block into the landing area: BaDev::ctlHost)
             g_bbsPolls++;
             bool all = true;
             for (int a = 0; a < NL; a++) all &= ((const int*)(b_ctl + (size_t)CTL_DOUBLES * a + CTL_INTS))[CI_STATE] == BA_DONE;
@@ -3250,9 +3271,7 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
         hipLaunchKernelGGL(k_ba_chi2_b, dim3(chiBlocks, NL), dim3(256), 0, stream, dTab, dAux, gather);
         g_baTimer.end(t);
         VS_HIP(hipGetLastError());
-        VS_HIP(hipMemcpyAsync(W.h_back + oBackWrong, dm + wrongBase, wrongEnd - wrongBase, hipMemcpyDeviceToHost, stream));
-        if (gather) VS_HIP(hipMemcpyAsync(W.h_back + oBackOut, dm + outBase, outEnd - outBase, hipMemcpyDeviceToHost, stream));
-        VS_HIP(vslam::stream_wait_blocking(stream));
+        VS_HIP(vslam::stream_wait_blocking(stream));      // (flags / values are in the landing area: see the argument tables)
         return VSLAM_OK;
     };
     // ---- pass 1 ------------------------------------------------------------------------------------------------------------------
@@ -3304,12 +3323,8 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
     if ((int)redo.size() < NL) {
         // re-armed control blocks and the membership arrays: the arena's head (control blocks) + each lane's present arrays
         VS_HIP(hipMemcpyAsync(A.dev(h_ctlAll), h_ctlAll, (size_t)CTL_DOUBLES * 8 * NL, hipMemcpyHostToDevice, stream));
-        for (int a = 0; a < NL; a++) {
-            Lane& q = lanes[act[a]];
-            if (!q.pass2) continue;
-            // (kfPresent | lmPresent are adjacent takes of the arena)
-            VS_HIP(hipMemcpyAsync(A.dev(q.H.h_kfPresent), q.H.h_kfPresent, (size_t)((q.H.h_lmPresent - q.H.h_kfPresent) + std::max(q.L, 1)), hipMemcpyHostToDevice, stream));
-        }
+        VS_HIP(hipMemcpyAsync(A.dev(h_present), h_present, presentBytes, hipMemcpyHostToDevice, stream));
+        memcpy(b_ctl, h_ctlAll, (size_t)CTL_DOUBLES * 8 * NL);      // (the re-armed blocks; lanes that stay out of the pass carry BA_DONE)
         hipLaunchKernelGGL(k_ba_second_pass_b, dim3(std::max(1, std::min((std::max(nfMax, valMax) + 255) / 256, 64)), NL), dim3(256), 0, stream, dTab, dAux);
         VS_CHECK(lm_loop(6));
         report(1);
