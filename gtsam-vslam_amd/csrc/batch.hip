@@ -536,10 +536,50 @@ vslam_status vslam_batch::step(const uint8_t* const* L, const uint8_t* const* R,
         if (!q.on) return;
         hipSetDevice(device);
         vslam_system* s = sys[b];
-        LANE_TRY(s->frame_begin_b(s->ctx));
-        if (!q.first) q.N = s->frame_candidates(s->ctx);
+        s->deferLca = true;
+        const vslam_status bs = s->frame_begin_b1(s->ctx);
+        s->deferLca = false;
+        LANE_TRY(bs);
+        if (!s->lcaReq.pending && !q.first) q.N = s->frame_candidates(s->ctx);
     });
     VS_CHECK(first_error());
+    // changePosesLCA of the lanes whose local BA landed at this step: their KeyFrame::updatePose kernels enqueued back to back on this
+    // thread's stream, ONE wait (each used to be a synchronous round trip of its own on a pool thread)
+    {
+        std::vector<int> lanesL;
+        for (int b = 0; b < B; b++) if (ls[b].on && sys[b]->lcaReq.pending) lanesL.push_back(b);
+        if (!lanesL.empty()) {
+            std::vector<vslam::KfUpdTicket> tk(lanesL.size());
+            std::vector<vslam_status> st(lanesL.size(), VSLAM_OK);
+            for (size_t i = 0; i < lanesL.size(); i++) st[i] = vslam::kf_update_pose_enqueue(&sys[lanesL[i]]->lcaReq.P, device, &tk[i]);
+            vslam::DevPool* dp = vslam::thread_pool(device);
+            if (!dp) return VSLAM_ERR_HIP;
+            VS_HIP(hipStreamSynchronize(dp->stream));
+            for (size_t i = 0; i < lanesL.size(); i++) {
+                if (st[i] != VSLAM_OK) continue;
+                vslam_system::LcaReq& r = sys[lanesL[i]]->lcaReq;
+                if (tk[i].drop_l && r.P.n_left) memcpy(r.dl.data(), tk[i].drop_l, r.P.n_left);
+                if (tk[i].drop_r && r.P.n_right) memcpy(r.dr.data(), tk[i].drop_r, r.P.n_right);
+                if (tk[i].lm_xyz && r.P.n_lm) memcpy(r.xyz.data(), tk[i].lm_xyz, (size_t)3 * r.P.n_lm * sizeof(double));
+            }
+            VS_HIP(dp->sync());          // (recycles the arena - after the copies)
+            for (size_t i = 0; i < lanesL.size(); i++) {
+                if (st[i] == VSLAM_OK) continue;
+                if (st[i] != VSLAM_ERR_CAPACITY) return st[i];
+                vslam_system::LcaReq& r = sys[lanesL[i]]->lcaReq;      // no staging room yet: the synchronous entry point
+                double poseOut[16];
+                VS_CHECK(vslam_keyframe_update_pose(&r.P, device, r.dl.data(), r.dr.data(), poseOut));
+            }
+            pool.run((int)lanesL.size(), [&](int i) {
+                const int b = lanesL[i];
+                LaneStep& q = ls[b];
+                vslam_system* s = sys[b];
+                LANE_TRY(s->frame_begin_b2(s->ctx));
+                if (!q.first) q.N = s->frame_candidates(s->ctx);
+            });
+            VS_CHECK(first_error());
+        }
+    }
     sub(2, ts);
     lap(0);
 

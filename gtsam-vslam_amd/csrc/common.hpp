@@ -222,6 +222,8 @@ void thread_release();
 // requests of a lockstep group's host phase served with ONE wait (batch.hip::serve_requests): enqueue-only forms of
 // vslam_calc_descriptors (newpts.hip) and vslam_ba_refresh_depth (ba.hip) on the calling thread's pool stream
 struct RefreshTicket { const float* dep; const uint8_t* clo; const uint8_t* up; };
+struct KfUpdTicket { const uint8_t* drop_l; const uint8_t* drop_r; const double* lm_xyz; };
+vslam_status kf_update_pose_enqueue(const vslam_kf_update_problem* P, int32_t device, KfUpdTicket* out);
 vslam_status calc_descriptors_enqueue(const uint8_t* descs, const int32_t* start, int32_t n_mp, int32_t device, const int** best_out);
 vslam_status refresh_depth_enqueue(const vslam_rig* rig, int n_kf, const double* kf_pose_wc, int n_lm, const double* lm_xyz,
                                    const uint8_t* lm_outlier, int n_pairs, const int* pair_kf, const int* pair_lm, const uint8_t* pair_wrong,

@@ -877,6 +877,52 @@ extern "C" vslam_status vslam_mono_new_points(const vslam_mono_points_problem* P
     return VSLAM_OK;
 }
 
+namespace vslam {
+// NOT synchronised form of vslam_keyframe_update_pose for the lockstep group's request service (one wait for all lanes whose local BA
+// landed at this step): operands staged in the calling thread's pinned arena, which the kernel addresses directly; the ticket's
+// pointers are valid once the pool's stream has been synchronised.  VSLAM_ERR_CAPACITY: no staging room yet (the caller takes the
+// synchronous entry point).  The problem was validated by the caller (vslam_system builds it from its own records).
+vslam_status kf_update_pose_enqueue(const vslam_kf_update_problem* P, int32_t device, KfUpdTicket* out) {
+    if (!P || !out) return VSLAM_ERR_INVALID;
+    VS_HIP(hipSetDevice(device));
+    KfUpdArgs A{};
+    DPose key, ref;
+    pose_from_rm16(P->key_pose, key); pose_from_rm16(P->ref_pose, ref); pose_from_rm16(P->cur_pose_inv, A.curInv);
+    pose_compose(key, ref, A.newPose);
+    pose_inverse(A.newPose, A.newPoseInv);
+    A.newPoseRInv = A.newPoseInv;
+    A.newPoseRInv.t[0] -= (double)P->rig.baseline;
+    A.nL = P->n_left; A.nR = P->n_right; A.numb = P->numb;
+    A.fx = P->rig.fx; A.fy = P->rig.fy; A.cx = P->rig.cx; A.cy = P->rig.cy;
+    for (int l = 0; l < P->n_levels; l++) A.invSigma[l] = P->inv_sigma_factor[l];
+    out->drop_l = out->drop_r = nullptr; out->lm_xyz = nullptr;
+    if (A.nL + A.nR == 0) return VSLAM_OK;
+    DevPool* pool = thread_pool(device);
+    if (!pool) { set_error("no device pool"); return VSLAM_ERR_HIP; }
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+    const size_t oKl = take((size_t)A.nL * sizeof(vslam_keypoint)), oKr = take((size_t)A.nR * sizeof(vslam_keypoint)), oSl = take((size_t)A.nL * 4),
+                 oSr = take((size_t)A.nR * 4), oLm = take((size_t)3 * std::max(P->n_lm, 1) * 8), oKdx = take((size_t)std::max(P->n_lm, 1) * 8),
+                 oOut = take(std::max(P->n_lm, 1)), oDl = take(std::max(A.nL, 1)), oDr = take(std::max(A.nR, 1));
+    uint8_t* st = pool->stage(off);
+    if (!st) return VSLAM_ERR_CAPACITY;
+    if (A.nL) { memcpy(st + oKl, P->kps_left, (size_t)A.nL * sizeof(vslam_keypoint)); memcpy(st + oSl, P->slot_lm_l, (size_t)A.nL * 4); }
+    if (A.nR) { memcpy(st + oKr, P->kps_right, (size_t)A.nR * sizeof(vslam_keypoint)); memcpy(st + oSr, P->slot_lm_r, (size_t)A.nR * 4); }
+    if (P->n_lm) {
+        memcpy(st + oLm, P->lm_xyz, (size_t)3 * P->n_lm * 8);
+        long long* kd = (long long*)(st + oKdx);
+        for (int i = 0; i < P->n_lm; i++) kd[i] = P->lm_kdx[i];
+        memcpy(st + oOut, P->lm_outlier, P->n_lm);
+    }
+    A.kpsL = (const vslam_keypoint*)(st + oKl); A.kpsR = (const vslam_keypoint*)(st + oKr); A.slotL = (const int*)(st + oSl); A.slotR = (const int*)(st + oSr);
+    A.lm = (double*)(st + oLm); A.kdx = (const long long*)(st + oKdx); A.outlier = st + oOut; A.dropL = st + oDl; A.dropR = st + oDr;
+    hipLaunchKernelGGL(k_kf_update_pose, dim3((std::max(A.nL, A.nR) + 255) / 256, 2), dim3(256), 0, pool->stream, A);
+    VS_HIP(hipGetLastError());
+    out->drop_l = st + oDl; out->drop_r = st + oDr; out->lm_xyz = (const double*)(st + oLm);
+    return VSLAM_OK;
+}
+}  // namespace vslam
+
 extern "C" vslam_status vslam_keyframe_update_pose(const vslam_kf_update_problem* P, int32_t device, uint8_t* drop_l, uint8_t* drop_r,
                                                    double* pose_out) {
     if (!P || !pose_out || !P->key_pose || !P->ref_pose || !P->cur_pose_inv || !P->inv_sigma_factor || P->n_levels < 1 ||

@@ -365,37 +365,39 @@ vslam_status vslam_system::insert_keyframe(SysKeys& keys, const std::vector<int>
     return VSLAM_OK;
 }
 
-// KeyFrame::updatePose (src/KeyFrame.cpp:6-76): k_kf_update_pose
-vslam_status vslam_system::kf_update_pose(SysKF& kf, const M4& keyPose) {
-    std::vector<int> lms, slotL(kf.lmpL.size(), -1), slotR(kf.lmpR.size(), -1);
+// KeyFrame::updatePose (src/KeyFrame.cpp:6-76): k_kf_update_pose.  gather -> device -> apply
+void vslam_system::kf_update_gather(SysKF& kf, const M4& keyPose, LcaReq& q) {
+    q.kf = kf.numb; q.keyPose = keyPose;
+    q.lms.clear(); q.slotL.assign(kf.lmpL.size(), -1); q.slotR.assign(kf.lmpR.size(), -1);
     if (lcaWhere.size() < mapPoints.size()) lcaWhere.resize(mapPoints.size() + mapPoints.size() / 2 + 64, -1);     // (grows with the map, reset below)
     auto slots = [&](const std::vector<int>& src, std::vector<int>& dst) {
         for (size_t i = 0; i < src.size(); i++) {
             if (src[i] < 0) continue;
             int& w = lcaWhere[src[i]];
-            if (w < 0) { w = (int)lms.size(); lms.push_back(src[i]); }
+            if (w < 0) { w = (int)q.lms.size(); q.lms.push_back(src[i]); }
             dst[i] = w;
         }
     };
-    slots(kf.lmpL, slotL); slots(kf.lmpR, slotR);
-    for (int m : lms) lcaWhere[m] = -1;
-    std::vector<double> xyz(std::max<size_t>(lms.size(), 1) * 3);
-    std::vector<int64_t> kdx(std::max<size_t>(lms.size(), 1));
-    std::vector<uint8_t> ol(std::max<size_t>(lms.size(), 1));
-    for (size_t j = 0; j < lms.size(); j++) {
-        const SysMP& m = mapPoints[lms[j]];
-        xyz[3 * j] = m.wp[0]; xyz[3 * j + 1] = m.wp[1]; xyz[3 * j + 2] = m.wp[2]; kdx[j] = m.kdx; ol[j] = mpOutlier[lms[j]];
+    slots(kf.lmpL, q.slotL); slots(kf.lmpR, q.slotR);
+    for (int m : q.lms) lcaWhere[m] = -1;
+    const size_t nl = std::max<size_t>(q.lms.size(), 1);
+    q.xyz.assign(nl * 3, 0.0); q.kdx.assign(nl, 0); q.ol.assign(nl, 0);
+    for (size_t j = 0; j < q.lms.size(); j++) {
+        const SysMP& m = mapPoints[q.lms[j]];
+        q.xyz[3 * j] = m.wp[0]; q.xyz[3 * j + 1] = m.wp[1]; q.xyz[3 * j + 2] = m.wp[2]; q.kdx[j] = m.kdx; q.ol[j] = mpOutlier[q.lms[j]];
     }
-    vslam_kf_update_problem P{};
+    q.dl.assign(std::max<size_t>(q.slotL.size(), 1), 0); q.dr.assign(std::max<size_t>(q.slotR.size(), 1), 0);
+    vslam_kf_update_problem& P = q.P;
+    P = vslam_kf_update_problem{};
     P.rig = cfg.rig; P.n_levels = nLev; P.inv_sigma_factor = invSigmaF.data(); P.numb = kf.numb;
-    P.key_pose = keyPose.data(); P.ref_pose = kf.refPose.data(); P.cur_pose_inv = kf.poseInv.data();
+    P.key_pose = q.keyPose.data(); P.ref_pose = kf.refPose.data(); P.cur_pose_inv = kf.poseInv.data();
     P.n_left = (int)kf.keys.kL.size(); P.n_right = (int)kf.keys.kR.size();
-    P.kps_left = kf.keys.kL.data(); P.kps_right = kf.keys.kR.data(); P.slot_lm_l = slotL.data(); P.slot_lm_r = slotR.data();
-    P.n_lm = (int)lms.size(); P.lm_xyz = xyz.data(); P.lm_kdx = kdx.data(); P.lm_outlier = ol.data();
-    std::vector<uint8_t> dl(std::max<size_t>(slotL.size(), 1)), dr(std::max<size_t>(slotR.size(), 1));
-    double poseOut[16];
-    VS_CHECK(vslam_keyframe_update_pose(&P, cfg.device, dl.data(), dr.data(), poseOut));
-    for (size_t j = 0; j < lms.size(); j++) { SysMP& m = mapPoints[lms[j]]; m.wp[0] = xyz[3 * j]; m.wp[1] = xyz[3 * j + 1]; m.wp[2] = xyz[3 * j + 2]; }
+    P.kps_left = kf.keys.kL.data(); P.kps_right = kf.keys.kR.data(); P.slot_lm_l = q.slotL.data(); P.slot_lm_r = q.slotR.data();
+    P.n_lm = (int)q.lms.size(); P.lm_xyz = q.xyz.data(); P.lm_kdx = q.kdx.data(); P.lm_outlier = q.ol.data();
+}
+
+void vslam_system::kf_update_apply(SysKF& kf, LcaReq& q) {
+    for (size_t j = 0; j < q.lms.size(); j++) { SysMP& m = mapPoints[q.lms[j]]; m.wp[0] = q.xyz[3 * j]; m.wp[1] = q.xyz[3 * j + 1]; m.wp[2] = q.xyz[3 * j + 2]; }
     auto drop = [&](std::vector<int>& lmp, std::vector<int>& un, const std::vector<uint8_t>& d) {
         for (size_t i = 0; i < lmp.size(); i++) {
             if (!d[i] || lmp[i] < 0) continue;
@@ -405,24 +407,43 @@ vslam_status vslam_system::kf_update_pose(SysKF& kf, const M4& keyPose) {
             lmp[i] = -1; un[i] = -1;
         }
     };
-    drop(kf.lmpL, kf.unF, dl); drop(kf.lmpR, kf.unFR, dr);
-    kf.setPose(m4_mul(keyPose, kf.refPose));               // pose.changePose(keyPose)
+    drop(kf.lmpL, kf.unF, q.dl); drop(kf.lmpR, kf.unFR, q.dr);
+    kf.setPose(m4_mul(q.keyPose, kf.refPose));               // pose.changePose(keyPose)
+}
+
+vslam_status vslam_system::kf_update_pose(SysKF& kf, const M4& keyPose) {
+    LcaReq q;
+    kf_update_gather(kf, keyPose, q);
+    double poseOut[16];
+    VS_CHECK(vslam_keyframe_update_pose(&q.P, cfg.device, q.dl.data(), q.dr.data(), poseOut));
+    kf_update_apply(kf, q);
     return VSLAM_OK;
 }
 
 // changePosesLCA (src/FeatureTracker.cpp:884-908)
-vslam_status vslam_system::change_poses_lca(int endIdx) {
-    int k = endIdx;
-    while (keyFrames[k].nextKF >= 0) {
-        const M4 keyPose = keyFrames[k].pose;
-        VS_CHECK(kf_update_pose(keyFrames[keyFrames[k].nextKF], keyPose));
-        k = keyFrames[k].nextKF;
-    }
+void vslam_system::lca_finish(int k) {
     const M4 keyPose = keyFrames[k].pose;
     camPose = m4_mul(keyPose, camRefPose); camPoseInv = m4_affine_inv(camPose);
     lastKFPoseInv = m4_affine_inv(keyPose);
     predNPose = m4_mul(camPose, predNPoseRef);
     predNPoseInv = m4_affine_inv(predNPose);
+}
+
+vslam_status vslam_system::change_poses_lca(int endIdx) {
+    int k = endIdx;
+    // a lockstep lane with exactly one keyframe behind the BA's newest (the usual case: keyframes are >= 5 frames apart, the write-back
+    // lands k frames after the hand-over) leaves the device step to the group's request service
+    if (deferLca && keyFrames[k].nextKF >= 0 && keyFrames[keyFrames[k].nextKF].nextKF < 0) {
+        kf_update_gather(keyFrames[keyFrames[k].nextKF], keyFrames[k].pose, lcaReq);
+        lcaReq.pending = true;
+        return VSLAM_OK;
+    }
+    while (keyFrames[k].nextKF >= 0) {
+        const M4 keyPose = keyFrames[k].pose;
+        VS_CHECK(kf_update_pose(keyFrames[keyFrames[k].nextKF], keyPose));
+        k = keyFrames[k].nextKF;
+    }
+    lca_finish(k);
     return VSLAM_OK;
 }
 
@@ -445,6 +466,11 @@ vslam_status vslam_system::frame_begin_a(SysFrameCtx& c, int frame, const vslam_
 }
 
 vslam_status vslam_system::frame_begin_b(SysFrameCtx& c) {
+    VS_CHECK(frame_begin_b1(c));
+    return frame_begin_b2(c);
+}
+
+vslam_status vslam_system::frame_begin_b1(SysFrameCtx& c) {
     std::lock_guard<std::mutex> lk(mapMutex);
     VS_CHECK(mapping_begin_b(c.frame));
     if (LBADone) {                                         // :1115-1122
@@ -452,6 +478,17 @@ vslam_status vslam_system::frame_begin_b(SysFrameCtx& c) {
         VS_CHECK(change_poses_lca(endLBAIdx));
         LBADone = false;
     }
+    return VSLAM_OK;
+}
+
+// the deferred keyframe update (served by the group between b1 and b2) lands; nothing to do otherwise
+vslam_status vslam_system::frame_begin_b2(SysFrameCtx&) {
+    if (!lcaReq.pending) return VSLAM_OK;
+    std::lock_guard<std::mutex> lk(mapMutex);
+    SysProfScope ps(sys_prof().lcaNs, sys_prof().lcaN);
+    kf_update_apply(keyFrames[lcaReq.kf], lcaReq);
+    lcaReq.pending = false;
+    lca_finish(lcaReq.kf);
     return VSLAM_OK;
 }
 

@@ -268,6 +268,22 @@ struct vslam_system {
     void calc_connections(SysKF& kf);
     vslam_status change_poses_lca(int endIdx);
     vslam_status kf_update_pose(SysKF& kf, const M4& keyPose);
+    // KeyFrame::updatePose in three steps, so that a lockstep group serves the device step of all its lanes with one wait:
+    // gather (host) -> vslam_keyframe_update_pose / kf_update_pose_enqueue (device) -> apply (host)
+    struct LcaReq {
+        bool pending = false;          // a one-keyframe chain waits for the group's request service (frame_begin_b1 -> serve -> frame_begin_b2)
+        int kf = -1;
+        M4 keyPose;
+        std::vector<int> lms, slotL, slotR;
+        std::vector<double> xyz; std::vector<int64_t> kdx; std::vector<uint8_t> ol, dl, dr;
+        vslam_kf_update_problem P{};
+    } lcaReq;
+    bool deferLca = false;             // vslam_batch: set around frame_begin_b1
+    void kf_update_gather(SysKF& kf, const M4& keyPose, LcaReq& q);
+    void kf_update_apply(SysKF& kf, LcaReq& q);
+    void lca_finish(int k);
+    vslam_status frame_begin_b1(SysFrameCtx& c);
+    vslam_status frame_begin_b2(SysFrameCtx& c);
     // the pass, in the order of the schedule (vslam_hip.h, vslam_system_config::mapping_delay)
     void mapping_window(std::vector<int>& actKeyF);
     void np_collect(MapPass& p);
