@@ -468,7 +468,21 @@ __global__ __launch_bounds__(256) void k_ba_factors(const BaDev* __restrict__ ta
         if (fuseCtl) {
             ba_ctl(D, MODE, relTol, absTol);
             sLast = MODE == 1 && !D.specLin && ((const int*)(D.ctl + CTL_INTS))[CI_STATE] == BA_LINEARIZE;
-            if (D.ctlHost) for (int i = 0; i < CTL_DOUBLES; i++) D.ctlHost[i] = D.ctl[i];
+            if (D.ctlHost) {
+                // The block was just written through int and double views of the same bytes: wait for those stores, then copy it with
+                // alias-safe accesses.  (Copied as doubles right behind ba_ctl, a read could overtake the int stores it aliases - the
+                // compiler sees no dependence between the types, and nothing else orders the load behind the store or keeps it off a
+                // cached line: the mirror then lagged one control step behind, and a lane's final BA_DONE never reached the host.
+                // Seen as one run in a dozen ending in "LM did not terminate" / a pass cut short.)
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                const unsigned long long* src = (const unsigned long long*)D.ctl;
+                unsigned long long* dst = (unsigned long long*)D.ctlHost;
+                for (int i = 0; i < CTL_DOUBLES; i++) dst[i] = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (from the L2, not a cached line)
+                // ... and the copy must have LANDED in host memory before this kernel ends: the next round's control step writes the same
+                // 128 bytes from another CU, and nothing orders two CUs' writes to system memory against each other - an older block
+                // arriving last would hide the lane's BA_DONE from the host for good (seen: one run in ten ended in "LM did not terminate")
+                __threadfence_system();
+            }
         }
     }
     __syncthreads();
@@ -658,6 +672,70 @@ __device__ __forceinline__ double ba2_dpp_xor(double v, int which) {      // lan
     else { l2 = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true); h2 = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true); }
     return __hiloint2double(h2, l2);
 }
+// per-lane roles of the staged forms (fixed for a kernel) and the shared front part: stage -> Hll | bl -> (Hll + lambda I)^-1 -> W rows
+struct Ba2Roles {
+    int hk, hq, hx, hy, hyStep; bool hOn; double hSign;      // h: lane 4k + q, k < 9
+    int ws, wi;                                               // W / WH: lane (s, i)
+    __device__ __forceinline__ void init(int lane) {
+        hk = lane >> 2; hq = lane & 3; hOn = hk < 9;
+        // k < 6: (a, b) in (0,0) (0,1) (0,2) (1,1) (1,2) (2,2): Jl[a] Jl[b] + Jl[3 + a] Jl[3 + b];  k >= 6: -(Jl[a] r0 + Jl[3 + a] r1), a = k - 6
+        const int ha = hk < 3 ? 0 : (hk < 5 ? 1 : (hk == 5 ? 2 : hk - 6));
+        const int hbx = hk < 3 ? hk : (hk < 5 ? hk - 2 : 2);
+        hx = 14 + ha;
+        hy = hk < 6 ? 14 + hbx : 0;
+        hyStep = hk < 6 ? 3 : 1;     // second operand of the second product: Jl[3 + b] or r1
+        hSign = hk < 6 ? 1.0 : -1.0;
+        ws = lane / 6; wi = lane - ws * 6;
+    }
+};
+struct Ba2Region { double* F; double* W; double* WH; double* hb; int* ffi; int* sst; int* sfi; };
+__device__ __forceinline__ Ba2Region ba2_region(double* base, int maxFac, int maxSlots) {
+    Ba2Region g;
+    g.F = base; g.W = g.F + maxFac * 20; g.WH = g.W + maxSlots * 18; g.hb = g.WH + maxSlots * 18;
+    g.ffi = (int*)(g.hb + 10); g.sst = g.ffi + maxFac; g.sfi = g.sst + maxSlots + 1;
+    return g;
+}
+// the landmark's factor rows, free indices and slot table into the wave's region; then h = Hll (6 unique, undamped) | bl in every lane
+__device__ __forceinline__ void ba2_stage_h(const BaDev& D, int lp, const Ba2Region& g, const Ba2Roles& R, int lane, double* h, int& nf, int& ns) {
+    const int f0 = D.lpStart[lp], s0 = D.lpSlotStart[lp];
+    nf = D.lpStart[lp + 1] - f0;
+    ns = D.lpSlotStart[lp + 1] - s0 - 1;     // one end sentinel per landmark
+    // (prefetching the next landmark's rows into registers under this one's arithmetic was measured: no gain)
+    {
+        const double2* src = (const double2*)(D.facJ + (size_t)f0 * 20);
+        double2* dst = (double2*)g.F;
+        for (int i = lane; i < nf * 10; i += 64) dst[i] = src[i];
+        for (int i = lane; i < nf; i += 64) g.ffi[i] = D.facFi[f0 + i];
+        for (int i = lane; i <= ns; i += 64) { g.sst[i] = D.slotStart[s0 + i] - f0; g.sfi[i] = D.slotFi[s0 + i]; }
+    }
+    ba_wave_fence();
+    {
+        double acc = 0;
+        if (R.hOn)
+            for (int f = R.hq; f < nf; f += 4) {
+                const double* o = g.F + f * 20;
+                acc += o[R.hx] * o[R.hy] + o[R.hx + 3] * o[R.hy + R.hyStep];
+            }
+        acc += ba2_dpp_xor(acc, 0);
+        acc += ba2_dpp_xor(acc, 1);
+        if (R.hOn && R.hq == 0) g.hb[R.hk] = R.hSign * acc;
+    }
+    ba_wave_fence();
+#pragma unroll
+    for (int k = 0; k < 9; k++) h[k] = g.hb[k];
+}
+// row i of slot s's Hpl block from the staged rows (lane (s, i), s < ns)
+__device__ __forceinline__ void ba2_w_row(const Ba2Region& g, const Ba2Roles& R, double& w0, double& w1, double& w2) {
+    w0 = w1 = w2 = 0;
+    for (int f = g.sst[R.ws]; f < g.sst[R.ws + 1]; f++) {
+        const double* o = g.F + f * 20;
+        const double a0 = o[2 + R.wi], a1 = o[8 + R.wi];
+        w0 += a0 * o[14] + a1 * o[17];
+        w1 += a0 * o[15] + a1 * o[18];
+        w2 += a0 * o[16] + a1 * o[19];
+    }
+}
+
 __global__ __launch_bounds__(1024) void k_ba_schur2(const BaDev* __restrict__ tab, int maxSlots, int maxFac) {
     BaDev D = *lane_entry(tab, blockIdx.z);      // per-lane argument block (grid z = problem of the cohort)
     extern __shared__ double sm[];
@@ -668,83 +746,31 @@ __global__ __launch_bounds__(1024) void k_ba_schur2(const BaDev* __restrict__ ta
     double* const racc = Sloc + (size_t)n * n;
     const int lane = threadIdx.x & 63;
     const int unit = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nu = blockDim.x >> 6, nt = blockDim.x;
-    double* const base = sm + sys + (size_t)unit * ba2_stage_doubles(maxFac, maxSlots);
-    double* const F = base;
-    double* const W = F + maxFac * 20;
-    double* const WH = W + maxSlots * 18;
-    double* const hb = WH + maxSlots * 18;               // h[0..8]
-    int* const ffi = (int*)(hb + 10);
-    int* const sst = ffi + maxFac;
-    int* const sfi = sst + maxSlots + 1;
+    const Ba2Region g = ba2_region(sm + sys + (size_t)unit * ba2_stage_doubles(maxFac, maxSlots), maxFac, maxSlots);
+    double* const F = g.F; double* const W = g.W; double* const WH = g.WH;
+    int* const ffi = g.ffi; int* const sfi = g.sfi;
     const double lam = D.lambda;
-    // ---- per-lane roles (fixed for the kernel) ----
-    // h: lane 4k + q, k < 9
-    const int hk = lane >> 2, hq = lane & 3;
-    const bool hOn = hk < 9;
-    int hx = 0, hy = 0;                    // offsets inside a factor row of the two operand pairs: x at (hx, hx + 3), y at (hy, hy + ...)
-    {
-        // k < 6: (a, b) in (0,0) (0,1) (0,2) (1,1) (1,2) (2,2): Jl[a] Jl[b] + Jl[3 + a] Jl[3 + b];  k >= 6: -(Jl[a] r0 + Jl[3 + a] r1), a = k - 6
-        const int ha = hk < 3 ? 0 : (hk < 5 ? 1 : (hk == 5 ? 2 : hk - 6));
-        const int hbx = hk < 3 ? hk : (hk < 5 ? hk - 2 : 2);
-        hx = 14 + ha;
-        hy = hk < 6 ? 14 + hbx : 0;
-    }
-    const int hyStep = hk < 6 ? 3 : 1;     // second operand of the second product: Jl[3 + b] or r1
-    const double hSign = hk < 6 ? 1.0 : -1.0;
-    // W / WH: lane (s, i)
-    const int ws = lane / 6, wi = lane - ws * 6;
-    // Hpp: lane (f, i), two factors' worth of rows per pass would need 12 lanes each: lane / 6 = factor within the pass
-    const int pf = lane / 6, pi = lane - pf * 6;           // pf < 10: ten factors per pass
+    Ba2Roles R;
+    R.init(lane);
+    const int pf = lane / 6, pi = lane - pf * 6;           // Hpp: lane (f, i), ten factors per pass
     for (int i = threadIdx.x; i < sys; i += nt) Sloc[i] = 0;
     __syncthreads();
     for (int lp = blockIdx.x * nu + unit; lp < D.Lp; lp += gridDim.x * nu) {
-        const int f0 = D.lpStart[lp], s0 = D.lpSlotStart[lp];
-        const int nf = D.lpStart[lp + 1] - f0;
-        const int ns = D.lpSlotStart[lp + 1] - s0 - 1;     // one end sentinel per landmark
-        // ---- stage ----  (prefetching the next landmark's rows into registers under this one's arithmetic was measured: no gain -
-        //                   the kernel is bound by its VALU instruction count, ~1 100 per landmark, not by this round trip)
-        {
-            const double2* src = (const double2*)(D.facJ + (size_t)f0 * 20);
-            double2* dst = (double2*)F;
-            for (int i = lane; i < nf * 10; i += 64) dst[i] = src[i];
-            for (int i = lane; i < nf; i += 64) ffi[i] = D.facFi[f0 + i];
-            for (int i = lane; i <= ns; i += 64) { sst[i] = D.slotStart[s0 + i] - f0; sfi[i] = D.slotFi[s0 + i]; }
-        }
-        ba_wave_fence();
-        // ---- h ----
-        {
-            double acc = 0;
-            if (hOn)
-                for (int f = hq; f < nf; f += 4) {
-                    const double* o = F + f * 20;
-                    acc += o[hx] * o[hy] + o[hx + 3] * o[hy + hyStep];
-                }
-            acc += ba2_dpp_xor(acc, 0);
-            acc += ba2_dpp_xor(acc, 1);
-            if (hOn && hq == 0) hb[hk] = hSign * acc;
-        }
-        ba_wave_fence();
         double h[9];
-#pragma unroll
-        for (int k = 0; k < 9; k++) h[k] = hb[k];
+        int nf, ns;
+        ba2_stage_h(D, lp, g, R, lane, h, nf, ns);
         double Hi[9];
         ba_hll_inverse(h, lam, Hi);
         // ---- W, WH, rhs: lane (s, i) ----
-        if (ws < ns) {
-            double w0 = 0, w1 = 0, w2 = 0;
-            for (int f = sst[ws]; f < sst[ws + 1]; f++) {
-                const double* o = F + f * 20;
-                const double a0 = o[2 + wi], a1 = o[8 + wi];
-                w0 += a0 * o[14] + a1 * o[17];
-                w1 += a0 * o[15] + a1 * o[18];
-                w2 += a0 * o[16] + a1 * o[19];
-            }
+        if (R.ws < ns) {
+            double w0, w1, w2;
+            ba2_w_row(g, R, w0, w1, w2);
             const double g0 = w0 * Hi[0] + w1 * Hi[3] + w2 * Hi[6], g1 = w0 * Hi[1] + w1 * Hi[4] + w2 * Hi[7], g2 = w0 * Hi[2] + w1 * Hi[5] + w2 * Hi[8];
-            double* wr = W + ws * 18 + wi * 3;
+            double* wr = W + R.ws * 18 + R.wi * 3;
             wr[0] = w0; wr[1] = w1; wr[2] = w2;
-            double* gr = WH + ws * 18 + wi * 3;
+            double* gr = WH + R.ws * 18 + R.wi * 3;
             gr[0] = g0; gr[1] = g1; gr[2] = g2;
-            atomicAdd(&racc[6 * sfi[ws] + wi], -(g0 * h[6] + g1 * h[7] + g2 * h[8]));
+            atomicAdd(&racc[6 * sfi[R.ws] + R.wi], -(g0 * h[6] + g1 * h[7] + g2 * h[8]));
         }
         ba_wave_fence();
         // ---- blocks: two lanes own one 6x6 block (s1 <= s2), three rows each; 32 blocks per pass ----
@@ -788,6 +814,55 @@ __global__ __launch_bounds__(1024) void k_ba_schur2(const BaDev* __restrict__ ta
     __syncthreads();
     double* dst = D.Spart + (size_t)blockIdx.x * sys;
     for (int i = threadIdx.x; i < sys; i += nt) dst[i] = Sloc[i];
+}
+
+// Back-substitution on the same staged front part: dl = (Hll + lambda I)^-1 (bl - sum_s W_s^T dP_s) per candidate, trial landmark positions.
+// Lane (s, i) multiplies its W row by its entry of the slot's pose update; the three sums over the <= 60 lanes finish with two DPP quad
+// steps + four shuffles.  No reduced-system copy in LDS: two workgroups of eight waves per CU.
+__global__ __launch_bounds__(512) void k_ba_back2(const BaDev* __restrict__ tab, int maxSlots, int maxFac) {
+    BaDev D = *lane_entry(tab, blockIdx.z);      // per-lane argument block (grid z = problem of the cohort)
+    extern __shared__ double sm[];
+    if (!ba_enter(D, BA_TRY, 0)) return;
+    const int nc = D.nAct;
+    const int sel = ((const int*)(D.ctl + CTL_INTS))[CI_SEL];
+    const int lane = threadIdx.x & 63;
+    const int unit = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nu = blockDim.x >> 6;
+    const Ba2Region g = ba2_region(sm + (size_t)unit * ba2_stage_doubles(maxFac, maxSlots), maxFac, maxSlots);
+    Ba2Roles R;
+    R.init(lane);
+    for (int lp = blockIdx.x * nu + unit; lp < D.Lp; lp += gridDim.x * nu) {
+        double h[9];
+        int nf, ns;
+        ba2_stage_h(D, lp, g, R, lane, h, nf, ns);
+        double w0 = 0, w1 = 0, w2 = 0;
+        int kcol = 0;
+        if (R.ws < ns) { ba2_w_row(g, R, w0, w1, w2); kcol = 6 * g.sfi[R.ws] + R.wi; }
+        const int l = D.lpOrig[lp];
+        double lamk = D.lambda;
+        for (int k = 0; k < nc; k++, lamk *= 10.0) {
+            const double* dPk = D.dP + (size_t)k * D.n;         // (ba_enter already applied candidate 0)
+            const double dp = R.ws < ns ? dPk[kcol] : 0.0;
+            double t0 = w0 * dp, t1 = w1 * dp, t2 = w2 * dp;
+            t0 += ba2_dpp_xor(t0, 0); t1 += ba2_dpp_xor(t1, 0); t2 += ba2_dpp_xor(t2, 0);
+            t0 += ba2_dpp_xor(t0, 1); t1 += ba2_dpp_xor(t1, 1); t2 += ba2_dpp_xor(t2, 1);
+#pragma unroll
+            for (int d = 4; d <= 32; d <<= 1) { t0 += __shfl_xor(t0, d); t1 += __shfl_xor(t1, d); t2 += __shfl_xor(t2, d); }
+            double Hi[9];
+            ba_hll_inverse(h, lamk, Hi);
+            if (lane < 3) {
+                const double u0 = h[6] - t0, u1 = h[7] - t1, u2 = h[8] - t2;
+                // (row `lane` of Hi picked by selects: indexing the register array by the lane would put it in scratch)
+                const double h0 = lane == 0 ? Hi[0] : (lane == 1 ? Hi[3] : Hi[6]);
+                const double h1 = lane == 0 ? Hi[1] : (lane == 1 ? Hi[4] : Hi[7]);
+                const double h2 = lane == 0 ? Hi[2] : (lane == 1 ? Hi[5] : Hi[8]);
+                const double dl = h0 * u0 + h1 * u1 + h2 * u2;
+                D.dL[(size_t)k * D.dLStride + 3 * (size_t)lp + lane] = dl;
+                double* lmT = D.lmBase + (size_t)ba_slot(sel, k, D.NB) * D.lmStride;
+                lmT[3 * (size_t)l + lane] = D.lmCur[3 * (size_t)l + lane] + dl;
+            }
+        }
+        ba_wave_fence();            // the region is rewritten for the next landmark
+    }
 }
 
 // Sum of the per-workgroup partial systems.  This is the buffer the landmark-sharded multi-GPU path all-reduces (RCCL)
@@ -2313,7 +2388,7 @@ static vslam_status ba_kernel_attributes() {
         const int cap = 160 * 1024;
         const void* fns[] = {(const void*)k_ba_schur, (const void*)k_ba_schur_win, (const void*)k_ba_solve, (const void*)k_ba_back,
                              (const void*)k_ba_solve_mfma, (const void*)k_ba_chol_col, (const void*)k_ba_chol_back, (const void*)k_ba_lm_prep,
-                             (const void*)k_ba_schur2};
+                             (const void*)k_ba_schur2, (const void*)k_ba_back2};
         for (const void* f : fns) {
             hipFuncAttributes fa{};      // (the limit is on static + dynamic LDS together)
             hipError_t e = hipFuncGetAttributes(&fa, f);
@@ -3101,6 +3176,9 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
     // (the kernel is a latency chain per landmark-wave: every workgroup of the cohort resident at once - one per CU at this LDS size -,
     //  each wave walks a few landmarks)
     if (useSchur2) lmBlocks = std::max(1, std::min((lpMax + 2 * s2Waves - 1) / (2 * s2Waves), lbEnv ? lbEnv : std::max(4, nCU / NL)));
+    static const bool b2Env = !(getenv("VSLAM_BA_BACK2") && atoi(getenv("VSLAM_BA_BACK2")) == 0);
+    const size_t b2Lds = 8 * s2StageB;
+    const int b2Blocks = std::max(1, std::min((lpMax + 15) / 16, std::max(8, 2 * nCU / NL)));
     int backWaves = BA_SCHUR_WAVES / BACK_LPW;
     auto back_lds = [&](int nw) { return (size_t)nw * BACK_LPW * maxSlots * 18 * sizeof(double) + (size_t)nw * BACK_LPW * maxSlots * sizeof(int) + 16; };
     while (backWaves > 1 && back_lds(backWaves) > 150 * 1024) backWaves /= 2;
@@ -3217,7 +3295,8 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
         if (anyMfma) hipLaunchKernelGGL(k_ba_solve_mfma, dim3(NB, 1, NL), dim3(64 * BA_MFMA_NW), mfmaLds, stream, dTab, (double*)nullptr);
         g_baTimer.end(t);
         t = g_baTimer.begin("ba_back");
-        hipLaunchKernelGGL(k_ba_back, dim3(backBlocks, sharedBack ? 1 : NB, NL), dim3(64 * backWaves), backLds, stream, dTab, maxSlots, sharedBack);
+        if (useSchur2 && b2Env) hipLaunchKernelGGL(k_ba_back2, dim3(b2Blocks, 1, NL), dim3(64 * 8), b2Lds, stream, dTab, maxSlots, maxFac);
+        else hipLaunchKernelGGL(k_ba_back, dim3(backBlocks, sharedBack ? 1 : NB, NL), dim3(64 * backWaves), backLds, stream, dTab, maxSlots, sharedBack);
         g_baTimer.end(t);
         t = g_baTimer.begin("ba_eval");
         hipLaunchKernelGGL(k_ba_factors<1>, dim3(facBlocks, NB, NL), dim3(256), 0, stream, dTab, obsBlocks, 1, relTol, absTol);
@@ -3235,13 +3314,14 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
     // synchronisation of this stream), then two at a time.
     auto lm_loop = [&](int first) -> vslam_status {
         static const int perPollEnv = getenv("VSLAM_BA_STEPS_PER_POLL") ? std::max(1, atoi(getenv("VSLAM_BA_STEPS_PER_POLL"))) : 0;
-        int enq = 0;
+        int enq = 0, polls = 0;
         for (;;) {
             const int batch = perPollEnv ? perPollEnv : (enq == 0 ? first : 2);
             for (int b = 0; b < batch; b++) VS_CHECK(step(enq + b == 0));
             enq += batch;
             static const bool mirrorOff = getenv("VSLAM_BA_CTL_MIRROR") && atoi(getenv("VSLAM_BA_CTL_MIRROR")) == 0;
-            if (mirrorOff) VS_HIP(hipMemcpyAsync(b_ctl, A.dev(h_ctlAll), (size_t)CTL_DOUBLES * 8 * NL, hipMemcpyDeviceToHost, stream));
+            // (belt and braces: a pass that needs more than a handful of polls reads the device's own blocks - the authoritative copy)
+            if (mirrorOff || ++polls > 4) VS_HIP(hipMemcpyAsync(b_ctl, A.dev(h_ctlAll), (size_t)CTL_DOUBLES * 8 * NL, hipMemcpyDeviceToHost, stream));
             VS_HIP(vslam::stream_wait_blocking(stream));      // (every control step mirrors its block into the landing area: BaDev::ctlHost)
             g_bbsPolls++;
             bool all = true;
