@@ -51,7 +51,7 @@ CONFIGS = {
     "c3": dict(rig="kitti", nfeat=2000, imu=False, name="C3-class: KITTI-00-like stereo 1241x376, 2000 features/image"),
 }
 # PMC passes of the default command's launch shape (tools/measure_set.sh); "_meta" names the shape they were taken on
-PMC_FILE = os.path.join(ROOT, "profiles", os.environ.get("VSLAM_BENCH_PMC", "r03_b_pmc_summary.json"))
+PMC_FILE = os.path.join(ROOT, "profiles", os.environ.get("VSLAM_BENCH_PMC", "r03_c_pmc_summary.json"))
 
 
 def level_pixels(w, h, nlevels=8, scale=1.2):
@@ -571,7 +571,7 @@ def main():
                      "proj_candidates": "k_proj_candidates" + bsfx, "proj_cells": "k_proj_cells" + bsfx, "imu_preintegrate": "k_imu_preintegrate" + bsfx,
                      "track_predict": "k_track_predict" + bsfx, "track_repredict": "k_track_repredict" + bsfx, "pack": "k_track_pack" + bsfx,
                      "pyramid": "k_resize", "ba_solve": "k_ba_solve_mfma64", "ssc": "k_ssc<2>",
-                     "ba_schur": "k_ba_schur2", "ba_back": "k_ba_back", "ba_eval": "k_ba_factors<1>", "ba_linearize": "k_ba_factors<0>", "ba_chi2": "k_ba_chi2",
+                     "ba_schur": "k_ba_schur2", "ba_back": "k_ba_back2", "ba_eval": "k_ba_factors<1>", "ba_linearize": "k_ba_factors<0>", "ba_chi2": "k_ba_chi2",
                      "fast": "k_fast", "blur": "k_blur", "gather": "k_gather", "orient_desc": "k_orient_desc"}
             try:
                 pmc_all = json.load(open(PMC_FILE))

@@ -3167,7 +3167,9 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
     int lmBlocks = std::max(1, std::min((lpMax + schurUnits - 1) / schurUnits, lbEnv ? lbEnv : std::max(16, 2 * nCU / NL)));
     // k_ba_schur2 (tracker windows): one LDS copy of the system + a staging region per landmark-wave
     static const bool s2Env = !(getenv("VSLAM_BA_SCHUR2") && atoi(getenv("VSLAM_BA_SCHUR2")) == 0);
-    const int s2WavesEnv = getenv("VSLAM_BA_SCHUR2_WAVES") ? atoi(getenv("VSLAM_BA_SCHUR2_WAVES")) : 16;
+    // (alone on the GPU 8 / 12 / 16 waves per workgroup take the same time; between the lockstep groups' wide kernels the smaller LDS footprint
+    //  finds a CU sooner: 8 waves here, 4 for the back-substitution - ba_back 15.7 -> 10.6 us per tracked frame)
+    const int s2WavesEnv = getenv("VSLAM_BA_SCHUR2_WAVES") ? atoi(getenv("VSLAM_BA_SCHUR2_WAVES")) : 8;
     const size_t s2StageB = (size_t)ba2_stage_doubles(maxFac, maxSlots) * sizeof(double);
     int s2Waves = std::max(2, std::min(16, s2WavesEnv));
     while (s2Waves > 2 && sysMax * sizeof(double) + s2Waves * s2StageB > 156 * 1024) s2Waves /= 2;
@@ -3175,10 +3177,11 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
     const bool useSchur2 = s2Env && fMax <= BA2_MAX_F && maxSlots <= BA2_MAX_F && s2Lds <= 156 * 1024;
     // (the kernel is a latency chain per landmark-wave: every workgroup of the cohort resident at once - one per CU at this LDS size -,
     //  each wave walks a few landmarks)
-    if (useSchur2) lmBlocks = std::max(1, std::min((lpMax + 2 * s2Waves - 1) / (2 * s2Waves), lbEnv ? lbEnv : std::max(4, nCU / NL)));
+    if (useSchur2) lmBlocks = std::max(1, std::min((lpMax + 2 * s2Waves - 1) / (2 * s2Waves), lbEnv ? lbEnv : std::max(4, (16 / s2Waves) * nCU / NL)));
     static const bool b2Env = !(getenv("VSLAM_BA_BACK2") && atoi(getenv("VSLAM_BA_BACK2")) == 0);
-    const size_t b2Lds = 8 * s2StageB;
-    const int b2Blocks = std::max(1, std::min((lpMax + 15) / 16, std::max(8, 2 * nCU / NL)));
+    const int b2Waves = std::max(1, std::min(8, getenv("VSLAM_BA_BACK2_WAVES") ? atoi(getenv("VSLAM_BA_BACK2_WAVES")) : 4));
+    const size_t b2Lds = b2Waves * s2StageB;
+    const int b2Blocks = std::max(1, std::min((lpMax + 2 * b2Waves - 1) / (2 * b2Waves), std::max(8, (16 / b2Waves) * nCU / NL)));
     int backWaves = BA_SCHUR_WAVES / BACK_LPW;
     auto back_lds = [&](int nw) { return (size_t)nw * BACK_LPW * maxSlots * 18 * sizeof(double) + (size_t)nw * BACK_LPW * maxSlots * sizeof(int) + 16; };
     while (backWaves > 1 && back_lds(backWaves) > 150 * 1024) backWaves /= 2;
@@ -3295,7 +3298,7 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
         if (anyMfma) hipLaunchKernelGGL(k_ba_solve_mfma, dim3(NB, 1, NL), dim3(64 * BA_MFMA_NW), mfmaLds, stream, dTab, (double*)nullptr);
         g_baTimer.end(t);
         t = g_baTimer.begin("ba_back");
-        if (useSchur2 && b2Env) hipLaunchKernelGGL(k_ba_back2, dim3(b2Blocks, 1, NL), dim3(64 * 8), b2Lds, stream, dTab, maxSlots, maxFac);
+        if (useSchur2 && b2Env) hipLaunchKernelGGL(k_ba_back2, dim3(b2Blocks, 1, NL), dim3(64 * b2Waves), b2Lds, stream, dTab, maxSlots, maxFac);
         else hipLaunchKernelGGL(k_ba_back, dim3(backBlocks, sharedBack ? 1 : NB, NL), dim3(64 * backWaves), backLds, stream, dTab, maxSlots, sharedBack);
         g_baTimer.end(t);
         t = g_baTimer.begin("ba_eval");

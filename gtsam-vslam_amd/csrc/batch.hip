@@ -26,6 +26,7 @@
 #include "imu_dev.hpp"
 #include "track_dev.hpp"
 #include "ba_pool.hpp"
+#include "job_engine.hpp"
 #include <chrono>
 #include <malloc.h>
 
@@ -55,10 +56,7 @@ inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 // VSLAM_MAP_ENGINE_PRIVATE=1: one engine per group (round-3 first form).
 struct MapEngine {
     int device = 0;
-    std::vector<std::thread> threads;
-    std::deque<vslam_system*> npQueue, baQueue;      // released jobs
-    std::mutex mu; std::condition_variable npCv, baCv;
-    bool stop = false;
+    vslam::JobEngine<vslam_system*> eng;           // queues + threads (job_engine.hpp: host-only, ThreadSanitizer-tested)
     // local-BA stage timing of the cohorts (HIP events on the engine's stream), summed since the last read
     std::atomic<int> baTimingOn{0};
     std::atomic<long long> baCohortSeq{0};
@@ -66,92 +64,58 @@ struct MapEngine {
     std::vector<std::pair<const char*, float>> baTimes;
     long long baTimedCohorts = 0, baTimedLanes = 0;
 
-    void release_jobs(std::deque<vslam_system*>& np, std::deque<vslam_system*>& ba) {
-        bool n = false, b = false;
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            for (vslam_system* s : np) { npQueue.push_back(s); n = true; }
-            for (vslam_system* s : ba) { baQueue.push_back(s); b = true; }
-        }
-        np.clear(); ba.clear();
-        if (n) npCv.notify_one();
-        if (b) baCv.notify_one();
+    void release_jobs(std::deque<vslam_system*>& np, std::deque<vslam_system*>& ba) { eng.release_jobs(np, ba); }
+    // the cohort's new-point searches: one upload, one launch per kernel, one download (vslam_find_new_points_batch)
+    void serve_np(std::vector<vslam_system*>& jobs) {
+        std::vector<const vslam_new_points_problem*> Ps; std::vector<vslam_new_points_result*> Rs;
+        for (vslam_system* s : jobs) { Ps.push_back(&s->pass.np.P); Rs.push_back(&s->pass.np.R); }
+        vslam_status st;
+        { SysProfScope pn(sys_prof().npNs, sys_prof().npN); st = vslam_find_new_points_batch(Ps.data(), Rs.data(), (int)jobs.size(), device); }
+        char err[200];
+        snprintf(err, sizeof(err), "%s", st == VSLAM_OK ? "" : vslam_last_error());
+        for (vslam_system* s : jobs) s->finish_job(st, err);
     }
-    void np_loop() {
-        hipSetDevice(device);
-        for (;;) {
-            std::vector<vslam_system*> jobs;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                npCv.wait(lk, [&] { return stop || !npQueue.empty(); });
-                if (npQueue.empty()) break;        // (stop requested and nothing left)
-                jobs.assign(npQueue.begin(), npQueue.end()); npQueue.clear();
-            }
-            // the cohort's new-point searches: one upload, one launch per kernel, one download (vslam_find_new_points_batch)
-            std::vector<const vslam_new_points_problem*> Ps; std::vector<vslam_new_points_result*> Rs;
-            for (vslam_system* s : jobs) { Ps.push_back(&s->pass.np.P); Rs.push_back(&s->pass.np.R); }
-            vslam_status st;
-            { SysProfScope pn(sys_prof().npNs, sys_prof().npN); st = vslam_find_new_points_batch(Ps.data(), Rs.data(), (int)jobs.size(), device); }
-            char err[200];
-            snprintf(err, sizeof(err), "%s", st == VSLAM_OK ? "" : vslam_last_error());
-            for (vslam_system* s : jobs) s->finish_job(st, err);
-        }
-        vslam::thread_release();
-    }
-    void ba_loop() {
-        hipSetDevice(device);
-        for (;;) {
-            std::vector<vslam_system*> jobs;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                baCv.wait(lk, [&] { return stop || !baQueue.empty(); });
-                if (baQueue.empty()) break;
-                jobs.assign(baQueue.begin(), baQueue.end()); baQueue.clear();
-            }
-            const auto t0 = std::chrono::steady_clock::now();
-            std::vector<const vslam_ba_problem*> Ps; std::vector<vslam_ba_result*> Rs;
-            for (vslam_system* s : jobs) { Ps.push_back(&s->pass.ba.P); Rs.push_back(&s->pass.ba.R); }
-            // stage timing (HIP events around every launch) on every 4th cohort while it is switched on: the events are launches of
-            // their own on a launch-bound path (measured: all cohorts timed costs 8 % frames/s)
-            const int timing = baTimingOn.load() && (baCohortSeq.fetch_add(1) % 4) == 0;
-            vslam_local_ba_set_timing(timing);
-            vslam_status st;
-            { SysProfScope pb(sys_prof().baNs, sys_prof().baN); st = vslam_local_ba_batch(Ps.data(), Rs.data(), (int)jobs.size(), device); }
-            if (st == VSLAM_OK && timing) {
-                const char* nm[32]; float ms[32]; int n = 0;
-                if (vslam_local_ba_timings(nm, ms, 32, &n) == VSLAM_OK) {
-                    std::lock_guard<std::mutex> lk(btMu);
-                    baTimedCohorts++; baTimedLanes += (long long)jobs.size();
-                    for (int i = 0; i < n; i++) {
-                        size_t j = 0;
-                        for (; j < baTimes.size(); j++) if (!strcmp(baTimes[j].first, nm[i])) break;
-                        if (j == baTimes.size()) baTimes.push_back({nm[i], 0.f});
-                        baTimes[j].second += ms[i];
-                    }
+    // the cohort's local BAs: ONE batched call (vslam_local_ba_batch: one launch per stage for all of them)
+    void serve_ba(std::vector<vslam_system*>& jobs) {
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<const vslam_ba_problem*> Ps; std::vector<vslam_ba_result*> Rs;
+        for (vslam_system* s : jobs) { Ps.push_back(&s->pass.ba.P); Rs.push_back(&s->pass.ba.R); }
+        // stage timing (HIP events around every launch) on every 4th cohort while it is switched on: the events are launches of
+        // their own on a launch-bound path (measured: all cohorts timed costs 8 % frames/s)
+        const int timing = baTimingOn.load() && (baCohortSeq.fetch_add(1) % 4) == 0;
+        vslam_local_ba_set_timing(timing);
+        vslam_status st;
+        { SysProfScope pb(sys_prof().baNs, sys_prof().baN); st = vslam_local_ba_batch(Ps.data(), Rs.data(), (int)jobs.size(), device); }
+        if (st == VSLAM_OK && timing) {
+            const char* nm[32]; float ms[32]; int n = 0;
+            if (vslam_local_ba_timings(nm, ms, 32, &n) == VSLAM_OK) {
+                std::lock_guard<std::mutex> lk(btMu);
+                baTimedCohorts++; baTimedLanes += (long long)jobs.size();
+                for (int i = 0; i < n; i++) {
+                    size_t j = 0;
+                    for (; j < baTimes.size(); j++) if (!strcmp(baTimes[j].first, nm[i])) break;
+                    if (j == baTimes.size()) baTimes.push_back({nm[i], 0.f});
+                    baTimes[j].second += ms[i];
                 }
             }
-            char err[200];
-            snprintf(err, sizeof(err), "%s", st == VSLAM_OK ? "" : vslam_last_error());
-            for (vslam_system* s : jobs) s->finish_job(st, err);
-            {
-                const long long d = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
-                SysProf& p = sys_prof();
-                p.mqNs += d; p.mqN++; p.mqLate += (long long)jobs.size();
-                if (d > 15000000) p.mapLate++;
-                long long m = p.mapMaxNs.load(); while (d > m && !p.mapMaxNs.compare_exchange_weak(m, d)) {}
-            }
         }
-        vslam::thread_release();
+        char err[200];
+        snprintf(err, sizeof(err), "%s", st == VSLAM_OK ? "" : vslam_last_error());
+        for (vslam_system* s : jobs) s->finish_job(st, err);
+        const long long d = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        SysProf& p = sys_prof();
+        p.mqNs += d; p.mqN++; p.mqLate += (long long)jobs.size();
+        if (d > 15000000) p.mapLate++;
+        long long m = p.mapMaxNs.load(); while (d > m && !p.mapMaxNs.compare_exchange_weak(m, d)) {}
     }
     void start(int nNp, int nBa) {
-        for (int t = 0; t < nNp; t++) threads.emplace_back([this]() { np_loop(); });
-        for (int t = 0; t < nBa; t++) threads.emplace_back([this]() { ba_loop(); });
+        eng.lanes[0].serve = [this](std::vector<vslam_system*>& j) { serve_np(j); };
+        eng.lanes[1].serve = [this](std::vector<vslam_system*>& j) { serve_ba(j); };
+        eng.onThreadStart = [this]() { hipSetDevice(device); };
+        eng.onThreadExit = []() { vslam::thread_release(); };
+        eng.start(nNp, nBa);
     }
-    ~MapEngine() {
-        { std::lock_guard<std::mutex> lk(mu); stop = true; }
-        npCv.notify_all(); baCv.notify_all();
-        for (auto& t : threads) t.join();
-    }
+    ~MapEngine() { eng.shutdown(); }
     // one engine per device, alive while a group of that device holds it
     static std::shared_ptr<MapEngine> acquire(int device, int nBaThreads) {
         static std::mutex gMu;
