@@ -86,7 +86,6 @@ struct SscArgs {
     int* flags;             // per image: [2 img] error bits of the suppression, [2 img + 1] capacity overflow
 };
 
-struct SscSide { hipStream_t a, b; hipEvent_t evFork, evA, evB; };
-void launch_ssc(hipStream_t s, const SscArgs& A, uint32_t* kept, int keptCap, int* keptOff, int* hostCounts, const SscSide* side = nullptr);
+void launch_ssc(hipStream_t s, const SscArgs& A, uint32_t* kept, int keptCap, int* keptOff, int* hostCounts);
 
 }  // namespace vslam

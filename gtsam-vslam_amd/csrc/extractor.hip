@@ -181,14 +181,6 @@ vslam_status vslam_extractor::init(const vslam_fe_params* p, int w, int h, int b
     VS_HIP(vslam::create_main_stream(&stream));
     VS_HIP(hipEventCreateWithFlags(&evGather, hipEventDisableTiming));
     VS_HIP(hipEventCreateWithFlags(&evDone, hipEventDisableTiming));
-    {
-        static const bool sideEnv = getenv("VSLAM_EXTRACT_SIDE") && atoi(getenv("VSLAM_EXTRACT_SIDE")) != 0;      // (measured: no gain - the chip is saturated by the two groups; kept as a switch)
-        sideStreams = sideEnv && nimg >= 8;      // (a stereo pair alone gains nothing: its kernels do not fill the chip either way)
-        if (sideStreams) {
-            for (hipStream_t* q : {&sBlur, &sSscA, &sSscB}) VS_HIP(vslam::create_main_stream(q));
-            for (hipEvent_t* e : {&evPyr, &evBlur, &evSscFork, &evSscA, &evSscB}) VS_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
-        }
-    }
     timer.stream = stream;
     // (+256: k_blur / k_resize read whole dwords up to 8 bytes past the last pixel of a row)
     VS_HIP(hipMalloc(&d_pyr, (size_t)nimg * P.imgStride + 256));
@@ -287,10 +279,6 @@ void vslam_extractor::release() {
     if (h_imgPtrs) hipHostFree(h_imgPtrs);
     hipFree(d_imgPtrs); h_imgPtrs = nullptr; d_imgPtrs = nullptr;
     d_sscTmp = nullptr; d_taskCount = nullptr; d_sscFlags = nullptr; h_counts = nullptr;
-    for (hipStream_t q : {sBlur, sSscA, sSscB}) if (q) { hipStreamSynchronize(q); hipStreamDestroy(q); }
-    sBlur = sSscA = sSscB = nullptr;
-    for (hipEvent_t e : {evPyr, evBlur, evSscFork, evSscA, evSscB}) if (e) hipEventDestroy(e);
-    evPyr = evBlur = evSscFork = evSscA = evSscB = nullptr;
     if (evGather) hipEventDestroy(evGather);
     if (evDone) hipEventDestroy(evDone);
     evGather = evDone = nullptr;
@@ -393,9 +381,7 @@ vslam_status vslam_extractor::enqueue_ssc() {
     S.tmp = d_sscTmp; S.aG = d_sscTmp + (size_t)nimg * candCap; S.sortedG = d_sscTmp + (size_t)2 * nimg * candCap;
     S.picksG = d_sscPicks; S.forceGlobal = sscForceGlobal ? 1 : 0;
     S.taskCount = d_taskCount; S.flags = d_sscFlags;
-    const bool side = sideStreams && !timer.enabled;
-    SscSide sd{sSscA, sSscB, evSscFork, evSscA, evSscB};
-    launch_ssc(stream, S, d_kept, keptCap, d_keptOff, d_counts, side ? &sd : nullptr);
+    launch_ssc(stream, S, d_kept, keptCap, d_keptOff, d_counts);
     return VSLAM_OK;
 }
 
@@ -419,14 +405,6 @@ vslam_status vslam_extractor::run() {
     for (int l = 1; l < nLevels; l++)
         launch_resize(stream, d_pyr, P, l, d_xtab + xtabOff[l], d_ytab + ytabOff[l], nimg);
     timer.end(t);
-    // (stage timing brackets launches with events on the main stream: everything stays there while it is on)
-    const bool side = sideStreams && !timer.enabled;
-    if (side) {
-        VS_HIP(hipEventRecord(evPyr, stream));
-        VS_HIP(hipStreamWaitEvent(sBlur, evPyr, 0));
-        launch_blur(sBlur, d_pyr, d_blur, P, B, nimg);
-        VS_HIP(hipEventRecord(evBlur, sBlur));
-    }
     t = timer.begin("fast");
     launch_fast(stream, d_pyr, P, F, d_cellSlots, d_cellCount, prm.max_fast_threshold,
                 prm.min_fast_threshold, nimg);
@@ -440,12 +418,9 @@ vslam_status vslam_extractor::run() {
     t = timer.begin("ssc");
     VS_CHECK(enqueue_ssc());
     timer.end(t);
-    if (side) VS_HIP(hipStreamWaitEvent(stream, evBlur, 0));
-    else {
-        t = timer.begin("blur");
-        launch_blur(stream, d_pyr, d_blur, P, B, nimg);
-        timer.end(t);
-    }
+    t = timer.begin("blur");
+    launch_blur(stream, d_pyr, d_blur, P, B, nimg);
+    timer.end(t);
     t = timer.begin("orient_desc");
     if (doubleOut) { outSel ^= 1; d_kps = d_kpsBuf[outSel]; d_desc = d_descBuf[outSel]; }
     launch_orient_desc(stream, d_pyr, d_blur, P, T, d_kept, d_keptOff, keptCap, discRows, d_kps,

@@ -24,11 +24,6 @@ struct vslam_extractor {
     // consumers = "last read of this extractor's buffers" events of the bound matchers, waited on before
     // the next frame overwrites the buffers
     hipEvent_t evGather = nullptr, evDone = nullptr;
-    // side streams of a run (batched extractors, stage timing off): the blur needs only the pyramid and runs beside FAST / the
-    // suppression; the suppression's three instantiations run side by side
-    hipStream_t sBlur = nullptr, sSscA = nullptr, sSscB = nullptr;
-    hipEvent_t evPyr = nullptr, evBlur = nullptr, evSscFork = nullptr, evSscA = nullptr, evSscB = nullptr;
-    bool sideStreams = false;
     std::vector<hipEvent_t> consumers;
     std::mutex consumersMu;
     void add_consumer(hipEvent_t e);

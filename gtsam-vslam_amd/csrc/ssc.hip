@@ -670,9 +670,7 @@ __global__ __launch_bounds__(256) void k_ssc_pack(SscArgs A, uint32_t* __restric
     }
 }
 
-// side (optional): two more streams + events.  The three instantiations serve disjoint (image, level) tasks, so they may run side by
-// side: the 148 KB tasks (one per CU, latency-bound chains) beside the 67 KB ones instead of after them.
-void launch_ssc(hipStream_t s, const SscArgs& A, uint32_t* kept, int keptCap, int* keptOff, int* hostCounts, const SscSide* side) {
+void launch_ssc(hipStream_t s, const SscArgs& A, uint32_t* kept, int keptCap, int* keptOff, int* hostCounts) {
     const size_t ldsL = ((size_t)2 * SscCfg<0>::NMAX + (size_t)4 * SscCfg<0>::SEGMAX) * 4;
     const size_t ldsS = ((size_t)2 * SscCfg<2>::NMAX + (size_t)4 * SscCfg<2>::SEGMAX) * 4;
     const size_t ldsG = ((size_t)4 * SscCfg<1>::SEGMAX + (size_t)SscCfg<1>::ARENA) * 4;
@@ -685,22 +683,11 @@ void launch_ssc(hipStream_t s, const SscArgs& A, uint32_t* kept, int keptCap, in
         (void)hipFuncSetAttribute((const void*)k_ssc<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsG);
     });
     // every (image, level) task is taken by exactly one of the three; the workgroups of the other two return at once
-    if (side) {
-        (void)hipEventRecord(side->evFork, s);
-        (void)hipStreamWaitEvent(side->a, side->evFork, 0);
-        (void)hipStreamWaitEvent(side->b, side->evFork, 0);
-        hipLaunchKernelGGL(k_ssc<0>, dim3(A.nimg * A.nLevels), dim3(SSC_NT), ldsL, side->a, A);
-        hipLaunchKernelGGL(k_ssc<1>, dim3(A.nimg * A.nLevels), dim3(SSC_NT), ldsG, side->b, A);
-        (void)hipEventRecord(side->evA, side->a);
-        (void)hipEventRecord(side->evB, side->b);
-        hipLaunchKernelGGL(k_ssc<2>, dim3(A.nimg * A.nLevels), dim3(SSC_NT), ldsS, s, A);
-        (void)hipStreamWaitEvent(s, side->evA, 0);
-        (void)hipStreamWaitEvent(s, side->evB, 0);
-    } else {
-        hipLaunchKernelGGL(k_ssc<2>, dim3(A.nimg * A.nLevels), dim3(SSC_NT), ldsS, s, A);
-        hipLaunchKernelGGL(k_ssc<0>, dim3(A.nimg * A.nLevels), dim3(SSC_NT), ldsL, s, A);
-        hipLaunchKernelGGL(k_ssc<1>, dim3(A.nimg * A.nLevels), dim3(SSC_NT), ldsG, s, A);
-    }
+    // (the three instantiations side by side on extra streams, and the blur beside FAST / the suppression, were measured in the full
+    //  run: no gain - the other lockstep group fills whatever a latency-bound kernel leaves idle - and removed again)
+    hipLaunchKernelGGL(k_ssc<2>, dim3(A.nimg * A.nLevels), dim3(SSC_NT), ldsS, s, A);
+    hipLaunchKernelGGL(k_ssc<0>, dim3(A.nimg * A.nLevels), dim3(SSC_NT), ldsL, s, A);
+    hipLaunchKernelGGL(k_ssc<1>, dim3(A.nimg * A.nLevels), dim3(SSC_NT), ldsG, s, A);
     hipLaunchKernelGGL(k_ssc_pack, dim3(A.nimg), dim3(256), 0, s, A, kept, keptCap, keptOff, hostCounts);
 }
 
