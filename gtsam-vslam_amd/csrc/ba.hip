@@ -360,9 +360,16 @@ __global__ __launch_bounds__(256) void k_ba_factors(const BaDev* __restrict__ ta
     __shared__ int sLast;
     double* const partialBase = D.partial;
     const int cand = MODE == 0 ? 0 : (int)blockIdx.y;      // trial launches: grid y = lambda candidate
-    if (!ba_enter(D, MODE == 0 ? BA_LINEARIZE : BA_TRY, cand)) return;
+    // A workgroup of a candidate beyond nAct has no work but still ARRIVES below: the control step rewrites the block every workgroup
+    // of this launch reads at entry (state, nAct, sel), so it may only run once all of them have read it.  (Counting the active
+    // candidates' workgroups only, a workgroup of candidate >= 1 that was dispatched late - behind other streams' kernels - could enter
+    // after a rejection had raised nAct from 1 to NB, take itself for active and bump the counter of the NEXT round: that round's
+    // control step then ran early or, with the counter past its target, never again - "LM did not terminate", seen in long runs.)
+    const bool active = ba_enter(D, MODE == 0 ? BA_LINEARIZE : BA_TRY, cand);
+    if (!active && ((const int*)(D.ctl + CTL_INTS))[CI_STATE] != (MODE == 0 ? BA_LINEARIZE : BA_TRY)) return;      // (not this lane's turn: no workgroup of it counts)
     const int tid = threadIdx.x;
-    if ((int)blockIdx.x < obsBlocks) {
+    if (!active) {
+    } else if ((int)blockIdx.x < obsBlocks) {
         double v[2] = {0, 0};
         for (int f = blockIdx.x * 256 + tid; f < D.NF; f += obsBlocks * 256) {
             if (MODE == 0) {
@@ -446,8 +453,8 @@ __global__ __launch_bounds__(256) void k_ba_factors(const BaDev* __restrict__ ta
     // the per-XCD L2), each publisher waits for its stores to complete before it bumps the arrival counter.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int nCandRun = MODE == 0 ? 1 : D.nAct;        // (workgroups of candidates beyond nAct left at ba_enter)
-    if (tid == 0) sLast = (__hip_atomic_fetch_add(&D.flags[FLAG_COUNT], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x * nCandRun - 1);
+    const int nCandRun = MODE == 0 ? 1 : D.nAct;        // (candidates with partials: ba_enter read nAct before it turned the others away)
+    if (tid == 0) sLast = (__hip_atomic_fetch_add(&D.flags[FLAG_COUNT], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)(gridDim.x * gridDim.y) - 1);
     __syncthreads();
     if (!sLast) return;
     const int nPart = obsBlocks + D.NE;         // (edge partials follow the observation partials)
@@ -3330,7 +3337,24 @@ static vslam_status ba_run_batch(const vslam_ba_problem* const* Ps, vslam_ba_res
             bool all = true;
             for (int a = 0; a < NL; a++) all &= ((const int*)(b_ctl + (size_t)CTL_DOUBLES * a + CTL_INTS))[CI_STATE] == BA_DONE;
             if (all) return VSLAM_OK;
-            if (enq > 400) { set_error("local BA batch: LM did not terminate"); return VSLAM_ERR_INVALID; }
+            if (enq > 400) {
+                // (diagnosis in the message: the control block of the first lane that is not done, as the device holds it)
+                (void)hipMemcpy(b_ctl, A.dev(h_ctlAll), (size_t)CTL_DOUBLES * 8 * NL, hipMemcpyDeviceToHost);
+                for (int a = 0; a < NL; a++) {
+                    const double* c = b_ctl + (size_t)CTL_DOUBLES * a;
+                    const int* ci = (const int*)(c + CTL_INTS);
+                    if (ci[CI_STATE] == BA_DONE) continue;
+                    int fl[8] = {0};
+                    (void)hipMemcpy(fl, lanes[act[a]].d_flags, sizeof(fl), hipMemcpyDeviceToHost);
+                    set_error("local BA batch: LM did not terminate (lane %d of %d: state %d sel %d iter %d inner %d maxit %d first %d nact %d rounds %d lambda %g error %g cur %g; "
+                              "F %d NF %d Lp %d NE %d; flags %d %d %d %d | %d %d %d %d; obsBlocks %d neMax %d)", a, NL, ci[CI_STATE], ci[CI_SEL], ci[CI_ITER], ci[CI_INNER], ci[CI_MAXIT], ci[CI_FIRST], ci[CI_NACT], ci[CI_ROUNDS],
+                              c[CTL_LAMBDA], c[CTL_ERROR], c[CTL_CUR], lanes[act[a]].H.F, lanes[act[a]].H.NF, lanes[act[a]].H.Lp, lanes[act[a]].H.NE,
+                              fl[0], fl[1], fl[2], fl[3], fl[4], fl[5], fl[6], fl[7], obsBlocks, neMax);
+                    return VSLAM_ERR_INVALID;
+                }
+                set_error("local BA batch: LM did not terminate (every lane done on the device: the host's copy lagged)");
+                return VSLAM_ERR_INVALID;
+            }
         }
     };
     auto report = [&](int ps) {

@@ -259,6 +259,37 @@ def test_ba_batch_equals_single_calls(oracle, capi):
     assert np.abs(ref["kf_pose"] - batch[0]["kf_pose"]).max() < 1e-6
 
 
+def test_ba_batch_under_contention_repeats_its_trajectory(oracle, capi):
+    """Three host threads (the mapping engine's shape) run cohorts of the batched BA at the same time, many times over: every
+    repetition must walk the same LM trajectory.  Regression for the arrival counter of k_ba_factors<1>: with one active lambda
+    candidate the control step could run while workgroups of the inactive candidates were still waiting for a CU; a late one then
+    read the rewritten control block, counted itself into the NEXT round and the lane's LM stalled ("LM did not terminate") or
+    decided on incomplete sums.  The problems carry outliers so that passes contain rejections (nAct 1 -> 4 -> 1 transitions)."""
+    import threading
+    ex = oracle.Extractor(1500)
+    rig = synth.RIGS["euroc"]
+    probs = [synth.make_ba_problem(n_local=4 + (i % 7), n_fixed=2 + (i % 3), n_lm=500 + 100 * (i % 5), seed=60 + i, outlier_frac=0.05 * (i % 4)) for i in range(12)]
+    want = [[(r["iterations"], r["inner"]) for r in b["reports"]] for b in capi.local_ba_batch(rig, ex.sigmaFactor, ex.InvSigmaFactor, probs)]
+    assert any(inner > it for rep in want for it, inner in rep)          # (some pass did reject a trial)
+    errs = []
+
+    def run():
+        try:
+            for _ in range(25):
+                got = capi.local_ba_batch(rig, ex.sigmaFactor, ex.InvSigmaFactor, probs)
+                if [[(r["iterations"], r["inner"]) for r in b["reports"]] for b in got] != want:
+                    errs.append("trajectory changed")
+        except Exception as e:      # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=run) for _ in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    assert not errs, errs[:3]
+
+
 @pytest.mark.parametrize("n_local,n_fixed", [(10, 4), (14, 3), (24, 2)])
 def test_ba_non_mfma_solves_parity(oracle, capi, n_local, n_fixed):
     """vslam_local_ba_set_solver(1): the reduced camera system solved WITHOUT the MFMA kernels - matrix rows in registers with
