@@ -1382,12 +1382,13 @@ __global__ __launch_bounds__(64 * BA_MFMA_NW) void k_ba_solve_mfma(const BaDev* 
     constexpr int N = BA_MFMA_N, NB = BA_MFMA_NB, LD = BA_MFMA_LD;
     if (D.Lg) Lg = D.Lg;
     Lg += (size_t)D.cand * N * N;
-    const int n = D.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = D.n, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (wave-uniform: the tile coordinates below stay in SGPRs - 34 VGPRs and the last spills)
     if (tid == 0) sBad = 0;
     // tile t = ib (ib + 1) / 2 + jb (jb <= ib) lives in slot t / 8 of wave t % 8; accumulator layout of
     // v_mfma_f64_16x16x4: register r of lane l = element (row (l >> 4) + 4 r, column l & 15)
     ba_d4 acc[BA_MFMA_SLOTS];
-    int tib[BA_MFMA_SLOTS], tjb[BA_MFMA_SLOTS];
+    int tpk[BA_MFMA_SLOTS];          // ib | jb << 8 (ib = 255: no tile), one SGPR per slot
 #pragma unroll
     for (int s = 0; s < BA_MFMA_SLOTS; s++) {
         const int t = s * BA_MFMA_NW + wave;
@@ -1395,7 +1396,7 @@ __global__ __launch_bounds__(64 * BA_MFMA_NW) void k_ba_solve_mfma(const BaDev* 
         while ((ib + 1) * (ib + 2) / 2 <= t) ib++;
         const int jb = t - ib * (ib + 1) / 2;
         const bool valid = ib < NB;
-        tib[s] = valid ? ib : -1; tjb[s] = jb;
+        tpk[s] = (valid ? ib : 255) | (jb << 8);
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int row = ib * 16 + (lane >> 4) + 4 * r, col = jb * 16 + (lane & 15);
@@ -1410,9 +1411,10 @@ __global__ __launch_bounds__(64 * BA_MFMA_NW) void k_ba_solve_mfma(const BaDev* 
         // (a) panel tiles (ib, kb), ib >= kb -> LDS
 #pragma unroll
         for (int s = 0; s < BA_MFMA_SLOTS; s++) {
-            if (tib[s] >= kb && tjb[s] == kb) {
+            const int tib = tpk[s] & 255, tjb = tpk[s] >> 8;
+            if (tib != 255 && tib >= kb && tjb == kb) {
 #pragma unroll
-                for (int r = 0; r < 4; r++) P[(tib[s] * 16 + (lane >> 4) + 4 * r) * LD + (lane & 15)] = acc[s][r];
+                for (int r = 0; r < 4; r++) P[(tib * 16 + (lane >> 4) + 4 * r) * LD + (lane & 15)] = acc[s][r];
             }
         }
         __syncthreads();
@@ -1464,9 +1466,10 @@ __global__ __launch_bounds__(64 * BA_MFMA_NW) void k_ba_solve_mfma(const BaDev* 
         // (d) trailing update: tile (ib, jb) -= L21[ib] L21[jb]^T, 4 k-steps of v_mfma_f64_16x16x4
 #pragma unroll
         for (int s = 0; s < BA_MFMA_SLOTS; s++) {
-            if (tib[s] > kb && tjb[s] > kb) {
-                const double* pa = P + (tib[s] * 16 + (lane & 15)) * LD + (lane >> 4);
-                const double* pb = P + (tjb[s] * 16 + (lane & 15)) * LD + (lane >> 4);
+            const int tib = tpk[s] & 255, tjb = tpk[s] >> 8;
+            if (tib != 255 && tib > kb && tjb > kb) {
+                const double* pa = P + (tib * 16 + (lane & 15)) * LD + (lane >> 4);
+                const double* pb = P + (tjb * 16 + (lane & 15)) * LD + (lane >> 4);
 #pragma unroll
                 for (int ks = 0; ks < 4; ks++) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * ks], pb[4 * ks], acc[s], 0, 0, 0);
             }
@@ -2117,6 +2120,221 @@ __global__ __launch_bounds__(256) void k_ba_init_slots_b(const BaDev* __restrict
     }
 }
 
+
+// ---- factor ordering on the device (large problems: the 100 k-landmark window) --------------------------------------------------
+// BaPassHost::count / fill as kernels over the raw pair arrays, which are on the device anyway (the chi2 kernel reads them).  The
+// factor order is (landmark, free index, pair, side): a TOTAL order - the bucket of a landmark is filled in arrival order (atomics)
+// and every factor then finds its place by counting the entries of its bucket that precede it, so the result does not depend on the
+// arrival order and equals the host's stable counting sort + insertion sort entry for entry.
+struct BaOrd {
+    int NP, L, K, world, rank;
+    const int* pairKf; const int* pairLm; const uint8_t* pairFlags; const uint8_t* wrong; const float* pairUv; const int* pairOct;
+    int* cnt; int* lpOf; int* tLpOrig; int* tLpStart; int* kfPres; uint8_t* lmPres; long long* scal;      // phase 1 (sized by L, K)
+    const int* fidx; int* fillc; int* ns; int* key; int* src; int* key2; int* src2;                        // phase 2 (sized by NF, Lp)
+    int* facKf; int* facFi; int* facLp; int* facLm; int* facPair; double* facZ; double* facIs; uint8_t* facRight;
+    int* lpStart; int* lpSlotStart; int* lpOrig; int* slotStart; int* slotFi;
+    float invSigma[MAX_LEVELS];
+};
+enum { ORD_LP = 0, ORD_NF = 1, ORD_NSLOT = 2, ORD_MAXSLOTS = 3, ORD_MAXFAC = 4, ORD_SUMK2 = 5, ORD_K2_MASKED = 6, ORD_SCAL = 8 };
+
+__global__ __launch_bounds__(256) void k_ord_count(BaOrd O) {
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < O.NP; p += gridDim.x * 256) {
+        if (O.wrong[p]) continue;
+        const int fl = O.pairFlags[p] & 3;
+        if (!fl) continue;
+        const int l = O.pairLm[p];
+        O.kfPres[O.pairKf[p]] = 1; O.lmPres[l] = 1;             // graph membership is global
+        if (l % O.world != O.rank) continue;                      // landmark shard of this rank
+        atomicAdd(&O.cnt[l], (fl & 1) + (fl >> 1));
+    }
+}
+// block-wide inclusive scan of two ints per thread (1024 threads)
+__device__ __forceinline__ void ord_scan2(int& a, int& b, int* sA, int* sB) {
+    const int tid = threadIdx.x;
+    sA[tid] = a; sB[tid] = b;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int va = tid >= d ? sA[tid - d] : 0, vb = tid >= d ? sB[tid - d] : 0;
+        __syncthreads();
+        sA[tid] += va; sB[tid] += vb;
+        __syncthreads();
+    }
+    a = sA[tid]; b = sB[tid];
+}
+// landmarks of this rank's shard that are in the graph, in index order: lpOf / lpOrig, and the start of every bucket
+__global__ __launch_bounds__(1024) void k_ord_scan_lm(BaOrd O) {
+    __shared__ int sA[1024], sB[1024];
+    const int tid = threadIdx.x, per = (O.L + 1023) / 1024, l0 = min(O.L, tid * per), l1 = min(O.L, l0 + per);
+    int a = 0, b = 0;
+    for (int l = l0; l < l1; l++) if (O.lmPres[l] && l % O.world == O.rank) { a++; b += O.cnt[l]; }
+    int ia = a, ib = b;
+    ord_scan2(ia, ib, sA, sB);
+    int ea = ia - a, eb = ib - b;
+    for (int l = l0; l < l1; l++) {
+        if (O.lmPres[l] && l % O.world == O.rank) { O.lpOf[l] = ea; O.tLpOrig[ea] = l; O.tLpStart[ea] = eb; ea++; eb += O.cnt[l]; }
+        else O.lpOf[l] = -1;
+    }
+    if (tid == 1023) { O.tLpStart[ia] = ib; O.scal[ORD_LP] = ia; O.scal[ORD_NF] = ib; O.scal[ORD_K2_MASKED] = 0; }
+}
+__global__ __launch_bounds__(256) void k_ord_scatter(BaOrd O) {
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < O.NP; p += gridDim.x * 256) {
+        if (O.wrong[p]) continue;
+        const int l = O.pairLm[p];
+        if (l % O.world != O.rank) continue;
+        const int fl = O.pairFlags[p] & 3;
+        if (!fl) continue;
+        const int lp = O.lpOf[l], fi = O.fidx[O.pairKf[p]];
+        const int c = (fl & 1) + (fl >> 1);
+        int pos = O.tLpStart[lp] + atomicAdd(&O.fillc[lp], c);
+        for (int side = 0; side < 2; side++) {
+            if (!((fl >> side) & 1)) continue;
+            O.key[pos] = fi; O.src[pos] = 2 * p + side; O.facLp[pos] = lp;
+            pos++;
+        }
+    }
+}
+// every factor finds its place inside its landmark's bucket: the number of entries (fi, 2 pair + side) that precede it
+__global__ __launch_bounds__(256) void k_ord_rank(BaOrd O, int NF) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= NF) return;
+    const int lp = O.facLp[f], f0 = O.tLpStart[lp], f1 = O.tLpStart[lp + 1];
+    const int k = O.key[f], v = O.src[f];
+    int r = 0;
+    for (int g = f0; g < f1; g++) { const int kg = O.key[g], vg = O.src[g]; r += (kg < k || (kg == k && vg < v)) ? 1 : 0; }
+    O.key2[f0 + r] = k; O.src2[f0 + r] = v;
+}
+__global__ __launch_bounds__(256) void k_ord_ns(BaOrd O, int Lp) {
+    const int lp = blockIdx.x * 256 + threadIdx.x;
+    if (lp >= Lp) return;
+    int last = -2, ns = 0;
+    for (int f = O.tLpStart[lp]; f < O.tLpStart[lp + 1]; f++) { const int fi = O.key2[f]; if (fi >= 0 && fi != last) { last = fi; ns++; } }
+    O.ns[lp] = ns;
+}
+// slot-table prefix (per landmark its slots + an end sentinel), the statistics of the pass, and the landmark arrays into their final place
+__global__ __launch_bounds__(1024) void k_ord_scan_slots(BaOrd O, int Lp) {
+    __shared__ int sA[1024], sB[1024];
+    __shared__ long long sK[1024];
+    const int tid = threadIdx.x, per = (Lp + 1023) / 1024, a0 = min(Lp, tid * per), a1 = min(Lp, a0 + per);
+    int a = 0, mx = 0, mf = 0;
+    long long k2 = 0;
+    for (int lp = a0; lp < a1; lp++) {
+        const int ns = O.ns[lp], nf = O.tLpStart[lp + 1] - O.tLpStart[lp];
+        a += ns + 1; mx = max(mx, ns); mf = max(mf, nf); k2 += (long long)ns * ns;
+        O.lpStart[lp] = O.tLpStart[lp]; O.lpOrig[lp] = O.tLpOrig[lp];
+    }
+    int ia = a, dummy = 0;
+    ord_scan2(ia, dummy, sA, sB);
+    int ea = ia - a;
+    for (int lp = a0; lp < a1; lp++) { O.lpSlotStart[lp] = ea; ea += O.ns[lp] + 1; }
+    __syncthreads();
+    sA[tid] = mx; sB[tid] = mf; sK[tid] = k2;
+    __syncthreads();
+    for (int d = 512; d >= 1; d >>= 1) {
+        if (tid < d) { sA[tid] = max(sA[tid], sA[tid + d]); sB[tid] = max(sB[tid], sB[tid + d]); sK[tid] += sK[tid + d]; }
+        __syncthreads();
+    }
+    if (tid == 1023) { O.lpSlotStart[Lp] = ia; O.lpStart[Lp] = O.tLpStart[Lp]; O.scal[ORD_NSLOT] = ia; }
+    if (tid == 0) { O.scal[ORD_MAXSLOTS] = max(sA[0], 1); O.scal[ORD_MAXFAC] = max(sB[0], 1); O.scal[ORD_SUMK2] = sK[0]; }
+}
+// statistics of the masked second pass: sum over the landmarks of (free keyframes still observing it)^2 with the rejected pairs left out
+__global__ __launch_bounds__(256) void k_ord_k2_masked(BaOrd O, int Lp) {
+    __shared__ long long sK[4];
+    const int lp = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long k2 = 0;
+    if (lp < Lp) {
+        int last = -2, ns = 0;
+        for (int f = O.lpStart[lp]; f < O.lpStart[lp + 1]; f++) {
+            if (O.wrong[O.facPair[f]]) continue;
+            const int fi = O.facFi[f];
+            if (fi >= 0 && fi != last) { last = fi; ns++; }
+        }
+        k2 = (long long)ns * ns;
+    }
+    for (int d = 32; d >= 1; d >>= 1) k2 += __shfl_xor(k2, d);
+    if (lane == 0) sK[wave] = k2;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd((unsigned long long*)&O.scal[ORD_K2_MASKED], (unsigned long long)(sK[0] + sK[1] + sK[2] + sK[3]));
+}
+__global__ __launch_bounds__(256) void k_ord_emit_fac(BaOrd O, int NF) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= NF) return;
+    const int fi = O.key2[f], sv = O.src2[f], p = sv >> 1, side = sv & 1;
+    O.facKf[f] = O.pairKf[p]; O.facFi[f] = fi; O.facLm[f] = O.pairLm[p];
+    O.facZ[2 * (size_t)f] = (double)O.pairUv[4 * (size_t)p + 2 * side]; O.facZ[2 * (size_t)f + 1] = (double)O.pairUv[4 * (size_t)p + 2 * side + 1];
+    O.facIs[f] = 1.0 / (1.0 / (double)O.invSigma[O.pairOct[2 * p + side]]);
+    O.facRight[f] = (uint8_t)side;
+    O.facPair[f] = p;
+}
+__global__ __launch_bounds__(256) void k_ord_emit_slots(BaOrd O, int Lp) {
+    const int lp = blockIdx.x * 256 + threadIdx.x;
+    if (lp >= Lp) return;
+    const int f0 = O.tLpStart[lp], f1 = O.tLpStart[lp + 1];
+    int se = O.lpSlotStart[lp], last = -2;
+    for (int f = f0; f < f1; f++) {
+        const int fi = O.key2[f];
+        if (fi >= 0 && fi != last) { O.slotStart[se] = f; O.slotFi[se] = fi; se++; last = fi; }
+    }
+    O.slotStart[se] = f1; O.slotFi[se] = -1;     // end sentinel
+}
+
+
+// ---- work lists of the windowed Schur accumulation on the device (same lists as the host sweep in ba_run: per window the landmarks
+// with slots in both of its block rows, ascending) : per 256-landmark block and window a count, a prefix over (window, block), the fill
+struct BaWinOrd {
+    int Lp, TB, nBR, nWin, nBlk;
+    const int* lpSlotStart; const int* slotFi;
+    int* blkCnt; int* blkOff;       // [nWin][nBlk]
+    int* winCnt;                    // [nWin + 1]
+    int* winLm;
+};
+template <int FILL>
+__global__ __launch_bounds__(256) void k_win_lists(BaWinOrd Q) {
+    __shared__ int sWave[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lp = blockIdx.x * 256 + tid;
+    unsigned long long rows = 0;        // block rows (free index / TB) this landmark has slots in: <= 43 for 170 free keyframes
+    if (lp < Q.Lp)
+        for (int se = Q.lpSlotStart[lp]; se < Q.lpSlotStart[lp + 1] - 1; se++) rows |= 1ull << (Q.slotFi[se] / Q.TB);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int w = 0;
+    for (int a = 0; a < Q.nBR; a++)
+        for (int b = a; b < Q.nBR; b++, w++) {
+            const bool has = ((rows >> a) & 1ull) && ((rows >> b) & 1ull);
+            const unsigned long long bal = __ballot(has);
+            int* sw = sWave[w & 1];                      // (double-buffered: one barrier per window)
+            if (lane == 0) sw[wave] = __popcll(bal);
+            __syncthreads();
+            int before = 0, total = 0;
+            for (int k = 0; k < 4; k++) { const int c = sw[k]; if (k < wave) before += c; total += c; }
+            if (FILL) { if (has) Q.winLm[Q.blkOff[(size_t)w * Q.nBlk + blockIdx.x] + before + __popcll(bal & lt)] = lp; }
+            else if (tid == 0) Q.blkCnt[(size_t)w * Q.nBlk + blockIdx.x] = total;
+        }
+}
+__global__ __launch_bounds__(1024) void k_win_prefix(BaWinOrd Q) {
+    extern __shared__ int sTot[];       // [nWin] totals, then bases
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int w = wave; w < Q.nWin; w += 16) {
+        int run = 0;
+        for (int base = 0; base < Q.nBlk; base += 64) {
+            const int c = base + lane;
+            const int v = c < Q.nBlk ? Q.blkCnt[(size_t)w * Q.nBlk + c] : 0;
+            int inc = v;
+            for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+            if (c < Q.nBlk) Q.blkOff[(size_t)w * Q.nBlk + c] = run + inc - v;
+            run += __shfl(inc, 63);
+        }
+        if (lane == 0) sTot[w] = run;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int w = 0; w < Q.nWin; w++) { const int t = sTot[w]; sTot[w] = run; Q.winCnt[w] = run; run += t; }
+        Q.winCnt[Q.nWin] = run;
+    }
+    __syncthreads();
+    for (int w = wave; w < Q.nWin; w += 16)
+        for (int c = lane; c < Q.nBlk; c += 64) Q.blkOff[(size_t)w * Q.nBlk + c] += sTot[w];
+}
+
 }  // namespace vslam
 
 using namespace vslam;
@@ -2259,13 +2477,18 @@ struct BaPassHost {
         };
         if (nr > 1) pool->run(nr, scan); else scan(0);
         for (int r = 0; r < nr; r++) { NF += (int)nfPart[r]; if (nr > 1) for (int k = 0; k < K; k++) T.kfPresent[k] |= kfPart[r][k]; }
+        T.lpOf.assign(L, -1);
+        Lp = 0;
+        for (int l = 0; l < L; l++) if (T.lmPresent[l] && l % world == rank) T.lpOf[l] = Lp++;
+        free_set_and_edges(P, rank, T);
+    }
+    // free keyframes and the BetweenFactor chain from T.kfPresent (shared by the host and the device ordering)
+    void free_set_and_edges(const vslam_ba_problem* P, int rank, BaHostTmp& T) {
+        const int K = P->n_kf;
         T.fidx.assign(K, -1);
         F = 0;
         for (int k = 0; k < K; k++) if (T.kfPresent[k] && !P->kf_fixed[k]) T.fidx[k] = F++;
         n = 6 * F;
-        T.lpOf.assign(L, -1);
-        Lp = 0;
-        for (int l = 0; l < L; l++) if (T.lmPresent[l] && l % world == rank) T.lpOf[l] = Lp++;
         // edges: id-consecutive keyframes of this pass's graph (src/OptimizationBA.cpp:750-768)
         T.order.clear();
         for (int k = 0; k < K; k++) if (T.kfPresent[k]) T.order.push_back(k);
@@ -2293,7 +2516,7 @@ struct BaPassHost {
     }
     // bucket by landmark (counting sort, pair order preserved), order each short bucket by free index, emit the arrays
     void fill(const vslam_ba_problem* P, const uint8_t* wrong, int rank, int world, BaHostTmp& T, const DPose* pose0, BaPool* pool, int edgeSlots) {
-        const int K = P->n_kf, L = P->n_lm, NP = P->n_pairs;
+        const int L = P->n_lm, NP = P->n_pairs;
         for (int l = 0; l < L; l++) if (T.lpOf[l] >= 0) { h_lpOrig[T.lpOf[l]] = l; }
         {
             int run = 0;
@@ -2372,8 +2595,13 @@ struct BaPassHost {
             }
         });
         h_lpSlotStart[Lp] = nSlotEntries;
-        for (int k = 0; k < K; k++) { h_fidx[k] = T.fidx[k]; h_kfPresent[k] = T.kfPresent[k]; }
         for (int l = 0; l < L; l++) h_lmPresent[l] = T.lmPresent[l];
+        fill_small(P, T, pose0, edgeSlots);
+    }
+    // the host-written small arrays: free index, membership of the keyframes, BetweenFactor edges
+    void fill_small(const vslam_ba_problem* P, BaHostTmp& T, const DPose* pose0, int edgeSlots) {
+        const int K = P->n_kf;
+        for (int k = 0; k < K; k++) { h_fidx[k] = T.fidx[k]; h_kfPresent[k] = T.kfPresent[k]; }
         for (int i = 0; i < NE; i++) {
             BaEdge e{};
             e.a = T.order[i]; e.b = T.order[i + 1]; e.fa = T.fidx[e.a]; e.fb = T.fidx[e.b];
@@ -2408,6 +2636,9 @@ static vslam_status ba_kernel_attributes() {
 }
 
 static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int device, const vslam_comm* comm) {
+#ifdef VSLAM_HOST_STAMPS
+    const double bhs_fn0 = bhs_now();
+#endif
 #ifndef VSLAM_HOST_STAMPS
     auto bhs_t = std::chrono::steady_clock::now();
     g_bhsCalls++;
@@ -2444,6 +2675,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         DevBuf<int> d_flags, d_win, d_cholFail;
         DevBuf<double> d_cholY, d_winW, d_winH;
         DevBuf<uint8_t> d_wrong;
+        DevBuf<int> d_ord1, d_ord2, d_winTmp; long long* h_ordScal = nullptr; size_t ordScalCap = 0;      // device-side factor ordering (large problems)
         PinnedArena arena;
         BaHostTmp tmp;
         BaPool pool;
@@ -2460,8 +2692,9 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
             for (void* p : {(void*)d_poseS.p, (void*)d_lmS.p, (void*)d_facJ.p, (void*)d_S.p, (void*)d_Spart.p,
                             (void*)d_Sedge.p, (void*)d_dP.p, (void*)d_dL.p, (void*)d_lmDiff.p, (void*)d_sums.p, (void*)d_partial.p, (void*)d_Lg.p,
                             (void*)d_win.p, (void*)d_cholFail.p, (void*)d_cholY.p, (void*)d_winW.p, (void*)d_winH.p, (void*)d_flags.p,
-                            (void*)d_wrong.p, (void*)arena.d})
+                            (void*)d_wrong.p, (void*)d_ord1.p, (void*)d_ord2.p, (void*)d_winTmp.p, (void*)arena.d})
                 if (p) hipFree(p);
+            if (h_ordScal) hipHostFree(h_ordScal);
             if (arena.h) hipHostFree(arena.h);
             if (h_ctlOut) hipHostFree(h_ctlOut);
             if (h_const) hipHostFree(h_const);
@@ -2585,19 +2818,91 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
     auto& T = ws->tmp;
 
 #ifdef VSLAM_HOST_STAMPS
+    hipStreamSynchronize(stream);
     double bhs_t = bhs_now();
+    fprintf(stderr, "  ba host: %-12s %8.1f us\n", "entry..const", bhs_t - bhs_fn0);
 #endif
     BHS("setup");
     for (int pass = 0; pass < 2; pass++) {
         // ---- host: factor list of this pass, ordered by (landmark, free index, pair, side) -----------
         // Everything the kernels read is written straight into ONE pinned arena and uploaded with one copy.
         BaPassHost H;
-        H.count(P, wrong.data(), rank, world, T, &ws->pool);
+        // Large problems order their factors ON THE DEVICE (k_ord_*: the raw pair arrays are there for the chi2 kernel anyway); the host
+        // keeps the free set, the BetweenFactor chain and - for the window lists / the second pass's statistics - read-backs of the
+        // slot table.  VSLAM_BA_DEVICE_ORDER = 0: host ordering always, 2: device ordering for every size (tests).
+        const int ordEnv = getenv("VSLAM_BA_DEVICE_ORDER") ? atoi(getenv("VSLAM_BA_DEVICE_ORDER")) : 1;
+        const bool devOrder = NP > 0 && L > 0 && (ordEnv == 2 || (ordEnv == 1 && NP >= 200000));
+        BaOrd O{};
+        if (devOrder) {
+            O.NP = NP; O.L = L; O.K = K; O.world = world; O.rank = rank;
+            O.pairKf = p_pairKf; O.pairLm = p_pairLm; O.pairFlags = p_pairFlags; O.wrong = d_wrong.p; O.pairUv = p_pairUv; O.pairOct = p_pairOct;
+            for (int l = 0; l < P->n_levels; l++) O.invSigma[l] = P->inv_sigma_factor[l];
+            // phase 1 buffers: cnt[L] | kfPres[K] | lmPres bytes[L] (zeroed) | lpOf[L] | tLpOrig[L] | tLpStart[L + 1] | scal
+            const size_t zInts = (size_t)L + K + ((size_t)L + 3) / 4, nInts1 = zInts + (size_t)3 * L + 1 + 2 * ORD_SCAL + 2;
+            VS_HIP(ws->d_ord1.alloc(nInts1));
+            int* w = ws->d_ord1.p;
+            O.cnt = w; O.kfPres = w + L; O.lmPres = (uint8_t*)(w + L + K);
+            O.lpOf = w + zInts; O.tLpOrig = O.lpOf + L; O.tLpStart = O.tLpOrig + L;
+            O.scal = (long long*)(w + ((zInts + (size_t)3 * L + 1 + 1) & ~(size_t)1));
+            const size_t scalBytes = ORD_SCAL * sizeof(long long) + (size_t)K * sizeof(int);
+            if (scalBytes > ws->ordScalCap) {
+                if (ws->h_ordScal) hipHostFree(ws->h_ordScal);
+                ws->ordScalCap = scalBytes + 1024;
+                VS_HIP(hipHostMalloc((void**)&ws->h_ordScal, ws->ordScalCap, hipHostMallocDefault));
+            }
+            VS_HIP(hipMemsetAsync(w, 0, zInts * sizeof(int), stream));
+            if (pass == 0) VS_HIP(hipMemsetAsync(d_wrong.p, 0, NP, stream));      // (later passes: the chi2 kernel's flags)
+            const int pairBlocks = std::max(1, std::min((NP + 255) / 256, 8 * nCU));
+            hipLaunchKernelGGL(k_ord_count, dim3(pairBlocks), dim3(256), 0, stream, O);
+            hipLaunchKernelGGL(k_ord_scan_lm, dim3(1), dim3(1024), 0, stream, O);
+            VS_HIP(hipGetLastError());
+            int* const h_kfPres = (int*)(ws->h_ordScal + ORD_SCAL);
+            VS_HIP(hipMemcpyAsync(ws->h_ordScal, O.scal, ORD_SCAL * sizeof(long long), hipMemcpyDeviceToHost, stream));
+            VS_HIP(hipMemcpyAsync(h_kfPres, O.kfPres, (size_t)K * sizeof(int), hipMemcpyDeviceToHost, stream));
+            VS_HIP(vslam::stream_wait_blocking(stream));
+            H.Lp = (int)ws->h_ordScal[ORD_LP]; H.NF = (int)ws->h_ordScal[ORD_NF];
+            T.kfPresent.assign(K, 0);
+            for (int k = 0; k < K; k++) T.kfPresent[k] = h_kfPres[k] ? 1 : 0;
+            H.free_set_and_edges(P, rank, T);
+        } else
+            H.count(P, wrong.data(), rank, world, T, &ws->pool);
+        BHS("count");
         const int NF = H.NF, F = H.F, n = H.n, Lp = H.Lp, NE = H.NE;
         VS_HIP(A.ensure(H.arena_bytes(K, L, specLin ? nSlots : 1), stream));
         A.reset();
         if (!H.take(A, K, L, specLin ? nSlots : 1)) { set_error("local BA: upload arena too small"); return VSLAM_ERR_CAPACITY; }
-        H.fill(P, wrong.data(), rank, world, T, pose0.data(), &ws->pool, specLin ? nSlots : 1);
+        if (devOrder) {
+            H.fill_small(P, T, pose0.data(), specLin ? nSlots : 1);
+            VS_HIP(hipMemcpyAsync(A.dev(H.h_fidx), H.h_fidx, (size_t)K * sizeof(int), hipMemcpyHostToDevice, stream));
+            // phase 2 buffers: fillc[Lp] (zeroed) | ns[Lp] | key | src | key2 | src2 [NF each]
+            VS_HIP(ws->d_ord2.alloc((size_t)2 * std::max(Lp, 1) + (size_t)4 * std::max(NF, 1)));
+            int* w = ws->d_ord2.p;
+            O.fillc = w; O.ns = w + std::max(Lp, 1); O.key = O.ns + std::max(Lp, 1); O.src = O.key + std::max(NF, 1); O.key2 = O.src + std::max(NF, 1); O.src2 = O.key2 + std::max(NF, 1);
+            O.fidx = A.dev(H.h_fidx);
+            O.facKf = A.dev(H.h_facKf); O.facFi = A.dev(H.h_facFi); O.facLp = A.dev(H.h_facLp); O.facLm = A.dev(H.h_facLm); O.facPair = A.dev(H.h_facPair);
+            O.facZ = A.dev(H.h_facZ); O.facIs = A.dev(H.h_facIs); O.facRight = A.dev(H.h_facRight);
+            O.lpStart = A.dev(H.h_lpStart); O.lpSlotStart = A.dev(H.h_lpSlotStart); O.lpOrig = A.dev(H.h_lpOrig);
+            O.slotStart = A.dev(H.h_slotStart); O.slotFi = A.dev(H.h_slotFi);
+            VS_HIP(hipMemsetAsync(O.fillc, 0, (size_t)std::max(Lp, 1) * sizeof(int), stream));
+            const int pairBlocks = std::max(1, std::min((NP + 255) / 256, 8 * nCU));
+            if (NF > 0) {
+                hipLaunchKernelGGL(k_ord_scatter, dim3(pairBlocks), dim3(256), 0, stream, O);
+                hipLaunchKernelGGL(k_ord_rank, dim3((NF + 255) / 256), dim3(256), 0, stream, O, NF);
+            }
+            if (Lp > 0) hipLaunchKernelGGL(k_ord_ns, dim3((Lp + 255) / 256), dim3(256), 0, stream, O, Lp);
+            hipLaunchKernelGGL(k_ord_scan_slots, dim3(1), dim3(1024), 0, stream, O, Lp);
+            if (NF > 0) hipLaunchKernelGGL(k_ord_emit_fac, dim3((NF + 255) / 256), dim3(256), 0, stream, O, NF);
+            if (Lp > 0) hipLaunchKernelGGL(k_ord_emit_slots, dim3((Lp + 255) / 256), dim3(256), 0, stream, O, Lp);
+            VS_HIP(hipGetLastError());
+            VS_HIP(hipMemcpyAsync(A.dev(H.h_lmPresent), O.lmPres, (size_t)L, hipMemcpyDeviceToDevice, stream));
+            VS_HIP(hipMemcpyAsync(ws->h_ordScal, O.scal, ORD_SCAL * sizeof(long long), hipMemcpyDeviceToHost, stream));
+            VS_HIP(vslam::stream_wait_blocking(stream));
+            H.nSlotEntries = (int)ws->h_ordScal[ORD_NSLOT]; H.maxSlots = (int)ws->h_ordScal[ORD_MAXSLOTS]; H.maxFac = (int)ws->h_ordScal[ORD_MAXFAC];
+            H.sumK2 = ws->h_ordScal[ORD_SUMK2];
+            // (nothing of the factor list comes back to the host: the window lists and the second pass's statistics are device work too)
+        } else
+            H.fill(P, wrong.data(), rank, world, T, pose0.data(), &ws->pool, specLin ? nSlots : 1);
+        BHS("fill");
         double* const h_ctl = H.h_ctl; BaDev* const h_D = H.h_D;
         int* const h_facKf = H.h_facKf; int* const h_facFi = H.h_facFi; int* const h_facLp = H.h_facLp; int* const h_facLm = H.h_facLm;
         double* const h_facZ = H.h_facZ; double* const h_facIs = H.h_facIs; uint8_t* const h_facRight = H.h_facRight; int* const h_facPair = H.h_facPair;
@@ -2615,7 +2920,12 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         init_ctl(pass);
         // The arena is complete except for the kernels' argument block (h_D, written after the launch geometry below): its upload
         // starts now and runs under the host work that follows (the window lists of a large problem); h_D follows as a copy of its own.
-        VS_HIP(A.upload(stream));
+        // (Device ordering: the factor arrays were written in place on the device; only the host-written small pieces travel.)
+        if (devOrder) {
+            VS_HIP(hipMemcpyAsync(A.dev(h_ctl), h_ctl, CTL_DOUBLES * sizeof(double), hipMemcpyHostToDevice, stream));
+            VS_HIP(hipMemcpyAsync(A.dev(h_kfPresent), h_kfPresent, (size_t)K, hipMemcpyHostToDevice, stream));
+            if (NE > 0) VS_HIP(hipMemcpyAsync(A.dev(h_edges), h_edges, (size_t)(specLin ? nSlots : 1) * NE * sizeof(BaEdge), hipMemcpyHostToDevice, stream));
+        } else VS_HIP(A.upload(stream));
         BHS("prep");
 
         // ---- device buffers, argument block, then ONE upload ----------------------------------------------
@@ -2691,7 +3001,30 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
             // Per landmark the distinct block rows of its slots (sorted by free index); every pair (i <= j) of them is one entry of
             // window (row_i, row_j).  Landmark chunks run on the pool: each counts its entries per window, a prefix over (window,
             // chunk) gives every chunk its own segment of every window's list - the same order as one sequential sweep.
-            const int nCh = (!ws->pool.workers.empty() && Lp >= 16384) ? std::min(32, Lp / 2048) : 1;
+            BaWinOrd Q{};
+            if (devOrder) {
+                // device ordering: the slot table is on the device - count per (window, 256-landmark block), prefix, and (below, once
+                // the list buffer has its size) the fill; only the nWin + 1 list starts come back
+                Q.Lp = Lp; Q.TB = TB; Q.nBR = nBR; Q.nWin = nWin; Q.nBlk = (Lp + 255) / 256;
+                Q.lpSlotStart = A.dev(h_lpSlotStart); Q.slotFi = A.dev(h_slotFi);
+                VS_HIP(ws->d_winTmp.alloc((size_t)2 * nWin * std::max(Q.nBlk, 1) + nWin + 1));
+                Q.blkCnt = ws->d_winTmp.p; Q.blkOff = Q.blkCnt + (size_t)nWin * std::max(Q.nBlk, 1); Q.winCnt = Q.blkOff + (size_t)nWin * std::max(Q.nBlk, 1);
+                const size_t need = ((size_t)nWin + 1) * sizeof(int);
+                if (need > ws->ordScalCap) {
+                    VS_HIP(hipStreamSynchronize(stream));
+                    if (ws->h_ordScal) hipHostFree(ws->h_ordScal);
+                    ws->ordScalCap = need + 1024;
+                    VS_HIP(hipHostMalloc((void**)&ws->h_ordScal, ws->ordScalCap, hipHostMallocDefault));
+                }
+                if (Q.nBlk > 0) hipLaunchKernelGGL(k_win_lists<0>, dim3(Q.nBlk), dim3(256), 0, stream, Q);
+                hipLaunchKernelGGL(k_win_prefix, dim3(1), dim3(1024), (size_t)nWin * sizeof(int), stream, Q);
+                VS_HIP(hipGetLastError());
+                VS_HIP(hipMemcpyAsync(ws->h_ordScal, Q.winCnt, need, hipMemcpyDeviceToHost, stream));
+                VS_HIP(vslam::stream_wait_blocking(stream));
+                const int* hc = (const int*)ws->h_ordScal;
+                for (int w = 0; w <= nWin; w++) winCnt[w] = hc[w];
+            }
+            const int nCh = devOrder ? 0 : (!ws->pool.workers.empty() && Lp >= 16384) ? std::min(32, Lp / 2048) : 1;
             std::vector<int> chCnt((size_t)nCh * nWin, 0);
             auto lm_rows = [&](int lp, int* rows) {
                 int nr = 0, last = -1;
@@ -2711,9 +3044,9 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
                     for (int i = 0; i < nr; i++) for (int j = i; j < nr; j++) cnt[win_of(rows[i], rows[j])]++;
                 }
             };
-            if (nCh > 1) ws->pool.run(nCh, count_chunk); else count_chunk(0);
+            if (nCh > 1) ws->pool.run(nCh, count_chunk); else if (nCh == 1) count_chunk(0);
             std::vector<int> chOff((size_t)nCh * nWin);
-            {
+            if (!devOrder) {
                 int run = 0;
                 for (int w = 0; w < nWin; w++) {
                     winCnt[w] = run;
@@ -2722,7 +3055,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
                 winCnt[nWin] = run;
             }
             const int total = winCnt[nWin];
-            std::vector<int> winLm((size_t)std::max(total, 1));
+            std::vector<int> winLm(devOrder ? (size_t)0 : (size_t)std::max(total, 1));
             auto fill_chunk = [&](int c) {
                 int a0, a1, rows[64];
                 ch_range(c, a0, a1);
@@ -2732,7 +3065,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
                     for (int i = 0; i < nr; i++) for (int j = i; j < nr; j++) winLm[off[win_of(rows[i], rows[j])]++] = lp;
                 }
             };
-            if (nCh > 1) ws->pool.run(nCh, fill_chunk); else fill_chunk(0);
+            if (nCh > 1) ws->pool.run(nCh, fill_chunk); else if (nCh == 1) fill_chunk(0);
             // workgroups: a window's list is cut into chunks of >= 256 entries, ~2 workgroups per CU overall
             const int chunk = std::max(256, (total + 2 * nCU - 1) / (2 * nCU));
             std::vector<int> wgWin, wgBegin, wgEnd, winFirst((size_t)nWin + 1, 0);
@@ -2752,9 +3085,14 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
             pack.insert(pack.end(), wgWin.begin(), wgWin.end()); pack.resize(oWg + std::max(nWinWg, 1));
             pack.insert(pack.end(), wgBegin.begin(), wgBegin.end()); pack.resize(oWg + 2 * (size_t)std::max(nWinWg, 1));
             pack.insert(pack.end(), wgEnd.begin(), wgEnd.end()); pack.resize(oWg + 3 * (size_t)std::max(nWinWg, 1));
-            pack.insert(pack.end(), winLm.begin(), winLm.end());
-            VS_HIP(d_win.alloc(pack.size()));
+            pack.insert(pack.end(), winLm.begin(), winLm.end());      // (device ordering: the lists are written in place by the fill kernel below)
+            VS_HIP(d_win.alloc(nInts));
             VS_HIP(hipMemcpyAsync(d_win.p, pack.data(), pack.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+            if (devOrder && Q.nBlk > 0 && total > 0) {
+                Q.winLm = d_win.p + oWg + 3 * (size_t)std::max(nWinWg, 1);
+                hipLaunchKernelGGL(k_win_lists<1>, dim3(Q.nBlk), dim3(256), 0, stream, Q);
+                VS_HIP(hipGetLastError());
+            }
             VS_HIP(hipStreamSynchronize(stream));          // (pack is a local: the copy must have left it)
             Wn.winA = d_win.p; Wn.winB = d_win.p + nWin; Wn.winFirstWg = d_win.p + 2 * nWin;
             Wn.wgWin = d_win.p + oWg; Wn.wgBegin = Wn.wgWin + std::max(nWinWg, 1); Wn.wgEnd = Wn.wgBegin + std::max(nWinWg, 1);
@@ -2943,34 +3281,76 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
         static const bool maskEnv = !getenv("VSLAM_BA_NO_MASK");
         if (pass == 0 && maskEnv && g_baMask) {
             // membership / statistics of the second graph from the chi2 flags
-            std::vector<uint8_t> kfP2(K, 0), lmP2(L, 0);
-            long long NF2 = 0;
-            for (int p = 0; p < NP; p++) {
-                if (wrong[p]) continue;
-                const int fl = P->pair_flags[p] & 3;
-                if (!fl) continue;
-                kfP2[P->pair_kf[p]] = 1; lmP2[P->pair_lm[p]] = 1;
-                if (P->pair_lm[p] % world == rank) NF2 += (fl & 1) + (fl >> 1);      // (statistics are per shard, summed in run_lm)
+            // (large problems: by landmark range on the pool, as BaPassHost::count - every worker reads all pairs and handles its range;
+            //  with the device ordering: the same kernels again, now with the chi2 flags - membership, counts, and the masked slot statistics)
+            std::vector<uint8_t> kfP2(K, 0), lmP2(devOrder ? 0 : L, 0);
+            long long NF2 = 0, Lp2dev = 0, k2dev = 0;
+            if (devOrder) {
+                const size_t zInts = (size_t)L + K + ((size_t)L + 3) / 4;
+                VS_HIP(hipMemsetAsync(ws->d_ord1.p, 0, zInts * sizeof(int), stream));
+                const int pairBlocks = std::max(1, std::min((NP + 255) / 256, 8 * nCU));
+                hipLaunchKernelGGL(k_ord_count, dim3(pairBlocks), dim3(256), 0, stream, O);
+                hipLaunchKernelGGL(k_ord_scan_lm, dim3(1), dim3(1024), 0, stream, O);
+                if (Lp > 0) hipLaunchKernelGGL(k_ord_k2_masked, dim3((Lp + 255) / 256), dim3(256), 0, stream, O, Lp);
+                VS_HIP(hipGetLastError());
+                int* const h_kfPres = (int*)(ws->h_ordScal + ORD_SCAL);
+                VS_HIP(hipMemcpyAsync(ws->h_ordScal, O.scal, ORD_SCAL * sizeof(long long), hipMemcpyDeviceToHost, stream));
+                VS_HIP(hipMemcpyAsync(h_kfPres, O.kfPres, (size_t)K * sizeof(int), hipMemcpyDeviceToHost, stream));
+                VS_HIP(vslam::stream_wait_blocking(stream));
+                for (int k = 0; k < K; k++) kfP2[k] = h_kfPres[k] ? 1 : 0;
+                NF2 = ws->h_ordScal[ORD_NF]; Lp2dev = ws->h_ordScal[ORD_LP]; k2dev = ws->h_ordScal[ORD_K2_MASKED];
+            } else {
+                const int nr = BaPassHost::par_ranges(&ws->pool, NP, L);
+                std::vector<long long> nfPart(nr, 0);
+                std::vector<std::vector<uint8_t>> kfPart(nr > 1 ? nr : 0);
+                auto scan = [&](int r) {
+                    const int l0 = (int)((long long)L * r / nr), l1 = (int)((long long)L * (r + 1) / nr);
+                    uint8_t* kfp = nr > 1 ? (kfPart[r].assign(K, 0), kfPart[r].data()) : kfP2.data();
+                    long long nf = 0;
+                    for (int p = 0; p < NP; p++) {
+                        const int l = P->pair_lm[p];
+                        if (l < l0 || l >= l1 || wrong[p]) continue;
+                        const int fl = P->pair_flags[p] & 3;
+                        if (!fl) continue;
+                        kfp[P->pair_kf[p]] = 1; lmP2[l] = 1;
+                        if (l % world == rank) nf += (fl & 1) + (fl >> 1);      // (statistics are per shard, summed in run_lm)
+                    }
+                    nfPart[r] = nf;
+                };
+                if (nr > 1) ws->pool.run(nr, scan); else scan(0);
+                for (int r = 0; r < nr; r++) { NF2 += nfPart[r]; if (nr > 1) for (int k = 0; k < K; k++) kfP2[k] |= kfPart[r][k]; }
             }
             bool same = true;
             for (int k = 0; k < K; k++) if (kfP2[k] != T.kfPresent[k]) { same = false; break; }
             if (same) {       // same keyframes => same free set, same BetweenFactor chain; landmarks may only drop out
-                long long Lp2 = 0, k2 = 0;
-                for (int l = 0; l < L; l++) if (l % world == rank) Lp2 += lmP2[l];
-                for (int lp = 0; lp < Lp; lp++) {
-                    int ns = 0, last = -2;
-                    for (int f = h_lpStart[lp]; f < h_lpStart[lp + 1]; f++) {
-                        if (wrong[h_facPair[f]]) continue;
-                        const int fi = h_facFi[f];
-                        if (fi >= 0 && fi != last) { last = fi; ns++; }
-                    }
-                    k2 += (long long)ns * ns;
+                long long Lp2 = Lp2dev, k2 = k2dev;
+                if (!devOrder) {
+                    const int nc = (!ws->pool.workers.empty() && Lp >= 16384) ? std::min(32, Lp / 2048) : 1;
+                    std::vector<long long> k2Part(nc, 0), lpPart(nc, 0);
+                    auto part = [&](int c) {
+                        long long kk = 0, ll = 0;
+                        for (int l = (int)((long long)L * c / nc), l1 = (int)((long long)L * (c + 1) / nc); l < l1; l++) if (l % world == rank) ll += lmP2[l];
+                        for (int lp = (int)((long long)Lp * c / nc), lp1 = (int)((long long)Lp * (c + 1) / nc); lp < lp1; lp++) {
+                            int ns = 0, last = -2;
+                            for (int f = h_lpStart[lp]; f < h_lpStart[lp + 1]; f++) {
+                                if (wrong[h_facPair[f]]) continue;
+                                const int fi = h_facFi[f];
+                                if (fi >= 0 && fi != last) { last = fi; ns++; }
+                            }
+                            kk += (long long)ns * ns;
+                        }
+                        k2Part[c] = kk; lpPart[c] = ll;
+                    };
+                    if (nc > 1) ws->pool.run(nc, part); else part(0);
+                    for (int c = 0; c < nc; c++) { k2 += k2Part[c]; Lp2 += lpPart[c]; }
                 }
+                BHS("p2stats");
                 for (int k = 0; k < K; k++) h_kfPresent[k] = kfP2[k];
-                for (int l = 0; l < L; l++) h_lmPresent[l] = lmP2[l];
+                if (!devOrder) for (int l = 0; l < L; l++) h_lmPresent[l] = lmP2[l];
                 init_ctl(1);
                 VS_HIP(hipMemcpyAsync(A.dev(h_kfPresent), h_kfPresent, K, hipMemcpyHostToDevice, stream));
-                if (L) VS_HIP(hipMemcpyAsync(A.dev(h_lmPresent), h_lmPresent, L, hipMemcpyHostToDevice, stream));
+                if (devOrder) VS_HIP(hipMemcpyAsync(A.dev(h_lmPresent), O.lmPres, (size_t)L, hipMemcpyDeviceToDevice, stream));
+                else if (L) VS_HIP(hipMemcpyAsync(A.dev(h_lmPresent), h_lmPresent, L, hipMemcpyHostToDevice, stream));
                 VS_HIP(hipMemcpyAsync(A.dev(h_ctl), h_ctl, CTL_DOUBLES * sizeof(double), hipMemcpyHostToDevice, stream));
                 if (NF) hipLaunchKernelGGL(k_ba_mask, dim3((NF + 255) / 256), dim3(256), 0, stream, NF, A.dev(h_facPair), d_wrong.p, A.dev(h_facIs));
                 {

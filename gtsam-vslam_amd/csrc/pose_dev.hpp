@@ -50,8 +50,8 @@ __device__ __forceinline__ int pose_factor_eval(const double* f, const DPose& T,
     const double is = f[7];
     if (J) for (int a = 0; a < 3; a++) for (int c = 0; c < 6; c++) J[a][c] = 0;
     if (q[2] <= 0) {
-        for (int a = 0; a < rows; a++) r[a] = 2.0 * A.fx * is;
-        if (rows == 2) r[2] = 0;
+        const double v = 2.0 * A.fx * is;      // (written out: a loop to `rows` indexes r[] dynamically and puts it in scratch)
+        r[0] = v; r[1] = v; r[2] = rows == 3 ? v : 0.0;
         return rows;
     }
     const double x = q[0], y = q[1], z = q[2], iz = 1.0 / z;
@@ -113,28 +113,32 @@ __device__ __forceinline__ void pose_factor_lin(const double* f, const DPose& T,
     const double is = f[7];
 #pragma unroll
     for (int c = 0; c < 6; c++) { L.JA[c] = 0; L.JB[c] = 0; L.JC[c] = 0; }
+    // (residuals go through scalars and are stored once: with stores to different members on the two paths the optimiser sinks them
+    //  into one store through a pointer phi, which keeps part of L in scratch)
+    double rA, rB, rC;
     if (q[2] <= 0) {                 // cheirality: constant residual, zero Jacobian
         const double rr = 2.0 * A.fx * is;
-        L.rA = rr; L.rB = type == 0 ? rr : 0.0; L.rC = rr;
-        return;
-    }
-    const double x = q[0], y = q[1], z = q[2], iz = 1.0 / z;
-    const double xb = x - A.b;
-    const double xx = type == 2 ? xb : x;             // mono factor of the right camera: its own u
-    const double a0 = A.fx * iz, a1 = A.fy * iz;
-    if (type == 0) {
-        L.rA = (A.fx * x * iz + A.cx - f[4]) * is;
-        L.rB = (A.fx * xb * iz + A.cx - f[5]) * is;
-        L.rC = (A.fy * y * iz + A.cy - f[6]) * is;
-        pose_row_u(a0, -A.fx * x * iz * iz, x, y, z, is, L.JA);
-        pose_row_u(a0, -A.fx * xb * iz * iz, x, y, z, is, L.JB);
+        rA = rr; rB = type == 0 ? rr : 0.0; rC = rr;
     } else {
-        L.rA = (A.fx * xx * iz + A.cx - f[4]) * is;
-        L.rB = 0.0;
-        L.rC = (A.fy * y * iz + A.cy - f[5]) * is;
-        pose_row_u(a0, -A.fx * xx * iz * iz, x, y, z, is, L.JA);
+        const double x = q[0], y = q[1], z = q[2], iz = 1.0 / z;
+        const double xb = x - A.b;
+        const double xx = type == 2 ? xb : x;             // mono factor of the right camera: its own u
+        const double a0 = A.fx * iz, a1 = A.fy * iz;
+        if (type == 0) {
+            rA = (A.fx * x * iz + A.cx - f[4]) * is;
+            rB = (A.fx * xb * iz + A.cx - f[5]) * is;
+            rC = (A.fy * y * iz + A.cy - f[6]) * is;
+            pose_row_u(a0, -A.fx * x * iz * iz, x, y, z, is, L.JA);
+            pose_row_u(a0, -A.fx * xb * iz * iz, x, y, z, is, L.JB);
+        } else {
+            rA = (A.fx * xx * iz + A.cx - f[4]) * is;
+            rB = 0.0;
+            rC = (A.fy * y * iz + A.cy - f[5]) * is;
+            pose_row_u(a0, -A.fx * xx * iz * iz, x, y, z, is, L.JA);
+        }
+        pose_row_v(a1, -A.fy * y * iz * iz, x, y, z, is, L.JC);
     }
-    pose_row_v(a1, -A.fy * y * iz * iz, x, y, z, is, L.JC);
+    L.rA = rA; L.rB = rB; L.rC = rC;
 }
 // v[0..20] += upper triangle of J^T J, v[21..26] -= J^T r, for one row whose entry `Z` is structurally zero
 template <int Z>

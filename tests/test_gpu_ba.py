@@ -333,3 +333,66 @@ def test_ba_second_pass_rebuild_equals_masked(oracle, capi):
         assert np.array_equal(o["pair_wrong1"], ref["pair_wrong1"]) and np.array_equal(o["pair_wrong"], ref["pair_wrong"])
         assert np.abs(o["kf_pose"] - ref["kf_pose"]).max() < 1e-6
     assert np.abs(a["kf_pose"] - b["kf_pose"]).max() < 1e-8
+
+
+def _same_ba(a, b, tol=1e-9):
+    assert [(r["iterations"], r["inner"]) for r in a["reports"]] == [(r["iterations"], r["inner"]) for r in b["reports"]]
+    for s in range(2):
+        assert abs(a["reports"][s]["finalError"] - b["reports"][s]["finalError"]) <= 1e-9 * max(1.0, a["reports"][s]["finalError"])
+    assert np.array_equal(a["pair_wrong1"], b["pair_wrong1"]) and np.array_equal(a["pair_wrong"], b["pair_wrong"])
+    assert (a["residuals"], a["landmarks"], a["free_kf"], a["sum_k2"]) == (b["residuals"], b["landmarks"], b["free_kf"], b["sum_k2"])
+    assert np.abs(a["kf_pose"] - b["kf_pose"]).max() < tol, np.abs(a["kf_pose"] - b["kf_pose"]).max()
+    d = np.linalg.norm(a["lm"] - b["lm"], axis=1)
+    assert np.median(d) < 1e-8 and d.max() < 1e-3, (np.median(d), d.max())
+
+
+@pytest.mark.parametrize("shape", ["tracker", "outliers_rebuild", "c5_window", "sharded"])
+def test_ba_device_factor_ordering_equals_host_ordering(oracle, capi, shape, monkeypatch):
+    """The factor list (landmark buckets ordered by free index / pair / side, slot table, membership, statistics) built by the k_ord_*
+    kernels from the raw pair arrays - the default for >= 200 000 pairs, forced here with VSLAM_BA_DEVICE_ORDER=2 - against the host's
+    counting sort (VSLAM_BA_DEVICE_ORDER=0): same LM trajectory, chi2 flags of both passes, work figures (residual blocks, landmarks,
+    sum of squared slot counts), poses to the round-off of the accumulation's atomics.  Shapes: a tracker window, a window whose chi2
+    check rejects pairs with the second graph REBUILT (the ordering runs again on the device with the first pass's flags), the C5
+    window (windowed Schur: the slot table read back for the window lists), two landmark shards (local transport)."""
+    import threading
+    ex = oracle.Extractor(1500)
+    if shape == "tracker":
+        prob = synth.make_ba_problem(n_local=10, n_fixed=4, n_lm=1500, seed=31)
+    elif shape == "outliers_rebuild":
+        prob = synth.make_ba_problem(n_local=10, n_fixed=3, n_lm=1500, seed=77, outlier_frac=0.12)
+    elif shape == "c5_window":
+        prob = synth.make_ba_problem_c5(n_lm=3000, seed=0xC5)
+    else:
+        prob = synth.make_ba_problem(n_local=12, n_fixed=3, n_lm=1200, seed=41, outlier_frac=0.05)
+
+    def run():
+        if shape != "sharded":
+            return capi.local_ba(prob["rig"], ex.sigmaFactor, ex.InvSigmaFactor, prob)
+        comms = capi.comm_create_local(2)
+        out = [None, None]
+
+        def rank(r):
+            out[r] = capi.local_ba(prob["rig"], ex.sigmaFactor, ex.InvSigmaFactor, prob, comm=comms[r])
+        th = [threading.Thread(target=rank, args=(r,)) for r in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=300)
+        for c in comms:
+            c.close()
+        assert out[0] is not None and out[1] is not None
+        assert np.array_equal(out[0]["kf_pose"], out[1]["kf_pose"])
+        return out[0]
+
+    try:
+        if shape == "outliers_rebuild":
+            capi.local_ba_set_lookahead(0, -1, 0)
+        monkeypatch.setenv("VSLAM_BA_DEVICE_ORDER", "0")
+        host = run()
+        monkeypatch.setenv("VSLAM_BA_DEVICE_ORDER", "2")
+        dev = run()
+    finally:
+        capi.local_ba_set_lookahead(0, -1, 1)
+    if shape == "outliers_rebuild":
+        assert host["pair_wrong1"].sum() > 0
+    _same_ba(host, dev, tol=1e-8 if shape == "sharded" else 1e-9)
