@@ -684,6 +684,8 @@ __device__ __forceinline__ void sincos_deg_range(float xf, float& s_out, float& 
 
 // Moments: lane = (half, u): lanes 0..30 walk the rows v = 0..15 of column u = lane - 15, lanes 32..62 the rows
 // -1..-15; a row's loads are contiguous bytes.  m10 = sum_u u * (column sum), m01 = sum v * I: integer sums, order-free.
+constexpr int OD_MROWS = 31, OD_MDW = 9;       // unblurred patch of the intensity centroid (31 + 3 alignment bytes fit 36)
+constexpr int OD_ROWS = 39, OD_DW = 11;      // blurred patch staged per keypoint: rows x dwords (39 + 3 alignment bytes fit 44)
 __global__ __launch_bounds__(256) void k_orient_desc(
     const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur, PyrDesc P, LevelTables T,
     const uint32_t* __restrict__ kept, const int* __restrict__ keptOff, int keptCap,
@@ -705,19 +707,53 @@ __global__ __launch_bounds__(256) void k_orient_desc(
     const int pitch = P.pitch[level];
     const size_t lvlOff = (size_t)img * P.imgStride + P.off[level];
     // wave-uniform bases moved to the top-left corner of the patch, so that the per-lane offsets are unsigned
-    const uint8_t* __restrict__ mb = pyr + lvlOff + (size_t)(y - 15) * pitch + (x - 15);
+    // the unblurred 31 x 31 patch of the intensity centroid, staged like the descriptor's patch below: 31 rows x 9 aligned dwords in
+    // five row-coalesced loads, then LDS byte reads by rows (lane = column; lanes 0..31 the rows below the centre, 32..63 above)
+    // The blurred 39 x 39 patch of the descriptor's taps (they lie within +-19 px) the same way: 39 rows x 11 aligned dwords in seven
+    // loads per wave, then the eight taps of a lane are LDS byte reads - instead of eight gathers whose 64 lanes touch ~40 different
+    // cache lines each (the kernel was bound by the texture path; FETCH_SIZE 2.4-4.9x the algorithmic bytes).  Both patches are private
+    // to the wave: its LDS traffic is processed in order, no workgroup barrier.
+    __shared__ unsigned sDisc[4][OD_MROWS * OD_MDW];
+    __shared__ unsigned sPatch[4][OD_ROWS * OD_DW];
+    unsigned* patch = sPatch[wave];
+    const int xa = (x - 19) & ~3, xoff = (x - 19) - xa;          // (x >= 19: the aligned column is inside the row)
     int m10, m01 = 0;
     {
+        unsigned* disc = sDisc[wave];
+        const int xm = (x - 15) & ~3, xmo = (x - 15) - xm;
+        const uint8_t* __restrict__ msrc = pyr + lvlOff + (size_t)(y - 15) * pitch + xm;
+        unsigned w5[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int i = k * 64 + lane, r = (i * 7282) >> 16, c = i - r * OD_MDW;       // i / 9 for i < 320
+            w5[k] = i < OD_MROWS * OD_MDW ? *(const unsigned*)(msrc + (size_t)r * pitch + 4 * c) : 0u;
+        }
+        // (the descriptor's patch is requested in the same breath: one memory round trip for both)
+        {
+            const uint8_t* __restrict__ bsrc = blur + lvlOff + (size_t)(y - 19) * pitch + xa;
+            unsigned v[7];
+#pragma unroll
+            for (int k = 0; k < 7; k++) {
+                const int i = k * 64 + lane, r = (i * 5958) >> 16, c = i - r * OD_DW;       // i / 11 for i < 448
+                v[k] = i < OD_ROWS * OD_DW ? *(const unsigned*)(bsrc + (size_t)r * pitch + 4 * c) : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 5; k++) { const int i = k * 64 + lane; if (i < OD_MROWS * OD_MDW) disc[i] = w5[k]; }
+#pragma unroll
+            for (int k = 0; k < 7; k++) { const int i = k * 64 + lane; if (i < OD_ROWS * OD_DW) patch[i] = v[k]; }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const uint8_t* mb = (const uint8_t*)disc + xmo;
         const unsigned lu = lane & 31;
         const int u = (int)lu - 15, au = u < 0 ? -u : u;
         const bool neg = lane >= 32;
-        const unsigned centre = 15u * (unsigned)pitch + 15u;
-        const unsigned step = neg ? 0u - (unsigned)pitch : (unsigned)pitch;
-        unsigned off = 15u * (unsigned)pitch + lu;
+        const unsigned centre = 15u * (unsigned)(OD_MDW * 4) + 15u;
+        const unsigned step = neg ? 0u - (unsigned)(OD_MDW * 4) : (unsigned)(OD_MDW * 4);
+        unsigned off = 15u * (unsigned)(OD_MDW * 4) + lu;
         int I[16];
         bool act[16];
 #pragma unroll
-        for (int v = 0; v < 16; v++) {           // all 16 loads are in flight together (inactive lanes read the centre)
+        for (int v = 0; v < 16; v++) {           // (inactive lanes read the centre)
             act[v] = au <= R.umax[v] && lu != 31u && !(neg && v == 0);
             I[v] = mb[act[v] ? off : centre];
             off += step;
@@ -745,7 +781,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(
     // see DESIGN.md "float trig")
     float a, b;
     sincos_deg_range(ang, b, a);
-    const uint8_t* __restrict__ bb = blur + lvlOff + (size_t)(y - 20) * pitch + (x - 20);   // taps lie within +-19 px
+    const uint8_t* pb = (const uint8_t*)patch + 19 * (OD_DW * 4) + 19 + xoff;      // the keypoint's own pixel
     const int pw[4] = {pat4.x, pat4.y, pat4.z, pat4.w};
     int nib = 0;
 #pragma unroll
@@ -754,8 +790,8 @@ __global__ __launch_bounds__(256) void k_orient_desc(
         const float x1 = (float)(signed char)((pw[j] >> 16) & 0xff), y1 = (float)(pw[j] >> 24);
         const int ry0 = __float2int_rn(x0 * b + y0 * a), rx0 = __float2int_rn(x0 * a - y0 * b);
         const int ry1 = __float2int_rn(x1 * b + y1 * a), rx1 = __float2int_rn(x1 * a - y1 * b);
-        const int t0 = bb[(unsigned)(ry0 + 20) * (unsigned)pitch + (unsigned)(rx0 + 20)];
-        const int t1 = bb[(unsigned)(ry1 + 20) * (unsigned)pitch + (unsigned)(rx1 + 20)];
+        const int t0 = pb[ry0 * (OD_DW * 4) + rx0];
+        const int t1 = pb[ry1 * (OD_DW * 4) + rx1];
         nib |= (t0 < t1) << j;
     }
     const int other = __shfl_xor(nib, 1);
