@@ -51,7 +51,7 @@ CONFIGS = {
     "c3": dict(rig="kitti", nfeat=2000, imu=False, name="C3-class: KITTI-00-like stereo 1241x376, 2000 features/image"),
 }
 # PMC passes of the default command's launch shape (tools/measure_set.sh); "_meta" names the shape they were taken on
-PMC_FILE = os.path.join(ROOT, "profiles", os.environ.get("VSLAM_BENCH_PMC", "r03_c_pmc_summary.json"))
+PMC_FILE = os.path.join(ROOT, "profiles", os.environ.get("VSLAM_BENCH_PMC", "r03_d_pmc_summary.json"))
 
 
 def level_pixels(w, h, nlevels=8, scale=1.2):
@@ -230,8 +230,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c5"])
-    ap.add_argument("--sessions", type=int, default=192, help="independent SLAM sessions (sequences) sharing each GPU")
-    ap.add_argument("--lanes", type=int, default=96, help="sessions per lockstep group (vslam_batch: one launch per stage for all lanes of a group); "
+    ap.add_argument("--sessions", type=int, default=384, help="independent SLAM sessions (sequences) sharing each GPU")
+    ap.add_argument("--lanes", type=int, default=128, help="sessions per lockstep group (vslam_batch: one launch per stage for all lanes of a group); "
                                                           "0 = one host thread and one set of launches per session")
     ap.add_argument("--scene", default="corridor", choices=["corridor", "room"], help="corridor: distinct poses along a long corridor, rendered on "
                     "the GPU, no session turns around inside a run; room: the parity tests' small scene replayed as a ping-pong (round 2)")

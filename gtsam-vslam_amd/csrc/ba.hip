@@ -2148,33 +2148,44 @@ __global__ __launch_bounds__(256) void k_ord_count(BaOrd O) {
         atomicAdd(&O.cnt[l], (fl & 1) + (fl >> 1));
     }
 }
-// block-wide inclusive scan of two ints per thread (1024 threads)
-__device__ __forceinline__ void ord_scan2(int& a, int& b, int* sA, int* sB) {
-    const int tid = threadIdx.x;
-    sA[tid] = a; sB[tid] = b;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        const int va = tid >= d ? sA[tid - d] : 0, vb = tid >= d ? sB[tid - d] : 0;
+// One workgroup walks an array in tiles of 1024 consecutive elements (coalesced): exclusive prefix of two ints per element = carry of the
+// tiles before + prefix of the waves before (LDS) + the wave's own inclusive scan (shuffles).  Two barriers per tile.
+struct OrdScan {
+    int carryA = 0, carryB = 0;
+    __device__ __forceinline__ void tile(int a, int b, int* sA, int* sB, int& exA, int& exB) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        int ia = a, ib = b;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int ta = __shfl_up(ia, d), tb = __shfl_up(ib, d);
+            if (lane >= d) { ia += ta; ib += tb; }
+        }
+        if (lane == 63) { sA[wave] = ia; sB[wave] = ib; }
         __syncthreads();
-        sA[tid] += va; sB[tid] += vb;
+        int pa = 0, pb = 0, ta = 0, tb = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) { const int va = sA[w], vb = sB[w]; if (w < wave) { pa += va; pb += vb; } ta += va; tb += vb; }
+        exA = carryA + pa + ia - a; exB = carryB + pb + ib - b;
+        carryA += ta; carryB += tb;
         __syncthreads();
     }
-    a = sA[tid]; b = sB[tid];
-}
+};
 // landmarks of this rank's shard that are in the graph, in index order: lpOf / lpOrig, and the start of every bucket
 __global__ __launch_bounds__(1024) void k_ord_scan_lm(BaOrd O) {
-    __shared__ int sA[1024], sB[1024];
-    const int tid = threadIdx.x, per = (O.L + 1023) / 1024, l0 = min(O.L, tid * per), l1 = min(O.L, l0 + per);
-    int a = 0, b = 0;
-    for (int l = l0; l < l1; l++) if (O.lmPres[l] && l % O.world == O.rank) { a++; b += O.cnt[l]; }
-    int ia = a, ib = b;
-    ord_scan2(ia, ib, sA, sB);
-    int ea = ia - a, eb = ib - b;
-    for (int l = l0; l < l1; l++) {
-        if (O.lmPres[l] && l % O.world == O.rank) { O.lpOf[l] = ea; O.tLpOrig[ea] = l; O.tLpStart[ea] = eb; ea++; eb += O.cnt[l]; }
-        else O.lpOf[l] = -1;
+    __shared__ int sA[16], sB[16];
+    OrdScan sc;
+    for (int base = 0; base < O.L; base += 1024) {
+        const int l = base + threadIdx.x;
+        const bool in = l < O.L && O.lmPres[l] && l % O.world == O.rank;
+        const int a = in ? 1 : 0, b = in ? O.cnt[l] : 0;
+        int ea, eb;
+        sc.tile(a, b, sA, sB, ea, eb);
+        if (l < O.L) {
+            if (in) { O.lpOf[l] = ea; O.tLpOrig[ea] = l; O.tLpStart[ea] = eb; }
+            else O.lpOf[l] = -1;
+        }
     }
-    if (tid == 1023) { O.tLpStart[ia] = ib; O.scal[ORD_LP] = ia; O.scal[ORD_NF] = ib; O.scal[ORD_K2_MASKED] = 0; }
+    if (threadIdx.x == 0) { O.tLpStart[sc.carryA] = sc.carryB; O.scal[ORD_LP] = sc.carryA; O.scal[ORD_NF] = sc.carryB; O.scal[ORD_K2_MASKED] = 0; }
 }
 __global__ __launch_bounds__(256) void k_ord_scatter(BaOrd O) {
     for (int p = blockIdx.x * 256 + threadIdx.x; p < O.NP; p += gridDim.x * 256) {
@@ -2212,29 +2223,35 @@ __global__ __launch_bounds__(256) void k_ord_ns(BaOrd O, int Lp) {
 }
 // slot-table prefix (per landmark its slots + an end sentinel), the statistics of the pass, and the landmark arrays into their final place
 __global__ __launch_bounds__(1024) void k_ord_scan_slots(BaOrd O, int Lp) {
-    __shared__ int sA[1024], sB[1024];
-    __shared__ long long sK[1024];
-    const int tid = threadIdx.x, per = (Lp + 1023) / 1024, a0 = min(Lp, tid * per), a1 = min(Lp, a0 + per);
-    int a = 0, mx = 0, mf = 0;
+    __shared__ int sA[16], sB[16];
+    __shared__ int rA[1024], rB[1024];
+    __shared__ long long rK[1024];
+    const int tid = threadIdx.x;
+    OrdScan sc;
+    int mx = 0, mf = 0;
     long long k2 = 0;
-    for (int lp = a0; lp < a1; lp++) {
-        const int ns = O.ns[lp], nf = O.tLpStart[lp + 1] - O.tLpStart[lp];
-        a += ns + 1; mx = max(mx, ns); mf = max(mf, nf); k2 += (long long)ns * ns;
-        O.lpStart[lp] = O.tLpStart[lp]; O.lpOrig[lp] = O.tLpOrig[lp];
+    for (int base = 0; base < Lp; base += 1024) {
+        const int lp = base + tid;
+        int a = 0;
+        if (lp < Lp) {
+            const int ns = O.ns[lp], f0 = O.tLpStart[lp], nf = O.tLpStart[lp + 1] - f0;
+            a = ns + 1; mx = max(mx, ns); mf = max(mf, nf); k2 += (long long)ns * ns;
+            O.lpStart[lp] = f0; O.lpOrig[lp] = O.tLpOrig[lp];
+        }
+        int ea, eb;
+        sc.tile(a, 0, sA, sB, ea, eb);
+        if (lp < Lp) O.lpSlotStart[lp] = ea;
     }
-    int ia = a, dummy = 0;
-    ord_scan2(ia, dummy, sA, sB);
-    int ea = ia - a;
-    for (int lp = a0; lp < a1; lp++) { O.lpSlotStart[lp] = ea; ea += O.ns[lp] + 1; }
-    __syncthreads();
-    sA[tid] = mx; sB[tid] = mf; sK[tid] = k2;
+    rA[tid] = mx; rB[tid] = mf; rK[tid] = k2;
     __syncthreads();
     for (int d = 512; d >= 1; d >>= 1) {
-        if (tid < d) { sA[tid] = max(sA[tid], sA[tid + d]); sB[tid] = max(sB[tid], sB[tid + d]); sK[tid] += sK[tid + d]; }
+        if (tid < d) { rA[tid] = max(rA[tid], rA[tid + d]); rB[tid] = max(rB[tid], rB[tid + d]); rK[tid] += rK[tid + d]; }
         __syncthreads();
     }
-    if (tid == 1023) { O.lpSlotStart[Lp] = ia; O.lpStart[Lp] = O.tLpStart[Lp]; O.scal[ORD_NSLOT] = ia; }
-    if (tid == 0) { O.scal[ORD_MAXSLOTS] = max(sA[0], 1); O.scal[ORD_MAXFAC] = max(sB[0], 1); O.scal[ORD_SUMK2] = sK[0]; }
+    if (tid == 0) {
+        O.lpSlotStart[Lp] = sc.carryA; O.lpStart[Lp] = O.tLpStart[Lp]; O.scal[ORD_NSLOT] = sc.carryA;
+        O.scal[ORD_MAXSLOTS] = max(rA[0], 1); O.scal[ORD_MAXFAC] = max(rB[0], 1); O.scal[ORD_SUMK2] = rK[0];
+    }
 }
 // statistics of the masked second pass: sum over the landmarks of (free keyframes still observing it)^2 with the rejected pairs left out
 __global__ __launch_bounds__(256) void k_ord_k2_masked(BaOrd O, int Lp) {

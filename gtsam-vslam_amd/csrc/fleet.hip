@@ -230,7 +230,7 @@ void vslam_fleet::loop(int si) {
 extern "C" {
 
 static vslam_status fleet_create(const vslam_system_config* config, int32_t n_sessions, const vslam_fleet_sequence* seq, int lanes, vslam_fleet** out) {
-    if (!config || !seq || !out || n_sessions < 1 || n_sessions > 256 || seq->n_frames < 2 || !seq->left || !seq->right || seq->stride < config->rig.width) {
+    if (!config || !seq || !out || n_sessions < 1 || n_sessions > 1024 || seq->n_frames < 2 || !seq->left || !seq->right || seq->stride < config->rig.width) {
         set_error("vslam_fleet_create: invalid arguments");
         return VSLAM_ERR_INVALID;
     }

@@ -31,9 +31,17 @@ rm -rf $OUT/kt
 echo "kernel trace done"
 for C in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CYCLES SQ_WAVES"; do
   N=$(echo $C | cut -d' ' -f1)
-  timeout -k 10 500 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$N -o p -- python3 $REPO/bench.py --no-cpu-baseline --no-latency-line --steps 60 --warmup 10 --sessions 96 --lanes 96 > $OUT/pmc_$N.json 2> $OUT/pmc_$N.err || exit 1
+  timeout -k 10 500 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$N -o p -- python3 $REPO/bench.py --no-cpu-baseline --no-latency-line --steps 60 --warmup 10 --sessions 128 --lanes 128 > $OUT/pmc_$N.json 2> $OUT/pmc_$N.err || exit 1
   echo "pmc $N done"
 done
 cd $REPO
-python3 tools/pmc_summary.py $OUT/${TAG}_pmc_summary.json --meta '{"config": "c2", "lanes": 96, "scene": "corridor", "shape": "--sessions 96 --lanes 96"}' $OUT/pmc_*/p_counter_collection.csv
+python3 tools/pmc_summary.py $OUT/${TAG}_pmc_summary.json --meta '{"config": "c2", "lanes": 128, "scene": "corridor", "shape": "--sessions 128 --lanes 128"}' $OUT/pmc_*/p_counter_collection.csv
 rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ_INSTS_VALU_MFMA_MOPS_F64
+# C5 (64 keyframes / 100 k landmarks): bench line + kernel trace of the same command
+python3 bench.py --config c5 > $OUT/${TAG}_c5_bench.json 2> $OUT/c5.err || exit 1
+echo "c5 done"; cut -c1-200 $OUT/${TAG}_c5_bench.json
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt5 -o kt -- python3 $REPO/bench.py --config c5 > $OUT/c5_under_rocprof.json 2> $OUT/kt5.err || exit 1
+cp $OUT/kt5/kt_kernel_stats.csv $OUT/${TAG}_c5_kernel_stats.csv; rm -rf $OUT/kt5
+cd $REPO
+echo "all done"

@@ -6,7 +6,7 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 REPO=$PWD
 PROF_SHAPE="${PROF_SHAPE:-}"                                   # kernel trace: the default command (two lockstep groups)
-PMC_SHAPE="${PMC_SHAPE:---sessions 96 --lanes 96}"            # counter passes: ONE group (the default shape's launch geometry per kernel)
+PMC_SHAPE="${PMC_SHAPE:---sessions 128 --lanes 128}"            # counter passes: ONE group (the default shape's launch geometry per kernel)
 if [ -z "$SKIP_BENCH" ]; then
 python3 bench.py > $OUT/${TAG}_c2_bench.json 2> $OUT/c2.err || exit 1
 echo "c2 bench done"; cut -c1-160 $OUT/${TAG}_c2_bench.json
@@ -61,7 +61,7 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CYCLES SQ_WA
   echo "pmc $N done"
 done
 cd $REPO
-python3 tools/pmc_summary.py $OUT/${TAG}_pmc_summary.json --meta '{"config": "c2", "lanes": 96, "scene": "corridor", "shape": "'"$PMC_SHAPE"'"}' $OUT/pmc_*/p_counter_collection.csv
+python3 tools/pmc_summary.py $OUT/${TAG}_pmc_summary.json --meta '{"config": "c2", "lanes": 128, "scene": "corridor", "shape": "'"$PMC_SHAPE"'"}' $OUT/pmc_*/p_counter_collection.csv
 rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ_INSTS_VALU_MFMA_MOPS_F64
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CYCLES SQ_WAVES"; do
