@@ -2674,10 +2674,15 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
     if (device < 0 || device >= ndev) return VSLAM_ERR_INVALID;
     VS_HIP(hipSetDevice(device));
     const int K = P->n_kf, L = P->n_lm, NP = P->n_pairs;
-    for (int p = 0; p < NP; p++)
-        if (P->pair_kf[p] < 0 || P->pair_kf[p] >= K || P->pair_lm[p] < 0 || P->pair_lm[p] >= L ||
-            P->pair_octave[2 * p] < 0 || P->pair_octave[2 * p] >= P->n_levels || P->pair_octave[2 * p + 1] < 0 ||
-            P->pair_octave[2 * p + 1] >= P->n_levels) { set_error("vslam_local_ba: pair index out of range"); return VSLAM_ERR_INVALID; }
+    auto pairs_in_range = [&](int p0, int p1) {
+        for (int p = p0; p < p1; p++)
+            if (P->pair_kf[p] < 0 || P->pair_kf[p] >= K || P->pair_lm[p] < 0 || P->pair_lm[p] >= L ||
+                P->pair_octave[2 * p] < 0 || P->pair_octave[2 * p] >= P->n_levels || P->pair_octave[2 * p + 1] < 0 ||
+                P->pair_octave[2 * p + 1] >= P->n_levels) return false;
+        return true;
+    };
+    // (the index check of a large problem - 1.2 M pairs: ~1 ms on one core - runs on the workspace's pool, below)
+    if (NP < 200000 && !pairs_in_range(0, NP)) { set_error("vslam_local_ba: pair index out of range"); return VSLAM_ERR_INVALID; }
 
 #ifndef VSLAM_HOST_STAMPS
     BHS("s_check");
@@ -2732,6 +2737,12 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
             if (const char* e = getenv("VSLAM_BA_HOST_THREADS")) nt = std::max(0, std::min(15, atoi(e)));
             ws->pool.start(nt);
         }
+    }
+    if (NP >= 200000) {
+        const int nr = (int)ws->pool.workers.size() + 1;
+        std::vector<uint8_t> ok(nr, 1);
+        ws->pool.run(nr, [&](int r) { ok[r] = pairs_in_range((int)((long long)NP * r / nr), (int)((long long)NP * (r + 1) / nr)) ? 1 : 0; });
+        for (int r = 0; r < nr; r++) if (!ok[r]) { set_error("vslam_local_ba: pair index out of range"); return VSLAM_ERR_INVALID; }
     }
     if ((size_t)P->n_pairs > ws->wrongCap) {
         if (ws->h_wrong) hipHostFree(ws->h_wrong);
