@@ -2174,14 +2174,25 @@ struct OrdScan {
 __global__ __launch_bounds__(1024) void k_ord_scan_lm(BaOrd O) {
     __shared__ int sA[16], sB[16];
     OrdScan sc;
-    for (int base = 0; base < O.L; base += 1024) {
-        const int l = base + threadIdx.x;
-        const bool in = l < O.L && O.lmPres[l] && l % O.world == O.rank;
-        const int a = in ? 1 : 0, b = in ? O.cnt[l] : 0;
+    constexpr int E = 4;             // consecutive elements per thread and tile
+    for (int base = 0; base < O.L; base += 1024 * E) {
+        const int l0 = base + threadIdx.x * E;
+        bool in[E]; int cn[E];
+        int a = 0, b = 0;
+#pragma unroll
+        for (int j = 0; j < E; j++) {
+            const int l = l0 + j;
+            in[j] = l < O.L && O.lmPres[l] && l % O.world == O.rank;
+            cn[j] = in[j] ? O.cnt[l] : 0;
+            a += in[j] ? 1 : 0; b += cn[j];
+        }
         int ea, eb;
         sc.tile(a, b, sA, sB, ea, eb);
-        if (l < O.L) {
-            if (in) { O.lpOf[l] = ea; O.tLpOrig[ea] = l; O.tLpStart[ea] = eb; }
+#pragma unroll
+        for (int j = 0; j < E; j++) {
+            const int l = l0 + j;
+            if (l >= O.L) break;
+            if (in[j]) { O.lpOf[l] = ea; O.tLpOrig[ea] = l; O.tLpStart[ea] = eb; ea++; eb += cn[j]; }
             else O.lpOf[l] = -1;
         }
     }
@@ -2230,17 +2241,25 @@ __global__ __launch_bounds__(1024) void k_ord_scan_slots(BaOrd O, int Lp) {
     OrdScan sc;
     int mx = 0, mf = 0;
     long long k2 = 0;
-    for (int base = 0; base < Lp; base += 1024) {
-        const int lp = base + tid;
+    constexpr int E = 4;
+    for (int base = 0; base < Lp; base += 1024 * E) {
+        const int lp0 = base + tid * E;
+        int nsv[E];
         int a = 0;
-        if (lp < Lp) {
-            const int ns = O.ns[lp], f0 = O.tLpStart[lp], nf = O.tLpStart[lp + 1] - f0;
-            a = ns + 1; mx = max(mx, ns); mf = max(mf, nf); k2 += (long long)ns * ns;
-            O.lpStart[lp] = f0; O.lpOrig[lp] = O.tLpOrig[lp];
+#pragma unroll
+        for (int j = 0; j < E; j++) {
+            const int lp = lp0 + j;
+            nsv[j] = 0;
+            if (lp < Lp) {
+                const int ns = O.ns[lp], f0 = O.tLpStart[lp], nf = O.tLpStart[lp + 1] - f0;
+                nsv[j] = ns + 1; a += ns + 1; mx = max(mx, ns); mf = max(mf, nf); k2 += (long long)ns * ns;
+                O.lpStart[lp] = f0; O.lpOrig[lp] = O.tLpOrig[lp];
+            }
         }
         int ea, eb;
         sc.tile(a, 0, sA, sB, ea, eb);
-        if (lp < Lp) O.lpSlotStart[lp] = ea;
+#pragma unroll
+        for (int j = 0; j < E; j++) { const int lp = lp0 + j; if (lp < Lp) { O.lpSlotStart[lp] = ea; ea += nsv[j]; } }
     }
     rA[tid] = mx; rB[tid] = mf; rK[tid] = k2;
     __syncthreads();
