@@ -41,3 +41,26 @@ def test_product_does_not_reference_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", "Makefile")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle" not in txt.lower().replace("no oracle", ""), os.path.join(dp, f)
+
+
+def test_hot_path_kernels_have_no_scratch():
+    """Register spills / stack objects of the built gfx950 code objects, read from their metadata (no GPU needed; tools/kernel_resources.py).
+    Every kernel of the per-frame path must run without scratch memory; the two large-window solve kernels that still spill are pinned to
+    what they use today, so that a regression (a dynamically indexed local array, a pointer phi the optimiser makes of two member stores,
+    a register budget blown by an unroll) shows up in the CPU suite."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    rows = kr.kernel_rows()
+    assert len(rows) >= 80
+    allowed = {"k_ba_solveEPK": 352, "k_ba_solve_mfmaEPK": 64}      # (A/B solve for > 144 unknowns without MFMA; 61..256-unknown MFMA solve)
+    bad = []
+    for name, vgpr, agpr, sgpr, scratch, lds, wg in rows:
+        limit = 0
+        for key, v in allowed.items():
+            if key in name:
+                limit = v
+        if int(scratch) > limit:
+            bad.append((name, int(scratch)))
+    assert not bad, bad

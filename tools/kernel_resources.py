@@ -12,9 +12,9 @@ LLVM = "/opt/rocm/lib/llvm/bin/"
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 
 
-def main():
-    pat = re.compile(sys.argv[1]) if len(sys.argv) > 1 else None
-    lib = os.path.join(ROOT, "gtsam-vslam_amd", "libvslam_hip.so")
+def kernel_rows(lib=None):
+    """[(demangled name, vgpr, agpr, sgpr, scratch bytes, static LDS bytes, max workgroup size)] of every kernel in the library"""
+    lib = lib or os.path.join(ROOT, "gtsam-vslam_amd", "libvslam_hip.so")
     with tempfile.TemporaryDirectory() as td:
         fat = os.path.join(td, "fat.bin")
         subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat], check=True)
@@ -39,10 +39,15 @@ def main():
                 except Exception:      # noqa: BLE001
                     pass
                 rows.append((name, g("vgpr_count"), blk.split()[0], g("sgpr_count"), g("private_segment_fixed_size"), g("group_segment_fixed_size"), g("max_flat_workgroup_size")))
-        print("%5s %5s %5s %8s %8s %6s  %s" % ("vgpr", "agpr", "sgpr", "scratch", "lds", "wg", "kernel"))
-        for name, v, a, s, p, l, w in sorted(rows):
-            if pat is None or pat.search(name):
-                print("%5s %5s %5s %8s %8s %6s  %s" % (v, a, s, p, l, w, name))
+        return sorted(rows)
+
+
+def main():
+    pat = re.compile(sys.argv[1]) if len(sys.argv) > 1 else None
+    print("%5s %5s %5s %8s %8s %6s  %s" % ("vgpr", "agpr", "sgpr", "scratch", "lds", "wg", "kernel"))
+    for name, v, a, s, p, l, w in kernel_rows():
+        if pat is None or pat.search(name):
+            print("%5s %5s %5s %8s %8s %6s  %s" % (v, a, s, p, l, w, name))
 
 
 if __name__ == "__main__":
