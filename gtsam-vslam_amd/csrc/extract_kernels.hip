@@ -280,9 +280,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, P
             for (int k = 0; k < 8; k++) if (at[k] >= 0) *(unsigned*)(tile + at[k]) = v[k];
         }
     }
-    // score-plane border (NMS reads one pixel beyond the detection area: those count as 0)
-    for (int i = lane; i < detW + 2; i += 64) { sc[i] = 0; sc[(detH + 1) * TP + i] = 0; }
-    for (int i = lane; i < detH + 2; i += 64) { sc[i * TP] = 0; sc[i * TP + detW + 1] = 0; }
+    // (the score plane - detection area + the one-pixel border the suppression reads, which counts as 0 - is cleared per pass, below)
 
     const int ro[16] = {3 * TP,      3 * TP + 1,  2 * TP + 2,  TP + 3,  3,       -TP + 3,
                         -2 * TP + 2, -3 * TP + 1, -3 * TP,     -3 * TP - 1, -2 * TP - 2, -TP - 3,
@@ -299,6 +297,9 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, P
         const int tq = pass == 0 ? maxThr : minThr;        // ring / cardinal tests and the suppression threshold of this pass
         int h1 = 0, t1 = 0, h2 = 0, t2 = 0;                // queue heads / tails (wave-uniform)
         int n3 = 0;                                        // corners listed in q3 (may exceed FQ3_CAP: then the full scan runs)
+        // every pixel that does not reach stage 3 scores 0: one dword clear of the plane per pass (a byte store per pixel in stage 1 was
+        // a third of that stage's LDS instructions); the wave's LDS traffic is in order, stage 3 overwrites behind it
+        for (int i = lane; i < ((detH + 2) * TP) >> 2; i += 64) ((unsigned*)sc)[i] = 0u;
 
         auto stage3 = [&](int rc, bool valid) {
             bool corner = false;
@@ -352,6 +353,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, P
         {
             int r = 0, c = lane;
             while (c >= detW) { c -= detW; r++; }
+            const int adv_r = 64 / detW, adv_c = 64 - adv_r * detW;      // 64 pixels further: wave-uniform quotient / remainder
             for (int base = 0; base < npix; base += 64) {
                 const bool valid = base + lane < npix;
                 bool ok = false;
@@ -362,14 +364,13 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, P
                     const bool d0 = c0 < lo, d4 = c4 < lo, d8 = c8 < lo, d12 = c12 < lo;
                     const bool b0 = c0 > hi, b4 = c4 > hi, b8 = c8 > hi, b12 = c12 > hi;
                     ok = (d0 && d4) || (d4 && d8) || (d8 && d12) || (d12 && d0) || (b0 && b4) || (b4 && b8) || (b8 && b12) || (b12 && b0);
-                    sc[(r + 1) * TP + (c + 1)] = 0;
                 }
                 const unsigned long long bal = __ballot(ok);
                 if (ok) q1[(t1 + __popcll(bal & lt)) & FQ_MASK] = (unsigned short)((r << 7) | c);
                 t1 += __popcll(bal);
                 drain1(false);
-                c += 64;
-                while (c >= detW) { c -= detW; r++; }
+                c += adv_c; r += adv_r;
+                if (c >= detW) { c -= detW; r++; }
             }
         }
         drain1(true);
