@@ -29,7 +29,7 @@ namespace vslam {
 
 constexpr int SSC_NT = 512, SSC_NW = SSC_NT / 64;       // 8 waves
 constexpr int SSC_NPROBE = 8;                           // speculative probes per round (waves 0..6 are used: a depth-3 tree)
-constexpr int SSC_COOP_MIN = 1024;                      // longer segments: block-cooperative partition
+constexpr int SSC_COOP_MIN = 2048;                      // longer segments: block-cooperative partition (VSLAM_SSC_COOP_MIN; 192 corridor images: 1024 -> 917 us, 2048 -> 882, 4096 -> 877, 512 -> 1023)
 constexpr int SSC_ARENA_WORDS = 20 * 1024;              // 80 KB of cover-grid bits (10 KB per speculating wave)
 constexpr int SSC_NMAX_SMALL = 6144;                    // levels up to this size: the 67 KB form, two workgroups per CU
 
@@ -122,8 +122,9 @@ __device__ __forceinline__ int ssc_eval(const uint32_t* sc, int n, int width, in
 // A level's list has two parts: [0, SSC_LONGMAX) the segments longer than SSC_COOP_MIN (count cntN[2]; at most
 // 65 535 / 1 025 of them exist at once), [SSC_LONGMAX, ...) the others (count cntN[0]).
 constexpr int SSC_LONGMAX = 64;
+__device__ int g_sscCoopMin = SSC_COOP_MIN;      // (a device variable so that VSLAM_SSC_COOP_MIN can move the threshold for measurements)
 __device__ __forceinline__ void ssc_push(uint32_t* segN, int* cntN, int segMax, int f, int e, int depth, int* sFail) {
-    if (e - f > SSC_COOP_MIN) {
+    if (e - f > g_sscCoopMin) {
         const int q = atomicAdd(cntN + 2, 1);
         if (q < SSC_LONGMAX) { segN[2 * q] = (uint32_t)f | ((uint32_t)e << 16); segN[2 * q + 1] = (uint32_t)depth; }
         else *sFail = 4;
@@ -678,6 +679,10 @@ void launch_ssc(hipStream_t s, const SscArgs& A, uint32_t* kept, int keptCap, in
     static_assert((size_t)SscCfg<2>::NMAX + 4 * SscCfg<2>::SEGMAX >= (size_t)SscCfg<2>::ARENA, "arena must fit a | seg");
     static std::once_flag attr;
     std::call_once(attr, [&] {
+        if (const char* e = getenv("VSLAM_SSC_COOP_MIN")) {
+            const int v = std::max(65, std::min(65535, atoi(e)));
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sscCoopMin), &v, sizeof(int));
+        }
         (void)hipFuncSetAttribute((const void*)k_ssc<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsL);
         (void)hipFuncSetAttribute((const void*)k_ssc<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsS);
         (void)hipFuncSetAttribute((const void*)k_ssc<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsG);
