@@ -271,7 +271,9 @@ static vslam_status fleet_create(const vslam_system_config* config, int32_t n_se
         const int nG = (n_sessions + lanes - 1) / lanes;
         F->groups.resize(nG);
         // host threads per group: the groups share the machine's cores
-        const int hw = (int)std::max(2u, std::thread::hardware_concurrency());
+        // (one process per GPU on a multi-GPU node: this process's share of the cores - torch.distributed.run exports LOCAL_WORLD_SIZE)
+        int hw = (int)std::max(2u, std::thread::hardware_concurrency());
+        if (const char* lws = getenv("LOCAL_WORLD_SIZE")) hw = std::max(2, hw / std::max(1, atoi(lws)));
         int hostThreads = std::max(1, std::min(8, hw / std::max(nG, 1) - 1));
         if (const char* e = getenv("VSLAM_FLEET_HOST_THREADS")) hostThreads = std::max(1, atoi(e));
         for (int g = 0; g < nG && st == VSLAM_OK; g++) {
