@@ -743,7 +743,8 @@ typedef struct vslam_fleet_report {
 
 vslam_status vslam_fleet_create(const vslam_system_config* config, int32_t n_sessions, const vslam_fleet_sequence* sequence,
                                 vslam_fleet** out);
-/* the same sessions as the lanes of ceil(n_sessions / lanes_per_group) lockstep groups (vslam_batch), one driver thread each */
+/* the same sessions as the lanes of ceil(n_sessions / lanes_per_group) lockstep groups (vslam_batch), one driver thread each
+   (1 <= n_sessions <= 1024; bench.py: 384 sessions in three groups of 128 per GPU) */
 vslam_status vslam_fleet_create_batched(const vslam_system_config* config, int32_t n_sessions, const vslam_fleet_sequence* sequence,
                                         int32_t lanes_per_group, vslam_fleet** out);
 void vslam_fleet_destroy(vslam_fleet* fleet);
