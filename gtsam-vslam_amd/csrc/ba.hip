@@ -3037,6 +3037,7 @@ static vslam_status ba_run(const vslam_ba_problem* P, vslam_ba_result* R, int de
                 if (tileB + metaB <= 150 * 1024) { TB = tb; break; }
             }
             if (const char* e = getenv("VSLAM_BA_WINDOW_TB")) TB = std::max(1, std::min(32, atoi(e)));
+            if (devOrder && (F + TB - 1) / TB > 64) TB = (F + 63) / 64;      // (k_win_lists keeps a landmark's block rows in a 64-bit mask)
             const int nBR = (F + TB - 1) / TB, nWin = nBR * (nBR + 1) / 2;
             Wn.TB = TB; Wn.T = 6 * TB; Wn.TP = Wn.T + 1; Wn.tileDoubles = Wn.T * Wn.TP + Wn.T; Wn.nWin = nWin;
             schurWaves = BA_SCHUR_WAVES;
